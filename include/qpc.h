@@ -1,0 +1,233 @@
+/*
+ * qpc.h -- C ABI of libqpcontrol_hip.so: batched whole-body-QP control on MI355X (gfx950).
+ *
+ * This is the drop-in boundary for the hot path of tkoolen/QPControl.jl: one
+ * `MomentumBasedController` tick (reference src/lowlevel/momentum.jl:41-81) for a BATCH of
+ * independent robot states.  A Julia host `ccall`s these entry points (binding shown in
+ * INTEGRATION.md and qpcontrol.jl_amd/julia/QPControlHIP.jl); the Python host mirror in
+ * qpcontrol.jl_amd/ binds the same symbols through ctypes.
+ *
+ * Conventions
+ *  - Plain C types only.  All functions return an int32 error code (QPC_OK == 0) unless noted;
+ *    qpc_last_error() returns a thread-local description of the last failure.
+ *  - Batched arrays are "column-major (dim x B)" in Julia terms: the record of QP b is
+ *    contiguous, element (i, b) lives at [b*dim + i].  Julia `Matrix{Float64}(dim, B)` and numpy
+ *    C-order arrays of shape (B, dim) both have exactly this layout.
+ *  - Bodies are numbered 0..nbodies-1 in topological order (parent[i] < i); the world/root body is
+ *    QPC_WORLD (-1).  Joint i is the joint between parent[i] and body i ("joint" arguments are
+ *    therefore body indices).  Body frame i == the frame after joint i (RigidBodyDynamics'
+ *    default frame of a URDF-parsed body).
+ *  - Spatial vectors are [angular(3); linear(3)] (RigidBodyDynamics layout).
+ *  - Handles are opaque, freed by *_destroy, usable from one host thread at a time.
+ *  - There is NO CPU fallback: every compute entry point needs a HIP device and fails with
+ *    QPC_ERR_NO_DEVICE otherwise.
+ */
+#ifndef QPC_H
+#define QPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QPC_WORLD (-1)
+#define QPC_FRAME_DEFAULT (-2) /* task frame = default frame of the task's target body */
+
+/* error codes (return values) */
+enum {
+  QPC_OK = 0,
+  QPC_ERR_INVALID_ARGUMENT = 1,
+  QPC_ERR_NOT_FINALIZED = 2,
+  QPC_ERR_ALREADY_FINALIZED = 3, /* reference: tasks/contacts must be added before the first tick,
+                                    momentum.jl:43-46,150-156,182-187 */
+  QPC_ERR_NO_DEVICE = 4,
+  QPC_ERR_HIP = 5,
+  QPC_ERR_UNSUPPORTED = 6, /* configuration exceeds the limits of the compiled kernels */
+  QPC_ERR_OUT_OF_MEMORY = 7
+};
+
+/* joint types -- RigidBodyDynamics Revolute / Prismatic / QuaternionFloating / Fixed */
+enum {
+  QPC_JOINT_REVOLUTE = 0,      /* nq = nv = 1 */
+  QPC_JOINT_PRISMATIC = 1,     /* nq = nv = 1 */
+  QPC_JOINT_QUAT_FLOATING = 2, /* q = [w x y z px py pz], v = [omega_body; v_body], nq 7, nv 6 */
+  QPC_JOINT_FIXED = 3          /* nq = nv = 0 */
+};
+
+/* motion task kinds -- the 7 task types of reference src/tasks.jl */
+enum {
+  QPC_TASK_SPATIAL_ACCELERATION = 0, /* src/tasks.jl:3-44    dim 6 */
+  QPC_TASK_ANGULAR_ACCELERATION = 1, /* src/tasks.jl:47-84   dim 3 */
+  QPC_TASK_LINEAR_ACCELERATION = 2,  /* src/tasks.jl:86-123  dim 3 */
+  QPC_TASK_POINT_ACCELERATION = 3,   /* src/tasks.jl:125-171 dim 3 */
+  QPC_TASK_JOINT_ACCELERATION = 4,   /* src/tasks.jl:173-189 dim nv(joint) */
+  QPC_TASK_MOMENTUM_RATE = 5,        /* src/tasks.jl:192-236 dim 6 */
+  QPC_TASK_LINEAR_MOMENTUM_RATE = 6  /* src/tasks.jl:239-262 dim 3 */
+};
+
+/* how a task enters the QP -- the three addtask! methods, momentum.jl:99-117 */
+enum {
+  QPC_WEIGHT_HARD = 0,          /* addtask!(c, task):      err == 0                      */
+  QPC_WEIGHT_SCALAR = 1,        /* addtask!(c, task, w):   obj += w * (e . e)            */
+  QPC_WEIGHT_MATRIX = 2,        /* addtask!(c, task, W):   obj += e' W e  (W dim x dim, row-major) */
+  QPC_WEIGHT_SCALAR_PER_QP = 3, /* w is a Parameter: one scalar per QP in task_weights[]   */
+  QPC_WEIGHT_MATRIX_PER_QP = 4  /* W is a Parameter: dim*dim per QP in task_weights[]      */
+};
+
+/* per-QP solve status -- mirrors checkstatus / QPSolveFailure, momentum.jl:83-91, exceptions.jl:1-11 */
+enum {
+  QPC_STATUS_OPTIMAL = 0,        /* MOI.OPTIMAL + FEASIBLE_POINT                      */
+  QPC_STATUS_ALMOST_OPTIMAL = 1, /* MOI.ALMOST_OPTIMAL (tolerated by checkstatus)     */
+  QPC_STATUS_INFEASIBLE = 2,
+  QPC_STATUS_DUAL_INFEASIBLE = 3,
+  QPC_STATUS_ITERATION_LIMIT = 4,
+  QPC_STATUS_NUMERICAL_ERROR = 5
+};
+
+typedef struct qpc_model qpc_model;
+typedef struct qpc_controller qpc_controller;
+
+/*
+ * Flat description of a tree mechanism == RigidBodyDynamics `Mechanism{Float64}` after
+ * remove_fixed_tree_joints! (reference notebooks/Standing controller.ipynb cell 2).
+ * The transform of joint i maps body-i coordinates to parent coordinates:
+ *     x_parent = joint_R[i] * (X_joint(q_i) * x_body) + joint_p[i]
+ */
+typedef struct qpc_model_desc {
+  int32_t nbodies;
+  const int32_t *parent;     /* [nbodies]   parent body or QPC_WORLD; parent[i] < i          */
+  const int32_t *joint_type; /* [nbodies]   QPC_JOINT_*                                       */
+  const double *joint_axis;  /* [nbodies*3] unit axis in the joint frame (revolute/prismatic) */
+  const double *joint_R;     /* [nbodies*9] row-major rotation joint-frame-before -> parent body frame */
+  const double *joint_p;     /* [nbodies*3] translation of the same transform                 */
+  const double *mass;        /* [nbodies]                                                     */
+  const double *com;         /* [nbodies*3] centre of mass in the body frame                  */
+  const double *inertia;     /* [nbodies*6] Ixx Iyy Izz Ixy Ixz Iyz about the CoM, body axes  */
+  double gravity[3];         /* gravitational acceleration in world frame, e.g. (0,0,-9.81)   */
+} qpc_model_desc;
+
+/* sizes of the frozen problem, reported by qpc_finalize / qpc_get_layout */
+typedef struct qpc_layout {
+  int32_t nq, nv;
+  int32_t n_tasks, n_contacts, n_basis;
+  int32_t n_desired;      /* sum of task dimensions: length of one QP's `desired` record        */
+  int32_t n_task_weights; /* doubles per QP in `task_weights` (0 if no *_PER_QP weights)        */
+  int32_t n_surface;      /* doubles per QP in `surfaces` = 4 * (#contacts with per_qp_surface) */
+  /* the reference-layout QP this replaces, for bookkeeping: */
+  int32_t ref_n_var, ref_n_eq, ref_n_ineq;
+  /* the reduced QP the kernels actually solve: */
+  int32_t n_free, n_pinned, n_slack, n_rho, n_eq_rows;
+  int32_t lds_bytes_per_qp;
+} qpc_layout;
+
+/* ---- model: mirrors Mechanism{Float64} ------------------------------------------------ */
+int32_t qpc_model_create(const qpc_model_desc *desc, qpc_model **out);
+void qpc_model_destroy(qpc_model *model);
+int32_t qpc_model_nq(const qpc_model *model);
+int32_t qpc_model_nv(const qpc_model *model);
+/* first configuration / velocity index and counts of joint `body` (velocity_range, RBD) */
+int32_t qpc_model_joint_ranges(const qpc_model *model, int32_t body, int32_t *q0, int32_t *nq,
+                               int32_t *v0, int32_t *nv);
+
+/* ---- controller: mirrors MomentumBasedController{N}(mechanism, optimizer; floatingjoint),
+ *      momentum.jl:15-33.  floating_body = successor body of the floating joint or QPC_WORLD(-1)
+ *      for `floatingjoint = nothing`.  n_basis == N (friction-cone basis size, contacts.jl:16). */
+int32_t qpc_controller_create(const qpc_model *model, int32_t n_basis, int32_t floating_body,
+                              qpc_controller **out);
+void qpc_controller_destroy(qpc_controller *ctrl);
+
+/* addtask! (momentum.jl:99-117) fused with the task constructor (src/tasks.jl:8-18,52-62,91-101,
+ * 131-142,177-179,196-201,243-248).
+ *   base_body/target_body: source/target of the kinematic path (ignored for JOINT/MOMENTUM kinds)
+ *   frame_body: body whose frame the task is expressed in (SPATIAL/ANGULAR/LINEAR only;
+ *               QPC_FRAME_DEFAULT = target body, QPC_WORLD = world). POINT tasks always use the
+ *               base body's frame (src/tasks.jl:139-140,154).
+ *   point: POINT task: point fixed in target body, target-body coordinates (src/tasks.jl:136-141)
+ *   joint_body: JOINT task: the joint
+ *   weight: NULL for HARD / *_PER_QP; 1 double for SCALAR; dim*dim row-major for MATRIX        */
+int32_t qpc_add_task(qpc_controller *ctrl, int32_t kind, int32_t base_body, int32_t target_body,
+                     int32_t frame_body, const double *point, int32_t joint_body,
+                     int32_t weight_kind, const double *weight, int32_t *out_task_id);
+
+/* regularize!(c, joint, w): obj += w * |vdot_joint|^2 ; weights add up (momentum.jl:128-131) */
+int32_t qpc_regularize(qpc_controller *ctrl, int32_t joint_body, double weight);
+
+/* addcontact!(c, body, position, normal, mu) (momentum.jl:133-148, contacts.jl:38-69).
+ * position/normal in the frame of `body`.  per_qp_surface != 0: normal and mu are Parameters
+ * (contacts.jl:39) supplied per QP as [nx ny nz mu] in `surfaces`.  A fresh contact has
+ * weight = 0 and maxnormalforce = 0 in the reference (contacts.jl:50); here both are per-QP
+ * inputs of qpc_control_batch. */
+int32_t qpc_add_contact(qpc_controller *ctrl, int32_t body, const double position[3],
+                        const double normal[3], double mu, int32_t per_qp_surface,
+                        int32_t *out_contact_id);
+
+/* initialize! (momentum.jl:150-156): freeze the layout, add the wrench-balance rows when a
+ * floating joint was given (momentum.jl:162-193), compile the task program and upload it to
+ * HIP device `device_id`. */
+int32_t qpc_finalize(qpc_controller *ctrl, int32_t device_id, qpc_layout *out_layout);
+int32_t qpc_get_layout(const qpc_controller *ctrl, qpc_layout *out_layout);
+
+/* solver knobs (all optional; defaults in parentheses) */
+typedef struct qpc_settings {
+  int32_t max_active_set_iters; /* (200) -> QPC_STATUS_ITERATION_LIMIT                      */
+  int32_t max_refine_iters;     /* (6) proximal/iterative-refinement sweeps                */
+  double eps_primal_reg;        /* (1e-9) relative primal proximal regularisation          */
+  double eps_dual_reg;          /* (1e-10) relative dual regularisation of equality rows   */
+  double tol_residual;          /* (1e-10) relative KKT residual for OPTIMAL               */
+  double tol_bound;             /* (1e-10) relative bound violation / multiplier sign tol  */
+} qpc_settings;
+int32_t qpc_default_settings(qpc_settings *s);
+int32_t qpc_set_settings(qpc_controller *ctrl, const qpc_settings *s);
+
+/* L2 -- the graded path: the callable (controller)(tau, t, x), momentum.jl:41-81, with
+ * setdesired! (src/tasks.jl:23,67,106,147,183,225,253), point.weight[] and
+ * point.maxnormalforce[] (contacts.jl:35-36) folded into per-QP input arrays.
+ *   in : q[nq*B], v[nv*B], desired[n_desired*B], contact_weight[nc*B],
+ *        contact_maxnormalforce[nc*B], task_weights[n_task_weights*B] or NULL,
+ *        surfaces[n_surface*B] or NULL
+ *   out: tau[nv*B], vdot[nv*B] (result.vdot, momentum.jl:62-64),
+ *        contact_wrench[6*nc*B] (value(wrench_world) per contact, world frame, [ang;lin],
+ *        contacts.jl:82-89) or NULL, status[B] (QPC_STATUS_*), iters[B] or NULL
+ * Host-pointer variant: synchronous (H2D, kernels, D2H). */
+int32_t qpc_control_batch(qpc_controller *ctrl, int64_t B, const double *q, const double *v,
+                          const double *desired, const double *contact_weight,
+                          const double *contact_maxnormalforce, const double *task_weights,
+                          const double *surfaces, double *tau, double *vdot,
+                          double *contact_wrench, int32_t *status, int32_t *iters);
+
+/* Same, but every pointer is a DEVICE pointer on the controller's device and the work is
+ * enqueued on `hip_stream` (a hipStream_t, NULL = default stream) without synchronising. */
+int32_t qpc_control_batch_device(qpc_controller *ctrl, int64_t B, const double *q,
+                                 const double *v, const double *desired,
+                                 const double *contact_weight,
+                                 const double *contact_maxnormalforce,
+                                 const double *task_weights, const double *surfaces, double *tau,
+                                 double *vdot, double *contact_wrench, int32_t *status,
+                                 int32_t *iters, void *hip_stream);
+
+/* L0 -- raw dense QPs in OSQP problem form (what Parametron.solve! hands to the MOI optimizer,
+ * momentum.jl:58; settings as test/runtests.jl:35-43):
+ *     min 1/2 x'Px + q'x   s.t.  l <= A x <= u
+ * P[n*n*B] (symmetric, row-major per QP), q[n*B], A[m*n*B] row-major, l[m*B], u[m*B]
+ * (+-1e20 or inf = unbounded); out x[n*B], y[m*B] (multipliers, OSQP sign convention),
+ * status[B], iters[B].  Host pointers, synchronous. */
+int32_t qpc_qp_solve_batch(int32_t n, int32_t m, int64_t B, const double *P, const double *q,
+                           const double *A, const double *l, const double *u,
+                           const qpc_settings *settings, int32_t device_id, double *x, double *y,
+                           int32_t *status, int32_t *iters);
+
+/* QPSolveFailure text (exceptions.jl:7-11) */
+const char *qpc_status_string(int32_t status);
+const char *qpc_last_error(void);
+const char *qpc_version(void);
+
+/* kernel timing hooks for bench.py / roofline: average duration in ms of the fused tick kernel
+ * over launches recorded since the last reset, measured with hipEvents on the launch stream. */
+int32_t qpc_timing_enable(qpc_controller *ctrl, int32_t enable);
+int32_t qpc_timing_read(qpc_controller *ctrl, double *avg_ms, int64_t *n_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QPC_H */
