@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- QP solves/sec of the batched whole-body-QP control path on MI355X.
+
+One "step" = one pass of the hot path (qpc_control_batch_device: state -> task/contact assembly
+-> QP solve -> v̇, contact wrenches -> inverse dynamics -> tau) over one batch of synthetic Atlas
+states with inputs already resident in HBM.  Workload = BASELINE.json config 3 (Atlas, 8
+ContactPoints, linearised friction cones, fp64) at 32768 QPs per GPU, so that `--gpus 8`
+reproduces config 4 (B = 262144 sharded over 8 GPUs, no collective in the data path) exactly.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALG_BYTES_PER_SOLVE = 1968  # in 8*(37+36+36+16) + out 8*(36+36+48) + 8
+ALG_FLOPS_PER_SOLVE = 4.6e5  # one reduced-KKT factor+solve + assembly + FK/RNEA
+HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md (spec; 6.29e12 measured)
+FP64_PEAK = 78.6e12  # FLOP/s vector fp64 (datasheet)
+
+
+def cpu_baseline(B_sample_max=4096, budget_s=12.0):
+    """The oracle (CPU restatement of the reference path: 143x178 reference-layout problem,
+    coefficient rewrite per tick, OSQP-algorithm ADMM with the test-suite settings of
+    test/runtests.jl:35-43, cold start, RNEA) timed on ONE host core on a bounded sample."""
+    import qpc_pkg
+    qpc_pkg.load()
+    from qpcontrol_jl_amd import workloads as W
+    from oracle import oracle as O
+    O.build(native=True)
+
+    def factory(mech, N, fl):
+        return O.OracleController(O.OracleModel(mech, native=True), N, fl)
+
+    oc, wl = W.atlas_workload(factory, B_sample_max, 3)
+    oc.set_settings(O.test_settings(polish=0))
+    done, t0, iters = 0, time.perf_counter(), 0
+    chunk = 64
+    while done < B_sample_max and time.perf_counter() - t0 < budget_s:
+        s = slice(done, done + chunk)
+        r = oc.tick_batch(wl.q[s], wl.v[s], wl.desired[s], wl.contact_weight[s], wl.contact_maxnormalforce[s])
+        iters += int(r["iters"].sum())
+        done += chunk
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "QP solves/s", "cores": 1, "kind": "port",
+            "sample": f"{done} QPs of the same Atlas config-3 workload, OSQP restatement eps_abs=1e-8 eps_rel=1e-16 "
+                      f"cold start, mean {iters / max(done, 1):.0f} ADMM iterations, {dt:.1f} s on 1 core "
+                      f"(host has {os.cpu_count()} cores)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch-per-gpu", type=int, default=32768)
+    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 5])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import qpc_pkg
+    qpc_pkg.load()
+    from qpcontrol_jl_amd import binding
+    from qpcontrol_jl_amd import workloads as W
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    B = args.batch_per_gpu
+
+    def factory(mech, n_basis, floating):
+        return binding.Controller(binding.Model(mech), n_basis, floating)
+
+    # every rank builds its own contiguous shard [rank*B, (rank+1)*B) of the global batch
+    import importlib
+    mech_ctrl = None
+    ctrl, wl = None, None
+
+    def make():
+        nonlocal ctrl, wl
+        real_finalize = binding.Controller.finalize
+
+        def fin(self, device_id=0):
+            return real_finalize(self, local_rank)
+        binding.Controller.finalize = fin
+        try:
+            ctrl, wl = W.atlas_workload(factory, B, args.config, seed={2: 2024, 3: 2025, 5: 2027}[args.config] + 7919 * rank)
+        finally:
+            binding.Controller.finalize = real_finalize
+    make()
+    lay = ctrl.layout
+    dev = torch.device("cuda", local_rank)
+
+    def dev_t(a):
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+
+    q, v, des = dev_t(wl.q), dev_t(wl.v), dev_t(wl.desired)
+    cw, cm = dev_t(wl.contact_weight), dev_t(wl.contact_maxnormalforce)
+    tau = torch.empty((B, lay.nv), dtype=torch.float64, device=dev)
+    vd = torch.empty((B, lay.nv), dtype=torch.float64, device=dev)
+    cwr = torch.empty((B, max(lay.n_contacts, 1) * 6), dtype=torch.float64, device=dev)
+    status = torch.empty(B, dtype=torch.int32, device=dev)
+    iters = torch.empty(B, dtype=torch.int32, device=dev)
+    L = ctrl.L
+    vp = ctypes.c_void_p
+
+    def ptr(t):
+        return vp(t.data_ptr()) if t is not None and t.numel() else vp(0)
+
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        rc = L.qpc_control_batch_device(ctrl.h, B, ptr(q), ptr(v), ptr(des), ptr(cw) if lay.n_contacts else vp(0),
+                                        ptr(cm) if lay.n_contacts else vp(0), vp(0), vp(0), ptr(tau), ptr(vd),
+                                        ptr(cwr) if lay.n_contacts else vp(0), ptr(status), ptr(iters),
+                                        vp(stream.cuda_stream))
+        if rc != 0:
+            raise RuntimeError(L.qpc_last_error().decode())
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    L.qpc_timing_enable(ctrl.h, 1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    avg_ms, nl = ctypes.c_double(0), ctypes.c_int64(0)
+    L.qpc_timing_read(ctrl.h, ctypes.byref(avg_ms), ctypes.byref(nl))
+    L.qpc_timing_enable(ctrl.h, 0)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    st = status.cpu().numpy()
+    it = iters.cpu().numpy() % 1000
+    n_opt = int((st == 0).sum())
+
+    if rank == 0:
+        total = B * world * args.steps
+        value = total / elapsed
+        kern_s = avg_ms.value * 1e-3
+        ach_bytes = ALG_BYTES_PER_SOLVE * B / kern_s if kern_s > 0 else 0.0
+        out = {
+            "metric": "QP solves/sec (Atlas ~30-DoF whole-body QP, batched)",
+            "value": value, "unit": "QP solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"atlas_config{args.config}: synthetic Atlas (nq 37, nv 36), StandingController task set, "
+                                   + ("8 ContactPoints x 4-ray friction cones, floating base wrench balance "
+                                      "(143 vars / 114 eq / 64 ineq in the reference layout)" if args.config != 2
+                                      else "no contacts (39 vars / 36 eq)"),
+                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"shard{world} (independent QPs, no collective)",
+                       "optimal_fraction": n_opt / B, "mean_active_set_iters": float(it.mean()),
+                       "lds_bytes_per_qp": int(lay.lds_bytes_per_qp)},
+            "roofline": {"bound": "hbm", "achieved": ach_bytes / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": ach_bytes / HBM_PEAK, "traffic": None,
+                         "kernel": "qpc_tick_kernel", "kernel_avg_ms": avg_ms.value, "launches": int(nl.value),
+                         "algorithmic_bytes_per_solve": ALG_BYTES_PER_SOLVE,
+                         "note": "path is fp64-VALU / LDS-latency bound, not HBM bound (SURVEY.md 8d); "
+                                 "fp64 fraction reported beside it",
+                         "fp64": {"achieved_tflops": ALG_FLOPS_PER_SOLVE * B / kern_s / 1e12 if kern_s > 0 else 0.0,
+                                  "peak_tflops": FP64_PEAK / 1e12,
+                                  "frac": (ALG_FLOPS_PER_SOLVE * B / kern_s) / FP64_PEAK if kern_s > 0 else 0.0,
+                                  "algorithmic_flops_per_solve": ALG_FLOPS_PER_SOLVE}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

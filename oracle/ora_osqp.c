@@ -502,6 +502,7 @@ static void kkt_certificate(ora_osqp *w, const double *x, const double *y, ora_t
   free(Axv); free(g); free(Aty);
 }
 
+static void kkt_certificate(ora_osqp *w, const double *x, const double *y, ora_tick_info *info);
 /* exact mode: active-set clean-up around the polish solve until the KKT conditions hold */
 static int exact_polish(ora_osqp *w, double *x, double *y, ora_tick_info *info) {
   int n = w->n, m = w->m;
@@ -517,13 +518,22 @@ static int exact_polish(ora_osqp *w, double *x, double *y, ora_tick_info *info) 
     else act[i] = 0;
   }
   int ok = 0;
-  for (int round = 0; round < 200 && !ok; round++) {
+  for (int round = 0; round < 400 && !ok; round++) {
     if (polish_solve(w, act, 30, 1e-7, xs, ys) != 0) break;
     A_mul(w, w->Ax0, xs, Axv);
     double tolp = 1e-9 * (1.0 + vmaxabs(Axv, m)), told = 1e-9 * (1.0 + vmaxabs(ys, m));
-    /* most violated primal constraint / most wrong-signed multiplier */
+    /* an inconsistent active set leaves a residual on the active rows (the regularised solve is
+     * then a least-squares compromise): release the active INEQUALITY row with the largest one */
     int worst = -1, wkind = 0;
     double wv = 0;
+    for (int i = 0; i < m; i++) {
+      if (act[i] == 1 || act[i] == -1) {
+        double res = fabs(Axv[i] - (act[i] == 1 ? w->u0[i] : w->l0[i]));
+        if (res > tolp && res / tolp > wv) { wv = res / tolp; worst = i; wkind = 0; }
+      }
+    }
+    if (worst >= 0) { act[worst] = wkind; continue; }
+    /* most violated primal constraint / most wrong-signed multiplier */
     for (int i = 0; i < m; i++) {
       if (act[i] == 0) {
         double lo = w->l0[i] - Axv[i], hi = Axv[i] - w->u0[i];
@@ -535,7 +545,14 @@ static int exact_polish(ora_osqp *w, double *x, double *y, ora_tick_info *info) 
         if (ys[i] > told && ys[i] / told > wv) { wv = ys[i] / told; worst = i; wkind = 0; }
       }
     }
-    if (worst < 0) ok = 1; else act[worst] = wkind;
+    if (worst < 0) {
+      /* accept only a verified KKT point: equality rows and stationarity must hold too */
+      ora_tick_info chk;
+      kkt_certificate(w, xs, ys, &chk);
+      double sx = 1.0 + vmaxabs(ys, m);
+      ok = chk.kkt_prim <= 1e-7 * (1.0 + vmaxabs(Axv, m)) && chk.kkt_stat <= 1e-7 * sx;
+      if (!ok) break;
+    } else act[worst] = wkind;
   }
   if (ok) {
     memcpy(x, xs, sizeof(double) * n);

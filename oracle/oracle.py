@@ -203,6 +203,7 @@ class OracleController:
         self.layout = None
         self.task_dims = []
         self.nc = 0
+        self.var_blocks = []  # reference-layout variable blocks after v̇, in creation order
 
     def __del__(self):
         try:
@@ -217,6 +218,8 @@ class OracleController:
                                   _p(w) if w is not None else None)
         assert tid >= 0, "ora_add_task failed"
         self.task_dims.append(self.L.ora_task_dim(self.h, tid))
+        if wkind != 0:
+            self.var_blocks.append(("slack", tid, self.task_dims[-1]))
         return tid
 
     def regularize(self, joint, w):
@@ -227,6 +230,8 @@ class OracleController:
                                      ctypes.c_double(mu), int(per_qp_surface))
         assert cid >= 0
         self.nc += 1
+        self.var_blocks.append(("contact", cid, self.N + 9))
+        self.contact_specs = getattr(self, "contact_specs", []) + [(np.asarray(normal, float), float(mu), int(per_qp_surface))]
         return cid
 
     def finalize(self):

@@ -1,0 +1,191 @@
+"""ctypes binding of the C ABI in include/qpc.h (libqpcontrol_hip.so).
+
+The product library is `qpcontrol.jl_amd/libqpcontrol_hip.so`, built in-tree by
+`__graft_entry__.build()` / `qpcontrol.jl_amd/build.py`.  There is NO CPU fallback: if the library
+is missing the import of any compute entry point raises, and on a box without a HIP device
+`qpc_finalize` fails with QPC_ERR_NO_DEVICE.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+from .models import Mechanism, ModelDesc
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "libqpcontrol_hip.so")
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_int32_p = ctypes.POINTER(ctypes.c_int32)
+
+STATUS_NAMES = ["OPTIMAL", "ALMOST_OPTIMAL", "INFEASIBLE", "DUAL_INFEASIBLE", "ITERATION_LIMIT", "NUMERICAL_ERROR"]
+
+
+class Layout(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "nq", "nv", "n_tasks", "n_contacts", "n_basis", "n_desired", "n_task_weights", "n_surface",
+        "ref_n_var", "ref_n_eq", "ref_n_ineq", "n_free", "n_pinned", "n_slack", "n_rho",
+        "n_eq_rows", "lds_bytes_per_qp")]
+
+
+class Settings(ctypes.Structure):
+    _fields_ = [("max_active_set_iters", ctypes.c_int32), ("max_refine_iters", ctypes.c_int32),
+                ("eps_primal_reg", ctypes.c_double), ("eps_dual_reg", ctypes.c_double),
+                ("tol_residual", ctypes.c_double), ("tol_bound", ctypes.c_double)]
+
+
+class QpcError(RuntimeError):
+    pass
+
+
+_LIBS = {}
+
+
+def load_library(path=None):
+    """Load the shared library and declare the prototypes of every symbol in include/qpc.h."""
+    path = path or DEFAULT_LIB
+    if path in _LIBS:
+        return _LIBS[path]
+    if not os.path.exists(path):
+        raise QpcError(f"{path} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; "
+                       f"g.build()'); there is no CPU fallback")
+    L = ctypes.CDLL(path)
+    vp, i32, i64, dbl = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double
+    L.qpc_model_create.argtypes = [ctypes.POINTER(ModelDesc), ctypes.POINTER(vp)]
+    L.qpc_model_destroy.argtypes = [vp]
+    L.qpc_model_destroy.restype = None
+    L.qpc_model_nq.argtypes = [vp]
+    L.qpc_model_nv.argtypes = [vp]
+    L.qpc_controller_create.argtypes = [vp, i32, i32, ctypes.POINTER(vp)]
+    L.qpc_controller_destroy.argtypes = [vp]
+    L.qpc_controller_destroy.restype = None
+    L.qpc_add_task.argtypes = [vp, i32, i32, i32, i32, c_double_p, i32, i32, c_double_p, c_int32_p]
+    L.qpc_regularize.argtypes = [vp, i32, dbl]
+    L.qpc_add_contact.argtypes = [vp, i32, c_double_p, c_double_p, dbl, i32, c_int32_p]
+    L.qpc_finalize.argtypes = [vp, i32, ctypes.POINTER(Layout)]
+    L.qpc_get_layout.argtypes = [vp, ctypes.POINTER(Layout)]
+    L.qpc_default_settings.argtypes = [ctypes.POINTER(Settings)]
+    L.qpc_set_settings.argtypes = [vp, ctypes.POINTER(Settings)]
+    L.qpc_control_batch.argtypes = [vp, i64] + [c_double_p] * 7 + [c_double_p] * 3 + [c_int32_p, c_int32_p]
+    L.qpc_status_string.argtypes = [i32]
+    L.qpc_status_string.restype = ctypes.c_char_p
+    L.qpc_last_error.restype = ctypes.c_char_p
+    L.qpc_version.restype = ctypes.c_char_p
+    if hasattr(L, "qpc_control_batch_device"):
+        L.qpc_control_batch_device.argtypes = [vp, i64] + [vp] * 12 + [vp]
+        L.qpc_timing_enable.argtypes = [vp, i32]
+        L.qpc_timing_read.argtypes = [vp, c_double_p, ctypes.POINTER(i64)]
+        L.qpc_qp_solve_batch.argtypes = [i32, i32, i64] + [c_double_p] * 5 + [ctypes.POINTER(Settings), i32,
+                                                                             c_double_p, c_double_p, c_int32_p, c_int32_p]
+    _LIBS[path] = L
+    return L
+
+
+def _check(L, rc, what):
+    if rc != 0:
+        raise QpcError(f"{what} failed (code {rc}): {L.qpc_last_error().decode()}")
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(c_double_p)
+
+
+class Model:
+    """qpc_model handle == Mechanism{Float64}."""
+
+    def __init__(self, mech: Mechanism, lib_path=None):
+        self.mech = mech
+        self.L = load_library(lib_path)
+        d, self._keep = mech.desc()
+        self.h = ctypes.c_void_p()
+        _check(self.L, self.L.qpc_model_create(ctypes.byref(d), ctypes.byref(self.h)), "qpc_model_create")
+        self.nq, self.nv = self.L.qpc_model_nq(self.h), self.L.qpc_model_nv(self.h)
+
+    def __del__(self):
+        try:
+            self.L.qpc_model_destroy(self.h)
+        except Exception:
+            pass
+
+
+class Controller:
+    """qpc_controller handle: the batched MomentumBasedController (momentum.jl:1-81)."""
+
+    def __init__(self, model: Model, n_basis=4, floating_body=-1):
+        self.model = model
+        self.L = model.L
+        self.h = ctypes.c_void_p()
+        _check(self.L, self.L.qpc_controller_create(model.h, int(n_basis), int(floating_body), ctypes.byref(self.h)),
+               "qpc_controller_create")
+        self.layout = None
+        self.n_basis = n_basis
+
+    def __del__(self):
+        try:
+            self.L.qpc_controller_destroy(self.h)
+        except Exception:
+            pass
+
+    def add_task(self, kind, base=-1, target=-1, frame=-2, point=None, joint=-1, wkind=0, weight=None):
+        pt = np.ascontiguousarray(point if point is not None else np.zeros(3), dtype=np.float64)
+        w = None if weight is None else np.ascontiguousarray(np.asarray(weight, dtype=np.float64).reshape(-1))
+        tid = ctypes.c_int32(-1)
+        _check(self.L, self.L.qpc_add_task(self.h, kind, base, target, frame, _dp(pt), joint, wkind, _dp(w),
+                                           ctypes.byref(tid)), "qpc_add_task")
+        return tid.value
+
+    def regularize(self, joint, w):
+        _check(self.L, self.L.qpc_regularize(self.h, int(joint), float(w)), "qpc_regularize")
+
+    def add_contact(self, body, pos, normal, mu, per_qp_surface=0):
+        p = np.ascontiguousarray(pos, dtype=np.float64)
+        n = np.ascontiguousarray(normal, dtype=np.float64)
+        cid = ctypes.c_int32(-1)
+        _check(self.L, self.L.qpc_add_contact(self.h, int(body), _dp(p), _dp(n), float(mu), int(per_qp_surface),
+                                              ctypes.byref(cid)), "qpc_add_contact")
+        return cid.value
+
+    def set_settings(self, **kw):
+        s = Settings()
+        self.L.qpc_default_settings(ctypes.byref(s))
+        for k, v in kw.items():
+            setattr(s, k, v)
+        _check(self.L, self.L.qpc_set_settings(self.h, ctypes.byref(s)), "qpc_set_settings")
+
+    def finalize(self, device_id=0):
+        lay = Layout()
+        _check(self.L, self.L.qpc_finalize(self.h, int(device_id), ctypes.byref(lay)), "qpc_finalize")
+        self.layout = lay
+        return lay
+
+    # ---- host-array tick (synchronous): the callable (controller)(tau, t, x) for a batch
+    def control_batch(self, q, v, desired=None, contact_weight=None, contact_maxnormalforce=None,
+                      task_weights=None, surfaces=None):
+        lay = self.layout
+        if lay is None:
+            raise QpcError("controller not finalized")
+        q = np.ascontiguousarray(q, dtype=np.float64).reshape(-1, lay.nq)
+        B = q.shape[0]
+
+        def arr(x, n):
+            if n == 0:
+                return None
+            if x is None:
+                raise QpcError("missing per-QP input array")
+            a = np.ascontiguousarray(x, dtype=np.float64).reshape(B, n)
+            return a
+
+        v = arr(v, lay.nv)
+        des, cw, cm = arr(desired, lay.n_desired), arr(contact_weight, lay.n_contacts), arr(contact_maxnormalforce, lay.n_contacts)
+        tw, sf = arr(task_weights, lay.n_task_weights), arr(surfaces, lay.n_surface)
+        tau, vd = np.zeros((B, lay.nv)), np.zeros((B, lay.nv))
+        cwr = np.zeros((B, max(lay.n_contacts, 1) * 6))
+        status, iters = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
+        rc = self.L.qpc_control_batch(self.h, B, _dp(q), _dp(v), _dp(des), _dp(cw), _dp(cm), _dp(tw), _dp(sf),
+                                      _dp(tau), _dp(vd), _dp(cwr) if lay.n_contacts else None,
+                                      status.ctypes.data_as(c_int32_p), iters.ctypes.data_as(c_int32_p))
+        _check(self.L, rc, "qpc_control_batch")
+        return dict(tau=tau, vdot=vd, cwrench=cwr[:, :6 * lay.n_contacts].reshape(B, lay.n_contacts, 6),
+                    status=status, iters=iters)

@@ -1,0 +1,168 @@
+// qpc_capi_build.cpp -- the construction half of the C ABI (include/qpc.h): model and controller
+// handles, addtask!/regularize!/addcontact! mirrors.  Pure host C++, no HIP; the run half
+// (qpc_finalize upload, qpc_control_batch*) lives in qpc_runtime.hip.
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#include "qpc_compile.h"
+
+extern "C" {
+
+int32_t qpc_model_create(const qpc_model_desc *d, qpc_model **out) {
+  if (!d || !out || d->nbodies <= 0) { qpc_set_error("qpc_model_create: bad arguments"); return QPC_ERR_INVALID_ARGUMENT; }
+  qpc_model *m = new (std::nothrow) qpc_model();
+  if (!m) return QPC_ERR_OUT_OF_MEMORY;
+  m->nb = d->nbodies;
+  int nq = 0, nv = 0;
+  for (int i = 0; i < m->nb; i++) {
+    if (d->parent[i] >= i || d->parent[i] < -1) {
+      delete m; qpc_set_error("qpc_model_create: bodies must be topologically ordered (parent[i] < i)");
+      return QPC_ERR_INVALID_ARGUMENT;
+    }
+    int nqj, nvj;
+    switch (d->joint_type[i]) {
+      case QPC_JOINT_REVOLUTE: case QPC_JOINT_PRISMATIC: nqj = 1; nvj = 1; break;
+      case QPC_JOINT_QUAT_FLOATING: nqj = 7; nvj = 6; break;
+      case QPC_JOINT_FIXED: nqj = 0; nvj = 0; break;
+      default: delete m; qpc_set_error("qpc_model_create: unknown joint type"); return QPC_ERR_INVALID_ARGUMENT;
+    }
+    m->parent.push_back(d->parent[i]); m->jtype.push_back(d->joint_type[i]);
+    m->qoff.push_back(nq); m->voff.push_back(nv); m->nqj.push_back(nqj); m->nvj.push_back(nvj);
+    nq += nqj; nv += nvj;
+    m->mass.push_back(d->mass[i]); m->mtot += d->mass[i];
+  }
+  m->nq = nq; m->nv = nv;
+  m->axis.assign(d->joint_axis, d->joint_axis + 3 * m->nb);
+  m->Rf.assign(d->joint_R, d->joint_R + 9 * m->nb);
+  m->pf.assign(d->joint_p, d->joint_p + 3 * m->nb);
+  m->com.assign(d->com, d->com + 3 * m->nb);
+  m->icom.assign(d->inertia, d->inertia + 6 * m->nb);
+  std::memcpy(m->gravity, d->gravity, sizeof(m->gravity));
+  *out = m;
+  return QPC_OK;
+}
+void qpc_model_destroy(qpc_model *m) { delete m; }
+int32_t qpc_model_nq(const qpc_model *m) { return m ? m->nq : -1; }
+int32_t qpc_model_nv(const qpc_model *m) { return m ? m->nv : -1; }
+int32_t qpc_model_joint_ranges(const qpc_model *m, int32_t body, int32_t *q0, int32_t *nq, int32_t *v0, int32_t *nv) {
+  if (!m || body < 0 || body >= m->nb) return QPC_ERR_INVALID_ARGUMENT;
+  if (q0) *q0 = m->qoff[body];
+  if (nq) *nq = m->nqj[body];
+  if (v0) *v0 = m->voff[body];
+  if (nv) *nv = m->nvj[body];
+  return QPC_OK;
+}
+
+int32_t qpc_default_settings(qpc_settings *s) {
+  if (!s) return QPC_ERR_INVALID_ARGUMENT;
+  s->max_active_set_iters = 200; s->max_refine_iters = 6;
+  s->eps_primal_reg = 1e-9; s->eps_dual_reg = 1e-11; s->tol_residual = 1e-10; s->tol_bound = 1e-10;
+  return QPC_OK;
+}
+
+int32_t qpc_controller_create(const qpc_model *model, int32_t n_basis, int32_t floating_body, qpc_controller **out) {
+  if (!model || !out || n_basis < 1 || n_basis > 8 || floating_body < -1 || floating_body >= model->nb) {
+    qpc_set_error("qpc_controller_create: bad arguments (n_basis in 1..8)");
+    return QPC_ERR_INVALID_ARGUMENT;
+  }
+  qpc_controller *c = new (std::nothrow) qpc_controller();
+  if (!c) return QPC_ERR_OUT_OF_MEMORY;
+  c->model = model; c->N = n_basis; c->floating = floating_body;
+  c->reg.assign(model->nv, 0.0);
+  qpc_default_settings(&c->settings);
+  std::memset(&c->layout, 0, sizeof(c->layout));
+  *out = c;
+  return QPC_OK;
+}
+
+int32_t qpc_set_settings(qpc_controller *c, const qpc_settings *s) {
+  if (!c || !s) return QPC_ERR_INVALID_ARGUMENT;
+  if (c->finalized) { qpc_set_error("settings must be set before qpc_finalize"); return QPC_ERR_ALREADY_FINALIZED; }
+  c->settings = *s;
+  return QPC_OK;
+}
+
+int32_t qpc_add_task(qpc_controller *c, int32_t kind, int32_t base_body, int32_t target_body, int32_t frame_body,
+                     const double *point, int32_t joint_body, int32_t weight_kind, const double *weight,
+                     int32_t *out_task_id) {
+  if (!c) return QPC_ERR_INVALID_ARGUMENT;
+  if (c->finalized) { qpc_set_error("tasks must be added before the first tick"); return QPC_ERR_ALREADY_FINALIZED; }
+  const qpc_model *m = c->model;
+  QpcTask t;
+  std::memset(t.point, 0, sizeof(t.point));
+  t.kind = kind; t.base = base_body; t.target = target_body; t.joint = joint_body; t.wkind = weight_kind;
+  t.dim = qpc_task_dim(m, kind, joint_body);
+  if (t.dim <= 0) { qpc_set_error("qpc_add_task: bad kind / joint"); return QPC_ERR_INVALID_ARGUMENT; }
+  bool path_task = kind <= QPC_TASK_POINT_ACCELERATION;
+  if (path_task && (base_body < -1 || base_body >= m->nb || target_body < -1 || target_body >= m->nb)) {
+    qpc_set_error("qpc_add_task: body index out of range"); return QPC_ERR_INVALID_ARGUMENT;
+  }
+  t.frame = frame_body == QPC_FRAME_DEFAULT ? target_body : frame_body;
+  if (kind == QPC_TASK_POINT_ACCELERATION) {
+    t.frame = base_body; // src/tasks.jl:139-140,154
+    if (target_body < 0) { qpc_set_error("PointAccelerationTask needs a moving target body"); return QPC_ERR_INVALID_ARGUMENT; }
+  }
+  if (path_task && (t.frame < -1 || t.frame >= m->nb)) { qpc_set_error("qpc_add_task: frame out of range"); return QPC_ERR_INVALID_ARGUMENT; }
+  if (point) std::memcpy(t.point, point, sizeof(t.point));
+  t.des_off = c->n_desired; t.tw_off = -1;
+  switch (weight_kind) {
+    case QPC_WEIGHT_HARD: break;
+    case QPC_WEIGHT_SCALAR:
+      if (!weight) { qpc_set_error("qpc_add_task: weight missing"); return QPC_ERR_INVALID_ARGUMENT; }
+      t.W.assign(weight, weight + 1); break;
+    case QPC_WEIGHT_MATRIX:
+      if (!weight) { qpc_set_error("qpc_add_task: weight missing"); return QPC_ERR_INVALID_ARGUMENT; }
+      t.W.assign(weight, weight + t.dim * t.dim); break;
+    case QPC_WEIGHT_SCALAR_PER_QP: t.tw_off = c->n_tw; c->n_tw += 1; break;
+    case QPC_WEIGHT_MATRIX_PER_QP: t.tw_off = c->n_tw; c->n_tw += t.dim * t.dim; break;
+    default: qpc_set_error("qpc_add_task: bad weight kind"); return QPC_ERR_INVALID_ARGUMENT;
+  }
+  c->n_desired += t.dim;
+  c->tasks.push_back(t);
+  if (out_task_id) *out_task_id = (int32_t)c->tasks.size() - 1;
+  return QPC_OK;
+}
+
+int32_t qpc_regularize(qpc_controller *c, int32_t joint, double w) {
+  if (!c || joint < 0 || joint >= c->model->nb) return QPC_ERR_INVALID_ARGUMENT;
+  if (c->finalized) { qpc_set_error("regularize! must be called before the first tick"); return QPC_ERR_ALREADY_FINALIZED; }
+  for (int k = 0; k < c->model->nvj[joint]; k++) c->reg[c->model->voff[joint] + k] += w;
+  return QPC_OK;
+}
+
+int32_t qpc_add_contact(qpc_controller *c, int32_t body, const double position[3], const double normal[3], double mu,
+                        int32_t per_qp_surface, int32_t *out_contact_id) {
+  if (!c || !position || !normal || body < -1 || body >= c->model->nb) return QPC_ERR_INVALID_ARGUMENT;
+  if (c->finalized) { qpc_set_error("contacts must be added before the first tick"); return QPC_ERR_ALREADY_FINALIZED; }
+  QpcContact k;
+  k.body = body; k.per_qp = per_qp_surface ? 1 : 0; k.surf_off = -1; k.mu = mu;
+  std::memcpy(k.pos, position, sizeof(k.pos));
+  std::memcpy(k.normal, normal, sizeof(k.normal));
+  if (k.per_qp) { k.surf_off = c->n_surf; c->n_surf += 4; }
+  c->contacts.push_back(k);
+  if (out_contact_id) *out_contact_id = (int32_t)c->contacts.size() - 1;
+  return QPC_OK;
+}
+
+int32_t qpc_get_layout(const qpc_controller *c, qpc_layout *out) {
+  if (!c || !out) return QPC_ERR_INVALID_ARGUMENT;
+  if (!c->finalized) { qpc_set_error("controller not finalized"); return QPC_ERR_NOT_FINALIZED; }
+  *out = c->layout;
+  return QPC_OK;
+}
+
+const char *qpc_status_string(int32_t s) {
+  switch (s) {
+    case QPC_STATUS_OPTIMAL: return "OPTIMAL";
+    case QPC_STATUS_ALMOST_OPTIMAL: return "ALMOST_OPTIMAL";
+    case QPC_STATUS_INFEASIBLE: return "INFEASIBLE";
+    case QPC_STATUS_DUAL_INFEASIBLE: return "DUAL_INFEASIBLE";
+    case QPC_STATUS_ITERATION_LIMIT: return "ITERATION_LIMIT";
+    case QPC_STATUS_NUMERICAL_ERROR: return "NUMERICAL_ERROR";
+  }
+  return "UNKNOWN";
+}
+const char *qpc_version(void) { return "qpcontrol_hip 0.1.0 (gfx950)"; }
+
+} // extern "C"

@@ -1,0 +1,286 @@
+// qpc_compile.cpp -- freezes a controller into the device "task program" (see qpc_program.h).
+// Pure host C++.  What is decided here, once, is what Parametron re-derives every tick on the CPU
+// path: which accelerations are pinned by hard JointAccelerationTasks
+// (src/tasks.jl:185-189), which soft tasks fold into the diagonal of the Hessian, the row layout of
+// the equality block, the kinematic-path sign tables of every Jacobian (geometric_jacobian!,
+// src/tasks.jl:33-34) and the per-QP LDS layout.
+#include "qpc_compile.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+static thread_local std::string g_err;
+void qpc_set_error(const std::string &msg) { g_err = msg; }
+extern "C" const char *qpc_last_error(void) { return g_err.c_str(); }
+
+int qpc_task_dim(const qpc_model *m, int kind, int joint) {
+  switch (kind) {
+    case QPC_TASK_SPATIAL_ACCELERATION: case QPC_TASK_MOMENTUM_RATE: return 6;
+    case QPC_TASK_ANGULAR_ACCELERATION: case QPC_TASK_LINEAR_ACCELERATION:
+    case QPC_TASK_POINT_ACCELERATION: case QPC_TASK_LINEAR_MOMENTUM_RATE: return 3;
+    case QPC_TASK_JOINT_ACCELERATION:
+      if (joint < 0 || joint >= m->nb) return -1;
+      return m->nvj[joint];
+  }
+  return -1;
+}
+
+namespace {
+struct Builder {
+  std::vector<int> it;
+  std::vector<double> dt;
+  QpcDims *D;
+  void ibegin(int id) { D->it[id] = (int)it.size(); }
+  void dbegin(int id) { D->dt[id] = (int)dt.size(); }
+};
+int odd(int x) { return x | 1; }
+} // namespace
+
+int qpc_compile_program(qpc_controller *c) {
+  const qpc_model *m = c->model;
+  QpcProgram &P = c->prog;
+  QpcDims &D = P.dims;
+  std::memset(&D, 0, sizeof(D));
+  Builder B;
+  B.D = &D;
+  const int nb = m->nb, nv = m->nv, N = c->N;
+  D.nb = nb; D.nq = m->nq; D.nv = nv; D.N = N; D.nc = (int)c->contacts.size();
+  D.floating = c->floating;
+  D.fv0 = c->floating >= 0 ? m->voff[c->floating] : -1;
+  D.n_desired = c->n_desired; D.n_tw = c->n_tw; D.n_surf = c->n_surf;
+  if (c->floating >= 0 && m->jtype[c->floating] != QPC_JOINT_QUAT_FLOATING) {
+    qpc_set_error("floating_body must be the successor of a QuaternionFloating joint");
+    return QPC_ERR_INVALID_ARGUMENT;
+  }
+  D.nw = c->floating >= 0 ? 6 : 0;
+  // ---- pass 1: pins (hard JointAccelerationTask on not-yet-pinned velocity indices)
+  std::vector<int> pin_des(nv, -1);
+  std::vector<char> task_is_pin(c->tasks.size(), 0);
+  for (size_t ti = 0; ti < c->tasks.size(); ti++) {
+    const QpcTask &t = c->tasks[ti];
+    if (t.kind != QPC_TASK_JOINT_ACCELERATION || t.wkind != QPC_WEIGHT_HARD) continue;
+    bool fresh = true;
+    for (int k = 0; k < t.dim; k++) fresh = fresh && pin_des[m->voff[t.joint] + k] < 0;
+    if (!fresh) continue; // duplicate pin stays a generic (possibly inconsistent) row block
+    for (int k = 0; k < t.dim; k++) pin_des[m->voff[t.joint] + k] = t.des_off + k;
+    task_is_pin[ti] = 1;
+  }
+  std::vector<int> free_of(nv, -1), free_k, pin_k, pin_d;
+  for (int k = 0; k < nv; k++) {
+    if (pin_des[k] >= 0) { pin_k.push_back(k); pin_d.push_back(pin_des[k]); }
+    else { free_of[k] = (int)free_k.size(); free_k.push_back(k); }
+  }
+  D.nf = (int)free_k.size(); D.npin = (int)pin_k.size();
+  // ---- pass 2: folded soft joint tasks and generic tasks
+  std::vector<int> sj_f, sj_des, sj_tw;
+  std::vector<double> sj_w;
+  std::vector<int> generic;
+  for (size_t ti = 0; ti < c->tasks.size(); ti++) {
+    const QpcTask &t = c->tasks[ti];
+    if (task_is_pin[ti]) continue;
+    if (t.kind == QPC_TASK_JOINT_ACCELERATION &&
+        (t.wkind == QPC_WEIGHT_SCALAR || t.wkind == QPC_WEIGHT_SCALAR_PER_QP)) {
+      for (int k = 0; k < t.dim; k++) {
+        int f = free_of[m->voff[t.joint] + k];
+        if (f < 0) continue; // soft task on a pinned acceleration is a constant
+        sj_f.push_back(f); sj_des.push_back(t.des_off + k);
+        sj_tw.push_back(t.wkind == QPC_WEIGHT_SCALAR_PER_QP ? t.tw_off : -1);
+        sj_w.push_back(t.wkind == QPC_WEIGHT_SCALAR ? t.W[0] : 0.0);
+      }
+      continue;
+    }
+    generic.push_back((int)ti);
+  }
+  D.nsj = (int)sj_f.size(); D.ntask = (int)generic.size();
+  // rows and slacks
+  int m1 = 0, ne = 0, wsize = 0;
+  std::vector<int> row0(generic.size()), slack0(generic.size(), -1), woff(generic.size(), -1);
+  for (size_t g = 0; g < generic.size(); g++) {
+    const QpcTask &t = c->tasks[generic[g]];
+    row0[g] = m1; m1 += t.dim;
+    if (t.wkind != QPC_WEIGHT_HARD) { slack0[g] = ne; ne += t.dim; woff[g] = wsize; wsize += t.dim * t.dim; }
+  }
+  D.m1 = m1; D.m = m1 + D.nw; D.ne = ne; D.wsize = wsize;
+  D.nrho = (D.nw > 0) ? D.nc * N : 0; // without wrench balance the rho decouple and stay 0
+  D.nfs = odd(D.nf > 0 ? D.nf : 1); D.ms = odd(D.m > 0 ? D.m : 1); D.m1s = odd(m1 > 0 ? m1 : 1);
+
+  // ---- integer tables
+  B.ibegin(IT_PARENT); for (int i = 0; i < nb; i++) B.it.push_back(m->parent[i]);
+  B.ibegin(IT_JTYPE); for (int i = 0; i < nb; i++) B.it.push_back(m->jtype[i]);
+  B.ibegin(IT_QOFF); for (int i = 0; i < nb; i++) B.it.push_back(m->qoff[i]);
+  B.ibegin(IT_VOFF); for (int i = 0; i < nb; i++) B.it.push_back(m->voff[i]);
+  B.ibegin(IT_NVJ); for (int i = 0; i < nb; i++) B.it.push_back(m->nvj[i]);
+  {
+    std::vector<int> ptr(nb + 1, 0), idx;
+    int maxdepth = 0;
+    for (int i = 0; i < nb; i++) {
+      int d = 0;
+      for (int a = m->parent[i]; a >= 0; a = m->parent[a]) { idx.push_back(a); d++; }
+      ptr[i + 1] = (int)idx.size();
+      maxdepth = std::max(maxdepth, d);
+    }
+    D.maxdepth = maxdepth;
+    B.ibegin(IT_ANC_PTR); B.it.insert(B.it.end(), ptr.begin(), ptr.end());
+    B.ibegin(IT_ANC_IDX); B.it.insert(B.it.end(), idx.begin(), idx.end());
+    std::vector<std::vector<int>> desc(nb);
+    for (int i = 0; i < nb; i++)
+      for (int a = i; a >= 0; a = m->parent[a]) desc[a].push_back(i);
+    std::vector<int> dptr(nb + 1, 0), didx;
+    for (int i = 0; i < nb; i++) { didx.insert(didx.end(), desc[i].begin(), desc[i].end()); dptr[i + 1] = (int)didx.size(); }
+    B.ibegin(IT_DESC_PTR); B.it.insert(B.it.end(), dptr.begin(), dptr.end());
+    B.ibegin(IT_DESC_IDX); B.it.insert(B.it.end(), didx.begin(), didx.end());
+  }
+  B.ibegin(IT_VBODY);
+  for (int i = 0; i < nb; i++) for (int k = 0; k < m->nvj[i]; k++) B.it.push_back(i);
+  B.ibegin(IT_VCOMP);
+  for (int i = 0; i < nb; i++) for (int k = 0; k < m->nvj[i]; k++) B.it.push_back(k);
+  B.ibegin(IT_FREE_OF); B.it.insert(B.it.end(), free_of.begin(), free_of.end());
+  B.ibegin(IT_FREE_K); B.it.insert(B.it.end(), free_k.begin(), free_k.end());
+  B.ibegin(IT_PIN_K); B.it.insert(B.it.end(), pin_k.begin(), pin_k.end());
+  B.ibegin(IT_PIN_DES); B.it.insert(B.it.end(), pin_d.begin(), pin_d.end());
+  B.ibegin(IT_SJ_F); B.it.insert(B.it.end(), sj_f.begin(), sj_f.end());
+  B.ibegin(IT_SJ_DES); B.it.insert(B.it.end(), sj_des.begin(), sj_des.end());
+  B.ibegin(IT_SJ_TW); B.it.insert(B.it.end(), sj_tw.begin(), sj_tw.end());
+  auto push_task_field = [&](int id, auto getter) {
+    B.ibegin(id);
+    for (size_t g = 0; g < generic.size(); g++) B.it.push_back(getter(g, c->tasks[generic[g]]));
+  };
+  push_task_field(IT_T_KIND, [](size_t, const QpcTask &t) { return t.kind; });
+  push_task_field(IT_T_BASE, [](size_t, const QpcTask &t) { return t.base; });
+  push_task_field(IT_T_TARGET, [](size_t, const QpcTask &t) { return t.target; });
+  push_task_field(IT_T_FRAME, [](size_t, const QpcTask &t) { return t.frame; });
+  push_task_field(IT_T_DIM, [](size_t, const QpcTask &t) { return t.dim; });
+  push_task_field(IT_T_ROW0, [&](size_t g, const QpcTask &) { return row0[g]; });
+  push_task_field(IT_T_DES, [](size_t, const QpcTask &t) { return t.des_off; });
+  push_task_field(IT_T_WKIND, [](size_t, const QpcTask &t) { return t.wkind; });
+  push_task_field(IT_T_TW, [](size_t, const QpcTask &t) { return t.tw_off; });
+  push_task_field(IT_T_SLACK0, [&](size_t g, const QpcTask &) { return slack0[g]; });
+  push_task_field(IT_T_WOFF, [&](size_t g, const QpcTask &) { return woff[g]; });
+  // path sign tables
+  B.ibegin(IT_T_SGN);
+  for (size_t g = 0; g < generic.size(); g++) {
+    const QpcTask &t = c->tasks[generic[g]];
+    std::vector<int> sgn(nv, 0);
+    if (t.kind == QPC_TASK_JOINT_ACCELERATION) {
+      for (int k = 0; k < t.dim; k++) sgn[m->voff[t.joint] + k] = 1;
+    } else if (t.kind == QPC_TASK_MOMENTUM_RATE || t.kind == QPC_TASK_LINEAR_MOMENTUM_RATE) {
+      for (int k = 0; k < nv; k++) sgn[k] = 1;
+    } else {
+      std::vector<char> mark(nb, 0);
+      for (int b = t.target; b >= 0; b = m->parent[b]) mark[b] = 1;
+      int lca = -1;
+      for (int b = t.base; b >= 0; b = m->parent[b]) if (mark[b]) { lca = b; break; }
+      for (int b = t.base; b >= 0 && b != lca; b = m->parent[b])
+        for (int k = 0; k < m->nvj[b]; k++) sgn[m->voff[b] + k] = -1;
+      for (int b = t.target; b >= 0 && b != lca; b = m->parent[b])
+        for (int k = 0; k < m->nvj[b]; k++) sgn[m->voff[b] + k] = 1;
+    }
+    B.it.insert(B.it.end(), sgn.begin(), sgn.end());
+  }
+  B.ibegin(IT_ROW_TASK);
+  for (size_t g = 0; g < generic.size(); g++) for (int a = 0; a < c->tasks[generic[g]].dim; a++) B.it.push_back((int)g);
+  for (int a = 0; a < D.nw; a++) B.it.push_back(-1);
+  B.ibegin(IT_ROW_COMP);
+  for (size_t g = 0; g < generic.size(); g++) for (int a = 0; a < c->tasks[generic[g]].dim; a++) B.it.push_back(a);
+  for (int a = 0; a < D.nw; a++) B.it.push_back(a);
+  B.ibegin(IT_C_BODY); for (auto &k : c->contacts) B.it.push_back(k.body);
+  B.ibegin(IT_C_PERQP); for (auto &k : c->contacts) B.it.push_back(k.per_qp);
+  B.ibegin(IT_C_SURF); for (auto &k : c->contacts) B.it.push_back(k.surf_off);
+  {
+    std::vector<int> ptr(nb + 1, 0), idx;
+    for (int i = 0; i < nb; i++) {
+      for (size_t ci = 0; ci < c->contacts.size(); ci++) if (c->contacts[ci].body == i) idx.push_back((int)ci);
+      ptr[i + 1] = (int)idx.size();
+    }
+    B.ibegin(IT_BC_PTR); B.it.insert(B.it.end(), ptr.begin(), ptr.end());
+    B.ibegin(IT_BC_IDX); B.it.insert(B.it.end(), idx.begin(), idx.end());
+  }
+  B.ibegin(IT_SLACK_TASK);
+  for (size_t g = 0; g < generic.size(); g++) if (slack0[g] >= 0) for (int a = 0; a < c->tasks[generic[g]].dim; a++) B.it.push_back((int)g);
+  B.ibegin(IT_SLACK_COMP);
+  for (size_t g = 0; g < generic.size(); g++) if (slack0[g] >= 0) for (int a = 0; a < c->tasks[generic[g]].dim; a++) B.it.push_back(a);
+  B.it.push_back(0); // never empty
+
+  // ---- double tables
+  B.dbegin(DT_AXIS); B.dt.insert(B.dt.end(), m->axis.begin(), m->axis.end());
+  B.dbegin(DT_RF); B.dt.insert(B.dt.end(), m->Rf.begin(), m->Rf.end());
+  B.dbegin(DT_PF); B.dt.insert(B.dt.end(), m->pf.begin(), m->pf.end());
+  B.dbegin(DT_MASS); B.dt.insert(B.dt.end(), m->mass.begin(), m->mass.end());
+  B.dbegin(DT_COM); B.dt.insert(B.dt.end(), m->com.begin(), m->com.end());
+  B.dbegin(DT_ICOM); B.dt.insert(B.dt.end(), m->icom.begin(), m->icom.end());
+  B.dbegin(DT_REG2); for (int k = 0; k < nv; k++) B.dt.push_back(2.0 * c->reg[k]);
+  B.dbegin(DT_GRAV); for (int k = 0; k < 3; k++) B.dt.push_back(m->gravity[k]);
+  B.dt.push_back(m->mtot);
+  B.dbegin(DT_SJ_W); B.dt.insert(B.dt.end(), sj_w.begin(), sj_w.end());
+  B.dbegin(DT_T_POINT);
+  for (size_t g = 0; g < generic.size(); g++) for (int k = 0; k < 3; k++) B.dt.push_back(c->tasks[generic[g]].point[k]);
+  B.dbegin(DT_T_W);
+  for (size_t g = 0; g < generic.size(); g++) {
+    const QpcTask &t = c->tasks[generic[g]];
+    if (slack0[g] < 0) continue;
+    // symmetric Hessian block of the slack: 2*sym(W) (P = 2x written weights)
+    for (int a = 0; a < t.dim; a++)
+      for (int b = 0; b < t.dim; b++) {
+        double w = 0.0;
+        if (t.wkind == QPC_WEIGHT_SCALAR) w = (a == b) ? 2.0 * t.W[0] : 0.0;
+        else if (t.wkind == QPC_WEIGHT_MATRIX) w = t.W[a * t.dim + b] + t.W[b * t.dim + a];
+        B.dt.push_back(w);
+      }
+  }
+  B.dbegin(DT_C_POS); for (auto &k : c->contacts) for (int a = 0; a < 3; a++) B.dt.push_back(k.pos[a]);
+  B.dbegin(DT_C_NORMAL); for (auto &k : c->contacts) for (int a = 0; a < 3; a++) B.dt.push_back(k.normal[a]);
+  B.dbegin(DT_C_MU); for (auto &k : c->contacts) B.dt.push_back(k.mu);
+  B.dt.push_back(0.0);
+
+  // ---- LDS layout
+  int off = 0;
+  auto L = [&](int id, int n) { D.lds[id] = off; off += (n > 0 ? n : 0); off += off & 1; };
+  const int nrho = D.nrho, mm = D.m;
+  L(L_Q, D.nq); L(L_V, nv); L(L_DES, D.n_desired); L(L_CW, D.nc); L(L_CMAX, D.nc);
+  L(L_TW, D.n_tw); L(L_SURF, D.n_surf);
+  L(L_RL, nb * 12); L(L_H, nb * 12); L(L_S, nv * 6);
+  L(L_TJ, nb * 6); L(L_T, nb * 6); L(L_CR, nb * 6); L(L_AB, nb * 6);
+  L(L_IW, nb * 10); L(L_IC, nb * 10); L(L_HB, nb * 6);
+  L(L_MISC, MS_COUNT); L(L_AMOM, 6 * nv); L(L_ACCP, (D.ntask + 1) * 6);
+  L(L_M, mm * D.nfs); L(L_D, mm); L(L_HV, D.nf); L(L_SQH, D.nf); L(L_GV, D.nf);
+  L(L_W, wsize); L(L_WINV, wsize);
+  L(L_SM, mm * D.ms); L(L_X, m1 * D.m1s);
+  L(L_B22, 36); L(L_C22, 36); L(L_L22, 36); L(L_S22I, 36);
+  L(L_G, 6 * nrho); L(L_Y, nrho * 6); L(L_HR, D.nc * N * N); L(L_KR, D.nc * N * N);
+  L(L_HI, nrho); L(L_WS, nrho); L(L_U, nrho);
+  L(L_XV, D.nf); L(L_XE, ne); L(L_XR, nrho); L(L_LAM, mm);
+  L(L_DV, D.nf); L(L_DE, ne); L(L_DR, nrho); L(L_DL, mm);
+  L(L_RV, D.nf); L(L_RE, ne); L(L_RR, nrho); L(L_RC, mm);
+  L(L_T1, mm); L(L_T2, mm); L(L_T3, mm); L(L_TR1, nrho); L(L_TR2, nrho); L(L_TE1, ne);
+  L(L_RED, 256); L(L_VD, nv); L(L_SV, nb * 6); L(L_F, nb * 6); L(L_CWR, D.nc * 6);
+  D.lds_doubles = off;
+  D.n_int = (int)B.it.size(); D.n_dbl = (int)B.dt.size();
+  // settings
+  D.max_as_iters = c->settings.max_active_set_iters;
+  D.max_refine = c->settings.max_refine_iters;
+  D.max_pdas = 12;
+  D.eps_primal = c->settings.eps_primal_reg;
+  D.tau_pivot = c->settings.eps_dual_reg;
+  D.tol_bound = c->settings.tol_bound;
+  D.tol_accept = 1e-7;
+  P.itab.swap(B.it);
+  P.dtab.swap(B.dt);
+
+  // ---- public layout
+  qpc_layout &Lo = c->layout;
+  std::memset(&Lo, 0, sizeof(Lo));
+  Lo.nq = m->nq; Lo.nv = nv; Lo.n_tasks = (int)c->tasks.size(); Lo.n_contacts = D.nc; Lo.n_basis = N;
+  Lo.n_desired = c->n_desired; Lo.n_task_weights = c->n_tw; Lo.n_surface = c->n_surf;
+  int nvar = nv, neq = 0;
+  for (auto &t : c->tasks) { neq += t.dim; if (t.wkind != QPC_WEIGHT_HARD) nvar += t.dim; }
+  nvar += D.nc * (N + 9); neq += D.nc * 9 + D.nw;
+  Lo.ref_n_var = nvar; Lo.ref_n_eq = neq; Lo.ref_n_ineq = D.nc * 2 * N;
+  Lo.n_free = D.nf; Lo.n_pinned = D.npin; Lo.n_slack = ne; Lo.n_rho = nrho; Lo.n_eq_rows = mm;
+  Lo.lds_bytes_per_qp = D.lds_doubles * 8;
+  if (Lo.lds_bytes_per_qp > 160 * 1024) {
+    qpc_set_error("problem does not fit the 160 KiB LDS of one CU");
+    return QPC_ERR_UNSUPPORTED;
+  }
+  return QPC_OK;
+}

@@ -1,0 +1,54 @@
+// qpc_compile.h -- host-side model / controller objects and the program compiler (pure C++,
+// no HIP): mirrors Mechanism + MomentumBasedController construction of the reference
+// (momentum.jl:15-33,99-160) and freezes it into a QpcDims + flat tables (qpc_program.h).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/qpc.h"
+#include "qpc_program.h"
+
+struct qpc_model {
+  int nb = 0, nq = 0, nv = 0;
+  std::vector<int> parent, jtype, qoff, voff, nqj, nvj;
+  std::vector<double> axis, Rf, pf, mass, com, icom;
+  double gravity[3] = {0, 0, 0};
+  double mtot = 0;
+};
+
+struct QpcTask {
+  int kind, base, target, frame, joint, wkind, dim, des_off, tw_off;
+  double point[3];
+  std::vector<double> W;
+};
+struct QpcContact {
+  int body, per_qp, surf_off;
+  double pos[3], normal[3], mu;
+};
+
+struct QpcProgram {
+  QpcDims dims;
+  std::vector<int> itab;
+  std::vector<double> dtab;
+};
+
+struct QpcDeviceState; // owned by the HIP runtime part (qpc_runtime.hip)
+
+struct qpc_controller {
+  const qpc_model *model = nullptr;
+  int N = 4, floating = -1;
+  std::vector<QpcTask> tasks;
+  std::vector<QpcContact> contacts;
+  std::vector<double> reg;
+  int n_desired = 0, n_tw = 0, n_surf = 0;
+  bool finalized = false;
+  qpc_settings settings;
+  QpcProgram prog;
+  qpc_layout layout;
+  QpcDeviceState *dev = nullptr;
+};
+
+void qpc_set_error(const std::string &msg);
+int qpc_task_dim(const qpc_model *m, int kind, int joint);
+// freeze the controller into prog + layout; returns QPC_OK or an error code
+int qpc_compile_program(qpc_controller *c);

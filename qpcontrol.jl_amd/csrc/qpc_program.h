@@ -1,0 +1,101 @@
+// qpc_program.h -- the compiled "task program" shared by the host compiler (qpc_compile.cpp)
+// and the device code (qpc_tick.h): a POD header of sizes + offsets into two flat tables (ints
+// and doubles) that live in HBM, plus the per-QP LDS layout.
+//
+// The program is what the reference builds lazily as Parametron Parameters / LazyExpressions at
+// addtask!/addcontact!/initialize! time (momentum.jl:99-193); here it is frozen at qpc_finalize.
+#pragma once
+#include <stdint.h>
+
+// integer tables (offsets into the int blob)
+enum {
+  IT_PARENT, IT_JTYPE, IT_QOFF, IT_VOFF, IT_NVJ,
+  IT_ANC_PTR, IT_ANC_IDX,   // ancestors of body i, nearest first (CSR)
+  IT_DESC_PTR, IT_DESC_IDX, // descendants of body i including i (CSR)
+  IT_VBODY, IT_VCOMP,       // velocity index -> body, component within the joint
+  IT_FREE_OF,               // velocity index -> free index or -1 (pinned)
+  IT_FREE_K,                // free index -> velocity index
+  IT_PIN_K, IT_PIN_DES,     // pinned: velocity index, index into the desired record
+  IT_SJ_F, IT_SJ_DES, IT_SJ_TW, // folded soft joint tasks: free index, desired index, tw index or -1
+  IT_T_KIND, IT_T_BASE, IT_T_TARGET, IT_T_FRAME, IT_T_DIM, IT_T_ROW0, IT_T_DES, IT_T_WKIND,
+  IT_T_TW, IT_T_SLACK0, IT_T_WOFF, // generic tasks
+  IT_T_SGN,                 // [ntask*nv] path sign of velocity index k for task t (-1,0,+1)
+  IT_ROW_TASK, IT_ROW_COMP, // row -> generic task (or -1 for wrench rows), component
+  IT_C_BODY, IT_C_PERQP, IT_C_SURF, // contacts
+  IT_BC_PTR, IT_BC_IDX,     // contacts attached to body i (CSR)
+  IT_SLACK_TASK, IT_SLACK_COMP, // slack index -> generic task, component
+  IT_COUNT
+};
+
+// double tables
+enum {
+  DT_AXIS, DT_RF, DT_PF, DT_MASS, DT_COM, DT_ICOM, DT_REG2, DT_GRAV /*3 + mtot*/,
+  DT_SJ_W,   // static weight of folded soft joint tasks
+  DT_T_POINT, DT_T_W, // per generic task: point[3]; static W (dim*dim, row-major, at IT_T_WOFF)
+  DT_C_POS, DT_C_NORMAL, DT_C_MU,
+  DT_COUNT
+};
+
+// LDS regions (offsets in doubles into the per-QP LDS slab)
+enum {
+  L_Q, L_V, L_DES, L_CW, L_CMAX, L_TW, L_SURF,
+  L_RL,   // nb*12 local transforms
+  L_H,    // nb*12 world transforms
+  L_S,    // nv*6 motion subspaces (world)
+  L_TJ, L_T, L_CR, L_AB, // nb*6 each
+  L_IW, L_IC,            // nb*10 each
+  L_HB,                  // nb*6
+  L_MISC,                // 48 scalars
+  L_AMOM,                // 6*nv
+  L_ACCP,                // (ntask+1)*6 contribution of pinned accelerations
+  L_M,                   // m * nfs   scaled constraint matrix  E * diag(sqrt(Hv^-1))
+  L_D,                   // m rhs
+  L_HV, L_SQH, L_GV,     // nf each
+  L_W, L_WINV,           // sum dim^2 over soft generic tasks
+  L_SM,                  // m * ms  Schur complement / its Cholesky factor (lower)
+  L_X,                   // m1 * m1s explicit inverse of L11
+  L_B22, L_C22, L_L22, L_S22I, // 36 each
+  L_G,                   // 6 * nrho
+  L_Y,                   // nrho * 6
+  L_HR, L_KR,            // nc * N * N
+  L_HI, L_WS, L_U,       // nrho
+  L_XV, L_XE, L_XR, L_LAM, // iterate
+  L_DV, L_DE, L_DR, L_DL, // step / direction
+  L_RV, L_RE, L_RR, L_RC, // residuals / right-hand sides
+  L_T1, L_T2, L_T3,      // m-sized temporaries
+  L_TR1, L_TR2,          // nrho-sized temporaries
+  L_TE1,                 // ne-sized temporary
+  L_RED,                 // 4 x 64 reduction scratch
+  L_VD,                  // nv solution accelerations
+  L_SV, L_F,             // nb*6
+  L_CWR,                 // nc*6 contact wrenches
+  L_COUNT
+};
+
+// slots inside L_MISC
+enum {
+  MS_COM = 0,      // 3
+  MS_ADV = 3,      // 6
+  MS_WG = 9,       // 6
+  MS_EPS = 15, MS_HSCALE = 16,
+  MS_STATUS = 17, MS_ITERS = 18, MS_FLAG = 19, MS_P = 20, MS_SIDE = 21, MS_T = 22, MS_JDROP = 23,
+  MS_NDROP = 24, MS_RPRIM = 25, MS_RSTAT = 26, MS_XBIG = 27, MS_DBIG = 28, MS_GSCALE = 29,
+  MS_TOLB = 30, MS_CHANGED = 31, MS_FULL = 32, MS_SCP = 33, MS_SCS = 34, MS_REFINE = 35,
+  MS_COUNT = 48
+};
+
+struct QpcDims {
+  int nb, nq, nv, nf, npin, nsj, ntask, nc, N, nrho, ne, m, m1, nw;
+  int floating, fv0; // floating body and its first velocity index (or -1)
+  int n_desired, n_tw, n_surf, maxdepth;
+  int nfs, ms, m1s;  // padded leading dimensions (odd) of L_M, L_SM, L_X
+  int wsize;         // doubles in L_W / L_WINV
+  int it[IT_COUNT];
+  int dt[DT_COUNT];
+  int lds[L_COUNT];
+  int lds_doubles;   // per-QP LDS slab size
+  int n_int, n_dbl;  // table sizes
+  // solver settings (qpc_settings)
+  int max_as_iters, max_refine, max_pdas;
+  double eps_primal, tau_pivot, tol_bound, tol_accept;
+};

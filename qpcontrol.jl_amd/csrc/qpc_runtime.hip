@@ -1,0 +1,260 @@
+// qpc_runtime.hip -- the run half of the C ABI (include/qpc.h): qpc_finalize (program upload),
+// qpc_control_batch / qpc_control_batch_device (kernel launch), timing hooks.  gfx950 only.
+//
+// Execution model: one wavefront (64 lanes) per QP, one 64-thread workgroup per wavefront so that
+// the phase barrier is a single-wave s_barrier; each workgroup owns one LDS slab
+// (QpcDims::lds_doubles) and grid-strides over the batch.  Inputs/outputs are per-QP contiguous
+// records, loaded/stored by consecutive lanes (coalesced); H, A, b and every factor live only in
+// LDS and never touch HBM.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "qpc_compile.h"
+
+#define QPC_FN __device__ __forceinline__
+#define QPC_PHASE(lane) { const int lane = (int)(threadIdx.x & 63);
+#define QPC_END_PHASE } __syncthreads();
+#define QPC_SINCOS(x, s, c) sincos((x), &(s), &(c))
+#define QPC_SQRT(x) sqrt((double)(x))
+#define QPC_FABS(x) fabs((double)(x))
+#include "qpc_tick.h"
+
+struct QpcBatchArgs {
+  long long B;
+  const double *q, *v, *desired, *cw, *cmax, *tw, *surf;
+  double *tau, *vdot, *cwrench;
+  int32_t *status, *iters;
+};
+
+extern "C" __global__ void __launch_bounds__(64)
+qpc_tick_kernel(const QpcDims D, const int *__restrict__ IT, const double *__restrict__ DT, const QpcBatchArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double qpc_lds[];
+  for (long long b = blockIdx.x; b < A.B; b += gridDim.x) {
+    qpc::TickIO io;
+    io.q = A.q + b * D.nq; io.v = A.v + b * D.nv;
+    io.desired = A.desired + b * D.n_desired;
+    io.cw = A.cw + b * D.nc; io.cmax = A.cmax + b * D.nc;
+    io.tw = A.tw + b * D.n_tw; io.surf = A.surf + b * D.n_surf;
+    io.tau = A.tau + b * D.nv; io.vdot = A.vdot + b * D.nv;
+    io.cwrench = A.cwrench ? A.cwrench + b * 6 * D.nc : nullptr;
+    io.status = A.status + b; io.iters = A.iters ? A.iters + b : nullptr;
+    qpc::qpc_tick<double *>(D, IT, DT, qpc_lds, io);
+    __syncthreads(); // the slab is reused by the next QP of this workgroup
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+struct QpcDeviceState {
+  int device = -1;
+  int *d_it = nullptr;
+  double *d_dt = nullptr;
+  int n_cu = 0, blocks_per_cu = 1;
+  hipStream_t stream = nullptr; // internal stream of the host-pointer entry point
+  // staging buffers of the host-pointer entry point
+  void *stage = nullptr;
+  size_t stage_bytes = 0;
+  // timing
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  std::vector<hipEvent_t> pool;
+};
+
+static int hip_fail(hipError_t e, const char *what) {
+  qpc_set_error(std::string(what) + ": " + hipGetErrorString(e));
+  return (e == hipErrorNoDevice || e == hipErrorInvalidDevice) ? QPC_ERR_NO_DEVICE : QPC_ERR_HIP;
+}
+#define HIP_TRY(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return hip_fail(e__, #call); } while (0)
+
+static int launch(qpc_controller *c, const QpcBatchArgs &a, hipStream_t stream) {
+  QpcDeviceState *S = c->dev;
+  const QpcDims &D = c->prog.dims;
+  long long grid = (long long)S->n_cu * S->blocks_per_cu;
+  if (grid > a.B) grid = a.B;
+  if (grid < 1) return QPC_OK;
+  size_t lds = (size_t)D.lds_doubles * sizeof(double);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (S->timing) {
+    auto get = [&](hipEvent_t &e) -> hipError_t {
+      if (!S->pool.empty()) { e = S->pool.back(); S->pool.pop_back(); return hipSuccess; }
+      return hipEventCreate(&e);
+    };
+    HIP_TRY(get(e0)); HIP_TRY(get(e1));
+    HIP_TRY(hipEventRecord(e0, stream));
+  }
+  hipLaunchKernelGGL(qpc_tick_kernel, dim3((unsigned)grid), dim3(64), lds, stream, D, S->d_it, S->d_dt, a);
+  HIP_TRY(hipGetLastError());
+  if (S->timing) {
+    HIP_TRY(hipEventRecord(e1, stream));
+    S->events.emplace_back(e0, e1);
+  }
+  return QPC_OK;
+}
+
+extern "C" {
+
+int32_t qpc_finalize(qpc_controller *c, int32_t device_id, qpc_layout *out) {
+  if (!c) return QPC_ERR_INVALID_ARGUMENT;
+  if (c->finalized) { if (out) *out = c->layout; return QPC_OK; }
+  int rc = qpc_compile_program(c);
+  if (rc != QPC_OK) return rc;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    qpc_set_error("qpc_finalize: no HIP device available (this library has no CPU fallback)");
+    return QPC_ERR_NO_DEVICE;
+  }
+  if (device_id < 0 || device_id >= ndev) { qpc_set_error("qpc_finalize: device_id out of range"); return QPC_ERR_NO_DEVICE; }
+  HIP_TRY(hipSetDevice(device_id));
+  QpcDeviceState *S = new QpcDeviceState();
+  S->device = device_id;
+  const QpcDims &D = c->prog.dims;
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+  S->n_cu = prop.multiProcessorCount;
+  size_t lds = (size_t)D.lds_doubles * sizeof(double);
+  if (lds > (size_t)prop.maxSharedMemoryPerMultiProcessor && lds > 160 * 1024) {
+    delete S; qpc_set_error("qpc_finalize: LDS slab exceeds the device limit"); return QPC_ERR_UNSUPPORTED;
+  }
+  HIP_TRY(hipFuncSetAttribute((const void *)qpc_tick_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int per_cu = (int)((160 * 1024) / (lds > 0 ? lds : 1));
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu > 16) per_cu = 16; // 32 waves/CU cap; leave room for registers
+  S->blocks_per_cu = per_cu;
+  HIP_TRY(hipMalloc(&S->d_it, sizeof(int) * c->prog.itab.size()));
+  HIP_TRY(hipMalloc(&S->d_dt, sizeof(double) * c->prog.dtab.size()));
+  HIP_TRY(hipMemcpy(S->d_it, c->prog.itab.data(), sizeof(int) * c->prog.itab.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(S->d_dt, c->prog.dtab.data(), sizeof(double) * c->prog.dtab.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipStreamCreate(&S->stream));
+  c->dev = S;
+  c->finalized = true;
+  if (out) *out = c->layout;
+  return QPC_OK;
+}
+
+void qpc_controller_destroy(qpc_controller *c) {
+  if (!c) return;
+  if (c->dev) {
+    QpcDeviceState *S = c->dev;
+    (void)hipSetDevice(S->device);
+    if (S->stream) (void)hipStreamSynchronize(S->stream);
+    for (auto &p : S->events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    for (auto &e : S->pool) (void)hipEventDestroy(e);
+    if (S->d_it) (void)hipFree(S->d_it);
+    if (S->d_dt) (void)hipFree(S->d_dt);
+    if (S->stage) (void)hipFree(S->stage);
+    if (S->stream) (void)hipStreamDestroy(S->stream);
+    delete S;
+  }
+  delete c;
+}
+
+int32_t qpc_control_batch_device(qpc_controller *c, int64_t B, const double *q, const double *v,
+                                 const double *desired, const double *cw, const double *cmax, const double *tw,
+                                 const double *surf, double *tau, double *vdot, double *cwrench, int32_t *status,
+                                 int32_t *iters, void *hip_stream) {
+  if (!c || !c->finalized || !c->dev) { qpc_set_error("controller not finalized"); return QPC_ERR_NOT_FINALIZED; }
+  const QpcDims &D = c->prog.dims;
+  if (B < 0 || !q || !v || !tau || !vdot || !status || (D.n_desired && !desired) || (D.nc && (!cw || !cmax)) ||
+      (D.n_tw && !tw) || (D.n_surf && !surf)) {
+    qpc_set_error("qpc_control_batch_device: missing array"); return QPC_ERR_INVALID_ARGUMENT;
+  }
+  QpcBatchArgs a;
+  a.B = B; a.q = q; a.v = v; a.desired = desired; a.cw = cw; a.cmax = cmax; a.tw = tw; a.surf = surf;
+  a.tau = tau; a.vdot = vdot; a.cwrench = cwrench; a.status = status; a.iters = iters;
+  HIP_TRY(hipSetDevice(c->dev->device));
+  return launch(c, a, (hipStream_t)hip_stream);
+}
+
+int32_t qpc_control_batch(qpc_controller *c, int64_t B, const double *q, const double *v, const double *desired,
+                          const double *cw, const double *cmax, const double *tw, const double *surf, double *tau,
+                          double *vdot, double *cwrench, int32_t *status, int32_t *iters) {
+  if (!c || !c->finalized || !c->dev) { qpc_set_error("controller not finalized"); return QPC_ERR_NOT_FINALIZED; }
+  const QpcDims &D = c->prog.dims;
+  QpcDeviceState *S = c->dev;
+  if (B < 0 || !q || !v || !tau || !vdot || !status || (D.n_desired && !desired) || (D.nc && (!cw || !cmax)) ||
+      (D.n_tw && !tw) || (D.n_surf && !surf)) {
+    qpc_set_error("qpc_control_batch: missing array"); return QPC_ERR_INVALID_ARGUMENT;
+  }
+  if (B == 0) return QPC_OK;
+  HIP_TRY(hipSetDevice(S->device));
+  // one staging slab: [q v desired cw cmax tw surf | tau vdot cwrench | status iters]
+  size_t nin[7] = {(size_t)D.nq, (size_t)D.nv, (size_t)D.n_desired, (size_t)D.nc, (size_t)D.nc, (size_t)D.n_tw, (size_t)D.n_surf};
+  const double *hin[7] = {q, v, desired, cw, cmax, tw, surf};
+  size_t nout[3] = {(size_t)D.nv, (size_t)D.nv, (size_t)6 * D.nc};
+  double *hout[3] = {tau, vdot, cwrench};
+  size_t total = 0;
+  for (int i = 0; i < 7; i++) total += nin[i] * B * sizeof(double);
+  for (int i = 0; i < 3; i++) total += nout[i] * B * sizeof(double);
+  total += 2 * B * sizeof(int32_t) + 64;
+  if (total > S->stage_bytes) {
+    if (S->stage) HIP_TRY(hipFree(S->stage));
+    S->stage = nullptr; S->stage_bytes = 0;
+    HIP_TRY(hipMalloc(&S->stage, total));
+    S->stage_bytes = total;
+  }
+  char *p = (char *)S->stage;
+  const double *din[7];
+  for (int i = 0; i < 7; i++) {
+    din[i] = (const double *)p;
+    size_t bytes = nin[i] * B * sizeof(double);
+    if (bytes) HIP_TRY(hipMemcpyAsync(p, hin[i], bytes, hipMemcpyHostToDevice, S->stream));
+    p += bytes;
+  }
+  double *dout[3];
+  for (int i = 0; i < 3; i++) { dout[i] = (double *)p; p += nout[i] * B * sizeof(double); }
+  int32_t *dstatus = (int32_t *)p; p += B * sizeof(int32_t);
+  int32_t *diters = (int32_t *)p;
+  QpcBatchArgs a;
+  a.B = B; a.q = din[0]; a.v = din[1]; a.desired = din[2]; a.cw = din[3]; a.cmax = din[4]; a.tw = din[5]; a.surf = din[6];
+  a.tau = dout[0]; a.vdot = dout[1]; a.cwrench = D.nc ? dout[2] : nullptr; a.status = dstatus; a.iters = diters;
+  int rc = launch(c, a, S->stream);
+  if (rc != QPC_OK) return rc;
+  for (int i = 0; i < 3; i++) {
+    size_t bytes = nout[i] * B * sizeof(double);
+    if (bytes && hout[i]) HIP_TRY(hipMemcpyAsync(hout[i], dout[i], bytes, hipMemcpyDeviceToHost, S->stream));
+  }
+  HIP_TRY(hipMemcpyAsync(status, dstatus, B * sizeof(int32_t), hipMemcpyDeviceToHost, S->stream));
+  if (iters) HIP_TRY(hipMemcpyAsync(iters, diters, B * sizeof(int32_t), hipMemcpyDeviceToHost, S->stream));
+  HIP_TRY(hipStreamSynchronize(S->stream));
+  return QPC_OK;
+}
+
+int32_t qpc_qp_solve_batch(int32_t n, int32_t m, int64_t B, const double *P, const double *q, const double *A,
+                           const double *l, const double *u, const qpc_settings *settings, int32_t device_id,
+                           double *x, double *y, int32_t *status, int32_t *iters) {
+  (void)n; (void)m; (void)B; (void)P; (void)q; (void)A; (void)l; (void)u; (void)settings; (void)device_id;
+  (void)x; (void)y; (void)status; (void)iters;
+  qpc_set_error("qpc_qp_solve_batch (L0 raw dense QPs) is not implemented in this round; use qpc_control_batch");
+  return QPC_ERR_UNSUPPORTED;
+}
+
+int32_t qpc_timing_enable(qpc_controller *c, int32_t enable) {
+  if (!c || !c->dev) return QPC_ERR_NOT_FINALIZED;
+  c->dev->timing = enable != 0;
+  return QPC_OK;
+}
+
+int32_t qpc_timing_read(qpc_controller *c, double *avg_ms, int64_t *n_launches) {
+  if (!c || !c->dev) return QPC_ERR_NOT_FINALIZED;
+  QpcDeviceState *S = c->dev;
+  HIP_TRY(hipSetDevice(S->device));
+  double sum = 0.0;
+  long long n = 0;
+  for (auto &p : S->events) {
+    HIP_TRY(hipEventSynchronize(p.second));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, p.first, p.second));
+    sum += ms; n++;
+    S->pool.push_back(p.first); S->pool.push_back(p.second);
+  }
+  S->events.clear();
+  if (avg_ms) *avg_ms = n ? sum / n : 0.0;
+  if (n_launches) *n_launches = n;
+  return QPC_OK;
+}
+
+} // extern "C"

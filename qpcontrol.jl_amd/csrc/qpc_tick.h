@@ -1,0 +1,1087 @@
+// qpc_tick.h -- one MomentumBasedController tick for ONE robot state on ONE wavefront (64 lanes),
+// every matrix of the QP resident in LDS.  This is the device code of the product; it is written
+// as a sequence of PHASES (a block of per-lane code followed by a wave barrier) with all
+// cross-lane communication through LDS, so that the very same source also compiles as a
+// lane-serial CPU emulation with an LDS race detector (tests/emul/) -- the GPU box is minutes
+// away, the emulator is not.
+//
+// The includer defines before including this file:
+//   QPC_FN                    function qualifier (__device__ __forceinline__ / inline)
+//   QPC_PHASE(lane) ... QPC_END_PHASE   per-lane block + barrier
+//   QPC_SINCOS(x, s, c), QPC_SQRT(x), QPC_FABS(x)
+// and instantiates qpc_tick<P> with P = LDS pointer type (double* on the device).
+//
+// Replaces, per reference function:
+//   a2  copyto!(state,x) + RBD cache sweeps          -> phases "kinematics"
+//   a3-a8 task_error of the 7 task types (src/tasks.jl) -> phases "assembly"
+//   a9-a10 ContactPoint / objectiveterm (contacts.jl) -> phase "contacts"
+//   a11 add_wrench_balance_constraint! (momentum.jl:162-193) -> wrench rows of the assembly
+//   a12 addtask!/regularize! objective (momentum.jl:99-131)  -> Hv / W blocks
+//   a13 Parametron.solve! -> OSQP (momentum.jl:58)    -> reduced range-space active-set solve
+//   a14 checkstatus (momentum.jl:83-91)               -> status code
+//   a15 solution extraction (momentum.jl:62-72)       -> vdot, contact wrenches
+//   a16-a17 inverse_dynamics! + zero_floating_joint_torques! (momentum.jl:75-78) -> "rnea"
+#pragma once
+#include "../../include/qpc.h"
+#include "qpc_program.h"
+
+namespace qpc {
+
+// ------------------------------------------------------------------------------------------
+// small dense helpers on registers
+// ------------------------------------------------------------------------------------------
+QPC_FN void cross3(const double *a, const double *b, double *c) {
+  double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  c[0] = x; c[1] = y; c[2] = z;
+}
+QPC_FN void mv3(const double *R, const double *x, double *y) {
+  double a = R[0] * x[0] + R[1] * x[1] + R[2] * x[2];
+  double b = R[3] * x[0] + R[4] * x[1] + R[5] * x[2];
+  double c = R[6] * x[0] + R[7] * x[1] + R[8] * x[2];
+  y[0] = a; y[1] = b; y[2] = c;
+}
+QPC_FN void mtv3(const double *R, const double *x, double *y) {
+  double a = R[0] * x[0] + R[3] * x[1] + R[6] * x[2];
+  double b = R[1] * x[0] + R[4] * x[1] + R[7] * x[2];
+  double c = R[2] * x[0] + R[5] * x[1] + R[8] * x[2];
+  y[0] = a; y[1] = b; y[2] = c;
+}
+QPC_FN void mm3(const double *A, const double *B, double *C) {
+  double T[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) T[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+#pragma unroll
+  for (int i = 0; i < 9; i++) C[i] = T[i];
+}
+// motion cross product ad(a) b
+QPC_FN void crm(const double *a, const double *b, double *c) {
+  double t1[3], t2[3], t3[3];
+  cross3(a, b, t1); cross3(a, b + 3, t2); cross3(a + 3, b, t3);
+  c[0] = t1[0]; c[1] = t1[1]; c[2] = t1[2];
+  c[3] = t2[0] + t3[0]; c[4] = t2[1] + t3[1]; c[5] = t2[2] + t3[2];
+}
+// force cross product (w,v) x* (k,l)
+QPC_FN void crf(const double *a, const double *f, double *c) {
+  double t1[3], t2[3], t3[3];
+  cross3(a, f, t1); cross3(a + 3, f + 3, t2); cross3(a, f + 3, t3);
+  c[0] = t1[0] + t2[0]; c[1] = t1[1] + t2[1]; c[2] = t1[2] + t2[2];
+  c[3] = t3[0]; c[4] = t3[1]; c[5] = t3[2];
+}
+// spatial inertia I = {m, h[3], J[6] = xx yy zz xy xz yz} times motion vector
+QPC_FN void inertia_mul(const double *I, const double *t, double *o) {
+  const double *h = I + 1, *J = I + 4, *w = t, *v = t + 3;
+  double hv[3], hw[3];
+  cross3(h, v, hv); cross3(h, w, hw);
+  o[0] = J[0] * w[0] + J[3] * w[1] + J[4] * w[2] + hv[0];
+  o[1] = J[3] * w[0] + J[1] * w[1] + J[5] * w[2] + hv[1];
+  o[2] = J[4] * w[0] + J[5] * w[1] + J[2] * w[2] + hv[2];
+  o[3] = I[0] * v[0] - hw[0]; o[4] = I[0] * v[1] - hw[1]; o[5] = I[0] * v[2] - hw[2];
+}
+// world -> frame (R,p) transform of a motion vector: w' = R^T w ; v' = R^T (v - p x w)
+QPC_FN void motion_to_frame(const double *H, const double *in, double *out) {
+  double pw[3], t[3];
+  cross3(H + 9, in, pw);
+  t[0] = in[3] - pw[0]; t[1] = in[4] - pw[1]; t[2] = in[5] - pw[2];
+  mtv3(H, in, out); mtv3(H, t, out + 3);
+}
+template <class P> QPC_FN void ld(P p, int n, double *out) { for (int i = 0; i < n; i++) out[i] = p[i]; }
+template <class P> QPC_FN void st(P p, int n, const double *in) { for (int i = 0; i < n; i++) p[i] = in[i]; }
+template <class P> QPC_FN void ldH(P sm, const QpcDims &D, int body, double *H) {
+  if (body < 0) { H[0] = 1; H[1] = 0; H[2] = 0; H[3] = 0; H[4] = 1; H[5] = 0; H[6] = 0; H[7] = 0; H[8] = 1; H[9] = 0; H[10] = 0; H[11] = 0; }
+  else ld(sm + D.lds[L_H] + 12 * body, 12, H);
+}
+template <class P> QPC_FN void ld6(P sm, int off, int body, double *x) {
+  if (body < 0) { for (int i = 0; i < 6; i++) x[i] = 0.0; }
+  else ld(sm + off + 6 * body, 6, x);
+}
+
+// uniform (all lanes identical) reductions over an LDS array, used OUTSIDE phases
+template <class P> QPC_FN double umax(P sm, int off, int n) {
+  double m = 0.0;
+  for (int i = 0; i < n; i++) { double a = sm[off + i]; m = a > m ? a : m; }
+  return m;
+}
+
+// in-place inverse of an SPD n x n matrix (row-major, leading dimension n) by ONE lane
+template <class P> QPC_FN void spd_inverse_inplace(P a, int n) {
+  // Gauss-Jordan without pivoting (SPD): after the sweep `a` holds the inverse
+  for (int k = 0; k < n; k++) {
+    double piv = 1.0 / a[k * n + k];
+    a[k * n + k] = 1.0;
+    for (int j = 0; j < n; j++) a[k * n + j] = a[k * n + j] * piv;
+    for (int i = 0; i < n; i++) {
+      if (i == k) continue;
+      double f = a[i * n + k];
+      a[i * n + k] = 0.0;
+      for (int j = 0; j < n; j++) a[i * n + j] = a[i * n + j] - f * a[k * n + j];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// per-QP global-memory records
+// ------------------------------------------------------------------------------------------
+struct TickIO {
+  const double *q, *v, *desired, *cw, *cmax, *tw, *surf;
+  double *tau, *vdot, *cwrench;
+  int32_t *status, *iters;
+};
+
+// ------------------------------------------------------------------------------------------
+// solver building blocks (each is a fixed sequence of phases; all lanes call them uniformly)
+// ------------------------------------------------------------------------------------------
+template <class P> struct Solver {
+  const QpcDims &D;
+  const int *IT;
+  const double *DT;
+  P sm;
+  bool use_rho;
+  QPC_FN Solver(const QpcDims &d, const int *it, const double *dt, P s) : D(d), IT(it), DT(dt), sm(s), use_rho(d.nrho > 0) {}
+
+  // Kr (block inverse of Hrho+eps on the free set), C22 = G Kr G', L22/S22I from B22 + C22
+  QPC_FN void refactor_rho() {
+    const int N = D.N, nc = D.nc, nrho = D.nrho, m1 = D.m1;
+    const double eps = sm[D.lds[L_MISC] + MS_EPS];
+    if (!use_rho && D.nw == 0) return;
+    QPC_PHASE(lane) {
+      if (use_rho)
+        for (int c = lane; c < nc; c += 64) {
+          P K = sm + D.lds[L_KR] + c * N * N;
+          for (int i = 0; i < N; i++)
+            for (int j = 0; j < N; j++) {
+              bool fi = sm[D.lds[L_WS] + c * N + i] == 0.0, fj = sm[D.lds[L_WS] + c * N + j] == 0.0;
+              double h = sm[D.lds[L_HR] + c * N * N + i * N + j];
+              K[i * N + j] = (fi && fj) ? h + (i == j ? eps : 0.0) : (i == j ? 1.0 : 0.0);
+            }
+          spd_inverse_inplace(K, N);
+          for (int i = 0; i < N; i++)
+            if (sm[D.lds[L_WS] + c * N + i] != 0.0) K[i * N + i] = 0.0;
+        }
+    } QPC_END_PHASE
+    QPC_PHASE(lane) {
+      if (use_rho)
+        for (int idx = lane; idx < nrho * 6; idx += 64) {
+          int j = idx / 6, b = idx % 6, c = j / N, jj = j % N;
+          double acc = 0.0;
+          for (int i = 0; i < N; i++) acc += sm[D.lds[L_KR] + c * N * N + jj * N + i] * sm[D.lds[L_G] + b * nrho + c * N + i];
+          sm[D.lds[L_Y] + j * 6 + b] = acc;
+        }
+    } QPC_END_PHASE
+    QPC_PHASE(lane) {
+      if (lane < 36) {
+        int a = lane / 6, b = lane % 6;
+        double acc = sm[D.lds[L_B22] + lane];
+        if (use_rho)
+          for (int j = 0; j < nrho; j++) acc += sm[D.lds[L_G] + a * nrho + j] * sm[D.lds[L_Y] + j * 6 + b];
+        sm[D.lds[L_C22] + lane] = acc; // S22 = B22 + G Kr G'
+      }
+    } QPC_END_PHASE
+    QPC_PHASE(lane) {
+      if (lane == 0) {
+        // 6x6 Cholesky with the infinite-pivot rule, then S22I = (L L')^-1 via L^-1
+        P Lm = sm + D.lds[L_L22];
+        P Sm = sm + D.lds[L_C22];
+        double invd[6];
+        for (int k = 0; k < 6; k++) {
+          double d = Sm[k * 6 + k];
+          for (int j = 0; j < k; j++) d -= Lm[k * 6 + j] * Lm[k * 6 + j];
+          double ref = sm[D.lds[L_SM] + (m1 + k) * D.ms + (m1 + k)] + (Sm[k * 6 + k] - sm[D.lds[L_B22] + k * 6 + k]);
+          bool ok = d > D.tau_pivot * (ref > 1e-300 ? ref : 1e-300);
+          double ld_ = ok ? QPC_SQRT(d) : 0.0;
+          invd[k] = ok ? 1.0 / ld_ : 0.0;
+          Lm[k * 6 + k] = ld_;
+          for (int i = k + 1; i < 6; i++) {
+            double t = Sm[i * 6 + k];
+            for (int j = 0; j < k; j++) t -= Lm[i * 6 + j] * Lm[k * 6 + j];
+            Lm[i * 6 + k] = t * invd[k];
+          }
+          for (int i = 0; i < k; i++) Lm[i * 6 + k] = 0.0;
+        }
+        // X = L^-1 (lower), stored temporarily in C22
+        for (int c = 0; c < 6; c++)
+          for (int r = 0; r < 6; r++) {
+            double t = (r == c) ? 1.0 : 0.0;
+            if (r < c) { Sm[r * 6 + c] = 0.0; continue; }
+            for (int j = c; j < r; j++) t -= Lm[r * 6 + j] * Sm[j * 6 + c];
+            Sm[r * 6 + c] = t * invd[r];
+          }
+        for (int a = 0; a < 6; a++)
+          for (int b = 0; b < 6; b++) {
+            double t = 0.0;
+            for (int k = (a > b ? a : b); k < 6; k++) t += Sm[k * 6 + a] * Sm[k * 6 + b];
+            sm[D.lds[L_S22I] + a * 6 + b] = t;
+          }
+      }
+    } QPC_END_PHASE
+  }
+
+  // lam = S^-1 t   (t in L_T1, result in `out`), using X = L11^-1, L21 (rows m1.. of L_SM), S22I
+  QPC_FN void solve_S(int out) {
+    const int m1 = D.m1, nw = D.nw;
+    QPC_PHASE(lane) {
+      for (int r = lane; r < m1; r += 64) {
+        double acc = 0.0;
+        for (int c = 0; c <= r; c++) acc += sm[D.lds[L_X] + r * D.m1s + c] * sm[D.lds[L_T1] + c];
+        sm[D.lds[L_T2] + r] = acc; // y1
+      }
+    } QPC_END_PHASE
+    if (nw) {
+      QPC_PHASE(lane) {
+        if (lane < 6) {
+          double acc = sm[D.lds[L_T1] + m1 + lane];
+          for (int j = 0; j < m1; j++) acc -= sm[D.lds[L_SM] + (m1 + lane) * D.ms + j] * sm[D.lds[L_T2] + j];
+          sm[D.lds[L_T2] + m1 + lane] = acc;
+        }
+      } QPC_END_PHASE
+      QPC_PHASE(lane) {
+        if (lane < 6) {
+          double acc = 0.0;
+          for (int b = 0; b < 6; b++) acc += sm[D.lds[L_S22I] + lane * 6 + b] * sm[D.lds[L_T2] + m1 + b];
+          sm[out + m1 + lane] = acc; // lam2
+        }
+      } QPC_END_PHASE
+      QPC_PHASE(lane) {
+        for (int r = lane; r < m1; r += 64) {
+          double acc = sm[D.lds[L_T2] + r];
+          for (int a = 0; a < 6; a++) acc -= sm[D.lds[L_SM] + (m1 + a) * D.ms + r] * sm[out + m1 + a];
+          sm[D.lds[L_T3] + r] = acc; // z1
+        }
+      } QPC_END_PHASE
+    } else {
+      QPC_PHASE(lane) {
+        for (int r = lane; r < m1; r += 64) sm[D.lds[L_T3] + r] = sm[D.lds[L_T2] + r];
+      } QPC_END_PHASE
+    }
+    QPC_PHASE(lane) {
+      for (int r = lane; r < m1; r += 64) {
+        double acc = 0.0;
+        for (int c = r; c < m1; c++) acc += sm[D.lds[L_X] + c * D.m1s + r] * sm[D.lds[L_T3] + c];
+        sm[out + r] = acc;
+      }
+    } QPC_END_PHASE
+  }
+
+  // [H+eps, E'; E, 0] [dx; dl] = [r1; r_c] on the free set. rhs in L_RV/L_RE/L_RR/L_RC,
+  // result in L_DV (scaled: dx_v / sqh), L_DE, L_DR, L_DL.
+  QPC_FN void kkt_solve() {
+    const int N = D.N, nf = D.nf, ne = D.ne, nrho = D.nrho, m = D.m, m1 = D.m1;
+    QPC_PHASE(lane) {
+      if (use_rho)
+        for (int j = lane; j < nrho; j += 64) {
+          int c = j / N, jj = j % N;
+          double acc = 0.0;
+          for (int i = 0; i < N; i++) acc += sm[D.lds[L_KR] + c * N * N + jj * N + i] * sm[D.lds[L_RR] + c * N + i];
+          sm[D.lds[L_TR1] + j] = acc;
+        }
+      for (int s = lane; s < ne; s += 64) {
+        int t = IT[D.it[IT_SLACK_TASK] + s], a = IT[D.it[IT_SLACK_COMP] + s];
+        int d = IT[D.it[IT_T_DIM] + t], w0 = IT[D.it[IT_T_WOFF] + t], s0 = IT[D.it[IT_T_SLACK0] + t];
+        double acc = 0.0;
+        for (int b = 0; b < d; b++) acc += sm[D.lds[L_WINV] + w0 + a * d + b] * sm[D.lds[L_RE] + s0 + b];
+        sm[D.lds[L_TE1] + s] = acc;
+      }
+    } QPC_END_PHASE
+    QPC_PHASE(lane) {
+      for (int r = lane; r < m; r += 64) {
+        double acc = -sm[D.lds[L_RC] + r];
+        for (int f = 0; f < nf; f++) acc += sm[D.lds[L_M] + r * D.nfs + f] * (sm[D.lds[L_SQH] + f] * sm[D.lds[L_RV] + f]);
+        int t = IT[D.it[IT_ROW_TASK] + r];
+        if (t >= 0) {
+          int s0 = IT[D.it[IT_T_SLACK0] + t];
+          if (s0 >= 0) acc -= sm[D.lds[L_TE1] + s0 + IT[D.it[IT_ROW_COMP] + r]];
+        } else if (use_rho) {
+          int a = r - m1;
+          for (int j = 0; j < nrho; j++) acc -= sm[D.lds[L_G] + a * nrho + j] * sm[D.lds[L_TR1] + j];
+        }
+        sm[D.lds[L_T1] + r] = acc;
+      }
+    } QPC_END_PHASE
+    solve_S(D.lds[L_DL]);
+    QPC_PHASE(lane) {
+      for (int f = lane; f < nf; f += 64) {
+        double acc = sm[D.lds[L_SQH] + f] * sm[D.lds[L_RV] + f];
+        for (int r = 0; r < m; r++) acc -= sm[D.lds[L_M] + r * D.nfs + f] * sm[D.lds[L_DL] + r];
+        sm[D.lds[L_DV] + f] = acc;
+      }
+      for (int s = lane; s < ne; s += 64) {
+        int t = IT[D.it[IT_SLACK_TASK] + s], a = IT[D.it[IT_SLACK_COMP] + s];
+        sm[D.lds[L_TE1] + s] = sm[D.lds[L_RE] + s] + sm[D.lds[L_DL] + IT[D.it[IT_T_ROW0] + t] + a];
+      }
+      if (use_rho)
+        for (int j = lane; j < nrho; j += 64) {
+          double acc = sm[D.lds[L_RR] + j];
+          for (int a = 0; a < 6; a++) acc += sm[D.lds[L_G] + a * nrho + j] * sm[D.lds[L_DL] + m1 + a];
+          sm[D.lds[L_TR2] + j] = acc;
+        }
+    } QPC_END_PHASE
+    QPC_PHASE(lane) {
+      for (int s = lane; s < ne; s += 64) {
+        int t = IT[D.it[IT_SLACK_TASK] + s], a = IT[D.it[IT_SLACK_COMP] + s];
+        int d = IT[D.it[IT_T_DIM] + t], w0 = IT[D.it[IT_T_WOFF] + t], s0 = IT[D.it[IT_T_SLACK0] + t];
+        double acc = 0.0;
+        for (int b = 0; b < d; b++) acc += sm[D.lds[L_WINV] + w0 + a * d + b] * sm[D.lds[L_TE1] + s0 + b];
+        sm[D.lds[L_DE] + s] = acc;
+      }
+      if (use_rho)
+        for (int j = lane; j < nrho; j += 64) {
+          int c = j / N, jj = j % N;
+          double acc = 0.0;
+          for (int i = 0; i < N; i++) acc += sm[D.lds[L_KR] + c * N * N + jj * N + i] * sm[D.lds[L_TR2] + c * N + i];
+          sm[D.lds[L_DR] + j] = acc;
+        }
+    } QPC_END_PHASE
+  }
+
+  // true (unregularised) KKT residuals of the EQP on the working set -> L_RV/L_RE/L_RR/L_RC;
+  // Lagrangian gradient w.r.t. rho -> L_TR1
+  QPC_FN void residuals() {
+    const int N = D.N, nf = D.nf, ne = D.ne, nrho = D.nrho, m = D.m, m1 = D.m1;
+    QPC_PHASE(lane) {
+      for (int r = lane; r < m; r += 64) {
+        double acc = sm[D.lds[L_D] + r];
+        for (int f = 0; f < nf; f++) acc -= sm[D.lds[L_M] + r * D.nfs + f] * sm[D.lds[L_XV] + f];
+        int t = IT[D.it[IT_ROW_TASK] + r];
+        if (t >= 0) {
+          int s0 = IT[D.it[IT_T_SLACK0] + t];
+          if (s0 >= 0) acc += sm[D.lds[L_XE] + s0 + IT[D.it[IT_ROW_COMP] + r]];
+        } else if (use_rho) {
+          int a = r - m1;
+          for (int j = 0; j < nrho; j++) acc += sm[D.lds[L_G] + a * nrho + j] * sm[D.lds[L_XR] + j];
+        }
+        sm[D.lds[L_RC] + r] = acc;
+      }
+      for (int f = lane; f < nf; f += 64) {
+        double mtl = 0.0;
+        for (int r = 0; r < m; r++) mtl += sm[D.lds[L_M] + r * D.nfs + f] * sm[D.lds[L_LAM] + r];
+        double sq = sm[D.lds[L_SQH] + f];
+        sm[D.lds[L_RV] + f] = -(sm[D.lds[L_HV] + f] * sq * sm[D.lds[L_XV] + f] + sm[D.lds[L_GV] + f] + mtl / sq);
+      }
+      for (int s = lane; s < ne; s += 64) {
+        int t = IT[D.it[IT_SLACK_TASK] + s], a = IT[D.it[IT_SLACK_COMP] + s];
+        int d = IT[D.it[IT_T_DIM] + t], w0 = IT[D.it[IT_T_WOFF] + t], s0 = IT[D.it[IT_T_SLACK0] + t];
+        double acc = 0.0;
+        for (int b = 0; b < d; b++) acc += sm[D.lds[L_W] + w0 + a * d + b] * sm[D.lds[L_XE] + s0 + b];
+        sm[D.lds[L_RE] + s] = -(acc - sm[D.lds[L_LAM] + IT[D.it[IT_T_ROW0] + t] + a]);
+      }
+      if (use_rho)
+        for (int j = lane; j < nrho; j += 64) {
+          int c = j / N, jj = j % N;
+          double gl = 0.0;
+          for (int i = 0; i < N; i++) gl += sm[D.lds[L_HR] + c * N * N + jj * N + i] * sm[D.lds[L_XR] + c * N + i];
+          for (int a = 0; a < 6; a++) gl -= sm[D.lds[L_G] + a * nrho + j] * sm[D.lds[L_LAM] + m1 + a];
+          sm[D.lds[L_TR1] + j] = gl;
+          sm[D.lds[L_RR] + j] = (sm[D.lds[L_WS] + j] == 0.0) ? -gl : 0.0;
+        }
+    } QPC_END_PHASE
+  }
+
+  // EQP of the current working set from scratch + `refine` iterative-refinement sweeps
+  QPC_FN int eqp(int refine) {
+    const int nf = D.nf, ne = D.ne, nrho = D.nrho, m = D.m;
+    QPC_PHASE(lane) {
+      for (int f = lane; f < nf; f += 64) sm[D.lds[L_XV] + f] = 0.0;
+      for (int s = lane; s < ne; s += 64) sm[D.lds[L_XE] + s] = 0.0;
+      for (int r = lane; r < m; r += 64) sm[D.lds[L_LAM] + r] = 0.0;
+      for (int j = lane; j < nrho; j += 64) sm[D.lds[L_XR] + j] = (sm[D.lds[L_WS] + j] == 1.0) ? sm[D.lds[L_HI] + j] : 0.0;
+    } QPC_END_PHASE
+    int it = 0;
+    for (;; it++) {
+      residuals();
+      kkt_solve();
+      QPC_PHASE(lane) {
+        double big = 0.0, dbig = 0.0;
+        for (int f = lane; f < nf; f += 64) {
+          double dx = sm[D.lds[L_DV] + f], x = sm[D.lds[L_XV] + f] + dx;
+          sm[D.lds[L_XV] + f] = x;
+          double sq = sm[D.lds[L_SQH] + f];
+          big = QPC_FABS(x * sq) > big ? QPC_FABS(x * sq) : big;
+          dbig = QPC_FABS(dx * sq) > dbig ? QPC_FABS(dx * sq) : dbig;
+        }
+        for (int s = lane; s < ne; s += 64) {
+          double dx = sm[D.lds[L_DE] + s], x = sm[D.lds[L_XE] + s] + dx;
+          sm[D.lds[L_XE] + s] = x;
+          big = QPC_FABS(x) > big ? QPC_FABS(x) : big;
+          dbig = QPC_FABS(dx) > dbig ? QPC_FABS(dx) : dbig;
+        }
+        for (int j = lane; j < nrho; j += 64) {
+          double dx = sm[D.lds[L_DR] + j], x = sm[D.lds[L_XR] + j] + dx;
+          sm[D.lds[L_XR] + j] = x;
+          big = QPC_FABS(x) > big ? QPC_FABS(x) : big;
+          dbig = QPC_FABS(dx) > dbig ? QPC_FABS(dx) : dbig;
+        }
+        for (int r = lane; r < m; r += 64) sm[D.lds[L_LAM] + r] = sm[D.lds[L_LAM] + r] + sm[D.lds[L_DL] + r];
+        sm[D.lds[L_RED] + lane] = big;
+        sm[D.lds[L_RED] + 64 + lane] = dbig;
+      } QPC_END_PHASE
+      if (it >= refine) break;
+      double big = umax(sm, D.lds[L_RED], 64), dbig = umax(sm, D.lds[L_RED] + 64, 64);
+      if (it > 0 && !(dbig > 1e-13 * (1.0 + big))) break;
+    }
+    return it;
+  }
+
+  // multipliers of the bound constraints from the rho-gradient in L_TR1 (residuals() just ran)
+  // -> L_U ; partial maxima for gscale / xr scale -> L_RED
+  QPC_FN void multipliers() {
+    const int nrho = D.nrho;
+    QPC_PHASE(lane) {
+      double g = 0.0, x = 0.0;
+      for (int j = lane; j < nrho; j += 64) {
+        double gl = sm[D.lds[L_TR1] + j], w = sm[D.lds[L_WS] + j];
+        sm[D.lds[L_U] + j] = (w == -1.0) ? gl : ((w == 1.0) ? -gl : 0.0);
+        g = QPC_FABS(gl) > g ? QPC_FABS(gl) : g;
+        double xr = QPC_FABS(sm[D.lds[L_XR] + j]);
+        x = xr > x ? xr : x;
+      }
+      sm[D.lds[L_RED] + lane] = g;
+      sm[D.lds[L_RED] + 64 + lane] = x;
+    } QPC_END_PHASE
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// the tick
+// ------------------------------------------------------------------------------------------
+template <class P>
+QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, const TickIO &io) {
+  const int nb = D.nb, nq = D.nq, nv = D.nv, nf = D.nf, nc = D.nc, N = D.N, nrho = D.nrho, ne = D.ne;
+  const int m = D.m, m1 = D.m1, nw = D.nw, ntask = D.ntask;
+  const int MISC = D.lds[L_MISC];
+  const bool use_rho = nrho > 0;
+  const int *parent = IT + D.it[IT_PARENT];
+  const int *anc_ptr = IT + D.it[IT_ANC_PTR], *anc_idx = IT + D.it[IT_ANC_IDX];
+  const int *desc_ptr = IT + D.it[IT_DESC_PTR], *desc_idx = IT + D.it[IT_DESC_IDX];
+  (void)parent;
+
+  // ======================================================================== inputs -> LDS
+  QPC_PHASE(lane) {
+    for (int i = lane; i < nq; i += 64) sm[D.lds[L_Q] + i] = io.q[i];
+    for (int i = lane; i < nv; i += 64) { sm[D.lds[L_V] + i] = io.v[i]; sm[D.lds[L_VD] + i] = 0.0; }
+    for (int i = lane; i < D.n_desired; i += 64) sm[D.lds[L_DES] + i] = io.desired[i];
+    for (int i = lane; i < nc; i += 64) { sm[D.lds[L_CW] + i] = io.cw[i]; sm[D.lds[L_CMAX] + i] = io.cmax[i]; }
+    for (int i = lane; i < D.n_tw; i += 64) sm[D.lds[L_TW] + i] = io.tw[i];
+    for (int i = lane; i < D.n_surf; i += 64) sm[D.lds[L_SURF] + i] = io.surf[i];
+  } QPC_END_PHASE
+
+  // ======================================================================== kinematics (a2)
+  QPC_PHASE(lane) { // joint transforms: x_parent = Rf (Rj x + pj) + pf
+    for (int i = lane; i < nb; i += 64) {
+      int jt = IT[D.it[IT_JTYPE] + i], q0 = IT[D.it[IT_QOFF] + i];
+      const double *ax = DT + D.dt[DT_AXIS] + 3 * i, *Rf = DT + D.dt[DT_RF] + 9 * i, *pf = DT + D.dt[DT_PF] + 3 * i;
+      double Rj[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pj[3] = {0, 0, 0};
+      if (jt == QPC_JOINT_REVOLUTE) {
+        double s, c;
+        QPC_SINCOS(sm[D.lds[L_Q] + q0], s, c);
+        double C = 1 - c;
+        Rj[0] = c + ax[0] * ax[0] * C; Rj[1] = ax[0] * ax[1] * C - ax[2] * s; Rj[2] = ax[0] * ax[2] * C + ax[1] * s;
+        Rj[3] = ax[1] * ax[0] * C + ax[2] * s; Rj[4] = c + ax[1] * ax[1] * C; Rj[5] = ax[1] * ax[2] * C - ax[0] * s;
+        Rj[6] = ax[2] * ax[0] * C - ax[1] * s; Rj[7] = ax[2] * ax[1] * C + ax[0] * s; Rj[8] = c + ax[2] * ax[2] * C;
+      } else if (jt == QPC_JOINT_PRISMATIC) {
+        double qq = sm[D.lds[L_Q] + q0];
+        pj[0] = ax[0] * qq; pj[1] = ax[1] * qq; pj[2] = ax[2] * qq;
+      } else if (jt == QPC_JOINT_QUAT_FLOATING) {
+        double w = sm[D.lds[L_Q] + q0], x = sm[D.lds[L_Q] + q0 + 1], y = sm[D.lds[L_Q] + q0 + 2], z = sm[D.lds[L_Q] + q0 + 3];
+        Rj[0] = 1 - 2 * (y * y + z * z); Rj[1] = 2 * (x * y - w * z); Rj[2] = 2 * (x * z + w * y);
+        Rj[3] = 2 * (x * y + w * z); Rj[4] = 1 - 2 * (x * x + z * z); Rj[5] = 2 * (y * z - w * x);
+        Rj[6] = 2 * (x * z - w * y); Rj[7] = 2 * (y * z + w * x); Rj[8] = 1 - 2 * (x * x + y * y);
+        pj[0] = sm[D.lds[L_Q] + q0 + 4]; pj[1] = sm[D.lds[L_Q] + q0 + 5]; pj[2] = sm[D.lds[L_Q] + q0 + 6];
+      }
+      double H[12];
+      mm3(Rf, Rj, H);
+      mv3(Rf, pj, H + 9);
+      H[9] += pf[0]; H[10] += pf[1]; H[11] += pf[2];
+      st(sm + D.lds[L_RL] + 12 * i, 12, H);
+    }
+  } QPC_END_PHASE
+  QPC_PHASE(lane) { // transform_to_root by walking the ancestor chain
+    for (int i = lane; i < nb; i += 64) {
+      double H[12], A[12], t[3];
+      ld(sm + D.lds[L_RL] + 12 * i, 12, H);
+      for (int e = anc_ptr[i]; e < anc_ptr[i + 1]; e++) {
+        ld(sm + D.lds[L_RL] + 12 * anc_idx[e], 12, A);
+        mv3(A, H + 9, t);
+        mm3(A, H, H);
+        H[9] = t[0] + A[9]; H[10] = t[1] + A[10]; H[11] = t[2] + A[11];
+      }
+      st(sm + D.lds[L_H] + 12 * i, 12, H);
+    }
+  } QPC_END_PHASE
+  QPC_PHASE(lane) { // motion subspaces in world; body inertias in world about the world origin
+    for (int k = lane; k < nv; k += 64) {
+      int b = IT[D.it[IT_VBODY] + k], c = IT[D.it[IT_VCOMP] + k], jt = IT[D.it[IT_JTYPE] + b];
+      double H[12], S[6] = {0, 0, 0, 0, 0, 0};
+      ld(sm + D.lds[L_H] + 12 * b, 12, H);
+      const double *ax = DT + D.dt[DT_AXIS] + 3 * b;
+      if (jt == QPC_JOINT_REVOLUTE) { mv3(H, ax, S); cross3(H + 9, S, S + 3); }
+      else if (jt == QPC_JOINT_PRISMATIC) { mv3(H, ax, S + 3); }
+      else { // quaternion floating: columns of Ad(H)
+        int cc = c % 3;
+        double col[3] = {H[cc], H[3 + cc], H[6 + cc]};
+        if (c < 3) { S[0] = col[0]; S[1] = col[1]; S[2] = col[2]; cross3(H + 9, col, S + 3); }
+        else { S[3] = col[0]; S[4] = col[1]; S[5] = col[2]; }
+      }
+      st(sm + D.lds[L_S] + 6 * k, 6, S);
+    }
+    for (int i = lane; i < nb; i += 64) {
+      double H[12], cw[3];
+      ld(sm + D.lds[L_H] + 12 * i, 12, H);
+      const double *I = DT + D.dt[DT_ICOM] + 6 * i;
+      mv3(H, DT + D.dt[DT_COM] + 3 * i, cw);
+      cw[0] += H[9]; cw[1] += H[10]; cw[2] += H[11];
+      double Ib[9] = {I[0], I[3], I[4], I[3], I[1], I[5], I[4], I[5], I[2]}, RI[9], Rt[9], Iw[9];
+      for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) Rt[3 * a + b] = H[3 * b + a];
+      mm3(H, Ib, RI);
+      mm3(RI, Rt, Iw);
+      double mm = DT[D.dt[DT_MASS] + i], cc = cw[0] * cw[0] + cw[1] * cw[1] + cw[2] * cw[2];
+      double o[10] = {mm, mm * cw[0], mm * cw[1], mm * cw[2],
+                      Iw[0] + mm * (cc - cw[0] * cw[0]), Iw[4] + mm * (cc - cw[1] * cw[1]), Iw[8] + mm * (cc - cw[2] * cw[2]),
+                      Iw[1] - mm * cw[0] * cw[1], Iw[2] - mm * cw[0] * cw[2], Iw[5] - mm * cw[1] * cw[2]};
+      st(sm + D.lds[L_IW] + 10 * i, 10, o);
+    }
+  } QPC_END_PHASE
+  QPC_PHASE(lane) { // joint twists S_j v_j
+    for (int i = lane; i < nb; i += 64) {
+      double tj[6] = {0, 0, 0, 0, 0, 0};
+      int v0 = IT[D.it[IT_VOFF] + i], n = IT[D.it[IT_NVJ] + i];
+      for (int c = 0; c < n; c++) {
+        double vv = sm[D.lds[L_V] + v0 + c];
+        for (int a = 0; a < 6; a++) tj[a] += sm[D.lds[L_S] + 6 * (v0 + c) + a] * vv;
+      }
+      st(sm + D.lds[L_TJ] + 6 * i, 6, tj);
+    }
+  } QPC_END_PHASE
+  QPC_PHASE(lane) { // twist_wrt_world (chain sum) and the bias increment T_i x (S_j v_j)
+    for (int i = lane; i < nb; i += 64) {
+      double T[6], tj[6], cr[6];
+      ld(sm + D.lds[L_TJ] + 6 * i, 6, tj);
+      for (int a = 0; a < 6; a++) T[a] = tj[a];
+      for (int e = anc_ptr[i]; e < anc_ptr[i + 1]; e++)
+        for (int a = 0; a < 6; a++) T[a] += sm[D.lds[L_TJ] + 6 * anc_idx[e] + a];
+      crm(T, tj, cr);
+      st(sm + D.lds[L_T] + 6 * i, 6, T);
+      st(sm + D.lds[L_CR] + 6 * i, 6, cr);
+    }
+  } QPC_END_PHASE
+  QPC_PHASE(lane) { // bias_acceleration, composite inertias, per-body momentum-rate bias
+    for (int i = lane; i < nb; i += 64) {
+      double Ab[6], T[6], I[10], Ic[10], h[6], ia[6], cf[6];
+      ld(sm + D.lds[L_CR] + 6 * i, 6, Ab);
+      for (int e = anc_ptr[i]; e < anc_ptr[i + 1]; e++)
+        for (int a = 0; a < 6; a++) Ab[a] += sm[D.lds[L_CR] + 6 * anc_idx[e] + a];
+      st(sm + D.lds[L_AB] + 6 * i, 6, Ab);
+      for (int a = 0; a < 10; a++) Ic[a] = 0.0;
+      for (int e = desc_ptr[i]; e < desc_ptr[i + 1]; e++)
+        for (int a = 0; a < 10; a++) Ic[a] += sm[D.lds[L_IW] + 10 * desc_idx[e] + a];
+      st(sm + D.lds[L_IC] + 10 * i, 10, Ic);
+      ld(sm + D.lds[L_IW] + 10 * i, 10, I);
+      ld(sm + D.lds[L_T] + 6 * i, 6, T);
+      inertia_mul(I, T, h);
+      inertia_mul(I, Ab, ia);
+      crf(T, h, cf);
+      for (int a = 0; a < 6; a++) { h[a] = cf[a]; ia[a] += cf[a]; }
+      st(sm + D.lds[L_HB] + 6 * i, 6, ia); // I Ab + T x* I T
+      st(sm + D.lds[L_F] + 6 * i, 6, h);   // T x* I T alone (velocity-product wrench for RNEA)
+    }
+  } QPC_END_PHASE
+  QPC_PHASE(lane) { // momentum matrix, CoM, momentum-rate bias, pinned accelerations, Hessian diag
+    for (int k = lane; k < nv; k += 64) {
+      double Ic[10], S[6], h[6];
+      ld(sm + D.lds[L_IC] + 10 * IT[D.it[IT_VBODY] + k], 10, Ic);
+      ld(sm + D.lds[L_S] + 6 * k, 6, S);
+      inertia_mul(Ic, S, h);
+      for (int a = 0; a < 6; a++) sm[D.lds[L_AMOM] + a * nv + k] = h[a];
+    }
+    if (lane < 3) {
+      double acc = 0.0;
+      for (int i = 0; i < nb; i++) acc += sm[D.lds[L_IW] + 10 * i + 1 + lane];
+      sm[MISC + MS_COM + lane] = acc / DT[D.dt[DT_GRAV] + 3];
+    } else if (lane < 9) {
+      double acc = 0.0;
+      for (int i = 0; i < nb; i++) acc += sm[D.lds[L_HB] + 6 * i + (lane - 3)];
+      sm[MISC + MS_ADV + (lane - 3)] = acc;
+    }
+    for (int p = lane; p < D.npin; p += 64)
+      sm[D.lds[L_VD] + IT[D.it[IT_PIN_K] + p]] = sm[D.lds[L_DES] + IT[D.it[IT_PIN_DES] + p]];
+    for (int f = lane; f < nf; f += 64) { // Hv = 2 reg + folded soft joint tasks (a12)
+      double hv = DT[D.dt[DT_REG2] + IT[D.it[IT_FREE_K] + f]], gv = 0.0;
+      for (int s = 0; s < D.nsj; s++)
+        if (IT[D.it[IT_SJ_F] + s] == f) {
+          int twi = IT[D.it[IT_SJ_TW] + s];
+          double w = twi >= 0 ? sm[D.lds[L_TW] + twi] : DT[D.dt[DT_SJ_W] + s];
+          hv += 2.0 * w;
+          gv -= 2.0 * w * sm[D.lds[L_DES] + IT[D.it[IT_SJ_DES] + s]];
+        }
+      sm[D.lds[L_HV] + f] = hv;
+      sm[D.lds[L_GV] + f] = gv;
+    }
+    for (int t = 0; t < ntask; t++) { // slack Hessian blocks 2*sym(W)
+      int w0 = IT[D.it[IT_T_WOFF] + t];
+      if (w0 < 0) continue;
+      int d = IT[D.it[IT_T_DIM] + t], wk = IT[D.it[IT_T_WKIND] + t], tw0 = IT[D.it[IT_T_TW] + t];
+      for (int e = lane; e < d * d; e += 64) {
+        int a = e / d, b = e % d;
+        double w;
+        if (wk == QPC_WEIGHT_SCALAR_PER_QP) w = (a == b) ? 2.0 * sm[D.lds[L_TW] + tw0] : 0.0;
+        else if (wk == QPC_WEIGHT_MATRIX_PER_QP) w = sm[D.lds[L_TW] + tw0 + a * d + b] + sm[D.lds[L_TW] + tw0 + b * d + a];
+        else w = DT[D.dt[DT_T_W] + w0 + e];
+        sm[D.lds[L_W] + w0 + e] = w;
+      }
+    }
+  } QPC_END_PHASE
+
+  // regularisation scale (uniform): eps = eps_primal * max diagonal of the Hessian
+  double hscale = 0.0;
+  for (int f = 0; f < nf; f++) { double a = QPC_FABS(sm[D.lds[L_HV] + f]); hscale = a > hscale ? a : hscale; }
+  for (int t = 0; t < ntask; t++) {
+    int w0 = IT[D.it[IT_T_WOFF] + t];
+    if (w0 < 0) continue;
+    int d = IT[D.it[IT_T_DIM] + t];
+    for (int a = 0; a < d; a++) { double w = QPC_FABS(sm[D.lds[L_W] + w0 + a * d + a]); hscale = w > hscale ? w : hscale; }
+  }
+  if (use_rho)
+    for (int c = 0; c < nc; c++) {
+      double w = (sm[D.lds[L_CMAX] + c] > 0.0) ? 2.0 * QPC_FABS(sm[D.lds[L_CW] + c]) : 0.0;
+      hscale = w > hscale ? w : hscale;
+    }
+  if (!(hscale > 0.0)) hscale = 1.0;
+  const double eps = D.eps_primal * hscale;
+
+  // ======================================================================== assembly (a3-a12)
+  QPC_PHASE(lane) {
+    if (lane == 0) { sm[MISC + MS_EPS] = eps; sm[MISC + MS_HSCALE] = hscale; }
+    if (lane < 6 && nw) { // gravity wrench about the world origin (momentum.jl:166-170)
+      double fg[3], cxf[3], com[3] = {sm[MISC + MS_COM], sm[MISC + MS_COM + 1], sm[MISC + MS_COM + 2]};
+      double mt = DT[D.dt[DT_GRAV] + 3];
+      fg[0] = mt * DT[D.dt[DT_GRAV]]; fg[1] = mt * DT[D.dt[DT_GRAV] + 1]; fg[2] = mt * DT[D.dt[DT_GRAV] + 2];
+      cross3(com, fg, cxf);
+      sm[MISC + MS_WG + lane] = lane < 3 ? cxf[lane] : fg[lane - 3];
+    }
+    for (int f = lane; f < nf; f += 64) sm[D.lds[L_SQH] + f] = 1.0 / QPC_SQRT(sm[D.lds[L_HV] + f] + eps);
+    for (int t = lane; t < ntask; t += 64) { // (W + eps I)^-1 per soft generic task
+      int w0 = IT[D.it[IT_T_WOFF] + t];
+      if (w0 < 0) continue;
+      int d = IT[D.it[IT_T_DIM] + t];
+      for (int e = 0; e < d * d; e++) sm[D.lds[L_WINV] + w0 + e] = sm[D.lds[L_W] + w0 + e] + ((e / d == e % d) ? eps : 0.0);
+      spd_inverse_inplace(sm + D.lds[L_WINV] + w0, d);
+    }
+    // contribution of the pinned accelerations: world-frame spatial acceleration (path tasks) or
+    // world momentum rate (momentum tasks, wrench rows): sum_k sgn * S_k * vd_k
+    for (int idx = lane; idx < (ntask + 1) * 6; idx += 64) {
+      int t = idx / 6, a = idx % 6;
+      int kind = t < ntask ? IT[D.it[IT_T_KIND] + t] : QPC_TASK_MOMENTUM_RATE;
+      double acc = 0.0;
+      for (int p = 0; p < D.npin; p++) {
+        int k = IT[D.it[IT_PIN_K] + p];
+        double vd = sm[D.lds[L_VD] + k];
+        if (kind == QPC_TASK_MOMENTUM_RATE || kind == QPC_TASK_LINEAR_MOMENTUM_RATE) acc += sm[D.lds[L_AMOM] + a * nv + k] * vd;
+        else if (kind != QPC_TASK_JOINT_ACCELERATION) acc += IT[D.it[IT_T_SGN] + t * nv + k] * sm[D.lds[L_S] + 6 * k + a] * vd;
+      }
+      sm[D.lds[L_ACCP] + idx] = acc;
+    }
+  } QPC_END_PHASE
+
+  QPC_PHASE(lane) { // scaled constraint matrix M = E diag(sqh), right-hand side d
+    for (int idx = lane; idx < m * nf; idx += 64) {
+      int r = idx / nf, f = idx % nf, k = IT[D.it[IT_FREE_K] + f];
+      int t = IT[D.it[IT_ROW_TASK] + r], a = IT[D.it[IT_ROW_COMP] + r];
+      double val = 0.0;
+      if (t < 0) val = sm[D.lds[L_AMOM] + a * nv + k]; // wrench balance rows (a11), S dropped (invertible)
+      else {
+        int kind = IT[D.it[IT_T_KIND] + t], sg = IT[D.it[IT_T_SGN] + t * nv + k];
+        if (sg != 0) {
+          if (kind == QPC_TASK_JOINT_ACCELERATION) val = (IT[D.it[IT_VCOMP] + k] == a) ? 1.0 : 0.0;
+          else if (kind == QPC_TASK_MOMENTUM_RATE || kind == QPC_TASK_LINEAR_MOMENTUM_RATE) {
+            int aa = kind == QPC_TASK_LINEAR_MOMENTUM_RATE ? a + 3 : a;
+            val = sm[D.lds[L_AMOM] + aa * nv + k];
+            if (aa < 3) { // centroidal: ang - com x lin (src/tasks.jl:208-213)
+              double com[3] = {sm[MISC + MS_COM], sm[MISC + MS_COM + 1], sm[MISC + MS_COM + 2]};
+              double lin[3] = {sm[D.lds[L_AMOM] + 3 * nv + k], sm[D.lds[L_AMOM] + 4 * nv + k], sm[D.lds[L_AMOM] + 5 * nv + k]}, cx[3];
+              cross3(com, lin, cx);
+              val -= cx[aa];
+            }
+          } else {
+            double H[12], S[6], J[6];
+            int frame = IT[D.it[IT_T_FRAME] + t];
+            ldH(sm, D, frame, H);
+            ld(sm + D.lds[L_S] + 6 * k, 6, S);
+            motion_to_frame(H, S, J);
+            if (kind == QPC_TASK_SPATIAL_ACCELERATION || kind == QPC_TASK_ANGULAR_ACCELERATION) val = sg * J[a];
+            else if (kind == QPC_TASK_LINEAR_ACCELERATION) val = sg * J[3 + a];
+            else { // point jacobian J_lin - p^ J_ang in the base frame (src/tasks.jl:157-160)
+              double Ht[12], pw[3], d3[3], pF[3], px[3];
+              int target = IT[D.it[IT_T_TARGET] + t];
+              ldH(sm, D, target, Ht);
+              mv3(Ht, DT + D.dt[DT_T_POINT] + 3 * t, pw);
+              d3[0] = pw[0] + Ht[9] - H[9]; d3[1] = pw[1] + Ht[10] - H[10]; d3[2] = pw[2] + Ht[11] - H[11];
+              mtv3(H, d3, pF);
+              cross3(pF, J, px);
+              val = sg * (J[3 + a] - px[a]);
+            }
+          }
+        }
+      }
+      sm[D.lds[L_M] + r * D.nfs + f] = val * sm[D.lds[L_SQH] + f];
+    }
+    for (int r = lane; r < m; r += 64) {
+      int t = IT[D.it[IT_ROW_TASK] + r], a = IT[D.it[IT_ROW_COMP] + r];
+      double rhs;
+      if (t < 0) rhs = sm[MISC + MS_WG + a] - sm[MISC + MS_ADV + a] - sm[D.lds[L_ACCP] + ntask * 6 + a];
+      else {
+        int kind = IT[D.it[IT_T_KIND] + t];
+        double des = sm[D.lds[L_DES] + IT[D.it[IT_T_DES] + t] + a];
+        if (kind == QPC_TASK_JOINT_ACCELERATION) {
+          // generic joint rows (duplicate pin / matrix weight): pinned part moves to the rhs
+          double pinned = 0.0;
+          for (int k = 0; k < nv; k++)
+            if (IT[D.it[IT_T_SGN] + t * nv + k] != 0 && IT[D.it[IT_VCOMP] + k] == a && IT[D.it[IT_FREE_OF] + k] < 0) pinned = sm[D.lds[L_VD] + k];
+          rhs = des - pinned;
+        } else if (kind == QPC_TASK_MOMENTUM_RATE || kind == QPC_TASK_LINEAR_MOMENTUM_RATE) {
+          int aa = kind == QPC_TASK_LINEAR_MOMENTUM_RATE ? a + 3 : a;
+          double b = sm[MISC + MS_ADV + aa] + sm[D.lds[L_ACCP] + t * 6 + aa];
+          if (aa < 3) {
+            double com[3] = {sm[MISC + MS_COM], sm[MISC + MS_COM + 1], sm[MISC + MS_COM + 2]}, lin[3], cx[3];
+            for (int i = 0; i < 3; i++) lin[i] = sm[MISC + MS_ADV + 3 + i] + sm[D.lds[L_ACCP] + t * 6 + 3 + i];
+            cross3(com, lin, cx);
+            b -= cx[aa];
+          }
+          rhs = des - b;
+        } else {
+          // J̇v = transform(state, bias(target) - bias(base), frame) (src/tasks.jl:37-38) plus the
+          // acceleration produced by the pinned joints, all as ONE world-frame spatial acceleration
+          int base = IT[D.it[IT_T_BASE] + t], target = IT[D.it[IT_T_TARGET] + t], frame = IT[D.it[IT_T_FRAME] + t];
+          double At[6], Abs[6], Tt[6], Tb[6], Tf[6], trel[6], cr[6], aw[6], aF[6], H[12];
+          ld6(sm, D.lds[L_AB], target, At); ld6(sm, D.lds[L_AB], base, Abs);
+          ld6(sm, D.lds[L_T], target, Tt); ld6(sm, D.lds[L_T], base, Tb); ld6(sm, D.lds[L_T], frame, Tf);
+          for (int i = 0; i < 6; i++) trel[i] = Tt[i] - Tb[i];
+          crm(Tf, trel, cr);
+          for (int i = 0; i < 6; i++) aw[i] = At[i] - Abs[i] - cr[i] + sm[D.lds[L_ACCP] + t * 6 + i];
+          ldH(sm, D, frame, H);
+          motion_to_frame(H, aw, aF);
+          if (kind == QPC_TASK_SPATIAL_ACCELERATION || kind == QPC_TASK_ANGULAR_ACCELERATION) rhs = des - aF[a];
+          else if (kind == QPC_TASK_LINEAR_ACCELERATION) rhs = des - aF[3 + a];
+          else { // point: w x pdot + J̇v_ang x p + J̇v_lin (src/tasks.jl:166-170)
+            double Ht[12], pw[3], d3[3], pF[3], TF[6], pd[3], t1[3], t2[3];
+            ldH(sm, D, target, Ht);
+            mv3(Ht, DT + D.dt[DT_T_POINT] + 3 * t, pw);
+            d3[0] = pw[0] + Ht[9] - H[9]; d3[1] = pw[1] + Ht[10] - H[10]; d3[2] = pw[2] + Ht[11] - H[11];
+            mtv3(H, d3, pF);
+            motion_to_frame(H, trel, TF);
+            cross3(TF, pF, pd);
+            pd[0] += TF[3]; pd[1] += TF[4]; pd[2] += TF[5];
+            cross3(TF, pd, t1);
+            cross3(aF, pF, t2);
+            rhs = des - (t1[a] + t2[a] + aF[3 + a]);
+          }
+        }
+      }
+      sm[D.lds[L_D] + r] = rhs;
+    }
+    // ---------------------------------------------------------------- contacts (a9, a10)
+    if (use_rho)
+      for (int j = lane; j < nrho; j += 64) {
+        int c = j / N, i = j % N, body = IT[D.it[IT_C_BODY] + c];
+        double nrm[3] = {DT[D.dt[DT_C_NORMAL] + 3 * c], DT[D.dt[DT_C_NORMAL] + 3 * c + 1], DT[D.dt[DT_C_NORMAL] + 3 * c + 2]};
+        double mu = DT[D.dt[DT_C_MU] + c];
+        if (IT[D.it[IT_C_PERQP] + c]) {
+          int so = IT[D.it[IT_C_SURF] + c];
+          nrm[0] = sm[D.lds[L_SURF] + so]; nrm[1] = sm[D.lds[L_SURF] + so + 1]; nrm[2] = sm[D.lds[L_SURF] + so + 2];
+          mu = sm[D.lds[L_SURF] + so + 3];
+        }
+        // Rotations.rotation_between(z, n) (contacts.jl:11)
+        double nn = QPC_SQRT(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
+        double w = nn + nrm[2], x, y, z = 0.0;
+        if (QPC_FABS(w) < 100 * 2.220446049250313e-16) { x = 0; y = 1; } else { x = -nrm[1]; y = nrm[0]; }
+        double qn = 1.0 / QPC_SQRT(w * w + x * x + y * y);
+        w *= qn; x *= qn; y *= qn;
+        double Rn[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                        2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                        2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)};
+        double H[12], Rc[9], pc[3];
+        ldH(sm, D, body, H);
+        mm3(H, Rn, Rc);
+        mv3(H, DT + D.dt[DT_C_POS] + 3 * c, pc);
+        pc[0] += H[9]; pc[1] += H[10]; pc[2] += H[11];
+        // forcebasis(mu, N) (contacts.jl:16-23)
+        double sn, cs, inv = 1.0 / QPC_SQRT(mu * mu + 1.0);
+        QPC_SINCOS(i * (6.283185307179586 / N), sn, cs);
+        double bi[3] = {mu * cs * inv, mu * sn * inv, inv}, lin[3], ang[3];
+        mv3(Rc, bi, lin);
+        cross3(pc, lin, ang);
+        for (int a = 0; a < 3; a++) { sm[D.lds[L_G] + a * nrho + j] = ang[a]; sm[D.lds[L_G] + (3 + a) * nrho + j] = lin[a]; }
+        double cw = sm[D.lds[L_CW] + c];
+        for (int i2 = 0; i2 < N; i2++) {
+          double s2, c2;
+          QPC_SINCOS(i2 * (6.283185307179586 / N), s2, c2);
+          double dot = (mu * cs * mu * c2 + mu * sn * mu * s2 + 1.0) * inv * inv;
+          sm[D.lds[L_HR] + c * N * N + i * N + i2] = 2.0 * cw * dot;
+        }
+        double hi = sm[D.lds[L_CMAX] + c] * inv / N; // maxrho (contacts.jl:57)
+        sm[D.lds[L_HI] + j] = hi;
+        sm[D.lds[L_WS] + j] = hi > 0.0 ? 0.0 : -1.0; // disable! (contacts.jl:72): rho pinned to 0
+      }
+  } QPC_END_PHASE
+
+  // ======================================================================== Schur complement S = M M' + W^-1 blocks
+  QPC_PHASE(lane) {
+    for (int idx = lane; idx < m * m; idx += 64) {
+      int r = idx / m, c = idx % m;
+      if (c > r) continue;
+      double acc = 0.0;
+      for (int f = 0; f < nf; f++) acc += sm[D.lds[L_M] + r * D.nfs + f] * sm[D.lds[L_M] + c * D.nfs + f];
+      int tr = IT[D.it[IT_ROW_TASK] + r], tc = IT[D.it[IT_ROW_TASK] + c];
+      if (tr >= 0 && tr == tc) {
+        int w0 = IT[D.it[IT_T_WOFF] + tr];
+        if (w0 >= 0) acc += sm[D.lds[L_WINV] + w0 + IT[D.it[IT_ROW_COMP] + r] * IT[D.it[IT_T_DIM] + tr] + IT[D.it[IT_ROW_COMP] + c]];
+      }
+      sm[D.lds[L_SM] + r * D.ms + c] = acc;
+    }
+  } QPC_END_PHASE
+  // left-looking Cholesky of the leading m1 x m1 block (+ the L21 rows), infinite-pivot rule
+  for (int k = 0; k < m1; k++) {
+    QPC_PHASE(lane) {
+      for (int r = lane + k; r < m; r += 64) {
+        double accr = 0.0, acck = 0.0;
+        for (int j = 0; j < k; j++) {
+          double lk = sm[D.lds[L_SM] + k * D.ms + j];
+          accr += lk * sm[D.lds[L_SM] + r * D.ms + j];
+          acck += lk * lk;
+        }
+        double skk = sm[D.lds[L_SM] + k * D.ms + k], dk = skk - acck;
+        bool ok = dk > D.tau_pivot * (skk > 1e-300 ? skk : 1e-300);
+        double ld_ = ok ? QPC_SQRT(dk) : 0.0, inv = ok ? 1.0 / ld_ : 0.0;
+        if (r == k) { sm[D.lds[L_T1] + k] = inv; sm[D.lds[L_T2] + k] = ld_; } // 1/L_kk (0 = dropped row)
+        else sm[D.lds[L_SM] + r * D.ms + k] = (sm[D.lds[L_SM] + r * D.ms + k] - accr) * inv;
+      }
+    } QPC_END_PHASE
+  }
+  QPC_PHASE(lane) { // B22 = S22 - L21 L21' ; X = L11^-1 (lane = column, private forward substitution)
+    if (lane < 36 && nw) {
+      int a = lane / 6, b = lane % 6, hi_ = a > b ? a : b, lo_ = a > b ? b : a;
+      double acc = sm[D.lds[L_SM] + (m1 + hi_) * D.ms + (m1 + lo_)];
+      for (int j = 0; j < m1; j++) acc -= sm[D.lds[L_SM] + (m1 + a) * D.ms + j] * sm[D.lds[L_SM] + (m1 + b) * D.ms + j];
+      sm[D.lds[L_B22] + lane] = acc;
+    }
+    for (int c = lane; c < m1; c += 64)
+      for (int r = c; r < m1; r++) {
+        double t = (r == c) ? 1.0 : 0.0;
+        for (int j = c; j < r; j++) t -= sm[D.lds[L_SM] + r * D.ms + j] * sm[D.lds[L_X] + j * D.m1s + c];
+        sm[D.lds[L_X] + r * D.m1s + c] = t * sm[D.lds[L_T1] + r];
+      }
+  } QPC_END_PHASE
+
+  // ======================================================================== active-set solve (a13)
+  Solver<P> S(D, IT, DT, sm);
+  int status = QPC_STATUS_OPTIMAL, iters = 0;
+  S.refactor_rho();
+  S.eqp(0);
+  if (use_rho) {
+    // ---- phase A: primal-dual active-set sweeps (multi-change)
+    for (int pd = 0; pd < D.max_pdas; pd++) {
+      S.residuals();
+      S.multipliers();
+      double gscale = 1.0 + umax(sm, D.lds[L_RED], 64), tolb = D.tol_bound * (1.0 + umax(sm, D.lds[L_RED] + 64, 64));
+      QPC_PHASE(lane) {
+        double changed = 0.0;
+        for (int j = lane; j < nrho; j += 64) {
+          double w = sm[D.lds[L_WS] + j], hi = sm[D.lds[L_HI] + j], x = sm[D.lds[L_XR] + j], nw_ = w;
+          if (!(hi > 0.0)) continue; // disabled
+          if (w != 0.0) { if (sm[D.lds[L_U] + j] < -D.tol_bound * gscale) nw_ = 0.0; }
+          else if (x < -tolb) nw_ = -1.0;
+          else if (x > hi + tolb) nw_ = 1.0;
+          if (nw_ != w) { sm[D.lds[L_WS] + j] = nw_; changed = 1.0; }
+        }
+        sm[D.lds[L_RED] + 128 + lane] = changed;
+      } QPC_END_PHASE
+      if (!(umax(sm, D.lds[L_RED] + 128, 64) > 0.0)) break;
+      iters++;
+      S.refactor_rho();
+      S.eqp(0);
+    }
+    // ---- phase B: drops until dual feasible, then Goldfarb-Idnani additions (finite)
+    while (true) {
+      if (iters > D.max_as_iters) { status = QPC_STATUS_ITERATION_LIMIT; break; }
+      S.residuals();
+      S.multipliers();
+      double gscale = 1.0 + umax(sm, D.lds[L_RED], 64), tolb = D.tol_bound * (1.0 + umax(sm, D.lds[L_RED] + 64, 64));
+      // most negative multiplier / most violated bound (uniform scans)
+      int jbad = -1, pviol = -1;
+      double ubad = -D.tol_bound * gscale, vmax = tolb;
+      bool finite = true;
+      for (int j = 0; j < nrho; j++) {
+        double w = sm[D.lds[L_WS] + j], hi = sm[D.lds[L_HI] + j], x = sm[D.lds[L_XR] + j];
+        if (!(x == x) || QPC_FABS(x) > 1e300) finite = false;
+        if (!(hi > 0.0)) continue;
+        if (w != 0.0) { double u = sm[D.lds[L_U] + j]; if (u < ubad) { ubad = u; jbad = j; } }
+        else { double vl = -x > x - hi ? -x : x - hi; if (vl > vmax) { vmax = vl; pviol = j; } }
+      }
+      if (!finite) { status = QPC_STATUS_NUMERICAL_ERROR; break; }
+      if (jbad >= 0) {
+        QPC_PHASE(lane) { if (lane == 0) sm[D.lds[L_WS] + jbad] = 0.0; } QPC_END_PHASE
+        iters++;
+        S.refactor_rho();
+        S.eqp(0);
+        continue;
+      }
+      if (pviol < 0) break; // optimal for this working set
+      const int p = pviol;
+      const double xp0 = sm[D.lds[L_XR] + p], hip = sm[D.lds[L_HI] + p];
+      const double side = (-xp0 > xp0 - hip) ? -1.0 : 1.0, nsign = side < 0 ? 1.0 : -1.0;
+      bool fail = false;
+      while (true) {
+        iters++;
+        if (iters > D.max_as_iters) { fail = true; break; }
+        QPC_PHASE(lane) { // rhs = n_p on the rho block, zero elsewhere
+          for (int f = lane; f < nf; f += 64) sm[D.lds[L_RV] + f] = 0.0;
+          for (int s = lane; s < ne; s += 64) sm[D.lds[L_RE] + s] = 0.0;
+          for (int r = lane; r < m; r += 64) sm[D.lds[L_RC] + r] = 0.0;
+          for (int j = lane; j < nrho; j += 64) sm[D.lds[L_RR] + j] = (j == p) ? nsign : 0.0;
+        } QPC_END_PHASE
+        S.kkt_solve();
+        QPC_PHASE(lane) { // dual direction r_j = -s_j (H_eff z)_j on the working set; step ratios
+          double best = 1e300;
+          double bestj = -1.0;
+          for (int j = lane; j < nrho; j += 64) {
+            int c = j / N, jj = j % N;
+            double w = sm[D.lds[L_WS] + j];
+            double rj = 0.0;
+            if (w != 0.0 && sm[D.lds[L_HI] + j] > 0.0) {
+              double hz = eps * sm[D.lds[L_DR] + j];
+              for (int i = 0; i < N; i++) hz += sm[D.lds[L_HR] + c * N * N + jj * N + i] * sm[D.lds[L_DR] + c * N + i];
+              for (int a = 0; a < 6; a++) hz -= sm[D.lds[L_G] + a * nrho + j] * sm[D.lds[L_DL] + m1 + a];
+              rj = (w == -1.0) ? -hz : hz;
+              if (rj > 1e-300) { double ratio = sm[D.lds[L_U] + j] / rj; if (ratio < best) { best = ratio; bestj = (double)j; } }
+            }
+            sm[D.lds[L_TR2] + j] = rj;
+          }
+          sm[D.lds[L_RED] + lane] = best;
+          sm[D.lds[L_RED] + 64 + lane] = bestj;
+        } QPC_END_PHASE
+        double t1 = 1e300;
+        int jdrop = -1;
+        for (int l = 0; l < 64; l++) { double b = sm[D.lds[L_RED] + l]; if (b < t1) { t1 = b; jdrop = (int)sm[D.lds[L_RED] + 64 + l]; } }
+        const double xp = sm[D.lds[L_XR] + p];
+        const double sp = nsign * xp - (side < 0 ? 0.0 : -hip); // < 0 : violation
+        const double zn = nsign * sm[D.lds[L_DR] + p];
+        const double t2 = zn > 1e-300 ? -sp / zn : 1e300;
+        const double tt = t1 < t2 ? t1 : t2;
+        if (!(tt < 1e299)) { status = QPC_STATUS_INFEASIBLE; fail = true; break; }
+        const bool full = t2 <= t1;
+        QPC_PHASE(lane) {
+          for (int f = lane; f < nf; f += 64) sm[D.lds[L_XV] + f] = sm[D.lds[L_XV] + f] + tt * sm[D.lds[L_DV] + f];
+          for (int s = lane; s < ne; s += 64) sm[D.lds[L_XE] + s] = sm[D.lds[L_XE] + s] + tt * sm[D.lds[L_DE] + s];
+          for (int r = lane; r < m; r += 64) sm[D.lds[L_LAM] + r] = sm[D.lds[L_LAM] + r] + tt * sm[D.lds[L_DL] + r];
+          for (int j = lane; j < nrho; j += 64) {
+            sm[D.lds[L_XR] + j] = sm[D.lds[L_XR] + j] + tt * sm[D.lds[L_DR] + j];
+            double u = sm[D.lds[L_U] + j] - tt * sm[D.lds[L_TR2] + j];
+            if (!full && j == jdrop) { u = 0.0; sm[D.lds[L_WS] + j] = 0.0; }
+            if (full && j == p) sm[D.lds[L_WS] + j] = side;
+            sm[D.lds[L_U] + j] = u;
+          }
+        } QPC_END_PHASE
+        S.refactor_rho();
+        if (full) { S.eqp(0); break; }
+      }
+      if (fail) { if (status == QPC_STATUS_OPTIMAL) status = QPC_STATUS_ITERATION_LIMIT; break; }
+    }
+  }
+  // ---- final refinement on the converged working set + acceptance test (a14)
+  int refine = 0;
+  if (status == QPC_STATUS_OPTIMAL) {
+    refine = S.eqp(D.max_refine);
+    S.residuals();
+    QPC_PHASE(lane) {
+      double rp = 0.0, rs = 0.0, sp = 0.0, ss = 0.0;
+      for (int r = lane; r < m; r += 64) {
+        double a = QPC_FABS(sm[D.lds[L_RC] + r]); rp = a > rp || !(a == a) ? a : rp;
+        double b = QPC_FABS(sm[D.lds[L_D] + r]); sp = b > sp ? b : sp;
+      }
+      for (int f = lane; f < nf; f += 64) {
+        double a = QPC_FABS(sm[D.lds[L_RV] + f]); rs = a > rs || !(a == a) ? a : rs;
+        double b = QPC_FABS(sm[D.lds[L_GV] + f]); ss = b > ss ? b : ss;
+        // |E_v' lam| scale
+        double mtl = 0.0;
+        for (int r = 0; r < m; r++) mtl += sm[D.lds[L_M] + r * D.nfs + f] * sm[D.lds[L_LAM] + r];
+        b = QPC_FABS(mtl / sm[D.lds[L_SQH] + f]); ss = b > ss ? b : ss;
+      }
+      for (int s = lane; s < ne; s += 64) { double a = QPC_FABS(sm[D.lds[L_RE] + s]); rs = a > rs || !(a == a) ? a : rs; }
+      for (int j = lane; j < nrho; j += 64) { double a = QPC_FABS(sm[D.lds[L_RR] + j]); rs = a > rs || !(a == a) ? a : rs; }
+      sm[D.lds[L_RED] + lane] = rp; sm[D.lds[L_RED] + 64 + lane] = rs;
+      sm[D.lds[L_RED] + 128 + lane] = sp; sm[D.lds[L_RED] + 192 + lane] = ss;
+    } QPC_END_PHASE
+    double rp = 0.0, rs = 0.0;
+    bool nan = false;
+    for (int l = 0; l < 64; l++) {
+      double a = sm[D.lds[L_RED] + l], b = sm[D.lds[L_RED] + 64 + l];
+      if (!(a == a) || !(b == b)) nan = true;
+      rp = a > rp ? a : rp; rs = b > rs ? b : rs;
+    }
+    double r_prim = rp / (1.0 + umax(sm, D.lds[L_RED] + 128, 64)), r_stat = rs / (1.0 + umax(sm, D.lds[L_RED] + 192, 64));
+    if (nan || !(r_prim < 1e300) || !(r_stat < 1e300)) status = QPC_STATUS_NUMERICAL_ERROR;
+    else if (r_prim > D.tol_accept) status = QPC_STATUS_INFEASIBLE; // equality rows inconsistent on the feasible set
+    else if (r_stat > D.tol_accept) status = QPC_STATUS_ALMOST_OPTIMAL;
+  }
+
+  // ======================================================================== extraction (a15) + RNEA (a16, a17)
+  QPC_PHASE(lane) {
+    for (int f = lane; f < nf; f += 64) sm[D.lds[L_VD] + IT[D.it[IT_FREE_K] + f]] = sm[D.lds[L_XV] + f] * sm[D.lds[L_SQH] + f];
+    for (int idx = lane; idx < nc * 6; idx += 64) { // value(wrench_world) = G_c rho_c
+      int c = idx / 6, a = idx % 6;
+      double acc = 0.0;
+      if (use_rho) for (int i = 0; i < N; i++) acc += sm[D.lds[L_G] + a * nrho + c * N + i] * sm[D.lds[L_XR] + c * N + i];
+      sm[D.lds[L_CWR] + idx] = acc;
+    }
+  } QPC_END_PHASE
+  QPC_PHASE(lane) { // S_j v̇_j per body
+    for (int i = lane; i < nb; i += 64) {
+      double sv[6] = {0, 0, 0, 0, 0, 0};
+      int v0 = IT[D.it[IT_VOFF] + i], n = IT[D.it[IT_NVJ] + i];
+      for (int c = 0; c < n; c++) {
+        double vd = sm[D.lds[L_VD] + v0 + c];
+        for (int a = 0; a < 6; a++) sv[a] += sm[D.lds[L_S] + 6 * (v0 + c) + a] * vd;
+      }
+      st(sm + D.lds[L_SV] + 6 * i, 6, sv);
+    }
+  } QPC_END_PHASE
+  QPC_PHASE(lane) { // body wrench: I (A + Ab - g) + T x* I T - external (contact) wrench
+    for (int i = lane; i < nb; i += 64) {
+      double A[6], I[10], ia[6];
+      ld(sm + D.lds[L_SV] + 6 * i, 6, A);
+      for (int e = anc_ptr[i]; e < anc_ptr[i + 1]; e++)
+        for (int a = 0; a < 6; a++) A[a] += sm[D.lds[L_SV] + 6 * anc_idx[e] + a];
+      for (int a = 0; a < 6; a++) A[a] += sm[D.lds[L_AB] + 6 * i + a];
+      A[3] -= DT[D.dt[DT_GRAV]]; A[4] -= DT[D.dt[DT_GRAV] + 1]; A[5] -= DT[D.dt[DT_GRAV] + 2];
+      ld(sm + D.lds[L_IW] + 10 * i, 10, I);
+      inertia_mul(I, A, ia);
+      for (int a = 0; a < 6; a++) ia[a] += sm[D.lds[L_F] + 6 * i + a];
+      for (int e = IT[D.it[IT_BC_PTR] + i]; e < IT[D.it[IT_BC_PTR] + i + 1]; e++) {
+        int c = IT[D.it[IT_BC_IDX] + e];
+        for (int a = 0; a < 6; a++) ia[a] -= sm[D.lds[L_CWR] + 6 * c + a];
+      }
+      st(sm + D.lds[L_HB] + 6 * i, 6, ia);
+    }
+  } QPC_END_PHASE
+  QPC_PHASE(lane) { // tau_k = S_k . (sum of subtree wrenches); floating joint torques exactly 0
+    for (int k = lane; k < nv; k += 64) {
+      int b = IT[D.it[IT_VBODY] + k];
+      double tau = 0.0;
+      if (b != D.floating) {
+        double F[6] = {0, 0, 0, 0, 0, 0};
+        for (int e = desc_ptr[b]; e < desc_ptr[b + 1]; e++)
+          for (int a = 0; a < 6; a++) F[a] += sm[D.lds[L_HB] + 6 * desc_idx[e] + a];
+        for (int a = 0; a < 6; a++) tau += sm[D.lds[L_S] + 6 * k + a] * F[a];
+      }
+      io.tau[k] = tau;
+      io.vdot[k] = sm[D.lds[L_VD] + k];
+    }
+    if (io.cwrench)
+      for (int idx = lane; idx < nc * 6; idx += 64) io.cwrench[idx] = sm[D.lds[L_CWR] + idx];
+    if (lane == 0) {
+      io.status[0] = status;
+      if (io.iters) io.iters[0] = iters + 1000 * refine;
+    }
+  } QPC_END_PHASE
+}
+
+} // namespace qpc

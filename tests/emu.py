@@ -1,0 +1,28 @@
+"""Test helper: drives the lane-serial CPU emulation of the device code (tests/emul/) through the
+product's own ctypes binding -- same symbols, different (test-only) shared object."""
+import ctypes
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMU_LIB = os.path.join(HERE, "_build", "libqpc_emul.so")
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", os.path.join(HERE, "emul")], check=True)
+    return EMU_LIB
+
+
+def factory(mech, n_basis, floating):
+    from qpcontrol_jl_amd import binding
+    build()
+    return binding.Controller(binding.Model(mech, EMU_LIB), n_basis, floating)
+
+
+def race_report():
+    """(races, uninitialised reads, writes outside phases, first message) since the last call."""
+    L = ctypes.CDLL(EMU_LIB)
+    r, u, o = ctypes.c_long(), ctypes.c_long(), ctypes.c_long()
+    buf = ctypes.create_string_buffer(256)
+    L.emu_report(ctypes.byref(r), ctypes.byref(u), ctypes.byref(o), buf, 256)
+    return r.value, u.value, o.value, buf.value.decode()

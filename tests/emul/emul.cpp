@@ -1,0 +1,132 @@
+// emul.cpp -- TEST-ONLY lane-serial CPU emulation of the device code in
+// qpcontrol.jl_amd/csrc/qpc_tick.h.  A "phase" runs its per-lane block for lanes 0..63 in turn;
+// LDS is a host array behind a checking proxy that reports, per phase,
+//   * read of a word another lane wrote in the same phase   (RAW race on the GPU)
+//   * write of a word another lane read or wrote in the same phase (WAR / WAW race)
+//   * read of a never-written word, writes outside a phase
+// This is the "CPU build" for sanitizers and algorithm debugging; it is never part of the
+// product library and never a fallback: it exports the same qpc_finalize / qpc_control_batch
+// symbols from a separate test-only shared object (tests/_build/libqpc_emul.so).
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../qpcontrol.jl_amd/csrc/qpc_compile.h"
+
+struct EmuState {
+  std::vector<double> mem;
+  std::vector<int> wphase, wlane, rphase, rlane;
+  int phase = 0, lane = -1;
+  long races = 0, uninit = 0, outside = 0;
+  std::string first;
+  void reset(int n) {
+    mem.assign(n, std::nan(""));
+    wphase.assign(n, -1); wlane.assign(n, -1); rphase.assign(n, -1); rlane.assign(n, -1);
+    phase = 0; lane = -1;
+  }
+  void note(const char *what, int i) {
+    if (first.empty()) { char b[160]; snprintf(b, sizeof b, "%s at lds[%d] phase %d lane %d (writer lane %d, reader lane %d)", what, i, phase, lane, wlane[i], rlane[i]); first = b; }
+  }
+  void on_read(int i) {
+    if (wphase[i] < 0) { uninit++; note("uninitialised read", i); }
+    if (lane >= 0) {
+      if (wphase[i] == phase && wlane[i] != lane) { races++; note("RAW race", i); }
+      if (rphase[i] == phase) { if (rlane[i] != lane) rlane[i] = -2; }
+      else { rphase[i] = phase; rlane[i] = lane; }
+    }
+  }
+  void on_write(int i) {
+    if (lane < 0) { outside++; note("write outside a phase", i); return; }
+    if (wphase[i] == phase && wlane[i] != lane) { races++; note("WAW race", i); }
+    if (rphase[i] == phase && rlane[i] != lane) { races++; note("WAR race", i); }
+    wphase[i] = phase; wlane[i] = lane;
+  }
+};
+static thread_local EmuState *g_emu = nullptr;
+
+struct Ref {
+  int i;
+  operator double() const { g_emu->on_read(i); return g_emu->mem[i]; }
+  Ref &operator=(double v) { g_emu->on_write(i); g_emu->mem[i] = v; return *this; }
+  Ref &operator=(const Ref &o) { return *this = (double)o; }
+};
+struct Lds {
+  int base;
+  Ref operator[](int i) const { return Ref{base + i}; }
+  Lds operator+(int o) const { return Lds{base + o}; }
+};
+
+#define QPC_FN inline
+#define QPC_PHASE(lane) for (int lane = 0; lane < 64; ++lane) { g_emu->lane = lane;
+#define QPC_END_PHASE } g_emu->lane = -1; g_emu->phase++;
+#define QPC_SINCOS(x, s, c) do { double x__ = (x); s = std::sin(x__); c = std::cos(x__); } while (0)
+#define QPC_SQRT(x) std::sqrt((double)(x))
+#define QPC_FABS(x) std::fabs((double)(x))
+#include "../../qpcontrol.jl_amd/csrc/qpc_tick.h"
+
+static long g_races = 0, g_uninit = 0, g_outside = 0;
+static std::string g_first;
+
+extern "C" {
+
+int32_t qpc_finalize(qpc_controller *c, int32_t device_id, qpc_layout *out) {
+  (void)device_id;
+  if (!c) return QPC_ERR_INVALID_ARGUMENT;
+  if (!c->finalized) {
+    int rc = qpc_compile_program(c);
+    if (rc != QPC_OK) return rc;
+    c->finalized = true;
+  }
+  if (out) *out = c->layout;
+  return QPC_OK;
+}
+void qpc_controller_destroy(qpc_controller *c) { delete c; }
+
+int32_t qpc_control_batch(qpc_controller *c, int64_t B, const double *q, const double *v, const double *desired,
+                          const double *cw, const double *cmax, const double *tw, const double *surf, double *tau,
+                          double *vdot, double *cwrench, int32_t *status, int32_t *iters) {
+  if (!c || !c->finalized) return QPC_ERR_NOT_FINALIZED;
+  const QpcDims &D = c->prog.dims;
+  EmuState emu;
+  g_emu = &emu;
+  for (int64_t b = 0; b < B; b++) {
+    emu.reset(D.lds_doubles);
+    qpc::TickIO io;
+    io.q = q + b * D.nq; io.v = v + b * D.nv; io.desired = desired ? desired + b * D.n_desired : nullptr;
+    io.cw = cw ? cw + b * D.nc : nullptr; io.cmax = cmax ? cmax + b * D.nc : nullptr;
+    io.tw = tw ? tw + b * D.n_tw : nullptr; io.surf = surf ? surf + b * D.n_surf : nullptr;
+    io.tau = tau + b * D.nv; io.vdot = vdot + b * D.nv; io.cwrench = cwrench ? cwrench + b * 6 * D.nc : nullptr;
+    io.status = status + b; io.iters = iters ? iters + b : nullptr;
+    qpc::qpc_tick<Lds>(D, c->prog.itab.data(), c->prog.dtab.data(), Lds{0}, io);
+    g_races += emu.races; g_uninit += emu.uninit; g_outside += emu.outside;
+    if (g_first.empty()) g_first = emu.first;
+  }
+  g_emu = nullptr;
+  return QPC_OK;
+}
+
+// race-detector report: counts since the last call
+void emu_report(long *races, long *uninit, long *outside, char *first, int n) {
+  *races = g_races; *uninit = g_uninit; *outside = g_outside;
+  snprintf(first, n, "%s", g_first.c_str());
+  g_races = g_uninit = g_outside = 0; g_first.clear();
+}
+}
+
+// self-test of the race detector: lane l reads the word lane l-1 writes in the same phase
+extern "C" long emu_selftest_race() {
+  EmuState emu;
+  g_emu = &emu;
+  emu.reset(128);
+  Lds sm{0};
+  QPC_PHASE(lane) { sm[lane] = 1.0; } QPC_END_PHASE
+  QPC_PHASE(lane) {
+    double x = sm[(lane + 63) % 64];
+    sm[lane] = x + 1.0;
+  } QPC_END_PHASE
+  long r = emu.races;
+  g_emu = nullptr;
+  return r;
+}
