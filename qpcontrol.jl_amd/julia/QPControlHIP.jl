@@ -1,0 +1,210 @@
+# QPControlHIP.jl -- thin Julia host over libqpcontrol_hip.so (include/qpc.h).
+#
+# Mirrors the exported surface of QPControl.jl (reference src/QPControl.jl:5-33) for BATCHES of
+# independent states: MomentumBasedController{N} / addtask! / addcontact! / regularize! /
+# setdesired! / disable! keep their names and argument meaning; the per-tick callable takes
+# matrices whose columns are the per-state records (Julia column-major == the C ABI's
+# "record of QP b is contiguous").
+#
+# NOTE: no `julia` binary exists in the build image, so this file is exercised only through the
+# identical ctypes binding (qpcontrol.jl_amd/binding.py, api.py) -- every ccall below binds one
+# symbol of include/qpc.h with the argument order shown there.
+module QPControlHIP
+
+export BatchedMomentumBasedController, QPCModel, addtask!, addcontact!, regularize!, finalize!,
+       QPSolveFailure, SpatialAccelerationTask, AngularAccelerationTask, LinearAccelerationTask,
+       PointAccelerationTask, JointAccelerationTask, MomentumRateTask, LinearMomentumRateTask
+
+const libqpc = get(ENV, "QPCONTROL_HIP_LIB", "libqpcontrol_hip.so")
+
+const QPC_WORLD = Int32(-1)
+const QPC_FRAME_DEFAULT = Int32(-2)
+@enum TaskKind::Int32 SPATIAL=0 ANGULAR=1 LINEAR=2 POINT=3 JOINT=4 MOMENTUM_RATE=5 LINEAR_MOMENTUM_RATE=6
+@enum WeightKind::Int32 HARD=0 SCALAR=1 MATRIX=2 SCALAR_PER_QP=3 MATRIX_PER_QP=4
+
+# exceptions.jl:1-11
+struct QPSolveFailure <: Exception
+    index::Int
+    status::Int32
+end
+Base.showerror(io::IO, e::QPSolveFailure) = print(io, "QP solve unsuccessful for batch element ",
+    e.index, ": ", unsafe_string(ccall((:qpc_status_string, libqpc), Cstring, (Int32,), e.status)))
+
+lasterror() = unsafe_string(ccall((:qpc_last_error, libqpc), Cstring, ()))
+check(rc, what) = rc == 0 ? nothing : error("$what failed (code $rc): $(lasterror())")
+
+# ---- qpc_model_desc (include/qpc.h) ----------------------------------------------------------
+struct ModelDesc
+    nbodies::Int32
+    parent::Ptr{Int32}
+    joint_type::Ptr{Int32}
+    joint_axis::Ptr{Float64}
+    joint_R::Ptr{Float64}
+    joint_p::Ptr{Float64}
+    mass::Ptr{Float64}
+    com::Ptr{Float64}
+    inertia::Ptr{Float64}
+    gravity::NTuple{3, Float64}
+end
+
+mutable struct QPCModel
+    handle::Ptr{Cvoid}
+    nq::Int
+    nv::Int
+end
+
+"""
+    QPCModel(parent, joint_type, axis, R, p, mass, com, inertia, gravity)
+
+Flat tree description == `Mechanism{Float64}` after `remove_fixed_tree_joints!`; with
+RigidBodyDynamics loaded, build the arrays by walking `tree_joints(mechanism)`:
+`parent[i]` = index of `predecessor(joint_i)`, `R/p` = `joint_to_predecessor(joint_i)`,
+`mass/com/inertia` from `spatial_inertia(successor(joint_i))` about its centre of mass.
+"""
+function QPCModel(parent::Vector{Int32}, joint_type::Vector{Int32}, axis::Matrix{Float64},
+                  R::Array{Float64, 3}, p::Matrix{Float64}, mass::Vector{Float64},
+                  com::Matrix{Float64}, inertia::Matrix{Float64}, gravity::NTuple{3, Float64})
+    nb = length(parent)
+    # C side wants row-major 3x3 per body: permute Julia's column-major
+    Rrm = permutedims(R, (2, 1, 3))
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve parent joint_type axis Rrm p mass com inertia begin
+        desc = ModelDesc(nb, pointer(parent), pointer(joint_type), pointer(axis), pointer(Rrm),
+                         pointer(p), pointer(mass), pointer(com), pointer(inertia), gravity)
+        check(ccall((:qpc_model_create, libqpc), Int32, (Ref{ModelDesc}, Ref{Ptr{Cvoid}}), desc, h),
+              "qpc_model_create")
+    end
+    m = QPCModel(h[], ccall((:qpc_model_nq, libqpc), Int32, (Ptr{Cvoid},), h[]),
+                 ccall((:qpc_model_nv, libqpc), Int32, (Ptr{Cvoid},), h[]))
+    finalizer(x -> ccall((:qpc_model_destroy, libqpc), Cvoid, (Ptr{Cvoid},), x.handle), m)
+    m
+end
+
+# ---- tasks: plain descriptors (src/tasks.jl structs without the Parametron machinery) --------
+abstract type AbstractMotionTask end
+struct SpatialAccelerationTask <: AbstractMotionTask; base::Int32; target::Int32; frame::Int32; end
+struct AngularAccelerationTask <: AbstractMotionTask; base::Int32; target::Int32; frame::Int32; end
+struct LinearAccelerationTask <: AbstractMotionTask; base::Int32; target::Int32; frame::Int32; end
+struct PointAccelerationTask <: AbstractMotionTask; base::Int32; target::Int32; point::NTuple{3, Float64}; end
+struct JointAccelerationTask <: AbstractMotionTask; joint::Int32; end
+struct MomentumRateTask <: AbstractMotionTask end
+struct LinearMomentumRateTask <: AbstractMotionTask end
+SpatialAccelerationTask(base, target; frame = QPC_FRAME_DEFAULT) = SpatialAccelerationTask(base, target, frame)
+AngularAccelerationTask(base, target; frame = QPC_FRAME_DEFAULT) = AngularAccelerationTask(base, target, frame)
+LinearAccelerationTask(base, target; frame = QPC_FRAME_DEFAULT) = LinearAccelerationTask(base, target, frame)
+
+kind(::SpatialAccelerationTask) = SPATIAL; kind(::AngularAccelerationTask) = ANGULAR
+kind(::LinearAccelerationTask) = LINEAR; kind(::PointAccelerationTask) = POINT
+kind(::JointAccelerationTask) = JOINT; kind(::MomentumRateTask) = MOMENTUM_RATE
+kind(::LinearMomentumRateTask) = LINEAR_MOMENTUM_RATE
+
+# ---- controller ------------------------------------------------------------------------------
+struct Layout
+    nq::Int32; nv::Int32; n_tasks::Int32; n_contacts::Int32; n_basis::Int32; n_desired::Int32
+    n_task_weights::Int32; n_surface::Int32; ref_n_var::Int32; ref_n_eq::Int32; ref_n_ineq::Int32
+    n_free::Int32; n_pinned::Int32; n_slack::Int32; n_rho::Int32; n_eq_rows::Int32
+    lds_bytes_per_qp::Int32
+end
+
+mutable struct BatchedMomentumBasedController{N}
+    handle::Ptr{Cvoid}
+    model::QPCModel
+    layout::Union{Nothing, Layout}
+    desired_offsets::Vector{Int}   # task id -> first row in `desired`
+    vdot::Matrix{Float64}          # result.v̇ of the last tick (momentum.jl:62-64)
+    contactwrenches::Matrix{Float64}
+    status::Vector{Int32}
+end
+
+# MomentumBasedController{N}(mechanism, optimizer; floatingjoint) -- momentum.jl:15-33.
+# There is no optimizer argument: the solver lives in the kernels.
+function BatchedMomentumBasedController{N}(model::QPCModel; floatingjoint::Integer = QPC_WORLD) where {N}
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:qpc_controller_create, libqpc), Int32, (Ptr{Cvoid}, Int32, Int32, Ref{Ptr{Cvoid}}),
+                model.handle, N, floatingjoint, h), "qpc_controller_create")
+    c = BatchedMomentumBasedController{N}(h[], model, nothing, Int[], zeros(0, 0), zeros(0, 0), Int32[])
+    finalizer(x -> ccall((:qpc_controller_destroy, libqpc), Cvoid, (Ptr{Cvoid},), x.handle), c)
+    c
+end
+
+function _addtask!(c, task, wkind::WeightKind, w)
+    base = hasproperty(task, :base) ? task.base : QPC_WORLD
+    target = hasproperty(task, :target) ? task.target : QPC_WORLD
+    frame = hasproperty(task, :frame) ? task.frame : QPC_FRAME_DEFAULT
+    point = hasproperty(task, :point) ? collect(task.point) : zeros(3)
+    joint = hasproperty(task, :joint) ? task.joint : QPC_WORLD
+    tid = Ref{Int32}(-1)
+    wptr = w === nothing ? Ptr{Float64}(C_NULL) : pointer(w)
+    GC.@preserve point w check(ccall((:qpc_add_task, libqpc), Int32,
+        (Ptr{Cvoid}, Int32, Int32, Int32, Int32, Ptr{Float64}, Int32, Int32, Ptr{Float64}, Ref{Int32}),
+        c.handle, Int32(kind(task)), base, target, frame, point, joint, Int32(wkind), wptr, tid), "qpc_add_task")
+    tid[]
+end
+# the three addtask! methods of momentum.jl:99-117 (+ per-QP "Parameter" weights)
+addtask!(c::BatchedMomentumBasedController, task::AbstractMotionTask) = _addtask!(c, task, HARD, nothing)
+addtask!(c::BatchedMomentumBasedController, task::AbstractMotionTask, w::Number) = _addtask!(c, task, SCALAR, [Float64(w)])
+# W is row-major on the C side: hand over W' so that element (a,b) lands at [a*dim+b]
+addtask!(c::BatchedMomentumBasedController, task::AbstractMotionTask, W::AbstractMatrix) =
+    _addtask!(c, task, MATRIX, vec(Matrix{Float64}(W')))
+addtask!(c::BatchedMomentumBasedController, task::AbstractMotionTask, ::Val{:scalar_per_qp}) = _addtask!(c, task, SCALAR_PER_QP, nothing)
+addtask!(c::BatchedMomentumBasedController, task::AbstractMotionTask, ::Val{:matrix_per_qp}) = _addtask!(c, task, MATRIX_PER_QP, nothing)
+
+# regularize! (momentum.jl:128-131)
+regularize!(c::BatchedMomentumBasedController, joint::Integer, weight::Real) =
+    check(ccall((:qpc_regularize, libqpc), Int32, (Ptr{Cvoid}, Int32, Float64), c.handle, joint, weight), "qpc_regularize")
+
+# addcontact!(controller, body, position, normal, mu) (momentum.jl:142-148); weight[] and
+# maxnormalforce[] (contacts.jl:35-36) are per-QP rows of the tick inputs; disable!(point)
+# (contacts.jl:72) == maxnormalforce = 0 for that QP.
+function addcontact!(c::BatchedMomentumBasedController, body::Integer, position, normal, mu::Real; per_qp_surface::Bool = false)
+    cid = Ref{Int32}(-1)
+    pos, nrm = collect(Float64, position), collect(Float64, normal)
+    GC.@preserve pos nrm check(ccall((:qpc_add_contact, libqpc), Int32,
+        (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}, Float64, Int32, Ref{Int32}),
+        c.handle, body, pos, nrm, mu, per_qp_surface, cid), "qpc_add_contact")
+    cid[]
+end
+
+# initialize! (momentum.jl:150-156): explicit here because the layout is needed to size inputs
+function finalize!(c::BatchedMomentumBasedController; device::Integer = 0)
+    lay = Ref{Layout}()
+    check(ccall((:qpc_finalize, libqpc), Int32, (Ptr{Cvoid}, Int32, Ref{Layout}), c.handle, device, lay), "qpc_finalize")
+    c.layout = lay[]
+    c
+end
+
+"""
+    controller(τ, t, q, v; desired, contact_weight, contact_maxnormalforce, task_weights, surfaces)
+
+The callable of momentum.jl:41-81 for a batch: `q` is nq×B, `v` nv×B, `desired` n_desired×B
+(what `setdesired!` would have stored), `τ` nv×B is overwritten and returned.  After the call
+`controller.vdot` (== `result.v̇`) and `controller.contactwrenches` (6·nc × B) are available.
+Throws `QPSolveFailure` for the first element whose status is not OPTIMAL / ALMOST_OPTIMAL
+(checkstatus, momentum.jl:83-91) unless `throw_on_failure = false`.
+"""
+function (c::BatchedMomentumBasedController)(τ::Matrix{Float64}, t::Number, q::Matrix{Float64}, v::Matrix{Float64};
+        desired::Matrix{Float64} = zeros(0, size(q, 2)), contact_weight::Matrix{Float64} = zeros(0, size(q, 2)),
+        contact_maxnormalforce::Matrix{Float64} = zeros(0, size(q, 2)),
+        task_weights::Union{Nothing, Matrix{Float64}} = nothing, surfaces::Union{Nothing, Matrix{Float64}} = nothing,
+        throw_on_failure::Bool = true)
+    lay = c.layout
+    lay === nothing && error("call finalize!(controller) first")
+    B = size(q, 2)
+    size(c.vdot) == (lay.nv, B) || (c.vdot = zeros(lay.nv, B))
+    size(c.contactwrenches) == (6 * lay.n_contacts, B) || (c.contactwrenches = zeros(6 * lay.n_contacts, B))
+    length(c.status) == B || (c.status = zeros(Int32, B))
+    ptr(x) = x === nothing || isempty(x) ? Ptr{Float64}(C_NULL) : pointer(x)
+    GC.@preserve q v desired contact_weight contact_maxnormalforce task_weights surfaces τ check(ccall(
+        (:qpc_control_batch, libqpc), Int32,
+        (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+         Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}),
+        c.handle, B, q, v, ptr(desired), ptr(contact_weight), ptr(contact_maxnormalforce), ptr(task_weights),
+        ptr(surfaces), τ, c.vdot, ptr(c.contactwrenches), c.status, Ptr{Int32}(C_NULL)), "qpc_control_batch")
+    if throw_on_failure
+        bad = findfirst(s -> s > 1, c.status)
+        bad === nothing || throw(QPSolveFailure(bad, c.status[bad]))
+    end
+    τ
+end
+
+end # module
