@@ -25,7 +25,9 @@
 #ifndef QPC_H
 #define QPC_H
 
+#ifndef __HIPCC_RTC__
 #include <stdint.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {

@@ -245,7 +245,7 @@ int qpc_compile_program(qpc_controller *c) {
   L(L_MISC, MS_COUNT); L(L_AMOM, 6 * nv); L(L_ACCP, (D.ntask + 1) * 6);
   L(L_M, mm * D.nfs); L(L_D, mm); L(L_HV, D.nf); L(L_SQH, D.nf); L(L_GV, D.nf);
   L(L_W, wsize); L(L_WINV, wsize);
-  L(L_SM, mm * D.ms); L(L_X, m1 * D.m1s);
+  L(L_SM, mm * D.ms); L(L_X, m1 * D.m1s); L(L_X2, m1 * 6);
   L(L_B22, 36); L(L_C22, 36); L(L_L22, 36); L(L_S22I, 36);
   L(L_G, 6 * nrho); L(L_Y, nrho * 6); L(L_HR, D.nc * N * N); L(L_KR, D.nc * N * N);
   L(L_HI, nrho); L(L_WS, nrho); L(L_U, nrho);

@@ -1,0 +1,99 @@
+// qpc_jit.cpp -- specialises qpc_tick.h on one controller's QpcDims with hiprtc: every loop bound
+// and every LDS offset of the per-QP program becomes a compile-time constant (full unrolling of
+// the small dot products, immediate-offset ds_read/ds_write, no kernarg/SGPR traffic for the
+// layout).  This is the device-side analogue of Parametron compiling its expression graphs once
+// at addtask!/initialize! time (momentum.jl:99-160) instead of interpreting them every tick.
+#include "qpc_jit.h"
+
+#include <hip/hiprtc.h>
+
+#include <cstdio>
+#include <sstream>
+
+#include "qpc_embedded.inc"
+
+static void put_ints(std::ostringstream &o, const int *a, int n) {
+  o << "{";
+  for (int i = 0; i < n; i++) o << a[i] << (i + 1 < n ? "," : "");
+  o << "}";
+}
+static std::string dbl(double x) {
+  char b[64];
+  snprintf(b, sizeof b, "%.17g", x);
+  std::string s(b);
+  if (s.find_first_of(".eEn") == std::string::npos) s += ".0";
+  return s;
+}
+
+std::string qpc_jit_source(const QpcDims &D) {
+  std::ostringstream o;
+  o << "typedef int int32_t;\ntypedef unsigned int uint32_t;\ntypedef long long int64_t;\n";
+  o << "#include \"qpc_device.h\"\n"
+       "#define QPC_JIT 1\n"
+       "#include \"qpc_tick.h\"\n";
+  // field order == struct QpcDims (qpc_program.h)
+  o << "static constexpr QpcDims kD = {" << D.nb << "," << D.nq << "," << D.nv << "," << D.nf << "," << D.npin << ","
+    << D.nsj << "," << D.ntask << "," << D.nc << "," << D.N << "," << D.nrho << "," << D.ne << "," << D.m << ","
+    << D.m1 << "," << D.nw << "," << D.floating << "," << D.fv0 << "," << D.n_desired << "," << D.n_tw << ","
+    << D.n_surf << "," << D.maxdepth << "," << D.nfs << "," << D.ms << "," << D.m1s << "," << D.wsize << ",";
+  put_ints(o, D.it, IT_COUNT); o << ",";
+  put_ints(o, D.dt, DT_COUNT); o << ",";
+  put_ints(o, D.lds, L_COUNT); o << ",";
+  o << D.lds_doubles << "," << D.n_int << "," << D.n_dbl << "," << D.max_as_iters << "," << D.max_refine << ","
+    << D.max_pdas << "," << dbl(D.eps_primal) << "," << dbl(D.tau_pivot) << "," << dbl(D.tol_bound) << ","
+    << dbl(D.tol_accept) << "};\n";
+  o << "struct QpcBatchArgs { long long B; const double *q, *v, *desired, *cw, *cmax, *tw, *surf; double *tau, *vdot, "
+       "*cwrench; int32_t *status, *iters; unsigned long long *prof; };\n";
+  o << "extern \"C\" __global__ void __launch_bounds__(64) qpc_tick_kernel_jit(const int *__restrict__ IT, "
+       "const double *__restrict__ DT, const QpcBatchArgs A) {\n"
+       "  __shared__ __attribute__((aligned(16))) double qpc_lds[" << (D.lds_doubles > 0 ? D.lds_doubles : 1) << "];\n"
+       "  for (long long b = blockIdx.x; b < A.B; b += gridDim.x) {\n"
+       "    qpc::TickIO io;\n"
+       "    io.q = A.q + b * kD.nq; io.v = A.v + b * kD.nv; io.desired = A.desired + b * kD.n_desired;\n"
+       "    io.cw = A.cw + b * kD.nc; io.cmax = A.cmax + b * kD.nc; io.tw = A.tw + b * kD.n_tw; io.surf = A.surf + b * kD.n_surf;\n"
+       "    io.tau = A.tau + b * kD.nv; io.vdot = A.vdot + b * kD.nv;\n"
+       "    io.cwrench = A.cwrench ? A.cwrench + b * 6 * kD.nc : nullptr;\n"
+       "    io.status = A.status + b; io.iters = A.iters ? A.iters + b : nullptr; io.prof = nullptr;\n"
+       "    qpc::qpc_tick<double *>(kD, IT, DT, qpc_lds, io);\n"
+       "    __syncthreads();\n"
+       "  }\n"
+       "}\n";
+  return o.str();
+}
+
+int qpc_jit_compile(const QpcDims &D, const std::string &arch, std::vector<char> &code, std::string &log) {
+  std::string src = qpc_jit_source(D);
+  hiprtcProgram prog;
+  if (hiprtcCreateProgram(&prog, src.c_str(), "qpc_tick_jit.hip", qpc_src_count, qpc_src_texts, qpc_src_names) != HIPRTC_SUCCESS) {
+    log = "hiprtcCreateProgram failed";
+    return -1;
+  }
+  std::string archopt = "--offload-arch=" + arch;
+  const char *opts[] = {archopt.c_str(), "-O3", "-std=c++17"};
+  hiprtcResult r = hiprtcCompileProgram(prog, 3, opts);
+  size_t ls = 0;
+  hiprtcGetProgramLogSize(prog, &ls);
+  log.assign(ls, ' ');
+  if (ls) hiprtcGetProgramLog(prog, &log[0]);
+  if (r != HIPRTC_SUCCESS) { hiprtcDestroyProgram(&prog); return -2; }
+  size_t cs = 0;
+  hiprtcGetCodeSize(prog, &cs);
+  code.resize(cs);
+  hiprtcGetCode(prog, code.data());
+  hiprtcDestroyProgram(&prog);
+  return 0;
+}
+
+// offline check / experiments: compile the specialised kernel of a controller without a device
+#include "qpc_compile.h"
+extern "C" int32_t qpc_debug_jit_compile(qpc_controller *c, const char *arch, const char *out_path, char *logbuf, int32_t logn) {
+  if (!c) return QPC_ERR_INVALID_ARGUMENT;
+  if (!c->finalized) { int rc = qpc_compile_program(c); if (rc != QPC_OK) return rc; }
+  std::vector<char> code;
+  std::string log;
+  int rc = qpc_jit_compile(c->prog.dims, arch ? arch : "gfx950", code, log);
+  if (logbuf && logn > 0) snprintf(logbuf, logn, "%s", log.c_str());
+  if (rc != 0) { qpc_set_error("JIT compile failed: " + log); return QPC_ERR_HIP; }
+  if (out_path) { FILE *f = fopen(out_path, "wb"); if (f) { fwrite(code.data(), 1, code.size(), f); fclose(f); } }
+  return QPC_OK;
+}

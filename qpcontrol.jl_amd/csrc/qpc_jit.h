@@ -1,0 +1,11 @@
+// qpc_jit.h -- JIT specialisation of the tick kernel on the frozen task program (hiprtc).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "qpc_program.h"
+
+// source of the specialised translation unit (QpcDims baked in as a constexpr object)
+std::string qpc_jit_source(const QpcDims &D);
+// compile for `arch` (e.g. "gfx950"); returns 0 and fills `code` on success, else fills `log`
+int qpc_jit_compile(const QpcDims &D, const std::string &arch, std::vector<char> &code, std::string &log);

@@ -5,7 +5,9 @@
 // The program is what the reference builds lazily as Parametron Parameters / LazyExpressions at
 // addtask!/addcontact!/initialize! time (momentum.jl:99-193); here it is frozen at qpc_finalize.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <stdint.h>
+#endif
 
 // integer tables (offsets into the int blob)
 enum {
@@ -54,6 +56,7 @@ enum {
   L_W, L_WINV,           // sum dim^2 over soft generic tasks
   L_SM,                  // m * ms  Schur complement / its Cholesky factor (lower)
   L_X,                   // m1 * m1s explicit inverse of L11
+  L_X2,                  // m1 * 6  Z = S11^-1 S12
   L_B22, L_C22, L_L22, L_S22I, // 36 each
   L_G,                   // 6 * nrho
   L_Y,                   // nrho * 6

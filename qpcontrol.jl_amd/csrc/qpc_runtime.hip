@@ -14,13 +14,13 @@
 #include <vector>
 
 #include "qpc_compile.h"
+#include "qpc_jit.h"
 
-#define QPC_FN __device__ __forceinline__
-#define QPC_PHASE(lane) { const int lane = (int)(threadIdx.x & 63);
-#define QPC_END_PHASE } __syncthreads();
-#define QPC_SINCOS(x, s, c) sincos((x), &(s), &(c))
-#define QPC_SQRT(x) sqrt((double)(x))
-#define QPC_FABS(x) fabs((double)(x))
+#include "qpc_device.h"
+#ifdef QPC_STAMPS
+#define QPC_PROF_T0() do { *PT = clock64(); } while (0)
+#define QPC_PROF_ACC(i) do { unsigned long long n__ = clock64(); PA[i] += n__ - *PT; *PT = n__; } while (0)
+#endif
 #include "qpc_tick.h"
 
 struct QpcBatchArgs {
@@ -28,6 +28,7 @@ struct QpcBatchArgs {
   const double *q, *v, *desired, *cw, *cmax, *tw, *surf;
   double *tau, *vdot, *cwrench;
   int32_t *status, *iters;
+  unsigned long long *prof;
 };
 
 extern "C" __global__ void __launch_bounds__(64)
@@ -42,6 +43,7 @@ qpc_tick_kernel(const QpcDims D, const int *__restrict__ IT, const double *__res
     io.tau = A.tau + b * D.nv; io.vdot = A.vdot + b * D.nv;
     io.cwrench = A.cwrench ? A.cwrench + b * 6 * D.nc : nullptr;
     io.status = A.status + b; io.iters = A.iters ? A.iters + b : nullptr;
+    io.prof = A.prof ? A.prof + b * PS_COUNT : nullptr;
     qpc::qpc_tick<double *>(D, IT, DT, qpc_lds, io);
     __syncthreads(); // the slab is reused by the next QP of this workgroup
   }
@@ -61,6 +63,10 @@ struct QpcDeviceState {
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   std::vector<hipEvent_t> pool;
+  unsigned long long *prof = nullptr; // PS_COUNT cycle counters per QP (diagnostic builds only)
+  // JIT-specialised kernel (qpc_jit.cpp); null -> the generic ahead-of-time kernel is launched
+  hipModule_t jit_module = nullptr;
+  hipFunction_t jit_func = nullptr;
 };
 
 static int hip_fail(hipError_t e, const char *what) {
@@ -85,8 +91,16 @@ static int launch(qpc_controller *c, const QpcBatchArgs &a, hipStream_t stream) 
     HIP_TRY(get(e0)); HIP_TRY(get(e1));
     HIP_TRY(hipEventRecord(e0, stream));
   }
-  hipLaunchKernelGGL(qpc_tick_kernel, dim3((unsigned)grid), dim3(64), lds, stream, D, S->d_it, S->d_dt, a);
-  HIP_TRY(hipGetLastError());
+  if (S->jit_func) {
+    const int *it = S->d_it;
+    const double *dt = S->d_dt;
+    QpcBatchArgs aa = a;
+    void *args[] = {(void *)&it, (void *)&dt, (void *)&aa};
+    HIP_TRY(hipModuleLaunchKernel(S->jit_func, (unsigned)grid, 1, 1, 64, 1, 1, 0, stream, args, nullptr));
+  } else {
+    hipLaunchKernelGGL(qpc_tick_kernel, dim3((unsigned)grid), dim3(64), lds, stream, D, S->d_it, S->d_dt, a);
+    HIP_TRY(hipGetLastError());
+  }
   if (S->timing) {
     HIP_TRY(hipEventRecord(e1, stream));
     S->events.emplace_back(e0, e1);
@@ -129,6 +143,26 @@ int32_t qpc_finalize(qpc_controller *c, int32_t device_id, qpc_layout *out) {
   HIP_TRY(hipMemcpy(S->d_it, c->prog.itab.data(), sizeof(int) * c->prog.itab.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(S->d_dt, c->prog.dtab.data(), sizeof(double) * c->prog.dtab.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipStreamCreate(&S->stream));
+  // JIT specialisation on this controller's program (QPC_DISABLE_JIT=1 keeps the generic kernel)
+  const char *nojit = getenv("QPC_DISABLE_JIT");
+  if (!(nojit && nojit[0] == '1')) {
+    std::vector<char> code;
+    std::string log;
+    std::string arch = prop.gcnArchName;
+    int jrc = qpc_jit_compile(D, arch, code, log);
+    if (jrc == 0 && hipModuleLoadData(&S->jit_module, code.data()) == hipSuccess &&
+        hipModuleGetFunction(&S->jit_func, S->jit_module, "qpc_tick_kernel_jit") == hipSuccess) {
+      // specialised kernel ready
+    } else {
+      S->jit_func = nullptr;
+      const char *strict = getenv("QPC_REQUIRE_JIT");
+      if (strict && strict[0] == '1') {
+        qpc_set_error("JIT specialisation failed: " + log);
+        return QPC_ERR_HIP;
+      }
+      fprintf(stderr, "[qpc] JIT specialisation unavailable (%s); using the generic gfx950 kernel\n", log.c_str());
+    }
+  }
   c->dev = S;
   c->finalized = true;
   if (out) *out = c->layout;
@@ -147,6 +181,7 @@ void qpc_controller_destroy(qpc_controller *c) {
     if (S->d_dt) (void)hipFree(S->d_dt);
     if (S->stage) (void)hipFree(S->stage);
     if (S->stream) (void)hipStreamDestroy(S->stream);
+    if (S->jit_module) (void)hipModuleUnload(S->jit_module);
     delete S;
   }
   delete c;
@@ -165,6 +200,7 @@ int32_t qpc_control_batch_device(qpc_controller *c, int64_t B, const double *q, 
   QpcBatchArgs a;
   a.B = B; a.q = q; a.v = v; a.desired = desired; a.cw = cw; a.cmax = cmax; a.tw = tw; a.surf = surf;
   a.tau = tau; a.vdot = vdot; a.cwrench = cwrench; a.status = status; a.iters = iters;
+  a.prof = c->dev->prof;
   HIP_TRY(hipSetDevice(c->dev->device));
   return launch(c, a, (hipStream_t)hip_stream);
 }
@@ -211,6 +247,7 @@ int32_t qpc_control_batch(qpc_controller *c, int64_t B, const double *q, const d
   QpcBatchArgs a;
   a.B = B; a.q = din[0]; a.v = din[1]; a.desired = din[2]; a.cw = din[3]; a.cmax = din[4]; a.tw = din[5]; a.surf = din[6];
   a.tau = dout[0]; a.vdot = dout[1]; a.cwrench = D.nc ? dout[2] : nullptr; a.status = dstatus; a.iters = diters;
+  a.prof = S->prof;
   int rc = launch(c, a, S->stream);
   if (rc != QPC_OK) return rc;
   for (int i = 0; i < 3; i++) {
@@ -231,6 +268,15 @@ int32_t qpc_qp_solve_batch(int32_t n, int32_t m, int64_t B, const double *P, con
   qpc_set_error("qpc_qp_solve_batch (L0 raw dense QPs) is not implemented in this round; use qpc_control_batch");
   return QPC_ERR_UNSUPPORTED;
 }
+
+// diagnostic (QPC_STAMPS builds): device buffer of B*PS_COUNT uint64 section cycle counters
+int32_t qpc_debug_set_profile_buffer(qpc_controller *c, void *device_buffer) {
+  if (!c || !c->dev) return QPC_ERR_NOT_FINALIZED;
+  c->dev->prof = (unsigned long long *)device_buffer;
+  return QPC_OK;
+}
+
+int32_t qpc_debug_jit_active(qpc_controller *c) { return (c && c->dev && c->dev->jit_func) ? 1 : 0; }
 
 int32_t qpc_timing_enable(qpc_controller *c, int32_t enable) {
   if (!c || !c->dev) return QPC_ERR_NOT_FINALIZED;

@@ -25,6 +25,13 @@
 #include "../../include/qpc.h"
 #include "qpc_program.h"
 
+// optional in-kernel section timers (diagnostic build only: -DQPC_STAMPS in qpc_runtime.hip)
+#ifndef QPC_PROF_ACC
+#define QPC_PROF_T0()
+#define QPC_PROF_ACC(i)
+#endif
+enum { PS_KIN, PS_ASM, PS_SBUILD, PS_CHOL, PS_XINV, PS_REFAC, PS_RESID, PS_KKT, PS_UPDATE, PS_LOGIC, PS_FINAL, PS_RNEA, PS_COUNT };
+
 namespace qpc {
 
 // ------------------------------------------------------------------------------------------
@@ -120,6 +127,90 @@ template <class P> QPC_FN void spd_inverse_inplace(P a, int n) {
   }
 }
 
+
+// (H_FF + eps I)^-1 of one contact's N x N rho block on its free set, in registers.
+// NB >= N is a compile-time bound so that the Gauss-Jordan sweep fully unrolls.
+template <int NB, class P> QPC_FN void kr_block(P sm, const QpcDims &D, int c, double eps) {
+  const int N = D.N;
+  double a[NB][NB];
+  bool fr[NB];
+#pragma unroll
+  for (int i = 0; i < NB; i++) fr[i] = (i < N) && (sm[D.lds[L_WS] + c * N + (i < N ? i : 0)] == 0.0);
+#pragma unroll
+  for (int i = 0; i < NB; i++)
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+      double h = (i < N && j < N) ? (double)sm[D.lds[L_HR] + c * N * N + (i < N ? i : 0) * N + (j < N ? j : 0)] : 0.0;
+      a[i][j] = (fr[i] && fr[j]) ? h + (i == j ? eps : 0.0) : (i == j ? 1.0 : 0.0);
+    }
+#pragma unroll
+  for (int k = 0; k < NB; k++) {
+    double piv = 1.0 / a[k][k];
+    a[k][k] = 1.0;
+#pragma unroll
+    for (int j = 0; j < NB; j++) a[k][j] *= piv;
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+      if (i == k) continue;
+      double f = a[i][k];
+      a[i][k] = 0.0;
+#pragma unroll
+      for (int j = 0; j < NB; j++) a[i][j] -= f * a[k][j];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NB; i++)
+#pragma unroll
+    for (int j = 0; j < NB; j++)
+      if (i < N && j < N) sm[D.lds[L_KR] + c * N * N + i * N + j] = (fr[i] && fr[j]) ? a[i][j] : 0.0;
+}
+
+// T = S^-1 of a symmetric 6x6 (infinite-pivot Cholesky: a dependent row gets a zero row/column in
+// T), all in registers of ONE lane.  `sref[k]` is the reference (unreduced) diagonal for the test.
+template <class P> QPC_FN void inv6_spd(P Sin, const double *sref, double tau, P Tout) {
+  double L[6][6], X[6][6], invd[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = 0; j < 6; j++) { L[i][j] = (j <= i) ? (double)Sin[i * 6 + j] : 0.0; X[i][j] = 0.0; }
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    double d = L[k][k];
+#pragma unroll
+    for (int j = 0; j < k; j++) d -= L[k][j] * L[k][j];
+    bool ok = d > tau * (sref[k] > 1e-300 ? sref[k] : 1e-300);
+    double ld_ = ok ? QPC_SQRT(d) : 0.0;
+    invd[k] = ok ? 1.0 / ld_ : 0.0;
+    L[k][k] = ld_;
+#pragma unroll
+    for (int i = k + 1; i < 6; i++) {
+      double t = L[i][k];
+#pragma unroll
+      for (int j = 0; j < k; j++) t -= L[i][j] * L[k][j];
+      L[i][k] = t * invd[k];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 6; c++)
+#pragma unroll
+    for (int r = c; r < 6; r++) {
+      double t = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+      for (int j = c; j < r; j++) t -= L[r][j] * X[j][c];
+      X[r][c] = t * invd[r];
+    }
+#pragma unroll
+  for (int a = 0; a < 6; a++)
+#pragma unroll
+    for (int b = 0; b <= a; b++) {
+      double t = 0.0;
+#pragma unroll
+      for (int k = a; k < 6; k++) t += X[k][a] * X[k][b];
+      Tout[a * 6 + b] = t;
+      if (a != b) Tout[b * 6 + a] = t;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // per-QP global-memory records
 // ------------------------------------------------------------------------------------------
@@ -127,6 +218,7 @@ struct TickIO {
   const double *q, *v, *desired, *cw, *cmax, *tw, *surf;
   double *tau, *vdot, *cwrench;
   int32_t *status, *iters;
+  unsigned long long *prof; // PS_COUNT section cycle counters (diagnostic build) or nullptr
 };
 
 // ------------------------------------------------------------------------------------------
@@ -138,37 +230,31 @@ template <class P> struct Solver {
   const double *DT;
   P sm;
   bool use_rho;
-  QPC_FN Solver(const QpcDims &d, const int *it, const double *dt, P s) : D(d), IT(it), DT(dt), sm(s), use_rho(d.nrho > 0) {}
+  unsigned long long *PA, *PT; // section timers (diagnostic build)
+  QPC_FN Solver(const QpcDims &d, const int *it, const double *dt, P s, unsigned long long *pa, unsigned long long *pt)
+      : D(d), IT(it), DT(dt), sm(s), use_rho(d.nrho > 0), PA(pa), PT(pt) {}
 
-  // Kr (block inverse of Hrho+eps on the free set), C22 = G Kr G', L22/S22I from B22 + C22
+  // Kr (block inverse of Hrho+eps on the free set), S22 = B22 + G Kr G', T22 = S22^-1
   QPC_FN void refactor_rho() {
     const int N = D.N, nc = D.nc, nrho = D.nrho, m1 = D.m1;
     const double eps = sm[D.lds[L_MISC] + MS_EPS];
     if (!use_rho && D.nw == 0) return;
-    QPC_PHASE(lane) {
-      if (use_rho)
+    QPC_PROF_ACC(PS_LOGIC);
+    if (use_rho) {
+      QPC_PHASE(lane) {
         for (int c = lane; c < nc; c += 64) {
-          P K = sm + D.lds[L_KR] + c * N * N;
-          for (int i = 0; i < N; i++)
-            for (int j = 0; j < N; j++) {
-              bool fi = sm[D.lds[L_WS] + c * N + i] == 0.0, fj = sm[D.lds[L_WS] + c * N + j] == 0.0;
-              double h = sm[D.lds[L_HR] + c * N * N + i * N + j];
-              K[i * N + j] = (fi && fj) ? h + (i == j ? eps : 0.0) : (i == j ? 1.0 : 0.0);
-            }
-          spd_inverse_inplace(K, N);
-          for (int i = 0; i < N; i++)
-            if (sm[D.lds[L_WS] + c * N + i] != 0.0) K[i * N + i] = 0.0;
+          if (N <= 4) kr_block<4>(sm, D, c, eps); else kr_block<8>(sm, D, c, eps);
         }
-    } QPC_END_PHASE
-    QPC_PHASE(lane) {
-      if (use_rho)
+      } QPC_END_PHASE
+      QPC_PHASE(lane) {
         for (int idx = lane; idx < nrho * 6; idx += 64) {
           int j = idx / 6, b = idx % 6, c = j / N, jj = j % N;
           double acc = 0.0;
           for (int i = 0; i < N; i++) acc += sm[D.lds[L_KR] + c * N * N + jj * N + i] * sm[D.lds[L_G] + b * nrho + c * N + i];
           sm[D.lds[L_Y] + j * 6 + b] = acc;
         }
-    } QPC_END_PHASE
+      } QPC_END_PHASE
+    }
     QPC_PHASE(lane) {
       if (lane < 36) {
         int a = lane / 6, b = lane % 6;
@@ -180,84 +266,41 @@ template <class P> struct Solver {
     } QPC_END_PHASE
     QPC_PHASE(lane) {
       if (lane == 0) {
-        // 6x6 Cholesky with the infinite-pivot rule, then S22I = (L L')^-1 via L^-1
-        P Lm = sm + D.lds[L_L22];
-        P Sm = sm + D.lds[L_C22];
-        double invd[6];
-        for (int k = 0; k < 6; k++) {
-          double d = Sm[k * 6 + k];
-          for (int j = 0; j < k; j++) d -= Lm[k * 6 + j] * Lm[k * 6 + j];
-          double ref = sm[D.lds[L_SM] + (m1 + k) * D.ms + (m1 + k)] + (Sm[k * 6 + k] - sm[D.lds[L_B22] + k * 6 + k]);
-          bool ok = d > D.tau_pivot * (ref > 1e-300 ? ref : 1e-300);
-          double ld_ = ok ? QPC_SQRT(d) : 0.0;
-          invd[k] = ok ? 1.0 / ld_ : 0.0;
-          Lm[k * 6 + k] = ld_;
-          for (int i = k + 1; i < 6; i++) {
-            double t = Sm[i * 6 + k];
-            for (int j = 0; j < k; j++) t -= Lm[i * 6 + j] * Lm[k * 6 + j];
-            Lm[i * 6 + k] = t * invd[k];
-          }
-          for (int i = 0; i < k; i++) Lm[i * 6 + k] = 0.0;
-        }
-        // X = L^-1 (lower), stored temporarily in C22
-        for (int c = 0; c < 6; c++)
-          for (int r = 0; r < 6; r++) {
-            double t = (r == c) ? 1.0 : 0.0;
-            if (r < c) { Sm[r * 6 + c] = 0.0; continue; }
-            for (int j = c; j < r; j++) t -= Lm[r * 6 + j] * Sm[j * 6 + c];
-            Sm[r * 6 + c] = t * invd[r];
-          }
-        for (int a = 0; a < 6; a++)
-          for (int b = 0; b < 6; b++) {
-            double t = 0.0;
-            for (int k = (a > b ? a : b); k < 6; k++) t += Sm[k * 6 + a] * Sm[k * 6 + b];
-            sm[D.lds[L_S22I] + a * 6 + b] = t;
-          }
+        double sref[6];
+        for (int k = 0; k < 6; k++)
+          sref[k] = sm[D.lds[L_SM] + (m1 + k) * D.ms + (m1 + k)] + (sm[D.lds[L_C22] + k * 6 + k] - sm[D.lds[L_B22] + k * 6 + k]);
+        inv6_spd(sm + D.lds[L_C22], sref, D.tau_pivot, sm + D.lds[L_S22I]);
       }
     } QPC_END_PHASE
+    QPC_PROF_ACC(PS_REFAC);
   }
 
-  // lam = S^-1 t   (t in L_T1, result in `out`), using X = L11^-1, L21 (rows m1.. of L_SM), S22I
+  // lam = S^-1 t (t in L_T1, result in `out`) through the block inverse:
+  //   lam2 = T22 (t2 - Z' t1) ;  lam1 = S11I t1 - Z lam2     (S11I in the leading block of L_SM,
+  //   Z = S11^-1 S12 in L_X2, T22 = (B22 + C22)^-1 in L_S22I) -- two phases, no serial chain.
   QPC_FN void solve_S(int out) {
     const int m1 = D.m1, nw = D.nw;
-    QPC_PHASE(lane) {
-      for (int r = lane; r < m1; r += 64) {
-        double acc = 0.0;
-        for (int c = 0; c <= r; c++) acc += sm[D.lds[L_X] + r * D.m1s + c] * sm[D.lds[L_T1] + c];
-        sm[D.lds[L_T2] + r] = acc; // y1
-      }
-    } QPC_END_PHASE
     if (nw) {
       QPC_PHASE(lane) {
         if (lane < 6) {
-          double acc = sm[D.lds[L_T1] + m1 + lane];
-          for (int j = 0; j < m1; j++) acc -= sm[D.lds[L_SM] + (m1 + lane) * D.ms + j] * sm[D.lds[L_T2] + j];
-          sm[D.lds[L_T2] + m1 + lane] = acc;
-        }
-      } QPC_END_PHASE
-      QPC_PHASE(lane) {
-        if (lane < 6) {
+          double u[6];
+          for (int b = 0; b < 6; b++) u[b] = sm[D.lds[L_T1] + m1 + b];
+          for (int r = 0; r < m1; r++) {
+            double t = sm[D.lds[L_T1] + r];
+            for (int b = 0; b < 6; b++) u[b] -= sm[D.lds[L_X2] + r * 6 + b] * t;
+          }
           double acc = 0.0;
-          for (int b = 0; b < 6; b++) acc += sm[D.lds[L_S22I] + lane * 6 + b] * sm[D.lds[L_T2] + m1 + b];
-          sm[out + m1 + lane] = acc; // lam2
+          for (int b = 0; b < 6; b++) acc += sm[D.lds[L_S22I] + lane * 6 + b] * u[b];
+          sm[out + m1 + lane] = acc;
         }
-      } QPC_END_PHASE
-      QPC_PHASE(lane) {
-        for (int r = lane; r < m1; r += 64) {
-          double acc = sm[D.lds[L_T2] + r];
-          for (int a = 0; a < 6; a++) acc -= sm[D.lds[L_SM] + (m1 + a) * D.ms + r] * sm[out + m1 + a];
-          sm[D.lds[L_T3] + r] = acc; // z1
-        }
-      } QPC_END_PHASE
-    } else {
-      QPC_PHASE(lane) {
-        for (int r = lane; r < m1; r += 64) sm[D.lds[L_T3] + r] = sm[D.lds[L_T2] + r];
       } QPC_END_PHASE
     }
     QPC_PHASE(lane) {
       for (int r = lane; r < m1; r += 64) {
         double acc = 0.0;
-        for (int c = r; c < m1; c++) acc += sm[D.lds[L_X] + c * D.m1s + r] * sm[D.lds[L_T3] + c];
+        for (int c = 0; c < m1; c++) acc += sm[D.lds[L_SM] + r * D.ms + c] * sm[D.lds[L_T1] + c];
+        if (nw)
+          for (int a = 0; a < 6; a++) acc -= sm[D.lds[L_X2] + r * 6 + a] * sm[out + m1 + a];
         sm[out + r] = acc;
       }
     } QPC_END_PHASE
@@ -267,6 +310,7 @@ template <class P> struct Solver {
   // result in L_DV (scaled: dx_v / sqh), L_DE, L_DR, L_DL.
   QPC_FN void kkt_solve() {
     const int N = D.N, nf = D.nf, ne = D.ne, nrho = D.nrho, m = D.m, m1 = D.m1;
+    QPC_PROF_ACC(PS_LOGIC);
     QPC_PHASE(lane) {
       if (use_rho)
         for (int j = lane; j < nrho; j += 64) {
@@ -332,12 +376,14 @@ template <class P> struct Solver {
           sm[D.lds[L_DR] + j] = acc;
         }
     } QPC_END_PHASE
+    QPC_PROF_ACC(PS_KKT);
   }
 
   // true (unregularised) KKT residuals of the EQP on the working set -> L_RV/L_RE/L_RR/L_RC;
   // Lagrangian gradient w.r.t. rho -> L_TR1
   QPC_FN void residuals() {
     const int N = D.N, nf = D.nf, ne = D.ne, nrho = D.nrho, m = D.m, m1 = D.m1;
+    QPC_PROF_ACC(PS_LOGIC);
     QPC_PHASE(lane) {
       for (int r = lane; r < m; r += 64) {
         double acc = sm[D.lds[L_D] + r];
@@ -375,6 +421,7 @@ template <class P> struct Solver {
           sm[D.lds[L_RR] + j] = (sm[D.lds[L_WS] + j] == 0.0) ? -gl : 0.0;
         }
     } QPC_END_PHASE
+    QPC_PROF_ACC(PS_RESID);
   }
 
   // EQP of the current working set from scratch + `refine` iterative-refinement sweeps
@@ -390,6 +437,7 @@ template <class P> struct Solver {
     for (;; it++) {
       residuals();
       kkt_solve();
+      double rbig = 0.0, rdbig = 0.0;
       QPC_PHASE(lane) {
         double big = 0.0, dbig = 0.0;
         for (int f = lane; f < nf; f += 64) {
@@ -412,20 +460,21 @@ template <class P> struct Solver {
           dbig = QPC_FABS(dx) > dbig ? QPC_FABS(dx) : dbig;
         }
         for (int r = lane; r < m; r += 64) sm[D.lds[L_LAM] + r] = sm[D.lds[L_LAM] + r] + sm[D.lds[L_DL] + r];
-        sm[D.lds[L_RED] + lane] = big;
-        sm[D.lds[L_RED] + 64 + lane] = dbig;
+        if (refine > 0) { QPC_RED_MAX_PUT(0, rbig, big); QPC_RED_MAX_PUT(1, rdbig, dbig); }
       } QPC_END_PHASE
+      QPC_PROF_ACC(PS_UPDATE);
       if (it >= refine) break;
-      double big = umax(sm, D.lds[L_RED], 64), dbig = umax(sm, D.lds[L_RED] + 64, 64);
-      if (it > 0 && !(dbig > 1e-13 * (1.0 + big))) break;
+      rbig = QPC_RED_MAX_GET(0, rbig); rdbig = QPC_RED_MAX_GET(1, rdbig);
+      if (it > 0 && !(rdbig > 1e-13 * (1.0 + rbig))) break;
     }
     return it;
   }
 
   // multipliers of the bound constraints from the rho-gradient in L_TR1 (residuals() just ran)
-  // -> L_U ; partial maxima for gscale / xr scale -> L_RED
-  QPC_FN void multipliers() {
+  // -> L_U ; returns max |gradient| and max |rho| (uniform) for the tolerances
+  QPC_FN void multipliers(double &gmax, double &xmax) {
     const int nrho = D.nrho;
+    double rg = 0.0, rx = 0.0;
     QPC_PHASE(lane) {
       double g = 0.0, x = 0.0;
       for (int j = lane; j < nrho; j += 64) {
@@ -435,9 +484,11 @@ template <class P> struct Solver {
         double xr = QPC_FABS(sm[D.lds[L_XR] + j]);
         x = xr > x ? xr : x;
       }
-      sm[D.lds[L_RED] + lane] = g;
-      sm[D.lds[L_RED] + 64 + lane] = x;
+      QPC_RED_MAX_PUT(0, rg, g);
+      QPC_RED_MAX_PUT(1, rx, x);
     } QPC_END_PHASE
+    gmax = QPC_RED_MAX_GET(0, rg);
+    xmax = QPC_RED_MAX_GET(1, rx);
   }
 };
 
@@ -454,6 +505,11 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
   const int *anc_ptr = IT + D.it[IT_ANC_PTR], *anc_idx = IT + D.it[IT_ANC_IDX];
   const int *desc_ptr = IT + D.it[IT_DESC_PTR], *desc_idx = IT + D.it[IT_DESC_IDX];
   (void)parent;
+  unsigned long long prof_acc_[PS_COUNT], prof_t_ = 0;
+  for (int i = 0; i < PS_COUNT; i++) prof_acc_[i] = 0;
+  unsigned long long *PA = prof_acc_, *PT = &prof_t_;
+  (void)PA; (void)PT;
+  QPC_PROF_T0();
 
   // ======================================================================== inputs -> LDS
   QPC_PHASE(lane) {
@@ -631,20 +687,26 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
     }
   } QPC_END_PHASE
 
-  // regularisation scale (uniform): eps = eps_primal * max diagonal of the Hessian
+  QPC_PROF_ACC(PS_KIN);
+  // regularisation scale: eps = eps_primal * max diagonal of the Hessian
   double hscale = 0.0;
-  for (int f = 0; f < nf; f++) { double a = QPC_FABS(sm[D.lds[L_HV] + f]); hscale = a > hscale ? a : hscale; }
-  for (int t = 0; t < ntask; t++) {
-    int w0 = IT[D.it[IT_T_WOFF] + t];
-    if (w0 < 0) continue;
-    int d = IT[D.it[IT_T_DIM] + t];
-    for (int a = 0; a < d; a++) { double w = QPC_FABS(sm[D.lds[L_W] + w0 + a * d + a]); hscale = w > hscale ? w : hscale; }
-  }
-  if (use_rho)
-    for (int c = 0; c < nc; c++) {
-      double w = (sm[D.lds[L_CMAX] + c] > 0.0) ? 2.0 * QPC_FABS(sm[D.lds[L_CW] + c]) : 0.0;
-      hscale = w > hscale ? w : hscale;
+  QPC_PHASE(lane) {
+    double h = 0.0;
+    for (int f = lane; f < nf; f += 64) { double a = QPC_FABS(sm[D.lds[L_HV] + f]); h = a > h ? a : h; }
+    for (int t = lane; t < ntask; t += 64) {
+      int w0 = IT[D.it[IT_T_WOFF] + t];
+      if (w0 < 0) continue;
+      int d = IT[D.it[IT_T_DIM] + t];
+      for (int a = 0; a < d; a++) { double w = QPC_FABS(sm[D.lds[L_W] + w0 + a * d + a]); h = w > h ? w : h; }
     }
+    if (use_rho)
+      for (int c = lane; c < nc; c += 64) {
+        double w = (sm[D.lds[L_CMAX] + c] > 0.0) ? 2.0 * QPC_FABS(sm[D.lds[L_CW] + c]) : 0.0;
+        h = w > h ? w : h;
+      }
+    QPC_RED_MAX_PUT(0, hscale, h);
+  } QPC_END_PHASE
+  hscale = QPC_RED_MAX_GET(0, hscale);
   if (!(hscale > 0.0)) hscale = 1.0;
   const double eps = D.eps_primal * hscale;
 
@@ -823,6 +885,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       }
   } QPC_END_PHASE
 
+  QPC_PROF_ACC(PS_ASM);
   // ======================================================================== Schur complement S = M M' + W^-1 blocks
   QPC_PHASE(lane) {
     for (int idx = lane; idx < m * m; idx += 64) {
@@ -838,6 +901,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       sm[D.lds[L_SM] + r * D.ms + c] = acc;
     }
   } QPC_END_PHASE
+  QPC_PROF_ACC(PS_SBUILD);
   // left-looking Cholesky of the leading m1 x m1 block (+ the L21 rows), infinite-pivot rule
   for (int k = 0; k < m1; k++) {
     QPC_PHASE(lane) {
@@ -856,6 +920,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       }
     } QPC_END_PHASE
   }
+  QPC_PROF_ACC(PS_CHOL);
   QPC_PHASE(lane) { // B22 = S22 - L21 L21' ; X = L11^-1 (lane = column, private forward substitution)
     if (lane < 36 && nw) {
       int a = lane / 6, b = lane % 6, hi_ = a > b ? a : b, lo_ = a > b ? b : a;
@@ -871,8 +936,25 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       }
   } QPC_END_PHASE
 
+  QPC_PHASE(lane) { // S11I = X'X into the (now free) leading block of L_SM ; Z = X' L21' = S11^-1 S12
+    for (int idx = lane; idx < m1 * m1; idx += 64) {
+      int r = idx / m1, c = idx % m1;
+      int k0 = r > c ? r : c;
+      double acc = 0.0;
+      for (int k = k0; k < m1; k++) acc += sm[D.lds[L_X] + k * D.m1s + r] * sm[D.lds[L_X] + k * D.m1s + c];
+      sm[D.lds[L_SM] + r * D.ms + c] = acc;
+    }
+    if (nw)
+      for (int idx = lane; idx < m1 * 6; idx += 64) {
+        int r = idx / 6, a = idx % 6;
+        double acc = 0.0;
+        for (int k = r; k < m1; k++) acc += sm[D.lds[L_X] + k * D.m1s + r] * sm[D.lds[L_SM] + (m1 + a) * D.ms + k];
+        sm[D.lds[L_X2] + idx] = acc;
+      }
+  } QPC_END_PHASE
+  QPC_PROF_ACC(PS_XINV);
   // ======================================================================== active-set solve (a13)
-  Solver<P> S(D, IT, DT, sm);
+  Solver<P> S(D, IT, DT, sm, PA, PT);
   int status = QPC_STATUS_OPTIMAL, iters = 0;
   S.refactor_rho();
   S.eqp(0);
@@ -880,8 +962,10 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
     // ---- phase A: primal-dual active-set sweeps (multi-change)
     for (int pd = 0; pd < D.max_pdas; pd++) {
       S.residuals();
-      S.multipliers();
-      double gscale = 1.0 + umax(sm, D.lds[L_RED], 64), tolb = D.tol_bound * (1.0 + umax(sm, D.lds[L_RED] + 64, 64));
+      double gmax, xmax;
+      S.multipliers(gmax, xmax);
+      const double gscale = 1.0 + gmax, tolb = D.tol_bound * (1.0 + xmax);
+      double rchg = 0.0;
       QPC_PHASE(lane) {
         double changed = 0.0;
         for (int j = lane; j < nrho; j += 64) {
@@ -892,9 +976,10 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
           else if (x > hi + tolb) nw_ = 1.0;
           if (nw_ != w) { sm[D.lds[L_WS] + j] = nw_; changed = 1.0; }
         }
-        sm[D.lds[L_RED] + 128 + lane] = changed;
+        QPC_RED_MAX_PUT(0, rchg, changed);
       } QPC_END_PHASE
-      if (!(umax(sm, D.lds[L_RED] + 128, 64) > 0.0)) break;
+      rchg = QPC_RED_MAX_GET(0, rchg);
+      if (!(rchg > 0.0)) break;
       iters++;
       S.refactor_rho();
       S.eqp(0);
@@ -903,19 +988,32 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
     while (true) {
       if (iters > D.max_as_iters) { status = QPC_STATUS_ITERATION_LIMIT; break; }
       S.residuals();
-      S.multipliers();
-      double gscale = 1.0 + umax(sm, D.lds[L_RED], 64), tolb = D.tol_bound * (1.0 + umax(sm, D.lds[L_RED] + 64, 64));
-      // most negative multiplier / most violated bound (uniform scans)
+      double gmax, xmax;
+      S.multipliers(gmax, xmax);
+      const double gscale = 1.0 + gmax, tolb = D.tol_bound * (1.0 + xmax);
+      // most negative multiplier / most violated bound (lane-parallel + wave argmin)
+      double ubad = 0.0, vneg = 0.0, rnan = 0.0;
       int jbad = -1, pviol = -1;
-      double ubad = -D.tol_bound * gscale, vmax = tolb;
-      bool finite = true;
-      for (int j = 0; j < nrho; j++) {
-        double w = sm[D.lds[L_WS] + j], hi = sm[D.lds[L_HI] + j], x = sm[D.lds[L_XR] + j];
-        if (!(x == x) || QPC_FABS(x) > 1e300) finite = false;
-        if (!(hi > 0.0)) continue;
-        if (w != 0.0) { double u = sm[D.lds[L_U] + j]; if (u < ubad) { ubad = u; jbad = j; } }
-        else { double vl = -x > x - hi ? -x : x - hi; if (vl > vmax) { vmax = vl; pviol = j; } }
-      }
+      QPC_PHASE(lane) {
+        double bu = 1e300, bv = 1e300, bad = 0.0;
+        int ju = 0x3fffffff, jv = 0x3fffffff;
+        for (int j = lane; j < nrho; j += 64) {
+          double w = sm[D.lds[L_WS] + j], hi = sm[D.lds[L_HI] + j], x = sm[D.lds[L_XR] + j];
+          if (!(x == x) || QPC_FABS(x) > 1e300) bad = 1.0;
+          if (!(hi > 0.0)) continue;
+          if (w != 0.0) { double u = sm[D.lds[L_U] + j]; if (u < bu) { bu = u; ju = j; } }
+          else { double vl = -x > x - hi ? -x : x - hi; if (-vl < bv) { bv = -vl; jv = j; } }
+        }
+        QPC_RED_ARGMIN_PUT(0, ubad, jbad, bu, ju);
+        QPC_RED_ARGMIN_PUT(1, vneg, pviol, bv, jv);
+        QPC_RED_MAX_PUT(2, rnan, bad);
+      } QPC_END_PHASE
+      QPC_RED_ARGMIN_GET(0, ubad, jbad);
+      QPC_RED_ARGMIN_GET(1, vneg, pviol);
+      rnan = QPC_RED_MAX_GET(2, rnan);
+      const bool finite = !(rnan > 0.0);
+      if (!(ubad < -D.tol_bound * gscale)) jbad = -1;
+      if (!(-vneg > tolb)) pviol = -1;
       if (!finite) { status = QPC_STATUS_NUMERICAL_ERROR; break; }
       if (jbad >= 0) {
         QPC_PHASE(lane) { if (lane == 0) sm[D.lds[L_WS] + jbad] = 0.0; } QPC_END_PHASE
@@ -939,6 +1037,8 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
           for (int j = lane; j < nrho; j += 64) sm[D.lds[L_RR] + j] = (j == p) ? nsign : 0.0;
         } QPC_END_PHASE
         S.kkt_solve();
+        double t1 = 1e300;
+        int jdrop = -1;
         QPC_PHASE(lane) { // dual direction r_j = -s_j (H_eff z)_j on the working set; step ratios
           double best = 1e300;
           double bestj = -1.0;
@@ -955,12 +1055,10 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
             }
             sm[D.lds[L_TR2] + j] = rj;
           }
-          sm[D.lds[L_RED] + lane] = best;
-          sm[D.lds[L_RED] + 64 + lane] = bestj;
+          QPC_RED_ARGMIN_PUT(0, t1, jdrop, best, bestj < 0.0 ? 0x3fffffff : (int)bestj);
         } QPC_END_PHASE
-        double t1 = 1e300;
-        int jdrop = -1;
-        for (int l = 0; l < 64; l++) { double b = sm[D.lds[L_RED] + l]; if (b < t1) { t1 = b; jdrop = (int)sm[D.lds[L_RED] + 64 + l]; } }
+        QPC_RED_ARGMIN_GET(0, t1, jdrop);
+        if (!(t1 < 1e299)) jdrop = -1;
         const double xp = sm[D.lds[L_XR] + p];
         const double sp = nsign * xp - (side < 0 ? 0.0 : -hip); // < 0 : violation
         const double zn = nsign * sm[D.lds[L_DR] + p];
@@ -986,11 +1084,13 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       if (fail) { if (status == QPC_STATUS_OPTIMAL) status = QPC_STATUS_ITERATION_LIMIT; break; }
     }
   }
+  QPC_PROF_ACC(PS_LOGIC);
   // ---- final refinement on the converged working set + acceptance test (a14)
   int refine = 0;
   if (status == QPC_STATUS_OPTIMAL) {
     refine = S.eqp(D.max_refine);
     S.residuals();
+    double arp = 0.0, ars = 0.0, asp = 0.0, ass = 0.0, anan = 0.0;
     QPC_PHASE(lane) {
       double rp = 0.0, rs = 0.0, sp = 0.0, ss = 0.0;
       for (int r = lane; r < m; r += 64) {
@@ -1007,22 +1107,20 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       }
       for (int s = lane; s < ne; s += 64) { double a = QPC_FABS(sm[D.lds[L_RE] + s]); rs = a > rs || !(a == a) ? a : rs; }
       for (int j = lane; j < nrho; j += 64) { double a = QPC_FABS(sm[D.lds[L_RR] + j]); rs = a > rs || !(a == a) ? a : rs; }
-      sm[D.lds[L_RED] + lane] = rp; sm[D.lds[L_RED] + 64 + lane] = rs;
-      sm[D.lds[L_RED] + 128 + lane] = sp; sm[D.lds[L_RED] + 192 + lane] = ss;
+      double bad = (!(rp == rp) || !(rs == rs)) ? 1.0 : 0.0;
+      QPC_RED_MAX_PUT(0, arp, rp == rp ? rp : 0.0); QPC_RED_MAX_PUT(1, ars, rs == rs ? rs : 0.0);
+      QPC_RED_MAX_PUT(2, asp, sp); QPC_RED_MAX_PUT(3, ass, ss); QPC_RED_MAX_PUT(4, anan, bad);
     } QPC_END_PHASE
-    double rp = 0.0, rs = 0.0;
-    bool nan = false;
-    for (int l = 0; l < 64; l++) {
-      double a = sm[D.lds[L_RED] + l], b = sm[D.lds[L_RED] + 64 + l];
-      if (!(a == a) || !(b == b)) nan = true;
-      rp = a > rp ? a : rp; rs = b > rs ? b : rs;
-    }
-    double r_prim = rp / (1.0 + umax(sm, D.lds[L_RED] + 128, 64)), r_stat = rs / (1.0 + umax(sm, D.lds[L_RED] + 192, 64));
+    arp = QPC_RED_MAX_GET(0, arp); ars = QPC_RED_MAX_GET(1, ars); asp = QPC_RED_MAX_GET(2, asp);
+    ass = QPC_RED_MAX_GET(3, ass); anan = QPC_RED_MAX_GET(4, anan);
+    const bool nan = anan > 0.0;
+    double r_prim = arp / (1.0 + asp), r_stat = ars / (1.0 + ass);
     if (nan || !(r_prim < 1e300) || !(r_stat < 1e300)) status = QPC_STATUS_NUMERICAL_ERROR;
     else if (r_prim > D.tol_accept) status = QPC_STATUS_INFEASIBLE; // equality rows inconsistent on the feasible set
     else if (r_stat > D.tol_accept) status = QPC_STATUS_ALMOST_OPTIMAL;
   }
 
+  QPC_PROF_ACC(PS_FINAL);
   // ======================================================================== extraction (a15) + RNEA (a16, a17)
   QPC_PHASE(lane) {
     for (int f = lane; f < nf; f += 64) sm[D.lds[L_VD] + IT[D.it[IT_FREE_K] + f]] = sm[D.lds[L_XV] + f] * sm[D.lds[L_SQH] + f];
@@ -1082,6 +1180,11 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       if (io.iters) io.iters[0] = iters + 1000 * refine;
     }
   } QPC_END_PHASE
+  QPC_PROF_ACC(PS_RNEA);
+#ifdef QPC_STAMPS
+  if (io.prof && (threadIdx.x & 63) == 0)
+    for (int i = 0; i < PS_COUNT; i++) io.prof[i] = prof_acc_[i];
+#endif
 }
 
 } // namespace qpc

@@ -64,6 +64,17 @@ struct Lds {
 #define QPC_SINCOS(x, s, c) do { double x__ = (x); s = std::sin(x__); c = std::cos(x__); } while (0)
 #define QPC_SQRT(x) std::sqrt((double)(x))
 #define QPC_FABS(x) std::fabs((double)(x))
+// reductions across a phase boundary: lane-serial form through the (emulator-only) scratch that
+// follows the kernel's LDS slab
+#define QPC_RED_MAX_PUT(slot, name, val) sm[D.lds_doubles + 128 * (slot) + lane] = (val)
+#define QPC_RED_MAX_GET(slot, name) qpc::umax(sm, D.lds_doubles + 128 * (slot), 64)
+#define QPC_RED_ARGMIN_PUT(slot, name, iname, val, idx) \
+  do { sm[D.lds_doubles + 128 * (slot) + lane] = (val); sm[D.lds_doubles + 128 * (slot) + 64 + lane] = (double)(idx); } while (0)
+#define QPC_RED_ARGMIN_GET(slot, name, iname) \
+  do { name = 1e308; iname = 0x3fffffff; \
+       for (int l__ = 0; l__ < 64; l__++) { double v__ = sm[D.lds_doubles + 128 * (slot) + l__]; \
+         int i__ = (int)(double)sm[D.lds_doubles + 128 * (slot) + 64 + l__]; \
+         if (v__ < name || (v__ == name && i__ < iname)) { name = v__; iname = i__; } } } while (0)
 #include "../../qpcontrol.jl_amd/csrc/qpc_tick.h"
 
 static long g_races = 0, g_uninit = 0, g_outside = 0;
@@ -92,13 +103,13 @@ int32_t qpc_control_batch(qpc_controller *c, int64_t B, const double *q, const d
   EmuState emu;
   g_emu = &emu;
   for (int64_t b = 0; b < B; b++) {
-    emu.reset(D.lds_doubles);
+    emu.reset(D.lds_doubles + 128 * 8);
     qpc::TickIO io;
     io.q = q + b * D.nq; io.v = v + b * D.nv; io.desired = desired ? desired + b * D.n_desired : nullptr;
     io.cw = cw ? cw + b * D.nc : nullptr; io.cmax = cmax ? cmax + b * D.nc : nullptr;
     io.tw = tw ? tw + b * D.n_tw : nullptr; io.surf = surf ? surf + b * D.n_surf : nullptr;
     io.tau = tau + b * D.nv; io.vdot = vdot + b * D.nv; io.cwrench = cwrench ? cwrench + b * 6 * D.nc : nullptr;
-    io.status = status + b; io.iters = iters ? iters + b : nullptr;
+    io.status = status + b; io.iters = iters ? iters + b : nullptr; io.prof = nullptr;
     qpc::qpc_tick<Lds>(D, c->prog.itab.data(), c->prog.dtab.data(), Lds{0}, io);
     g_races += emu.races; g_uninit += emu.uninit; g_outside += emu.outside;
     if (g_first.empty()) g_first = emu.first;
