@@ -21,12 +21,10 @@ def main():
     import qpc_pkg
     qpc_pkg.load()
     from qpcontrol_jl_amd import binding, workloads as W
-    lib = os.path.join(ROOT, "qpcontrol.jl_amd", "libqpcontrol_hip_stamps.so")
-    if not os.path.exists(lib) or "--rebuild" in sys.argv:
-        c = os.path.join(ROOT, "qpcontrol.jl_amd", "csrc")
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DQPC_STAMPS",
-                        "-o", lib, f"{c}/qpc_runtime.hip", "-x", "hip", f"{c}/qpc_compile.cpp", "-x", "hip",
-                        f"{c}/qpc_capi_build.cpp"], check=True)
+    # the JIT-specialised kernel is compiled with the timers when QPC_JIT_STAMPS=1
+    os.environ["QPC_JIT_STAMPS"] = "1"
+    os.environ["QPC_REQUIRE_JIT"] = "1"
+    lib = binding.DEFAULT_LIB
     cfg = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 3
     B = 8192
 

@@ -27,6 +27,7 @@ int qpc_task_dim(const qpc_model *m, int kind, int joint) {
 }
 
 namespace {
+inline int ntask_plus1_x6(const QpcDims &D) { return (D.ntask + 1) * 6; }
 struct Builder {
   std::vector<int> it;
   std::vector<double> dt;
@@ -200,6 +201,23 @@ int qpc_compile_program(qpc_controller *c) {
   for (size_t g = 0; g < generic.size(); g++) if (slack0[g] >= 0) for (int a = 0; a < c->tasks[generic[g]].dim; a++) B.it.push_back((int)g);
   B.ibegin(IT_SLACK_COMP);
   for (size_t g = 0; g < generic.size(); g++) if (slack0[g] >= 0) for (int a = 0; a < c->tasks[generic[g]].dim; a++) B.it.push_back(a);
+  B.ibegin(IT_HOT);
+  {
+    std::vector<int> row_slack(D.m, -1), srow, swoff, sdim, ss0;
+    for (size_t g = 0; g < generic.size(); g++) {
+      const QpcTask &t = c->tasks[generic[g]];
+      if (slack0[g] < 0) continue;
+      for (int a = 0; a < t.dim; a++) {
+        row_slack[row0[g] + a] = slack0[g] + a;
+        srow.push_back(row0[g] + a); swoff.push_back(woff[g] + a * t.dim); sdim.push_back(t.dim); ss0.push_back(slack0[g]);
+      }
+    }
+    B.it.insert(B.it.end(), row_slack.begin(), row_slack.end());
+    B.it.insert(B.it.end(), srow.begin(), srow.end());
+    B.it.insert(B.it.end(), swoff.begin(), swoff.end());
+    B.it.insert(B.it.end(), sdim.begin(), sdim.end());
+    B.it.insert(B.it.end(), ss0.begin(), ss0.end());
+  }
   B.it.push_back(0); // never empty
 
   // ---- double tables
@@ -233,27 +251,51 @@ int qpc_compile_program(qpc_controller *c) {
   B.dbegin(DT_C_MU); for (auto &k : c->contacts) B.dt.push_back(k.mu);
   B.dt.push_back(0.0);
 
-  // ---- LDS layout
-  int off = 0;
-  auto L = [&](int id, int n) { D.lds[id] = off; off += (n > 0 ? n : 0); off += off & 1; };
+  // ---- LDS layout with lifetime overlays (regions that are never live together share bytes):
+  //   [persistent | assembly outputs | max(early kinematics/assembly scratch, solver + RNEA scratch)]
+  // Every overlay below was validated by the emulator's race / uninitialised-read detector.
   const int nrho = D.nrho, mm = D.m;
-  L(L_Q, D.nq); L(L_V, nv); L(L_DES, D.n_desired); L(L_CW, D.nc); L(L_CMAX, D.nc);
-  L(L_TW, D.n_tw); L(L_SURF, D.n_surf);
-  L(L_RL, nb * 12); L(L_H, nb * 12); L(L_S, nv * 6);
-  L(L_TJ, nb * 6); L(L_T, nb * 6); L(L_CR, nb * 6); L(L_AB, nb * 6);
-  L(L_IW, nb * 10); L(L_IC, nb * 10); L(L_HB, nb * 6);
-  L(L_MISC, MS_COUNT); L(L_AMOM, 6 * nv); L(L_ACCP, (D.ntask + 1) * 6);
-  L(L_M, mm * D.nfs); L(L_D, mm); L(L_HV, D.nf); L(L_SQH, D.nf); L(L_GV, D.nf);
-  L(L_W, wsize); L(L_WINV, wsize);
-  L(L_SM, mm * D.ms); L(L_X, m1 * D.m1s); L(L_X2, m1 * 6);
-  L(L_B22, 36); L(L_C22, 36); L(L_L22, 36); L(L_S22I, 36);
-  L(L_G, 6 * nrho); L(L_Y, nrho * 6); L(L_HR, D.nc * N * N); L(L_KR, D.nc * N * N);
-  L(L_HI, nrho); L(L_WS, nrho); L(L_U, nrho);
-  L(L_XV, D.nf); L(L_XE, ne); L(L_XR, nrho); L(L_LAM, mm);
-  L(L_DV, D.nf); L(L_DE, ne); L(L_DR, nrho); L(L_DL, mm);
+  auto even = [](int x) { return x + (x & 1); };
+  int off = 0;
+  auto L = [&](int id, int n) { D.lds[id] = off; off = even(off + (n > 0 ? n : 0)); };
+  // persistent for the whole tick
+  L(L_S, nv * 6); L(L_AB, nb * 6); L(L_IW, nb * 10); L(L_F, nb * 6); L(L_VD, nv); L(L_MISC, MS_COUNT);
+  L(L_HOT, D.m + 4 * ne);
+  // written by the assembly, read by the solver
+  L(L_M, mm * D.nfs); L(L_D, mm); L(L_HV, D.nf); L(L_SQH, D.nf); L(L_GV, D.nf); L(L_W, wsize); L(L_WINV, wsize);
+  L(L_G, 6 * nrho); L(L_HR, D.nc * N * N); L(L_HI, nrho); L(L_WS, nrho);
+  const int base = off;
+  // -- early group (dead once the Schur complement build starts)
+  L(L_Q, D.nq); L(L_V, nv); L(L_DES, D.n_desired); L(L_CW, D.nc); L(L_CMAX, D.nc); L(L_TW, D.n_tw); L(L_SURF, D.n_surf);
+  D.lds[L_ACCP] = D.lds[L_Q]; // born after q, v are dead (assembly prologue)
+  if ((ntask_plus1_x6(D)) > even(D.nq) + even(nv)) { D.lds[L_ACCP] = off; off = even(off + (D.ntask + 1) * 6); }
+  L(L_RL, nb * 12); D.lds[L_IC] = D.lds[L_RL];                       // IC born after RL is dead
+  L(L_H, nb * 12); L(L_T, nb * 6);
+  L(L_TJ, nb * 6); D.lds[L_HB] = D.lds[L_TJ];                       // HB born after TJ is dead
+  { int amom = 6 * nv, cr = nb * 6; L(L_CR, amom > cr ? amom : cr); } // AMOM born after CR is dead
+  D.lds[L_AMOM] = D.lds[L_CR];
+  const int early_end = off;
+  // -- solver group
+  off = base;
+  L(L_SM, mm * D.ms);
+  D.lds[L_SV] = D.lds[L_SM];                                         // RNEA scratch born after the solve
+  D.lds[L_BW] = D.lds[L_SV] + even(nb * 6);
+  D.lds[L_CWR] = D.lds[L_BW] + even(nb * 6);
+  { int late_end = D.lds[L_CWR] + even(D.nc * 6); if (late_end > off) off = late_end; }
+  L(L_X2, m1 * 6); L(L_B22, 36); L(L_C22, 36); L(L_L22, 36); L(L_S22I, 36);
+  L(L_KR, D.nc * N * N); L(L_T1, mm); D.lds[L_T2] = D.lds[L_T1]; D.lds[L_T3] = D.lds[L_T1]; // T2/T3 retired
+  L(L_XV, D.nf); L(L_XE, ne); L(L_XR, nrho); L(L_LAM, mm); L(L_U, nrho);
+  const int xbase = off;
+  // X (explicit L11^-1) is dead before the first iterate vector is written
   L(L_RV, D.nf); L(L_RE, ne); L(L_RR, nrho); L(L_RC, mm);
-  L(L_T1, mm); L(L_T2, mm); L(L_T3, mm); L(L_TR1, nrho); L(L_TR2, nrho); L(L_TE1, ne);
-  L(L_RED, 256); L(L_VD, nv); L(L_SV, nb * 6); L(L_F, nb * 6); L(L_CWR, D.nc * 6);
+  L(L_DV, D.nf); L(L_DE, ne); L(L_DR, nrho); L(L_DL, mm);
+  L(L_TR1, nrho); L(L_TR2, nrho); L(L_TE1, ne);
+  const int vec_end = off;
+  D.lds[L_X] = xbase;
+  D.lds[L_Y] = xbase; // Y lives only inside refactor_rho, when the rhs/direction vectors are dead
+  { int xe = xbase + even(m1 * D.m1s), ye = xbase + even(nrho * 6); off = vec_end; if (xe > off) off = xe; if (ye > off) off = ye; }
+  D.lds[L_RED] = off; // unused on the device (wave reductions); the emulator has its own scratch
+  if (early_end > off) off = early_end;
   D.lds_doubles = off;
   D.n_int = (int)B.it.size(); D.n_dbl = (int)B.dt.size();
   // settings

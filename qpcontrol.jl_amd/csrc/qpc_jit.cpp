@@ -8,6 +8,7 @@
 #include <hip/hiprtc.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <sstream>
 
 #include "qpc_embedded.inc"
@@ -28,7 +29,14 @@ static std::string dbl(double x) {
 std::string qpc_jit_source(const QpcDims &D) {
   std::ostringstream o;
   o << "typedef int int32_t;\ntypedef unsigned int uint32_t;\ntypedef long long int64_t;\n";
-  o << "#include \"qpc_device.h\"\n"
+  o << "#include \"qpc_device.h\"\n";
+  const char *st = getenv("QPC_JIT_STAMPS"); // diagnostic: in-kernel section timers
+  const bool stamps = st && st[0] == '1';
+  if (stamps)
+    o << "#define QPC_STAMPS 1\n"
+         "#define QPC_PROF_T0() do { *PT = clock64(); } while (0)\n"
+         "#define QPC_PROF_ACC(i) do { unsigned long long n__ = clock64(); PA[i] += n__ - *PT; *PT = n__; } while (0)\n";
+  o << ""
        "#define QPC_JIT 1\n"
        "#include \"qpc_tick.h\"\n";
   // field order == struct QpcDims (qpc_program.h)
@@ -44,7 +52,7 @@ std::string qpc_jit_source(const QpcDims &D) {
     << dbl(D.tol_accept) << "};\n";
   o << "struct QpcBatchArgs { long long B; const double *q, *v, *desired, *cw, *cmax, *tw, *surf; double *tau, *vdot, "
        "*cwrench; int32_t *status, *iters; unsigned long long *prof; };\n";
-  o << "extern \"C\" __global__ void __launch_bounds__(64) qpc_tick_kernel_jit(const int *__restrict__ IT, "
+  o << "extern \"C\" __global__ void __launch_bounds__(64, 2) qpc_tick_kernel_jit(const int *__restrict__ IT, "
        "const double *__restrict__ DT, const QpcBatchArgs A) {\n"
        "  __shared__ __attribute__((aligned(16))) double qpc_lds[" << (D.lds_doubles > 0 ? D.lds_doubles : 1) << "];\n"
        "  for (long long b = blockIdx.x; b < A.B; b += gridDim.x) {\n"
@@ -53,7 +61,7 @@ std::string qpc_jit_source(const QpcDims &D) {
        "    io.cw = A.cw + b * kD.nc; io.cmax = A.cmax + b * kD.nc; io.tw = A.tw + b * kD.n_tw; io.surf = A.surf + b * kD.n_surf;\n"
        "    io.tau = A.tau + b * kD.nv; io.vdot = A.vdot + b * kD.nv;\n"
        "    io.cwrench = A.cwrench ? A.cwrench + b * 6 * kD.nc : nullptr;\n"
-       "    io.status = A.status + b; io.iters = A.iters ? A.iters + b : nullptr; io.prof = nullptr;\n"
+       "    io.status = A.status + b; io.iters = A.iters ? A.iters + b : nullptr; io.prof = A.prof ? A.prof + b * PS_COUNT : nullptr;\n"
        "    qpc::qpc_tick<double *>(kD, IT, DT, qpc_lds, io);\n"
        "    __syncthreads();\n"
        "  }\n"

@@ -26,6 +26,7 @@ enum {
   IT_C_BODY, IT_C_PERQP, IT_C_SURF, // contacts
   IT_BC_PTR, IT_BC_IDX,     // contacts attached to body i (CSR)
   IT_SLACK_TASK, IT_SLACK_COMP, // slack index -> generic task, component
+  IT_HOT, // solver lookups staged into LDS per QP: row_slack[m], slack_row[ne], slack_woff[ne], slack_dim[ne], slack_s0[ne]
   IT_COUNT
 };
 
@@ -41,6 +42,7 @@ enum {
 // LDS regions (offsets in doubles into the per-QP LDS slab)
 enum {
   L_Q, L_V, L_DES, L_CW, L_CMAX, L_TW, L_SURF,
+  L_HOT,  // m + 4*ne hot solver lookups (IT_HOT) as doubles
   L_RL,   // nb*12 local transforms
   L_H,    // nb*12 world transforms
   L_S,    // nv*6 motion subspaces (world)
@@ -72,6 +74,7 @@ enum {
   L_VD,                  // nv solution accelerations
   L_SV, L_F,             // nb*6
   L_CWR,                 // nc*6 contact wrenches
+  L_BW,                  // nb*6 body wrenches (RNEA)
   L_COUNT
 };
 
@@ -84,7 +87,7 @@ enum {
   MS_STATUS = 17, MS_ITERS = 18, MS_FLAG = 19, MS_P = 20, MS_SIDE = 21, MS_T = 22, MS_JDROP = 23,
   MS_NDROP = 24, MS_RPRIM = 25, MS_RSTAT = 26, MS_XBIG = 27, MS_DBIG = 28, MS_GSCALE = 29,
   MS_TOLB = 30, MS_CHANGED = 31, MS_FULL = 32, MS_SCP = 33, MS_SCS = 34, MS_REFINE = 35,
-  MS_COUNT = 48
+  MS_COUNT = 36
 };
 
 struct QpcDims {

@@ -31,7 +31,7 @@ struct QpcBatchArgs {
   unsigned long long *prof;
 };
 
-extern "C" __global__ void __launch_bounds__(64)
+extern "C" __global__ void __launch_bounds__(64, 2)
 qpc_tick_kernel(const QpcDims D, const int *__restrict__ IT, const double *__restrict__ DT, const QpcBatchArgs A) {
   extern __shared__ __attribute__((aligned(16))) double qpc_lds[];
   for (long long b = blockIdx.x; b < A.B; b += gridDim.x) {

@@ -231,6 +231,12 @@ template <class P> struct Solver {
   P sm;
   bool use_rho;
   unsigned long long *PA, *PT; // section timers (diagnostic build)
+  // hot lookups staged in LDS (IT_HOT)
+  QPC_FN int row_slack(int r) const { return (int)(double)sm[D.lds[L_HOT] + r]; }
+  QPC_FN int slack_row(int s) const { return (int)(double)sm[D.lds[L_HOT] + D.m + s]; }
+  QPC_FN int slack_woff(int s) const { return (int)(double)sm[D.lds[L_HOT] + D.m + D.ne + s]; }
+  QPC_FN int slack_dim(int s) const { return (int)(double)sm[D.lds[L_HOT] + D.m + 2 * D.ne + s]; }
+  QPC_FN int slack_s0(int s) const { return (int)(double)sm[D.lds[L_HOT] + D.m + 3 * D.ne + s]; }
   QPC_FN Solver(const QpcDims &d, const int *it, const double *dt, P s, unsigned long long *pa, unsigned long long *pt)
       : D(d), IT(it), DT(dt), sm(s), use_rho(d.nrho > 0), PA(pa), PT(pt) {}
 
@@ -320,10 +326,9 @@ template <class P> struct Solver {
           sm[D.lds[L_TR1] + j] = acc;
         }
       for (int s = lane; s < ne; s += 64) {
-        int t = IT[D.it[IT_SLACK_TASK] + s], a = IT[D.it[IT_SLACK_COMP] + s];
-        int d = IT[D.it[IT_T_DIM] + t], w0 = IT[D.it[IT_T_WOFF] + t], s0 = IT[D.it[IT_T_SLACK0] + t];
+        int d = slack_dim(s), wr = slack_woff(s), s0 = slack_s0(s);
         double acc = 0.0;
-        for (int b = 0; b < d; b++) acc += sm[D.lds[L_WINV] + w0 + a * d + b] * sm[D.lds[L_RE] + s0 + b];
+        for (int b = 0; b < d; b++) acc += sm[D.lds[L_WINV] + wr + b] * sm[D.lds[L_RE] + s0 + b];
         sm[D.lds[L_TE1] + s] = acc;
       }
     } QPC_END_PHASE
@@ -331,10 +336,9 @@ template <class P> struct Solver {
       for (int r = lane; r < m; r += 64) {
         double acc = -sm[D.lds[L_RC] + r];
         for (int f = 0; f < nf; f++) acc += sm[D.lds[L_M] + r * D.nfs + f] * (sm[D.lds[L_SQH] + f] * sm[D.lds[L_RV] + f]);
-        int t = IT[D.it[IT_ROW_TASK] + r];
-        if (t >= 0) {
-          int s0 = IT[D.it[IT_T_SLACK0] + t];
-          if (s0 >= 0) acc -= sm[D.lds[L_TE1] + s0 + IT[D.it[IT_ROW_COMP] + r]];
+        if (r < m1) {
+          int sl = row_slack(r);
+          if (sl >= 0) acc -= sm[D.lds[L_TE1] + sl];
         } else if (use_rho) {
           int a = r - m1;
           for (int j = 0; j < nrho; j++) acc -= sm[D.lds[L_G] + a * nrho + j] * sm[D.lds[L_TR1] + j];
@@ -349,10 +353,7 @@ template <class P> struct Solver {
         for (int r = 0; r < m; r++) acc -= sm[D.lds[L_M] + r * D.nfs + f] * sm[D.lds[L_DL] + r];
         sm[D.lds[L_DV] + f] = acc;
       }
-      for (int s = lane; s < ne; s += 64) {
-        int t = IT[D.it[IT_SLACK_TASK] + s], a = IT[D.it[IT_SLACK_COMP] + s];
-        sm[D.lds[L_TE1] + s] = sm[D.lds[L_RE] + s] + sm[D.lds[L_DL] + IT[D.it[IT_T_ROW0] + t] + a];
-      }
+      for (int s = lane; s < ne; s += 64) sm[D.lds[L_TE1] + s] = sm[D.lds[L_RE] + s] + sm[D.lds[L_DL] + slack_row(s)];
       if (use_rho)
         for (int j = lane; j < nrho; j += 64) {
           double acc = sm[D.lds[L_RR] + j];
@@ -362,10 +363,9 @@ template <class P> struct Solver {
     } QPC_END_PHASE
     QPC_PHASE(lane) {
       for (int s = lane; s < ne; s += 64) {
-        int t = IT[D.it[IT_SLACK_TASK] + s], a = IT[D.it[IT_SLACK_COMP] + s];
-        int d = IT[D.it[IT_T_DIM] + t], w0 = IT[D.it[IT_T_WOFF] + t], s0 = IT[D.it[IT_T_SLACK0] + t];
+        int d = slack_dim(s), wr = slack_woff(s), s0 = slack_s0(s);
         double acc = 0.0;
-        for (int b = 0; b < d; b++) acc += sm[D.lds[L_WINV] + w0 + a * d + b] * sm[D.lds[L_TE1] + s0 + b];
+        for (int b = 0; b < d; b++) acc += sm[D.lds[L_WINV] + wr + b] * sm[D.lds[L_TE1] + s0 + b];
         sm[D.lds[L_DE] + s] = acc;
       }
       if (use_rho)
@@ -388,10 +388,9 @@ template <class P> struct Solver {
       for (int r = lane; r < m; r += 64) {
         double acc = sm[D.lds[L_D] + r];
         for (int f = 0; f < nf; f++) acc -= sm[D.lds[L_M] + r * D.nfs + f] * sm[D.lds[L_XV] + f];
-        int t = IT[D.it[IT_ROW_TASK] + r];
-        if (t >= 0) {
-          int s0 = IT[D.it[IT_T_SLACK0] + t];
-          if (s0 >= 0) acc += sm[D.lds[L_XE] + s0 + IT[D.it[IT_ROW_COMP] + r]];
+        if (r < m1) {
+          int sl = row_slack(r);
+          if (sl >= 0) acc += sm[D.lds[L_XE] + sl];
         } else if (use_rho) {
           int a = r - m1;
           for (int j = 0; j < nrho; j++) acc += sm[D.lds[L_G] + a * nrho + j] * sm[D.lds[L_XR] + j];
@@ -405,11 +404,10 @@ template <class P> struct Solver {
         sm[D.lds[L_RV] + f] = -(sm[D.lds[L_HV] + f] * sq * sm[D.lds[L_XV] + f] + sm[D.lds[L_GV] + f] + mtl / sq);
       }
       for (int s = lane; s < ne; s += 64) {
-        int t = IT[D.it[IT_SLACK_TASK] + s], a = IT[D.it[IT_SLACK_COMP] + s];
-        int d = IT[D.it[IT_T_DIM] + t], w0 = IT[D.it[IT_T_WOFF] + t], s0 = IT[D.it[IT_T_SLACK0] + t];
+        int d = slack_dim(s), wr = slack_woff(s), s0 = slack_s0(s);
         double acc = 0.0;
-        for (int b = 0; b < d; b++) acc += sm[D.lds[L_W] + w0 + a * d + b] * sm[D.lds[L_XE] + s0 + b];
-        sm[D.lds[L_RE] + s] = -(acc - sm[D.lds[L_LAM] + IT[D.it[IT_T_ROW0] + t] + a]);
+        for (int b = 0; b < d; b++) acc += sm[D.lds[L_W] + wr + b] * sm[D.lds[L_XE] + s0 + b];
+        sm[D.lds[L_RE] + s] = -(acc - sm[D.lds[L_LAM] + slack_row(s)]);
       }
       if (use_rho)
         for (int j = lane; j < nrho; j += 64) {
@@ -519,6 +517,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
     for (int i = lane; i < nc; i += 64) { sm[D.lds[L_CW] + i] = io.cw[i]; sm[D.lds[L_CMAX] + i] = io.cmax[i]; }
     for (int i = lane; i < D.n_tw; i += 64) sm[D.lds[L_TW] + i] = io.tw[i];
     for (int i = lane; i < D.n_surf; i += 64) sm[D.lds[L_SURF] + i] = io.surf[i];
+    for (int i = lane; i < m + 4 * ne; i += 64) sm[D.lds[L_HOT] + i] = (double)IT[D.it[IT_HOT] + i];
   } QPC_END_PHASE
 
   // ======================================================================== kinematics (a2)
@@ -915,7 +914,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
         double skk = sm[D.lds[L_SM] + k * D.ms + k], dk = skk - acck;
         bool ok = dk > D.tau_pivot * (skk > 1e-300 ? skk : 1e-300);
         double ld_ = ok ? QPC_SQRT(dk) : 0.0, inv = ok ? 1.0 / ld_ : 0.0;
-        if (r == k) { sm[D.lds[L_T1] + k] = inv; sm[D.lds[L_T2] + k] = ld_; } // 1/L_kk (0 = dropped row)
+        if (r == k) sm[D.lds[L_T1] + k] = inv; // 1/L_kk (0 = dropped row)
         else sm[D.lds[L_SM] + r * D.ms + k] = (sm[D.lds[L_SM] + r * D.ms + k] - accr) * inv;
       }
     } QPC_END_PHASE
@@ -1157,7 +1156,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
         int c = IT[D.it[IT_BC_IDX] + e];
         for (int a = 0; a < 6; a++) ia[a] -= sm[D.lds[L_CWR] + 6 * c + a];
       }
-      st(sm + D.lds[L_HB] + 6 * i, 6, ia);
+      st(sm + D.lds[L_BW] + 6 * i, 6, ia);
     }
   } QPC_END_PHASE
   QPC_PHASE(lane) { // tau_k = S_k . (sum of subtree wrenches); floating joint torques exactly 0
@@ -1167,7 +1166,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       if (b != D.floating) {
         double F[6] = {0, 0, 0, 0, 0, 0};
         for (int e = desc_ptr[b]; e < desc_ptr[b + 1]; e++)
-          for (int a = 0; a < 6; a++) F[a] += sm[D.lds[L_HB] + 6 * desc_idx[e] + a];
+          for (int a = 0; a < 6; a++) F[a] += sm[D.lds[L_BW] + 6 * desc_idx[e] + a];
         for (int a = 0; a < 6; a++) tau += sm[D.lds[L_S] + 6 * k + a] * F[a];
       }
       io.tau[k] = tau;
