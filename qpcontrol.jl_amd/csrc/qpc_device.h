@@ -8,6 +8,11 @@
 #define QPC_SINCOS(x, s, c) sincos((x), &(s), &(c))
 #define QPC_SQRT(x) sqrt((double)(x))
 #define QPC_FABS(x) fabs((double)(x))
+#ifdef QPC_JIT
+#define QPC_UNROLL _Pragma("unroll")
+#else
+#define QPC_UNROLL _Pragma("unroll 4")
+#endif
 
 namespace qpc {
 // wave-uniform reductions over the 64 lanes (butterfly over ds_bpermute/DPP; no LDS traffic)

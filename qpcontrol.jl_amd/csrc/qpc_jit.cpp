@@ -29,7 +29,7 @@ static std::string dbl(double x) {
 std::string qpc_jit_source(const QpcDims &D) {
   std::ostringstream o;
   o << "typedef int int32_t;\ntypedef unsigned int uint32_t;\ntypedef long long int64_t;\n";
-  o << "#include \"qpc_device.h\"\n";
+  o << "#define QPC_JIT 1\n#include \"qpc_device.h\"\n";
   const char *st = getenv("QPC_JIT_STAMPS"); // diagnostic: in-kernel section timers
   const bool stamps = st && st[0] == '1';
   if (stamps)
@@ -37,7 +37,6 @@ std::string qpc_jit_source(const QpcDims &D) {
          "#define QPC_PROF_T0() do { *PT = clock64(); } while (0)\n"
          "#define QPC_PROF_ACC(i) do { unsigned long long n__ = clock64(); PA[i] += n__ - *PT; *PT = n__; } while (0)\n";
   o << ""
-       "#define QPC_JIT 1\n"
        "#include \"qpc_tick.h\"\n";
   // field order == struct QpcDims (qpc_program.h)
   o << "static constexpr QpcDims kD = {" << D.nb << "," << D.nq << "," << D.nv << "," << D.nf << "," << D.npin << ","
@@ -51,11 +50,15 @@ std::string qpc_jit_source(const QpcDims &D) {
     << D.max_pdas << "," << dbl(D.eps_primal) << "," << dbl(D.tau_pivot) << "," << dbl(D.tol_bound) << ","
     << dbl(D.tol_accept) << "};\n";
   o << "struct QpcBatchArgs { long long B; const double *q, *v, *desired, *cw, *cmax, *tw, *surf; double *tau, *vdot, "
-       "*cwrench; int32_t *status, *iters; unsigned long long *prof; };\n";
+       "*cwrench; int32_t *status, *iters; unsigned long long *prof; unsigned long long *ticket; };\n";
   o << "extern \"C\" __global__ void __launch_bounds__(64, 2) qpc_tick_kernel_jit(const int *__restrict__ IT, "
        "const double *__restrict__ DT, const QpcBatchArgs A) {\n"
        "  __shared__ __attribute__((aligned(16))) double qpc_lds[" << (D.lds_doubles > 0 ? D.lds_doubles : 1) << "];\n"
-       "  for (long long b = blockIdx.x; b < A.B; b += gridDim.x) {\n"
+       "  while (true) {\n"
+       "    unsigned long long t = 0;\n"
+       "    if ((threadIdx.x & 63) == 0) t = atomicAdd(A.ticket, 1ull);\n"
+       "    const long long b = (long long)__shfl(t, 0, 64);\n"
+       "    if (b >= A.B) break;\n"
        "    qpc::TickIO io;\n"
        "    io.q = A.q + b * kD.nq; io.v = A.v + b * kD.nv; io.desired = A.desired + b * kD.n_desired;\n"
        "    io.cw = A.cw + b * kD.nc; io.cmax = A.cmax + b * kD.nc; io.tw = A.tw + b * kD.n_tw; io.surf = A.surf + b * kD.n_surf;\n"

@@ -29,12 +29,19 @@ struct QpcBatchArgs {
   double *tau, *vdot, *cwrench;
   int32_t *status, *iters;
   unsigned long long *prof;
+  unsigned long long *ticket; // dynamic work distribution: next QP index (zeroed before each launch)
 };
 
 extern "C" __global__ void __launch_bounds__(64, 2)
 qpc_tick_kernel(const QpcDims D, const int *__restrict__ IT, const double *__restrict__ DT, const QpcBatchArgs A) {
   extern __shared__ __attribute__((aligned(16))) double qpc_lds[];
-  for (long long b = blockIdx.x; b < A.B; b += gridDim.x) {
+  // active-set iteration counts differ per QP (p99 ~ 3x mean): QPs are handed out through one
+  // device-scope ticket counter instead of a static grid-stride, so no workgroup idles at the tail
+  while (true) {
+    unsigned long long t = 0;
+    if ((threadIdx.x & 63) == 0) t = atomicAdd(A.ticket, 1ull);
+    const long long b = (long long)__shfl(t, 0, 64);
+    if (b >= A.B) break;
     qpc::TickIO io;
     io.q = A.q + b * D.nq; io.v = A.v + b * D.nv;
     io.desired = A.desired + b * D.n_desired;
@@ -67,6 +74,7 @@ struct QpcDeviceState {
   // JIT-specialised kernel (qpc_jit.cpp); null -> the generic ahead-of-time kernel is launched
   hipModule_t jit_module = nullptr;
   hipFunction_t jit_func = nullptr;
+  unsigned long long *d_ticket = nullptr;
 };
 
 static int hip_fail(hipError_t e, const char *what) {
@@ -91,14 +99,16 @@ static int launch(qpc_controller *c, const QpcBatchArgs &a, hipStream_t stream) 
     HIP_TRY(get(e0)); HIP_TRY(get(e1));
     HIP_TRY(hipEventRecord(e0, stream));
   }
+  QpcBatchArgs aa = a;
+  aa.ticket = S->d_ticket;
+  HIP_TRY(hipMemsetAsync(S->d_ticket, 0, sizeof(unsigned long long), stream));
   if (S->jit_func) {
     const int *it = S->d_it;
     const double *dt = S->d_dt;
-    QpcBatchArgs aa = a;
     void *args[] = {(void *)&it, (void *)&dt, (void *)&aa};
     HIP_TRY(hipModuleLaunchKernel(S->jit_func, (unsigned)grid, 1, 1, 64, 1, 1, 0, stream, args, nullptr));
   } else {
-    hipLaunchKernelGGL(qpc_tick_kernel, dim3((unsigned)grid), dim3(64), lds, stream, D, S->d_it, S->d_dt, a);
+    hipLaunchKernelGGL(qpc_tick_kernel, dim3((unsigned)grid), dim3(64), lds, stream, D, S->d_it, S->d_dt, aa);
     HIP_TRY(hipGetLastError());
   }
   if (S->timing) {
@@ -143,6 +153,7 @@ int32_t qpc_finalize(qpc_controller *c, int32_t device_id, qpc_layout *out) {
   HIP_TRY(hipMemcpy(S->d_it, c->prog.itab.data(), sizeof(int) * c->prog.itab.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(S->d_dt, c->prog.dtab.data(), sizeof(double) * c->prog.dtab.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipStreamCreate(&S->stream));
+  HIP_TRY(hipMalloc(&S->d_ticket, sizeof(unsigned long long)));
   // JIT specialisation on this controller's program (QPC_DISABLE_JIT=1 keeps the generic kernel)
   const char *nojit = getenv("QPC_DISABLE_JIT");
   if (!(nojit && nojit[0] == '1')) {
@@ -180,6 +191,7 @@ void qpc_controller_destroy(qpc_controller *c) {
     if (S->d_it) (void)hipFree(S->d_it);
     if (S->d_dt) (void)hipFree(S->d_dt);
     if (S->stage) (void)hipFree(S->stage);
+    if (S->d_ticket) (void)hipFree(S->d_ticket);
     if (S->stream) (void)hipStreamDestroy(S->stream);
     if (S->jit_module) (void)hipModuleUnload(S->jit_module);
     delete S;

@@ -25,6 +25,12 @@
 #include "../../include/qpc.h"
 #include "qpc_program.h"
 
+// inner-loop unrolling hint: full unroll when trip counts are compile-time constants (JIT),
+// a modest factor in the generic kernel, nothing in the emulator
+#ifndef QPC_UNROLL
+#define QPC_UNROLL
+#endif
+
 // optional in-kernel section timers (diagnostic build only: -DQPC_STAMPS in qpc_runtime.hip)
 #ifndef QPC_PROF_ACC
 #define QPC_PROF_T0()
@@ -256,6 +262,7 @@ template <class P> struct Solver {
         for (int idx = lane; idx < nrho * 6; idx += 64) {
           int j = idx / 6, b = idx % 6, c = j / N, jj = j % N;
           double acc = 0.0;
+          QPC_UNROLL
           for (int i = 0; i < N; i++) acc += sm[D.lds[L_KR] + c * N * N + jj * N + i] * sm[D.lds[L_G] + b * nrho + c * N + i];
           sm[D.lds[L_Y] + j * 6 + b] = acc;
         }
@@ -266,6 +273,7 @@ template <class P> struct Solver {
         int a = lane / 6, b = lane % 6;
         double acc = sm[D.lds[L_B22] + lane];
         if (use_rho)
+          QPC_UNROLL
           for (int j = 0; j < nrho; j++) acc += sm[D.lds[L_G] + a * nrho + j] * sm[D.lds[L_Y] + j * 6 + b];
         sm[D.lds[L_C22] + lane] = acc; // S22 = B22 + G Kr G'
       }
@@ -290,12 +298,15 @@ template <class P> struct Solver {
       QPC_PHASE(lane) {
         if (lane < 6) {
           double u[6];
+          QPC_UNROLL
           for (int b = 0; b < 6; b++) u[b] = sm[D.lds[L_T1] + m1 + b];
           for (int r = 0; r < m1; r++) {
             double t = sm[D.lds[L_T1] + r];
+            QPC_UNROLL
             for (int b = 0; b < 6; b++) u[b] -= sm[D.lds[L_X2] + r * 6 + b] * t;
           }
           double acc = 0.0;
+          QPC_UNROLL
           for (int b = 0; b < 6; b++) acc += sm[D.lds[L_S22I] + lane * 6 + b] * u[b];
           sm[out + m1 + lane] = acc;
         }
@@ -304,8 +315,10 @@ template <class P> struct Solver {
     QPC_PHASE(lane) {
       for (int r = lane; r < m1; r += 64) {
         double acc = 0.0;
+        QPC_UNROLL
         for (int c = 0; c < m1; c++) acc += sm[D.lds[L_SM] + r * D.ms + c] * sm[D.lds[L_T1] + c];
         if (nw)
+          QPC_UNROLL
           for (int a = 0; a < 6; a++) acc -= sm[D.lds[L_X2] + r * 6 + a] * sm[out + m1 + a];
         sm[out + r] = acc;
       }
@@ -322,12 +335,14 @@ template <class P> struct Solver {
         for (int j = lane; j < nrho; j += 64) {
           int c = j / N, jj = j % N;
           double acc = 0.0;
+          QPC_UNROLL
           for (int i = 0; i < N; i++) acc += sm[D.lds[L_KR] + c * N * N + jj * N + i] * sm[D.lds[L_RR] + c * N + i];
           sm[D.lds[L_TR1] + j] = acc;
         }
       for (int s = lane; s < ne; s += 64) {
         int d = slack_dim(s), wr = slack_woff(s), s0 = slack_s0(s);
         double acc = 0.0;
+        QPC_UNROLL
         for (int b = 0; b < d; b++) acc += sm[D.lds[L_WINV] + wr + b] * sm[D.lds[L_RE] + s0 + b];
         sm[D.lds[L_TE1] + s] = acc;
       }
@@ -335,12 +350,14 @@ template <class P> struct Solver {
     QPC_PHASE(lane) {
       for (int r = lane; r < m; r += 64) {
         double acc = -sm[D.lds[L_RC] + r];
+        QPC_UNROLL
         for (int f = 0; f < nf; f++) acc += sm[D.lds[L_M] + r * D.nfs + f] * (sm[D.lds[L_SQH] + f] * sm[D.lds[L_RV] + f]);
         if (r < m1) {
           int sl = row_slack(r);
           if (sl >= 0) acc -= sm[D.lds[L_TE1] + sl];
         } else if (use_rho) {
           int a = r - m1;
+          QPC_UNROLL
           for (int j = 0; j < nrho; j++) acc -= sm[D.lds[L_G] + a * nrho + j] * sm[D.lds[L_TR1] + j];
         }
         sm[D.lds[L_T1] + r] = acc;
@@ -350,6 +367,7 @@ template <class P> struct Solver {
     QPC_PHASE(lane) {
       for (int f = lane; f < nf; f += 64) {
         double acc = sm[D.lds[L_SQH] + f] * sm[D.lds[L_RV] + f];
+        QPC_UNROLL
         for (int r = 0; r < m; r++) acc -= sm[D.lds[L_M] + r * D.nfs + f] * sm[D.lds[L_DL] + r];
         sm[D.lds[L_DV] + f] = acc;
       }
@@ -357,6 +375,7 @@ template <class P> struct Solver {
       if (use_rho)
         for (int j = lane; j < nrho; j += 64) {
           double acc = sm[D.lds[L_RR] + j];
+          QPC_UNROLL
           for (int a = 0; a < 6; a++) acc += sm[D.lds[L_G] + a * nrho + j] * sm[D.lds[L_DL] + m1 + a];
           sm[D.lds[L_TR2] + j] = acc;
         }
@@ -365,6 +384,7 @@ template <class P> struct Solver {
       for (int s = lane; s < ne; s += 64) {
         int d = slack_dim(s), wr = slack_woff(s), s0 = slack_s0(s);
         double acc = 0.0;
+        QPC_UNROLL
         for (int b = 0; b < d; b++) acc += sm[D.lds[L_WINV] + wr + b] * sm[D.lds[L_TE1] + s0 + b];
         sm[D.lds[L_DE] + s] = acc;
       }
@@ -372,6 +392,7 @@ template <class P> struct Solver {
         for (int j = lane; j < nrho; j += 64) {
           int c = j / N, jj = j % N;
           double acc = 0.0;
+          QPC_UNROLL
           for (int i = 0; i < N; i++) acc += sm[D.lds[L_KR] + c * N * N + jj * N + i] * sm[D.lds[L_TR2] + c * N + i];
           sm[D.lds[L_DR] + j] = acc;
         }
@@ -387,18 +408,21 @@ template <class P> struct Solver {
     QPC_PHASE(lane) {
       for (int r = lane; r < m; r += 64) {
         double acc = sm[D.lds[L_D] + r];
+        QPC_UNROLL
         for (int f = 0; f < nf; f++) acc -= sm[D.lds[L_M] + r * D.nfs + f] * sm[D.lds[L_XV] + f];
         if (r < m1) {
           int sl = row_slack(r);
           if (sl >= 0) acc += sm[D.lds[L_XE] + sl];
         } else if (use_rho) {
           int a = r - m1;
+          QPC_UNROLL
           for (int j = 0; j < nrho; j++) acc += sm[D.lds[L_G] + a * nrho + j] * sm[D.lds[L_XR] + j];
         }
         sm[D.lds[L_RC] + r] = acc;
       }
       for (int f = lane; f < nf; f += 64) {
         double mtl = 0.0;
+        QPC_UNROLL
         for (int r = 0; r < m; r++) mtl += sm[D.lds[L_M] + r * D.nfs + f] * sm[D.lds[L_LAM] + r];
         double sq = sm[D.lds[L_SQH] + f];
         sm[D.lds[L_RV] + f] = -(sm[D.lds[L_HV] + f] * sq * sm[D.lds[L_XV] + f] + sm[D.lds[L_GV] + f] + mtl / sq);
@@ -406,6 +430,7 @@ template <class P> struct Solver {
       for (int s = lane; s < ne; s += 64) {
         int d = slack_dim(s), wr = slack_woff(s), s0 = slack_s0(s);
         double acc = 0.0;
+        QPC_UNROLL
         for (int b = 0; b < d; b++) acc += sm[D.lds[L_W] + wr + b] * sm[D.lds[L_XE] + s0 + b];
         sm[D.lds[L_RE] + s] = -(acc - sm[D.lds[L_LAM] + slack_row(s)]);
       }
@@ -413,7 +438,9 @@ template <class P> struct Solver {
         for (int j = lane; j < nrho; j += 64) {
           int c = j / N, jj = j % N;
           double gl = 0.0;
+          QPC_UNROLL
           for (int i = 0; i < N; i++) gl += sm[D.lds[L_HR] + c * N * N + jj * N + i] * sm[D.lds[L_XR] + c * N + i];
+          QPC_UNROLL
           for (int a = 0; a < 6; a++) gl -= sm[D.lds[L_G] + a * nrho + j] * sm[D.lds[L_LAM] + m1 + a];
           sm[D.lds[L_TR1] + j] = gl;
           sm[D.lds[L_RR] + j] = (sm[D.lds[L_WS] + j] == 0.0) ? -gl : 0.0;
@@ -468,15 +495,21 @@ template <class P> struct Solver {
     return it;
   }
 
-  // multipliers of the bound constraints from the rho-gradient in L_TR1 (residuals() just ran)
-  // -> L_U ; returns max |gradient| and max |rho| (uniform) for the tolerances
+  // multipliers of the bound constraints: u = +-(H_rho rho - G' lam_w) on the working set -> L_U;
+  // returns max |gradient| and max |rho| (uniform) for the tolerances
   QPC_FN void multipliers(double &gmax, double &xmax) {
-    const int nrho = D.nrho;
+    const int nrho = D.nrho, N = D.N, m1 = D.m1;
     double rg = 0.0, rx = 0.0;
     QPC_PHASE(lane) {
       double g = 0.0, x = 0.0;
       for (int j = lane; j < nrho; j += 64) {
-        double gl = sm[D.lds[L_TR1] + j], w = sm[D.lds[L_WS] + j];
+        int c = j / N, jj = j % N;
+        double gl = 0.0;
+        QPC_UNROLL
+        for (int i = 0; i < N; i++) gl += sm[D.lds[L_HR] + c * N * N + jj * N + i] * sm[D.lds[L_XR] + c * N + i];
+        QPC_UNROLL
+        for (int a = 0; a < 6; a++) gl -= sm[D.lds[L_G] + a * nrho + j] * sm[D.lds[L_LAM] + m1 + a];
+        double w = sm[D.lds[L_WS] + j];
         sm[D.lds[L_U] + j] = (w == -1.0) ? gl : ((w == 1.0) ? -gl : 0.0);
         g = QPC_FABS(gl) > g ? QPC_FABS(gl) : g;
         double xr = QPC_FABS(sm[D.lds[L_XR] + j]);
@@ -487,6 +520,44 @@ template <class P> struct Solver {
     } QPC_END_PHASE
     gmax = QPC_RED_MAX_GET(0, rg);
     xmax = QPC_RED_MAX_GET(1, rx);
+  }
+
+  // EQP of the current working set solved from x = 0: the residual IS the right-hand side, so no
+  // mat-vec pass is needed; one KKT solve, no refinement (used inside the active-set search)
+  QPC_FN void eqp_fresh() {
+    const int nf = D.nf, ne = D.ne, nrho = D.nrho, m = D.m, m1 = D.m1, N = D.N;
+    QPC_PROF_ACC(PS_LOGIC);
+    QPC_PHASE(lane) {
+      for (int f = lane; f < nf; f += 64) sm[D.lds[L_RV] + f] = -sm[D.lds[L_GV] + f];
+      for (int s = lane; s < ne; s += 64) sm[D.lds[L_RE] + s] = 0.0;
+      for (int r = lane; r < m; r += 64) {
+        double acc = sm[D.lds[L_D] + r];
+        if (r >= m1 && use_rho) {
+          int a = r - m1;
+          for (int j = 0; j < nrho; j++)
+            if (sm[D.lds[L_WS] + j] == 1.0) acc += sm[D.lds[L_G] + a * nrho + j] * sm[D.lds[L_HI] + j];
+        }
+        sm[D.lds[L_RC] + r] = acc;
+      }
+      for (int j = lane; j < nrho; j += 64) {
+        int c = j / N, jj = j % N;
+        double acc = 0.0;
+        if (sm[D.lds[L_WS] + j] == 0.0)
+          for (int i = 0; i < N; i++)
+            if (sm[D.lds[L_WS] + c * N + i] == 1.0) acc -= sm[D.lds[L_HR] + c * N * N + jj * N + i] * sm[D.lds[L_HI] + c * N + i];
+        sm[D.lds[L_RR] + j] = acc;
+      }
+    } QPC_END_PHASE
+    QPC_PROF_ACC(PS_RESID);
+    kkt_solve();
+    QPC_PHASE(lane) {
+      for (int f = lane; f < nf; f += 64) sm[D.lds[L_XV] + f] = sm[D.lds[L_DV] + f];
+      for (int s = lane; s < ne; s += 64) sm[D.lds[L_XE] + s] = sm[D.lds[L_DE] + s];
+      for (int r = lane; r < m; r += 64) sm[D.lds[L_LAM] + r] = sm[D.lds[L_DL] + r];
+      for (int j = lane; j < nrho; j += 64)
+        sm[D.lds[L_XR] + j] = sm[D.lds[L_DR] + j] + ((sm[D.lds[L_WS] + j] == 1.0) ? (double)sm[D.lds[L_HI] + j] : 0.0);
+    } QPC_END_PHASE
+    QPC_PROF_ACC(PS_UPDATE);
   }
 };
 
@@ -891,6 +962,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       int r = idx / m, c = idx % m;
       if (c > r) continue;
       double acc = 0.0;
+      QPC_UNROLL
       for (int f = 0; f < nf; f++) acc += sm[D.lds[L_M] + r * D.nfs + f] * sm[D.lds[L_M] + c * D.nfs + f];
       int tr = IT[D.it[IT_ROW_TASK] + r], tc = IT[D.it[IT_ROW_TASK] + c];
       if (tr >= 0 && tr == tc) {
@@ -956,11 +1028,10 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
   Solver<P> S(D, IT, DT, sm, PA, PT);
   int status = QPC_STATUS_OPTIMAL, iters = 0;
   S.refactor_rho();
-  S.eqp(0);
+  S.eqp_fresh();
   if (use_rho) {
     // ---- phase A: primal-dual active-set sweeps (multi-change)
     for (int pd = 0; pd < D.max_pdas; pd++) {
-      S.residuals();
       double gmax, xmax;
       S.multipliers(gmax, xmax);
       const double gscale = 1.0 + gmax, tolb = D.tol_bound * (1.0 + xmax);
@@ -981,12 +1052,11 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       if (!(rchg > 0.0)) break;
       iters++;
       S.refactor_rho();
-      S.eqp(0);
+      S.eqp_fresh();
     }
     // ---- phase B: drops until dual feasible, then Goldfarb-Idnani additions (finite)
     while (true) {
       if (iters > D.max_as_iters) { status = QPC_STATUS_ITERATION_LIMIT; break; }
-      S.residuals();
       double gmax, xmax;
       S.multipliers(gmax, xmax);
       const double gscale = 1.0 + gmax, tolb = D.tol_bound * (1.0 + xmax);
@@ -1018,7 +1088,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
         QPC_PHASE(lane) { if (lane == 0) sm[D.lds[L_WS] + jbad] = 0.0; } QPC_END_PHASE
         iters++;
         S.refactor_rho();
-        S.eqp(0);
+        S.eqp_fresh();
         continue;
       }
       if (pviol < 0) break; // optimal for this working set
@@ -1078,7 +1148,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
           }
         } QPC_END_PHASE
         S.refactor_rho();
-        if (full) { S.eqp(0); break; }
+        if (full) { S.eqp_fresh(); break; }
       }
       if (fail) { if (status == QPC_STATUS_OPTIMAL) status = QPC_STATUS_ITERATION_LIMIT; break; }
     }
