@@ -1,0 +1,229 @@
+"""Host mirror of the reference's operator interface for the hot path, batched.
+
+Same names and argument meaning as `src/QPControl.jl:5-33` (Julia `!` dropped): tasks are
+constructed from a mechanism and body/joint names, `addtask` has the hard / scalar-weight /
+matrix-weight forms of `momentum.jl:99-117`, `addcontact` returns a `ContactPoint` whose `weight`
+and `maxnormalforce` cells (contacts.jl:35-36, default 0 as in contacts.jl:50) may be scalars or
+per-state arrays, `setdesired` stores what the next tick uses, and the controller is callable as
+`controller(tau, t, x)` with `x = (q[B, nq], v[B, nv])`.  After a call `controller.result_vdot` and
+`controller.contactwrenches` hold what `controller.result.v̇` / `controller.contactwrenches` hold
+in the reference (momentum.jl:62-72).  Everything numeric happens in libqpcontrol_hip.so.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import binding
+from .models import FRAME_DEFAULT, WORLD, Mechanism
+from .workloads import (ANGULAR, HARD, JOINT, LINEAR, LINEAR_MOMENTUM_RATE, MATRIX, MATRIX_PER_QP,
+                        MOMENTUM_RATE, POINT, SCALAR, SCALAR_PER_QP, SPATIAL)
+
+
+class QPSolveFailure(RuntimeError):
+    """exceptions.jl:1-11 -- raised by checkstatus (momentum.jl:83-91) for the first bad element."""
+
+    def __init__(self, index, status):
+        self.index, self.status = index, status
+        super().__init__(f"QP solve unsuccessful for batch element {index}: {binding.STATUS_NAMES[status]}")
+
+
+def _body(mech: Mechanism, b):
+    return b if isinstance(b, (int, np.integer)) else mech.findbody(b)
+
+
+def _joint(mech: Mechanism, j):
+    return j if isinstance(j, (int, np.integer)) else mech.findjoint(j)
+
+
+class AbstractMotionTask:
+    kind = None
+    dim = 0
+
+    def __init__(self):
+        self.desired = None
+        self._id = None
+
+    def _args(self):
+        return {}
+
+
+class _PathTask(AbstractMotionTask):
+    def __init__(self, mechanism, base, target, frame=FRAME_DEFAULT):
+        super().__init__()
+        self.base, self.target = _body(mechanism, base), _body(mechanism, target)
+        self.frame = frame if frame == FRAME_DEFAULT else _body(mechanism, frame)
+        self.desired = np.zeros(self.dim)
+
+    def _args(self):
+        return dict(base=self.base, target=self.target, frame=self.frame)
+
+
+class SpatialAccelerationTask(_PathTask):  # src/tasks.jl:3-44
+    kind, dim = SPATIAL, 6
+
+
+class AngularAccelerationTask(_PathTask):  # src/tasks.jl:47-84
+    kind, dim = ANGULAR, 3
+
+
+class LinearAccelerationTask(_PathTask):  # src/tasks.jl:86-123
+    kind, dim = LINEAR, 3
+
+
+class PointAccelerationTask(AbstractMotionTask):  # src/tasks.jl:125-171
+    kind, dim = POINT, 3
+
+    def __init__(self, mechanism, base, target, point):
+        super().__init__()
+        self.base, self.target = _body(mechanism, base), _body(mechanism, target)
+        self.point = np.asarray(point, dtype=np.float64)
+        self.desired = np.zeros(3)
+
+    def _args(self):
+        return dict(base=self.base, target=self.target, point=self.point)
+
+
+class JointAccelerationTask(AbstractMotionTask):  # src/tasks.jl:173-189
+    kind = JOINT
+
+    def __init__(self, mechanism, joint):
+        super().__init__()
+        self.joint = _joint(mechanism, joint)
+        self.dim = len(mechanism.velocity_range(self.joint))
+        self.desired = np.zeros(self.dim)
+
+    def _args(self):
+        return dict(joint=self.joint)
+
+
+class MomentumRateTask(AbstractMotionTask):  # src/tasks.jl:192-236
+    kind, dim = MOMENTUM_RATE, 6
+
+    def __init__(self, mechanism=None, centroidalframe=None):
+        super().__init__()
+        self.desired = np.zeros(6)
+
+
+class LinearMomentumRateTask(AbstractMotionTask):  # src/tasks.jl:239-262
+    kind, dim = LINEAR_MOMENTUM_RATE, 3
+
+    def __init__(self, mechanism=None, centroidalframe=None):
+        super().__init__()
+        self.desired = np.zeros(3)
+
+
+def setdesired(task: AbstractMotionTask, desired):
+    """setdesired!(task, desired): a (dim,) value for every state or a (B, dim) array."""
+    d = np.asarray(desired, dtype=np.float64)
+    if d.ndim == 0:
+        d = d.reshape(1)
+    if d.shape[-1] != task.dim:
+        raise ValueError(f"desired has trailing dimension {d.shape[-1]}, task dimension is {task.dim}")
+    task.desired = d
+
+
+class ContactPoint:
+    """contacts.jl:27-36: `weight` and `maxnormalforce` default to 0 (a fresh contact is disabled)."""
+
+    def __init__(self, cid, body, position, normal, mu, parametric):
+        self._id, self.body = cid, body
+        self.position, self.normal, self.mu = np.asarray(position, float), np.asarray(normal, float), mu
+        self.weight = 0.0
+        self.maxnormalforce = 0.0
+        self.parametric = parametric
+
+
+def disable(point: ContactPoint):
+    point.maxnormalforce = 0.0
+
+
+def isenabled(point: ContactPoint):
+    return bool(np.any(np.asarray(point.maxnormalforce) > 0))
+
+
+class Parameter:
+    """Marker for a per-state ("Parameter" in Parametron) weight: `value` is (B,) or (B, dim, dim)."""
+
+    def __init__(self, value):
+        self.value = np.asarray(value, dtype=np.float64)
+
+
+class MomentumBasedController:
+    """MomentumBasedController{N}(mechanism, optimizer; floatingjoint) -- momentum.jl:1-81 -- without an
+    optimizer argument: the QP is solved by the HIP kernels."""
+
+    def __init__(self, mechanism: Mechanism, n_basis=4, floatingjoint=None, lib_path=None):
+        self.mechanism = mechanism
+        self.floating = WORLD if floatingjoint is None else _joint(mechanism, floatingjoint)
+        self._c = binding.Controller(binding.Model(mechanism, lib_path), n_basis, self.floating)
+        self.tasks, self.contacts, self._weights = [], [], []
+        self.initialized = False
+        self.result_vdot = None
+        self.contactwrenches = None
+        self.status = None
+
+    # -- construction ------------------------------------------------------------------------
+    def addtask(self, task: AbstractMotionTask, weight=None):
+        if weight is None:
+            wk, w = HARD, None
+        elif isinstance(weight, Parameter):
+            wk, w = (SCALAR_PER_QP if weight.value.ndim <= 1 else MATRIX_PER_QP), None
+            self._weights.append((task, weight))
+        elif np.ndim(weight) == 0:
+            wk, w = SCALAR, [float(weight)]
+        else:
+            wk, w = MATRIX, np.asarray(weight, dtype=np.float64)
+        task._id = self._c.add_task(task.kind, wkind=wk, weight=w, **task._args())
+        self.tasks.append(task)
+        return task
+
+    def regularize(self, joint, weight):
+        self._c.regularize(_joint(self.mechanism, joint), weight)
+
+    def addcontact(self, body, position, normal, mu, parametric=False):
+        b = _body(self.mechanism, body)
+        cid = self._c.add_contact(b, position, normal, mu, per_qp_surface=int(parametric))
+        cp = ContactPoint(cid, b, position, normal, mu, parametric)
+        self.contacts.append(cp)
+        return cp
+
+    def finalize(self, device_id=0):
+        """initialize!(controller) (momentum.jl:150-156); implicit on the first call."""
+        self.layout = self._c.finalize(device_id)
+        self.initialized = True
+        return self.layout
+
+    # -- the tick ----------------------------------------------------------------------------
+    def __call__(self, tau, t, x, surfaces=None, throw_on_failure=True):
+        if not self.initialized:
+            self.finalize()
+        q, v = x
+        q = np.atleast_2d(np.asarray(q, dtype=np.float64))
+        v = np.atleast_2d(np.asarray(v, dtype=np.float64))
+        B = q.shape[0]
+        lay = self.layout
+
+        def bc(val, n):
+            return np.ascontiguousarray(np.broadcast_to(np.asarray(val, dtype=np.float64).reshape(-1, n) if np.ndim(val) > 1
+                                                        else np.asarray(val, dtype=np.float64), (B, n)))
+
+        des = np.concatenate([bc(tk.desired, tk.dim) for tk in self.tasks], axis=1) if self.tasks else None
+        cw = np.stack([np.broadcast_to(np.asarray(c.weight, float), (B,)) for c in self.contacts], 1) if self.contacts else None
+        cm = np.stack([np.broadcast_to(np.asarray(c.maxnormalforce, float), (B,)) for c in self.contacts], 1) if self.contacts else None
+        tw = None
+        if self._weights:
+            tw = np.concatenate([np.broadcast_to(w.value.reshape(w.value.shape[0] if w.value.ndim else 1, -1)
+                                                 if w.value.ndim else w.value.reshape(1, 1),
+                                                 (B, 1 if w.value.ndim <= 1 else tk.dim * tk.dim))
+                                 for tk, w in self._weights], axis=1)
+        r = self._c.control_batch(q, v, des, cw, cm, tw, surfaces)
+        self.result_vdot, self.contactwrenches, self.status = r["vdot"], r["cwrench"], r["status"]
+        self.iters = r["iters"]
+        if throw_on_failure:
+            bad = np.where(r["status"] > 1)[0]
+            if len(bad):
+                raise QPSolveFailure(int(bad[0]), int(r["status"][bad[0]]))
+        if tau is not None:
+            np.copyto(tau, r["tau"])
+            return tau
+        return r["tau"]

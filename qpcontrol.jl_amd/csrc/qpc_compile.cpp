@@ -320,6 +320,10 @@ int qpc_compile_program(qpc_controller *c) {
   Lo.ref_n_var = nvar; Lo.ref_n_eq = neq; Lo.ref_n_ineq = D.nc * 2 * N;
   Lo.n_free = D.nf; Lo.n_pinned = D.npin; Lo.n_slack = ne; Lo.n_rho = nrho; Lo.n_eq_rows = mm;
   Lo.lds_bytes_per_qp = D.lds_doubles * 8;
+  if (D.m > 64) {
+    qpc_set_error("more than 64 equality rows in the reduced QP are not supported by the lane=row factorization");
+    return QPC_ERR_UNSUPPORTED;
+  }
   if (Lo.lds_bytes_per_qp > 160 * 1024) {
     qpc_set_error("problem does not fit the 160 KiB LDS of one CU");
     return QPC_ERR_UNSUPPORTED;

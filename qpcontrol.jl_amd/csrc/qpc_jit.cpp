@@ -29,7 +29,7 @@ static std::string dbl(double x) {
 std::string qpc_jit_source(const QpcDims &D) {
   std::ostringstream o;
   o << "typedef int int32_t;\ntypedef unsigned int uint32_t;\ntypedef long long int64_t;\n";
-  o << "#define QPC_JIT 1\n#include \"qpc_device.h\"\n";
+  o << "#define QPC_JIT 1\n#define QPC_M1_MAX " << (D.m1 > 0 ? D.m1 : 1) << "\n#include \"qpc_device.h\"\n";
   const char *st = getenv("QPC_JIT_STAMPS"); // diagnostic: in-kernel section timers
   const bool stamps = st && st[0] == '1';
   if (stamps)
@@ -106,5 +106,17 @@ extern "C" int32_t qpc_debug_jit_compile(qpc_controller *c, const char *arch, co
   if (logbuf && logn > 0) snprintf(logbuf, logn, "%s", log.c_str());
   if (rc != 0) { qpc_set_error("JIT compile failed: " + log); return QPC_ERR_HIP; }
   if (out_path) { FILE *f = fopen(out_path, "wb"); if (f) { fwrite(code.data(), 1, code.size(), f); fclose(f); } }
+  return QPC_OK;
+}
+
+// diagnostic: write the specialised translation unit to a file (for offline ISA experiments)
+extern "C" int32_t qpc_debug_jit_source(qpc_controller *c, const char *out_path) {
+  if (!c || !out_path) return QPC_ERR_INVALID_ARGUMENT;
+  if (!c->finalized) { int rc = qpc_compile_program(c); if (rc != QPC_OK) return rc; }
+  std::string src = qpc_jit_source(c->prog.dims);
+  FILE *f = fopen(out_path, "wb");
+  if (!f) return QPC_ERR_INVALID_ARGUMENT;
+  fwrite(src.data(), 1, src.size(), f);
+  fclose(f);
   return QPC_OK;
 }

@@ -110,6 +110,37 @@ template <class P> QPC_FN void ld6(P sm, int off, int body, double *x) {
   else ld(sm + off + 6 * body, 6, x);
 }
 
+
+// Strided LDS dot product with the loads issued in explicit batches of 8 operand pairs BEFORE the
+// FMAs: hipcc keeps LDS loads in source order inside this (huge, fully inlined) kernel, so the
+// naive `acc += a[i]*b[i]` loop pays one full LDS latency per term; batched, it pays one per 8.
+#ifndef QPC_UNROLL_FULL
+#define QPC_UNROLL_FULL
+#endif
+// compile-time bound of the leading Schur block (the JIT defines it as the actual m1)
+#ifndef QPC_M1_MAX
+#define QPC_M1_MAX 64
+#endif
+template <class PA, class PB> QPC_FN double dotp(PA a, int sa, PB b, int sb, int n) {
+  double acc0 = 0.0, acc1 = 0.0;
+  for (int i0 = 0; i0 < n; i0 += 8) {
+    double x[8], y[8];
+    QPC_UNROLL_FULL
+    for (int u = 0; u < 8; u++) {
+      const int i = i0 + u;
+      const int ic = i < n ? i : 0;
+      x[u] = a[ic * sa];
+      y[u] = b[ic * sb];
+    }
+    QPC_UNROLL_FULL
+    for (int u = 0; u < 8; u += 2) {
+      acc0 += (i0 + u < n) ? x[u] * y[u] : 0.0;
+      acc1 += (i0 + u + 1 < n) ? x[u + 1] * y[u + 1] : 0.0;
+    }
+  }
+  return acc0 + acc1;
+}
+
 // uniform (all lanes identical) reductions over an LDS array, used OUTSIDE phases
 template <class P> QPC_FN double umax(P sm, int off, int n) {
   double m = 0.0;
@@ -246,6 +277,24 @@ template <class P> struct Solver {
   QPC_FN Solver(const QpcDims &d, const int *it, const double *dt, P s, unsigned long long *pa, unsigned long long *pt)
       : D(d), IT(it), DT(dt), sm(s), use_rho(d.nrho > 0), PA(pa), PT(pt) {}
 
+  // sum_j G[a][j] * rho_fix[j] with rho_fix = hi on the upper-active set (batched like dotp)
+  QPC_FN double dot_fix(int goff, int gstride, int j0, int n) const {
+    double acc = 0.0;
+    for (int i0 = 0; i0 < n; i0 += 8) {
+      double g[8], w[8], h[8];
+      QPC_UNROLL_FULL
+      for (int u = 0; u < 8; u++) {
+        const int i = i0 + u, ic = i < n ? i : 0;
+        g[u] = sm[goff + ic * gstride];
+        w[u] = sm[D.lds[L_WS] + j0 + ic];
+        h[u] = sm[D.lds[L_HI] + j0 + ic];
+      }
+      QPC_UNROLL_FULL
+      for (int u = 0; u < 8; u++) acc += (i0 + u < n && w[u] == 1.0) ? g[u] * h[u] : 0.0;
+    }
+    return acc;
+  }
+
   // Kr (block inverse of Hrho+eps on the free set), S22 = B22 + G Kr G', T22 = S22^-1
   QPC_FN void refactor_rho() {
     const int N = D.N, nc = D.nc, nrho = D.nrho, m1 = D.m1;
@@ -261,10 +310,7 @@ template <class P> struct Solver {
       QPC_PHASE(lane) {
         for (int idx = lane; idx < nrho * 6; idx += 64) {
           int j = idx / 6, b = idx % 6, c = j / N, jj = j % N;
-          double acc = 0.0;
-          QPC_UNROLL
-          for (int i = 0; i < N; i++) acc += sm[D.lds[L_KR] + c * N * N + jj * N + i] * sm[D.lds[L_G] + b * nrho + c * N + i];
-          sm[D.lds[L_Y] + j * 6 + b] = acc;
+          sm[D.lds[L_Y] + j * 6 + b] = dotp(sm + D.lds[L_KR] + c * N * N + jj * N, 1, sm + D.lds[L_G] + b * nrho + c * N, 1, N);
         }
       } QPC_END_PHASE
     }
@@ -272,9 +318,7 @@ template <class P> struct Solver {
       if (lane < 36) {
         int a = lane / 6, b = lane % 6;
         double acc = sm[D.lds[L_B22] + lane];
-        if (use_rho)
-          QPC_UNROLL
-          for (int j = 0; j < nrho; j++) acc += sm[D.lds[L_G] + a * nrho + j] * sm[D.lds[L_Y] + j * 6 + b];
+        if (use_rho) acc += dotp(sm + D.lds[L_G] + a * nrho, 1, sm + D.lds[L_Y] + b, 6, nrho);
         sm[D.lds[L_C22] + lane] = acc; // S22 = B22 + G Kr G'
       }
     } QPC_END_PHASE
@@ -291,35 +335,21 @@ template <class P> struct Solver {
 
   // lam = S^-1 t (t in L_T1, result in `out`) through the block inverse:
   //   lam2 = T22 (t2 - Z' t1) ;  lam1 = S11I t1 - Z lam2     (S11I in the leading block of L_SM,
-  //   Z = S11^-1 S12 in L_X2, T22 = (B22 + C22)^-1 in L_S22I) -- two phases, no serial chain.
+  //   Z = S11^-1 S12 in L_X2, T22 = (B22 + C22)^-1 in L_S22I) -- no serial chain.
   QPC_FN void solve_S(int out) {
     const int m1 = D.m1, nw = D.nw;
     if (nw) {
+      QPC_PHASE(lane) { // u = t2 - Z' t1  (temporary in L_C22, free outside refactor_rho)
+        if (lane < 6) sm[D.lds[L_C22] + lane] = sm[D.lds[L_T1] + m1 + lane] - dotp(sm + D.lds[L_X2] + lane, 6, sm + D.lds[L_T1], 1, m1);
+      } QPC_END_PHASE
       QPC_PHASE(lane) {
-        if (lane < 6) {
-          double u[6];
-          QPC_UNROLL
-          for (int b = 0; b < 6; b++) u[b] = sm[D.lds[L_T1] + m1 + b];
-          for (int r = 0; r < m1; r++) {
-            double t = sm[D.lds[L_T1] + r];
-            QPC_UNROLL
-            for (int b = 0; b < 6; b++) u[b] -= sm[D.lds[L_X2] + r * 6 + b] * t;
-          }
-          double acc = 0.0;
-          QPC_UNROLL
-          for (int b = 0; b < 6; b++) acc += sm[D.lds[L_S22I] + lane * 6 + b] * u[b];
-          sm[out + m1 + lane] = acc;
-        }
+        if (lane < 6) sm[out + m1 + lane] = dotp(sm + D.lds[L_S22I] + lane * 6, 1, sm + D.lds[L_C22], 1, 6);
       } QPC_END_PHASE
     }
     QPC_PHASE(lane) {
       for (int r = lane; r < m1; r += 64) {
-        double acc = 0.0;
-        QPC_UNROLL
-        for (int c = 0; c < m1; c++) acc += sm[D.lds[L_SM] + r * D.ms + c] * sm[D.lds[L_T1] + c];
-        if (nw)
-          QPC_UNROLL
-          for (int a = 0; a < 6; a++) acc -= sm[D.lds[L_X2] + r * 6 + a] * sm[out + m1 + a];
+        double acc = dotp(sm + D.lds[L_SM] + r * D.ms, 1, sm + D.lds[L_T1], 1, m1);
+        if (nw) acc -= dotp(sm + D.lds[L_X2] + r * 6, 1, sm + out + m1, 1, 6);
         sm[out + r] = acc;
       }
     } QPC_END_PHASE
@@ -334,67 +364,44 @@ template <class P> struct Solver {
       if (use_rho)
         for (int j = lane; j < nrho; j += 64) {
           int c = j / N, jj = j % N;
-          double acc = 0.0;
-          QPC_UNROLL
-          for (int i = 0; i < N; i++) acc += sm[D.lds[L_KR] + c * N * N + jj * N + i] * sm[D.lds[L_RR] + c * N + i];
-          sm[D.lds[L_TR1] + j] = acc;
+          sm[D.lds[L_TR1] + j] = dotp(sm + D.lds[L_KR] + c * N * N + jj * N, 1, sm + D.lds[L_RR] + c * N, 1, N);
         }
       for (int s = lane; s < ne; s += 64) {
         int d = slack_dim(s), wr = slack_woff(s), s0 = slack_s0(s);
-        double acc = 0.0;
-        QPC_UNROLL
-        for (int b = 0; b < d; b++) acc += sm[D.lds[L_WINV] + wr + b] * sm[D.lds[L_RE] + s0 + b];
-        sm[D.lds[L_TE1] + s] = acc;
+        sm[D.lds[L_TE1] + s] = dotp(sm + D.lds[L_WINV] + wr, 1, sm + D.lds[L_RE] + s0, 1, d);
       }
+      for (int f = lane; f < nf; f += 64) sm[D.lds[L_DV] + f] = sm[D.lds[L_SQH] + f] * sm[D.lds[L_RV] + f];
     } QPC_END_PHASE
     QPC_PHASE(lane) {
       for (int r = lane; r < m; r += 64) {
-        double acc = -sm[D.lds[L_RC] + r];
-        QPC_UNROLL
-        for (int f = 0; f < nf; f++) acc += sm[D.lds[L_M] + r * D.nfs + f] * (sm[D.lds[L_SQH] + f] * sm[D.lds[L_RV] + f]);
+        double acc = dotp(sm + D.lds[L_M] + r * D.nfs, 1, sm + D.lds[L_DV], 1, nf) - sm[D.lds[L_RC] + r];
         if (r < m1) {
           int sl = row_slack(r);
           if (sl >= 0) acc -= sm[D.lds[L_TE1] + sl];
         } else if (use_rho) {
-          int a = r - m1;
-          QPC_UNROLL
-          for (int j = 0; j < nrho; j++) acc -= sm[D.lds[L_G] + a * nrho + j] * sm[D.lds[L_TR1] + j];
+          acc -= dotp(sm + D.lds[L_G] + (r - m1) * nrho, 1, sm + D.lds[L_TR1], 1, nrho);
         }
         sm[D.lds[L_T1] + r] = acc;
       }
     } QPC_END_PHASE
     solve_S(D.lds[L_DL]);
     QPC_PHASE(lane) {
-      for (int f = lane; f < nf; f += 64) {
-        double acc = sm[D.lds[L_SQH] + f] * sm[D.lds[L_RV] + f];
-        QPC_UNROLL
-        for (int r = 0; r < m; r++) acc -= sm[D.lds[L_M] + r * D.nfs + f] * sm[D.lds[L_DL] + r];
-        sm[D.lds[L_DV] + f] = acc;
-      }
+      for (int f = lane; f < nf; f += 64)
+        sm[D.lds[L_DV] + f] = sm[D.lds[L_DV] + f] - dotp(sm + D.lds[L_M] + f, D.nfs, sm + D.lds[L_DL], 1, m);
       for (int s = lane; s < ne; s += 64) sm[D.lds[L_TE1] + s] = sm[D.lds[L_RE] + s] + sm[D.lds[L_DL] + slack_row(s)];
       if (use_rho)
-        for (int j = lane; j < nrho; j += 64) {
-          double acc = sm[D.lds[L_RR] + j];
-          QPC_UNROLL
-          for (int a = 0; a < 6; a++) acc += sm[D.lds[L_G] + a * nrho + j] * sm[D.lds[L_DL] + m1 + a];
-          sm[D.lds[L_TR2] + j] = acc;
-        }
+        for (int j = lane; j < nrho; j += 64)
+          sm[D.lds[L_TR2] + j] = sm[D.lds[L_RR] + j] + dotp(sm + D.lds[L_G] + j, nrho, sm + D.lds[L_DL] + m1, 1, 6);
     } QPC_END_PHASE
     QPC_PHASE(lane) {
       for (int s = lane; s < ne; s += 64) {
         int d = slack_dim(s), wr = slack_woff(s), s0 = slack_s0(s);
-        double acc = 0.0;
-        QPC_UNROLL
-        for (int b = 0; b < d; b++) acc += sm[D.lds[L_WINV] + wr + b] * sm[D.lds[L_TE1] + s0 + b];
-        sm[D.lds[L_DE] + s] = acc;
+        sm[D.lds[L_DE] + s] = dotp(sm + D.lds[L_WINV] + wr, 1, sm + D.lds[L_TE1] + s0, 1, d);
       }
       if (use_rho)
         for (int j = lane; j < nrho; j += 64) {
           int c = j / N, jj = j % N;
-          double acc = 0.0;
-          QPC_UNROLL
-          for (int i = 0; i < N; i++) acc += sm[D.lds[L_KR] + c * N * N + jj * N + i] * sm[D.lds[L_TR2] + c * N + i];
-          sm[D.lds[L_DR] + j] = acc;
+          sm[D.lds[L_DR] + j] = dotp(sm + D.lds[L_KR] + c * N * N + jj * N, 1, sm + D.lds[L_TR2] + c * N, 1, N);
         }
     } QPC_END_PHASE
     QPC_PROF_ACC(PS_KKT);
@@ -407,41 +414,30 @@ template <class P> struct Solver {
     QPC_PROF_ACC(PS_LOGIC);
     QPC_PHASE(lane) {
       for (int r = lane; r < m; r += 64) {
-        double acc = sm[D.lds[L_D] + r];
-        QPC_UNROLL
-        for (int f = 0; f < nf; f++) acc -= sm[D.lds[L_M] + r * D.nfs + f] * sm[D.lds[L_XV] + f];
+        double acc = sm[D.lds[L_D] + r] - dotp(sm + D.lds[L_M] + r * D.nfs, 1, sm + D.lds[L_XV], 1, nf);
         if (r < m1) {
           int sl = row_slack(r);
           if (sl >= 0) acc += sm[D.lds[L_XE] + sl];
         } else if (use_rho) {
-          int a = r - m1;
-          QPC_UNROLL
-          for (int j = 0; j < nrho; j++) acc += sm[D.lds[L_G] + a * nrho + j] * sm[D.lds[L_XR] + j];
+          acc += dotp(sm + D.lds[L_G] + (r - m1) * nrho, 1, sm + D.lds[L_XR], 1, nrho);
         }
         sm[D.lds[L_RC] + r] = acc;
       }
       for (int f = lane; f < nf; f += 64) {
-        double mtl = 0.0;
-        QPC_UNROLL
-        for (int r = 0; r < m; r++) mtl += sm[D.lds[L_M] + r * D.nfs + f] * sm[D.lds[L_LAM] + r];
+        double mtl = dotp(sm + D.lds[L_M] + f, D.nfs, sm + D.lds[L_LAM], 1, m);
         double sq = sm[D.lds[L_SQH] + f];
         sm[D.lds[L_RV] + f] = -(sm[D.lds[L_HV] + f] * sq * sm[D.lds[L_XV] + f] + sm[D.lds[L_GV] + f] + mtl / sq);
       }
       for (int s = lane; s < ne; s += 64) {
         int d = slack_dim(s), wr = slack_woff(s), s0 = slack_s0(s);
-        double acc = 0.0;
-        QPC_UNROLL
-        for (int b = 0; b < d; b++) acc += sm[D.lds[L_W] + wr + b] * sm[D.lds[L_XE] + s0 + b];
+        double acc = dotp(sm + D.lds[L_W] + wr, 1, sm + D.lds[L_XE] + s0, 1, d);
         sm[D.lds[L_RE] + s] = -(acc - sm[D.lds[L_LAM] + slack_row(s)]);
       }
       if (use_rho)
         for (int j = lane; j < nrho; j += 64) {
           int c = j / N, jj = j % N;
-          double gl = 0.0;
-          QPC_UNROLL
-          for (int i = 0; i < N; i++) gl += sm[D.lds[L_HR] + c * N * N + jj * N + i] * sm[D.lds[L_XR] + c * N + i];
-          QPC_UNROLL
-          for (int a = 0; a < 6; a++) gl -= sm[D.lds[L_G] + a * nrho + j] * sm[D.lds[L_LAM] + m1 + a];
+          double gl = dotp(sm + D.lds[L_HR] + c * N * N + jj * N, 1, sm + D.lds[L_XR] + c * N, 1, N) -
+                      dotp(sm + D.lds[L_G] + j, nrho, sm + D.lds[L_LAM] + m1, 1, 6);
           sm[D.lds[L_TR1] + j] = gl;
           sm[D.lds[L_RR] + j] = (sm[D.lds[L_WS] + j] == 0.0) ? -gl : 0.0;
         }
@@ -504,11 +500,8 @@ template <class P> struct Solver {
       double g = 0.0, x = 0.0;
       for (int j = lane; j < nrho; j += 64) {
         int c = j / N, jj = j % N;
-        double gl = 0.0;
-        QPC_UNROLL
-        for (int i = 0; i < N; i++) gl += sm[D.lds[L_HR] + c * N * N + jj * N + i] * sm[D.lds[L_XR] + c * N + i];
-        QPC_UNROLL
-        for (int a = 0; a < 6; a++) gl -= sm[D.lds[L_G] + a * nrho + j] * sm[D.lds[L_LAM] + m1 + a];
+        double gl = dotp(sm + D.lds[L_HR] + c * N * N + jj * N, 1, sm + D.lds[L_XR] + c * N, 1, N) -
+                    dotp(sm + D.lds[L_G] + j, nrho, sm + D.lds[L_LAM] + m1, 1, 6);
         double w = sm[D.lds[L_WS] + j];
         sm[D.lds[L_U] + j] = (w == -1.0) ? gl : ((w == 1.0) ? -gl : 0.0);
         g = QPC_FABS(gl) > g ? QPC_FABS(gl) : g;
@@ -532,19 +525,13 @@ template <class P> struct Solver {
       for (int s = lane; s < ne; s += 64) sm[D.lds[L_RE] + s] = 0.0;
       for (int r = lane; r < m; r += 64) {
         double acc = sm[D.lds[L_D] + r];
-        if (r >= m1 && use_rho) {
-          int a = r - m1;
-          for (int j = 0; j < nrho; j++)
-            if (sm[D.lds[L_WS] + j] == 1.0) acc += sm[D.lds[L_G] + a * nrho + j] * sm[D.lds[L_HI] + j];
-        }
+        if (r >= m1 && use_rho) acc += dot_fix(D.lds[L_G] + (r - m1) * nrho, 1, 0, nrho);
         sm[D.lds[L_RC] + r] = acc;
       }
       for (int j = lane; j < nrho; j += 64) {
         int c = j / N, jj = j % N;
         double acc = 0.0;
-        if (sm[D.lds[L_WS] + j] == 0.0)
-          for (int i = 0; i < N; i++)
-            if (sm[D.lds[L_WS] + c * N + i] == 1.0) acc -= sm[D.lds[L_HR] + c * N * N + jj * N + i] * sm[D.lds[L_HI] + c * N + i];
+        if (sm[D.lds[L_WS] + j] == 0.0) acc = -dot_fix(D.lds[L_HR] + c * N * N + jj * N, 1, c * N, N);
         sm[D.lds[L_RR] + j] = acc;
       }
     } QPC_END_PHASE
@@ -961,9 +948,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
     for (int idx = lane; idx < m * m; idx += 64) {
       int r = idx / m, c = idx % m;
       if (c > r) continue;
-      double acc = 0.0;
-      QPC_UNROLL
-      for (int f = 0; f < nf; f++) acc += sm[D.lds[L_M] + r * D.nfs + f] * sm[D.lds[L_M] + c * D.nfs + f];
+      double acc = dotp(sm + D.lds[L_M] + r * D.nfs, 1, sm + D.lds[L_M] + c * D.nfs, 1, nf);
       int tr = IT[D.it[IT_ROW_TASK] + r], tc = IT[D.it[IT_ROW_TASK] + c];
       if (tr >= 0 && tr == tc) {
         int w0 = IT[D.it[IT_T_WOFF] + tr];
@@ -973,54 +958,70 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
     }
   } QPC_END_PHASE
   QPC_PROF_ACC(PS_SBUILD);
-  // left-looking Cholesky of the leading m1 x m1 block (+ the L21 rows), infinite-pivot rule
-  for (int k = 0; k < m1; k++) {
-    QPC_PHASE(lane) {
-      for (int r = lane + k; r < m; r += 64) {
-        double accr = 0.0, acck = 0.0;
-        for (int j = 0; j < k; j++) {
-          double lk = sm[D.lds[L_SM] + k * D.ms + j];
-          accr += lk * sm[D.lds[L_SM] + r * D.ms + j];
-          acck += lk * lk;
+  // left-looking Cholesky of the leading m1 x m1 block (+ the L21 rows), infinite-pivot rule.
+  // lane = row; the row's own factor entries stay in registers (constant indices once the k loop
+  // is unrolled by the JIT specialisation), row k is broadcast from LDS.
+  {
+    QPC_LANE_ARRAY(lrow_, QPC_M1_MAX); // lane-private across the k phases
+    for (int k = 0; k < m1; k++) {
+      QPC_PHASE(lane) {
+        if (lane >= k && lane < m) { // m <= 64 (checked by the host compiler)
+          const int r = lane;
+          double *lrow = QPC_LA(lrow_, lane);
+          double accr = 0.0, acck = 0.0;
+          for (int j0 = 0; j0 < k; j0 += 8) {
+            double lk[8];
+            QPC_UNROLL_FULL
+            for (int u = 0; u < 8; u++) lk[u] = sm[D.lds[L_SM] + k * D.ms + (j0 + u < k ? j0 + u : 0)];
+            QPC_UNROLL_FULL
+            for (int u = 0; u < 8; u++)
+              if (j0 + u < k) { accr += lk[u] * lrow[j0 + u]; acck += lk[u] * lk[u]; }
+          }
+          double skk = sm[D.lds[L_SM] + k * D.ms + k], srk = sm[D.lds[L_SM] + r * D.ms + k], dk = skk - acck;
+          bool ok = dk > D.tau_pivot * (skk > 1e-300 ? skk : 1e-300);
+          double ld_ = ok ? QPC_SQRT(dk) : 0.0, inv = ok ? 1.0 / ld_ : 0.0;
+          if (r == k) sm[D.lds[L_T1] + k] = inv; // 1/L_kk (0 = dropped row)
+          else { double v = (srk - accr) * inv; lrow[k] = v; sm[D.lds[L_SM] + r * D.ms + k] = v; }
         }
-        double skk = sm[D.lds[L_SM] + k * D.ms + k], dk = skk - acck;
-        bool ok = dk > D.tau_pivot * (skk > 1e-300 ? skk : 1e-300);
-        double ld_ = ok ? QPC_SQRT(dk) : 0.0, inv = ok ? 1.0 / ld_ : 0.0;
-        if (r == k) sm[D.lds[L_T1] + k] = inv; // 1/L_kk (0 = dropped row)
-        else sm[D.lds[L_SM] + r * D.ms + k] = (sm[D.lds[L_SM] + r * D.ms + k] - accr) * inv;
-      }
-    } QPC_END_PHASE
+      } QPC_END_PHASE
+    }
   }
   QPC_PROF_ACC(PS_CHOL);
-  QPC_PHASE(lane) { // B22 = S22 - L21 L21' ; X = L11^-1 (lane = column, private forward substitution)
+  QPC_PHASE(lane) { // B22 = S22 - L21 L21' ; X = L11^-1 (lane = column, forward substitution in registers)
     if (lane < 36 && nw) {
       int a = lane / 6, b = lane % 6, hi_ = a > b ? a : b, lo_ = a > b ? b : a;
-      double acc = sm[D.lds[L_SM] + (m1 + hi_) * D.ms + (m1 + lo_)];
-      for (int j = 0; j < m1; j++) acc -= sm[D.lds[L_SM] + (m1 + a) * D.ms + j] * sm[D.lds[L_SM] + (m1 + b) * D.ms + j];
-      sm[D.lds[L_B22] + lane] = acc;
+      sm[D.lds[L_B22] + lane] = sm[D.lds[L_SM] + (m1 + hi_) * D.ms + (m1 + lo_)] -
+                                dotp(sm + D.lds[L_SM] + (m1 + a) * D.ms, 1, sm + D.lds[L_SM] + (m1 + b) * D.ms, 1, m1);
     }
-    for (int c = lane; c < m1; c += 64)
-      for (int r = c; r < m1; r++) {
+    if (lane < m1) {
+      const int c = lane;
+      double xc[QPC_M1_MAX];
+      for (int r = 0; r < m1; r++) {
         double t = (r == c) ? 1.0 : 0.0;
-        for (int j = c; j < r; j++) t -= sm[D.lds[L_SM] + r * D.ms + j] * sm[D.lds[L_X] + j * D.m1s + c];
-        sm[D.lds[L_X] + r * D.m1s + c] = t * sm[D.lds[L_T1] + r];
+        for (int j0 = 0; j0 < r; j0 += 8) {
+          double lr[8];
+          QPC_UNROLL_FULL
+          for (int u = 0; u < 8; u++) lr[u] = sm[D.lds[L_SM] + r * D.ms + (j0 + u < r ? j0 + u : 0)];
+          QPC_UNROLL_FULL
+          for (int u = 0; u < 8; u++)
+            if (j0 + u < r) t -= lr[u] * xc[j0 + u];
+        }
+        double x = (r >= c) ? t * sm[D.lds[L_T1] + r] : 0.0;
+        xc[r] = x;
+        sm[D.lds[L_X] + r * D.m1s + c] = x;
       }
+    }
   } QPC_END_PHASE
-
   QPC_PHASE(lane) { // S11I = X'X into the (now free) leading block of L_SM ; Z = X' L21' = S11^-1 S12
     for (int idx = lane; idx < m1 * m1; idx += 64) {
       int r = idx / m1, c = idx % m1;
       int k0 = r > c ? r : c;
-      double acc = 0.0;
-      for (int k = k0; k < m1; k++) acc += sm[D.lds[L_X] + k * D.m1s + r] * sm[D.lds[L_X] + k * D.m1s + c];
-      sm[D.lds[L_SM] + r * D.ms + c] = acc;
+      sm[D.lds[L_SM] + r * D.ms + c] = dotp(sm + D.lds[L_X] + k0 * D.m1s + r, D.m1s, sm + D.lds[L_X] + k0 * D.m1s + c, D.m1s, m1 - k0);
     }
     if (nw)
       for (int idx = lane; idx < m1 * 6; idx += 64) {
         int r = idx / 6, a = idx % 6;
-        double acc = 0.0;
-        for (int k = r; k < m1; k++) acc += sm[D.lds[L_X] + k * D.m1s + r] * sm[D.lds[L_SM] + (m1 + a) * D.ms + k];
-        sm[D.lds[L_X2] + idx] = acc;
+        sm[D.lds[L_X2] + idx] = dotp(sm + D.lds[L_X] + r * D.m1s + r, D.m1s, sm + D.lds[L_SM] + (m1 + a) * D.ms + r, 1, m1 - r);
       }
   } QPC_END_PHASE
   QPC_PROF_ACC(PS_XINV);

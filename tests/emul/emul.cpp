@@ -64,6 +64,8 @@ struct Lds {
 #define QPC_SINCOS(x, s, c) do { double x__ = (x); s = std::sin(x__); c = std::cos(x__); } while (0)
 #define QPC_SQRT(x) std::sqrt((double)(x))
 #define QPC_FABS(x) std::fabs((double)(x))
+#define QPC_LANE_ARRAY(name, n) double name[64][n]
+#define QPC_LA(name, lane) name[lane]
 // reductions across a phase boundary: lane-serial form through the (emulator-only) scratch that
 // follows the kernel's LDS slab
 #define QPC_RED_MAX_PUT(slot, name, val) sm[D.lds_doubles + 128 * (slot) + lane] = (val)
