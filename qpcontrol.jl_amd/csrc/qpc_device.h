@@ -13,6 +13,7 @@
 #define QPC_LANE_ARRAY(name, n) double name[n]
 #define QPC_LA(name, lane) name
 #ifdef QPC_JIT
+#define QPC_UNROLL_JIT _Pragma("unroll")
 #define QPC_UNROLL _Pragma("unroll")
 #else
 #define QPC_UNROLL _Pragma("unroll 4")

@@ -84,10 +84,9 @@ enum {
   MS_ADV = 3,      // 6
   MS_WG = 9,       // 6
   MS_EPS = 15, MS_HSCALE = 16,
-  MS_STATUS = 17, MS_ITERS = 18, MS_FLAG = 19, MS_P = 20, MS_SIDE = 21, MS_T = 22, MS_JDROP = 23,
-  MS_NDROP = 24, MS_RPRIM = 25, MS_RSTAT = 26, MS_XBIG = 27, MS_DBIG = 28, MS_GSCALE = 29,
-  MS_TOLB = 30, MS_CHANGED = 31, MS_FULL = 32, MS_SCP = 33, MS_SCS = 34, MS_REFINE = 35,
-  MS_COUNT = 36
+  MS_S22D = 17,    // 6: diagonal of S22 before inversion
+  MS_S22OK = 23,   // 6: pivot accepted flags
+  MS_COUNT = 30
 };
 
 struct QpcDims {

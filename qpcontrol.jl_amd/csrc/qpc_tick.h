@@ -121,6 +121,10 @@ template <class P> QPC_FN void ld6(P sm, int off, int body, double *x) {
 #ifndef QPC_M1_MAX
 #define QPC_M1_MAX 64
 #endif
+// full unroll only when trip counts are compile-time constants (JIT specialisation)
+#ifndef QPC_UNROLL_JIT
+#define QPC_UNROLL_JIT
+#endif
 template <class PA, class PB> QPC_FN double dotp(PA a, int sa, PB b, int sb, int n) {
   double acc0 = 0.0, acc1 = 0.0;
   for (int i0 = 0; i0 < n; i0 += 8) {
@@ -320,14 +324,39 @@ template <class P> struct Solver {
         double acc = sm[D.lds[L_B22] + lane];
         if (use_rho) acc += dotp(sm + D.lds[L_G] + a * nrho, 1, sm + D.lds[L_Y] + b, 6, nrho);
         sm[D.lds[L_C22] + lane] = acc; // S22 = B22 + G Kr G'
+        if (a == b) sm[D.lds[L_MISC] + MS_S22D + a] = acc;
       }
     } QPC_END_PHASE
-    QPC_PHASE(lane) {
-      if (lane == 0) {
-        double sref[6];
-        for (int k = 0; k < 6; k++)
-          sref[k] = sm[D.lds[L_SM] + (m1 + k) * D.ms + (m1 + k)] + (sm[D.lds[L_C22] + k * 6 + k] - sm[D.lds[L_B22] + k * 6 + k]);
-        inv6_spd(sm + D.lds[L_C22], sref, D.tau_pivot, sm + D.lds[L_S22I]);
+    // T22 = S22^-1 by in-place Gauss-Jordan, one entry per lane, one phase per pivot (ping-pong
+    // between L_C22 and L_L22); a pivot below tau * reference marks a redundant wrench row: its
+    // elimination step is skipped and its row/column of T22 are zeroed (infinite-pivot rule).
+    for (int k = 0; k < 6; k++) {
+      const int src = (k & 1) ? D.lds[L_L22] : D.lds[L_C22], dst = (k & 1) ? D.lds[L_C22] : D.lds[L_L22];
+      QPC_PHASE(lane) {
+        if (lane < 36) {
+          const int i = lane / 6, j = lane % 6;
+          const double p = sm[src + k * 6 + k], aij = sm[src + lane], aik = sm[src + i * 6 + k], akj = sm[src + k * 6 + j];
+          const double ref = sm[D.lds[L_SM] + (m1 + k) * D.ms + (m1 + k)] + (sm[D.lds[L_MISC] + MS_S22D + k] - sm[D.lds[L_B22] + k * 6 + k]);
+          const bool ok = p > D.tau_pivot * (ref > 1e-300 ? ref : 1e-300);
+          double r;
+          if (!ok) r = aij;
+          else {
+            const double ip = 1.0 / p;
+            if (i == k && j == k) r = ip;
+            else if (i == k) r = akj * ip;
+            else if (j == k) r = -aik * ip;
+            else r = aij - aik * akj * ip;
+          }
+          sm[dst + lane] = r;
+          if (j == 0 && i == k) sm[D.lds[L_MISC] + MS_S22OK + k] = ok ? 1.0 : 0.0;
+        }
+      } QPC_END_PHASE
+    }
+    QPC_PHASE(lane) { // after 6 ping-pong steps the result sits in L_C22
+      if (lane < 36) {
+        const int i = lane / 6, j = lane % 6;
+        const bool ok = sm[D.lds[L_MISC] + MS_S22OK + i] != 0.0 && sm[D.lds[L_MISC] + MS_S22OK + j] != 0.0;
+        sm[D.lds[L_S22I] + lane] = ok ? (double)sm[D.lds[L_C22] + lane] : 0.0;
       }
     } QPC_END_PHASE
     QPC_PROF_ACC(PS_REFAC);
@@ -963,6 +992,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
   // is unrolled by the JIT specialisation), row k is broadcast from LDS.
   {
     QPC_LANE_ARRAY(lrow_, QPC_M1_MAX); // lane-private across the k phases
+    QPC_UNROLL_JIT
     for (int k = 0; k < m1; k++) {
       QPC_PHASE(lane) {
         if (lane >= k && lane < m) { // m <= 64 (checked by the host compiler)
@@ -996,6 +1026,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
     if (lane < m1) {
       const int c = lane;
       double xc[QPC_M1_MAX];
+      QPC_UNROLL_JIT
       for (int r = 0; r < m1; r++) {
         double t = (r == c) ? 1.0 : 0.0;
         for (int j0 = 0; j0 < r; j0 += 8) {

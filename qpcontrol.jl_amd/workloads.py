@@ -250,3 +250,21 @@ def atlas_workload(ctrl_factory, B, config=3, seed=None):
         active = rng.uniform(size=(B, nc)) < pq[:, None]
         cmax = np.where(active, 1e6, 0.0)  # disable!(contact): maxnormalforce := 0 (contacts.jl:72)
     return ctrl, Workload(f"atlas_config{config}", mech, st, q, v, des, cw, cmax, floating)
+
+
+# ------------------------------------------------------------------------------------------
+# multi-GPU: the batch shards embarrassingly, no collective in the data path
+# ------------------------------------------------------------------------------------------
+def shard_bounds(B_global, rank, world):
+    """Contiguous shard [lo, hi) of QP indices owned by `rank` (sizes differ by at most one)."""
+    base, rem = divmod(B_global, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def run_sharded(ctrl, wl: Workload, rank, world):
+    """Solve this rank's shard of a global workload with its own controller replica."""
+    lo, hi = shard_bounds(wl.q.shape[0], rank, world)
+    r = ctrl.control_batch(wl.q[lo:hi], wl.v[lo:hi], wl.desired[lo:hi], wl.contact_weight[lo:hi],
+                           wl.contact_maxnormalforce[lo:hi])
+    return lo, hi, r

@@ -1,0 +1,68 @@
+"""N > 1 path on CPU: two processes (gloo) each own a contiguous shard of a global batch and a
+replica of the controller; results gathered over the process group equal the single-process
+result bitwise.  The compute backend here is the test-only emulation of the device code (no GPU in
+this container); bench.py runs the same sharding with one MI355X per rank."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import qpc_pkg; qpc_pkg.load()
+import emu
+from qpcontrol_jl_amd import workloads as W
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+B = 13  # deliberately not divisible by 2
+ctrl, wl = W.atlas_workload(emu.factory, B, 3)
+lo, hi, r = W.run_sharded(ctrl, wl, rank, world)
+assert (lo, hi) == W.shard_bounds(B, rank, world)
+# gather (padded) shards on every rank -- test-side only; the data path itself has no collective
+nv = wl.mech.nv
+pad = (B + world - 1) // world
+buf = torch.zeros(pad, nv + 1, dtype=torch.float64)
+buf[: hi - lo, :nv] = torch.from_numpy(r["tau"]); buf[: hi - lo, nv] = torch.from_numpy(r["status"].astype(np.float64))
+out = [torch.zeros_like(buf) for _ in range(world)]
+dist.all_gather(out, buf)
+t = torch.tensor([float(hi - lo)], dtype=torch.float64)
+dist.all_reduce(t)  # sum of shard sizes == B
+if rank == 0:
+    tau = np.concatenate([out[k][: W.shard_bounds(B, k, world)[1] - W.shard_bounds(B, k, world)[0], :nv].numpy() for k in range(world)])
+    full = ctrl.control_batch(wl.q, wl.v, wl.desired, wl.contact_weight, wl.contact_maxnormalforce)
+    assert int(t.item()) == B
+    assert np.array_equal(tau, full["tau"]), np.abs(tau - full["tau"]).max()
+    print("SHARDED_OK", B, world)
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_sharding_matches_single_process(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531")
+    procs = []
+    for rank in range(2):
+        e = dict(env, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "SHARDED_OK 13 2" in outs[0]
+
+
+def test_shard_bounds_cover_batch():
+    from qpcontrol_jl_amd import workloads as W
+    for B in (1, 7, 8, 262144):
+        for world in (1, 2, 3, 4, 8):
+            b = [W.shard_bounds(B, r, world) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == B
+            assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
