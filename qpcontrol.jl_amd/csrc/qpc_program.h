@@ -86,7 +86,8 @@ enum {
   MS_EPS = 15, MS_HSCALE = 16,
   MS_S22D = 17,    // 6: diagonal of S22 before inversion
   MS_S22OK = 23,   // 6: pivot accepted flags
-  MS_COUNT = 30
+  MS_U0 = 29,      // 6: wrench-space constant u0 = c2 - Z'c1 of the active-set search
+  MS_COUNT = 36
 };
 
 struct QpcDims {

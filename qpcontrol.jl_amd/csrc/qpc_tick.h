@@ -520,6 +520,66 @@ template <class P> struct Solver {
     return it;
   }
 
+  // ---- wrench-space solves for the active-set SEARCH --------------------------------------
+  // rho enters the equality block only through the 6 wrench-balance rows, so for a given working
+  // set   lam_w = T22 (u0 - G (K r_r + rho_fix)),   rho_F = K (r_r + G' lam_w)   with the 6-vector
+  // u0 = c2 - Z' c1 fixed for the whole tick (c = E H^-1 (-g) - d, no rho terms).  Task-row
+  // multipliers, v̇ and slacks are NOT needed to decide the working set; they are recovered by the
+  // refined full solve at the end.
+  //   base = true : EQP of the working set (r_r = -(H_rho rho_fix)_F), result -> L_XR, L_LAM[m1..]
+  //   base = false: Goldfarb-Idnani direction for r_r = nsign * e_p,   result -> L_DR, L_DL[m1..]
+  QPC_FN void rho_solve(bool base, int p, double nsign, bool any_upper) {
+    const int N = D.N, nrho = D.nrho, m1 = D.m1;
+    const int outr = base ? D.lds[L_XR] : D.lds[L_DR], outl = (base ? D.lds[L_LAM] : D.lds[L_DL]) + m1;
+    QPC_PROF_ACC(PS_LOGIC);
+    const bool need_kr = !base || any_upper;
+    if (need_kr) {
+      QPC_PHASE(lane) { // TR1 = K r_r + rho_fix ; RR kept for the back-substitution
+        for (int j = lane; j < nrho; j += 64) {
+          int c = j / N, jj = j % N;
+          double acc = 0.0, fix = 0.0;
+          if (base) {
+            fix = (sm[D.lds[L_WS] + j] == 1.0) ? (double)sm[D.lds[L_HI] + j] : 0.0;
+            // r_r(i) = -(H rho_fix)_i on free i ;  acc = sum_i K[jj][i] r_r(i)
+            for (int i = 0; i < N; i++) {
+              double rr = (sm[D.lds[L_WS] + c * N + i] == 0.0) ? -dot_fix(D.lds[L_HR] + c * N * N + i * N, 1, c * N, N) : 0.0;
+              acc += sm[D.lds[L_KR] + c * N * N + jj * N + i] * rr;
+              if (i == jj) sm[D.lds[L_RR] + j] = rr;
+            }
+          } else {
+            acc = (p / N == c) ? nsign * sm[D.lds[L_KR] + c * N * N + jj * N + (p % N)] : 0.0;
+            sm[D.lds[L_RR] + j] = (j == p) ? nsign : 0.0;
+          }
+          sm[D.lds[L_TR1] + j] = acc + fix;
+        }
+      } QPC_END_PHASE
+    }
+    QPC_PHASE(lane) { // u = u0 - G (K r_r + rho_fix)   (temporary in L_C22[0..5])
+      if (lane < 6) {
+        double u = base ? (double)sm[D.lds[L_MISC] + MS_U0 + lane] : 0.0;
+        if (need_kr) u -= dotp(sm + D.lds[L_G] + lane * nrho, 1, sm + D.lds[L_TR1], 1, nrho);
+        sm[D.lds[L_C22] + lane] = u;
+      }
+    } QPC_END_PHASE
+    QPC_PHASE(lane) {
+      if (lane < 6) sm[outl + lane] = dotp(sm + D.lds[L_S22I] + lane * 6, 1, sm + D.lds[L_C22], 1, 6);
+    } QPC_END_PHASE
+    QPC_PHASE(lane) { // rho_F = K (r_r + G' lam_w) (+ rho_fix); each lane rebuilds its contact's N w's
+      for (int j = lane; j < nrho; j += 64) {
+        int c = j / N, jj = j % N;
+        double acc = 0.0;
+        for (int i = 0; i < N; i++) {
+          double w = dotp(sm + D.lds[L_G] + c * N + i, nrho, sm + outl, 1, 6);
+          if (need_kr) w += sm[D.lds[L_RR] + c * N + i];
+          acc += sm[D.lds[L_KR] + c * N * N + jj * N + i] * w;
+        }
+        if (base && sm[D.lds[L_WS] + j] == 1.0) acc += sm[D.lds[L_HI] + j];
+        sm[outr + j] = acc;
+      }
+    } QPC_END_PHASE
+    QPC_PROF_ACC(PS_KKT);
+  }
+
   // multipliers of the bound constraints: u = +-(H_rho rho - G' lam_w) on the working set -> L_U;
   // returns max |gradient| and max |rho| (uniform) for the tolerances
   QPC_FN void multipliers(double &gmax, double &xmax) {
@@ -1059,17 +1119,29 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
   // ======================================================================== active-set solve (a13)
   Solver<P> S(D, IT, DT, sm, PA, PT);
   int status = QPC_STATUS_OPTIMAL, iters = 0;
-  S.refactor_rho();
-  S.eqp_fresh();
   if (use_rho) {
+    // u0 = c2 - Z' c1 with c = E H^-1 (-g) - d : fixed for the whole tick (see Solver::rho_solve)
+    QPC_PHASE(lane) {
+      for (int f = lane; f < nf; f += 64) sm[D.lds[L_XV] + f] = -sm[D.lds[L_SQH] + f] * sm[D.lds[L_GV] + f];
+    } QPC_END_PHASE
+    QPC_PHASE(lane) {
+      for (int r = lane; r < m; r += 64)
+        sm[D.lds[L_T1] + r] = dotp(sm + D.lds[L_M] + r * D.nfs, 1, sm + D.lds[L_XV], 1, nf) - sm[D.lds[L_D] + r];
+    } QPC_END_PHASE
+    QPC_PHASE(lane) {
+      if (lane < 6) sm[MISC + MS_U0 + lane] = sm[D.lds[L_T1] + m1 + lane] - dotp(sm + D.lds[L_X2] + lane, 6, sm + D.lds[L_T1], 1, m1);
+    } QPC_END_PHASE
+    bool any_upper = false;
+    S.refactor_rho();
+    S.rho_solve(true, 0, 0.0, any_upper);
     // ---- phase A: primal-dual active-set sweeps (multi-change)
     for (int pd = 0; pd < D.max_pdas; pd++) {
       double gmax, xmax;
       S.multipliers(gmax, xmax);
       const double gscale = 1.0 + gmax, tolb = D.tol_bound * (1.0 + xmax);
-      double rchg = 0.0;
+      double rchg = 0.0, rup = 0.0;
       QPC_PHASE(lane) {
-        double changed = 0.0;
+        double changed = 0.0, up = 0.0;
         for (int j = lane; j < nrho; j += 64) {
           double w = sm[D.lds[L_WS] + j], hi = sm[D.lds[L_HI] + j], x = sm[D.lds[L_XR] + j], nw_ = w;
           if (!(hi > 0.0)) continue; // disabled
@@ -1077,14 +1149,18 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
           else if (x < -tolb) nw_ = -1.0;
           else if (x > hi + tolb) nw_ = 1.0;
           if (nw_ != w) { sm[D.lds[L_WS] + j] = nw_; changed = 1.0; }
+          if (nw_ == 1.0) up = 1.0;
         }
         QPC_RED_MAX_PUT(0, rchg, changed);
+        QPC_RED_MAX_PUT(1, rup, up);
       } QPC_END_PHASE
       rchg = QPC_RED_MAX_GET(0, rchg);
+      rup = QPC_RED_MAX_GET(1, rup);
       if (!(rchg > 0.0)) break;
+      any_upper = rup > 0.0;
       iters++;
       S.refactor_rho();
-      S.eqp_fresh();
+      S.rho_solve(true, 0, 0.0, any_upper);
     }
     // ---- phase B: drops until dual feasible, then Goldfarb-Idnani additions (finite)
     while (true) {
@@ -1120,7 +1196,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
         QPC_PHASE(lane) { if (lane == 0) sm[D.lds[L_WS] + jbad] = 0.0; } QPC_END_PHASE
         iters++;
         S.refactor_rho();
-        S.eqp_fresh();
+        S.rho_solve(true, 0, 0.0, true);
         continue;
       }
       if (pviol < 0) break; // optimal for this working set
@@ -1131,13 +1207,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       while (true) {
         iters++;
         if (iters > D.max_as_iters) { fail = true; break; }
-        QPC_PHASE(lane) { // rhs = n_p on the rho block, zero elsewhere
-          for (int f = lane; f < nf; f += 64) sm[D.lds[L_RV] + f] = 0.0;
-          for (int s = lane; s < ne; s += 64) sm[D.lds[L_RE] + s] = 0.0;
-          for (int r = lane; r < m; r += 64) sm[D.lds[L_RC] + r] = 0.0;
-          for (int j = lane; j < nrho; j += 64) sm[D.lds[L_RR] + j] = (j == p) ? nsign : 0.0;
-        } QPC_END_PHASE
-        S.kkt_solve();
+        S.rho_solve(false, p, nsign, true);
         double t1 = 1e300;
         int jdrop = -1;
         QPC_PHASE(lane) { // dual direction r_j = -s_j (H_eff z)_j on the working set; step ratios
@@ -1167,10 +1237,8 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
         const double tt = t1 < t2 ? t1 : t2;
         if (!(tt < 1e299)) { status = QPC_STATUS_INFEASIBLE; fail = true; break; }
         const bool full = t2 <= t1;
-        QPC_PHASE(lane) {
-          for (int f = lane; f < nf; f += 64) sm[D.lds[L_XV] + f] = sm[D.lds[L_XV] + f] + tt * sm[D.lds[L_DV] + f];
-          for (int s = lane; s < ne; s += 64) sm[D.lds[L_XE] + s] = sm[D.lds[L_XE] + s] + tt * sm[D.lds[L_DE] + s];
-          for (int r = lane; r < m; r += 64) sm[D.lds[L_LAM] + r] = sm[D.lds[L_LAM] + r] + tt * sm[D.lds[L_DL] + r];
+        QPC_PHASE(lane) { // the step moves rho and the wrench multipliers only (see rho_solve)
+          if (lane < 6) sm[D.lds[L_LAM] + m1 + lane] = sm[D.lds[L_LAM] + m1 + lane] + tt * sm[D.lds[L_DL] + m1 + lane];
           for (int j = lane; j < nrho; j += 64) {
             sm[D.lds[L_XR] + j] = sm[D.lds[L_XR] + j] + tt * sm[D.lds[L_DR] + j];
             double u = sm[D.lds[L_U] + j] - tt * sm[D.lds[L_TR2] + j];
@@ -1180,10 +1248,12 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
           }
         } QPC_END_PHASE
         S.refactor_rho();
-        if (full) { S.eqp_fresh(); break; }
+        if (full) { S.rho_solve(true, 0, 0.0, true); break; }
       }
       if (fail) { if (status == QPC_STATUS_OPTIMAL) status = QPC_STATUS_ITERATION_LIMIT; break; }
     }
+  } else {
+    S.refactor_rho();
   }
   QPC_PROF_ACC(PS_LOGIC);
   // ---- final refinement on the converged working set + acceptance test (a14)
