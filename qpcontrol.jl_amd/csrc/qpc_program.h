@@ -84,10 +84,8 @@ enum {
   MS_ADV = 3,      // 6
   MS_WG = 9,       // 6
   MS_EPS = 15, MS_HSCALE = 16,
-  MS_S22D = 17,    // 6: diagonal of S22 before inversion
-  MS_S22OK = 23,   // 6: pivot accepted flags
-  MS_U0 = 29,      // 6: wrench-space constant u0 = c2 - Z'c1 of the active-set search
-  MS_COUNT = 36
+  MS_U0 = 17,      // 6: wrench-space constant u0 = c2 - Z'c1 of the active-set search
+  MS_COUNT = 24
 };
 
 struct QpcDims {

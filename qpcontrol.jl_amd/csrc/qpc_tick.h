@@ -252,6 +252,47 @@ template <class P> QPC_FN void inv6_spd(P Sin, const double *sref, double tau, P
     }
 }
 
+// Column `col` of T = S^-1 for a symmetric 6x6 S: Cholesky in registers (every calling lane redoes
+// it -- 6 lanes, one column each, one phase) then forward/back substitution for e_col.  A pivot
+// below tau * sref[k] marks a redundant row: zero row/column in T (infinite-pivot rule).
+template <class P> QPC_FN void inv6_column(P Sin, const double *sref, double tau, int col, double *x) {
+  double L[6][6], invd[6], y[6];
+  QPC_UNROLL_FULL
+  for (int i = 0; i < 6; i++)
+    QPC_UNROLL_FULL
+    for (int j = 0; j < 6; j++) L[i][j] = (j <= i) ? (double)Sin[i * 6 + j] : 0.0;
+  QPC_UNROLL_FULL
+  for (int k = 0; k < 6; k++) {
+    double d = L[k][k];
+    QPC_UNROLL_FULL
+    for (int j = 0; j < k; j++) d -= L[k][j] * L[k][j];
+    bool ok = d > tau * (sref[k] > 1e-300 ? sref[k] : 1e-300);
+    double ld_ = ok ? QPC_SQRT(d) : 0.0;
+    invd[k] = ok ? 1.0 / ld_ : 0.0;
+    QPC_UNROLL_FULL
+    for (int i = k + 1; i < 6; i++) {
+      double t = L[i][k];
+      QPC_UNROLL_FULL
+      for (int j = 0; j < k; j++) t -= L[i][j] * L[k][j];
+      L[i][k] = t * invd[k];
+    }
+  }
+  QPC_UNROLL_FULL
+  for (int r = 0; r < 6; r++) {
+    double t = (r == col) ? 1.0 : 0.0;
+    QPC_UNROLL_FULL
+    for (int j = 0; j < r; j++) t -= L[r][j] * y[j];
+    y[r] = t * invd[r];
+  }
+  QPC_UNROLL_FULL
+  for (int r = 5; r >= 0; r--) {
+    double t = y[r];
+    QPC_UNROLL_FULL
+    for (int j = r + 1; j < 6; j++) t -= L[j][r] * x[j];
+    x[r] = t * invd[r];
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // per-QP global-memory records
 // ------------------------------------------------------------------------------------------
@@ -272,6 +313,7 @@ template <class P> struct Solver {
   P sm;
   bool use_rho;
   unsigned long long *PA, *PT; // section timers (diagnostic build)
+  double last_gmax = 0.0, last_xmax = 0.0; // scales of the last base rho_solve (uniform)
   // hot lookups staged in LDS (IT_HOT)
   QPC_FN int row_slack(int r) const { return (int)(double)sm[D.lds[L_HOT] + r]; }
   QPC_FN int slack_row(int s) const { return (int)(double)sm[D.lds[L_HOT] + D.m + s]; }
@@ -324,39 +366,15 @@ template <class P> struct Solver {
         double acc = sm[D.lds[L_B22] + lane];
         if (use_rho) acc += dotp(sm + D.lds[L_G] + a * nrho, 1, sm + D.lds[L_Y] + b, 6, nrho);
         sm[D.lds[L_C22] + lane] = acc; // S22 = B22 + G Kr G'
-        if (a == b) sm[D.lds[L_MISC] + MS_S22D + a] = acc;
       }
     } QPC_END_PHASE
-    // T22 = S22^-1 by in-place Gauss-Jordan, one entry per lane, one phase per pivot (ping-pong
-    // between L_C22 and L_L22); a pivot below tau * reference marks a redundant wrench row: its
-    // elimination step is skipped and its row/column of T22 are zeroed (infinite-pivot rule).
-    for (int k = 0; k < 6; k++) {
-      const int src = (k & 1) ? D.lds[L_L22] : D.lds[L_C22], dst = (k & 1) ? D.lds[L_C22] : D.lds[L_L22];
-      QPC_PHASE(lane) {
-        if (lane < 36) {
-          const int i = lane / 6, j = lane % 6;
-          const double p = sm[src + k * 6 + k], aij = sm[src + lane], aik = sm[src + i * 6 + k], akj = sm[src + k * 6 + j];
-          const double ref = sm[D.lds[L_SM] + (m1 + k) * D.ms + (m1 + k)] + (sm[D.lds[L_MISC] + MS_S22D + k] - sm[D.lds[L_B22] + k * 6 + k]);
-          const bool ok = p > D.tau_pivot * (ref > 1e-300 ? ref : 1e-300);
-          double r;
-          if (!ok) r = aij;
-          else {
-            const double ip = 1.0 / p;
-            if (i == k && j == k) r = ip;
-            else if (i == k) r = akj * ip;
-            else if (j == k) r = -aik * ip;
-            else r = aij - aik * akj * ip;
-          }
-          sm[dst + lane] = r;
-          if (j == 0 && i == k) sm[D.lds[L_MISC] + MS_S22OK + k] = ok ? 1.0 : 0.0;
-        }
-      } QPC_END_PHASE
-    }
-    QPC_PHASE(lane) { // after 6 ping-pong steps the result sits in L_C22
-      if (lane < 36) {
-        const int i = lane / 6, j = lane % 6;
-        const bool ok = sm[D.lds[L_MISC] + MS_S22OK + i] != 0.0 && sm[D.lds[L_MISC] + MS_S22OK + j] != 0.0;
-        sm[D.lds[L_S22I] + lane] = ok ? (double)sm[D.lds[L_C22] + lane] : 0.0;
+    QPC_PHASE(lane) { // T22 = S22^-1 : lane c < 6 computes column c (Cholesky redone per lane, in registers)
+      if (lane < 6) {
+        double sref[6], x[6];
+        for (int k = 0; k < 6; k++)
+          sref[k] = sm[D.lds[L_SM] + (m1 + k) * D.ms + (m1 + k)] + (sm[D.lds[L_C22] + k * 6 + k] - sm[D.lds[L_B22] + k * 6 + k]);
+        inv6_column(sm + D.lds[L_C22], sref, D.tau_pivot, lane, x);
+        for (int r = 0; r < 6; r++) sm[D.lds[L_S22I] + r * 6 + lane] = x[r];
       }
     } QPC_END_PHASE
     QPC_PROF_ACC(PS_REFAC);
@@ -554,29 +572,49 @@ template <class P> struct Solver {
         }
       } QPC_END_PHASE
     }
-    QPC_PHASE(lane) { // u = u0 - G (K r_r + rho_fix)   (temporary in L_C22[0..5])
-      if (lane < 6) {
-        double u = base ? (double)sm[D.lds[L_MISC] + MS_U0 + lane] : 0.0;
-        if (need_kr) u -= dotp(sm + D.lds[L_G] + lane * nrho, 1, sm + D.lds[L_TR1], 1, nrho);
-        sm[D.lds[L_C22] + lane] = u;
-      }
-    } QPC_END_PHASE
+    if (need_kr) {
+      QPC_PHASE(lane) { // u = u0 - G (K r_r + rho_fix)   (temporary in L_C22[0..5])
+        if (lane < 6) {
+          double u = base ? (double)sm[D.lds[L_MISC] + MS_U0 + lane] : 0.0;
+          u -= dotp(sm + D.lds[L_G] + lane * nrho, 1, sm + D.lds[L_TR1], 1, nrho);
+          sm[D.lds[L_C22] + lane] = u;
+        }
+      } QPC_END_PHASE
+    }
     QPC_PHASE(lane) {
-      if (lane < 6) sm[outl + lane] = dotp(sm + D.lds[L_S22I] + lane * 6, 1, sm + D.lds[L_C22], 1, 6);
+      if (lane < 6) sm[outl + lane] = dotp(sm + D.lds[L_S22I] + lane * 6, 1, sm + (need_kr ? D.lds[L_C22] : D.lds[L_MISC] + MS_U0), 1, 6);
     } QPC_END_PHASE
-    QPC_PHASE(lane) { // rho_F = K (r_r + G' lam_w) (+ rho_fix); each lane rebuilds its contact's N w's
+    double rg = 0.0, rx = 0.0;
+    QPC_PHASE(lane) { // rho_F = K (r_r + G' lam_w) (+ rho_fix); each lane rebuilds its contact's N rho's,
+                      // and in base mode also its multiplier u_j = +-(H_rho rho - G' lam_w)_j
+      double g = 0.0, xm = 0.0;
       for (int j = lane; j < nrho; j += 64) {
         int c = j / N, jj = j % N;
-        double acc = 0.0;
+        double w[8], rho_c[8];
         for (int i = 0; i < N; i++) {
-          double w = dotp(sm + D.lds[L_G] + c * N + i, nrho, sm + outl, 1, 6);
-          if (need_kr) w += sm[D.lds[L_RR] + c * N + i];
-          acc += sm[D.lds[L_KR] + c * N * N + jj * N + i] * w;
+          w[i] = dotp(sm + D.lds[L_G] + c * N + i, nrho, sm + outl, 1, 6);
+          if (i == jj) g = w[i]; // (G' lam_w)_j, reused below
+          if (need_kr) w[i] += sm[D.lds[L_RR] + c * N + i];
         }
-        if (base && sm[D.lds[L_WS] + j] == 1.0) acc += sm[D.lds[L_HI] + j];
-        sm[outr + j] = acc;
+        for (int i2 = 0; i2 < N; i2++) {
+          double acc = 0.0;
+          for (int i = 0; i < N; i++) acc += sm[D.lds[L_KR] + c * N * N + i2 * N + i] * w[i];
+          if (base && sm[D.lds[L_WS] + c * N + i2] == 1.0) acc += sm[D.lds[L_HI] + c * N + i2];
+          rho_c[i2] = acc;
+        }
+        sm[outr + j] = rho_c[jj];
+        if (base) {
+          double gl = -g;
+          for (int i = 0; i < N; i++) gl += sm[D.lds[L_HR] + c * N * N + jj * N + i] * rho_c[i];
+          double wsj = sm[D.lds[L_WS] + j];
+          sm[D.lds[L_U] + j] = (wsj == -1.0) ? gl : ((wsj == 1.0) ? -gl : 0.0);
+          g = QPC_FABS(gl);
+          xm = QPC_FABS(rho_c[jj]);
+        }
       }
+      if (base) { QPC_RED_MAX_PUT(0, rg, g); QPC_RED_MAX_PUT(1, rx, xm); }
     } QPC_END_PHASE
+    if (base) { last_gmax = QPC_RED_MAX_GET(0, rg); last_xmax = QPC_RED_MAX_GET(1, rx); }
     QPC_PROF_ACC(PS_KKT);
   }
 
@@ -1136,9 +1174,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
     S.rho_solve(true, 0, 0.0, any_upper);
     // ---- phase A: primal-dual active-set sweeps (multi-change)
     for (int pd = 0; pd < D.max_pdas; pd++) {
-      double gmax, xmax;
-      S.multipliers(gmax, xmax);
-      const double gscale = 1.0 + gmax, tolb = D.tol_bound * (1.0 + xmax);
+      const double gscale = 1.0 + S.last_gmax, tolb = D.tol_bound * (1.0 + S.last_xmax); // U is current (rho_solve)
       double rchg = 0.0, rup = 0.0;
       QPC_PHASE(lane) {
         double changed = 0.0, up = 0.0;
@@ -1165,9 +1201,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
     // ---- phase B: drops until dual feasible, then Goldfarb-Idnani additions (finite)
     while (true) {
       if (iters > D.max_as_iters) { status = QPC_STATUS_ITERATION_LIMIT; break; }
-      double gmax, xmax;
-      S.multipliers(gmax, xmax);
-      const double gscale = 1.0 + gmax, tolb = D.tol_bound * (1.0 + xmax);
+      const double gscale = 1.0 + S.last_gmax, tolb = D.tol_bound * (1.0 + S.last_xmax); // U is current (rho_solve)
       // most negative multiplier / most violated bound (lane-parallel + wave argmin)
       double ubad = 0.0, vneg = 0.0, rnan = 0.0;
       int jbad = -1, pviol = -1;
