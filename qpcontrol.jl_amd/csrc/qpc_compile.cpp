@@ -201,6 +201,59 @@ int qpc_compile_program(qpc_controller *c) {
   for (size_t g = 0; g < generic.size(); g++) if (slack0[g] >= 0) for (int a = 0; a < c->tasks[generic[g]].dim; a++) B.it.push_back((int)g);
   B.ibegin(IT_SLACK_COMP);
   for (size_t g = 0; g < generic.size(); g++) if (slack0[g] >= 0) for (int a = 0; a < c->tasks[generic[g]].dim; a++) B.it.push_back(a);
+  {
+    const int maxd = D.maxdepth > 0 ? D.maxdepth : 1;
+    D.maxd = maxd;
+    std::vector<int> tab((size_t)nb * maxd, -1), mask(2 * (size_t)nb, 0), pdes(nv, -1);
+    for (int i = 0; i < nb; i++) {
+      int sidx = 0;
+      for (int a = m->parent[i]; a >= 0; a = m->parent[a]) tab[(size_t)i * maxd + sidx++] = a;
+      for (int a = i; a >= 0; a = m->parent[a]) {
+        if (i < 32) mask[2 * a] |= (int)(1u << i); else mask[2 * a + 1] |= (int)(1u << (i - 32));
+      }
+    }
+    for (size_t p = 0; p < pin_k.size(); p++) pdes[pin_k[p]] = pin_d[p];
+    B.ibegin(IT_ANC_TAB); B.it.insert(B.it.end(), tab.begin(), tab.end());
+    B.ibegin(IT_DESC_MASK); B.it.insert(B.it.end(), mask.begin(), mask.end());
+    B.ibegin(IT_PDES_K); B.it.insert(B.it.end(), pdes.begin(), pdes.end());
+    // packed assembly codes: kind(3) | sg+1(2) | a(3) | k(7) | frame+1(7) | t(6)   (kind 7 = wrench row)
+    std::vector<int> mcode((size_t)D.m * D.nf, 0), rcode(D.m, 0), rdes(D.m, -1), rt(D.m, -1), rpink(D.m, -1);
+    for (int r = 0; r < D.m; r++) {
+      int g = -1, a = r - m1;
+      if (r < m1) { for (size_t gg = 0; gg < generic.size(); gg++) if (r >= row0[gg] && r < row0[gg] + c->tasks[generic[gg]].dim) g = (int)gg; a = r - row0[g]; }
+      const QpcTask *t = g >= 0 ? &c->tasks[generic[g]] : nullptr;
+      int kind = t ? t->kind : 7, frame = t ? t->frame : -1, base = t ? t->base : -1, target = t ? t->target : -1;
+      rcode[r] = kind | (a << 3) | ((frame + 1) << 6) | ((base + 1) << 13) | ((target + 1) << 20);
+      rdes[r] = t ? t->des_off + a : -1;
+      rt[r] = g;
+      for (int f = 0; f < D.nf; f++) {
+        int k = free_k[f], sg = 0;
+        if (!t) sg = 1;
+        else if (t->kind == QPC_TASK_JOINT_ACCELERATION) sg = (k >= m->voff[t->joint] && k < m->voff[t->joint] + t->dim && k - m->voff[t->joint] == a) ? 1 : 0;
+        else if (t->kind == QPC_TASK_MOMENTUM_RATE || t->kind == QPC_TASK_LINEAR_MOMENTUM_RATE) sg = 1;
+        else {
+          std::vector<char> mark(nb, 0);
+          for (int b = t->target; b >= 0; b = m->parent[b]) mark[b] = 1;
+          int lca = -1;
+          for (int b = t->base; b >= 0; b = m->parent[b]) if (mark[b]) { lca = b; break; }
+          int kb = -1;
+          for (int b = 0; b < nb; b++) if (k >= m->voff[b] && k < m->voff[b] + m->nvj[b]) kb = b;
+          for (int b = t->base; b >= 0 && b != lca; b = m->parent[b]) if (b == kb) sg = -1;
+          for (int b = t->target; b >= 0 && b != lca; b = m->parent[b]) if (b == kb) sg = 1;
+        }
+        mcode[(size_t)r * D.nf + f] = kind | ((sg + 1) << 3) | (a << 5) | (k << 8) | ((frame + 1) << 15) | ((g >= 0 ? g : 0) << 22);
+      }
+      if (t && t->kind == QPC_TASK_JOINT_ACCELERATION) {
+        int k = m->voff[t->joint] + a;
+        if (free_of[k] < 0) rpink[r] = k;
+      }
+    }
+    B.ibegin(IT_MCODE); B.it.insert(B.it.end(), mcode.begin(), mcode.end());
+    B.ibegin(IT_RCODE); B.it.insert(B.it.end(), rcode.begin(), rcode.end());
+    B.ibegin(IT_R_DES); B.it.insert(B.it.end(), rdes.begin(), rdes.end());
+    B.ibegin(IT_R_T); B.it.insert(B.it.end(), rt.begin(), rt.end());
+    B.ibegin(IT_R_PINK); B.it.insert(B.it.end(), rpink.begin(), rpink.end());
+  }
   B.ibegin(IT_HOT);
   {
     std::vector<int> row_slack(D.m, -1), srow, swoff, sdim, ss0;
@@ -320,6 +373,10 @@ int qpc_compile_program(qpc_controller *c) {
   Lo.ref_n_var = nvar; Lo.ref_n_eq = neq; Lo.ref_n_ineq = D.nc * 2 * N;
   Lo.n_free = D.nf; Lo.n_pinned = D.npin; Lo.n_slack = ne; Lo.n_rho = nrho; Lo.n_eq_rows = mm;
   Lo.lds_bytes_per_qp = D.lds_doubles * 8;
+  if (nb > 64 || nv > 64 || D.ntask > 63 || D.maxdepth > 32) {
+    qpc_set_error("limits of the one-wave-per-QP kernels exceeded (bodies <= 64, velocities <= 64, tree depth <= 32)");
+    return QPC_ERR_UNSUPPORTED;
+  }
   if (D.m > 64) {
     qpc_set_error("more than 64 equality rows in the reduced QP are not supported by the lane=row factorization");
     return QPC_ERR_UNSUPPORTED;

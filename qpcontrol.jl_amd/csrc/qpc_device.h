@@ -12,6 +12,9 @@
 // lane-private storage that persists across phases (registers on the device)
 #define QPC_LANE_ARRAY(name, n) double name[n]
 #define QPC_LA(name, lane) name
+#define QPC_LANE_INTS(name, n) int name[n]
+#define QPC_LI(name, lane) name
+#define QPC_CTZ64(x) (__ffsll((unsigned long long)(x)) - 1)
 #ifdef QPC_JIT
 #define QPC_UNROLL_JIT _Pragma("unroll")
 #define QPC_UNROLL _Pragma("unroll")

@@ -29,7 +29,7 @@ static std::string dbl(double x) {
 std::string qpc_jit_source(const QpcDims &D) {
   std::ostringstream o;
   o << "typedef int int32_t;\ntypedef unsigned int uint32_t;\ntypedef long long int64_t;\n";
-  o << "#define QPC_JIT 1\n#define QPC_M1_MAX " << (D.m1 > 0 ? D.m1 : 1) << "\n#include \"qpc_device.h\"\n";
+  o << "#define QPC_JIT 1\n#define QPC_M1_MAX " << (D.m1 > 0 ? D.m1 : 1) << "\n#define QPC_MAXD " << D.maxd << "\n#include \"qpc_device.h\"\n";
   const char *st = getenv("QPC_JIT_STAMPS"); // diagnostic: in-kernel section timers
   const bool stamps = st && st[0] == '1';
   if (stamps)
@@ -42,7 +42,7 @@ std::string qpc_jit_source(const QpcDims &D) {
   o << "static constexpr QpcDims kD = {" << D.nb << "," << D.nq << "," << D.nv << "," << D.nf << "," << D.npin << ","
     << D.nsj << "," << D.ntask << "," << D.nc << "," << D.N << "," << D.nrho << "," << D.ne << "," << D.m << ","
     << D.m1 << "," << D.nw << "," << D.floating << "," << D.fv0 << "," << D.n_desired << "," << D.n_tw << ","
-    << D.n_surf << "," << D.maxdepth << "," << D.nfs << "," << D.ms << "," << D.m1s << "," << D.wsize << ",";
+    << D.n_surf << "," << D.maxdepth << "," << D.maxd << "," << D.nfs << "," << D.ms << "," << D.m1s << "," << D.wsize << ",";
   put_ints(o, D.it, IT_COUNT); o << ",";
   put_ints(o, D.dt, DT_COUNT); o << ",";
   put_ints(o, D.lds, L_COUNT); o << ",";

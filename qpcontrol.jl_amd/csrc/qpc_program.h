@@ -26,6 +26,12 @@ enum {
   IT_C_BODY, IT_C_PERQP, IT_C_SURF, // contacts
   IT_BC_PTR, IT_BC_IDX,     // contacts attached to body i (CSR)
   IT_SLACK_TASK, IT_SLACK_COMP, // slack index -> generic task, component
+  IT_ANC_TAB,   // [nb * maxd] s-th ancestor of body i (nearest first), -1 padded; maxd = max(maxdepth,1)
+  IT_DESC_MASK, // [nb * 2] 64-bit subtree membership mask of body i (lo, hi), bit k = body k in subtree(i)
+  IT_PDES_K,    // [nv] desired-record index that pins velocity index k, or -1 (free)
+  IT_MCODE,     // [m * nf] packed assembly code of constraint-matrix entry (row r, free column f)
+  IT_RCODE,     // [m] packed row code ; IT_R_DES [m] desired index ; IT_R_T [m] generic task ; IT_R_PINK [m]
+  IT_R_DES, IT_R_T, IT_R_PINK,
   IT_HOT, // solver lookups staged into LDS per QP: row_slack[m], slack_row[ne], slack_woff[ne], slack_dim[ne], slack_s0[ne]
   IT_COUNT
 };
@@ -92,6 +98,7 @@ struct QpcDims {
   int nb, nq, nv, nf, npin, nsj, ntask, nc, N, nrho, ne, m, m1, nw;
   int floating, fv0; // floating body and its first velocity index (or -1)
   int n_desired, n_tw, n_surf, maxdepth;
+  int maxd; // row length of IT_ANC_TAB
   int nfs, ms, m1s;  // padded leading dimensions (odd) of L_M, L_SM, L_X
   int wsize;         // doubles in L_W / L_WINV
   int it[IT_COUNT];

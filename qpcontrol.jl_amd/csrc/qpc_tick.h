@@ -121,6 +121,10 @@ template <class P> QPC_FN void ld6(P sm, int off, int body, double *x) {
 #ifndef QPC_M1_MAX
 #define QPC_M1_MAX 64
 #endif
+// compile-time bound of the tree depth (the JIT defines it as the actual depth)
+#ifndef QPC_MAXD
+#define QPC_MAXD 32
+#endif
 // full unroll only when trip counts are compile-time constants (JIT specialisation)
 #ifndef QPC_UNROLL_JIT
 #define QPC_UNROLL_JIT
@@ -695,9 +699,33 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
   QPC_PROF_T0();
 
   // ======================================================================== inputs -> LDS
+  // Static per-lane metadata (lane = body i and lane = velocity index k) is read ONCE per QP here
+  // and kept in registers: no table lookup sits on a dependent path of the tree sweeps below.
+  //   [0] jtype(i) [1] q0(i) [2] v0(i) [3] nvj(i) [4,5] subtree mask of body i
+  //   [6] vbody(k) [7] vcomp(k) [8] pin-desired index of k or -1 [9,10] subtree mask of vbody(k)
+  //   [11 + s] s-th ancestor of body i (nearest first) or -1
+  QPC_LANE_INTS(meta_, 11 + QPC_MAXD);
   QPC_PHASE(lane) {
+    int *mt = QPC_LI(meta_, lane);
+    for (int e = 0; e < 11 + QPC_MAXD; e++) mt[e] = -1;
+    if (lane < nb) {
+      mt[0] = IT[D.it[IT_JTYPE] + lane]; mt[1] = IT[D.it[IT_QOFF] + lane]; mt[2] = IT[D.it[IT_VOFF] + lane];
+      mt[3] = IT[D.it[IT_NVJ] + lane];
+      mt[4] = IT[D.it[IT_DESC_MASK] + 2 * lane]; mt[5] = IT[D.it[IT_DESC_MASK] + 2 * lane + 1];
+      QPC_UNROLL_JIT
+      for (int s = 0; s < QPC_MAXD; s++) mt[11 + s] = s < D.maxd ? IT[D.it[IT_ANC_TAB] + lane * D.maxd + s] : -1;
+    }
+    if (lane < nv) {
+      const int vb = IT[D.it[IT_VBODY] + lane];
+      mt[6] = vb; mt[7] = IT[D.it[IT_VCOMP] + lane]; mt[8] = IT[D.it[IT_PDES_K] + lane];
+      mt[9] = IT[D.it[IT_DESC_MASK] + 2 * vb]; mt[10] = IT[D.it[IT_DESC_MASK] + 2 * vb + 1];
+    }
     for (int i = lane; i < nq; i += 64) sm[D.lds[L_Q] + i] = io.q[i];
-    for (int i = lane; i < nv; i += 64) { sm[D.lds[L_V] + i] = io.v[i]; sm[D.lds[L_VD] + i] = 0.0; }
+    for (int i = lane; i < nv; i += 64) {
+      sm[D.lds[L_V] + i] = io.v[i];
+      const int pd = IT[D.it[IT_PDES_K] + i]; // pinned accelerations (hard JointAccelerationTask)
+      sm[D.lds[L_VD] + i] = pd >= 0 ? io.desired[pd] : 0.0;
+    }
     for (int i = lane; i < D.n_desired; i += 64) sm[D.lds[L_DES] + i] = io.desired[i];
     for (int i = lane; i < nc; i += 64) { sm[D.lds[L_CW] + i] = io.cw[i]; sm[D.lds[L_CMAX] + i] = io.cmax[i]; }
     for (int i = lane; i < D.n_tw; i += 64) sm[D.lds[L_TW] + i] = io.tw[i];
@@ -707,8 +735,10 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
 
   // ======================================================================== kinematics (a2)
   QPC_PHASE(lane) { // joint transforms: x_parent = Rf (Rj x + pj) + pf
-    for (int i = lane; i < nb; i += 64) {
-      int jt = IT[D.it[IT_JTYPE] + i], q0 = IT[D.it[IT_QOFF] + i];
+    if (lane < nb) {
+      const int i = lane;
+      const int *mt = QPC_LI(meta_, lane);
+      const int jt = mt[0], q0 = mt[1];
       const double *ax = DT + D.dt[DT_AXIS] + 3 * i, *Rf = DT + D.dt[DT_RF] + 9 * i, *pf = DT + D.dt[DT_PF] + 3 * i;
       double Rj[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pj[3] = {0, 0, 0};
       if (jt == QPC_JOINT_REVOLUTE) {
@@ -735,38 +765,48 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       st(sm + D.lds[L_RL] + 12 * i, 12, H);
     }
   } QPC_END_PHASE
-  QPC_PHASE(lane) { // transform_to_root by walking the ancestor chain
-    for (int i = lane; i < nb; i += 64) {
+  QPC_PHASE(lane) { // transform_to_root by walking the (register-resident) ancestor chain
+    if (lane < nb) {
+      const int *mt = QPC_LI(meta_, lane);
       double H[12], A[12], t[3];
-      ld(sm + D.lds[L_RL] + 12 * i, 12, H);
-      for (int e = anc_ptr[i]; e < anc_ptr[i + 1]; e++) {
-        ld(sm + D.lds[L_RL] + 12 * anc_idx[e], 12, A);
-        mv3(A, H + 9, t);
-        mm3(A, H, H);
-        H[9] = t[0] + A[9]; H[10] = t[1] + A[10]; H[11] = t[2] + A[11];
+      ld(sm + D.lds[L_RL] + 12 * lane, 12, H);
+      QPC_UNROLL_JIT
+      for (int s = 0; s < QPC_MAXD; s++) {
+        const int an = mt[11 + s];
+        if (an >= 0) {
+          ld(sm + D.lds[L_RL] + 12 * an, 12, A);
+          mv3(A, H + 9, t);
+          mm3(A, H, H);
+          H[9] = t[0] + A[9]; H[10] = t[1] + A[10]; H[11] = t[2] + A[11];
+        }
       }
-      st(sm + D.lds[L_H] + 12 * i, 12, H);
+      st(sm + D.lds[L_H] + 12 * lane, 12, H);
     }
   } QPC_END_PHASE
-  QPC_PHASE(lane) { // motion subspaces in world; body inertias in world about the world origin
-    for (int k = lane; k < nv; k += 64) {
-      int b = IT[D.it[IT_VBODY] + k], c = IT[D.it[IT_VCOMP] + k], jt = IT[D.it[IT_JTYPE] + b];
-      double H[12], S[6] = {0, 0, 0, 0, 0, 0};
-      ld(sm + D.lds[L_H] + 12 * b, 12, H);
-      const double *ax = DT + D.dt[DT_AXIS] + 3 * b;
-      if (jt == QPC_JOINT_REVOLUTE) { mv3(H, ax, S); cross3(H + 9, S, S + 3); }
-      else if (jt == QPC_JOINT_PRISMATIC) { mv3(H, ax, S + 3); }
-      else { // quaternion floating: columns of Ad(H)
-        int cc = c % 3;
-        double col[3] = {H[cc], H[3 + cc], H[6 + cc]};
-        if (c < 3) { S[0] = col[0]; S[1] = col[1]; S[2] = col[2]; cross3(H + 9, col, S + 3); }
-        else { S[3] = col[0]; S[4] = col[1]; S[5] = col[2]; }
-      }
-      st(sm + D.lds[L_S] + 6 * k, 6, S);
-    }
-    for (int i = lane; i < nb; i += 64) {
-      double H[12], cw[3];
+  QPC_PHASE(lane) { // per body: motion subspace columns of its joint (world), joint twist, world inertia
+    if (lane < nb) {
+      const int i = lane;
+      const int *mt = QPC_LI(meta_, lane);
+      const int jt = mt[0], v0 = mt[2], n = mt[3];
+      double H[12], tj[6] = {0, 0, 0, 0, 0, 0};
       ld(sm + D.lds[L_H] + 12 * i, 12, H);
+      const double *ax = DT + D.dt[DT_AXIS] + 3 * i;
+      for (int c = 0; c < n; c++) {
+        double S[6] = {0, 0, 0, 0, 0, 0};
+        if (jt == QPC_JOINT_REVOLUTE) { mv3(H, ax, S); cross3(H + 9, S, S + 3); }
+        else if (jt == QPC_JOINT_PRISMATIC) { mv3(H, ax, S + 3); }
+        else { // quaternion floating: columns of Ad(H)
+          int cc = c % 3;
+          double col[3] = {H[cc], H[3 + cc], H[6 + cc]};
+          if (c < 3) { S[0] = col[0]; S[1] = col[1]; S[2] = col[2]; cross3(H + 9, col, S + 3); }
+          else { S[3] = col[0]; S[4] = col[1]; S[5] = col[2]; }
+        }
+        st(sm + D.lds[L_S] + 6 * (v0 + c), 6, S);
+        const double vv = sm[D.lds[L_V] + v0 + c];
+        for (int a = 0; a < 6; a++) tj[a] += S[a] * vv;
+      }
+      st(sm + D.lds[L_TJ] + 6 * i, 6, tj);
+      double cw[3];
       const double *I = DT + D.dt[DT_ICOM] + 6 * i;
       mv3(H, DT + D.dt[DT_COM] + 3 * i, cw);
       cw[0] += H[9]; cw[1] += H[10]; cw[2] += H[11];
@@ -781,39 +821,51 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       st(sm + D.lds[L_IW] + 10 * i, 10, o);
     }
   } QPC_END_PHASE
-  QPC_PHASE(lane) { // joint twists S_j v_j
-    for (int i = lane; i < nb; i += 64) {
-      double tj[6] = {0, 0, 0, 0, 0, 0};
-      int v0 = IT[D.it[IT_VOFF] + i], n = IT[D.it[IT_NVJ] + i];
-      for (int c = 0; c < n; c++) {
-        double vv = sm[D.lds[L_V] + v0 + c];
-        for (int a = 0; a < 6; a++) tj[a] += sm[D.lds[L_S] + 6 * (v0 + c) + a] * vv;
-      }
-      st(sm + D.lds[L_TJ] + 6 * i, 6, tj);
-    }
-  } QPC_END_PHASE
-  QPC_PHASE(lane) { // twist_wrt_world (chain sum) and the bias increment T_i x (S_j v_j)
-    for (int i = lane; i < nb; i += 64) {
+  QPC_PHASE(lane) { // twist_wrt_world (chain sum); bias increment T_i x (S_j v_j) + S_j v̇_j(pinned):
+                    // the accelerations of the PINNED joints ride along with the velocity-product bias,
+                    // so every J̇v / Ȧv below already contains J_pin v̇_pin (no separate pass)
+    if (lane < nb) {
+      const int i = lane;
+      const int *mt = QPC_LI(meta_, lane);
       double T[6], tj[6], cr[6];
       ld(sm + D.lds[L_TJ] + 6 * i, 6, tj);
       for (int a = 0; a < 6; a++) T[a] = tj[a];
-      for (int e = anc_ptr[i]; e < anc_ptr[i + 1]; e++)
-        for (int a = 0; a < 6; a++) T[a] += sm[D.lds[L_TJ] + 6 * anc_idx[e] + a];
+      QPC_UNROLL_JIT
+      for (int s = 0; s < QPC_MAXD; s++) {
+        const int an = mt[11 + s];
+        if (an >= 0)
+          for (int a = 0; a < 6; a++) T[a] += sm[D.lds[L_TJ] + 6 * an + a];
+      }
       crm(T, tj, cr);
+      const int v0 = mt[2], n = mt[3];
+      for (int c = 0; c < n; c++) {
+        const double vdp = sm[D.lds[L_VD] + v0 + c]; // zero for free joints at this point
+        for (int a = 0; a < 6; a++) cr[a] += sm[D.lds[L_S] + 6 * (v0 + c) + a] * vdp;
+      }
       st(sm + D.lds[L_T] + 6 * i, 6, T);
       st(sm + D.lds[L_CR] + 6 * i, 6, cr);
     }
   } QPC_END_PHASE
-  QPC_PHASE(lane) { // bias_acceleration, composite inertias, per-body momentum-rate bias
-    for (int i = lane; i < nb; i += 64) {
+  QPC_PHASE(lane) { // bias_acceleration (+ pinned), composite inertias (subtree mask), momentum-rate bias
+    if (lane < nb) {
+      const int i = lane;
+      const int *mt = QPC_LI(meta_, lane);
       double Ab[6], T[6], I[10], Ic[10], h[6], ia[6], cf[6];
       ld(sm + D.lds[L_CR] + 6 * i, 6, Ab);
-      for (int e = anc_ptr[i]; e < anc_ptr[i + 1]; e++)
-        for (int a = 0; a < 6; a++) Ab[a] += sm[D.lds[L_CR] + 6 * anc_idx[e] + a];
+      QPC_UNROLL_JIT
+      for (int s = 0; s < QPC_MAXD; s++) {
+        const int an = mt[11 + s];
+        if (an >= 0)
+          for (int a = 0; a < 6; a++) Ab[a] += sm[D.lds[L_CR] + 6 * an + a];
+      }
       st(sm + D.lds[L_AB] + 6 * i, 6, Ab);
       for (int a = 0; a < 10; a++) Ic[a] = 0.0;
-      for (int e = desc_ptr[i]; e < desc_ptr[i + 1]; e++)
-        for (int a = 0; a < 10; a++) Ic[a] += sm[D.lds[L_IW] + 10 * desc_idx[e] + a];
+      unsigned long long msk = ((unsigned long long)(unsigned)mt[5] << 32) | (unsigned long long)(unsigned)mt[4];
+      while (msk) {
+        const int k = QPC_CTZ64(msk);
+        msk &= msk - 1;
+        for (int a = 0; a < 10; a++) Ic[a] += sm[D.lds[L_IW] + 10 * k + a];
+      }
       st(sm + D.lds[L_IC] + 10 * i, 10, Ic);
       ld(sm + D.lds[L_IW] + 10 * i, 10, I);
       ld(sm + D.lds[L_T] + 6 * i, 6, T);
@@ -821,14 +873,16 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       inertia_mul(I, Ab, ia);
       crf(T, h, cf);
       for (int a = 0; a < 6; a++) { h[a] = cf[a]; ia[a] += cf[a]; }
-      st(sm + D.lds[L_HB] + 6 * i, 6, ia); // I Ab + T x* I T
+      st(sm + D.lds[L_HB] + 6 * i, 6, ia); // I (Ab + A_pinned) + T x* I T
       st(sm + D.lds[L_F] + 6 * i, 6, h);   // T x* I T alone (velocity-product wrench for RNEA)
     }
   } QPC_END_PHASE
-  QPC_PHASE(lane) { // momentum matrix, CoM, momentum-rate bias, pinned accelerations, Hessian diag
-    for (int k = lane; k < nv; k += 64) {
+  QPC_PHASE(lane) { // momentum matrix, CoM, momentum-rate bias, Hessian diagonal
+    if (lane < nv) {
+      const int k = lane;
+      const int *mt = QPC_LI(meta_, lane);
       double Ic[10], S[6], h[6];
-      ld(sm + D.lds[L_IC] + 10 * IT[D.it[IT_VBODY] + k], 10, Ic);
+      ld(sm + D.lds[L_IC] + 10 * mt[6], 10, Ic);
       ld(sm + D.lds[L_S] + 6 * k, 6, S);
       inertia_mul(Ic, S, h);
       for (int a = 0; a < 6; a++) sm[D.lds[L_AMOM] + a * nv + k] = h[a];
@@ -840,10 +894,8 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
     } else if (lane < 9) {
       double acc = 0.0;
       for (int i = 0; i < nb; i++) acc += sm[D.lds[L_HB] + 6 * i + (lane - 3)];
-      sm[MISC + MS_ADV + (lane - 3)] = acc;
+      sm[MISC + MS_ADV + (lane - 3)] = acc; // Ȧv + A_pin v̇_pin
     }
-    for (int p = lane; p < D.npin; p += 64)
-      sm[D.lds[L_VD] + IT[D.it[IT_PIN_K] + p]] = sm[D.lds[L_DES] + IT[D.it[IT_PIN_DES] + p]];
     for (int f = lane; f < nf; f += 64) { // Hv = 2 reg + folded soft joint tasks (a12)
       double hv = DT[D.dt[DT_REG2] + IT[D.it[IT_FREE_K] + f]], gv = 0.0;
       for (int s = 0; s < D.nsj; s++)
@@ -912,97 +964,80 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       for (int e = 0; e < d * d; e++) sm[D.lds[L_WINV] + w0 + e] = sm[D.lds[L_W] + w0 + e] + ((e / d == e % d) ? eps : 0.0);
       spd_inverse_inplace(sm + D.lds[L_WINV] + w0, d);
     }
-    // contribution of the pinned accelerations: world-frame spatial acceleration (path tasks) or
-    // world momentum rate (momentum tasks, wrench rows): sum_k sgn * S_k * vd_k
-    for (int idx = lane; idx < (ntask + 1) * 6; idx += 64) {
-      int t = idx / 6, a = idx % 6;
-      int kind = t < ntask ? IT[D.it[IT_T_KIND] + t] : QPC_TASK_MOMENTUM_RATE;
-      double acc = 0.0;
-      for (int p = 0; p < D.npin; p++) {
-        int k = IT[D.it[IT_PIN_K] + p];
-        double vd = sm[D.lds[L_VD] + k];
-        if (kind == QPC_TASK_MOMENTUM_RATE || kind == QPC_TASK_LINEAR_MOMENTUM_RATE) acc += sm[D.lds[L_AMOM] + a * nv + k] * vd;
-        else if (kind != QPC_TASK_JOINT_ACCELERATION) acc += IT[D.it[IT_T_SGN] + t * nv + k] * sm[D.lds[L_S] + 6 * k + a] * vd;
-      }
-      sm[D.lds[L_ACCP] + idx] = acc;
-    }
   } QPC_END_PHASE
 
   QPC_PHASE(lane) { // scaled constraint matrix M = E diag(sqh), right-hand side d
     for (int idx = lane; idx < m * nf; idx += 64) {
-      int r = idx / nf, f = idx % nf, k = IT[D.it[IT_FREE_K] + f];
-      int t = IT[D.it[IT_ROW_TASK] + r], a = IT[D.it[IT_ROW_COMP] + r];
+      // one packed code per entry: kind(3) | sg+1(2) | a(3) | k(7) | frame+1(7) | task(6); kind 7 = wrench row
+      const int code = IT[D.it[IT_MCODE] + idx];
+      const int kind = code & 7, sg = ((code >> 3) & 3) - 1, a = (code >> 5) & 7, k = (code >> 8) & 127;
+      const int frame = ((code >> 15) & 127) - 1, t = (code >> 22) & 63;
+      const int r = idx / nf, f = idx % nf;
       double val = 0.0;
-      if (t < 0) val = sm[D.lds[L_AMOM] + a * nv + k]; // wrench balance rows (a11), S dropped (invertible)
-      else {
-        int kind = IT[D.it[IT_T_KIND] + t], sg = IT[D.it[IT_T_SGN] + t * nv + k];
-        if (sg != 0) {
-          if (kind == QPC_TASK_JOINT_ACCELERATION) val = (IT[D.it[IT_VCOMP] + k] == a) ? 1.0 : 0.0;
-          else if (kind == QPC_TASK_MOMENTUM_RATE || kind == QPC_TASK_LINEAR_MOMENTUM_RATE) {
-            int aa = kind == QPC_TASK_LINEAR_MOMENTUM_RATE ? a + 3 : a;
-            val = sm[D.lds[L_AMOM] + aa * nv + k];
-            if (aa < 3) { // centroidal: ang - com x lin (src/tasks.jl:208-213)
-              double com[3] = {sm[MISC + MS_COM], sm[MISC + MS_COM + 1], sm[MISC + MS_COM + 2]};
-              double lin[3] = {sm[D.lds[L_AMOM] + 3 * nv + k], sm[D.lds[L_AMOM] + 4 * nv + k], sm[D.lds[L_AMOM] + 5 * nv + k]}, cx[3];
-              cross3(com, lin, cx);
-              val -= cx[aa];
-            }
-          } else {
-            double H[12], S[6], J[6];
-            int frame = IT[D.it[IT_T_FRAME] + t];
-            ldH(sm, D, frame, H);
-            ld(sm + D.lds[L_S] + 6 * k, 6, S);
-            motion_to_frame(H, S, J);
-            if (kind == QPC_TASK_SPATIAL_ACCELERATION || kind == QPC_TASK_ANGULAR_ACCELERATION) val = sg * J[a];
-            else if (kind == QPC_TASK_LINEAR_ACCELERATION) val = sg * J[3 + a];
-            else { // point jacobian J_lin - p^ J_ang in the base frame (src/tasks.jl:157-160)
-              double Ht[12], pw[3], d3[3], pF[3], px[3];
-              int target = IT[D.it[IT_T_TARGET] + t];
-              ldH(sm, D, target, Ht);
-              mv3(Ht, DT + D.dt[DT_T_POINT] + 3 * t, pw);
-              d3[0] = pw[0] + Ht[9] - H[9]; d3[1] = pw[1] + Ht[10] - H[10]; d3[2] = pw[2] + Ht[11] - H[11];
-              mtv3(H, d3, pF);
-              cross3(pF, J, px);
-              val = sg * (J[3 + a] - px[a]);
-            }
+      if (kind == 7) val = sm[D.lds[L_AMOM] + a * nv + k]; // wrench balance rows (a11), S dropped (invertible)
+      else if (sg != 0) {
+        if (kind == QPC_TASK_JOINT_ACCELERATION) val = 1.0;
+        else if (kind == QPC_TASK_MOMENTUM_RATE || kind == QPC_TASK_LINEAR_MOMENTUM_RATE) {
+          int aa = kind == QPC_TASK_LINEAR_MOMENTUM_RATE ? a + 3 : a;
+          val = sm[D.lds[L_AMOM] + aa * nv + k];
+          if (aa < 3) { // centroidal: ang - com x lin (src/tasks.jl:208-213)
+            double com[3] = {sm[MISC + MS_COM], sm[MISC + MS_COM + 1], sm[MISC + MS_COM + 2]};
+            double lin[3] = {sm[D.lds[L_AMOM] + 3 * nv + k], sm[D.lds[L_AMOM] + 4 * nv + k], sm[D.lds[L_AMOM] + 5 * nv + k]}, cx[3];
+            cross3(com, lin, cx);
+            val -= cx[aa];
+          }
+        } else {
+          double H[12], S[6], J[6];
+          ldH(sm, D, frame, H);
+          ld(sm + D.lds[L_S] + 6 * k, 6, S);
+          motion_to_frame(H, S, J);
+          if (kind == QPC_TASK_SPATIAL_ACCELERATION || kind == QPC_TASK_ANGULAR_ACCELERATION) val = sg * J[a];
+          else if (kind == QPC_TASK_LINEAR_ACCELERATION) val = sg * J[3 + a];
+          else { // point jacobian J_lin - p^ J_ang in the base frame (src/tasks.jl:157-160)
+            double Ht[12], pw[3], d3[3], pF[3], px[3];
+            int target = IT[D.it[IT_T_TARGET] + t];
+            ldH(sm, D, target, Ht);
+            mv3(Ht, DT + D.dt[DT_T_POINT] + 3 * t, pw);
+            d3[0] = pw[0] + Ht[9] - H[9]; d3[1] = pw[1] + Ht[10] - H[10]; d3[2] = pw[2] + Ht[11] - H[11];
+            mtv3(H, d3, pF);
+            cross3(pF, J, px);
+            val = sg * (J[3 + a] - px[a]);
           }
         }
       }
       sm[D.lds[L_M] + r * D.nfs + f] = val * sm[D.lds[L_SQH] + f];
     }
     for (int r = lane; r < m; r += 64) {
-      int t = IT[D.it[IT_ROW_TASK] + r], a = IT[D.it[IT_ROW_COMP] + r];
+      // packed row code: kind(3) | a(3) | frame+1(7) | base+1(7) | target+1(7)
+      const int code = IT[D.it[IT_RCODE] + r], di = IT[D.it[IT_R_DES] + r], t = IT[D.it[IT_R_T] + r], pk = IT[D.it[IT_R_PINK] + r];
+      const int kind = code & 7, a = (code >> 3) & 7, frame = ((code >> 6) & 127) - 1, base = ((code >> 13) & 127) - 1,
+                target = ((code >> 20) & 127) - 1;
       double rhs;
-      if (t < 0) rhs = sm[MISC + MS_WG + a] - sm[MISC + MS_ADV + a] - sm[D.lds[L_ACCP] + ntask * 6 + a];
+      if (kind == 7) rhs = sm[MISC + MS_WG + a] - sm[MISC + MS_ADV + a];
       else {
-        int kind = IT[D.it[IT_T_KIND] + t];
-        double des = sm[D.lds[L_DES] + IT[D.it[IT_T_DES] + t] + a];
+        double des = sm[D.lds[L_DES] + di];
         if (kind == QPC_TASK_JOINT_ACCELERATION) {
-          // generic joint rows (duplicate pin / matrix weight): pinned part moves to the rhs
-          double pinned = 0.0;
-          for (int k = 0; k < nv; k++)
-            if (IT[D.it[IT_T_SGN] + t * nv + k] != 0 && IT[D.it[IT_VCOMP] + k] == a && IT[D.it[IT_FREE_OF] + k] < 0) pinned = sm[D.lds[L_VD] + k];
-          rhs = des - pinned;
+          // generic joint rows (duplicate pin / matrix weight): a pinned acceleration moves to the rhs
+          rhs = des - (pk >= 0 ? (double)sm[D.lds[L_VD] + pk] : 0.0);
         } else if (kind == QPC_TASK_MOMENTUM_RATE || kind == QPC_TASK_LINEAR_MOMENTUM_RATE) {
           int aa = kind == QPC_TASK_LINEAR_MOMENTUM_RATE ? a + 3 : a;
-          double b = sm[MISC + MS_ADV + aa] + sm[D.lds[L_ACCP] + t * 6 + aa];
+          double b = sm[MISC + MS_ADV + aa];
           if (aa < 3) {
             double com[3] = {sm[MISC + MS_COM], sm[MISC + MS_COM + 1], sm[MISC + MS_COM + 2]}, lin[3], cx[3];
-            for (int i = 0; i < 3; i++) lin[i] = sm[MISC + MS_ADV + 3 + i] + sm[D.lds[L_ACCP] + t * 6 + 3 + i];
+            for (int i = 0; i < 3; i++) lin[i] = sm[MISC + MS_ADV + 3 + i];
             cross3(com, lin, cx);
             b -= cx[aa];
           }
           rhs = des - b;
         } else {
-          // J̇v = transform(state, bias(target) - bias(base), frame) (src/tasks.jl:37-38) plus the
-          // acceleration produced by the pinned joints, all as ONE world-frame spatial acceleration
-          int base = IT[D.it[IT_T_BASE] + t], target = IT[D.it[IT_T_TARGET] + t], frame = IT[D.it[IT_T_FRAME] + t];
+          // J̇v = transform(state, bias(target) - bias(base), frame) (src/tasks.jl:37-38); the bias
+          // already carries the acceleration produced by the pinned joints
           double At[6], Abs[6], Tt[6], Tb[6], Tf[6], trel[6], cr[6], aw[6], aF[6], H[12];
           ld6(sm, D.lds[L_AB], target, At); ld6(sm, D.lds[L_AB], base, Abs);
           ld6(sm, D.lds[L_T], target, Tt); ld6(sm, D.lds[L_T], base, Tb); ld6(sm, D.lds[L_T], frame, Tf);
           for (int i = 0; i < 6; i++) trel[i] = Tt[i] - Tb[i];
           crm(Tf, trel, cr);
-          for (int i = 0; i < 6; i++) aw[i] = At[i] - Abs[i] - cr[i] + sm[D.lds[L_ACCP] + t * 6 + i];
+          for (int i = 0; i < 6; i++) aw[i] = At[i] - Abs[i] - cr[i];
           ldH(sm, D, frame, H);
           motion_to_frame(H, aw, aF);
           if (kind == QPC_TASK_SPATIAL_ACCELERATION || kind == QPC_TASK_ANGULAR_ACCELERATION) rhs = des - aF[a];
@@ -1336,23 +1371,32 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       sm[D.lds[L_CWR] + idx] = acc;
     }
   } QPC_END_PHASE
-  QPC_PHASE(lane) { // S_j v̇_j per body
-    for (int i = lane; i < nb; i += 64) {
+  QPC_PHASE(lane) { // S_j v̇_j per body, FREE joints only (the pinned ones already ride in Ab)
+    if (lane < nb) {
+      const int i = lane;
+      const int *mt = QPC_LI(meta_, lane);
       double sv[6] = {0, 0, 0, 0, 0, 0};
-      int v0 = IT[D.it[IT_VOFF] + i], n = IT[D.it[IT_NVJ] + i];
+      const int v0 = mt[2], n = mt[3];
       for (int c = 0; c < n; c++) {
-        double vd = sm[D.lds[L_VD] + v0 + c];
+        const bool pinned = IT[D.it[IT_PDES_K] + v0 + c] >= 0;
+        const double vd = pinned ? 0.0 : (double)sm[D.lds[L_VD] + v0 + c];
         for (int a = 0; a < 6; a++) sv[a] += sm[D.lds[L_S] + 6 * (v0 + c) + a] * vd;
       }
       st(sm + D.lds[L_SV] + 6 * i, 6, sv);
     }
   } QPC_END_PHASE
   QPC_PHASE(lane) { // body wrench: I (A + Ab - g) + T x* I T - external (contact) wrench
-    for (int i = lane; i < nb; i += 64) {
+    if (lane < nb) {
+      const int i = lane;
+      const int *mt = QPC_LI(meta_, lane);
       double A[6], I[10], ia[6];
       ld(sm + D.lds[L_SV] + 6 * i, 6, A);
-      for (int e = anc_ptr[i]; e < anc_ptr[i + 1]; e++)
-        for (int a = 0; a < 6; a++) A[a] += sm[D.lds[L_SV] + 6 * anc_idx[e] + a];
+      QPC_UNROLL_JIT
+      for (int s = 0; s < QPC_MAXD; s++) {
+        const int an = mt[11 + s];
+        if (an >= 0)
+          for (int a = 0; a < 6; a++) A[a] += sm[D.lds[L_SV] + 6 * an + a];
+      }
       for (int a = 0; a < 6; a++) A[a] += sm[D.lds[L_AB] + 6 * i + a];
       A[3] -= DT[D.dt[DT_GRAV]]; A[4] -= DT[D.dt[DT_GRAV] + 1]; A[5] -= DT[D.dt[DT_GRAV] + 2];
       ld(sm + D.lds[L_IW] + 10 * i, 10, I);
@@ -1366,13 +1410,18 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
     }
   } QPC_END_PHASE
   QPC_PHASE(lane) { // tau_k = S_k . (sum of subtree wrenches); floating joint torques exactly 0
-    for (int k = lane; k < nv; k += 64) {
-      int b = IT[D.it[IT_VBODY] + k];
+    if (lane < nv) {
+      const int k = lane;
+      const int *mt = QPC_LI(meta_, lane);
       double tau = 0.0;
-      if (b != D.floating) {
+      if (mt[6] != D.floating) {
         double F[6] = {0, 0, 0, 0, 0, 0};
-        for (int e = desc_ptr[b]; e < desc_ptr[b + 1]; e++)
-          for (int a = 0; a < 6; a++) F[a] += sm[D.lds[L_BW] + 6 * desc_idx[e] + a];
+        unsigned long long msk = ((unsigned long long)(unsigned)mt[10] << 32) | (unsigned long long)(unsigned)mt[9];
+        while (msk) {
+          const int b = QPC_CTZ64(msk);
+          msk &= msk - 1;
+          for (int a = 0; a < 6; a++) F[a] += sm[D.lds[L_BW] + 6 * b + a];
+        }
         for (int a = 0; a < 6; a++) tau += sm[D.lds[L_S] + 6 * k + a] * F[a];
       }
       io.tau[k] = tau;

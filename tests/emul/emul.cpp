@@ -66,6 +66,9 @@ struct Lds {
 #define QPC_FABS(x) std::fabs((double)(x))
 #define QPC_LANE_ARRAY(name, n) double name[64][n]
 #define QPC_LA(name, lane) name[lane]
+#define QPC_LANE_INTS(name, n) int name[64][n]
+#define QPC_LI(name, lane) name[lane]
+#define QPC_CTZ64(x) __builtin_ctzll((unsigned long long)(x))
 // reductions across a phase boundary: lane-serial form through the (emulator-only) scratch that
 // follows the kernel's LDS slab
 #define QPC_RED_MAX_PUT(slot, name, val) sm[D.lds_doubles + 128 * (slot) + lane] = (val)
