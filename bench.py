@@ -26,6 +26,10 @@ sys.path.insert(0, ROOT)
 
 ALG_BYTES_PER_SOLVE = 1968  # in 8*(37+36+36+16) + out 8*(36+36+48) + 8
 ALG_FLOPS_PER_SOLVE = 4.6e5  # one reduced-KKT factor+solve + assembly + FK/RNEA
+# HBM traffic per solve measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes
+# (profiles/r01_traffic/): 31.25 MB read + 65.53 MB written per 32768-QP launch.  8-byte-per-lane
+# accesses: the gfx950 "x2 for 16-B wide reads" correction of MI355X_MICROARCH.md does not apply.
+MEASURED_TRAFFIC_BYTES_PER_SOLVE = (31252.3 + 65531.5) * 1024 / 32768
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md (spec; 6.29e12 measured)
 FP64_PEAK = 78.6e12  # FLOP/s vector fp64 (datasheet)
 
@@ -184,7 +188,9 @@ def main():
                        "optimal_fraction": n_opt / B, "mean_active_set_iters": float(it.mean()),
                        "lds_bytes_per_qp": int(lay.lds_bytes_per_qp)},
             "roofline": {"bound": "hbm", "achieved": ach_bytes / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": ach_bytes / HBM_PEAK, "traffic": None,
+                         "frac": ach_bytes / HBM_PEAK,
+                         "traffic": MEASURED_TRAFFIC_BYTES_PER_SOLVE * B if args.config == 3 else None,
+                         "traffic_source": "profiles/r01_traffic (rocprofv3 PMC, v7 kernel), bytes per launch",
                          "kernel": "qpc_tick_kernel", "kernel_avg_ms": avg_ms.value, "launches": int(nl.value),
                          "algorithmic_bytes_per_solve": ALG_BYTES_PER_SOLVE,
                          "note": "path is fp64-VALU / LDS-latency bound, not HBM bound (SURVEY.md 8d); "
