@@ -214,6 +214,19 @@ int qpc_compile_program(qpc_controller *c) {
     }
     for (size_t p = 0; p < pin_k.size(); p++) pdes[pin_k[p]] = pin_d[p];
     B.ibegin(IT_ANC_TAB); B.it.insert(B.it.end(), tab.begin(), tab.end());
+    {
+      std::vector<int> crb(mask);
+      D.crb_full_body = -1;
+      for (int i = 0; i < nb; i++) {
+        bool has_free = false;
+        for (int k = 0; k < m->nvj[i]; k++) has_free = has_free || free_of[m->voff[i] + k] >= 0;
+        unsigned long long mk = ((unsigned long long)(unsigned)mask[2 * i + 1] << 32) | (unsigned)mask[2 * i];
+        const unsigned long long all = nb >= 64 ? ~0ull : ((1ull << nb) - 1);
+        if (!has_free) { crb[2 * i] = crb[2 * i + 1] = 0; }
+        else if (mk == all && D.crb_full_body < 0) { D.crb_full_body = i; crb[2 * i] = crb[2 * i + 1] = 0; }
+      }
+      B.ibegin(IT_CRB_MASK); B.it.insert(B.it.end(), crb.begin(), crb.end());
+    }
     B.ibegin(IT_DESC_MASK); B.it.insert(B.it.end(), mask.begin(), mask.end());
     B.ibegin(IT_PDES_K); B.it.insert(B.it.end(), pdes.begin(), pdes.end());
     // packed assembly codes: kind(3) | sg+1(2) | a(3) | k(7) | frame+1(7) | t(6)   (kind 7 = wrench row)

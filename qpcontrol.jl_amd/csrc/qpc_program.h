@@ -27,6 +27,8 @@ enum {
   IT_BC_PTR, IT_BC_IDX,     // contacts attached to body i (CSR)
   IT_SLACK_TASK, IT_SLACK_COMP, // slack index -> generic task, component
   IT_ANC_TAB,   // [nb * maxd] s-th ancestor of body i (nearest first), -1 padded; maxd = max(maxdepth,1)
+  IT_CRB_MASK,  // [nb * 2] like IT_DESC_MASK but zero where the composite inertia is not needed (joint has no free
+                //          velocity column) or comes from the whole-robot total (crb_full_body)
   IT_DESC_MASK, // [nb * 2] 64-bit subtree membership mask of body i (lo, hi), bit k = body k in subtree(i)
   IT_PDES_K,    // [nv] desired-record index that pins velocity index k, or -1 (free)
   IT_MCODE,     // [m * nf] packed assembly code of constraint-matrix entry (row r, free column f)
@@ -99,6 +101,7 @@ struct QpcDims {
   int floating, fv0; // floating body and its first velocity index (or -1)
   int n_desired, n_tw, n_surf, maxdepth;
   int maxd; // row length of IT_ANC_TAB
+  int crb_full_body; // body whose subtree is the whole mechanism and owns free columns (its composite inertia = total), or -1
   int nfs, ms, m1s;  // padded leading dimensions (odd) of L_M, L_SM, L_X
   int wsize;         // doubles in L_W / L_WINV
   int it[IT_COUNT];

@@ -36,7 +36,8 @@
 #define QPC_PROF_T0()
 #define QPC_PROF_ACC(i)
 #endif
-enum { PS_KIN, PS_ASM, PS_SBUILD, PS_CHOL, PS_XINV, PS_REFAC, PS_RESID, PS_KKT, PS_UPDATE, PS_LOGIC, PS_FINAL, PS_RNEA, PS_COUNT };
+enum { PS_KIN, PS_ASM, PS_SBUILD, PS_CHOL, PS_XINV, PS_REFAC, PS_RESID, PS_KKT, PS_UPDATE, PS_LOGIC, PS_FINAL, PS_RNEA,
+       PS_K_INPUT, PS_K_JOINT, PS_K_WORLD, PS_K_SUBSP, PS_K_TWIST, PS_K_BIAS, PS_COUNT };
 
 namespace qpc {
 
@@ -507,7 +508,7 @@ template <class P> struct Solver {
     } QPC_END_PHASE
     int it = 0;
     for (;; it++) {
-      residuals();
+      if (it == 0) fresh_rhs(); else residuals();
       kkt_solve();
       double rbig = 0.0, rdbig = 0.0;
       QPC_PHASE(lane) {
@@ -648,7 +649,7 @@ template <class P> struct Solver {
 
   // EQP of the current working set solved from x = 0: the residual IS the right-hand side, so no
   // mat-vec pass is needed; one KKT solve, no refinement (used inside the active-set search)
-  QPC_FN void eqp_fresh() {
+  QPC_FN void fresh_rhs() {
     const int nf = D.nf, ne = D.ne, nrho = D.nrho, m = D.m, m1 = D.m1, N = D.N;
     QPC_PROF_ACC(PS_LOGIC);
     QPC_PHASE(lane) {
@@ -667,6 +668,10 @@ template <class P> struct Solver {
       }
     } QPC_END_PHASE
     QPC_PROF_ACC(PS_RESID);
+  }
+  QPC_FN void eqp_fresh() {
+    const int nf = D.nf, ne = D.ne, nrho = D.nrho, m = D.m;
+    fresh_rhs();
     kkt_solve();
     QPC_PHASE(lane) {
       for (int f = lane; f < nf; f += 64) sm[D.lds[L_XV] + f] = sm[D.lds[L_DV] + f];
@@ -701,7 +706,8 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
   // ======================================================================== inputs -> LDS
   // Static per-lane metadata (lane = body i and lane = velocity index k) is read ONCE per QP here
   // and kept in registers: no table lookup sits on a dependent path of the tree sweeps below.
-  //   [0] jtype(i) [1] q0(i) [2] v0(i) [3] nvj(i) [4,5] subtree mask of body i
+  //   [0] jtype(i) [1] q0(i) [2] v0(i) [3] nvj(i) [4,5] subtree mask of body i for the composite inertia
+  //       (zero when not needed: no free column / whole-robot total)
   //   [6] vbody(k) [7] vcomp(k) [8] pin-desired index of k or -1 [9,10] subtree mask of vbody(k)
   //   [11 + s] s-th ancestor of body i (nearest first) or -1
   QPC_LANE_INTS(meta_, 11 + QPC_MAXD);
@@ -711,7 +717,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
     if (lane < nb) {
       mt[0] = IT[D.it[IT_JTYPE] + lane]; mt[1] = IT[D.it[IT_QOFF] + lane]; mt[2] = IT[D.it[IT_VOFF] + lane];
       mt[3] = IT[D.it[IT_NVJ] + lane];
-      mt[4] = IT[D.it[IT_DESC_MASK] + 2 * lane]; mt[5] = IT[D.it[IT_DESC_MASK] + 2 * lane + 1];
+      mt[4] = IT[D.it[IT_CRB_MASK] + 2 * lane]; mt[5] = IT[D.it[IT_CRB_MASK] + 2 * lane + 1];
       QPC_UNROLL_JIT
       for (int s = 0; s < QPC_MAXD; s++) mt[11 + s] = s < D.maxd ? IT[D.it[IT_ANC_TAB] + lane * D.maxd + s] : -1;
     }
@@ -733,6 +739,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
     for (int i = lane; i < m + 4 * ne; i += 64) sm[D.lds[L_HOT] + i] = (double)IT[D.it[IT_HOT] + i];
   } QPC_END_PHASE
 
+  QPC_PROF_ACC(PS_K_INPUT);
   // ======================================================================== kinematics (a2)
   QPC_PHASE(lane) { // joint transforms: x_parent = Rf (Rj x + pj) + pf
     if (lane < nb) {
@@ -765,6 +772,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       st(sm + D.lds[L_RL] + 12 * i, 12, H);
     }
   } QPC_END_PHASE
+  QPC_PROF_ACC(PS_K_JOINT);
   QPC_PHASE(lane) { // transform_to_root by walking the (register-resident) ancestor chain
     if (lane < nb) {
       const int *mt = QPC_LI(meta_, lane);
@@ -783,6 +791,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       st(sm + D.lds[L_H] + 12 * lane, 12, H);
     }
   } QPC_END_PHASE
+  QPC_PROF_ACC(PS_K_WORLD);
   QPC_PHASE(lane) { // per body: motion subspace columns of its joint (world), joint twist, world inertia
     if (lane < nb) {
       const int i = lane;
@@ -821,6 +830,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       st(sm + D.lds[L_IW] + 10 * i, 10, o);
     }
   } QPC_END_PHASE
+  QPC_PROF_ACC(PS_K_SUBSP);
   QPC_PHASE(lane) { // twist_wrt_world (chain sum); bias increment T_i x (S_j v_j) + S_j v̇_j(pinned):
                     // the accelerations of the PINNED joints ride along with the velocity-product bias,
                     // so every J̇v / Ȧv below already contains J_pin v̇_pin (no separate pass)
@@ -846,6 +856,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       st(sm + D.lds[L_CR] + 6 * i, 6, cr);
     }
   } QPC_END_PHASE
+  QPC_PROF_ACC(PS_K_TWIST);
   QPC_PHASE(lane) { // bias_acceleration (+ pinned), composite inertias (subtree mask), momentum-rate bias
     if (lane < nb) {
       const int i = lane;
@@ -866,7 +877,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
         msk &= msk - 1;
         for (int a = 0; a < 10; a++) Ic[a] += sm[D.lds[L_IW] + 10 * k + a];
       }
-      st(sm + D.lds[L_IC] + 10 * i, 10, Ic);
+      if (i != D.crb_full_body) st(sm + D.lds[L_IC] + 10 * i, 10, Ic);
       ld(sm + D.lds[L_IW] + 10 * i, 10, I);
       ld(sm + D.lds[L_T] + 6 * i, 6, T);
       inertia_mul(I, T, h);
@@ -876,7 +887,20 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       st(sm + D.lds[L_HB] + 6 * i, 6, ia); // I (Ab + A_pinned) + T x* I T
       st(sm + D.lds[L_F] + 6 * i, 6, h);   // T x* I T alone (velocity-product wrench for RNEA)
     }
+    if (lane >= 54 && D.crb_full_body >= 0) { // whole-robot composite inertia: component (lane-54), batched sum
+      const int a = lane - 54;
+      double acc = 0.0;
+      for (int i0 = 0; i0 < nb; i0 += 8) {
+        double x[8];
+        QPC_UNROLL_FULL
+        for (int u = 0; u < 8; u++) x[u] = sm[D.lds[L_IW] + 10 * (i0 + u < nb ? i0 + u : 0) + a];
+        QPC_UNROLL_FULL
+        for (int u = 0; u < 8; u++) acc += (i0 + u < nb) ? x[u] : 0.0;
+      }
+      sm[D.lds[L_IC] + 10 * D.crb_full_body + a] = acc;
+    }
   } QPC_END_PHASE
+  QPC_PROF_ACC(PS_K_BIAS);
   QPC_PHASE(lane) { // momentum matrix, CoM, momentum-rate bias, Hessian diagonal
     if (lane < nv) {
       const int k = lane;
@@ -1111,10 +1135,12 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       int r = idx / m, c = idx % m;
       if (c > r) continue;
       double acc = dotp(sm + D.lds[L_M] + r * D.nfs, 1, sm + D.lds[L_M] + c * D.nfs, 1, nf);
-      int tr = IT[D.it[IT_ROW_TASK] + r], tc = IT[D.it[IT_ROW_TASK] + c];
-      if (tr >= 0 && tr == tc) {
-        int w0 = IT[D.it[IT_T_WOFF] + tr];
-        if (w0 >= 0) acc += sm[D.lds[L_WINV] + w0 + IT[D.it[IT_ROW_COMP] + r] * IT[D.it[IT_T_DIM] + tr] + IT[D.it[IT_ROW_COMP] + c]];
+      if (ne > 0 && r < m1) { // slack rows of the same soft task: + (W+eps)^-1 entry (lookups from the LDS hot table)
+        const int slr = (int)(double)sm[D.lds[L_HOT] + r], slc = (int)(double)sm[D.lds[L_HOT] + c];
+        if (slr >= 0 && slc >= 0) {
+          const int s0r = (int)(double)sm[D.lds[L_HOT] + m + 3 * ne + slr], s0c = (int)(double)sm[D.lds[L_HOT] + m + 3 * ne + slc];
+          if (s0r == s0c) acc += sm[D.lds[L_WINV] + (int)(double)sm[D.lds[L_HOT] + m + ne + slr] + (slc - s0c)];
+        }
       }
       sm[D.lds[L_SM] + r * D.ms + c] = acc;
     }
