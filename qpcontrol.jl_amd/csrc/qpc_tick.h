@@ -257,10 +257,10 @@ template <class P> QPC_FN void inv6_spd(P Sin, const double *sref, double tau, P
     }
 }
 
-// Column `col` of T = S^-1 for a symmetric 6x6 S: Cholesky in registers (every calling lane redoes
-// it -- 6 lanes, one column each, one phase) then forward/back substitution for e_col.  A pivot
+// x = S^-1 rhs for a symmetric 6x6 S: Cholesky in registers then forward/back substitution (with
+// rhs = e_c this is column c of S^-1: 6 lanes, one column each, one phase).  A pivot
 // below tau * sref[k] marks a redundant row: zero row/column in T (infinite-pivot rule).
-template <class P> QPC_FN void inv6_column(P Sin, const double *sref, double tau, int col, double *x) {
+template <class P> QPC_FN void chol6_solve(P Sin, const double *sref, double tau, const double *rhs, double *x) {
   double L[6][6], invd[6], y[6];
   QPC_UNROLL_FULL
   for (int i = 0; i < 6; i++)
@@ -284,7 +284,7 @@ template <class P> QPC_FN void inv6_column(P Sin, const double *sref, double tau
   }
   QPC_UNROLL_FULL
   for (int r = 0; r < 6; r++) {
-    double t = (r == col) ? 1.0 : 0.0;
+    double t = rhs[r];
     QPC_UNROLL_FULL
     for (int j = 0; j < r; j++) t -= L[r][j] * y[j];
     y[r] = t * invd[r];
@@ -378,7 +378,9 @@ template <class P> struct Solver {
         double sref[6], x[6];
         for (int k = 0; k < 6; k++)
           sref[k] = sm[D.lds[L_SM] + (m1 + k) * D.ms + (m1 + k)] + (sm[D.lds[L_C22] + k * 6 + k] - sm[D.lds[L_B22] + k * 6 + k]);
-        inv6_column(sm + D.lds[L_C22], sref, D.tau_pivot, lane, x);
+        double ec[6];
+        for (int r = 0; r < 6; r++) ec[r] = (r == lane) ? 1.0 : 0.0;
+        chol6_solve(sm + D.lds[L_C22], sref, D.tau_pivot, ec, x);
         for (int r = 0; r < 6; r++) sm[D.lds[L_S22I] + r * 6 + lane] = x[r];
       }
     } QPC_END_PHASE
@@ -543,6 +545,108 @@ template <class P> struct Solver {
     return it;
   }
 
+  // ---- one primal-dual active-set sweep in 4 phases (the common path: no upper bound active) ----
+  //   1 lane = contact: flip the working set of its N rays (fix violated, free wrong-signed),
+  //     then K_c = (H_FF + eps)^-1 and Y_c = K_c G_c' for the NEW set
+  //   2 S22 = B22 + G Y                         3 lam_w = S22^-1 u0 (Cholesky-solve, no inverse formed)
+  //   4 rho = K G' lam_w and the bound multipliers
+  // returns false (nothing changed: the current point is optimal for the sweep rule) without
+  // touching rho; `upper` reports whether any upper bound became active (then the caller must use
+  // the general refactor_rho / rho_solve path instead).
+  QPC_FN bool pdas_sweep(double gscale, double tolb, bool &upper) {
+    const int N = D.N, nc = D.nc, nrho = D.nrho, m1 = D.m1;
+    const double eps = sm[D.lds[L_MISC] + MS_EPS];
+    double rchg = 0.0, rup = 0.0;
+    QPC_PROF_ACC(PS_LOGIC);
+    QPC_PHASE(lane) {
+      double changed = 0.0, up = 0.0;
+      for (int c = lane; c < nc; c += 64) {
+        for (int i = 0; i < N; i++) {
+          const int j = c * N + i;
+          double w = sm[D.lds[L_WS] + j], hi = sm[D.lds[L_HI] + j], x = sm[D.lds[L_XR] + j], nw_ = w;
+          if (hi > 0.0) {
+            if (w != 0.0) { if (sm[D.lds[L_U] + j] < -D.tol_bound * gscale) nw_ = 0.0; }
+            else if (x < -tolb) nw_ = -1.0;
+            else if (x > hi + tolb) nw_ = 1.0;
+            if (nw_ != w) { sm[D.lds[L_WS] + j] = nw_; changed = 1.0; }
+            if (nw_ == 1.0) up = 1.0;
+          }
+        }
+        if (N <= 4) kr_block<4>(sm, D, c, eps); else kr_block<8>(sm, D, c, eps);
+        for (int jj = 0; jj < N; jj++)
+          for (int b = 0; b < 6; b++)
+            sm[D.lds[L_Y] + (c * N + jj) * 6 + b] = dotp(sm + D.lds[L_KR] + c * N * N + jj * N, 1, sm + D.lds[L_G] + b * nrho + c * N, 1, N);
+      }
+      QPC_RED_MAX_PUT(0, rchg, changed);
+      QPC_RED_MAX_PUT(1, rup, up);
+    } QPC_END_PHASE
+    rchg = QPC_RED_MAX_GET(0, rchg);
+    rup = QPC_RED_MAX_GET(1, rup);
+    upper = rup > 0.0;
+    QPC_PROF_ACC(PS_REFAC);
+    if (!(rchg > 0.0) || upper) return rchg > 0.0;
+    QPC_PHASE(lane) {
+      if (lane < 36) {
+        int a = lane / 6, b = lane % 6;
+        sm[D.lds[L_C22] + lane] = sm[D.lds[L_B22] + lane] + dotp(sm + D.lds[L_G] + a * nrho, 1, sm + D.lds[L_Y] + b, 6, nrho);
+      }
+    } QPC_END_PHASE
+    QPC_PHASE(lane) {
+      if (lane < 6) {
+        double sref[6], u0[6], x[6];
+        for (int k = 0; k < 6; k++) {
+          sref[k] = sm[D.lds[L_SM] + (m1 + k) * D.ms + (m1 + k)] + (sm[D.lds[L_C22] + k * 6 + k] - sm[D.lds[L_B22] + k * 6 + k]);
+          u0[k] = sm[D.lds[L_MISC] + MS_U0 + k];
+        }
+        chol6_solve(sm + D.lds[L_C22], sref, D.tau_pivot, u0, x);
+        double xl = 0.0;
+        for (int k = 0; k < 6; k++) xl = (k == lane) ? x[k] : xl;
+        sm[D.lds[L_LAM] + m1 + lane] = xl;
+      }
+    } QPC_END_PHASE
+    QPC_PROF_ACC(PS_REFAC);
+    rho_back(true, false);
+    return true;
+  }
+
+  // rho_F = K (r_r + G' lam_w) (+ rho_fix) and, in base mode, the bound multipliers and scales
+  QPC_FN void rho_back(bool base, bool need_kr) {
+    const int N = D.N, nrho = D.nrho, m1 = D.m1;
+    const int outr = base ? D.lds[L_XR] : D.lds[L_DR], outl = (base ? D.lds[L_LAM] : D.lds[L_DL]) + m1;
+    double rg = 0.0, rx = 0.0;
+    QPC_PHASE(lane) { // rho_F = K (r_r + G' lam_w) (+ rho_fix); each lane rebuilds its contact's N rho's,
+                      // and in base mode also its multiplier u_j = +-(H_rho rho - G' lam_w)_j
+      double g = 0.0, xm = 0.0;
+      for (int j = lane; j < nrho; j += 64) {
+        int c = j / N, jj = j % N;
+        double w[8], rho_c[8];
+        for (int i = 0; i < N; i++) {
+          w[i] = dotp(sm + D.lds[L_G] + c * N + i, nrho, sm + outl, 1, 6);
+          if (i == jj) g = w[i]; // (G' lam_w)_j, reused below
+          if (need_kr) w[i] += sm[D.lds[L_RR] + c * N + i];
+        }
+        for (int i2 = 0; i2 < N; i2++) {
+          double acc = 0.0;
+          for (int i = 0; i < N; i++) acc += sm[D.lds[L_KR] + c * N * N + i2 * N + i] * w[i];
+          if (base && sm[D.lds[L_WS] + c * N + i2] == 1.0) acc += sm[D.lds[L_HI] + c * N + i2];
+          rho_c[i2] = acc;
+        }
+        sm[outr + j] = rho_c[jj];
+        if (base) {
+          double gl = -g;
+          for (int i = 0; i < N; i++) gl += sm[D.lds[L_HR] + c * N * N + jj * N + i] * rho_c[i];
+          double wsj = sm[D.lds[L_WS] + j];
+          sm[D.lds[L_U] + j] = (wsj == -1.0) ? gl : ((wsj == 1.0) ? -gl : 0.0);
+          g = QPC_FABS(gl);
+          xm = QPC_FABS(rho_c[jj]);
+        }
+      }
+      if (base) { QPC_RED_MAX_PUT(0, rg, g); QPC_RED_MAX_PUT(1, rx, xm); }
+    } QPC_END_PHASE
+    if (base) { last_gmax = QPC_RED_MAX_GET(0, rg); last_xmax = QPC_RED_MAX_GET(1, rx); }
+    QPC_PROF_ACC(PS_KKT);
+  }
+
   // ---- wrench-space solves for the active-set SEARCH --------------------------------------
   // rho enters the equality block only through the 6 wrench-balance rows, so for a given working
   // set   lam_w = T22 (u0 - G (K r_r + rho_fix)),   rho_F = K (r_r + G' lam_w)   with the 6-vector
@@ -589,37 +693,7 @@ template <class P> struct Solver {
     QPC_PHASE(lane) {
       if (lane < 6) sm[outl + lane] = dotp(sm + D.lds[L_S22I] + lane * 6, 1, sm + (need_kr ? D.lds[L_C22] : D.lds[L_MISC] + MS_U0), 1, 6);
     } QPC_END_PHASE
-    double rg = 0.0, rx = 0.0;
-    QPC_PHASE(lane) { // rho_F = K (r_r + G' lam_w) (+ rho_fix); each lane rebuilds its contact's N rho's,
-                      // and in base mode also its multiplier u_j = +-(H_rho rho - G' lam_w)_j
-      double g = 0.0, xm = 0.0;
-      for (int j = lane; j < nrho; j += 64) {
-        int c = j / N, jj = j % N;
-        double w[8], rho_c[8];
-        for (int i = 0; i < N; i++) {
-          w[i] = dotp(sm + D.lds[L_G] + c * N + i, nrho, sm + outl, 1, 6);
-          if (i == jj) g = w[i]; // (G' lam_w)_j, reused below
-          if (need_kr) w[i] += sm[D.lds[L_RR] + c * N + i];
-        }
-        for (int i2 = 0; i2 < N; i2++) {
-          double acc = 0.0;
-          for (int i = 0; i < N; i++) acc += sm[D.lds[L_KR] + c * N * N + i2 * N + i] * w[i];
-          if (base && sm[D.lds[L_WS] + c * N + i2] == 1.0) acc += sm[D.lds[L_HI] + c * N + i2];
-          rho_c[i2] = acc;
-        }
-        sm[outr + j] = rho_c[jj];
-        if (base) {
-          double gl = -g;
-          for (int i = 0; i < N; i++) gl += sm[D.lds[L_HR] + c * N * N + jj * N + i] * rho_c[i];
-          double wsj = sm[D.lds[L_WS] + j];
-          sm[D.lds[L_U] + j] = (wsj == -1.0) ? gl : ((wsj == 1.0) ? -gl : 0.0);
-          g = QPC_FABS(gl);
-          xm = QPC_FABS(rho_c[jj]);
-        }
-      }
-      if (base) { QPC_RED_MAX_PUT(0, rg, g); QPC_RED_MAX_PUT(1, rx, xm); }
-    } QPC_END_PHASE
-    if (base) { last_gmax = QPC_RED_MAX_GET(0, rg); last_xmax = QPC_RED_MAX_GET(1, rx); }
+    rho_back(base, need_kr);
     QPC_PROF_ACC(PS_KKT);
   }
 
@@ -1233,32 +1307,20 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
     bool any_upper = false;
     S.refactor_rho();
     S.rho_solve(true, 0, 0.0, any_upper);
-    // ---- phase A: primal-dual active-set sweeps (multi-change)
+    // ---- phase A: primal-dual active-set sweeps (multi-change), fused 4-phase form
     for (int pd = 0; pd < D.max_pdas; pd++) {
-      const double gscale = 1.0 + S.last_gmax, tolb = D.tol_bound * (1.0 + S.last_xmax); // U is current (rho_solve)
-      double rchg = 0.0, rup = 0.0;
-      QPC_PHASE(lane) {
-        double changed = 0.0, up = 0.0;
-        for (int j = lane; j < nrho; j += 64) {
-          double w = sm[D.lds[L_WS] + j], hi = sm[D.lds[L_HI] + j], x = sm[D.lds[L_XR] + j], nw_ = w;
-          if (!(hi > 0.0)) continue; // disabled
-          if (w != 0.0) { if (sm[D.lds[L_U] + j] < -D.tol_bound * gscale) nw_ = 0.0; }
-          else if (x < -tolb) nw_ = -1.0;
-          else if (x > hi + tolb) nw_ = 1.0;
-          if (nw_ != w) { sm[D.lds[L_WS] + j] = nw_; changed = 1.0; }
-          if (nw_ == 1.0) up = 1.0;
-        }
-        QPC_RED_MAX_PUT(0, rchg, changed);
-        QPC_RED_MAX_PUT(1, rup, up);
-      } QPC_END_PHASE
-      rchg = QPC_RED_MAX_GET(0, rchg);
-      rup = QPC_RED_MAX_GET(1, rup);
-      if (!(rchg > 0.0)) break;
-      any_upper = rup > 0.0;
+      const double gscale = 1.0 + S.last_gmax, tolb = D.tol_bound * (1.0 + S.last_xmax); // U is current
+      bool upper = false;
+      const bool changed = S.pdas_sweep(gscale, tolb, upper);
+      if (!changed) break;
       iters++;
-      S.refactor_rho();
-      S.rho_solve(true, 0, 0.0, any_upper);
+      if (upper) { // rare: an upper bound became active -> general path for this sweep
+        any_upper = true;
+        S.refactor_rho();
+        S.rho_solve(true, 0, 0.0, true);
+      }
     }
+    S.refactor_rho(); // the sweeps do not form T22: rebuild it once for phase B / the final polish
     // ---- phase B: drops until dual feasible, then Goldfarb-Idnani additions (finite)
     while (true) {
       if (iters > D.max_as_iters) { status = QPC_STATUS_ITERATION_LIMIT; break; }
