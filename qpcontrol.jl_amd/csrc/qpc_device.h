@@ -48,3 +48,19 @@ __device__ __forceinline__ int wave_min_int(int x) {
 #define QPC_RED_ARGMIN_PUT(slot, name, iname, val, idx) \
   do { double v__ = (val); name = qpc::wave_min(v__); iname = qpc::wave_min_int(v__ == name ? (int)(idx) : 0x3fffffff); } while (0)
 #define QPC_RED_ARGMIN_GET(slot, name, iname) ((void)0)
+
+// fp64 matrix core: acc(16x16 tile, 4 f64 per lane) += A(16x4) * B(4x16) with v_mfma_f64_16x16x4_f64.
+//   lane l supplies A[i = l&15][k = l>>4] (AEXPR) and B[k = l>>4][j = l&15] (BEXPR);
+//   acc[r] is C[row = (l>>4) + 4 r][col = l&15]  (the f64-specific C/D map, cdna_hip_programming.md 3)
+// Must be executed by all 64 lanes (EXEC all ones): only use it at phase level, never under a
+// lane-dependent branch.
+typedef double qpc_v4d __attribute__((ext_vector_type(4)));
+#define QPC_MFMA_F64_16x16x4(lane, ACC, AEXPR, BEXPR)                                           \
+  {                                                                                              \
+    const int lane = (int)(threadIdx.x & 63);                                                    \
+    double *acc__ = (ACC);                                                                       \
+    const double a__ = (AEXPR), b__ = (BEXPR);                                                   \
+    qpc_v4d c__ = {acc__[0], acc__[1], acc__[2], acc__[3]};                                      \
+    c__ = __builtin_amdgcn_mfma_f64_16x16x4f64(a__, b__, c__, 0, 0, 0);                          \
+    acc__[0] = c__[0]; acc__[1] = c__[1]; acc__[2] = c__[2]; acc__[3] = c__[3];                  \
+  }

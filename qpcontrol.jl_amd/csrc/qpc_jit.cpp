@@ -29,7 +29,7 @@ static std::string dbl(double x) {
 std::string qpc_jit_source(const QpcDims &D) {
   std::ostringstream o;
   o << "typedef int int32_t;\ntypedef unsigned int uint32_t;\ntypedef long long int64_t;\n";
-  o << "#define QPC_JIT 1\n#define QPC_M1_MAX " << (D.m1 > 0 ? D.m1 : 1) << "\n#define QPC_MAXD " << D.maxd << "\n#include \"qpc_device.h\"\n";
+  o << "#define QPC_JIT 1\n#define QPC_M1_MAX " << (D.m1 > 0 ? D.m1 : 1) << "\n#define QPC_MAXD " << D.maxd << "\n#define QPC_NTILE_MAX " << (((D.m + 15) / 16) * (((D.m + 15) / 16) + 1) / 2 > 0 ? ((D.m + 15) / 16) * (((D.m + 15) / 16) + 1) / 2 : 1) << "\n#include \"qpc_device.h\"\n";
   const char *st = getenv("QPC_JIT_STAMPS"); // diagnostic: in-kernel section timers
   const bool stamps = st && st[0] == '1';
   if (stamps)

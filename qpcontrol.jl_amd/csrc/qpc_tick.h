@@ -122,6 +122,10 @@ template <class P> QPC_FN void ld6(P sm, int off, int body, double *x) {
 #ifndef QPC_M1_MAX
 #define QPC_M1_MAX 64
 #endif
+// number of lower-triangular 16x16 tiles of the Schur complement (m <= 64 -> at most 10)
+#ifndef QPC_NTILE_MAX
+#define QPC_NTILE_MAX 10
+#endif
 // compile-time bound of the tree depth (the JIT defines it as the actual depth)
 #ifndef QPC_MAXD
 #define QPC_MAXD 32
@@ -543,70 +547,6 @@ template <class P> struct Solver {
       if (it > 0 && !(rdbig > 1e-13 * (1.0 + rbig))) break;
     }
     return it;
-  }
-
-  // ---- one primal-dual active-set sweep in 4 phases (the common path: no upper bound active) ----
-  //   1 lane = contact: flip the working set of its N rays (fix violated, free wrong-signed),
-  //     then K_c = (H_FF + eps)^-1 and Y_c = K_c G_c' for the NEW set
-  //   2 S22 = B22 + G Y                         3 lam_w = S22^-1 u0 (Cholesky-solve, no inverse formed)
-  //   4 rho = K G' lam_w and the bound multipliers
-  // returns false (nothing changed: the current point is optimal for the sweep rule) without
-  // touching rho; `upper` reports whether any upper bound became active (then the caller must use
-  // the general refactor_rho / rho_solve path instead).
-  QPC_FN bool pdas_sweep(double gscale, double tolb, bool &upper) {
-    const int N = D.N, nc = D.nc, nrho = D.nrho, m1 = D.m1;
-    const double eps = sm[D.lds[L_MISC] + MS_EPS];
-    double rchg = 0.0, rup = 0.0;
-    QPC_PROF_ACC(PS_LOGIC);
-    QPC_PHASE(lane) {
-      double changed = 0.0, up = 0.0;
-      for (int c = lane; c < nc; c += 64) {
-        for (int i = 0; i < N; i++) {
-          const int j = c * N + i;
-          double w = sm[D.lds[L_WS] + j], hi = sm[D.lds[L_HI] + j], x = sm[D.lds[L_XR] + j], nw_ = w;
-          if (hi > 0.0) {
-            if (w != 0.0) { if (sm[D.lds[L_U] + j] < -D.tol_bound * gscale) nw_ = 0.0; }
-            else if (x < -tolb) nw_ = -1.0;
-            else if (x > hi + tolb) nw_ = 1.0;
-            if (nw_ != w) { sm[D.lds[L_WS] + j] = nw_; changed = 1.0; }
-            if (nw_ == 1.0) up = 1.0;
-          }
-        }
-        if (N <= 4) kr_block<4>(sm, D, c, eps); else kr_block<8>(sm, D, c, eps);
-        for (int jj = 0; jj < N; jj++)
-          for (int b = 0; b < 6; b++)
-            sm[D.lds[L_Y] + (c * N + jj) * 6 + b] = dotp(sm + D.lds[L_KR] + c * N * N + jj * N, 1, sm + D.lds[L_G] + b * nrho + c * N, 1, N);
-      }
-      QPC_RED_MAX_PUT(0, rchg, changed);
-      QPC_RED_MAX_PUT(1, rup, up);
-    } QPC_END_PHASE
-    rchg = QPC_RED_MAX_GET(0, rchg);
-    rup = QPC_RED_MAX_GET(1, rup);
-    upper = rup > 0.0;
-    QPC_PROF_ACC(PS_REFAC);
-    if (!(rchg > 0.0) || upper) return rchg > 0.0;
-    QPC_PHASE(lane) {
-      if (lane < 36) {
-        int a = lane / 6, b = lane % 6;
-        sm[D.lds[L_C22] + lane] = sm[D.lds[L_B22] + lane] + dotp(sm + D.lds[L_G] + a * nrho, 1, sm + D.lds[L_Y] + b, 6, nrho);
-      }
-    } QPC_END_PHASE
-    QPC_PHASE(lane) {
-      if (lane < 6) {
-        double sref[6], u0[6], x[6];
-        for (int k = 0; k < 6; k++) {
-          sref[k] = sm[D.lds[L_SM] + (m1 + k) * D.ms + (m1 + k)] + (sm[D.lds[L_C22] + k * 6 + k] - sm[D.lds[L_B22] + k * 6 + k]);
-          u0[k] = sm[D.lds[L_MISC] + MS_U0 + k];
-        }
-        chol6_solve(sm + D.lds[L_C22], sref, D.tau_pivot, u0, x);
-        double xl = 0.0;
-        for (int k = 0; k < 6; k++) xl = (k == lane) ? x[k] : xl;
-        sm[D.lds[L_LAM] + m1 + lane] = xl;
-      }
-    } QPC_END_PHASE
-    QPC_PROF_ACC(PS_REFAC);
-    rho_back(true, false);
-    return true;
   }
 
   // rho_F = K (r_r + G' lam_w) (+ rho_fix) and, in base mode, the bound multipliers and scales
@@ -1204,21 +1144,59 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
 
   QPC_PROF_ACC(PS_ASM);
   // ======================================================================== Schur complement S = M M' + W^-1 blocks
-  QPC_PHASE(lane) {
-    for (int idx = lane; idx < m * m; idx += 64) {
-      int r = idx / m, c = idx % m;
-      if (c > r) continue;
-      double acc = dotp(sm + D.lds[L_M] + r * D.nfs, 1, sm + D.lds[L_M] + c * D.nfs, 1, nf);
-      if (ne > 0 && r < m1) { // slack rows of the same soft task: + (W+eps)^-1 entry (lookups from the LDS hot table)
-        const int slr = (int)(double)sm[D.lds[L_HOT] + r], slc = (int)(double)sm[D.lds[L_HOT] + c];
-        if (slr >= 0 && slc >= 0) {
-          const int s0r = (int)(double)sm[D.lds[L_HOT] + m + 3 * ne + slr], s0c = (int)(double)sm[D.lds[L_HOT] + m + 3 * ne + slc];
-          if (s0r == s0c) acc += sm[D.lds[L_WINV] + (int)(double)sm[D.lds[L_HOT] + m + ne + slr] + (slc - s0c)];
+  // The one GEMM-shaped step of the tick (a12: the J'J small GEMM): lower-triangular 16x16 tiles of
+  // S = M M' on the fp64 matrix core (v_mfma_f64_16x16x4_f64), operands straight from the LDS copy of
+  // M (zero padded to multiples of 16 x 4), accumulators in registers, written once to LDS.
+  {
+    const int nt = (m + 15) / 16, nk = (nf + 3) / 4;
+    QPC_LANE_ARRAY(sacc_, 4 * QPC_NTILE_MAX);
+    QPC_PHASE(lane) {
+      double *acc = QPC_LA(sacc_, lane);
+      for (int e = 0; e < 4 * QPC_NTILE_MAX; e++) acc[e] = 0.0;
+    } QPC_END_PHASE
+    {
+      int tile = 0;
+      QPC_UNROLL_JIT
+      for (int ti = 0; ti < nt; ti++) {
+        QPC_UNROLL_JIT
+        for (int tj = 0; tj <= ti; tj++, tile++) {
+          QPC_UNROLL_JIT
+          for (int ks = 0; ks < nk; ks++) {
+            QPC_MFMA_F64_16x16x4(lane, QPC_LA(sacc_, lane) + 4 * tile,
+                                 ((16 * ti + (lane & 15) < m && 4 * ks + (lane >> 4) < nf)
+                                      ? (double)sm[D.lds[L_M] + (16 * ti + (lane & 15)) * D.nfs + 4 * ks + (lane >> 4)] : 0.0),
+                                 ((16 * tj + (lane & 15) < m && 4 * ks + (lane >> 4) < nf)
+                                      ? (double)sm[D.lds[L_M] + (16 * tj + (lane & 15)) * D.nfs + 4 * ks + (lane >> 4)] : 0.0))
+          }
         }
       }
-      sm[D.lds[L_SM] + r * D.ms + c] = acc;
     }
-  } QPC_END_PHASE
+    QPC_PHASE(lane) {
+      const double *acc = QPC_LA(sacc_, lane);
+      int tile = 0;
+      QPC_UNROLL_JIT
+      for (int ti = 0; ti < nt; ti++) {
+        QPC_UNROLL_JIT
+        for (int tj = 0; tj <= ti; tj++, tile++) {
+          QPC_UNROLL_FULL
+          for (int reg = 0; reg < 4; reg++) {
+            const int r = 16 * ti + (lane >> 4) + 4 * reg, c = 16 * tj + (lane & 15);
+            if (r < m && c <= r) {
+              double v = acc[4 * tile + reg];
+              if (ne > 0 && r < m1) { // slack rows of the same soft task: + (W+eps)^-1 entry (LDS hot table)
+                const int slr = (int)(double)sm[D.lds[L_HOT] + r], slc = (int)(double)sm[D.lds[L_HOT] + c];
+                if (slr >= 0 && slc >= 0) {
+                  const int s0r = (int)(double)sm[D.lds[L_HOT] + m + 3 * ne + slr], s0c = (int)(double)sm[D.lds[L_HOT] + m + 3 * ne + slc];
+                  if (s0r == s0c) v += sm[D.lds[L_WINV] + (int)(double)sm[D.lds[L_HOT] + m + ne + slr] + (slc - s0c)];
+                }
+              }
+              sm[D.lds[L_SM] + r * D.ms + c] = v;
+            }
+          }
+        }
+      }
+    } QPC_END_PHASE
+  }
   QPC_PROF_ACC(PS_SBUILD);
   // left-looking Cholesky of the leading m1 x m1 block (+ the L21 rows), infinite-pivot rule.
   // lane = row; the row's own factor entries stay in registers (constant indices once the k loop
@@ -1307,20 +1285,32 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
     bool any_upper = false;
     S.refactor_rho();
     S.rho_solve(true, 0, 0.0, any_upper);
-    // ---- phase A: primal-dual active-set sweeps (multi-change), fused 4-phase form
+    // ---- phase A: primal-dual active-set sweeps (multi-change)
     for (int pd = 0; pd < D.max_pdas; pd++) {
-      const double gscale = 1.0 + S.last_gmax, tolb = D.tol_bound * (1.0 + S.last_xmax); // U is current
-      bool upper = false;
-      const bool changed = S.pdas_sweep(gscale, tolb, upper);
-      if (!changed) break;
+      const double gscale = 1.0 + S.last_gmax, tolb = D.tol_bound * (1.0 + S.last_xmax); // U is current (rho_solve)
+      double rchg = 0.0, rup = 0.0;
+      QPC_PHASE(lane) {
+        double changed = 0.0, up = 0.0;
+        for (int j = lane; j < nrho; j += 64) {
+          double w = sm[D.lds[L_WS] + j], hi = sm[D.lds[L_HI] + j], x = sm[D.lds[L_XR] + j], nw_ = w;
+          if (!(hi > 0.0)) continue; // disabled
+          if (w != 0.0) { if (sm[D.lds[L_U] + j] < -D.tol_bound * gscale) nw_ = 0.0; }
+          else if (x < -tolb) nw_ = -1.0;
+          else if (x > hi + tolb) nw_ = 1.0;
+          if (nw_ != w) { sm[D.lds[L_WS] + j] = nw_; changed = 1.0; }
+          if (nw_ == 1.0) up = 1.0;
+        }
+        QPC_RED_MAX_PUT(0, rchg, changed);
+        QPC_RED_MAX_PUT(1, rup, up);
+      } QPC_END_PHASE
+      rchg = QPC_RED_MAX_GET(0, rchg);
+      rup = QPC_RED_MAX_GET(1, rup);
+      if (!(rchg > 0.0)) break;
+      any_upper = rup > 0.0;
       iters++;
-      if (upper) { // rare: an upper bound became active -> general path for this sweep
-        any_upper = true;
-        S.refactor_rho();
-        S.rho_solve(true, 0, 0.0, true);
-      }
+      S.refactor_rho();
+      S.rho_solve(true, 0, 0.0, any_upper);
     }
-    S.refactor_rho(); // the sweeps do not form T22: rebuild it once for phase B / the final polish
     // ---- phase B: drops until dual feasible, then Goldfarb-Idnani additions (finite)
     while (true) {
       if (iters > D.max_as_iters) { status = QPC_STATUS_ITERATION_LIMIT; break; }

@@ -69,6 +69,17 @@ struct Lds {
 #define QPC_LANE_INTS(name, n) int name[64][n]
 #define QPC_LI(name, lane) name[lane]
 #define QPC_CTZ64(x) __builtin_ctzll((unsigned long long)(x))
+// lane-serial model of v_mfma_f64_16x16x4_f64 (operand / accumulator lane maps of the guide)
+static thread_local double emu_mfma_a[64], emu_mfma_b[64];
+#define QPC_MFMA_F64_16x16x4(lane, ACC, AEXPR, BEXPR)                                                    \
+  QPC_PHASE(lane) { emu_mfma_a[lane] = (AEXPR); emu_mfma_b[lane] = (BEXPR); } QPC_END_PHASE               \
+  QPC_PHASE(lane) {                                                                                       \
+    double *acc__ = (ACC);                                                                                \
+    for (int r__ = 0; r__ < 4; r__++) {                                                                   \
+      const int row__ = (lane >> 4) + 4 * r__, col__ = lane & 15;                                         \
+      for (int k__ = 0; k__ < 4; k__++) acc__[r__] += emu_mfma_a[row__ + 16 * k__] * emu_mfma_b[col__ + 16 * k__]; \
+    }                                                                                                     \
+  } QPC_END_PHASE
 // reductions across a phase boundary: lane-serial form through the (emulator-only) scratch that
 // follows the kernel's LDS slab
 #define QPC_RED_MAX_PUT(slot, name, val) sm[D.lds_doubles + 128 * (slot) + lane] = (val)
