@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=32768)
     ap.add_argument("--config", type=int, default=3, choices=[2, 3, 5])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-path", action="store_true",
+                    help="also time the host-pointer entry point (PCIe-inclusive; reported in config, never `value`)")
     args = ap.parse_args()
 
     import torch
@@ -170,6 +172,14 @@ def main():
     it = iters.cpu().numpy() % 1000
     n_opt = int((st == 0).sum())
 
+    host_rate = None
+    if args.host_path and world == 1:
+        ctrl.control_batch(wl.q, wl.v, wl.desired, wl.contact_weight, wl.contact_maxnormalforce)
+        th = time.perf_counter()
+        for _ in range(3):
+            ctrl.control_batch(wl.q, wl.v, wl.desired, wl.contact_weight, wl.contact_maxnormalforce)
+        host_rate = 3 * B / (time.perf_counter() - th)
+
     if rank == 0:
         total = B * world * args.steps
         value = total / elapsed
@@ -186,7 +196,8 @@ def main():
                                       else "no contacts (39 vars / 36 eq)"),
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"shard{world} (independent QPs, no collective)",
                        "optimal_fraction": n_opt / B, "mean_active_set_iters": float(it.mean()),
-                       "lds_bytes_per_qp": int(lay.lds_bytes_per_qp)},
+                       "lds_bytes_per_qp": int(lay.lds_bytes_per_qp),
+                       "host_pointer_path_solves_per_s": host_rate},
             "roofline": {"bound": "hbm", "achieved": ach_bytes / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": ach_bytes / HBM_PEAK,
                          "traffic": MEASURED_TRAFFIC_BYTES_PER_SOLVE * B if args.config == 3 else None,

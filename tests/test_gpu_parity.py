@@ -75,3 +75,23 @@ def test_large_batch_properties():
     concl = oko | (ro["status"] == 2)
     assert np.array_equal(oko[concl], ok[idx][concl])
     np.testing.assert_allclose(r1["tau"][idx][oko], ro["tau"][oko], atol=1e-8, rtol=0)
+
+
+@pytest.mark.parametrize("name", ["atlas_config3", "mixed_tasks", "momentum_rate"])
+def test_generic_kernel_without_jit(ora_cases, name, monkeypatch):
+    """The ahead-of-time generic kernel (QPC_DISABLE_JIT=1) is the path taken when hiprtc is not
+    available; it must pass the same parity bar as the JIT-specialised kernel."""
+    monkeypatch.setenv("QPC_DISABLE_JIT", "1")
+    builders = {"atlas_config3": lambda: SC.atlas_config(gpu_factory, 3, 32), "mixed_tasks": lambda: SC.mixed_tasks(gpu_factory),
+                "momentum_rate": lambda: SC.momentum_rate(gpu_factory)}
+    g = builders[name]()
+    assert g.ctrl.L.qpc_debug_jit_active(g.ctrl.h) == 0
+    o = ora_cases[name]
+    rg = g.ctrl.control_batch(g.q, g.v, g.desired, g.cweight, g.cmaxf, g.tw, g.surf)
+    ro = o.ctrl.tick_batch(o.q, o.v, o.desired, o.cweight, o.cmaxf, o.tw, o.surf)
+    parity.compare(g, rg, o, ro)
+
+
+def test_jit_is_active_by_default(gpu_cases):
+    g = gpu_cases["atlas_config3"]
+    assert g.ctrl.L.qpc_debug_jit_active(g.ctrl.h) == 1
