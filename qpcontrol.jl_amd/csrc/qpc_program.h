@@ -96,6 +96,11 @@ enum {
   MS_COUNT = 24
 };
 
+// tree-depth bound of the ahead-of-time generic kernel (the JIT-specialised kernel has no such
+// bound).  NOTE: hipcc -O3 (ROCm 7.2) miscompiles the generic kernel with a bound of 32 (wrong
+// kinematics on gfx950, correct at -O1 and in the emulator); 16 is validated by the GPU tests.
+#define QPC_GENERIC_MAXD 16
+
 struct QpcDims {
   int nb, nq, nv, nf, npin, nsj, ntask, nc, N, nrho, ne, m, m1, nw;
   int floating, fv0; // floating body and its first velocity index (or -1)

@@ -156,6 +156,10 @@ int32_t qpc_finalize(qpc_controller *c, int32_t device_id, qpc_layout *out) {
   HIP_TRY(hipMalloc(&S->d_ticket, sizeof(unsigned long long)));
   // JIT specialisation on this controller's program (QPC_DISABLE_JIT=1 keeps the generic kernel)
   const char *nojit = getenv("QPC_DISABLE_JIT");
+  if (nojit && nojit[0] == '1' && D.maxdepth > QPC_GENERIC_MAXD) {
+    qpc_set_error("QPC_DISABLE_JIT=1 but the tree is deeper than the generic kernel supports");
+    return QPC_ERR_UNSUPPORTED;
+  }
   if (!(nojit && nojit[0] == '1')) {
     std::vector<char> code;
     std::string log;
@@ -170,6 +174,10 @@ int32_t qpc_finalize(qpc_controller *c, int32_t device_id, qpc_layout *out) {
       if (strict && strict[0] == '1') {
         qpc_set_error("JIT specialisation failed: " + log);
         return QPC_ERR_HIP;
+      }
+      if (D.maxdepth > QPC_GENERIC_MAXD) {
+        qpc_set_error("JIT specialisation failed and the tree is deeper than the generic kernel supports: " + log);
+        return QPC_ERR_UNSUPPORTED;
       }
       fprintf(stderr, "[qpc] JIT specialisation unavailable (%s); using the generic gfx950 kernel\n", log.c_str());
     }

@@ -128,7 +128,7 @@ template <class P> QPC_FN void ld6(P sm, int off, int body, double *x) {
 #endif
 // compile-time bound of the tree depth (the JIT defines it as the actual depth)
 #ifndef QPC_MAXD
-#define QPC_MAXD 32
+#define QPC_MAXD QPC_GENERIC_MAXD
 #endif
 // full unroll only when trip counts are compile-time constants (JIT specialisation)
 #ifndef QPC_UNROLL_JIT
