@@ -73,12 +73,12 @@ def load_library(path=None):
     L.qpc_status_string.restype = ctypes.c_char_p
     L.qpc_last_error.restype = ctypes.c_char_p
     L.qpc_version.restype = ctypes.c_char_p
+    L.qpc_qp_solve_batch.argtypes = [i32, i32, i64] + [c_double_p] * 5 + [ctypes.POINTER(Settings), i32, c_double_p,
+                                                                         c_double_p, c_int32_p, c_int32_p]
     if hasattr(L, "qpc_control_batch_device"):
         L.qpc_control_batch_device.argtypes = [vp, i64] + [vp] * 12 + [vp]
         L.qpc_timing_enable.argtypes = [vp, i32]
         L.qpc_timing_read.argtypes = [vp, c_double_p, ctypes.POINTER(i64)]
-        L.qpc_qp_solve_batch.argtypes = [i32, i32, i64] + [c_double_p] * 5 + [ctypes.POINTER(Settings), i32,
-                                                                             c_double_p, c_double_p, c_int32_p, c_int32_p]
     _LIBS[path] = L
     return L
 
@@ -189,3 +189,28 @@ class Controller:
         _check(self.L, rc, "qpc_control_batch")
         return dict(tau=tau, vdot=vd, cwrench=cwr[:, :6 * lay.n_contacts].reshape(B, lay.n_contacts, 6),
                     status=status, iters=iters)
+
+
+def qp_solve_batch(P, q, A, l, u, device_id=0, lib_path=None, **settings):
+    """L0: raw dense QPs  min 1/2 x'Px + q'x  s.t.  l <= A x <= u  (OSQP form) for a batch:
+    P[B,n,n], q[B,n], A[B,m,n], l[B,m], u[B,m] -> dict(x[B,n], y[B,m], status[B], iters[B])."""
+    L = load_library(lib_path)
+    P = np.ascontiguousarray(P, dtype=np.float64)
+    if P.ndim == 2:
+        P, q, A, l, u = P[None], np.asarray(q)[None], np.asarray(A)[None], np.asarray(l)[None], np.asarray(u)[None]
+    B, n = P.shape[0], P.shape[1]
+    q = np.ascontiguousarray(q, dtype=np.float64).reshape(B, n)
+    A = np.ascontiguousarray(A, dtype=np.float64).reshape(B, -1, n)
+    m = A.shape[1]
+    l = np.ascontiguousarray(np.clip(l, -1e20, 1e20), dtype=np.float64).reshape(B, m)
+    u = np.ascontiguousarray(np.clip(u, -1e20, 1e20), dtype=np.float64).reshape(B, m)
+    st = Settings()
+    L.qpc_default_settings(ctypes.byref(st))
+    for k, v in settings.items():
+        setattr(st, k, v)
+    x, y = np.zeros((B, n)), np.zeros((B, max(m, 1)))
+    status, iters = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
+    rc = L.qpc_qp_solve_batch(n, m, B, _dp(P), _dp(q), _dp(A), _dp(l), _dp(u), ctypes.byref(st), int(device_id), _dp(x),
+                              _dp(y), status.ctypes.data_as(c_int32_p), iters.ctypes.data_as(c_int32_p))
+    _check(L, rc, "qpc_qp_solve_batch")
+    return dict(x=x, y=y[:, :m], status=status, iters=iters)

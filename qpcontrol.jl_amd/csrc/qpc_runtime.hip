@@ -22,6 +22,18 @@
 #define QPC_PROF_ACC(i) do { unsigned long long n__ = clock64(); PA[i] += n__ - *PT; *PT = n__; } while (0)
 #endif
 #include "qpc_tick.h"
+#include "qpc_qp_dense.h"
+
+// L0: one lane per dense QP (plumbing path, see qpc_qp_dense.h)
+extern "C" __global__ void __launch_bounds__(64)
+qpc_qp_dense_kernel(int n, int m, long long B, const double *P, const double *q, const double *A, const double *l,
+                    const double *u, qpc_settings st, double *ws, long long ws_stride, double *x, double *y,
+                    int32_t *status, int32_t *iters) {
+  const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  qpc::qp_solve_dense(n, m, P + b * n * n, q + b * n, A + b * m * n, l + b * m, u + b * m, st, ws + b * ws_stride,
+                      x + b * n, y + b * m, status + b, iters ? iters + b : nullptr);
+}
 
 struct QpcBatchArgs {
   long long B;
@@ -283,10 +295,48 @@ int32_t qpc_control_batch(qpc_controller *c, int64_t B, const double *q, const d
 int32_t qpc_qp_solve_batch(int32_t n, int32_t m, int64_t B, const double *P, const double *q, const double *A,
                            const double *l, const double *u, const qpc_settings *settings, int32_t device_id,
                            double *x, double *y, int32_t *status, int32_t *iters) {
-  (void)n; (void)m; (void)B; (void)P; (void)q; (void)A; (void)l; (void)u; (void)settings; (void)device_id;
-  (void)x; (void)y; (void)status; (void)iters;
-  qpc_set_error("qpc_qp_solve_batch (L0 raw dense QPs) is not implemented in this round; use qpc_control_batch");
-  return QPC_ERR_UNSUPPORTED;
+  if (n <= 0 || m < 0 || B < 0 || !P || !q || (m && (!A || !l || !u)) || !x || (m && !y) || !status) {
+    qpc_set_error("qpc_qp_solve_batch: bad arguments"); return QPC_ERR_INVALID_ARGUMENT;
+  }
+  if (B == 0) return QPC_OK;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    qpc_set_error("qpc_qp_solve_batch: no HIP device available (this library has no CPU fallback)");
+    return QPC_ERR_NO_DEVICE;
+  }
+  if (device_id < 0 || device_id >= ndev) { qpc_set_error("qpc_qp_solve_batch: device_id out of range"); return QPC_ERR_NO_DEVICE; }
+  HIP_TRY(hipSetDevice(device_id));
+  qpc_settings st;
+  if (settings) st = *settings; else qpc_default_settings(&st);
+  const long long wsd = qpc::qp_dense_workspace_doubles(n, m);
+  const size_t nP = (size_t)B * n * n, nq = (size_t)B * n, nA = (size_t)B * m * n, nm = (size_t)B * m;
+  const size_t total = (nP + nq + nA + 2 * nm + nq + nm + (size_t)B * wsd) * sizeof(double) + 2 * (size_t)B * sizeof(int32_t) + 64;
+  char *buf = nullptr;
+  if (hipMalloc(&buf, total) != hipSuccess) { qpc_set_error("qpc_qp_solve_batch: out of device memory"); return QPC_ERR_OUT_OF_MEMORY; }
+  double *dP = (double *)buf, *dq = dP + nP, *dA = dq + nq, *dl = dA + nA, *du = dl + nm, *dx = du + nm, *dy = dx + nq,
+         *dws = dy + nm;
+  int32_t *dst = (int32_t *)(dws + (size_t)B * wsd), *dit = dst + B;
+  int rc = QPC_OK;
+  auto chk = [&](hipError_t e, const char *w) { if (e != hipSuccess && rc == QPC_OK) rc = hip_fail(e, w); };
+  chk(hipMemcpy(dP, P, nP * sizeof(double), hipMemcpyHostToDevice), "copy P");
+  chk(hipMemcpy(dq, q, nq * sizeof(double), hipMemcpyHostToDevice), "copy q");
+  if (m) {
+    chk(hipMemcpy(dA, A, nA * sizeof(double), hipMemcpyHostToDevice), "copy A");
+    chk(hipMemcpy(dl, l, nm * sizeof(double), hipMemcpyHostToDevice), "copy l");
+    chk(hipMemcpy(du, u, nm * sizeof(double), hipMemcpyHostToDevice), "copy u");
+  }
+  if (rc == QPC_OK) {
+    hipLaunchKernelGGL(qpc_qp_dense_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, 0, (int)n, (int)m, (long long)B, dP, dq,
+                       dA, dl, du, st, dws, wsd, dx, dy, dst, dit);
+    chk(hipGetLastError(), "launch qpc_qp_dense_kernel");
+    chk(hipDeviceSynchronize(), "qpc_qp_dense_kernel");
+    chk(hipMemcpy(x, dx, nq * sizeof(double), hipMemcpyDeviceToHost), "copy x");
+    if (m) chk(hipMemcpy(y, dy, nm * sizeof(double), hipMemcpyDeviceToHost), "copy y");
+    chk(hipMemcpy(status, dst, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost), "copy status");
+    if (iters) chk(hipMemcpy(iters, dit, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost), "copy iters");
+  }
+  (void)hipFree(buf);
+  return rc;
 }
 
 // diagnostic (QPC_STAMPS builds): device buffer of B*PS_COUNT uint64 section cycle counters

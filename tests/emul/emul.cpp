@@ -92,6 +92,7 @@ static thread_local double emu_mfma_a[64], emu_mfma_b[64];
          int i__ = (int)(double)sm[D.lds_doubles + 128 * (slot) + 64 + l__]; \
          if (v__ < name || (v__ == name && i__ < iname)) { name = v__; iname = i__; } } } while (0)
 #include "../../qpcontrol.jl_amd/csrc/qpc_tick.h"
+#include "../../qpcontrol.jl_amd/csrc/qpc_qp_dense.h"
 
 static long g_races = 0, g_uninit = 0, g_outside = 0;
 static std::string g_first;
@@ -131,6 +132,20 @@ int32_t qpc_control_batch(qpc_controller *c, int64_t B, const double *q, const d
     if (g_first.empty()) g_first = emu.first;
   }
   g_emu = nullptr;
+  return QPC_OK;
+}
+
+// L0 (qpc_qp_dense.h is plain serial code per QP: the emulation is the same function on the host)
+int32_t qpc_qp_solve_batch(int32_t n, int32_t m, int64_t B, const double *P, const double *q, const double *A,
+                           const double *l, const double *u, const qpc_settings *settings, int32_t device_id,
+                           double *x, double *y, int32_t *status, int32_t *iters) {
+  (void)device_id;
+  qpc_settings st;
+  if (settings) st = *settings; else qpc_default_settings(&st);
+  std::vector<double> ws(qpc::qp_dense_workspace_doubles(n, m));
+  for (int64_t b = 0; b < B; b++)
+    qpc::qp_solve_dense(n, m, P + b * n * n, q + b * n, A + b * m * n, l + b * m, u + b * m, st, ws.data(), x + b * n,
+                        y + b * m, status + b, iters ? iters + b : nullptr);
   return QPC_OK;
 }
 

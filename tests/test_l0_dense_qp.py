@@ -1,0 +1,85 @@
+"""L0 (qpc_qp_solve_batch, raw dense QPs in OSQP form -- the MOI-optimizer-level plug) against the
+oracle's OSQP restatement + exact polish: random QPs, and the full reference-layout problems the
+oracle builds for the Acrobot and the Atlas standing controller (143 x 178)."""
+import numpy as np
+import pytest
+
+import emu
+import scenarios as SC
+from oracle import oracle as O
+from qpcontrol_jl_amd import binding
+
+
+def _random_qp(rng, n, m, n_eq):
+    M = rng.normal(size=(n, n))
+    P = M @ M.T * 0.3 + 0.05 * np.eye(n)
+    q = rng.normal(size=n)
+    A = rng.normal(size=(m, n))
+    x0 = rng.normal(size=n)
+    b = A @ x0
+    l, u = b - rng.uniform(0.1, 1.0, size=m), b + rng.uniform(0.1, 1.0, size=m)
+    l[:n_eq] = u[:n_eq] = b[:n_eq]
+    l[n_eq::3] = -1e30  # one-sided rows
+    return P, q, A, l, u
+
+
+def _check(backend_lib, device_id=0):
+    rng = np.random.default_rng(5)
+    probs = [_random_qp(rng, n, m, ne) for n, m, ne in ((5, 7, 2), (12, 20, 4), (30, 45, 10), (8, 0, 0))]
+    for P, q, A, l, u in probs:
+        r = binding.qp_solve_batch(P, q, A, l, u, device_id=device_id, lib_path=backend_lib)
+        assert r["status"][0] == 0
+        if len(l):
+            ro = O.qp_solve(P, q, A, l, u)
+            assert ro["status"] == 0
+            np.testing.assert_allclose(r["x"][0], ro["x"], atol=1e-8)
+            np.testing.assert_allclose(r["y"][0], ro["y"], atol=1e-6)
+        else:
+            np.testing.assert_allclose(r["x"][0], -np.linalg.solve(P, q), atol=1e-9)
+
+
+def _check_reference_layout(backend_lib, device_id=0):
+    def ofactory(mech, N, fl):
+        return O.OracleController(O.OracleModel(mech), N, fl)
+    for case in (SC.acrobot_point_task(ofactory, B=2), SC.atlas_config(ofactory, 3, 3)):
+        oc = case.ctrl
+        Ps, qs, As, ls, us, xs = [], [], [], [], [], []
+        for b in range(case.B):
+            P, q, A, l, u = oc.build_qp(case.q[b], case.v[b], case.desired[b], case.cweight[b], case.cmaxf[b])
+            r = oc.tick(case.q[b], case.v[b], case.desired[b], case.cweight[b], case.cmaxf[b])
+            assert r["status"] == 0
+            Ps.append(P); qs.append(q); As.append(A); ls.append(l); us.append(u); xs.append(r["x"])
+        r = binding.qp_solve_batch(np.array(Ps), np.array(qs), np.array(As), np.array(ls), np.array(us),
+                                   device_id=device_id, lib_path=backend_lib)
+        assert np.all(r["status"] == 0), r["status"]
+        nv = case.mech.nv
+        for b in range(case.B):  # v̇ is unique (regularised); rho of the N = 4 basis is not
+            np.testing.assert_allclose(r["x"][b][:nv], xs[b][:nv], atol=1e-7)
+
+
+def test_l0_emulated_random():
+    emu.build()
+    _check(emu.EMU_LIB)
+
+
+def test_l0_emulated_reference_layout():
+    emu.build()
+    _check_reference_layout(emu.EMU_LIB)
+
+
+def test_l0_infeasible_and_status():
+    emu.build()
+    P, q = np.eye(2), np.zeros(2)
+    A = np.array([[1.0, 0.0], [1.0, 0.0]])
+    r = binding.qp_solve_batch(P, q, A, np.array([1.0, -1e30]), np.array([1e30, 0.0]), lib_path=emu.EMU_LIB)  # x0 >= 1 and x0 <= 0
+    assert r["status"][0] != 0
+
+
+@pytest.mark.gpu
+def test_l0_gpu_random():
+    _check(None)
+
+
+@pytest.mark.gpu
+def test_l0_gpu_reference_layout():
+    _check_reference_layout(None)
