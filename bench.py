@@ -27,9 +27,11 @@ sys.path.insert(0, ROOT)
 ALG_BYTES_PER_SOLVE = 1968  # in 8*(37+36+36+16) + out 8*(36+36+48) + 8
 ALG_FLOPS_PER_SOLVE = 4.6e5  # one reduced-KKT factor+solve + assembly + FK/RNEA
 # HBM traffic per solve measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes
-# (profiles/r01_traffic/): 31.25 MB read + 65.53 MB written per 32768-QP launch.  8-byte-per-lane
-# accesses: the gfx950 "x2 for 16-B wide reads" correction of MI355X_MICROARCH.md does not apply.
-MEASURED_TRAFFIC_BYTES_PER_SOLVE = (31252.3 + 65531.5) * 1024 / 32768
+# (profiles/r01_v14_pmc_*.csv, r01_v14_traffic_summary.json): 29362 KiB read + 57769 KiB written per
+# 32768-QP launch (v14 kernel; writes include L2 evictions of the 288 B/lane scratch spill area).
+# 8-byte-per-lane accesses: the gfx950 "x2 for 16-B wide reads" correction of MI355X_MICROARCH.md
+# does not apply.
+MEASURED_TRAFFIC_BYTES_PER_SOLVE = (29362.0 + 57768.6) * 1024 / 32768
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md (spec; 6.29e12 measured)
 FP64_PEAK = 78.6e12  # FLOP/s vector fp64 (datasheet)
 
@@ -201,7 +203,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": ach_bytes / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": ach_bytes / HBM_PEAK,
                          "traffic": MEASURED_TRAFFIC_BYTES_PER_SOLVE * B if args.config == 3 else None,
-                         "traffic_source": "profiles/r01_traffic (rocprofv3 PMC, v7 kernel), bytes per launch",
+                         "traffic_source": "profiles/r01_v14_traffic_summary.json (rocprofv3 PMC FETCH_SIZE + WRITE_SIZE, separate passes), bytes per launch",
                          "kernel": "qpc_tick_kernel", "kernel_avg_ms": avg_ms.value, "launches": int(nl.value),
                          "algorithmic_bytes_per_solve": ALG_BYTES_PER_SOLVE,
                          "note": "path is fp64-VALU / LDS-latency bound, not HBM bound (SURVEY.md 8d); "
