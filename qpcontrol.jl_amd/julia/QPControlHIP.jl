@@ -11,7 +11,7 @@
 # symbol of include/qpc.h with the argument order shown there.
 module QPControlHIP
 
-export BatchedMomentumBasedController, QPCModel, addtask!, addcontact!, regularize!, finalize!,
+export qp_solve_batch, BatchedMomentumBasedController, QPCModel, addtask!, addcontact!, regularize!, finalize!,
        QPSolveFailure, SpatialAccelerationTask, AngularAccelerationTask, LinearAccelerationTask,
        PointAccelerationTask, JointAccelerationTask, MomentumRateTask, LinearMomentumRateTask
 
@@ -205,6 +205,48 @@ function (c::BatchedMomentumBasedController)(τ::Matrix{Float64}, t::Number, q::
         bad === nothing || throw(QPSolveFailure(bad, c.status[bad]))
     end
     τ
+end
+
+# ---------------------------------------------------------------------------------------------
+# b-1: solver-level plug.  `MomentumBasedController{N}(mechanism, optimizer)` (reference
+# src/lowlevel/momentum.jl:15-16,27) accepts any MOI.AbstractOptimizer; the reference's tests build
+# an OSQP one (test/runtests.jl:35-43).  `qp_solve_batch` is the ccall that an optimizer subtype
+# forwards `MOI.optimize!` to with B = 1: dense OSQP-form data in, (x, y, status) out.  The MOI
+# bookkeeping (copy_to, constraint-coefficient modification with fixed sparsity, VariablePrimal /
+# TerminationStatus getters) is a thin Julia layer on this call; it needs a Julia toolchain to be
+# written against and is not part of this repository's tested surface.
+struct Settings
+    max_active_set_iters::Int32
+    max_refine_iters::Int32
+    eps_primal_reg::Float64
+    eps_dual_reg::Float64
+    tol_residual::Float64
+    tol_bound::Float64
+end
+
+function default_settings()
+    s = Ref(Settings(0, 0, 0.0, 0.0, 0.0, 0.0))
+    ccall((:qpc_default_settings, libqpc), Int32, (Ptr{Settings},), s)
+    s[]
+end
+
+"""
+    qp_solve_batch(P, q, A, l, u; device = 0, settings = default_settings())
+
+`min ½x'Px + q'x  s.t. l ≤ Ax ≤ u` for B problems.  Array layouts: `P[n, n, B]` (symmetric),
+`q[n, B]`, `A[n, m, B]` (i.e. Aᵀ per problem: the ABI is row-major per QP), `l[m, B]`, `u[m, B]`.
+Returns `(x[n, B], y[m, B], status[B], iters[B])`, multipliers in OSQP's sign convention.
+"""
+function qp_solve_batch(P::Array{Float64, 3}, q::Matrix{Float64}, At::Array{Float64, 3}, l::Matrix{Float64},
+                        u::Matrix{Float64}; device::Integer = 0, settings::Settings = default_settings())
+    n, B = size(q); m = size(l, 1)
+    x = zeros(n, B); y = zeros(max(m, 1), B); status = zeros(Int32, B); iters = zeros(Int32, B)
+    rc = ccall((:qpc_qp_solve_batch, libqpc), Int32,
+               (Int32, Int32, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+                Ref{Settings}, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}),
+               n, m, B, P, q, At, l, u, Ref(settings), device, x, y, status, iters)
+    rc == 0 || error(unsafe_string(ccall((:qpc_last_error, libqpc), Cstring, ())))
+    x, y[1:m, :], status, iters
 end
 
 end # module
