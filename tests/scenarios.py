@@ -217,20 +217,28 @@ def atlas_config(factory, config, B):
                 wl.contact_maxnormalforce, floating=wl.floating_body)
 
 
-def all_cases(factory, small=True):
+def all_cases(factory, small=True, only=None):
+    """every scenario (built lazily; `only` = a name or a collection of names restricts the set)"""
     B = 6 if small else 32
-    yield fixed_base_joint_space(factory, True)
-    yield fixed_base_joint_space(factory, False)
-    yield acrobot_config1(factory)
-    yield acrobot_point_task(factory)
-    yield free_fall(factory)
-    yield momentum_rate(factory)
+    makers = [("fixed_base_hard", lambda: fixed_base_joint_space(factory, True)),
+              ("fixed_base_soft", lambda: fixed_base_joint_space(factory, False)),
+              ("acrobot_config1", lambda: acrobot_config1(factory)),
+              ("acrobot_point", lambda: acrobot_point_task(factory)),
+              ("free_fall", lambda: free_fall(factory)),
+              ("momentum_rate", lambda: momentum_rate(factory))]
     for mode in ("constraint", "scalar", "scalar_param", "matrix", "matrix_param"):
-        yield spatial_acceleration(factory, mode)
-    yield mixed_tasks(factory)
-    yield mixed_tasks(factory, floating=False, seed=78)
+        makers.append(("spatial_" + mode, lambda mode=mode: spatial_acceleration(factory, mode)))
+    makers.append(("mixed_tasks", lambda: mixed_tasks(factory)))
+    makers.append(("mixed_tasks_fixed", lambda: mixed_tasks(factory, floating=False, seed=78)))
     for cfg in (2, 3, 5):
-        yield atlas_config(factory, cfg, B)
+        makers.append((f"atlas_config{cfg}", lambda cfg=cfg: atlas_config(factory, cfg, B)))
+    if isinstance(only, str):
+        only = (only,)
+    for name, mk in makers:
+        if only is None or name in only:
+            c = mk()
+            assert c.name == name, (c.name, name)
+            yield c
 
 
 def run_backend(case: Case, tick_fn):
