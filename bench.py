@@ -73,6 +73,9 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=32768)
     ap.add_argument("--config", type=int, default=3, choices=[2, 3, 5])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fused-laws", action="store_true",
+                    help="SURVEY 8 f-1: StandingController PD laws (standing.jl:58-89) evaluated in the kernel, no `desired` "
+                         "input (a pure (q, v) -> tau map); default is the reference boundary with desireds as inputs")
     ap.add_argument("--host-path", action="store_true",
                     help="also time the host-pointer entry point (PCIe-inclusive; reported in config, never `value`)")
     args = ap.parse_args()
@@ -116,7 +119,8 @@ def main():
             return real_finalize(self, local_rank)
         binding.Controller.finalize = fin
         try:
-            ctrl, wl = W.atlas_workload(factory, B, args.config, seed={2: 2024, 3: 2025, 5: 2027}[args.config] + 7919 * rank)
+            ctrl, wl = W.atlas_workload(factory, B, args.config, seed={2: 2024, 3: 2025, 5: 2027}[args.config] + 7919 * rank,
+                                        fused_laws=args.fused_laws)
         finally:
             binding.Controller.finalize = real_finalize
     make()
@@ -126,7 +130,7 @@ def main():
     def dev_t(a):
         return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
 
-    q, v, des = dev_t(wl.q), dev_t(wl.v), dev_t(wl.desired)
+    q, v, des = dev_t(wl.q), dev_t(wl.v), (None if args.fused_laws else dev_t(wl.desired))
     cw, cm = dev_t(wl.contact_weight), dev_t(wl.contact_maxnormalforce)
     tau = torch.empty((B, lay.nv), dtype=torch.float64, device=dev)
     vd = torch.empty((B, lay.nv), dtype=torch.float64, device=dev)
@@ -176,17 +180,22 @@ def main():
 
     host_rate = None
     if args.host_path and world == 1:
-        ctrl.control_batch(wl.q, wl.v, wl.desired, wl.contact_weight, wl.contact_maxnormalforce)
+        hdes = None if args.fused_laws else wl.desired
+        ctrl.control_batch(wl.q, wl.v, hdes, wl.contact_weight, wl.contact_maxnormalforce)
         th = time.perf_counter()
         for _ in range(3):
-            ctrl.control_batch(wl.q, wl.v, wl.desired, wl.contact_weight, wl.contact_maxnormalforce)
+            ctrl.control_batch(wl.q, wl.v, hdes, wl.contact_weight, wl.contact_maxnormalforce)
         host_rate = 3 * B / (time.perf_counter() - th)
 
     if rank == 0:
         total = B * world * args.steps
         value = total / elapsed
         kern_s = avg_ms.value * 1e-3
-        ach_bytes = ALG_BYTES_PER_SOLVE * B / kern_s if kern_s > 0 else 0.0
+        # compulsory bytes at the boundary = inputs + outputs (+ status, iters)
+        nc_ = int(lay.n_contacts)
+        alg_bytes = 8 * (lay.nq + lay.nv + (0 if args.fused_laws else lay.n_desired) + 2 * nc_) + 8 * (2 * lay.nv + 6 * nc_) + 8
+        assert args.config != 3 or args.fused_laws or alg_bytes == ALG_BYTES_PER_SOLVE
+        ach_bytes = alg_bytes * B / kern_s if kern_s > 0 else 0.0
         out = {
             "metric": "QP solves/sec (Atlas ~30-DoF whole-body QP, batched)",
             "value": value, "unit": "QP solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -199,13 +208,14 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"shard{world} (independent QPs, no collective)",
                        "optimal_fraction": n_opt / B, "mean_active_set_iters": float(it.mean()),
                        "lds_bytes_per_qp": int(lay.lds_bytes_per_qp),
+                       "desired": "device PD laws (standing.jl:58-89 fused)" if args.fused_laws else "input record",
                        "host_pointer_path_solves_per_s": host_rate},
             "roofline": {"bound": "hbm", "achieved": ach_bytes / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": ach_bytes / HBM_PEAK,
                          "traffic": MEASURED_TRAFFIC_BYTES_PER_SOLVE * B if args.config == 3 else None,
                          "traffic_source": "profiles/r01_v14_traffic_summary.json (rocprofv3 PMC FETCH_SIZE + WRITE_SIZE, separate passes), bytes per launch",
                          "kernel": "qpc_tick_kernel", "kernel_avg_ms": avg_ms.value, "launches": int(nl.value),
-                         "algorithmic_bytes_per_solve": ALG_BYTES_PER_SOLVE,
+                         "algorithmic_bytes_per_solve": alg_bytes,
                          "note": "path is fp64-VALU / LDS-latency bound, not HBM bound (SURVEY.md 8d); "
                                  "fp64 fraction reported beside it",
                          "fp64": {"achieved_tflops": ALG_FLOPS_PER_SOLVE * B / kern_s / 1e12 if kern_s > 0 else 0.0,

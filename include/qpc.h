@@ -121,6 +121,8 @@ typedef struct qpc_layout {
   /* the reduced QP the kernels actually solve: */
   int32_t n_free, n_pinned, n_slack, n_rho, n_eq_rows;
   int32_t lds_bytes_per_qp;
+  int32_t n_desired_inputs; /* entries of `desired` still read from the caller (tasks without a
+                             * desired law, qpc_task_set_law); 0 => `desired` may be NULL          */
 } qpc_layout;
 
 /* ---- model: mirrors Mechanism{Float64} ------------------------------------------------ */
@@ -151,6 +153,28 @@ void qpc_controller_destroy(qpc_controller *ctrl);
 int32_t qpc_add_task(qpc_controller *ctrl, int32_t kind, int32_t base_body, int32_t target_body,
                      int32_t frame_body, const double *point, int32_t joint_body,
                      int32_t weight_kind, const double *weight, int32_t *out_task_id);
+
+/* Desired-acceleration LAWS evaluated on the device from the state of each QP -- the PD laws of
+ * (controller::StandingController)(tau, t, state), src/highlevel/standing.jl:58-89, which in the
+ * reference run on the CPU and call setdesired! before every tick.  A task with a law ignores
+ * its slice of `desired`; when every task has one, `desired` may be NULL and the tick is a pure
+ * (q, v) -> tau map.  gains = PDGains(kp, kd) (standing.jl:26-28).
+ *   QPC_LAW_INPUT          (default) desired comes from the caller (setdesired!, src/tasks.jl:23..253)
+ *   QPC_LAW_CONSTANT       desired = ref[0..dim)            (e.g. foot tasks: zero, standing.jl:37-38)
+ *   QPC_LAW_JOINT_PD       JOINT task of a 1-DoF joint: kp (ref[0] - q) - kd v      (standing.jl:80-86)
+ *   QPC_LAW_COM_PD         LINEAR_MOMENTUM_RATE task: m (-kp (c - ref[0..3)) - kd h_lin / m), c = centre
+ *                          of mass, h = momentum(state)                              (standing.jl:60-67)
+ *   QPC_LAW_ORIENTATION_PD ANGULAR task with base = world, frame = target body: -kp rotation_vector(R)
+ *                          - kd R' omega  of the target body                          (standing.jl:70-77) */
+enum {
+  QPC_LAW_INPUT = 0,
+  QPC_LAW_CONSTANT = 1,
+  QPC_LAW_JOINT_PD = 2,
+  QPC_LAW_COM_PD = 3,
+  QPC_LAW_ORIENTATION_PD = 4
+};
+int32_t qpc_task_set_law(qpc_controller *ctrl, int32_t task_id, int32_t law, double kp, double kd,
+                         const double *ref, int32_t n_ref);
 
 /* regularize!(c, joint, w): obj += w * |vdot_joint|^2 ; weights add up (momentum.jl:128-131) */
 int32_t qpc_regularize(qpc_controller *ctrl, int32_t joint_body, double weight);

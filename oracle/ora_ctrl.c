@@ -153,6 +153,7 @@ static void fill_layout(const ora_ctrl *c, qpc_layout *L) {
   L->nq = c->m->nq; L->nv = c->m->nv; L->n_tasks = c->nt; L->n_contacts = c->nc; L->n_basis = c->N;
   L->n_desired = c->n_desired; L->n_task_weights = c->n_tw; L->n_surface = c->n_surf;
   L->ref_n_var = c->nvar; L->ref_n_eq = c->neq; L->ref_n_ineq = c->nineq;
+  L->n_desired_inputs = c->n_desired; /* the oracle has no device laws: setdesired! semantics only */
 }
 
 /* J (dim x nv) and bias with task_error = J v̇ + bias - desired */

@@ -97,6 +97,12 @@ void ora_relative_twist(const ora_model *m, const ora_state *s, int body, int ba
 void ora_transform_accel(const ora_model *m, const ora_state *s, const double Aw[6], int body,
                          int base, int frame, double out[6]);
 
+/* PD laws of the StandingController tick (src/highlevel/standing.jl:58-89), ora_standing.c */
+void ora_standing_com_law(const ora_model *m, const ora_state *s, const double *v, double kp, double kd,
+                          const double comref[3], double out[3]);
+void ora_standing_orientation_law(const ora_state *s, int body, double kp, double kd, double out[3]);
+double ora_standing_joint_law(double kp, double kd, double q, double qref, double v);
+
 /* ------------------------------------------------------------------------------------------
  * controller (reference layout QP)
  * ---------------------------------------------------------------------------------------- */

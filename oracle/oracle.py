@@ -23,7 +23,7 @@ class Layout(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "nq", "nv", "n_tasks", "n_contacts", "n_basis", "n_desired", "n_task_weights", "n_surface",
         "ref_n_var", "ref_n_eq", "ref_n_ineq", "n_free", "n_pinned", "n_slack", "n_rho",
-        "n_eq_rows", "lds_bytes_per_qp")]
+        "n_eq_rows", "lds_bytes_per_qp", "n_desired_inputs")]
 
 
 class OsqpSettings(ctypes.Structure):
@@ -122,6 +122,23 @@ class OracleModel:
         c = np.zeros(3)
         self.L.ora_get_com(self.s, _p(c))
         return c
+
+    # PD laws of the StandingController tick (standing.jl:58-89) on the current state
+    def standing_com_law(self, v, kp, kd, comref):
+        out = np.zeros(3)
+        self.L.ora_standing_com_law(self.h, self.s, _p(_arr(v, self.nv)), ctypes.c_double(kp), ctypes.c_double(kd),
+                                    _p(_arr(comref, 3)), _p(out))
+        return out
+
+    def standing_orientation_law(self, body, kp, kd):
+        out = np.zeros(3)
+        self.L.ora_standing_orientation_law(self.s, int(body), ctypes.c_double(kp), ctypes.c_double(kd), _p(out))
+        return out
+
+    def standing_joint_law(self, kp, kd, q, qref, v):
+        f = self.L.ora_standing_joint_law
+        f.restype = ctypes.c_double
+        return f(ctypes.c_double(kp), ctypes.c_double(kd), ctypes.c_double(q), ctypes.c_double(qref), ctypes.c_double(v))
 
     def momentum_matrix(self):
         A, Adv = np.zeros((6, self.nv)), np.zeros(6)

@@ -141,6 +141,13 @@ def isenabled(point: ContactPoint):
     return bool(np.any(np.asarray(point.maxnormalforce) > 0))
 
 
+class PDGains:
+    """RigidBodyDynamics.PDControl.PDGains(k, d) as used by standing.jl:26-28"""
+
+    def __init__(self, k, d):
+        self.k, self.d = float(k), float(d)
+
+
 class Parameter:
     """Marker for a per-state ("Parameter" in Parametron) weight: `value` is (B,) or (B, dim, dim)."""
 
@@ -180,6 +187,13 @@ class MomentumBasedController:
     def regularize(self, joint, weight):
         self._c.regularize(_joint(self.mechanism, joint), weight)
 
+    def setlaw(self, task: AbstractMotionTask, law, gains: PDGains = None, ref=()):
+        """Replace the per-tick `setdesired!(task, pd(...))` of a high-level controller
+        (standing.jl:58-89) by a law the device evaluates from each state (qpc_task_set_law)."""
+        g = gains or PDGains(0.0, 0.0)
+        self._c.set_task_law(task._id, law, g.k, g.d, ref)
+        task.desired = None
+
     def addcontact(self, body, position, normal, mu, parametric=False):
         b = _body(self.mechanism, body)
         cid = self._c.add_contact(b, position, normal, mu, per_qp_surface=int(parametric))
@@ -207,7 +221,10 @@ class MomentumBasedController:
             return np.ascontiguousarray(np.broadcast_to(np.asarray(val, dtype=np.float64).reshape(-1, n) if np.ndim(val) > 1
                                                         else np.asarray(val, dtype=np.float64), (B, n)))
 
-        des = np.concatenate([bc(tk.desired, tk.dim) for tk in self.tasks], axis=1) if self.tasks else None
+        des = None
+        if self.tasks and lay.n_desired_inputs:
+            des = np.concatenate([bc(tk.desired if tk.desired is not None else np.zeros(tk.dim), tk.dim)
+                                  for tk in self.tasks], axis=1)
         cw = np.stack([np.broadcast_to(np.asarray(c.weight, float), (B,)) for c in self.contacts], 1) if self.contacts else None
         cm = np.stack([np.broadcast_to(np.asarray(c.maxnormalforce, float), (B,)) for c in self.contacts], 1) if self.contacts else None
         tw = None
@@ -227,3 +244,54 @@ class MomentumBasedController:
             np.copyto(tau, r["tau"])
             return tau
         return r["tau"]
+
+
+class StandingController:
+    """StandingController(lowlevel, feet, pelvis, nominalstate; ...) -- src/highlevel/standing.jl:1-89.
+
+    Construction registers exactly the reference's task set on `lowlevel` (standing.jl:35-49).  The
+    tick of the reference evaluates three PD laws on the CPU and calls `setdesired!` (standing.jl:
+    58-86) before `lowlevel(tau, t, state)`; here the laws are handed to the device at construction,
+    so the call is a pure (q, v) -> tau map for a batch of states."""
+
+    def __init__(self, lowlevel: MomentumBasedController, feet, pelvis, nominal_q, joint_regularization=0.05,
+                 linear_momentum_weight=1.0, comgains=None, pelvisgains=None, jointgains=None, comref=None,
+                 jointrefs=None):
+        from .models import FIXED, REVOLUTE
+        from .workloads import batch_kinematics
+        mech = lowlevel.mechanism
+        self.lowlevel = lowlevel
+        self.robotmass = mech.total_mass()
+        self.comgains = comgains or PDGains(10.0, 2 * np.sqrt(10.0))      # standing.jl:26
+        self.pelvisgains = pelvisgains or PDGains(20.0, 2 * np.sqrt(20.0))  # standing.jl:27
+        default_joint = PDGains(100.0, 20.0)                              # standing.jl:28
+        nominal_q = np.asarray(nominal_q, dtype=np.float64)
+        if comref is None:  # standing.jl:29
+            comref = batch_kinematics(mech, nominal_q, np.zeros(mech.nv))["com"][0] - np.array([0.0, 0.0, 0.05])
+        self.comref = np.asarray(comref, dtype=np.float64)
+        for j in range(mech.nbodies):  # standing.jl:35
+            if mech.joint_type[j] != FIXED:
+                lowlevel.regularize(j, joint_regularization)
+        feet = [_body(mech, f) for f in feet]
+        self.foottasks = {f: lowlevel.addtask(SpatialAccelerationTask(mech, WORLD, f)) for f in feet}  # :37-38
+        self.linmomtask = lowlevel.addtask(LinearMomentumRateTask(mech), linear_momentum_weight)      # :40-41
+        self.pelvistask = lowlevel.addtask(AngularAccelerationTask(mech, WORLD, _body(mech, pelvis)))  # :43-44
+        on_foot_path = set()
+        for f in feet:
+            on_foot_path.update(mech.path_joints(WORLD, f))
+        self.jointtasks, self.jointrefs, self.jointgains = {}, {}, {}
+        for j in range(mech.nbodies):  # standing.jl:46-49
+            if mech.joint_type[j] == REVOLUTE and j not in on_foot_path:
+                self.jointtasks[j] = lowlevel.addtask(JointAccelerationTask(mech, j))
+                self.jointrefs[j] = float(nominal_q[mech.configuration_range(j)[0]]) if jointrefs is None else jointrefs[j]
+                self.jointgains[j] = default_joint if jointgains is None else jointgains[j]
+        # the laws of standing.jl:58-86, evaluated per state on the device
+        for t in self.foottasks.values():
+            lowlevel.setlaw(t, binding.LAW_CONSTANT, ref=np.zeros(6))
+        lowlevel.setlaw(self.linmomtask, binding.LAW_COM_PD, self.comgains, self.comref)
+        lowlevel.setlaw(self.pelvistask, binding.LAW_ORIENTATION_PD, self.pelvisgains)
+        for j, t in self.jointtasks.items():
+            lowlevel.setlaw(t, binding.LAW_JOINT_PD, self.jointgains[j], [self.jointrefs[j]])
+
+    def __call__(self, tau, t, x, **kw):
+        return self.lowlevel(tau, t, x, **kw)

@@ -20,6 +20,7 @@ DEFAULT_LIB = os.path.join(_HERE, "libqpcontrol_hip.so")
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_int32_p = ctypes.POINTER(ctypes.c_int32)
 
+LAW_INPUT, LAW_CONSTANT, LAW_JOINT_PD, LAW_COM_PD, LAW_ORIENTATION_PD = range(5)
 STATUS_NAMES = ["OPTIMAL", "ALMOST_OPTIMAL", "INFEASIBLE", "DUAL_INFEASIBLE", "ITERATION_LIMIT", "NUMERICAL_ERROR"]
 
 
@@ -27,7 +28,7 @@ class Layout(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "nq", "nv", "n_tasks", "n_contacts", "n_basis", "n_desired", "n_task_weights", "n_surface",
         "ref_n_var", "ref_n_eq", "ref_n_ineq", "n_free", "n_pinned", "n_slack", "n_rho",
-        "n_eq_rows", "lds_bytes_per_qp")]
+        "n_eq_rows", "lds_bytes_per_qp", "n_desired_inputs")]
 
 
 class Settings(ctypes.Structure):
@@ -63,6 +64,7 @@ def load_library(path=None):
     L.qpc_controller_destroy.restype = None
     L.qpc_add_task.argtypes = [vp, i32, i32, i32, i32, c_double_p, i32, i32, c_double_p, c_int32_p]
     L.qpc_regularize.argtypes = [vp, i32, dbl]
+    L.qpc_task_set_law.argtypes = [vp, i32, i32, dbl, dbl, c_double_p, i32]
     L.qpc_add_contact.argtypes = [vp, i32, c_double_p, c_double_p, dbl, i32, c_int32_p]
     L.qpc_finalize.argtypes = [vp, i32, ctypes.POINTER(Layout)]
     L.qpc_get_layout.argtypes = [vp, ctypes.POINTER(Layout)]
@@ -136,6 +138,12 @@ class Controller:
                                            ctypes.byref(tid)), "qpc_add_task")
         return tid.value
 
+    def set_task_law(self, task_id, law, kp=0.0, kd=0.0, ref=()):
+        """desired law evaluated on the device (qpc_task_set_law; standing.jl:58-89)"""
+        r = np.ascontiguousarray(np.asarray(ref, dtype=np.float64).reshape(-1))
+        _check(self.L, self.L.qpc_task_set_law(self.h, int(task_id), int(law), float(kp), float(kd),
+                                               _dp(r) if r.size else None, int(r.size)), "qpc_task_set_law")
+
     def regularize(self, joint, w):
         _check(self.L, self.L.qpc_regularize(self.h, int(joint), float(w)), "qpc_regularize")
 
@@ -178,7 +186,8 @@ class Controller:
             return a
 
         v = arr(v, lay.nv)
-        des, cw, cm = arr(desired, lay.n_desired), arr(contact_weight, lay.n_contacts), arr(contact_maxnormalforce, lay.n_contacts)
+        des = None if (desired is None and lay.n_desired_inputs == 0) else arr(desired, lay.n_desired)
+        cw, cm = arr(contact_weight, lay.n_contacts), arr(contact_maxnormalforce, lay.n_contacts)
         tw, sf = arr(task_weights, lay.n_task_weights), arr(surfaces, lay.n_surface)
         tau, vd = np.zeros((B, lay.nv)), np.zeros((B, lay.nv))
         cwr = np.zeros((B, max(lay.n_contacts, 1) * 6))

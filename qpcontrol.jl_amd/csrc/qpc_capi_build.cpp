@@ -124,6 +124,42 @@ int32_t qpc_add_task(qpc_controller *c, int32_t kind, int32_t base_body, int32_t
   return QPC_OK;
 }
 
+int32_t qpc_task_set_law(qpc_controller *c, int32_t task_id, int32_t law, double kp, double kd, const double *ref,
+                         int32_t n_ref) {
+  if (!c || task_id < 0 || task_id >= (int)c->tasks.size() || n_ref < 0 || (n_ref && !ref)) {
+    qpc_set_error("qpc_task_set_law: bad task id / reference"); return QPC_ERR_INVALID_ARGUMENT;
+  }
+  if (c->finalized) { qpc_set_error("desired laws must be set before the first tick"); return QPC_ERR_ALREADY_FINALIZED; }
+  QpcTask &t = c->tasks[task_id];
+  const qpc_model *m = c->model;
+  int need = 0;
+  switch (law) {
+    case QPC_LAW_INPUT: break;
+    case QPC_LAW_CONSTANT: need = t.dim; break;
+    case QPC_LAW_JOINT_PD:
+      if (t.kind != QPC_TASK_JOINT_ACCELERATION || m->nvj[t.joint] != 1 || m->nqj[t.joint] != 1) {
+        qpc_set_error("QPC_LAW_JOINT_PD needs a JointAccelerationTask of a 1-DoF joint"); return QPC_ERR_INVALID_ARGUMENT;
+      }
+      need = 1; break;
+    case QPC_LAW_COM_PD:
+      if (t.kind != QPC_TASK_LINEAR_MOMENTUM_RATE) {
+        qpc_set_error("QPC_LAW_COM_PD needs a LinearMomentumRateTask"); return QPC_ERR_INVALID_ARGUMENT;
+      }
+      need = 3; break;
+    case QPC_LAW_ORIENTATION_PD:
+      if (t.kind != QPC_TASK_ANGULAR_ACCELERATION || t.base != QPC_WORLD || t.target < 0 || t.frame != t.target) {
+        qpc_set_error("QPC_LAW_ORIENTATION_PD needs an AngularAccelerationTask world -> body expressed in the body frame");
+        return QPC_ERR_INVALID_ARGUMENT;
+      }
+      break;
+    default: qpc_set_error("qpc_task_set_law: unknown law"); return QPC_ERR_INVALID_ARGUMENT;
+  }
+  if (n_ref != need) { qpc_set_error("qpc_task_set_law: wrong reference length for this law"); return QPC_ERR_INVALID_ARGUMENT; }
+  t.law = law; t.kp = kp; t.kd = kd;
+  t.ref.assign(ref, ref + n_ref);
+  return QPC_OK;
+}
+
 int32_t qpc_regularize(qpc_controller *c, int32_t joint, double w) {
   if (!c || joint < 0 || joint >= c->model->nb) return QPC_ERR_INVALID_ARGUMENT;
   if (c->finalized) { qpc_set_error("regularize! must be called before the first tick"); return QPC_ERR_ALREADY_FINALIZED; }

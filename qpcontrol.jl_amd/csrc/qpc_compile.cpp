@@ -55,6 +55,7 @@ int qpc_compile_program(qpc_controller *c) {
     return QPC_ERR_INVALID_ARGUMENT;
   }
   D.nw = c->floating >= 0 ? 6 : 0;
+  std::vector<double> law_tab;
   // ---- pass 1: pins (hard JointAccelerationTask on not-yet-pinned velocity indices)
   std::vector<int> pin_des(nv, -1);
   std::vector<char> task_is_pin(c->tasks.size(), 0);
@@ -217,8 +218,10 @@ int qpc_compile_program(qpc_controller *c) {
     {
       std::vector<int> crb(mask);
       D.crb_full_body = -1;
+      bool com_law = false;
+      for (auto &t : c->tasks) com_law = com_law || t.law == QPC_LAW_COM_PD;
       for (int i = 0; i < nb; i++) {
-        bool has_free = false;
+        bool has_free = com_law; // a COM law needs the whole momentum matrix (h = A v), pinned columns included
         for (int k = 0; k < m->nvj[i]; k++) has_free = has_free || free_of[m->voff[i] + k] >= 0;
         unsigned long long mk = ((unsigned long long)(unsigned)mask[2 * i + 1] << 32) | (unsigned)mask[2 * i];
         const unsigned long long all = nb >= 64 ? ~0ull : ((1ull << nb) - 1);
@@ -266,6 +269,27 @@ int qpc_compile_program(qpc_controller *c) {
     B.ibegin(IT_R_DES); B.it.insert(B.it.end(), rdes.begin(), rdes.end());
     B.ibegin(IT_R_T); B.it.insert(B.it.end(), rt.begin(), rt.end());
     B.ibegin(IT_R_PINK); B.it.insert(B.it.end(), rpink.begin(), rpink.end());
+  }
+  // ---- desired laws (qpc_task_set_law; standing.jl:58-89 evaluated on the device)
+  {
+    std::vector<int> law_i(3 * (size_t)c->n_desired, 0);
+    std::vector<double> law_d(3 * (size_t)c->n_desired, 0.0);
+    D.n_des_inputs = 0; D.n_des_late = 0;
+    for (auto &t : c->tasks)
+      for (int a = 0; a < t.dim; a++) {
+        const int i = t.des_off + a;
+        law_i[3 * i] = t.law; law_d[3 * i] = t.kp; law_d[3 * i + 1] = t.kd;
+        switch (t.law) {
+          case QPC_LAW_INPUT: D.n_des_inputs++; break;
+          case QPC_LAW_CONSTANT: law_d[3 * i + 2] = t.ref[a]; break;
+          case QPC_LAW_JOINT_PD: law_i[3 * i + 1] = m->qoff[t.joint]; law_i[3 * i + 2] = m->voff[t.joint]; law_d[3 * i + 2] = t.ref[0]; break;
+          case QPC_LAW_COM_PD: law_i[3 * i + 1] = a; law_d[3 * i + 2] = t.ref[a]; D.n_des_late++; break;
+          case QPC_LAW_ORIENTATION_PD: law_i[3 * i + 1] = t.target; law_i[3 * i + 2] = a; D.n_des_late++; break;
+        }
+      }
+    B.ibegin(IT_LAW); B.it.insert(B.it.end(), law_i.begin(), law_i.end());
+    B.it.push_back(0);
+    law_tab.swap(law_d);
   }
   B.ibegin(IT_HOT);
   {
@@ -315,6 +339,8 @@ int qpc_compile_program(qpc_controller *c) {
   B.dbegin(DT_C_POS); for (auto &k : c->contacts) for (int a = 0; a < 3; a++) B.dt.push_back(k.pos[a]);
   B.dbegin(DT_C_NORMAL); for (auto &k : c->contacts) for (int a = 0; a < 3; a++) B.dt.push_back(k.normal[a]);
   B.dbegin(DT_C_MU); for (auto &k : c->contacts) B.dt.push_back(k.mu);
+  B.dt.push_back(0.0);
+  B.dbegin(DT_LAW); B.dt.insert(B.dt.end(), law_tab.begin(), law_tab.end());
   B.dt.push_back(0.0);
 
   // ---- LDS layout with lifetime overlays (regions that are never live together share bytes):
@@ -386,6 +412,7 @@ int qpc_compile_program(qpc_controller *c) {
   Lo.ref_n_var = nvar; Lo.ref_n_eq = neq; Lo.ref_n_ineq = D.nc * 2 * N;
   Lo.n_free = D.nf; Lo.n_pinned = D.npin; Lo.n_slack = ne; Lo.n_rho = nrho; Lo.n_eq_rows = mm;
   Lo.lds_bytes_per_qp = D.lds_doubles * 8;
+  Lo.n_desired_inputs = D.n_des_inputs;
   if (nb > 64 || nv > 64 || D.ntask > 63 || D.maxdepth > 32) {
     qpc_set_error("limits of the one-wave-per-QP kernels exceeded (bodies <= 64, velocities <= 64, tree depth <= 32)");
     return QPC_ERR_UNSUPPORTED;

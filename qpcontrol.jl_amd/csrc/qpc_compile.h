@@ -20,6 +20,9 @@ struct QpcTask {
   int kind, base, target, frame, joint, wkind, dim, des_off, tw_off;
   double point[3];
   std::vector<double> W;
+  int law = 0; // QPC_LAW_*
+  double kp = 0, kd = 0;
+  std::vector<double> ref;
 };
 struct QpcContact {
   int body, per_qp, surf_off;

@@ -8,6 +8,7 @@
 #define QPC_SINCOS(x, s, c) sincos((x), &(s), &(c))
 #define QPC_SQRT(x) sqrt((double)(x))
 #define QPC_FABS(x) fabs((double)(x))
+#define QPC_ATAN2(y, x) atan2((double)(y), (double)(x))
 #define QPC_UNROLL_FULL _Pragma("unroll")
 // lane-private storage that persists across phases (registers on the device)
 #define QPC_LANE_ARRAY(name, n) double name[n]

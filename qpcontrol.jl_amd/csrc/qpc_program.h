@@ -34,6 +34,8 @@ enum {
   IT_MCODE,     // [m * nf] packed assembly code of constraint-matrix entry (row r, free column f)
   IT_RCODE,     // [m] packed row code ; IT_R_DES [m] desired index ; IT_R_T [m] generic task ; IT_R_PINK [m]
   IT_R_DES, IT_R_T, IT_R_PINK,
+  IT_LAW, // [n_desired * 3] desired law of entry i: kind (QPC_LAW_*), arg0, arg1
+          //   JOINT_PD: q index, v index;  COM_PD: component, -;  ORIENTATION_PD: body, component
   IT_HOT, // solver lookups staged into LDS per QP: row_slack[m], slack_row[ne], slack_woff[ne], slack_dim[ne], slack_s0[ne]
   IT_COUNT
 };
@@ -44,6 +46,7 @@ enum {
   DT_SJ_W,   // static weight of folded soft joint tasks
   DT_T_POINT, DT_T_W, // per generic task: point[3]; static W (dim*dim, row-major, at IT_T_WOFF)
   DT_C_POS, DT_C_NORMAL, DT_C_MU,
+  DT_LAW, // [n_desired * 3] kp, kd, ref of the desired law of entry i
   DT_COUNT
 };
 
@@ -105,6 +108,7 @@ struct QpcDims {
   int nb, nq, nv, nf, npin, nsj, ntask, nc, N, nrho, ne, m, m1, nw;
   int floating, fv0; // floating body and its first velocity index (or -1)
   int n_desired, n_tw, n_surf, maxdepth;
+  int n_des_inputs, n_des_late; // desired entries read from the caller / computed after the kinematics (COM, orientation laws)
   int maxd; // row length of IT_ANC_TAB
   int crb_full_body; // body whose subtree is the whole mechanism and owns free columns (its composite inertia = total), or -1
   int nfs, ms, m1s;  // padded leading dimensions (odd) of L_M, L_SM, L_X

@@ -225,7 +225,7 @@ int32_t qpc_control_batch_device(qpc_controller *c, int64_t B, const double *q, 
                                  int32_t *iters, void *hip_stream) {
   if (!c || !c->finalized || !c->dev) { qpc_set_error("controller not finalized"); return QPC_ERR_NOT_FINALIZED; }
   const QpcDims &D = c->prog.dims;
-  if (B < 0 || !q || !v || !tau || !vdot || !status || (D.n_desired && !desired) || (D.nc && (!cw || !cmax)) ||
+  if (B < 0 || !q || !v || !tau || !vdot || !status || (D.n_des_inputs && !desired) || (D.nc && (!cw || !cmax)) ||
       (D.n_tw && !tw) || (D.n_surf && !surf)) {
     qpc_set_error("qpc_control_batch_device: missing array"); return QPC_ERR_INVALID_ARGUMENT;
   }
@@ -243,14 +243,14 @@ int32_t qpc_control_batch(qpc_controller *c, int64_t B, const double *q, const d
   if (!c || !c->finalized || !c->dev) { qpc_set_error("controller not finalized"); return QPC_ERR_NOT_FINALIZED; }
   const QpcDims &D = c->prog.dims;
   QpcDeviceState *S = c->dev;
-  if (B < 0 || !q || !v || !tau || !vdot || !status || (D.n_desired && !desired) || (D.nc && (!cw || !cmax)) ||
+  if (B < 0 || !q || !v || !tau || !vdot || !status || (D.n_des_inputs && !desired) || (D.nc && (!cw || !cmax)) ||
       (D.n_tw && !tw) || (D.n_surf && !surf)) {
     qpc_set_error("qpc_control_batch: missing array"); return QPC_ERR_INVALID_ARGUMENT;
   }
   if (B == 0) return QPC_OK;
   HIP_TRY(hipSetDevice(S->device));
   // one staging slab: [q v desired cw cmax tw surf | tau vdot cwrench | status iters]
-  size_t nin[7] = {(size_t)D.nq, (size_t)D.nv, (size_t)D.n_desired, (size_t)D.nc, (size_t)D.nc, (size_t)D.n_tw, (size_t)D.n_surf};
+  size_t nin[7] = {(size_t)D.nq, (size_t)D.nv, desired ? (size_t)D.n_desired : 0, (size_t)D.nc, (size_t)D.nc, (size_t)D.n_tw, (size_t)D.n_surf};
   const double *hin[7] = {q, v, desired, cw, cmax, tw, surf};
   size_t nout[3] = {(size_t)D.nv, (size_t)D.nv, (size_t)6 * D.nc};
   double *hout[3] = {tau, vdot, cwrench};

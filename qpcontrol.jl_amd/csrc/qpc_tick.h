@@ -698,6 +698,40 @@ template <class P> struct Solver {
   }
 };
 
+// desired entry i from the caller (setdesired!) or from a law that only needs (q, v):
+// constant, joint-space PD kp (ref - q) - kd v (standing.jl:80-86).  COM / orientation laws need
+// the kinematics and are filled in later (desired_late); until then the entry is 0.
+QPC_FN double desired_early(const QpcDims &D, const int *IT, const double *DT, const TickIO &io, int i) {
+  if (D.n_des_inputs == D.n_desired) return io.desired[i];
+  const int *li = IT + D.it[IT_LAW] + 3 * i;
+  const double *ld_ = DT + D.dt[DT_LAW] + 3 * i;
+  const int kind = li[0];
+  if (kind == QPC_LAW_INPUT) return io.desired[i];
+  if (kind == QPC_LAW_CONSTANT) return ld_[2];
+  if (kind == QPC_LAW_JOINT_PD) return ld_[0] * (ld_[2] - io.q[li[1]]) - ld_[1] * io.v[li[2]];
+  return 0.0;
+}
+
+// rotation_vector(R) (angle * axis), the error term of the orientation PD law (standing.jl:74-76).
+// Branch on the angle like a robust log map: sin-based formula away from pi, diagonal-based near pi.
+QPC_FN void rotation_vector(const double *R, double *rv) {
+  const double ax = R[7] - R[5], ay = R[2] - R[6], az = R[3] - R[1]; // 2 sin(th) * axis
+  const double s2 = QPC_SQRT(ax * ax + ay * ay + az * az);          // 2 sin(th)
+  const double c2 = R[0] + R[4] + R[8] - 1.0;                      // 2 cos(th)
+  const double th = QPC_ATAN2(s2, c2);
+  if (s2 < 1e-12 && c2 > 0.0) { rv[0] = 0.5 * ax; rv[1] = 0.5 * ay; rv[2] = 0.5 * az; return; } // th -> 0
+  if (s2 > 1e-6) { const double k = th / s2; rv[0] = k * ax; rv[1] = k * ay; rv[2] = k * az; return; }
+  // th near pi: axis from the diagonal, signs from the off-diagonal sums
+  const double cth = 0.5 * c2;
+  double x = QPC_SQRT((R[0] - cth) / (1.0 - cth) > 0.0 ? (R[0] - cth) / (1.0 - cth) : 0.0);
+  double y = QPC_SQRT((R[4] - cth) / (1.0 - cth) > 0.0 ? (R[4] - cth) / (1.0 - cth) : 0.0);
+  double z = QPC_SQRT((R[8] - cth) / (1.0 - cth) > 0.0 ? (R[8] - cth) / (1.0 - cth) : 0.0);
+  if (x >= y && x >= z) { if (R[1] + R[3] < 0.0) y = -y; if (R[2] + R[6] < 0.0) z = -z; if (ax < 0.0) { x = -x; y = -y; z = -z; } }
+  else if (y >= z) { if (R[1] + R[3] < 0.0) x = -x; if (R[5] + R[7] < 0.0) z = -z; if (ay < 0.0) { x = -x; y = -y; z = -z; } }
+  else { if (R[2] + R[6] < 0.0) x = -x; if (R[5] + R[7] < 0.0) y = -y; if (az < 0.0) { x = -x; y = -y; z = -z; } }
+  rv[0] = th * x; rv[1] = th * y; rv[2] = th * z;
+}
+
 // ------------------------------------------------------------------------------------------
 // the tick
 // ------------------------------------------------------------------------------------------
@@ -744,9 +778,9 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
     for (int i = lane; i < nv; i += 64) {
       sm[D.lds[L_V] + i] = io.v[i];
       const int pd = IT[D.it[IT_PDES_K] + i]; // pinned accelerations (hard JointAccelerationTask)
-      sm[D.lds[L_VD] + i] = pd >= 0 ? io.desired[pd] : 0.0;
+      sm[D.lds[L_VD] + i] = pd >= 0 ? desired_early(D, IT, DT, io, pd) : 0.0;
     }
-    for (int i = lane; i < D.n_desired; i += 64) sm[D.lds[L_DES] + i] = io.desired[i];
+    for (int i = lane; i < D.n_desired; i += 64) sm[D.lds[L_DES] + i] = desired_early(D, IT, DT, io, i);
     for (int i = lane; i < nc; i += 64) { sm[D.lds[L_CW] + i] = io.cw[i]; sm[D.lds[L_CMAX] + i] = io.cmax[i]; }
     for (int i = lane; i < D.n_tw; i += 64) sm[D.lds[L_TW] + i] = io.tw[i];
     for (int i = lane; i < D.n_surf; i += 64) sm[D.lds[L_SURF] + i] = io.surf[i];
@@ -978,6 +1012,26 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
         double w = (sm[D.lds[L_CMAX] + c] > 0.0) ? 2.0 * QPC_FABS(sm[D.lds[L_CW] + c]) : 0.0;
         h = w > h ? w : h;
       }
+    if (D.n_des_late) { // desired laws that need the kinematics (standing.jl:60-77), lane = desired entry
+      for (int i = lane; i < D.n_desired; i += 64) {
+        const int *li = IT + D.it[IT_LAW] + 3 * i;
+        const double *lw = DT + D.dt[DT_LAW] + 3 * i;
+        if (li[0] == QPC_LAW_COM_PD) { // m c̈,  c̈ = -kp (c - c_ref) - kd h_lin / m
+          const int a = li[1];
+          const double hl = dotp(sm + D.lds[L_AMOM] + (3 + a) * nv, 1, sm + D.lds[L_V], 1, nv); // linear momentum
+          const double mt = DT[D.dt[DT_GRAV] + 3];
+          sm[D.lds[L_DES] + i] = mt * (-lw[0] * (sm[MISC + MS_COM + a] - lw[2])) - lw[1] * hl;
+        } else if (li[0] == QPC_LAW_ORIENTATION_PD) { // -kp rotation_vector(R) - kd R' omega (body frame)
+          const int body = li[1], a = li[2];
+          double H[12], rv[3];
+          ldH(sm, D, body, H);
+          rotation_vector(H, rv);
+          double wb = 0.0;
+          for (int r = 0; r < 3; r++) wb += H[3 * r + a] * sm[D.lds[L_T] + 6 * body + r];
+          sm[D.lds[L_DES] + i] = -lw[0] * rv[a] - lw[1] * wb;
+        }
+      }
+    }
     QPC_RED_MAX_PUT(0, hscale, h);
   } QPC_END_PHASE
   hscale = QPC_RED_MAX_GET(0, hscale);

@@ -103,7 +103,7 @@ struct Layout
     nq::Int32; nv::Int32; n_tasks::Int32; n_contacts::Int32; n_basis::Int32; n_desired::Int32
     n_task_weights::Int32; n_surface::Int32; ref_n_var::Int32; ref_n_eq::Int32; ref_n_ineq::Int32
     n_free::Int32; n_pinned::Int32; n_slack::Int32; n_rho::Int32; n_eq_rows::Int32
-    lds_bytes_per_qp::Int32
+    lds_bytes_per_qp::Int32; n_desired_inputs::Int32
 end
 
 mutable struct BatchedMomentumBasedController{N}

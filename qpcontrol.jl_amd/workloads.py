@@ -129,9 +129,11 @@ class StandingSetup:
 
 
 def standing_setup(ctrl, mech: M.Mechanism, nominal_q, contacts=True, joint_regularization=0.05,
-                   linear_momentum_weight=1.0, feet=("l_foot", "r_foot"), pelvis="pelvis"):
+                   linear_momentum_weight=1.0, feet=("l_foot", "r_foot"), pelvis="pelvis", fused_laws=False):
     """Register the standing task set on `ctrl` in the reference's order: contacts first
-    (notebook cell 5), then regularize!, foot tasks, linear momentum (soft), pelvis, joints."""
+    (notebook cell 5), then regularize!, foot tasks, linear momentum (soft), pelvis, joints.
+    fused_laws: hand the PD laws of standing.jl:58-89 to the controller (`set_task_law`) so that
+    the device evaluates them per QP and no `desired` record is needed."""
     feet_idx = [mech.findbody(f) for f in feet]
     st = StandingSetup(mech, feet_idx, mech.findbody(pelvis))
     if contacts:
@@ -167,6 +169,14 @@ def standing_setup(ctrl, mech: M.Mechanism, nominal_q, contacts=True, joint_regu
     for j in range(mech.nbodies):
         if mech.joint_type[j] == M.REVOLUTE:
             st.jointrefs[j] = float(nominal_q[mech.configuration_range(j)[0]])
+    if fused_laws:
+        LAW_CONSTANT, LAW_JOINT_PD, LAW_COM_PD, LAW_ORIENTATION_PD = 1, 2, 3, 4  # include/qpc.h QPC_LAW_*
+        for tid in st.foot_tasks:
+            ctrl.set_task_law(tid, LAW_CONSTANT, ref=np.zeros(6))
+        ctrl.set_task_law(st.linmom_task, LAW_COM_PD, st.comgains[0], st.comgains[1], st.comref)
+        ctrl.set_task_law(st.pelvis_task, LAW_ORIENTATION_PD, st.pelvisgains[0], st.pelvisgains[1])
+        for j, tid in st.joint_tasks.items():
+            ctrl.set_task_law(tid, LAW_JOINT_PD, st.jointgains[0], st.jointgains[1], [st.jointrefs[j]])
     return st
 
 
@@ -228,7 +238,7 @@ class Workload:
     n_basis: int = 4
 
 
-def atlas_workload(ctrl_factory, B, config=3, seed=None):
+def atlas_workload(ctrl_factory, B, config=3, seed=None, fused_laws=False):
     """BASELINE.json configs 2-5 on the synthetic Atlas.  `ctrl_factory(mech, n_basis, floating_body)`
     returns a controller object (product binding or oracle) which is populated and finalized."""
     mech = M.atlas()
@@ -237,7 +247,7 @@ def atlas_workload(ctrl_factory, B, config=3, seed=None):
     floating = mech.findbody("pelvis") if contacts else M.WORLD
     ctrl = ctrl_factory(mech, 4, floating)
     q0 = M.atlas_nominal_configuration(mech)
-    st = standing_setup(ctrl, mech, q0, contacts=contacts)
+    st = standing_setup(ctrl, mech, q0, contacts=contacts, fused_laws=fused_laws)
     ctrl.finalize()
     q, v = standing_states(mech, B, seed)
     des = standing_desired(st, q, v)

@@ -100,3 +100,28 @@ class _Null:
 
     def regularize(self, *a, **k):
         pass
+
+
+def test_standing_controller_mirror_matches_oracle():
+    """api.StandingController == the reference's highlevel/standing.jl object: same constructor
+    arguments, tick = (tau, t, state) -> tau with the PD laws evaluated on the device."""
+    emu.build()
+    mech = M.atlas()
+    low = api.MomentumBasedController(mech, n_basis=4, floatingjoint="pelvis_to_world", lib_path=emu.EMU_LIB)
+    for cp in mech.contact_points:  # notebook cell 5
+        pt = low.addcontact(cp.body, cp.position, cp.normal, cp.mu)
+        pt.maxnormalforce, pt.weight = 1e6, 1e-3
+    ctrl = api.StandingController(low, ["l_foot", "r_foot"], "pelvis", M.atlas_nominal_configuration(mech))
+    B = 4
+    q, v = W.standing_states(mech, B, 12)
+    tau = ctrl(np.zeros((B, mech.nv)), 0.0, (q, v))
+    assert low.layout.n_desired_inputs == 0
+
+    def ofactory(mech_, N, fl):
+        return O.OracleController(O.OracleModel(mech_), N, fl)
+    oc, _ = W.atlas_workload(ofactory, 1, 3)
+    st = W.standing_setup(_Null(), mech, M.atlas_nominal_configuration(mech))
+    ro = oc.tick_batch(q, v, W.standing_desired(st, q, v), np.full((B, 8), 1e-3), np.full((B, 8), 1e6))
+    ok = ro["status"] == 0
+    assert ok.any()
+    np.testing.assert_allclose(tau[ok], ro["tau"][ok], atol=1e-8, rtol=0)
