@@ -44,7 +44,7 @@ struct QpcBatchArgs {
   unsigned long long *ticket; // dynamic work distribution: next QP index (zeroed before each launch)
 };
 
-extern "C" __global__ void __launch_bounds__(64, 2)
+extern "C" __global__ void __launch_bounds__(64, 1)
 qpc_tick_kernel(const QpcDims D, const int *__restrict__ IT, const double *__restrict__ DT, const QpcBatchArgs A) {
   extern __shared__ __attribute__((aligned(16))) double qpc_lds[];
   // active-set iteration counts differ per QP (p99 ~ 3x mean): QPs are handed out through one
