@@ -391,6 +391,50 @@ template <class P> struct Solver {
     QPC_PROF_ACC(PS_REFAC);
   }
 
+  // refactor_rho() followed by rho_solve(base = true).  Without upper-active bounds (r_r = 0, the
+  // common case: rho_max is a large cap) the two fuse into 5 phases instead of 7: S22 is built
+  // once and the same register Cholesky yields lam_w = S22^-1 u0 (lane 0) and the columns of
+  // T22 = S22^-1 (lanes 1..6, needed by the GI directions and the final full solve).
+  QPC_FN void refactor_solve(bool any_upper) {
+    if (any_upper) { refactor_rho(); rho_solve(true, 0, 0.0, true); return; }
+    const int N = D.N, nc = D.nc, nrho = D.nrho, m1 = D.m1;
+    const double eps = sm[D.lds[L_MISC] + MS_EPS];
+    QPC_PROF_ACC(PS_LOGIC);
+    QPC_PHASE(lane) {
+      for (int c = lane; c < nc; c += 64) {
+        if (N <= 4) kr_block<4>(sm, D, c, eps); else kr_block<8>(sm, D, c, eps);
+      }
+    } QPC_END_PHASE
+    QPC_PHASE(lane) {
+      for (int idx = lane; idx < nrho * 6; idx += 64) {
+        int j = idx / 6, b = idx % 6, c = j / N, jj = j % N;
+        sm[D.lds[L_Y] + j * 6 + b] = dotp(sm + D.lds[L_KR] + c * N * N + jj * N, 1, sm + D.lds[L_G] + b * nrho + c * N, 1, N);
+      }
+    } QPC_END_PHASE
+    QPC_PHASE(lane) {
+      if (lane < 36) {
+        int a = lane / 6, b = lane % 6;
+        sm[D.lds[L_C22] + lane] = sm[D.lds[L_B22] + lane] + dotp(sm + D.lds[L_G] + a * nrho, 1, sm + D.lds[L_Y] + b, 6, nrho);
+      }
+    } QPC_END_PHASE
+    QPC_PROF_ACC(PS_REFAC);
+    QPC_PHASE(lane) {
+      if (lane < 7) {
+        double sref[6], x[6], rhs[6];
+        for (int k = 0; k < 6; k++)
+          sref[k] = sm[D.lds[L_SM] + (m1 + k) * D.ms + (m1 + k)] + (sm[D.lds[L_C22] + k * 6 + k] - sm[D.lds[L_B22] + k * 6 + k]);
+        for (int r = 0; r < 6; r++) rhs[r] = lane == 0 ? (double)sm[D.lds[L_MISC] + MS_U0 + r] : ((r == lane - 1) ? 1.0 : 0.0);
+        chol6_solve(sm + D.lds[L_C22], sref, D.tau_pivot, rhs, x);
+        for (int r = 0; r < 6; r++) {
+          if (lane == 0) sm[D.lds[L_LAM] + m1 + r] = x[r];
+          else sm[D.lds[L_S22I] + r * 6 + (lane - 1)] = x[r];
+        }
+      }
+    } QPC_END_PHASE
+    rho_back(true, false);
+    QPC_PROF_ACC(PS_KKT);
+  }
+
   // lam = S^-1 t (t in L_T1, result in `out`) through the block inverse:
   //   lam2 = T22 (t2 - Z' t1) ;  lam1 = S11I t1 - Z lam2     (S11I in the leading block of L_SM,
   //   Z = S11^-1 S12 in L_X2, T22 = (B22 + C22)^-1 in L_S22I) -- no serial chain.
@@ -513,6 +557,7 @@ template <class P> struct Solver {
       for (int j = lane; j < nrho; j += 64) sm[D.lds[L_XR] + j] = (sm[D.lds[L_WS] + j] == 1.0) ? sm[D.lds[L_HI] + j] : 0.0;
     } QPC_END_PHASE
     int it = 0;
+    double prev_dbig = 1e300;
     for (;; it++) {
       if (it == 0) fresh_rhs(); else residuals();
       kkt_solve();
@@ -544,7 +589,15 @@ template <class P> struct Solver {
       QPC_PROF_ACC(PS_UPDATE);
       if (it >= refine) break;
       rbig = QPC_RED_MAX_GET(0, rbig); rdbig = QPC_RED_MAX_GET(1, rdbig);
-      if (it > 0 && !(rdbig > 1e-13 * (1.0 + rbig))) break;
+      // converged, or the correction stopped shrinking (rounding floor of this KKT system): further
+      // sweeps only re-apply noise; the acceptance test on the true residuals follows either way
+      // or the NEXT correction, predicted from the observed contraction, is already below tolerance;
+      if (it > 0) {
+        const double tol = 1e-13 * (1.0 + rbig);
+        if (!(rdbig > tol) || rdbig > 0.25 * prev_dbig) break;
+        if (it >= 2 && rdbig * (rdbig / prev_dbig) < tol) break;
+      }
+      prev_dbig = rdbig;
     }
     return it;
   }
@@ -1337,8 +1390,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       if (lane < 6) sm[MISC + MS_U0 + lane] = sm[D.lds[L_T1] + m1 + lane] - dotp(sm + D.lds[L_X2] + lane, 6, sm + D.lds[L_T1], 1, m1);
     } QPC_END_PHASE
     bool any_upper = false;
-    S.refactor_rho();
-    S.rho_solve(true, 0, 0.0, any_upper);
+    S.refactor_solve(any_upper);
     // ---- phase A: primal-dual active-set sweeps (multi-change)
     for (int pd = 0; pd < D.max_pdas; pd++) {
       const double gscale = 1.0 + S.last_gmax, tolb = D.tol_bound * (1.0 + S.last_xmax); // U is current (rho_solve)
@@ -1362,8 +1414,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       if (!(rchg > 0.0)) break;
       any_upper = rup > 0.0;
       iters++;
-      S.refactor_rho();
-      S.rho_solve(true, 0, 0.0, any_upper);
+      S.refactor_solve(any_upper);
     }
     // ---- phase B: drops until dual feasible, then Goldfarb-Idnani additions (finite)
     while (true) {
@@ -1396,8 +1447,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       if (jbad >= 0) {
         QPC_PHASE(lane) { if (lane == 0) sm[D.lds[L_WS] + jbad] = 0.0; } QPC_END_PHASE
         iters++;
-        S.refactor_rho();
-        S.rho_solve(true, 0, 0.0, true);
+        S.refactor_solve(true);
         continue;
       }
       if (pviol < 0) break; // optimal for this working set
@@ -1448,8 +1498,8 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
             sm[D.lds[L_U] + j] = u;
           }
         } QPC_END_PHASE
+        if (full) { S.refactor_solve(true); break; }
         S.refactor_rho();
-        if (full) { S.rho_solve(true, 0, 0.0, true); break; }
       }
       if (fail) { if (status == QPC_STATUS_OPTIMAL) status = QPC_STATUS_ITERATION_LIMIT; break; }
     }
