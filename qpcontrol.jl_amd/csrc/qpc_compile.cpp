@@ -27,7 +27,6 @@ int qpc_task_dim(const qpc_model *m, int kind, int joint) {
 }
 
 namespace {
-inline int ntask_plus1_x6(const QpcDims &D) { return (D.ntask + 1) * 6; }
 struct Builder {
   std::vector<int> it;
   std::vector<double> dt;
@@ -343,38 +342,51 @@ int qpc_compile_program(qpc_controller *c) {
   B.dbegin(DT_LAW); B.dt.insert(B.dt.end(), law_tab.begin(), law_tab.end());
   B.dt.push_back(0.0);
 
-  // ---- LDS layout with lifetime overlays (regions that are never live together share bytes):
-  //   [persistent | assembly outputs | max(early kinematics/assembly scratch, solver + RNEA scratch)]
+  // ---- LDS layout with lifetime overlays (regions that are never live together share bytes).
+  //   [ persistent | small assembly outputs | A | B ]
+  //   A = { kinematics-only scratch: RL->IC, TJ->HB, CR }  U  { big assembly outputs: M, G, HR, HI, WS }
+  //   B = { what the assembly still reads: H, inputs, T, S, AB, IW->AMOM }  U  { solver scratch }  U  { RNEA scratch }
+  // What the inverse dynamics needs again after the solve (I_i, W0_i, S_k) is NOT kept in LDS: it is
+  // lane-private and parked in the workgroup's HBM spill slot (qpc_program.h SCR_*).
   // Every overlay below was validated by the emulator's race / uninitialised-read detector.
   const int nrho = D.nrho, mm = D.m;
   auto even = [](int x) { return x + (x & 1); };
   int off = 0;
   auto L = [&](int id, int n) { D.lds[id] = off; off = even(off + (n > 0 ? n : 0)); };
   // persistent for the whole tick
-  L(L_S, nv * 6); L(L_AB, nb * 6); L(L_IW, nb * 10); L(L_F, nb * 6); L(L_VD, nv); L(L_MISC, MS_COUNT);
-  L(L_HOT, D.m + 4 * ne);
-  // written by the assembly, read by the solver
-  L(L_M, mm * D.nfs); L(L_D, mm); L(L_HV, D.nf); L(L_SQH, D.nf); L(L_GV, D.nf); L(L_W, wsize); L(L_WINV, wsize);
-  L(L_G, 6 * nrho); L(L_HR, D.nc * N * N); L(L_HI, nrho); L(L_WS, nrho);
-  const int base = off;
-  // -- early group (dead once the Schur complement build starts)
-  L(L_Q, D.nq); L(L_V, nv); L(L_DES, D.n_desired); L(L_CW, D.nc); L(L_CMAX, D.nc); L(L_TW, D.n_tw); L(L_SURF, D.n_surf);
-  D.lds[L_ACCP] = D.lds[L_Q]; // born after q, v are dead (assembly prologue)
-  if ((ntask_plus1_x6(D)) > even(D.nq) + even(nv)) { D.lds[L_ACCP] = off; off = even(off + (D.ntask + 1) * 6); }
+  L(L_VD, nv); L(L_MISC, MS_COUNT); L(L_HOT, D.m + 4 * ne);
+  // small assembly outputs (written while the kinematics scratch is still live)
+  L(L_D, mm); L(L_HV, D.nf); L(L_SQH, D.nf); L(L_GV, D.nf); L(L_W, wsize); L(L_WINV, wsize);
+  // ---- region A
+  const int a_base = off;
   L(L_RL, nb * 12); D.lds[L_IC] = D.lds[L_RL];                       // IC born after RL is dead
-  L(L_H, nb * 12); L(L_T, nb * 6);
   L(L_TJ, nb * 6); D.lds[L_HB] = D.lds[L_TJ];                       // HB born after TJ is dead
-  { int amom = 6 * nv, cr = nb * 6; L(L_CR, amom > cr ? amom : cr); } // AMOM born after CR is dead
-  D.lds[L_AMOM] = D.lds[L_CR];
+  L(L_CR, nb * 6);
+  const int a_kin_end = off;
+  off = a_base;
+  L(L_M, mm * D.nfs); L(L_G, 6 * nrho); L(L_HR, D.nc * N * N); L(L_HI, nrho); L(L_WS, nrho);
+  if (a_kin_end > off) off = a_kin_end;
+  // ---- region B
+  const int b_base = off;
+  // -- early group (dead once the Schur complement build starts)
+  L(L_H, nb * 12);
+  L(L_Q, D.nq); L(L_V, nv); L(L_DES, D.n_desired); L(L_CW, D.nc); L(L_CMAX, D.nc); L(L_TW, D.n_tw); L(L_SURF, D.n_surf);
+  D.lds[L_ACCP] = D.lds[L_Q]; // retired
+  L(L_T, nb * 6); L(L_S, nv * 6); L(L_AB, nb * 6);
+  { int iw = nb * 10, amom = 6 * nv; L(L_IW, iw > amom ? iw : amom); } // AMOM born after the last read of IW
+  D.lds[L_AMOM] = D.lds[L_IW];
+  D.lds[L_F] = D.lds[L_IW]; // retired (W0 lives in the spill slot)
   const int early_end = off;
   // -- solver group
-  off = base;
+  off = b_base;
   L(L_SM, mm * D.ms);
   D.lds[L_SV] = D.lds[L_SM];                                         // RNEA scratch born after the solve
   D.lds[L_BW] = D.lds[L_SV] + even(nb * 6);
   D.lds[L_CWR] = D.lds[L_BW] + even(nb * 6);
-  { int late_end = D.lds[L_CWR] + even(D.nc * 6); if (late_end > off) off = late_end; }
-  L(L_X2, m1 * 6); L(L_B22, 36); L(L_C22, 36); L(L_L22, 36); L(L_S22I, 36);
+  D.lds[L_SVK] = D.lds[L_CWR] + even(D.nc * 6);
+  { int late_end = D.lds[L_SVK] + even(nv * 6); if (late_end > off) off = late_end; }
+  L(L_X2, m1 * 6); L(L_B22, 36); L(L_C22, 36); L(L_S22I, 36);
+  D.lds[L_L22] = D.lds[L_C22]; // retired
   L(L_KR, D.nc * N * N); L(L_T1, mm); D.lds[L_T2] = D.lds[L_T1]; D.lds[L_T3] = D.lds[L_T1]; // T2/T3 retired
   L(L_XV, D.nf); L(L_XE, ne); L(L_XR, nrho); L(L_LAM, mm); L(L_U, nrho);
   const int xbase = off;

@@ -51,7 +51,7 @@ std::string qpc_jit_source(const QpcDims &D) {
     << D.max_pdas << "," << dbl(D.eps_primal) << "," << dbl(D.tau_pivot) << "," << dbl(D.tol_bound) << ","
     << dbl(D.tol_accept) << "};\n";
   o << "struct QpcBatchArgs { long long B; const double *q, *v, *desired, *cw, *cmax, *tw, *surf; double *tau, *vdot, "
-       "*cwrench; int32_t *status, *iters; unsigned long long *prof; unsigned long long *ticket; };\n";
+       "*cwrench; int32_t *status, *iters; unsigned long long *prof; unsigned long long *ticket; double *scratch; };\n";
   o << "extern \"C\" __global__ void __launch_bounds__(64, 2) qpc_tick_kernel_jit(const int *__restrict__ IT, "
        "const double *__restrict__ DT, const QpcBatchArgs A) {\n"
        "  __shared__ __attribute__((aligned(16))) double qpc_lds[" << (D.lds_doubles > 0 ? D.lds_doubles : 1) << "];\n"
@@ -66,6 +66,7 @@ std::string qpc_jit_source(const QpcDims &D) {
        "    io.tau = A.tau + b * kD.nv; io.vdot = A.vdot + b * kD.nv;\n"
        "    io.cwrench = A.cwrench ? A.cwrench + b * 6 * kD.nc : nullptr;\n"
        "    io.status = A.status + b; io.iters = A.iters ? A.iters + b : nullptr; io.prof = A.prof ? A.prof + b * PS_COUNT : nullptr;\n"
+       "    io.scratch = A.scratch + (size_t)blockIdx.x * QPC_SCRATCH_DOUBLES;\n"
        "    qpc::qpc_tick<double *>(kD, IT, DT, qpc_lds, io);\n"
        "    __syncthreads();\n"
        "  }\n"

@@ -42,6 +42,7 @@ struct QpcBatchArgs {
   int32_t *status, *iters;
   unsigned long long *prof;
   unsigned long long *ticket; // dynamic work distribution: next QP index (zeroed before each launch)
+  double *scratch;            // QPC_SCRATCH_DOUBLES per resident workgroup (lane-private spill slots)
 };
 
 extern "C" __global__ void __launch_bounds__(64, 1)
@@ -63,6 +64,7 @@ qpc_tick_kernel(const QpcDims D, const int *__restrict__ IT, const double *__res
     io.cwrench = A.cwrench ? A.cwrench + b * 6 * D.nc : nullptr;
     io.status = A.status + b; io.iters = A.iters ? A.iters + b : nullptr;
     io.prof = A.prof ? A.prof + b * PS_COUNT : nullptr;
+    io.scratch = A.scratch + (size_t)blockIdx.x * QPC_SCRATCH_DOUBLES;
     qpc::qpc_tick<double *>(D, IT, DT, qpc_lds, io);
     __syncthreads(); // the slab is reused by the next QP of this workgroup
   }
@@ -87,6 +89,7 @@ struct QpcDeviceState {
   hipModule_t jit_module = nullptr;
   hipFunction_t jit_func = nullptr;
   unsigned long long *d_ticket = nullptr;
+  double *d_scratch = nullptr;
 };
 
 static int hip_fail(hipError_t e, const char *what) {
@@ -113,6 +116,7 @@ static int launch(qpc_controller *c, const QpcBatchArgs &a, hipStream_t stream) 
   }
   QpcBatchArgs aa = a;
   aa.ticket = S->d_ticket;
+  aa.scratch = S->d_scratch;
   HIP_TRY(hipMemsetAsync(S->d_ticket, 0, sizeof(unsigned long long), stream));
   if (S->jit_func) {
     const int *it = S->d_it;
@@ -166,6 +170,7 @@ int32_t qpc_finalize(qpc_controller *c, int32_t device_id, qpc_layout *out) {
   HIP_TRY(hipMemcpy(S->d_dt, c->prog.dtab.data(), sizeof(double) * c->prog.dtab.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipStreamCreate(&S->stream));
   HIP_TRY(hipMalloc(&S->d_ticket, sizeof(unsigned long long)));
+  HIP_TRY(hipMalloc(&S->d_scratch, sizeof(double) * QPC_SCRATCH_DOUBLES * (size_t)S->n_cu * S->blocks_per_cu));
   // JIT specialisation on this controller's program (QPC_DISABLE_JIT=1 keeps the generic kernel)
   const char *nojit = getenv("QPC_DISABLE_JIT");
   if (nojit && nojit[0] == '1' && D.maxdepth > QPC_GENERIC_MAXD) {
@@ -212,6 +217,7 @@ void qpc_controller_destroy(qpc_controller *c) {
     if (S->d_dt) (void)hipFree(S->d_dt);
     if (S->stage) (void)hipFree(S->stage);
     if (S->d_ticket) (void)hipFree(S->d_ticket);
+    if (S->d_scratch) (void)hipFree(S->d_scratch);
     if (S->stream) (void)hipStreamDestroy(S->stream);
     if (S->jit_module) (void)hipModuleUnload(S->jit_module);
     delete S;

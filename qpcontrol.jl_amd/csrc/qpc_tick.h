@@ -310,6 +310,7 @@ struct TickIO {
   double *tau, *vdot, *cwrench;
   int32_t *status, *iters;
   unsigned long long *prof; // PS_COUNT section cycle counters (diagnostic build) or nullptr
+  double *scratch;          // QPC_SCRATCH_DOUBLES lane-private spill slot of this workgroup (HBM)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -929,6 +930,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
                       Iw[0] + mm * (cc - cw[0] * cw[0]), Iw[4] + mm * (cc - cw[1] * cw[1]), Iw[8] + mm * (cc - cw[2] * cw[2]),
                       Iw[1] - mm * cw[0] * cw[1], Iw[2] - mm * cw[0] * cw[2], Iw[5] - mm * cw[1] * cw[2]};
       st(sm + D.lds[L_IW] + 10 * i, 10, o);
+      for (int a = 0; a < 10; a++) io.scratch[(SCR_IW + a) * 64 + lane] = o[a]; // needed again by the RNEA only
     }
   } QPC_END_PHASE
   QPC_PROF_ACC(PS_K_SUBSP);
@@ -984,9 +986,24 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       inertia_mul(I, T, h);
       inertia_mul(I, Ab, ia);
       crf(T, h, cf);
-      for (int a = 0; a < 6; a++) { h[a] = cf[a]; ia[a] += cf[a]; }
+      for (int a = 0; a < 6; a++) ia[a] += cf[a];
       st(sm + D.lds[L_HB] + 6 * i, 6, ia); // I (Ab + A_pinned) + T x* I T
-      st(sm + D.lds[L_F] + 6 * i, 6, h);   // T x* I T alone (velocity-product wrench for RNEA)
+      // W0 = I (Ab - g) + T x* I T : everything of the body wrench that does not depend on the solution
+      double mg[6] = {0, 0, 0, -DT[D.dt[DT_GRAV]], -DT[D.dt[DT_GRAV] + 1], -DT[D.dt[DT_GRAV] + 2]}, ig[6];
+      inertia_mul(I, mg, ig);
+      for (int a = 0; a < 6; a++) io.scratch[(SCR_W0 + a) * 64 + lane] = ia[a] + ig[a];
+    }
+    if (lane >= 51 && lane < 54) { // centre of mass (IW[1..3] = m c): last reader of L_IW, which L_AMOM overlays
+      const int a = lane - 51;
+      double acc = 0.0;
+      for (int i0 = 0; i0 < nb; i0 += 8) {
+        double x[8];
+        QPC_UNROLL_FULL
+        for (int u = 0; u < 8; u++) x[u] = sm[D.lds[L_IW] + 10 * (i0 + u < nb ? i0 + u : 0) + 1 + a];
+        QPC_UNROLL_FULL
+        for (int u = 0; u < 8; u++) acc += (i0 + u < nb) ? x[u] : 0.0;
+      }
+      sm[MISC + MS_COM + a] = acc / DT[D.dt[DT_GRAV] + 3];
     }
     if (lane >= 54 && D.crb_full_body >= 0) { // whole-robot composite inertia: component (lane-54), batched sum
       const int a = lane - 54;
@@ -1009,14 +1026,11 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       double Ic[10], S[6], h[6];
       ld(sm + D.lds[L_IC] + 10 * mt[6], 10, Ic);
       ld(sm + D.lds[L_S] + 6 * k, 6, S);
+      for (int a = 0; a < 6; a++) io.scratch[(SCR_S + a) * 64 + lane] = S[a]; // for tau_k = S_k . F (RNEA)
       inertia_mul(Ic, S, h);
       for (int a = 0; a < 6; a++) sm[D.lds[L_AMOM] + a * nv + k] = h[a];
     }
-    if (lane < 3) {
-      double acc = 0.0;
-      for (int i = 0; i < nb; i++) acc += sm[D.lds[L_IW] + 10 * i + 1 + lane];
-      sm[MISC + MS_COM + lane] = acc / DT[D.dt[DT_GRAV] + 3];
-    } else if (lane < 9) {
+    if (lane >= 3 && lane < 9) {
       double acc = 0.0;
       for (int i = 0; i < nb; i++) acc += sm[D.lds[L_HB] + 6 * i + (lane - 3)];
       sm[MISC + MS_ADV + (lane - 3)] = acc; // Ȧv + A_pin v̇_pin
@@ -1544,6 +1558,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
 
   QPC_PROF_ACC(PS_FINAL);
   // ======================================================================== extraction (a15) + RNEA (a16, a17)
+  QPC_LANE_ARRAY(sk_, 6); // this lane's motion subspace column, back from the spill slot
   QPC_PHASE(lane) {
     for (int f = lane; f < nf; f += 64) sm[D.lds[L_VD] + IT[D.it[IT_FREE_K] + f]] = sm[D.lds[L_XV] + f] * sm[D.lds[L_SQH] + f];
     for (int idx = lane; idx < nc * 6; idx += 64) { // value(wrench_world) = G_c rho_c
@@ -1552,22 +1567,25 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       if (use_rho) for (int i = 0; i < N; i++) acc += sm[D.lds[L_G] + a * nrho + c * N + i] * sm[D.lds[L_XR] + c * N + i];
       sm[D.lds[L_CWR] + idx] = acc;
     }
+    if (lane < nv) { // S_k v̇_k of the FREE velocity indices (the pinned ones already ride in Ab)
+      double *sk = QPC_LA(sk_, lane);
+      for (int a = 0; a < 6; a++) sk[a] = io.scratch[(SCR_S + a) * 64 + lane];
+      const int f = IT[D.it[IT_FREE_OF] + lane];
+      const double vd = f >= 0 ? (double)sm[D.lds[L_XV] + f] * (double)sm[D.lds[L_SQH] + f] : 0.0;
+      for (int a = 0; a < 6; a++) sm[D.lds[L_SVK] + 6 * lane + a] = sk[a] * vd;
+    }
   } QPC_END_PHASE
-  QPC_PHASE(lane) { // S_j v̇_j per body, FREE joints only (the pinned ones already ride in Ab)
+  QPC_PHASE(lane) { // S_j v̇_j per body
     if (lane < nb) {
-      const int i = lane;
       const int *mt = QPC_LI(meta_, lane);
       double sv[6] = {0, 0, 0, 0, 0, 0};
       const int v0 = mt[2], n = mt[3];
-      for (int c = 0; c < n; c++) {
-        const bool pinned = IT[D.it[IT_PDES_K] + v0 + c] >= 0;
-        const double vd = pinned ? 0.0 : (double)sm[D.lds[L_VD] + v0 + c];
-        for (int a = 0; a < 6; a++) sv[a] += sm[D.lds[L_S] + 6 * (v0 + c) + a] * vd;
-      }
-      st(sm + D.lds[L_SV] + 6 * i, 6, sv);
+      for (int c = 0; c < n; c++)
+        for (int a = 0; a < 6; a++) sv[a] += sm[D.lds[L_SVK] + 6 * (v0 + c) + a];
+      st(sm + D.lds[L_SV] + 6 * lane, 6, sv);
     }
   } QPC_END_PHASE
-  QPC_PHASE(lane) { // body wrench: I (A + Ab - g) + T x* I T - external (contact) wrench
+  QPC_PHASE(lane) { // body wrench: I A_free + W0 - external (contact) wrench,  W0 = I (Ab - g) + T x* I T
     if (lane < nb) {
       const int i = lane;
       const int *mt = QPC_LI(meta_, lane);
@@ -1579,11 +1597,9 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
         if (an >= 0)
           for (int a = 0; a < 6; a++) A[a] += sm[D.lds[L_SV] + 6 * an + a];
       }
-      for (int a = 0; a < 6; a++) A[a] += sm[D.lds[L_AB] + 6 * i + a];
-      A[3] -= DT[D.dt[DT_GRAV]]; A[4] -= DT[D.dt[DT_GRAV] + 1]; A[5] -= DT[D.dt[DT_GRAV] + 2];
-      ld(sm + D.lds[L_IW] + 10 * i, 10, I);
+      for (int a = 0; a < 10; a++) I[a] = io.scratch[(SCR_IW + a) * 64 + lane];
       inertia_mul(I, A, ia);
-      for (int a = 0; a < 6; a++) ia[a] += sm[D.lds[L_F] + 6 * i + a];
+      for (int a = 0; a < 6; a++) ia[a] += io.scratch[(SCR_W0 + a) * 64 + lane];
       for (int e = IT[D.it[IT_BC_PTR] + i]; e < IT[D.it[IT_BC_PTR] + i + 1]; e++) {
         int c = IT[D.it[IT_BC_IDX] + e];
         for (int a = 0; a < 6; a++) ia[a] -= sm[D.lds[L_CWR] + 6 * c + a];
@@ -1604,7 +1620,8 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
           msk &= msk - 1;
           for (int a = 0; a < 6; a++) F[a] += sm[D.lds[L_BW] + 6 * b + a];
         }
-        for (int a = 0; a < 6; a++) tau += sm[D.lds[L_S] + 6 * k + a] * F[a];
+        const double *sk = QPC_LA(sk_, lane);
+        for (int a = 0; a < 6; a++) tau += sk[a] * F[a];
       }
       io.tau[k] = tau;
       io.vdot[k] = sm[D.lds[L_VD] + k];

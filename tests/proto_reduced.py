@@ -16,6 +16,7 @@ from qpcontrol_jl_amd.workloads import (HARD, JOINT, MATRIX, MATRIX_PER_QP, SCAL
 
 @dataclass
 class Settings:
+    detect_cycles: bool = False
     max_active_set_iters: int = 200
     max_refine_iters: int = 6
     eps_primal_reg: float = 1e-9
@@ -178,7 +179,7 @@ def chol_inf(S, tau):
     return L, dropped
 
 
-def solve_reduced(P: Reduced, st: Settings = Settings(), stats=None):
+def solve_reduced(P: Reduced, st: Settings = Settings(), stats=None, guess=None):
     """x = [v̇_free; e; rho].  Returns dict(vd_free, e, rho, status, iters, refine)."""
     nf, ne, nrho = len(P.Hv), P.E_e.shape[1], len(P.rho_max)
     m, nw = len(P.d), P.n_wrench
@@ -275,8 +276,16 @@ def solve_reduced(P: Reduced, st: Settings = Settings(), stats=None):
     status, iters, refine = 0, 0, 0
     F = factor()
     xv, xe, xr, lam, _ = eqp(F, 0)
+    if use_rho and guess is not None:  # experiment hook: initial working set from the unconstrained solve
+        new = guess(P, xr, ws, enabled, N)
+        if not np.array_equal(new, ws):
+            ws = new
+            iters += 1
+            F = factor()
+            xv, xe, xr, lam, _ = eqp(F, 0)
     if use_rho:
         # ---- phase A: primal-dual active set passes (multi-change), cheap and usually enough
+        seen = [tuple(ws)]
         for _pd in range(12):
             u, gl = multipliers(xr, lam)
             gscale = 1.0 + np.abs(gl).max()
@@ -287,6 +296,9 @@ def solve_reduced(P: Reduced, st: Settings = Settings(), stats=None):
             new[(ws == 0) & (xr > hi + tolb)] = 1
             if np.array_equal(new, ws):
                 break
+            if st.detect_cycles and tuple(new) in seen:
+                break  # primal-dual sweeps cycle: hand over to the finite phase B now
+            seen.append(tuple(new))
             ws = new
             iters += 1
             F = factor()
