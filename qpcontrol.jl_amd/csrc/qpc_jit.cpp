@@ -55,6 +55,7 @@ std::string qpc_jit_source(const QpcDims &D) {
   o << "extern \"C\" __global__ void __launch_bounds__(64, 2) qpc_tick_kernel_jit(const int *__restrict__ IT, "
        "const double *__restrict__ DT, const QpcBatchArgs A) {\n"
        "  __shared__ __attribute__((aligned(16))) double qpc_lds[" << (D.lds_doubles > 0 ? D.lds_doubles : 1) << "];\n"
+       "  qpc::qpc_tick_prologue<double *>(kD, IT, qpc_lds);\n"
        "  while (true) {\n"
        "    unsigned long long t = 0;\n"
        "    if ((threadIdx.x & 63) == 0) t = atomicAdd(A.ticket, 1ull);\n"

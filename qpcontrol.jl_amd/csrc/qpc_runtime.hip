@@ -48,6 +48,7 @@ struct QpcBatchArgs {
 extern "C" __global__ void __launch_bounds__(64, 1)
 qpc_tick_kernel(const QpcDims D, const int *__restrict__ IT, const double *__restrict__ DT, const QpcBatchArgs A) {
   extern __shared__ __attribute__((aligned(16))) double qpc_lds[];
+  qpc::qpc_tick_prologue<double *>(D, IT, qpc_lds);
   // active-set iteration counts differ per QP (p99 ~ 3x mean): QPs are handed out through one
   // device-scope ticket counter instead of a static grid-stride, so no workgroup idles at the tail
   while (true) {

@@ -789,6 +789,25 @@ QPC_FN void rotation_vector(const double *R, double *rv) {
 // ------------------------------------------------------------------------------------------
 // the tick
 // ------------------------------------------------------------------------------------------
+// Static per-lane metadata (lane = body i and lane = velocity index k), read once per QP into
+// registers: no table lookup sits on a dependent path of the tree sweeps.  (Keeping it live across
+// the QPs of a workgroup was measured: the extra register pressure costs more than the reload.)
+//   [0] jtype(i) [1] q0(i) [2] v0(i) [3] nvj(i) [4,5] subtree mask of body i for the composite inertia
+//       (zero when not needed: no free column / whole-robot total)
+//   [6] vbody(k) [7] vcomp(k) [8] pin-desired index of k or -1 [9,10] subtree mask of vbody(k)
+//   [11 + s] s-th ancestor of body i (nearest first) or -1
+struct TickMeta {
+  QPC_LANE_INTS(v, 11 + QPC_MAXD);
+};
+
+// once per workgroup (before its first QP): hot solver lookups -> the persistent L_HOT region of
+// the LDS slab (never overlaid, so it survives from QP to QP)
+template <class P> QPC_FN void qpc_tick_prologue(const QpcDims &D, const int *IT, P sm) {
+  QPC_PHASE(lane) {
+    for (int i = lane; i < D.m + 4 * D.ne; i += 64) sm[D.lds[L_HOT] + i] = (double)IT[D.it[IT_HOT] + i];
+  } QPC_END_PHASE
+}
+
 template <class P>
 QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, const TickIO &io) {
   const int nb = D.nb, nq = D.nq, nv = D.nv, nf = D.nf, nc = D.nc, N = D.N, nrho = D.nrho, ne = D.ne;
@@ -806,15 +825,9 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
   QPC_PROF_T0();
 
   // ======================================================================== inputs -> LDS
-  // Static per-lane metadata (lane = body i and lane = velocity index k) is read ONCE per QP here
-  // and kept in registers: no table lookup sits on a dependent path of the tree sweeps below.
-  //   [0] jtype(i) [1] q0(i) [2] v0(i) [3] nvj(i) [4,5] subtree mask of body i for the composite inertia
-  //       (zero when not needed: no free column / whole-robot total)
-  //   [6] vbody(k) [7] vcomp(k) [8] pin-desired index of k or -1 [9,10] subtree mask of vbody(k)
-  //   [11 + s] s-th ancestor of body i (nearest first) or -1
-  QPC_LANE_INTS(meta_, 11 + QPC_MAXD);
+  TickMeta M;
   QPC_PHASE(lane) {
-    int *mt = QPC_LI(meta_, lane);
+    int *mt = QPC_LI(M.v, lane);
     for (int e = 0; e < 11 + QPC_MAXD; e++) mt[e] = -1;
     if (lane < nb) {
       mt[0] = IT[D.it[IT_JTYPE] + lane]; mt[1] = IT[D.it[IT_QOFF] + lane]; mt[2] = IT[D.it[IT_VOFF] + lane];
@@ -838,7 +851,6 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
     for (int i = lane; i < nc; i += 64) { sm[D.lds[L_CW] + i] = io.cw[i]; sm[D.lds[L_CMAX] + i] = io.cmax[i]; }
     for (int i = lane; i < D.n_tw; i += 64) sm[D.lds[L_TW] + i] = io.tw[i];
     for (int i = lane; i < D.n_surf; i += 64) sm[D.lds[L_SURF] + i] = io.surf[i];
-    for (int i = lane; i < m + 4 * ne; i += 64) sm[D.lds[L_HOT] + i] = (double)IT[D.it[IT_HOT] + i];
   } QPC_END_PHASE
 
   QPC_PROF_ACC(PS_K_INPUT);
@@ -846,7 +858,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
   QPC_PHASE(lane) { // joint transforms: x_parent = Rf (Rj x + pj) + pf
     if (lane < nb) {
       const int i = lane;
-      const int *mt = QPC_LI(meta_, lane);
+      const int *mt = QPC_LI(M.v, lane);
       const int jt = mt[0], q0 = mt[1];
       const double *ax = DT + D.dt[DT_AXIS] + 3 * i, *Rf = DT + D.dt[DT_RF] + 9 * i, *pf = DT + D.dt[DT_PF] + 3 * i;
       double Rj[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pj[3] = {0, 0, 0};
@@ -877,7 +889,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
   QPC_PROF_ACC(PS_K_JOINT);
   QPC_PHASE(lane) { // transform_to_root by walking the (register-resident) ancestor chain
     if (lane < nb) {
-      const int *mt = QPC_LI(meta_, lane);
+      const int *mt = QPC_LI(M.v, lane);
       double H[12], A[12], t[3];
       ld(sm + D.lds[L_RL] + 12 * lane, 12, H);
       QPC_UNROLL_JIT
@@ -897,7 +909,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
   QPC_PHASE(lane) { // per body: motion subspace columns of its joint (world), joint twist, world inertia
     if (lane < nb) {
       const int i = lane;
-      const int *mt = QPC_LI(meta_, lane);
+      const int *mt = QPC_LI(M.v, lane);
       const int jt = mt[0], v0 = mt[2], n = mt[3];
       double H[12], tj[6] = {0, 0, 0, 0, 0, 0};
       ld(sm + D.lds[L_H] + 12 * i, 12, H);
@@ -939,7 +951,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
                     // so every J̇v / Ȧv below already contains J_pin v̇_pin (no separate pass)
     if (lane < nb) {
       const int i = lane;
-      const int *mt = QPC_LI(meta_, lane);
+      const int *mt = QPC_LI(M.v, lane);
       double T[6], tj[6], cr[6];
       ld(sm + D.lds[L_TJ] + 6 * i, 6, tj);
       for (int a = 0; a < 6; a++) T[a] = tj[a];
@@ -963,7 +975,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
   QPC_PHASE(lane) { // bias_acceleration (+ pinned), composite inertias (subtree mask), momentum-rate bias
     if (lane < nb) {
       const int i = lane;
-      const int *mt = QPC_LI(meta_, lane);
+      const int *mt = QPC_LI(M.v, lane);
       double Ab[6], T[6], I[10], Ic[10], h[6], ia[6], cf[6];
       ld(sm + D.lds[L_CR] + 6 * i, 6, Ab);
       QPC_UNROLL_JIT
@@ -1022,7 +1034,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
   QPC_PHASE(lane) { // momentum matrix, CoM, momentum-rate bias, Hessian diagonal
     if (lane < nv) {
       const int k = lane;
-      const int *mt = QPC_LI(meta_, lane);
+      const int *mt = QPC_LI(M.v, lane);
       double Ic[10], S[6], h[6];
       ld(sm + D.lds[L_IC] + 10 * mt[6], 10, Ic);
       ld(sm + D.lds[L_S] + 6 * k, 6, S);
@@ -1558,7 +1570,8 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
 
   QPC_PROF_ACC(PS_FINAL);
   // ======================================================================== extraction (a15) + RNEA (a16, a17)
-  QPC_LANE_ARRAY(sk_, 6); // this lane's motion subspace column, back from the spill slot
+  QPC_LANE_ARRAY(sk_, 6);  // this lane's motion subspace column, back from the spill slot
+  QPC_LANE_ARRAY(iw_, 16); // this lane's body inertia (10) and W0 (6): one HBM round trip for all three
   QPC_PHASE(lane) {
     for (int f = lane; f < nf; f += 64) sm[D.lds[L_VD] + IT[D.it[IT_FREE_K] + f]] = sm[D.lds[L_XV] + f] * sm[D.lds[L_SQH] + f];
     for (int idx = lane; idx < nc * 6; idx += 64) { // value(wrench_world) = G_c rho_c
@@ -1570,6 +1583,10 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
     if (lane < nv) { // S_k v̇_k of the FREE velocity indices (the pinned ones already ride in Ab)
       double *sk = QPC_LA(sk_, lane);
       for (int a = 0; a < 6; a++) sk[a] = io.scratch[(SCR_S + a) * 64 + lane];
+      if (lane < nb) {
+        double *iw = QPC_LA(iw_, lane);
+        for (int a = 0; a < 16; a++) iw[a] = io.scratch[(SCR_IW + a) * 64 + lane];
+      }
       const int f = IT[D.it[IT_FREE_OF] + lane];
       const double vd = f >= 0 ? (double)sm[D.lds[L_XV] + f] * (double)sm[D.lds[L_SQH] + f] : 0.0;
       for (int a = 0; a < 6; a++) sm[D.lds[L_SVK] + 6 * lane + a] = sk[a] * vd;
@@ -1577,7 +1594,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
   } QPC_END_PHASE
   QPC_PHASE(lane) { // S_j v̇_j per body
     if (lane < nb) {
-      const int *mt = QPC_LI(meta_, lane);
+      const int *mt = QPC_LI(M.v, lane);
       double sv[6] = {0, 0, 0, 0, 0, 0};
       const int v0 = mt[2], n = mt[3];
       for (int c = 0; c < n; c++)
@@ -1588,7 +1605,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
   QPC_PHASE(lane) { // body wrench: I A_free + W0 - external (contact) wrench,  W0 = I (Ab - g) + T x* I T
     if (lane < nb) {
       const int i = lane;
-      const int *mt = QPC_LI(meta_, lane);
+      const int *mt = QPC_LI(M.v, lane);
       double A[6], I[10], ia[6];
       ld(sm + D.lds[L_SV] + 6 * i, 6, A);
       QPC_UNROLL_JIT
@@ -1597,9 +1614,10 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
         if (an >= 0)
           for (int a = 0; a < 6; a++) A[a] += sm[D.lds[L_SV] + 6 * an + a];
       }
-      for (int a = 0; a < 10; a++) I[a] = io.scratch[(SCR_IW + a) * 64 + lane];
+      const double *iw = QPC_LA(iw_, lane);
+      for (int a = 0; a < 10; a++) I[a] = iw[a];
       inertia_mul(I, A, ia);
-      for (int a = 0; a < 6; a++) ia[a] += io.scratch[(SCR_W0 + a) * 64 + lane];
+      for (int a = 0; a < 6; a++) ia[a] += iw[10 + a];
       for (int e = IT[D.it[IT_BC_PTR] + i]; e < IT[D.it[IT_BC_PTR] + i + 1]; e++) {
         int c = IT[D.it[IT_BC_IDX] + e];
         for (int a = 0; a < 6; a++) ia[a] -= sm[D.lds[L_CWR] + 6 * c + a];
@@ -1610,7 +1628,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
   QPC_PHASE(lane) { // tau_k = S_k . (sum of subtree wrenches); floating joint torques exactly 0
     if (lane < nv) {
       const int k = lane;
-      const int *mt = QPC_LI(meta_, lane);
+      const int *mt = QPC_LI(M.v, lane);
       double tau = 0.0;
       if (mt[6] != D.floating) {
         double F[6] = {0, 0, 0, 0, 0, 0};

@@ -130,6 +130,7 @@ int32_t qpc_control_batch(qpc_controller *c, int64_t B, const double *q, const d
     io.status = status + b; io.iters = iters ? iters + b : nullptr; io.prof = nullptr;
     std::vector<double> scratch(QPC_SCRATCH_DOUBLES, std::nan("")); // a fresh (poisoned) spill slot per QP
     io.scratch = scratch.data();
+    qpc::qpc_tick_prologue<Lds>(D, c->prog.itab.data(), Lds{0});
     qpc::qpc_tick<Lds>(D, c->prog.itab.data(), c->prog.dtab.data(), Lds{0}, io);
     g_races += emu.races; g_uninit += emu.uninit; g_outside += emu.outside;
     if (g_first.empty()) g_first = emu.first;
