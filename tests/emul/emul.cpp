@@ -18,7 +18,7 @@
 struct EmuState {
   std::vector<double> mem;
   std::vector<int> wphase, wlane, rphase, rlane;
-  int phase = 0, lane = -1;
+  int phase = 0, lane = -1, section = -1;
   long races = 0, uninit = 0, outside = 0;
   std::string first;
   void reset(int n) {
@@ -27,10 +27,10 @@ struct EmuState {
     phase = 0; lane = -1;
   }
   void note(const char *what, int i) {
-    if (first.empty()) { char b[160]; snprintf(b, sizeof b, "%s at lds[%d] phase %d lane %d (writer lane %d, reader lane %d)", what, i, phase, lane, wlane[i], rlane[i]); first = b; }
+    if (first.empty()) { char b[160]; snprintf(b, sizeof b, "%s at lds[%d] phase %d (after section %d) lane %d (writer lane %d, reader lane %d)", what, i, phase, section, lane, wlane[i], rlane[i]); first = b; }
   }
   void on_read(int i) {
-    if (wphase[i] < 0) { uninit++; note("uninitialised read", i); }
+    if (wphase[i] < 0) { uninit++; note("uninitialised read", i); if (getenv("EMU_TRACE")) fprintf(stderr, "uninit read lds[%d] phase %d section %d lane %d\n", i, phase, section, lane); }
     if (lane >= 0) {
       if (wphase[i] == phase && wlane[i] != lane) { races++; note("RAW race", i); }
       if (rphase[i] == phase) { if (rlane[i] != lane) rlane[i] = -2; }
@@ -58,6 +58,8 @@ struct Lds {
   Lds operator+(int o) const { return Lds{base + o}; }
 };
 
+#define QPC_PROF_T0()
+#define QPC_PROF_ACC(i) (g_emu->section = (i)) // the last section marker passed: locates a report in the source
 #define QPC_FN inline
 #define QPC_PHASE(lane) for (int lane = 0; lane < 64; ++lane) { g_emu->lane = lane;
 #define QPC_END_PHASE } g_emu->lane = -1; g_emu->phase++;
