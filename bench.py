@@ -27,45 +27,81 @@ sys.path.insert(0, ROOT)
 ALG_BYTES_PER_SOLVE = 1968  # in 8*(37+36+36+16) + out 8*(36+36+48) + 8
 ALG_FLOPS_PER_SOLVE = 4.6e5  # one reduced-KKT factor+solve + assembly + FK/RNEA
 # HBM traffic per solve measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes
-# (profiles/r01_v14_pmc_*.csv, r01_v14_traffic_summary.json): 29362 KiB read + 57769 KiB written per
-# 32768-QP launch (v14 kernel; writes include L2 evictions of the 288 B/lane scratch spill area).
+# (profiles/r01_v18_pmc_*.csv, r01_v18_traffic_summary.json): 292261 KiB read + 276802 KiB written per
+# 32768-QP launch.  ~8.7 KB each way per solve is the deliberate lane-private spill slot (inertias,
+# bias wrenches, motion subspaces parked in HBM during the solve so that 8 QPs fit the LDS of a CU,
+# DESIGN.md 4); the slots total 23 MB and live in L2 / Infinity Cache, TCC->EA requests count them anyway.
 # 8-byte-per-lane accesses: the gfx950 "x2 for 16-B wide reads" correction of MI355X_MICROARCH.md
 # does not apply.
-MEASURED_TRAFFIC_BYTES_PER_SOLVE = (29362.0 + 57768.6) * 1024 / 32768
+MEASURED_TRAFFIC_BYTES_PER_SOLVE = (292260.6 + 276802.0) * 1024 / 32768
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md (spec; 6.29e12 measured)
 FP64_PEAK = 78.6e12  # FLOP/s vector fp64 (datasheet)
 
 
-def cpu_baseline(B_sample_max=4096, budget_s=12.0):
-    """The oracle (CPU restatement of the reference path: 143x178 reference-layout problem,
-    coefficient rewrite per tick, OSQP-algorithm ADMM with the test-suite settings of
-    test/runtests.jl:35-43, cold start, RNEA) timed on ONE host core on a bounded sample."""
+def _cpu_worker(rank, B_sample, budget_s):
+    """One host core: the oracle's reference-layout tick on its own slice of the workload for
+    `budget_s` seconds.  Runs in a child process (no torch, no HIP)."""
     import qpc_pkg
     qpc_pkg.load()
     from qpcontrol_jl_amd import workloads as W
     from oracle import oracle as O
-    O.build(native=True)
 
     def factory(mech, N, fl):
         return O.OracleController(O.OracleModel(mech, native=True), N, fl)
 
-    oc, wl = W.atlas_workload(factory, B_sample_max, 3)
+    oc, wl = W.atlas_workload(factory, B_sample, 3, seed=2025 + 104729 * rank)
     oc.set_settings(O.test_settings(polish=0))
-    done, t0, iters = 0, time.perf_counter(), 0
-    chunk = 64
-    while done < B_sample_max and time.perf_counter() - t0 < budget_s:
+    done, iters, chunk = 0, 0, 16
+    t0 = time.perf_counter()
+    while done < B_sample and time.perf_counter() - t0 < budget_s:
         s = slice(done, done + chunk)
         r = oc.tick_batch(wl.q[s], wl.v[s], wl.desired[s], wl.contact_weight[s], wl.contact_maxnormalforce[s])
         iters += int(r["iters"].sum())
-        done += chunk
-    dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "QP solves/s", "cores": 1, "kind": "port",
-            "sample": f"{done} QPs of the same Atlas config-3 workload, OSQP restatement eps_abs=1e-8 eps_rel=1e-16 "
-                      f"cold start, mean {iters / max(done, 1):.0f} ADMM iterations, {dt:.1f} s on 1 core "
-                      f"(host has {os.cpu_count()} cores)"}
+        done += len(r["iters"])
+    print(json.dumps({"done": done, "iters": iters, "seconds": time.perf_counter() - t0}))
+
+
+def cpu_baseline(budget_s=12.0, max_workers=64):
+    """The oracle (CPU restatement of the reference path: 143x178 reference-layout problem,
+    coefficient rewrite per tick, OSQP-algorithm ADMM with the test-suite settings of
+    test/runtests.jl:35-43, cold start, RNEA) timed on the host cores of the box: one independent
+    controller per process over disjoint slices, bounded by `budget_s` seconds.
+    `value` is the all-cores rate, `single_core` the rate of one of those processes.
+    The workers are child processes of this script (`--cpu-worker`): they never touch torch or HIP."""
+    import subprocess
+    from oracle import oracle as O
+    O.build(native=True)  # build once, before the workers load the library
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    n = max(1, min(avail, max_workers))
+    B_sample = max(64, int(120 * budget_s))  # more than one core can finish in the budget
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(r), str(B_sample), str(budget_s)],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for r in range(n)]
+    res = []
+    for p in procs:
+        out, _ = p.communicate(timeout=budget_s * 4 + 120)
+        if p.returncode == 0 and out.strip():
+            res.append(json.loads(out.strip().splitlines()[-1]))
+    wall = time.perf_counter() - t0
+    if not res:
+        raise RuntimeError("cpu_baseline: no worker finished")
+    done = sum(r["done"] for r in res)
+    iters = sum(r["iters"] for r in res)
+    busy = max(r["seconds"] for r in res)
+    return {"value": done / busy, "unit": "QP solves/s", "cores": len(res), "kind": "port",
+            "single_core": res[0]["done"] / res[0]["seconds"],
+            "sample": f"{done} QPs of the same Atlas config-3 workload over {len(res)} processes (one controller each, disjoint "
+                      f"seeded slices), OSQP restatement eps_abs=1e-8 eps_rel=1e-16 cold start, mean "
+                      f"{iters / max(done, 1):.0f} ADMM iterations, {busy:.1f} s of solving ({wall:.1f} s with process start-up); "
+                      f"host has {os.cpu_count()} cores"}
 
 
 def main():
+    if len(sys.argv) >= 5 and sys.argv[1] == "--cpu-worker":
+        return _cpu_worker(int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -213,7 +249,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": ach_bytes / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": ach_bytes / HBM_PEAK,
                          "traffic": MEASURED_TRAFFIC_BYTES_PER_SOLVE * B if args.config == 3 else None,
-                         "traffic_source": "profiles/r01_v14_traffic_summary.json (rocprofv3 PMC FETCH_SIZE + WRITE_SIZE, separate passes), bytes per launch",
+                         "traffic_source": "profiles/r01_v18_traffic_summary.json (rocprofv3 PMC FETCH_SIZE + WRITE_SIZE, separate passes), bytes per launch; includes the HBM spill slots (DESIGN.md 4)",
                          "kernel": "qpc_tick_kernel", "kernel_avg_ms": avg_ms.value, "launches": int(nl.value),
                          "algorithmic_bytes_per_solve": alg_bytes,
                          "note": "path is fp64-VALU / LDS-latency bound, not HBM bound (SURVEY.md 8d); "

@@ -66,3 +66,16 @@ def test_jit_source_compiles_offline(lib):
     buf = ctypes.create_string_buffer(4000)
     rc = lib.qpc_debug_jit_compile(c.h, b"gfx950", None, buf, 4000)
     assert rc == 0, buf.value.decode()
+
+
+def test_bench_cpu_worker_cli():
+    """bench.py's cpu_baseline leg: a child process (`--cpu-worker`) that only touches the oracle"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--cpu-worker", "0", "16", "0.5"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-500:]
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r["done"] >= 16 and r["iters"] > 0 and r["seconds"] > 0
