@@ -75,6 +75,12 @@ def cpu_baseline(budget_s=12.0, max_workers=64):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
+    try:  # a container's CPU quota (cgroup v2) is the real number of cores this job may keep busy
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            avail = min(avail, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
     n = max(1, min(avail, max_workers))
     B_sample = max(64, int(120 * budget_s))  # more than one core can finish in the budget
     t0 = time.perf_counter()
