@@ -232,6 +232,27 @@ int32_t qpc_control_batch_device(qpc_controller *ctrl, int64_t B, const double *
                                  double *vdot, double *contact_wrench, int32_t *status,
                                  int32_t *iters, void *hip_stream);
 
+/* L1 -- assembly + solve from HOST-EVALUATED blocks: `solve!` + `value` of the reference
+ * (momentum.jl:58-72) with the kinematics taken out.  Per QP the caller supplies
+ * what the reference evaluates from the MechanismState:
+ *   task_J[n_desired*nv*B], task_bias[n_desired*B]  rows of all tasks stacked in task order,
+ *        task_error = J vdot + bias - desired   (src/tasks.jl:31-44,73-84,112-123,153-171,185-189,230-236,258-262)
+ *   momentum_A[6*nv*B], momentum_rhs[6*B]           world-frame momentum matrix and W_g - Adot v of the
+ *        wrench balance (momentum.jl:162-193); NULL without a floating joint
+ *   contact_R[9*nc*B], contact_p[3*nc*B]            world pose of each z-up contact frame (contacts.jl:61)
+ *   desired, contact_weight, contact_maxnormalforce, task_weights as in qpc_control_batch;
+ *   surfaces: only mu ([.. .. .. mu] per per-QP contact) is read, the normal is already in contact_R
+ * Out: vdot[nv*B], contact_wrench[6*nc*B] (may be NULL), status[B], iters[B] (may be NULL).
+ * Dense one-lane-per-QP path sharing nothing with the fused tick kernel: parity / cross-check, not
+ * the performance path.  Host pointers, synchronous; the controller must be finalized. */
+int32_t qpc_assemble_solve_batch(qpc_controller *ctrl, int64_t B, const double *task_J,
+                                 const double *task_bias, const double *desired,
+                                 const double *momentum_A, const double *momentum_rhs,
+                                 const double *contact_R, const double *contact_p,
+                                 const double *contact_weight, const double *contact_maxnormalforce,
+                                 const double *task_weights, const double *surfaces, double *vdot,
+                                 double *contact_wrench, int32_t *status, int32_t *iters);
+
 /* L0 -- raw dense QPs in OSQP problem form (what Parametron.solve! hands to the MOI optimizer,
  * momentum.jl:58; settings as test/runtests.jl:35-43):
  *     min 1/2 x'Px + q'x   s.t.  l <= A x <= u

@@ -77,6 +77,7 @@ def load_library(path=None):
     L.qpc_version.restype = ctypes.c_char_p
     L.qpc_qp_solve_batch.argtypes = [i32, i32, i64] + [c_double_p] * 5 + [ctypes.POINTER(Settings), i32, c_double_p,
                                                                          c_double_p, c_int32_p, c_int32_p]
+    L.qpc_assemble_solve_batch.argtypes = [vp, i64] + [c_double_p] * 11 + [c_double_p, c_double_p, c_int32_p, c_int32_p]
     if hasattr(L, "qpc_control_batch_device"):
         L.qpc_control_batch_device.argtypes = [vp, i64] + [vp] * 12 + [vp]
         L.qpc_timing_enable.argtypes = [vp, i32]
@@ -198,6 +199,31 @@ class Controller:
         _check(self.L, rc, "qpc_control_batch")
         return dict(tau=tau, vdot=vd, cwrench=cwr[:, :6 * lay.n_contacts].reshape(B, lay.n_contacts, 6),
                     status=status, iters=iters)
+
+
+def assemble_solve_batch(ctrl: Controller, task_J, task_bias, desired, momentum_A=None, momentum_rhs=None, contact_R=None,
+                         contact_p=None, contact_weight=None, contact_maxnormalforce=None, task_weights=None, surfaces=None,
+                         B=None):
+    """L1: assembly + solve from host-evaluated blocks (qpc_assemble_solve_batch)."""
+    lay = ctrl.layout
+    if B is None:  # batch size from the first per-QP array that has a batch axis
+        B = next(np.shape(a)[0] for a in (task_J, momentum_rhs, contact_p, contact_weight) if a is not None and np.ndim(a) >= 2)
+    task_J = None if lay.n_desired == 0 else np.ascontiguousarray(task_J, dtype=np.float64).reshape(B, lay.n_desired, lay.nv)
+
+    def arr(x, n):
+        return None if (x is None or n == 0) else np.ascontiguousarray(x, dtype=np.float64).reshape(B, n)
+    bias, des = arr(task_bias, lay.n_desired), arr(desired, lay.n_desired)
+    Am, mr = arr(momentum_A, 6 * lay.nv), arr(momentum_rhs, 6)
+    cR, cp = arr(contact_R, 9 * lay.n_contacts), arr(contact_p, 3 * lay.n_contacts)
+    cw, cm = arr(contact_weight, lay.n_contacts), arr(contact_maxnormalforce, lay.n_contacts)
+    tw, sf = arr(task_weights, lay.n_task_weights), arr(surfaces, lay.n_surface)
+    vd, wr = np.zeros((B, lay.nv)), np.zeros((B, max(lay.n_contacts, 1) * 6))
+    status, iters = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
+    rc = ctrl.L.qpc_assemble_solve_batch(ctrl.h, B, _dp(task_J), _dp(bias), _dp(des), _dp(Am), _dp(mr), _dp(cR), _dp(cp), _dp(cw),
+                                         _dp(cm), _dp(tw), _dp(sf), _dp(vd), _dp(wr), status.ctypes.data_as(c_int32_p),
+                                         iters.ctypes.data_as(c_int32_p))
+    _check(ctrl.L, rc, "qpc_assemble_solve_batch")
+    return dict(vdot=vd, cwrench=wr[:, :6 * lay.n_contacts].reshape(B, lay.n_contacts, 6), status=status, iters=iters)
 
 
 def qp_solve_batch(P, q, A, l, u, device_id=0, lib_path=None, **settings):

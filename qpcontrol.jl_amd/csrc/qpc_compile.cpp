@@ -439,3 +439,25 @@ int qpc_compile_program(qpc_controller *c) {
   }
   return QPC_OK;
 }
+
+void qpc_l1_build_tables(const qpc_controller *c, std::vector<int> &it, std::vector<double> &dt, int &n, int &m) {
+  const qpc_model *md = c->model;
+  const int nv = md->nv, ntask = (int)c->tasks.size(), nc = (int)c->contacts.size(), N = c->N;
+  int ne = 0, wsize = 0;
+  it.assign(7, 0);
+  dt.assign(c->reg.begin(), c->reg.end());
+  for (auto &t : c->tasks) {
+    int s0 = -1, wo = 0;
+    if (t.wkind != QPC_WEIGHT_HARD) { s0 = ne; ne += t.dim; }
+    if (t.wkind == QPC_WEIGHT_SCALAR || t.wkind == QPC_WEIGHT_MATRIX) { wo = wsize; wsize += (int)t.W.size(); dt.insert(dt.end(), t.W.begin(), t.W.end()); }
+    const int row[6] = {t.dim, t.wkind, t.des_off, s0, wo, t.tw_off};
+    it.insert(it.end(), row, row + 6);
+  }
+  for (auto &k : c->contacts) it.push_back(k.per_qp ? k.surf_off : -1);
+  it.push_back(wsize);
+  for (auto &k : c->contacts) dt.push_back(k.mu);
+  dt.push_back(0.0);
+  it[0] = nv; it[1] = ntask; it[2] = nc; it[3] = N; it[4] = c->floating >= 0 ? 1 : 0; it[5] = ne; it[6] = c->n_desired;
+  n = nv + ne + nc * N;
+  m = c->n_desired + (c->floating >= 0 ? 6 : 0) + nc * N;
+}

@@ -55,3 +55,5 @@ void qpc_set_error(const std::string &msg);
 int qpc_task_dim(const qpc_model *m, int kind, int joint);
 // freeze the controller into prog + layout; returns QPC_OK or an error code
 int qpc_compile_program(qpc_controller *c);
+// static tables of the L1 path (layout documented in qpc_l1_dense.h); n / m = size of its dense QP
+void qpc_l1_build_tables(const qpc_controller *c, std::vector<int> &it, std::vector<double> &dt, int &n, int &m);

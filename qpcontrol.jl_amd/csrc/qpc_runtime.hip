@@ -23,6 +23,7 @@
 #endif
 #include "qpc_tick.h"
 #include "qpc_qp_dense.h"
+#include "qpc_l1_dense.h"
 
 // L0: one lane per dense QP (plumbing path, see qpc_qp_dense.h)
 extern "C" __global__ void __launch_bounds__(64)
@@ -33,6 +34,27 @@ qpc_qp_dense_kernel(int n, int m, long long B, const double *P, const double *q,
   if (b >= B) return;
   qpc::qp_solve_dense(n, m, P + b * n * n, q + b * n, A + b * m * n, l + b * m, u + b * m, st, ws + b * ws_stride,
                       x + b * n, y + b * m, status + b, iters ? iters + b : nullptr);
+}
+
+// L1: one lane per QP, dense assembly from host-evaluated blocks + the L0 solver (qpc_l1_dense.h)
+struct QpcL1Args {
+  long long B;
+  const int *it;
+  const double *dt;
+  const double *J, *bias, *desired, *Am, *mrhs, *cR, *cp, *cw, *cmax, *tw, *surf;
+  double *ws, *vdot, *cwrench;
+  int32_t *status, *iters;
+  long long ws_stride;
+  int nv, nd, nc, ntw, nsurf;
+};
+extern "C" __global__ void __launch_bounds__(64) qpc_l1_kernel(const QpcL1Args a, qpc_settings st) {
+  const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  qpc::L1Prog pg{a.it, a.dt};
+  qpc::l1_assemble_solve(pg, a.J + b * a.nd * a.nv, a.bias + b * a.nd, a.desired + b * a.nd,
+                         a.Am ? a.Am + b * 6 * a.nv : nullptr, a.mrhs ? a.mrhs + b * 6 : nullptr, a.cR + b * 9 * a.nc,
+                         a.cp + b * 3 * a.nc, a.cw + b * a.nc, a.cmax + b * a.nc, a.tw + b * a.ntw, a.surf + b * a.nsurf, st,
+                         a.ws + b * a.ws_stride, a.vdot + b * a.nv, a.cwrench + b * 6 * a.nc, a.status + b, a.iters + b);
 }
 
 struct QpcBatchArgs {
@@ -297,6 +319,71 @@ int32_t qpc_control_batch(qpc_controller *c, int64_t B, const double *q, const d
   if (iters) HIP_TRY(hipMemcpyAsync(iters, diters, B * sizeof(int32_t), hipMemcpyDeviceToHost, S->stream));
   HIP_TRY(hipStreamSynchronize(S->stream));
   return QPC_OK;
+}
+
+int32_t qpc_assemble_solve_batch(qpc_controller *c, int64_t B, const double *task_J, const double *task_bias,
+                                 const double *desired, const double *momentum_A, const double *momentum_rhs,
+                                 const double *contact_R, const double *contact_p, const double *cw, const double *cmax,
+                                 const double *tw, const double *surf, double *vdot, double *cwrench, int32_t *status,
+                                 int32_t *iters) {
+  if (!c || !c->finalized || !c->dev) { qpc_set_error("controller not finalized"); return QPC_ERR_NOT_FINALIZED; }
+  const int nv = c->model->nv, nd = c->n_desired, nc = (int)c->contacts.size(), fl = c->floating >= 0;
+  if (B < 0 || !vdot || !status || (nd && (!task_J || !task_bias || !desired)) || (fl && (!momentum_A || !momentum_rhs)) ||
+      (nc && (!contact_R || !contact_p || !cw || !cmax)) || (c->n_tw && !tw) || (c->n_surf && !surf)) {
+    qpc_set_error("qpc_assemble_solve_batch: missing array"); return QPC_ERR_INVALID_ARGUMENT;
+  }
+  if (B == 0) return QPC_OK;
+  if (c->N > 8) { qpc_set_error("qpc_assemble_solve_batch: friction basis larger than 8"); return QPC_ERR_UNSUPPORTED; }
+  HIP_TRY(hipSetDevice(c->dev->device));
+  std::vector<int> it;
+  std::vector<double> dt;
+  int n = 0, m = 0;
+  qpc_l1_build_tables(c, it, dt, n, m);
+  const long long wsd = qpc::l1_workspace_doubles(n, m);
+  // one device slab: [tables | inputs | workspace | outputs]
+  const size_t nin[11] = {(size_t)nd * nv, (size_t)nd, (size_t)nd, fl ? (size_t)6 * nv : 0, fl ? (size_t)6 : 0, (size_t)9 * nc,
+                          (size_t)3 * nc, (size_t)nc, (size_t)nc, (size_t)c->n_tw, (size_t)c->n_surf};
+  const double *hin[11] = {task_J, task_bias, desired, momentum_A, momentum_rhs, contact_R, contact_p, cw, cmax, tw, surf};
+  size_t total = it.size() * sizeof(int) + 64 + dt.size() * sizeof(double);
+  for (int i = 0; i < 11; i++) total += nin[i] * B * sizeof(double);
+  total += ((size_t)wsd + nv + 6 * (size_t)(nc > 0 ? nc : 1)) * B * sizeof(double) + 2 * (size_t)B * sizeof(int32_t) + 256;
+  char *buf = nullptr;
+  if (hipMalloc(&buf, total) != hipSuccess) { qpc_set_error("qpc_assemble_solve_batch: out of device memory"); return QPC_ERR_OUT_OF_MEMORY; }
+  int rc = QPC_OK;
+  auto chk = [&](hipError_t e, const char *w) { if (e != hipSuccess && rc == QPC_OK) rc = hip_fail(e, w); };
+  char *p = buf;
+  auto take = [&](size_t bytes) { char *r = p; p += (bytes + 63) & ~(size_t)63; return r; };
+  QpcL1Args a;
+  a.B = B; a.nv = nv; a.nd = nd; a.nc = nc; a.ntw = c->n_tw; a.nsurf = c->n_surf; a.ws_stride = wsd;
+  double *ddt = (double *)take(dt.size() * sizeof(double));
+  int *dit = (int *)take(it.size() * sizeof(int));
+  chk(hipMemcpy(ddt, dt.data(), dt.size() * sizeof(double), hipMemcpyHostToDevice), "copy tables");
+  chk(hipMemcpy(dit, it.data(), it.size() * sizeof(int), hipMemcpyHostToDevice), "copy tables");
+  a.it = dit; a.dt = ddt;
+  const double *din[11];
+  for (int i = 0; i < 11; i++) {
+    const size_t bytes = nin[i] * B * sizeof(double);
+    din[i] = (const double *)take(bytes);
+    if (bytes) chk(hipMemcpy((void *)din[i], hin[i], bytes, hipMemcpyHostToDevice), "copy inputs");
+  }
+  a.J = din[0]; a.bias = din[1]; a.desired = din[2]; a.Am = fl ? din[3] : nullptr; a.mrhs = fl ? din[4] : nullptr;
+  a.cR = din[5]; a.cp = din[6]; a.cw = din[7]; a.cmax = din[8]; a.tw = din[9]; a.surf = din[10];
+  a.ws = (double *)take((size_t)wsd * B * sizeof(double));
+  a.vdot = (double *)take((size_t)nv * B * sizeof(double));
+  a.cwrench = (double *)take((size_t)6 * (nc > 0 ? nc : 1) * B * sizeof(double));
+  a.status = (int32_t *)take((size_t)B * sizeof(int32_t));
+  a.iters = (int32_t *)take((size_t)B * sizeof(int32_t));
+  if (rc == QPC_OK) {
+    hipLaunchKernelGGL(qpc_l1_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, 0, a, c->settings);
+    chk(hipGetLastError(), "launch qpc_l1_kernel");
+    chk(hipDeviceSynchronize(), "qpc_l1_kernel");
+    chk(hipMemcpy(vdot, a.vdot, (size_t)nv * B * sizeof(double), hipMemcpyDeviceToHost), "copy vdot");
+    if (cwrench && nc) chk(hipMemcpy(cwrench, a.cwrench, (size_t)6 * nc * B * sizeof(double), hipMemcpyDeviceToHost), "copy wrenches");
+    chk(hipMemcpy(status, a.status, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost), "copy status");
+    if (iters) chk(hipMemcpy(iters, a.iters, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost), "copy iters");
+  }
+  (void)hipFree(buf);
+  return rc;
 }
 
 int32_t qpc_qp_solve_batch(int32_t n, int32_t m, int64_t B, const double *P, const double *q, const double *A,

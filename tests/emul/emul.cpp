@@ -96,6 +96,7 @@ static thread_local double emu_mfma_a[64], emu_mfma_b[64];
          if (v__ < name || (v__ == name && i__ < iname)) { name = v__; iname = i__; } } } while (0)
 #include "../../qpcontrol.jl_amd/csrc/qpc_tick.h"
 #include "../../qpcontrol.jl_amd/csrc/qpc_qp_dense.h"
+#include "../../qpcontrol.jl_amd/csrc/qpc_l1_dense.h"
 
 static long g_races = 0, g_uninit = 0, g_outside = 0;
 static std::string g_first;
@@ -138,6 +139,32 @@ int32_t qpc_control_batch(qpc_controller *c, int64_t B, const double *q, const d
     if (g_first.empty()) g_first = emu.first;
   }
   g_emu = nullptr;
+  return QPC_OK;
+}
+
+// L1 (plain serial code per QP, like L0)
+int32_t qpc_assemble_solve_batch(qpc_controller *c, int64_t B, const double *task_J, const double *task_bias,
+                                 const double *desired, const double *momentum_A, const double *momentum_rhs,
+                                 const double *contact_R, const double *contact_p, const double *cw, const double *cmax,
+                                 const double *tw, const double *surf, double *vdot, double *cwrench, int32_t *status,
+                                 int32_t *iters) {
+  if (!c || !c->finalized) return QPC_ERR_NOT_FINALIZED;
+  const int nv = c->model->nv, nd = c->n_desired, nc = (int)c->contacts.size(), fl = c->floating >= 0;
+  std::vector<int> it;
+  std::vector<double> dt;
+  int n = 0, m = 0;
+  qpc_l1_build_tables(c, it, dt, n, m);
+  std::vector<double> ws(qpc::l1_workspace_doubles(n, m)), wr(6 * (nc > 0 ? nc : 1));
+  qpc::L1Prog pg{it.data(), dt.data()};
+  for (int64_t b = 0; b < B; b++) {
+    int32_t itn = 0;
+    qpc::l1_assemble_solve(pg, task_J + b * nd * nv, task_bias + b * nd, desired + b * nd, fl ? momentum_A + b * 6 * nv : nullptr,
+                           fl ? momentum_rhs + b * 6 : nullptr, contact_R + b * 9 * nc, contact_p + b * 3 * nc, cw + b * nc,
+                           cmax + b * nc, tw ? tw + b * c->n_tw : nullptr, surf ? surf + b * c->n_surf : nullptr, c->settings,
+                           ws.data(), vdot + b * nv, wr.data(), status + b, &itn);
+    if (cwrench) for (int i = 0; i < 6 * nc; i++) cwrench[b * 6 * nc + i] = wr[i];
+    if (iters) iters[b] = itn;
+  }
   return QPC_OK;
 }
 
