@@ -588,15 +588,21 @@ template <class P> struct Solver {
         if (refine > 0) { QPC_RED_MAX_PUT(0, rbig, big); QPC_RED_MAX_PUT(1, rdbig, dbig); }
       } QPC_END_PHASE
       QPC_PROF_ACC(PS_UPDATE);
-      if (it >= refine) break;
+      if (refine <= 0) break;
       rbig = QPC_RED_MAX_GET(0, rbig); rdbig = QPC_RED_MAX_GET(1, rdbig);
-      // converged, or the correction stopped shrinking (rounding floor of this KKT system): further
-      // sweeps only re-apply noise; the acceptance test on the true residuals follows either way
-      // or the NEXT correction, predicted from the observed contraction, is already below tolerance;
+      // Stop when: converged; the correction sits on the rounding floor of this KKT system (small and
+      // no longer shrinking: further sweeps only re-apply noise); the NEXT correction, predicted from
+      // the observed contraction, is already below tolerance; or there is no progress at all.  A
+      // slowly but steadily contracting sequence (Hessian eigenvalues comparable to eps, e.g.
+      // friction coefficients near zero) is allowed up to 5x the nominal sweep count.
       if (it > 0) {
         const double tol = 1e-13 * (1.0 + rbig);
-        if (!(rdbig > tol) || rdbig > 0.25 * prev_dbig) break;
+        if (!(rdbig > tol)) break;
+        if (rdbig > 0.25 * prev_dbig && rdbig < 1e-9 * (1.0 + rbig)) break;
+        if (rdbig > 0.95 * prev_dbig) break;
         if (it >= 2 && rdbig * (rdbig / prev_dbig) < tol) break;
+        if (it >= refine && !(rdbig > 0.25 * prev_dbig)) break; // nominal budget spent and not in the slow regime
+        if (it >= 5 * refine) break;
       }
       prev_dbig = rdbig;
     }
@@ -1536,36 +1542,75 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
   // ---- final refinement on the converged working set + acceptance test (a14)
   int refine = 0;
   if (status == QPC_STATUS_OPTIMAL) {
-    refine = S.eqp(D.max_refine);
-    S.residuals();
-    double arp = 0.0, ars = 0.0, asp = 0.0, ass = 0.0, anan = 0.0;
-    QPC_PHASE(lane) {
-      double rp = 0.0, rs = 0.0, sp = 0.0, ss = 0.0;
-      for (int r = lane; r < m; r += 64) {
-        double a = QPC_FABS(sm[D.lds[L_RC] + r]); rp = a > rp || !(a == a) ? a : rp;
-        double b = QPC_FABS(sm[D.lds[L_D] + r]); sp = b > sp ? b : sp;
-      }
-      for (int f = lane; f < nf; f += 64) {
-        double a = QPC_FABS(sm[D.lds[L_RV] + f]); rs = a > rs || !(a == a) ? a : rs;
-        double b = QPC_FABS(sm[D.lds[L_GV] + f]); ss = b > ss ? b : ss;
-        // |E_v' lam| scale
-        double mtl = 0.0;
-        for (int r = 0; r < m; r++) mtl += sm[D.lds[L_M] + r * D.nfs + f] * sm[D.lds[L_LAM] + r];
-        b = QPC_FABS(mtl / sm[D.lds[L_SQH] + f]); ss = b > ss ? b : ss;
-      }
-      for (int s = lane; s < ne; s += 64) { double a = QPC_FABS(sm[D.lds[L_RE] + s]); rs = a > rs || !(a == a) ? a : rs; }
-      for (int j = lane; j < nrho; j += 64) { double a = QPC_FABS(sm[D.lds[L_RR] + j]); rs = a > rs || !(a == a) ? a : rs; }
-      double bad = (!(rp == rp) || !(rs == rs)) ? 1.0 : 0.0;
-      QPC_RED_MAX_PUT(0, arp, rp == rp ? rp : 0.0); QPC_RED_MAX_PUT(1, ars, rs == rs ? rs : 0.0);
-      QPC_RED_MAX_PUT(2, asp, sp); QPC_RED_MAX_PUT(3, ass, ss); QPC_RED_MAX_PUT(4, anan, bad);
-    } QPC_END_PHASE
-    arp = QPC_RED_MAX_GET(0, arp); ars = QPC_RED_MAX_GET(1, ars); asp = QPC_RED_MAX_GET(2, asp);
-    ass = QPC_RED_MAX_GET(3, ass); anan = QPC_RED_MAX_GET(4, anan);
-    const bool nan = anan > 0.0;
-    double r_prim = arp / (1.0 + asp), r_stat = ars / (1.0 + ass);
-    if (nan || !(r_prim < 1e300) || !(r_stat < 1e300)) status = QPC_STATUS_NUMERICAL_ERROR;
-    else if (r_prim > D.tol_accept) status = QPC_STATUS_INFEASIBLE; // equality rows inconsistent on the feasible set
-    else if (r_stat > D.tol_accept) status = QPC_STATUS_ALMOST_OPTIMAL;
+    for (int outer = 0;; outer++) {
+      refine = S.eqp(D.max_refine);
+      S.residuals();
+      double arp = 0.0, ars = 0.0, asp = 0.0, ass = 0.0, anan = 0.0, abv = 0.0, agm = 0.0, axm = 0.0;
+      QPC_PHASE(lane) {
+        double rp = 0.0, rs = 0.0, sp = 0.0, ss = 0.0, bv = 0.0, gm = 0.0, xm = 0.0;
+        for (int r = lane; r < m; r += 64) {
+          double a = QPC_FABS(sm[D.lds[L_RC] + r]); rp = a > rp || !(a == a) ? a : rp;
+          double b = QPC_FABS(sm[D.lds[L_D] + r]); sp = b > sp ? b : sp;
+        }
+        for (int f = lane; f < nf; f += 64) {
+          double a = QPC_FABS(sm[D.lds[L_RV] + f]); rs = a > rs || !(a == a) ? a : rs;
+          double b = QPC_FABS(sm[D.lds[L_GV] + f]); ss = b > ss ? b : ss;
+          // |E_v' lam| scale
+          double mtl = 0.0;
+          for (int r = 0; r < m; r++) mtl += sm[D.lds[L_M] + r * D.nfs + f] * sm[D.lds[L_LAM] + r];
+          b = QPC_FABS(mtl / sm[D.lds[L_SQH] + f]); ss = b > ss ? b : ss;
+        }
+        for (int s = lane; s < ne; s += 64) { double a = QPC_FABS(sm[D.lds[L_RE] + s]); rs = a > rs || !(a == a) ? a : rs; }
+        for (int j = lane; j < nrho; j += 64) {
+          double a = QPC_FABS(sm[D.lds[L_RR] + j]); rs = a > rs || !(a == a) ? a : rs;
+          // bound conditions of the REFINED solution (the search decided on eps-regularised solves):
+          // L_TR1 = Lagrangian gradient w.r.t. rho (Solver::residuals)
+          const double w = sm[D.lds[L_WS] + j], hi = sm[D.lds[L_HI] + j], x = sm[D.lds[L_XR] + j], gl = sm[D.lds[L_TR1] + j];
+          if (hi > 0.0) {
+            const double u = (w == -1.0) ? gl : ((w == 1.0) ? -gl : 0.0);
+            sm[D.lds[L_U] + j] = u;
+            gm = QPC_FABS(gl) > gm ? QPC_FABS(gl) : gm;
+            xm = QPC_FABS(x) > xm ? QPC_FABS(x) : xm;
+          }
+        }
+        double bad = (!(rp == rp) || !(rs == rs)) ? 1.0 : 0.0;
+        QPC_RED_MAX_PUT(0, arp, rp == rp ? rp : 0.0); QPC_RED_MAX_PUT(1, ars, rs == rs ? rs : 0.0);
+        QPC_RED_MAX_PUT(2, asp, sp); QPC_RED_MAX_PUT(3, ass, ss); QPC_RED_MAX_PUT(4, anan, bad);
+        QPC_RED_MAX_PUT(5, agm, gm); QPC_RED_MAX_PUT(6, axm, xm);
+      } QPC_END_PHASE
+      arp = QPC_RED_MAX_GET(0, arp); ars = QPC_RED_MAX_GET(1, ars); asp = QPC_RED_MAX_GET(2, asp);
+      ass = QPC_RED_MAX_GET(3, ass); anan = QPC_RED_MAX_GET(4, anan);
+      agm = QPC_RED_MAX_GET(5, agm); axm = QPC_RED_MAX_GET(6, axm);
+      const bool nan = anan > 0.0;
+      double r_prim = arp / (1.0 + asp), r_stat = ars / (1.0 + ass);
+      if (nan || !(r_prim < 1e300) || !(r_stat < 1e300)) { status = QPC_STATUS_NUMERICAL_ERROR; break; }
+      if (r_prim > D.tol_accept) { status = QPC_STATUS_INFEASIBLE; break; } // equality rows inconsistent on the feasible set
+      if (r_stat > D.tol_accept) status = QPC_STATUS_ALMOST_OPTIMAL;
+      if (!use_rho) break;
+      // primal-dual test on the refined solution, at the acceptance tolerance: normally nothing moves
+      // (one phase); if the eps-regularised search settled on a working set that is not optimal for
+      // the true problem (near-degenerate friction cones), correct it and polish again
+      S.last_gmax = agm; S.last_xmax = axm;
+      QPC_PHASE(lane) {
+        double changed = 0.0;
+        const double tolu = D.tol_accept * (1.0 + agm), tolb = D.tol_accept * (1.0 + axm);
+        for (int j = lane; j < nrho; j += 64) {
+          double w = sm[D.lds[L_WS] + j], hi = sm[D.lds[L_HI] + j], x = sm[D.lds[L_XR] + j], nw_ = w;
+          if (!(hi > 0.0)) continue;
+          if (w != 0.0) { if (sm[D.lds[L_U] + j] < -tolu) nw_ = 0.0; }
+          else if (x < -tolb) nw_ = -1.0;
+          else if (x > hi + tolb) nw_ = 1.0;
+          if (nw_ != w) { changed = 1.0; if (outer < 8) sm[D.lds[L_WS] + j] = nw_; }
+        }
+        QPC_RED_MAX_PUT(0, abv, changed);
+      } QPC_END_PHASE
+      abv = QPC_RED_MAX_GET(0, abv);
+      if (!(abv > 0.0)) break;
+      if (outer >= 8) { status = QPC_STATUS_ITERATION_LIMIT; break; }
+      status = QPC_STATUS_OPTIMAL;
+      iters++;
+      S.refactor_rho();
+    }
   }
 
   QPC_PROF_ACC(PS_FINAL);

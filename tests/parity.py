@@ -14,12 +14,15 @@ def compare(g, rg, o, ro, check_floating_zero=True):
     conclusive = (so == 0) | (so == 2)
     assert np.array_equal((sg == 0)[conclusive], (so == 0)[conclusive]), (sg, so)
     ok = so == 0
-    assert ok.any()
-    for b in np.where(~conclusive & (sg == 0))[0]:
+    certified = np.where(~conclusive & (sg == 0))[0]
+    assert ok.any() or len(certified), "nothing to compare: no OPTIMAL element on either side"
+    for b in certified:
         c = kkt_check.certify(o.ctrl, o.q[b], o.v[b], o.desired[b], o.cweight[b], o.cmaxf[b], rg["vdot"][b],
                               rg["cwrench"][b], None if o.tw is None else o.tw[b], None if o.surf is None else o.surf[b])
         assert c["ok"], (g.name, b, c["primal"], c["stationarity"])
-    if np.isfinite(g.tol_tau):
+    if not ok.any():
+        pass  # every OPTIMAL answer of the backend was certified independently above
+    elif np.isfinite(g.tol_tau):
         np.testing.assert_allclose(rg["tau"][ok], ro["tau"][ok], atol=g.tol_tau, rtol=0)
         np.testing.assert_allclose(rg["cwrench"][ok], ro["cwrench"][ok], atol=100 * g.tol_tau, rtol=0)
         np.testing.assert_allclose(rg["vdot"][ok], ro["vdot"][ok], atol=g.tol_tau, rtol=0)
