@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 NAMES = ["kinematics", "assembly", "schur_build", "cholesky", "x_inverse", "refactor_rho", "residuals", "kkt_solve",
          "update", "logic", "final_refine", "rnea", "k_input", "k_joint", "k_world", "k_subspace_inertia", "k_twist",
-         "k_bias_crb"]
+         "k_bias_crb", "sweep_kr", "sweep_y", "sweep_c22", "sweep_chol", "sweep_back", "sweep_test"]
 
 
 def main():

@@ -24,28 +24,57 @@
 #endif
 
 namespace qpc {
-// wave-uniform reductions over the 64 lanes (butterfly over ds_bpermute/DPP; no LDS traffic)
+// Wave-uniform reductions over the 64 lanes through DPP row shifts / row broadcasts: VALU only
+// (3 short instructions per step for a double: two v_mov_dpp halves + one v_max/min_f64), against
+// the 12 dependent ds_bpermute round trips of a __shfl_xor butterfly -- the reductions sit on the
+// critical path of every active-set sweep.  All 64 lanes must be active (phase level only).
+// DPP controls: row_shr:n = 0x110 + n, row_bcast:15 = 0x142 (row_mask 0xa), row_bcast:31 = 0x143
+// (row_mask 0xc); lanes without a valid source keep `old` = their own value (neutral for max/min).
+// The result is complete in lane 63 and broadcast with v_readlane.
+#define QPC_DPP_STEPS(OP)                                                                          \
+  OP(0x111, 0xf) OP(0x112, 0xf) OP(0x114, 0xf) OP(0x118, 0xf) OP(0x142, 0xa) OP(0x143, 0xc)
 __device__ __forceinline__ double wave_max(double x) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { double y = __shfl_xor(x, o, 64); x = y > x ? y : x; }
-  return x;
+#define QPC_DPP_OP(ctrl, rmask)                                                                    \
+  {                                                                                                \
+    const int lo__ = __double2loint(x), hi__ = __double2hiint(x);                                  \
+    const int tl__ = __builtin_amdgcn_update_dpp(lo__, lo__, ctrl, rmask, 0xf, false);             \
+    const int th__ = __builtin_amdgcn_update_dpp(hi__, hi__, ctrl, rmask, 0xf, false);             \
+    x = fmax(x, __hiloint2double(th__, tl__));                                                     \
+  }
+  QPC_DPP_STEPS(QPC_DPP_OP)
+#undef QPC_DPP_OP
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 63), __builtin_amdgcn_readlane(__double2loint(x), 63));
 }
 __device__ __forceinline__ double wave_min(double x) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { double y = __shfl_xor(x, o, 64); x = y < x ? y : x; }
-  return x;
+#define QPC_DPP_OP(ctrl, rmask)                                                                    \
+  {                                                                                                \
+    const int lo__ = __double2loint(x), hi__ = __double2hiint(x);                                  \
+    const int tl__ = __builtin_amdgcn_update_dpp(lo__, lo__, ctrl, rmask, 0xf, false);             \
+    const int th__ = __builtin_amdgcn_update_dpp(hi__, hi__, ctrl, rmask, 0xf, false);             \
+    x = fmin(x, __hiloint2double(th__, tl__));                                                     \
+  }
+  QPC_DPP_STEPS(QPC_DPP_OP)
+#undef QPC_DPP_OP
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 63), __builtin_amdgcn_readlane(__double2loint(x), 63));
 }
 __device__ __forceinline__ int wave_min_int(int x) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { int y = __shfl_xor(x, o, 64); x = y < x ? y : x; }
-  return x;
+#define QPC_DPP_OP(ctrl, rmask)                                                                    \
+  {                                                                                                \
+    const int t__ = __builtin_amdgcn_update_dpp(x, x, ctrl, rmask, 0xf, false);                    \
+    x = t__ < x ? t__ : x;                                                                         \
+  }
+  QPC_DPP_STEPS(QPC_DPP_OP)
+#undef QPC_DPP_OP
+  return __builtin_amdgcn_readlane(x, 63);
 }
+#undef QPC_DPP_STEPS
 } // namespace qpc
 
 // reductions that straddle a phase boundary: *_PUT inside the phase (every lane, exactly once),
 // *_GET after QPC_END_PHASE.  `name` is a double (and `iname` an int) declared before the phase.
 #define QPC_RED_MAX_PUT(slot, name, val) name = qpc::wave_max(val)
 #define QPC_RED_MAX_GET(slot, name) (name)
+
 #define QPC_RED_ARGMIN_PUT(slot, name, iname, val, idx) \
   do { double v__ = (val); name = qpc::wave_min(v__); iname = qpc::wave_min_int(v__ == name ? (int)(idx) : 0x3fffffff); } while (0)
 #define QPC_RED_ARGMIN_GET(slot, name, iname) ((void)0)

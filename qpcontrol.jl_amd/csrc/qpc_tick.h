@@ -37,7 +37,8 @@
 #define QPC_PROF_ACC(i)
 #endif
 enum { PS_KIN, PS_ASM, PS_SBUILD, PS_CHOL, PS_XINV, PS_REFAC, PS_RESID, PS_KKT, PS_UPDATE, PS_LOGIC, PS_FINAL, PS_RNEA,
-       PS_K_INPUT, PS_K_JOINT, PS_K_WORLD, PS_K_SUBSP, PS_K_TWIST, PS_K_BIAS, PS_COUNT };
+       PS_K_INPUT, PS_K_JOINT, PS_K_WORLD, PS_K_SUBSP, PS_K_TWIST, PS_K_BIAS,
+       PS_S_KR, PS_S_Y, PS_S_C22, PS_S_CHOL, PS_S_BACK, PS_S_TEST, PS_COUNT };
 
 namespace qpc {
 
@@ -406,19 +407,21 @@ template <class P> struct Solver {
         if (N <= 4) kr_block<4>(sm, D, c, eps); else kr_block<8>(sm, D, c, eps);
       }
     } QPC_END_PHASE
+    QPC_PROF_ACC(PS_S_KR);
     QPC_PHASE(lane) {
       for (int idx = lane; idx < nrho * 6; idx += 64) {
         int j = idx / 6, b = idx % 6, c = j / N, jj = j % N;
         sm[D.lds[L_Y] + j * 6 + b] = dotp(sm + D.lds[L_KR] + c * N * N + jj * N, 1, sm + D.lds[L_G] + b * nrho + c * N, 1, N);
       }
     } QPC_END_PHASE
+    QPC_PROF_ACC(PS_S_Y);
     QPC_PHASE(lane) {
       if (lane < 36) {
         int a = lane / 6, b = lane % 6;
         sm[D.lds[L_C22] + lane] = sm[D.lds[L_B22] + lane] + dotp(sm + D.lds[L_G] + a * nrho, 1, sm + D.lds[L_Y] + b, 6, nrho);
       }
     } QPC_END_PHASE
-    QPC_PROF_ACC(PS_REFAC);
+    QPC_PROF_ACC(PS_S_C22);
     QPC_PHASE(lane) {
       if (lane < 7) {
         double sref[6], x[6], rhs[6];
@@ -432,8 +435,8 @@ template <class P> struct Solver {
         }
       }
     } QPC_END_PHASE
-    rho_back(true, false);
-    QPC_PROF_ACC(PS_KKT);
+    QPC_PROF_ACC(PS_S_CHOL);
+    rho_back(true, false, PS_S_BACK);
   }
 
   // lam = S^-1 t (t in L_T1, result in `out`) through the block inverse:
@@ -610,7 +613,7 @@ template <class P> struct Solver {
   }
 
   // rho_F = K (r_r + G' lam_w) (+ rho_fix) and, in base mode, the bound multipliers and scales
-  QPC_FN void rho_back(bool base, bool need_kr) {
+  QPC_FN void rho_back(bool base, bool need_kr, int section = PS_KKT) {
     const int N = D.N, nrho = D.nrho, m1 = D.m1;
     const int outr = base ? D.lds[L_XR] : D.lds[L_DR], outl = (base ? D.lds[L_LAM] : D.lds[L_DL]) + m1;
     double rg = 0.0, rx = 0.0;
@@ -644,7 +647,7 @@ template <class P> struct Solver {
       if (base) { QPC_RED_MAX_PUT(0, rg, g); QPC_RED_MAX_PUT(1, rx, xm); }
     } QPC_END_PHASE
     if (base) { last_gmax = QPC_RED_MAX_GET(0, rg); last_xmax = QPC_RED_MAX_GET(1, rx); }
-    QPC_PROF_ACC(PS_KKT);
+    QPC_PROF_ACC(section);
   }
 
   // ---- wrench-space solves for the active-set SEARCH --------------------------------------
@@ -1443,6 +1446,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       } QPC_END_PHASE
       rchg = QPC_RED_MAX_GET(0, rchg);
       rup = QPC_RED_MAX_GET(1, rup);
+      QPC_PROF_ACC(PS_S_TEST);
       if (!(rchg > 0.0)) break;
       any_upper = rup > 0.0;
       iters++;
