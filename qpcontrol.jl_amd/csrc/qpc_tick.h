@@ -8,7 +8,7 @@
 // The includer defines before including this file:
 //   QPC_FN                    function qualifier (__device__ __forceinline__ / inline)
 //   QPC_PHASE(lane) ... QPC_END_PHASE   per-lane block + barrier
-//   QPC_SINCOS(x, s, c), QPC_SQRT(x), QPC_FABS(x)
+//   QPC_SINCOS(x, s, c), QPC_SQRT(x), QPC_FABS(x), QPC_RCP(x) = 1/x, QPC_RSQRT(x) = 1/sqrt(x) (pivots: ~1 ulp)
 // and instantiates qpc_tick<P> with P = LDS pointer type (double* on the device).
 //
 // Replaces, per reference function:
@@ -196,7 +196,7 @@ template <int NB, class P> QPC_FN void kr_block(P sm, const QpcDims &D, int c, d
     }
 #pragma unroll
   for (int k = 0; k < NB; k++) {
-    double piv = 1.0 / a[k][k];
+    double piv = QPC_RCP(a[k][k]);
     a[k][k] = 1.0;
 #pragma unroll
     for (int j = 0; j < NB; j++) a[k][j] *= piv;
@@ -216,52 +216,6 @@ template <int NB, class P> QPC_FN void kr_block(P sm, const QpcDims &D, int c, d
       if (i < N && j < N) sm[D.lds[L_KR] + c * N * N + i * N + j] = (fr[i] && fr[j]) ? a[i][j] : 0.0;
 }
 
-// T = S^-1 of a symmetric 6x6 (infinite-pivot Cholesky: a dependent row gets a zero row/column in
-// T), all in registers of ONE lane.  `sref[k]` is the reference (unreduced) diagonal for the test.
-template <class P> QPC_FN void inv6_spd(P Sin, const double *sref, double tau, P Tout) {
-  double L[6][6], X[6][6], invd[6];
-#pragma unroll
-  for (int i = 0; i < 6; i++)
-#pragma unroll
-    for (int j = 0; j < 6; j++) { L[i][j] = (j <= i) ? (double)Sin[i * 6 + j] : 0.0; X[i][j] = 0.0; }
-#pragma unroll
-  for (int k = 0; k < 6; k++) {
-    double d = L[k][k];
-#pragma unroll
-    for (int j = 0; j < k; j++) d -= L[k][j] * L[k][j];
-    bool ok = d > tau * (sref[k] > 1e-300 ? sref[k] : 1e-300);
-    double ld_ = ok ? QPC_SQRT(d) : 0.0;
-    invd[k] = ok ? 1.0 / ld_ : 0.0;
-    L[k][k] = ld_;
-#pragma unroll
-    for (int i = k + 1; i < 6; i++) {
-      double t = L[i][k];
-#pragma unroll
-      for (int j = 0; j < k; j++) t -= L[i][j] * L[k][j];
-      L[i][k] = t * invd[k];
-    }
-  }
-#pragma unroll
-  for (int c = 0; c < 6; c++)
-#pragma unroll
-    for (int r = c; r < 6; r++) {
-      double t = (r == c) ? 1.0 : 0.0;
-#pragma unroll
-      for (int j = c; j < r; j++) t -= L[r][j] * X[j][c];
-      X[r][c] = t * invd[r];
-    }
-#pragma unroll
-  for (int a = 0; a < 6; a++)
-#pragma unroll
-    for (int b = 0; b <= a; b++) {
-      double t = 0.0;
-#pragma unroll
-      for (int k = a; k < 6; k++) t += X[k][a] * X[k][b];
-      Tout[a * 6 + b] = t;
-      if (a != b) Tout[b * 6 + a] = t;
-    }
-}
-
 // x = S^-1 rhs for a symmetric 6x6 S: Cholesky in registers then forward/back substitution (with
 // rhs = e_c this is column c of S^-1: 6 lanes, one column each, one phase).  A pivot
 // below tau * sref[k] marks a redundant row: zero row/column in T (infinite-pivot rule).
@@ -277,8 +231,7 @@ template <class P> QPC_FN void chol6_solve(P Sin, const double *sref, double tau
     QPC_UNROLL_FULL
     for (int j = 0; j < k; j++) d -= L[k][j] * L[k][j];
     bool ok = d > tau * (sref[k] > 1e-300 ? sref[k] : 1e-300);
-    double ld_ = ok ? QPC_SQRT(d) : 0.0;
-    invd[k] = ok ? 1.0 / ld_ : 0.0;
+    invd[k] = ok ? QPC_RSQRT(d) : 0.0; // 1 / L_kk
     QPC_UNROLL_FULL
     for (int i = k + 1; i < 6; i++) {
       double t = L[i][k];
@@ -1362,7 +1315,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
           }
           double skk = sm[D.lds[L_SM] + k * D.ms + k], srk = sm[D.lds[L_SM] + r * D.ms + k], dk = skk - acck;
           bool ok = dk > D.tau_pivot * (skk > 1e-300 ? skk : 1e-300);
-          double ld_ = ok ? QPC_SQRT(dk) : 0.0, inv = ok ? 1.0 / ld_ : 0.0;
+          const double inv = ok ? QPC_RSQRT(dk) : 0.0; // 1 / L_kk
           if (r == k) sm[D.lds[L_T1] + k] = inv; // 1/L_kk (0 = dropped row)
           else { double v = (srk - accr) * inv; lrow[k] = v; sm[D.lds[L_SM] + r * D.ms + k] = v; }
         }

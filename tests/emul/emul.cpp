@@ -67,6 +67,8 @@ struct Lds {
 #define QPC_SQRT(x) std::sqrt((double)(x))
 #define QPC_FABS(x) std::fabs((double)(x))
 #define QPC_ATAN2(y, x) std::atan2((double)(y), (double)(x))
+#define QPC_RCP(x) (1.0 / (double)(x))
+#define QPC_RSQRT(x) (1.0 / std::sqrt((double)(x)))
 #define QPC_LANE_ARRAY(name, n) double name[64][n]
 #define QPC_LA(name, lane) name[lane]
 #define QPC_LANE_INTS(name, n) int name[64][n]
