@@ -49,6 +49,9 @@ int qpc_compile_program(qpc_controller *c) {
   D.floating = c->floating;
   D.fv0 = c->floating >= 0 ? m->voff[c->floating] : -1;
   D.n_desired = c->n_desired; D.n_tw = c->n_tw; D.n_surf = c->n_surf;
+  D.ve_exact_ok = 1;
+  for (auto &t : c->tasks)
+    if (t.wkind == QPC_WEIGHT_MATRIX || t.wkind == QPC_WEIGHT_MATRIX_PER_QP) D.ve_exact_ok = 0; // eigenvalues not on the diagonal
   if (c->floating >= 0 && m->jtype[c->floating] != QPC_JOINT_QUAT_FLOATING) {
     qpc_set_error("floating_body must be the successor of a QuaternionFloating joint");
     return QPC_ERR_INVALID_ARGUMENT;

@@ -117,6 +117,7 @@ struct QpcDims {
   int nb, nq, nv, nf, npin, nsj, ntask, nc, N, nrho, ne, m, m1, nw;
   int floating, fv0; // floating body and its first velocity index (or -1)
   int n_desired, n_tw, n_surf, maxdepth;
+  int ve_exact_ok; // no matrix-weighted slack block: the v̇ / slack blocks of H may be used unregularised (exact polish)
   int n_des_inputs, n_des_late; // desired entries read from the caller / computed after the kinematics (COM, orientation laws)
   int maxd; // row length of IT_ANC_TAB
   int crb_full_body; // body whose subtree is the whole mechanism and owns free columns (its composite inertia = total), or -1

@@ -278,6 +278,8 @@ template <class P> struct Solver {
   bool use_rho;
   unsigned long long *PA, *PT; // section timers (diagnostic build)
   double last_gmax = 0.0, last_xmax = 0.0; // scales of the last base rho_solve (uniform)
+  double last_dmax = 0.0;                   // max |rho - rho_prev| of the last proximal sweep (uniform)
+  bool c_valid = false;                     // L_T1 holds c = E H^-1 (-g) - d (clobbered by kkt_solve)
   // hot lookups staged in LDS (IT_HOT)
   QPC_FN int row_slack(int r) const { return (int)(double)sm[D.lds[L_HOT] + r]; }
   QPC_FN int slack_row(int s) const { return (int)(double)sm[D.lds[L_HOT] + D.m + s]; }
@@ -418,6 +420,7 @@ template <class P> struct Solver {
   // result in L_DV (scaled: dx_v / sqh), L_DE, L_DR, L_DL.
   QPC_FN void kkt_solve() {
     const int N = D.N, nf = D.nf, ne = D.ne, nrho = D.nrho, m = D.m, m1 = D.m1;
+    c_valid = false;
     QPC_PROF_ACC(PS_LOGIC);
     QPC_PHASE(lane) {
       if (use_rho)
@@ -505,15 +508,18 @@ template <class P> struct Solver {
   }
 
   // EQP of the current working set from scratch + `refine` iterative-refinement sweeps
-  QPC_FN int eqp(int refine) {
+  // from_current: keep the iterate (x, lam) and only run refinement sweeps on it
+  QPC_FN int eqp(int refine, bool from_current = false) {
     const int nf = D.nf, ne = D.ne, nrho = D.nrho, m = D.m;
-    QPC_PHASE(lane) {
-      for (int f = lane; f < nf; f += 64) sm[D.lds[L_XV] + f] = 0.0;
-      for (int s = lane; s < ne; s += 64) sm[D.lds[L_XE] + s] = 0.0;
-      for (int r = lane; r < m; r += 64) sm[D.lds[L_LAM] + r] = 0.0;
-      for (int j = lane; j < nrho; j += 64) sm[D.lds[L_XR] + j] = (sm[D.lds[L_WS] + j] == 1.0) ? sm[D.lds[L_HI] + j] : 0.0;
-    } QPC_END_PHASE
-    int it = 0;
+    if (!from_current) {
+      QPC_PHASE(lane) {
+        for (int f = lane; f < nf; f += 64) sm[D.lds[L_XV] + f] = 0.0;
+        for (int s = lane; s < ne; s += 64) sm[D.lds[L_XE] + s] = 0.0;
+        for (int r = lane; r < m; r += 64) sm[D.lds[L_LAM] + r] = 0.0;
+        for (int j = lane; j < nrho; j += 64) sm[D.lds[L_XR] + j] = (sm[D.lds[L_WS] + j] == 1.0) ? sm[D.lds[L_HI] + j] : 0.0;
+      } QPC_END_PHASE
+    }
+    int it = from_current ? 1 : 0;
     double prev_dbig = 1e300;
     for (;; it++) {
       if (it == 0) fresh_rhs(); else residuals();
@@ -554,6 +560,9 @@ template <class P> struct Solver {
       if (it > 0) {
         const double tol = 1e-13 * (1.0 + rbig);
         if (!(rdbig > tol)) break;
+        // first correction of an already polished iterate: its size IS the error estimate of that
+        // iterate, and the corrected one is better by the contraction factor (<= 1e-5)
+        if (from_current && it == 1 && !(rdbig > 1e-9 * (1.0 + rbig))) break;
         if (rdbig > 0.25 * prev_dbig && rdbig < 1e-9 * (1.0 + rbig)) break;
         if (rdbig > 0.95 * prev_dbig) break;
         if (it >= 2 && rdbig * (rdbig / prev_dbig) < tol) break;
@@ -566,13 +575,13 @@ template <class P> struct Solver {
   }
 
   // rho_F = K (r_r + G' lam_w) (+ rho_fix) and, in base mode, the bound multipliers and scales
-  QPC_FN void rho_back(bool base, bool need_kr, int section = PS_KKT) {
+  QPC_FN void rho_back(bool base, bool need_kr, int section = PS_KKT, bool prox = false) {
     const int N = D.N, nrho = D.nrho, m1 = D.m1;
     const int outr = base ? D.lds[L_XR] : D.lds[L_DR], outl = (base ? D.lds[L_LAM] : D.lds[L_DL]) + m1;
-    double rg = 0.0, rx = 0.0;
+    double rg = 0.0, rx = 0.0, rd = 0.0;
     QPC_PHASE(lane) { // rho_F = K (r_r + G' lam_w) (+ rho_fix); each lane rebuilds its contact's N rho's,
                       // and in base mode also its multiplier u_j = +-(H_rho rho - G' lam_w)_j
-      double g = 0.0, xm = 0.0;
+      double g = 0.0, xm = 0.0, dm = 0.0;
       for (int j = lane; j < nrho; j += 64) {
         int c = j / N, jj = j % N;
         double w[8], rho_c[8];
@@ -587,6 +596,7 @@ template <class P> struct Solver {
           if (base && sm[D.lds[L_WS] + c * N + i2] == 1.0) acc += sm[D.lds[L_HI] + c * N + i2];
           rho_c[i2] = acc;
         }
+        if (prox) { const double dl_ = QPC_FABS(rho_c[jj] - (double)sm[outr + j]); dm = dl_ > dm ? dl_ : dm; }
         sm[outr + j] = rho_c[jj];
         if (base) {
           double gl = -g;
@@ -598,8 +608,10 @@ template <class P> struct Solver {
         }
       }
       if (base) { QPC_RED_MAX_PUT(0, rg, g); QPC_RED_MAX_PUT(1, rx, xm); }
+      if (prox) { QPC_RED_MAX_PUT(2, rd, dm); }
     } QPC_END_PHASE
     if (base) { last_gmax = QPC_RED_MAX_GET(0, rg); last_xmax = QPC_RED_MAX_GET(1, rx); }
+    if (prox) last_dmax = QPC_RED_MAX_GET(2, rd);
     QPC_PROF_ACC(section);
   }
 
@@ -611,11 +623,12 @@ template <class P> struct Solver {
   // refined full solve at the end.
   //   base = true : EQP of the working set (r_r = -(H_rho rho_fix)_F), result -> L_XR, L_LAM[m1..]
   //   base = false: Goldfarb-Idnani direction for r_r = nsign * e_p,   result -> L_DR, L_DL[m1..]
-  QPC_FN void rho_solve(bool base, int p, double nsign, bool any_upper) {
+  QPC_FN void rho_solve(bool base, int p, double nsign, bool any_upper, bool prox = false) {
     const int N = D.N, nrho = D.nrho, m1 = D.m1;
     const int outr = base ? D.lds[L_XR] : D.lds[L_DR], outl = (base ? D.lds[L_LAM] : D.lds[L_DL]) + m1;
     QPC_PROF_ACC(PS_LOGIC);
-    const bool need_kr = !base || any_upper;
+    const bool need_kr = !base || any_upper || prox;
+    const double eps_prox = prox ? (double)sm[D.lds[L_MISC] + MS_EPS] : 0.0;
     if (need_kr) {
       QPC_PHASE(lane) { // TR1 = K r_r + rho_fix ; RR kept for the back-substitution
         for (int j = lane; j < nrho; j += 64) {
@@ -626,6 +639,8 @@ template <class P> struct Solver {
             // r_r(i) = -(H rho_fix)_i on free i ;  acc = sum_i K[jj][i] r_r(i)
             for (int i = 0; i < N; i++) {
               double rr = (sm[D.lds[L_WS] + c * N + i] == 0.0) ? -dot_fix(D.lds[L_HR] + c * N * N + i * N, 1, c * N, N) : 0.0;
+              // proximal sweep: the eps of K = (H_FF + eps I)^-1 is compensated by eps * rho_prev
+              if (prox && sm[D.lds[L_WS] + c * N + i] == 0.0) rr += eps_prox * sm[D.lds[L_XR] + c * N + i];
               acc += sm[D.lds[L_KR] + c * N * N + jj * N + i] * rr;
               if (i == jj) sm[D.lds[L_RR] + j] = rr;
             }
@@ -649,7 +664,7 @@ template <class P> struct Solver {
     QPC_PHASE(lane) {
       if (lane < 6) sm[outl + lane] = dotp(sm + D.lds[L_S22I] + lane * 6, 1, sm + (need_kr ? D.lds[L_C22] : D.lds[L_MISC] + MS_U0), 1, 6);
     } QPC_END_PHASE
-    rho_back(base, need_kr);
+    rho_back(base, need_kr, PS_KKT, prox);
     QPC_PROF_ACC(PS_KKT);
   }
 
@@ -675,6 +690,65 @@ template <class P> struct Solver {
     } QPC_END_PHASE
     gmax = QPC_RED_MAX_GET(0, rg);
     xmax = QPC_RED_MAX_GET(1, rx);
+  }
+
+  // c = E H^-1 (-g) - d -> L_T1 (all rows), with -sqh .* g as a by-product in L_XV
+  QPC_FN void compute_c() {
+    const int nf = D.nf, m = D.m;
+    QPC_PHASE(lane) {
+      for (int f = lane; f < nf; f += 64) sm[D.lds[L_XV] + f] = -sm[D.lds[L_SQH] + f] * sm[D.lds[L_GV] + f];
+    } QPC_END_PHASE
+    QPC_PHASE(lane) {
+      for (int r = lane; r < m; r += 64)
+        sm[D.lds[L_T1] + r] = dotp(sm + D.lds[L_M] + r * D.nfs, 1, sm + D.lds[L_XV], 1, nf) - sm[D.lds[L_D] + r];
+    } QPC_END_PHASE
+    c_valid = true;
+  }
+
+  // Final solve of the EQP on the converged working set when the v̇ and slack blocks of the Hessian
+  // are used UNREGULARISED (exact_ve): the only eps left is the one inside K = (H_rho,FF + eps I)^-1,
+  // and rho enters the equality block through the 6 wrench rows alone.  So the eps bias is removed by
+  // proximal sweeps in wrench space (each one a rho_solve with r_r += eps rho_prev: 4 short phases,
+  // contraction eps / lambda_min(H_rho) ~ 1e-6 per sweep), and v̇, slacks and task-row multipliers
+  // follow from ONE back-substitution:  lam_1 = S11^-1 c_1 - Z lam_w ,  x_v = H_v^-1 (-g - E_v' lam),
+  // e = W^-1 lam_slack -- instead of 3-4 refinement sweeps of the full KKT system.  The caller checks
+  // the true residuals afterwards and falls back to eqp(from_current) if they are not at rounding level.
+  QPC_FN int polish_exact(bool any_upper) {
+    const int nf = D.nf, ne = D.ne, m1 = D.m1, nw = D.nw, m = D.m;
+    int k = 0;
+    if (!c_valid) compute_c();
+    if (use_rho) {
+      double prev = 1e300;
+      for (k = 1; k <= 10; k++) {
+        rho_solve(true, 0, 0.0, any_upper, true);
+        const double tol = 1e-13 * (1.0 + last_xmax);
+        if (!(last_dmax > tol)) break;
+        if (k >= 2 && last_dmax * (last_dmax / prev) < tol) break;
+        if (last_dmax > 0.95 * prev) break; // rounding floor / no progress
+        prev = last_dmax;
+      }
+      QPC_PHASE(lane) { // lam_1 = S11^-1 c_1 - Z lam_w
+        for (int r = lane; r < m1; r += 64) {
+          double acc = dotp(sm + D.lds[L_SM] + r * D.ms, 1, sm + D.lds[L_T1], 1, m1);
+          if (nw) acc -= dotp(sm + D.lds[L_X2] + r * 6, 1, sm + D.lds[L_LAM] + m1, 1, 6);
+          sm[D.lds[L_LAM] + r] = acc;
+        }
+      } QPC_END_PHASE
+    } else {
+      solve_S(D.lds[L_LAM]); // lam = S^-1 c (no rho: S22 = B22)
+    }
+    QPC_PHASE(lane) { // x_v (scaled) = -sqh g - M' lam ; e = W^-1 lam_slack
+      for (int f = lane; f < nf; f += 64)
+        sm[D.lds[L_XV] + f] = -sm[D.lds[L_SQH] + f] * sm[D.lds[L_GV] + f] - dotp(sm + D.lds[L_M] + f, D.nfs, sm + D.lds[L_LAM], 1, m);
+      for (int s = lane; s < ne; s += 64) {
+        int d = slack_dim(s), wr = slack_woff(s), s0 = slack_s0(s);
+        double acc = 0.0;
+        for (int i = 0; i < d; i++) acc += sm[D.lds[L_WINV] + wr + i] * sm[D.lds[L_LAM] + slack_row(s0 + i)];
+        sm[D.lds[L_XE] + s] = acc;
+      }
+    } QPC_END_PHASE
+    QPC_PROF_ACC(PS_FINAL);
+    return k;
   }
 
   // EQP of the current working set solved from x = 0: the residual IS the right-hand side, so no
@@ -1038,16 +1112,17 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
 
   QPC_PROF_ACC(PS_KIN);
   // regularisation scale: eps = eps_primal * max diagonal of the Hessian
-  double hscale = 0.0;
+  double hscale = 0.0, hinvmax = 0.0;
   QPC_PHASE(lane) {
-    double h = 0.0;
-    for (int f = lane; f < nf; f += 64) { double a = QPC_FABS(sm[D.lds[L_HV] + f]); h = a > h ? a : h; }
+    double h = 0.0, hm = 1e300; // largest diagonal of H; smallest diagonal of its v̇ and slack blocks
+    for (int f = lane; f < nf; f += 64) { double a = sm[D.lds[L_HV] + f]; hm = a < hm ? a : hm; a = QPC_FABS(a); h = a > h ? a : h; }
     for (int t = lane; t < ntask; t += 64) {
       int w0 = IT[D.it[IT_T_WOFF] + t];
       if (w0 < 0) continue;
       int d = IT[D.it[IT_T_DIM] + t];
-      for (int a = 0; a < d; a++) { double w = QPC_FABS(sm[D.lds[L_W] + w0 + a * d + a]); h = w > h ? w : h; }
+      for (int a = 0; a < d; a++) { double w = sm[D.lds[L_W] + w0 + a * d + a]; hm = w < hm ? w : hm; w = QPC_FABS(w); h = w > h ? w : h; }
     }
+    QPC_RED_MAX_PUT(1, hinvmax, hm < 1e300 ? (hm > 1e-300 ? 1.0 / hm : 1e300) : 0.0); // (reductions are max over non-negative values)
     if (use_rho)
       for (int c = lane; c < nc; c += 64) {
         double w = (sm[D.lds[L_CMAX] + c] > 0.0) ? 2.0 * QPC_FABS(sm[D.lds[L_CW] + c]) : 0.0;
@@ -1076,8 +1151,14 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
     QPC_RED_MAX_PUT(0, hscale, h);
   } QPC_END_PHASE
   hscale = QPC_RED_MAX_GET(0, hscale);
+  hinvmax = QPC_RED_MAX_GET(1, hinvmax);
   if (!(hscale > 0.0)) hscale = 1.0;
   const double eps = D.eps_primal * hscale;
+  // exact_ve: every v̇ and slack diagonal of the Hessian is comfortably positive (and no matrix-weighted
+  // slack block): those blocks are then inverted WITHOUT the proximal eps, which confines the eps bias to
+  // the (rank-deficient) rho blocks and enables the cheap wrench-space polish (Solver::polish_exact)
+  const bool exact_ve = D.ve_exact_ok && (hinvmax * 1e-6 * hscale <= 1.0); // min diagonal >= 1e-6 * max diagonal
+  const double eps_ve = exact_ve ? 0.0 : eps;
 
   // ======================================================================== assembly (a3-a12)
   QPC_PHASE(lane) {
@@ -1089,12 +1170,12 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       cross3(com, fg, cxf);
       sm[MISC + MS_WG + lane] = lane < 3 ? cxf[lane] : fg[lane - 3];
     }
-    for (int f = lane; f < nf; f += 64) sm[D.lds[L_SQH] + f] = 1.0 / QPC_SQRT(sm[D.lds[L_HV] + f] + eps);
+    for (int f = lane; f < nf; f += 64) sm[D.lds[L_SQH] + f] = 1.0 / QPC_SQRT(sm[D.lds[L_HV] + f] + eps_ve);
     for (int t = lane; t < ntask; t += 64) { // (W + eps I)^-1 per soft generic task
       int w0 = IT[D.it[IT_T_WOFF] + t];
       if (w0 < 0) continue;
       int d = IT[D.it[IT_T_DIM] + t];
-      for (int e = 0; e < d * d; e++) sm[D.lds[L_WINV] + w0 + e] = sm[D.lds[L_W] + w0 + e] + ((e / d == e % d) ? eps : 0.0);
+      for (int e = 0; e < d * d; e++) sm[D.lds[L_WINV] + w0 + e] = sm[D.lds[L_W] + w0 + e] + ((e / d == e % d) ? eps_ve : 0.0);
       spd_inverse_inplace(sm + D.lds[L_WINV] + w0, d);
     }
   } QPC_END_PHASE
@@ -1367,13 +1448,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
   int status = QPC_STATUS_OPTIMAL, iters = 0;
   if (use_rho) {
     // u0 = c2 - Z' c1 with c = E H^-1 (-g) - d : fixed for the whole tick (see Solver::rho_solve)
-    QPC_PHASE(lane) {
-      for (int f = lane; f < nf; f += 64) sm[D.lds[L_XV] + f] = -sm[D.lds[L_SQH] + f] * sm[D.lds[L_GV] + f];
-    } QPC_END_PHASE
-    QPC_PHASE(lane) {
-      for (int r = lane; r < m; r += 64)
-        sm[D.lds[L_T1] + r] = dotp(sm + D.lds[L_M] + r * D.nfs, 1, sm + D.lds[L_XV], 1, nf) - sm[D.lds[L_D] + r];
-    } QPC_END_PHASE
+    S.compute_c();
     QPC_PHASE(lane) {
       if (lane < 6) sm[MISC + MS_U0 + lane] = sm[D.lds[L_T1] + m1 + lane] - dotp(sm + D.lds[L_X2] + lane, 6, sm + D.lds[L_T1], 1, m1);
     } QPC_END_PHASE
@@ -1500,7 +1575,11 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
   int refine = 0;
   if (status == QPC_STATUS_OPTIMAL) {
     for (int outer = 0;; outer++) {
-      refine = S.eqp(D.max_refine);
+      // exact_ve: wrench-space proximal sweeps + one back-substitution (Solver::polish_exact), then
+      // refinement of the full KKT system from that iterate -- one sweep when its correction confirms
+      // that the iterate was already accurate; otherwise: solve + refine the full system from scratch
+      if (exact_ve) { refine = S.polish_exact(true); refine += S.eqp(D.max_refine, true) - 1; }
+      else refine = S.eqp(D.max_refine);
       S.residuals();
       double arp = 0.0, ars = 0.0, asp = 0.0, ass = 0.0, anan = 0.0, abv = 0.0, agm = 0.0, axm = 0.0;
       QPC_PHASE(lane) {
