@@ -1,0 +1,58 @@
+"""End-to-end acceptance in the spirit of the reference's notebook (Standing controller.ipynb cells
+9-11: simulate, the robot must keep standing): B perturbed Atlas robots on compliant ground, one
+batched StandingController tick (PD laws fused on the device, a pure (q, v) -> tau map) per
+millisecond.  Every QP must solve, nobody falls, the centre of mass settles on its reference."""
+import numpy as np
+import pytest
+
+import emu
+import sim
+from qpcontrol_jl_amd import api, models as M, workloads as W
+
+
+def build(lib_path, B, seed=3):
+    mech = M.atlas()
+    low = api.MomentumBasedController(mech, n_basis=4, floatingjoint="pelvis_to_world", lib_path=lib_path)
+    for cp in mech.contact_points:  # notebook cell 5
+        pt = low.addcontact(cp.body, cp.position, cp.normal, cp.mu)
+        pt.maxnormalforce, pt.weight = 1e6, 1e-3
+    q_nom = M.atlas_nominal_configuration(mech)
+    ctrl = api.StandingController(low, ["l_foot", "r_foot"], "pelvis", q_nom)
+    q, v = W.standing_states(mech, B, seed, dq=0.02, drot=0.01, vstd=0.0)
+    v[:, 3] = np.linspace(-0.08, 0.08, B)  # a push along x: 8 cm/s either way
+    # ground such that the nominal stance is in normal-force equilibrium
+    k = 6.0e4
+    z_contact = 0.01308714
+    ground = sim.GroundContact(z_contact + mech.total_mass() * 9.81 / (8 * k), k=k)
+    return mech, low, ctrl, q, v, ground
+
+
+def run(lib_path, B, steps):
+    mech, low, ctrl, q, v, ground = build(lib_path, B)
+
+    def tick(qq, vv):
+        tau = ctrl(None, 0.0, (qq, vv), throw_on_failure=False)
+        return dict(tau=tau, status=low.status)
+    log = sim.rollout(tick, mech, q, v, steps, ground=ground)
+    assert log["bad"] == 0, f'{log["bad"]} failed QPs'
+    pz = np.array(log["pelvis_z"])
+    assert pz.min() > 0.70 and pz.max() < 0.95, (pz.min(), pz.max())  # nobody falls (nominal 0.85)
+    return ctrl, log
+
+
+def test_closed_loop_emulated():
+    emu.build()
+    ctrl, log = run(emu.EMU_LIB, 2, 1500)  # 1.5 s of simulated time through the CPU emulation of the device code
+    com = log["com"][-1]
+    assert np.all(np.abs(com[:, :2] - ctrl.comref[:2]) < 0.02), com[:, :2] - ctrl.comref[:2]
+    assert np.all(np.abs(com[:, 2] - ctrl.comref[2]) < 0.03), com[:, 2] - ctrl.comref[2]
+    assert np.all(log["vnorm"][-1] < 0.3), log["vnorm"][-1]
+
+
+@pytest.mark.gpu
+def test_closed_loop_gpu():
+    ctrl, log = run(None, 16, 2000)  # 2 s of simulated time, 16 robots
+    com = log["com"][-1]
+    assert np.all(np.abs(com[:, :2] - ctrl.comref[:2]) < 0.02), com[:, :2] - ctrl.comref[:2]
+    assert np.all(np.abs(com[:, 2] - ctrl.comref[2]) < 0.03), com[:, 2] - ctrl.comref[2]
+    assert np.all(log["vnorm"][-1] < 0.3), log["vnorm"][-1]
