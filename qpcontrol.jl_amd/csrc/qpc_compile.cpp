@@ -235,7 +235,9 @@ int qpc_compile_program(qpc_controller *c) {
     B.ibegin(IT_DESC_MASK); B.it.insert(B.it.end(), mask.begin(), mask.end());
     B.ibegin(IT_PDES_K); B.it.insert(B.it.end(), pdes.begin(), pdes.end());
     // packed assembly codes: kind(3) | sg+1(2) | a(3) | k(7) | frame+1(7) | t(6)   (kind 7 = wrench row)
-    std::vector<int> mcode((size_t)D.m * D.nf, 0), rcode(D.m, 0), rdes(D.m, -1), rt(D.m, -1), rpink(D.m, -1);
+    std::vector<int> rcode(D.m, 0), rdes(D.m, -1), rt(D.m, -1), rpink(D.m, -1);
+    struct Item { int cost, c0, c1; };
+    std::vector<Item> items;
     for (int r = 0; r < D.m; r++) {
       int g = -1, a = r - m1;
       if (r < m1) { for (size_t gg = 0; gg < generic.size(); gg++) if (r >= row0[gg] && r < row0[gg] + c->tasks[generic[gg]].dim) g = (int)gg; a = r - row0[g]; }
@@ -244,11 +246,17 @@ int qpc_compile_program(qpc_controller *c) {
       rcode[r] = kind | (a << 3) | ((frame + 1) << 6) | ((base + 1) << 13) | ((target + 1) << 20);
       rdes[r] = t ? t->des_off + a : -1;
       rt[r] = g;
-      for (int f = 0; f < D.nf; f++) {
-        int k = free_k[f], sg = 0;
+      // one assembly item per (row block, free column): emitted with the block's first row
+      for (int f = 0; f < D.nf && a == 0; f++) {
+        int k = free_k[f], sg = 0, aux = frame + 1, cost = 1;
+        const int dim = t ? t->dim : 6;
         if (!t) sg = 1;
-        else if (t->kind == QPC_TASK_JOINT_ACCELERATION) sg = (k >= m->voff[t->joint] && k < m->voff[t->joint] + t->dim && k - m->voff[t->joint] == a) ? 1 : 0;
-        else if (t->kind == QPC_TASK_MOMENTUM_RATE || t->kind == QPC_TASK_LINEAR_MOMENTUM_RATE) sg = 1;
+        else if (t->kind == QPC_TASK_JOINT_ACCELERATION) {
+          const int comp = k - m->voff[t->joint];
+          sg = (comp >= 0 && comp < t->dim) ? 1 : 0;
+          aux = sg ? comp + 1 : 0; // the one row of the block that carries the 1
+        }
+        else if (t->kind == QPC_TASK_MOMENTUM_RATE || t->kind == QPC_TASK_LINEAR_MOMENTUM_RATE) { sg = 1; cost = 2; }
         else {
           std::vector<char> mark(nb, 0);
           for (int b = t->target; b >= 0; b = m->parent[b]) mark[b] = 1;
@@ -258,15 +266,25 @@ int qpc_compile_program(qpc_controller *c) {
           for (int b = 0; b < nb; b++) if (k >= m->voff[b] && k < m->voff[b] + m->nvj[b]) kb = b;
           for (int b = t->base; b >= 0 && b != lca; b = m->parent[b]) if (b == kb) sg = -1;
           for (int b = t->target; b >= 0 && b != lca; b = m->parent[b]) if (b == kb) sg = 1;
+          if (sg != 0) cost = t->kind == QPC_TASK_POINT_ACCELERATION ? 12 : 8; // one Jacobian column transform
         }
-        mcode[(size_t)r * D.nf + f] = kind | ((sg + 1) << 3) | (a << 5) | (k << 8) | ((frame + 1) << 15) | ((g >= 0 ? g : 0) << 22);
+        Item it_;
+        it_.cost = cost;
+        it_.c0 = kind | ((sg + 1) << 3) | (k << 5) | (aux << 12) | ((g >= 0 ? g : 0) << 19);
+        it_.c1 = r | (dim << 7) | (f << 11);
+        items.push_back(it_);
       }
       if (t && t->kind == QPC_TASK_JOINT_ACCELERATION) {
         int k = m->voff[t->joint] + a;
         if (free_of[k] < 0) rpink[r] = k;
       }
     }
-    B.ibegin(IT_MCODE); B.it.insert(B.it.end(), mcode.begin(), mcode.end());
+    // heaviest items first: lane l takes items l, l + 64, ... so every round is balanced
+    std::stable_sort(items.begin(), items.end(), [](const Item &x, const Item &y) { return x.cost > y.cost; });
+    D.n_items = (int)items.size();
+    B.ibegin(IT_MCODE);
+    for (auto &it_ : items) { B.it.push_back(it_.c0); B.it.push_back(it_.c1); }
+    B.it.push_back(0);
     B.ibegin(IT_RCODE); B.it.insert(B.it.end(), rcode.begin(), rcode.end());
     B.ibegin(IT_R_DES); B.it.insert(B.it.end(), rdes.begin(), rdes.end());
     B.ibegin(IT_R_T); B.it.insert(B.it.end(), rt.begin(), rt.end());

@@ -31,7 +31,9 @@ enum {
                 //          velocity column) or comes from the whole-robot total (crb_full_body)
   IT_DESC_MASK, // [nb * 2] 64-bit subtree membership mask of body i (lo, hi), bit k = body k in subtree(i)
   IT_PDES_K,    // [nv] desired-record index that pins velocity index k, or -1 (free)
-  IT_MCODE,     // [m * nf] packed assembly code of constraint-matrix entry (row r, free column f)
+  IT_MCODE,     // [n_items * 2] packed assembly code of one (row block, free column) item of the constraint matrix:
+                //   int0 = kind(3) | sg+1(2) | k(7) | frame+1 or joint component+1 (7) | generic task(6)
+                //   int1 = first row(7) | rows(4) | free column f(7)       kind 7 = wrench-balance block
   IT_RCODE,     // [m] packed row code ; IT_R_DES [m] desired index ; IT_R_T [m] generic task ; IT_R_PINK [m]
   IT_R_DES, IT_R_T, IT_R_PINK,
   IT_LAW, // [n_desired * 3] desired law of entry i: kind (QPC_LAW_*), arg0, arg1
@@ -117,6 +119,7 @@ struct QpcDims {
   int nb, nq, nv, nf, npin, nsj, ntask, nc, N, nrho, ne, m, m1, nw;
   int floating, fv0; // floating body and its first velocity index (or -1)
   int n_desired, n_tw, n_surf, maxdepth;
+  int n_items; // (row block, free column) items of the constraint-matrix assembly (IT_MCODE)
   int ve_exact_ok; // no matrix-weighted slack block: the v̇ / slack blocks of H may be used unregularised (exact polish)
   int n_des_inputs, n_des_late; // desired entries read from the caller / computed after the kinematics (COM, orientation laws)
   int maxd; // row length of IT_ANC_TAB

@@ -1181,32 +1181,36 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
   } QPC_END_PHASE
 
   QPC_PHASE(lane) { // scaled constraint matrix M = E diag(sqh), right-hand side d
-    for (int idx = lane; idx < m * nf; idx += 64) {
-      // one packed code per entry: kind(3) | sg+1(2) | a(3) | k(7) | frame+1(7) | task(6); kind 7 = wrench row
-      const int code = IT[D.it[IT_MCODE] + idx];
-      const int kind = code & 7, sg = ((code >> 3) & 3) - 1, a = (code >> 5) & 7, k = (code >> 8) & 127;
-      const int frame = ((code >> 15) & 127) - 1, t = (code >> 22) & 63;
-      const int r = idx / nf, f = idx % nf;
-      double val = 0.0;
-      if (kind == 7) val = sm[D.lds[L_AMOM] + a * nv + k]; // wrench balance rows (a11), S dropped (invertible)
-      else if (sg != 0) {
-        if (kind == QPC_TASK_JOINT_ACCELERATION) val = 1.0;
-        else if (kind == QPC_TASK_MOMENTUM_RATE || kind == QPC_TASK_LINEAR_MOMENTUM_RATE) {
-          int aa = kind == QPC_TASK_LINEAR_MOMENTUM_RATE ? a + 3 : a;
-          val = sm[D.lds[L_AMOM] + aa * nv + k];
-          if (aa < 3) { // centroidal: ang - com x lin (src/tasks.jl:208-213)
-            double com[3] = {sm[MISC + MS_COM], sm[MISC + MS_COM + 1], sm[MISC + MS_COM + 2]};
-            double lin[3] = {sm[D.lds[L_AMOM] + 3 * nv + k], sm[D.lds[L_AMOM] + 4 * nv + k], sm[D.lds[L_AMOM] + 5 * nv + k]}, cx[3];
+    for (int it_ = lane; it_ < D.n_items; it_ += 64) {
+      // one item = one (row block, free column): the Jacobian column of a path task is transformed
+      // into the task frame ONCE and fills all rows of the block (qpc_program.h IT_MCODE)
+      const int c0 = IT[D.it[IT_MCODE] + 2 * it_], c1 = IT[D.it[IT_MCODE] + 2 * it_ + 1];
+      const int kind = c0 & 7, sg = ((c0 >> 3) & 3) - 1, k = (c0 >> 5) & 127, aux = (c0 >> 12) & 127, t = (c0 >> 19) & 63;
+      const int r0 = c1 & 127, dim = (c1 >> 7) & 15, f = (c1 >> 11) & 127;
+      const double sq = sm[D.lds[L_SQH] + f];
+      double val[6] = {0, 0, 0, 0, 0, 0};
+      if (kind == 7) { // wrench balance rows (a11), S dropped (invertible)
+        for (int a = 0; a < 6; a++) val[a] = sm[D.lds[L_AMOM] + a * nv + k];
+      } else if (sg != 0) {
+        if (kind == QPC_TASK_JOINT_ACCELERATION) {
+          for (int a = 0; a < 6; a++) val[a] = (a == aux - 1) ? 1.0 : 0.0;
+        } else if (kind == QPC_TASK_MOMENTUM_RATE || kind == QPC_TASK_LINEAR_MOMENTUM_RATE) {
+          double lin[3] = {sm[D.lds[L_AMOM] + 3 * nv + k], sm[D.lds[L_AMOM] + 4 * nv + k], sm[D.lds[L_AMOM] + 5 * nv + k]};
+          if (kind == QPC_TASK_LINEAR_MOMENTUM_RATE) { val[0] = lin[0]; val[1] = lin[1]; val[2] = lin[2]; }
+          else { // centroidal: ang - com x lin (src/tasks.jl:208-213)
+            double com[3] = {sm[MISC + MS_COM], sm[MISC + MS_COM + 1], sm[MISC + MS_COM + 2]}, cx[3];
             cross3(com, lin, cx);
-            val -= cx[aa];
+            for (int a = 0; a < 3; a++) { val[a] = sm[D.lds[L_AMOM] + a * nv + k] - cx[a]; val[3 + a] = lin[a]; }
           }
         } else {
+          const int frame = aux - 1;
           double H[12], S[6], J[6];
           ldH(sm, D, frame, H);
           ld(sm + D.lds[L_S] + 6 * k, 6, S);
           motion_to_frame(H, S, J);
-          if (kind == QPC_TASK_SPATIAL_ACCELERATION || kind == QPC_TASK_ANGULAR_ACCELERATION) val = sg * J[a];
-          else if (kind == QPC_TASK_LINEAR_ACCELERATION) val = sg * J[3 + a];
+          if (kind == QPC_TASK_SPATIAL_ACCELERATION) { for (int a = 0; a < 6; a++) val[a] = sg * J[a]; }
+          else if (kind == QPC_TASK_ANGULAR_ACCELERATION) { for (int a = 0; a < 3; a++) val[a] = sg * J[a]; }
+          else if (kind == QPC_TASK_LINEAR_ACCELERATION) { for (int a = 0; a < 3; a++) val[a] = sg * J[3 + a]; }
           else { // point jacobian J_lin - p^ J_ang in the base frame (src/tasks.jl:157-160)
             double Ht[12], pw[3], d3[3], pF[3], px[3];
             int target = IT[D.it[IT_T_TARGET] + t];
@@ -1215,11 +1219,12 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
             d3[0] = pw[0] + Ht[9] - H[9]; d3[1] = pw[1] + Ht[10] - H[10]; d3[2] = pw[2] + Ht[11] - H[11];
             mtv3(H, d3, pF);
             cross3(pF, J, px);
-            val = sg * (J[3 + a] - px[a]);
+            for (int a = 0; a < 3; a++) val[a] = sg * (J[3 + a] - px[a]);
           }
         }
       }
-      sm[D.lds[L_M] + r * D.nfs + f] = val * sm[D.lds[L_SQH] + f];
+      for (int a = 0; a < 6; a++)
+        if (a < dim) sm[D.lds[L_M] + (r0 + a) * D.nfs + f] = val[a] * sq;
     }
     for (int r = lane; r < m; r += 64) {
       // packed row code: kind(3) | a(3) | frame+1(7) | base+1(7) | target+1(7)
