@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 static thread_local std::string g_err;
@@ -426,7 +427,10 @@ int qpc_compile_program(qpc_controller *c) {
   // settings
   D.max_as_iters = c->settings.max_active_set_iters;
   D.max_refine = c->settings.max_refine_iters;
-  D.max_pdas = 12;
+  // primal-dual sweeps before the finite phase B takes over.  Measured on the Atlas workload (mean
+  // changes per QP / p99): 12 sweeps 6.92 / 36, 6: 6.74, 5: 6.41, 4: 6.08 / 18, 3: 6.82 -- QPs that have
+  // not converged after 4 sweeps rarely do, and Goldfarb-Idnani from their working set is cheaper
+  D.max_pdas = 4;
   D.eps_primal = c->settings.eps_primal_reg;
   D.tau_pivot = c->settings.eps_dual_reg;
   D.tol_bound = c->settings.tol_bound;

@@ -1516,7 +1516,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       if (jbad >= 0) {
         QPC_PHASE(lane) { if (lane == 0) sm[D.lds[L_WS] + jbad] = 0.0; } QPC_END_PHASE
         iters++;
-        S.refactor_solve(true);
+        S.refactor_solve(any_upper); // dropping a bound cannot create an upper-active one
         continue;
       }
       if (pviol < 0) break; // optimal for this working set
@@ -1567,7 +1567,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
             sm[D.lds[L_U] + j] = u;
           }
         } QPC_END_PHASE
-        if (full) { S.refactor_solve(true); break; }
+        if (full) { any_upper = any_upper || side > 0.0; S.refactor_solve(any_upper); break; }
         S.refactor_rho();
       }
       if (fail) { if (status == QPC_STATUS_OPTIMAL) status = QPC_STATUS_ITERATION_LIMIT; break; }

@@ -286,7 +286,7 @@ def solve_reduced(P: Reduced, st: Settings = Settings(), stats=None, guess=None)
     if use_rho:
         # ---- phase A: primal-dual active set passes (multi-change), cheap and usually enough
         seen = [tuple(ws)]
-        for _pd in range(12):
+        for _pd in range(4):  # more sweeps rarely converge; the finite phase B is cheaper from there
             u, gl = multipliers(xr, lam)
             gscale = 1.0 + np.abs(gl).max()
             tolb = st.tol_bound * (1.0 + np.abs(xr).max())
