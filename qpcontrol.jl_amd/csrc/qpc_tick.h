@@ -1666,13 +1666,13 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       if (use_rho) for (int i = 0; i < N; i++) acc += sm[D.lds[L_G] + a * nrho + c * N + i] * sm[D.lds[L_XR] + c * N + i];
       sm[D.lds[L_CWR] + idx] = acc;
     }
+    if (lane < nb) {
+      double *iw = QPC_LA(iw_, lane);
+      for (int a = 0; a < 16; a++) iw[a] = io.scratch[(SCR_IW + a) * 64 + lane];
+    }
     if (lane < nv) { // S_k v̇_k of the FREE velocity indices (the pinned ones already ride in Ab)
       double *sk = QPC_LA(sk_, lane);
       for (int a = 0; a < 6; a++) sk[a] = io.scratch[(SCR_S + a) * 64 + lane];
-      if (lane < nb) {
-        double *iw = QPC_LA(iw_, lane);
-        for (int a = 0; a < 16; a++) iw[a] = io.scratch[(SCR_IW + a) * 64 + lane];
-      }
       const int f = IT[D.it[IT_FREE_OF] + lane];
       const double vd = f >= 0 ? (double)sm[D.lds[L_XV] + f] * (double)sm[D.lds[L_SQH] + f] : 0.0;
       for (int a = 0; a < 6; a++) sm[D.lds[L_SVK] + 6 * lane + a] = sk[a] * vd;

@@ -17,6 +17,8 @@ from qpcontrol_jl_amd.workloads import (HARD, JOINT, MATRIX, MATRIX_PER_QP, SCAL
 @dataclass
 class Settings:
     detect_cycles: bool = False
+    multi_drop: bool = False  # experiment: phase B drops every wrong-signed multiplier at once
+    max_pdas: int = 4
     max_active_set_iters: int = 200
     max_refine_iters: int = 6
     eps_primal_reg: float = 1e-9
@@ -286,7 +288,7 @@ def solve_reduced(P: Reduced, st: Settings = Settings(), stats=None, guess=None)
     if use_rho:
         # ---- phase A: primal-dual active set passes (multi-change), cheap and usually enough
         seen = [tuple(ws)]
-        for _pd in range(4):  # more sweeps rarely converge; the finite phase B is cheaper from there
+        for _pd in range(st.max_pdas):  # more sweeps rarely converge; the finite phase B is cheaper from there
             u, gl = multipliers(xr, lam)
             gscale = 1.0 + np.abs(gl).max()
             tolb = st.tol_bound * (1.0 + np.abs(xr).max())
@@ -317,8 +319,14 @@ def solve_reduced(P: Reduced, st: Settings = Settings(), stats=None, guess=None)
             act = np.where((ws != 0) & enabled)[0]
             bad = [j for j in act if u[j] < -st.tol_bound * gscale]
             if bad:
-                j = min(bad, key=lambda j: u[j])
-                ws[j] = 0
+                if stats is not None:
+                    stats["drops"] = stats.get("drops", 0) + 1
+                if st.multi_drop:
+                    for j in bad:
+                        ws[j] = 0
+                else:
+                    j = min(bad, key=lambda j: u[j])
+                    ws[j] = 0
                 F = factor(); xv, xe, xr, lam, _ = eqp(F, 0); iters += 1
                 continue
             viol = np.where(ws == 0, np.maximum(lo - xr, xr - hi), 0.0)
@@ -329,6 +337,8 @@ def solve_reduced(P: Reduced, st: Settings = Settings(), stats=None, guess=None)
             nsign = 1.0 if side == -1 else -1.0
             fail = False
             while True:
+                if stats is not None:
+                    stats["adds"] = stats.get("adds", 0) + 1
                 iters += 1
                 if iters > st.max_active_set_iters:
                     fail = True
