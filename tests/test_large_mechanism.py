@@ -1,0 +1,74 @@
+"""Sizes beyond Atlas: more than 32 bodies (second word of the subtree bit masks), about 50
+velocity coordinates, many contacts with a 6-ray basis (60 rho's: almost one per lane), ~40
+equality rows.  Fused kernel vs the oracle tick."""
+import numpy as np
+import pytest
+
+import emu
+import parity
+import scenarios as SC
+from oracle import oracle as O
+from qpcontrol_jl_amd import models as M
+from qpcontrol_jl_amd.workloads import ANGULAR, HARD, JOINT, LINEAR_MOMENTUM_RATE, POINT, SCALAR, SPATIAL
+
+
+def ora_factory(mech, n_basis, floating):
+    return O.OracleController(O.OracleModel(mech), n_basis, floating)
+
+
+def make(factory, B=3, seed=9, big=False):
+    rng = np.random.default_rng(seed)
+    types = [M.QUAT_FLOATING] + [M.REVOLUTE] * 40 + [M.PRISMATIC] * 3
+    mech = M.rand_tree(types, seed=seed)
+    nb = mech.nbodies
+    assert nb > 32 and mech.nv == 49
+    c = factory(mech, 6, 0)
+    contact_bodies = [nb - 1, nb - 2, nb - 5, 35, 33] + ([30] if big else [])  # big: 72 rho's, two per lane
+    for b in contact_bodies:
+        for sx in (-0.1, 0.1):
+            c.add_contact(b, [sx, 0.02, -0.1], [0.0, 0.1, 1.0], 0.9)
+    for j in range(nb):
+        c.regularize(j, 0.05)
+    c.add_task(SPATIAL, base=M.WORLD, target=nb - 1, frame=M.FRAME_DEFAULT, wkind=SCALAR, weight=[5.0])
+    c.add_task(SPATIAL, base=M.WORLD, target=34, frame=M.FRAME_DEFAULT, wkind=SCALAR, weight=[2.0])
+    c.add_task(POINT, base=2, target=40, point=[0.1, 0.0, -0.1], wkind=SCALAR, weight=[3.0])
+    c.add_task(ANGULAR, base=M.WORLD, target=0, frame=M.FRAME_DEFAULT, wkind=HARD)
+    c.add_task(LINEAR_MOMENTUM_RATE, wkind=SCALAR, weight=[1.0])
+    extra = (25, 28, 31) if big else ()
+    for t in extra:  # big: 45 equality rows (three 16 x 16 MFMA tiles per side)
+        c.add_task(SPATIAL, base=M.WORLD, target=t, frame=M.FRAME_DEFAULT, wkind=SCALAR, weight=[1.0])
+    for j in (5, 12, 20, 33, 38, 41, 43):
+        c.add_task(JOINT, joint=j, wkind=HARD)
+    c.finalize()
+    qs, vs = zip(*(M.rand_state(mech, rng, 0.2) for _ in range(B)))
+    nc = 2 * len(contact_bodies)
+    des = rng.normal(size=(B, 6 + 6 + 3 + 3 + 3 + 6 * len(extra) + 7)) * 0.5
+    return SC.Case("large_mechanism" + ("_big" if big else ""), mech, c, np.array(qs), np.array(vs), des, np.full((B, nc), 1e-2),
+                   np.full((B, nc), 1e4), floating=0, n_basis=6, tol_tau=1e-6)
+
+
+def _run(factory, big=False):
+    g, o = make(factory, big=big), make(ora_factory, big=big)
+    lay = g.ctrl.layout
+    assert lay.n_rho == (72 if big else 60) and lay.lds_bytes_per_qp <= 160 * 1024
+    rg = g.ctrl.control_batch(g.q, g.v, g.desired, g.cweight, g.cmaxf)
+    ro = o.ctrl.tick_batch(o.q, o.v, o.desired, o.cweight, o.cmaxf)
+    parity.compare(g, rg, o, ro)
+    return lay
+
+
+@pytest.mark.parametrize("big", [False, True])
+def test_large_mechanism_emulated(big):
+    emu.build()
+    emu.race_report()
+    lay = _run(emu.factory, big)
+    races, uninit, outside, first = emu.race_report()
+    assert (races, uninit, outside) == (0, 0, 0), first
+    print("rows", lay.n_eq_rows, "lds", lay.lds_bytes_per_qp)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("big", [False, True])
+def test_large_mechanism_gpu(big):
+    from qpcontrol_jl_amd import binding
+    _run(lambda mech, N, fl: binding.Controller(binding.Model(mech), N, fl), big)
