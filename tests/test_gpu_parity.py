@@ -95,3 +95,24 @@ def test_generic_kernel_without_jit(ora_cases, name, monkeypatch):
 def test_jit_is_active_by_default(gpu_cases):
     g = gpu_cases["atlas_config3"]
     assert g.ctrl.L.qpc_debug_jit_active(g.ctrl.h) == 1
+
+
+@pytest.mark.parametrize("which", ["large", "large_big", "fixed_joints", "edge_N6", "fused_laws"])
+def test_generic_kernel_without_jit_other_shapes(which, monkeypatch):
+    """the non-JIT kernel on the shapes the JIT path is tested on elsewhere: > 32 bodies, > 64 rho's,
+    welded bodies, a 6-ray basis, device-side desired laws"""
+    monkeypatch.setenv("QPC_DISABLE_JIT", "1")
+    import test_edge_contacts as TE
+    import test_fixed_joints as TF
+    import test_large_mechanism as TL
+    if which == "fused_laws":
+        import test_standing_laws as TS
+        rf, wl = TS._fused_vs_host(gpu_factory, 16, 3, 1e-9)
+        return
+    maker = {"large": lambda f: TL.make(f), "large_big": lambda f: TL.make(f, big=True),
+             "fixed_joints": lambda f: TF.make(f, False), "edge_N6": lambda f: TE.make(f, n_basis=6)}[which]
+    g, o = maker(gpu_factory), maker(ora_factory)
+    assert g.ctrl.L.qpc_debug_jit_active(g.ctrl.h) == 0
+    rg = g.ctrl.control_batch(g.q, g.v, g.desired, g.cweight, g.cmaxf, g.tw, g.surf)
+    ro = o.ctrl.tick_batch(o.q, o.v, o.desired, o.cweight, o.cmaxf, o.tw, o.surf)
+    parity.compare(g, rg, o, ro)
