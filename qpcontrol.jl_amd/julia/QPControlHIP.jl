@@ -11,7 +11,8 @@
 # symbol of include/qpc.h with the argument order shown there.
 module QPControlHIP
 
-export qp_solve_batch, BatchedMomentumBasedController, QPCModel, addtask!, addcontact!, regularize!, finalize!,
+export qp_solve_batch, setlaw!, LAW_INPUT, LAW_CONSTANT, LAW_JOINT_PD, LAW_COM_PD, LAW_ORIENTATION_PD,
+       BatchedMomentumBasedController, QPCModel, addtask!, addcontact!, regularize!, finalize!,
        QPSolveFailure, SpatialAccelerationTask, AngularAccelerationTask, LinearAccelerationTask,
        PointAccelerationTask, JointAccelerationTask, MomentumRateTask, LinearMomentumRateTask
 
@@ -156,6 +157,18 @@ regularize!(c::BatchedMomentumBasedController, joint::Integer, weight::Real) =
 # addcontact!(controller, body, position, normal, mu) (momentum.jl:142-148); weight[] and
 # maxnormalforce[] (contacts.jl:35-36) are per-QP rows of the tick inputs; disable!(point)
 # (contacts.jl:72) == maxnormalforce = 0 for that QP.
+# Desired-acceleration laws evaluated on the device (include/qpc.h qpc_task_set_law): what the
+# reference's StandingController computes on the CPU before every tick (src/highlevel/standing.jl:58-89).
+# `task_id` is the value returned by addtask!.  With a law on every task the tick needs no `desired`.
+const LAW_INPUT = Int32(0); const LAW_CONSTANT = Int32(1); const LAW_JOINT_PD = Int32(2)
+const LAW_COM_PD = Int32(3); const LAW_ORIENTATION_PD = Int32(4)
+function setlaw!(c::BatchedMomentumBasedController, task_id::Integer, law::Int32; kp::Real = 0.0, kd::Real = 0.0,
+                 ref::Vector{Float64} = Float64[])
+    check(ccall((:qpc_task_set_law, libqpc), Int32, (Ptr{Cvoid}, Int32, Int32, Float64, Float64, Ptr{Float64}, Int32),
+                c.handle, task_id, law, kp, kd, ref, length(ref)), "qpc_task_set_law")
+    nothing
+end
+
 function addcontact!(c::BatchedMomentumBasedController, body::Integer, position, normal, mu::Real; per_qp_surface::Bool = false)
     cid = Ref{Int32}(-1)
     pos, nrm = collect(Float64, position), collect(Float64, normal)
