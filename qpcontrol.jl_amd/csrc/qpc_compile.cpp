@@ -208,7 +208,7 @@ int qpc_compile_program(qpc_controller *c) {
   {
     const int maxd = D.maxdepth > 0 ? D.maxdepth : 1;
     D.maxd = maxd;
-    std::vector<int> tab((size_t)nb * maxd, -1), mask(2 * (size_t)nb, 0), pdes(nv, -1);
+    std::vector<int> tab((size_t)nb * maxd, -1), mask(2 * (size_t)nb, 0), pdes(nv, -1), crb_keep;
     for (int i = 0; i < nb; i++) {
       int sidx = 0;
       for (int a = m->parent[i]; a >= 0; a = m->parent[a]) tab[(size_t)i * maxd + sidx++] = a;
@@ -232,6 +232,26 @@ int qpc_compile_program(qpc_controller *c) {
         else if (mk == all && D.crb_full_body < 0) { D.crb_full_body = i; crb[2 * i] = crb[2 * i + 1] = 0; }
       }
       B.ibegin(IT_CRB_MASK); B.it.insert(B.it.end(), crb.begin(), crb.end());
+      crb_keep = crb;
+    }
+    { // packed per-lane metadata: lane = body i (words 0-2, 6..) and lane = velocity index k (words 3-5)
+      const int aw = (maxd + 3) / 4, rowlen = 6 + aw;
+      std::vector<int> meta((size_t)64 * rowlen, 0);
+      for (int l = 0; l < 64; l++) {
+        int *row = &meta[(size_t)l * rowlen];
+        if (l < nb) {
+          row[0] = (m->jtype[l] & 3) | (m->qoff[l] << 2) | (m->voff[l] << 9) | (m->nvj[l] << 16);
+          row[1] = crb_keep[2 * l]; row[2] = crb_keep[2 * l + 1];
+          for (int sidx = 0; sidx < maxd; sidx++) row[6 + sidx / 4] |= ((tab[(size_t)l * maxd + sidx] + 1) & 255) << (8 * (sidx % 4));
+        }
+        if (l < nv) {
+          int vb = -1;
+          for (int b = 0; b < nb; b++) if (l >= m->voff[b] && l < m->voff[b] + m->nvj[b]) vb = b;
+          row[3] = vb & 127;
+          row[4] = mask[2 * vb]; row[5] = mask[2 * vb + 1];
+        }
+      }
+      B.ibegin(IT_META); B.it.insert(B.it.end(), meta.begin(), meta.end());
     }
     B.ibegin(IT_DESC_MASK); B.it.insert(B.it.end(), mask.begin(), mask.end());
     B.ibegin(IT_PDES_K); B.it.insert(B.it.end(), pdes.begin(), pdes.end());

@@ -36,6 +36,7 @@ enum {
                 //   int1 = first row(7) | rows(4) | free column f(7)       kind 7 = wrench-balance block
   IT_RCODE,     // [m] packed row code ; IT_R_DES [m] desired index ; IT_R_T [m] generic task ; IT_R_PINK [m]
   IT_R_DES, IT_R_T, IT_R_PINK,
+  IT_META, // [64 * (6 + (maxd + 3) / 4)] packed per-lane metadata (qpc_tick.h TickMeta): one row per lane
   IT_LAW, // [n_desired * 3] desired law of entry i: kind (QPC_LAW_*), arg0, arg1
           //   JOINT_PD: q index, v index;  COM_PD: component, -;  ORIENTATION_PD: body, component
   IT_HOT, // solver lookups staged into LDS per QP: row_slack[m], slack_row[ne], slack_woff[ne], slack_dim[ne], slack_s0[ne]

@@ -825,16 +825,24 @@ QPC_FN void rotation_vector(const double *R, double *rv) {
 // ------------------------------------------------------------------------------------------
 // the tick
 // ------------------------------------------------------------------------------------------
-// Static per-lane metadata (lane = body i and lane = velocity index k), read once per QP into
-// registers: no table lookup sits on a dependent path of the tree sweeps.  (Keeping it live across
-// the QPs of a workgroup was measured: the extra register pressure costs more than the reload.)
-//   [0] jtype(i) [1] q0(i) [2] v0(i) [3] nvj(i) [4,5] subtree mask of body i for the composite inertia
-//       (zero when not needed: no free column / whole-robot total)
-//   [6] vbody(k) [7] vcomp(k) [8] pin-desired index of k or -1 [9,10] subtree mask of vbody(k)
-//   [11 + s] s-th ancestor of body i (nearest first) or -1
+// Static per-lane metadata (lane = body i and lane = velocity index k), read once per QP into a few
+// registers (packed by the host compiler, IT_META): no table lookup sits on a dependent path of the
+// tree sweeps, and the whole row costs 6 + MAXD/4 VGPRs.  (Keeping it live across the QPs of a
+// workgroup was measured: the extra register pressure costs more than the reload.)
+//   [0] jtype(2) | q0(7) << 2 | v0(7) << 9 | nvj(3) << 16 of body i
+//   [1,2] subtree mask of body i for the composite inertia (zero when not needed)
+//   [3] vbody(k)   [4,5] subtree mask of vbody(k)
+//   [6 + s/4] byte s%4: s-th ancestor of body i (nearest first) + 1, 0 = none
+#define QPC_META_WORDS (6 + (QPC_MAXD + 3) / 4)
 struct TickMeta {
-  QPC_LANE_INTS(v, 11 + QPC_MAXD);
+  QPC_LANE_INTS(v, QPC_META_WORDS);
 };
+#define MT_JT(mt) ((mt)[0] & 3)
+#define MT_Q0(mt) (((mt)[0] >> 2) & 127)
+#define MT_V0(mt) (((mt)[0] >> 9) & 127)
+#define MT_NVJ(mt) (((mt)[0] >> 16) & 7)
+#define MT_VBODY(mt) ((mt)[3] & 127)
+#define MT_ANC(mt, s) ((int)(((unsigned)(mt)[6 + ((s) >> 2)] >> (8 * ((s) & 3))) & 255u) - 1)
 
 // once per workgroup (before its first QP): hot solver lookups -> the persistent L_HOT region of
 // the LDS slab (never overlaid, so it survives from QP to QP)
@@ -864,18 +872,10 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
   TickMeta M;
   QPC_PHASE(lane) {
     int *mt = QPC_LI(M.v, lane);
-    for (int e = 0; e < 11 + QPC_MAXD; e++) mt[e] = -1;
-    if (lane < nb) {
-      mt[0] = IT[D.it[IT_JTYPE] + lane]; mt[1] = IT[D.it[IT_QOFF] + lane]; mt[2] = IT[D.it[IT_VOFF] + lane];
-      mt[3] = IT[D.it[IT_NVJ] + lane];
-      mt[4] = IT[D.it[IT_CRB_MASK] + 2 * lane]; mt[5] = IT[D.it[IT_CRB_MASK] + 2 * lane + 1];
+    {
+      const int aw = (D.maxd + 3) / 4, rowlen = 6 + aw;
       QPC_UNROLL_JIT
-      for (int s = 0; s < QPC_MAXD; s++) mt[11 + s] = s < D.maxd ? IT[D.it[IT_ANC_TAB] + lane * D.maxd + s] : -1;
-    }
-    if (lane < nv) {
-      const int vb = IT[D.it[IT_VBODY] + lane];
-      mt[6] = vb; mt[7] = IT[D.it[IT_VCOMP] + lane]; mt[8] = IT[D.it[IT_PDES_K] + lane];
-      mt[9] = IT[D.it[IT_DESC_MASK] + 2 * vb]; mt[10] = IT[D.it[IT_DESC_MASK] + 2 * vb + 1];
+      for (int e = 0; e < QPC_META_WORDS; e++) mt[e] = e < rowlen ? IT[D.it[IT_META] + lane * rowlen + e] : 0;
     }
     for (int i = lane; i < nq; i += 64) sm[D.lds[L_Q] + i] = io.q[i];
     for (int i = lane; i < nv; i += 64) {
@@ -895,7 +895,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
     if (lane < nb) {
       const int i = lane;
       const int *mt = QPC_LI(M.v, lane);
-      const int jt = mt[0], q0 = mt[1];
+      const int jt = MT_JT(mt), q0 = MT_Q0(mt);
       const double *ax = DT + D.dt[DT_AXIS] + 3 * i, *Rf = DT + D.dt[DT_RF] + 9 * i, *pf = DT + D.dt[DT_PF] + 3 * i;
       double Rj[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pj[3] = {0, 0, 0};
       if (jt == QPC_JOINT_REVOLUTE) {
@@ -930,7 +930,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       ld(sm + D.lds[L_RL] + 12 * lane, 12, H);
       QPC_UNROLL_JIT
       for (int s = 0; s < QPC_MAXD; s++) {
-        const int an = mt[11 + s];
+        const int an = MT_ANC(mt, s);
         if (an >= 0) {
           ld(sm + D.lds[L_RL] + 12 * an, 12, A);
           mv3(A, H + 9, t);
@@ -946,7 +946,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
     if (lane < nb) {
       const int i = lane;
       const int *mt = QPC_LI(M.v, lane);
-      const int jt = mt[0], v0 = mt[2], n = mt[3];
+      const int jt = MT_JT(mt), v0 = MT_V0(mt), n = MT_NVJ(mt);
       double H[12], tj[6] = {0, 0, 0, 0, 0, 0};
       ld(sm + D.lds[L_H] + 12 * i, 12, H);
       const double *ax = DT + D.dt[DT_AXIS] + 3 * i;
@@ -993,12 +993,12 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       for (int a = 0; a < 6; a++) T[a] = tj[a];
       QPC_UNROLL_JIT
       for (int s = 0; s < QPC_MAXD; s++) {
-        const int an = mt[11 + s];
+        const int an = MT_ANC(mt, s);
         if (an >= 0)
           for (int a = 0; a < 6; a++) T[a] += sm[D.lds[L_TJ] + 6 * an + a];
       }
       crm(T, tj, cr);
-      const int v0 = mt[2], n = mt[3];
+      const int v0 = MT_V0(mt), n = MT_NVJ(mt);
       for (int c = 0; c < n; c++) {
         const double vdp = sm[D.lds[L_VD] + v0 + c]; // zero for free joints at this point
         for (int a = 0; a < 6; a++) cr[a] += sm[D.lds[L_S] + 6 * (v0 + c) + a] * vdp;
@@ -1016,13 +1016,13 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       ld(sm + D.lds[L_CR] + 6 * i, 6, Ab);
       QPC_UNROLL_JIT
       for (int s = 0; s < QPC_MAXD; s++) {
-        const int an = mt[11 + s];
+        const int an = MT_ANC(mt, s);
         if (an >= 0)
           for (int a = 0; a < 6; a++) Ab[a] += sm[D.lds[L_CR] + 6 * an + a];
       }
       st(sm + D.lds[L_AB] + 6 * i, 6, Ab);
       for (int a = 0; a < 10; a++) Ic[a] = 0.0;
-      unsigned long long msk = ((unsigned long long)(unsigned)mt[5] << 32) | (unsigned long long)(unsigned)mt[4];
+      unsigned long long msk = ((unsigned long long)(unsigned)mt[2] << 32) | (unsigned long long)(unsigned)mt[1];
       while (msk) {
         const int k = QPC_CTZ64(msk);
         msk &= msk - 1;
@@ -1072,7 +1072,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       const int k = lane;
       const int *mt = QPC_LI(M.v, lane);
       double Ic[10], S[6], h[6];
-      ld(sm + D.lds[L_IC] + 10 * mt[6], 10, Ic);
+      ld(sm + D.lds[L_IC] + 10 * MT_VBODY(mt), 10, Ic);
       ld(sm + D.lds[L_S] + 6 * k, 6, S);
       for (int a = 0; a < 6; a++) io.scratch[(SCR_S + a) * 64 + lane] = S[a]; // for tau_k = S_k . F (RNEA)
       inertia_mul(Ic, S, h);
@@ -1682,7 +1682,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
     if (lane < nb) {
       const int *mt = QPC_LI(M.v, lane);
       double sv[6] = {0, 0, 0, 0, 0, 0};
-      const int v0 = mt[2], n = mt[3];
+      const int v0 = MT_V0(mt), n = MT_NVJ(mt);
       for (int c = 0; c < n; c++)
         for (int a = 0; a < 6; a++) sv[a] += sm[D.lds[L_SVK] + 6 * (v0 + c) + a];
       st(sm + D.lds[L_SV] + 6 * lane, 6, sv);
@@ -1696,7 +1696,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       ld(sm + D.lds[L_SV] + 6 * i, 6, A);
       QPC_UNROLL_JIT
       for (int s = 0; s < QPC_MAXD; s++) {
-        const int an = mt[11 + s];
+        const int an = MT_ANC(mt, s);
         if (an >= 0)
           for (int a = 0; a < 6; a++) A[a] += sm[D.lds[L_SV] + 6 * an + a];
       }
@@ -1716,9 +1716,9 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       const int k = lane;
       const int *mt = QPC_LI(M.v, lane);
       double tau = 0.0;
-      if (mt[6] != D.floating) {
+      if (MT_VBODY(mt) != D.floating) {
         double F[6] = {0, 0, 0, 0, 0, 0};
-        unsigned long long msk = ((unsigned long long)(unsigned)mt[10] << 32) | (unsigned long long)(unsigned)mt[9];
+        unsigned long long msk = ((unsigned long long)(unsigned)mt[5] << 32) | (unsigned long long)(unsigned)mt[4];
         while (msk) {
           const int b = QPC_CTZ64(msk);
           msk &= msk - 1;
