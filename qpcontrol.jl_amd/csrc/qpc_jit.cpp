@@ -68,7 +68,11 @@ std::string qpc_jit_source(const QpcDims &D) {
        "    io.cwrench = A.cwrench ? A.cwrench + b * 6 * kD.nc : nullptr;\n"
        "    io.status = A.status + b; io.iters = A.iters ? A.iters + b : nullptr; io.prof = A.prof ? A.prof + b * PS_COUNT : nullptr;\n"
        "    io.scratch = A.scratch + (size_t)blockIdx.x * QPC_SCRATCH_DOUBLES;\n"
-       "    qpc::qpc_tick<double *>(kD, IT, DT, qpc_lds, io);\n"
+       "    // opaque copies of the table pointers: keeps the compiler from hoisting dozens of per-lane table\n"
+       "    // addresses out of this loop (they would stay live across the whole tick and spill)\n"
+       "    const int *ITq = IT; const double *DTq = DT;\n"
+       "    asm volatile(\"\" : \"+s\"(ITq), \"+s\"(DTq));\n"
+       "    qpc::qpc_tick<double *>(kD, ITq, DTq, qpc_lds, io);\n"
        "    __syncthreads();\n"
        "  }\n"
        "}\n";
