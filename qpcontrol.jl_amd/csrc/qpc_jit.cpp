@@ -51,7 +51,7 @@ std::string qpc_jit_source(const QpcDims &D) {
     << D.max_pdas << "," << dbl(D.eps_primal) << "," << dbl(D.tau_pivot) << "," << dbl(D.tol_bound) << ","
     << dbl(D.tol_accept) << "};\n";
   o << "struct QpcBatchArgs { long long B; const double *q, *v, *desired, *cw, *cmax, *tw, *surf; double *tau, *vdot, "
-       "*cwrench; int32_t *status, *iters; unsigned long long *prof; unsigned long long *ticket; double *scratch; };\n";
+       "*cwrench; int32_t *status, *iters; unsigned long long *prof; unsigned long long *ticket; unsigned long long ticket_base; double *scratch; };\n";
   o << "extern \"C\" __global__ void __launch_bounds__(64, 2) qpc_tick_kernel_jit(const int *__restrict__ IT, "
        "const double *__restrict__ DT, const QpcBatchArgs A) {\n"
        "  __shared__ __attribute__((aligned(16))) double qpc_lds[" << (D.lds_doubles > 0 ? D.lds_doubles : 1) << "];\n"
@@ -59,7 +59,7 @@ std::string qpc_jit_source(const QpcDims &D) {
        "  while (true) {\n"
        "    unsigned long long t = 0;\n"
        "    if ((threadIdx.x & 63) == 0) t = atomicAdd(A.ticket, 1ull);\n"
-       "    const long long b = (long long)__shfl(t, 0, 64);\n"
+       "    const long long b = (long long)(__shfl(t, 0, 64) - A.ticket_base);\n"
        "    if (b >= A.B) break;\n"
        "    qpc::TickIO io;\n"
        "    io.q = A.q + b * kD.nq; io.v = A.v + b * kD.nv; io.desired = A.desired + b * kD.n_desired;\n"

@@ -63,7 +63,10 @@ struct QpcBatchArgs {
   double *tau, *vdot, *cwrench;
   int32_t *status, *iters;
   unsigned long long *prof;
-  unsigned long long *ticket; // dynamic work distribution: next QP index (zeroed before each launch)
+  unsigned long long *ticket; // dynamic work distribution: a counter that is never reset; a launch draws exactly
+                              // B + gridDim.x tickets (every workgroup draws one past the end), so the host knows
+                              // where the next launch starts (ticket_base) without a memset in between
+  unsigned long long ticket_base;
   double *scratch;            // QPC_SCRATCH_DOUBLES per resident workgroup (lane-private spill slots)
 };
 
@@ -76,7 +79,7 @@ qpc_tick_kernel(const QpcDims D, const int *__restrict__ IT, const double *__res
   while (true) {
     unsigned long long t = 0;
     if ((threadIdx.x & 63) == 0) t = atomicAdd(A.ticket, 1ull);
-    const long long b = (long long)__shfl(t, 0, 64);
+    const long long b = (long long)(__shfl(t, 0, 64) - A.ticket_base);
     if (b >= A.B) break;
     qpc::TickIO io;
     io.q = A.q + b * D.nq; io.v = A.v + b * D.nv;
@@ -112,6 +115,7 @@ struct QpcDeviceState {
   hipModule_t jit_module = nullptr;
   hipFunction_t jit_func = nullptr;
   unsigned long long *d_ticket = nullptr;
+  unsigned long long ticket_next = 0; // value of *d_ticket once every launch enqueued so far has drained
   double *d_scratch = nullptr;
 };
 
@@ -139,8 +143,9 @@ static int launch(qpc_controller *c, const QpcBatchArgs &a, hipStream_t stream) 
   }
   QpcBatchArgs aa = a;
   aa.ticket = S->d_ticket;
+  aa.ticket_base = S->ticket_next;
+  S->ticket_next += (unsigned long long)a.B + (unsigned long long)grid;
   aa.scratch = S->d_scratch;
-  HIP_TRY(hipMemsetAsync(S->d_ticket, 0, sizeof(unsigned long long), stream));
   if (S->jit_func) {
     const int *it = S->d_it;
     const double *dt = S->d_dt;
@@ -193,6 +198,7 @@ int32_t qpc_finalize(qpc_controller *c, int32_t device_id, qpc_layout *out) {
   HIP_TRY(hipMemcpy(S->d_dt, c->prog.dtab.data(), sizeof(double) * c->prog.dtab.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipStreamCreate(&S->stream));
   HIP_TRY(hipMalloc(&S->d_ticket, sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(S->d_ticket, 0, sizeof(unsigned long long)));
   HIP_TRY(hipMalloc(&S->d_scratch, sizeof(double) * QPC_SCRATCH_DOUBLES * (size_t)S->n_cu * S->blocks_per_cu));
   // JIT specialisation on this controller's program (QPC_DISABLE_JIT=1 keeps the generic kernel)
   const char *nojit = getenv("QPC_DISABLE_JIT");
