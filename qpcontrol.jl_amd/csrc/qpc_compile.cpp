@@ -430,7 +430,7 @@ int qpc_compile_program(qpc_controller *c) {
   L(L_X2, m1 * 6); L(L_B22, 36); L(L_C22, 36); L(L_S22I, 36);
   D.lds[L_L22] = D.lds[L_C22]; // retired
   L(L_KR, D.nc * N * N); L(L_T1, mm); D.lds[L_T2] = D.lds[L_T1]; D.lds[L_T3] = D.lds[L_T1]; // T2/T3 retired
-  L(L_XV, D.nf); L(L_XE, ne); L(L_XR, nrho); L(L_LAM, mm); L(L_U, nrho);
+  L(L_XV, D.nf); L(L_XE, ne); L(L_XR, nrho); L(L_LAM, mm); L(L_U, nrho); L(L_WSP, nrho);
   const int xbase = off;
   // X (explicit L11^-1) is dead before the first iterate vector is written
   L(L_RV, D.nf); L(L_RE, ne); L(L_RR, nrho); L(L_RC, mm);

@@ -90,6 +90,7 @@ enum {
   L_CWR,                 // nc*6 contact wrenches
   L_BW,                  // nb*6 body wrenches (RNEA)
   L_SVK,                 // nv*6 S_k * vdot_k (RNEA)
+  L_WSP,                 // nrho working set before the last primal-dual update (fallback of the search)
   L_COUNT
 };
 

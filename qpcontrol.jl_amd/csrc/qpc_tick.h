@@ -1467,6 +1467,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
         double changed = 0.0, up = 0.0;
         for (int j = lane; j < nrho; j += 64) {
           double w = sm[D.lds[L_WS] + j], hi = sm[D.lds[L_HI] + j], x = sm[D.lds[L_XR] + j], nw_ = w;
+          sm[D.lds[L_WSP] + j] = w; // the set this solution belongs to (fallback, see below)
           if (!(hi > 0.0)) continue; // disabled
           if (w != 0.0) { if (sm[D.lds[L_U] + j] < -D.tol_bound * gscale) nw_ = 0.0; }
           else if (x < -tolb) nw_ = -1.0;
@@ -1484,6 +1485,34 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       any_upper = rup > 0.0;
       iters++;
       S.refactor_solve(any_upper);
+    }
+    // The multi-change sweeps can land on a working set with so many rho's pinned that the wrench
+    // rows have no solution on it (the EQP is inconsistent although the QP is feasible); its
+    // "solution" is meaningless and phase B, which assumes a valid point, must not start from it.
+    // Measured: it happens to ~0.5 % of the QPs and only at the last sweep, so the working set of the
+    // sweep before (L_WSP) is tried first; the all-free set -- consistent whenever the QP is feasible
+    // at all, but ~30 Goldfarb-Idnani additions away from the optimum -- is the last resort.
+    if (!any_upper) {
+      for (int attempt = 0; attempt < 3; attempt++) {
+        double incons = 0.0; // residual of S22 lam_w = u0: rows the infinite-pivot rule dropped as dependent
+                             // must still be satisfied (L_C22 still holds S22 of this working set: fused path)
+        QPC_PHASE(lane) {
+          double r = 0.0;
+          if (lane < 6) {
+            const double u = sm[MISC + MS_U0 + lane];
+            r = QPC_FABS(u - dotp(sm + D.lds[L_C22] + lane * 6, 1, sm + D.lds[L_LAM] + m1, 1, 6)) / (1.0 + QPC_FABS(u));
+          }
+          QPC_RED_MAX_PUT(0, incons, r);
+        } QPC_END_PHASE
+        incons = QPC_RED_MAX_GET(0, incons);
+        if (!(incons > 1e-6) || attempt == 2) break;
+        QPC_PHASE(lane) {
+          for (int j = lane; j < nrho; j += 64)
+            sm[D.lds[L_WS] + j] = attempt == 0 ? (double)sm[D.lds[L_WSP] + j] : (sm[D.lds[L_HI] + j] > 0.0 ? 0.0 : -1.0);
+        } QPC_END_PHASE
+        iters++;
+        S.refactor_solve(false);
+      }
     }
     // ---- phase B: drops until dual feasible, then Goldfarb-Idnani additions (finite)
     while (true) {
