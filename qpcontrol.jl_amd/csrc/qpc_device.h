@@ -95,6 +95,9 @@ __device__ __forceinline__ int wave_min_int(int x) {
 #define QPC_RED_ARGMIN_PUT(slot, name, iname, val, idx) \
   do { double v__ = (val); name = qpc::wave_min(v__); iname = qpc::wave_min_int(v__ == name ? (int)(idx) : 0x3fffffff); } while (0)
 #define QPC_RED_ARGMIN_GET(slot, name, iname) ((void)0)
+// 64-bit lane mask of a predicate (one scalar compare); same PUT / GET protocol
+#define QPC_BALLOT_PUT(slot, name, pred) name = __ballot((pred) ? 1 : 0)
+#define QPC_BALLOT_GET(slot, name) ((void)0)
 
 // fp64 matrix core: acc(16x16 tile, 4 f64 per lane) += A(16x4) * B(4x16) with v_mfma_f64_16x16x4_f64.
 //   lane l supplies A[i = l&15][k = l>>4] (AEXPR) and B[k = l>>4][j = l&15] (BEXPR);

@@ -1514,13 +1514,21 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
         S.refactor_solve(false);
       }
     }
-    // ---- phase B: drops until dual feasible, then Goldfarb-Idnani additions (finite)
+    // ---- phase B: drops until dual feasible, then Goldfarb-Idnani additions (finite in exact
+    //      arithmetic: no working set is visited twice).  A repeated working set therefore means the
+    //      iteration is cycling on rounding noise (seen on infeasible single-contact QPs, which used to
+    //      burn all max_active_set_iters): recognised from the bit masks of the last 8 working sets.
+    const bool track_b = nrho <= 64; // one rho per lane: two ballots ARE the working set
+    unsigned long long lo_h[8], up_h[8];
+    for (int h = 0; h < 8; h++) { lo_h[h] = ~0ull; up_h[h] = ~0ull; }
+    int hpos = 0;
     while (true) {
       if (iters > D.max_as_iters) { status = QPC_STATUS_ITERATION_LIMIT; break; }
       const double gscale = 1.0 + S.last_gmax, tolb = D.tol_bound * (1.0 + S.last_xmax); // U is current (rho_solve)
       // most negative multiplier / most violated bound (lane-parallel + wave argmin)
       double ubad = 0.0, vneg = 0.0, rnan = 0.0;
       int jbad = -1, pviol = -1;
+      unsigned long long lo_now = 0ull, up_now = 0ull;
       QPC_PHASE(lane) {
         double bu = 1e300, bv = 1e300, bad = 0.0;
         int ju = 0x3fffffff, jv = 0x3fffffff;
@@ -1534,10 +1542,22 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
         QPC_RED_ARGMIN_PUT(0, ubad, jbad, bu, ju);
         QPC_RED_ARGMIN_PUT(1, vneg, pviol, bv, jv);
         QPC_RED_MAX_PUT(2, rnan, bad);
+        const double wl_ = lane < nrho ? (double)sm[D.lds[L_WS] + (lane < nrho ? lane : 0)] : 0.0;
+        QPC_BALLOT_PUT(3, lo_now, wl_ == -1.0);
+        QPC_BALLOT_PUT(4, up_now, wl_ == 1.0);
       } QPC_END_PHASE
       QPC_RED_ARGMIN_GET(0, ubad, jbad);
       QPC_RED_ARGMIN_GET(1, vneg, pviol);
       rnan = QPC_RED_MAX_GET(2, rnan);
+      QPC_BALLOT_GET(3, lo_now);
+      QPC_BALLOT_GET(4, up_now);
+      if (track_b) {
+        bool seen = false;
+        if (iters >= 10) // ordinary QPs are done long before: only the stragglers pay for the comparisons
+          for (int h = 0; h < 8; h++) seen = seen || (lo_h[h] == lo_now && up_h[h] == up_now);
+        if (seen) { status = QPC_STATUS_ITERATION_LIMIT; break; }
+        lo_h[hpos] = lo_now; up_h[hpos] = up_now; hpos = (hpos + 1) & 7;
+      }
       const bool finite = !(rnan > 0.0);
       if (!(ubad < -D.tol_bound * gscale)) jbad = -1;
       if (!(-vneg > tolb)) pviol = -1;

@@ -89,6 +89,9 @@ static thread_local double emu_mfma_a[64], emu_mfma_b[64];
 // follows the kernel's LDS slab
 #define QPC_RED_MAX_PUT(slot, name, val) sm[D.lds_doubles + 128 * (slot) + lane] = (val)
 #define QPC_RED_MAX_GET(slot, name) qpc::umax(sm, D.lds_doubles + 128 * (slot), 64)
+#define QPC_BALLOT_PUT(slot, name, pred) sm[D.lds_doubles + 128 * (slot) + lane] = (pred) ? 1.0 : 0.0
+#define QPC_BALLOT_GET(slot, name) \
+  do { name = 0ull; for (int l__ = 0; l__ < 64; l__++) if ((double)sm[D.lds_doubles + 128 * (slot) + l__] != 0.0) name |= 1ull << l__; } while (0)
 #define QPC_RED_ARGMIN_PUT(slot, name, iname, val, idx) \
   do { sm[D.lds_doubles + 128 * (slot) + lane] = (val); sm[D.lds_doubles + 128 * (slot) + 64 + lane] = (double)(idx); } while (0)
 #define QPC_RED_ARGMIN_GET(slot, name, iname) \
