@@ -1,0 +1,124 @@
+"""Seeded fuzzing of the task program compiler + device assembly: random tree mechanisms, random
+task sets (every task kind, hard / scalar / matrix / per-QP weights, foreign frames, reversed
+paths, duplicate and path-joint pins), random contacts -- emulated kernel vs the oracle tick.
+Infeasible combinations are fine (both sides must then agree on the verdict)."""
+import numpy as np
+import pytest
+
+import emu
+import parity
+import scenarios as SC
+from oracle import oracle as O
+from qpcontrol_jl_amd import models as M
+from qpcontrol_jl_amd.workloads import (ANGULAR, HARD, JOINT, LINEAR, LINEAR_MOMENTUM_RATE, MATRIX, MATRIX_PER_QP,
+                                        MOMENTUM_RATE, POINT, SCALAR, SCALAR_PER_QP, SPATIAL)
+
+
+def ora_factory(mech, n_basis, floating):
+    return O.OracleController(O.OracleModel(mech), n_basis, floating)
+
+
+def build(factory, seed, B=2):
+    rng = np.random.default_rng(seed)
+    floating = bool(rng.integers(0, 2))
+    n = int(rng.integers(4, 12))
+    types = ([M.QUAT_FLOATING] if floating else []) + [int(rng.choice([M.REVOLUTE, M.REVOLUTE, M.PRISMATIC, M.FIXED])) for _ in range(n)]
+    mech = M.rand_tree(types, seed=seed + 1000, chain=bool(rng.integers(0, 2)))
+    nb = mech.nbodies
+    N = int(rng.choice([3, 4, 4, 5]))
+    fl = 0 if floating else -1
+    c = factory(mech, N, fl)
+    nc = int(rng.integers(0, 4)) if floating else 0
+    for _ in range(nc):
+        c.add_contact(int(rng.integers(1, nb)), rng.normal(size=3) * 0.2, [rng.normal() * 0.2, rng.normal() * 0.2, 1.0], float(rng.uniform(0.3, 1.0)))
+    for j in range(nb):
+        c.regularize(j, float(rng.uniform(0.02, 0.2)))
+    dims, ntw = [], 0
+    moving = [j for j in range(nb) if mech.joint_type[j] != M.FIXED]
+    for _ in range(int(rng.integers(1, 5))):
+        kind = int(rng.choice([SPATIAL, ANGULAR, LINEAR, POINT, JOINT, JOINT, LINEAR_MOMENTUM_RATE, MOMENTUM_RATE]))
+        wsel = int(rng.integers(0, 5))
+        dim = {SPATIAL: 6, ANGULAR: 3, LINEAR: 3, POINT: 3, LINEAR_MOMENTUM_RATE: 3, MOMENTUM_RATE: 6}.get(kind)
+        kw = {}
+        if kind == JOINT:
+            j = int(rng.choice(moving))
+            if mech.joint_type[j] == M.QUAT_FLOATING:
+                continue
+            dim = 1
+            kw = dict(joint=j)
+        elif kind in (SPATIAL, ANGULAR, LINEAR):
+            base = int(rng.integers(-1, nb))
+            target = int(rng.integers(0, nb))
+            if base == target:
+                continue
+            kw = dict(base=base, target=target, frame=int(rng.choice([M.FRAME_DEFAULT, M.WORLD, int(rng.integers(0, nb))])))
+        elif kind == POINT:
+            base = int(rng.integers(-1, nb))
+            target = int(rng.integers(0, nb))
+            if base == target:
+                continue
+            kw = dict(base=base, target=target, point=rng.normal(size=3) * 0.2)
+        if kind in (SPATIAL, MOMENTUM_RATE) and wsel == 0:
+            wsel = 1  # a hard 6-row task on a short random tree is almost always infeasible: keep it soft
+        if wsel == 0:
+            c.add_task(kind, wkind=HARD, **kw)
+        elif wsel == 1:
+            c.add_task(kind, wkind=SCALAR, weight=[float(rng.uniform(0.5, 3.0))], **kw)
+        elif wsel == 2:
+            Wm = rng.normal(size=(dim, dim))
+            c.add_task(kind, wkind=MATRIX, weight=Wm @ Wm.T + 0.2 * np.eye(dim), **kw)
+        elif wsel == 3:
+            c.add_task(kind, wkind=SCALAR_PER_QP, **kw)
+            ntw += 1
+        else:
+            c.add_task(kind, wkind=MATRIX_PER_QP, **kw)
+            ntw += dim * dim
+        dims.append((dim, wsel))
+    c.finalize()
+    qs, vs = zip(*(M.rand_state(mech, rng, 0.3) for _ in range(B)))
+    des = rng.normal(size=(B, sum(d for d, _ in dims))) * 0.5
+    tw = None
+    if ntw:
+        cols = []
+        for d, wsel in dims:
+            if wsel == 3:
+                cols.append(rng.uniform(0.5, 2.0, size=(B, 1)))
+            elif wsel == 4:
+                Ws = []
+                for _b in range(B):
+                    Wm = rng.normal(size=(d, d))
+                    Ws.append((Wm @ Wm.T + 0.2 * np.eye(d)).reshape(-1))
+                cols.append(np.array(Ws))
+        tw = np.concatenate(cols, axis=1)
+    return SC.Case(f"fuzz{seed}", mech, c, np.array(qs), np.array(vs), des, np.full((B, nc), 1e-2), np.full((B, nc), 1e4),
+                   tw=tw, floating=fl, n_basis=N, tol_tau=1e-6)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_fuzz_emulated(seed):
+    emu.build()
+    emu.race_report()
+    g, o = build(emu.factory, seed), build(ora_factory, seed)
+    rg = g.ctrl.control_batch(g.q, g.v, g.desired, g.cweight, g.cmaxf, g.tw, g.surf)
+    ro = o.ctrl.tick_batch(o.q, o.v, o.desired, o.cweight, o.cmaxf, o.tw, o.surf)
+    races, uninit, outside, first = emu.race_report()
+    assert (races, uninit, outside) == (0, 0, 0), first
+    so, sg = ro["status"], rg["status"]
+    concl = (so == 0) | (so == 2)
+    assert np.array_equal((sg == 0)[concl], (so == 0)[concl]), (sg, so)
+    if (so == 0).any() or (~concl & (sg == 0)).any():
+        parity.compare(g, rg, o, ro)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(100, 112))
+def test_fuzz_gpu(seed):
+    from qpcontrol_jl_amd import binding
+    g, o = build(lambda mech, N, fl: binding.Controller(binding.Model(mech), N, fl), seed, B=4), build(ora_factory, seed, B=4)
+    rg = g.ctrl.control_batch(g.q, g.v, g.desired, g.cweight, g.cmaxf, g.tw, g.surf)
+    ro = o.ctrl.tick_batch(o.q, o.v, o.desired, o.cweight, o.cmaxf, o.tw, o.surf)
+    so, sg = ro["status"], rg["status"]
+    concl = (so == 0) | (so == 2)
+    assert np.array_equal((sg == 0)[concl], (so == 0)[concl]), (sg, so)
+    if (so == 0).any() or (~concl & (sg == 0)).any():
+        parity.compare(g, rg, o, ro)
