@@ -295,3 +295,78 @@ class StandingController:
 
     def __call__(self, tau, t, x, **kw):
         return self.lowlevel(tau, t, x, **kw)
+
+
+class SE3PDGains:
+    """RigidBodyDynamics.PDControl.SE3PDGains(FramePDGains(frame, PDGains(k, d)) x 2) with scalar gains,
+    both expressed in the controlled body's frame (test/controller.jl:13)."""
+
+    def __init__(self, angular: PDGains, linear: PDGains):
+        self.angular, self.linear = angular, linear
+
+
+class SE3PDController:
+    """SE3PDController(base, body, trajectory, weight, gains) -- src/lowlevel/se3pdcontroller.jl:1-18.
+
+    `controller(t, (q, v))` returns, per state, the desired spatial acceleration of `body` w.r.t.
+    `base` expressed in the body frame: `Tdref + pd(gains, H, Href, T, Tref)` (se3pdcontroller.jl:13-18),
+    ready for `setdesired(SpatialAccelerationTask(mechanism, base, body), ...)`; `weight` is kept for
+    the caller's `addtask(task, weight)` as in the reference struct.  The SE(3) PD law itself lives in
+    the un-vendored RigidBodyDynamics.PDControl; it is restated here from its documented form (double
+    geodesic law, Bullo & Murray 1995, Thm. 12): with e = inv(Href) H (actual body frame -> desired
+    frame) and edot = T - Ad(inv(e)) Tref,  ang = -k_w log(R_e) - d_w edot_ang,
+    lin = -k_v R_e' p_e - d_v edot_lin.  [recalled semantics: the reference tree only smoke-tests this
+    controller (test/controller.jl:1-20), so its numerics are unpinned.]"""
+
+    def __init__(self, mechanism: Mechanism, base, body, trajectory, weight, gains: SE3PDGains):
+        self.mechanism = mechanism
+        self.base, self.body = _body(mechanism, base), _body(mechanism, body)
+        self.trajectory, self.weight, self.gains = trajectory, weight, gains
+
+    @staticmethod
+    def _rotvec(R):
+        from .trajectories import Quat  # log map through the quaternion
+        tr = np.trace(R)
+        w = 0.5 * np.sqrt(max(1.0 + tr, 0.0))
+        if w > 1e-8:
+            v = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]) / (4.0 * w)
+        else:  # rotation by pi
+            d = np.sqrt(np.maximum((np.diag(R) + 1.0) / 2.0, 0.0))
+            v = d
+        angle, axis = Quat(w, *v).angle_axis()
+        return angle * axis
+
+    def __call__(self, t, x):
+        from .workloads import batch_kinematics
+        q, v = x
+        kin = batch_kinematics(self.mechanism, q, v)
+        B = np.atleast_2d(q).shape[0]
+        Href, Tref, Tdref = self.trajectory(t, 2)
+        out = np.zeros((B, 6))
+
+        def pose(b, i):
+            return (np.eye(3), np.zeros(3)) if i < 0 else (kin["R"][i][b], kin["p"][i][b])
+
+        def twist(b, i):  # world-frame twist about the world origin
+            return (np.zeros(3), np.zeros(3)) if i < 0 else (kin["w"][i][b], kin["v"][i][b])
+        for b in range(B):
+            Rb, pb = pose(b, self.body)
+            Ra, pa = pose(b, self.base)
+            R = Ra.T @ Rb                      # H = relative_transform(body -> base)
+            p = Ra.T @ (pb - pa)
+            wb, vb = twist(b, self.body)
+            wa, va = twist(b, self.base)
+            w_rel = wb - wa                    # relative twist, world coordinates about the world origin
+            v_rel = vb - va
+            T_ang = Rb.T @ w_rel               # ... re-expressed in the body frame (origin at the body frame)
+            T_lin = Rb.T @ (v_rel + np.cross(w_rel, pb))
+            Re = Href["R"].T @ R               # e = inv(Href) * H
+            pe = Href["R"].T @ (p - Href["p"])
+            # Tref (given in the DESIRED body frame) seen from the actual body frame: Ad(inv(e))
+            Tr_ang = Re.T @ Tref["v"][:3]
+            Tr_lin = Re.T @ (Tref["v"][3:] + np.cross(Tref["v"][:3], pe))
+            ed_ang, ed_lin = T_ang - Tr_ang, T_lin - Tr_lin
+            ang = -self.gains.angular.k * self._rotvec(Re) - self.gains.angular.d * ed_ang
+            lin = -self.gains.linear.k * (Re.T @ pe) - self.gains.linear.d * ed_lin
+            out[b] = Tdref["v"] + np.concatenate([ang, lin])
+        return out
