@@ -136,12 +136,20 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    # QPC_BENCH_TEST_ONE_DEVICE=1 (test hook): every rank uses cuda:0 and the process group is gloo, so that the
+    # multi-rank code path can be exercised on a single-GPU box; the numbers of such a run mean nothing
+    one_device = os.environ.get("QPC_BENCH_TEST_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     B = args.batch_per_gpu
 
@@ -213,7 +221,7 @@ def main():
     L.qpc_timing_read(ctrl.h, ctypes.byref(avg_ms), ctypes.byref(nl))
     L.qpc_timing_enable(ctrl.h, 0)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_device else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st = status.cpu().numpy()

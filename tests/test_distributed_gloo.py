@@ -66,3 +66,25 @@ def test_shard_bounds_cover_batch():
             assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
             sizes = [hi - lo for lo, hi in b]
             assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_device():
+    """bench.py's multi-rank code path (torch.distributed.run launch, env parsing, barrier, max-over-ranks
+    time, one JSON line from rank 0) on a single-GPU box: both ranks share cuda:0 through the
+    QPC_BENCH_TEST_ONE_DEVICE hook (gloo instead of RCCL).  The value is meaningless, the plumbing is not."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, QPC_BENCH_TEST_ONE_DEVICE="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3",
+                          "--warmup", "1", "--batch-per-gpu", "2048"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4096 and d["scaling"] == "weak" and d["value"] > 0
+    assert "cpu_baseline" not in d  # rank 0 at N = 1 only
