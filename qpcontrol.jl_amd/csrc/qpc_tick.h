@@ -489,6 +489,7 @@ template <class P> struct Solver {
         double mtl = dotp(sm + D.lds[L_M] + f, D.nfs, sm + D.lds[L_LAM], 1, m);
         double sq = sm[D.lds[L_SQH] + f];
         sm[D.lds[L_RV] + f] = -(sm[D.lds[L_HV] + f] * sq * sm[D.lds[L_XV] + f] + sm[D.lds[L_GV] + f] + mtl / sq);
+        sm[D.lds[L_DV] + f] = QPC_FABS(mtl / sq); // |E_v' lam|: scale of the stationarity test (L_DV is free here)
       }
       for (int s = lane; s < ne; s += 64) {
         int d = slack_dim(s), wr = slack_woff(s), s0 = slack_s0(s);
@@ -1645,10 +1646,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
         for (int f = lane; f < nf; f += 64) {
           double a = QPC_FABS(sm[D.lds[L_RV] + f]); rs = a > rs || !(a == a) ? a : rs;
           double b = QPC_FABS(sm[D.lds[L_GV] + f]); ss = b > ss ? b : ss;
-          // |E_v' lam| scale
-          double mtl = 0.0;
-          for (int r = 0; r < m; r++) mtl += sm[D.lds[L_M] + r * D.nfs + f] * sm[D.lds[L_LAM] + r];
-          b = QPC_FABS(mtl / sm[D.lds[L_SQH] + f]); ss = b > ss ? b : ss;
+          b = sm[D.lds[L_DV] + f]; ss = b > ss ? b : ss; // |E_v' lam| scale, left there by Solver::residuals
         }
         for (int s = lane; s < ne; s += 64) { double a = QPC_FABS(sm[D.lds[L_RE] + s]); rs = a > rs || !(a == a) ? a : rs; }
         for (int j = lane; j < nrho; j += 64) {
