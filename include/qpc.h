@@ -264,6 +264,53 @@ int32_t qpc_qp_solve_batch(int32_t n, int32_t m, int64_t B, const double *P, con
                            const qpc_settings *settings, int32_t device_id, double *x, double *y,
                            int32_t *status, int32_t *iters);
 
+/* ---- closed loop: what the reference's acceptance test does around the tick,
+ *      notebooks/Standing controller.ipynb cells 9-11 -- `Dynamics(mechanism, controller)` with a
+ *      soft contact model, stepped by RigidBodySim `simulate` -- for a batch of robots on the device.
+ * Ground: the half space z <= ground_z, felt at the controller's contact points (qpc_add_contact:
+ * body, position, mu): normal force max(stiffness*penetration - damping*v_z, 0), tangential force
+ * -tangential_damping*v_xy capped at mu * normal force.  Integrator: semi-implicit Euler,
+ * v += dt*vdot, q <- q (+) v*dt on the configuration manifold (unit quaternion renormalised). */
+typedef struct qpc_sim_params {
+  double dt;                 /* step, e.g. 1e-3 (the control rate)  */
+  double ground_z;           /* height of the ground plane          */
+  double stiffness;          /* N/m   per contact point             */
+  double damping;            /* N s/m per contact point, normal     */
+  double tangential_damping; /* N s/m per contact point, tangential */
+} qpc_sim_params;
+
+/* One forward-dynamics step  M(q) vdot = tau - c(q, v, ground)  per robot, in place on q[nq*B], v[nv*B].
+ * tau[nv*B]: joint torques (floating-joint entries are applied as given: the tick writes zeros there,
+ * momentum.jl:93-97).  status[B] or NULL: tick statuses; a robot whose QP failed (status beyond
+ * ALMOST_OPTIMAL, checkstatus momentum.jl:83-91) gets zero torque for the step.  bad[B] or NULL:
+ * incremented for such a robot (and for a non-positive-definite mass matrix, which leaves the state
+ * untouched).  Host pointers, synchronous; the controller must be finalized. */
+int32_t qpc_sim_step_batch(qpc_controller *ctrl, int64_t B, double *q, double *v, const double *tau,
+                           const int32_t *status, const qpc_sim_params *params, int32_t *bad);
+/* Same with DEVICE pointers, enqueued on `hip_stream` without synchronising. */
+int32_t qpc_sim_step_batch_device(qpc_controller *ctrl, int64_t B, double *q, double *v,
+                                  const double *tau, const int32_t *status,
+                                  const qpc_sim_params *params, int32_t *bad, void *hip_stream);
+
+/* n_steps x (controller tick -> simulation step) without leaving the device: the batched counterpart
+ * of `simulate(problem, ...)` in the notebook.  q, v are advanced in place; the tick inputs (desired,
+ * contact_weight, ...) are as in qpc_control_batch and held constant over the rollout (`desired` may be
+ * NULL when every task has a desired law, qpc_task_set_law).  Out: tau[nv*B] and status[B] of the LAST
+ * tick (either may be NULL), bad[B] = number of steps whose QP failed per robot (may be NULL).
+ * Host pointers, synchronous. */
+int32_t qpc_rollout_batch(qpc_controller *ctrl, int64_t B, int64_t n_steps, double *q, double *v,
+                          const double *desired, const double *contact_weight,
+                          const double *contact_maxnormalforce, const double *task_weights,
+                          const double *surfaces, const qpc_sim_params *params, double *tau,
+                          int32_t *status, int32_t *bad);
+/* Same with DEVICE pointers on `hip_stream`, not synchronised.  tau[nv*B], vdot[nv*B], status[B] are
+ * caller-provided work/output buffers (all required); bad[B] may be NULL. */
+int32_t qpc_rollout_batch_device(qpc_controller *ctrl, int64_t B, int64_t n_steps, double *q, double *v,
+                                 const double *desired, const double *contact_weight,
+                                 const double *contact_maxnormalforce, const double *task_weights,
+                                 const double *surfaces, const qpc_sim_params *params, double *tau,
+                                 double *vdot, int32_t *status, int32_t *bad, void *hip_stream);
+
 /* QPSolveFailure text (exceptions.jl:7-11) */
 const char *qpc_status_string(int32_t status);
 const char *qpc_last_error(void);

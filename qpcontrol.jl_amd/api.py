@@ -208,13 +208,9 @@ class MomentumBasedController:
         return self.layout
 
     # -- the tick ----------------------------------------------------------------------------
-    def __call__(self, tau, t, x, surfaces=None, throw_on_failure=True):
-        if not self.initialized:
-            self.finalize()
-        q, v = x
-        q = np.atleast_2d(np.asarray(q, dtype=np.float64))
-        v = np.atleast_2d(np.asarray(v, dtype=np.float64))
-        B = q.shape[0]
+    def _inputs(self, B):
+        """per-QP input arrays from the mutable cells of the reference objects (task.desired,
+        point.weight, point.maxnormalforce, Parameter weights), broadcast over the batch"""
         lay = self.layout
 
         def bc(val, n):
@@ -233,6 +229,15 @@ class MomentumBasedController:
                                                  if w.value.ndim else w.value.reshape(1, 1),
                                                  (B, 1 if w.value.ndim <= 1 else tk.dim * tk.dim))
                                  for tk, w in self._weights], axis=1)
+        return des, cw, cm, tw
+
+    def __call__(self, tau, t, x, surfaces=None, throw_on_failure=True):
+        if not self.initialized:
+            self.finalize()
+        q, v = x
+        q = np.atleast_2d(np.asarray(q, dtype=np.float64))
+        v = np.atleast_2d(np.asarray(v, dtype=np.float64))
+        des, cw, cm, tw = self._inputs(q.shape[0])
         r = self._c.control_batch(q, v, des, cw, cm, tw, surfaces)
         self.result_vdot, self.contactwrenches, self.status = r["vdot"], r["cwrench"], r["status"]
         self.iters = r["iters"]
@@ -244,6 +249,33 @@ class MomentumBasedController:
             np.copyto(tau, r["tau"])
             return tau
         return r["tau"]
+
+    # -- closed loop -------------------------------------------------------------------------
+    def simulate(self, x, n_steps, ground: "SoftGround", dt=1e-3, surfaces=None):
+        """Batched counterpart of the notebook's acceptance run (Standing controller.ipynb cells 9-11:
+        `Dynamics(mechanism, controller)` + soft contacts + `simulate`): n_steps x (tick -> forward-dynamics
+        step on compliant ground at this controller's contact points), all on the device
+        (qpc_rollout_batch).  Returns dict(q, v, tau, status, bad) with bad[b] = failed QPs of robot b."""
+        if not self.initialized:
+            self.finalize()
+        q, v = x
+        q = np.atleast_2d(np.asarray(q, dtype=np.float64))
+        v = np.atleast_2d(np.asarray(v, dtype=np.float64))
+        des, cw, cm, tw = self._inputs(q.shape[0])
+        r = self._c.rollout(q, v, n_steps, ground.params(dt), des, cw, cm, tw, surfaces)
+        self.status = r["status"]
+        return r
+
+
+class SoftGround:
+    """Compliant half space z <= z under the controller's contact points: normal spring/damper,
+    viscous tangential friction capped by Coulomb's law (qpc_sim_params)."""
+
+    def __init__(self, z, stiffness=6.0e4, damping=400.0, tangential_damping=300.0):
+        self.z, self.stiffness, self.damping, self.tangential_damping = z, stiffness, damping, tangential_damping
+
+    def params(self, dt):
+        return binding.SimParams(dt, self.z, self.stiffness, self.damping, self.tangential_damping)
 
 
 class StandingController:

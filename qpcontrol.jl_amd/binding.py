@@ -37,6 +37,12 @@ class Settings(ctypes.Structure):
                 ("tol_residual", ctypes.c_double), ("tol_bound", ctypes.c_double)]
 
 
+class SimParams(ctypes.Structure):
+    """qpc_sim_params: step and compliant-ground gains of the closed-loop step (include/qpc.h)."""
+    _fields_ = [("dt", ctypes.c_double), ("ground_z", ctypes.c_double), ("stiffness", ctypes.c_double),
+                ("damping", ctypes.c_double), ("tangential_damping", ctypes.c_double)]
+
+
 class QpcError(RuntimeError):
     pass
 
@@ -78,6 +84,11 @@ def load_library(path=None):
     L.qpc_qp_solve_batch.argtypes = [i32, i32, i64] + [c_double_p] * 5 + [ctypes.POINTER(Settings), i32, c_double_p,
                                                                          c_double_p, c_int32_p, c_int32_p]
     L.qpc_assemble_solve_batch.argtypes = [vp, i64] + [c_double_p] * 11 + [c_double_p, c_double_p, c_int32_p, c_int32_p]
+    L.qpc_sim_step_batch.argtypes = [vp, i64, c_double_p, c_double_p, c_double_p, c_int32_p, ctypes.POINTER(SimParams), c_int32_p]
+    L.qpc_rollout_batch.argtypes = [vp, i64, i64] + [c_double_p] * 7 + [ctypes.POINTER(SimParams), c_double_p, c_int32_p, c_int32_p]
+    if hasattr(L, "qpc_sim_step_batch_device"):
+        L.qpc_sim_step_batch_device.argtypes = [vp, i64, vp, vp, vp, vp, ctypes.POINTER(SimParams), vp, vp]
+        L.qpc_rollout_batch_device.argtypes = [vp, i64, i64] + [vp] * 7 + [ctypes.POINTER(SimParams)] + [vp] * 5
     if hasattr(L, "qpc_control_batch_device"):
         L.qpc_control_batch_device.argtypes = [vp, i64] + [vp] * 12 + [vp]
         L.qpc_timing_enable.argtypes = [vp, i32]
@@ -199,6 +210,50 @@ class Controller:
         _check(self.L, rc, "qpc_control_batch")
         return dict(tau=tau, vdot=vd, cwrench=cwr[:, :6 * lay.n_contacts].reshape(B, lay.n_contacts, 6),
                     status=status, iters=iters)
+
+    # ---- closed loop: forward-dynamics step and tick+step rollouts on the device
+    def sim_step(self, q, v, tau, params: SimParams, status=None, bad=None):
+        """one simulation step per robot (qpc_sim_step_batch); returns the new (q, v) and the failure counters"""
+        lay = self.layout
+        if lay is None:
+            raise QpcError("controller not finalized")
+        q = np.array(q, dtype=np.float64).reshape(-1, lay.nq)
+        B = q.shape[0]
+        v = np.array(v, dtype=np.float64).reshape(B, lay.nv)
+        tau = np.ascontiguousarray(tau, dtype=np.float64).reshape(B, lay.nv)
+        st = None if status is None else np.ascontiguousarray(status, dtype=np.int32).reshape(B)
+        bad = np.zeros(B, dtype=np.int32) if bad is None else np.array(bad, dtype=np.int32).reshape(B)
+        rc = self.L.qpc_sim_step_batch(self.h, B, _dp(q), _dp(v), _dp(tau), None if st is None else st.ctypes.data_as(c_int32_p),
+                                       ctypes.byref(params), bad.ctypes.data_as(c_int32_p))
+        _check(self.L, rc, "qpc_sim_step_batch")
+        return q, v, bad
+
+    def rollout(self, q, v, n_steps, params: SimParams, desired=None, contact_weight=None, contact_maxnormalforce=None,
+                task_weights=None, surfaces=None):
+        """n_steps x (tick -> simulation step) without leaving the device (qpc_rollout_batch)"""
+        lay = self.layout
+        if lay is None:
+            raise QpcError("controller not finalized")
+        q = np.array(q, dtype=np.float64).reshape(-1, lay.nq)
+        B = q.shape[0]
+        v = np.array(v, dtype=np.float64).reshape(B, lay.nv)
+
+        def arr(x, n):
+            if n == 0:
+                return None
+            if x is None:
+                raise QpcError("missing per-QP input array")
+            return np.ascontiguousarray(x, dtype=np.float64).reshape(B, n)
+        des = None if (desired is None and lay.n_desired_inputs == 0) else arr(desired, lay.n_desired)
+        cw, cm = arr(contact_weight, lay.n_contacts), arr(contact_maxnormalforce, lay.n_contacts)
+        tw, sf = arr(task_weights, lay.n_task_weights), arr(surfaces, lay.n_surface)
+        tau = np.zeros((B, lay.nv))
+        status, bad = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
+        rc = self.L.qpc_rollout_batch(self.h, B, int(n_steps), _dp(q), _dp(v), _dp(des), _dp(cw), _dp(cm), _dp(tw), _dp(sf),
+                                      ctypes.byref(params), _dp(tau), status.ctypes.data_as(c_int32_p),
+                                      bad.ctypes.data_as(c_int32_p))
+        _check(self.L, rc, "qpc_rollout_batch")
+        return dict(q=q, v=v, tau=tau, status=status, bad=bad)
 
 
 def assemble_solve_batch(ctrl: Controller, task_J, task_bias, desired, momentum_A=None, momentum_rhs=None, contact_R=None,

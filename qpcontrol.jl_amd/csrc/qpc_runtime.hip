@@ -22,6 +22,7 @@
 #define QPC_PROF_ACC(i) do { unsigned long long n__ = clock64(); PA[i] += n__ - *PT; *PT = n__; } while (0)
 #endif
 #include "qpc_tick.h"
+#include "qpc_sim.h"
 #include "qpc_qp_dense.h"
 #include "qpc_l1_dense.h"
 
@@ -96,6 +97,30 @@ qpc_tick_kernel(const QpcDims D, const int *__restrict__ IT, const double *__res
   }
 }
 
+// f-2: one simulation step per robot (qpc_sim.h), one wavefront per robot, static grid-stride (the
+// step has no data-dependent iteration count, so there is no tail to balance)
+struct QpcSimArgs {
+  long long B;
+  double *q, *v;
+  const double *tau;
+  const int32_t *status;
+  int32_t *bad;
+  qpc_sim_params sp;
+};
+extern "C" __global__ void __launch_bounds__(64)
+qpc_sim_kernel(const QpcDims D, const int *__restrict__ IT, const double *__restrict__ DT, const QpcSimArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double qpc_lds[];
+  for (long long b = blockIdx.x; b < A.B; b += gridDim.x) {
+    qpc::SimIO io;
+    io.q = A.q + b * D.nq; io.v = A.v + b * D.nv; io.tau = A.tau + b * D.nv;
+    io.status = A.status ? A.status + b : nullptr;
+    io.q_out = A.q + b * D.nq; io.v_out = A.v + b * D.nv;
+    io.bad = A.bad ? A.bad + b : nullptr;
+    qpc::qpc_sim_step<double *>(D, IT, DT, qpc_lds, io, A.sp);
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 struct QpcDeviceState {
   int device = -1;
@@ -117,6 +142,7 @@ struct QpcDeviceState {
   unsigned long long *d_ticket = nullptr;
   unsigned long long ticket_next = 0; // value of *d_ticket once every launch enqueued so far has drained
   double *d_scratch = nullptr;
+  int sim_blocks_per_cu = 1;
 };
 
 static int hip_fail(hipError_t e, const char *what) {
@@ -162,6 +188,18 @@ static int launch(qpc_controller *c, const QpcBatchArgs &a, hipStream_t stream) 
   return QPC_OK;
 }
 
+static int launch_sim(qpc_controller *c, const QpcSimArgs &a, hipStream_t stream) {
+  QpcDeviceState *S = c->dev;
+  const QpcDims &D = c->prog.dims;
+  long long grid = (long long)S->n_cu * S->sim_blocks_per_cu;
+  if (grid > a.B) grid = a.B;
+  if (grid < 1) return QPC_OK;
+  const size_t lds = (size_t)qpc::sim_layout(D).total * sizeof(double);
+  hipLaunchKernelGGL(qpc_sim_kernel, dim3((unsigned)grid), dim3(64), lds, stream, D, S->d_it, S->d_dt, a);
+  HIP_TRY(hipGetLastError());
+  return QPC_OK;
+}
+
 extern "C" {
 
 int32_t qpc_finalize(qpc_controller *c, int32_t device_id, qpc_layout *out) {
@@ -192,6 +230,13 @@ int32_t qpc_finalize(qpc_controller *c, int32_t device_id, qpc_layout *out) {
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 16) per_cu = 16; // 32 waves/CU cap; leave room for registers
   S->blocks_per_cu = per_cu;
+  {
+    const size_t slds = (size_t)qpc::sim_layout(D).total * sizeof(double);
+    if (slds > 160 * 1024) { delete S; qpc_set_error("qpc_finalize: simulation LDS slab exceeds the device limit"); return QPC_ERR_UNSUPPORTED; }
+    HIP_TRY(hipFuncSetAttribute((const void *)qpc_sim_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
+    int sper = (int)((160 * 1024) / (slds > 0 ? slds : 1));
+    S->sim_blocks_per_cu = sper < 1 ? 1 : (sper > 8 ? 8 : sper);
+  }
   HIP_TRY(hipMalloc(&S->d_it, sizeof(int) * c->prog.itab.size()));
   HIP_TRY(hipMalloc(&S->d_dt, sizeof(double) * c->prog.dtab.size()));
   HIP_TRY(hipMemcpy(S->d_it, c->prog.itab.data(), sizeof(int) * c->prog.itab.size(), hipMemcpyHostToDevice));
@@ -437,6 +482,108 @@ int32_t qpc_qp_solve_batch(int32_t n, int32_t m, int64_t B, const double *P, con
   }
   (void)hipFree(buf);
   return rc;
+}
+
+static int sim_check(qpc_controller *c, int64_t B, const void *q, const void *v, const void *tau, const qpc_sim_params *p, const char *who) {
+  if (!c || !c->finalized || !c->dev) { qpc_set_error("controller not finalized"); return QPC_ERR_NOT_FINALIZED; }
+  if (B < 0 || !q || !v || !tau || !p) { qpc_set_error(std::string(who) + ": missing array"); return QPC_ERR_INVALID_ARGUMENT; }
+  if (!(p->dt > 0.0) || !(p->stiffness >= 0.0) || !(p->damping >= 0.0) || !(p->tangential_damping >= 0.0)) {
+    qpc_set_error(std::string(who) + ": dt must be positive and the ground gains non-negative"); return QPC_ERR_INVALID_ARGUMENT;
+  }
+  return QPC_OK;
+}
+
+int32_t qpc_sim_step_batch_device(qpc_controller *c, int64_t B, double *q, double *v, const double *tau, const int32_t *status,
+                                  const qpc_sim_params *params, int32_t *bad, void *hip_stream) {
+  int rc = sim_check(c, B, q, v, tau, params, "qpc_sim_step_batch_device");
+  if (rc != QPC_OK) return rc;
+  HIP_TRY(hipSetDevice(c->dev->device));
+  QpcSimArgs a;
+  a.B = B; a.q = q; a.v = v; a.tau = tau; a.status = status; a.bad = bad; a.sp = *params;
+  return launch_sim(c, a, (hipStream_t)hip_stream);
+}
+
+int32_t qpc_rollout_batch_device(qpc_controller *c, int64_t B, int64_t n_steps, double *q, double *v, const double *desired,
+                                 const double *cw, const double *cmax, const double *tw, const double *surf,
+                                 const qpc_sim_params *params, double *tau, double *vdot, int32_t *status, int32_t *bad,
+                                 void *hip_stream) {
+  int rc = sim_check(c, B, q, v, tau, params, "qpc_rollout_batch_device");
+  if (rc != QPC_OK) return rc;
+  if (n_steps < 0 || !vdot || !status) { qpc_set_error("qpc_rollout_batch_device: missing array"); return QPC_ERR_INVALID_ARGUMENT; }
+  // two kernels per step on one stream; the tick's launch is asynchronous and its ticket base is
+  // tracked on the host, so n_steps steps are enqueued back to back without any synchronisation
+  for (int64_t s = 0; s < n_steps; s++) {
+    rc = qpc_control_batch_device(c, B, q, v, desired, cw, cmax, tw, surf, tau, vdot, nullptr, status, nullptr, hip_stream);
+    if (rc != QPC_OK) return rc;
+    rc = qpc_sim_step_batch_device(c, B, q, v, tau, status, params, bad, hip_stream);
+    if (rc != QPC_OK) return rc;
+  }
+  return QPC_OK;
+}
+
+// host-pointer variants: one device slab, synchronous
+static int rollout_host(qpc_controller *c, int64_t B, int64_t n_steps, bool tick, double *q, double *v, const double *desired,
+                        const double *cw, const double *cmax, const double *tw, const double *surf, const qpc_sim_params *params,
+                        double *tau, int32_t *status, int32_t *bad) {
+  const QpcDims &D = c->prog.dims;
+  QpcDeviceState *S = c->dev;
+  if (B == 0) return QPC_OK;
+  HIP_TRY(hipSetDevice(S->device));
+  const size_t nd[9] = {(size_t)D.nq, (size_t)D.nv, (size_t)D.nv, (size_t)D.nv, desired ? (size_t)D.n_desired : 0,
+                        (size_t)D.nc, (size_t)D.nc, (size_t)D.n_tw, (size_t)D.n_surf}; // q v tau vdot desired cw cmax tw surf
+  size_t total = 2 * (size_t)B * sizeof(int32_t) + 256;
+  for (int i = 0; i < 9; i++) total += ((nd[i] * B * sizeof(double)) + 63) & ~(size_t)63;
+  char *buf = nullptr;
+  if (hipMalloc(&buf, total) != hipSuccess) { qpc_set_error("rollout: out of device memory"); return QPC_ERR_OUT_OF_MEMORY; }
+  int rc = QPC_OK;
+  auto chk = [&](hipError_t e, const char *w) { if (e != hipSuccess && rc == QPC_OK) rc = hip_fail(e, w); };
+  char *p = buf;
+  double *d[9];
+  for (int i = 0; i < 9; i++) { d[i] = (double *)p; p += ((nd[i] * B * sizeof(double)) + 63) & ~(size_t)63; }
+  int32_t *dstatus = (int32_t *)p, *dbad = dstatus + B;
+  const double *hin[9] = {q, v, tick ? nullptr : tau, nullptr, desired, cw, cmax, tw, surf};
+  for (int i = 0; i < 9; i++)
+    if (hin[i] && nd[i]) chk(hipMemcpyAsync(d[i], hin[i], nd[i] * B * sizeof(double), hipMemcpyHostToDevice, S->stream), "copy inputs");
+  if (!tick && status) chk(hipMemcpyAsync(dstatus, status, B * sizeof(int32_t), hipMemcpyHostToDevice, S->stream), "copy status");
+  if (bad) chk(hipMemcpyAsync(dbad, bad, B * sizeof(int32_t), hipMemcpyHostToDevice, S->stream), "copy bad");
+  else chk(hipMemsetAsync(dbad, 0, B * sizeof(int32_t), S->stream), "clear bad");
+  if (rc == QPC_OK) {
+    if (tick)
+      rc = qpc_rollout_batch_device(c, B, n_steps, d[0], d[1], desired ? d[4] : nullptr, d[5], d[6], d[7], d[8], params, d[2],
+                                    d[3], dstatus, dbad, S->stream);
+    else
+      rc = qpc_sim_step_batch_device(c, B, d[0], d[1], d[2], status ? dstatus : nullptr, params, dbad, S->stream);
+  }
+  if (rc == QPC_OK) {
+    chk(hipMemcpyAsync(q, d[0], nd[0] * B * sizeof(double), hipMemcpyDeviceToHost, S->stream), "copy q");
+    chk(hipMemcpyAsync(v, d[1], nd[1] * B * sizeof(double), hipMemcpyDeviceToHost, S->stream), "copy v");
+    if (tick && tau) chk(hipMemcpyAsync(tau, d[2], nd[2] * B * sizeof(double), hipMemcpyDeviceToHost, S->stream), "copy tau");
+    if (tick && status) chk(hipMemcpyAsync(status, dstatus, B * sizeof(int32_t), hipMemcpyDeviceToHost, S->stream), "copy status");
+    if (bad) chk(hipMemcpyAsync(bad, dbad, B * sizeof(int32_t), hipMemcpyDeviceToHost, S->stream), "copy bad");
+  }
+  chk(hipStreamSynchronize(S->stream), "rollout");
+  (void)hipFree(buf);
+  return rc;
+}
+
+int32_t qpc_sim_step_batch(qpc_controller *c, int64_t B, double *q, double *v, const double *tau, const int32_t *status,
+                           const qpc_sim_params *params, int32_t *bad) {
+  int rc = sim_check(c, B, q, v, tau, params, "qpc_sim_step_batch");
+  if (rc != QPC_OK) return rc;
+  return rollout_host(c, B, 1, false, q, v, nullptr, nullptr, nullptr, nullptr, nullptr, params, const_cast<double *>(tau),
+                      const_cast<int32_t *>(status), bad);
+}
+
+int32_t qpc_rollout_batch(qpc_controller *c, int64_t B, int64_t n_steps, double *q, double *v, const double *desired,
+                          const double *cw, const double *cmax, const double *tw, const double *surf,
+                          const qpc_sim_params *params, double *tau, int32_t *status, int32_t *bad) {
+  int rc = sim_check(c, B, q, v, q, params, "qpc_rollout_batch");
+  if (rc != QPC_OK) return rc;
+  const QpcDims &D = c->prog.dims;
+  if (n_steps < 0 || (D.n_des_inputs && !desired) || (D.nc && (!cw || !cmax)) || (D.n_tw && !tw) || (D.n_surf && !surf)) {
+    qpc_set_error("qpc_rollout_batch: missing array"); return QPC_ERR_INVALID_ARGUMENT;
+  }
+  return rollout_host(c, B, n_steps, true, q, v, desired, cw, cmax, tw, surf, params, tau, status, bad);
 }
 
 // diagnostic (QPC_STAMPS builds): device buffer of B*PS_COUNT uint64 section cycle counters

@@ -100,6 +100,7 @@ static thread_local double emu_mfma_a[64], emu_mfma_b[64];
          int i__ = (int)(double)sm[D.lds_doubles + 128 * (slot) + 64 + l__]; \
          if (v__ < name || (v__ == name && i__ < iname)) { name = v__; iname = i__; } } } while (0)
 #include "../../qpcontrol.jl_amd/csrc/qpc_tick.h"
+#include "../../qpcontrol.jl_amd/csrc/qpc_sim.h"
 #include "../../qpcontrol.jl_amd/csrc/qpc_qp_dense.h"
 #include "../../qpcontrol.jl_amd/csrc/qpc_l1_dense.h"
 
@@ -184,6 +185,45 @@ int32_t qpc_qp_solve_batch(int32_t n, int32_t m, int64_t B, const double *P, con
   for (int64_t b = 0; b < B; b++)
     qpc::qp_solve_dense(n, m, P + b * n * n, q + b * n, A + b * m * n, l + b * m, u + b * m, st, ws.data(), x + b * n,
                         y + b * m, status + b, iters ? iters + b : nullptr);
+  return QPC_OK;
+}
+
+// f-2: simulation step / rollout through the lane-serial emulation of qpc_sim.h
+int32_t qpc_sim_step_batch(qpc_controller *c, int64_t B, double *q, double *v, const double *tau, const int32_t *status,
+                           const qpc_sim_params *params, int32_t *bad) {
+  if (!c || !c->finalized) return QPC_ERR_NOT_FINALIZED;
+  if (!q || !v || !tau || !params || !(params->dt > 0.0)) return QPC_ERR_INVALID_ARGUMENT;
+  const QpcDims &D = c->prog.dims;
+  EmuState emu;
+  g_emu = &emu;
+  for (int64_t b = 0; b < B; b++) {
+    emu.reset(qpc::sim_layout(D).total);
+    qpc::SimIO io;
+    io.q = q + b * D.nq; io.v = v + b * D.nv; io.tau = tau + b * D.nv; io.status = status ? status + b : nullptr;
+    io.q_out = q + b * D.nq; io.v_out = v + b * D.nv; io.bad = bad ? bad + b : nullptr;
+    qpc::qpc_sim_step<Lds>(D, c->prog.itab.data(), c->prog.dtab.data(), Lds{0}, io, *params);
+    g_races += emu.races; g_uninit += emu.uninit; g_outside += emu.outside;
+    if (g_first.empty()) g_first = emu.first;
+  }
+  g_emu = nullptr;
+  return QPC_OK;
+}
+
+int32_t qpc_rollout_batch(qpc_controller *c, int64_t B, int64_t n_steps, double *q, double *v, const double *desired,
+                          const double *cw, const double *cmax, const double *tw, const double *surf,
+                          const qpc_sim_params *params, double *tau, int32_t *status, int32_t *bad) {
+  if (!c || !c->finalized) return QPC_ERR_NOT_FINALIZED;
+  const QpcDims &D = c->prog.dims;
+  std::vector<double> t(B * D.nv), vd(B * D.nv);
+  std::vector<int32_t> st(B);
+  for (int64_t s = 0; s < n_steps; s++) {
+    int rc = qpc_control_batch(c, B, q, v, desired, cw, cmax, tw, surf, t.data(), vd.data(), nullptr, st.data(), nullptr);
+    if (rc != QPC_OK) return rc;
+    rc = qpc_sim_step_batch(c, B, q, v, t.data(), st.data(), params, bad);
+    if (rc != QPC_OK) return rc;
+  }
+  if (tau) memcpy(tau, t.data(), sizeof(double) * t.size());
+  if (status) memcpy(status, st.data(), sizeof(int32_t) * st.size());
   return QPC_OK;
 }
 

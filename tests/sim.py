@@ -14,10 +14,10 @@ class GroundContact:
     def __init__(self, z_ground, k=6.0e4, d=400.0, ct=300.0):  # explicit Euler at 1 kHz: d dt / m_foot well below 1
         self.z, self.k, self.d, self.ct = z_ground, k, d, ct
 
-    def wrenches(self, om, mech):
+    def wrenches(self, om, mech, contact_points=None):
         """external wrench per body, world frame about the world origin [ang; lin]"""
         w = np.zeros((mech.nbodies, 6))
-        for cp in mech.contact_points:
+        for cp in (mech.contact_points if contact_points is None else contact_points):
             R, t = om.transform(cp.body)
             p = R @ cp.position + t
             pen = self.z - p[2]
@@ -35,6 +35,16 @@ class GroundContact:
             w[cp.body, :3] += np.cross(p, f)
             w[cp.body, 3:] += f
         return w
+
+
+def step(om, mech, ground, q, v, tau, dt, contact_points=None):
+    """one reference step for one robot: oracle forward dynamics under the ground wrenches, semi-implicit
+    Euler, oracle manifold integration -- what qpc_sim_step_batch is checked against"""
+    om.set_state(q, v)
+    wext = ground.wrenches(om, mech, contact_points) if ground is not None else None
+    vd = om.forward_dynamics(tau, wext)
+    vn = v + dt * vd
+    return om.integrate(q, vn, dt), vn
 
 
 def rollout(ctrl_tick, mech, q0, v0, steps, dt=1e-3, ground=None, record_every=50):

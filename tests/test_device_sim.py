@@ -1,0 +1,199 @@
+"""SURVEY.md 8 f-2 on the device: the forward-dynamics / compliant-ground / integration step
+(qpcontrol.jl_amd/csrc/qpc_sim.h, qpc_sim_step_batch) and the tick+step rollout (qpc_rollout_batch)
+against the oracle's forward dynamics and manifold integration with the Python contact model of
+tests/sim.py -- the batched counterpart of the reference notebook's closed-loop run
+(notebooks/Standing controller.ipynb cells 9-11).  Tolerance: 1e-9 relative on the new state (fp64,
+one 36 x 36 factorization deep)."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+import emu
+import sim
+from oracle import oracle as O
+from qpcontrol_jl_amd import api, binding, models as M, workloads as W
+from qpcontrol_jl_amd.workloads import HARD, JOINT
+
+TOL = 1e-9
+
+
+def gpu_factory(mech, n_basis, floating):
+    return binding.Controller(binding.Model(mech), n_basis, floating)
+
+
+def atlas_case(factory, B, seed=5):
+    """Atlas with its 8 contact points; states around the stance with the feet in / near / off the ground"""
+    mech = M.atlas()
+    c = factory(mech, 4, mech.findbody("pelvis"))
+    for cp in mech.contact_points:
+        c.add_contact(cp.body, cp.position, cp.normal, cp.mu)
+    for j in range(mech.nbodies):
+        c.regularize(j, 0.05)
+    c.finalize()
+    q, v = W.standing_states(mech, B, seed, dq=0.15, drot=0.1, vstd=0.5)
+    rng = np.random.default_rng(seed)
+    q[:, 6] += rng.uniform(-0.03, 0.03, size=B)  # pelvis height: some feet penetrate, some hover
+    tau = rng.normal(scale=30.0, size=(B, mech.nv))
+    tau[:, :6] = 0.0
+    ground = sim.GroundContact(0.02, k=6.0e4, d=400.0, ct=300.0)
+    return mech, c, q, v, tau, ground, mech.contact_points
+
+
+def tree_case(factory, B, floating, seed=11):
+    """random trees with prismatic and FIXED joints, contact points on two bodies"""
+    types = ([M.QUAT_FLOATING] if floating else []) + [M.REVOLUTE, M.PRISMATIC, M.FIXED, M.REVOLUTE, M.REVOLUTE, M.FIXED,
+                                                       M.PRISMATIC, M.REVOLUTE]
+    mech = M.rand_tree(types, seed=seed)
+    nb = mech.nbodies
+    c = factory(mech, 4, 0 if floating else -1)
+    cps = [SimpleNamespace(body=nb - 1, position=np.array([0.1, 0.0, -0.1]), mu=0.6),
+           SimpleNamespace(body=nb - 1, position=np.array([-0.1, 0.05, -0.1]), mu=0.6),
+           SimpleNamespace(body=nb - 3, position=np.array([0.0, 0.1, 0.2]), mu=1.1)]
+    if floating:  # the ABI ties contacts to a floating base (wrench balance)
+        for cp in cps:
+            c.add_contact(cp.body, cp.position, [0.0, 0.0, 1.0], cp.mu)
+    else:
+        cps = []
+    for j in range(nb):
+        c.regularize(j, 0.1)
+    c.add_task(JOINT, joint=nb - 1, wkind=HARD)
+    c.finalize()
+    rng = np.random.default_rng(seed)
+    qs, vs = zip(*(M.rand_state(mech, rng, 0.8) for _ in range(B)))
+    tau = rng.normal(scale=2.0, size=(B, mech.nv))
+    ground = sim.GroundContact(0.3, k=2.0e3, d=30.0, ct=50.0)  # high plane: most points are inside
+    return mech, c, np.array(qs), np.array(vs), tau, ground, cps
+
+
+def params(ground, dt):
+    return binding.SimParams(dt, ground.z, ground.k, ground.d, ground.ct)
+
+
+def check_step(case, dt=1e-3):
+    mech, c, q, v, tau, ground, cps = case
+    qn, vn, bad = c.sim_step(q, v, tau, params(ground, dt))
+    assert not bad.any()
+    om = O.OracleModel(mech)
+    in_contact = 0
+    for b in range(q.shape[0]):
+        qr, vr = sim.step(om, mech, ground, q[b], v[b], tau[b], dt, cps)
+        np.testing.assert_allclose(vn[b], vr, rtol=TOL, atol=TOL * (1.0 + np.abs(vr).max()))
+        np.testing.assert_allclose(qn[b], qr, rtol=TOL, atol=TOL)
+        om.set_state(q[b], v[b])
+        in_contact += int(np.abs(ground.wrenches(om, mech, cps)).sum() > 0)
+    return in_contact
+
+
+def test_sim_step_atlas_emulated():
+    emu.build()
+    emu.race_report()
+    n = check_step(atlas_case(emu.factory, 6))
+    assert n >= 2  # the ground model was exercised
+    races, uninit, outside, first = emu.race_report()
+    assert (races, uninit, outside) == (0, 0, 0), first
+
+
+@pytest.mark.parametrize("floating", [False, True])
+def test_sim_step_random_trees_emulated(floating):
+    emu.build()
+    emu.race_report()
+    n = check_step(tree_case(emu.factory, 5, floating), dt=2e-3)
+    assert n >= 1 or not floating
+    races, uninit, outside, first = emu.race_report()
+    assert (races, uninit, outside) == (0, 0, 0), first
+
+
+def check_failed_qp(factory):
+    """a robot whose QP failed gets zero torque for the step and is counted (tests/sim.py does the same)"""
+    mech, c, q, v, tau, ground, cps = atlas_case(factory, 3)
+    status = np.array([0, 4, 1], dtype=np.int32)
+    qn, vn, bad = c.sim_step(q, v, tau, params(ground, 1e-3), status=status, bad=np.array([0, 2, 0]))
+    assert list(bad) == [0, 3, 0]
+    om = O.OracleModel(mech)
+    for b in range(3):
+        qr, vr = sim.step(om, mech, ground, q[b], v[b], tau[b] if status[b] <= 1 else np.zeros(mech.nv), 1e-3, cps)
+        np.testing.assert_allclose(vn[b], vr, rtol=TOL, atol=TOL * (1.0 + np.abs(vr).max()))
+        np.testing.assert_allclose(qn[b], qr, rtol=TOL, atol=TOL)
+
+
+def test_sim_failed_qp_emulated():
+    emu.build()
+    check_failed_qp(emu.factory)
+
+
+def standing(lib_path, B):
+    mech = M.atlas()
+    low = api.MomentumBasedController(mech, n_basis=4, floatingjoint="pelvis_to_world", lib_path=lib_path)
+    for cp in mech.contact_points:
+        pt = low.addcontact(cp.body, cp.position, cp.normal, cp.mu)
+        pt.maxnormalforce, pt.weight = 1e6, 1e-3
+    ctrl = api.StandingController(low, ["l_foot", "r_foot"], "pelvis", M.atlas_nominal_configuration(mech))
+    q, v = W.standing_states(mech, B, 3, dq=0.02, drot=0.01, vstd=0.0)
+    v[:, 3] = np.linspace(-0.08, 0.08, B)
+    k = 6.0e4
+    z = 0.01308714 + mech.total_mass() * 9.81 / (8 * k)
+    return mech, low, ctrl, q, v, api.SoftGround(z, k), sim.GroundContact(z, k=k)
+
+
+def check_rollout(lib_path, B, steps):
+    """qpc_rollout_batch == the host loop (device tick, oracle dynamics) of tests/sim.py, step for step"""
+    mech, low, ctrl, q, v, ground, ref_ground = standing(lib_path, B)
+    r = low.simulate((q, v), steps, ground)
+    assert not r["bad"].any() and (r["status"] <= 1).all()
+
+    def tick(qq, vv):
+        return dict(tau=ctrl(None, 0.0, (qq, vv), throw_on_failure=False), status=low.status)
+    log = sim.rollout(tick, mech, q, v, steps, ground=ref_ground)
+    # the closed loop is stable, so the two trajectories stay together at rounding level
+    np.testing.assert_allclose(r["q"], log["q"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(r["v"], log["v"], rtol=0, atol=1e-6)
+
+
+def test_rollout_matches_host_loop_emulated():
+    emu.build()
+    check_rollout(emu.EMU_LIB, 2, 12)
+
+
+def test_sim_argument_errors():
+    emu.build()
+    mech, c, q, v, tau, ground, cps = atlas_case(emu.factory, 1)
+    with pytest.raises(binding.QpcError):
+        c.sim_step(q, v, tau, binding.SimParams(0.0, 0.0, 1.0, 1.0, 1.0))  # dt must be positive
+
+
+# ------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_sim_step_atlas_gpu():
+    assert check_step(atlas_case(gpu_factory, 64)) >= 8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("floating", [False, True])
+def test_sim_step_random_trees_gpu(floating):
+    check_step(tree_case(gpu_factory, 32, floating), dt=2e-3)
+
+
+@pytest.mark.gpu
+def test_sim_failed_qp_gpu():
+    check_failed_qp(gpu_factory)
+
+
+@pytest.mark.gpu
+def test_rollout_matches_host_loop_gpu():
+    check_rollout(None, 8, 40)
+
+
+@pytest.mark.gpu
+def test_rollout_standing_acceptance_gpu():
+    """the notebook's acceptance criterion, entirely on the device: 256 pushed robots, 2 s at 1 kHz,
+    every QP solves, nobody falls, the centre of mass settles on its reference"""
+    mech, low, ctrl, q, v, ground, _ = standing(None, 256)
+    r = low.simulate((q, v), 2000, ground)
+    assert not r["bad"].any()
+    kin = W.batch_kinematics(mech, r["q"], r["v"])
+    com = kin["com"]
+    assert np.all(np.abs(com[:, :2] - ctrl.comref[:2]) < 0.02)
+    assert np.all(np.abs(com[:, 2] - ctrl.comref[2]) < 0.03)
+    assert np.all(np.abs(r["v"]).max(axis=1) < 0.3)
+    assert r["q"][:, 6].min() > 0.70 and r["q"][:, 6].max() < 0.95
