@@ -3,7 +3,6 @@
 #pragma once
 
 #define QPC_FN __device__ __forceinline__
-#define QPC_FN_HD __host__ __device__ __forceinline__
 #define QPC_PHASE(lane) { const int lane = (int)(threadIdx.x & 63);
 #define QPC_END_PHASE } __syncthreads();
 #define QPC_SINCOS(x, s, c) sincos((x), &(s), &(c))

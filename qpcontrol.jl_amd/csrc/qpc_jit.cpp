@@ -36,8 +36,9 @@ std::string qpc_jit_source(const QpcDims &D) {
     o << "#define QPC_STAMPS 1\n"
          "#define QPC_PROF_T0() do { *PT = clock64(); } while (0)\n"
          "#define QPC_PROF_ACC(i) do { unsigned long long n__ = clock64(); PA[i] += n__ - *PT; *PT = n__; } while (0)\n";
-  o << ""
-       "#include \"qpc_tick.h\"\n";
+  o << "#define QPC_SIM_ROWS_MAX " << (D.nv + 1) << "\n"
+       "#include \"qpc_tick.h\"\n"
+       "#include \"qpc_sim.h\"\n";
   // field order == struct QpcDims (qpc_program.h)
   o << "static_assert(sizeof(QpcDims) == " << sizeof(QpcDims) << ", \"QpcDims layout differs between host and JIT source\");\n";
   o << "static constexpr QpcDims kD = {" << D.nb << "," << D.nq << "," << D.nv << "," << D.nf << "," << D.npin << ","
@@ -73,6 +74,24 @@ std::string qpc_jit_source(const QpcDims &D) {
        "    const int *ITq = IT; const double *DTq = DT;\n"
        "    asm volatile(\"\" : \"+s\"(ITq), \"+s\"(DTq));\n"
        "    qpc::qpc_tick<double *>(kD, ITq, DTq, qpc_lds, io);\n"
+       "    __syncthreads();\n"
+       "  }\n"
+       "}\n";
+  // f-2: the simulation step specialised on the same dims (qpc_sim.h)
+  o << "struct QpcSimArgs { long long B; double *q, *v; const double *tau; const int32_t *status; int32_t *bad; qpc_sim_params sp; };\n";
+  o << "extern \"C\" __global__ void __launch_bounds__(64, 2) qpc_sim_kernel_jit(const int *__restrict__ IT, "
+       "const double *__restrict__ DT, const QpcSimArgs A) {\n"
+       "  __shared__ __attribute__((aligned(16))) double qpc_lds[" << qpc_sim_layout(D).total << "];\n"
+       "  qpc::qpc_sim_prologue<double *>(kD, IT, qpc_lds);\n"
+       "  for (long long b = blockIdx.x; b < A.B; b += gridDim.x) {\n"
+       "    qpc::SimIO io;\n"
+       "    io.q = A.q + b * kD.nq; io.v = A.v + b * kD.nv; io.tau = A.tau + b * kD.nv;\n"
+       "    io.status = A.status ? A.status + b : nullptr;\n"
+       "    io.q_out = A.q + b * kD.nq; io.v_out = A.v + b * kD.nv;\n"
+       "    io.bad = A.bad ? A.bad + b : nullptr;\n"
+       "    const int *ITq = IT; const double *DTq = DT;\n"
+       "    asm volatile(\"\" : \"+s\"(ITq), \"+s\"(DTq));\n"
+       "    qpc::qpc_sim_step<double *>(kD, ITq, DTq, qpc_lds, io, A.sp);\n"
        "    __syncthreads();\n"
        "  }\n"
        "}\n";

@@ -137,3 +137,43 @@ struct QpcDims {
   int max_as_iters, max_refine, max_pdas;
   double eps_primal, tau_pivot, tol_bound, tol_accept;
 };
+
+// LDS slab of the simulation step (qpc_sim.h), offsets in doubles (fields in allocation order).  `vb` (velocity index -> body) is
+// staged once per workgroup by qpc_sim_prologue and survives from robot to robot.
+struct QpcSimLayout {
+  int vb, q, v, tau, rl, h, s, tj, t, cr, ab, iw, ic, f, cf, hk, mm, dinv, x, flag, mstride, total;
+};
+#if defined(__HIPCC__) || defined(__HIPCC_RTC__)
+#define QPC_HOST_DEVICE __host__ __device__
+#else
+#define QPC_HOST_DEVICE
+#endif
+QPC_HOST_DEVICE inline QpcSimLayout qpc_sim_layout(const QpcDims &D) {
+  QpcSimLayout L{};
+  int o = 0;
+#define QPC_SIM_TAKE(field, n) L.field = o; o += (n)
+  QPC_SIM_TAKE(vb, D.nv);
+  QPC_SIM_TAKE(q, D.nq); QPC_SIM_TAKE(v, D.nv); QPC_SIM_TAKE(tau, D.nv);
+  QPC_SIM_TAKE(rl, 12 * D.nb); QPC_SIM_TAKE(h, 12 * D.nb);
+  QPC_SIM_TAKE(s, 6 * D.nv);
+  QPC_SIM_TAKE(tj, 6 * D.nb); QPC_SIM_TAKE(t, 6 * D.nb); QPC_SIM_TAKE(cr, 6 * D.nb); QPC_SIM_TAKE(ab, 6 * D.nb);
+  QPC_SIM_TAKE(iw, 10 * D.nb); QPC_SIM_TAKE(ic, 10 * D.nb);
+  QPC_SIM_TAKE(f, 6 * D.nb);
+  QPC_SIM_TAKE(cf, 6 * (D.nc > 0 ? D.nc : 1));
+  QPC_SIM_TAKE(hk, 6 * D.nv);
+  L.mstride = (D.nv + 1) | 1; // odd leading dimension: column accesses spread over the banks
+  {
+    // the (nv+1) x (nv+1) system overlays rl .. ab: local / world transforms, motion subspaces (each
+    // velocity lane keeps its column in registers), joint twists, twists and bias terms are all dead
+    // once the body wrenches and h_k exist, which is when the mass matrix is assembled
+    const int need = (D.nv + 1) * L.mstride, have = L.iw - L.rl;
+    if (need <= have) L.mm = L.rl;
+    else { L.mm = o; o += need; }
+  }
+  QPC_SIM_TAKE(dinv, D.nv);
+  QPC_SIM_TAKE(x, D.nv);
+  QPC_SIM_TAKE(flag, 2);
+#undef QPC_SIM_TAKE
+  L.total = o;
+  return L;
+}

@@ -110,6 +110,7 @@ struct QpcSimArgs {
 extern "C" __global__ void __launch_bounds__(64)
 qpc_sim_kernel(const QpcDims D, const int *__restrict__ IT, const double *__restrict__ DT, const QpcSimArgs A) {
   extern __shared__ __attribute__((aligned(16))) double qpc_lds[];
+  qpc::qpc_sim_prologue<double *>(D, IT, qpc_lds);
   for (long long b = blockIdx.x; b < A.B; b += gridDim.x) {
     qpc::SimIO io;
     io.q = A.q + b * D.nq; io.v = A.v + b * D.nv; io.tau = A.tau + b * D.nv;
@@ -139,6 +140,7 @@ struct QpcDeviceState {
   // JIT-specialised kernel (qpc_jit.cpp); null -> the generic ahead-of-time kernel is launched
   hipModule_t jit_module = nullptr;
   hipFunction_t jit_func = nullptr;
+  hipFunction_t jit_sim_func = nullptr; // qpc_sim_kernel_jit of the same module
   unsigned long long *d_ticket = nullptr;
   unsigned long long ticket_next = 0; // value of *d_ticket once every launch enqueued so far has drained
   double *d_scratch = nullptr;
@@ -194,7 +196,15 @@ static int launch_sim(qpc_controller *c, const QpcSimArgs &a, hipStream_t stream
   long long grid = (long long)S->n_cu * S->sim_blocks_per_cu;
   if (grid > a.B) grid = a.B;
   if (grid < 1) return QPC_OK;
-  const size_t lds = (size_t)qpc::sim_layout(D).total * sizeof(double);
+  if (S->jit_sim_func) {
+    const int *it = S->d_it;
+    const double *dt = S->d_dt;
+    QpcSimArgs aa = a;
+    void *args[] = {(void *)&it, (void *)&dt, (void *)&aa};
+    HIP_TRY(hipModuleLaunchKernel(S->jit_sim_func, (unsigned)grid, 1, 1, 64, 1, 1, 0, stream, args, nullptr));
+    return QPC_OK;
+  }
+  const size_t lds = (size_t)qpc_sim_layout(D).total * sizeof(double);
   hipLaunchKernelGGL(qpc_sim_kernel, dim3((unsigned)grid), dim3(64), lds, stream, D, S->d_it, S->d_dt, a);
   HIP_TRY(hipGetLastError());
   return QPC_OK;
@@ -231,7 +241,7 @@ int32_t qpc_finalize(qpc_controller *c, int32_t device_id, qpc_layout *out) {
   if (per_cu > 16) per_cu = 16; // 32 waves/CU cap; leave room for registers
   S->blocks_per_cu = per_cu;
   {
-    const size_t slds = (size_t)qpc::sim_layout(D).total * sizeof(double);
+    const size_t slds = (size_t)qpc_sim_layout(D).total * sizeof(double);
     if (slds > 160 * 1024) { delete S; qpc_set_error("qpc_finalize: simulation LDS slab exceeds the device limit"); return QPC_ERR_UNSUPPORTED; }
     HIP_TRY(hipFuncSetAttribute((const void *)qpc_sim_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
     int sper = (int)((160 * 1024) / (slds > 0 ? slds : 1));
@@ -258,9 +268,10 @@ int32_t qpc_finalize(qpc_controller *c, int32_t device_id, qpc_layout *out) {
     int jrc = qpc_jit_compile(D, arch, code, log);
     if (jrc == 0 && hipModuleLoadData(&S->jit_module, code.data()) == hipSuccess &&
         hipModuleGetFunction(&S->jit_func, S->jit_module, "qpc_tick_kernel_jit") == hipSuccess) {
-      // specialised kernel ready
+      // specialised kernel ready; the simulation step of the same module (optional)
+      if (hipModuleGetFunction(&S->jit_sim_func, S->jit_module, "qpc_sim_kernel_jit") != hipSuccess) S->jit_sim_func = nullptr;
     } else {
-      S->jit_func = nullptr;
+      S->jit_func = nullptr; S->jit_sim_func = nullptr;
       const char *strict = getenv("QPC_REQUIRE_JIT");
       if (strict && strict[0] == '1') {
         qpc_set_error("JIT specialisation failed: " + log);
@@ -487,6 +498,10 @@ int32_t qpc_qp_solve_batch(int32_t n, int32_t m, int64_t B, const double *P, con
 static int sim_check(qpc_controller *c, int64_t B, const void *q, const void *v, const void *tau, const qpc_sim_params *p, const char *who) {
   if (!c || !c->finalized || !c->dev) { qpc_set_error("controller not finalized"); return QPC_ERR_NOT_FINALIZED; }
   if (B < 0 || !q || !v || !tau || !p) { qpc_set_error(std::string(who) + ": missing array"); return QPC_ERR_INVALID_ARGUMENT; }
+  if (c->prog.dims.nv > 63) { qpc_set_error(std::string(who) + ": the simulation step supports at most 63 velocity coordinates"); return QPC_ERR_UNSUPPORTED; }
+  if (!c->dev->jit_sim_func && c->prog.dims.maxdepth > QPC_GENERIC_MAXD) {
+    qpc_set_error(std::string(who) + ": tree deeper than the generic kernel supports and no JIT kernel"); return QPC_ERR_UNSUPPORTED;
+  }
   if (!(p->dt > 0.0) || !(p->stiffness >= 0.0) || !(p->damping >= 0.0) || !(p->tangential_damping >= 0.0)) {
     qpc_set_error(std::string(who) + ": dt must be positive and the ground gains non-negative"); return QPC_ERR_INVALID_ARGUMENT;
   }

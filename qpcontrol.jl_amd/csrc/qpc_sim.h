@@ -13,43 +13,26 @@
 //                           normal spring/damper and viscous tangential friction capped by Coulomb's law
 //   dynamics bias  c      : RNEA with v̇ = 0 and the contact wrenches as external wrenches
 //   mass matrix    M      : composite rigid body algorithm (lower triangle, lane = row)
-//   M v̇ = tau - c         : LDL' with the right-hand side carried as an extra row, lane = row
+//   M v̇ = tau - c         : Cholesky with the right-hand side carried as an extra row, lane = row, the row's
+//                           factor entries in registers (JIT-specialised like the tick)
 //   integration           : v += dt v̇ ; q <- q (+) v dt on the configuration manifold
 // Checked against the oracle's forward dynamics / integrate and the Python contact model of
 // tests/sim.py (tests/test_device_sim.py).
 #pragma once
 #include "../../include/qpc.h"
 #include "qpc_program.h"
+#include "qpc_tick.h" // small dense helpers, TickMeta
 
 namespace qpc {
 
-// LDS slab of the simulation step (offsets in doubles)
-struct SimLayout {
-  int q, v, tau, rl, h, s, tj, t, cr, ab, iw, ic, f, cf, hk, mm, x, flag, mstride, total;
-};
-#ifndef QPC_FN_HD
-#define QPC_FN_HD QPC_FN
+// compile-time bound of nv + 1 (rows of the factorization incl. the right-hand side row): the JIT
+// specialisation defines it as the actual value so that the row registers index statically
+#ifndef QPC_SIM_ROWS_MAX
+#define QPC_SIM_ROWS_MAX 64
 #endif
-QPC_FN_HD SimLayout sim_layout(const QpcDims &D) {
-  SimLayout L;
-  int o = 0;
-#define QPC_SIM_TAKE(field, n) L.field = o; o += (n)
-  QPC_SIM_TAKE(q, D.nq); QPC_SIM_TAKE(v, D.nv); QPC_SIM_TAKE(tau, D.nv);
-  QPC_SIM_TAKE(rl, 12 * D.nb); QPC_SIM_TAKE(h, 12 * D.nb);
-  QPC_SIM_TAKE(s, 6 * D.nv);
-  QPC_SIM_TAKE(tj, 6 * D.nb); QPC_SIM_TAKE(t, 6 * D.nb); QPC_SIM_TAKE(cr, 6 * D.nb); QPC_SIM_TAKE(ab, 6 * D.nb);
-  QPC_SIM_TAKE(iw, 10 * D.nb); QPC_SIM_TAKE(ic, 10 * D.nb);
-  QPC_SIM_TAKE(f, 6 * D.nb);
-  QPC_SIM_TAKE(cf, 6 * (D.nc > 0 ? D.nc : 1));
-  QPC_SIM_TAKE(hk, 6 * D.nv);
-  L.mstride = (D.nv + 1) | 1; // odd leading dimension: column reads spread over the banks
-  QPC_SIM_TAKE(mm, (D.nv + 1) * L.mstride);
-  QPC_SIM_TAKE(x, D.nv);
-  QPC_SIM_TAKE(flag, 2);
-#undef QPC_SIM_TAKE
-  L.total = o;
-  return L;
-}
+
+typedef QpcSimLayout SimLayout;
+QPC_FN SimLayout sim_layout(const QpcDims &D) { return qpc_sim_layout(D); }
 
 struct SimIO {
   const double *q, *v, *tau; // this robot's records
@@ -58,24 +41,46 @@ struct SimIO {
   int32_t *bad;              // failure counter of this robot or nullptr
 };
 
+// once per workgroup: velocity index -> body into the persistent head of the slab
+template <class P> QPC_FN void qpc_sim_prologue(const QpcDims &D, const int *IT, P sm) {
+  const SimLayout L = sim_layout(D);
+  QPC_PHASE(lane) {
+    for (int k = lane; k < D.nv; k += 64) sm[L.vb + k] = (double)IT[D.it[IT_VBODY] + k];
+  } QPC_END_PHASE
+}
+
 template <class P>
 QPC_FN void qpc_sim_step(const QpcDims &D, const int *IT, const double *DT, P sm, const SimIO &io, const qpc_sim_params &sp) {
-  const int nb = D.nb, nq = D.nq, nv = D.nv, nc = D.nc, maxd = D.maxd;
+  const int nb = D.nb, nq = D.nq, nv = D.nv, nc = D.nc;
   const SimLayout L = sim_layout(D);
-  const int *jtype = IT + D.it[IT_JTYPE], *qoff = IT + D.it[IT_QOFF], *voff = IT + D.it[IT_VOFF], *nvj = IT + D.it[IT_NVJ];
-  const int *anc = IT + D.it[IT_ANC_TAB], *dmask = IT + D.it[IT_DESC_MASK], *vbody = IT + D.it[IT_VBODY];
   // a failed QP (checkstatus, momentum.jl:83-91) applies no torque for this step and is counted
   const bool failed = io.status && io.status[0] > QPC_STATUS_ALMOST_OPTIMAL;
 
+  // per-lane static metadata in registers, as in the tick (TickMeta): joint type / offsets / ancestor
+  // chain of body `lane`, subtree mask of the body of velocity index `lane`; plus the full subtree
+  // mask of body `lane` for the composite inertias (the tick's copy is pruned to the free joints)
+  TickMeta M;
+  QPC_LANE_INTS(dm_, 2);
   QPC_PHASE(lane) {
+    int *mt = QPC_LI(M.v, lane);
+    {
+      const int aw = (D.maxd + 3) / 4, rowlen = 6 + aw;
+      QPC_UNROLL_JIT
+      for (int e = 0; e < QPC_META_WORDS; e++) mt[e] = e < rowlen ? IT[D.it[IT_META] + lane * rowlen + e] : 0;
+    }
+    int *dm = QPC_LI(dm_, lane);
+    dm[0] = lane < nb ? IT[D.it[IT_DESC_MASK] + 2 * lane] : 0;
+    dm[1] = lane < nb ? IT[D.it[IT_DESC_MASK] + 2 * lane + 1] : 0;
     for (int i = lane; i < nq; i += 64) sm[L.q + i] = io.q[i];
     for (int i = lane; i < nv; i += 64) { sm[L.v + i] = io.v[i]; sm[L.tau + i] = failed ? 0.0 : io.tau[i]; }
     if (lane == 0) sm[L.flag] = 0.0;
   } QPC_END_PHASE
 
   QPC_PHASE(lane) { // joint transforms  x_parent = Rf (Rj x + pj) + pf
-    for (int i = lane; i < nb; i += 64) {
-      const int jt = jtype[i], q0 = qoff[i];
+    if (lane < nb) {
+      const int i = lane;
+      const int *mt = QPC_LI(M.v, lane);
+      const int jt = MT_JT(mt), q0 = MT_Q0(mt);
       const double *ax = DT + D.dt[DT_AXIS] + 3 * i, *Rf = DT + D.dt[DT_RF] + 9 * i, *pf = DT + D.dt[DT_PF] + 3 * i;
       double Rj[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pj[3] = {0, 0, 0};
       if (jt == QPC_JOINT_REVOLUTE) {
@@ -103,25 +108,30 @@ QPC_FN void qpc_sim_step(const QpcDims &D, const int *IT, const double *DT, P sm
     }
   } QPC_END_PHASE
 
-  QPC_PHASE(lane) { // transform_to_root along the ancestor chain (nearest ancestor first)
-    for (int i = lane; i < nb; i += 64) {
+  QPC_PHASE(lane) { // transform_to_root along the (register-resident) ancestor chain, nearest first
+    if (lane < nb) {
+      const int *mt = QPC_LI(M.v, lane);
       double H[12], A[12], t[3];
-      ld(sm + L.rl + 12 * i, 12, H);
-      for (int s = 0; s < maxd; s++) {
-        const int an = anc[i * maxd + s];
-        if (an < 0) break;
-        ld(sm + L.rl + 12 * an, 12, A);
-        mv3(A, H + 9, t);
-        mm3(A, H, H);
-        H[9] = t[0] + A[9]; H[10] = t[1] + A[10]; H[11] = t[2] + A[11];
+      ld(sm + L.rl + 12 * lane, 12, H);
+      QPC_UNROLL_JIT
+      for (int s = 0; s < QPC_MAXD; s++) {
+        const int an = MT_ANC(mt, s);
+        if (an >= 0) {
+          ld(sm + L.rl + 12 * an, 12, A);
+          mv3(A, H + 9, t);
+          mm3(A, H, H);
+          H[9] = t[0] + A[9]; H[10] = t[1] + A[10]; H[11] = t[2] + A[11];
+        }
       }
-      st(sm + L.h + 12 * i, 12, H);
+      st(sm + L.h + 12 * lane, 12, H);
     }
   } QPC_END_PHASE
 
   QPC_PHASE(lane) { // motion subspace columns (world), joint twist, world inertia
-    for (int i = lane; i < nb; i += 64) {
-      const int jt = jtype[i], v0 = voff[i], n = nvj[i];
+    if (lane < nb) {
+      const int i = lane;
+      const int *mt = QPC_LI(M.v, lane);
+      const int jt = MT_JT(mt), v0 = MT_V0(mt), n = MT_NVJ(mt);
       double H[12], tj[6] = {0, 0, 0, 0, 0, 0};
       ld(sm + L.h + 12 * i, 12, H);
       const double *ax = DT + D.dt[DT_AXIS] + 3 * i;
@@ -157,14 +167,17 @@ QPC_FN void qpc_sim_step(const QpcDims &D, const int *IT, const double *DT, P sm
   } QPC_END_PHASE
 
   QPC_PHASE(lane) { // twist_wrt_world, bias increment T_i x (S_i v_i)
-    for (int i = lane; i < nb; i += 64) {
+    if (lane < nb) {
+      const int i = lane;
+      const int *mt = QPC_LI(M.v, lane);
       double T[6], tj[6], cr[6];
       ld(sm + L.tj + 6 * i, 6, tj);
       for (int a = 0; a < 6; a++) T[a] = tj[a];
-      for (int s = 0; s < maxd; s++) {
-        const int an = anc[i * maxd + s];
-        if (an < 0) break;
-        for (int a = 0; a < 6; a++) T[a] += sm[L.tj + 6 * an + a];
+      QPC_UNROLL_JIT
+      for (int s = 0; s < QPC_MAXD; s++) {
+        const int an = MT_ANC(mt, s);
+        if (an >= 0)
+          for (int a = 0; a < 6; a++) T[a] += sm[L.tj + 6 * an + a];
       }
       crm(T, tj, cr);
       st(sm + L.t + 6 * i, 6, T);
@@ -173,17 +186,20 @@ QPC_FN void qpc_sim_step(const QpcDims &D, const int *IT, const double *DT, P sm
   } QPC_END_PHASE
 
   QPC_PHASE(lane) { // bias accelerations, composite inertias; ground reaction per contact point
-    for (int i = lane; i < nb; i += 64) {
+    if (lane < nb) {
+      const int i = lane;
+      const int *mt = QPC_LI(M.v, lane), *dm = QPC_LI(dm_, lane);
       double Ab[6], Ic[10];
       ld(sm + L.cr + 6 * i, 6, Ab);
-      for (int s = 0; s < maxd; s++) {
-        const int an = anc[i * maxd + s];
-        if (an < 0) break;
-        for (int a = 0; a < 6; a++) Ab[a] += sm[L.cr + 6 * an + a];
+      QPC_UNROLL_JIT
+      for (int s = 0; s < QPC_MAXD; s++) {
+        const int an = MT_ANC(mt, s);
+        if (an >= 0)
+          for (int a = 0; a < 6; a++) Ab[a] += sm[L.cr + 6 * an + a];
       }
       st(sm + L.ab + 6 * i, 6, Ab);
       for (int a = 0; a < 10; a++) Ic[a] = 0.0;
-      unsigned long long msk = ((unsigned long long)(unsigned)dmask[2 * i + 1] << 32) | (unsigned long long)(unsigned)dmask[2 * i];
+      unsigned long long msk = ((unsigned long long)(unsigned)dm[1] << 32) | (unsigned long long)(unsigned)dm[0];
       while (msk) {
         const int k = QPC_CTZ64(msk);
         msk &= msk - 1;
@@ -216,8 +232,10 @@ QPC_FN void qpc_sim_step(const QpcDims &D, const int *IT, const double *DT, P sm
     }
   } QPC_END_PHASE
 
+  QPC_LANE_ARRAY(sk_, 6); // motion subspace column of velocity index `lane`
   QPC_PHASE(lane) { // body wrenches of the v̇ = 0 inverse dynamics; h_k = Ic(vbody k) S_k
-    for (int i = lane; i < nb; i += 64) {
+    if (lane < nb) {
+      const int i = lane;
       double Ab[6], T[6], I[10], h[6], ia[6], cf[6];
       ld(sm + L.ab + 6 * i, 6, Ab);
       ld(sm + L.t + 6 * i, 6, T);
@@ -233,64 +251,102 @@ QPC_FN void qpc_sim_step(const QpcDims &D, const int *IT, const double *DT, P sm
       }
       st(sm + L.f + 6 * i, 6, ia);
     }
-    for (int k = lane; k < nv; k += 64) {
-      double Ic[10], S[6], h[6];
-      ld(sm + L.ic + 10 * vbody[k], 10, Ic);
-      ld(sm + L.s + 6 * k, 6, S);
+    if (lane < nv) {
+      const int *mt = QPC_LI(M.v, lane);
+      double Ic[10], h[6];
+      double *S = QPC_LA(sk_, lane);
+      ld(sm + L.ic + 10 * MT_VBODY(mt), 10, Ic);
+      ld(sm + L.s + 6 * lane, 6, S);
       inertia_mul(Ic, S, h);
-      st(sm + L.hk + 6 * k, 6, h);
+      st(sm + L.hk + 6 * lane, 6, h);
     }
   } QPC_END_PHASE
 
-  QPC_PHASE(lane) { // row k of the mass matrix (lower triangle) and entry k of the right-hand side row
-    for (int k = lane; k < nv; k += 64) {
-      const int bk = vbody[k];
-      double S[6], h[6], F[6] = {0, 0, 0, 0, 0, 0};
-      ld(sm + L.s + 6 * k, 6, S);
-      ld(sm + L.hk + 6 * k, 6, h);
-      unsigned long long msk = ((unsigned long long)(unsigned)dmask[2 * bk + 1] << 32) | (unsigned long long)(unsigned)dmask[2 * bk];
+  QPC_PHASE(lane) { // column j of the mass matrix (lower triangle: rows k >= j) and entry j of the rhs row
+    if (lane < nv) {
+      const int j = lane;
+      const int *mt = QPC_LI(M.v, lane);
+      const double *S = QPC_LA(sk_, lane);
+      const unsigned long long sub = ((unsigned long long)(unsigned)mt[5] << 32) | (unsigned long long)(unsigned)mt[4];
+      double F[6] = {0, 0, 0, 0, 0, 0};
+      unsigned long long msk = sub;
       while (msk) {
         const int b = QPC_CTZ64(msk);
         msk &= msk - 1;
         for (int a = 0; a < 6; a++) F[a] += sm[L.f + 6 * b + a];
       }
-      double ck = 0.0;
-      for (int a = 0; a < 6; a++) ck += S[a] * F[a];
-      sm[L.mm + nv * L.mstride + k] = sm[L.tau + k] - ck;
-      for (int j = 0; j <= k; j++) { // M[k][j] = S_j . Ic(vbody k) S_k when joint j supports body(k)
-        const int bj = vbody[j];
-        const bool on_path = ((bk < 32 ? (unsigned)dmask[2 * bj] >> bk : (unsigned)dmask[2 * bj + 1] >> (bk - 32)) & 1u) != 0;
-        double acc = 0.0;
-        if (on_path)
-          for (int a = 0; a < 6; a++) acc += sm[L.s + 6 * j + a] * h[a];
-        sm[L.mm + k * L.mstride + j] = acc;
+      double cj = 0.0;
+      for (int a = 0; a < 6; a++) cj += S[a] * F[a];
+      sm[L.mm + nv * L.mstride + j] = sm[L.tau + j] - cj;
+      // M[k][j] = S_j . Ic(vbody k) S_k when joint j supports the body of k (k in the subtree of vbody j)
+      for (int k0 = 0; k0 < nv; k0 += 4) {
+        double hb[4][6];
+        int on[4];
+        QPC_UNROLL_FULL
+        for (int u = 0; u < 4; u++) {
+          const int k = k0 + u < nv ? k0 + u : 0;
+          on[u] = (int)((sub >> (int)(double)sm[L.vb + k]) & 1ull);
+          QPC_UNROLL_FULL
+          for (int a = 0; a < 6; a++) hb[u][a] = sm[L.hk + 6 * k + a];
+        }
+        QPC_UNROLL_FULL
+        for (int u = 0; u < 4; u++) {
+          const int k = k0 + u;
+          if (k < nv && k >= j) {
+            double acc = 0.0;
+            QPC_UNROLL_FULL
+            for (int a = 0; a < 6; a++) acc += S[a] * hb[u][a];
+            sm[L.mm + k * L.mstride + j] = on[u] ? acc : 0.0;
+          }
+        }
       }
     }
   } QPC_END_PHASE
 
-  // LDL' of M with the right-hand side as row nv: after step k column k holds L(:,k) d_k and the
-  // trailing rows are updated; the rhs row ends as y = D L' v̇.  lane = row.
+  // left-looking Cholesky of M with the right-hand side as row nv (lane = row, the row's own factor
+  // entries in registers, row k broadcast from LDS -- the scheme of the tick's S11 factorization):
+  // afterwards row nv holds y = L^-1 (tau - c) and dinv[k] = 1 / L_kk
+  QPC_LANE_ARRAY(lrow_, QPC_SIM_ROWS_MAX);
+  QPC_UNROLL_JIT
   for (int k = 0; k < nv; k++) {
     QPC_PHASE(lane) {
-      const double dk = sm[L.mm + k * L.mstride + k];
-      if (lane == 0 && !(dk > 0.0)) sm[L.flag] = 1.0; // not positive definite: the step is rejected below
-      const double inv = QPC_RCP(dk > 0.0 ? dk : 1.0);
-      for (int r = k + 1 + lane; r <= nv; r += 64) {
-        const double lrk = sm[L.mm + r * L.mstride + k] * inv;
-        const int jend = r < nv ? r : nv - 1;
-        for (int j = k + 1; j <= jend; j++)
-          sm[L.mm + r * L.mstride + j] = sm[L.mm + r * L.mstride + j] - lrk * sm[L.mm + j * L.mstride + k];
+      if (lane >= k && lane <= nv) {
+        const int r = lane;
+        double *lrow = QPC_LA(lrow_, lane);
+        double accr = 0.0, acck = 0.0;
+        for (int j0 = 0; j0 < k; j0 += 8) {
+          double lk[8];
+          QPC_UNROLL_FULL
+          for (int u = 0; u < 8; u++) lk[u] = sm[L.mm + k * L.mstride + (j0 + u < k ? j0 + u : 0)];
+          QPC_UNROLL_FULL
+          for (int u = 0; u < 8; u++)
+            if (j0 + u < k) { accr += lk[u] * lrow[j0 + u]; acck += lk[u] * lk[u]; }
+        }
+        const double mkk = sm[L.mm + k * L.mstride + k], mrk = sm[L.mm + r * L.mstride + k], dk = mkk - acck;
+        const bool ok = dk > 1e-14 * mkk;
+        const double inv = ok ? QPC_RSQRT(dk) : 0.0; // 1 / L_kk
+        if (r == k) { sm[L.dinv + k] = inv; if (!ok) sm[L.flag] = 1.0; } // not positive definite: the step is rejected
+        else { const double v = (mrk - accr) * inv; lrow[k] = v; sm[L.mm + r * L.mstride + k] = v; }
       }
     } QPC_END_PHASE
   }
-  for (int k = nv - 1; k >= 0; k--) { // back substitution  v̇_k = (y_k - sum_{r>k} M[r][k] v̇_r) / d_k, column sweep
+  // back substitution L' v̇ = y, one phase per unknown: lane j keeps y_j in a register and applies the
+  // update of the previous unknown before lane k closes v̇_k
+  {
+    QPC_LANE_ARRAY(y_, 1);
     QPC_PHASE(lane) {
-      const double dk = sm[L.mm + k * L.mstride + k];
-      const double xk = sm[L.mm + nv * L.mstride + k] * QPC_RCP(dk > 0.0 ? dk : 1.0);
-      if (lane == 0) sm[L.x + k] = xk;
-      for (int j = lane; j < k; j += 64)
-        sm[L.mm + nv * L.mstride + j] = sm[L.mm + nv * L.mstride + j] - sm[L.mm + k * L.mstride + j] * xk;
+      if (lane < nv) QPC_LA(y_, lane)[0] = sm[L.mm + nv * L.mstride + lane];
     } QPC_END_PHASE
+    QPC_UNROLL_JIT
+    for (int k = nv - 1; k >= 0; k--) {
+      QPC_PHASE(lane) {
+        if (lane <= k) {
+          double *y = QPC_LA(y_, lane);
+          if (k + 1 < nv) y[0] -= sm[L.mm + (k + 1) * L.mstride + lane] * sm[L.x + k + 1];
+          if (lane == k) sm[L.x + k] = y[0] * sm[L.dinv + k];
+        }
+      } QPC_END_PHASE
+    }
   }
 
   const bool reject = sm[L.flag] != 0.0;
@@ -304,8 +360,9 @@ QPC_FN void qpc_sim_step(const QpcDims &D, const int *IT, const double *DT, P sm
   } QPC_END_PHASE
   QPC_PHASE(lane) { // configuration update on the manifold (revolute / prismatic: q += v dt; floating joint:
                     // quat <- quat * exp(w_body dt / 2) renormalised, pos += R(quat) v_body dt)
-    for (int i = lane; i < nb; i += 64) {
-      const int jt = jtype[i], q0 = qoff[i], v0 = voff[i];
+    if (lane < nb) {
+      const int *mt = QPC_LI(M.v, lane);
+      const int jt = MT_JT(mt), q0 = MT_Q0(mt), v0 = MT_V0(mt);
       const double dt = reject ? 0.0 : sp.dt;
       if (jt == QPC_JOINT_REVOLUTE || jt == QPC_JOINT_PRISMATIC) {
         io.q_out[q0] = sm[L.q + q0] + sm[L.tau + v0] * dt;

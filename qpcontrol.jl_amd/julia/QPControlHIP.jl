@@ -11,7 +11,7 @@
 # symbol of include/qpc.h with the argument order shown there.
 module QPControlHIP
 
-export qp_solve_batch, setlaw!, LAW_INPUT, LAW_CONSTANT, LAW_JOINT_PD, LAW_COM_PD, LAW_ORIENTATION_PD,
+export qp_solve_batch, setlaw!, simulate!, SimParams, LAW_INPUT, LAW_CONSTANT, LAW_JOINT_PD, LAW_COM_PD, LAW_ORIENTATION_PD,
        BatchedMomentumBasedController, QPCModel, addtask!, addcontact!, regularize!, finalize!,
        QPSolveFailure, SpatialAccelerationTask, AngularAccelerationTask, LinearAccelerationTask,
        PointAccelerationTask, JointAccelerationTask, MomentumRateTask, LinearMomentumRateTask
@@ -218,6 +218,45 @@ function (c::BatchedMomentumBasedController)(τ::Matrix{Float64}, t::Number, q::
         bad === nothing || throw(QPSolveFailure(bad, c.status[bad]))
     end
     τ
+end
+
+# ---------------------------------------------------------------------------------------------
+# f-2: closed loop on the device.  The reference's acceptance run (notebooks/Standing controller.ipynb
+# cells 9-11) wraps the controller in `Dynamics(mechanism, controller)`, adds soft contacts and calls
+# RigidBodySim `simulate`; `simulate!` below is the batched counterpart: n_steps x (tick -> forward
+# dynamics on compliant ground at the controller's contact points -> semi-implicit Euler), columns of
+# q / v are robots and are advanced in place.
+struct SimParams
+    dt::Float64
+    ground_z::Float64
+    stiffness::Float64
+    damping::Float64
+    tangential_damping::Float64
+end
+
+"""
+    simulate!(controller, q, v, n_steps, params; desired, contact_weight, contact_maxnormalforce, ...)
+
+Returns `(τ_last, status_last, bad)`; `bad[b]` counts the steps whose QP failed for robot `b`
+(the reference would have thrown `QPSolveFailure` at the first one).
+"""
+function simulate!(c::BatchedMomentumBasedController, q::Matrix{Float64}, v::Matrix{Float64}, n_steps::Integer,
+        params::SimParams; desired::Matrix{Float64} = zeros(0, size(q, 2)),
+        contact_weight::Matrix{Float64} = zeros(0, size(q, 2)),
+        contact_maxnormalforce::Matrix{Float64} = zeros(0, size(q, 2)),
+        task_weights::Union{Nothing, Matrix{Float64}} = nothing, surfaces::Union{Nothing, Matrix{Float64}} = nothing)
+    lay = c.layout
+    lay === nothing && error("call finalize!(controller) first")
+    B = size(q, 2)
+    τ = zeros(lay.nv, B); status = zeros(Int32, B); bad = zeros(Int32, B)
+    ptr(x) = x === nothing || isempty(x) ? Ptr{Float64}(C_NULL) : pointer(x)
+    GC.@preserve q v desired contact_weight contact_maxnormalforce task_weights surfaces check(ccall(
+        (:qpc_rollout_batch, libqpc), Int32,
+        (Ptr{Cvoid}, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+         Ptr{Float64}, Ref{SimParams}, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}),
+        c.handle, B, n_steps, q, v, ptr(desired), ptr(contact_weight), ptr(contact_maxnormalforce), ptr(task_weights),
+        ptr(surfaces), Ref(params), τ, status, bad), "qpc_rollout_batch")
+    τ, status, bad
 end
 
 # ---------------------------------------------------------------------------------------------
