@@ -7,6 +7,7 @@
 
 #include <hip/hiprtc.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <sstream>
@@ -36,6 +37,14 @@ std::string qpc_jit_source(const QpcDims &D) {
     o << "#define QPC_STAMPS 1\n"
          "#define QPC_PROF_T0() do { *PT = clock64(); } while (0)\n"
          "#define QPC_PROF_ACC(i) do { unsigned long long n__ = clock64(); PA[i] += n__ - *PT; *PT = n__; } while (0)\n";
+  if (D.N >= 1 && D.N <= 8) { // friction-cone basis directions (contacts.jl:16-23) as literals
+    o << "#define QPC_BASIS_TABLE {";
+    for (int i = 0; i < 8; i++) {
+      const double a = i * (6.283185307179586 / D.N);
+      o << dbl(i < D.N ? std::cos(a) : 1.0) << "," << dbl(i < D.N ? std::sin(a) : 0.0) << (i < 7 ? "," : "");
+    }
+    o << "}\n";
+  }
   o << "#define QPC_SIM_ROWS_MAX " << (D.nv + 1) << "\n"
        "#include \"qpc_tick.h\"\n"
        "#include \"qpc_sim.h\"\n";

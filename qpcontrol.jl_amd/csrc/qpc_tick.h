@@ -1306,18 +1306,39 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
         pc[0] += H[9]; pc[1] += H[10]; pc[2] += H[11];
         // forcebasis(mu, N) (contacts.jl:16-23)
         double sn, cs, inv = 1.0 / QPC_SQRT(mu * mu + 1.0);
+#ifdef QPC_BASIS_TABLE
+        // JIT: cos / sin of the N basis directions are literals (computed by the host when the source is
+        // generated); the lane's own pair is picked with selects instead of an fp64 sincos per use
+        constexpr double kb_[16] = QPC_BASIS_TABLE;
+        sn = 0.0; cs = 1.0;
+        QPC_UNROLL_FULL
+        for (int ii = 1; ii < 8; ii++)
+          if (ii < N && ii == i) { cs = kb_[2 * ii]; sn = kb_[2 * ii + 1]; }
+#else
         QPC_SINCOS(i * (6.283185307179586 / N), sn, cs);
+#endif
         double bi[3] = {mu * cs * inv, mu * sn * inv, inv}, lin[3], ang[3];
         mv3(Rc, bi, lin);
         cross3(pc, lin, ang);
         for (int a = 0; a < 3; a++) { sm[D.lds[L_G] + a * nrho + j] = ang[a]; sm[D.lds[L_G] + (3 + a) * nrho + j] = lin[a]; }
         double cw = sm[D.lds[L_CW] + c];
+#ifdef QPC_BASIS_TABLE
+        QPC_UNROLL_FULL
+        for (int i2 = 0; i2 < 8; i2++) {
+          if (i2 < N) {
+            const double c2 = kb_[2 * i2], s2 = kb_[2 * i2 + 1];
+            double dot = (mu * cs * mu * c2 + mu * sn * mu * s2 + 1.0) * inv * inv;
+            sm[D.lds[L_HR] + c * N * N + i * N + i2] = 2.0 * cw * dot;
+          }
+        }
+#else
         for (int i2 = 0; i2 < N; i2++) {
           double s2, c2;
           QPC_SINCOS(i2 * (6.283185307179586 / N), s2, c2);
           double dot = (mu * cs * mu * c2 + mu * sn * mu * s2 + 1.0) * inv * inv;
           sm[D.lds[L_HR] + c * N * N + i * N + i2] = 2.0 * cw * dot;
         }
+#endif
         double hi = sm[D.lds[L_CMAX] + c] * inv / N; // maxrho (contacts.jl:57)
         sm[D.lds[L_HI] + j] = hi;
         sm[D.lds[L_WS] + j] = hi > 0.0 ? 0.0 : -1.0; // disable! (contacts.jl:72): rho pinned to 0

@@ -197,3 +197,58 @@ def test_rollout_standing_acceptance_gpu():
     assert np.all(np.abs(com[:, 2] - ctrl.comref[2]) < 0.03)
     assert np.all(np.abs(r["v"]).max(axis=1) < 0.3)
     assert r["q"][:, 6].min() > 0.70 and r["q"][:, 6].max() < 0.95
+
+
+def fuzz_case(factory, seed, B=3):
+    """random mechanism (floating or fixed base, mixed joint types, random tree shape) with random contact
+    points, random ground height and gains"""
+    rng = np.random.default_rng(seed)
+    floating = bool(rng.integers(2))
+    kinds = [M.REVOLUTE, M.REVOLUTE, M.REVOLUTE, M.PRISMATIC, M.FIXED]
+    types = ([M.QUAT_FLOATING] if floating else []) + [kinds[int(k)] for k in rng.integers(len(kinds), size=int(rng.integers(3, 14)))]
+    mech = M.rand_tree(types, seed=seed, chain=bool(rng.integers(2)))
+    nb = mech.nbodies
+    c = factory(mech, 4, 0 if floating else -1)
+    cps = []
+    if floating:
+        for _ in range(int(rng.integers(1, 6))):
+            cp = SimpleNamespace(body=int(rng.integers(nb)), position=rng.normal(scale=0.2, size=3), mu=float(rng.uniform(0.2, 1.2)))
+            cps.append(cp)
+            c.add_contact(cp.body, cp.position, [0.0, 0.0, 1.0], cp.mu)
+    for j in range(nb):
+        c.regularize(j, 0.1)
+    c.finalize()
+    qs, vs = zip(*(M.rand_state(mech, rng, 1.0) for _ in range(B)))
+    tau = rng.normal(scale=3.0, size=(B, mech.nv))
+    ground = sim.GroundContact(float(rng.uniform(-0.5, 0.5)), k=float(rng.uniform(1e2, 5e3)), d=float(rng.uniform(0, 50)),
+                               ct=float(rng.uniform(0, 80)))
+    return mech, c, np.array(qs), np.array(vs), tau, ground, cps
+
+
+@pytest.mark.parametrize("seed", range(400, 412))
+def test_sim_step_fuzz_emulated(seed):
+    emu.build()
+    emu.race_report()
+    check_step(fuzz_case(emu.factory, seed), dt=float(np.random.default_rng(seed).choice([1e-3, 5e-3])))
+    races, uninit, outside, first = emu.race_report()
+    assert (races, uninit, outside) == (0, 0, 0), first
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("jit", [True, False])
+def test_sim_step_fuzz_gpu(jit, monkeypatch):
+    """8 random mechanisms through the JIT-specialised kernel (a hiprtc compile each), 24 through the generic one"""
+    if not jit:
+        monkeypatch.setenv("QPC_DISABLE_JIT", "1")
+    for seed in (range(500, 508) if jit else range(520, 544)):
+        check_step(fuzz_case(gpu_factory, seed, B=5), dt=1e-3)
+
+
+@pytest.mark.gpu
+def test_sim_generic_kernel_without_jit(monkeypatch):
+    """the ahead-of-time generic simulation kernel (QPC_DISABLE_JIT=1) passes the same bar"""
+    monkeypatch.setenv("QPC_DISABLE_JIT", "1")
+    case = atlas_case(gpu_factory, 16)
+    assert case[1].L.qpc_debug_jit_active(case[1].h) == 0
+    assert check_step(case) >= 2
+    check_step(tree_case(gpu_factory, 8, True), dt=2e-3)
