@@ -27,13 +27,13 @@ sys.path.insert(0, ROOT)
 ALG_BYTES_PER_SOLVE = 1968  # in 8*(37+36+36+16) + out 8*(36+36+48) + 8
 ALG_FLOPS_PER_SOLVE = 4.6e5  # one reduced-KKT factor+solve + assembly + FK/RNEA
 # HBM traffic per solve measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes
-# (profiles/r01_v26_pmc_*.csv, r01_v26_traffic_summary.json): 180450 KiB read + 258194 KiB written per
+# (profiles/r01_v27_pmc_*.csv, r01_v27_traffic_summary.json; tools/profile_round.sh): 180973 KiB read + 258518 KiB written per
 # 32768-QP launch.  ~8.7 KB each way per solve is the deliberate lane-private spill slot (inertias,
 # bias wrenches, motion subspaces parked in HBM during the solve so that 8 QPs fit the LDS of a CU,
 # DESIGN.md 4); the slots total 23 MB and live in L2 / Infinity Cache, TCC->EA requests count them anyway.
 # 8-byte-per-lane accesses: the gfx950 "x2 for 16-B wide reads" correction of MI355X_MICROARCH.md
 # does not apply.
-MEASURED_TRAFFIC_BYTES_PER_SOLVE = (180449.5 + 258193.5) * 1024 / 32768
+MEASURED_TRAFFIC_BYTES_PER_SOLVE = (180973.3 + 258517.8) * 1024 / 32768
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md (spec; 6.29e12 measured)
 FP64_PEAK = 78.6e12  # FLOP/s vector fp64 (datasheet)
 
@@ -58,7 +58,20 @@ def _cpu_worker(rank, B_sample, budget_s):
         r = oc.tick_batch(wl.q[s], wl.v[s], wl.desired[s], wl.contact_weight[s], wl.contact_maxnormalforce[s])
         iters += int(r["iters"].sum())
         done += len(r["iters"])
-    print(json.dumps({"done": done, "iters": iters, "seconds": time.perf_counter() - t0}))
+    sec = time.perf_counter() - t0
+    # the same path at the looser tolerances of the reference's notebook (Standing controller.ipynb:64-71,
+    # eps 1e-5): what a user of the reference would run interactively; a third of the budget
+    oc.set_settings(O.notebook_settings(polish=0))
+    nb_done, nb_iters, off = 0, 0, 0
+    t1 = time.perf_counter()
+    while off < B_sample and time.perf_counter() - t1 < budget_s / 3:
+        s = slice(off, off + chunk)
+        r = oc.tick_batch(wl.q[s], wl.v[s], wl.desired[s], wl.contact_weight[s], wl.contact_maxnormalforce[s])
+        nb_iters += int(r["iters"].sum())
+        nb_done += len(r["iters"])
+        off += chunk
+    print(json.dumps({"done": done, "iters": iters, "seconds": sec, "nb_done": nb_done, "nb_iters": nb_iters,
+                      "nb_seconds": time.perf_counter() - t1}))
 
 
 def cpu_baseline(budget_s=12.0, max_workers=64):
@@ -88,7 +101,7 @@ def cpu_baseline(budget_s=12.0, max_workers=64):
                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for r in range(n)]
     res = []
     for p in procs:
-        out, _ = p.communicate(timeout=budget_s * 4 + 120)
+        out, _ = p.communicate(timeout=budget_s * 6 + 120)
         if p.returncode == 0 and out.strip():
             res.append(json.loads(out.strip().splitlines()[-1]))
     wall = time.perf_counter() - t0
@@ -99,6 +112,10 @@ def cpu_baseline(budget_s=12.0, max_workers=64):
     busy = max(r["seconds"] for r in res)
     return {"value": done / busy, "unit": "QP solves/s", "cores": len(res), "kind": "port",
             "single_core": res[0]["done"] / res[0]["seconds"],
+            "notebook_settings": {"value": sum(r["nb_done"] for r in res) / max(max(r["nb_seconds"] for r in res), 1e-9),
+                                  "mean_admm_iterations": sum(r["nb_iters"] for r in res) / max(sum(r["nb_done"] for r in res), 1),
+                                  "note": "same workload and cores at the notebook's OSQP tolerances (eps_abs = eps_rel = 1e-5): "
+                                          "tau then agrees with the fp64 optimum to ~1e-3 only"},
             "sample": f"{done} QPs of the same Atlas config-3 workload over {len(res)} processes (one controller each, disjoint "
                       f"seeded slices), OSQP restatement eps_abs=1e-8 eps_rel=1e-16 cold start, mean "
                       f"{iters / max(done, 1):.0f} ADMM iterations, {busy:.1f} s of solving ({wall:.1f} s with process start-up); "
@@ -263,7 +280,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": ach_bytes / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": ach_bytes / HBM_PEAK,
                          "traffic": MEASURED_TRAFFIC_BYTES_PER_SOLVE * B if args.config == 3 else None,
-                         "traffic_source": "profiles/r01_v26_traffic_summary.json (rocprofv3 PMC FETCH_SIZE + WRITE_SIZE, separate passes), bytes per launch; includes the HBM spill slots (DESIGN.md 4)",
+                         "traffic_source": "profiles/r01_v27_traffic_summary.json (rocprofv3 PMC FETCH_SIZE + WRITE_SIZE, separate passes), bytes per launch; includes the HBM spill slots (DESIGN.md 4)",
                          "kernel": "qpc_tick_kernel", "kernel_avg_ms": avg_ms.value, "launches": int(nl.value),
                          "algorithmic_bytes_per_solve": alg_bytes,
                          "note": "path is fp64-VALU / LDS-latency bound, not HBM bound (SURVEY.md 8d); "

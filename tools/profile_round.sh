@@ -1,0 +1,19 @@
+#!/bin/bash
+# Profiles of one bench.py run for profiles/ (run on the GPU box through gpurun, from the repo root):
+#   tools/profile_round.sh <tag>      ->  gpurun_out/prof_<tag>/{stats,fetch,write,sq_a,sq_b}/...
+# rocprofv3 passes are kept separate (kernel trace + stats; one --pmc group per pass), the program itself
+# follows `--` (no env / shell hops), outputs land under gpurun_out/.
+set -e -o pipefail
+TAG=${1:-vX}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o k --output-format csv -- $BENCH > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
+rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o k --output-format csv -- $BENCH > /dev/null 2> $OUT/fetch.log
+rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o k --output-format csv -- $BENCH > /dev/null 2> $OUT/write.log
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS -d $OUT/sq_a -o k --output-format csv -- $BENCH > /dev/null 2> $OUT/sq_a.log
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY -d $OUT/sq_b -o k --output-format csv -- $BENCH > /dev/null 2> $OUT/sq_b.log
+python3 $ROOT/bench.py --steps 20 --warmup 3 > $OUT/bench_full.json 2> $OUT/bench_full.err
+find $OUT -name "*.csv" | head -20

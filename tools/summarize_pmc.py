@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Reduce the rocprofv3 outputs of tools/profile_round.sh to the summaries kept under profiles/:
+python tools/summarize_pmc.py gpurun_out/prof_<tag> profiles/r01_<tag>   (per-launch means over the timed launches of
+the tick kernel; FETCH_SIZE / WRITE_SIZE are KiB as rocprofv3 reports them on gfx950)"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+
+def rows(d, pattern):
+    out = []
+    for f in glob.glob(os.path.join(d, "**", pattern), recursive=True):
+        with open(f) as fh:
+            out += list(csv.DictReader(fh))
+    return out
+
+
+def counters(d):
+    acc = {}
+    for r in rows(d, "*counter_collection.csv"):
+        if not r["Kernel_Name"].startswith("qpc_tick_kernel"):
+            continue
+        acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    return acc
+
+
+def main():
+    src, dst = sys.argv[1], sys.argv[2]
+    stats = [r for r in rows(os.path.join(src, "stats"), "*kernel_stats.csv")]
+    for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True):
+        shutil.copy(f, dst + "_kernel_stats.csv")
+    traffic = {}
+    for name, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+        v = counters(os.path.join(src, sub)).get(name, [])
+        v = v[3:] if len(v) > 3 else v  # drop the warm-up launches
+        for f in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
+            shutil.copy(f, f"{dst}_pmc_{name.lower()}.csv")
+        traffic[name] = {"per_launch_KiB": sum(v) / max(len(v), 1), "launches": len(v), "min": min(v, default=0), "max": max(v, default=0)}
+    json.dump(traffic, open(dst + "_traffic_summary.json", "w"), indent=1)
+    sq = {}
+    for sub in ("sq_a", "sq_b"):
+        for k, v in counters(os.path.join(src, sub)).items():
+            v = v[3:] if len(v) > 3 else v
+            sq[k] = sum(v) / max(len(v), 1)
+    tick = [r for r in stats if r["Name"].startswith("qpc_tick_kernel")]
+    json.dump({"kernel": tick[0]["Name"] if tick else None, "qps_per_launch": 32768,
+               "kernel_avg_ms_under_rocprof": float(tick[0]["AverageNs"]) / 1e6 if tick else None, "per_launch": sq},
+              open(dst + "_pmc_summary.json", "w"), indent=1)
+    for name in ("bench_full.json", "bench_under_rocprof.json"):
+        if os.path.exists(os.path.join(src, name)):
+            shutil.copy(os.path.join(src, name), f"{dst}_{name}")
+    print(json.dumps({"traffic": traffic, "kernel_stats": [(r["Name"][:40], r["Calls"], r["AverageNs"]) for r in stats[:3]]}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
