@@ -1457,18 +1457,60 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       }
     }
   } QPC_END_PHASE
-  QPC_PHASE(lane) { // S11I = X'X into the (now free) leading block of L_SM ; Z = X' L21' = S11^-1 S12
-    for (int idx = lane; idx < m1 * m1; idx += 64) {
-      int r = idx / m1, c = idx % m1;
-      int k0 = r > c ? r : c;
-      sm[D.lds[L_SM] + r * D.ms + c] = dotp(sm + D.lds[L_X] + k0 * D.m1s + r, D.m1s, sm + D.lds[L_X] + k0 * D.m1s + c, D.m1s, m1 - k0);
-    }
-    if (nw)
-      for (int idx = lane; idx < m1 * 6; idx += 64) {
-        int r = idx / 6, a = idx % 6;
-        sm[D.lds[L_X2] + idx] = dotp(sm + D.lds[L_X] + r * D.m1s + r, D.m1s, sm + D.lds[L_SM] + (m1 + a) * D.ms + r, 1, m1 - r);
+  // S11I = X'X into the (now free) leading block of L_SM: the second GEMM-shaped step of the tick, on the
+  // fp64 matrix core like S = M M' above -- lower-triangular 16x16 tiles, operands straight from the LDS
+  // copy of X (lower triangular: tile row ti only needs k >= 16 ti), two LDS reads per lane and k-step
+  // instead of the ~2 x 13 per entry of the dot-product form.  Z = X' L21' = S11^-1 S12 rides in the
+  // write-out phase.
+  {
+    const int nt1 = (m1 + 15) / 16, nk1 = (m1 + 3) / 4;
+    QPC_LANE_ARRAY(xacc_, 4 * QPC_NTILE_MAX);
+    QPC_PHASE(lane) {
+      double *acc = QPC_LA(xacc_, lane);
+      for (int e = 0; e < 4 * QPC_NTILE_MAX; e++) acc[e] = 0.0;
+    } QPC_END_PHASE
+    {
+      int tile = 0;
+      QPC_UNROLL_JIT
+      for (int ti = 0; ti < nt1; ti++) {
+        QPC_UNROLL_JIT
+        for (int tj = 0; tj <= ti; tj++, tile++) {
+          QPC_UNROLL_JIT
+          for (int ks = 4 * ti; ks < nk1; ks++) {
+            QPC_MFMA_F64_16x16x4(lane, QPC_LA(xacc_, lane) + 4 * tile,
+                                 ((16 * ti + (lane & 15) < m1 && 4 * ks + (lane >> 4) < m1)
+                                      ? (double)sm[D.lds[L_X] + (4 * ks + (lane >> 4)) * D.m1s + 16 * ti + (lane & 15)] : 0.0),
+                                 ((16 * tj + (lane & 15) < m1 && 4 * ks + (lane >> 4) < m1)
+                                      ? (double)sm[D.lds[L_X] + (4 * ks + (lane >> 4)) * D.m1s + 16 * tj + (lane & 15)] : 0.0))
+          }
+        }
       }
-  } QPC_END_PHASE
+    }
+    QPC_PHASE(lane) {
+      const double *acc = QPC_LA(xacc_, lane);
+      int tile = 0;
+      QPC_UNROLL_JIT
+      for (int ti = 0; ti < nt1; ti++) {
+        QPC_UNROLL_JIT
+        for (int tj = 0; tj <= ti; tj++, tile++) {
+          QPC_UNROLL_FULL
+          for (int reg = 0; reg < 4; reg++) {
+            const int r = 16 * ti + (lane >> 4) + 4 * reg, c = 16 * tj + (lane & 15);
+            if (r < m1 && c <= r) {
+              const double v = acc[4 * tile + reg];
+              sm[D.lds[L_SM] + r * D.ms + c] = v;
+              if (c < r) sm[D.lds[L_SM] + c * D.ms + r] = v;
+            }
+          }
+        }
+      }
+      if (nw)
+        for (int idx = lane; idx < m1 * 6; idx += 64) {
+          int r = idx / 6, a = idx % 6;
+          sm[D.lds[L_X2] + idx] = dotp(sm + D.lds[L_X] + r * D.m1s + r, D.m1s, sm + D.lds[L_SM] + (m1 + a) * D.ms + r, 1, m1 - r);
+        }
+    } QPC_END_PHASE
+  }
   QPC_PROF_ACC(PS_XINV);
   // ======================================================================== active-set solve (a13)
   Solver<P> S(D, IT, DT, sm, PA, PT);
