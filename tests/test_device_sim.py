@@ -252,3 +252,76 @@ def test_sim_generic_kernel_without_jit(monkeypatch):
     assert case[1].L.qpc_debug_jit_active(case[1].h) == 0
     assert check_step(case) >= 2
     check_step(tree_case(gpu_factory, 8, True), dt=2e-3)
+
+
+# ------------------------------------------------------------------------------------------ physics
+def floating_tree(factory, seed, gravity):
+    mech = M.rand_tree([M.QUAT_FLOATING, M.REVOLUTE, M.REVOLUTE, M.PRISMATIC, M.REVOLUTE, M.FIXED, M.REVOLUTE], seed=seed)
+    mech.gravity = gravity
+    c = factory(mech, 4, 0)
+    for j in range(mech.nbodies):
+        c.regularize(j, 0.1)
+    c.finalize()
+    return mech, c
+
+
+def check_newton_euler(factory):
+    """free flight (no ground in reach, arbitrary joint torques): whatever the joints do, the step's v̇ satisfies
+    A v̇ + Ȧv = W_gravity -- the whole-robot Newton-Euler equation the controller's wrench balance is built on
+    (momentum.jl:162-193) and the reference's free-fall test asserts (test/controller.jl:128-165)"""
+    mech, c = floating_tree(factory, 31, (0.3, -0.2, -9.81))
+    rng = np.random.default_rng(2)
+    B, dt = 6, 1e-3
+    qs, vs = zip(*(M.rand_state(mech, rng, 1.0) for _ in range(B)))
+    q, v = np.array(qs), np.array(vs)
+    tau = rng.normal(scale=2.0, size=(B, mech.nv))
+    tau[:, :6] = 0.0  # nothing pushes on the floating base
+    qn, vn, bad = c.sim_step(q, v, tau, binding.SimParams(dt, -1e3, 1.0, 1.0, 1.0))
+    assert not bad.any()
+    om = O.OracleModel(mech)
+    g = np.array(mech.gravity)
+    for b in range(B):
+        om.set_state(q[b], v[b])
+        A, Adv = om.momentum_matrix()
+        com = om.center_of_mass()
+        mtot = mech.total_mass()
+        rate = A @ ((vn[b] - v[b]) / dt) + Adv
+        wg = np.concatenate([np.cross(com, mtot * g), mtot * g])
+        np.testing.assert_allclose(rate, wg, rtol=0, atol=1e-7 * (1.0 + np.abs(wg).max()))
+
+
+def check_energy_drift(factory):
+    """no gravity, no torque, no ground: kinetic energy is conserved by the dynamics; the semi-implicit Euler step
+    drifts at first order in dt (halving dt at fixed simulated time roughly halves the drift)"""
+    mech, c = floating_tree(factory, 32, (0.0, 0.0, 0.0))
+    rng = np.random.default_rng(3)
+    q0, v0 = M.rand_state(mech, rng, 0.5)
+    om = O.OracleModel(mech)
+
+    def energy(q, v):
+        om.set_state(q, v)
+        return 0.5 * v @ om.mass_matrix() @ v
+    drift = []
+    for steps, dt in ((50, 2e-3), (100, 1e-3)):
+        q, v = q0[None].copy(), v0[None].copy()
+        for _ in range(steps):
+            q, v, bad = c.sim_step(q, v, np.zeros((1, mech.nv)), binding.SimParams(dt, -1e3, 1.0, 1.0, 1.0))
+            assert not bad.any()
+        drift.append(abs(energy(q[0], v[0]) - energy(q0, v0)) / energy(q0, v0))
+    assert drift[0] < 0.05 and drift[1] < 0.6 * drift[0] + 1e-9, drift
+
+
+def test_sim_newton_euler_emulated():
+    emu.build()
+    check_newton_euler(emu.factory)
+
+
+def test_sim_energy_drift_emulated():
+    emu.build()
+    check_energy_drift(emu.factory)
+
+
+@pytest.mark.gpu
+def test_sim_physics_gpu():
+    check_newton_euler(gpu_factory)
+    check_energy_drift(gpu_factory)
