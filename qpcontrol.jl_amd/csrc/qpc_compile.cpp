@@ -254,6 +254,26 @@ int qpc_compile_program(qpc_controller *c) {
       B.ibegin(IT_META); B.it.insert(B.it.end(), meta.begin(), meta.end());
     }
     B.ibegin(IT_DESC_MASK); B.it.insert(B.it.end(), mask.begin(), mask.end());
+    { // simulation step (qpc_sim.h): per body lane {children mask lo, hi, height above the leaves, depth below the
+      // roots}, then one extra row {max height, max depth, 0, 0}
+      std::vector<int> sim(4 * (size_t)(nb + 1), 0), height(nb, 0);
+      int maxh = 0, maxdp = 0;
+      for (int i = nb - 1; i >= 0; i--) { // parent[i] < i: children are visited before their parents
+        const int pa = m->parent[i];
+        if (pa >= 0) {
+          if (i < 32) sim[4 * pa] |= (int)(1u << i); else sim[4 * pa + 1] |= (int)(1u << (i - 32));
+          height[pa] = std::max(height[pa], height[i] + 1);
+        }
+      }
+      for (int i = 0; i < nb; i++) {
+        int dp = 0;
+        for (int a = m->parent[i]; a >= 0; a = m->parent[a]) dp++;
+        sim[4 * i + 2] = height[i]; sim[4 * i + 3] = dp;
+        maxh = std::max(maxh, height[i]); maxdp = std::max(maxdp, dp);
+      }
+      sim[4 * nb] = maxh; sim[4 * nb + 1] = maxdp;
+      B.ibegin(IT_SIM_TREE); B.it.insert(B.it.end(), sim.begin(), sim.end());
+    }
     B.ibegin(IT_PDES_K); B.it.insert(B.it.end(), pdes.begin(), pdes.end());
     // packed assembly codes: kind(3) | sg+1(2) | a(3) | k(7) | frame+1(7) | t(6)   (kind 7 = wrench row)
     std::vector<int> rcode(D.m, 0), rdes(D.m, -1), rt(D.m, -1), rpink(D.m, -1);

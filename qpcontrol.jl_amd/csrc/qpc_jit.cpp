@@ -45,8 +45,7 @@ std::string qpc_jit_source(const QpcDims &D) {
     }
     o << "}\n";
   }
-  o << "#define QPC_SIM_ROWS_MAX " << (D.nv + 1) << "\n"
-       "#include \"qpc_tick.h\"\n"
+  o << "#include \"qpc_tick.h\"\n"
        "#include \"qpc_sim.h\"\n";
   // field order == struct QpcDims (qpc_program.h)
   o << "static_assert(sizeof(QpcDims) == " << sizeof(QpcDims) << ", \"QpcDims layout differs between host and JIT source\");\n";
@@ -91,7 +90,6 @@ std::string qpc_jit_source(const QpcDims &D) {
   o << "extern \"C\" __global__ void __launch_bounds__(64, 2) qpc_sim_kernel_jit(const int *__restrict__ IT, "
        "const double *__restrict__ DT, const QpcSimArgs A) {\n"
        "  __shared__ __attribute__((aligned(16))) double qpc_lds[" << qpc_sim_layout(D).total << "];\n"
-       "  qpc::qpc_sim_prologue<double *>(kD, IT, qpc_lds);\n"
        "  for (long long b = blockIdx.x; b < A.B; b += gridDim.x) {\n"
        "    qpc::SimIO io;\n"
        "    io.q = A.q + b * kD.nq; io.v = A.v + b * kD.nv; io.tau = A.tau + b * kD.nv;\n"

@@ -39,6 +39,7 @@ enum {
   IT_META, // [64 * (6 + (maxd + 3) / 4)] packed per-lane metadata (qpc_tick.h TickMeta): one row per lane
   IT_LAW, // [n_desired * 3] desired law of entry i: kind (QPC_LAW_*), arg0, arg1
           //   JOINT_PD: q index, v index;  COM_PD: component, -;  ORIENTATION_PD: body, component
+  IT_SIM_TREE, // [(nb + 1) * 4] simulation step: per body {children mask lo, hi, height, depth}; last row {max height, max depth}
   IT_HOT, // solver lookups staged into LDS per QP: row_slack[m], slack_row[ne], slack_woff[ne], slack_dim[ne], slack_s0[ne]
   IT_COUNT
 };
@@ -138,10 +139,9 @@ struct QpcDims {
   double eps_primal, tau_pivot, tol_bound, tol_accept;
 };
 
-// LDS slab of the simulation step (qpc_sim.h), offsets in doubles (fields in allocation order).  `vb` (velocity index -> body) is
-// staged once per workgroup by qpc_sim_prologue and survives from robot to robot.
+// LDS slab of the simulation step (qpc_sim.h), offsets in doubles (fields in allocation order)
 struct QpcSimLayout {
-  int vb, q, v, tau, rl, h, s, tj, t, cr, ab, iw, ic, f, cf, hk, mm, dinv, x, flag, mstride, total;
+  int q, v, tau, rl, h, s, tj, t, cr, iw, cf, ia, pa, acc, x, total;
 };
 #if defined(__HIPCC__) || defined(__HIPCC_RTC__)
 #define QPC_HOST_DEVICE __host__ __device__
@@ -152,27 +152,18 @@ QPC_HOST_DEVICE inline QpcSimLayout qpc_sim_layout(const QpcDims &D) {
   QpcSimLayout L{};
   int o = 0;
 #define QPC_SIM_TAKE(field, n) L.field = o; o += (n)
-  QPC_SIM_TAKE(vb, D.nv);
   QPC_SIM_TAKE(q, D.nq); QPC_SIM_TAKE(v, D.nv); QPC_SIM_TAKE(tau, D.nv);
-  QPC_SIM_TAKE(rl, 12 * D.nb); QPC_SIM_TAKE(h, 12 * D.nb);
+  QPC_SIM_TAKE(rl, 12 * D.nb); // local and world transforms are dead once the ground reactions exist (the floating-joint
+  QPC_SIM_TAKE(h, 12 * D.nb);  // lanes keep their own transform in registers): the articulated inertias overlay both
   QPC_SIM_TAKE(s, 6 * D.nv);
-  QPC_SIM_TAKE(tj, 6 * D.nb); QPC_SIM_TAKE(t, 6 * D.nb); QPC_SIM_TAKE(cr, 6 * D.nb); QPC_SIM_TAKE(ab, 6 * D.nb);
-  QPC_SIM_TAKE(iw, 10 * D.nb); QPC_SIM_TAKE(ic, 10 * D.nb);
-  QPC_SIM_TAKE(f, 6 * D.nb);
+  QPC_SIM_TAKE(tj, 6 * D.nb); QPC_SIM_TAKE(t, 6 * D.nb); QPC_SIM_TAKE(cr, 6 * D.nb);
+  QPC_SIM_TAKE(iw, 10 * D.nb);
   QPC_SIM_TAKE(cf, 6 * (D.nc > 0 ? D.nc : 1));
-  QPC_SIM_TAKE(hk, 6 * D.nv);
-  L.mstride = (D.nv + 1) | 1; // odd leading dimension: column accesses spread over the banks
-  {
-    // the (nv+1) x (nv+1) system overlays rl .. ab: local / world transforms, motion subspaces (each
-    // velocity lane keeps its column in registers), joint twists, twists and bias terms are all dead
-    // once the body wrenches and h_k exist, which is when the mass matrix is assembled
-    const int need = (D.nv + 1) * L.mstride, have = L.iw - L.rl;
-    if (need <= have) L.mm = L.rl;
-    else { L.mm = o; o += need; }
-  }
-  QPC_SIM_TAKE(dinv, D.nv);
+  // articulated-body contributions to the parent: 21 (packed symmetric 6x6, over rl + h) + 6 (over tj) per body
+  L.ia = L.rl;
+  L.pa = L.tj;
+  QPC_SIM_TAKE(acc, 6 * D.nb);
   QPC_SIM_TAKE(x, D.nv);
-  QPC_SIM_TAKE(flag, 2);
 #undef QPC_SIM_TAKE
   L.total = o;
   return L;

@@ -110,7 +110,6 @@ struct QpcSimArgs {
 extern "C" __global__ void __launch_bounds__(64)
 qpc_sim_kernel(const QpcDims D, const int *__restrict__ IT, const double *__restrict__ DT, const QpcSimArgs A) {
   extern __shared__ __attribute__((aligned(16))) double qpc_lds[];
-  qpc::qpc_sim_prologue<double *>(D, IT, qpc_lds);
   for (long long b = blockIdx.x; b < A.B; b += gridDim.x) {
     qpc::SimIO io;
     io.q = A.q + b * D.nq; io.v = A.v + b * D.nv; io.tau = A.tau + b * D.nv;
@@ -498,7 +497,6 @@ int32_t qpc_qp_solve_batch(int32_t n, int32_t m, int64_t B, const double *P, con
 static int sim_check(qpc_controller *c, int64_t B, const void *q, const void *v, const void *tau, const qpc_sim_params *p, const char *who) {
   if (!c || !c->finalized || !c->dev) { qpc_set_error("controller not finalized"); return QPC_ERR_NOT_FINALIZED; }
   if (B < 0 || !q || !v || !tau || !p) { qpc_set_error(std::string(who) + ": missing array"); return QPC_ERR_INVALID_ARGUMENT; }
-  if (c->prog.dims.nv > 63) { qpc_set_error(std::string(who) + ": the simulation step supports at most 63 velocity coordinates"); return QPC_ERR_UNSUPPORTED; }
   if (!c->dev->jit_sim_func && c->prog.dims.maxdepth > QPC_GENERIC_MAXD) {
     qpc_set_error(std::string(who) + ": tree deeper than the generic kernel supports and no JIT kernel"); return QPC_ERR_UNSUPPORTED;
   }

@@ -11,10 +11,11 @@
 //                           world inertias (the a2 sweeps of the tick, without pinned accelerations)
 //   ground contact        : per contact point of the controller (addcontact!, momentum.jl:133-148) a
 //                           normal spring/damper and viscous tangential friction capped by Coulomb's law
-//   dynamics bias  c      : RNEA with v̇ = 0 and the contact wrenches as external wrenches
-//   mass matrix    M      : composite rigid body algorithm (lower triangle, lane = row)
-//   M v̇ = tau - c         : Cholesky with the right-hand side carried as an extra row, lane = row, the row's
-//                           factor entries in registers (JIT-specialised like the tick)
+//   forward dynamics      : articulated-body algorithm in world coordinates, lane = body, one phase per tree
+//                           level: leaves -> roots for the articulated inertias / bias forces (siblings in
+//                           parallel, a parent gathers its children), roots -> leaves for the accelerations.
+//                           A first version built the mass matrix (CRBA) and factorised it with a 36-step
+//                           Cholesky + 36-step back substitution; the level-parallel form has ~2 x 12 steps.
 //   integration           : v += dt v̇ ; q <- q (+) v dt on the configuration manifold
 // Checked against the oracle's forward dynamics / integrate and the Python contact model of
 // tests/sim.py (tests/test_device_sim.py).
@@ -24,12 +25,6 @@
 #include "qpc_tick.h" // small dense helpers, TickMeta
 
 namespace qpc {
-
-// compile-time bound of nv + 1 (rows of the factorization incl. the right-hand side row): the JIT
-// specialisation defines it as the actual value so that the row registers index statically
-#ifndef QPC_SIM_ROWS_MAX
-#define QPC_SIM_ROWS_MAX 64
-#endif
 
 typedef QpcSimLayout SimLayout;
 QPC_FN SimLayout sim_layout(const QpcDims &D) { return qpc_sim_layout(D); }
@@ -41,13 +36,8 @@ struct SimIO {
   int32_t *bad;              // failure counter of this robot or nullptr
 };
 
-// once per workgroup: velocity index -> body into the persistent head of the slab
-template <class P> QPC_FN void qpc_sim_prologue(const QpcDims &D, const int *IT, P sm) {
-  const SimLayout L = sim_layout(D);
-  QPC_PHASE(lane) {
-    for (int k = lane; k < D.nv; k += 64) sm[L.vb + k] = (double)IT[D.it[IT_VBODY] + k];
-  } QPC_END_PHASE
-}
+// packed lower triangle of a symmetric 6x6: entry (r, c), r >= c
+#define QPC_SYM6(r, c) ((r) * ((r) + 1) / 2 + (c))
 
 template <class P>
 QPC_FN void qpc_sim_step(const QpcDims &D, const int *IT, const double *DT, P sm, const SimIO &io, const qpc_sim_params &sp) {
@@ -55,12 +45,12 @@ QPC_FN void qpc_sim_step(const QpcDims &D, const int *IT, const double *DT, P sm
   const SimLayout L = sim_layout(D);
   // a failed QP (checkstatus, momentum.jl:83-91) applies no torque for this step and is counted
   const bool failed = io.status && io.status[0] > QPC_STATUS_ALMOST_OPTIMAL;
+  const int maxh = IT[D.it[IT_SIM_TREE] + 4 * nb], maxdp = IT[D.it[IT_SIM_TREE] + 4 * nb + 1];
 
-  // per-lane static metadata in registers, as in the tick (TickMeta): joint type / offsets / ancestor
-  // chain of body `lane`, subtree mask of the body of velocity index `lane`; plus the full subtree
-  // mask of body `lane` for the composite inertias (the tick's copy is pruned to the free joints)
+  // per-lane static metadata in registers, as in the tick (TickMeta): joint type / offsets / ancestor chain of
+  // body `lane`; plus its children mask, height above the leaves and depth below the roots
   TickMeta M;
-  QPC_LANE_INTS(dm_, 2);
+  QPC_LANE_INTS(tr_, 4);
   QPC_PHASE(lane) {
     int *mt = QPC_LI(M.v, lane);
     {
@@ -68,12 +58,10 @@ QPC_FN void qpc_sim_step(const QpcDims &D, const int *IT, const double *DT, P sm
       QPC_UNROLL_JIT
       for (int e = 0; e < QPC_META_WORDS; e++) mt[e] = e < rowlen ? IT[D.it[IT_META] + lane * rowlen + e] : 0;
     }
-    int *dm = QPC_LI(dm_, lane);
-    dm[0] = lane < nb ? IT[D.it[IT_DESC_MASK] + 2 * lane] : 0;
-    dm[1] = lane < nb ? IT[D.it[IT_DESC_MASK] + 2 * lane + 1] : 0;
+    int *tr = QPC_LI(tr_, lane);
+    for (int e = 0; e < 4; e++) tr[e] = lane < nb ? IT[D.it[IT_SIM_TREE] + 4 * lane + e] : (e < 2 ? 0 : -1);
     for (int i = lane; i < nq; i += 64) sm[L.q + i] = io.q[i];
     for (int i = lane; i < nv; i += 64) { sm[L.v + i] = io.v[i]; sm[L.tau + i] = failed ? 0.0 : io.tau[i]; }
-    if (lane == 0) sm[L.flag] = 0.0;
   } QPC_END_PHASE
 
   QPC_PHASE(lane) { // joint transforms  x_parent = Rf (Rj x + pj) + pf
@@ -108,10 +96,12 @@ QPC_FN void qpc_sim_step(const QpcDims &D, const int *IT, const double *DT, P sm
     }
   } QPC_END_PHASE
 
+  QPC_LANE_ARRAY(hreg_, 12); // world transform of body `lane` (the floating-joint lanes need it after LDS has moved on)
   QPC_PHASE(lane) { // transform_to_root along the (register-resident) ancestor chain, nearest first
     if (lane < nb) {
       const int *mt = QPC_LI(M.v, lane);
-      double H[12], A[12], t[3];
+      double *H = QPC_LA(hreg_, lane);
+      double A[12], t[3];
       ld(sm + L.rl + 12 * lane, 12, H);
       QPC_UNROLL_JIT
       for (int s = 0; s < QPC_MAXD; s++) {
@@ -132,8 +122,8 @@ QPC_FN void qpc_sim_step(const QpcDims &D, const int *IT, const double *DT, P sm
       const int i = lane;
       const int *mt = QPC_LI(M.v, lane);
       const int jt = MT_JT(mt), v0 = MT_V0(mt), n = MT_NVJ(mt);
-      double H[12], tj[6] = {0, 0, 0, 0, 0, 0};
-      ld(sm + L.h + 12 * i, 12, H);
+      const double *H = QPC_LA(hreg_, lane);
+      double tj[6] = {0, 0, 0, 0, 0, 0};
       const double *ax = DT + D.dt[DT_AXIS] + 3 * i;
       for (int c = 0; c < n; c++) {
         double S[6] = {0, 0, 0, 0, 0, 0};
@@ -166,7 +156,7 @@ QPC_FN void qpc_sim_step(const QpcDims &D, const int *IT, const double *DT, P sm
     }
   } QPC_END_PHASE
 
-  QPC_PHASE(lane) { // twist_wrt_world, bias increment T_i x (S_i v_i)
+  QPC_PHASE(lane) { // twist_wrt_world, velocity-product acceleration c_i = T_i x (S_i v_i)
     if (lane < nb) {
       const int i = lane;
       const int *mt = QPC_LI(M.v, lane);
@@ -185,28 +175,7 @@ QPC_FN void qpc_sim_step(const QpcDims &D, const int *IT, const double *DT, P sm
     }
   } QPC_END_PHASE
 
-  QPC_PHASE(lane) { // bias accelerations, composite inertias; ground reaction per contact point
-    if (lane < nb) {
-      const int i = lane;
-      const int *mt = QPC_LI(M.v, lane), *dm = QPC_LI(dm_, lane);
-      double Ab[6], Ic[10];
-      ld(sm + L.cr + 6 * i, 6, Ab);
-      QPC_UNROLL_JIT
-      for (int s = 0; s < QPC_MAXD; s++) {
-        const int an = MT_ANC(mt, s);
-        if (an >= 0)
-          for (int a = 0; a < 6; a++) Ab[a] += sm[L.cr + 6 * an + a];
-      }
-      st(sm + L.ab + 6 * i, 6, Ab);
-      for (int a = 0; a < 10; a++) Ic[a] = 0.0;
-      unsigned long long msk = ((unsigned long long)(unsigned)dm[1] << 32) | (unsigned long long)(unsigned)dm[0];
-      while (msk) {
-        const int k = QPC_CTZ64(msk);
-        msk &= msk - 1;
-        for (int a = 0; a < 10; a++) Ic[a] += sm[L.iw + 10 * k + a];
-      }
-      st(sm + L.ic + 10 * i, 10, Ic);
-    }
+  QPC_PHASE(lane) { // ground reaction per contact point
     for (int c = lane; c < nc; c += 64) {
       // compliant half space z <= ground_z: normal spring/damper (unilateral), viscous tangential
       // friction capped at mu * normal force; wrench about the world origin
@@ -232,124 +201,150 @@ QPC_FN void qpc_sim_step(const QpcDims &D, const int *IT, const double *DT, P sm
     }
   } QPC_END_PHASE
 
-  QPC_LANE_ARRAY(sk_, 6); // motion subspace column of velocity index `lane`
-  QPC_PHASE(lane) { // body wrenches of the v̇ = 0 inverse dynamics; h_k = Ic(vbody k) S_k
+  // ---- articulated-body pass, leaves -> roots, one phase per height.  In world coordinates nothing has to be
+  // transformed between bodies: IA_i = I_i + sum_children Ia_c,  pA_i = T_i x* I_i T_i - f_ext,i + sum_children pa_c,
+  //   1-DoF joint:  U = IA S, d = S.U, u = tau - S.pA,  Ia = IA - U U'/d,  pa = pA + Ia c_i + U u/d
+  //   fixed joint:  Ia = IA, pa = pA + IA c_i
+  //   floating joint (S invertible): the subtree decouples, Ia = 0, pa = S^-T tau (the joint "torque" as a world wrench)
+  // The lane keeps U, 1/d, u (or IA, pA - S^-T tau for a floating joint) in registers for the second pass.
+  QPC_LANE_ARRAY(ab_, 29); // [0..5] U, [6] 1/d, [7] u   |  floating: [0..20] IA packed, [21..26] S^-T tau - pA ; [28] failure
+  QPC_PHASE(lane) { // bias forces pA0_i = T_i x* I_i T_i - f_ext,i for all bodies at once (parked in the acceleration slots)
+    QPC_LA(ab_, lane)[28] = 0.0;
     if (lane < nb) {
       const int i = lane;
-      double Ab[6], T[6], I[10], h[6], ia[6], cf[6];
-      ld(sm + L.ab + 6 * i, 6, Ab);
-      ld(sm + L.t + 6 * i, 6, T);
+      double T[6], I[10], h[6], pA[6];
       ld(sm + L.iw + 10 * i, 10, I);
-      for (int a = 0; a < 3; a++) Ab[3 + a] -= DT[D.dt[DT_GRAV] + a]; // root acceleration -g
-      inertia_mul(I, Ab, ia);
+      ld(sm + L.t + 6 * i, 6, T);
       inertia_mul(I, T, h);
-      crf(T, h, cf);
-      for (int a = 0; a < 6; a++) ia[a] += cf[a];
+      crf(T, h, pA);
       for (int e = IT[D.it[IT_BC_PTR] + i]; e < IT[D.it[IT_BC_PTR] + i + 1]; e++) {
-        const int c = IT[D.it[IT_BC_IDX] + e];
-        for (int a = 0; a < 6; a++) ia[a] -= sm[L.cf + 6 * c + a];
+        const int cc = IT[D.it[IT_BC_IDX] + e];
+        for (int a = 0; a < 6; a++) pA[a] -= sm[L.cf + 6 * cc + a];
       }
-      st(sm + L.f + 6 * i, 6, ia);
-    }
-    if (lane < nv) {
-      const int *mt = QPC_LI(M.v, lane);
-      double Ic[10], h[6];
-      double *S = QPC_LA(sk_, lane);
-      ld(sm + L.ic + 10 * MT_VBODY(mt), 10, Ic);
-      ld(sm + L.s + 6 * lane, 6, S);
-      inertia_mul(Ic, S, h);
-      st(sm + L.hk + 6 * lane, 6, h);
+      st(sm + L.acc + 6 * i, 6, pA);
     }
   } QPC_END_PHASE
-
-  QPC_PHASE(lane) { // column j of the mass matrix (lower triangle: rows k >= j) and entry j of the rhs row
-    if (lane < nv) {
-      const int j = lane;
-      const int *mt = QPC_LI(M.v, lane);
-      const double *S = QPC_LA(sk_, lane);
-      const unsigned long long sub = ((unsigned long long)(unsigned)mt[5] << 32) | (unsigned long long)(unsigned)mt[4];
-      double F[6] = {0, 0, 0, 0, 0, 0};
-      unsigned long long msk = sub;
-      while (msk) {
-        const int b = QPC_CTZ64(msk);
-        msk &= msk - 1;
-        for (int a = 0; a < 6; a++) F[a] += sm[L.f + 6 * b + a];
-      }
-      double cj = 0.0;
-      for (int a = 0; a < 6; a++) cj += S[a] * F[a];
-      sm[L.mm + nv * L.mstride + j] = sm[L.tau + j] - cj;
-      // M[k][j] = S_j . Ic(vbody k) S_k when joint j supports the body of k (k in the subtree of vbody j)
-      for (int k0 = 0; k0 < nv; k0 += 4) {
-        double hb[4][6];
-        int on[4];
-        QPC_UNROLL_FULL
-        for (int u = 0; u < 4; u++) {
-          const int k = k0 + u < nv ? k0 + u : 0;
-          on[u] = (int)((sub >> (int)(double)sm[L.vb + k]) & 1ull);
-          QPC_UNROLL_FULL
-          for (int a = 0; a < 6; a++) hb[u][a] = sm[L.hk + 6 * k + a];
+  for (int lvl = 0; lvl <= maxh; lvl++) {
+    QPC_PHASE(lane) {
+      const int *tr = QPC_LI(tr_, lane);
+      if (lane < nb && tr[2] == lvl) {
+        const int i = lane;
+        const int *mt = QPC_LI(M.v, lane);
+        const int jt = MT_JT(mt), v0 = MT_V0(mt);
+        double *ab = QPC_LA(ab_, lane);
+        double IA[21], pA[6], I[10], c[6];
+        ld(sm + L.iw + 10 * i, 10, I);
+        ld(sm + L.acc + 6 * i, 6, pA);
+        ld(sm + L.cr + 6 * i, 6, c);
+        { // spatial inertia {m, h, J} as a packed symmetric 6x6 in [angular; linear] order: [[J, h^], [h^', m 1]]
+          const double m_ = I[0], hx = I[1], hy = I[2], hz = I[3];
+          IA[QPC_SYM6(0, 0)] = I[4]; IA[QPC_SYM6(1, 0)] = I[7]; IA[QPC_SYM6(1, 1)] = I[5];
+          IA[QPC_SYM6(2, 0)] = I[8]; IA[QPC_SYM6(2, 1)] = I[9]; IA[QPC_SYM6(2, 2)] = I[6];
+          IA[QPC_SYM6(3, 0)] = 0.0; IA[QPC_SYM6(3, 1)] = hz; IA[QPC_SYM6(3, 2)] = -hy;
+          IA[QPC_SYM6(4, 0)] = -hz; IA[QPC_SYM6(4, 1)] = 0.0; IA[QPC_SYM6(4, 2)] = hx;
+          IA[QPC_SYM6(5, 0)] = hy; IA[QPC_SYM6(5, 1)] = -hx; IA[QPC_SYM6(5, 2)] = 0.0;
+          IA[QPC_SYM6(3, 3)] = m_; IA[QPC_SYM6(4, 3)] = 0.0; IA[QPC_SYM6(4, 4)] = m_;
+          IA[QPC_SYM6(5, 3)] = 0.0; IA[QPC_SYM6(5, 4)] = 0.0; IA[QPC_SYM6(5, 5)] = m_;
         }
-        QPC_UNROLL_FULL
-        for (int u = 0; u < 4; u++) {
-          const int k = k0 + u;
-          if (k < nv && k >= j) {
-            double acc = 0.0;
-            QPC_UNROLL_FULL
-            for (int a = 0; a < 6; a++) acc += S[a] * hb[u][a];
-            sm[L.mm + k * L.mstride + j] = on[u] ? acc : 0.0;
+        unsigned long long kids = ((unsigned long long)(unsigned)tr[1] << 32) | (unsigned long long)(unsigned)tr[0];
+        while (kids) {
+          const int k = QPC_CTZ64(kids);
+          kids &= kids - 1;
+          for (int a = 0; a < 21; a++) IA[a] += sm[L.ia + 21 * k + a];
+          for (int a = 0; a < 6; a++) pA[a] += sm[L.pa + 6 * k + a];
+        }
+        double Ia[21], pa[6];
+        if (jt == QPC_JOINT_QUAT_FLOATING) {
+          // tau (body-frame wrench [n; f] dual to v = [omega_body; v_body]) as a world wrench: S^-T tau
+          const double *H = QPC_LA(hreg_, lane);
+          double tb[6], fw[3], nw[3], pxf[3];
+          for (int a = 0; a < 6; a++) tb[a] = sm[L.tau + v0 + a];
+          mv3(H, tb, nw); mv3(H, tb + 3, fw);
+          cross3(H + 9, fw, pxf);
+          for (int a = 0; a < 21; a++) { ab[a] = IA[a]; Ia[a] = 0.0; }
+          for (int a = 0; a < 3; a++) { pa[a] = nw[a] + pxf[a]; pa[3 + a] = fw[a]; }
+          for (int a = 0; a < 6; a++) ab[21 + a] = pa[a] - pA[a];
+        } else if (jt == QPC_JOINT_FIXED) {
+          for (int a = 0; a < 21; a++) Ia[a] = IA[a];
+          for (int r = 0; r < 6; r++) {
+            double acc = pA[r];
+            for (int k = 0; k < 6; k++) acc += IA[r >= k ? QPC_SYM6(r, k) : QPC_SYM6(k, r)] * c[k];
+            pa[r] = acc;
           }
+        } else {
+          double S[6], U[6];
+          ld(sm + L.s + 6 * v0, 6, S);
+          double d = 0.0, u = sm[L.tau + v0];
+          for (int r = 0; r < 6; r++) {
+            double acc = 0.0;
+            for (int k = 0; k < 6; k++) acc += IA[r >= k ? QPC_SYM6(r, k) : QPC_SYM6(k, r)] * S[k];
+            U[r] = acc;
+            d += S[r] * acc;
+            u -= S[r] * pA[r];
+          }
+          const bool ok = d > 0.0;
+          if (!ok) ab[28] = 1.0; // not positive definite: the step is rejected below
+          const double dinv = ok ? QPC_RCP(d) : 0.0;
+          for (int r = 0; r < 6; r++)
+            for (int k = 0; k <= r; k++) Ia[QPC_SYM6(r, k)] = IA[QPC_SYM6(r, k)] - U[r] * U[k] * dinv;
+          for (int r = 0; r < 6; r++) {
+            double acc = pA[r] + U[r] * (u * dinv);
+            for (int k = 0; k < 6; k++) acc += Ia[r >= k ? QPC_SYM6(r, k) : QPC_SYM6(k, r)] * c[k];
+            pa[r] = acc;
+          }
+          for (int a = 0; a < 6; a++) ab[a] = U[a];
+          ab[6] = dinv; ab[7] = u;
         }
+        st(sm + L.ia + 21 * i, 21, Ia);
+        st(sm + L.pa + 6 * i, 6, pa);
       }
-    }
+    } QPC_END_PHASE
+  }
+
+  // ---- acceleration pass, roots -> leaves, one phase per depth: a' = a_parent + c_i (a_world = -g),
+  //   1-DoF: qdd = (u - U.a')/d, a = a' + S qdd;  fixed: a = a';  floating: a = IA^-1 (S^-T tau - pA), qdd = S^-1 (a - a')
+  for (int lvl = 0; lvl <= maxdp; lvl++) {
+    QPC_PHASE(lane) {
+      const int *tr = QPC_LI(tr_, lane);
+      if (lane < nb && tr[3] == lvl) {
+        const int i = lane;
+        const int *mt = QPC_LI(M.v, lane);
+        const int jt = MT_JT(mt), v0 = MT_V0(mt), par = MT_ANC(mt, 0);
+        const double *ab = QPC_LA(ab_, lane);
+        double ap[6], a[6];
+        ld(sm + L.cr + 6 * i, 6, ap);
+        if (par >= 0) { for (int k = 0; k < 6; k++) ap[k] += sm[L.acc + 6 * par + k]; }
+        else { for (int k = 0; k < 3; k++) ap[3 + k] -= DT[D.dt[DT_GRAV] + k]; }
+        if (jt == QPC_JOINT_QUAT_FLOATING) {
+          double S6[36], sref[6], rhs[6], d[6], qdd[6];
+          for (int r = 0; r < 6; r++)
+            for (int k = 0; k < 6; k++) S6[6 * r + k] = ab[r >= k ? QPC_SYM6(r, k) : QPC_SYM6(k, r)];
+          for (int r = 0; r < 6; r++) { sref[r] = S6[7 * r]; rhs[r] = ab[21 + r]; }
+          chol6_solve(S6, sref, 1e-14, rhs, a);
+          for (int k = 0; k < 6; k++) d[k] = a[k] - ap[k];
+          motion_to_frame(QPC_LA(hreg_, lane), d, qdd);
+          for (int k = 0; k < 6; k++) sm[L.x + v0 + k] = qdd[k];
+        } else if (jt == QPC_JOINT_FIXED) {
+          for (int k = 0; k < 6; k++) a[k] = ap[k];
+        } else {
+          double S[6], ua = ab[7];
+          ld(sm + L.s + 6 * v0, 6, S);
+          for (int k = 0; k < 6; k++) ua -= ab[k] * ap[k];
+          const double qdd = ua * ab[6];
+          for (int k = 0; k < 6; k++) a[k] = ap[k] + S[k] * qdd;
+          sm[L.x + v0] = qdd;
+        }
+        st(sm + L.acc + 6 * i, 6, a);
+      }
+    } QPC_END_PHASE
+  }
+
+  double rej = 0.0;
+  QPC_PHASE(lane) {
+    QPC_RED_MAX_PUT(0, rej, QPC_LA(ab_, lane)[28]);
   } QPC_END_PHASE
-
-  // left-looking Cholesky of M with the right-hand side as row nv (lane = row, the row's own factor
-  // entries in registers, row k broadcast from LDS -- the scheme of the tick's S11 factorization):
-  // afterwards row nv holds y = L^-1 (tau - c) and dinv[k] = 1 / L_kk
-  QPC_LANE_ARRAY(lrow_, QPC_SIM_ROWS_MAX);
-  QPC_UNROLL_JIT
-  for (int k = 0; k < nv; k++) {
-    QPC_PHASE(lane) {
-      if (lane >= k && lane <= nv) {
-        const int r = lane;
-        double *lrow = QPC_LA(lrow_, lane);
-        double accr = 0.0, acck = 0.0;
-        for (int j0 = 0; j0 < k; j0 += 8) {
-          double lk[8];
-          QPC_UNROLL_FULL
-          for (int u = 0; u < 8; u++) lk[u] = sm[L.mm + k * L.mstride + (j0 + u < k ? j0 + u : 0)];
-          QPC_UNROLL_FULL
-          for (int u = 0; u < 8; u++)
-            if (j0 + u < k) { accr += lk[u] * lrow[j0 + u]; acck += lk[u] * lk[u]; }
-        }
-        const double mkk = sm[L.mm + k * L.mstride + k], mrk = sm[L.mm + r * L.mstride + k], dk = mkk - acck;
-        const bool ok = dk > 1e-14 * mkk;
-        const double inv = ok ? QPC_RSQRT(dk) : 0.0; // 1 / L_kk
-        if (r == k) { sm[L.dinv + k] = inv; if (!ok) sm[L.flag] = 1.0; } // not positive definite: the step is rejected
-        else { const double v = (mrk - accr) * inv; lrow[k] = v; sm[L.mm + r * L.mstride + k] = v; }
-      }
-    } QPC_END_PHASE
-  }
-  // back substitution L' v̇ = y, one phase per unknown: lane j keeps y_j in a register and applies the
-  // update of the previous unknown before lane k closes v̇_k
-  {
-    QPC_LANE_ARRAY(y_, 1);
-    QPC_PHASE(lane) {
-      if (lane < nv) QPC_LA(y_, lane)[0] = sm[L.mm + nv * L.mstride + lane];
-    } QPC_END_PHASE
-    QPC_UNROLL_JIT
-    for (int k = nv - 1; k >= 0; k--) {
-      QPC_PHASE(lane) {
-        if (lane <= k) {
-          double *y = QPC_LA(y_, lane);
-          if (k + 1 < nv) y[0] -= sm[L.mm + (k + 1) * L.mstride + lane] * sm[L.x + k + 1];
-          if (lane == k) sm[L.x + k] = y[0] * sm[L.dinv + k];
-        }
-      } QPC_END_PHASE
-    }
-  }
-
-  const bool reject = sm[L.flag] != 0.0;
+  rej = QPC_RED_MAX_GET(0, rej);
+  const bool reject = rej > 0.0;
   QPC_PHASE(lane) { // semi-implicit Euler: the new velocity moves the configuration
     for (int k = lane; k < nv; k += 64) {
       const double vn = reject ? (double)sm[L.v + k] : sm[L.v + k] + sp.dt * sm[L.x + k];

@@ -193,13 +193,11 @@ int32_t qpc_sim_step_batch(qpc_controller *c, int64_t B, double *q, double *v, c
                            const qpc_sim_params *params, int32_t *bad) {
   if (!c || !c->finalized) return QPC_ERR_NOT_FINALIZED;
   if (!q || !v || !tau || !params || !(params->dt > 0.0)) return QPC_ERR_INVALID_ARGUMENT;
-  if (c->prog.dims.nv > 63) return QPC_ERR_UNSUPPORTED;
   const QpcDims &D = c->prog.dims;
   EmuState emu;
   g_emu = &emu;
   for (int64_t b = 0; b < B; b++) {
-    emu.reset(qpc_sim_layout(D).total);
-    qpc::qpc_sim_prologue<Lds>(D, c->prog.itab.data(), Lds{0});
+    emu.reset((qpc_sim_layout(D).total > D.lds_doubles ? qpc_sim_layout(D).total : D.lds_doubles) + 128 * 8); // + reduction scratch
     qpc::SimIO io;
     io.q = q + b * D.nq; io.v = v + b * D.nv; io.tau = tau + b * D.nv; io.status = status ? status + b : nullptr;
     io.q_out = q + b * D.nq; io.v_out = v + b * D.nv; io.bad = bad ? bad + b : nullptr;
