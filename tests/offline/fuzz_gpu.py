@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Offline fuzzing on the GPU: tests/test_fuzz_controllers.build over many seeds, HIP path vs oracle.
-python tools/fuzz_gpu.py [first_seed=1000] [count=200]   (QPC_DISABLE_JIT=1 for the generic kernel: no compile time)"""
+python tests/offline/fuzz_gpu.py [first_seed=1000] [count=200]   (QPC_DISABLE_JIT=1 for the generic kernel: no compile time)"""
 import collections
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import qpc_pkg  # noqa: E402

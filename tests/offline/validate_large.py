@@ -3,7 +3,7 @@
 CPU time).  N seeded Atlas states per config, the oracle ticks spread over worker processes; every
 disagreement is classified with the independent KKT certificate (tests/kkt_check.py).
 
-    python tools/validate_large.py [N=4096] [configs=3,5]
+    python tests/offline/validate_large.py [N=4096] [configs=3,5]
 """
 import json
 import os
@@ -12,7 +12,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Every scenario of tests/scenarios.py that takes a batch size, at a larger B than the test-suite
-uses, HIP path vs oracle (tests/parity.py rules).  python tools/validate_scenarios.py [B=256]"""
+uses, HIP path vs oracle (tests/parity.py rules).  python tests/offline/validate_scenarios.py [B=256]"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import qpc_pkg  # noqa: E402
