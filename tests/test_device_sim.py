@@ -325,3 +325,18 @@ def test_sim_energy_drift_emulated():
 def test_sim_physics_gpu():
     check_newton_euler(gpu_factory)
     check_energy_drift(gpu_factory)
+
+
+@pytest.mark.gpu
+def test_rollout_equals_sequential_calls_large_batch_gpu():
+    """a rollout over a batch larger than the resident grid equals the one-call-per-kernel sequence bit for bit"""
+    B, steps = 8192 + 3, 3
+    mech, low, ctrl, q, v, ground, _ = standing(None, B)
+    r = low.simulate((q, v), steps, ground)
+    qs, vs = q.copy(), v.copy()
+    bad = np.zeros(B, dtype=np.int32)
+    for _ in range(steps):
+        tau = ctrl(None, 0.0, (qs, vs), throw_on_failure=False)
+        qs, vs, bad = low._c.sim_step(qs, vs, tau, ground.params(1e-3), status=low.status, bad=bad)
+    assert np.array_equal(r["q"], qs) and np.array_equal(r["v"], vs) and np.array_equal(r["bad"], bad)
+    assert np.array_equal(r["tau"], tau)
