@@ -244,6 +244,11 @@ def main():
         elapsed = float(t.item())
     st = status.cpu().numpy()
     it = iters.cpu().numpy() % 1000
+    fp64_measured = ctypes.c_double(0.0)  # vector-fp64 FMA peak measured on this box, outside the timed region
+    if rank == 0 and hasattr(L, "qpc_debug_measure_fp64_peak"):
+        L.qpc_debug_measure_fp64_peak.argtypes = [ctypes.c_int32, ctypes.POINTER(ctypes.c_double)]
+        if L.qpc_debug_measure_fp64_peak(local_rank, ctypes.byref(fp64_measured)) != 0:
+            fp64_measured = ctypes.c_double(0.0)
     n_opt = int((st == 0).sum())
 
     host_rate = None
@@ -289,7 +294,10 @@ def main():
                          "fp64": {"achieved_tflops": ALG_FLOPS_PER_SOLVE * B / kern_s / 1e12 if kern_s > 0 else 0.0,
                                   "peak_tflops": FP64_PEAK / 1e12,
                                   "frac": (ALG_FLOPS_PER_SOLVE * B / kern_s) / FP64_PEAK if kern_s > 0 else 0.0,
-                                  "algorithmic_flops_per_solve": ALG_FLOPS_PER_SOLVE}},
+                                  "algorithmic_flops_per_solve": ALG_FLOPS_PER_SOLVE,
+                                  "peak_measured_tflops": fp64_measured.value or None,
+                                  "frac_of_measured_peak": ((ALG_FLOPS_PER_SOLVE * B / kern_s) / (fp64_measured.value * 1e12)
+                                                            if kern_s > 0 and fp64_measured.value > 0 else None)}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

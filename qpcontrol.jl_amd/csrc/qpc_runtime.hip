@@ -599,6 +599,48 @@ int32_t qpc_rollout_batch(qpc_controller *c, int64_t B, int64_t n_steps, double 
   return rollout_host(c, B, n_steps, true, q, v, desired, cw, cmax, tw, surf, params, tau, status, bad);
 }
 
+// Measured vector-fp64 FMA peak of the device (SURVEY.md 8d asks for a measured peak beside the datasheet's 78.6 TFLOP/s):
+// every lane runs 16 independent v_fma_f64 chains, enough waves to fill every SIMD; flops = 2 per FMA.
+extern "C" __global__ void __launch_bounds__(256) qpc_fp64_peak_kernel(double *out, int iters, double a, double b) {
+  double x[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) x[k] = a + 1e-3 * k + 1e-6 * threadIdx.x;
+  for (int i = 0; i < iters; i++) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = fma(x[k], a, b);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) s += x[k];
+  if (s == 123.456) out[0] = s; // never true: keeps the chains alive
+}
+
+int32_t qpc_debug_measure_fp64_peak(int32_t device_id, double *tflops) {
+  if (!tflops) return QPC_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+  double *out = nullptr;
+  HIP_TRY(hipMalloc(&out, sizeof(double)));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+  const int blocks = prop.multiProcessorCount * 8, iters = 20000;
+  double best = 0.0;
+  for (int rep = 0; rep < 4; rep++) {
+    HIP_TRY(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(qpc_fp64_peak_kernel, dim3(blocks), dim3(256), 0, 0, out, iters, 0.999999, 1e-7);
+    HIP_TRY(hipEventRecord(e1, 0));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    const double fl = 2.0 * 16.0 * (double)iters * 256.0 * (double)blocks;
+    if (rep > 0 && ms > 0.f && fl / (ms * 1e-3) > best) best = fl / (ms * 1e-3);
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(out);
+  *tflops = best / 1e12;
+  return QPC_OK;
+}
+
 // diagnostic (QPC_STAMPS builds): device buffer of B*PS_COUNT uint64 section cycle counters
 int32_t qpc_debug_set_profile_buffer(qpc_controller *c, void *device_buffer) {
   if (!c || !c->dev) return QPC_ERR_NOT_FINALIZED;
