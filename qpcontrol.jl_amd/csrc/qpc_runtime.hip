@@ -534,7 +534,7 @@ int32_t qpc_rollout_batch_device(qpc_controller *c, int64_t B, int64_t n_steps, 
   return QPC_OK;
 }
 
-// host-pointer variants: one device slab, synchronous
+// host-pointer variants: one device slab, synchronous.  tick = false: one simulation step with the caller's tau / status.
 static int rollout_host(qpc_controller *c, int64_t B, int64_t n_steps, bool tick, double *q, double *v, const double *desired,
                         const double *cw, const double *cmax, const double *tw, const double *surf, const qpc_sim_params *params,
                         double *tau, int32_t *status, int32_t *bad) {
@@ -542,35 +542,38 @@ static int rollout_host(qpc_controller *c, int64_t B, int64_t n_steps, bool tick
   QpcDeviceState *S = c->dev;
   if (B == 0) return QPC_OK;
   HIP_TRY(hipSetDevice(S->device));
-  const size_t nd[9] = {(size_t)D.nq, (size_t)D.nv, (size_t)D.nv, (size_t)D.nv, desired ? (size_t)D.n_desired : 0,
-                        (size_t)D.nc, (size_t)D.nc, (size_t)D.n_tw, (size_t)D.n_surf}; // q v tau vdot desired cw cmax tw surf
+  enum { A_Q, A_V, A_TAU, A_VDOT, A_DES, A_CW, A_CMAX, A_TW, A_SURF, A_COUNT };
+  const size_t dim[A_COUNT] = {(size_t)D.nq, (size_t)D.nv, (size_t)D.nv, (size_t)D.nv, desired ? (size_t)D.n_desired : 0,
+                               (size_t)D.nc, (size_t)D.nc, (size_t)D.n_tw, (size_t)D.n_surf};
+  const double *host_in[A_COUNT] = {q, v, tick ? nullptr : tau, nullptr, desired, cw, cmax, tw, surf};
+  auto padded = [&](int i) { return ((dim[i] * B * sizeof(double)) + 63) & ~(size_t)63; };
   size_t total = 2 * (size_t)B * sizeof(int32_t) + 256;
-  for (int i = 0; i < 9; i++) total += ((nd[i] * B * sizeof(double)) + 63) & ~(size_t)63;
+  for (int i = 0; i < A_COUNT; i++) total += padded(i);
   char *buf = nullptr;
   if (hipMalloc(&buf, total) != hipSuccess) { qpc_set_error("rollout: out of device memory"); return QPC_ERR_OUT_OF_MEMORY; }
   int rc = QPC_OK;
   auto chk = [&](hipError_t e, const char *w) { if (e != hipSuccess && rc == QPC_OK) rc = hip_fail(e, w); };
   char *p = buf;
-  double *d[9];
-  for (int i = 0; i < 9; i++) { d[i] = (double *)p; p += ((nd[i] * B * sizeof(double)) + 63) & ~(size_t)63; }
+  double *dev[A_COUNT];
+  for (int i = 0; i < A_COUNT; i++) { dev[i] = (double *)p; p += padded(i); }
   int32_t *dstatus = (int32_t *)p, *dbad = dstatus + B;
-  const double *hin[9] = {q, v, tick ? nullptr : tau, nullptr, desired, cw, cmax, tw, surf};
-  for (int i = 0; i < 9; i++)
-    if (hin[i] && nd[i]) chk(hipMemcpyAsync(d[i], hin[i], nd[i] * B * sizeof(double), hipMemcpyHostToDevice, S->stream), "copy inputs");
+  for (int i = 0; i < A_COUNT; i++)
+    if (host_in[i] && dim[i])
+      chk(hipMemcpyAsync(dev[i], host_in[i], dim[i] * B * sizeof(double), hipMemcpyHostToDevice, S->stream), "copy inputs");
   if (!tick && status) chk(hipMemcpyAsync(dstatus, status, B * sizeof(int32_t), hipMemcpyHostToDevice, S->stream), "copy status");
   if (bad) chk(hipMemcpyAsync(dbad, bad, B * sizeof(int32_t), hipMemcpyHostToDevice, S->stream), "copy bad");
   else chk(hipMemsetAsync(dbad, 0, B * sizeof(int32_t), S->stream), "clear bad");
   if (rc == QPC_OK) {
     if (tick)
-      rc = qpc_rollout_batch_device(c, B, n_steps, d[0], d[1], desired ? d[4] : nullptr, d[5], d[6], d[7], d[8], params, d[2],
-                                    d[3], dstatus, dbad, S->stream);
+      rc = qpc_rollout_batch_device(c, B, n_steps, dev[A_Q], dev[A_V], desired ? dev[A_DES] : nullptr, dev[A_CW], dev[A_CMAX],
+                                    dev[A_TW], dev[A_SURF], params, dev[A_TAU], dev[A_VDOT], dstatus, dbad, S->stream);
     else
-      rc = qpc_sim_step_batch_device(c, B, d[0], d[1], d[2], status ? dstatus : nullptr, params, dbad, S->stream);
+      rc = qpc_sim_step_batch_device(c, B, dev[A_Q], dev[A_V], dev[A_TAU], status ? dstatus : nullptr, params, dbad, S->stream);
   }
   if (rc == QPC_OK) {
-    chk(hipMemcpyAsync(q, d[0], nd[0] * B * sizeof(double), hipMemcpyDeviceToHost, S->stream), "copy q");
-    chk(hipMemcpyAsync(v, d[1], nd[1] * B * sizeof(double), hipMemcpyDeviceToHost, S->stream), "copy v");
-    if (tick && tau) chk(hipMemcpyAsync(tau, d[2], nd[2] * B * sizeof(double), hipMemcpyDeviceToHost, S->stream), "copy tau");
+    chk(hipMemcpyAsync(q, dev[A_Q], dim[A_Q] * B * sizeof(double), hipMemcpyDeviceToHost, S->stream), "copy q");
+    chk(hipMemcpyAsync(v, dev[A_V], dim[A_V] * B * sizeof(double), hipMemcpyDeviceToHost, S->stream), "copy v");
+    if (tick && tau) chk(hipMemcpyAsync(tau, dev[A_TAU], dim[A_TAU] * B * sizeof(double), hipMemcpyDeviceToHost, S->stream), "copy tau");
     if (tick && status) chk(hipMemcpyAsync(status, dstatus, B * sizeof(int32_t), hipMemcpyDeviceToHost, S->stream), "copy status");
     if (bad) chk(hipMemcpyAsync(bad, dbad, B * sizeof(int32_t), hipMemcpyDeviceToHost, S->stream), "copy bad");
   }
