@@ -1527,6 +1527,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
     for (int pd = 0; pd < D.max_pdas; pd++) {
       const double gscale = 1.0 + S.last_gmax, tolb = D.tol_bound * (1.0 + S.last_xmax); // U is current (rho_solve)
       double rchg = 0.0, rup = 0.0;
+      unsigned long long bchg = 0ull, bup = 0ull;
       QPC_PHASE(lane) {
         double changed = 0.0, up = 0.0;
         for (int j = lane; j < nrho; j += 64) {
@@ -1539,11 +1540,13 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
           if (nw_ != w) { sm[D.lds[L_WS] + j] = nw_; changed = 1.0; }
           if (nw_ == 1.0) up = 1.0;
         }
-        QPC_RED_MAX_PUT(0, rchg, changed);
-        QPC_RED_MAX_PUT(1, rup, up);
+        QPC_BALLOT_PUT(0, bchg, changed != 0.0); // flags: one compare each instead of a 6-step max reduction
+        QPC_BALLOT_PUT(1, bup, up != 0.0);
       } QPC_END_PHASE
-      rchg = QPC_RED_MAX_GET(0, rchg);
-      rup = QPC_RED_MAX_GET(1, rup);
+      QPC_BALLOT_GET(0, bchg);
+      QPC_BALLOT_GET(1, bup);
+      rchg = bchg ? 1.0 : 0.0;
+      rup = bup ? 1.0 : 0.0;
       QPC_PROF_ACC(PS_S_TEST);
       if (!(rchg > 0.0)) break;
       any_upper = rup > 0.0;
@@ -1592,7 +1595,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       // most negative multiplier / most violated bound (lane-parallel + wave argmin)
       double ubad = 0.0, vneg = 0.0, rnan = 0.0;
       int jbad = -1, pviol = -1;
-      unsigned long long lo_now = 0ull, up_now = 0ull;
+      unsigned long long lo_now = 0ull, up_now = 0ull, bnan = 0ull;
       QPC_PHASE(lane) {
         double bu = 1e300, bv = 1e300, bad = 0.0;
         int ju = 0x3fffffff, jv = 0x3fffffff;
@@ -1605,14 +1608,15 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
         }
         QPC_RED_ARGMIN_PUT(0, ubad, jbad, bu, ju);
         QPC_RED_ARGMIN_PUT(1, vneg, pviol, bv, jv);
-        QPC_RED_MAX_PUT(2, rnan, bad);
+        QPC_BALLOT_PUT(2, bnan, bad != 0.0);
         const double wl_ = lane < nrho ? (double)sm[D.lds[L_WS] + (lane < nrho ? lane : 0)] : 0.0;
         QPC_BALLOT_PUT(3, lo_now, wl_ == -1.0);
         QPC_BALLOT_PUT(4, up_now, wl_ == 1.0);
       } QPC_END_PHASE
       QPC_RED_ARGMIN_GET(0, ubad, jbad);
       QPC_RED_ARGMIN_GET(1, vneg, pviol);
-      rnan = QPC_RED_MAX_GET(2, rnan);
+      QPC_BALLOT_GET(2, bnan);
+      rnan = bnan ? 1.0 : 0.0;
       QPC_BALLOT_GET(3, lo_now);
       QPC_BALLOT_GET(4, up_now);
       if (track_b) {
@@ -1700,6 +1704,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       else refine = S.eqp(D.max_refine);
       S.residuals();
       double arp = 0.0, ars = 0.0, asp = 0.0, ass = 0.0, anan = 0.0, abv = 0.0, agm = 0.0, axm = 0.0;
+      unsigned long long bbad = 0ull, bchanged = 0ull;
       QPC_PHASE(lane) {
         double rp = 0.0, rs = 0.0, sp = 0.0, ss = 0.0, bv = 0.0, gm = 0.0, xm = 0.0;
         for (int r = lane; r < m; r += 64) {
@@ -1726,11 +1731,11 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
         }
         double bad = (!(rp == rp) || !(rs == rs)) ? 1.0 : 0.0;
         QPC_RED_MAX_PUT(0, arp, rp == rp ? rp : 0.0); QPC_RED_MAX_PUT(1, ars, rs == rs ? rs : 0.0);
-        QPC_RED_MAX_PUT(2, asp, sp); QPC_RED_MAX_PUT(3, ass, ss); QPC_RED_MAX_PUT(4, anan, bad);
+        QPC_RED_MAX_PUT(2, asp, sp); QPC_RED_MAX_PUT(3, ass, ss); QPC_BALLOT_PUT(4, bbad, bad != 0.0);
         QPC_RED_MAX_PUT(5, agm, gm); QPC_RED_MAX_PUT(6, axm, xm);
       } QPC_END_PHASE
       arp = QPC_RED_MAX_GET(0, arp); ars = QPC_RED_MAX_GET(1, ars); asp = QPC_RED_MAX_GET(2, asp);
-      ass = QPC_RED_MAX_GET(3, ass); anan = QPC_RED_MAX_GET(4, anan);
+      ass = QPC_RED_MAX_GET(3, ass); QPC_BALLOT_GET(4, bbad); anan = bbad ? 1.0 : 0.0;
       agm = QPC_RED_MAX_GET(5, agm); axm = QPC_RED_MAX_GET(6, axm);
       const bool nan = anan > 0.0;
       double r_prim = arp / (1.0 + asp), r_stat = ars / (1.0 + ass);
@@ -1753,9 +1758,10 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
           else if (x > hi + tolb) nw_ = 1.0;
           if (nw_ != w) { changed = 1.0; if (outer < 8) sm[D.lds[L_WS] + j] = nw_; }
         }
-        QPC_RED_MAX_PUT(0, abv, changed);
+        QPC_BALLOT_PUT(0, bchanged, changed != 0.0);
       } QPC_END_PHASE
-      abv = QPC_RED_MAX_GET(0, abv);
+      QPC_BALLOT_GET(0, bchanged);
+      abv = bchanged ? 1.0 : 0.0;
       if (!(abv > 0.0)) break;
       if (outer >= 8) { status = QPC_STATUS_ITERATION_LIMIT; break; }
       status = QPC_STATUS_OPTIMAL;
