@@ -62,6 +62,21 @@ __device__ __forceinline__ double wave_max(double x) {
 #undef QPC_DPP_OP
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 63), __builtin_amdgcn_readlane(__double2loint(x), 63));
 }
+// Maximum of NON-NEGATIVE doubles to 20 mantissa bits: the bit pattern of a non-negative double orders like an
+// unsigned integer, so the maximum of the HIGH words (one v_mov_dpp + one v_max_u32 per step instead of two moves and a
+// v_max_f64) is the true maximum rounded down by at most 2^-20 relative.  Every max reduction of the tick is a SCALE of
+// a tolerance or a stopping test, for which that is exact enough; arg-min reductions stay exact (wave_min).
+__device__ __forceinline__ double wave_max_scale(double x) {
+  unsigned h = (unsigned)__double2hiint(x) & 0x7fffffffu; // callers pass magnitudes; a stray sign bit must not win
+#define QPC_DPP_OP(ctrl, rmask)                                                                    \
+  {                                                                                                \
+    const unsigned t__ = (unsigned)__builtin_amdgcn_update_dpp((int)h, (int)h, ctrl, rmask, 0xf, false); \
+    h = t__ > h ? t__ : h;                                                                         \
+  }
+  QPC_DPP_STEPS(QPC_DPP_OP)
+#undef QPC_DPP_OP
+  return __hiloint2double(__builtin_amdgcn_readlane((int)h, 63), 0);
+}
 __device__ __forceinline__ double wave_min(double x) {
 #define QPC_DPP_OP(ctrl, rmask)                                                                    \
   {                                                                                                \
@@ -89,7 +104,7 @@ __device__ __forceinline__ int wave_min_int(int x) {
 
 // reductions that straddle a phase boundary: *_PUT inside the phase (every lane, exactly once),
 // *_GET after QPC_END_PHASE.  `name` is a double (and `iname` an int) declared before the phase.
-#define QPC_RED_MAX_PUT(slot, name, val) name = qpc::wave_max(val)
+#define QPC_RED_MAX_PUT(slot, name, val) name = qpc::wave_max_scale(val)
 #define QPC_RED_MAX_GET(slot, name) (name)
 
 #define QPC_RED_ARGMIN_PUT(slot, name, iname, val, idx) \

@@ -88,7 +88,15 @@ static thread_local double emu_mfma_a[64], emu_mfma_b[64];
 // reductions across a phase boundary: lane-serial form through the (emulator-only) scratch that
 // follows the kernel's LDS slab
 #define QPC_RED_MAX_PUT(slot, name, val) sm[D.lds_doubles + 128 * (slot) + lane] = (val)
-#define QPC_RED_MAX_GET(slot, name) qpc::umax(sm, D.lds_doubles + 128 * (slot), 64)
+// like the device (qpc_device.h wave_max_scale): maximum of non-negative values, low mantissa word dropped
+static inline double emu_scale_trunc(double x) {
+  unsigned long long b;
+  std::memcpy(&b, &x, 8);
+  b &= 0x7fffffff00000000ull;
+  std::memcpy(&x, &b, 8);
+  return x;
+}
+#define QPC_RED_MAX_GET(slot, name) emu_scale_trunc(qpc::umax(sm, D.lds_doubles + 128 * (slot), 64))
 #define QPC_BALLOT_PUT(slot, name, pred) sm[D.lds_doubles + 128 * (slot) + lane] = (pred) ? 1.0 : 0.0
 #define QPC_BALLOT_GET(slot, name) \
   do { name = 0ull; for (int l__ = 0; l__ < 64; l__++) if ((double)sm[D.lds_doubles + 128 * (slot) + l__] != 0.0) name |= 1ull << l__; } while (0)
