@@ -114,6 +114,29 @@ __device__ __forceinline__ int wave_min_int(int x) {
 #define QPC_BALLOT_PUT(slot, name, pred) name = __ballot((pred) ? 1 : 0)
 #define QPC_BALLOT_GET(slot, name) ((void)0)
 
+// OUT4[i] = XEXPR evaluated in lane 4 * (lane / 4) + i, i = 0..3: DPP quad_perm broadcasts (no LDS).  Must be executed
+// by all 64 lanes (phase level, like the MFMA macro below).
+__device__ __forceinline__ double qpc_quad_bcast(double x, int i) {
+  const int lo = __double2loint(x), hi = __double2hiint(x);
+  int l, h;
+  switch (i) { // quad_perm:[i,i,i,i] = i * 0x55
+    case 0: l = __builtin_amdgcn_update_dpp(lo, lo, 0x00, 0xf, 0xf, false); h = __builtin_amdgcn_update_dpp(hi, hi, 0x00, 0xf, 0xf, false); break;
+    case 1: l = __builtin_amdgcn_update_dpp(lo, lo, 0x55, 0xf, 0xf, false); h = __builtin_amdgcn_update_dpp(hi, hi, 0x55, 0xf, 0xf, false); break;
+    case 2: l = __builtin_amdgcn_update_dpp(lo, lo, 0xaa, 0xf, 0xf, false); h = __builtin_amdgcn_update_dpp(hi, hi, 0xaa, 0xf, 0xf, false); break;
+    default: l = __builtin_amdgcn_update_dpp(lo, lo, 0xff, 0xf, 0xf, false); h = __builtin_amdgcn_update_dpp(hi, hi, 0xff, 0xf, 0xf, false); break;
+  }
+  return __hiloint2double(h, l);
+}
+#define QPC_QUAD_GATHER(lane, OUT4, XEXPR)                                                        \
+  {                                                                                              \
+    const int lane = (int)(threadIdx.x & 63);                                                    \
+    (void)lane;                                                                                  \
+    double *out__ = (OUT4);                                                                      \
+    const double x__ = (XEXPR);                                                                  \
+    out__[0] = qpc_quad_bcast(x__, 0); out__[1] = qpc_quad_bcast(x__, 1);                        \
+    out__[2] = qpc_quad_bcast(x__, 2); out__[3] = qpc_quad_bcast(x__, 3);                        \
+  }
+
 // fp64 matrix core: acc(16x16 tile, 4 f64 per lane) += A(16x4) * B(4x16) with v_mfma_f64_16x16x4_f64.
 //   lane l supplies A[i = l&15][k = l>>4] (AEXPR) and B[k = l>>4][j = l&15] (BEXPR);
 //   acc[r] is C[row = (l>>4) + 4 r][col = l&15]  (the f64-specific C/D map, cdna_hip_programming.md 3)

@@ -580,6 +580,54 @@ template <class P> struct Solver {
     const int N = D.N, nrho = D.nrho, m1 = D.m1;
     const int outr = base ? D.lds[L_XR] : D.lds[L_DR], outl = (base ? D.lds[L_LAM] : D.lds[L_DL]) + m1;
     double rg = 0.0, rx = 0.0, rd = 0.0;
+    if (N == 4 && nrho <= 64) {
+      // N = 4: the four rays of a contact sit in the four lanes of a quad, so each lane computes ITS (G' lam_w)_j and
+      // ITS rho_j only and takes the other three from its quad with DPP quad_perm moves -- a quarter of the dot products
+      // and LDS reads of the general form below, same operations in the same order (bit-identical results)
+      QPC_LANE_ARRAY(q4_, 10); // [0..3] w of the quad, [4..7] rho of the quad, [8] own value in flight, [9] (G' lam_w)_j
+      QPC_PHASE(lane) {
+        double *q = QPC_LA(q4_, lane);
+        const int j = lane < nrho ? lane : 0;
+        double wj = dotp(sm + D.lds[L_G] + j, nrho, sm + outl, 1, 6);
+        q[9] = wj;
+        if (need_kr) wj += sm[D.lds[L_RR] + j];
+        q[8] = wj;
+      } QPC_END_PHASE
+      QPC_QUAD_GATHER(lane, QPC_LA(q4_, lane), QPC_LA(q4_, lane)[8])
+      QPC_PHASE(lane) {
+        double *q = QPC_LA(q4_, lane);
+        const int j = lane < nrho ? lane : 0;
+        double acc = 0.0;
+        for (int i = 0; i < 4; i++) acc += sm[D.lds[L_KR] + 4 * j + i] * q[i]; // row jj of K_c: KR[c][jj][i] at 16 c + 4 jj + i
+        if (base && sm[D.lds[L_WS] + j] == 1.0) acc += sm[D.lds[L_HI] + j];
+        q[8] = acc;
+      } QPC_END_PHASE
+      QPC_QUAD_GATHER(lane, QPC_LA(q4_, lane) + 4, QPC_LA(q4_, lane)[8])
+      QPC_PHASE(lane) {
+        const double *q = QPC_LA(q4_, lane);
+        double g = 0.0, xm = 0.0, dm = 0.0;
+        if (lane < nrho) {
+          const int j = lane;
+          const double rho_j = q[8];
+          if (prox) dm = QPC_FABS(rho_j - (double)sm[outr + j]);
+          sm[outr + j] = rho_j;
+          if (base) {
+            double gl = -q[9];
+            for (int i = 0; i < 4; i++) gl += sm[D.lds[L_HR] + 4 * j + i] * q[4 + i];
+            const double wsj = sm[D.lds[L_WS] + j];
+            sm[D.lds[L_U] + j] = (wsj == -1.0) ? gl : ((wsj == 1.0) ? -gl : 0.0);
+            g = QPC_FABS(gl);
+            xm = QPC_FABS(rho_j);
+          }
+        }
+        if (base) { QPC_RED_MAX_PUT(0, rg, g); QPC_RED_MAX_PUT(1, rx, xm); }
+        if (prox) { QPC_RED_MAX_PUT(2, rd, dm); }
+      } QPC_END_PHASE
+      if (base) { last_gmax = QPC_RED_MAX_GET(0, rg); last_xmax = QPC_RED_MAX_GET(1, rx); }
+      if (prox) last_dmax = QPC_RED_MAX_GET(2, rd);
+      QPC_PROF_ACC(section);
+      return;
+    }
     QPC_PHASE(lane) { // rho_F = K (r_r + G' lam_w) (+ rho_fix); each lane rebuilds its contact's N rho's,
                       // and in base mode also its multiplier u_j = +-(H_rho rho - G' lam_w)_j
       double g = 0.0, xm = 0.0, dm = 0.0;

@@ -85,6 +85,11 @@ static thread_local double emu_mfma_a[64], emu_mfma_b[64];
       for (int k__ = 0; k__ < 4; k__++) acc__[r__] += emu_mfma_a[row__ + 16 * k__] * emu_mfma_b[col__ + 16 * k__]; \
     }                                                                                                     \
   } QPC_END_PHASE
+// lane-serial model of the DPP quad broadcasts: publish, then gather from the quad
+static thread_local double emu_quad[64];
+#define QPC_QUAD_GATHER(lane, OUT4, XEXPR)                                                    \
+  QPC_PHASE(lane) { emu_quad[lane] = (XEXPR); } QPC_END_PHASE                                  \
+  QPC_PHASE(lane) { double *o__ = (OUT4); for (int i__ = 0; i__ < 4; i__++) o__[i__] = emu_quad[(lane & ~3) + i__]; } QPC_END_PHASE
 // reductions across a phase boundary: lane-serial form through the (emulator-only) scratch that
 // follows the kernel's LDS slab
 #define QPC_RED_MAX_PUT(slot, name, val) sm[D.lds_doubles + 128 * (slot) + lane] = (val)
