@@ -678,7 +678,30 @@ template <class P> struct Solver {
     QPC_PROF_ACC(PS_LOGIC);
     const bool need_kr = !base || any_upper || prox;
     const double eps_prox = prox ? (double)sm[D.lds[L_MISC] + MS_EPS] : 0.0;
-    if (need_kr) {
+    if (need_kr && base && N == 4 && nrho <= 64) {
+      // quad form (see rho_back): each lane its own r_r(j), the other three of the contact through DPP
+      QPC_LANE_ARRAY(r4_, 5); // [0..3] r_r of the quad, [4] own
+      QPC_PHASE(lane) {
+        const int j = lane < nrho ? lane : 0;
+        const double wsj = sm[D.lds[L_WS] + j];
+        double rr = (wsj == 0.0) ? -dot_fix(D.lds[L_HR] + 4 * j, 1, 4 * (j / 4), 4) : 0.0;
+        // proximal sweep: the eps of K = (H_FF + eps I)^-1 is compensated by eps * rho_prev
+        if (prox && wsj == 0.0) rr += eps_prox * sm[D.lds[L_XR] + j];
+        if (lane < nrho) sm[D.lds[L_RR] + j] = rr;
+        QPC_LA(r4_, lane)[4] = rr;
+      } QPC_END_PHASE
+      QPC_QUAD_GATHER(lane, QPC_LA(r4_, lane), QPC_LA(r4_, lane)[4])
+      QPC_PHASE(lane) {
+        if (lane < nrho) {
+          const int j = lane;
+          const double *r4 = QPC_LA(r4_, lane);
+          const double fix = (sm[D.lds[L_WS] + j] == 1.0) ? (double)sm[D.lds[L_HI] + j] : 0.0;
+          double acc = 0.0;
+          for (int i = 0; i < 4; i++) acc += sm[D.lds[L_KR] + 4 * j + i] * r4[i];
+          sm[D.lds[L_TR1] + j] = acc + fix;
+        }
+      } QPC_END_PHASE
+    } else if (need_kr) {
       QPC_PHASE(lane) { // TR1 = K r_r + rho_fix ; RR kept for the back-substitution
         for (int j = lane; j < nrho; j += 64) {
           int c = j / N, jj = j % N;
