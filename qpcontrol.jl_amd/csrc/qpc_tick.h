@@ -740,30 +740,6 @@ template <class P> struct Solver {
     QPC_PROF_ACC(PS_KKT);
   }
 
-  // multipliers of the bound constraints: u = +-(H_rho rho - G' lam_w) on the working set -> L_U;
-  // returns max |gradient| and max |rho| (uniform) for the tolerances
-  QPC_FN void multipliers(double &gmax, double &xmax) {
-    const int nrho = D.nrho, N = D.N, m1 = D.m1;
-    double rg = 0.0, rx = 0.0;
-    QPC_PHASE(lane) {
-      double g = 0.0, x = 0.0;
-      for (int j = lane; j < nrho; j += 64) {
-        int c = j / N, jj = j % N;
-        double gl = dotp(sm + D.lds[L_HR] + c * N * N + jj * N, 1, sm + D.lds[L_XR] + c * N, 1, N) -
-                    dotp(sm + D.lds[L_G] + j, nrho, sm + D.lds[L_LAM] + m1, 1, 6);
-        double w = sm[D.lds[L_WS] + j];
-        sm[D.lds[L_U] + j] = (w == -1.0) ? gl : ((w == 1.0) ? -gl : 0.0);
-        g = QPC_FABS(gl) > g ? QPC_FABS(gl) : g;
-        double xr = QPC_FABS(sm[D.lds[L_XR] + j]);
-        x = xr > x ? xr : x;
-      }
-      QPC_RED_MAX_PUT(0, rg, g);
-      QPC_RED_MAX_PUT(1, rx, x);
-    } QPC_END_PHASE
-    gmax = QPC_RED_MAX_GET(0, rg);
-    xmax = QPC_RED_MAX_GET(1, rx);
-  }
-
   // c = E H^-1 (-g) - d -> L_T1 (all rows), with -sqh .* g as a by-product in L_XV
   QPC_FN void compute_c() {
     const int nf = D.nf, m = D.m;
