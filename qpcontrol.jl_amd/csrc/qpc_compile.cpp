@@ -426,7 +426,7 @@ int qpc_compile_program(qpc_controller *c) {
   L(L_CR, nb * 6);
   const int a_kin_end = off;
   off = a_base;
-  L(L_M, mm * D.nfs); L(L_G, 6 * nrho); L(L_HR, D.nc * N * N); L(L_HI, nrho); L(L_WS, nrho);
+  L(L_M, mm * D.nfs); L(L_G, 6 * QPC_GS(nrho)); L(L_HR, D.nc * N * N); L(L_HI, nrho); L(L_WS, nrho);
   if (a_kin_end > off) off = a_kin_end;
   // ---- region B
   const int b_base = off;

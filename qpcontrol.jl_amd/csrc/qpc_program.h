@@ -95,6 +95,11 @@ enum {
   L_COUNT
 };
 
+// Row stride of G (6 x nrho, L_G): nrho is typically a multiple of 32 doubles, which would put the six rows -- read
+// side by side by the lanes (a, b) of the S22 build and by the wrench-row mat-vecs -- on the same LDS banks; two extra
+// doubles per row shift each row by four banks and keep 16-byte alignment
+#define QPC_GS(nrho) (((nrho) % 4 == 0) ? (nrho) + 2 : (nrho))
+
 // slots inside L_MISC
 enum {
   MS_COM = 0,      // 3

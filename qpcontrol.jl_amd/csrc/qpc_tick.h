@@ -322,7 +322,7 @@ template <class P> struct Solver {
       QPC_PHASE(lane) {
         for (int idx = lane; idx < nrho * 6; idx += 64) {
           int j = idx / 6, b = idx % 6, c = j / N, jj = j % N;
-          sm[D.lds[L_Y] + j * 6 + b] = dotp(sm + D.lds[L_KR] + c * N * N + jj * N, 1, sm + D.lds[L_G] + b * nrho + c * N, 1, N);
+          sm[D.lds[L_Y] + j * 6 + b] = dotp(sm + D.lds[L_KR] + c * N * N + jj * N, 1, sm + D.lds[L_G] + b * QPC_GS(nrho) + c * N, 1, N);
         }
       } QPC_END_PHASE
     }
@@ -330,7 +330,7 @@ template <class P> struct Solver {
       if (lane < 36) {
         int a = lane / 6, b = lane % 6;
         double acc = sm[D.lds[L_B22] + lane];
-        if (use_rho) acc += dotp(sm + D.lds[L_G] + a * nrho, 1, sm + D.lds[L_Y] + b, 6, nrho);
+        if (use_rho) acc += dotp(sm + D.lds[L_G] + a * QPC_GS(nrho), 1, sm + D.lds[L_Y] + b, 6, nrho);
         sm[D.lds[L_C22] + lane] = acc; // S22 = B22 + G Kr G'
       }
     } QPC_END_PHASE
@@ -366,14 +366,14 @@ template <class P> struct Solver {
     QPC_PHASE(lane) {
       for (int idx = lane; idx < nrho * 6; idx += 64) {
         int j = idx / 6, b = idx % 6, c = j / N, jj = j % N;
-        sm[D.lds[L_Y] + j * 6 + b] = dotp(sm + D.lds[L_KR] + c * N * N + jj * N, 1, sm + D.lds[L_G] + b * nrho + c * N, 1, N);
+        sm[D.lds[L_Y] + j * 6 + b] = dotp(sm + D.lds[L_KR] + c * N * N + jj * N, 1, sm + D.lds[L_G] + b * QPC_GS(nrho) + c * N, 1, N);
       }
     } QPC_END_PHASE
     QPC_PROF_ACC(PS_S_Y);
     QPC_PHASE(lane) {
       if (lane < 36) {
         int a = lane / 6, b = lane % 6;
-        sm[D.lds[L_C22] + lane] = sm[D.lds[L_B22] + lane] + dotp(sm + D.lds[L_G] + a * nrho, 1, sm + D.lds[L_Y] + b, 6, nrho);
+        sm[D.lds[L_C22] + lane] = sm[D.lds[L_B22] + lane] + dotp(sm + D.lds[L_G] + a * QPC_GS(nrho), 1, sm + D.lds[L_Y] + b, 6, nrho);
       }
     } QPC_END_PHASE
     QPC_PROF_ACC(PS_S_C22);
@@ -441,7 +441,7 @@ template <class P> struct Solver {
           int sl = row_slack(r);
           if (sl >= 0) acc -= sm[D.lds[L_TE1] + sl];
         } else if (use_rho) {
-          acc -= dotp(sm + D.lds[L_G] + (r - m1) * nrho, 1, sm + D.lds[L_TR1], 1, nrho);
+          acc -= dotp(sm + D.lds[L_G] + (r - m1) * QPC_GS(nrho), 1, sm + D.lds[L_TR1], 1, nrho);
         }
         sm[D.lds[L_T1] + r] = acc;
       }
@@ -453,7 +453,7 @@ template <class P> struct Solver {
       for (int s = lane; s < ne; s += 64) sm[D.lds[L_TE1] + s] = sm[D.lds[L_RE] + s] + sm[D.lds[L_DL] + slack_row(s)];
       if (use_rho)
         for (int j = lane; j < nrho; j += 64)
-          sm[D.lds[L_TR2] + j] = sm[D.lds[L_RR] + j] + dotp(sm + D.lds[L_G] + j, nrho, sm + D.lds[L_DL] + m1, 1, 6);
+          sm[D.lds[L_TR2] + j] = sm[D.lds[L_RR] + j] + dotp(sm + D.lds[L_G] + j, QPC_GS(nrho), sm + D.lds[L_DL] + m1, 1, 6);
     } QPC_END_PHASE
     QPC_PHASE(lane) {
       for (int s = lane; s < ne; s += 64) {
@@ -481,7 +481,7 @@ template <class P> struct Solver {
           int sl = row_slack(r);
           if (sl >= 0) acc += sm[D.lds[L_XE] + sl];
         } else if (use_rho) {
-          acc += dotp(sm + D.lds[L_G] + (r - m1) * nrho, 1, sm + D.lds[L_XR], 1, nrho);
+          acc += dotp(sm + D.lds[L_G] + (r - m1) * QPC_GS(nrho), 1, sm + D.lds[L_XR], 1, nrho);
         }
         sm[D.lds[L_RC] + r] = acc;
       }
@@ -500,7 +500,7 @@ template <class P> struct Solver {
         for (int j = lane; j < nrho; j += 64) {
           int c = j / N, jj = j % N;
           double gl = dotp(sm + D.lds[L_HR] + c * N * N + jj * N, 1, sm + D.lds[L_XR] + c * N, 1, N) -
-                      dotp(sm + D.lds[L_G] + j, nrho, sm + D.lds[L_LAM] + m1, 1, 6);
+                      dotp(sm + D.lds[L_G] + j, QPC_GS(nrho), sm + D.lds[L_LAM] + m1, 1, 6);
           sm[D.lds[L_TR1] + j] = gl;
           sm[D.lds[L_RR] + j] = (sm[D.lds[L_WS] + j] == 0.0) ? -gl : 0.0;
         }
@@ -588,7 +588,7 @@ template <class P> struct Solver {
       QPC_PHASE(lane) {
         double *q = QPC_LA(q4_, lane);
         const int j = lane < nrho ? lane : 0;
-        double wj = dotp(sm + D.lds[L_G] + j, nrho, sm + outl, 1, 6);
+        double wj = dotp(sm + D.lds[L_G] + j, QPC_GS(nrho), sm + outl, 1, 6);
         q[9] = wj;
         if (need_kr) wj += sm[D.lds[L_RR] + j];
         q[8] = wj;
@@ -635,7 +635,7 @@ template <class P> struct Solver {
         int c = j / N, jj = j % N;
         double w[8], rho_c[8];
         for (int i = 0; i < N; i++) {
-          w[i] = dotp(sm + D.lds[L_G] + c * N + i, nrho, sm + outl, 1, 6);
+          w[i] = dotp(sm + D.lds[L_G] + c * N + i, QPC_GS(nrho), sm + outl, 1, 6);
           if (i == jj) g = w[i]; // (G' lam_w)_j, reused below
           if (need_kr) w[i] += sm[D.lds[L_RR] + c * N + i];
         }
@@ -728,7 +728,7 @@ template <class P> struct Solver {
       QPC_PHASE(lane) { // u = u0 - G (K r_r + rho_fix)   (temporary in L_C22[0..5])
         if (lane < 6) {
           double u = base ? (double)sm[D.lds[L_MISC] + MS_U0 + lane] : 0.0;
-          u -= dotp(sm + D.lds[L_G] + lane * nrho, 1, sm + D.lds[L_TR1], 1, nrho);
+          u -= dotp(sm + D.lds[L_G] + lane * QPC_GS(nrho), 1, sm + D.lds[L_TR1], 1, nrho);
           sm[D.lds[L_C22] + lane] = u;
         }
       } QPC_END_PHASE
@@ -809,7 +809,7 @@ template <class P> struct Solver {
       for (int s = lane; s < ne; s += 64) sm[D.lds[L_RE] + s] = 0.0;
       for (int r = lane; r < m; r += 64) {
         double acc = sm[D.lds[L_D] + r];
-        if (r >= m1 && use_rho) acc += dot_fix(D.lds[L_G] + (r - m1) * nrho, 1, 0, nrho);
+        if (r >= m1 && use_rho) acc += dot_fix(D.lds[L_G] + (r - m1) * QPC_GS(nrho), 1, 0, nrho);
         sm[D.lds[L_RC] + r] = acc;
       }
       for (int j = lane; j < nrho; j += 64) {
@@ -1367,7 +1367,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
         double bi[3] = {mu * cs * inv, mu * sn * inv, inv}, lin[3], ang[3];
         mv3(Rc, bi, lin);
         cross3(pc, lin, ang);
-        for (int a = 0; a < 3; a++) { sm[D.lds[L_G] + a * nrho + j] = ang[a]; sm[D.lds[L_G] + (3 + a) * nrho + j] = lin[a]; }
+        for (int a = 0; a < 3; a++) { sm[D.lds[L_G] + a * QPC_GS(nrho) + j] = ang[a]; sm[D.lds[L_G] + (3 + a) * QPC_GS(nrho) + j] = lin[a]; }
         double cw = sm[D.lds[L_CW] + c];
 #ifdef QPC_BASIS_TABLE
         QPC_UNROLL_FULL
@@ -1704,7 +1704,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
             if (w != 0.0 && sm[D.lds[L_HI] + j] > 0.0) {
               double hz = eps * sm[D.lds[L_DR] + j];
               for (int i = 0; i < N; i++) hz += sm[D.lds[L_HR] + c * N * N + jj * N + i] * sm[D.lds[L_DR] + c * N + i];
-              for (int a = 0; a < 6; a++) hz -= sm[D.lds[L_G] + a * nrho + j] * sm[D.lds[L_DL] + m1 + a];
+              for (int a = 0; a < 6; a++) hz -= sm[D.lds[L_G] + a * QPC_GS(nrho) + j] * sm[D.lds[L_DL] + m1 + a];
               rj = (w == -1.0) ? -hz : hz;
               if (rj > 1e-300) { double ratio = sm[D.lds[L_U] + j] / rj; if (ratio < best) { best = ratio; bestj = (double)j; } }
             }
@@ -1826,7 +1826,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
     for (int idx = lane; idx < nc * 6; idx += 64) { // value(wrench_world) = G_c rho_c
       int c = idx / 6, a = idx % 6;
       double acc = 0.0;
-      if (use_rho) for (int i = 0; i < N; i++) acc += sm[D.lds[L_G] + a * nrho + c * N + i] * sm[D.lds[L_XR] + c * N + i];
+      if (use_rho) for (int i = 0; i < N; i++) acc += sm[D.lds[L_G] + a * QPC_GS(nrho) + c * N + i] * sm[D.lds[L_XR] + c * N + i];
       sm[D.lds[L_CWR] + idx] = acc;
     }
     if (lane < nb) {
