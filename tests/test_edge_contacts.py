@@ -18,11 +18,19 @@ def ora_factory(mech, n_basis, floating):
     return O.OracleController(O.OracleModel(mech), n_basis, floating)
 
 
-def make(factory, n_basis=4, mu=None, one_foot=False, B=4, seed=5):
+def make(factory, n_basis=4, mu=None, one_foot=False, B=4, seed=5, dense=False):
     mech = M.atlas()
     if mu is not None:
         for cp in mech.contact_points:
             cp.mu = mu
+    if dense:  # 16 contact points x 4 rays = 64 rho: every lane of the wavefront is a ray (the quad paths at full width)
+        import copy
+        extra = []
+        for cp in mech.contact_points:
+            e = copy.deepcopy(cp)
+            e.position = np.array(cp.position) * np.array([0.5, 0.6, 1.0])
+            extra.append(e)
+        mech.contact_points = list(mech.contact_points) + extra
     if one_foot:
         lf = mech.findbody("l_foot")
         mech.contact_points = [cp for cp in mech.contact_points if cp.body == lf]
@@ -33,12 +41,12 @@ def make(factory, n_basis=4, mu=None, one_foot=False, B=4, seed=5):
     q, v = W.standing_states(mech, B, seed, dq=0.05, drot=0.02, vstd=0.05)
     des = W.standing_desired(st, q, v)
     nc = len(st.contact_ids)
-    return SC.Case(f"edge_N{n_basis}_mu{mu}_{'one' if one_foot else 'two'}", mech, c, q, v, des, np.full((B, nc), 1e-3),
+    return SC.Case(f"edge_N{n_basis}_mu{mu}_{'one' if one_foot else 'two'}{'_dense' if dense else ''}", mech, c, q, v, des, np.full((B, nc), 1e-3),
                    np.full((B, nc), 1e6), floating=floating, n_basis=n_basis)
 
 
 CASES = [dict(n_basis=3), dict(n_basis=6), dict(n_basis=8), dict(mu=0.0), dict(mu=1e-3), dict(one_foot=True),
-         dict(n_basis=5, one_foot=True)]
+         dict(n_basis=5, one_foot=True), dict(dense=True)]
 
 
 def _run(factory, kw):
