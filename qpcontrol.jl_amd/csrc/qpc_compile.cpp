@@ -459,7 +459,7 @@ int qpc_compile_program(qpc_controller *c) {
   const int vec_end = off;
   D.lds[L_X] = xbase;
   D.lds[L_Y] = xbase; // Y lives only inside refactor_rho, when the rhs/direction vectors are dead
-  { int xe = xbase + even(m1 * D.m1s), ye = xbase + even(nrho * 6); off = vec_end; if (xe > off) off = xe; if (ye > off) off = ye; }
+  { int xe = xbase + even(m1 * D.m1s), ye = xbase + even(QPC_GS(nrho) * 6); off = vec_end; if (xe > off) off = xe; if (ye > off) off = ye; }
   D.lds[L_RED] = off; // unused on the device (wave reductions); the emulator has its own scratch
   if (early_end > off) off = early_end;
   D.lds_doubles = off;

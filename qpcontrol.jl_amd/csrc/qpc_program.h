@@ -76,7 +76,7 @@ enum {
   L_X2,                  // m1 * 6  Z = S11^-1 S12
   L_B22, L_C22, L_L22, L_S22I, // 36 each
   L_G,                   // 6 * nrho
-  L_Y,                   // nrho * 6
+  L_Y,                   // 6 x nrho, (K G')' with G's padded row stride QPC_GS(nrho)
   L_HR, L_KR,            // nc * N * N
   L_HI, L_WS, L_U,       // nrho
   L_XV, L_XE, L_XR, L_LAM, // iterate

@@ -322,7 +322,7 @@ template <class P> struct Solver {
       QPC_PHASE(lane) {
         for (int idx = lane; idx < nrho * 6; idx += 64) {
           int j = idx / 6, b = idx % 6, c = j / N, jj = j % N;
-          sm[D.lds[L_Y] + j * 6 + b] = dotp(sm + D.lds[L_KR] + c * N * N + jj * N, 1, sm + D.lds[L_G] + b * QPC_GS(nrho) + c * N, 1, N);
+          sm[D.lds[L_Y] + b * QPC_GS(nrho) + j] = dotp(sm + D.lds[L_KR] + c * N * N + jj * N, 1, sm + D.lds[L_G] + b * QPC_GS(nrho) + c * N, 1, N);
         }
       } QPC_END_PHASE
     }
@@ -330,7 +330,7 @@ template <class P> struct Solver {
       if (lane < 36) {
         int a = lane / 6, b = lane % 6;
         double acc = sm[D.lds[L_B22] + lane];
-        if (use_rho) acc += dotp(sm + D.lds[L_G] + a * QPC_GS(nrho), 1, sm + D.lds[L_Y] + b, 6, nrho);
+        if (use_rho) acc += dotp(sm + D.lds[L_G] + a * QPC_GS(nrho), 1, sm + D.lds[L_Y] + b * QPC_GS(nrho), 1, nrho);
         sm[D.lds[L_C22] + lane] = acc; // S22 = B22 + G Kr G'
       }
     } QPC_END_PHASE
@@ -366,14 +366,14 @@ template <class P> struct Solver {
     QPC_PHASE(lane) {
       for (int idx = lane; idx < nrho * 6; idx += 64) {
         int j = idx / 6, b = idx % 6, c = j / N, jj = j % N;
-        sm[D.lds[L_Y] + j * 6 + b] = dotp(sm + D.lds[L_KR] + c * N * N + jj * N, 1, sm + D.lds[L_G] + b * QPC_GS(nrho) + c * N, 1, N);
+        sm[D.lds[L_Y] + b * QPC_GS(nrho) + j] = dotp(sm + D.lds[L_KR] + c * N * N + jj * N, 1, sm + D.lds[L_G] + b * QPC_GS(nrho) + c * N, 1, N);
       }
     } QPC_END_PHASE
     QPC_PROF_ACC(PS_S_Y);
     QPC_PHASE(lane) {
       if (lane < 36) {
         int a = lane / 6, b = lane % 6;
-        sm[D.lds[L_C22] + lane] = sm[D.lds[L_B22] + lane] + dotp(sm + D.lds[L_G] + a * QPC_GS(nrho), 1, sm + D.lds[L_Y] + b, 6, nrho);
+        sm[D.lds[L_C22] + lane] = sm[D.lds[L_B22] + lane] + dotp(sm + D.lds[L_G] + a * QPC_GS(nrho), 1, sm + D.lds[L_Y] + b * QPC_GS(nrho), 1, nrho);
       }
     } QPC_END_PHASE
     QPC_PROF_ACC(PS_S_C22);
