@@ -216,43 +216,46 @@ template <int NB, class P> QPC_FN void kr_block(P sm, const QpcDims &D, int c, d
       if (i < N && j < N) sm[D.lds[L_KR] + c * N * N + i * N + j] = (fr[i] && fr[j]) ? a[i][j] : 0.0;
 }
 
-// x = S^-1 rhs for a symmetric 6x6 S: Cholesky in registers then forward/back substitution (with
+// x = S^-1 rhs for a symmetric 6x6 S: square-root-free LDL' in registers then forward/back substitution (with
 // rhs = e_c this is column c of S^-1: 6 lanes, one column each, one phase).  A pivot
 // below tau * sref[k] marks a redundant row: zero row/column in T (infinite-pivot rule).
+// (LDL' instead of Cholesky: a reciprocal per pivot instead of a reciprocal square root -- 5 dependent instructions
+// instead of 9 on the serial chain -- and no scaling of the off-diagonal entries by 1/L_kk.)
 template <class P> QPC_FN void chol6_solve(P Sin, const double *sref, double tau, const double *rhs, double *x) {
-  double L[6][6], invd[6], y[6];
+  double L[6][6], U[6][6], invd[6], y[6]; // L unit lower triangular, U[i][k] = L[i][k] d_k
   QPC_UNROLL_FULL
   for (int i = 0; i < 6; i++)
     QPC_UNROLL_FULL
-    for (int j = 0; j < 6; j++) L[i][j] = (j <= i) ? (double)Sin[i * 6 + j] : 0.0;
+    for (int j = 0; j < 6; j++) { L[i][j] = 0.0; U[i][j] = (j <= i) ? (double)Sin[i * 6 + j] : 0.0; }
   QPC_UNROLL_FULL
   for (int k = 0; k < 6; k++) {
-    double d = L[k][k];
+    double d = U[k][k];
     QPC_UNROLL_FULL
-    for (int j = 0; j < k; j++) d -= L[k][j] * L[k][j];
-    bool ok = d > tau * (sref[k] > 1e-300 ? sref[k] : 1e-300);
-    invd[k] = ok ? QPC_RSQRT(d) : 0.0; // 1 / L_kk
+    for (int j = 0; j < k; j++) d -= U[k][j] * L[k][j];
+    const bool ok = d > tau * (sref[k] > 1e-300 ? sref[k] : 1e-300);
+    invd[k] = ok ? QPC_RCP(d) : 0.0; // 1 / d_k
     QPC_UNROLL_FULL
     for (int i = k + 1; i < 6; i++) {
-      double t = L[i][k];
+      double t = U[i][k];
       QPC_UNROLL_FULL
-      for (int j = 0; j < k; j++) t -= L[i][j] * L[k][j];
+      for (int j = 0; j < k; j++) t -= U[i][j] * L[k][j];
+      U[i][k] = t;
       L[i][k] = t * invd[k];
     }
   }
   QPC_UNROLL_FULL
-  for (int r = 0; r < 6; r++) {
+  for (int r = 0; r < 6; r++) { // L y = rhs
     double t = rhs[r];
     QPC_UNROLL_FULL
     for (int j = 0; j < r; j++) t -= L[r][j] * y[j];
-    y[r] = t * invd[r];
+    y[r] = t;
   }
   QPC_UNROLL_FULL
-  for (int r = 5; r >= 0; r--) {
-    double t = y[r];
+  for (int r = 5; r >= 0; r--) { // L' x = D^-1 y
+    double t = y[r] * invd[r];
     QPC_UNROLL_FULL
     for (int j = r + 1; j < 6; j++) t -= L[j][r] * x[j];
-    x[r] = t * invd[r];
+    x[r] = t;
   }
 }
 
