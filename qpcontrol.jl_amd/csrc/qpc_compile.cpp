@@ -426,7 +426,7 @@ int qpc_compile_program(qpc_controller *c) {
   L(L_CR, nb * 6);
   const int a_kin_end = off;
   off = a_base;
-  L(L_M, mm * D.nfs); L(L_G, 6 * QPC_GS(nrho)); L(L_HR, D.nc * N * N); L(L_HI, nrho); L(L_WS, nrho);
+  L(L_M, mm * D.nfs); L(L_G, 6 * QPC_GS(nrho)); L(L_HR, D.nc * QPC_CSH(N)); L(L_HI, nrho); L(L_WS, nrho);
   if (a_kin_end > off) off = a_kin_end;
   // ---- region B
   const int b_base = off;
@@ -449,7 +449,7 @@ int qpc_compile_program(qpc_controller *c) {
   { int late_end = D.lds[L_SVK] + even(nv * 6); if (late_end > off) off = late_end; }
   L(L_X2, m1 * 6); L(L_B22, 36); L(L_C22, 36); L(L_S22I, 36);
   D.lds[L_L22] = D.lds[L_C22]; // retired
-  L(L_KR, D.nc * N * N); L(L_T1, mm); D.lds[L_T2] = D.lds[L_T1]; D.lds[L_T3] = D.lds[L_T1]; // T2/T3 retired
+  L(L_KR, D.nc * QPC_CS(N)); L(L_T1, mm); D.lds[L_T2] = D.lds[L_T1]; D.lds[L_T3] = D.lds[L_T1]; // T2/T3 retired
   L(L_XV, D.nf); L(L_XE, ne); L(L_XR, nrho); L(L_LAM, mm); L(L_U, nrho); L(L_WSP, nrho);
   const int xbase = off;
   // X (explicit L11^-1) is dead before the first iterate vector is written

@@ -100,6 +100,12 @@ enum {
 // doubles per row shift each row by four banks and keep 16-byte alignment
 #define QPC_GS(nrho) (((nrho) % 4 == 0) ? (nrho) + 2 : (nrho))
 
+// Per-contact stride of the N x N blocks H_rho / K (L_HR, L_KR): 16 doubles = 128 B is exactly one sweep over the LDS
+// banks, so the lanes that work one contact each (kr_block) would all hit the same banks; two doubles of padding
+#define QPC_CS(N) ((((N) * (N)) % 16 == 0) ? (N) * (N) + 2 : (N) * (N))
+
+#define QPC_CSH(N) ((N) * (N)) // H_rho keeps the dense stride (no LDS left to pad it too: the slab must stay <= 20 480 B)
+
 // slots inside L_MISC
 enum {
   MS_COM = 0,      // 3

@@ -191,7 +191,7 @@ template <int NB, class P> QPC_FN void kr_block(P sm, const QpcDims &D, int c, d
   for (int i = 0; i < NB; i++)
 #pragma unroll
     for (int j = 0; j < NB; j++) {
-      double h = (i < N && j < N) ? (double)sm[D.lds[L_HR] + c * N * N + (i < N ? i : 0) * N + (j < N ? j : 0)] : 0.0;
+      double h = (i < N && j < N) ? (double)sm[D.lds[L_HR] + c * QPC_CSH(N) + (i < N ? i : 0) * N + (j < N ? j : 0)] : 0.0;
       a[i][j] = (fr[i] && fr[j]) ? h + (i == j ? eps : 0.0) : (i == j ? 1.0 : 0.0);
     }
 #pragma unroll
@@ -213,7 +213,7 @@ template <int NB, class P> QPC_FN void kr_block(P sm, const QpcDims &D, int c, d
   for (int i = 0; i < NB; i++)
 #pragma unroll
     for (int j = 0; j < NB; j++)
-      if (i < N && j < N) sm[D.lds[L_KR] + c * N * N + i * N + j] = (fr[i] && fr[j]) ? a[i][j] : 0.0;
+      if (i < N && j < N) sm[D.lds[L_KR] + c * QPC_CS(N) + i * N + j] = (fr[i] && fr[j]) ? a[i][j] : 0.0;
 }
 
 // x = S^-1 rhs for a symmetric 6x6 S: square-root-free LDL' in registers then forward/back substitution (with
@@ -325,7 +325,7 @@ template <class P> struct Solver {
       QPC_PHASE(lane) {
         for (int idx = lane; idx < nrho * 6; idx += 64) {
           int j = idx / 6, b = idx % 6, c = j / N, jj = j % N;
-          sm[D.lds[L_Y] + b * QPC_GS(nrho) + j] = dotp(sm + D.lds[L_KR] + c * N * N + jj * N, 1, sm + D.lds[L_G] + b * QPC_GS(nrho) + c * N, 1, N);
+          sm[D.lds[L_Y] + b * QPC_GS(nrho) + j] = dotp(sm + D.lds[L_KR] + c * QPC_CS(N) + jj * N, 1, sm + D.lds[L_G] + b * QPC_GS(nrho) + c * N, 1, N);
         }
       } QPC_END_PHASE
     }
@@ -369,7 +369,7 @@ template <class P> struct Solver {
     QPC_PHASE(lane) {
       for (int idx = lane; idx < nrho * 6; idx += 64) {
         int j = idx / 6, b = idx % 6, c = j / N, jj = j % N;
-        sm[D.lds[L_Y] + b * QPC_GS(nrho) + j] = dotp(sm + D.lds[L_KR] + c * N * N + jj * N, 1, sm + D.lds[L_G] + b * QPC_GS(nrho) + c * N, 1, N);
+        sm[D.lds[L_Y] + b * QPC_GS(nrho) + j] = dotp(sm + D.lds[L_KR] + c * QPC_CS(N) + jj * N, 1, sm + D.lds[L_G] + b * QPC_GS(nrho) + c * N, 1, N);
       }
     } QPC_END_PHASE
     QPC_PROF_ACC(PS_S_Y);
@@ -429,7 +429,7 @@ template <class P> struct Solver {
       if (use_rho)
         for (int j = lane; j < nrho; j += 64) {
           int c = j / N, jj = j % N;
-          sm[D.lds[L_TR1] + j] = dotp(sm + D.lds[L_KR] + c * N * N + jj * N, 1, sm + D.lds[L_RR] + c * N, 1, N);
+          sm[D.lds[L_TR1] + j] = dotp(sm + D.lds[L_KR] + c * QPC_CS(N) + jj * N, 1, sm + D.lds[L_RR] + c * N, 1, N);
         }
       for (int s = lane; s < ne; s += 64) {
         int d = slack_dim(s), wr = slack_woff(s), s0 = slack_s0(s);
@@ -466,7 +466,7 @@ template <class P> struct Solver {
       if (use_rho)
         for (int j = lane; j < nrho; j += 64) {
           int c = j / N, jj = j % N;
-          sm[D.lds[L_DR] + j] = dotp(sm + D.lds[L_KR] + c * N * N + jj * N, 1, sm + D.lds[L_TR2] + c * N, 1, N);
+          sm[D.lds[L_DR] + j] = dotp(sm + D.lds[L_KR] + c * QPC_CS(N) + jj * N, 1, sm + D.lds[L_TR2] + c * N, 1, N);
         }
     } QPC_END_PHASE
     QPC_PROF_ACC(PS_KKT);
@@ -502,7 +502,7 @@ template <class P> struct Solver {
       if (use_rho)
         for (int j = lane; j < nrho; j += 64) {
           int c = j / N, jj = j % N;
-          double gl = dotp(sm + D.lds[L_HR] + c * N * N + jj * N, 1, sm + D.lds[L_XR] + c * N, 1, N) -
+          double gl = dotp(sm + D.lds[L_HR] + c * QPC_CSH(N) + jj * N, 1, sm + D.lds[L_XR] + c * N, 1, N) -
                       dotp(sm + D.lds[L_G] + j, QPC_GS(nrho), sm + D.lds[L_LAM] + m1, 1, 6);
           sm[D.lds[L_TR1] + j] = gl;
           sm[D.lds[L_RR] + j] = (sm[D.lds[L_WS] + j] == 0.0) ? -gl : 0.0;
@@ -601,7 +601,7 @@ template <class P> struct Solver {
         double *q = QPC_LA(q4_, lane);
         const int j = lane < nrho ? lane : 0;
         double acc = 0.0;
-        for (int i = 0; i < 4; i++) acc += sm[D.lds[L_KR] + 4 * j + i] * q[i]; // row jj of K_c: KR[c][jj][i] at 16 c + 4 jj + i
+        for (int i = 0; i < 4; i++) acc += sm[D.lds[L_KR] + QPC_CS(4) * (j / 4) + 4 * (j % 4) + i] * q[i]; // row jj of K_c: KR[c][jj][i] at 16 c + 4 jj + i
         if (base && sm[D.lds[L_WS] + j] == 1.0) acc += sm[D.lds[L_HI] + j];
         q[8] = acc;
       } QPC_END_PHASE
@@ -616,7 +616,7 @@ template <class P> struct Solver {
           sm[outr + j] = rho_j;
           if (base) {
             double gl = -q[9];
-            for (int i = 0; i < 4; i++) gl += sm[D.lds[L_HR] + 4 * j + i] * q[4 + i];
+            for (int i = 0; i < 4; i++) gl += sm[D.lds[L_HR] + QPC_CSH(4) * (j / 4) + 4 * (j % 4) + i] * q[4 + i];
             const double wsj = sm[D.lds[L_WS] + j];
             sm[D.lds[L_U] + j] = (wsj == -1.0) ? gl : ((wsj == 1.0) ? -gl : 0.0);
             g = QPC_FABS(gl);
@@ -644,7 +644,7 @@ template <class P> struct Solver {
         }
         for (int i2 = 0; i2 < N; i2++) {
           double acc = 0.0;
-          for (int i = 0; i < N; i++) acc += sm[D.lds[L_KR] + c * N * N + i2 * N + i] * w[i];
+          for (int i = 0; i < N; i++) acc += sm[D.lds[L_KR] + c * QPC_CS(N) + i2 * N + i] * w[i];
           if (base && sm[D.lds[L_WS] + c * N + i2] == 1.0) acc += sm[D.lds[L_HI] + c * N + i2];
           rho_c[i2] = acc;
         }
@@ -652,7 +652,7 @@ template <class P> struct Solver {
         sm[outr + j] = rho_c[jj];
         if (base) {
           double gl = -g;
-          for (int i = 0; i < N; i++) gl += sm[D.lds[L_HR] + c * N * N + jj * N + i] * rho_c[i];
+          for (int i = 0; i < N; i++) gl += sm[D.lds[L_HR] + c * QPC_CSH(N) + jj * N + i] * rho_c[i];
           double wsj = sm[D.lds[L_WS] + j];
           sm[D.lds[L_U] + j] = (wsj == -1.0) ? gl : ((wsj == 1.0) ? -gl : 0.0);
           g = QPC_FABS(gl);
@@ -687,7 +687,7 @@ template <class P> struct Solver {
       QPC_PHASE(lane) {
         const int j = lane < nrho ? lane : 0;
         const double wsj = sm[D.lds[L_WS] + j];
-        double rr = (wsj == 0.0) ? -dot_fix(D.lds[L_HR] + 4 * j, 1, 4 * (j / 4), 4) : 0.0;
+        double rr = (wsj == 0.0) ? -dot_fix(D.lds[L_HR] + QPC_CSH(4) * (j / 4) + 4 * (j % 4), 1, 4 * (j / 4), 4) : 0.0;
         // proximal sweep: the eps of K = (H_FF + eps I)^-1 is compensated by eps * rho_prev
         if (prox && wsj == 0.0) rr += eps_prox * sm[D.lds[L_XR] + j];
         if (lane < nrho) sm[D.lds[L_RR] + j] = rr;
@@ -700,7 +700,7 @@ template <class P> struct Solver {
           const double *r4 = QPC_LA(r4_, lane);
           const double fix = (sm[D.lds[L_WS] + j] == 1.0) ? (double)sm[D.lds[L_HI] + j] : 0.0;
           double acc = 0.0;
-          for (int i = 0; i < 4; i++) acc += sm[D.lds[L_KR] + 4 * j + i] * r4[i];
+          for (int i = 0; i < 4; i++) acc += sm[D.lds[L_KR] + QPC_CS(4) * (j / 4) + 4 * (j % 4) + i] * r4[i];
           sm[D.lds[L_TR1] + j] = acc + fix;
         }
       } QPC_END_PHASE
@@ -713,14 +713,14 @@ template <class P> struct Solver {
             fix = (sm[D.lds[L_WS] + j] == 1.0) ? (double)sm[D.lds[L_HI] + j] : 0.0;
             // r_r(i) = -(H rho_fix)_i on free i ;  acc = sum_i K[jj][i] r_r(i)
             for (int i = 0; i < N; i++) {
-              double rr = (sm[D.lds[L_WS] + c * N + i] == 0.0) ? -dot_fix(D.lds[L_HR] + c * N * N + i * N, 1, c * N, N) : 0.0;
+              double rr = (sm[D.lds[L_WS] + c * N + i] == 0.0) ? -dot_fix(D.lds[L_HR] + c * QPC_CSH(N) + i * N, 1, c * N, N) : 0.0;
               // proximal sweep: the eps of K = (H_FF + eps I)^-1 is compensated by eps * rho_prev
               if (prox && sm[D.lds[L_WS] + c * N + i] == 0.0) rr += eps_prox * sm[D.lds[L_XR] + c * N + i];
-              acc += sm[D.lds[L_KR] + c * N * N + jj * N + i] * rr;
+              acc += sm[D.lds[L_KR] + c * QPC_CS(N) + jj * N + i] * rr;
               if (i == jj) sm[D.lds[L_RR] + j] = rr;
             }
           } else {
-            acc = (p / N == c) ? nsign * sm[D.lds[L_KR] + c * N * N + jj * N + (p % N)] : 0.0;
+            acc = (p / N == c) ? nsign * sm[D.lds[L_KR] + c * QPC_CS(N) + jj * N + (p % N)] : 0.0;
             sm[D.lds[L_RR] + j] = (j == p) ? nsign : 0.0;
           }
           sm[D.lds[L_TR1] + j] = acc + fix;
@@ -818,7 +818,7 @@ template <class P> struct Solver {
       for (int j = lane; j < nrho; j += 64) {
         int c = j / N, jj = j % N;
         double acc = 0.0;
-        if (sm[D.lds[L_WS] + j] == 0.0) acc = -dot_fix(D.lds[L_HR] + c * N * N + jj * N, 1, c * N, N);
+        if (sm[D.lds[L_WS] + j] == 0.0) acc = -dot_fix(D.lds[L_HR] + c * QPC_CSH(N) + jj * N, 1, c * N, N);
         sm[D.lds[L_RR] + j] = acc;
       }
     } QPC_END_PHASE
@@ -1378,7 +1378,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
           if (i2 < N) {
             const double c2 = kb_[2 * i2], s2 = kb_[2 * i2 + 1];
             double dot = (mu * cs * mu * c2 + mu * sn * mu * s2 + 1.0) * inv * inv;
-            sm[D.lds[L_HR] + c * N * N + i * N + i2] = 2.0 * cw * dot;
+            sm[D.lds[L_HR] + c * QPC_CSH(N) + i * N + i2] = 2.0 * cw * dot;
           }
         }
 #else
@@ -1386,7 +1386,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
           double s2, c2;
           QPC_SINCOS(i2 * (6.283185307179586 / N), s2, c2);
           double dot = (mu * cs * mu * c2 + mu * sn * mu * s2 + 1.0) * inv * inv;
-          sm[D.lds[L_HR] + c * N * N + i * N + i2] = 2.0 * cw * dot;
+          sm[D.lds[L_HR] + c * QPC_CSH(N) + i * N + i2] = 2.0 * cw * dot;
         }
 #endif
         double hi = sm[D.lds[L_CMAX] + c] * inv / N; // maxrho (contacts.jl:57)
@@ -1706,7 +1706,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
             double rj = 0.0;
             if (w != 0.0 && sm[D.lds[L_HI] + j] > 0.0) {
               double hz = eps * sm[D.lds[L_DR] + j];
-              for (int i = 0; i < N; i++) hz += sm[D.lds[L_HR] + c * N * N + jj * N + i] * sm[D.lds[L_DR] + c * N + i];
+              for (int i = 0; i < N; i++) hz += sm[D.lds[L_HR] + c * QPC_CSH(N) + jj * N + i] * sm[D.lds[L_DR] + c * N + i];
               for (int a = 0; a < 6; a++) hz -= sm[D.lds[L_G] + a * QPC_GS(nrho) + j] * sm[D.lds[L_DL] + m1 + a];
               rj = (w == -1.0) ? -hz : hz;
               if (rj > 1e-300) { double ratio = sm[D.lds[L_U] + j] / rj; if (ratio < best) { best = ratio; bestj = (double)j; } }
