@@ -108,7 +108,10 @@ int qpc_compile_program(qpc_controller *c) {
   }
   D.m1 = m1; D.m = m1 + D.nw; D.ne = ne; D.wsize = wsize;
   D.nrho = (D.nw > 0) ? D.nc * N : 0; // without wrench balance the rho decouple and stay 0
-  D.nfs = odd(D.nf > 0 ? D.nf : 1); D.ms = odd(D.m > 0 ? D.m : 1); D.m1s = odd(m1 > 0 ? m1 : 1);
+  // leading dimensions of M and S: even (16-byte row starts, so a row loads as 16-byte pairs) and not a multiple of 8
+  // doubles (rows read side by side by consecutive lanes would share banks with a period of 2 or 4 lanes)
+  auto lead = [](int n) { int s = (n > 0 ? n : 1); s += s & 1; if (s % 8 == 0) s += 2; return s; };
+  D.nfs = lead(D.nf); D.ms = lead(D.m); D.m1s = odd(m1 > 0 ? m1 : 1);
 
   // ---- integer tables
   B.ibegin(IT_PARENT); for (int i = 0; i < nb; i++) B.it.push_back(m->parent[i]);

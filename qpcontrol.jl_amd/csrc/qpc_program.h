@@ -104,7 +104,7 @@ enum {
 // banks, so the lanes that work one contact each (kr_block) would all hit the same banks; two doubles of padding
 #define QPC_CS(N) ((((N) * (N)) % 16 == 0) ? (N) * (N) + 2 : (N) * (N))
 
-#define QPC_CSH(N) ((N) * (N)) // H_rho keeps the dense stride (no LDS left to pad it too: the slab must stay <= 20 480 B)
+#define QPC_CSH(N) QPC_CS(N) // H_rho blocks likewise
 
 // slots inside L_MISC
 enum {
