@@ -254,7 +254,11 @@ int qpc_compile_program(qpc_controller *c) {
           row[4] = mask[2 * vb]; row[5] = mask[2 * vb + 1];
         }
       }
-      B.ibegin(IT_META); B.it.insert(B.it.end(), meta.begin(), meta.end());
+      // stored word-major ([word][lane]): one load instruction of the wave reads 64 consecutive ints
+      std::vector<int> metat((size_t)64 * rowlen, 0);
+      for (int l = 0; l < 64; l++)
+        for (int e = 0; e < rowlen; e++) metat[(size_t)e * 64 + l] = meta[(size_t)l * rowlen + e];
+      B.ibegin(IT_META); B.it.insert(B.it.end(), metat.begin(), metat.end());
     }
     B.ibegin(IT_DESC_MASK); B.it.insert(B.it.end(), mask.begin(), mask.end());
     { // simulation step (qpc_sim.h): per body lane {children mask lo, hi, height above the leaves, depth below the
@@ -375,12 +379,17 @@ int qpc_compile_program(qpc_controller *c) {
   B.it.push_back(0); // never empty
 
   // ---- double tables
-  B.dbegin(DT_AXIS); B.dt.insert(B.dt.end(), m->axis.begin(), m->axis.end());
-  B.dbegin(DT_RF); B.dt.insert(B.dt.end(), m->Rf.begin(), m->Rf.end());
-  B.dbegin(DT_PF); B.dt.insert(B.dt.end(), m->pf.begin(), m->pf.end());
+  // per-body constants component-major ([component][body]): lane = body reads them, so one load instruction of the
+  // wave covers nb consecutive doubles instead of nb records 24 / 72 / 48 bytes apart
+  auto by_component = [&](const std::vector<double> &v, int dim) {
+    for (int k = 0; k < dim; k++) for (int i = 0; i < nb; i++) B.dt.push_back(v[(size_t)i * dim + k]);
+  };
+  B.dbegin(DT_AXIS); by_component(m->axis, 3);
+  B.dbegin(DT_RF); by_component(m->Rf, 9);
+  B.dbegin(DT_PF); by_component(m->pf, 3);
   B.dbegin(DT_MASS); B.dt.insert(B.dt.end(), m->mass.begin(), m->mass.end());
-  B.dbegin(DT_COM); B.dt.insert(B.dt.end(), m->com.begin(), m->com.end());
-  B.dbegin(DT_ICOM); B.dt.insert(B.dt.end(), m->icom.begin(), m->icom.end());
+  B.dbegin(DT_COM); by_component(m->com, 3);
+  B.dbegin(DT_ICOM); by_component(m->icom, 6);
   B.dbegin(DT_REG2); for (int k = 0; k < nv; k++) B.dt.push_back(2.0 * c->reg[k]);
   B.dbegin(DT_GRAV); for (int k = 0; k < 3; k++) B.dt.push_back(m->gravity[k]);
   B.dt.push_back(m->mtot);

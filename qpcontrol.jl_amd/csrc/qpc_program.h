@@ -36,7 +36,7 @@ enum {
                 //   int1 = first row(7) | rows(4) | free column f(7)       kind 7 = wrench-balance block
   IT_RCODE,     // [m] packed row code ; IT_R_DES [m] desired index ; IT_R_T [m] generic task ; IT_R_PINK [m]
   IT_R_DES, IT_R_T, IT_R_PINK,
-  IT_META, // [64 * (6 + (maxd + 3) / 4)] packed per-lane metadata (qpc_tick.h TickMeta): one row per lane
+  IT_META, // [(6 + (maxd + 3) / 4) * 64] packed per-lane metadata (qpc_tick.h TickMeta), word-major: [word][lane]
   IT_LAW, // [n_desired * 3] desired law of entry i: kind (QPC_LAW_*), arg0, arg1
           //   JOINT_PD: q index, v index;  COM_PD: component, -;  ORIENTATION_PD: body, component
   IT_SIM_TREE, // [(nb + 1) * 4] simulation step: per body {children mask lo, hi, height, depth}; last row {max height, max depth}
@@ -46,7 +46,8 @@ enum {
 
 // double tables
 enum {
-  DT_AXIS, DT_RF, DT_PF, DT_MASS, DT_COM, DT_ICOM, DT_REG2, DT_GRAV /*3 + mtot*/,
+  DT_AXIS, DT_RF, DT_PF, DT_MASS, DT_COM, DT_ICOM, // per-body constants, component-major: [component][body]
+  DT_REG2, DT_GRAV /*3 + mtot*/,
   DT_SJ_W,   // static weight of folded soft joint tasks
   DT_T_POINT, DT_T_W, // per generic task: point[3]; static W (dim*dim, row-major, at IT_T_WOFF)
   DT_C_POS, DT_C_NORMAL, DT_C_MU,

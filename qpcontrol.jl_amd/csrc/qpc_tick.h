@@ -926,7 +926,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
     {
       const int aw = (D.maxd + 3) / 4, rowlen = 6 + aw;
       QPC_UNROLL_JIT
-      for (int e = 0; e < QPC_META_WORDS; e++) mt[e] = e < rowlen ? IT[D.it[IT_META] + lane * rowlen + e] : 0;
+      for (int e = 0; e < QPC_META_WORDS; e++) mt[e] = e < rowlen ? IT[D.it[IT_META] + e * 64 + lane] : 0;
     }
     for (int i = lane; i < nq; i += 64) sm[D.lds[L_Q] + i] = io.q[i];
     for (int i = lane; i < nv; i += 64) {
@@ -947,7 +947,9 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       const int i = lane;
       const int *mt = QPC_LI(M.v, lane);
       const int jt = MT_JT(mt), q0 = MT_Q0(mt);
-      const double *ax = DT + D.dt[DT_AXIS] + 3 * i, *Rf = DT + D.dt[DT_RF] + 9 * i, *pf = DT + D.dt[DT_PF] + 3 * i;
+      double ax[3], Rf[9], pf[3]; // per-body constants, stored [component][body]
+      for (int k = 0; k < 3; k++) { ax[k] = DT[D.dt[DT_AXIS] + k * nb + i]; pf[k] = DT[D.dt[DT_PF] + k * nb + i]; }
+      for (int k = 0; k < 9; k++) Rf[k] = DT[D.dt[DT_RF] + k * nb + i];
       double Rj[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pj[3] = {0, 0, 0};
       if (jt == QPC_JOINT_REVOLUTE) {
         double s, c;
@@ -1000,7 +1002,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       const int jt = MT_JT(mt), v0 = MT_V0(mt), n = MT_NVJ(mt);
       double H[12], tj[6] = {0, 0, 0, 0, 0, 0};
       ld(sm + D.lds[L_H] + 12 * i, 12, H);
-      const double *ax = DT + D.dt[DT_AXIS] + 3 * i;
+      const double ax[3] = {DT[D.dt[DT_AXIS] + i], DT[D.dt[DT_AXIS] + nb + i], DT[D.dt[DT_AXIS] + 2 * nb + i]};
       for (int c = 0; c < n; c++) {
         double S[6] = {0, 0, 0, 0, 0, 0};
         if (jt == QPC_JOINT_REVOLUTE) { mv3(H, ax, S); cross3(H + 9, S, S + 3); }
@@ -1017,8 +1019,10 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       }
       st(sm + D.lds[L_TJ] + 6 * i, 6, tj);
       double cw[3];
-      const double *I = DT + D.dt[DT_ICOM] + 6 * i;
-      mv3(H, DT + D.dt[DT_COM] + 3 * i, cw);
+      double I[6], cb[3];
+      for (int k = 0; k < 6; k++) I[k] = DT[D.dt[DT_ICOM] + k * nb + i];
+      for (int k = 0; k < 3; k++) cb[k] = DT[D.dt[DT_COM] + k * nb + i];
+      mv3(H, cb, cw);
       cw[0] += H[9]; cw[1] += H[10]; cw[2] += H[11];
       double Ib[9] = {I[0], I[3], I[4], I[3], I[1], I[5], I[4], I[5], I[2]}, RI[9], Rt[9], Iw[9];
       for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) Rt[3 * a + b] = H[3 * b + a];
