@@ -162,20 +162,38 @@ template <class P> QPC_FN double umax(P sm, int off, int n) {
   return m;
 }
 
-// in-place inverse of an SPD n x n matrix (row-major, leading dimension n) by ONE lane
-template <class P> QPC_FN void spd_inverse_inplace(P a, int n) {
-  // Gauss-Jordan without pivoting (SPD): after the sweep `a` holds the inverse
-  for (int k = 0; k < n; k++) {
-    double piv = 1.0 / a[k * n + k];
-    a[k * n + k] = 1.0;
-    for (int j = 0; j < n; j++) a[k * n + j] = a[k * n + j] * piv;
-    for (int i = 0; i < n; i++) {
+// in-place inverse of an SPD n x n matrix (row-major, leading dimension n, n <= NB) by ONE lane: Gauss-Jordan without
+// pivoting in registers (identity padding up to the compile-time bound NB so that the sweep fully unrolls); the LDS
+// copy is read once and written once
+template <int NB, class P> QPC_FN void spd_inverse_small(P a, int n) {
+  double r[NB][NB];
+#pragma unroll
+  for (int i = 0; i < NB; i++)
+#pragma unroll
+    for (int j = 0; j < NB; j++) r[i][j] = (i < n && j < n) ? (double)a[(i < n ? i : 0) * n + (j < n ? j : 0)] : (i == j ? 1.0 : 0.0);
+#pragma unroll
+  for (int k = 0; k < NB; k++) {
+    const double piv = QPC_RCP(r[k][k]);
+    r[k][k] = 1.0;
+#pragma unroll
+    for (int j = 0; j < NB; j++) r[k][j] *= piv;
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
       if (i == k) continue;
-      double f = a[i * n + k];
-      a[i * n + k] = 0.0;
-      for (int j = 0; j < n; j++) a[i * n + j] = a[i * n + j] - f * a[k * n + j];
+      const double f = r[i][k];
+      r[i][k] = 0.0;
+#pragma unroll
+      for (int j = 0; j < NB; j++) r[i][j] -= f * r[k][j];
     }
   }
+#pragma unroll
+  for (int i = 0; i < NB; i++)
+#pragma unroll
+    for (int j = 0; j < NB; j++)
+      if (i < n && j < n) a[i * n + j] = r[i][j];
+}
+template <class P> QPC_FN void spd_inverse_inplace(P a, int n) {
+  if (n <= 3) spd_inverse_small<3>(a, n); else spd_inverse_small<6>(a, n);
 }
 
 
@@ -1225,7 +1243,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       cross3(com, fg, cxf);
       sm[MISC + MS_WG + lane] = lane < 3 ? cxf[lane] : fg[lane - 3];
     }
-    for (int f = lane; f < nf; f += 64) sm[D.lds[L_SQH] + f] = 1.0 / QPC_SQRT(sm[D.lds[L_HV] + f] + eps_ve);
+    for (int f = lane; f < nf; f += 64) sm[D.lds[L_SQH] + f] = QPC_RSQRT(sm[D.lds[L_HV] + f] + eps_ve);
     for (int t = lane; t < ntask; t += 64) { // (W + eps I)^-1 per soft generic task
       int w0 = IT[D.it[IT_T_WOFF] + t];
       if (w0 < 0) continue;
@@ -1348,7 +1366,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
         double nn = QPC_SQRT(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
         double w = nn + nrm[2], x, y, z = 0.0;
         if (QPC_FABS(w) < 100 * 2.220446049250313e-16) { x = 0; y = 1; } else { x = -nrm[1]; y = nrm[0]; }
-        double qn = 1.0 / QPC_SQRT(w * w + x * x + y * y);
+        double qn = QPC_RSQRT(w * w + x * x + y * y);
         w *= qn; x *= qn; y *= qn;
         double Rn[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
                         2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
@@ -1359,7 +1377,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
         mv3(H, DT + D.dt[DT_C_POS] + 3 * c, pc);
         pc[0] += H[9]; pc[1] += H[10]; pc[2] += H[11];
         // forcebasis(mu, N) (contacts.jl:16-23)
-        double sn, cs, inv = 1.0 / QPC_SQRT(mu * mu + 1.0);
+        double sn, cs, inv = QPC_RSQRT(mu * mu + 1.0);
 #ifdef QPC_BASIS_TABLE
         // JIT: cos / sin of the N basis directions are literals (computed by the host when the source is
         // generated); the lane's own pair is picked with selects instead of an fp64 sincos per use
