@@ -1153,7 +1153,13 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
     }
     if (lane >= 3 && lane < 9) {
       double acc = 0.0;
-      for (int i = 0; i < nb; i++) acc += sm[D.lds[L_HB] + 6 * i + (lane - 3)];
+      for (int i0 = 0; i0 < nb; i0 += 8) { // loads in batches of 8 ahead of the adds, like the centre-of-mass sums above
+        double x[8];
+        QPC_UNROLL_FULL
+        for (int u = 0; u < 8; u++) x[u] = sm[D.lds[L_HB] + 6 * (i0 + u < nb ? i0 + u : 0) + (lane - 3)];
+        QPC_UNROLL_FULL
+        for (int u = 0; u < 8; u++) acc += (i0 + u < nb) ? x[u] : 0.0;
+      }
       sm[MISC + MS_ADV + (lane - 3)] = acc; // Ȧv + A_pin v̇_pin
     }
     for (int f = lane; f < nf; f += 64) { // Hv = 2 reg + folded soft joint tasks (a12)
