@@ -11,6 +11,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <sstream>
+#include <string>
+#include <vector>
 
 #include "qpc_embedded.inc"
 
@@ -113,8 +115,14 @@ int qpc_jit_compile(const QpcDims &D, const std::string &arch, std::vector<char>
     return -1;
   }
   std::string archopt = "--offload-arch=" + arch;
-  const char *opts[] = {archopt.c_str(), "-O3", "-std=c++17"};
-  hiprtcResult r = hiprtcCompileProgram(prog, 3, opts);
+  std::vector<std::string> extra; // QPC_JIT_EXTRA_FLAGS="-mllvm -foo ...": compiler experiments without a rebuild
+  if (const char *e = getenv("QPC_JIT_EXTRA_FLAGS")) {
+    std::istringstream is(e);
+    for (std::string tok; is >> tok;) extra.push_back(tok);
+  }
+  std::vector<const char *> opts = {archopt.c_str(), "-O3", "-std=c++17"};
+  for (auto &x : extra) opts.push_back(x.c_str());
+  hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
   size_t ls = 0;
   hiprtcGetProgramLogSize(prog, &ls);
   log.assign(ls, ' ');
