@@ -1664,8 +1664,12 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
     //      iteration is cycling on rounding noise (seen on infeasible single-contact QPs, which used to
     //      burn all max_active_set_iters): recognised from the bit masks of the last 8 working sets.
     const bool track_b = nrho <= 64; // one rho per lane: two ballots ARE the working set
-    unsigned long long lo_h[8], up_h[8];
-    for (int h = 0; h < 8; h++) { lo_h[h] = ~0ull; up_h[h] = ~0ull; }
+    QPC_LANE_INTS(hist_, 4); // lane h < 8 remembers one of the last 8 working sets: lo / up masks as 2 x 2 ints (four VGPRs
+                             // instead of 32 scalar registers of wave-uniform history)
+    QPC_PHASE(lane) {
+      int *hs = QPC_LI(hist_, lane);
+      hs[0] = hs[1] = hs[2] = hs[3] = -1;
+    } QPC_END_PHASE
     int hpos = 0;
     while (true) {
       if (iters > D.max_as_iters) { status = QPC_STATUS_ITERATION_LIMIT; break; }
@@ -1698,11 +1702,17 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       QPC_BALLOT_GET(3, lo_now);
       QPC_BALLOT_GET(4, up_now);
       if (track_b) {
-        bool seen = false;
-        if (iters >= 10) // ordinary QPs are done long before: only the stragglers pay for the comparisons
-          for (int h = 0; h < 8; h++) seen = seen || (lo_h[h] == lo_now && up_h[h] == up_now);
-        if (seen) { status = QPC_STATUS_ITERATION_LIMIT; break; }
-        lo_h[hpos] = lo_now; up_h[hpos] = up_now; hpos = (hpos + 1) & 7;
+        unsigned long long bseen = 0ull;
+        const int l0 = (int)(unsigned)lo_now, l1 = (int)(unsigned)(lo_now >> 32), u0_ = (int)(unsigned)up_now, u1 = (int)(unsigned)(up_now >> 32);
+        QPC_PHASE(lane) {
+          int *hs = QPC_LI(hist_, lane);
+          QPC_BALLOT_PUT(5, bseen, lane < 8 && hs[0] == l0 && hs[1] == l1 && hs[2] == u0_ && hs[3] == u1);
+          if (lane == hpos) { hs[0] = l0; hs[1] = l1; hs[2] = u0_; hs[3] = u1; }
+        } QPC_END_PHASE
+        QPC_BALLOT_GET(5, bseen);
+        // (ordinary QPs are done long before iteration 10: a repeat only counts for the stragglers)
+        if (iters >= 10 && bseen != 0ull) { status = QPC_STATUS_ITERATION_LIMIT; break; }
+        hpos = (hpos + 1) & 7;
       }
       const bool finite = !(rnan > 0.0);
       if (!(ubad < -D.tol_bound * gscale)) jbad = -1;
