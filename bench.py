@@ -27,14 +27,14 @@ sys.path.insert(0, ROOT)
 ALG_BYTES_PER_SOLVE = 1968  # in 8*(37+36+36+16) + out 8*(36+36+48) + 8
 ALG_FLOPS_PER_SOLVE = 4.6e5  # one reduced-KKT factor+solve + assembly + FK/RNEA
 # HBM traffic per solve measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes
-# (profiles/r01_v34_pmc_*.csv, r01_v34_traffic_summary.json; tools/profile_round.sh): 218221 KiB read + 292439 KiB written per
+# (profiles/r01_v35_pmc_*.csv, r01_v35_traffic_summary.json; tools/profile_round.sh): 185389 KiB read + 259537 KiB written per
 # 32768-QP launch.  ~5.6 KB each way per solve is the deliberate lane-private spill slot (22 x 32 lanes x 8 B), the rest
 # register spills of the 256-VGPR kernel; the slot (inertias,
 # bias wrenches, motion subspaces parked in HBM during the solve so that 8 QPs fit the LDS of a CU,
 # DESIGN.md 4); the slots total 23 MB and live in L2 / Infinity Cache, TCC->EA requests count them anyway.
 # 8-byte-per-lane accesses: the gfx950 "x2 for 16-B wide reads" correction of MI355X_MICROARCH.md
 # does not apply.
-MEASURED_TRAFFIC_BYTES_PER_SOLVE = (218220.8 + 292438.9) * 1024 / 32768
+MEASURED_TRAFFIC_BYTES_PER_SOLVE = (185389.1 + 259537.1) * 1024 / 32768
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md (spec; 6.29e12 measured)
 FP64_PEAK = 78.6e12  # FLOP/s vector fp64 (datasheet)
 
@@ -286,7 +286,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": ach_bytes / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": ach_bytes / HBM_PEAK,
                          "traffic": MEASURED_TRAFFIC_BYTES_PER_SOLVE * B if args.config == 3 else None,
-                         "traffic_source": "profiles/r01_v34_traffic_summary.json (rocprofv3 PMC FETCH_SIZE + WRITE_SIZE, separate passes), bytes per launch; includes the HBM spill slots (DESIGN.md 4)",
+                         "traffic_source": "profiles/r01_v35_traffic_summary.json (rocprofv3 PMC FETCH_SIZE + WRITE_SIZE, separate passes), bytes per launch; includes the HBM spill slots (DESIGN.md 4)",
                          "kernel": "qpc_tick_kernel", "kernel_avg_ms": avg_ms.value, "launches": int(nl.value),
                          "algorithmic_bytes_per_solve": alg_bytes,
                          "note": "path is fp64-VALU / LDS-latency bound, not HBM bound (SURVEY.md 8d); "
