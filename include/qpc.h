@@ -19,6 +19,16 @@
  *    default frame of a URDF-parsed body).
  *  - Spatial vectors are [angular(3); linear(3)] (RigidBodyDynamics layout).
  *  - Handles are opaque, freed by *_destroy, usable from one host thread at a time.
+ *  - Limits of the one-wavefront-per-QP kernels (qpc_finalize returns QPC_ERR_UNSUPPORTED beyond them):
+ *    bodies <= 64, velocity coordinates nv <= 64, generic (non-pinned) tasks <= 63, tree depth <= 32
+ *    (<= 16 without the hiprtc-specialised kernel), equality rows of the reduced QP (task rows that
+ *    are not pins + 6 wrench-balance rows) <= 64, friction basis N <= 8, per-QP LDS slab <= 160 KiB.
+ *  - Streams: the *_device entry points enqueue on the caller's stream.  All launches of one
+ *    controller on one device share a work counter, so they are serialised: when consecutive calls
+ *    use DIFFERENT streams the library inserts an event dependency between them (no overlap, no
+ *    corruption).  Under hipStreamBeginCapture the dependency cannot be recorded: capture every
+ *    launch of a controller into ONE stream / graph and do not run the same controller on another
+ *    stream while that graph executes.
  *  - There is NO CPU fallback: every compute entry point needs a HIP device and fails with
  *    QPC_ERR_NO_DEVICE otherwise.
  */
@@ -192,14 +202,39 @@ int32_t qpc_add_contact(qpc_controller *ctrl, int32_t body, const double positio
  * floating joint was given (momentum.jl:162-193), compile the task program and upload it to
  * HIP device `device_id`. */
 int32_t qpc_finalize(qpc_controller *ctrl, int32_t device_id, qpc_layout *out_layout);
+/* Same for SEVERAL devices of this process: the task program is replicated on every
+ * device of device_ids[0..n_devices) and the host-pointer entry points (qpc_control_batch,
+ * qpc_control_batch_async, qpc_rollout_batch) shard every batch into contiguous ranges, one per
+ * device, QP index range [g B/G, (g+1) B/G) -> device_ids[g]; no collective, the QPs are independent.
+ * The *_device entry points address device_ids[0] unless they take a device index. */
+int32_t qpc_finalize_devices(qpc_controller *ctrl, int32_t n_devices, const int32_t *device_ids,
+                             qpc_layout *out_layout);
+int32_t qpc_n_devices(const qpc_controller *ctrl);
 int32_t qpc_get_layout(const qpc_controller *ctrl, qpc_layout *out_layout);
+
+/* Host-pointer pipeline (before or after qpc_finalize*; not while a job is in flight): every device's
+ * shard of a batch is cut into chunks of `chunk_qps` QPs (<= 0: keep; default 8192) that flow through
+ * `slots_per_device` pipeline slots per device (<= 0: keep; default 3; only before qpc_finalize*) --
+ * the H2D copy of one chunk, the kernel of another and the D2H copy of a third overlap.  Batches of at
+ * most `inline_qps` QPs (< 0: keep; default 2048) are run on the caller's thread without a hand-off. */
+int32_t qpc_set_host_pipeline(qpc_controller *ctrl, int64_t chunk_qps, int32_t slots_per_device,
+                              int64_t inline_qps);
+
+/* Page-locked host memory.  Arrays handed to the host-pointer entry points that live in pinned memory
+ * (from qpc_host_alloc, qpc_host_register, hipHostMalloc / hipHostRegister or torch pin_memory) are
+ * DMA-ed in place; pageable arrays are staged through the library's own pinned buffers (one extra
+ * host copy each way, done by the pipeline's worker threads). */
+void *qpc_host_alloc(uint64_t bytes);
+void qpc_host_free(void *ptr);
+int32_t qpc_host_register(void *ptr, uint64_t bytes);
+int32_t qpc_host_unregister(void *ptr);
 
 /* solver knobs (all optional; defaults in parentheses) */
 typedef struct qpc_settings {
   int32_t max_active_set_iters; /* (200) -> QPC_STATUS_ITERATION_LIMIT                      */
   int32_t max_refine_iters;     /* (6) proximal/iterative-refinement sweeps                */
   double eps_primal_reg;        /* (1e-9) relative primal proximal regularisation          */
-  double eps_dual_reg;          /* (1e-10) relative dual regularisation of equality rows   */
+  double eps_dual_reg;          /* (1e-11) relative dual regularisation of equality rows   */
   double tol_residual;          /* (1e-10) relative KKT residual for OPTIMAL               */
   double tol_bound;             /* (1e-10) relative bound violation / multiplier sign tol  */
 } qpc_settings;
@@ -215,12 +250,23 @@ int32_t qpc_set_settings(qpc_controller *ctrl, const qpc_settings *s);
  *   out: tau[nv*B], vdot[nv*B] (result.vdot, momentum.jl:62-64),
  *        contact_wrench[6*nc*B] (value(wrench_world) per contact, world frame, [ang;lin],
  *        contacts.jl:82-89) or NULL, status[B] (QPC_STATUS_*), iters[B] or NULL
- * Host-pointer variant: synchronous (H2D, kernels, D2H). */
+ * Host-pointer variant: synchronous; the batch is sharded over the controller's devices and
+ * pipelined in chunks (H2D || kernel || D2H, qpc_set_host_pipeline). */
 int32_t qpc_control_batch(qpc_controller *ctrl, int64_t B, const double *q, const double *v,
                           const double *desired, const double *contact_weight,
                           const double *contact_maxnormalforce, const double *task_weights,
                           const double *surfaces, double *tau, double *vdot,
                           double *contact_wrench, int32_t *status, int32_t *iters);
+/* Same, but returns as soon as the job is posted to the controller's worker threads; every array
+ * must stay valid and untouched until qpc_wait(ctrl) returns.  One job in flight per controller: a
+ * second *_async call first waits for the previous job.  qpc_wait returns the error of the job
+ * (QPC_OK if there is none in flight). */
+int32_t qpc_control_batch_async(qpc_controller *ctrl, int64_t B, const double *q, const double *v,
+                                const double *desired, const double *contact_weight,
+                                const double *contact_maxnormalforce, const double *task_weights,
+                                const double *surfaces, double *tau, double *vdot,
+                                double *contact_wrench, int32_t *status, int32_t *iters);
+int32_t qpc_wait(qpc_controller *ctrl);
 
 /* Same, but every pointer is a DEVICE pointer on the controller's device and the work is
  * enqueued on `hip_stream` (a hipStream_t, NULL = default stream) without synchronising. */
@@ -231,6 +277,41 @@ int32_t qpc_control_batch_device(qpc_controller *ctrl, int64_t B, const double *
                                  const double *task_weights, const double *surfaces, double *tau,
                                  double *vdot, double *contact_wrench, int32_t *status,
                                  int32_t *iters, void *hip_stream);
+/* Same on device device_ids[device_index] of a multi-device controller (qpc_finalize_devices). */
+int32_t qpc_control_batch_device_on(qpc_controller *ctrl, int32_t device_index, int64_t B,
+                                    const double *q, const double *v, const double *desired,
+                                    const double *contact_weight,
+                                    const double *contact_maxnormalforce,
+                                    const double *task_weights, const double *surfaces,
+                                    double *tau, double *vdot, double *contact_wrench,
+                                    int32_t *status, int32_t *iters, void *hip_stream);
+
+/* Warm start -- the counterpart of the reference's persistent OSQP workspace (momentum.jl:58 calls
+ * solve! on the SAME model every tick, so OSQP starts from the previous tick's iterate).  Here the
+ * carried state is the working set of the active-set search: per QP two 64-bit masks,
+ * working_set[2 b] bit j = rho_j at its lower bound (0), working_set[2 b + 1] bit j = rho_j at its
+ * upper bound (maxrho, contacts.jl:57), j = N * contact + ray.  The caller keeps the array between
+ * ticks (zeros = cold start); the tick reads it as the starting set and overwrites it with the final
+ * one.  The result never depends on the hint: a search that fails from a warm set is repeated from the
+ * cold start inside the kernel.  qpc_enable_warm_start(ctrl, 1) before qpc_finalize builds the
+ * (separately compiled) warm-started kernel next to the cold one, whose speed it does not touch; it
+ * needs the hiprtc-specialised kernel and at most 64 rho's (else QPC_ERR_UNSUPPORTED at qpc_finalize).
+ * qpc_rollout_batch[_device] then warm-start their ticks by themselves. */
+int32_t qpc_enable_warm_start(qpc_controller *ctrl, int32_t enable);
+int32_t qpc_control_batch_warm(qpc_controller *ctrl, int64_t B, const double *q, const double *v,
+                               const double *desired, const double *contact_weight,
+                               const double *contact_maxnormalforce, const double *task_weights,
+                               const double *surfaces, double *tau, double *vdot,
+                               double *contact_wrench, int32_t *status, int32_t *iters,
+                               uint64_t *working_set);
+int32_t qpc_control_batch_device_warm(qpc_controller *ctrl, int32_t device_index, int64_t B,
+                                      const double *q, const double *v, const double *desired,
+                                      const double *contact_weight,
+                                      const double *contact_maxnormalforce,
+                                      const double *task_weights, const double *surfaces,
+                                      double *tau, double *vdot, double *contact_wrench,
+                                      int32_t *status, int32_t *iters, uint64_t *working_set,
+                                      void *hip_stream);
 
 /* L1 -- assembly + solve from HOST-EVALUATED blocks: `solve!` + `value` of the reference
  * (momentum.jl:58-72) with the kinematics taken out.  Per QP the caller supplies
@@ -263,6 +344,15 @@ int32_t qpc_qp_solve_batch(int32_t n, int32_t m, int64_t B, const double *P, con
                            const double *A, const double *l, const double *u,
                            const qpc_settings *settings, int32_t device_id, double *x, double *y,
                            int32_t *status, int32_t *iters);
+/* Same with DEVICE pointers on device `device_id`, enqueued on `hip_stream` without synchronising;
+ * `workspace` = at least qpc_qp_workspace_bytes(n, m, B) bytes of device memory owned by the caller
+ * (the host-pointer variant keeps a persistent one per device). */
+uint64_t qpc_qp_workspace_bytes(int32_t n, int32_t m, int64_t B);
+int32_t qpc_qp_solve_batch_device(int32_t n, int32_t m, int64_t B, const double *P, const double *q,
+                                  const double *A, const double *l, const double *u,
+                                  const qpc_settings *settings, int32_t device_id, double *x,
+                                  double *y, int32_t *status, int32_t *iters, void *workspace,
+                                  uint64_t workspace_bytes, void *hip_stream);
 
 /* ---- closed loop: what the reference's acceptance test does around the tick,
  *      notebooks/Standing controller.ipynb cells 9-11 -- `Dynamics(mechanism, controller)` with a

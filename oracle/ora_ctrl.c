@@ -231,7 +231,7 @@ int ora_task_eval(const ora_ctrl *c, const ora_state *s, int ti, double *J, doub
 static void rotation_between_z(const double n[3], double R[9]) {
   double nn = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
   double w = nn + n[2], x, y, z;
-  if (fabs(w) < 100 * 2.220446049250313e-16) { x = 0; y = 1; z = 0; } /* perpendicular_vector(z) */
+  if (fabs(w) < 100 * 2.220446049250313e-16) { x = 1; y = 0; z = 0; } /* Rotations.perpendicular_vector((0,0,1)) = (1,0,0): pi about x */
   else { x = -n[1]; y = n[0]; z = 0; }
   double qn = sqrt(w * w + x * x + y * y + z * z);
   w /= qn; x /= qn; y /= qn; z /= qn;

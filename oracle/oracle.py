@@ -56,9 +56,7 @@ def lib(native=False):
     if _LIB is None:
         _LIB = {}
     if key not in _LIB:
-        path = os.path.join(_HERE, "_build", "liboracle_native.so" if native else "liboracle.so")
-        if not os.path.exists(path):
-            build(native)
+        path = build(native)  # `make`: a no-op when the library is newer than its sources, a rebuild when they changed
         L = ctypes.CDLL(path)
         L.ora_model_create.restype = ctypes.c_void_p
         L.ora_state_create.restype = ctypes.c_void_p

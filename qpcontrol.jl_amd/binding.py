@@ -86,6 +86,27 @@ def load_library(path=None):
     L.qpc_assemble_solve_batch.argtypes = [vp, i64] + [c_double_p] * 11 + [c_double_p, c_double_p, c_int32_p, c_int32_p]
     L.qpc_sim_step_batch.argtypes = [vp, i64, c_double_p, c_double_p, c_double_p, c_int32_p, ctypes.POINTER(SimParams), c_int32_p]
     L.qpc_rollout_batch.argtypes = [vp, i64, i64] + [c_double_p] * 7 + [ctypes.POINTER(SimParams), c_double_p, c_int32_p, c_int32_p]
+    u64 = ctypes.c_uint64
+    c_uint64_p = ctypes.POINTER(u64)
+    L.qpc_finalize_devices.argtypes = [vp, i32, c_int32_p, ctypes.POINTER(Layout)]
+    L.qpc_n_devices.argtypes = [vp]
+    L.qpc_set_host_pipeline.argtypes = [vp, i64, i32, i64]
+    L.qpc_control_batch_async.argtypes = L.qpc_control_batch.argtypes
+    L.qpc_wait.argtypes = [vp]
+    L.qpc_enable_warm_start.argtypes = [vp, i32]
+    L.qpc_control_batch_warm.argtypes = L.qpc_control_batch.argtypes + [c_uint64_p]
+    if hasattr(L, "qpc_host_alloc"):  # (the test emulator has no pinned memory)
+        L.qpc_host_alloc.argtypes = [u64]
+        L.qpc_host_alloc.restype = vp
+        L.qpc_host_free.argtypes = [vp]
+        L.qpc_host_free.restype = None
+        L.qpc_host_register.argtypes = [vp, u64]
+        L.qpc_host_unregister.argtypes = [vp]
+        L.qpc_control_batch_device_on.argtypes = [vp, i32, i64] + [vp] * 12 + [vp]
+        L.qpc_control_batch_device_warm.argtypes = [vp, i32, i64] + [vp] * 12 + [vp, vp]
+        L.qpc_qp_workspace_bytes.argtypes = [i32, i32, i64]
+        L.qpc_qp_workspace_bytes.restype = u64
+        L.qpc_qp_solve_batch_device.argtypes = [i32, i32, i64] + [vp] * 5 + [ctypes.POINTER(Settings), i32] + [vp] * 4 + [vp, u64, vp]
     if hasattr(L, "qpc_sim_step_batch_device"):
         L.qpc_sim_step_batch_device.argtypes = [vp, i64, vp, vp, vp, vp, ctypes.POINTER(SimParams), vp, vp]
         L.qpc_rollout_batch_device.argtypes = [vp, i64, i64] + [vp] * 7 + [ctypes.POINTER(SimParams)] + [vp] * 5
@@ -174,15 +195,35 @@ class Controller:
             setattr(s, k, v)
         _check(self.L, self.L.qpc_set_settings(self.h, ctypes.byref(s)), "qpc_set_settings")
 
-    def finalize(self, device_id=0):
+    def finalize(self, device_id=0, devices=None):
+        """initialize! (momentum.jl:150-156).  devices = [ids]: replicate the program on several devices of this
+        process; the host-array entry points then shard every batch over them (qpc_finalize_devices)."""
         lay = Layout()
-        _check(self.L, self.L.qpc_finalize(self.h, int(device_id), ctypes.byref(lay)), "qpc_finalize")
+        if devices is None:
+            _check(self.L, self.L.qpc_finalize(self.h, int(device_id), ctypes.byref(lay)), "qpc_finalize")
+        else:
+            ids = np.ascontiguousarray(devices, dtype=np.int32)
+            _check(self.L, self.L.qpc_finalize_devices(self.h, len(ids), ids.ctypes.data_as(c_int32_p), ctypes.byref(lay)),
+                   "qpc_finalize_devices")
         self.layout = lay
         return lay
 
-    # ---- host-array tick (synchronous): the callable (controller)(tau, t, x) for a batch
+    def set_host_pipeline(self, chunk_qps=0, slots_per_device=0, inline_qps=-1):
+        _check(self.L, self.L.qpc_set_host_pipeline(self.h, int(chunk_qps), int(slots_per_device), int(inline_qps)),
+               "qpc_set_host_pipeline")
+
+    def enable_warm_start(self, enable=True):
+        _check(self.L, self.L.qpc_enable_warm_start(self.h, 1 if enable else 0), "qpc_enable_warm_start")
+
+    def n_devices(self):
+        return self.L.qpc_n_devices(self.h)
+
+    # ---- host-array tick: the callable (controller)(tau, t, x) for a batch
     def control_batch(self, q, v, desired=None, contact_weight=None, contact_maxnormalforce=None,
-                      task_weights=None, surfaces=None):
+                      task_weights=None, surfaces=None, working_set=None, asynchronous=False, out=None):
+        """working_set: uint64[B, 2] warm-start masks, updated in place (qpc_control_batch_warm).
+        asynchronous: post the job and return a `PendingBatch`; its .wait() returns the result dict
+        (qpc_control_batch_async + qpc_wait).  out: dict of preallocated output arrays to reuse."""
         lay = self.layout
         if lay is None:
             raise QpcError("controller not finalized")
@@ -201,15 +242,30 @@ class Controller:
         des = None if (desired is None and lay.n_desired_inputs == 0) else arr(desired, lay.n_desired)
         cw, cm = arr(contact_weight, lay.n_contacts), arr(contact_maxnormalforce, lay.n_contacts)
         tw, sf = arr(task_weights, lay.n_task_weights), arr(surfaces, lay.n_surface)
-        tau, vd = np.zeros((B, lay.nv)), np.zeros((B, lay.nv))
-        cwr = np.zeros((B, max(lay.n_contacts, 1) * 6))
-        status, iters = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
-        rc = self.L.qpc_control_batch(self.h, B, _dp(q), _dp(v), _dp(des), _dp(cw), _dp(cm), _dp(tw), _dp(sf),
-                                      _dp(tau), _dp(vd), _dp(cwr) if lay.n_contacts else None,
-                                      status.ctypes.data_as(c_int32_p), iters.ctypes.data_as(c_int32_p))
-        _check(self.L, rc, "qpc_control_batch")
-        return dict(tau=tau, vdot=vd, cwrench=cwr[:, :6 * lay.n_contacts].reshape(B, lay.n_contacts, 6),
-                    status=status, iters=iters)
+        if out is not None:
+            tau, vd, cwr, status, iters = out["tau"], out["vdot"], out["cwrench_flat"], out["status"], out["iters"]
+        else:
+            tau, vd = np.zeros((B, lay.nv)), np.zeros((B, lay.nv))
+            cwr = np.zeros((B, max(lay.n_contacts, 1) * 6))
+            status, iters = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
+        args = [self.h, B, _dp(q), _dp(v), _dp(des), _dp(cw), _dp(cm), _dp(tw), _dp(sf),
+                _dp(tau), _dp(vd), _dp(cwr) if lay.n_contacts else None,
+                status.ctypes.data_as(c_int32_p), iters.ctypes.data_as(c_int32_p)]
+        res = dict(tau=tau, vdot=vd, cwrench=cwr[:, :6 * lay.n_contacts].reshape(B, lay.n_contacts, 6),
+                   status=status, iters=iters)
+        if working_set is not None:
+            assert working_set.dtype == np.uint64 and working_set.shape == (B, 2) and working_set.flags.c_contiguous
+            rc = self.L.qpc_control_batch_warm(*args, working_set.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)))
+            _check(self.L, rc, "qpc_control_batch_warm")
+            return res
+        if asynchronous:
+            _check(self.L, self.L.qpc_control_batch_async(*args), "qpc_control_batch_async")
+            return PendingBatch(self, res, (q, v, des, cw, cm, tw, sf))
+        _check(self.L, self.L.qpc_control_batch(*args), "qpc_control_batch")
+        return res
+
+    def wait(self):
+        _check(self.L, self.L.qpc_wait(self.h), "qpc_wait")
 
     # ---- closed loop: forward-dynamics step and tick+step rollouts on the device
     def sim_step(self, q, v, tau, params: SimParams, status=None, bad=None):
@@ -254,6 +310,32 @@ class Controller:
                                       bad.ctypes.data_as(c_int32_p))
         _check(self.L, rc, "qpc_rollout_batch")
         return dict(q=q, v=v, tau=tau, status=status, bad=bad)
+
+
+class PendingBatch:
+    """A posted qpc_control_batch_async job: keeps the input arrays alive until wait()."""
+
+    def __init__(self, ctrl, result, keep):
+        self.ctrl, self.result, self._keep = ctrl, result, keep
+
+    def wait(self):
+        self.ctrl.wait()
+        self._keep = None
+        return self.result
+
+
+def pinned_array(L, shape, dtype=np.float64):
+    """numpy array in page-locked host memory (qpc_host_alloc): the host-pointer entry points DMA it in place.
+    The memory is released when the array (and every view of it) is garbage-collected."""
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    ptr = L.qpc_host_alloc(max(n, 1))
+    if not ptr:
+        raise QpcError("qpc_host_alloc failed: " + L.qpc_last_error().decode())
+    buf = (ctypes.c_char * max(n, 1)).from_address(ptr)
+    a = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+    import weakref
+    weakref.finalize(buf, L.qpc_host_free, ptr)
+    return a
 
 
 def assemble_solve_batch(ctrl: Controller, task_J, task_bias, desired, momentum_A=None, momentum_rhs=None, contact_R=None,

@@ -181,6 +181,13 @@ int32_t qpc_add_contact(qpc_controller *c, int32_t body, const double position[3
   return QPC_OK;
 }
 
+int32_t qpc_enable_warm_start(qpc_controller *c, int32_t enable) {
+  if (!c) return QPC_ERR_INVALID_ARGUMENT;
+  if (c->finalized) { qpc_set_error("qpc_enable_warm_start must be called before qpc_finalize"); return QPC_ERR_ALREADY_FINALIZED; }
+  c->warm_start = enable ? 1 : 0;
+  return QPC_OK;
+}
+
 int32_t qpc_get_layout(const qpc_controller *c, qpc_layout *out) {
   if (!c || !out) return QPC_ERR_INVALID_ARGUMENT;
   if (!c->finalized) { qpc_set_error("controller not finalized"); return QPC_ERR_NOT_FINALIZED; }

@@ -510,6 +510,10 @@ int qpc_compile_program(qpc_controller *c) {
     qpc_set_error("more than 64 equality rows in the reduced QP are not supported by the lane=row factorization");
     return QPC_ERR_UNSUPPORTED;
   }
+  if (c->warm_start && D.nrho > 64) {
+    qpc_set_error("warm start carries the working set as two 64-bit masks: at most 64 rho's");
+    return QPC_ERR_UNSUPPORTED;
+  }
   if (Lo.lds_bytes_per_qp > 160 * 1024) {
     qpc_set_error("problem does not fit the 160 KiB LDS of one CU");
     return QPC_ERR_UNSUPPORTED;

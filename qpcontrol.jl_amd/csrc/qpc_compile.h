@@ -35,7 +35,7 @@ struct QpcProgram {
   std::vector<double> dtab;
 };
 
-struct QpcDeviceState; // owned by the HIP runtime part (qpc_runtime.hip)
+struct QpcRuntime; // device states, worker threads: owned by the run half (qpc_runtime.hip; tests/emul/emul.cpp)
 
 struct qpc_controller {
   const qpc_model *model = nullptr;
@@ -48,7 +48,10 @@ struct qpc_controller {
   qpc_settings settings;
   QpcProgram prog;
   qpc_layout layout;
-  QpcDeviceState *dev = nullptr;
+  QpcRuntime *rt = nullptr;
+  int warm_start = 0;                       // qpc_enable_warm_start: also build the warm-started kernel variant
+  int pipe_slots = 0;                       // qpc_set_host_pipeline (0 / -1: defaults)
+  long long pipe_chunk = 0, pipe_inline = -1;
 };
 
 void qpc_set_error(const std::string &msg);

@@ -29,9 +29,9 @@ static std::string dbl(double x) {
   return s;
 }
 
-std::string qpc_jit_source(const QpcDims &D) {
+std::string qpc_jit_source(const QpcDims &D, bool warm) {
   std::ostringstream o;
-  o << "typedef int int32_t;\ntypedef unsigned int uint32_t;\ntypedef long long int64_t;\n";
+  o << "typedef int int32_t;\ntypedef unsigned int uint32_t;\ntypedef long long int64_t;\ntypedef unsigned long long uint64_t;\n";
   o << "#define QPC_JIT 1\n#define QPC_M1_MAX " << (D.m1 > 0 ? D.m1 : 1) << "\n#define QPC_MAXD " << D.maxd << "\n#define QPC_NTILE_MAX " << (((D.m + 15) / 16) * (((D.m + 15) / 16) + 1) / 2 > 0 ? ((D.m + 15) / 16) * (((D.m + 15) / 16) + 1) / 2 : 1) << "\n#include \"qpc_device.h\"\n";
   const char *st = getenv("QPC_JIT_STAMPS"); // diagnostic: in-kernel section timers
   const bool stamps = st && st[0] == '1';
@@ -62,31 +62,39 @@ std::string qpc_jit_source(const QpcDims &D) {
     << D.max_pdas << "," << dbl(D.eps_primal) << "," << dbl(D.tau_pivot) << "," << dbl(D.tol_bound) << ","
     << dbl(D.tol_accept) << "};\n";
   o << "struct QpcBatchArgs { long long B; const double *q, *v, *desired, *cw, *cmax, *tw, *surf; double *tau, *vdot, "
-       "*cwrench; int32_t *status, *iters; unsigned long long *prof; unsigned long long *ticket; unsigned long long ticket_base; double *scratch; };\n";
-  o << "extern \"C\" __global__ void __launch_bounds__(64, 2) qpc_tick_kernel_jit(const int *__restrict__ IT, "
-       "const double *__restrict__ DT, const QpcBatchArgs A) {\n"
-       "  __shared__ __attribute__((aligned(16))) double qpc_lds[" << (D.lds_doubles > 0 ? D.lds_doubles : 1) << "];\n"
-       "  qpc::qpc_tick_prologue<double *>(kD, IT, qpc_lds);\n"
-       "  while (true) {\n"
-       "    unsigned long long t = 0;\n"
-       "    if ((threadIdx.x & 63) == 0) t = atomicAdd(A.ticket, 1ull);\n"
-       "    const long long b = (long long)(__shfl(t, 0, 64) - A.ticket_base);\n"
-       "    if (b >= A.B) break;\n"
-       "    qpc::TickIO io;\n"
-       "    io.q = A.q + b * kD.nq; io.v = A.v + b * kD.nv; io.desired = A.desired + b * kD.n_desired;\n"
-       "    io.cw = A.cw + b * kD.nc; io.cmax = A.cmax + b * kD.nc; io.tw = A.tw + b * kD.n_tw; io.surf = A.surf + b * kD.n_surf;\n"
-       "    io.tau = A.tau + b * kD.nv; io.vdot = A.vdot + b * kD.nv;\n"
-       "    io.cwrench = A.cwrench ? A.cwrench + b * 6 * kD.nc : nullptr;\n"
-       "    io.status = A.status + b; io.iters = A.iters ? A.iters + b : nullptr; io.prof = A.prof ? A.prof + b * PS_COUNT : nullptr;\n"
-       "    io.scratch = A.scratch + (size_t)blockIdx.x * QPC_SCRATCH_DOUBLES;\n"
-       "    // opaque copies of the table pointers: keeps the compiler from hoisting dozens of per-lane table\n"
-       "    // addresses out of this loop (they would stay live across the whole tick and spill)\n"
-       "    const int *ITq = IT; const double *DTq = DT;\n"
-       "    asm volatile(\"\" : \"+s\"(ITq), \"+s\"(DTq));\n"
-       "    qpc::qpc_tick<double *>(kD, ITq, DTq, qpc_lds, io);\n"
-       "    __syncthreads();\n"
-       "  }\n"
-       "}\n";
+       "*cwrench; int32_t *status, *iters; unsigned long long *prof; unsigned long long *ticket; unsigned long long *wsets; double *scratch; };\n";
+  // the tick kernel (cold start) and, on request, its warm-started twin: same loop, qpc_tick<P, true>
+  for (int variant = 0; variant < (warm ? 2 : 1); variant++) {
+    o << "extern \"C\" __global__ void __launch_bounds__(64, 2) " << (variant ? "qpc_tick_kernel_jit_warm" : "qpc_tick_kernel_jit")
+      << "(const int *__restrict__ IT, const double *__restrict__ DT, const QpcBatchArgs A) {\n"
+         "  __shared__ __attribute__((aligned(16))) double qpc_lds[" << (D.lds_doubles > 0 ? D.lds_doubles : 1) << "];\n"
+         "  qpc::qpc_tick_prologue<double *>(kD, IT, qpc_lds);\n"
+         "  while (true) {\n"
+         "    unsigned long long t = 0;\n"
+         "    if ((threadIdx.x & 63) == 0) t = atomicAdd(A.ticket, 1ull);\n"
+         "    const long long b = (long long)__shfl(t, 0, 64);\n"
+         "    if (b >= A.B) {\n"
+         "      // a launch draws exactly B + gridDim.x tickets; whoever draws the last one re-arms the counter\n"
+         "      if ((threadIdx.x & 63) == 0 && b == A.B + (long long)gridDim.x - 1) atomicExch(A.ticket, 0ull);\n"
+         "      break;\n"
+         "    }\n"
+         "    qpc::TickIO io;\n"
+         "    io.q = A.q + b * kD.nq; io.v = A.v + b * kD.nv; io.desired = A.desired + b * kD.n_desired;\n"
+         "    io.cw = A.cw + b * kD.nc; io.cmax = A.cmax + b * kD.nc; io.tw = A.tw + b * kD.n_tw; io.surf = A.surf + b * kD.n_surf;\n"
+         "    io.tau = A.tau + b * kD.nv; io.vdot = A.vdot + b * kD.nv;\n"
+         "    io.cwrench = A.cwrench ? A.cwrench + b * 6 * kD.nc : nullptr;\n"
+         "    io.status = A.status + b; io.iters = A.iters ? A.iters + b : nullptr; io.prof = A.prof ? A.prof + b * PS_COUNT : nullptr;\n"
+         "    io.wset = " << (variant ? "A.wsets ? A.wsets + 2 * b : nullptr" : "nullptr") << ";\n"
+         "    io.scratch = A.scratch + (size_t)blockIdx.x * QPC_SCRATCH_DOUBLES;\n"
+         "    // opaque copies of the table pointers: keeps the compiler from hoisting dozens of per-lane table\n"
+         "    // addresses out of this loop (they would stay live across the whole tick and spill)\n"
+         "    const int *ITq = IT; const double *DTq = DT;\n"
+         "    asm volatile(\"\" : \"+s\"(ITq), \"+s\"(DTq));\n"
+         "    qpc::qpc_tick<double *, " << (variant ? "true" : "false") << ">(kD, ITq, DTq, qpc_lds, io);\n"
+         "    __syncthreads();\n"
+         "  }\n"
+         "}\n";
+  }
   // f-2: the simulation step specialised on the same dims (qpc_sim.h)
   o << "struct QpcSimArgs { long long B; double *q, *v; const double *tau; const int32_t *status; int32_t *bad; qpc_sim_params sp; };\n";
   o << "extern \"C\" __global__ void __launch_bounds__(64, 2) qpc_sim_kernel_jit(const int *__restrict__ IT, "
@@ -107,8 +115,8 @@ std::string qpc_jit_source(const QpcDims &D) {
   return o.str();
 }
 
-int qpc_jit_compile(const QpcDims &D, const std::string &arch, std::vector<char> &code, std::string &log) {
-  std::string src = qpc_jit_source(D);
+int qpc_jit_compile(const QpcDims &D, const std::string &arch, bool warm, std::vector<char> &code, std::string &log) {
+  std::string src = qpc_jit_source(D, warm);
   hiprtcProgram prog;
   if (hiprtcCreateProgram(&prog, src.c_str(), "qpc_tick_jit.hip", qpc_src_count, qpc_src_texts, qpc_src_names) != HIPRTC_SUCCESS) {
     log = "hiprtcCreateProgram failed";
@@ -143,7 +151,7 @@ extern "C" int32_t qpc_debug_jit_compile(qpc_controller *c, const char *arch, co
   if (!c->finalized) { int rc = qpc_compile_program(c); if (rc != QPC_OK) return rc; }
   std::vector<char> code;
   std::string log;
-  int rc = qpc_jit_compile(c->prog.dims, arch ? arch : "gfx950", code, log);
+  int rc = qpc_jit_compile(c->prog.dims, arch ? arch : "gfx950", c->warm_start != 0, code, log);
   if (logbuf && logn > 0) snprintf(logbuf, logn, "%s", log.c_str());
   if (rc != 0) { qpc_set_error("JIT compile failed: " + log); return QPC_ERR_HIP; }
   if (out_path) { FILE *f = fopen(out_path, "wb"); if (f) { fwrite(code.data(), 1, code.size(), f); fclose(f); } }
@@ -154,7 +162,7 @@ extern "C" int32_t qpc_debug_jit_compile(qpc_controller *c, const char *arch, co
 extern "C" int32_t qpc_debug_jit_source(qpc_controller *c, const char *out_path) {
   if (!c || !out_path) return QPC_ERR_INVALID_ARGUMENT;
   if (!c->finalized) { int rc = qpc_compile_program(c); if (rc != QPC_OK) return rc; }
-  std::string src = qpc_jit_source(c->prog.dims);
+  std::string src = qpc_jit_source(c->prog.dims, c->warm_start != 0);
   FILE *f = fopen(out_path, "wb");
   if (!f) return QPC_ERR_INVALID_ARGUMENT;
   fwrite(src.data(), 1, src.size(), f);

@@ -6,6 +6,7 @@
 #include "qpc_program.h"
 
 // source of the specialised translation unit (QpcDims baked in as a constexpr object)
-std::string qpc_jit_source(const QpcDims &D);
+// warm: also emit qpc_tick_kernel_jit_warm (the warm-started variant, qpc_enable_warm_start)
+std::string qpc_jit_source(const QpcDims &D, bool warm);
 // compile for `arch` (e.g. "gfx950"); returns 0 and fills `code` on success, else fills `log`
-int qpc_jit_compile(const QpcDims &D, const std::string &arch, std::vector<char> &code, std::string &log);
+int qpc_jit_compile(const QpcDims &D, const std::string &arch, bool warm, std::vector<char> &code, std::string &log);

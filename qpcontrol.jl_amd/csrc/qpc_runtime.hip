@@ -1,5 +1,7 @@
-// qpc_runtime.hip -- the run half of the C ABI (include/qpc.h): qpc_finalize (program upload),
-// qpc_control_batch / qpc_control_batch_device (kernel launch), timing hooks.  gfx950 only.
+// qpc_runtime.hip -- the run half of the C ABI (include/qpc.h): qpc_finalize[_devices] (program upload to
+// every device), qpc_control_batch[_async] + qpc_wait (host-pointer jobs: sharded over the devices, pipelined in
+// chunks, qpc_pipeline.h), qpc_control_batch_device* (kernel launch on the caller's stream), L0 / L1 plumbing
+// entries, closed-loop step / rollout, timing hooks.  gfx950 only.
 //
 // Execution model: one wavefront (64 lanes) per QP, one 64-thread workgroup per wavefront so that
 // the phase barrier is a single-wave s_barrier; each workgroup owns one LDS slab
@@ -9,12 +11,16 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "qpc_compile.h"
 #include "qpc_jit.h"
+#include "qpc_pipeline.h"
 
 #include "qpc_device.h"
 #ifdef QPC_STAMPS
@@ -64,10 +70,12 @@ struct QpcBatchArgs {
   double *tau, *vdot, *cwrench;
   int32_t *status, *iters;
   unsigned long long *prof;
-  unsigned long long *ticket; // dynamic work distribution: a counter that is never reset; a launch draws exactly
-                              // B + gridDim.x tickets (every workgroup draws one past the end), so the host knows
-                              // where the next launch starts (ticket_base) without a memset in between
-  unsigned long long ticket_base;
+  unsigned long long *ticket; // dynamic work distribution: every workgroup draws QP indices from this counter until it
+                              // draws one past the end, so a launch draws exactly B + gridDim.x tickets; the workgroup
+                              // that draws the LAST of them re-arms the counter (stores 0) for the next launch.  No host
+                              // bookkeeping, no memset between launches, safe under hipGraph replay.  Launches that share
+                              // a counter must not overlap (one counter per pipeline slot, see QpcSlot)
+  unsigned long long *wsets;  // warm-start working sets, 2 x uint64 per QP (in/out), or nullptr (cold start)
   double *scratch;            // QPC_SCRATCH_DOUBLES per resident workgroup (lane-private spill slots)
 };
 
@@ -80,8 +88,11 @@ qpc_tick_kernel(const QpcDims D, const int *__restrict__ IT, const double *__res
   while (true) {
     unsigned long long t = 0;
     if ((threadIdx.x & 63) == 0) t = atomicAdd(A.ticket, 1ull);
-    const long long b = (long long)(__shfl(t, 0, 64) - A.ticket_base);
-    if (b >= A.B) break;
+    const long long b = (long long)__shfl(t, 0, 64);
+    if (b >= A.B) {
+      if ((threadIdx.x & 63) == 0 && b == A.B + (long long)gridDim.x - 1) atomicExch(A.ticket, 0ull); // last draw of the launch
+      break;
+    }
     qpc::TickIO io;
     io.q = A.q + b * D.nq; io.v = A.v + b * D.nv;
     io.desired = A.desired + b * D.n_desired;
@@ -91,6 +102,7 @@ qpc_tick_kernel(const QpcDims D, const int *__restrict__ IT, const double *__res
     io.cwrench = A.cwrench ? A.cwrench + b * 6 * D.nc : nullptr;
     io.status = A.status + b; io.iters = A.iters ? A.iters + b : nullptr;
     io.prof = A.prof ? A.prof + b * PS_COUNT : nullptr;
+    io.wset = A.wsets ? A.wsets + 2 * b : nullptr;
     io.scratch = A.scratch + (size_t)blockIdx.x * QPC_SCRATCH_DOUBLES;
     qpc::qpc_tick<double *>(D, IT, DT, qpc_lds, io);
     __syncthreads(); // the slab is reused by the next QP of this workgroup
@@ -122,28 +134,43 @@ qpc_sim_kernel(const QpcDims D, const int *__restrict__ IT, const double *__rest
 }
 
 // ------------------------------------------------------------------------------------------
+// One pipeline slot of a device: everything two launches in flight must NOT share -- the ticket
+// counter, the lane-private spill slots, the staging buffers -- plus the stream the slot's work is
+// ordered on.  Worker slots [0, P) and the inline slot P own their stream; the user slot P + 1 (the
+// *_device entry points) runs on whatever stream the caller passes and remembers the last one so that
+// a change of stream is turned into an event dependency instead of a race on the counter.
+struct QpcSlot {
+  hipStream_t stream = nullptr; // own stream (null for the user slot)
+  unsigned long long *d_ticket = nullptr;
+  double *d_scratch = nullptr;
+  char *d_stage = nullptr; size_t d_stage_bytes = 0; // device staging slab of the host-pointer path
+  char *h_stage = nullptr; size_t h_stage_bytes = 0; // pinned host staging slab (pageable caller arrays)
+  hipEvent_t last_event = nullptr; // recorded after the slot's last launch (user slot only)
+  hipStream_t last_stream = nullptr;
+  bool has_last = false;
+};
+
 struct QpcDeviceState {
   int device = -1;
   int *d_it = nullptr;
   double *d_dt = nullptr;
-  int n_cu = 0, blocks_per_cu = 1;
-  hipStream_t stream = nullptr; // internal stream of the host-pointer entry point
-  // staging buffers of the host-pointer entry point
-  void *stage = nullptr;
-  size_t stage_bytes = 0;
-  // timing
+  int n_cu = 0, blocks_per_cu = 1, sim_blocks_per_cu = 1;
+  std::vector<QpcSlot> slots; // [0, P) workers, [P] inline host path, [P + 1] user streams
+  // timing (bench.py / roofline): events on the launch stream
   bool timing = false;
+  std::mutex timing_mu;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   std::vector<hipEvent_t> pool;
   unsigned long long *prof = nullptr; // PS_COUNT cycle counters per QP (diagnostic builds only)
-  // JIT-specialised kernel (qpc_jit.cpp); null -> the generic ahead-of-time kernel is launched
+  // JIT-specialised kernels (qpc_jit.cpp); null -> the generic ahead-of-time kernel is launched
   hipModule_t jit_module = nullptr;
   hipFunction_t jit_func = nullptr;
-  hipFunction_t jit_sim_func = nullptr; // qpc_sim_kernel_jit of the same module
-  unsigned long long *d_ticket = nullptr;
-  unsigned long long ticket_next = 0; // value of *d_ticket once every launch enqueued so far has drained
-  double *d_scratch = nullptr;
-  int sim_blocks_per_cu = 1;
+  hipFunction_t jit_sim_func = nullptr;  // qpc_sim_kernel_jit of the same module
+  hipFunction_t jit_warm_func = nullptr; // qpc_tick_kernel_jit_warm (qpc_enable_warm_start)
+  // persistent buffers: L1 workspace, rollout slab, warm-start working sets of the rollout
+  char *l1_buf = nullptr; size_t l1_bytes = 0;
+  char *roll_buf = nullptr; size_t roll_bytes = 0;
+  unsigned long long *roll_ws = nullptr; size_t roll_ws_bytes = 0;
 };
 
 static int hip_fail(hipError_t e, const char *what) {
@@ -152,15 +179,39 @@ static int hip_fail(hipError_t e, const char *what) {
 }
 #define HIP_TRY(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return hip_fail(e__, #call); } while (0)
 
-static int launch(qpc_controller *c, const QpcBatchArgs &a, hipStream_t stream) {
-  QpcDeviceState *S = c->dev;
+class QpcHipBackend;
+struct QpcRuntime {
+  std::vector<QpcDeviceState *> devs;
+  int slots = 3;            // worker slots per device
+  QpcHipBackend *backend = nullptr;
+  QpcHostPipeline *pipe = nullptr;
+  int inline_slot() const { return slots; }
+  int user_slot() const { return slots + 1; }
+};
+
+// dynamic-LDS limit of the generic kernels is a per-function attribute shared by every controller of the
+// process: never lower it below what an earlier (still live) controller needs
+static std::mutex g_attr_mu;
+static size_t g_tick_lds_max = 0, g_sim_lds_max = 0;
+
+static int launch(qpc_controller *c, QpcDeviceState *S, QpcSlot &sl, const QpcBatchArgs &a, hipStream_t stream, bool warm) {
   const QpcDims &D = c->prog.dims;
   long long grid = (long long)S->n_cu * S->blocks_per_cu;
   if (grid > a.B) grid = a.B;
   if (grid < 1) return QPC_OK;
   size_t lds = (size_t)D.lds_doubles * sizeof(double);
+  const bool user_stream = sl.stream == nullptr;
+  bool capturing = false;
+  if (user_stream && stream) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) == hipSuccess) capturing = cs != hipStreamCaptureStatusNone;
+    else (void)hipGetLastError();
+  }
+  if (user_stream && !capturing && sl.has_last && sl.last_stream != stream)
+    HIP_TRY(hipStreamWaitEvent(stream, sl.last_event, 0)); // launches of one slot share its ticket counter: serialise
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (S->timing) {
+  if (S->timing && !capturing) {
+    std::lock_guard<std::mutex> lk(S->timing_mu);
     auto get = [&](hipEvent_t &e) -> hipError_t {
       if (!S->pool.empty()) { e = S->pool.back(); S->pool.pop_back(); return hipSuccess; }
       return hipEventCreate(&e);
@@ -169,28 +220,33 @@ static int launch(qpc_controller *c, const QpcBatchArgs &a, hipStream_t stream) 
     HIP_TRY(hipEventRecord(e0, stream));
   }
   QpcBatchArgs aa = a;
-  aa.ticket = S->d_ticket;
-  aa.ticket_base = S->ticket_next;
-  S->ticket_next += (unsigned long long)a.B + (unsigned long long)grid;
-  aa.scratch = S->d_scratch;
-  if (S->jit_func) {
+  aa.ticket = sl.d_ticket;
+  aa.scratch = sl.d_scratch;
+  hipFunction_t fn = warm ? S->jit_warm_func : S->jit_func;
+  if (warm && !fn) { qpc_set_error("warm-start kernel not available (qpc_enable_warm_start before qpc_finalize; needs the hiprtc-specialised kernel)"); return QPC_ERR_UNSUPPORTED; }
+  if (!warm) aa.wsets = nullptr;
+  if (fn) {
     const int *it = S->d_it;
     const double *dt = S->d_dt;
     void *args[] = {(void *)&it, (void *)&dt, (void *)&aa};
-    HIP_TRY(hipModuleLaunchKernel(S->jit_func, (unsigned)grid, 1, 1, 64, 1, 1, 0, stream, args, nullptr));
+    HIP_TRY(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 64, 1, 1, 0, stream, args, nullptr));
   } else {
     hipLaunchKernelGGL(qpc_tick_kernel, dim3((unsigned)grid), dim3(64), lds, stream, D, S->d_it, S->d_dt, aa);
     HIP_TRY(hipGetLastError());
   }
-  if (S->timing) {
+  if (e0) {
     HIP_TRY(hipEventRecord(e1, stream));
+    std::lock_guard<std::mutex> lk(S->timing_mu);
     S->events.emplace_back(e0, e1);
+  }
+  if (user_stream && !capturing) {
+    HIP_TRY(hipEventRecord(sl.last_event, stream));
+    sl.last_stream = stream; sl.has_last = true;
   }
   return QPC_OK;
 }
 
-static int launch_sim(qpc_controller *c, const QpcSimArgs &a, hipStream_t stream) {
-  QpcDeviceState *S = c->dev;
+static int launch_sim(qpc_controller *c, QpcDeviceState *S, const QpcSimArgs &a, hipStream_t stream) {
   const QpcDims &D = c->prog.dims;
   long long grid = (long long)S->n_cu * S->sim_blocks_per_cu;
   if (grid > a.B) grid = a.B;
@@ -209,73 +265,275 @@ static int launch_sim(qpc_controller *c, const QpcSimArgs &a, hipStream_t stream
   return QPC_OK;
 }
 
+static void destroy_device_state(QpcDeviceState *S) {
+  if (!S) return;
+  (void)hipSetDevice(S->device);
+  for (auto &sl : S->slots) {
+    if (sl.stream) (void)hipStreamSynchronize(sl.stream);
+    if (sl.has_last) (void)hipEventSynchronize(sl.last_event);
+  }
+  for (auto &p : S->events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+  for (auto &e : S->pool) (void)hipEventDestroy(e);
+  for (auto &sl : S->slots) {
+    if (sl.d_ticket) (void)hipFree(sl.d_ticket);
+    if (sl.d_scratch) (void)hipFree(sl.d_scratch);
+    if (sl.d_stage) (void)hipFree(sl.d_stage);
+    if (sl.h_stage) (void)hipHostFree(sl.h_stage);
+    if (sl.last_event) (void)hipEventDestroy(sl.last_event);
+    if (sl.stream) (void)hipStreamDestroy(sl.stream);
+  }
+  if (S->d_it) (void)hipFree(S->d_it);
+  if (S->d_dt) (void)hipFree(S->d_dt);
+  if (S->l1_buf) (void)hipFree(S->l1_buf);
+  if (S->roll_buf) (void)hipFree(S->roll_buf);
+  if (S->roll_ws) (void)hipFree(S->roll_ws);
+  if (S->jit_module) (void)hipModuleUnload(S->jit_module);
+  delete S;
+}
+
+// program upload + per-slot resources + kernel modules of ONE device.  `code` = the hiprtc code object of the
+// controller (empty: generic kernel).  On any failure everything allocated so far is released by the caller
+// through destroy_device_state (S is always left in a destructible state).
+static int init_device_state(qpc_controller *c, QpcDeviceState *S, int device_id, int n_slots, const std::vector<char> &code,
+                             const hipDeviceProp_t &prop) {
+  const QpcDims &D = c->prog.dims;
+  S->device = device_id;
+  HIP_TRY(hipSetDevice(device_id));
+  S->n_cu = prop.multiProcessorCount;
+  const size_t lds = (size_t)D.lds_doubles * sizeof(double);
+  if (lds > 160 * 1024) { qpc_set_error("qpc_finalize: LDS slab exceeds the device limit"); return QPC_ERR_UNSUPPORTED; }
+  const size_t slds = (size_t)qpc_sim_layout(D).total * sizeof(double);
+  if (slds > 160 * 1024) { qpc_set_error("qpc_finalize: simulation LDS slab exceeds the device limit"); return QPC_ERR_UNSUPPORTED; }
+  {
+    std::lock_guard<std::mutex> lk(g_attr_mu);
+    if (lds > g_tick_lds_max) g_tick_lds_max = lds;
+    if (slds > g_sim_lds_max) g_sim_lds_max = slds;
+    HIP_TRY(hipFuncSetAttribute((const void *)qpc_tick_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_tick_lds_max));
+    HIP_TRY(hipFuncSetAttribute((const void *)qpc_sim_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_sim_lds_max));
+  }
+  int per_cu = (int)((160 * 1024) / (lds > 0 ? lds : 1));
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu > 16) per_cu = 16; // 32 waves/CU cap; leave room for registers
+  S->blocks_per_cu = per_cu;
+  int sper = (int)((160 * 1024) / (slds > 0 ? slds : 1));
+  S->sim_blocks_per_cu = sper < 1 ? 1 : (sper > 8 ? 8 : sper);
+  HIP_TRY(hipMalloc(&S->d_it, sizeof(int) * c->prog.itab.size()));
+  HIP_TRY(hipMalloc(&S->d_dt, sizeof(double) * c->prog.dtab.size()));
+  HIP_TRY(hipMemcpy(S->d_it, c->prog.itab.data(), sizeof(int) * c->prog.itab.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(S->d_dt, c->prog.dtab.data(), sizeof(double) * c->prog.dtab.size(), hipMemcpyHostToDevice));
+  S->slots.resize((size_t)n_slots + 2);
+  for (size_t i = 0; i < S->slots.size(); i++) {
+    QpcSlot &sl = S->slots[i];
+    if (i + 1 < S->slots.size()) HIP_TRY(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+    else HIP_TRY(hipEventCreateWithFlags(&sl.last_event, hipEventDisableTiming));
+    HIP_TRY(hipMalloc(&sl.d_ticket, sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(sl.d_ticket, 0, sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&sl.d_scratch, sizeof(double) * QPC_SCRATCH_DOUBLES * (size_t)S->n_cu * S->blocks_per_cu));
+  }
+  if (!code.empty()) {
+    if (hipModuleLoadData(&S->jit_module, code.data()) == hipSuccess &&
+        hipModuleGetFunction(&S->jit_func, S->jit_module, "qpc_tick_kernel_jit") == hipSuccess) {
+      if (hipModuleGetFunction(&S->jit_sim_func, S->jit_module, "qpc_sim_kernel_jit") != hipSuccess) S->jit_sim_func = nullptr;
+      if (!c->warm_start || hipModuleGetFunction(&S->jit_warm_func, S->jit_module, "qpc_tick_kernel_jit_warm") != hipSuccess) S->jit_warm_func = nullptr;
+      (void)hipGetLastError();
+    } else {
+      (void)hipGetLastError();
+      S->jit_func = nullptr; S->jit_sim_func = nullptr; S->jit_warm_func = nullptr;
+      qpc_set_error("loading the hiprtc code object failed");
+      return QPC_ERR_HIP;
+    }
+  }
+  return QPC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// HIP backend of the host-pointer pipeline (qpc_pipeline.h): one chunk = stage in, tick kernel, stage out
+static inline size_t pad64(size_t b) { return (b + 63) & ~(size_t)63; }
+
+class QpcHipBackend : public QpcChunkBackend {
+ public:
+  explicit QpcHipBackend(qpc_controller *c) : c_(c) {}
+  int n_devices() const override { return (int)c_->rt->devs.size(); }
+  void bind_thread(int d) override { (void)hipSetDevice(c_->rt->devs[d]->device); }
+  int run_chunk(int d, int slot, const QpcHostJob &job, int64_t lo, int64_t n, std::string &err) override {
+    const int rc = run(d, slot, job, lo, n);
+    if (rc != QPC_OK) err = qpc_last_error(); // thread-local of THIS worker thread -> handed to the waiting caller
+    return rc;
+  }
+
+ private:
+  int run(int d, int slot, const QpcHostJob &job, int64_t lo, int64_t n) {
+    QpcDeviceState *S = c_->rt->devs[d];
+    QpcSlot &sl = S->slots[slot];
+    const QpcDims &D = c_->prog.dims;
+    // staging slab: [inputs | outputs | status | iters | working sets], every array 64-byte aligned
+    size_t in_off[QpcHostJob::N_IN], out_off[QpcHostJob::N_OUT], off = 0;
+    bool all_in_pageable = true, any_in_pageable = false, any_out_pageable = false, all_out_pageable = true;
+    for (int i = 0; i < QpcHostJob::N_IN; i++) {
+      in_off[i] = off;
+      const size_t bytes = job.in[i] ? job.in_dim[i] * (size_t)n * sizeof(double) : 0;
+      off += pad64(bytes);
+      if (bytes) { if (job.in_pinned[i]) all_in_pageable = false; else any_in_pageable = true; }
+    }
+    const size_t in_end = off;
+    // the kernel always writes tau, vdot, status; cwrench and iters only when the caller wants them
+    for (int i = 0; i < QpcHostJob::N_OUT; i++) {
+      out_off[i] = off;
+      const size_t bytes = (job.out[i] || i != QpcHostJob::OUT_CWRENCH) ? job.out_dim[i] * (size_t)n * sizeof(double) : 0;
+      off += pad64(bytes);
+      if (job.out[i] && job.out_dim[i]) { if (job.out_pinned[i]) all_out_pageable = false; else any_out_pageable = true; }
+    }
+    const size_t st_off = off; off += pad64((size_t)n * sizeof(int32_t));
+    const size_t it_off = off; off += pad64(job.iters ? (size_t)n * sizeof(int32_t) : 0);
+    const size_t ws_off = off; off += pad64(job.working_set ? 2 * (size_t)n * sizeof(uint64_t) : 0);
+    const size_t out_end = off;
+    if (job.status_pinned) all_out_pageable = false; else any_out_pageable = true;
+    if (job.iters) { if (job.iters_pinned) all_out_pageable = false; else any_out_pageable = true; }
+    if (job.working_set) { if (job.ws_pinned) { all_out_pageable = false; all_in_pageable = false; } else { any_out_pageable = true; any_in_pageable = true; } }
+    if (off > sl.d_stage_bytes) {
+      if (sl.d_stage) HIP_TRY(hipFree(sl.d_stage));
+      sl.d_stage = nullptr; sl.d_stage_bytes = 0;
+      HIP_TRY(hipMalloc(&sl.d_stage, off));
+      sl.d_stage_bytes = off;
+    }
+    if ((any_in_pageable || any_out_pageable) && off > sl.h_stage_bytes) {
+      if (sl.h_stage) HIP_TRY(hipHostFree(sl.h_stage));
+      sl.h_stage = nullptr; sl.h_stage_bytes = 0;
+      HIP_TRY(hipHostMalloc(&sl.h_stage, off, hipHostMallocDefault));
+      sl.h_stage_bytes = off;
+    }
+    hipStream_t st = sl.stream;
+    // ---- inputs
+    for (int i = 0; i < QpcHostJob::N_IN; i++) {
+      const size_t bytes = job.in[i] ? job.in_dim[i] * (size_t)n * sizeof(double) : 0;
+      if (!bytes) continue;
+      const double *src = job.in[i] + (size_t)lo * job.in_dim[i];
+      if (job.in_pinned[i]) HIP_TRY(hipMemcpyAsync(sl.d_stage + in_off[i], src, bytes, hipMemcpyHostToDevice, st));
+      else {
+        std::memcpy(sl.h_stage + in_off[i], src, bytes);
+        if (!all_in_pageable) HIP_TRY(hipMemcpyAsync(sl.d_stage + in_off[i], sl.h_stage + in_off[i], bytes, hipMemcpyHostToDevice, st));
+      }
+    }
+    if (job.working_set) {
+      const size_t bytes = 2 * (size_t)n * sizeof(uint64_t);
+      const uint64_t *src = job.working_set + 2 * (size_t)lo;
+      if (job.ws_pinned) HIP_TRY(hipMemcpyAsync(sl.d_stage + ws_off, src, bytes, hipMemcpyHostToDevice, st));
+      else { std::memcpy(sl.h_stage + ws_off, src, bytes); HIP_TRY(hipMemcpyAsync(sl.d_stage + ws_off, sl.h_stage + ws_off, bytes, hipMemcpyHostToDevice, st)); }
+    }
+    if (all_in_pageable && in_end) // every input went through the pinned slab: ONE DMA for the whole input region
+      HIP_TRY(hipMemcpyAsync(sl.d_stage, sl.h_stage, in_end, hipMemcpyHostToDevice, st));
+    // ---- kernel
+    auto din = [&](int i) { return job.in[i] ? (const double *)(sl.d_stage + in_off[i]) : nullptr; };
+    QpcBatchArgs a;
+    a.B = n;
+    a.q = din(QpcHostJob::IN_Q); a.v = din(QpcHostJob::IN_V); a.desired = din(QpcHostJob::IN_DES);
+    a.cw = din(QpcHostJob::IN_CW); a.cmax = din(QpcHostJob::IN_CMAX); a.tw = din(QpcHostJob::IN_TW); a.surf = din(QpcHostJob::IN_SURF);
+    a.tau = (double *)(sl.d_stage + out_off[QpcHostJob::OUT_TAU]); a.vdot = (double *)(sl.d_stage + out_off[QpcHostJob::OUT_VDOT]);
+    a.cwrench = (D.nc && job.out[QpcHostJob::OUT_CWRENCH]) ? (double *)(sl.d_stage + out_off[QpcHostJob::OUT_CWRENCH]) : nullptr;
+    a.status = (int32_t *)(sl.d_stage + st_off);
+    a.iters = job.iters ? (int32_t *)(sl.d_stage + it_off) : nullptr;
+    a.wsets = job.working_set ? (unsigned long long *)(sl.d_stage + ws_off) : nullptr;
+    a.prof = nullptr;
+    int rc = launch(c_, S, sl, a, st, job.working_set != nullptr);
+    if (rc != QPC_OK) return rc;
+    // ---- outputs
+    if (all_out_pageable) {
+      HIP_TRY(hipMemcpyAsync(sl.h_stage + in_end, sl.d_stage + in_end, out_end - in_end, hipMemcpyDeviceToHost, st)); // ONE DMA
+    } else {
+      for (int i = 0; i < QpcHostJob::N_OUT; i++) {
+        const size_t bytes = job.out_dim[i] * (size_t)n * sizeof(double);
+        if (!job.out[i] || !bytes) continue;
+        void *dst = job.out_pinned[i] ? (void *)(job.out[i] + (size_t)lo * job.out_dim[i]) : (void *)(sl.h_stage + out_off[i]);
+        HIP_TRY(hipMemcpyAsync(dst, sl.d_stage + out_off[i], bytes, hipMemcpyDeviceToHost, st));
+      }
+      HIP_TRY(hipMemcpyAsync(job.status_pinned ? (void *)(job.status + lo) : (void *)(sl.h_stage + st_off), sl.d_stage + st_off,
+                             (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      if (job.iters)
+        HIP_TRY(hipMemcpyAsync(job.iters_pinned ? (void *)(job.iters + lo) : (void *)(sl.h_stage + it_off), sl.d_stage + it_off,
+                               (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      if (job.working_set)
+        HIP_TRY(hipMemcpyAsync(job.ws_pinned ? (void *)(job.working_set + 2 * (size_t)lo) : (void *)(sl.h_stage + ws_off), sl.d_stage + ws_off,
+                               2 * (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int i = 0; i < QpcHostJob::N_OUT; i++) {
+      const size_t bytes = job.out_dim[i] * (size_t)n * sizeof(double);
+      if (job.out[i] && bytes && !job.out_pinned[i]) std::memcpy(job.out[i] + (size_t)lo * job.out_dim[i], sl.h_stage + out_off[i], bytes);
+    }
+    if (!job.status_pinned) std::memcpy(job.status + lo, sl.h_stage + st_off, (size_t)n * sizeof(int32_t));
+    if (job.iters && !job.iters_pinned) std::memcpy(job.iters + lo, sl.h_stage + it_off, (size_t)n * sizeof(int32_t));
+    if (job.working_set && !job.ws_pinned) std::memcpy(job.working_set + 2 * (size_t)lo, sl.h_stage + ws_off, 2 * (size_t)n * sizeof(uint64_t));
+    return QPC_OK;
+  }
+  qpc_controller *c_;
+};
+
+// is `p` page-locked host memory HIP can DMA from / to directly (hipHostMalloc, hipHostRegister, torch pin_memory)?
+static bool host_pinned(const void *p) {
+  if (!p) return false;
+  hipPointerAttribute_t at;
+  std::memset(&at, 0, sizeof(at));
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return at.type == hipMemoryTypeHost;
+}
+
+static int fill_job(qpc_controller *c, QpcHostJob &job, int64_t B, const double *q, const double *v, const double *desired,
+                    const double *cw, const double *cmax, const double *tw, const double *surf, double *tau, double *vdot,
+                    double *cwrench, int32_t *status, int32_t *iters, uint64_t *wsets, const char *who) {
+  if (!c || !c->finalized || !c->rt) { qpc_set_error("controller not finalized"); return QPC_ERR_NOT_FINALIZED; }
+  const QpcDims &D = c->prog.dims;
+  if (B < 0 || !q || !v || !tau || !vdot || !status || (D.n_des_inputs && !desired) || (D.nc && (!cw || !cmax)) ||
+      (D.n_tw && !tw) || (D.n_surf && !surf)) {
+    qpc_set_error(std::string(who) + ": missing array"); return QPC_ERR_INVALID_ARGUMENT;
+  }
+  job.B = B;
+  const double *hin[QpcHostJob::N_IN] = {q, v, desired, D.nc ? cw : nullptr, D.nc ? cmax : nullptr, D.n_tw ? tw : nullptr, D.n_surf ? surf : nullptr};
+  const size_t nin[QpcHostJob::N_IN] = {(size_t)D.nq, (size_t)D.nv, (size_t)D.n_desired, (size_t)D.nc, (size_t)D.nc, (size_t)D.n_tw, (size_t)D.n_surf};
+  for (int i = 0; i < QpcHostJob::N_IN; i++) { job.in[i] = nin[i] ? hin[i] : nullptr; job.in_dim[i] = nin[i]; job.in_pinned[i] = job.in[i] && host_pinned(job.in[i]); }
+  double *hout[QpcHostJob::N_OUT] = {tau, vdot, D.nc ? cwrench : nullptr};
+  const size_t nout[QpcHostJob::N_OUT] = {(size_t)D.nv, (size_t)D.nv, (size_t)6 * D.nc};
+  for (int i = 0; i < QpcHostJob::N_OUT; i++) { job.out[i] = hout[i]; job.out_dim[i] = nout[i]; job.out_pinned[i] = job.out[i] && host_pinned(job.out[i]); }
+  job.status = status; job.iters = iters; job.working_set = wsets;
+  job.status_pinned = host_pinned(status); job.iters_pinned = iters && host_pinned(iters); job.ws_pinned = wsets && host_pinned(wsets);
+  return QPC_OK;
+}
+
 extern "C" {
 
-int32_t qpc_finalize(qpc_controller *c, int32_t device_id, qpc_layout *out) {
-  if (!c) return QPC_ERR_INVALID_ARGUMENT;
+int32_t qpc_finalize_devices(qpc_controller *c, int32_t n_devices, const int32_t *device_ids, qpc_layout *out) {
+  if (!c || n_devices < 1 || !device_ids) { qpc_set_error("qpc_finalize_devices: bad arguments"); return QPC_ERR_INVALID_ARGUMENT; }
   if (c->finalized) { if (out) *out = c->layout; return QPC_OK; }
   int rc = qpc_compile_program(c);
   if (rc != QPC_OK) return rc;
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0) {
+    (void)hipGetLastError();
     qpc_set_error("qpc_finalize: no HIP device available (this library has no CPU fallback)");
     return QPC_ERR_NO_DEVICE;
   }
-  if (device_id < 0 || device_id >= ndev) { qpc_set_error("qpc_finalize: device_id out of range"); return QPC_ERR_NO_DEVICE; }
-  HIP_TRY(hipSetDevice(device_id));
-  QpcDeviceState *S = new QpcDeviceState();
-  S->device = device_id;
+  for (int i = 0; i < n_devices; i++) {
+    if (device_ids[i] < 0 || device_ids[i] >= ndev) { qpc_set_error("qpc_finalize: device_id out of range"); return QPC_ERR_NO_DEVICE; }
+    for (int j = 0; j < i; j++) if (device_ids[j] == device_ids[i]) { qpc_set_error("qpc_finalize_devices: duplicate device id"); return QPC_ERR_INVALID_ARGUMENT; }
+  }
   const QpcDims &D = c->prog.dims;
-  hipDeviceProp_t prop;
-  HIP_TRY(hipGetDeviceProperties(&prop, device_id));
-  S->n_cu = prop.multiProcessorCount;
-  size_t lds = (size_t)D.lds_doubles * sizeof(double);
-  if (lds > (size_t)prop.maxSharedMemoryPerMultiProcessor && lds > 160 * 1024) {
-    delete S; qpc_set_error("qpc_finalize: LDS slab exceeds the device limit"); return QPC_ERR_UNSUPPORTED;
-  }
-  HIP_TRY(hipFuncSetAttribute((const void *)qpc_tick_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  int per_cu = (int)((160 * 1024) / (lds > 0 ? lds : 1));
-  if (per_cu < 1) per_cu = 1;
-  if (per_cu > 16) per_cu = 16; // 32 waves/CU cap; leave room for registers
-  S->blocks_per_cu = per_cu;
-  {
-    const size_t slds = (size_t)qpc_sim_layout(D).total * sizeof(double);
-    if (slds > 160 * 1024) { delete S; qpc_set_error("qpc_finalize: simulation LDS slab exceeds the device limit"); return QPC_ERR_UNSUPPORTED; }
-    HIP_TRY(hipFuncSetAttribute((const void *)qpc_sim_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
-    int sper = (int)((160 * 1024) / (slds > 0 ? slds : 1));
-    S->sim_blocks_per_cu = sper < 1 ? 1 : (sper > 8 ? 8 : sper);
-  }
-  HIP_TRY(hipMalloc(&S->d_it, sizeof(int) * c->prog.itab.size()));
-  HIP_TRY(hipMalloc(&S->d_dt, sizeof(double) * c->prog.dtab.size()));
-  HIP_TRY(hipMemcpy(S->d_it, c->prog.itab.data(), sizeof(int) * c->prog.itab.size(), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(S->d_dt, c->prog.dtab.data(), sizeof(double) * c->prog.dtab.size(), hipMemcpyHostToDevice));
-  HIP_TRY(hipStreamCreate(&S->stream));
-  HIP_TRY(hipMalloc(&S->d_ticket, sizeof(unsigned long long)));
-  HIP_TRY(hipMemset(S->d_ticket, 0, sizeof(unsigned long long)));
-  HIP_TRY(hipMalloc(&S->d_scratch, sizeof(double) * QPC_SCRATCH_DOUBLES * (size_t)S->n_cu * S->blocks_per_cu));
-  // JIT specialisation on this controller's program (QPC_DISABLE_JIT=1 keeps the generic kernel)
+  hipDeviceProp_t prop0;
+  HIP_TRY(hipGetDeviceProperties(&prop0, device_ids[0]));
+  // JIT specialisation on this controller's program, once for all devices (QPC_DISABLE_JIT=1 keeps the generic kernel)
+  std::vector<char> code;
   const char *nojit = getenv("QPC_DISABLE_JIT");
-  if (nojit && nojit[0] == '1' && D.maxdepth > QPC_GENERIC_MAXD) {
+  const bool jit_off = nojit && nojit[0] == '1';
+  if (jit_off && D.maxdepth > QPC_GENERIC_MAXD) {
     qpc_set_error("QPC_DISABLE_JIT=1 but the tree is deeper than the generic kernel supports");
     return QPC_ERR_UNSUPPORTED;
   }
-  if (!(nojit && nojit[0] == '1')) {
-    std::vector<char> code;
+  if (!jit_off) {
     std::string log;
-    std::string arch = prop.gcnArchName;
-    int jrc = qpc_jit_compile(D, arch, code, log);
-    if (jrc == 0 && hipModuleLoadData(&S->jit_module, code.data()) == hipSuccess &&
-        hipModuleGetFunction(&S->jit_func, S->jit_module, "qpc_tick_kernel_jit") == hipSuccess) {
-      // specialised kernel ready; the simulation step of the same module (optional)
-      if (hipModuleGetFunction(&S->jit_sim_func, S->jit_module, "qpc_sim_kernel_jit") != hipSuccess) S->jit_sim_func = nullptr;
-    } else {
-      S->jit_func = nullptr; S->jit_sim_func = nullptr;
+    const int jrc = qpc_jit_compile(D, prop0.gcnArchName, c->warm_start != 0, code, log);
+    if (jrc != 0) {
+      code.clear();
       const char *strict = getenv("QPC_REQUIRE_JIT");
-      if (strict && strict[0] == '1') {
-        qpc_set_error("JIT specialisation failed: " + log);
-        return QPC_ERR_HIP;
-      }
+      if (strict && strict[0] == '1') { qpc_set_error("JIT specialisation failed: " + log); return QPC_ERR_HIP; }
       if (D.maxdepth > QPC_GENERIC_MAXD) {
         qpc_set_error("JIT specialisation failed and the tree is deeper than the generic kernel supports: " + log);
         return QPC_ERR_UNSUPPORTED;
@@ -283,103 +541,190 @@ int32_t qpc_finalize(qpc_controller *c, int32_t device_id, qpc_layout *out) {
       fprintf(stderr, "[qpc] JIT specialisation unavailable (%s); using the generic gfx950 kernel\n", log.c_str());
     }
   }
-  c->dev = S;
+  QpcRuntime *rt = new QpcRuntime();
+  rt->slots = c->pipe_slots > 0 ? c->pipe_slots : 3;
+  if (const char *es = getenv("QPC_HOST_SLOTS")) { const int v = atoi(es); if (v >= 1 && v <= 16) rt->slots = v; }
+  auto fail = [&](int code_) { for (auto *S : rt->devs) destroy_device_state(S); delete rt; return code_; };
+  for (int i = 0; i < n_devices; i++) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_ids[i]) != hipSuccess) { qpc_set_error("hipGetDeviceProperties failed"); return fail(QPC_ERR_HIP); }
+    if (std::string(prop.gcnArchName) != std::string(prop0.gcnArchName)) { qpc_set_error("qpc_finalize_devices: devices of different architectures"); return fail(QPC_ERR_UNSUPPORTED); }
+    QpcDeviceState *S = new QpcDeviceState();
+    rt->devs.push_back(S); // owned by rt from here on: released by fail() on any error below
+    rc = init_device_state(c, S, device_ids[i], rt->slots, code, prop);
+    if (rc != QPC_OK) {
+      const char *strict = getenv("QPC_REQUIRE_JIT");
+      if (!code.empty() && rc == QPC_ERR_HIP && !(strict && strict[0] == '1') && D.maxdepth <= QPC_GENERIC_MAXD && !S->jit_func) {
+        // code object would not load: fall back to the generic gfx950 kernel on every device
+        fprintf(stderr, "[qpc] JIT code object unusable (%s); using the generic gfx950 kernel\n", qpc_last_error());
+        for (auto *T : rt->devs) destroy_device_state(T);
+        rt->devs.clear(); code.clear(); i = -1;
+        continue;
+      }
+      return fail(rc);
+    }
+  }
+  HIP_TRY(hipSetDevice(device_ids[0]));
+  c->rt = rt;
+  rt->backend = new QpcHipBackend(c);
+  int64_t chunk = c->pipe_chunk > 0 ? c->pipe_chunk : 8192, inl = c->pipe_inline >= 0 ? c->pipe_inline : 2048;
+  if (const char *ec = getenv("QPC_HOST_CHUNK")) { const long long v = atoll(ec); if (v >= 1) chunk = v; }
+  rt->pipe = new QpcHostPipeline(rt->backend, rt->slots, chunk, inl);
   c->finalized = true;
   if (out) *out = c->layout;
   return QPC_OK;
 }
 
+int32_t qpc_finalize(qpc_controller *c, int32_t device_id, qpc_layout *out) {
+  return qpc_finalize_devices(c, 1, &device_id, out);
+}
+
+int32_t qpc_n_devices(const qpc_controller *c) { return (c && c->rt) ? (int32_t)c->rt->devs.size() : 0; }
+
+int32_t qpc_set_host_pipeline(qpc_controller *c, int64_t chunk_qps, int32_t slots_per_device, int64_t inline_qps) {
+  if (!c) return QPC_ERR_INVALID_ARGUMENT;
+  if (slots_per_device > 0) {
+    if (c->finalized) { qpc_set_error("qpc_set_host_pipeline: the number of slots is fixed by qpc_finalize"); return QPC_ERR_ALREADY_FINALIZED; }
+    if (slots_per_device > 16) { qpc_set_error("qpc_set_host_pipeline: at most 16 slots per device"); return QPC_ERR_INVALID_ARGUMENT; }
+    c->pipe_slots = slots_per_device;
+  }
+  if (chunk_qps > 0) c->pipe_chunk = chunk_qps;
+  if (inline_qps >= 0) c->pipe_inline = inline_qps;
+  if (c->rt && c->rt->pipe) {
+    std::string e;
+    (void)c->rt->pipe->wait(e);
+    if (chunk_qps > 0) c->rt->pipe->set_chunk_qps(chunk_qps);
+    if (inline_qps >= 0) c->rt->pipe->set_inline_qps(inline_qps);
+  }
+  return QPC_OK;
+}
+
+void *qpc_host_alloc(uint64_t bytes) {
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes ? (size_t)bytes : 1, hipHostMallocDefault | hipHostMallocPortable) != hipSuccess) {
+    hip_fail(hipGetLastError(), "hipHostMalloc");
+    return nullptr;
+  }
+  return p;
+}
+void qpc_host_free(void *p) { if (p) (void)hipHostFree(p); }
+int32_t qpc_host_register(void *p, uint64_t bytes) {
+  if (!p || !bytes) return QPC_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipHostRegister(p, (size_t)bytes, hipHostRegisterDefault | hipHostRegisterPortable));
+  return QPC_OK;
+}
+int32_t qpc_host_unregister(void *p) {
+  if (!p) return QPC_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipHostUnregister(p));
+  return QPC_OK;
+}
+
 void qpc_controller_destroy(qpc_controller *c) {
   if (!c) return;
-  if (c->dev) {
-    QpcDeviceState *S = c->dev;
-    (void)hipSetDevice(S->device);
-    if (S->stream) (void)hipStreamSynchronize(S->stream);
-    for (auto &p : S->events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-    for (auto &e : S->pool) (void)hipEventDestroy(e);
-    if (S->d_it) (void)hipFree(S->d_it);
-    if (S->d_dt) (void)hipFree(S->d_dt);
-    if (S->stage) (void)hipFree(S->stage);
-    if (S->d_ticket) (void)hipFree(S->d_ticket);
-    if (S->d_scratch) (void)hipFree(S->d_scratch);
-    if (S->stream) (void)hipStreamDestroy(S->stream);
-    if (S->jit_module) (void)hipModuleUnload(S->jit_module);
-    delete S;
+  if (c->rt) {
+    QpcRuntime *rt = c->rt;
+    delete rt->pipe; // joins the workers after the job in flight (if any)
+    delete rt->backend;
+    for (auto *S : rt->devs) destroy_device_state(S);
+    delete rt;
   }
   delete c;
+}
+
+static int control_device(qpc_controller *c, int device_index, int64_t B, const double *q, const double *v, const double *desired,
+                          const double *cw, const double *cmax, const double *tw, const double *surf, double *tau, double *vdot,
+                          double *cwrench, int32_t *status, int32_t *iters, unsigned long long *wsets, void *hip_stream,
+                          const char *who) {
+  if (!c || !c->finalized || !c->rt) { qpc_set_error("controller not finalized"); return QPC_ERR_NOT_FINALIZED; }
+  if (device_index < 0 || device_index >= (int)c->rt->devs.size()) { qpc_set_error(std::string(who) + ": device index out of range"); return QPC_ERR_INVALID_ARGUMENT; }
+  const QpcDims &D = c->prog.dims;
+  if (B < 0 || !q || !v || !tau || !vdot || !status || (D.n_des_inputs && !desired) || (D.nc && (!cw || !cmax)) ||
+      (D.n_tw && !tw) || (D.n_surf && !surf)) {
+    qpc_set_error(std::string(who) + ": missing array"); return QPC_ERR_INVALID_ARGUMENT;
+  }
+  QpcDeviceState *S = c->rt->devs[device_index];
+  QpcBatchArgs a;
+  a.B = B; a.q = q; a.v = v; a.desired = desired; a.cw = cw; a.cmax = cmax; a.tw = tw; a.surf = surf;
+  a.tau = tau; a.vdot = vdot; a.cwrench = cwrench; a.status = status; a.iters = iters;
+  a.prof = S->prof; a.wsets = wsets;
+  HIP_TRY(hipSetDevice(S->device));
+  return launch(c, S, S->slots[c->rt->user_slot()], a, (hipStream_t)hip_stream, wsets != nullptr);
 }
 
 int32_t qpc_control_batch_device(qpc_controller *c, int64_t B, const double *q, const double *v,
                                  const double *desired, const double *cw, const double *cmax, const double *tw,
                                  const double *surf, double *tau, double *vdot, double *cwrench, int32_t *status,
                                  int32_t *iters, void *hip_stream) {
-  if (!c || !c->finalized || !c->dev) { qpc_set_error("controller not finalized"); return QPC_ERR_NOT_FINALIZED; }
-  const QpcDims &D = c->prog.dims;
-  if (B < 0 || !q || !v || !tau || !vdot || !status || (D.n_des_inputs && !desired) || (D.nc && (!cw || !cmax)) ||
-      (D.n_tw && !tw) || (D.n_surf && !surf)) {
-    qpc_set_error("qpc_control_batch_device: missing array"); return QPC_ERR_INVALID_ARGUMENT;
-  }
-  QpcBatchArgs a;
-  a.B = B; a.q = q; a.v = v; a.desired = desired; a.cw = cw; a.cmax = cmax; a.tw = tw; a.surf = surf;
-  a.tau = tau; a.vdot = vdot; a.cwrench = cwrench; a.status = status; a.iters = iters;
-  a.prof = c->dev->prof;
-  HIP_TRY(hipSetDevice(c->dev->device));
-  return launch(c, a, (hipStream_t)hip_stream);
+  return control_device(c, 0, B, q, v, desired, cw, cmax, tw, surf, tau, vdot, cwrench, status, iters, nullptr, hip_stream,
+                        "qpc_control_batch_device");
+}
+
+int32_t qpc_control_batch_device_on(qpc_controller *c, int32_t device_index, int64_t B, const double *q, const double *v,
+                                    const double *desired, const double *cw, const double *cmax, const double *tw,
+                                    const double *surf, double *tau, double *vdot, double *cwrench, int32_t *status,
+                                    int32_t *iters, void *hip_stream) {
+  return control_device(c, device_index, B, q, v, desired, cw, cmax, tw, surf, tau, vdot, cwrench, status, iters, nullptr,
+                        hip_stream, "qpc_control_batch_device_on");
+}
+
+int32_t qpc_control_batch_device_warm(qpc_controller *c, int32_t device_index, int64_t B, const double *q, const double *v,
+                                      const double *desired, const double *cw, const double *cmax, const double *tw,
+                                      const double *surf, double *tau, double *vdot, double *cwrench, int32_t *status,
+                                      int32_t *iters, uint64_t *working_set, void *hip_stream) {
+  if (!working_set) { qpc_set_error("qpc_control_batch_device_warm: working_set missing"); return QPC_ERR_INVALID_ARGUMENT; }
+  return control_device(c, device_index, B, q, v, desired, cw, cmax, tw, surf, tau, vdot, cwrench, status, iters,
+                        (unsigned long long *)working_set, hip_stream, "qpc_control_batch_device_warm");
+}
+
+static int host_wait(qpc_controller *c) {
+  std::string err;
+  const int rc = c->rt->pipe->wait(err);
+  if (rc != QPC_OK) qpc_set_error(err);
+  return rc;
 }
 
 int32_t qpc_control_batch(qpc_controller *c, int64_t B, const double *q, const double *v, const double *desired,
                           const double *cw, const double *cmax, const double *tw, const double *surf, double *tau,
                           double *vdot, double *cwrench, int32_t *status, int32_t *iters) {
-  if (!c || !c->finalized || !c->dev) { qpc_set_error("controller not finalized"); return QPC_ERR_NOT_FINALIZED; }
-  const QpcDims &D = c->prog.dims;
-  QpcDeviceState *S = c->dev;
-  if (B < 0 || !q || !v || !tau || !vdot || !status || (D.n_des_inputs && !desired) || (D.nc && (!cw || !cmax)) ||
-      (D.n_tw && !tw) || (D.n_surf && !surf)) {
-    qpc_set_error("qpc_control_batch: missing array"); return QPC_ERR_INVALID_ARGUMENT;
-  }
-  if (B == 0) return QPC_OK;
-  HIP_TRY(hipSetDevice(S->device));
-  // one staging slab: [q v desired cw cmax tw surf | tau vdot cwrench | status iters]
-  size_t nin[7] = {(size_t)D.nq, (size_t)D.nv, desired ? (size_t)D.n_desired : 0, (size_t)D.nc, (size_t)D.nc, (size_t)D.n_tw, (size_t)D.n_surf};
-  const double *hin[7] = {q, v, desired, cw, cmax, tw, surf};
-  size_t nout[3] = {(size_t)D.nv, (size_t)D.nv, (size_t)6 * D.nc};
-  double *hout[3] = {tau, vdot, cwrench};
-  size_t total = 0;
-  for (int i = 0; i < 7; i++) total += nin[i] * B * sizeof(double);
-  for (int i = 0; i < 3; i++) total += nout[i] * B * sizeof(double);
-  total += 2 * B * sizeof(int32_t) + 64;
-  if (total > S->stage_bytes) {
-    if (S->stage) HIP_TRY(hipFree(S->stage));
-    S->stage = nullptr; S->stage_bytes = 0;
-    HIP_TRY(hipMalloc(&S->stage, total));
-    S->stage_bytes = total;
-  }
-  char *p = (char *)S->stage;
-  const double *din[7];
-  for (int i = 0; i < 7; i++) {
-    din[i] = (const double *)p;
-    size_t bytes = nin[i] * B * sizeof(double);
-    if (bytes) HIP_TRY(hipMemcpyAsync(p, hin[i], bytes, hipMemcpyHostToDevice, S->stream));
-    p += bytes;
-  }
-  double *dout[3];
-  for (int i = 0; i < 3; i++) { dout[i] = (double *)p; p += nout[i] * B * sizeof(double); }
-  int32_t *dstatus = (int32_t *)p; p += B * sizeof(int32_t);
-  int32_t *diters = (int32_t *)p;
-  QpcBatchArgs a;
-  a.B = B; a.q = din[0]; a.v = din[1]; a.desired = din[2]; a.cw = din[3]; a.cmax = din[4]; a.tw = din[5]; a.surf = din[6];
-  a.tau = dout[0]; a.vdot = dout[1]; a.cwrench = D.nc ? dout[2] : nullptr; a.status = dstatus; a.iters = diters;
-  a.prof = S->prof;
-  int rc = launch(c, a, S->stream);
+  QpcHostJob job;
+  int rc = fill_job(c, job, B, q, v, desired, cw, cmax, tw, surf, tau, vdot, cwrench, status, iters, nullptr, "qpc_control_batch");
   if (rc != QPC_OK) return rc;
-  for (int i = 0; i < 3; i++) {
-    size_t bytes = nout[i] * B * sizeof(double);
-    if (bytes && hout[i]) HIP_TRY(hipMemcpyAsync(hout[i], dout[i], bytes, hipMemcpyDeviceToHost, S->stream));
-  }
-  HIP_TRY(hipMemcpyAsync(status, dstatus, B * sizeof(int32_t), hipMemcpyDeviceToHost, S->stream));
-  if (iters) HIP_TRY(hipMemcpyAsync(iters, diters, B * sizeof(int32_t), hipMemcpyDeviceToHost, S->stream));
-  HIP_TRY(hipStreamSynchronize(S->stream));
+  if (B == 0) return host_wait(c);
+  std::string err;
+  rc = c->rt->pipe->run(job, err);
+  if (rc != QPC_OK) qpc_set_error(err);
+  return rc;
+}
+
+int32_t qpc_control_batch_async(qpc_controller *c, int64_t B, const double *q, const double *v, const double *desired,
+                                const double *cw, const double *cmax, const double *tw, const double *surf, double *tau,
+                                double *vdot, double *cwrench, int32_t *status, int32_t *iters) {
+  QpcHostJob job;
+  int rc = fill_job(c, job, B, q, v, desired, cw, cmax, tw, surf, tau, vdot, cwrench, status, iters, nullptr, "qpc_control_batch_async");
+  if (rc != QPC_OK) return rc;
+  if (B == 0) return QPC_OK;
+  c->rt->pipe->submit(job);
   return QPC_OK;
+}
+
+int32_t qpc_control_batch_warm(qpc_controller *c, int64_t B, const double *q, const double *v, const double *desired,
+                               const double *cw, const double *cmax, const double *tw, const double *surf, double *tau,
+                               double *vdot, double *cwrench, int32_t *status, int32_t *iters, uint64_t *working_set) {
+  if (!working_set) { qpc_set_error("qpc_control_batch_warm: working_set missing"); return QPC_ERR_INVALID_ARGUMENT; }
+  if (c && !c->warm_start) { qpc_set_error("qpc_control_batch_warm: call qpc_enable_warm_start before qpc_finalize"); return QPC_ERR_UNSUPPORTED; }
+  QpcHostJob job;
+  int rc = fill_job(c, job, B, q, v, desired, cw, cmax, tw, surf, tau, vdot, cwrench, status, iters, working_set, "qpc_control_batch_warm");
+  if (rc != QPC_OK) return rc;
+  if (B == 0) return host_wait(c);
+  std::string err;
+  rc = c->rt->pipe->run(job, err);
+  if (rc != QPC_OK) qpc_set_error(err);
+  return rc;
+}
+
+int32_t qpc_wait(qpc_controller *c) {
+  if (!c || !c->finalized || !c->rt) { qpc_set_error("controller not finalized"); return QPC_ERR_NOT_FINALIZED; }
+  return host_wait(c);
 }
 
 int32_t qpc_assemble_solve_batch(qpc_controller *c, int64_t B, const double *task_J, const double *task_bias,
@@ -387,7 +732,7 @@ int32_t qpc_assemble_solve_batch(qpc_controller *c, int64_t B, const double *tas
                                  const double *contact_R, const double *contact_p, const double *cw, const double *cmax,
                                  const double *tw, const double *surf, double *vdot, double *cwrench, int32_t *status,
                                  int32_t *iters) {
-  if (!c || !c->finalized || !c->dev) { qpc_set_error("controller not finalized"); return QPC_ERR_NOT_FINALIZED; }
+  if (!c || !c->finalized || !c->rt) { qpc_set_error("controller not finalized"); return QPC_ERR_NOT_FINALIZED; }
   const int nv = c->model->nv, nd = c->n_desired, nc = (int)c->contacts.size(), fl = c->floating >= 0;
   if (B < 0 || !vdot || !status || (nd && (!task_J || !task_bias || !desired)) || (fl && (!momentum_A || !momentum_rhs)) ||
       (nc && (!contact_R || !contact_p || !cw || !cmax)) || (c->n_tw && !tw) || (c->n_surf && !surf)) {
@@ -395,57 +740,99 @@ int32_t qpc_assemble_solve_batch(qpc_controller *c, int64_t B, const double *tas
   }
   if (B == 0) return QPC_OK;
   if (c->N > 8) { qpc_set_error("qpc_assemble_solve_batch: friction basis larger than 8"); return QPC_ERR_UNSUPPORTED; }
-  HIP_TRY(hipSetDevice(c->dev->device));
+  int rc = host_wait(c); // the inline slot's stream is shared with small host-pointer jobs
+  if (rc != QPC_OK) return rc;
+  QpcDeviceState *S = c->rt->devs[0];
+  hipStream_t st = S->slots[c->rt->inline_slot()].stream;
+  HIP_TRY(hipSetDevice(S->device));
   std::vector<int> it;
   std::vector<double> dt;
   int n = 0, m = 0;
   qpc_l1_build_tables(c, it, dt, n, m);
   const long long wsd = qpc::l1_workspace_doubles(n, m);
-  // one device slab: [tables | inputs | workspace | outputs]
+  // one persistent device slab: [tables | inputs | workspace | outputs]; every sub-buffer is 64-byte aligned and the
+  // total is computed with exactly the rounding take() applies below
   const size_t nin[11] = {(size_t)nd * nv, (size_t)nd, (size_t)nd, fl ? (size_t)6 * nv : 0, fl ? (size_t)6 : 0, (size_t)9 * nc,
                           (size_t)3 * nc, (size_t)nc, (size_t)nc, (size_t)c->n_tw, (size_t)c->n_surf};
   const double *hin[11] = {task_J, task_bias, desired, momentum_A, momentum_rhs, contact_R, contact_p, cw, cmax, tw, surf};
-  size_t total = it.size() * sizeof(int) + 64 + dt.size() * sizeof(double);
-  for (int i = 0; i < 11; i++) total += nin[i] * B * sizeof(double);
-  total += ((size_t)wsd + nv + 6 * (size_t)(nc > 0 ? nc : 1)) * B * sizeof(double) + 2 * (size_t)B * sizeof(int32_t) + 256;
-  char *buf = nullptr;
-  if (hipMalloc(&buf, total) != hipSuccess) { qpc_set_error("qpc_assemble_solve_batch: out of device memory"); return QPC_ERR_OUT_OF_MEMORY; }
-  int rc = QPC_OK;
+  const size_t ncw = 6 * (size_t)(nc > 0 ? nc : 1);
+  size_t total = pad64(dt.size() * sizeof(double)) + pad64(it.size() * sizeof(int));
+  for (int i = 0; i < 11; i++) total += pad64(nin[i] * (size_t)B * sizeof(double));
+  total += pad64((size_t)wsd * B * sizeof(double)) + pad64((size_t)nv * B * sizeof(double)) + pad64(ncw * B * sizeof(double)) +
+           2 * pad64((size_t)B * sizeof(int32_t));
+  if (total > S->l1_bytes) {
+    if (S->l1_buf) (void)hipFree(S->l1_buf);
+    S->l1_buf = nullptr; S->l1_bytes = 0;
+    if (hipMalloc(&S->l1_buf, total) != hipSuccess) { (void)hipGetLastError(); qpc_set_error("qpc_assemble_solve_batch: out of device memory"); return QPC_ERR_OUT_OF_MEMORY; }
+    S->l1_bytes = total;
+  }
+  char *buf = S->l1_buf;
+  rc = QPC_OK;
   auto chk = [&](hipError_t e, const char *w) { if (e != hipSuccess && rc == QPC_OK) rc = hip_fail(e, w); };
   char *p = buf;
-  auto take = [&](size_t bytes) { char *r = p; p += (bytes + 63) & ~(size_t)63; return r; };
+  auto take = [&](size_t bytes) { char *r = p; p += pad64(bytes); return r; };
   QpcL1Args a;
   a.B = B; a.nv = nv; a.nd = nd; a.nc = nc; a.ntw = c->n_tw; a.nsurf = c->n_surf; a.ws_stride = wsd;
   double *ddt = (double *)take(dt.size() * sizeof(double));
   int *dit = (int *)take(it.size() * sizeof(int));
-  chk(hipMemcpy(ddt, dt.data(), dt.size() * sizeof(double), hipMemcpyHostToDevice), "copy tables");
-  chk(hipMemcpy(dit, it.data(), it.size() * sizeof(int), hipMemcpyHostToDevice), "copy tables");
+  chk(hipMemcpyAsync(ddt, dt.data(), dt.size() * sizeof(double), hipMemcpyHostToDevice, st), "copy tables");
+  chk(hipMemcpyAsync(dit, it.data(), it.size() * sizeof(int), hipMemcpyHostToDevice, st), "copy tables");
   a.it = dit; a.dt = ddt;
   const double *din[11];
   for (int i = 0; i < 11; i++) {
-    const size_t bytes = nin[i] * B * sizeof(double);
+    const size_t bytes = nin[i] * (size_t)B * sizeof(double);
     din[i] = (const double *)take(bytes);
-    if (bytes) chk(hipMemcpy((void *)din[i], hin[i], bytes, hipMemcpyHostToDevice), "copy inputs");
+    if (bytes) chk(hipMemcpyAsync((void *)din[i], hin[i], bytes, hipMemcpyHostToDevice, st), "copy inputs");
   }
   a.J = din[0]; a.bias = din[1]; a.desired = din[2]; a.Am = fl ? din[3] : nullptr; a.mrhs = fl ? din[4] : nullptr;
   a.cR = din[5]; a.cp = din[6]; a.cw = din[7]; a.cmax = din[8]; a.tw = din[9]; a.surf = din[10];
   a.ws = (double *)take((size_t)wsd * B * sizeof(double));
   a.vdot = (double *)take((size_t)nv * B * sizeof(double));
-  a.cwrench = (double *)take((size_t)6 * (nc > 0 ? nc : 1) * B * sizeof(double));
+  a.cwrench = (double *)take(ncw * B * sizeof(double));
   a.status = (int32_t *)take((size_t)B * sizeof(int32_t));
   a.iters = (int32_t *)take((size_t)B * sizeof(int32_t));
+  if ((size_t)(p - buf) > total) { qpc_set_error("qpc_assemble_solve_batch: internal slab sizing error"); return QPC_ERR_HIP; }
   if (rc == QPC_OK) {
-    hipLaunchKernelGGL(qpc_l1_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, 0, a, c->settings);
+    hipLaunchKernelGGL(qpc_l1_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, a, c->settings);
     chk(hipGetLastError(), "launch qpc_l1_kernel");
-    chk(hipDeviceSynchronize(), "qpc_l1_kernel");
-    chk(hipMemcpy(vdot, a.vdot, (size_t)nv * B * sizeof(double), hipMemcpyDeviceToHost), "copy vdot");
-    if (cwrench && nc) chk(hipMemcpy(cwrench, a.cwrench, (size_t)6 * nc * B * sizeof(double), hipMemcpyDeviceToHost), "copy wrenches");
-    chk(hipMemcpy(status, a.status, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost), "copy status");
-    if (iters) chk(hipMemcpy(iters, a.iters, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost), "copy iters");
+    chk(hipMemcpyAsync(vdot, a.vdot, (size_t)nv * B * sizeof(double), hipMemcpyDeviceToHost, st), "copy vdot");
+    if (cwrench && nc) chk(hipMemcpyAsync(cwrench, a.cwrench, (size_t)6 * nc * B * sizeof(double), hipMemcpyDeviceToHost, st), "copy wrenches");
+    chk(hipMemcpyAsync(status, a.status, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, st), "copy status");
+    if (iters) chk(hipMemcpyAsync(iters, a.iters, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, st), "copy iters");
   }
-  (void)hipFree(buf);
+  chk(hipStreamSynchronize(st), "qpc_l1_kernel"); // also on error: `it` / `dt` must outlive the async table copies
   return rc;
 }
+
+// ---- L0: raw dense QPs.  Workspace per QP in HBM (qpc_qp_dense.h).
+uint64_t qpc_qp_workspace_bytes(int32_t n, int32_t m, int64_t B) {
+  if (n <= 0 || m < 0 || B < 0) return 0;
+  return (uint64_t)qpc::qp_dense_workspace_doubles(n, m) * (uint64_t)B * sizeof(double);
+}
+
+int32_t qpc_qp_solve_batch_device(int32_t n, int32_t m, int64_t B, const double *P, const double *q, const double *A,
+                                  const double *l, const double *u, const qpc_settings *settings, int32_t device_id,
+                                  double *x, double *y, int32_t *status, int32_t *iters, void *workspace,
+                                  uint64_t workspace_bytes, void *hip_stream) {
+  if (n <= 0 || m < 0 || B < 0 || !P || !q || (m && (!A || !l || !u)) || !x || (m && !y) || !status || !workspace) {
+    qpc_set_error("qpc_qp_solve_batch_device: bad arguments"); return QPC_ERR_INVALID_ARGUMENT;
+  }
+  if (workspace_bytes < qpc_qp_workspace_bytes(n, m, B)) { qpc_set_error("qpc_qp_solve_batch_device: workspace smaller than qpc_qp_workspace_bytes(n, m, B)"); return QPC_ERR_INVALID_ARGUMENT; }
+  if (B == 0) return QPC_OK;
+  HIP_TRY(hipSetDevice(device_id));
+  qpc_settings st;
+  if (settings) st = *settings; else qpc_default_settings(&st);
+  hipLaunchKernelGGL(qpc_qp_dense_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, (hipStream_t)hip_stream, (int)n, (int)m,
+                     (long long)B, P, q, A, l, u, st, (double *)workspace, (long long)qpc::qp_dense_workspace_doubles(n, m), x, y,
+                     status, iters);
+  HIP_TRY(hipGetLastError());
+  return QPC_OK;
+}
+
+// persistent device slab + stream of the host-pointer L0 entry, one per device of the process
+struct QpcL0Cache { char *buf = nullptr; size_t bytes = 0; hipStream_t stream = nullptr; };
+static std::mutex g_l0_mu;
+static std::map<int, QpcL0Cache> g_l0;
 
 int32_t qpc_qp_solve_batch(int32_t n, int32_t m, int64_t B, const double *P, const double *q, const double *A,
                            const double *l, const double *u, const qpc_settings *settings, int32_t device_id,
@@ -456,48 +843,53 @@ int32_t qpc_qp_solve_batch(int32_t n, int32_t m, int64_t B, const double *P, con
   if (B == 0) return QPC_OK;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    (void)hipGetLastError();
     qpc_set_error("qpc_qp_solve_batch: no HIP device available (this library has no CPU fallback)");
     return QPC_ERR_NO_DEVICE;
   }
   if (device_id < 0 || device_id >= ndev) { qpc_set_error("qpc_qp_solve_batch: device_id out of range"); return QPC_ERR_NO_DEVICE; }
   HIP_TRY(hipSetDevice(device_id));
-  qpc_settings st;
-  if (settings) st = *settings; else qpc_default_settings(&st);
-  const long long wsd = qpc::qp_dense_workspace_doubles(n, m);
+  std::lock_guard<std::mutex> lk(g_l0_mu); // one L0 call per process at a time (plumbing path)
+  QpcL0Cache &C = g_l0[device_id];
+  if (!C.stream) HIP_TRY(hipStreamCreateWithFlags(&C.stream, hipStreamNonBlocking));
   const size_t nP = (size_t)B * n * n, nq = (size_t)B * n, nA = (size_t)B * m * n, nm = (size_t)B * m;
-  const size_t total = (nP + nq + nA + 2 * nm + nq + nm + (size_t)B * wsd) * sizeof(double) + 2 * (size_t)B * sizeof(int32_t) + 64;
-  char *buf = nullptr;
-  if (hipMalloc(&buf, total) != hipSuccess) { qpc_set_error("qpc_qp_solve_batch: out of device memory"); return QPC_ERR_OUT_OF_MEMORY; }
-  double *dP = (double *)buf, *dq = dP + nP, *dA = dq + nq, *dl = dA + nA, *du = dl + nm, *dx = du + nm, *dy = dx + nq,
-         *dws = dy + nm;
-  int32_t *dst = (int32_t *)(dws + (size_t)B * wsd), *dit = dst + B;
+  const size_t wsb = (size_t)qpc_qp_workspace_bytes(n, m, B);
+  const size_t total = pad64(nP * 8) + 2 * pad64(nq * 8) + pad64(nA * 8) + 3 * pad64(nm * 8) + pad64(wsb) + 2 * pad64((size_t)B * sizeof(int32_t));
+  if (total > C.bytes) {
+    if (C.buf) (void)hipFree(C.buf);
+    C.buf = nullptr; C.bytes = 0;
+    if (hipMalloc(&C.buf, total) != hipSuccess) { (void)hipGetLastError(); qpc_set_error("qpc_qp_solve_batch: out of device memory"); return QPC_ERR_OUT_OF_MEMORY; }
+    C.bytes = total;
+  }
+  char *p = C.buf;
+  auto take = [&](size_t bytes) { char *r = p; p += pad64(bytes); return r; };
+  double *dP = (double *)take(nP * 8), *dq = (double *)take(nq * 8), *dA = (double *)take(nA * 8), *dl = (double *)take(nm * 8),
+         *du = (double *)take(nm * 8), *dx = (double *)take(nq * 8), *dy = (double *)take(nm * 8), *dws = (double *)take(wsb);
+  int32_t *dst = (int32_t *)take((size_t)B * sizeof(int32_t)), *dit = (int32_t *)take((size_t)B * sizeof(int32_t));
   int rc = QPC_OK;
   auto chk = [&](hipError_t e, const char *w) { if (e != hipSuccess && rc == QPC_OK) rc = hip_fail(e, w); };
-  chk(hipMemcpy(dP, P, nP * sizeof(double), hipMemcpyHostToDevice), "copy P");
-  chk(hipMemcpy(dq, q, nq * sizeof(double), hipMemcpyHostToDevice), "copy q");
+  chk(hipMemcpyAsync(dP, P, nP * sizeof(double), hipMemcpyHostToDevice, C.stream), "copy P");
+  chk(hipMemcpyAsync(dq, q, nq * sizeof(double), hipMemcpyHostToDevice, C.stream), "copy q");
   if (m) {
-    chk(hipMemcpy(dA, A, nA * sizeof(double), hipMemcpyHostToDevice), "copy A");
-    chk(hipMemcpy(dl, l, nm * sizeof(double), hipMemcpyHostToDevice), "copy l");
-    chk(hipMemcpy(du, u, nm * sizeof(double), hipMemcpyHostToDevice), "copy u");
+    chk(hipMemcpyAsync(dA, A, nA * sizeof(double), hipMemcpyHostToDevice, C.stream), "copy A");
+    chk(hipMemcpyAsync(dl, l, nm * sizeof(double), hipMemcpyHostToDevice, C.stream), "copy l");
+    chk(hipMemcpyAsync(du, u, nm * sizeof(double), hipMemcpyHostToDevice, C.stream), "copy u");
   }
+  if (rc == QPC_OK) rc = qpc_qp_solve_batch_device(n, m, B, dP, dq, dA, dl, du, settings, device_id, dx, dy, dst, dit, dws, wsb, C.stream);
   if (rc == QPC_OK) {
-    hipLaunchKernelGGL(qpc_qp_dense_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, 0, (int)n, (int)m, (long long)B, dP, dq,
-                       dA, dl, du, st, dws, wsd, dx, dy, dst, dit);
-    chk(hipGetLastError(), "launch qpc_qp_dense_kernel");
-    chk(hipDeviceSynchronize(), "qpc_qp_dense_kernel");
-    chk(hipMemcpy(x, dx, nq * sizeof(double), hipMemcpyDeviceToHost), "copy x");
-    if (m) chk(hipMemcpy(y, dy, nm * sizeof(double), hipMemcpyDeviceToHost), "copy y");
-    chk(hipMemcpy(status, dst, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost), "copy status");
-    if (iters) chk(hipMemcpy(iters, dit, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost), "copy iters");
+    chk(hipMemcpyAsync(x, dx, nq * sizeof(double), hipMemcpyDeviceToHost, C.stream), "copy x");
+    if (m) chk(hipMemcpyAsync(y, dy, nm * sizeof(double), hipMemcpyDeviceToHost, C.stream), "copy y");
+    chk(hipMemcpyAsync(status, dst, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, C.stream), "copy status");
+    if (iters) chk(hipMemcpyAsync(iters, dit, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, C.stream), "copy iters");
   }
-  (void)hipFree(buf);
+  chk(hipStreamSynchronize(C.stream), "qpc_qp_dense_kernel");
   return rc;
 }
 
 static int sim_check(qpc_controller *c, int64_t B, const void *q, const void *v, const void *tau, const qpc_sim_params *p, const char *who) {
-  if (!c || !c->finalized || !c->dev) { qpc_set_error("controller not finalized"); return QPC_ERR_NOT_FINALIZED; }
+  if (!c || !c->finalized || !c->rt) { qpc_set_error("controller not finalized"); return QPC_ERR_NOT_FINALIZED; }
   if (B < 0 || !q || !v || !tau || !p) { qpc_set_error(std::string(who) + ": missing array"); return QPC_ERR_INVALID_ARGUMENT; }
-  if (!c->dev->jit_sim_func && c->prog.dims.maxdepth > QPC_GENERIC_MAXD) {
+  if (!c->rt->devs[0]->jit_sim_func && c->prog.dims.maxdepth > QPC_GENERIC_MAXD) {
     qpc_set_error(std::string(who) + ": tree deeper than the generic kernel supports and no JIT kernel"); return QPC_ERR_UNSUPPORTED;
   }
   if (!(p->dt > 0.0) || !(p->stiffness >= 0.0) || !(p->damping >= 0.0) || !(p->tangential_damping >= 0.0)) {
@@ -506,14 +898,36 @@ static int sim_check(qpc_controller *c, int64_t B, const void *q, const void *v,
   return QPC_OK;
 }
 
+static int sim_step_device(qpc_controller *c, int di, int64_t B, double *q, double *v, const double *tau, const int32_t *status,
+                           const qpc_sim_params *params, int32_t *bad, hipStream_t stream) {
+  QpcDeviceState *S = c->rt->devs[di];
+  HIP_TRY(hipSetDevice(S->device));
+  QpcSimArgs a;
+  a.B = B; a.q = q; a.v = v; a.tau = tau; a.status = status; a.bad = bad; a.sp = *params;
+  return launch_sim(c, S, a, stream);
+}
+
 int32_t qpc_sim_step_batch_device(qpc_controller *c, int64_t B, double *q, double *v, const double *tau, const int32_t *status,
                                   const qpc_sim_params *params, int32_t *bad, void *hip_stream) {
   int rc = sim_check(c, B, q, v, tau, params, "qpc_sim_step_batch_device");
   if (rc != QPC_OK) return rc;
-  HIP_TRY(hipSetDevice(c->dev->device));
-  QpcSimArgs a;
-  a.B = B; a.q = q; a.v = v; a.tau = tau; a.status = status; a.bad = bad; a.sp = *params;
-  return launch_sim(c, a, (hipStream_t)hip_stream);
+  return sim_step_device(c, 0, B, q, v, tau, status, params, bad, (hipStream_t)hip_stream);
+}
+
+// n_steps x (tick -> step) on device `di`, stream `stream`; wsets != nullptr: warm-started ticks (working sets carried
+// from step to step in `wsets`, 2 x uint64 per robot, zero-initialised by the caller = cold first tick)
+static int rollout_device(qpc_controller *c, int di, int64_t B, int64_t n_steps, double *q, double *v, const double *desired,
+                          const double *cw, const double *cmax, const double *tw, const double *surf, const qpc_sim_params *params,
+                          double *tau, double *vdot, int32_t *status, int32_t *bad, unsigned long long *wsets, hipStream_t stream) {
+  // two kernels per step on one stream, nothing else: the tick's work counter re-arms itself on the device
+  for (int64_t s = 0; s < n_steps; s++) {
+    int rc = control_device(c, di, B, q, v, desired, cw, cmax, tw, surf, tau, vdot, nullptr, status, nullptr, wsets, stream,
+                            "qpc_rollout_batch_device");
+    if (rc != QPC_OK) return rc;
+    rc = sim_step_device(c, di, B, q, v, tau, status, params, bad, stream);
+    if (rc != QPC_OK) return rc;
+  }
+  return QPC_OK;
 }
 
 int32_t qpc_rollout_batch_device(qpc_controller *c, int64_t B, int64_t n_steps, double *q, double *v, const double *desired,
@@ -523,62 +937,100 @@ int32_t qpc_rollout_batch_device(qpc_controller *c, int64_t B, int64_t n_steps, 
   int rc = sim_check(c, B, q, v, tau, params, "qpc_rollout_batch_device");
   if (rc != QPC_OK) return rc;
   if (n_steps < 0 || !vdot || !status) { qpc_set_error("qpc_rollout_batch_device: missing array"); return QPC_ERR_INVALID_ARGUMENT; }
-  // two kernels per step on one stream; the tick's launch is asynchronous and its ticket base is
-  // tracked on the host, so n_steps steps are enqueued back to back without any synchronisation
-  for (int64_t s = 0; s < n_steps; s++) {
-    rc = qpc_control_batch_device(c, B, q, v, desired, cw, cmax, tw, surf, tau, vdot, nullptr, status, nullptr, hip_stream);
-    if (rc != QPC_OK) return rc;
-    rc = qpc_sim_step_batch_device(c, B, q, v, tau, status, params, bad, hip_stream);
-    if (rc != QPC_OK) return rc;
+  unsigned long long *wsets = nullptr;
+  if (c->warm_start && c->rt->devs[0]->jit_warm_func && n_steps > 0) { // warm-started ticks: working sets in a persistent device buffer
+    QpcDeviceState *S = c->rt->devs[0];
+    HIP_TRY(hipSetDevice(S->device));
+    const size_t need = 2 * (size_t)B * sizeof(unsigned long long);
+    if (need > S->roll_ws_bytes) {
+      if (S->roll_ws) HIP_TRY(hipFree(S->roll_ws));
+      S->roll_ws = nullptr; S->roll_ws_bytes = 0;
+      HIP_TRY(hipMalloc(&S->roll_ws, need));
+      S->roll_ws_bytes = need;
+    }
+    HIP_TRY(hipMemsetAsync(S->roll_ws, 0, need, (hipStream_t)hip_stream));
+    wsets = S->roll_ws;
   }
-  return QPC_OK;
+  return rollout_device(c, 0, B, n_steps, q, v, desired, cw, cmax, tw, surf, params, tau, vdot, status, bad, wsets, (hipStream_t)hip_stream);
 }
 
-// host-pointer variants: one device slab, synchronous.  tick = false: one simulation step with the caller's tau / status.
+// host-pointer variants: the batch is sharded over the controller's devices; per device one persistent slab, everything
+// asynchronous on the device's inline-slot stream, one synchronisation per device at the end (the devices run
+// concurrently).  tick = false: one simulation step with the caller's tau / status.
 static int rollout_host(qpc_controller *c, int64_t B, int64_t n_steps, bool tick, double *q, double *v, const double *desired,
                         const double *cw, const double *cmax, const double *tw, const double *surf, const qpc_sim_params *params,
                         double *tau, int32_t *status, int32_t *bad) {
   const QpcDims &D = c->prog.dims;
-  QpcDeviceState *S = c->dev;
   if (B == 0) return QPC_OK;
-  HIP_TRY(hipSetDevice(S->device));
+  int rc = host_wait(c);
+  if (rc != QPC_OK) return rc;
   enum { A_Q, A_V, A_TAU, A_VDOT, A_DES, A_CW, A_CMAX, A_TW, A_SURF, A_COUNT };
   const size_t dim[A_COUNT] = {(size_t)D.nq, (size_t)D.nv, (size_t)D.nv, (size_t)D.nv, desired ? (size_t)D.n_desired : 0,
                                (size_t)D.nc, (size_t)D.nc, (size_t)D.n_tw, (size_t)D.n_surf};
   const double *host_in[A_COUNT] = {q, v, tick ? nullptr : tau, nullptr, desired, cw, cmax, tw, surf};
-  auto padded = [&](int i) { return ((dim[i] * B * sizeof(double)) + 63) & ~(size_t)63; };
-  size_t total = 2 * (size_t)B * sizeof(int32_t) + 256;
-  for (int i = 0; i < A_COUNT; i++) total += padded(i);
-  char *buf = nullptr;
-  if (hipMalloc(&buf, total) != hipSuccess) { qpc_set_error("rollout: out of device memory"); return QPC_ERR_OUT_OF_MEMORY; }
-  int rc = QPC_OK;
+  const int G = (int)c->rt->devs.size();
   auto chk = [&](hipError_t e, const char *w) { if (e != hipSuccess && rc == QPC_OK) rc = hip_fail(e, w); };
-  char *p = buf;
-  double *dev[A_COUNT];
-  for (int i = 0; i < A_COUNT; i++) { dev[i] = (double *)p; p += padded(i); }
-  int32_t *dstatus = (int32_t *)p, *dbad = dstatus + B;
-  for (int i = 0; i < A_COUNT; i++)
-    if (host_in[i] && dim[i])
-      chk(hipMemcpyAsync(dev[i], host_in[i], dim[i] * B * sizeof(double), hipMemcpyHostToDevice, S->stream), "copy inputs");
-  if (!tick && status) chk(hipMemcpyAsync(dstatus, status, B * sizeof(int32_t), hipMemcpyHostToDevice, S->stream), "copy status");
-  if (bad) chk(hipMemcpyAsync(dbad, bad, B * sizeof(int32_t), hipMemcpyHostToDevice, S->stream), "copy bad");
-  else chk(hipMemsetAsync(dbad, 0, B * sizeof(int32_t), S->stream), "clear bad");
-  if (rc == QPC_OK) {
-    if (tick)
-      rc = qpc_rollout_batch_device(c, B, n_steps, dev[A_Q], dev[A_V], desired ? dev[A_DES] : nullptr, dev[A_CW], dev[A_CMAX],
-                                    dev[A_TW], dev[A_SURF], params, dev[A_TAU], dev[A_VDOT], dstatus, dbad, S->stream);
-    else
-      rc = qpc_sim_step_batch_device(c, B, dev[A_Q], dev[A_V], dev[A_TAU], status ? dstatus : nullptr, params, dbad, S->stream);
+  struct Shard { int64_t lo, n; double *dev[A_COUNT]; int32_t *dstatus, *dbad; hipStream_t st; };
+  std::vector<Shard> sh(G);
+  const bool warm = tick && c->warm_start && c->rt->devs[0]->jit_warm_func;
+  for (int g = 0; g < G && rc == QPC_OK; g++) {
+    QpcDeviceState *S = c->rt->devs[g];
+    int64_t lo, hi;
+    qpc_shard_bounds(B, g, G, lo, hi);
+    Shard &s = sh[g];
+    s.lo = lo; s.n = hi - lo; s.st = S->slots[c->rt->inline_slot()].stream;
+    if (s.n == 0) continue;
+    chk(hipSetDevice(S->device), "hipSetDevice");
+    auto padded = [&](int i) { return pad64(dim[i] * (size_t)s.n * sizeof(double)); };
+    size_t total = 2 * pad64((size_t)s.n * sizeof(int32_t)) + pad64(warm ? 2 * (size_t)s.n * sizeof(unsigned long long) : 0);
+    for (int i = 0; i < A_COUNT; i++) total += padded(i);
+    if (total > S->roll_bytes) {
+      if (S->roll_buf) (void)hipFree(S->roll_buf);
+  if (S->roll_ws) (void)hipFree(S->roll_ws);
+      S->roll_buf = nullptr; S->roll_bytes = 0;
+      if (hipMalloc(&S->roll_buf, total) != hipSuccess) { (void)hipGetLastError(); qpc_set_error("rollout: out of device memory"); rc = QPC_ERR_OUT_OF_MEMORY; break; }
+      S->roll_bytes = total;
+    }
+    char *p = S->roll_buf;
+    for (int i = 0; i < A_COUNT; i++) { s.dev[i] = (double *)p; p += padded(i); }
+    s.dstatus = (int32_t *)p; p += pad64((size_t)s.n * sizeof(int32_t));
+    s.dbad = (int32_t *)p; p += pad64((size_t)s.n * sizeof(int32_t));
+    unsigned long long *dws = warm ? (unsigned long long *)p : nullptr;
+    for (int i = 0; i < A_COUNT; i++)
+      if (host_in[i] && dim[i])
+        chk(hipMemcpyAsync(s.dev[i], host_in[i] + (size_t)lo * dim[i], dim[i] * (size_t)s.n * sizeof(double), hipMemcpyHostToDevice, s.st), "copy inputs");
+    if (!tick && status) chk(hipMemcpyAsync(s.dstatus, status + lo, (size_t)s.n * sizeof(int32_t), hipMemcpyHostToDevice, s.st), "copy status");
+    if (bad) chk(hipMemcpyAsync(s.dbad, bad + lo, (size_t)s.n * sizeof(int32_t), hipMemcpyHostToDevice, s.st), "copy bad");
+    else chk(hipMemsetAsync(s.dbad, 0, (size_t)s.n * sizeof(int32_t), s.st), "clear bad");
+    if (dws) chk(hipMemsetAsync(dws, 0, 2 * (size_t)s.n * sizeof(unsigned long long), s.st), "clear working sets");
+    if (rc != QPC_OK) break;
+    if (tick) {
+      // the inline slot owns its stream, ticket counter and spill slots: launch through it (not the user slot)
+      for (int64_t k = 0; k < n_steps && rc == QPC_OK; k++) {
+        QpcBatchArgs a;
+        a.B = s.n; a.q = s.dev[A_Q]; a.v = s.dev[A_V]; a.desired = desired ? s.dev[A_DES] : nullptr; a.cw = s.dev[A_CW]; a.cmax = s.dev[A_CMAX];
+        a.tw = s.dev[A_TW]; a.surf = s.dev[A_SURF]; a.tau = s.dev[A_TAU]; a.vdot = s.dev[A_VDOT]; a.cwrench = nullptr;
+        a.status = s.dstatus; a.iters = nullptr; a.prof = nullptr; a.wsets = dws;
+        rc = launch(c, S, S->slots[c->rt->inline_slot()], a, s.st, dws != nullptr);
+        if (rc == QPC_OK) rc = sim_step_device(c, g, s.n, s.dev[A_Q], s.dev[A_V], s.dev[A_TAU], s.dstatus, params, s.dbad, s.st);
+      }
+    } else {
+      rc = sim_step_device(c, g, s.n, s.dev[A_Q], s.dev[A_V], s.dev[A_TAU], status ? s.dstatus : nullptr, params, s.dbad, s.st);
+    }
+    if (rc == QPC_OK) {
+      chk(hipMemcpyAsync(q + (size_t)lo * dim[A_Q], s.dev[A_Q], dim[A_Q] * (size_t)s.n * sizeof(double), hipMemcpyDeviceToHost, s.st), "copy q");
+      chk(hipMemcpyAsync(v + (size_t)lo * dim[A_V], s.dev[A_V], dim[A_V] * (size_t)s.n * sizeof(double), hipMemcpyDeviceToHost, s.st), "copy v");
+      if (tick && tau) chk(hipMemcpyAsync(tau + (size_t)lo * dim[A_TAU], s.dev[A_TAU], dim[A_TAU] * (size_t)s.n * sizeof(double), hipMemcpyDeviceToHost, s.st), "copy tau");
+      if (tick && status) chk(hipMemcpyAsync(status + lo, s.dstatus, (size_t)s.n * sizeof(int32_t), hipMemcpyDeviceToHost, s.st), "copy status");
+      if (bad) chk(hipMemcpyAsync(bad + lo, s.dbad, (size_t)s.n * sizeof(int32_t), hipMemcpyDeviceToHost, s.st), "copy bad");
+    }
   }
-  if (rc == QPC_OK) {
-    chk(hipMemcpyAsync(q, dev[A_Q], dim[A_Q] * B * sizeof(double), hipMemcpyDeviceToHost, S->stream), "copy q");
-    chk(hipMemcpyAsync(v, dev[A_V], dim[A_V] * B * sizeof(double), hipMemcpyDeviceToHost, S->stream), "copy v");
-    if (tick && tau) chk(hipMemcpyAsync(tau, dev[A_TAU], dim[A_TAU] * B * sizeof(double), hipMemcpyDeviceToHost, S->stream), "copy tau");
-    if (tick && status) chk(hipMemcpyAsync(status, dstatus, B * sizeof(int32_t), hipMemcpyDeviceToHost, S->stream), "copy status");
-    if (bad) chk(hipMemcpyAsync(bad, dbad, B * sizeof(int32_t), hipMemcpyDeviceToHost, S->stream), "copy bad");
+  for (int g = 0; g < G; g++) {
+    if (sh[g].n == 0 && rc == QPC_OK) continue;
+    (void)hipSetDevice(c->rt->devs[g]->device);
+    chk(hipStreamSynchronize(c->rt->devs[g]->slots[c->rt->inline_slot()].stream), "rollout");
   }
-  chk(hipStreamSynchronize(S->stream), "rollout");
-  (void)hipFree(buf);
+  (void)hipSetDevice(c->rt->devs[0]->device);
   return rc;
 }
 
@@ -644,35 +1096,39 @@ int32_t qpc_debug_measure_fp64_peak(int32_t device_id, double *tflops) {
   return QPC_OK;
 }
 
-// diagnostic (QPC_STAMPS builds): device buffer of B*PS_COUNT uint64 section cycle counters
+// diagnostic (QPC_STAMPS builds): device buffer of B*PS_COUNT uint64 section cycle counters (device 0, *_device entry)
 int32_t qpc_debug_set_profile_buffer(qpc_controller *c, void *device_buffer) {
-  if (!c || !c->dev) return QPC_ERR_NOT_FINALIZED;
-  c->dev->prof = (unsigned long long *)device_buffer;
+  if (!c || !c->rt) return QPC_ERR_NOT_FINALIZED;
+  c->rt->devs[0]->prof = (unsigned long long *)device_buffer;
   return QPC_OK;
 }
 
-int32_t qpc_debug_jit_active(qpc_controller *c) { return (c && c->dev && c->dev->jit_func) ? 1 : 0; }
+int32_t qpc_debug_jit_active(qpc_controller *c) { return (c && c->rt && c->rt->devs[0]->jit_func) ? 1 : 0; }
+int32_t qpc_debug_warm_active(qpc_controller *c) { return (c && c->rt && c->rt->devs[0]->jit_warm_func) ? 1 : 0; }
 
 int32_t qpc_timing_enable(qpc_controller *c, int32_t enable) {
-  if (!c || !c->dev) return QPC_ERR_NOT_FINALIZED;
-  c->dev->timing = enable != 0;
+  if (!c || !c->rt) return QPC_ERR_NOT_FINALIZED;
+  for (auto *S : c->rt->devs) S->timing = enable != 0;
   return QPC_OK;
 }
 
 int32_t qpc_timing_read(qpc_controller *c, double *avg_ms, int64_t *n_launches) {
-  if (!c || !c->dev) return QPC_ERR_NOT_FINALIZED;
-  QpcDeviceState *S = c->dev;
-  HIP_TRY(hipSetDevice(S->device));
+  if (!c || !c->rt) return QPC_ERR_NOT_FINALIZED;
   double sum = 0.0;
   long long n = 0;
-  for (auto &p : S->events) {
-    HIP_TRY(hipEventSynchronize(p.second));
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, p.first, p.second));
-    sum += ms; n++;
-    S->pool.push_back(p.first); S->pool.push_back(p.second);
+  for (auto *S : c->rt->devs) {
+    HIP_TRY(hipSetDevice(S->device));
+    std::lock_guard<std::mutex> lk(S->timing_mu);
+    for (auto &p : S->events) {
+      HIP_TRY(hipEventSynchronize(p.second));
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, p.first, p.second));
+      sum += ms; n++;
+      S->pool.push_back(p.first); S->pool.push_back(p.second);
+    }
+    S->events.clear();
   }
-  S->events.clear();
+  (void)hipSetDevice(c->rt->devs[0]->device);
   if (avg_ms) *avg_ms = n ? sum / n : 0.0;
   if (n_launches) *n_launches = n;
   return QPC_OK;

@@ -185,6 +185,10 @@ QPC_FN void qpc_sim_step(const QpcDims &D, const int *IT, const double *DT, P sm
       // friction capped at mu * normal force; wrench about the world origin
       const int body = IT[D.it[IT_C_BODY] + c];
       double H[12], T[6], p[3], wxp[3], f[3] = {0, 0, 0}, mo[3];
+      if (body < 0) { // a contact point of the WORLD body (qpc_add_contact accepts QPC_WORLD): it pushes on nothing that moves
+        for (int a = 0; a < 6; a++) sm[L.cf + 6 * c + a] = 0.0;
+        continue;
+      }
       ld(sm + L.h + 12 * body, 12, H);
       ld(sm + L.t + 6 * body, 6, T);
       mv3(H, DT + D.dt[DT_C_POS] + 3 * c, p);

@@ -286,6 +286,8 @@ struct TickIO {
   int32_t *status, *iters;
   unsigned long long *prof; // PS_COUNT section cycle counters (diagnostic build) or nullptr
   double *scratch;          // QPC_SCRATCH_DOUBLES lane-private spill slot of this workgroup (HBM)
+  unsigned long long *wset; // warm start (qpc_tick<P, true> only): working set of this QP's previous tick, in / out:
+                            // [0] bit j = rho_j at its lower bound, [1] bit j = rho_j at its upper bound; nullptr / zeros = cold
 };
 
 // ------------------------------------------------------------------------------------------
@@ -921,7 +923,11 @@ template <class P> QPC_FN void qpc_tick_prologue(const QpcDims &D, const int *IT
   } QPC_END_PHASE
 }
 
-template <class P>
+// WARM = true is the warm-started variant (separately compiled: qpc_enable_warm_start): the active-set search starts
+// from the working set the caller carries from tick to tick -- the counterpart of the reference's OSQP workspace, which
+// persists between ticks (momentum.jl:58 calls solve! on the same model every tick) -- and hands the final one back.
+// A search that fails from a warm set is repeated once from the cold start, so the answer never depends on the hint.
+template <class P, bool WARM = false>
 QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, const TickIO &io) {
   const int nb = D.nb, nq = D.nq, nv = D.nv, nf = D.nf, nc = D.nc, N = D.N, nrho = D.nrho, ne = D.ne;
   const int m = D.m, m1 = D.m1, nw = D.nw, ntask = D.ntask;
@@ -1371,7 +1377,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
         // Rotations.rotation_between(z, n) (contacts.jl:11)
         double nn = QPC_SQRT(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
         double w = nn + nrm[2], x, y, z = 0.0;
-        if (QPC_FABS(w) < 100 * 2.220446049250313e-16) { x = 0; y = 1; } else { x = -nrm[1]; y = nrm[0]; }
+        if (QPC_FABS(w) < 100 * 2.220446049250313e-16) { x = 1; y = 0; } /* Rotations.perpendicular_vector((0,0,1)) = (1,0,0) */ else { x = -nrm[1]; y = nrm[0]; }
         double qn = QPC_RSQRT(w * w + x * x + y * y);
         w *= qn; x *= qn; y *= qn;
         double Rn[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
@@ -1419,7 +1425,12 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
 #endif
         double hi = sm[D.lds[L_CMAX] + c] * inv / N; // maxrho (contacts.jl:57)
         sm[D.lds[L_HI] + j] = hi;
-        sm[D.lds[L_WS] + j] = hi > 0.0 ? 0.0 : -1.0; // disable! (contacts.jl:72): rho pinned to 0
+        double ws0 = hi > 0.0 ? 0.0 : -1.0; // disable! (contacts.jl:72): rho pinned to 0
+        if (WARM && io.wset && hi > 0.0 && j < 64) { // hint from the previous tick of this robot
+          const unsigned long long wlo = io.wset[0], wup = io.wset[1];
+          ws0 = ((wlo >> j) & 1ull) ? -1.0 : (((wup >> j) & 1ull) ? 1.0 : 0.0);
+        }
+        sm[D.lds[L_WS] + j] = ws0;
       }
   } QPC_END_PHASE
 
@@ -1593,6 +1604,18 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
   // ======================================================================== active-set solve (a13)
   Solver<P> S(D, IT, DT, sm, PA, PT);
   int status = QPC_STATUS_OPTIMAL, iters = 0;
+  int refine = 0;
+  bool warm_hint = false; // WARM: the search below starts from a non-trivial working set
+  for (int attempt = 0; attempt < (WARM ? 2 : 1); attempt++) {
+  if (WARM && attempt == 1) {
+    // the warm-started search failed: once more from the cold start (all enabled rho free)
+    if (!warm_hint || status == QPC_STATUS_OPTIMAL || status == QPC_STATUS_ALMOST_OPTIMAL) break;
+    QPC_PHASE(lane) {
+      for (int j = lane; j < nrho; j += 64) sm[D.lds[L_WS] + j] = sm[D.lds[L_HI] + j] > 0.0 ? 0.0 : -1.0;
+    } QPC_END_PHASE
+    status = QPC_STATUS_OPTIMAL;
+    warm_hint = false;
+  }
   if (use_rho) {
     // u0 = c2 - Z' c1 with c = E H^-1 (-g) - d : fixed for the whole tick (see Solver::rho_solve)
     S.compute_c();
@@ -1600,6 +1623,23 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       if (lane < 6) sm[MISC + MS_U0 + lane] = sm[D.lds[L_T1] + m1 + lane] - dotp(sm + D.lds[L_X2] + lane, 6, sm + D.lds[L_T1], 1, m1);
     } QPC_END_PHASE
     bool any_upper = false;
+    if (WARM && attempt == 0) { // upper-active bounds / any hint at all in the starting set?
+      unsigned long long bup0 = 0ull, bhint = 0ull;
+      QPC_PHASE(lane) {
+        double up = 0.0, hint = 0.0;
+        for (int j = lane; j < nrho; j += 64) {
+          const double w = sm[D.lds[L_WS] + j];
+          if (w == 1.0) up = 1.0;
+          if (w != 0.0 && sm[D.lds[L_HI] + j] > 0.0) hint = 1.0;
+        }
+        QPC_BALLOT_PUT(0, bup0, up != 0.0);
+        QPC_BALLOT_PUT(1, bhint, hint != 0.0);
+      } QPC_END_PHASE
+      QPC_BALLOT_GET(0, bup0);
+      QPC_BALLOT_GET(1, bhint);
+      any_upper = bup0 != 0ull;
+      warm_hint = bhint != 0ull;
+    }
     S.refactor_solve(any_upper);
     // ---- phase A: primal-dual active-set sweeps (multi-change)
     for (int pd = 0; pd < D.max_pdas; pd++) {
@@ -1782,7 +1822,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
   }
   QPC_PROF_ACC(PS_LOGIC);
   // ---- final refinement on the converged working set + acceptance test (a14)
-  int refine = 0;
+  refine = 0;
   if (status == QPC_STATUS_OPTIMAL) {
     for (int outer = 0;; outer++) {
       // exact_ve: wrench-space proximal sweeps + one back-substitution (Solver::polish_exact), then
@@ -1856,6 +1896,22 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       iters++;
       S.refactor_rho();
     }
+  }
+
+  } // attempt (WARM: warm start, then cold start if that failed)
+  if (WARM && io.wset) { // the working set goes back to the caller (zeros = "start cold" after a failed solve)
+    unsigned long long blo = 0ull, bupf = 0ull;
+    QPC_PHASE(lane) {
+      const double w = (lane < nrho) ? (double)sm[D.lds[L_WS] + (lane < nrho ? lane : 0)] : 0.0;
+      QPC_BALLOT_PUT(0, blo, w == -1.0);
+      QPC_BALLOT_PUT(1, bupf, w == 1.0);
+    } QPC_END_PHASE
+    QPC_BALLOT_GET(0, blo);
+    QPC_BALLOT_GET(1, bupf);
+    const bool good = status == QPC_STATUS_OPTIMAL || status == QPC_STATUS_ALMOST_OPTIMAL;
+    QPC_PHASE(lane) {
+      if (lane == 0) { io.wset[0] = good ? blo : 0ull; io.wset[1] = good ? bupf : 0ull; }
+    } QPC_END_PHASE
   }
 
   QPC_PROF_ACC(PS_FINAL);

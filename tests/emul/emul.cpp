@@ -10,10 +10,12 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "../../qpcontrol.jl_amd/csrc/qpc_compile.h"
+#include "../../qpcontrol.jl_amd/csrc/qpc_pipeline.h"
 
 struct EmuState {
   std::vector<double> mem;
@@ -117,49 +119,177 @@ static inline double emu_scale_trunc(double x) {
 #include "../../qpcontrol.jl_amd/csrc/qpc_qp_dense.h"
 #include "../../qpcontrol.jl_amd/csrc/qpc_l1_dense.h"
 
+static std::mutex g_rep_mu; // the host pipeline's worker threads report into these
 static long g_races = 0, g_uninit = 0, g_outside = 0;
 static std::string g_first;
 
+// one emulated tick per QP of [lo, lo + n): what a chunk of the host pipeline does on a (fake) device
+static void emu_ticks(qpc_controller *c, const QpcHostJob &job, int64_t lo, int64_t n) {
+  const QpcDims &D = c->prog.dims;
+  EmuState emu;
+  g_emu = &emu;
+  long races = 0, uninit = 0, outside = 0;
+  std::string first;
+  auto in = [&](int i, int64_t b) { return job.in[i] ? job.in[i] + b * (int64_t)job.in_dim[i] : nullptr; };
+  for (int64_t b = lo; b < lo + n; b++) {
+    emu.reset(D.lds_doubles + 128 * 8);
+    qpc::TickIO io;
+    io.q = in(QpcHostJob::IN_Q, b); io.v = in(QpcHostJob::IN_V, b); io.desired = in(QpcHostJob::IN_DES, b);
+    io.cw = in(QpcHostJob::IN_CW, b); io.cmax = in(QpcHostJob::IN_CMAX, b);
+    io.tw = in(QpcHostJob::IN_TW, b); io.surf = in(QpcHostJob::IN_SURF, b);
+    io.tau = job.out[QpcHostJob::OUT_TAU] + b * D.nv; io.vdot = job.out[QpcHostJob::OUT_VDOT] + b * D.nv;
+    io.cwrench = job.out[QpcHostJob::OUT_CWRENCH] ? job.out[QpcHostJob::OUT_CWRENCH] + b * 6 * D.nc : nullptr;
+    io.status = job.status + b; io.iters = job.iters ? job.iters + b : nullptr; io.prof = nullptr;
+    io.wset = job.working_set ? (unsigned long long *)job.working_set + 2 * b : nullptr;
+    std::vector<double> scratch(QPC_SCRATCH_DOUBLES, std::nan("")); // a fresh (poisoned) spill slot per QP
+    io.scratch = scratch.data();
+    qpc::qpc_tick_prologue<Lds>(D, c->prog.itab.data(), Lds{0});
+    if (job.working_set) qpc::qpc_tick<Lds, true>(D, c->prog.itab.data(), c->prog.dtab.data(), Lds{0}, io);
+    else qpc::qpc_tick<Lds, false>(D, c->prog.itab.data(), c->prog.dtab.data(), Lds{0}, io);
+    races += emu.races; uninit += emu.uninit; outside += emu.outside;
+    if (first.empty()) first = emu.first;
+  }
+  g_emu = nullptr;
+  std::lock_guard<std::mutex> lk(g_rep_mu);
+  g_races += races; g_uninit += uninit; g_outside += outside;
+  if (g_first.empty()) g_first = first;
+}
+
+// CPU backend of the host pipeline (qpc_pipeline.h) with any number of fake devices: the pipeline's shard / chunk
+// arithmetic, worker hand-off and error propagation run exactly as in the product, the "device" is the emulator
+class EmuBackend : public QpcChunkBackend {
+ public:
+  EmuBackend(qpc_controller *c, int ndev) : c_(c), ndev_(ndev) {}
+  int n_devices() const override { return ndev_; }
+  void bind_thread(int) override {}
+  int run_chunk(int d, int slot, const QpcHostJob &job, int64_t lo, int64_t n, std::string &err) override {
+    if (fail_at >= 0 && lo <= fail_at && fail_at < lo + n) { err = "injected failure"; return QPC_ERR_HIP; } // test hook
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      chunks.push_back({d, slot, lo, n});
+    }
+    emu_ticks(c_, job, lo, n);
+    return QPC_OK;
+  }
+  struct Rec { int dev, slot; int64_t lo, n; };
+  std::mutex mu;
+  std::vector<Rec> chunks;
+  int64_t fail_at = -1;
+
+ private:
+  qpc_controller *c_;
+  int ndev_;
+};
+struct QpcRuntime {
+  EmuBackend *backend = nullptr;
+  QpcHostPipeline *pipe = nullptr;
+};
+
+static int fill_job(qpc_controller *c, QpcHostJob &job, int64_t B, const double *q, const double *v, const double *desired,
+                    const double *cw, const double *cmax, const double *tw, const double *surf, double *tau, double *vdot,
+                    double *cwrench, int32_t *status, int32_t *iters, uint64_t *wsets) {
+  if (!c || !c->finalized || !c->rt) return QPC_ERR_NOT_FINALIZED;
+  const QpcDims &D = c->prog.dims;
+  job.B = B;
+  const double *hin[QpcHostJob::N_IN] = {q, v, desired, cw, cmax, tw, surf};
+  const size_t nin[QpcHostJob::N_IN] = {(size_t)D.nq, (size_t)D.nv, (size_t)D.n_desired, (size_t)D.nc, (size_t)D.nc, (size_t)D.n_tw, (size_t)D.n_surf};
+  for (int i = 0; i < QpcHostJob::N_IN; i++) { job.in[i] = nin[i] ? hin[i] : nullptr; job.in_dim[i] = nin[i]; }
+  double *hout[QpcHostJob::N_OUT] = {tau, vdot, D.nc ? cwrench : nullptr};
+  const size_t nout[QpcHostJob::N_OUT] = {(size_t)D.nv, (size_t)D.nv, (size_t)6 * D.nc};
+  for (int i = 0; i < QpcHostJob::N_OUT; i++) { job.out[i] = hout[i]; job.out_dim[i] = nout[i]; }
+  job.status = status; job.iters = iters; job.working_set = wsets;
+  return QPC_OK;
+}
+
 extern "C" {
 
-int32_t qpc_finalize(qpc_controller *c, int32_t device_id, qpc_layout *out) {
-  (void)device_id;
-  if (!c) return QPC_ERR_INVALID_ARGUMENT;
+int32_t qpc_finalize_devices(qpc_controller *c, int32_t n_devices, const int32_t *device_ids, qpc_layout *out) {
+  if (!c || n_devices < 1 || !device_ids) return QPC_ERR_INVALID_ARGUMENT;
   if (!c->finalized) {
     int rc = qpc_compile_program(c);
     if (rc != QPC_OK) return rc;
+    c->rt = new QpcRuntime();
+    c->rt->backend = new EmuBackend(c, n_devices);
+    c->rt->pipe = new QpcHostPipeline(c->rt->backend, c->pipe_slots > 0 ? c->pipe_slots : 3, c->pipe_chunk > 0 ? c->pipe_chunk : 8192,
+                                      c->pipe_inline >= 0 ? c->pipe_inline : 2048);
     c->finalized = true;
   }
   if (out) *out = c->layout;
   return QPC_OK;
 }
-void qpc_controller_destroy(qpc_controller *c) { delete c; }
+int32_t qpc_finalize(qpc_controller *c, int32_t device_id, qpc_layout *out) { return qpc_finalize_devices(c, 1, &device_id, out); }
+int32_t qpc_n_devices(const qpc_controller *c) { return (c && c->rt) ? c->rt->backend->n_devices() : 0; }
+void qpc_controller_destroy(qpc_controller *c) {
+  if (!c) return;
+  if (c->rt) { delete c->rt->pipe; delete c->rt->backend; delete c->rt; }
+  delete c;
+}
+int32_t qpc_set_host_pipeline(qpc_controller *c, int64_t chunk_qps, int32_t slots_per_device, int64_t inline_qps) {
+  if (!c) return QPC_ERR_INVALID_ARGUMENT;
+  if (slots_per_device > 0) { if (c->finalized) return QPC_ERR_ALREADY_FINALIZED; c->pipe_slots = slots_per_device; }
+  if (chunk_qps > 0) c->pipe_chunk = chunk_qps;
+  if (inline_qps >= 0) c->pipe_inline = inline_qps;
+  if (c->rt) {
+    std::string e;
+    (void)c->rt->pipe->wait(e);
+    if (chunk_qps > 0) c->rt->pipe->set_chunk_qps(chunk_qps);
+    if (inline_qps >= 0) c->rt->pipe->set_inline_qps(inline_qps);
+  }
+  return QPC_OK;
+}
+
+static int run_job(qpc_controller *c, const QpcHostJob &job) {
+  if (job.B == 0) return QPC_OK;
+  std::string err;
+  const int rc = c->rt->pipe->run(job, err);
+  if (rc != QPC_OK) qpc_set_error(err);
+  return rc;
+}
 
 int32_t qpc_control_batch(qpc_controller *c, int64_t B, const double *q, const double *v, const double *desired,
                           const double *cw, const double *cmax, const double *tw, const double *surf, double *tau,
                           double *vdot, double *cwrench, int32_t *status, int32_t *iters) {
-  if (!c || !c->finalized) return QPC_ERR_NOT_FINALIZED;
-  const QpcDims &D = c->prog.dims;
-  EmuState emu;
-  g_emu = &emu;
-  for (int64_t b = 0; b < B; b++) {
-    emu.reset(D.lds_doubles + 128 * 8);
-    qpc::TickIO io;
-    io.q = q + b * D.nq; io.v = v + b * D.nv; io.desired = desired ? desired + b * D.n_desired : nullptr;
-    io.cw = cw ? cw + b * D.nc : nullptr; io.cmax = cmax ? cmax + b * D.nc : nullptr;
-    io.tw = tw ? tw + b * D.n_tw : nullptr; io.surf = surf ? surf + b * D.n_surf : nullptr;
-    io.tau = tau + b * D.nv; io.vdot = vdot + b * D.nv; io.cwrench = cwrench ? cwrench + b * 6 * D.nc : nullptr;
-    io.status = status + b; io.iters = iters ? iters + b : nullptr; io.prof = nullptr;
-    std::vector<double> scratch(QPC_SCRATCH_DOUBLES, std::nan("")); // a fresh (poisoned) spill slot per QP
-    io.scratch = scratch.data();
-    qpc::qpc_tick_prologue<Lds>(D, c->prog.itab.data(), Lds{0});
-    qpc::qpc_tick<Lds>(D, c->prog.itab.data(), c->prog.dtab.data(), Lds{0}, io);
-    g_races += emu.races; g_uninit += emu.uninit; g_outside += emu.outside;
-    if (g_first.empty()) g_first = emu.first;
-  }
-  g_emu = nullptr;
+  QpcHostJob job;
+  int rc = fill_job(c, job, B, q, v, desired, cw, cmax, tw, surf, tau, vdot, cwrench, status, iters, nullptr);
+  return rc != QPC_OK ? rc : run_job(c, job);
+}
+int32_t qpc_control_batch_warm(qpc_controller *c, int64_t B, const double *q, const double *v, const double *desired,
+                               const double *cw, const double *cmax, const double *tw, const double *surf, double *tau,
+                               double *vdot, double *cwrench, int32_t *status, int32_t *iters, uint64_t *working_set) {
+  if (!working_set) return QPC_ERR_INVALID_ARGUMENT;
+  if (c && !c->warm_start) { qpc_set_error("qpc_control_batch_warm: call qpc_enable_warm_start before qpc_finalize"); return QPC_ERR_UNSUPPORTED; }
+  QpcHostJob job;
+  int rc = fill_job(c, job, B, q, v, desired, cw, cmax, tw, surf, tau, vdot, cwrench, status, iters, working_set);
+  return rc != QPC_OK ? rc : run_job(c, job);
+}
+int32_t qpc_control_batch_async(qpc_controller *c, int64_t B, const double *q, const double *v, const double *desired,
+                                const double *cw, const double *cmax, const double *tw, const double *surf, double *tau,
+                                double *vdot, double *cwrench, int32_t *status, int32_t *iters) {
+  QpcHostJob job;
+  int rc = fill_job(c, job, B, q, v, desired, cw, cmax, tw, surf, tau, vdot, cwrench, status, iters, nullptr);
+  if (rc != QPC_OK) return rc;
+  if (B > 0) c->rt->pipe->submit(job);
   return QPC_OK;
 }
+int32_t qpc_wait(qpc_controller *c) {
+  if (!c || !c->finalized || !c->rt) return QPC_ERR_NOT_FINALIZED;
+  std::string err;
+  const int rc = c->rt->pipe->wait(err);
+  if (rc != QPC_OK) qpc_set_error(err);
+  return rc;
+}
+// test hooks of the fake-device backend: which (device, slot) ran which chunk; inject a failure into the chunk holding QP b
+int32_t emu_chunk_log(qpc_controller *c, int64_t *out, int32_t max_rows) {
+  std::lock_guard<std::mutex> lk(c->rt->backend->mu);
+  int n = 0;
+  for (auto &r : c->rt->backend->chunks) {
+    if (n < max_rows) { out[4 * n] = r.dev; out[4 * n + 1] = r.slot; out[4 * n + 2] = r.lo; out[4 * n + 3] = r.n; }
+    n++;
+  }
+  c->rt->backend->chunks.clear();
+  return n;
+}
+void emu_fail_at(qpc_controller *c, int64_t b) { c->rt->backend->fail_at = b; }
 
 // L1 (plain serial code per QP, like L0)
 int32_t qpc_assemble_solve_batch(qpc_controller *c, int64_t B, const double *task_J, const double *task_bias,
@@ -242,6 +372,7 @@ int32_t qpc_rollout_batch(qpc_controller *c, int64_t B, int64_t n_steps, double 
 
 // race-detector report: counts since the last call
 void emu_report(long *races, long *uninit, long *outside, char *first, int n) {
+  std::lock_guard<std::mutex> lk(g_rep_mu);
   *races = g_races; *uninit = g_uninit; *outside = g_outside;
   snprintf(first, n, "%s", g_first.c_str());
   g_races = g_uninit = g_outside = 0; g_first.clear();

@@ -80,7 +80,7 @@ def acrobot_point_task(factory, B=4, seed=9):
     q = rng.uniform(-1.0, 1.0, size=(B, 2)) + np.array([-np.pi, 0.8])
     v = rng.normal(size=(B, 2))
     des = rng.normal(size=(B, 3)) * np.array([1.0, 0.0, 1.0])  # the tip moves in the x-z plane
-    return Case("acrobot_point", mech, c, q, v, des, np.zeros((B, 0)), np.zeros((B, 0)), tol_tau=1e-6)
+    return Case("acrobot_point", mech, c, q, v, des, np.zeros((B, 0)), np.zeros((B, 0)))
 
 
 def free_fall(factory, B=3, seed=5354):
@@ -143,7 +143,7 @@ def momentum_rate(factory, seed=533454):
         qs.append(q); vs.append(v); des.append(hdes); cws.append(cw); cmaxs.append(cmax)
     B = len(qs)
     return Case("momentum_rate", mech, c, np.array(qs), np.array(vs), np.array(des), np.array(cws),
-                np.array(cmaxs), surf=np.tile(surf1, (B, 1)), floating=fl, tol_tau=1e-6)
+                np.array(cmaxs), surf=np.tile(surf1, (B, 1)), floating=fl)
 
 
 def spatial_acceleration(factory, mode, B=2, seed=533):
@@ -207,7 +207,7 @@ def mixed_tasks(factory, B=6, seed=77, floating=True):
     cw = np.full((B, nc), 1e-2)
     cmax = np.full((B, nc), 1e4)
     cmax[1::3, 0] = 0.0
-    return Case("mixed_tasks" if floating else "mixed_tasks_fixed", mech, c, q, v, des, cw, cmax, tw=tw, floating=fl, tol_tau=1e-6)
+    return Case("mixed_tasks" if floating else "mixed_tasks_fixed", mech, c, q, v, des, cw, cmax, tw=tw, floating=fl)
 
 
 def atlas_config(factory, config, B):

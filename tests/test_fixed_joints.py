@@ -39,7 +39,7 @@ def make(factory, floating, B=4, seed=21):
     nc = 4 if floating else 0
     des = rng.normal(size=(B, 3 + 1 + 3))
     return SC.Case("fixed_joints_" + ("floating" if floating else "fixedbase"), mech, c, np.array(qs), np.array(vs), des,
-                   np.full((B, nc), 1e-2), np.full((B, nc), 1e4), floating=fl, tol_tau=1e-7)
+                   np.full((B, nc), 1e-2), np.full((B, nc), 1e4), floating=fl)
 
 
 def _run(factory, floating):

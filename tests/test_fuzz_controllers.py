@@ -91,7 +91,7 @@ def build(factory, seed, B=2):
                 cols.append(np.array(Ws))
         tw = np.concatenate(cols, axis=1)
     return SC.Case(f"fuzz{seed}", mech, c, np.array(qs), np.array(vs), des, np.full((B, nc), 1e-2), np.full((B, nc), 1e4),
-                   tw=tw, floating=fl, n_basis=N, tol_tau=1e-6)
+                   tw=tw, floating=fl, n_basis=N)
 
 
 @pytest.mark.parametrize("seed", range(40))

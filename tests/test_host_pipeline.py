@@ -1,0 +1,225 @@
+"""Host-pointer pipeline of the C ABI (qpcontrol.jl_amd/csrc/qpc_pipeline.h): qpc_finalize_devices,
+qpc_control_batch sharded over devices and cut into chunks, qpc_control_batch_async + qpc_wait,
+error propagation from a worker thread.
+
+The pipeline is backend-agnostic C++; here it drives the test emulator's fake devices (CPU), so what
+is checked is exactly what can go wrong on the host side: shard / chunk offsets, every QP solved
+exactly once, results bitwise equal to the single-shard call, a job in flight is waited for, a
+failing chunk surfaces as the call's error.  The `-m gpu` twin runs the HIP backend."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import emu
+from qpcontrol_jl_amd import binding
+from qpcontrol_jl_amd import workloads as W
+
+
+def _workload(factory, B, config=3, devices=None, chunk=0, slots=0, inline=-1, warm=False):
+    real = binding.Controller.finalize
+
+    def fin(self, device_id=0):
+        if slots or chunk or inline >= 0:
+            self.set_host_pipeline(chunk, slots, inline)
+        if warm:
+            self.enable_warm_start()
+        return real(self, device_id, devices=devices)
+    binding.Controller.finalize = fin
+    try:
+        return W.atlas_workload(factory, B, config)
+    finally:
+        binding.Controller.finalize = real
+
+
+def _tick(c, wl, **kw):
+    return c.control_batch(wl.q, wl.v, wl.desired, wl.contact_weight, wl.contact_maxnormalforce, **kw)
+
+
+def _chunk_log(c):
+    L = ctypes.CDLL(emu.EMU_LIB)
+    L.emu_chunk_log.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_int32]
+    buf = (ctypes.c_int64 * (4 * 4096))()
+    n = L.emu_chunk_log(c.h, buf, 4096)
+    return np.array(buf[:4 * n], dtype=np.int64).reshape(n, 4)
+
+
+def test_shard_bounds_match_python_mirror():
+    for B in (0, 1, 7, 8, 9, 1000):
+        for G in (1, 2, 3, 8):
+            cover = []
+            for g in range(G):
+                lo, hi = W.shard_bounds(B, g, G)
+                cover += list(range(lo, hi))
+            assert cover == list(range(B))
+
+
+@pytest.mark.parametrize("ndev,chunk,slots", [(2, 3, 2), (3, 4, 1), (1, 5, 3), (8, 1, 2)])
+def test_two_shards_in_one_process_bitwise_equal(ndev, chunk, slots):
+    """one process drives several (fake) devices; the result equals the single-shard call bit for bit
+    and every QP is solved exactly once by the device that owns its contiguous shard."""
+    emu.build()
+    B = 29
+    c1, wl = _workload(emu.factory, B, inline=10 ** 9)            # everything inline on the caller's thread
+    cN, _ = _workload(emu.factory, B, devices=list(range(ndev)), chunk=chunk, slots=slots, inline=0)
+    assert cN.n_devices() == ndev
+    r1 = _tick(c1, wl)
+    _chunk_log(cN)
+    rN = _tick(cN, wl)
+    for k in ("tau", "vdot", "cwrench", "status", "iters"):
+        assert np.array_equal(r1[k], rN[k]), k
+    log = _chunk_log(cN)
+    owner = -np.ones(B, dtype=int)
+    for dev, slot, lo, n in log:
+        assert 0 <= slot < slots and 1 <= n <= chunk
+        assert np.all(owner[lo:lo + n] == -1)  # no QP twice
+        owner[lo:lo + n] = dev
+    for g in range(ndev):  # QP index range [g B/G, (g+1) B/G) -> device g
+        lo, hi = W.shard_bounds(B, g, ndev)
+        assert np.all(owner[lo:hi] == g)
+
+
+def test_async_then_wait_and_back_to_back_jobs():
+    emu.build()
+    B = 12
+    c, wl = _workload(emu.factory, B, devices=[0, 1], chunk=2, slots=2, inline=0)
+    ref = _tick(c, wl)
+    p1 = _tick(c, wl, asynchronous=True)
+    # a second job posted while the first may still be running: it first waits for the first (one job in flight)
+    wl2q = wl.q[::-1].copy()
+    p2 = c.control_batch(wl2q, wl.v[::-1].copy(), wl.desired[::-1].copy(), wl.contact_weight[::-1].copy(),
+                         wl.contact_maxnormalforce[::-1].copy(), asynchronous=True)
+    r2 = p2.wait()
+    r1 = p1.result  # complete: job 2 could not start before job 1 was done
+    assert np.array_equal(r1["tau"], ref["tau"]) and np.array_equal(r1["status"], ref["status"])
+    assert np.array_equal(r2["tau"], ref["tau"][::-1])
+    c.wait()  # nothing in flight: returns at once with QPC_OK
+    # B = 0 is a no-op
+    e = c.control_batch(np.zeros((0, wl.q.shape[1])), np.zeros((0, wl.v.shape[1])), np.zeros((0, wl.desired.shape[1])),
+                        np.zeros((0, 8)), np.zeros((0, 8)))
+    assert e["tau"].shape[0] == 0
+
+
+def test_worker_error_reaches_the_caller():
+    emu.build()
+    B = 16
+    c, wl = _workload(emu.factory, B, devices=[0, 1], chunk=2, slots=2, inline=0)
+    L = ctypes.CDLL(emu.EMU_LIB)
+    L.emu_fail_at.argtypes = [ctypes.c_void_p, ctypes.c_int64]
+    L.emu_fail_at(c.h, 11)
+    with pytest.raises(binding.QpcError, match="injected failure"):
+        _tick(c, wl)
+    p = _tick(c, wl, asynchronous=True)  # async: the error is the job's, reported by wait
+    with pytest.raises(binding.QpcError, match="injected failure"):
+        p.wait()
+    L.emu_fail_at(c.h, -1)
+    r = _tick(c, wl)  # the controller stays usable
+    assert (r["status"] == 0).all()
+
+
+def test_pipeline_settings_validation():
+    emu.build()
+    c, wl = _workload(emu.factory, 4)
+    with pytest.raises(binding.QpcError):
+        c.set_host_pipeline(slots_per_device=2)  # fixed by qpc_finalize
+    c.set_host_pipeline(chunk_qps=2, inline_qps=0)  # chunk / inline threshold may change between jobs
+    r = _tick(c, wl)
+    assert (r["status"] == 0).all()
+
+
+# ---- GPU: the same properties through the HIP backend --------------------------------------------
+def gpu_factory(mech, n_basis, floating):
+    return binding.Controller(binding.Model(mech), n_basis, floating)
+
+
+@pytest.mark.gpu
+def test_gpu_pipelined_host_path_equals_device_path():
+    """chunked + multi-slot host-pointer path == one inline launch, bitwise (the QPs are independent and the kernel is
+    deterministic per QP), for pageable AND pinned caller arrays, sync and async."""
+    B = 5000
+    c1, wl = _workload(gpu_factory, B, inline=10 ** 9, chunk=10 ** 9)
+    cN, _ = _workload(gpu_factory, B, chunk=512, slots=3, inline=0)
+    r1 = _tick(c1, wl)
+    rN = _tick(cN, wl)
+    for k in ("tau", "vdot", "cwrench", "status", "iters"):
+        assert np.array_equal(r1[k], rN[k]), k
+    ra = _tick(cN, wl, asynchronous=True).wait()
+    assert np.array_equal(ra["tau"], r1["tau"])
+    # pinned caller arrays are DMA-ed in place
+    L = cN.L
+    pin = {k: binding.pinned_array(L, a.shape) for k, a in dict(q=wl.q, v=wl.v, d=wl.desired, cw=wl.contact_weight,
+                                                               cm=wl.contact_maxnormalforce).items()}
+    for k, a in dict(q=wl.q, v=wl.v, d=wl.desired, cw=wl.contact_weight, cm=wl.contact_maxnormalforce).items():
+        pin[k][...] = a
+    lay = cN.layout
+    out = dict(tau=binding.pinned_array(L, (B, lay.nv)), vdot=binding.pinned_array(L, (B, lay.nv)),
+               cwrench_flat=binding.pinned_array(L, (B, 6 * lay.n_contacts)), status=binding.pinned_array(L, (B,), np.int32),
+               iters=binding.pinned_array(L, (B,), np.int32))
+    rp = cN.control_batch(pin["q"], pin["v"], pin["d"], pin["cw"], pin["cm"], out=out)
+    for k in ("tau", "vdot", "cwrench", "status", "iters"):
+        assert np.array_equal(r1[k], rp[k]), k
+    # ragged: B not a multiple of the chunk, smaller than one chunk, one QP
+    for Bs in (1, 511, 513):
+        rs = cN.control_batch(wl.q[:Bs], wl.v[:Bs], wl.desired[:Bs], wl.contact_weight[:Bs], wl.contact_maxnormalforce[:Bs])
+        assert np.array_equal(rs["tau"], r1["tau"][:Bs])
+
+
+@pytest.mark.gpu
+def test_gpu_user_streams_are_serialised():
+    """two launches of one controller on different streams share the work counter; the library turns the
+    change of stream into an event dependency -- both results must be complete and correct."""
+    import torch
+    B = 4096
+    c, wl = _workload(gpu_factory, B)
+    ref = _tick(c, wl)
+    dev = torch.device("cuda", 0)
+    t = {k: torch.from_numpy(np.ascontiguousarray(a)).to(dev) for k, a in dict(q=wl.q, v=wl.v, d=wl.desired, cw=wl.contact_weight,
+                                                                               cm=wl.contact_maxnormalforce).items()}
+    lay = c.layout
+    outs = []
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    vp = ctypes.c_void_p
+    for rep in range(6):
+        tau = torch.full((B, lay.nv), float("nan"), dtype=torch.float64, device=dev)
+        vd = torch.empty((B, lay.nv), dtype=torch.float64, device=dev)
+        st = torch.full((B,), -1, dtype=torch.int32, device=dev)
+        s = streams[rep % 3]
+        rc = c.L.qpc_control_batch_device(c.h, B, vp(t["q"].data_ptr()), vp(t["v"].data_ptr()), vp(t["d"].data_ptr()),
+                                          vp(t["cw"].data_ptr()), vp(t["cm"].data_ptr()), vp(0), vp(0), vp(tau.data_ptr()),
+                                          vp(vd.data_ptr()), vp(0), vp(st.data_ptr()), vp(0), vp(s.cuda_stream))
+        assert rc == 0
+        outs.append((tau, st))
+    torch.cuda.synchronize(dev)
+    for tau, st in outs:
+        assert np.array_equal(st.cpu().numpy(), ref["status"])
+        assert np.array_equal(tau.cpu().numpy(), ref["tau"])
+
+
+@pytest.mark.gpu
+def test_gpu_graph_replay_of_the_tick():
+    """the work counter re-arms itself on the device, so a captured tick can be replayed (hipGraph)"""
+    import torch
+    B = 2048
+    c, wl = _workload(gpu_factory, B)
+    ref = _tick(c, wl)
+    dev = torch.device("cuda", 0)
+    t = {k: torch.from_numpy(np.ascontiguousarray(a)).to(dev) for k, a in dict(q=wl.q, v=wl.v, d=wl.desired, cw=wl.contact_weight,
+                                                                               cm=wl.contact_maxnormalforce).items()}
+    lay = c.layout
+    tau = torch.zeros((B, lay.nv), dtype=torch.float64, device=dev)
+    vd = torch.zeros((B, lay.nv), dtype=torch.float64, device=dev)
+    st = torch.zeros((B,), dtype=torch.int32, device=dev)
+    vp = ctypes.c_void_p
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream(dev)
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            rc = c.L.qpc_control_batch_device(c.h, B, vp(t["q"].data_ptr()), vp(t["v"].data_ptr()), vp(t["d"].data_ptr()),
+                                              vp(t["cw"].data_ptr()), vp(t["cm"].data_ptr()), vp(0), vp(0), vp(tau.data_ptr()),
+                                              vp(vd.data_ptr()), vp(0), vp(st.data_ptr()), vp(0), vp(s.cuda_stream))
+            assert rc == 0
+    for _ in range(3):
+        tau.fill_(float("nan"))
+        g.replay()
+        torch.cuda.synchronize(dev)
+        assert np.array_equal(tau.cpu().numpy(), ref["tau"])

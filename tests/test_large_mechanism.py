@@ -44,7 +44,7 @@ def make(factory, B=3, seed=9, big=False):
     nc = 2 * len(contact_bodies)
     des = rng.normal(size=(B, 6 + 6 + 3 + 3 + 3 + 6 * len(extra) + 7)) * 0.5
     return SC.Case("large_mechanism" + ("_big" if big else ""), mech, c, np.array(qs), np.array(vs), des, np.full((B, nc), 1e-2),
-                   np.full((B, nc), 1e4), floating=0, n_basis=6, tol_tau=1e-6)
+                   np.full((B, nc), 1e4), floating=0, n_basis=6)
 
 
 def _run(factory, big=False):

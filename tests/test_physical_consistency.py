@@ -24,7 +24,7 @@ def check(factory, B, config, fused_laws=False):
     oc, _ = W.atlas_workload(ora_factory, 1, config)
     om, mech, st = oc.model, wl.mech, wl.setup
     ok = np.where(r["status"] == 0)[0]
-    assert len(ok) >= B // 2
+    assert len(ok) == B if config != 5 else len(ok) >= B // 2  # configs 2 and 3: every QP solves
     for b in ok:
         om.set_state(wl.q[b], wl.v[b])
         wext = np.zeros((mech.nbodies, 6))
@@ -34,13 +34,13 @@ def check(factory, B, config, fused_laws=False):
             _, _, R, p = oc.contact_eval(ci, cp.normal, cp.mu, wl.contact_maxnormalforce[b, ci])
             f = R.T @ r["cwrench"][b, ci, 3:]
             assert f[2] >= -1e-7 and np.hypot(f[0], f[1]) <= cp.mu * f[2] + 1e-6, (b, ci, f)
-            np.testing.assert_allclose(r["cwrench"][b, ci, :3], np.cross(p, r["cwrench"][b, ci, 3:]), atol=1e-7)
+            np.testing.assert_allclose(r["cwrench"][b, ci, :3], np.cross(p, r["cwrench"][b, ci, 3:]), atol=1e-9)
         vd_fd = om.forward_dynamics(r["tau"][b], wext)
-        np.testing.assert_allclose(vd_fd, r["vdot"][b], atol=2e-7, rtol=0)
+        np.testing.assert_allclose(vd_fd, r["vdot"][b], atol=5e-10, rtol=0)  # achieved: ~3e-11 (reference ID o FD bar: 1e-10 on a 3-joint arm)
         for tid in list(st.foot_tasks) + [st.pelvis_task]:  # hard tasks
             J, bias = oc.task_eval(tid)
             o = st.offsets[tid]
-            np.testing.assert_allclose(J @ r["vdot"][b] + bias, wl.desired[b, o:o + len(bias)], atol=1e-7, rtol=0)
+            np.testing.assert_allclose(J @ r["vdot"][b] + bias, wl.desired[b, o:o + len(bias)], atol=1e-10, rtol=0)  # achieved: ~3e-15
     return len(ok)
 
 
