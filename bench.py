@@ -10,10 +10,17 @@ reproduces config 4 (B = 262144 sharded over 8 GPUs, no collective in the data p
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  Beside the headline (device-resident, timed region = K launches):
+  config.secondary   the literal BASELINE batches on the same GPU, measured after the timed region:
+                     config 2 @ 1024, config 3 @ 8192, config 5 @ 32768, config 3 @ 262144
+  config.host_pointer_path_*   the host-pointer entry point the Julia shim binds (PCIe inclusive; never `value`)
+  roofline           HBM (algorithmic bytes) + fp64 (algorithmic flops) fractions of the tick kernel, live HIP events
+  cpu_baseline       the oracle (CPU restatement of the reference path) on the host cores: cold start, the
+                     reference's operating regime (same model every tick: warm start), notebook tolerances
 """
 import argparse
 import ctypes
+import glob
 import json
 import os
 import sys
@@ -26,22 +33,16 @@ sys.path.insert(0, ROOT)
 
 ALG_BYTES_PER_SOLVE = 1968  # in 8*(37+36+36+16) + out 8*(36+36+48) + 8
 ALG_FLOPS_PER_SOLVE = 4.6e5  # one reduced-KKT factor+solve + assembly + FK/RNEA
-# HBM traffic per solve measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes
-# (profiles/r01_v35_pmc_*.csv, r01_v35_traffic_summary.json; tools/profile_round.sh): 185389 KiB read + 259537 KiB written per
-# 32768-QP launch.  ~5.6 KB each way per solve is the deliberate lane-private spill slot (22 x 32 lanes x 8 B), the rest
-# register spills of the 256-VGPR kernel; the slot (inertias,
-# bias wrenches, motion subspaces parked in HBM during the solve so that 8 QPs fit the LDS of a CU,
-# DESIGN.md 4); the slots total 23 MB and live in L2 / Infinity Cache, TCC->EA requests count them anyway.
-# 8-byte-per-lane accesses: the gfx950 "x2 for 16-B wide reads" correction of MI355X_MICROARCH.md
-# does not apply.
-MEASURED_TRAFFIC_BYTES_PER_SOLVE = (185389.1 + 259537.1) * 1024 / 32768
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md (spec; 6.29e12 measured)
 FP64_PEAK = 78.6e12  # FLOP/s vector fp64 (datasheet)
 
 
+# ------------------------------------------------------------------------------------------ CPU baseline (child processes)
 def _cpu_worker(rank, B_sample, budget_s):
-    """One host core: the oracle's reference-layout tick on its own slice of the workload for
-    `budget_s` seconds.  Runs in a child process (no torch, no HIP)."""
+    """One host core: the oracle's reference-layout tick on its own slice of the workload.  Three legs:
+    cold start at the test-suite tolerances (budget_s), the reference's operating regime -- ONE model ticked every
+    millisecond along a closed-loop trajectory, OSQP warm-started from the previous tick (momentum.jl:58) -- at the same
+    tolerances (budget_s / 2), and cold start at the notebook's tolerances (budget_s / 3).  No torch, no HIP."""
     import qpc_pkg
     qpc_pkg.load()
     from qpcontrol_jl_amd import workloads as W
@@ -52,36 +53,61 @@ def _cpu_worker(rank, B_sample, budget_s):
 
     oc, wl = W.atlas_workload(factory, B_sample, 3, seed=2025 + 104729 * rank)
     oc.set_settings(O.test_settings(polish=0))
-    done, iters, chunk = 0, 0, 16
+    done, chunk = 0, 16
+    iters = []
     t0 = time.perf_counter()
     while done < B_sample and time.perf_counter() - t0 < budget_s:
         s = slice(done, done + chunk)
         r = oc.tick_batch(wl.q[s], wl.v[s], wl.desired[s], wl.contact_weight[s], wl.contact_maxnormalforce[s])
-        iters += int(r["iters"].sum())
+        iters += [int(x) for x in r["iters"]]
         done += len(r["iters"])
     sec = time.perf_counter() - t0
-    # the same path at the looser tolerances of the reference's notebook (Standing controller.ipynb:64-71,
-    # eps 1e-5): what a user of the reference would run interactively; a third of the budget
+    # warm start: closed-loop 1 kHz trajectories (tick -> semi-implicit Euler with the QP's own v̇), desireds from the
+    # StandingController laws at every step; the first tick of a trajectory is cold and not counted
+    om = oc.model
+    w_done, w_iters, w_sec, traj = 0, [], 0.0, 0
+    t1 = time.perf_counter()
+    while time.perf_counter() - t1 < budget_s / 2 and traj < B_sample:
+        q, v = wl.q[traj].copy(), wl.v[traj].copy()
+        for k in range(40):
+            des = W.standing_desired(wl.setup, q[None], v[None])[0]
+            ta = time.perf_counter()
+            r = oc.tick(q, v, des, wl.contact_weight[traj], wl.contact_maxnormalforce[traj], warm=(k > 0))
+            tb = time.perf_counter()
+            if r["status"] != 0:
+                break
+            if k > 0:
+                w_done += 1; w_iters.append(int(r["info"].iters)); w_sec += tb - ta
+            v = v + 1e-3 * r["vdot"]
+            q = om.integrate(q, v, 1e-3)
+        traj += 1
     oc.set_settings(O.notebook_settings(polish=0))
     nb_done, nb_iters, off = 0, 0, 0
-    t1 = time.perf_counter()
-    while off < B_sample and time.perf_counter() - t1 < budget_s / 3:
+    t2 = time.perf_counter()
+    while off < B_sample and time.perf_counter() - t2 < budget_s / 3:
         s = slice(off, off + chunk)
         r = oc.tick_batch(wl.q[s], wl.v[s], wl.desired[s], wl.contact_weight[s], wl.contact_maxnormalforce[s])
         nb_iters += int(r["iters"].sum())
         nb_done += len(r["iters"])
         off += chunk
-    print(json.dumps({"done": done, "iters": iters, "seconds": sec, "nb_done": nb_done, "nb_iters": nb_iters,
-                      "nb_seconds": time.perf_counter() - t1}))
+    print(json.dumps({"done": done, "iters": iters, "seconds": sec, "warm_done": w_done, "warm_iters": w_iters, "warm_seconds": w_sec,
+                      "nb_done": nb_done, "nb_iters": nb_iters, "nb_seconds": time.perf_counter() - t2}))
 
 
-def cpu_baseline(budget_s=12.0, max_workers=64):
-    """The oracle (CPU restatement of the reference path: 143x178 reference-layout problem,
-    coefficient rewrite per tick, OSQP-algorithm ADMM with the test-suite settings of
-    test/runtests.jl:35-43, cold start, RNEA) timed on the host cores of the box: one independent
-    controller per process over disjoint slices, bounded by `budget_s` seconds.
-    `value` is the all-cores rate, `single_core` the rate of one of those processes.
-    The workers are child processes of this script (`--cpu-worker`): they never touch torch or HIP."""
+def _histogram(iters, max_iter=20000):
+    edges = [0, 100, 250, 500, 1000, 2500, 5000, 10000, max_iter]
+    it = np.asarray(iters)
+    h = {f"{lo}-{hi}": int(((it >= lo) & (it < hi)).sum()) for lo, hi in zip(edges[:-1], edges[1:])}
+    h[f">={max_iter} (iteration limit)"] = int((it >= max_iter).sum())
+    return h
+
+
+def cpu_baseline(budget_s=9.0, max_workers=64):
+    """The oracle (CPU restatement of the reference path: 143x178 reference-layout problem, coefficient rewrite per
+    tick, OSQP-algorithm ADMM with the test-suite settings of test/runtests.jl:35-43, RNEA) timed on the host cores of the
+    box: one independent controller per process over disjoint slices, bounded by `budget_s` seconds per leg.
+    `value` is the all-cores COLD-start rate, `single_core` the rate of one of those processes; `warm_start` the same path
+    in the reference's own operating regime.  The workers are child processes (`--cpu-worker`): no torch, no HIP."""
     import subprocess
     from oracle import oracle as O
     O.build(native=True)  # build once, before the workers load the library
@@ -102,27 +128,168 @@ def cpu_baseline(budget_s=12.0, max_workers=64):
                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for r in range(n)]
     res = []
     for p in procs:
-        out, _ = p.communicate(timeout=budget_s * 6 + 120)
+        out, _ = p.communicate(timeout=budget_s * 8 + 180)
         if p.returncode == 0 and out.strip():
             res.append(json.loads(out.strip().splitlines()[-1]))
     wall = time.perf_counter() - t0
     if not res:
         raise RuntimeError("cpu_baseline: no worker finished")
     done = sum(r["done"] for r in res)
-    iters = sum(r["iters"] for r in res)
+    iters = [i for r in res for i in r["iters"]]
     busy = max(r["seconds"] for r in res)
+    w_done = sum(r["warm_done"] for r in res)
+    w_iters = [i for r in res for i in r["warm_iters"]]
+    w_rate = sum(r["warm_done"] / r["warm_seconds"] for r in res if r["warm_seconds"] > 0)
     return {"value": done / busy, "unit": "QP solves/s", "cores": len(res), "kind": "port",
             "single_core": res[0]["done"] / res[0]["seconds"],
+            "admm_iterations": {"mean": float(np.mean(iters)), "median": float(np.median(iters)), "histogram": _histogram(iters)},
+            "warm_start": {"value": w_rate, "single_core": (res[0]["warm_done"] / res[0]["warm_seconds"]) if res[0]["warm_seconds"] > 0 else None,
+                           "ticks": w_done,
+                           "admm_iterations": {"mean": float(np.mean(w_iters)) if w_iters else None,
+                                               "median": float(np.median(w_iters)) if w_iters else None,
+                                               "histogram": _histogram(w_iters) if w_iters else None},
+                           "note": "the reference's own regime: ONE controller ticked at 1 kHz along closed-loop trajectories (tick -> "
+                                   "Euler step with the QP's v̇, StandingController laws re-evaluated), OSQP warm-started from the "
+                                   "previous tick's iterate as momentum.jl:58 does; same tolerances; solve time only"},
             "notebook_settings": {"value": sum(r["nb_done"] for r in res) / max(max(r["nb_seconds"] for r in res), 1e-9),
                                   "mean_admm_iterations": sum(r["nb_iters"] for r in res) / max(sum(r["nb_done"] for r in res), 1),
-                                  "note": "same workload and cores at the notebook's OSQP tolerances (eps_abs = eps_rel = 1e-5): "
+                                  "note": "same workload and cores, cold start, at the notebook's OSQP tolerances (eps_abs = eps_rel = 1e-5): "
                                           "tau then agrees with the fp64 optimum to ~1e-3 only"},
             "sample": f"{done} QPs of the same Atlas config-3 workload over {len(res)} processes (one controller each, disjoint "
-                      f"seeded slices), OSQP restatement eps_abs=1e-8 eps_rel=1e-16 cold start, mean "
-                      f"{iters / max(done, 1):.0f} ADMM iterations, {busy:.1f} s of solving ({wall:.1f} s with process start-up); "
-                      f"host has {os.cpu_count()} cores"}
+                      f"seeded slices), OSQP restatement eps_abs=1e-8 eps_rel=1e-16 max_iter=20000 cold start, mean "
+                      f"{np.mean(iters):.0f} ADMM iterations, {busy:.1f} s of solving ({wall:.1f} s for all three legs with "
+                      f"process start-up); host has {os.cpu_count()} cores"}
 
 
+# ------------------------------------------------------------------------------------------ device-side helpers
+class DeviceRun:
+    """A controller + one workload resident in HBM (torch tensors), launched through qpc_control_batch_device."""
+
+    def __init__(self, torch, binding, W, B, config, seed, device_index, fused_laws=False):
+        self.torch, self.B = torch, B
+        real_finalize = binding.Controller.finalize
+
+        def fin(self_, device_id=0):
+            return real_finalize(self_, device_index)
+        binding.Controller.finalize = fin
+        try:
+            self.ctrl, self.wl = W.atlas_workload(lambda m, N, fl: binding.Controller(binding.Model(m), N, fl), B, config, seed=seed,
+                                                  fused_laws=fused_laws)
+        finally:
+            binding.Controller.finalize = real_finalize
+        self.lay = lay = self.ctrl.layout
+        self.dev = dev = torch.device("cuda", device_index)
+        wl = self.wl
+
+        def dev_t(a):
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+        self.q, self.v = dev_t(wl.q), dev_t(wl.v)
+        self.des = None if fused_laws else dev_t(wl.desired)
+        self.cw, self.cm = dev_t(wl.contact_weight), dev_t(wl.contact_maxnormalforce)
+        self.tau = torch.empty((B, lay.nv), dtype=torch.float64, device=dev)
+        self.vd = torch.empty((B, lay.nv), dtype=torch.float64, device=dev)
+        self.cwr = torch.empty((B, max(lay.n_contacts, 1) * 6), dtype=torch.float64, device=dev)
+        self.status = torch.empty(B, dtype=torch.int32, device=dev)
+        self.iters = torch.empty(B, dtype=torch.int32, device=dev)
+        self.stream = torch.cuda.current_stream(dev)
+
+    def step(self):
+        vp = ctypes.c_void_p
+        L, lay = self.ctrl.L, self.lay
+
+        def ptr(t):
+            return vp(t.data_ptr()) if t is not None and t.numel() else vp(0)
+        nc = lay.n_contacts
+        rc = L.qpc_control_batch_device(self.ctrl.h, self.B, ptr(self.q), ptr(self.v), ptr(self.des), ptr(self.cw) if nc else vp(0),
+                                        ptr(self.cm) if nc else vp(0), vp(0), vp(0), ptr(self.tau), ptr(self.vd),
+                                        ptr(self.cwr) if nc else vp(0), ptr(self.status), ptr(self.iters), vp(self.stream.cuda_stream))
+        if rc != 0:
+            raise RuntimeError(L.qpc_last_error().decode())
+
+    def timed(self, steps, warmup):
+        """(wall seconds for `steps` launches, average kernel ms from HIP events on the launch stream, launches)"""
+        L = self.ctrl.L
+        for _ in range(warmup):
+            self.step()
+        self.torch.cuda.synchronize(self.dev)
+        L.qpc_timing_enable(self.ctrl.h, 1)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        self.torch.cuda.synchronize(self.dev)
+        el = time.perf_counter() - t0
+        avg_ms, nl = ctypes.c_double(0), ctypes.c_int64(0)
+        L.qpc_timing_read(self.ctrl.h, ctypes.byref(avg_ms), ctypes.byref(nl))
+        L.qpc_timing_enable(self.ctrl.h, 0)
+        return el, avg_ms.value, int(nl.value)
+
+
+def secondary_points(torch, binding, W, device_index):
+    """The literal BASELINE.json batches on this GPU (device-resident inputs, same kernel), outside the headline's timed
+    region: config 2 @ 1024, config 3 @ 8192, config 5 @ 32768, config 3 @ 262144."""
+    out = []
+    for config, B, steps in ((2, 1024, 50), (3, 8192, 30), (5, 32768, 20), (3, 262144, 5)):
+        run = DeviceRun(torch, binding, W, B, config, {2: 2024, 3: 2025, 5: 2027}[config], device_index)
+        el, kms, nl = run.timed(steps, 3)
+        st = run.status.cpu().numpy()
+        out.append({"config": config, "batch": B, "solves_per_s": B * steps / el, "ms_per_launch": 1e3 * el / steps, "kernel_ms": kms,
+                    "optimal_fraction": float((st == 0).mean()), "mean_active_set_iters": float((run.iters.cpu().numpy() % 1000).mean())})
+        del run
+    return out
+
+
+def host_pointer_path(binding, run, reps=5):
+    """PCIe-inclusive rate of the host-pointer entry qpc_control_batch on the headline workload (never `value`):
+    with the caller's arrays page-locked (qpc_host_alloc / qpc_host_register, what the Julia shim does with the buffers
+    it owns: the kernel reads and writes them in place) and with plain pageable arrays (staged in chunks)."""
+    c, wl, lay, B = run.ctrl, run.wl, run.lay, run.B
+    L = c.L
+    ins = dict(q=wl.q, v=wl.v, d=wl.desired, cw=wl.contact_weight, cm=wl.contact_maxnormalforce)
+    res = {}
+    for mode in ("pinned", "pageable"):
+        if mode == "pinned":
+            arr = {k: binding.pinned_array(L, a.shape) for k, a in ins.items()}
+            for k, a in ins.items():
+                arr[k][...] = a
+            mk = lambda shape, dt=np.float64: binding.pinned_array(L, shape, dt)  # noqa: E731
+        else:
+            arr = {k: np.ascontiguousarray(a) for k, a in ins.items()}
+            mk = lambda shape, dt=np.float64: np.zeros(shape, dtype=dt)  # noqa: E731
+        out = dict(tau=mk((B, lay.nv)), vdot=mk((B, lay.nv)), cwrench_flat=mk((B, 6 * lay.n_contacts)),
+                   status=mk((B,), np.int32), iters=mk((B,), np.int32))
+        for a in out.values():
+            a[...] = 0
+        for _ in range(2):
+            c.control_batch(arr["q"], arr["v"], arr["d"], arr["cw"], arr["cm"], out=out)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            c.control_batch(arr["q"], arr["v"], arr["d"], arr["cw"], arr["cm"], out=out)
+        res[mode] = B * reps / (time.perf_counter() - t0)
+        assert (out["status"] == 0).mean() > 0.9
+    return res
+
+
+def measured_traffic(fingerprint):
+    """HBM bytes per launch of the tick kernel from the newest rocprofv3 PMC summary under profiles/ whose kernel
+    fingerprint equals the built kernel's (tools/profile_round.sh + tools/summarize_pmc.py); None if there is none."""
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_summary.json"))):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if d.get("kernel_fingerprint") == fingerprint and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+            best = (f, d)
+    if best is None:
+        return None, "no profile under profiles/ carries the fingerprint of the built kernel (" + fingerprint + "): traffic not quoted"
+    f, d = best
+    bytes_per_launch = (d["FETCH_SIZE"]["per_launch_KiB"] + d["WRITE_SIZE"]["per_launch_KiB"]) * 1024.0
+    return bytes_per_launch, (f"{os.path.relpath(f, ROOT)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, KiB as reported on gfx950; "
+                              f"8-byte-per-lane accesses, so the x2 wide-read correction of MI355X_MICROARCH.md does not apply), "
+                              f"{d.get('qps_per_launch', 32768)} QPs per launch, kernel fingerprint {fingerprint} == built kernel")
+
+
+# ------------------------------------------------------------------------------------------ main
 def main():
     if len(sys.argv) >= 5 and sys.argv[1] == "--cpu-worker":
         return _cpu_worker(int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]))
@@ -133,11 +300,10 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=32768)
     ap.add_argument("--config", type=int, default=3, choices=[2, 3, 5])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the literal-BASELINE-batch points and the host-pointer path")
     ap.add_argument("--fused-laws", action="store_true",
                     help="SURVEY 8 f-1: StandingController PD laws (standing.jl:58-89) evaluated in the kernel, no `desired` "
                          "input (a pure (q, v) -> tau map); default is the reference boundary with desireds as inputs")
-    ap.add_argument("--host-path", action="store_true",
-                    help="also time the host-pointer entry point (PCIe-inclusive; reported in config, never `value`)")
     args = ap.parse_args()
 
     import torch
@@ -170,56 +336,11 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     B = args.batch_per_gpu
-
-    def factory(mech, n_basis, floating):
-        return binding.Controller(binding.Model(mech), n_basis, floating)
-
     # every rank builds its own contiguous shard [rank*B, (rank+1)*B) of the global batch
-    import importlib
-    mech_ctrl = None
-    ctrl, wl = None, None
-
-    def make():
-        nonlocal ctrl, wl
-        real_finalize = binding.Controller.finalize
-
-        def fin(self, device_id=0):
-            return real_finalize(self, local_rank)
-        binding.Controller.finalize = fin
-        try:
-            ctrl, wl = W.atlas_workload(factory, B, args.config, seed={2: 2024, 3: 2025, 5: 2027}[args.config] + 7919 * rank,
-                                        fused_laws=args.fused_laws)
-        finally:
-            binding.Controller.finalize = real_finalize
-    make()
-    lay = ctrl.layout
-    dev = torch.device("cuda", local_rank)
-
-    def dev_t(a):
-        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
-
-    q, v, des = dev_t(wl.q), dev_t(wl.v), (None if args.fused_laws else dev_t(wl.desired))
-    cw, cm = dev_t(wl.contact_weight), dev_t(wl.contact_maxnormalforce)
-    tau = torch.empty((B, lay.nv), dtype=torch.float64, device=dev)
-    vd = torch.empty((B, lay.nv), dtype=torch.float64, device=dev)
-    cwr = torch.empty((B, max(lay.n_contacts, 1) * 6), dtype=torch.float64, device=dev)
-    status = torch.empty(B, dtype=torch.int32, device=dev)
-    iters = torch.empty(B, dtype=torch.int32, device=dev)
-    L = ctrl.L
-    vp = ctypes.c_void_p
-
-    def ptr(t):
-        return vp(t.data_ptr()) if t is not None and t.numel() else vp(0)
-
-    stream = torch.cuda.current_stream(dev)
-
-    def step():
-        rc = L.qpc_control_batch_device(ctrl.h, B, ptr(q), ptr(v), ptr(des), ptr(cw) if lay.n_contacts else vp(0),
-                                        ptr(cm) if lay.n_contacts else vp(0), vp(0), vp(0), ptr(tau), ptr(vd),
-                                        ptr(cwr) if lay.n_contacts else vp(0), ptr(status), ptr(iters),
-                                        vp(stream.cuda_stream))
-        if rc != 0:
-            raise RuntimeError(L.qpc_last_error().decode())
+    run = DeviceRun(torch, binding, W, B, args.config, {2: 2024, 3: 2025, 5: 2027}[args.config] + 7919 * rank, local_rank,
+                    fused_laws=args.fused_laws)
+    ctrl, lay, L = run.ctrl, run.lay, run.ctrl.L
+    dev = run.dev
 
     def barrier():
         if dist is not None:
@@ -227,12 +348,12 @@ def main():
         torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
-        step()
+        run.step()
     barrier()
     L.qpc_timing_enable(ctrl.h, 1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        run.step()
     barrier()
     elapsed = time.perf_counter() - t0
     avg_ms, nl = ctypes.c_double(0), ctypes.c_int64(0)
@@ -242,8 +363,8 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_device else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    st = status.cpu().numpy()
-    it = iters.cpu().numpy() % 1000
+    st = run.status.cpu().numpy()
+    it = run.iters.cpu().numpy() % 1000
     fp64_measured = ctypes.c_double(0.0)  # vector-fp64 FMA peak measured on this box, outside the timed region
     if rank == 0 and hasattr(L, "qpc_debug_measure_fp64_peak"):
         L.qpc_debug_measure_fp64_peak.argtypes = [ctypes.c_int32, ctypes.POINTER(ctypes.c_double)]
@@ -251,14 +372,11 @@ def main():
             fp64_measured = ctypes.c_double(0.0)
     n_opt = int((st == 0).sum())
 
-    host_rate = None
-    if args.host_path and world == 1:
-        hdes = None if args.fused_laws else wl.desired
-        ctrl.control_batch(wl.q, wl.v, hdes, wl.contact_weight, wl.contact_maxnormalforce)
-        th = time.perf_counter()
-        for _ in range(3):
-            ctrl.control_batch(wl.q, wl.v, hdes, wl.contact_weight, wl.contact_maxnormalforce)
-        host_rate = 3 * B / (time.perf_counter() - th)
+    host_rates, secondary = None, None
+    if rank == 0 and world == 1 and not args.no_secondary:
+        if not args.fused_laws:
+            host_rates = host_pointer_path(binding, run)
+        secondary = secondary_points(torch, binding, W, local_rank)
 
     if rank == 0:
         total = B * world * args.steps
@@ -269,6 +387,12 @@ def main():
         alg_bytes = 8 * (lay.nq + lay.nv + (0 if args.fused_laws else lay.n_desired) + 2 * nc_) + 8 * (2 * lay.nv + 6 * nc_) + 8
         assert args.config != 3 or args.fused_laws or alg_bytes == ALG_BYTES_PER_SOLVE
         ach_bytes = alg_bytes * B / kern_s if kern_s > 0 else 0.0
+        fingerprint = L.qpc_kernel_fingerprint().decode() if hasattr(L, "qpc_kernel_fingerprint") else "unknown"
+        traffic, traffic_source = (None, "measured for config 3 at 32768 QPs per launch only")
+        if args.config == 3 and not args.fused_laws:
+            traffic, traffic_source = measured_traffic(fingerprint)
+            if traffic is not None and B != 32768:
+                traffic = traffic * B / 32768.0
         out = {
             "metric": "QP solves/sec (Atlas ~30-DoF whole-body QP, batched)",
             "value": value, "unit": "QP solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -282,12 +406,17 @@ def main():
                        "optimal_fraction": n_opt / B, "mean_active_set_iters": float(it.mean()),
                        "lds_bytes_per_qp": int(lay.lds_bytes_per_qp),
                        "desired": "device PD laws (standing.jl:58-89 fused)" if args.fused_laws else "input record",
-                       "host_pointer_path_solves_per_s": host_rate},
+                       "host_pointer_path_solves_per_s": host_rates["pinned"] if host_rates else None,
+                       "host_pointer_path_pageable_solves_per_s": host_rates["pageable"] if host_rates else None,
+                       "host_pointer_path_note": "qpc_control_batch on this workload, PCIe inclusive, synchronous calls: page-locked caller "
+                                                 "arrays are read / written in place by the kernel (what QPControlHIP.jl does with the "
+                                                 "buffers it owns); pageable arrays are staged chunk by chunk by worker threads",
+                       "secondary": secondary,
+                       "kernel_fingerprint": fingerprint},
             "roofline": {"bound": "hbm", "achieved": ach_bytes / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": ach_bytes / HBM_PEAK,
-                         "traffic": MEASURED_TRAFFIC_BYTES_PER_SOLVE * B if args.config == 3 else None,
-                         "traffic_source": "profiles/r01_v35_traffic_summary.json (rocprofv3 PMC FETCH_SIZE + WRITE_SIZE, separate passes), bytes per launch; includes the HBM spill slots (DESIGN.md 4)",
-                         "kernel": "qpc_tick_kernel", "kernel_avg_ms": avg_ms.value, "launches": int(nl.value),
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": "qpc_tick_kernel_jit", "kernel_avg_ms": avg_ms.value, "launches": int(nl.value),
                          "algorithmic_bytes_per_solve": alg_bytes,
                          "note": "path is fp64-VALU / LDS-latency bound, not HBM bound (SURVEY.md 8d); "
                                  "fp64 fraction reported beside it",

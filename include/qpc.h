@@ -213,17 +213,19 @@ int32_t qpc_n_devices(const qpc_controller *ctrl);
 int32_t qpc_get_layout(const qpc_controller *ctrl, qpc_layout *out_layout);
 
 /* Host-pointer pipeline (before or after qpc_finalize*; not while a job is in flight): every device's
- * shard of a batch is cut into chunks of `chunk_qps` QPs (<= 0: keep; default 8192) that flow through
- * `slots_per_device` pipeline slots per device (<= 0: keep; default 3; only before qpc_finalize*) --
- * the H2D copy of one chunk, the kernel of another and the D2H copy of a third overlap.  Batches of at
+ * shard of a batch is cut into chunks of `chunk_qps` QPs (<= 0: keep; default 4096) that flow through
+ * `slots_per_device` pipeline slots per device (<= 0: keep; default 4; only before qpc_finalize*), one
+ * worker thread each -- staging one chunk, the kernel of another and un-staging a third overlap.  Batches of at
  * most `inline_qps` QPs (< 0: keep; default 2048) are run on the caller's thread without a hand-off. */
 int32_t qpc_set_host_pipeline(qpc_controller *ctrl, int64_t chunk_qps, int32_t slots_per_device,
                               int64_t inline_qps);
 
 /* Page-locked host memory.  Arrays handed to the host-pointer entry points that live in pinned memory
  * (from qpc_host_alloc, qpc_host_register, hipHostMalloc / hipHostRegister or torch pin_memory) are
- * DMA-ed in place; pageable arrays are staged through the library's own pinned buffers (one extra
- * host copy each way, done by the pipeline's worker threads). */
+ * used IN PLACE: when every array of a call is page-locked the kernels read the records and write
+ * the results over PCIe directly (one launch per device, no staging, no chunks; measured 89 % of the
+ * device-resident rate).  Pageable arrays are staged through the library's own pinned buffers (one
+ * extra host copy each way, done chunk by chunk by the pipeline's worker threads). */
 void *qpc_host_alloc(uint64_t bytes);
 void qpc_host_free(void *ptr);
 int32_t qpc_host_register(void *ptr, uint64_t bytes);
@@ -405,6 +407,9 @@ int32_t qpc_rollout_batch_device(qpc_controller *ctrl, int64_t B, int64_t n_step
 const char *qpc_status_string(int32_t status);
 const char *qpc_last_error(void);
 const char *qpc_version(void);
+/* 16 hex digits identifying the device code of this build (hash of the kernel sources): stored with every
+ * profile under profiles/ so that a quoted measurement can be matched to the kernel that produced it */
+const char *qpc_kernel_fingerprint(void);
 
 /* kernel timing hooks for bench.py / roofline: average duration in ms of the fused tick kernel
  * over launches recorded since the last reset, measured with hipEvents on the launch stream. */

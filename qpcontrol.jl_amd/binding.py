@@ -81,6 +81,8 @@ def load_library(path=None):
     L.qpc_status_string.restype = ctypes.c_char_p
     L.qpc_last_error.restype = ctypes.c_char_p
     L.qpc_version.restype = ctypes.c_char_p
+    if hasattr(L, "qpc_kernel_fingerprint"):
+        L.qpc_kernel_fingerprint.restype = ctypes.c_char_p
     L.qpc_qp_solve_batch.argtypes = [i32, i32, i64] + [c_double_p] * 5 + [ctypes.POINTER(Settings), i32, c_double_p,
                                                                          c_double_p, c_int32_p, c_int32_p]
     L.qpc_assemble_solve_batch.argtypes = [vp, i64] + [c_double_p] * 11 + [c_double_p, c_double_p, c_int32_p, c_int32_p]

@@ -144,6 +144,19 @@ int qpc_jit_compile(const QpcDims &D, const std::string &arch, bool warm, std::v
   return 0;
 }
 
+// identity of the device code this library was built from (FNV-1a over the embedded device headers): profiles under
+// profiles/ record it, and bench.py only quotes a measured-traffic figure whose fingerprint equals the built kernel's
+extern "C" const char *qpc_kernel_fingerprint(void) {
+  static char buf[24];
+  if (!buf[0]) {
+    unsigned long long h = 1469598103934665603ull;
+    for (int i = 0; i < qpc_src_count; i++)
+      for (const char *p = qpc_src_texts[i]; *p; p++) { h ^= (unsigned char)*p; h *= 1099511628211ull; }
+    snprintf(buf, sizeof buf, "%016llx", h);
+  }
+  return buf;
+}
+
 // offline check / experiments: compile the specialised kernel of a controller without a device
 #include "qpc_compile.h"
 extern "C" int32_t qpc_debug_jit_compile(qpc_controller *c, const char *arch, const char *out_path, char *logbuf, int32_t logn) {

@@ -952,12 +952,11 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       QPC_UNROLL_JIT
       for (int e = 0; e < QPC_META_WORDS; e++) mt[e] = e < rowlen ? IT[D.it[IT_META] + e * 64 + lane] : 0;
     }
+    // every load of this phase is independent of the others (ONE round trip to the records, which may live in pinned
+    // host memory behind PCIe: qpc_control_batch reads the caller's arrays in place); the pinned accelerations, which
+    // need desired[IT_PDES_K[k]], are picked out of the LDS copy of the desired record one phase later
     for (int i = lane; i < nq; i += 64) sm[D.lds[L_Q] + i] = io.q[i];
-    for (int i = lane; i < nv; i += 64) {
-      sm[D.lds[L_V] + i] = io.v[i];
-      const int pd = IT[D.it[IT_PDES_K] + i]; // pinned accelerations (hard JointAccelerationTask)
-      sm[D.lds[L_VD] + i] = pd >= 0 ? desired_early(D, IT, DT, io, pd) : 0.0;
-    }
+    for (int i = lane; i < nv; i += 64) sm[D.lds[L_V] + i] = io.v[i];
     for (int i = lane; i < D.n_desired; i += 64) sm[D.lds[L_DES] + i] = desired_early(D, IT, DT, io, i);
     for (int i = lane; i < nc; i += 64) { sm[D.lds[L_CW] + i] = io.cw[i]; sm[D.lds[L_CMAX] + i] = io.cmax[i]; }
     for (int i = lane; i < D.n_tw; i += 64) sm[D.lds[L_TW] + i] = io.tw[i];
@@ -967,6 +966,10 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
   QPC_PROF_ACC(PS_K_INPUT);
   // ======================================================================== kinematics (a2)
   QPC_PHASE(lane) { // joint transforms: x_parent = Rf (Rj x + pj) + pf
+    for (int i = lane; i < nv; i += 64) { // pinned accelerations (hard JointAccelerationTask, src/tasks.jl:185-189)
+      const int pd = IT[D.it[IT_PDES_K] + i];
+      sm[D.lds[L_VD] + i] = pd >= 0 ? (double)sm[D.lds[L_DES] + pd] : 0.0;
+    }
     if (lane < nb) {
       const int i = lane;
       const int *mt = QPC_LI(M.v, lane);

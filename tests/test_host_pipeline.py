@@ -164,62 +164,27 @@ def test_gpu_pipelined_host_path_equals_device_path():
         assert np.array_equal(rs["tau"], r1["tau"][:Bs])
 
 
+def _run_torch_check(which):
+    """torch device tensors + streams next to the product library: in a child process that initialises torch's HIP
+    runtime FIRST (as bench.py does) -- in the pytest process the library is already loaded by the time torch would
+    initialise, and torch then finds no device."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, os.path.join(here, "gpu_torch_checks.py"), which], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "CHECK_OK" in out.stdout
+
+
 @pytest.mark.gpu
 def test_gpu_user_streams_are_serialised():
     """two launches of one controller on different streams share the work counter; the library turns the
-    change of stream into an event dependency -- both results must be complete and correct."""
-    import torch
-    B = 4096
-    c, wl = _workload(gpu_factory, B)
-    ref = _tick(c, wl)
-    dev = torch.device("cuda", 0)
-    t = {k: torch.from_numpy(np.ascontiguousarray(a)).to(dev) for k, a in dict(q=wl.q, v=wl.v, d=wl.desired, cw=wl.contact_weight,
-                                                                               cm=wl.contact_maxnormalforce).items()}
-    lay = c.layout
-    outs = []
-    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
-    vp = ctypes.c_void_p
-    for rep in range(6):
-        tau = torch.full((B, lay.nv), float("nan"), dtype=torch.float64, device=dev)
-        vd = torch.empty((B, lay.nv), dtype=torch.float64, device=dev)
-        st = torch.full((B,), -1, dtype=torch.int32, device=dev)
-        s = streams[rep % 3]
-        rc = c.L.qpc_control_batch_device(c.h, B, vp(t["q"].data_ptr()), vp(t["v"].data_ptr()), vp(t["d"].data_ptr()),
-                                          vp(t["cw"].data_ptr()), vp(t["cm"].data_ptr()), vp(0), vp(0), vp(tau.data_ptr()),
-                                          vp(vd.data_ptr()), vp(0), vp(st.data_ptr()), vp(0), vp(s.cuda_stream))
-        assert rc == 0
-        outs.append((tau, st))
-    torch.cuda.synchronize(dev)
-    for tau, st in outs:
-        assert np.array_equal(st.cpu().numpy(), ref["status"])
-        assert np.array_equal(tau.cpu().numpy(), ref["tau"])
+    change of stream into an event dependency -- every result must be complete and correct (tests/gpu_torch_checks.py)."""
+    _run_torch_check("streams")
 
 
 @pytest.mark.gpu
 def test_gpu_graph_replay_of_the_tick():
     """the work counter re-arms itself on the device, so a captured tick can be replayed (hipGraph)"""
-    import torch
-    B = 2048
-    c, wl = _workload(gpu_factory, B)
-    ref = _tick(c, wl)
-    dev = torch.device("cuda", 0)
-    t = {k: torch.from_numpy(np.ascontiguousarray(a)).to(dev) for k, a in dict(q=wl.q, v=wl.v, d=wl.desired, cw=wl.contact_weight,
-                                                                               cm=wl.contact_maxnormalforce).items()}
-    lay = c.layout
-    tau = torch.zeros((B, lay.nv), dtype=torch.float64, device=dev)
-    vd = torch.zeros((B, lay.nv), dtype=torch.float64, device=dev)
-    st = torch.zeros((B,), dtype=torch.int32, device=dev)
-    vp = ctypes.c_void_p
-    g = torch.cuda.CUDAGraph()
-    s = torch.cuda.Stream(dev)
-    with torch.cuda.stream(s):
-        with torch.cuda.graph(g, stream=s):
-            rc = c.L.qpc_control_batch_device(c.h, B, vp(t["q"].data_ptr()), vp(t["v"].data_ptr()), vp(t["d"].data_ptr()),
-                                              vp(t["cw"].data_ptr()), vp(t["cm"].data_ptr()), vp(0), vp(0), vp(tau.data_ptr()),
-                                              vp(vd.data_ptr()), vp(0), vp(st.data_ptr()), vp(0), vp(s.cuda_stream))
-            assert rc == 0
-    for _ in range(3):
-        tau.fill_(float("nan"))
-        g.replay()
-        torch.cuda.synchronize(dev)
-        assert np.array_equal(tau.cpu().numpy(), ref["tau"])
+    _run_torch_check("graph")

@@ -9,7 +9,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+BENCH="python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o k --output-format csv -- $BENCH > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o k --output-format csv -- $BENCH > /dev/null 2> $OUT/fetch.log
 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o k --output-format csv -- $BENCH > /dev/null 2> $OUT/write.log

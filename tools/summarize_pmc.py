@@ -39,6 +39,13 @@ def main():
         for f in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
             shutil.copy(f, f"{dst}_pmc_{name.lower()}.csv")
         traffic[name] = {"per_launch_KiB": sum(v) / max(len(v), 1), "launches": len(v), "min": min(v, default=0), "max": max(v, default=0)}
+    # identity of the kernel these counters belong to: bench.py quotes the traffic only for the kernel it was measured on
+    try:
+        bj = json.loads(open(os.path.join(src, "bench_under_rocprof.json")).read().strip().splitlines()[-1])
+        traffic["kernel_fingerprint"] = bj["config"].get("kernel_fingerprint")
+        traffic["qps_per_launch"] = bj["config"]["batch_per_gpu"]
+    except (OSError, ValueError, KeyError, IndexError):
+        traffic["kernel_fingerprint"] = None
     json.dump(traffic, open(dst + "_traffic_summary.json", "w"), indent=1)
     sq = {}
     for sub in ("sq_a", "sq_b"):
