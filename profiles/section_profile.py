@@ -14,11 +14,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 NAMES = ["kinematics", "assembly", "schur_build", "cholesky", "x_inverse", "refactor_rho", "residuals", "kkt_solve",
          "update", "logic", "final_refine", "rnea", "k_input", "k_joint", "k_world", "k_subspace_inertia", "k_twist",
-         "k_bias_crb", "sweep_kr", "sweep_y", "sweep_c22", "sweep_chol", "sweep_back", "sweep_test"]
+         "k_bias_crb", "sweep_kr", "sweep_y", "sweep_c22", "sweep_chol", "sweep_back", "sweep_test",
+         "l_u0", "l_guard", "l_gi_check", "l_gi_step", "polish_prox", "polish_back", "accept", "rnea_reload"]
 
 
 def main():
     import torch
+    torch.cuda.init()
     import qpc_pkg
     qpc_pkg.load()
     from qpcontrol_jl_amd import binding, workloads as W
@@ -35,7 +37,22 @@ def main():
     prof = torch.zeros((B, len(NAMES)), dtype=torch.int64, device="cuda")
     ctrl.L.qpc_debug_set_profile_buffer.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     ctrl.L.qpc_debug_set_profile_buffer(ctrl.h, ctypes.c_void_p(prof.data_ptr()))
-    r = ctrl.control_batch(wl.q, wl.v, wl.desired, wl.contact_weight, wl.contact_maxnormalforce)
+    # the section counters are written by the *_device entry (device-resident arrays on the caller's stream)
+    dev = torch.device("cuda", 0)
+    t = {k: torch.from_numpy(np.ascontiguousarray(a)).to(dev) for k, a in dict(q=wl.q, v=wl.v, d=wl.desired, cw=wl.contact_weight,
+                                                                               cm=wl.contact_maxnormalforce).items()}
+    lay = ctrl.layout
+    tau = torch.zeros((B, lay.nv), dtype=torch.float64, device=dev)
+    vd = torch.zeros((B, lay.nv), dtype=torch.float64, device=dev)
+    st = torch.zeros((B,), dtype=torch.int32, device=dev)
+    its = torch.zeros((B,), dtype=torch.int32, device=dev)
+    vp = ctypes.c_void_p
+    rc = ctrl.L.qpc_control_batch_device(ctrl.h, B, vp(t["q"].data_ptr()), vp(t["v"].data_ptr()), vp(t["d"].data_ptr()),
+                                         vp(t["cw"].data_ptr()) if lay.n_contacts else vp(0), vp(t["cm"].data_ptr()) if lay.n_contacts else vp(0),
+                                         vp(0), vp(0), vp(tau.data_ptr()), vp(vd.data_ptr()), vp(0), vp(st.data_ptr()), vp(its.data_ptr()), vp(0))
+    assert rc == 0
+    torch.cuda.synchronize()
+    r = {"iters": its.cpu().numpy()}
     torch.cuda.synchronize()
     p = prof.cpu().numpy().astype(np.float64)
     tot = p.sum(1)

@@ -38,7 +38,8 @@
 #endif
 enum { PS_KIN, PS_ASM, PS_SBUILD, PS_CHOL, PS_XINV, PS_REFAC, PS_RESID, PS_KKT, PS_UPDATE, PS_LOGIC, PS_FINAL, PS_RNEA,
        PS_K_INPUT, PS_K_JOINT, PS_K_WORLD, PS_K_SUBSP, PS_K_TWIST, PS_K_BIAS,
-       PS_S_KR, PS_S_Y, PS_S_C22, PS_S_CHOL, PS_S_BACK, PS_S_TEST, PS_COUNT };
+       PS_S_KR, PS_S_Y, PS_S_C22, PS_S_CHOL, PS_S_BACK, PS_S_TEST,
+       PS_L_U0, PS_L_GUARD, PS_L_GICHECK, PS_L_GISTEP, PS_P_PROX, PS_P_BACK, PS_F_ACCEPT, PS_R_LOAD, PS_COUNT };
 
 namespace qpc {
 
@@ -303,6 +304,8 @@ template <class P> struct Solver {
   double last_gmax = 0.0, last_xmax = 0.0; // scales of the last base rho_solve (uniform)
   double last_dmax = 0.0;                   // max |rho - rho_prev| of the last proximal sweep (uniform)
   bool c_valid = false;                     // L_T1 holds c = E H^-1 (-g) - d (clobbered by kkt_solve)
+  bool confirmed = false;                   // eqp(from_current) stopped after ONE sweep whose correction was <= 1e-9 relative:
+                                            // the residual arrays (of the iterate before that correction) bound the final ones
   // hot lookups staged in LDS (IT_HOT)
   QPC_FN int row_slack(int r) const { return (int)(double)sm[D.lds[L_HOT] + r]; }
   QPC_FN int slack_row(int s) const { return (int)(double)sm[D.lds[L_HOT] + D.m + s]; }
@@ -525,6 +528,7 @@ template <class P> struct Solver {
           double gl = dotp(sm + D.lds[L_HR] + c * QPC_CSH(N) + jj * N, 1, sm + D.lds[L_XR] + c * N, 1, N) -
                       dotp(sm + D.lds[L_G] + j, QPC_GS(nrho), sm + D.lds[L_LAM] + m1, 1, 6);
           sm[D.lds[L_TR1] + j] = gl;
+          sm[D.lds[L_WSP] + j] = gl; // kept for the acceptance test (L_TR1 is scratch of kkt_solve; L_WSP is dead after the search)
           sm[D.lds[L_RR] + j] = (sm[D.lds[L_WS] + j] == 0.0) ? -gl : 0.0;
         }
     } QPC_END_PHASE
@@ -545,6 +549,7 @@ template <class P> struct Solver {
     }
     int it = from_current ? 1 : 0;
     double prev_dbig = 1e300;
+    confirmed = false;
     for (;; it++) {
       if (it == 0) fresh_rhs(); else residuals();
       kkt_solve();
@@ -586,7 +591,7 @@ template <class P> struct Solver {
         if (!(rdbig > tol)) break;
         // first correction of an already polished iterate: its size IS the error estimate of that
         // iterate, and the corrected one is better by the contraction factor (<= 1e-5)
-        if (from_current && it == 1 && !(rdbig > 1e-9 * (1.0 + rbig))) break;
+        if (from_current && it == 1 && !(rdbig > 1e-9 * (1.0 + rbig))) { confirmed = true; break; }
         if (rdbig > 0.25 * prev_dbig && rdbig < 1e-9 * (1.0 + rbig)) break;
         if (rdbig > 0.95 * prev_dbig) break;
         if (it >= 2 && rdbig * (rdbig / prev_dbig) < tol) break;
@@ -695,7 +700,7 @@ template <class P> struct Solver {
   // refined full solve at the end.
   //   base = true : EQP of the working set (r_r = -(H_rho rho_fix)_F), result -> L_XR, L_LAM[m1..]
   //   base = false: Goldfarb-Idnani direction for r_r = nsign * e_p,   result -> L_DR, L_DL[m1..]
-  QPC_FN void rho_solve(bool base, int p, double nsign, bool any_upper, bool prox = false) {
+  QPC_FN void rho_solve(bool base, int p, double nsign, bool any_upper, bool prox = false, int section = PS_KKT) {
     const int N = D.N, nrho = D.nrho, m1 = D.m1;
     const int outr = base ? D.lds[L_XR] : D.lds[L_DR], outl = (base ? D.lds[L_LAM] : D.lds[L_DL]) + m1;
     QPC_PROF_ACC(PS_LOGIC);
@@ -759,8 +764,8 @@ template <class P> struct Solver {
     QPC_PHASE(lane) {
       if (lane < 6) sm[outl + lane] = dotp(sm + D.lds[L_S22I] + lane * 6, 1, sm + (need_kr ? D.lds[L_C22] : D.lds[L_MISC] + MS_U0), 1, 6);
     } QPC_END_PHASE
-    rho_back(base, need_kr, PS_KKT, prox);
-    QPC_PROF_ACC(PS_KKT);
+    rho_back(base, need_kr, section, prox);
+    QPC_PROF_ACC(section);
   }
 
   // c = E H^-1 (-g) - d -> L_T1 (all rows), with -sqh .* g as a by-product in L_XV
@@ -791,9 +796,13 @@ template <class P> struct Solver {
     if (use_rho) {
       double prev = 1e300;
       for (k = 1; k <= 10; k++) {
-        rho_solve(true, 0, 0.0, any_upper, true);
+        rho_solve(true, 0, 0.0, any_upper, true, PS_P_PROX);
         const double tol = 1e-13 * (1.0 + last_xmax);
         if (!(last_dmax > tol)) break;
+        // the first sweep's correction IS the eps bias of the search's solution, i.e. the contraction factor times |rho|:
+        // at <= 1e-4 the iterate is already 1e-8 accurate and the confirming sweep of the full system (contraction again)
+        // finishes the job -- no second proximal sweep
+        if (k == 1 && !(last_dmax > 1e-4 * (1.0 + last_xmax))) break;
         if (k >= 2 && last_dmax * (last_dmax / prev) < tol) break;
         if (last_dmax > 0.95 * prev) break; // rounding floor / no progress
         prev = last_dmax;
@@ -818,7 +827,7 @@ template <class P> struct Solver {
         sm[D.lds[L_XE] + s] = acc;
       }
     } QPC_END_PHASE
-    QPC_PROF_ACC(PS_FINAL);
+    QPC_PROF_ACC(PS_P_BACK);
     return k;
   }
 
@@ -1626,6 +1635,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       if (lane < 6) sm[MISC + MS_U0 + lane] = sm[D.lds[L_T1] + m1 + lane] - dotp(sm + D.lds[L_X2] + lane, 6, sm + D.lds[L_T1], 1, m1);
     } QPC_END_PHASE
     bool any_upper = false;
+    bool pd_converged = false; // the last primal-dual test found nothing to change: the working set is optimal at D.tol_bound
     if (WARM && attempt == 0) { // upper-active bounds / any hint at all in the starting set?
       unsigned long long bup0 = 0ull, bhint = 0ull;
       QPC_PHASE(lane) {
@@ -1643,6 +1653,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       any_upper = bup0 != 0ull;
       warm_hint = bhint != 0ull;
     }
+    QPC_PROF_ACC(PS_L_U0);
     S.refactor_solve(any_upper);
     // ---- phase A: primal-dual active-set sweeps (multi-change)
     for (int pd = 0; pd < D.max_pdas; pd++) {
@@ -1669,7 +1680,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       rchg = bchg ? 1.0 : 0.0;
       rup = bup ? 1.0 : 0.0;
       QPC_PROF_ACC(PS_S_TEST);
-      if (!(rchg > 0.0)) break;
+      if (!(rchg > 0.0)) { pd_converged = true; break; }
       any_upper = rup > 0.0;
       iters++;
       S.refactor_solve(any_upper);
@@ -1681,7 +1692,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
     // sweep before (L_WSP) is tried first; the all-free set -- consistent whenever the QP is feasible
     // at all, but ~30 Goldfarb-Idnani additions away from the optimum -- is the last resort.
     if (!any_upper) {
-      for (int attempt = 0; attempt < 3; attempt++) {
+      for (int ga = 0; ga < 3; ga++) {
         double incons = 0.0; // residual of S22 lam_w = u0: rows the infinite-pivot rule dropped as dependent
                              // must still be satisfied (L_C22 still holds S22 of this working set: fused path)
         QPC_PHASE(lane) {
@@ -1693,19 +1704,24 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
           QPC_RED_MAX_PUT(0, incons, r);
         } QPC_END_PHASE
         incons = QPC_RED_MAX_GET(0, incons);
-        if (!(incons > 1e-6) || attempt == 2) break;
+        if (!(incons > 1e-6) || ga == 2) break;
         QPC_PHASE(lane) {
           for (int j = lane; j < nrho; j += 64)
-            sm[D.lds[L_WS] + j] = attempt == 0 ? (double)sm[D.lds[L_WSP] + j] : (sm[D.lds[L_HI] + j] > 0.0 ? 0.0 : -1.0);
+            sm[D.lds[L_WS] + j] = ga == 0 ? (double)sm[D.lds[L_WSP] + j] : (sm[D.lds[L_HI] + j] > 0.0 ? 0.0 : -1.0);
         } QPC_END_PHASE
         iters++;
+        pd_converged = false; // another working set: phase B has to judge it
         S.refactor_solve(false);
       }
     }
+    QPC_PROF_ACC(PS_L_GUARD);
     // ---- phase B: drops until dual feasible, then Goldfarb-Idnani additions (finite in exact
     //      arithmetic: no working set is visited twice).  A repeated working set therefore means the
     //      iteration is cycling on rounding noise (seen on infeasible single-contact QPs, which used to
     //      burn all max_active_set_iters): recognised from the bit masks of the last 8 working sets.
+    // (skipped when the last primal-dual test found nothing to change: its conditions -- no multiplier below
+    //  -tol_bound * gscale, no rho outside its bounds by more than tolb -- are exactly phase B's stopping test)
+    if (!pd_converged) {
     const bool track_b = nrho <= 64; // one rho per lane: two ballots ARE the working set
     QPC_LANE_INTS(hist_, 4); // lane h < 8 remembers one of the last 8 working sets: lo / up masks as 2 x 2 ints (four VGPRs
                              // instead of 32 scalar registers of wave-uniform history)
@@ -1744,7 +1760,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       rnan = bnan ? 1.0 : 0.0;
       QPC_BALLOT_GET(3, lo_now);
       QPC_BALLOT_GET(4, up_now);
-      if (track_b) {
+      if (track_b && iters >= 6) { // (ordinary QPs are done long before: the history only matters for the stragglers)
         unsigned long long bseen = 0ull;
         const int l0 = (int)(unsigned)lo_now, l1 = (int)(unsigned)(lo_now >> 32), u0_ = (int)(unsigned)up_now, u1 = (int)(unsigned)(up_now >> 32);
         QPC_PHASE(lane) {
@@ -1757,6 +1773,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
         if (iters >= 10 && bseen != 0ull) { status = QPC_STATUS_ITERATION_LIMIT; break; }
         hpos = (hpos + 1) & 7;
       }
+      QPC_PROF_ACC(PS_L_GICHECK);
       const bool finite = !(rnan > 0.0);
       if (!(ubad < -D.tol_bound * gscale)) jbad = -1;
       if (!(-vneg > tolb)) pviol = -1;
@@ -1815,11 +1832,13 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
             sm[D.lds[L_U] + j] = u;
           }
         } QPC_END_PHASE
+        QPC_PROF_ACC(PS_L_GISTEP);
         if (full) { any_upper = any_upper || side > 0.0; S.refactor_solve(any_upper); break; }
         S.refactor_rho();
       }
       if (fail) { if (status == QPC_STATUS_OPTIMAL) status = QPC_STATUS_ITERATION_LIMIT; break; }
     }
+    } // !pd_converged
   } else {
     S.refactor_rho();
   }
@@ -1833,7 +1852,10 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       // that the iterate was already accurate; otherwise: solve + refine the full system from scratch
       if (exact_ve) { refine = S.polish_exact(true); refine += S.eqp(D.max_refine, true) - 1; }
       else refine = S.eqp(D.max_refine);
-      S.residuals();
+      // acceptance needs the true KKT residuals of the final iterate.  When the single confirming sweep changed the
+      // iterate by <= 1e-9 relative, the residuals it started from (still in L_RV / L_RE / L_RR / L_RC, gradient in
+      // L_WSP) are those of an iterate 1e-9 away -- far inside the 1e-7 acceptance tolerance -- and are not recomputed
+      if (!S.confirmed) S.residuals();
       double arp = 0.0, ars = 0.0, asp = 0.0, ass = 0.0, anan = 0.0, abv = 0.0, agm = 0.0, axm = 0.0;
       unsigned long long bbad = 0ull, bchanged = 0ull;
       QPC_PHASE(lane) {
@@ -1851,8 +1873,8 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
         for (int j = lane; j < nrho; j += 64) {
           double a = QPC_FABS(sm[D.lds[L_RR] + j]); rs = a > rs || !(a == a) ? a : rs;
           // bound conditions of the REFINED solution (the search decided on eps-regularised solves):
-          // L_TR1 = Lagrangian gradient w.r.t. rho (Solver::residuals)
-          const double w = sm[D.lds[L_WS] + j], hi = sm[D.lds[L_HI] + j], x = sm[D.lds[L_XR] + j], gl = sm[D.lds[L_TR1] + j];
+          // L_WSP = Lagrangian gradient w.r.t. rho (Solver::residuals)
+          const double w = sm[D.lds[L_WS] + j], hi = sm[D.lds[L_HI] + j], x = sm[D.lds[L_XR] + j], gl = sm[D.lds[L_WSP] + j];
           if (hi > 0.0) {
             const double u = (w == -1.0) ? gl : ((w == 1.0) ? -gl : 0.0);
             sm[D.lds[L_U] + j] = u;
@@ -1865,6 +1887,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
         QPC_RED_MAX_PUT(2, asp, sp); QPC_RED_MAX_PUT(3, ass, ss); QPC_BALLOT_PUT(4, bbad, bad != 0.0);
         QPC_RED_MAX_PUT(5, agm, gm); QPC_RED_MAX_PUT(6, axm, xm);
       } QPC_END_PHASE
+      QPC_PROF_ACC(PS_F_ACCEPT);
       arp = QPC_RED_MAX_GET(0, arp); ars = QPC_RED_MAX_GET(1, ars); asp = QPC_RED_MAX_GET(2, asp);
       ass = QPC_RED_MAX_GET(3, ass); QPC_BALLOT_GET(4, bbad); anan = bbad ? 1.0 : 0.0;
       agm = QPC_RED_MAX_GET(5, agm); axm = QPC_RED_MAX_GET(6, axm);
@@ -1941,6 +1964,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       for (int a = 0; a < 6; a++) sm[D.lds[L_SVK] + 6 * lane + a] = sk[a] * vd;
     }
   } QPC_END_PHASE
+  QPC_PROF_ACC(PS_R_LOAD);
   QPC_PHASE(lane) { // S_j v̇_j per body
     if (lane < nb) {
       const int *mt = QPC_LI(M.v, lane);
