@@ -253,6 +253,9 @@ int qpc_compile_program(qpc_controller *c) {
           row[3] = vb & 127;
           row[4] = mask[2 * vb]; row[5] = mask[2 * vb + 1];
         }
+        if (l < nb) // bits 8..31 of word 3: contacts 0..23 attached to body l (the RNEA subtracts their wrenches)
+          for (size_t ci = 0; ci < c->contacts.size() && ci < 24; ci++)
+            if (c->contacts[ci].body == l) row[3] |= (int)(1u << (8 + ci));
       }
       // stored word-major ([word][lane]): one load instruction of the wave reads 64 consecutive ints
       std::vector<int> metat((size_t)64 * rowlen, 0);
@@ -415,6 +418,54 @@ int qpc_compile_program(qpc_controller *c) {
   B.dt.push_back(0.0);
   B.dbegin(DT_LAW); B.dt.insert(B.dt.end(), law_tab.begin(), law_tab.end());
   B.dt.push_back(0.0);
+  // ---- static Hessian blocks (no per-QP task weights): what the tick would otherwise re-derive for every QP
+  {
+    D.h_static = (c->n_tw == 0) ? 1 : 0;
+    double hmax = 0.0, hmin = 1e300;
+    B.dbegin(DT_HV0);
+    for (int f = 0; f < D.nf; f++) {
+      double hv = 2.0 * c->reg[free_k[f]];
+      for (size_t si = 0; si < sj_f.size(); si++)
+        if (sj_f[si] == f && sj_tw[si] < 0) hv += 2.0 * sj_w[si];
+      B.dt.push_back(hv);
+      hmax = std::max(hmax, std::fabs(hv)); hmin = std::min(hmin, hv);
+    }
+    B.dt.push_back(0.0);
+    B.dbegin(DT_WINV0);
+    std::vector<double> winv((size_t)wsize + 1, 0.0);
+    for (size_t g = 0; g < generic.size(); g++) {
+      const QpcTask &t = c->tasks[generic[g]];
+      if (slack0[g] < 0) continue;
+      const int d = t.dim;
+      std::vector<double> a((size_t)d * d, 0.0), inv((size_t)d * d, 0.0);
+      for (int i = 0; i < d; i++)
+        for (int j = 0; j < d; j++) {
+          double w = 0.0;
+          if (t.wkind == QPC_WEIGHT_SCALAR) w = (i == j) ? 2.0 * t.W[0] : 0.0;
+          else if (t.wkind == QPC_WEIGHT_MATRIX) w = t.W[i * d + j] + t.W[j * d + i];
+          a[(size_t)i * d + j] = w;
+          inv[(size_t)i * d + j] = (i == j) ? 1.0 : 0.0;
+        }
+      for (int i = 0; i < d; i++) { hmax = std::max(hmax, std::fabs(a[(size_t)i * d + i])); hmin = std::min(hmin, a[(size_t)i * d + i]); }
+      bool ok = true;
+      for (int k = 0; k < d && ok; k++) { // Gauss-Jordan without pivoting (SPD blocks), like the device code
+        const double piv = a[(size_t)k * d + k];
+        if (!(std::fabs(piv) > 1e-300)) { ok = false; break; }
+        for (int j = 0; j < d; j++) { a[(size_t)k * d + j] /= piv; inv[(size_t)k * d + j] /= piv; }
+        for (int i = 0; i < d; i++) {
+          if (i == k) continue;
+          const double f_ = a[(size_t)i * d + k];
+          for (int j = 0; j < d; j++) { a[(size_t)i * d + j] -= f_ * a[(size_t)k * d + j]; inv[(size_t)i * d + j] -= f_ * inv[(size_t)k * d + j]; }
+        }
+      }
+      if (!ok) D.h_static = 0; // singular static weight: leave it to the per-QP (regularised) path
+      for (int e = 0; e < d * d; e++) winv[(size_t)woff[g] + e] = inv[(size_t)e];
+    }
+    B.dt.insert(B.dt.end(), winv.begin(), winv.end());
+    D.h_static_max = hmax;
+    D.h_static_min = hmin < 1e300 ? hmin : 0.0;
+    if (D.nf == 0 && wsize == 0) D.h_static = 0;
+  }
 
   // ---- LDS layout with lifetime overlays (regions that are never live together share bytes).
   //   [ persistent | small assembly outputs | A | B ]

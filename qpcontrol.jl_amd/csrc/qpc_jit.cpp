@@ -54,13 +54,13 @@ std::string qpc_jit_source(const QpcDims &D, bool warm) {
   o << "static constexpr QpcDims kD = {" << D.nb << "," << D.nq << "," << D.nv << "," << D.nf << "," << D.npin << ","
     << D.nsj << "," << D.ntask << "," << D.nc << "," << D.N << "," << D.nrho << "," << D.ne << "," << D.m << ","
     << D.m1 << "," << D.nw << "," << D.floating << "," << D.fv0 << "," << D.n_desired << "," << D.n_tw << ","
-    << D.n_surf << "," << D.maxdepth << "," << D.n_items << "," << D.ve_exact_ok << "," << D.n_des_inputs << "," << D.n_des_late << "," << D.maxd << "," << D.crb_full_body << "," << D.nfs << "," << D.ms << "," << D.m1s << "," << D.wsize << ",";
+    << D.n_surf << "," << D.maxdepth << "," << D.n_items << "," << D.ve_exact_ok << "," << D.n_des_inputs << "," << D.n_des_late << "," << D.maxd << "," << D.crb_full_body << "," << D.nfs << "," << D.ms << "," << D.m1s << "," << D.wsize << "," << D.h_static << ",";
   put_ints(o, D.it, IT_COUNT); o << ",";
   put_ints(o, D.dt, DT_COUNT); o << ",";
   put_ints(o, D.lds, L_COUNT); o << ",";
   o << D.lds_doubles << "," << D.n_int << "," << D.n_dbl << "," << D.max_as_iters << "," << D.max_refine << ","
     << D.max_pdas << "," << dbl(D.eps_primal) << "," << dbl(D.tau_pivot) << "," << dbl(D.tol_bound) << ","
-    << dbl(D.tol_accept) << "};\n";
+    << dbl(D.tol_accept) << "," << dbl(D.h_static_max) << "," << dbl(D.h_static_min) << "};\n";
   o << "struct QpcBatchArgs { long long B; const double *q, *v, *desired, *cw, *cmax, *tw, *surf; double *tau, *vdot, "
        "*cwrench; int32_t *status, *iters; unsigned long long *prof; unsigned long long *ticket; unsigned long long *wsets; double *scratch; };\n";
   // the tick kernel (cold start) and, on request, its warm-started twin: same loop, qpc_tick<P, true>

@@ -52,6 +52,8 @@ enum {
   DT_T_POINT, DT_T_W, // per generic task: point[3]; static W (dim*dim, row-major, at IT_T_WOFF)
   DT_C_POS, DT_C_NORMAL, DT_C_MU,
   DT_LAW, // [n_desired * 3] kp, kd, ref of the desired law of entry i
+  DT_HV0,   // [nf] static Hessian diagonal of the free accelerations: 2 reg + folded soft joint tasks with static weights
+  DT_WINV0, // [wsize] inverses of the static slack Hessian blocks 2 sym(W) (no eps), valid when h_static
   DT_COUNT
 };
 
@@ -141,6 +143,7 @@ struct QpcDims {
   int crb_full_body; // body whose subtree is the whole mechanism and owns free columns (its composite inertia = total), or -1
   int nfs, ms, m1s;  // padded leading dimensions (odd) of L_M, L_SM, L_X
   int wsize;         // doubles in L_W / L_WINV
+  int h_static;      // no per-QP task weights: the v̇ / slack blocks of the Hessian are the same for every QP (DT_HV0, DT_WINV0)
   int it[IT_COUNT];
   int dt[DT_COUNT];
   int lds[L_COUNT];
@@ -149,6 +152,7 @@ struct QpcDims {
   // solver settings (qpc_settings)
   int max_as_iters, max_refine, max_pdas;
   double eps_primal, tau_pivot, tol_bound, tol_accept;
+  double h_static_max, h_static_min; // largest |diagonal| / smallest diagonal of the static v̇ and slack blocks (h_static)
 };
 
 // LDS slab of the simulation step (qpc_sim.h), offsets in doubles (fields in allocation order)

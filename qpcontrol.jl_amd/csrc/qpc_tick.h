@@ -39,7 +39,8 @@
 enum { PS_KIN, PS_ASM, PS_SBUILD, PS_CHOL, PS_XINV, PS_REFAC, PS_RESID, PS_KKT, PS_UPDATE, PS_LOGIC, PS_FINAL, PS_RNEA,
        PS_K_INPUT, PS_K_JOINT, PS_K_WORLD, PS_K_SUBSP, PS_K_TWIST, PS_K_BIAS,
        PS_S_KR, PS_S_Y, PS_S_C22, PS_S_CHOL, PS_S_BACK, PS_S_TEST,
-       PS_L_U0, PS_L_GUARD, PS_L_GICHECK, PS_L_GISTEP, PS_P_PROX, PS_P_BACK, PS_F_ACCEPT, PS_R_LOAD, PS_COUNT };
+       PS_L_U0, PS_L_GUARD, PS_L_GICHECK, PS_L_GISTEP, PS_P_PROX, PS_P_BACK, PS_F_ACCEPT, PS_R_LOAD,
+       PS_A_PRE, PS_A_ITEMS, PS_A_ROWS, PS_X_X, PS_X_MFMA, PS_R_SV, PS_R_BW, PS_COUNT };
 
 namespace qpc {
 
@@ -922,6 +923,7 @@ struct TickMeta {
 #define MT_V0(mt) (((mt)[0] >> 9) & 127)
 #define MT_NVJ(mt) (((mt)[0] >> 16) & 7)
 #define MT_VBODY(mt) ((mt)[3] & 127)
+#define MT_CMASK(mt) ((unsigned)(mt)[3] >> 8) /* contacts 0..23 attached to body `lane` */
 #define MT_ANC(mt, s) ((int)(((unsigned)(mt)[6 + ((s) >> 2)] >> (8 * ((s) & 3))) & 255u) - 1)
 
 // once per workgroup (before its first QP): hot solver lookups -> the persistent L_HOT region of
@@ -954,6 +956,9 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
 
   // ======================================================================== inputs -> LDS
   TickMeta M;
+  double hscale = 0.0, hinvmax = 0.0, eps = 0.0, eps_ve = 0.0;
+  bool exact_ve = false, h_fast = false;
+  const bool h_static_path = D.h_static && D.n_des_late == 0;
   QPC_PHASE(lane) {
     int *mt = QPC_LI(M.v, lane);
     {
@@ -967,10 +972,28 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
     for (int i = lane; i < nq; i += 64) sm[D.lds[L_Q] + i] = io.q[i];
     for (int i = lane; i < nv; i += 64) sm[D.lds[L_V] + i] = io.v[i];
     for (int i = lane; i < D.n_desired; i += 64) sm[D.lds[L_DES] + i] = desired_early(D, IT, DT, io, i);
-    for (int i = lane; i < nc; i += 64) { sm[D.lds[L_CW] + i] = io.cw[i]; sm[D.lds[L_CMAX] + i] = io.cmax[i]; }
+    double hc = 0.0; // this lane's share of the regularisation scale: 2 |weight| of its enabled contacts
+    for (int i = lane; i < nc; i += 64) {
+      const double cwi = io.cw[i], cmi = io.cmax[i];
+      sm[D.lds[L_CW] + i] = cwi; sm[D.lds[L_CMAX] + i] = cmi;
+      if (use_rho && cmi > 0.0 && 2.0 * QPC_FABS(cwi) > hc) hc = 2.0 * QPC_FABS(cwi);
+    }
     for (int i = lane; i < D.n_tw; i += 64) sm[D.lds[L_TW] + i] = io.tw[i];
     for (int i = lane; i < D.n_surf; i += 64) sm[D.lds[L_SURF] + i] = io.surf[i];
+    if (h_static_path) { QPC_RED_MAX_PUT(0, hscale, hc); }
   } QPC_END_PHASE
+  // Static Hessian blocks (D.h_static: no per-QP task weights): the regularisation scale is max(static diagonal,
+  // contact weights of THIS QP), known right after the input phase -- the two phases that used to derive it from the LDS
+  // copies of H (a max reduction over HV / W, then rsqrt / block inverses: 4 % of the tick) are only run in the general case
+  if (h_static_path) {
+    hscale = QPC_RED_MAX_GET(0, hscale);
+    if (D.h_static_max > hscale) hscale = D.h_static_max;
+    if (!(hscale > 0.0)) hscale = 1.0;
+    eps = D.eps_primal * hscale;
+    exact_ve = D.ve_exact_ok && (1e-6 * hscale <= D.h_static_min);
+    eps_ve = exact_ve ? 0.0 : eps;
+    h_fast = exact_ve; // everything static is exact: HV, SQH, W, WINV come from the tables
+  }
 
   QPC_PROF_ACC(PS_K_INPUT);
   // ======================================================================== kinematics (a2)
@@ -1181,16 +1204,30 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       sm[MISC + MS_ADV + (lane - 3)] = acc; // Ȧv + A_pin v̇_pin
     }
     for (int f = lane; f < nf; f += 64) { // Hv = 2 reg + folded soft joint tasks (a12)
-      double hv = DT[D.dt[DT_REG2] + IT[D.it[IT_FREE_K] + f]], gv = 0.0;
+      double hv = h_fast ? DT[D.dt[DT_HV0] + f] : DT[D.dt[DT_REG2] + IT[D.it[IT_FREE_K] + f]], gv = 0.0;
       for (int s = 0; s < D.nsj; s++)
         if (IT[D.it[IT_SJ_F] + s] == f) {
           int twi = IT[D.it[IT_SJ_TW] + s];
           double w = twi >= 0 ? sm[D.lds[L_TW] + twi] : DT[D.dt[DT_SJ_W] + s];
-          hv += 2.0 * w;
+          if (!h_fast) hv += 2.0 * w;
           gv -= 2.0 * w * sm[D.lds[L_DES] + IT[D.it[IT_SJ_DES] + s]];
         }
       sm[D.lds[L_HV] + f] = hv;
       sm[D.lds[L_GV] + f] = gv;
+      if (h_fast) sm[D.lds[L_SQH] + f] = QPC_RSQRT(hv);
+    }
+    if (h_fast) {
+      for (int e = lane; e < D.wsize; e += 64) sm[D.lds[L_WINV] + e] = DT[D.dt[DT_WINV0] + e];
+      if (lane == 63) { sm[MISC + MS_EPS] = eps; sm[MISC + MS_HSCALE] = hscale; }
+      if (lane >= 10 && lane < 16 && nw) { // gravity wrench about the world origin (momentum.jl:166-170); the centre of
+                                           // mass is one phase old
+        const int a = lane - 10;
+        double fg[3], cxf[3], com[3] = {sm[MISC + MS_COM], sm[MISC + MS_COM + 1], sm[MISC + MS_COM + 2]};
+        const double mt = DT[D.dt[DT_GRAV] + 3];
+        fg[0] = mt * DT[D.dt[DT_GRAV]]; fg[1] = mt * DT[D.dt[DT_GRAV] + 1]; fg[2] = mt * DT[D.dt[DT_GRAV] + 2];
+        cross3(com, fg, cxf);
+        sm[MISC + MS_WG + a] = a < 3 ? cxf[a] : fg[a - 3];
+      }
     }
     for (int t = 0; t < ntask; t++) { // slack Hessian blocks 2*sym(W)
       int w0 = IT[D.it[IT_T_WOFF] + t];
@@ -1209,7 +1246,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
 
   QPC_PROF_ACC(PS_KIN);
   // regularisation scale: eps = eps_primal * max diagonal of the Hessian
-  double hscale = 0.0, hinvmax = 0.0;
+  if (!h_fast) {
   QPC_PHASE(lane) {
     double h = 0.0, hm = 1e300; // largest diagonal of H; smallest diagonal of its v̇ and slack blocks
     for (int f = lane; f < nf; f += 64) { double a = sm[D.lds[L_HV] + f]; hm = a < hm ? a : hm; a = QPC_FABS(a); h = a > h ? a : h; }
@@ -1250,14 +1287,16 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
   hscale = QPC_RED_MAX_GET(0, hscale);
   hinvmax = QPC_RED_MAX_GET(1, hinvmax);
   if (!(hscale > 0.0)) hscale = 1.0;
-  const double eps = D.eps_primal * hscale;
+  eps = D.eps_primal * hscale;
   // exact_ve: every v̇ and slack diagonal of the Hessian is comfortably positive (and no matrix-weighted
   // slack block): those blocks are then inverted WITHOUT the proximal eps, which confines the eps bias to
   // the (rank-deficient) rho blocks and enables the cheap wrench-space polish (Solver::polish_exact)
-  const bool exact_ve = D.ve_exact_ok && (hinvmax * 1e-6 * hscale <= 1.0); // min diagonal >= 1e-6 * max diagonal
-  const double eps_ve = exact_ve ? 0.0 : eps;
+  exact_ve = D.ve_exact_ok && (hinvmax * 1e-6 * hscale <= 1.0); // min diagonal >= 1e-6 * max diagonal
+  eps_ve = exact_ve ? 0.0 : eps;
+  } // !h_fast
 
   // ======================================================================== assembly (a3-a12)
+  if (!h_fast) {
   QPC_PHASE(lane) {
     if (lane == 0) { sm[MISC + MS_EPS] = eps; sm[MISC + MS_HSCALE] = hscale; }
     if (lane < 6 && nw) { // gravity wrench about the world origin (momentum.jl:166-170)
@@ -1276,7 +1315,9 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       spd_inverse_inplace(sm + D.lds[L_WINV] + w0, d);
     }
   } QPC_END_PHASE
+  } // !h_fast
 
+  QPC_PROF_ACC(PS_A_PRE);
   QPC_PHASE(lane) { // scaled constraint matrix M = E diag(sqh), right-hand side d
     for (int it_ = lane; it_ < D.n_items; it_ += 64) {
       // one item = one (row block, free column): the Jacobian column of a path task is transformed
@@ -1323,6 +1364,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       for (int a = 0; a < 6; a++)
         if (a < dim) sm[D.lds[L_M] + (r0 + a) * D.nfs + f] = val[a] * sq;
     }
+    QPC_PROF_ACC(PS_A_ITEMS);
     for (int r = lane; r < m; r += 64) {
       // packed row code: kind(3) | a(3) | frame+1(7) | base+1(7) | target+1(7)
       const int code = IT[D.it[IT_RCODE] + r], di = IT[D.it[IT_R_DES] + r], t = IT[D.it[IT_R_T] + r], pk = IT[D.it[IT_R_PINK] + r];
@@ -1375,6 +1417,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       }
       sm[D.lds[L_D] + r] = rhs;
     }
+    QPC_PROF_ACC(PS_A_ROWS);
     // ---------------------------------------------------------------- contacts (a9, a10)
     if (use_rho)
       for (int j = lane; j < nrho; j += 64) {
@@ -1505,12 +1548,21 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
   // left-looking Cholesky of the leading m1 x m1 block (+ the L21 rows), infinite-pivot rule.
   // lane = row; the row's own factor entries stay in registers (constant indices once the k loop
   // is unrolled by the JIT specialisation), row k is broadcast from LDS.
+  // X = L11^-1 rides along for free: the forward substitutions L x = e_c are the SAME recurrence applied to identity
+  // rows, so lanes m .. m + m1 - 1 carry one column of X each through the k phases (more active lanes, not more
+  // instructions) instead of a separate phase of m1 serial steps afterwards (it was 5 % of the tick).
+#ifdef QPC_NO_XAUG
+  const bool xaug = false;
+#else
+  const bool xaug = m + m1 <= 64;
+#endif
   {
     QPC_LANE_ARRAY(lrow_, QPC_M1_MAX); // lane-private across the k phases
     QPC_UNROLL_JIT
     for (int k = 0; k < m1; k++) {
       QPC_PHASE(lane) {
-        if (lane >= k && lane < m) { // m <= 64 (checked by the host compiler)
+        const bool idrow = xaug && lane >= m && lane < m + m1;
+        if ((lane >= k && lane < m) || idrow) { // m <= 64 (checked by the host compiler)
           const int r = lane;
           double *lrow = QPC_LA(lrow_, lane);
           double accr = 0.0, acck = 0.0;
@@ -1522,11 +1574,17 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
             for (int u = 0; u < 8; u++)
               if (j0 + u < k) { accr += lk[u] * lrow[j0 + u]; acck += lk[u] * lk[u]; }
           }
-          double skk = sm[D.lds[L_SM] + k * D.ms + k], srk = sm[D.lds[L_SM] + r * D.ms + k], dk = skk - acck;
+          double skk = sm[D.lds[L_SM] + k * D.ms + k], dk = skk - acck;
+          const double srk = idrow ? ((r - m) == k ? 1.0 : 0.0) : (double)sm[D.lds[L_SM] + (idrow ? k : r) * D.ms + k];
           bool ok = dk > D.tau_pivot * (skk > 1e-300 ? skk : 1e-300);
           const double inv = ok ? QPC_RSQRT(dk) : 0.0; // 1 / L_kk
           if (r == k) sm[D.lds[L_T1] + k] = inv; // 1/L_kk (0 = dropped row)
-          else { double v = (srk - accr) * inv; lrow[k] = v; sm[D.lds[L_SM] + r * D.ms + k] = v; }
+          else {
+            const double v = (srk - accr) * inv;
+            lrow[k] = v;
+            if (idrow) sm[D.lds[L_X] + k * D.m1s + (r - m)] = v; // X[k][c], c = r - m (zero above the diagonal by itself)
+            else sm[D.lds[L_SM] + r * D.ms + k] = v;
+          }
         }
       } QPC_END_PHASE
     }
@@ -1538,7 +1596,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       sm[D.lds[L_B22] + lane] = sm[D.lds[L_SM] + (m1 + hi_) * D.ms + (m1 + lo_)] -
                                 dotp(sm + D.lds[L_SM] + (m1 + a) * D.ms, 1, sm + D.lds[L_SM] + (m1 + b) * D.ms, 1, m1);
     }
-    if (lane < m1) {
+    if (!xaug && lane < m1) { // (more than 64 rows in the augmented factorization: X by forward substitution)
       const int c = lane;
       double xc[QPC_M1_MAX];
       QPC_UNROLL_JIT
@@ -1558,6 +1616,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       }
     }
   } QPC_END_PHASE
+  QPC_PROF_ACC(PS_X_X);
   // S11I = X'X into the (now free) leading block of L_SM: the second GEMM-shaped step of the tick, on the
   // fp64 matrix core like S = M M' above -- lower-triangular 16x16 tiles, operands straight from the LDS
   // copy of X (lower triangular: tile row ti only needs k >= 16 ti), two LDS reads per lane and k-step
@@ -1587,6 +1646,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
         }
       }
     }
+    QPC_PROF_ACC(PS_X_MFMA);
     QPC_PHASE(lane) {
       const double *acc = QPC_LA(xacc_, lane);
       int tile = 0;
@@ -1975,6 +2035,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       st(sm + D.lds[L_SV] + 6 * lane, 6, sv);
     }
   } QPC_END_PHASE
+  QPC_PROF_ACC(PS_R_SV);
   QPC_PHASE(lane) { // body wrench: I A_free + W0 - external (contact) wrench,  W0 = I (Ab - g) + T x* I T
     if (lane < nb) {
       const int i = lane;
@@ -1991,13 +2052,23 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       for (int a = 0; a < 10; a++) I[a] = iw[a];
       inertia_mul(I, A, ia);
       for (int a = 0; a < 6; a++) ia[a] += iw[10 + a];
-      for (int e = IT[D.it[IT_BC_PTR] + i]; e < IT[D.it[IT_BC_PTR] + i + 1]; e++) {
-        int c = IT[D.it[IT_BC_IDX] + e];
-        for (int a = 0; a < 6; a++) ia[a] -= sm[D.lds[L_CWR] + 6 * c + a];
+      if (nc <= 24) { // contacts of this body from the lane's metadata word: no table look-ups on this path
+        unsigned cm = MT_CMASK(mt);
+        while (cm) {
+          const int c = QPC_CTZ64(cm);
+          cm &= cm - 1;
+          for (int a = 0; a < 6; a++) ia[a] -= sm[D.lds[L_CWR] + 6 * c + a];
+        }
+      } else {
+        for (int e = IT[D.it[IT_BC_PTR] + i]; e < IT[D.it[IT_BC_PTR] + i + 1]; e++) {
+          int c = IT[D.it[IT_BC_IDX] + e];
+          for (int a = 0; a < 6; a++) ia[a] -= sm[D.lds[L_CWR] + 6 * c + a];
+        }
       }
       st(sm + D.lds[L_BW] + 6 * i, 6, ia);
     }
   } QPC_END_PHASE
+  QPC_PROF_ACC(PS_R_BW);
   QPC_PHASE(lane) { // tau_k = S_k . (sum of subtree wrenches); floating joint torques exactly 0
     if (lane < nv) {
       const int k = lane;
