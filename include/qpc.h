@@ -125,7 +125,7 @@ typedef struct qpc_layout {
   int32_t n_tasks, n_contacts, n_basis;
   int32_t n_desired;      /* sum of task dimensions: length of one QP's `desired` record        */
   int32_t n_task_weights; /* doubles per QP in `task_weights` (0 if no *_PER_QP weights)        */
-  int32_t n_surface;      /* doubles per QP in `surfaces` = 4 * (#contacts with per_qp_surface) */
+  int32_t n_surface;      /* doubles per QP in `surfaces`: 4 per contact with a per-QP surface + 3 per contact with a per-QP position */
   /* the reference-layout QP this replaces, for bookkeeping: */
   int32_t ref_n_var, ref_n_eq, ref_n_ineq;
   /* the reduced QP the kernels actually solve: */
@@ -190,10 +190,16 @@ int32_t qpc_task_set_law(qpc_controller *ctrl, int32_t task_id, int32_t law, dou
 int32_t qpc_regularize(qpc_controller *ctrl, int32_t joint_body, double weight);
 
 /* addcontact!(c, body, position, normal, mu) (momentum.jl:133-148, contacts.jl:38-69).
- * position/normal in the frame of `body`.  per_qp_surface != 0: normal and mu are Parameters
- * (contacts.jl:39) supplied per QP as [nx ny nz mu] in `surfaces`.  A fresh contact has
- * weight = 0 and maxnormalforce = 0 in the reference (contacts.jl:50); here both are per-QP
- * inputs of qpc_control_batch. */
+ * position/normal in the frame of `body`.  The reference lets position, normal and mu be Parameters
+ * (`position::Union{Point3D, Parameter{<:Point3D}}` ..., contacts.jl:39); here `per_qp_surface` is a
+ * bit set: QPC_CONTACT_SURFACE_PER_QP (1): normal and mu come per QP as [nx ny nz mu] in `surfaces`;
+ * QPC_CONTACT_POSITION_PER_QP (2): the position comes per QP as [px py pz].  A contact's record in
+ * `surfaces` is [nx ny nz mu] (if bit 1) followed by [px py pz] (if bit 2); the records of all such
+ * contacts are concatenated in contact order (layout.n_surface doubles per QP).  The static arguments
+ * are ignored for what is per QP.  (The closed-loop step qpc_sim_step_batch feels the ground at the
+ * STATIC positions.)  A fresh contact has weight = 0 and maxnormalforce = 0 in the reference
+ * (contacts.jl:50); here both are per-QP inputs of qpc_control_batch. */
+enum { QPC_CONTACT_SURFACE_PER_QP = 1, QPC_CONTACT_POSITION_PER_QP = 2 };
 int32_t qpc_add_contact(qpc_controller *ctrl, int32_t body, const double position[3],
                         const double normal[3], double mu, int32_t per_qp_surface,
                         int32_t *out_contact_id);

@@ -140,7 +140,7 @@ int ora_add_contact(ora_ctrl *c, int body, const double pos[3], const double nor
   k->body = body; k->mu = mu; k->per_qp = per_qp_surface;
   memcpy(k->pos, pos, 24); memcpy(k->normal, normal, 24);
   k->surf_off = -1;
-  if (per_qp_surface) { k->surf_off = c->n_surf; c->n_surf += 4; }
+  if (per_qp_surface) { k->surf_off = c->n_surf; c->n_surf += ((per_qp_surface & 1) ? 4 : 0) + ((per_qp_surface & 2) ? 3 : 0); }
   k->var0 = c->nvar; c->nvar += c->N + 9;
   k->row0 = c->nrow; c->nrow += 2 * c->N + 9;
   c->neq += 9; c->nineq += 2 * c->N;
@@ -395,8 +395,16 @@ static void build_values(ora_ctrl *c, const double *q, const double *v, const do
     int rho = k->var0, f = rho + N, wa = f + 3, wl = wa + 3, r0 = k->row0;
     double B[3 * ORA_MAXBASIS], maxrho, R[9], p[3], nrm[3], mu = k->mu;
     memcpy(nrm, k->normal, 24);
-    if (k->per_qp) { memcpy(nrm, surf + k->surf_off, 24); mu = surf[k->surf_off + 3]; }
+    /* position / normal / mu may be Parameters (contacts.jl:39): per-QP record [nx ny nz mu][px py pz] */
+    double pos_static[3];
+    memcpy(pos_static, k->pos, 24);
+    if (k->per_qp) {
+      int so = k->surf_off;
+      if (k->per_qp & 1) { memcpy(nrm, surf + so, 24); mu = surf[so + 3]; so += 4; }
+      if (k->per_qp & 2) memcpy(k->pos, surf + so, 24);
+    }
     ora_contact_eval(c, s, ci, nrm, mu, cmaxf[ci], B, &maxrho, R, p);
+    memcpy(k->pos, pos_static, 24);
     /* objectiveterm: weight * (f . f) (contacts.jl:75-79) */
     for (int r = 0; r < 3; r++) c->P[(f + r) * n + f + r] = 2.0 * cweight[ci];
     /* force_local == basis * rho (contacts.jl:63) */

@@ -172,10 +172,11 @@ int32_t qpc_add_contact(qpc_controller *c, int32_t body, const double position[3
   if (!c || !position || !normal || body < -1 || body >= c->model->nb) return QPC_ERR_INVALID_ARGUMENT;
   if (c->finalized) { qpc_set_error("contacts must be added before the first tick"); return QPC_ERR_ALREADY_FINALIZED; }
   QpcContact k;
-  k.body = body; k.per_qp = per_qp_surface ? 1 : 0; k.surf_off = -1; k.mu = mu;
+  if (per_qp_surface < 0 || per_qp_surface > 3) { qpc_set_error("qpc_add_contact: per_qp_surface is a bit set of QPC_CONTACT_*_PER_QP"); return QPC_ERR_INVALID_ARGUMENT; }
+  k.body = body; k.per_qp = per_qp_surface; k.surf_off = -1; k.mu = mu;
   std::memcpy(k.pos, position, sizeof(k.pos));
   std::memcpy(k.normal, normal, sizeof(k.normal));
-  if (k.per_qp) { k.surf_off = c->n_surf; c->n_surf += 4; }
+  if (k.per_qp) { k.surf_off = c->n_surf; c->n_surf += ((k.per_qp & 1) ? 4 : 0) + ((k.per_qp & 2) ? 3 : 0); }
   c->contacts.push_back(k);
   if (out_contact_id) *out_contact_id = (int32_t)c->contacts.size() - 1;
   return QPC_OK;

@@ -585,7 +585,7 @@ void qpc_l1_build_tables(const qpc_controller *c, std::vector<int> &it, std::vec
     const int row[6] = {t.dim, t.wkind, t.des_off, s0, wo, t.tw_off};
     it.insert(it.end(), row, row + 6);
   }
-  for (auto &k : c->contacts) it.push_back(k.per_qp ? k.surf_off : -1);
+  for (auto &k : c->contacts) it.push_back((k.per_qp & 1) ? k.surf_off : -1); // L1 reads mu only (the pose comes evaluated)
   it.push_back(wsize);
   for (auto &k : c->contacts) dt.push_back(k.mu);
   dt.push_back(0.0);

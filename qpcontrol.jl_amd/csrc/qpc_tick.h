@@ -1424,10 +1424,16 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
         int c = j / N, i = j % N, body = IT[D.it[IT_C_BODY] + c];
         double nrm[3] = {DT[D.dt[DT_C_NORMAL] + 3 * c], DT[D.dt[DT_C_NORMAL] + 3 * c + 1], DT[D.dt[DT_C_NORMAL] + 3 * c + 2]};
         double mu = DT[D.dt[DT_C_MU] + c];
-        if (IT[D.it[IT_C_PERQP] + c]) {
+        const int pq = IT[D.it[IT_C_PERQP] + c]; // QPC_CONTACT_*_PER_QP bits (contacts.jl:39: Parameters)
+        double pos[3] = {DT[D.dt[DT_C_POS] + 3 * c], DT[D.dt[DT_C_POS] + 3 * c + 1], DT[D.dt[DT_C_POS] + 3 * c + 2]};
+        if (pq) {
           int so = IT[D.it[IT_C_SURF] + c];
-          nrm[0] = sm[D.lds[L_SURF] + so]; nrm[1] = sm[D.lds[L_SURF] + so + 1]; nrm[2] = sm[D.lds[L_SURF] + so + 2];
-          mu = sm[D.lds[L_SURF] + so + 3];
+          if (pq & 1) {
+            nrm[0] = sm[D.lds[L_SURF] + so]; nrm[1] = sm[D.lds[L_SURF] + so + 1]; nrm[2] = sm[D.lds[L_SURF] + so + 2];
+            mu = sm[D.lds[L_SURF] + so + 3];
+            so += 4;
+          }
+          if (pq & 2) { pos[0] = sm[D.lds[L_SURF] + so]; pos[1] = sm[D.lds[L_SURF] + so + 1]; pos[2] = sm[D.lds[L_SURF] + so + 2]; }
         }
         // Rotations.rotation_between(z, n) (contacts.jl:11)
         double nn = QPC_SQRT(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
@@ -1441,7 +1447,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
         double H[12], Rc[9], pc[3];
         ldH(sm, D, body, H);
         mm3(H, Rn, Rc);
-        mv3(H, DT + D.dt[DT_C_POS] + 3 * c, pc);
+        mv3(H, pos, pc);
         pc[0] += H[9]; pc[1] += H[10]; pc[2] += H[11];
         // forcebasis(mu, N) (contacts.jl:16-23)
         double sn, cs, inv = QPC_RSQRT(mu * mu + 1.0);
