@@ -175,16 +175,32 @@ int32_t qpc_add_task(qpc_controller *ctrl, int32_t kind, int32_t base_body, int3
  *   QPC_LAW_COM_PD         LINEAR_MOMENTUM_RATE task: m (-kp (c - ref[0..3)) - kd h_lin / m), c = centre
  *                          of mass, h = momentum(state)                              (standing.jl:60-67)
  *   QPC_LAW_ORIENTATION_PD ANGULAR task with base = world, frame = target body: -kp rotation_vector(R)
- *                          - kd R' omega  of the target body                          (standing.jl:70-77) */
+ *                          - kd R' omega  of the target body                          (standing.jl:70-77)
+ *   QPC_LAW_SE3_PD         SPATIAL task expressed in its target body's frame: the reference's SE3PDController
+ *                          (src/lowlevel/se3pdcontroller.jl:13-18) with its SE3Trajectory (src/trajectories/se3.jl)
+ *                          evaluated on the device:  desired = Tdref + pd(gains, H, Href, T, Tref), where
+ *                          (Href, Tref, Tdref) = trajectory(t, Val(2)) and H, T are the pose / twist of the body w.r.t.
+ *                          the base of THIS QP's state.  kp, kd = angular gains, ref[0..1] = linear gains (kp, kd).
+ *                          The task's slice of `desired` becomes a per-QP TRAJECTORY RECORD of QPC_SE3_RECORD doubles
+ *                          (qpc_task_desired_range tells where): [0..5] unused, [6] t, [7] x0, [8] xf, [9..14]
+ *                          c0..c5 of the interpolator alpha(theta) = sum c_i theta^i (identity: 0,1,0,0,0,0; a
+ *                          fit_quintic warp: its coefficients), [15..18] quaternion y0 (w x y z), [19..22] quaternion
+ *                          yf (rotation body -> base at x0 / xf, interpolated.jl:68-83), [23..25] p0, [26..28] pf
+ *                          (translation body -> base).  theta = clamp((t - x0) / (xf - x0), 0, 1) (interpolated.jl:29-40). */
 enum {
   QPC_LAW_INPUT = 0,
   QPC_LAW_CONSTANT = 1,
   QPC_LAW_JOINT_PD = 2,
   QPC_LAW_COM_PD = 3,
-  QPC_LAW_ORIENTATION_PD = 4
+  QPC_LAW_ORIENTATION_PD = 4,
+  QPC_LAW_SE3_PD = 5
 };
+#define QPC_SE3_RECORD 29
 int32_t qpc_task_set_law(qpc_controller *ctrl, int32_t task_id, int32_t law, double kp, double kd,
                          const double *ref, int32_t n_ref);
+/* where task `task_id` lives in one QP's `desired` record (after qpc_finalize): first entry and length
+ * (the task dimension, or QPC_SE3_RECORD for a task with the SE3 PD law) */
+int32_t qpc_task_desired_range(const qpc_controller *ctrl, int32_t task_id, int32_t *offset, int32_t *length);
 
 /* regularize!(c, joint, w): obj += w * |vdot_joint|^2 ; weights add up (momentum.jl:128-131) */
 int32_t qpc_regularize(qpc_controller *ctrl, int32_t joint_body, double weight);

@@ -368,6 +368,39 @@ class SE3PDController:
         angle, axis = Quat(w, *v).angle_axis()
         return angle * axis
 
+    def device_record(self, t):
+        """The trajectory record of the device-side law QPC_LAW_SE3_PD (include/qpc.h) for time(s) t: an array
+        [..., 29] = [6 unused | t x0 xf | c0..c5 of the interpolator | quaternion y0 | quaternion yf | p0 | pf].  With it
+        in the task's slice of `desired` (binding.Controller.task_desired_range) and
+        `set_task_law(task, LAW_SE3_PD, k_ang, d_ang, [k_lin, d_lin])`, the tick evaluates this controller per QP on the
+        device instead of the host calling it and `setdesired!` before every tick."""
+        from .trajectories import Interpolated, Polynomial, PolyDerivEvaluator, Quat, SE3Trajectory
+        tr = self.trajectory
+        if not (isinstance(tr, SE3Trajectory) and isinstance(tr.angular, Interpolated) and isinstance(tr.linear, Interpolated)):
+            raise TypeError("device_record: an SE3Trajectory of two Interpolated trajectories is needed")
+        a, l = tr.angular, tr.linear
+        if (a.x0, a.xf) != (l.x0, l.xf) or not isinstance(a.y0, Quat) or not isinstance(a.yf, Quat):
+            raise ValueError("device_record: angular and linear parts must share [x0, xf]; angular end points must be Quat")
+
+        def coeffs(f):
+            if f is None:
+                return (0.0, 1.0, 0.0, 0.0, 0.0, 0.0)
+            p = f.f if isinstance(f, PolyDerivEvaluator) else f
+            if not isinstance(p, Polynomial) or p.shift != 0.0 or p.scale != 1.0 or len(p.c) > 6:
+                raise ValueError("device_record: the interpolator must be a monomial Polynomial of degree <= 5 on [0, 1]")
+            return tuple(p.c) + (0.0,) * (6 - len(p.c))
+        ca = coeffs(a.interpolator)
+        if ca != coeffs(l.interpolator):
+            raise ValueError("device_record: angular and linear parts must share the interpolator")
+        t = np.asarray(t, dtype=np.float64)
+        rec = np.zeros(t.shape + (29,))
+        rec[..., 6] = t
+        rec[..., 7], rec[..., 8] = a.x0, a.xf
+        rec[..., 9:15] = ca
+        rec[..., 15:19], rec[..., 19:23] = a.y0.q, a.yf.q
+        rec[..., 23:26], rec[..., 26:29] = np.asarray(l.y0, dtype=float), np.asarray(l.yf, dtype=float)
+        return rec
+
     def __call__(self, t, x):
         from .workloads import batch_kinematics
         q, v = x

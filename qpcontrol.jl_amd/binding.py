@@ -20,7 +20,8 @@ DEFAULT_LIB = os.path.join(_HERE, "libqpcontrol_hip.so")
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_int32_p = ctypes.POINTER(ctypes.c_int32)
 
-LAW_INPUT, LAW_CONSTANT, LAW_JOINT_PD, LAW_COM_PD, LAW_ORIENTATION_PD = range(5)
+LAW_INPUT, LAW_CONSTANT, LAW_JOINT_PD, LAW_COM_PD, LAW_ORIENTATION_PD, LAW_SE3_PD = range(6)
+SE3_RECORD = 29  # include/qpc.h QPC_SE3_RECORD
 STATUS_NAMES = ["OPTIMAL", "ALMOST_OPTIMAL", "INFEASIBLE", "DUAL_INFEASIBLE", "ITERATION_LIMIT", "NUMERICAL_ERROR"]
 
 
@@ -71,6 +72,7 @@ def load_library(path=None):
     L.qpc_add_task.argtypes = [vp, i32, i32, i32, i32, c_double_p, i32, i32, c_double_p, c_int32_p]
     L.qpc_regularize.argtypes = [vp, i32, dbl]
     L.qpc_task_set_law.argtypes = [vp, i32, i32, dbl, dbl, c_double_p, i32]
+    L.qpc_task_desired_range.argtypes = [vp, i32, c_int32_p, c_int32_p]
     L.qpc_add_contact.argtypes = [vp, i32, c_double_p, c_double_p, dbl, i32, c_int32_p]
     L.qpc_finalize.argtypes = [vp, i32, ctypes.POINTER(Layout)]
     L.qpc_get_layout.argtypes = [vp, ctypes.POINTER(Layout)]
@@ -178,6 +180,12 @@ class Controller:
         r = np.ascontiguousarray(np.asarray(ref, dtype=np.float64).reshape(-1))
         _check(self.L, self.L.qpc_task_set_law(self.h, int(task_id), int(law), float(kp), float(kd),
                                                _dp(r) if r.size else None, int(r.size)), "qpc_task_set_law")
+
+    def task_desired_range(self, task_id):
+        """(offset, length) of a task's slice of one QP's `desired` record (after finalize)"""
+        o, n = ctypes.c_int32(0), ctypes.c_int32(0)
+        _check(self.L, self.L.qpc_task_desired_range(self.h, int(task_id), ctypes.byref(o), ctypes.byref(n)), "qpc_task_desired_range")
+        return o.value, n.value
 
     def regularize(self, joint, w):
         _check(self.L, self.L.qpc_regularize(self.h, int(joint), float(w)), "qpc_regularize")

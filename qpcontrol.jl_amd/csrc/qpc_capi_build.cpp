@@ -152,11 +152,26 @@ int32_t qpc_task_set_law(qpc_controller *c, int32_t task_id, int32_t law, double
         return QPC_ERR_INVALID_ARGUMENT;
       }
       break;
+    case QPC_LAW_SE3_PD:
+      if (t.kind != QPC_TASK_SPATIAL_ACCELERATION || t.target < 0 || t.frame != t.target) {
+        qpc_set_error("QPC_LAW_SE3_PD needs a SpatialAccelerationTask expressed in its target body's frame");
+        return QPC_ERR_INVALID_ARGUMENT;
+      }
+      need = 2; break; // linear gains (kp, kd); the angular ones are the kp / kd arguments
     default: qpc_set_error("qpc_task_set_law: unknown law"); return QPC_ERR_INVALID_ARGUMENT;
   }
   if (n_ref != need) { qpc_set_error("qpc_task_set_law: wrong reference length for this law"); return QPC_ERR_INVALID_ARGUMENT; }
   t.law = law; t.kp = kp; t.kd = kd;
   t.ref.assign(ref, ref + n_ref);
+  return QPC_OK;
+}
+
+int32_t qpc_task_desired_range(const qpc_controller *c, int32_t task_id, int32_t *offset, int32_t *length) {
+  if (!c || task_id < 0 || task_id >= (int)c->tasks.size()) return QPC_ERR_INVALID_ARGUMENT;
+  if (!c->finalized) { qpc_set_error("controller not finalized"); return QPC_ERR_NOT_FINALIZED; }
+  const QpcTask &t = c->tasks[task_id];
+  if (offset) *offset = t.des_off;
+  if (length) *length = t.law == QPC_LAW_SE3_PD ? QPC_SE3_RECORD : t.dim;
   return QPC_OK;
 }
 

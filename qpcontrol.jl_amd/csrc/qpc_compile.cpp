@@ -46,6 +46,11 @@ int qpc_compile_program(qpc_controller *c) {
   Builder B;
   B.D = &D;
   const int nb = m->nb, nv = m->nv, N = c->N;
+  { // slices of the per-QP `desired` record: the task dimension, or a trajectory record for a task with the SE3 PD law
+    int off = 0;
+    for (auto &t : c->tasks) { t.des_off = off; off += (t.law == QPC_LAW_SE3_PD) ? QPC_SE3_RECORD : t.dim; }
+    c->n_desired = off;
+  }
   D.nb = nb; D.nq = m->nq; D.nv = nv; D.N = N; D.nc = (int)c->contacts.size();
   D.floating = c->floating;
   D.fv0 = c->floating >= 0 ? m->voff[c->floating] : -1;
@@ -356,8 +361,16 @@ int qpc_compile_program(qpc_controller *c) {
           case QPC_LAW_JOINT_PD: law_i[3 * i + 1] = m->qoff[t.joint]; law_i[3 * i + 2] = m->voff[t.joint]; law_d[3 * i + 2] = t.ref[0]; break;
           case QPC_LAW_COM_PD: law_i[3 * i + 1] = a; law_d[3 * i + 2] = t.ref[a]; D.n_des_late++; break;
           case QPC_LAW_ORIENTATION_PD: law_i[3 * i + 1] = t.target; law_i[3 * i + 2] = a; D.n_des_late++; break;
+          case QPC_LAW_SE3_PD: // entry a: body / base / component packed, offset of the task's record; per-entry gains
+            law_i[3 * i + 1] = (t.target + 1) | ((t.base + 1) << 8) | (a << 16);
+            law_i[3 * i + 2] = t.des_off;
+            if (a >= 3) { law_d[3 * i] = t.ref[0]; law_d[3 * i + 1] = t.ref[1]; }
+            D.n_des_late++;
+            break;
         }
       }
+    for (auto &t : c->tasks) // the rest of a trajectory record are plain per-QP inputs
+      if (t.law == QPC_LAW_SE3_PD) D.n_des_inputs += QPC_SE3_RECORD - t.dim;
     B.ibegin(IT_LAW); B.it.insert(B.it.end(), law_i.begin(), law_i.end());
     B.it.push_back(0);
     law_tab.swap(law_d);

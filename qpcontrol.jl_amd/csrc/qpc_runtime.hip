@@ -856,6 +856,8 @@ int32_t qpc_assemble_solve_batch(qpc_controller *c, int64_t B, const double *tas
   }
   if (B == 0) return QPC_OK;
   if (c->N > 8) { qpc_set_error("qpc_assemble_solve_batch: friction basis larger than 8"); return QPC_ERR_UNSUPPORTED; }
+  for (auto &t : c->tasks)
+    if (t.law == QPC_LAW_SE3_PD) { qpc_set_error("qpc_assemble_solve_batch: tasks with a trajectory-record law are not supported by the L1 path"); return QPC_ERR_UNSUPPORTED; }
   int rc = host_wait(c); // the inline slot's stream is shared with small host-pointer jobs
   if (rc != QPC_OK) return rc;
   QpcDeviceState *S = c->rt->devs[0];

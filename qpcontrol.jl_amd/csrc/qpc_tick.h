@@ -903,6 +903,87 @@ QPC_FN void rotation_vector(const double *R, double *rv) {
   rv[0] = th * x; rv[1] = th * y; rv[2] = th * z;
 }
 
+// SE3PDController (src/lowlevel/se3pdcontroller.jl:13-18) with its SE3Trajectory (src/trajectories/se3.jl:8-27) made of
+// two Interpolated trajectories (src/trajectories/interpolated.jl:20-83), evaluated for ONE state:
+//   rec = the task's trajectory record (include/qpc.h QPC_LAW_SE3_PD; rec[0] is entry 6 of the slice: t)
+//   Hb / Ha = world pose of body / base (R row-major [0..8], p [9..11]), Tb / Ta = their world twists about the world origin
+//   gains: ka, da (angular), kl, dl (linear), all expressed in the body frame (test/controller.jl:13)
+// out[6] = Tdref + pd(gains, H, Href, T, Tref): desired spatial acceleration of body w.r.t. base in the body frame.
+// The SE(3) PD law itself lives in the un-vendored RigidBodyDynamics.PDControl; restated as in api.SE3PDController
+// (double-geodesic law: e = inv(Href) H, edot = T - Ad(inv(e)) Tref).
+template <class PR>
+QPC_FN void se3_pd_law(PR rec, const double *Hb, const double *Ha, const double *Tb, const double *Ta, double ka, double da,
+                       double kl, double dl, double *out) {
+  const double t = rec[0], x0 = rec[1], xf = rec[2];
+  // theta = clamp((t - x0) / (xf - x0), 0, 1) and its derivative (interpolated.jl:29-40)
+  const double dx = xf - x0;
+  double th = (t - x0) / dx, dth = 1.0 / dx;
+  if (th <= 0.0) { th = 0.0; dth = 0.0; } else if (th >= 1.0) { th = 1.0; dth = 0.0; }
+  // alpha(theta) = sum c_i theta^i and two derivatives (PolyDerivEvaluator; identity = 0,1,0,...)
+  double c[6];
+  for (int i = 0; i < 6; i++) c[i] = rec[3 + i];
+  const double al = c[0] + th * (c[1] + th * (c[2] + th * (c[3] + th * (c[4] + th * c[5]))));
+  const double a1 = c[1] + th * (2.0 * c[2] + th * (3.0 * c[3] + th * (4.0 * c[4] + th * 5.0 * c[5])));
+  const double a2 = 2.0 * c[2] + th * (6.0 * c[3] + th * (12.0 * c[4] + th * 20.0 * c[5]));
+  const double ax = a1 * dth, axx = a2 * dth * dth; // chain rule: higher derivatives of theta vanish (interpolated.jl:47-51)
+  // linear part: p = p0 + alpha (pf - p0) (interpolated.jl:60-65)
+  double p[3], pd[3], pdd[3];
+  for (int i = 0; i < 3; i++) { const double d = rec[20 + i] - rec[17 + i]; p[i] = rec[17 + i] + al * d; pd[i] = d * ax; pdd[i] = d * axx; }
+  // angular part: y = y0 * Quat(AngleAxis(alpha * angle, axis)), dy/dalpha = axis * angle (interpolated.jl:72-83)
+  const double w0 = rec[9], x0q = rec[10], y0q = rec[11], z0q = rec[12], w1 = rec[13], x1 = rec[14], y1 = rec[15], z1 = rec[16];
+  // qd = inv(y0) * yf
+  double dw = w0 * w1 + x0q * x1 + y0q * y1 + z0q * z1;
+  double dv[3] = {w0 * x1 - x0q * w1 - y0q * z1 + z0q * y1, w0 * y1 + x0q * z1 - y0q * w1 - z0q * x1, w0 * z1 - x0q * y1 + y0q * x1 - z0q * w1};
+  if (dw < 0.0) { dw = -dw; dv[0] = -dv[0]; dv[1] = -dv[1]; dv[2] = -dv[2]; }
+  const double sn = QPC_SQRT(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2]);
+  const double angle = 2.0 * QPC_ATAN2(sn, dw);
+  double axis[3] = {1.0, 0.0, 0.0};
+  if (sn > 1e-300) { axis[0] = dv[0] / sn; axis[1] = dv[1] / sn; axis[2] = dv[2] / sn; }
+  double sh, ch;
+  QPC_SINCOS(0.5 * al * angle, sh, ch);
+  const double iw = ch, ix = sh * axis[0], iy = sh * axis[1], iz = sh * axis[2];
+  const double qw = w0 * iw - x0q * ix - y0q * iy - z0q * iz, qx = w0 * ix + x0q * iw + y0q * iz - z0q * iy,
+               qy = w0 * iy - x0q * iz + y0q * iw + z0q * ix, qz = w0 * iz + x0q * iy - y0q * ix + z0q * iw;
+  const double Rr[9] = {1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qw * qz), 2 * (qx * qz + qw * qy),
+                        2 * (qx * qy + qw * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qw * qx),
+                        2 * (qx * qz - qw * qy), 2 * (qy * qz + qw * qx), 1 - 2 * (qx * qx + qy * qy)};
+  const double wbase[3] = {axis[0] * angle * ax, axis[1] * angle * ax, axis[2] * angle * ax};
+  const double wdbase[3] = {axis[0] * angle * axx, axis[1] * angle * axx, axis[2] * angle * axx};
+  // SE3Trajectory (se3.jl:8-27): everything re-expressed in the (desired) body frame
+  double wr[3], nur[3], wdr[3], nudr[3], cr[3];
+  mtv3(Rr, wbase, wr); mtv3(Rr, pd, nur); mtv3(Rr, wdbase, wdr); mtv3(Rr, pdd, nudr);
+  cross3(wr, nur, cr);
+  nudr[0] += cr[0]; nudr[1] += cr[1]; nudr[2] += cr[2];
+  // state: H = relative_transform(body -> base), T = relative twist in the body frame (se3pdcontroller.jl:15-16)
+  double R[9], Rat[9], dpw[3], pr[3];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rat[3 * i + j] = Ha[3 * j + i];
+  mm3(Rat, Hb, R);
+  dpw[0] = Hb[9] - Ha[9]; dpw[1] = Hb[10] - Ha[10]; dpw[2] = Hb[11] - Ha[11];
+  mtv3(Ha, dpw, pr);
+  double wrel[3] = {Tb[0] - Ta[0], Tb[1] - Ta[1], Tb[2] - Ta[2]}, vrel[3] = {Tb[3] - Ta[3], Tb[4] - Ta[4], Tb[5] - Ta[5]};
+  double wxp[3], Tang[3], Tlin[3];
+  cross3(wrel, Hb + 9, wxp);
+  vrel[0] += wxp[0]; vrel[1] += wxp[1]; vrel[2] += wxp[2];
+  mtv3(Hb, wrel, Tang); mtv3(Hb, vrel, Tlin);
+  // e = inv(Href) * H ; Tref seen from the actual body frame: Ad(inv(e))
+  double Re[9], Rrt[9], dpe[3] = {pr[0] - p[0], pr[1] - p[1], pr[2] - p[2]}, pe[3];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rrt[3 * i + j] = Rr[3 * j + i];
+  mm3(Rrt, R, Re);
+  mtv3(Rr, dpe, pe);
+  double Trang[3], tl[3], Trlin[3];
+  mtv3(Re, wr, Trang);
+  cross3(wr, pe, tl);
+  tl[0] += nur[0]; tl[1] += nur[1]; tl[2] += nur[2];
+  mtv3(Re, tl, Trlin);
+  double rv[3], Rtp[3];
+  rotation_vector(Re, rv);
+  mtv3(Re, pe, Rtp);
+  for (int i = 0; i < 3; i++) {
+    out[i] = wdr[i] - ka * rv[i] - da * (Tang[i] - Trang[i]);
+    out[3 + i] = nudr[i] - kl * Rtp[i] - dl * (Tlin[i] - Trlin[i]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // the tick
 // ------------------------------------------------------------------------------------------
@@ -1279,6 +1360,14 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
           double wb = 0.0;
           for (int r = 0; r < 3; r++) wb += H[3 * r + a] * sm[D.lds[L_T] + 6 * body + r];
           sm[D.lds[L_DES] + i] = -lw[0] * rv[a] - lw[1] * wb;
+        } else if (li[0] == QPC_LAW_SE3_PD) { // SE3PDController on the device (se3pdcontroller.jl:13-18), lane = component
+          const int body = (li[1] & 255) - 1, base = ((li[1] >> 8) & 255) - 1, a = (li[1] >> 16) & 7, rec0 = li[2] + 6;
+          double Hb[12], Ha[12], Tb[6], Ta[6], out[6];
+          ldH(sm, D, body, Hb); ldH(sm, D, base, Ha);
+          ld6(sm, D.lds[L_T], body, Tb); ld6(sm, D.lds[L_T], base, Ta);
+          const double *lwa = DT + D.dt[DT_LAW] + 3 * li[2], *lwl = lwa + 9; // gains of entries 0 (angular) and 3 (linear)
+          se3_pd_law(sm + D.lds[L_DES] + rec0, Hb, Ha, Tb, Ta, lwa[0], lwa[1], lwl[0], lwl[1], out);
+          sm[D.lds[L_DES] + i] = out[a];
         }
       }
     }
