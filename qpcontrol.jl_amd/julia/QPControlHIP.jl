@@ -12,6 +12,7 @@
 module QPControlHIP
 
 export qp_solve_batch, setlaw!, simulate!, SimParams, LAW_INPUT, LAW_CONSTANT, LAW_JOINT_PD, LAW_COM_PD, LAW_ORIENTATION_PD,
+       LAW_SE3_PD, SE3_RECORD, QPCOptimizer, pin!, pinned_zeros, enable_warm_start!, control_async!, wait!, desired_range,
        BatchedMomentumBasedController, QPCModel, addtask!, addcontact!, regularize!, finalize!,
        QPSolveFailure, SpatialAccelerationTask, AngularAccelerationTask, LinearAccelerationTask,
        PointAccelerationTask, JointAccelerationTask, MomentumRateTask, LinearMomentumRateTask
@@ -162,6 +163,10 @@ regularize!(c::BatchedMomentumBasedController, joint::Integer, weight::Real) =
 # `task_id` is the value returned by addtask!.  With a law on every task the tick needs no `desired`.
 const LAW_INPUT = Int32(0); const LAW_CONSTANT = Int32(1); const LAW_JOINT_PD = Int32(2)
 const LAW_COM_PD = Int32(3); const LAW_ORIENTATION_PD = Int32(4)
+# SE3PDController + SE3Trajectory on the device (src/lowlevel/se3pdcontroller.jl:13-18): kp / kd = angular gains,
+# ref = [kp_linear, kd_linear]; the task's rows of `desired` become a trajectory record of SE3_RECORD entries
+# (include/qpc.h QPC_LAW_SE3_PD; `desired_range(controller, task_id)` tells which rows)
+const LAW_SE3_PD = Int32(5); const SE3_RECORD = 29
 function setlaw!(c::BatchedMomentumBasedController, task_id::Integer, law::Int32; kp::Real = 0.0, kd::Real = 0.0,
                  ref::Vector{Float64} = Float64[])
     check(ccall((:qpc_task_set_law, libqpc), Int32, (Ptr{Cvoid}, Int32, Int32, Float64, Float64, Ptr{Float64}, Int32),
@@ -169,22 +174,56 @@ function setlaw!(c::BatchedMomentumBasedController, task_id::Integer, law::Int32
     nothing
 end
 
-function addcontact!(c::BatchedMomentumBasedController, body::Integer, position, normal, mu::Real; per_qp_surface::Bool = false)
+# position / normal / mu may be Parameters in the reference (contacts.jl:39): per_qp_surface (normal, mu) and
+# per_qp_position make them rows of the per-QP `surfaces` input ([nx ny nz mu] then [px py pz] per such contact)
+function addcontact!(c::BatchedMomentumBasedController, body::Integer, position, normal, mu::Real;
+                     per_qp_surface::Bool = false, per_qp_position::Bool = false)
     cid = Ref{Int32}(-1)
     pos, nrm = collect(Float64, position), collect(Float64, normal)
+    flags = Int32(per_qp_surface ? 1 : 0) | Int32(per_qp_position ? 2 : 0)
     GC.@preserve pos nrm check(ccall((:qpc_add_contact, libqpc), Int32,
         (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}, Float64, Int32, Ref{Int32}),
-        c.handle, body, pos, nrm, mu, per_qp_surface, cid), "qpc_add_contact")
+        c.handle, body, pos, nrm, mu, flags, cid), "qpc_add_contact")
     cid[]
 end
 
-# initialize! (momentum.jl:150-156): explicit here because the layout is needed to size inputs
-function finalize!(c::BatchedMomentumBasedController; device::Integer = 0)
+# warm-started ticks (the reference's OSQP workspace persists between ticks, momentum.jl:58): call before finalize!;
+# the tick then takes / returns `working_set` (2 x B UInt64, zeros = cold start)
+enable_warm_start!(c::BatchedMomentumBasedController, on::Bool = true) =
+    check(ccall((:qpc_enable_warm_start, libqpc), Int32, (Ptr{Cvoid}, Int32), c.handle, on), "qpc_enable_warm_start")
+
+# initialize! (momentum.jl:150-156): explicit here because the layout is needed to size inputs.
+# devices = [0, 1, ...]: the task program is replicated on every device and each batch is split into contiguous
+# column ranges, one per device (qpc_finalize_devices) -- one Julia process drives all GPUs of the node.
+function finalize!(c::BatchedMomentumBasedController; device::Integer = 0, devices::Union{Nothing, Vector{Int32}} = nothing)
     lay = Ref{Layout}()
-    check(ccall((:qpc_finalize, libqpc), Int32, (Ptr{Cvoid}, Int32, Ref{Layout}), c.handle, device, lay), "qpc_finalize")
+    if devices === nothing
+        check(ccall((:qpc_finalize, libqpc), Int32, (Ptr{Cvoid}, Int32, Ref{Layout}), c.handle, device, lay), "qpc_finalize")
+    else
+        check(ccall((:qpc_finalize_devices, libqpc), Int32, (Ptr{Cvoid}, Int32, Ptr{Int32}, Ref{Layout}),
+                    c.handle, length(devices), devices, lay), "qpc_finalize_devices")
+    end
     c.layout = lay[]
     c
 end
+
+# rows of `desired` that belong to a task (after finalize!): first row (1-based) and count
+function desired_range(c::BatchedMomentumBasedController, task_id::Integer)
+    off, len = Ref{Int32}(0), Ref{Int32}(0)
+    check(ccall((:qpc_task_desired_range, libqpc), Int32, (Ptr{Cvoid}, Int32, Ref{Int32}, Ref{Int32}), c.handle, task_id, off, len),
+          "qpc_task_desired_range")
+    (off[] + 1):(off[] + len[])
+end
+
+# Page-locked batch arrays: the kernels read / write them IN PLACE over PCIe (no staging copies; measured 89 % of
+# the device-resident rate against ~60 % for pageable arrays).  Allocate the batch matrices once, pin them, reuse
+# them every tick -- what a control loop does anyway.
+function pin!(A::Array)
+    check(ccall((:qpc_host_register, libqpc), Int32, (Ptr{Cvoid}, UInt64), pointer(A), sizeof(A)), "qpc_host_register")
+    finalizer(x -> ccall((:qpc_host_unregister, libqpc), Int32, (Ptr{Cvoid},), pointer(x)), A)
+    A
+end
+pinned_zeros(::Type{T}, dims...) where {T} = pin!(zeros(T, dims...))
 
 """
     controller(τ, t, q, v; desired, contact_weight, contact_maxnormalforce, task_weights, surfaces)
@@ -219,6 +258,26 @@ function (c::BatchedMomentumBasedController)(τ::Matrix{Float64}, t::Number, q::
     end
     τ
 end
+
+# asynchronous tick: returns once the job is posted (qpc_control_batch_async); every array must stay alive and
+# untouched until wait!(controller) -- keep them in pinned, preallocated buffers.  One job in flight per controller.
+function control_async!(c::BatchedMomentumBasedController, τ::Matrix{Float64}, q::Matrix{Float64}, v::Matrix{Float64};
+        desired::Matrix{Float64} = zeros(0, size(q, 2)), contact_weight::Matrix{Float64} = zeros(0, size(q, 2)),
+        contact_maxnormalforce::Matrix{Float64} = zeros(0, size(q, 2)))
+    lay = c.layout
+    B = size(q, 2)
+    size(c.vdot) == (lay.nv, B) || (c.vdot = zeros(lay.nv, B))
+    size(c.contactwrenches) == (6 * lay.n_contacts, B) || (c.contactwrenches = zeros(6 * lay.n_contacts, B))
+    length(c.status) == B || (c.status = zeros(Int32, B))
+    ptr(x) = isempty(x) ? Ptr{Float64}(C_NULL) : pointer(x)
+    check(ccall((:qpc_control_batch_async, libqpc), Int32,
+        (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+         Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}),
+        c.handle, B, q, v, ptr(desired), ptr(contact_weight), ptr(contact_maxnormalforce), Ptr{Float64}(C_NULL),
+        Ptr{Float64}(C_NULL), τ, c.vdot, ptr(c.contactwrenches), c.status, Ptr{Int32}(C_NULL)), "qpc_control_batch_async")
+    nothing
+end
+wait!(c::BatchedMomentumBasedController) = check(ccall((:qpc_wait, libqpc), Int32, (Ptr{Cvoid},), c.handle), "qpc_wait")
 
 # ---------------------------------------------------------------------------------------------
 # f-2: closed loop on the device.  The reference's acceptance run (notebooks/Standing controller.ipynb
@@ -262,11 +321,8 @@ end
 # ---------------------------------------------------------------------------------------------
 # b-1: solver-level plug.  `MomentumBasedController{N}(mechanism, optimizer)` (reference
 # src/lowlevel/momentum.jl:15-16,27) accepts any MOI.AbstractOptimizer; the reference's tests build
-# an OSQP one (test/runtests.jl:35-43).  `qp_solve_batch` is the ccall that an optimizer subtype
-# forwards `MOI.optimize!` to with B = 1: dense OSQP-form data in, (x, y, status) out.  The MOI
-# bookkeeping (copy_to, constraint-coefficient modification with fixed sparsity, VariablePrimal /
-# TerminationStatus getters) is a thin Julia layer on this call; it needs a Julia toolchain to be
-# written against and is not part of this repository's tested surface.
+# an OSQP one (test/runtests.jl:35-43).  `qp_solve_batch` is the ccall that `QPCOptimizer` (end of this
+# file) forwards `MOI.optimize!` to with B = 1: dense OSQP-form data in, (x, y, status) out.
 struct Settings
     max_active_set_iters::Int32
     max_refine_iters::Int32
@@ -301,4 +357,172 @@ function qp_solve_batch(P::Array{Float64, 3}, q::Matrix{Float64}, At::Array{Floa
     x, y[1:m, :], status, iters
 end
 
+# ---------------------------------------------------------------------------------------------
+# f-3: `QPCOptimizer <: MOI.AbstractOptimizer` -- lets UNMODIFIED QPControl.jl run its QP on the GPU:
+#
+#     controller = MomentumBasedController{4}(mechanism, QPControlHIP.QPCOptimizer(), floatingjoint = ...)
+#
+# Parametron (0.9, MathOptInterface 0.8) drives an optimizer like this (momentum.jl:27,58):
+#   * once:        MOI.copy_to(optimizer, backend_model)         -- variables, ONE ScalarQuadraticFunction objective,
+#                  VectorAffineFunction-in-{Zeros, Nonnegatives, Nonpositives} constraints
+#   * every tick:  MOI.set(optimizer, MOI.ObjectiveFunction{F}(), f)   and
+#                  MOI.set(optimizer, MOI.ConstraintFunction(), ci, f)  -- same terms, new coefficients
+#                  MOI.optimize!(optimizer)
+#   * afterwards:  MOI.get(optimizer, MOI.VariablePrimal(), vi), MOI.TerminationStatus(), MOI.PrimalStatus(),
+#                  MOI.DualStatus() (checkstatus, momentum.jl:83-91)
+# The optimizer keeps the problem dense (P n x n, q, A' n x m so that the C side sees row-major A, l, u) and
+# forwards optimize! to qp_solve_batch with B = 1.  Assembly stays on the CPU here: this is the compatibility
+# plug (SURVEY.md 8 b-1); the performance path is BatchedMomentumBasedController.
+#
+# Written against the MOI 0.8 API from memory -- there is no `julia` in the build image, so this block is
+# UNTESTED there; its Python twin (qpcontrol.jl_amd/moi.py) replays the same life cycle against the same
+# L0 entry in tests/test_moi_optimizer.py.  MathOptInterface (already a dependency of QPControl.jl, Project.toml)
+# is the only package this file needs.
+import MathOptInterface
+const MOI = MathOptInterface
+using LinearAlgebra: dot
+
+mutable struct QPCOptimizer <: MOI.AbstractOptimizer
+    device::Int32
+    settings::Settings
+    n::Int
+    m::Int
+    P::Matrix{Float64}          # n x n symmetric
+    q::Vector{Float64}
+    At::Matrix{Float64}         # n x m (column j = row j of A): row-major A for the C ABI
+    l::Vector{Float64}
+    u::Vector{Float64}
+    objconstant::Float64
+    sense::MOI.OptimizationSense
+    rowranges::Dict{Any, UnitRange{Int}}   # constraint index -> rows of A
+    rowsets::Dict{Any, Any}                 # constraint index -> its set (Zeros / Nonnegatives / Nonpositives)
+    x::Vector{Float64}
+    y::Vector{Float64}
+    status::Int32                           # QPC_STATUS_* of the last optimize!, -1 before
+    QPCOptimizer(; device::Integer = 0, settings::Settings = default_settings()) =
+        new(device, settings, 0, 0, zeros(0, 0), Float64[], zeros(0, 0), Float64[], Float64[], 0.0,
+            MOI.MIN_SENSE, Dict{Any, UnitRange{Int}}(), Dict{Any, Any}(), Float64[], Float64[], Int32(-1))
+end
+
+MOI.get(::QPCOptimizer, ::MOI.SolverName) = "qpcontrol_hip (gfx950)"
+MOI.is_empty(o::QPCOptimizer) = o.n == 0
+function MOI.empty!(o::QPCOptimizer)
+    o.n = o.m = 0; o.P = zeros(0, 0); o.q = Float64[]; o.At = zeros(0, 0); o.l = Float64[]; o.u = Float64[]
+    o.objconstant = 0.0; empty!(o.rowranges); empty!(o.rowsets); o.x = Float64[]; o.y = Float64[]; o.status = Int32(-1)
+    nothing
+end
+
+const _QPCSets = Union{MOI.Zeros, MOI.Nonnegatives, MOI.Nonpositives}
+MOI.supports(::QPCOptimizer, ::MOI.ObjectiveSense) = true
+MOI.supports(::QPCOptimizer, ::MOI.ObjectiveFunction{MOI.ScalarQuadraticFunction{Float64}}) = true
+MOI.supports(::QPCOptimizer, ::MOI.ObjectiveFunction{MOI.ScalarAffineFunction{Float64}}) = true
+MOI.supports_constraint(::QPCOptimizer, ::Type{MOI.VectorAffineFunction{Float64}}, ::Type{<:_QPCSets}) = true
+
+# rows of one vector constraint: A x + b in set  ->  l <= A x <= u
+function _setrows!(o::QPCOptimizer, rows::UnitRange{Int}, f::MOI.VectorAffineFunction{Float64}, set)
+    o.At[:, rows] .= 0.0
+    for t in f.terms
+        o.At[t.scalar_term.variable_index.value, rows[t.output_index]] += t.scalar_term.coefficient
+    end
+    for (k, r) in enumerate(rows)
+        b = f.constants[k]
+        if set isa MOI.Zeros
+            o.l[r] = -b; o.u[r] = -b
+        elseif set isa MOI.Nonnegatives
+            o.l[r] = -b; o.u[r] = Inf
+        else
+            o.l[r] = -Inf; o.u[r] = -b
+        end
+    end
+end
+function _setobjective!(o::QPCOptimizer, f::MOI.ScalarQuadraticFunction{Float64})
+    o.P .= 0.0; o.q .= 0.0
+    for t in f.quadratic_terms   # MOI: 1/2 x'Qx; an off-diagonal term appears once and stands for both entries
+        i, j = t.variable_index_1.value, t.variable_index_2.value
+        o.P[i, j] += t.coefficient
+        i == j || (o.P[j, i] += t.coefficient)
+    end
+    for t in f.affine_terms
+        o.q[t.variable_index.value] += t.coefficient
+    end
+    o.objconstant = f.constant
+end
+function _setobjective!(o::QPCOptimizer, f::MOI.ScalarAffineFunction{Float64})
+    o.P .= 0.0; o.q .= 0.0
+    for t in f.terms
+        o.q[t.variable_index.value] += t.coefficient
+    end
+    o.objconstant = f.constant
+end
+
+# MOI.copy_to: variables keep their indices (Parametron creates them 1:n), constraints are laid out in
+# the order of ListOfConstraints / ListOfConstraintIndices
+function MOI.copy_to(dest::QPCOptimizer, src::MOI.ModelLike; copy_names::Bool = false)
+    MOI.empty!(dest)
+    vis = MOI.get(src, MOI.ListOfVariableIndices())
+    n = length(vis)
+    idxmap = MOI.Utilities.IndexMap()
+    for (k, vi) in enumerate(vis)
+        idxmap[vi] = MOI.VariableIndex(k)
+    end
+    cons = Any[]
+    m = 0
+    for (F, S) in MOI.get(src, MOI.ListOfConstraints())
+        (F == MOI.VectorAffineFunction{Float64} && S <: _QPCSets) || throw(MOI.UnsupportedConstraint{F, S}())
+        for ci in MOI.get(src, MOI.ListOfConstraintIndices{F, S}())
+            f = MOI.get(src, MOI.ConstraintFunction(), ci)
+            s = MOI.get(src, MOI.ConstraintSet(), ci)
+            push!(cons, (ci, f, s, (m + 1):(m + MOI.dimension(s))))
+            m += MOI.dimension(s)
+        end
+    end
+    dest.n = n; dest.m = m
+    dest.P = zeros(n, n); dest.q = zeros(n); dest.At = zeros(n, m); dest.l = zeros(m); dest.u = zeros(m)
+    for (ci, f, s, rows) in cons
+        fm = MOI.Utilities.mapvariables(idxmap, f)
+        dest.rowranges[ci] = rows; dest.rowsets[ci] = s
+        idxmap[ci] = ci
+        _setrows!(dest, rows, fm, s)
+    end
+    dest.sense = MOI.get(src, MOI.ObjectiveSense())
+    dest.sense == MOI.MAX_SENSE && error("QPCOptimizer: minimisation only (momentum.jl:158-160 uses Minimize)")
+    F = MOI.get(src, MOI.ObjectiveFunctionType())
+    _setobjective!(dest, MOI.Utilities.mapvariables(idxmap, MOI.get(src, MOI.ObjectiveFunction{F}())))
+    idxmap
+end
+
+# per-tick coefficient updates (Parametron update!)
+MOI.set(o::QPCOptimizer, ::MOI.ObjectiveFunction{F}, f::F) where {F <: Union{MOI.ScalarQuadraticFunction{Float64}, MOI.ScalarAffineFunction{Float64}}} =
+    _setobjective!(o, f)
+MOI.set(o::QPCOptimizer, ::MOI.ObjectiveSense, s::MOI.OptimizationSense) = (o.sense = s)
+function MOI.set(o::QPCOptimizer, ::MOI.ConstraintFunction, ci::MOI.ConstraintIndex, f::MOI.VectorAffineFunction{Float64})
+    _setrows!(o, o.rowranges[ci], f, o.rowsets[ci])
+end
+MOI.set(o::QPCOptimizer, ::MOI.ConstraintSet, ci::MOI.ConstraintIndex, s) = (o.rowsets[ci] = s)
+
+function MOI.optimize!(o::QPCOptimizer)
+    lc = clamp.(o.l, -1e20, 1e20); uc = clamp.(o.u, -1e20, 1e20)   # +-1e20 = unbounded (include/qpc.h L0)
+    x, y, status, _ = qp_solve_batch(reshape(o.P, o.n, o.n, 1), reshape(o.q, o.n, 1), reshape(o.At, o.n, o.m, 1),
+                                     reshape(lc, o.m, 1), reshape(uc, o.m, 1); device = o.device, settings = o.settings)
+    o.x = vec(x); o.y = vec(y); o.status = status[1]
+    nothing
+end
+
+# results: exactly what checkstatus reads (momentum.jl:83-91)
+function MOI.get(o::QPCOptimizer, ::MOI.TerminationStatus)
+    s = o.status
+    s == -1 ? MOI.OPTIMIZE_NOT_CALLED : s == 0 ? MOI.OPTIMAL : s == 1 ? MOI.ALMOST_OPTIMAL : s == 2 ? MOI.INFEASIBLE :
+    s == 3 ? MOI.DUAL_INFEASIBLE : s == 4 ? MOI.ITERATION_LIMIT : MOI.NUMERICAL_ERROR
+end
+MOI.get(o::QPCOptimizer, ::MOI.PrimalStatus) =
+    o.status == 0 ? MOI.FEASIBLE_POINT : o.status == 2 ? MOI.NO_SOLUTION : o.status == 3 ? MOI.INFEASIBILITY_CERTIFICATE :
+    o.status == -1 ? MOI.NO_SOLUTION : MOI.UNKNOWN_RESULT_STATUS
+MOI.get(o::QPCOptimizer, ::MOI.DualStatus) =
+    o.status == 0 ? MOI.FEASIBLE_POINT : o.status == 2 ? MOI.INFEASIBILITY_CERTIFICATE : o.status == -1 ? MOI.NO_SOLUTION :
+    MOI.UNKNOWN_RESULT_STATUS
+MOI.get(o::QPCOptimizer, ::MOI.ResultCount) = o.status == -1 ? 0 : 1
+MOI.get(o::QPCOptimizer, ::MOI.VariablePrimal, vi::MOI.VariableIndex) = o.x[vi.value]
+MOI.get(o::QPCOptimizer, ::MOI.ObjectiveValue) = 0.5 * dot(o.x, o.P * o.x) + dot(o.q, o.x) + o.objconstant
+MOI.get(o::QPCOptimizer, ::MOI.ConstraintDual, ci::MOI.ConstraintIndex) = -o.y[o.rowranges[ci]]  # OSQP sign convention
+MOI.get(o::QPCOptimizer, ::MOI.ConstraintPrimal, ci::MOI.ConstraintIndex) = (o.At' * o.x)[o.rowranges[ci]]
 end # module
