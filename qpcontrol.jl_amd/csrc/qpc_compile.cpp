@@ -547,6 +547,7 @@ int qpc_compile_program(qpc_controller *c) {
   // changes per QP / p99): 12 sweeps 6.92 / 36, 6: 6.74, 5: 6.41, 4: 6.08 / 18, 3: 6.82 -- QPs that have
   // not converged after 4 sweeps rarely do, and Goldfarb-Idnani from their working set is cheaper
   D.max_pdas = 4;
+  if (const char *e = getenv("QPC_MAX_PDAS")) { const int v = atoi(e); if (v >= 0 && v <= 64) D.max_pdas = v; } // experiments
   D.eps_primal = c->settings.eps_primal_reg;
   D.tau_pivot = c->settings.eps_dual_reg;
   D.tol_bound = c->settings.tol_bound;

@@ -123,6 +123,23 @@ __device__ __forceinline__ int wave_min_int(int x) {
 #undef QPC_DPP_STEPS
 } // namespace qpc
 
+// Experiment switch QPC_F32_LDS=1 (BASELINE config 5's "fp32 storage" question): the whole per-QP LDS slab
+// kept in fp32 -- half the bytes, every load converted to fp64 for the arithmetic, every store rounded.  The tick is
+// written against an abstract LDS pointer type P (the emulator's race-checking proxy is one), so this is just another P.
+namespace qpc {
+struct F32Ref {
+  float *p;
+  __device__ __forceinline__ operator double() const { return (double)*p; }
+  __device__ __forceinline__ F32Ref &operator=(double v) { *p = (float)v; return *this; }
+  __device__ __forceinline__ F32Ref &operator=(const F32Ref &o) { *p = *o.p; return *this; }
+};
+struct F32Ptr {
+  float *base;
+  __device__ __forceinline__ F32Ref operator[](int i) const { return F32Ref{base + i}; }
+  __device__ __forceinline__ F32Ptr operator+(int o) const { return F32Ptr{base + o}; }
+};
+} // namespace qpc
+
 // reductions that straddle a phase boundary: *_PUT inside the phase (every lane, exactly once),
 // *_GET after QPC_END_PHASE.  `name` is a double (and `iname` an int) declared before the phase.
 #define QPC_RED_MAX_PUT(slot, name, val) name = qpc::wave_max_scale(val)

@@ -32,7 +32,8 @@ static std::string dbl(double x) {
 std::string qpc_jit_source(const QpcDims &D, bool warm) {
   std::ostringstream o;
   o << "typedef int int32_t;\ntypedef unsigned int uint32_t;\ntypedef long long int64_t;\ntypedef unsigned long long uint64_t;\n";
-  o << "#define QPC_JIT 1\n#define QPC_M1_MAX " << (D.m1 > 0 ? D.m1 : 1) << "\n#define QPC_MAXD " << D.maxd << "\n#define QPC_NTILE_MAX " << (((D.m + 15) / 16) * (((D.m + 15) / 16) + 1) / 2 > 0 ? ((D.m + 15) / 16) * (((D.m + 15) / 16) + 1) / 2 : 1) << "\n#include \"qpc_device.h\"\n";
+  o << "#define QPC_JIT 1\n#define QPC_M1_MAX " << (D.m1 > 0 ? D.m1 : 1) << "\n#define QPC_MAXD " << D.maxd << "\n#define QPC_NTILE_MAX " << (((D.m + 15) / 16) * (((D.m + 15) / 16) + 1) / 2 > 0 ? ((D.m + 15) / 16) * (((D.m + 15) / 16) + 1) / 2 : 1) << "\n#define QPC_XTILE_MAX " << (((D.m1 + 15) / 16) * (((D.m1 + 15) / 16) + 1) / 2 + (D.m1 + 15) / 16 > 0 ? ((D.m1 + 15) / 16) * (((D.m1 + 15) / 16) + 1) / 2 + (D.m1 + 15) / 16 : 1)
+    << "\n#include \"qpc_device.h\"\n";
   const char *st = getenv("QPC_JIT_STAMPS"); // diagnostic: in-kernel section timers
   const bool stamps = st && st[0] == '1';
   if (stamps)
@@ -64,11 +65,15 @@ std::string qpc_jit_source(const QpcDims &D, bool warm) {
   o << "struct QpcBatchArgs { long long B; const double *q, *v, *desired, *cw, *cmax, *tw, *surf; double *tau, *vdot, "
        "*cwrench; int32_t *status, *iters; unsigned long long *prof; unsigned long long *ticket; unsigned long long *wsets; double *scratch; };\n";
   // the tick kernel (cold start) and, on request, its warm-started twin: same loop, qpc_tick<P, true>
+  const char *f32e = getenv("QPC_F32_LDS"); // experiment: fp32 LDS storage (qpc_device.h F32Ptr)
+  const bool f32 = f32e && f32e[0] == '1';
   for (int variant = 0; variant < (warm ? 2 : 1); variant++) {
     o << "extern \"C\" __global__ void __launch_bounds__(64, 2) " << (variant ? "qpc_tick_kernel_jit_warm" : "qpc_tick_kernel_jit")
       << "(const int *__restrict__ IT, const double *__restrict__ DT, const QpcBatchArgs A) {\n"
-         "  __shared__ __attribute__((aligned(16))) double qpc_lds[" << (D.lds_doubles > 0 ? D.lds_doubles : 1) << "];\n"
-         "  qpc::qpc_tick_prologue<double *>(kD, IT, qpc_lds);\n"
+         "  __shared__ __attribute__((aligned(16))) " << (f32 ? "float" : "double") << " qpc_lds_raw[" << (D.lds_doubles > 0 ? D.lds_doubles : 1) << "];\n"
+         "  " << (f32 ? "const qpc::F32Ptr qpc_lds{qpc_lds_raw};" : "double *const qpc_lds = qpc_lds_raw;") << "\n"
+         "  typedef " << (f32 ? "qpc::F32Ptr" : "double *") << " LdsP;\n"
+         "  qpc::qpc_tick_prologue<LdsP>(kD, IT, qpc_lds);\n"
          "  while (true) {\n"
          "    unsigned long long t = 0;\n"
          "    if ((threadIdx.x & 63) == 0) t = atomicAdd(A.ticket, 1ull);\n"
@@ -90,7 +95,7 @@ std::string qpc_jit_source(const QpcDims &D, bool warm) {
          "    // addresses out of this loop (they would stay live across the whole tick and spill)\n"
          "    const int *ITq = IT; const double *DTq = DT;\n"
          "    asm volatile(\"\" : \"+s\"(ITq), \"+s\"(DTq));\n"
-         "    qpc::qpc_tick<double *, " << (variant ? "true" : "false") << ">(kD, ITq, DTq, qpc_lds, io);\n"
+         "    qpc::qpc_tick<LdsP, " << (variant ? "true" : "false") << ">(kD, ITq, DTq, qpc_lds, io);\n"
          "    __syncthreads();\n"
          "  }\n"
          "}\n";

@@ -129,6 +129,10 @@ template <class P> QPC_FN void ld6(P sm, int off, int body, double *x) {
 #ifndef QPC_NTILE_MAX
 #define QPC_NTILE_MAX 10
 #endif
+// tiles of the X'[X | L21'] product: lower-triangular tiles of the m1 x m1 block plus one column of tiles for Z
+#ifndef QPC_XTILE_MAX
+#define QPC_XTILE_MAX 14
+#endif
 // compile-time bound of the tree depth (the JIT defines it as the actual depth)
 #ifndef QPC_MAXD
 #define QPC_MAXD QPC_GENERIC_MAXD
@@ -1263,6 +1267,14 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
   } QPC_END_PHASE
   QPC_PROF_ACC(PS_K_BIAS);
   QPC_PHASE(lane) { // momentum matrix, CoM, momentum-rate bias, Hessian diagonal
+    // static-Hessian path: its table reads are issued FIRST, so that they travel while the momentum matrix is computed
+    // (in source order they sat behind three dependent waits at the end of the phase)
+    double hv0_pre = 0.0, winv_pre = 0.0, grav_pre[4] = {0.0, 0.0, 0.0, 0.0};
+    if (h_fast) {
+      hv0_pre = DT[D.dt[DT_HV0] + (lane < nf ? lane : 0)];
+      winv_pre = DT[D.dt[DT_WINV0] + (lane < D.wsize ? lane : 0)];
+      for (int a = 0; a < 4; a++) grav_pre[a] = DT[D.dt[DT_GRAV] + a];
+    }
     if (lane < nv) {
       const int k = lane;
       const int *mt = QPC_LI(M.v, lane);
@@ -1285,7 +1297,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       sm[MISC + MS_ADV + (lane - 3)] = acc; // Ȧv + A_pin v̇_pin
     }
     for (int f = lane; f < nf; f += 64) { // Hv = 2 reg + folded soft joint tasks (a12)
-      double hv = h_fast ? DT[D.dt[DT_HV0] + f] : DT[D.dt[DT_REG2] + IT[D.it[IT_FREE_K] + f]], gv = 0.0;
+      double hv = h_fast ? (f < 64 ? hv0_pre : DT[D.dt[DT_HV0] + f]) : DT[D.dt[DT_REG2] + IT[D.it[IT_FREE_K] + f]], gv = 0.0;
       for (int s = 0; s < D.nsj; s++)
         if (IT[D.it[IT_SJ_F] + s] == f) {
           int twi = IT[D.it[IT_SJ_TW] + s];
@@ -1298,14 +1310,14 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       if (h_fast) sm[D.lds[L_SQH] + f] = QPC_RSQRT(hv);
     }
     if (h_fast) {
-      for (int e = lane; e < D.wsize; e += 64) sm[D.lds[L_WINV] + e] = DT[D.dt[DT_WINV0] + e];
+      for (int e = lane; e < D.wsize; e += 64) sm[D.lds[L_WINV] + e] = e < 64 ? winv_pre : DT[D.dt[DT_WINV0] + e];
       if (lane == 63) { sm[MISC + MS_EPS] = eps; sm[MISC + MS_HSCALE] = hscale; }
       if (lane >= 10 && lane < 16 && nw) { // gravity wrench about the world origin (momentum.jl:166-170); the centre of
                                            // mass is one phase old
         const int a = lane - 10;
         double fg[3], cxf[3], com[3] = {sm[MISC + MS_COM], sm[MISC + MS_COM + 1], sm[MISC + MS_COM + 2]};
-        const double mt = DT[D.dt[DT_GRAV] + 3];
-        fg[0] = mt * DT[D.dt[DT_GRAV]]; fg[1] = mt * DT[D.dt[DT_GRAV] + 1]; fg[2] = mt * DT[D.dt[DT_GRAV] + 2];
+        const double mt = grav_pre[3];
+        fg[0] = mt * grav_pre[0]; fg[1] = mt * grav_pre[1]; fg[2] = mt * grav_pre[2];
         cross3(com, fg, cxf);
         sm[MISC + MS_WG + a] = a < 3 ? cxf[a] : fg[a - 3];
       }
@@ -1715,14 +1727,14 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
   // S11I = X'X into the (now free) leading block of L_SM: the second GEMM-shaped step of the tick, on the
   // fp64 matrix core like S = M M' above -- lower-triangular 16x16 tiles, operands straight from the LDS
   // copy of X (lower triangular: tile row ti only needs k >= 16 ti), two LDS reads per lane and k-step
-  // instead of the ~2 x 13 per entry of the dot-product form.  Z = X' L21' = S11^-1 S12 rides in the
-  // write-out phase.
+  // instead of the ~2 x 13 per entry of the dot-product form.  Z = X' L21' = S11^-1 S12 is one more column of
+  // tiles of the same product, X' [X | L21'] (it used to be 6 m1 strided dot products in the write-out phase).
   {
-    const int nt1 = (m1 + 15) / 16, nk1 = (m1 + 3) / 4;
-    QPC_LANE_ARRAY(xacc_, 4 * QPC_NTILE_MAX);
+    const int nt1 = (m1 + 15) / 16, nk1 = (m1 + 3) / 4, ntri = nt1 * (nt1 + 1) / 2;
+    QPC_LANE_ARRAY(xacc_, 4 * QPC_XTILE_MAX);
     QPC_PHASE(lane) {
       double *acc = QPC_LA(xacc_, lane);
-      for (int e = 0; e < 4 * QPC_NTILE_MAX; e++) acc[e] = 0.0;
+      for (int e = 0; e < 4 * QPC_XTILE_MAX; e++) acc[e] = 0.0;
     } QPC_END_PHASE
     {
       int tile = 0;
@@ -1737,6 +1749,19 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
                                       ? (double)sm[D.lds[L_X] + (4 * ks + (lane >> 4)) * D.m1s + 16 * ti + (lane & 15)] : 0.0),
                                  ((16 * tj + (lane & 15) < m1 && 4 * ks + (lane >> 4) < m1)
                                       ? (double)sm[D.lds[L_X] + (4 * ks + (lane >> 4)) * D.m1s + 16 * tj + (lane & 15)] : 0.0))
+          }
+        }
+      }
+      if (nw) { // Z tiles: rows 16 ti .. of X' times the six columns L21'[k][a] = L21[a][k]
+        QPC_UNROLL_JIT
+        for (int ti = 0; ti < nt1; ti++) {
+          QPC_UNROLL_JIT
+          for (int ks = 4 * ti; ks < nk1; ks++) {
+            QPC_MFMA_F64_16x16x4(lane, QPC_LA(xacc_, lane) + 4 * (ntri + ti),
+                                 ((16 * ti + (lane & 15) < m1 && 4 * ks + (lane >> 4) < m1)
+                                      ? (double)sm[D.lds[L_X] + (4 * ks + (lane >> 4)) * D.m1s + 16 * ti + (lane & 15)] : 0.0),
+                                 (((lane & 15) < 6 && 4 * ks + (lane >> 4) < m1)
+                                      ? (double)sm[D.lds[L_SM] + (m1 + (lane & 15)) * D.ms + 4 * ks + (lane >> 4)] : 0.0))
           }
         }
       }
@@ -1760,11 +1785,16 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
           }
         }
       }
-      if (nw)
-        for (int idx = lane; idx < m1 * 6; idx += 64) {
-          int r = idx / 6, a = idx % 6;
-          sm[D.lds[L_X2] + idx] = dotp(sm + D.lds[L_X] + r * D.m1s + r, D.m1s, sm + D.lds[L_SM] + (m1 + a) * D.ms + r, 1, m1 - r);
+      if (nw) {
+        QPC_UNROLL_JIT
+        for (int ti = 0; ti < nt1; ti++) {
+          QPC_UNROLL_FULL
+          for (int reg = 0; reg < 4; reg++) {
+            const int r = 16 * ti + (lane >> 4) + 4 * reg, a = lane & 15;
+            if (r < m1 && a < 6) sm[D.lds[L_X2] + r * 6 + a] = acc[4 * (ntri + ti) + reg];
+          }
         }
+      }
     } QPC_END_PHASE
   }
   QPC_PROF_ACC(PS_XINV);
