@@ -485,7 +485,7 @@ int qpc_compile_program(qpc_controller *c) {
   //   A = { kinematics-only scratch: RL->IC, TJ->HB, CR }  U  { big assembly outputs: M, G, HR, HI, WS }
   //   B = { what the assembly still reads: H, inputs, T, S, AB, IW->AMOM }  U  { solver scratch }  U  { RNEA scratch }
   // What the inverse dynamics needs again after the solve (I_i, W0_i, S_k) is NOT kept in LDS: it is
-  // lane-private and parked in the workgroup's HBM spill slot (qpc_program.h SCR_*).
+  // lane-private and stays in the lane's registers (qpc_tick.h keep_iw_ / keep_sk_).
   // Every overlay below was validated by the emulator's race / uninitialised-read detector.
   const int nrho = D.nrho, mm = D.m;
   auto even = [](int x) { return x + (x & 1); };

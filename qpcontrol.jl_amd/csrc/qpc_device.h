@@ -3,7 +3,20 @@
 #pragma once
 
 #define QPC_FN __device__ __forceinline__
+// The lane index is made OPAQUE once per phase: without it the compiler treats everything derived from the lane (table
+// addresses, lane-dependent constants of the unrolled factorization phases, ...) as invariant of the persistent per-QP
+// loop, hoists dozens of such values out of it and, out of registers, spills them -- to be reloaded from scratch in the
+// hot phases (measured: 136 MB of extra HBM reads per 32768-QP launch).  Recomputing them per phase is a few integer ops.
+__device__ __forceinline__ int qpc_opaque_lane() {
+  int l = (int)(threadIdx.x & 63);
+  asm volatile("" : "+v"(l));
+  return l;
+}
+#ifdef QPC_NO_OPAQUE_LANE
 #define QPC_PHASE(lane) { const int lane = (int)(threadIdx.x & 63);
+#else
+#define QPC_PHASE(lane) { const int lane = qpc_opaque_lane();
+#endif
 #define QPC_END_PHASE } __syncthreads();
 #define QPC_SINCOS(x, s, c) qpc_sincos((double)(x), (s), (c))
 #define QPC_SQRT(x) sqrt((double)(x))

@@ -63,7 +63,7 @@ std::string qpc_jit_source(const QpcDims &D, bool warm) {
     << D.max_pdas << "," << dbl(D.eps_primal) << "," << dbl(D.tau_pivot) << "," << dbl(D.tol_bound) << ","
     << dbl(D.tol_accept) << "," << dbl(D.h_static_max) << "," << dbl(D.h_static_min) << "};\n";
   o << "struct QpcBatchArgs { long long B; const double *q, *v, *desired, *cw, *cmax, *tw, *surf; double *tau, *vdot, "
-       "*cwrench; int32_t *status, *iters; unsigned long long *prof; unsigned long long *ticket; unsigned long long *wsets; double *scratch; };\n";
+       "*cwrench; int32_t *status, *iters; unsigned long long *prof; unsigned long long *ticket; unsigned long long *wsets; };\n";
   // the tick kernel (cold start) and, on request, its warm-started twin: same loop, qpc_tick<P, true>
   const char *f32e = getenv("QPC_F32_LDS"); // experiment: fp32 LDS storage (qpc_device.h F32Ptr)
   const bool f32 = f32e && f32e[0] == '1';
@@ -90,7 +90,6 @@ std::string qpc_jit_source(const QpcDims &D, bool warm) {
          "    io.cwrench = A.cwrench ? A.cwrench + b * 6 * kD.nc : nullptr;\n"
          "    io.status = A.status + b; io.iters = A.iters ? A.iters + b : nullptr; io.prof = A.prof ? A.prof + b * PS_COUNT : nullptr;\n"
          "    io.wset = " << (variant ? "A.wsets ? A.wsets + 2 * b : nullptr" : "nullptr") << ";\n"
-         "    io.scratch = A.scratch + (size_t)blockIdx.x * QPC_SCRATCH_DOUBLES;\n"
          "    // opaque copies of the table pointers: keeps the compiler from hoisting dozens of per-lane table\n"
          "    // addresses out of this loop (they would stay live across the whole tick and spill)\n"
          "    const int *ITq = IT; const double *DTq = DT;\n"

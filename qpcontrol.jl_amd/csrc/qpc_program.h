@@ -119,14 +119,6 @@ enum {
   MS_COUNT = 24
 };
 
-// Lane-private spill area in HBM (one slot per resident workgroup, [component][lane] so that every
-// access is a coalesced 512-byte row): what the inverse dynamics needs again after the solve but
-// nothing in between does -- body lane i: world inertia I_i (10) and the velocity-product / bias
-// wrench W0_i = I_i (Ab_i - g) + T_i x* I_i T_i (6); velocity lane k: motion subspace column S_k (6).
-// Keeping these 22 x 64 doubles out of LDS is what lets 8 QPs share a CU.
-enum { SCR_IW = 0, SCR_W0 = 10, SCR_S = 16, SCR_ROWS = 22 };
-#define QPC_SCRATCH_DOUBLES (SCR_ROWS * 64)
-
 // tree-depth bound of the ahead-of-time generic kernel (the JIT-specialised kernel has no such
 // bound).  NOTE: hipcc -O3 (ROCm 7.2) miscompiles the generic kernel with a bound of 32 (wrong
 // kinematics on gfx950, correct at -O1 and in the emulator); 16 is validated by the GPU tests.

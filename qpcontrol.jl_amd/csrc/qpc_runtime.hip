@@ -76,7 +76,6 @@ struct QpcBatchArgs {
                               // bookkeeping, no memset between launches, safe under hipGraph replay.  Launches that share
                               // a counter must not overlap (one counter per pipeline slot, see QpcSlot)
   unsigned long long *wsets;  // warm-start working sets, 2 x uint64 per QP (in/out), or nullptr (cold start)
-  double *scratch;            // QPC_SCRATCH_DOUBLES per resident workgroup (lane-private spill slots)
 };
 
 extern "C" __global__ void __launch_bounds__(64, 1)
@@ -103,7 +102,6 @@ qpc_tick_kernel(const QpcDims D, const int *__restrict__ IT, const double *__res
     io.status = A.status + b; io.iters = A.iters ? A.iters + b : nullptr;
     io.prof = A.prof ? A.prof + b * PS_COUNT : nullptr;
     io.wset = A.wsets ? A.wsets + 2 * b : nullptr;
-    io.scratch = A.scratch + (size_t)blockIdx.x * QPC_SCRATCH_DOUBLES;
     qpc::qpc_tick<double *>(D, IT, DT, qpc_lds, io);
     __syncthreads(); // the slab is reused by the next QP of this workgroup
   }
@@ -135,14 +133,13 @@ qpc_sim_kernel(const QpcDims D, const int *__restrict__ IT, const double *__rest
 
 // ------------------------------------------------------------------------------------------
 // One pipeline slot of a device: everything two launches in flight must NOT share -- the ticket
-// counter, the lane-private spill slots, the staging buffers -- plus the stream the slot's work is
+// counter, the staging buffers -- plus the stream the slot's work is
 // ordered on.  Worker slots [0, P) and the inline slot P own their stream; the user slot P + 1 (the
 // *_device entry points) runs on whatever stream the caller passes and remembers the last one so that
 // a change of stream is turned into an event dependency instead of a race on the counter.
 struct QpcSlot {
   hipStream_t stream = nullptr; // own stream (null for the user slot)
   unsigned long long *d_ticket = nullptr;
-  double *d_scratch = nullptr;
   char *d_stage = nullptr; size_t d_stage_bytes = 0; // device staging slab of the host-pointer path
   char *h_stage = nullptr; size_t h_stage_bytes = 0; // pinned host staging slab (pageable caller arrays)
   hipEvent_t last_event = nullptr; // recorded after the slot's last launch (user slot only)
@@ -225,7 +222,6 @@ static int launch(qpc_controller *c, QpcDeviceState *S, QpcSlot &sl, const QpcBa
   }
   QpcBatchArgs aa = a;
   aa.ticket = sl.d_ticket;
-  aa.scratch = sl.d_scratch;
   hipFunction_t fn = warm ? S->jit_warm_func : S->jit_func;
   if (warm && !fn) { qpc_set_error("warm-start kernel not available (qpc_enable_warm_start before qpc_finalize; needs the hiprtc-specialised kernel)"); return QPC_ERR_UNSUPPORTED; }
   if (!warm) aa.wsets = nullptr;
@@ -280,7 +276,6 @@ static void destroy_device_state(QpcDeviceState *S) {
   for (auto &e : S->pool) (void)hipEventDestroy(e);
   for (auto &sl : S->slots) {
     if (sl.d_ticket) (void)hipFree(sl.d_ticket);
-    if (sl.d_scratch) (void)hipFree(sl.d_scratch);
     if (sl.d_stage) (void)hipFree(sl.d_stage);
     if (sl.h_stage) (void)hipHostFree(sl.h_stage);
     if (sl.last_event) (void)hipEventDestroy(sl.last_event);
@@ -332,7 +327,6 @@ static int init_device_state(qpc_controller *c, QpcDeviceState *S, int device_id
     else HIP_TRY(hipEventCreateWithFlags(&sl.last_event, hipEventDisableTiming));
     HIP_TRY(hipMalloc(&sl.d_ticket, sizeof(unsigned long long)));
     HIP_TRY(hipMemset(sl.d_ticket, 0, sizeof(unsigned long long)));
-    HIP_TRY(hipMalloc(&sl.d_scratch, sizeof(double) * QPC_SCRATCH_DOUBLES * (size_t)S->n_cu * S->blocks_per_cu));
   }
   if (!code.empty()) {
     if (hipModuleLoadData(&S->jit_module, code.data()) == hipSuccess &&
@@ -1123,7 +1117,7 @@ static int rollout_host(qpc_controller *c, int64_t B, int64_t n_steps, bool tick
     if (dws) chk(hipMemsetAsync(dws, 0, 2 * (size_t)s.n * sizeof(unsigned long long), s.st), "clear working sets");
     if (rc != QPC_OK) break;
     if (tick) {
-      // the inline slot owns its stream, ticket counter and spill slots: launch through it (not the user slot)
+      // the inline slot owns its stream and ticket counter: launch through it (not the user slot)
       for (int64_t k = 0; k < n_steps && rc == QPC_OK; k++) {
         QpcBatchArgs a;
         a.B = s.n; a.q = s.dev[A_Q]; a.v = s.dev[A_V]; a.desired = desired ? s.dev[A_DES] : nullptr; a.cw = s.dev[A_CW]; a.cmax = s.dev[A_CMAX];

@@ -291,7 +291,6 @@ struct TickIO {
   double *tau, *vdot, *cwrench;
   int32_t *status, *iters;
   unsigned long long *prof; // PS_COUNT section cycle counters (diagnostic build) or nullptr
-  double *scratch;          // QPC_SCRATCH_DOUBLES lane-private spill slot of this workgroup (HBM)
   unsigned long long *wset; // warm start (qpc_tick<P, true> only): working set of this QP's previous tick, in / out:
                             // [0] bit j = rho_j at its lower bound, [1] bit j = rho_j at its upper bound; nullptr / zeros = cold
 };
@@ -1041,6 +1040,13 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
 
   // ======================================================================== inputs -> LDS
   TickMeta M;
+  // What the inverse dynamics needs again after the solve but nothing in between does -- this lane's body inertia (10) and
+  // solution-independent wrench W0 (6), this lane's motion subspace column (6) -- stays in the lane's REGISTERS across the
+  // solver (QPC_KEEP_REGS).  It used to be parked in a per-workgroup slot in HBM (5.7 KB written and read back per QP); with
+  // the lane index opaque per phase the kernel needs ~205 VGPRs without them, so the 44 registers are there (251 VGPRs,
+  // no spills); HBM traffic per solve went from 13.9 KB to 1.9 KB, the algorithmic 1 968 B.
+  QPC_LANE_ARRAY(keep_iw_, 16);
+  QPC_LANE_ARRAY(keep_sk_, 6);
   double hscale = 0.0, hinvmax = 0.0, eps = 0.0, eps_ve = 0.0;
   bool exact_ve = false, h_fast = false;
   const bool h_static_path = D.h_static && D.n_des_late == 0;
@@ -1177,7 +1183,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
                       Iw[0] + mm * (cc - cw[0] * cw[0]), Iw[4] + mm * (cc - cw[1] * cw[1]), Iw[8] + mm * (cc - cw[2] * cw[2]),
                       Iw[1] - mm * cw[0] * cw[1], Iw[2] - mm * cw[0] * cw[2], Iw[5] - mm * cw[1] * cw[2]};
       st(sm + D.lds[L_IW] + 10 * i, 10, o);
-      for (int a = 0; a < 10; a++) io.scratch[(SCR_IW + a) * 64 + lane] = o[a]; // needed again by the RNEA only
+      for (int a = 0; a < 10; a++) QPC_LA(keep_iw_, lane)[a] = o[a]; // needed again by the RNEA only
     }
   } QPC_END_PHASE
   QPC_PROF_ACC(PS_K_SUBSP);
@@ -1238,7 +1244,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       // W0 = I (Ab - g) + T x* I T : everything of the body wrench that does not depend on the solution
       double mg[6] = {0, 0, 0, -DT[D.dt[DT_GRAV]], -DT[D.dt[DT_GRAV] + 1], -DT[D.dt[DT_GRAV] + 2]}, ig[6];
       inertia_mul(I, mg, ig);
-      for (int a = 0; a < 6; a++) io.scratch[(SCR_W0 + a) * 64 + lane] = ia[a] + ig[a];
+      for (int a = 0; a < 6; a++) QPC_LA(keep_iw_, lane)[10 + a] = ia[a] + ig[a];
     }
     if (lane >= 51 && lane < 54) { // centre of mass (IW[1..3] = m c): last reader of L_IW, which L_AMOM overlays
       const int a = lane - 51;
@@ -1281,7 +1287,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       double Ic[10], S[6], h[6];
       ld(sm + D.lds[L_IC] + 10 * MT_VBODY(mt), 10, Ic);
       ld(sm + D.lds[L_S] + 6 * k, 6, S);
-      for (int a = 0; a < 6; a++) io.scratch[(SCR_S + a) * 64 + lane] = S[a]; // for tau_k = S_k . F (RNEA)
+      for (int a = 0; a < 6; a++) QPC_LA(keep_sk_, lane)[a] = S[a]; // for tau_k = S_k . F (RNEA)
       inertia_mul(Ic, S, h);
       for (int a = 0; a < 6; a++) sm[D.lds[L_AMOM] + a * nv + k] = h[a];
     }
@@ -2139,11 +2145,11 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
     }
     if (lane < nb) {
       double *iw = QPC_LA(iw_, lane);
-      for (int a = 0; a < 16; a++) iw[a] = io.scratch[(SCR_IW + a) * 64 + lane];
+      for (int a = 0; a < 16; a++) iw[a] = QPC_LA(keep_iw_, lane)[a];
     }
     if (lane < nv) { // S_k v̇_k of the FREE velocity indices (the pinned ones already ride in Ab)
       double *sk = QPC_LA(sk_, lane);
-      for (int a = 0; a < 6; a++) sk[a] = io.scratch[(SCR_S + a) * 64 + lane];
+      for (int a = 0; a < 6; a++) sk[a] = QPC_LA(keep_sk_, lane)[a];
       const int f = IT[D.it[IT_FREE_OF] + lane];
       const double vd = f >= 0 ? (double)sm[D.lds[L_XV] + f] * (double)sm[D.lds[L_SQH] + f] : 0.0;
       for (int a = 0; a < 6; a++) sm[D.lds[L_SVK] + 6 * lane + a] = sk[a] * vd;

@@ -141,8 +141,6 @@ static void emu_ticks(qpc_controller *c, const QpcHostJob &job, int64_t lo, int6
     io.cwrench = job.out[QpcHostJob::OUT_CWRENCH] ? job.out[QpcHostJob::OUT_CWRENCH] + b * 6 * D.nc : nullptr;
     io.status = job.status + b; io.iters = job.iters ? job.iters + b : nullptr; io.prof = nullptr;
     io.wset = job.working_set ? (unsigned long long *)job.working_set + 2 * b : nullptr;
-    std::vector<double> scratch(QPC_SCRATCH_DOUBLES, std::nan("")); // a fresh (poisoned) spill slot per QP
-    io.scratch = scratch.data();
     qpc::qpc_tick_prologue<Lds>(D, c->prog.itab.data(), Lds{0});
     if (job.working_set) qpc::qpc_tick<Lds, true>(D, c->prog.itab.data(), c->prog.dtab.data(), Lds{0}, io);
     else qpc::qpc_tick<Lds, false>(D, c->prog.itab.data(), c->prog.dtab.data(), Lds{0}, io);
