@@ -3,19 +3,33 @@
 #pragma once
 
 #define QPC_FN __device__ __forceinline__
-// The lane index is made OPAQUE once per phase: without it the compiler treats everything derived from the lane (table
-// addresses, lane-dependent constants of the unrolled factorization phases, ...) as invariant of the persistent per-QP
-// loop, hoists dozens of such values out of it and, out of registers, spills them -- to be reloaded from scratch in the
-// hot phases (measured: 136 MB of extra HBM reads per 32768-QP launch).  Recomputing them per phase is a few integer ops.
+// The lane index is made OPAQUE once per QP (per function scope that runs phases: QPC_LANE_SCOPE).  Without it the compiler
+// treats everything derived from the lane (table addresses, lane-dependent constants of the unrolled factorization phases,
+// ...) as invariant of the persistent per-QP loop, hoists dozens of such values out of it and, out of registers, spills
+// them -- to be reloaded from scratch in the hot phases (measured: 77 spilled VGPRs, 136 MB of extra HBM reads per
+// 32768-QP launch).  Opaque per QP the values are recomputed once per QP and shared by its phases: 2 spilled VGPRs,
+// 25.6 M solves/s; opaque per PHASE (-DQPC_LANE_PER_PHASE) nothing is spilled (205 VGPRs before the register-resident RNEA
+// inputs) but every phase redoes its address arithmetic (+18 % VALU instructions): 24.2 M.
 __device__ __forceinline__ int qpc_opaque_lane() {
   int l = (int)(threadIdx.x & 63);
   asm volatile("" : "+v"(l));
   return l;
 }
-#ifdef QPC_NO_OPAQUE_LANE
+#if defined(QPC_NO_OPAQUE_LANE)
 #define QPC_PHASE(lane) { const int lane = (int)(threadIdx.x & 63);
-#else
+#define QPC_LANE_SCOPE
+#elif defined(QPC_LANE_PER_PHASE)
 #define QPC_PHASE(lane) { const int lane = qpc_opaque_lane();
+#define QPC_LANE_SCOPE
+#else
+#define QPC_PHASE(lane) { const int lane = qpc_lane_q;
+#define QPC_LANE_SCOPE const int qpc_lane_q = qpc_opaque_lane();
+#define QPC_LANE_IN_SCOPE 1
+#endif
+#if defined(QPC_LANE_IN_SCOPE) && !defined(QPC_MACRO_LANE_TID)
+#define QPC_MACRO_LANE qpc_lane_q
+#else
+#define QPC_MACRO_LANE ((int)(threadIdx.x & 63))
 #endif
 #define QPC_END_PHASE } __syncthreads();
 #define QPC_SINCOS(x, s, c) qpc_sincos((double)(x), (s), (c))
@@ -180,7 +194,7 @@ __device__ __forceinline__ double qpc_quad_bcast(double x, int i) {
 }
 #define QPC_QUAD_GATHER(lane, OUT4, XEXPR)                                                        \
   {                                                                                              \
-    const int lane = (int)(threadIdx.x & 63);                                                    \
+    const int lane = QPC_MACRO_LANE;                                                             \
     (void)lane;                                                                                  \
     double *out__ = (OUT4);                                                                      \
     const double x__ = (XEXPR);                                                                  \
@@ -196,7 +210,7 @@ __device__ __forceinline__ double qpc_quad_bcast(double x, int i) {
 typedef double qpc_v4d __attribute__((ext_vector_type(4)));
 #define QPC_MFMA_F64_16x16x4(lane, ACC, AEXPR, BEXPR)                                           \
   {                                                                                              \
-    const int lane = (int)(threadIdx.x & 63);                                                    \
+    const int lane = QPC_MACRO_LANE;                                                             \
     double *acc__ = (ACC);                                                                       \
     const double a__ = (AEXPR), b__ = (BEXPR);                                                   \
     qpc_v4d c__ = {acc__[0], acc__[1], acc__[2], acc__[3]};                                      \

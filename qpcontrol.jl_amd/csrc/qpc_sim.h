@@ -41,6 +41,7 @@ struct SimIO {
 
 template <class P>
 QPC_FN void qpc_sim_step(const QpcDims &D, const int *IT, const double *DT, P sm, const SimIO &io, const qpc_sim_params &sp) {
+  QPC_LANE_SCOPE
   const int nb = D.nb, nq = D.nq, nv = D.nv, nc = D.nc;
   const SimLayout L = sim_layout(D);
   // a failed QP (checkstatus, momentum.jl:83-91) applies no torque for this step and is counted

@@ -304,6 +304,7 @@ template <class P> struct Solver {
   const double *DT;
   P sm;
   bool use_rho;
+  QPC_LANE_SCOPE
   unsigned long long *PA, *PT; // section timers (diagnostic build)
   double last_gmax = 0.0, last_xmax = 0.0; // scales of the last base rho_solve (uniform)
   double last_dmax = 0.0;                   // max |rho - rho_prev| of the last proximal sweep (uniform)
@@ -1013,6 +1014,7 @@ struct TickMeta {
 // once per workgroup (before its first QP): hot solver lookups -> the persistent L_HOT region of
 // the LDS slab (never overlaid, so it survives from QP to QP)
 template <class P> QPC_FN void qpc_tick_prologue(const QpcDims &D, const int *IT, P sm) {
+  QPC_LANE_SCOPE
   QPC_PHASE(lane) {
     for (int i = lane; i < D.m + 4 * D.ne; i += 64) sm[D.lds[L_HOT] + i] = (double)IT[D.it[IT_HOT] + i];
   } QPC_END_PHASE
@@ -1024,6 +1026,7 @@ template <class P> QPC_FN void qpc_tick_prologue(const QpcDims &D, const int *IT
 // A search that fails from a warm set is repeated once from the cold start, so the answer never depends on the hint.
 template <class P, bool WARM = false>
 QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, const TickIO &io) {
+  QPC_LANE_SCOPE
   const int nb = D.nb, nq = D.nq, nv = D.nv, nf = D.nf, nc = D.nc, N = D.N, nrho = D.nrho, ne = D.ne;
   const int m = D.m, m1 = D.m1, nw = D.nw, ntask = D.ntask;
   const int MISC = D.lds[L_MISC];

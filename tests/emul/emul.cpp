@@ -65,6 +65,7 @@ struct Lds {
 #define QPC_FN inline
 #define QPC_PHASE(lane) for (int lane = 0; lane < 64; ++lane) { g_emu->lane = lane;
 #define QPC_END_PHASE } g_emu->lane = -1; g_emu->phase++;
+#define QPC_LANE_SCOPE
 #define QPC_SINCOS(x, s, c) do { double x__ = (x); s = std::sin(x__); c = std::cos(x__); } while (0)
 #define QPC_SQRT(x) std::sqrt((double)(x))
 #define QPC_FABS(x) std::fabs((double)(x))
