@@ -48,7 +48,7 @@ def main():
     nc = lay.n_contacts
     rfoot = mech.findbody("r_foot")
     right = np.array([cp.body == rfoot for cp in mech.contact_points])
-    cap = 0.30 * mech.total_mass() * 9.81 / right.sum()  # the right foot may carry ~30 % of the weight in the capped phases
+    cap = 0.45 * mech.total_mass() * 9.81 / right.sum()  # the right foot may carry ~45 % of the weight in the capped phases
     cm_free = np.full((B, nc), 1e6)
     cm_cap = cm_free.copy()
     cm_cap[:, right] = cap
