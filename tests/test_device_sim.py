@@ -340,3 +340,46 @@ def test_rollout_equals_sequential_calls_large_batch_gpu():
         qs, vs, bad = low._c.sim_step(qs, vs, tau, ground.params(1e-3), status=low.status, bad=bad)
     assert np.array_equal(r["q"], qs) and np.array_equal(r["v"], vs) and np.array_equal(r["bad"], bad)
     assert np.array_equal(r["tau"], tau)
+
+
+# ---- a contact point registered on the WORLD body (qpc_add_contact accepts QPC_WORLD) ----------------
+def check_world_contact(factory):
+    """the simulation step must ignore it (it pushes on nothing that moves) instead of reading LDS in front of the body
+    arrays: same new state as the twin controller without that contact, everything finite"""
+    def make(with_world):
+        mech = M.atlas()
+        c = factory(mech, 4, mech.findbody("pelvis"))
+        if with_world:
+            c.add_contact(M.WORLD, [0.3, 0.1, 0.0], [0.0, 0.0, 1.0], 0.5)
+        for cp in mech.contact_points:
+            c.add_contact(cp.body, cp.position, cp.normal, cp.mu)
+        for j in range(mech.nbodies):
+            c.regularize(j, 0.05)
+        c.finalize()
+        return mech, c
+    mech, cw_ = make(True)
+    _, c0 = make(False)
+    B = 6
+    q, v = W.standing_states(mech, B, 9, dq=0.1, drot=0.05, vstd=0.3)
+    q[:, 6] -= 0.02
+    rng = np.random.default_rng(9)
+    tau = rng.normal(scale=20.0, size=(B, mech.nv))
+    tau[:, :6] = 0.0
+    sp = params(sim.GroundContact(0.02, k=6.0e4, d=400.0, ct=300.0), 1e-3)
+    q1, v1, bad1 = cw_.sim_step(q, v, tau, sp)
+    q0, v0, bad0 = c0.sim_step(q, v, tau, sp)
+    assert np.isfinite(q1).all() and np.isfinite(v1).all()
+    assert np.array_equal(q1, q0) and np.array_equal(v1, v0) and np.array_equal(bad1, bad0)
+
+
+def test_sim_world_contact_emulated():
+    emu.build()
+    emu.race_report()
+    check_world_contact(emu.factory)
+    races, uninit, outside, first = emu.race_report()
+    assert (races, uninit, outside) == (0, 0, 0), first
+
+
+@pytest.mark.gpu
+def test_sim_world_contact_gpu():
+    check_world_contact(gpu_factory)
