@@ -21,20 +21,34 @@ def main():
     def factory(mech, n_basis, floating):
         return binding.Controller(binding.Model(mech), n_basis, floating)
     ctrl, wl = W.atlas_workload(factory, 2048, 3)
-    out = {"metric": "tick latency, host pointers in / out (Atlas config 3)", "unit": "us", "batches": {}}
-    for B in (1, 8, 64, 512, 2048):
-        a = (wl.q[:B], wl.v[:B], wl.desired[:B], wl.contact_weight[:B], wl.contact_maxnormalforce[:B])
-        for _ in range(20):
-            ctrl.control_batch(*a)
-        ts = []
-        for _ in range(300):
-            t0 = time.perf_counter()
-            r = ctrl.control_batch(*a)
-            ts.append(time.perf_counter() - t0)
-        assert (r["status"] <= 1).all()
-        ts = np.array(ts) * 1e6
-        out["batches"][str(B)] = {"median_us": float(np.median(ts)), "p99_us": float(np.percentile(ts, 99)),
-                                  "solves_per_s": float(B / np.median(ts) * 1e6)}
+    out = {"metric": "tick latency, host pointers in / out, synchronous call through ctypes (Atlas config 3)", "unit": "us"}
+    lay = ctrl.layout
+    for mode in ("pageable", "pinned"):
+        res = {}
+        for B in (1, 8, 64, 512, 2048):
+            src = (wl.q[:B], wl.v[:B], wl.desired[:B], wl.contact_weight[:B], wl.contact_maxnormalforce[:B])
+            if mode == "pinned":  # page-locked, preallocated: the kernel reads / writes the caller's arrays in place
+                a = tuple(binding.pinned_array(ctrl.L, x.shape) for x in src)
+                for d, x in zip(a, src):
+                    d[...] = x
+                mk = lambda shape, dt=np.float64: binding.pinned_array(ctrl.L, shape, dt)  # noqa: E731
+            else:
+                a = tuple(np.ascontiguousarray(x) for x in src)
+                mk = lambda shape, dt=np.float64: np.zeros(shape, dtype=dt)  # noqa: E731
+            o = dict(tau=mk((B, lay.nv)), vdot=mk((B, lay.nv)), cwrench_flat=mk((B, 6 * lay.n_contacts)), status=mk((B,), np.int32),
+                     iters=mk((B,), np.int32))
+            for _ in range(20):
+                ctrl.control_batch(*a, out=o)
+            ts = []
+            for _ in range(300):
+                t0 = time.perf_counter()
+                r = ctrl.control_batch(*a, out=o)
+                ts.append(time.perf_counter() - t0)
+            assert (r["status"] <= 1).all()
+            ts = np.array(ts) * 1e6
+            res[str(B)] = {"median_us": float(np.median(ts)), "p99_us": float(np.percentile(ts, 99)),
+                           "solves_per_s": float(B / np.median(ts) * 1e6)}
+        out["batches_" + mode] = res
     print(json.dumps(out))
 
 
