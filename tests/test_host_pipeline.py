@@ -158,6 +158,22 @@ def test_gpu_pipelined_host_path_equals_device_path():
     rp = cN.control_batch(pin["q"], pin["v"], pin["d"], pin["cw"], pin["cm"], out=out)
     for k in ("tau", "vdot", "cwrench", "status", "iters"):
         assert np.array_equal(r1[k], rp[k]), k
+    # caller-owned arrays page-locked IN PLACE (qpc_host_register: what QPControlHIP.pin! does with Julia arrays)
+    own = {k: np.ascontiguousarray(a).copy() for k, a in dict(q=wl.q, v=wl.v, d=wl.desired, cw=wl.contact_weight, cm=wl.contact_maxnormalforce).items()}
+    outs = dict(tau=np.zeros((B, lay.nv)), vdot=np.zeros((B, lay.nv)), cwrench_flat=np.zeros((B, 6 * lay.n_contacts)),
+                status=np.zeros(B, dtype=np.int32), iters=np.zeros(B, dtype=np.int32))
+    regs = list(own.values()) + list(outs.values())
+    for a in regs:
+        assert L.qpc_host_register(ctypes.c_void_p(a.ctypes.data), a.nbytes) == 0, L.qpc_last_error()
+    try:
+        rr = cN.control_batch(own["q"], own["v"], own["d"], own["cw"], own["cm"], out=outs)
+        for k in ("tau", "vdot", "cwrench", "status", "iters"):
+            assert np.array_equal(r1[k], rr[k]), k
+        ra2 = cN.control_batch(own["q"], own["v"], own["d"], own["cw"], own["cm"], out=outs, asynchronous=True).wait()
+        assert np.array_equal(ra2["tau"], r1["tau"])
+    finally:
+        for a in regs:
+            assert L.qpc_host_unregister(ctypes.c_void_p(a.ctypes.data)) == 0
     # ragged: B not a multiple of the chunk, smaller than one chunk, one QP
     for Bs in (1, 511, 513):
         rs = cN.control_batch(wl.q[:Bs], wl.v[:Bs], wl.desired[:Bs], wl.contact_weight[:Bs], wl.contact_maxnormalforce[:Bs])
