@@ -141,6 +141,13 @@ template <class P> QPC_FN void ld6(P sm, int off, int body, double *x) {
 #ifndef QPC_UNROLL_JIT
 #define QPC_UNROLL_JIT
 #endif
+// diagnostic: -DQPC_STOP_AFTER=<n> leaves the tick after section n (garbage outputs): instruction counters per section by
+// differencing PMC runs (tools/pmc_probe.sh)
+#ifdef QPC_STOP_AFTER
+#define QPC_STOP(n) if (QPC_STOP_AFTER == (n)) return;
+#else
+#define QPC_STOP(n)
+#endif
 template <class PA, class PB> QPC_FN double dotp(PA a, int sa, PB b, int sb, int n) {
   double acc0 = 0.0, acc1 = 0.0;
   for (int i0 = 0; i0 < n; i0 += 8) {
@@ -1347,6 +1354,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
   } QPC_END_PHASE
 
   QPC_PROF_ACC(PS_KIN);
+  QPC_STOP(1)
   // regularisation scale: eps = eps_primal * max diagonal of the Hessian
   if (!h_fast) {
   QPC_PHASE(lane) {
@@ -1606,6 +1614,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
   } QPC_END_PHASE
 
   QPC_PROF_ACC(PS_ASM);
+  QPC_STOP(2)
   // ======================================================================== Schur complement S = M M' + W^-1 blocks
   // The one GEMM-shaped step of the tick (a12: the J'J small GEMM): lower-triangular 16x16 tiles of
   // S = M M' on the fp64 matrix core (v_mfma_f64_16x16x4_f64), operands straight from the LDS copy of
@@ -1661,6 +1670,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
     } QPC_END_PHASE
   }
   QPC_PROF_ACC(PS_SBUILD);
+  QPC_STOP(3)
   // left-looking Cholesky of the leading m1 x m1 block (+ the L21 rows), infinite-pivot rule.
   // lane = row; the row's own factor entries stay in registers (constant indices once the k loop
   // is unrolled by the JIT specialisation), row k is broadcast from LDS.
@@ -1706,6 +1716,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
     }
   }
   QPC_PROF_ACC(PS_CHOL);
+  QPC_STOP(4)
   QPC_PHASE(lane) { // B22 = S22 - L21 L21' ; X = L11^-1 (lane = column, forward substitution in registers)
     if (lane < 36 && nw) {
       int a = lane / 6, b = lane % 6, hi_ = a > b ? a : b, lo_ = a > b ? b : a;
@@ -1807,6 +1818,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
     } QPC_END_PHASE
   }
   QPC_PROF_ACC(PS_XINV);
+  QPC_STOP(5)
   // ======================================================================== active-set solve (a13)
   Solver<P> S(D, IT, DT, sm, PA, PT);
   int status = QPC_STATUS_OPTIMAL, iters = 0;
@@ -2037,6 +2049,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
     S.refactor_rho();
   }
   QPC_PROF_ACC(PS_LOGIC);
+  QPC_STOP(6)
   // ---- final refinement on the converged working set + acceptance test (a14)
   refine = 0;
   if (status == QPC_STATUS_OPTIMAL) {
@@ -2135,6 +2148,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
   }
 
   QPC_PROF_ACC(PS_FINAL);
+  QPC_STOP(7)
   // ======================================================================== extraction (a15) + RNEA (a16, a17)
   QPC_LANE_ARRAY(sk_, 6);  // this lane's motion subspace column, back from the spill slot
   QPC_LANE_ARRAY(iw_, 16); // this lane's body inertia (10) and W0 (6): one HBM round trip for all three
