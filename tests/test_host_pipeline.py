@@ -204,3 +204,46 @@ def test_gpu_user_streams_are_serialised():
 def test_gpu_graph_replay_of_the_tick():
     """the work counter re-arms itself on the device, so a captured tick can be replayed (hipGraph)"""
     _run_torch_check("graph")
+
+
+@pytest.mark.gpu
+def test_gpu_finalize_devices_single_and_errors():
+    """qpc_finalize_devices on the one GPU of the box (the multi-device sharding itself is covered with the emulator's
+    fake devices): device list validation, qpc_n_devices, the device-indexed *_device entry."""
+    from qpcontrol_jl_amd import models as M
+    mech = M.atlas()
+    bad = binding.Controller(binding.Model(mech), 4, mech.findbody("pelvis"))
+    W.standing_setup(bad, mech, M.atlas_nominal_configuration(mech))
+    with pytest.raises(binding.QpcError, match="duplicate"):
+        bad.finalize(devices=[0, 0])
+    with pytest.raises(binding.QpcError, match="out of range"):
+        bad.finalize(devices=[0, 97])
+    c, wl = _workload(gpu_factory, 256, devices=[0])
+    assert c.n_devices() == 1
+    r = _tick(c, wl)
+    assert (r["status"] == 0).all()
+    L = c.L
+    vp = ctypes.c_void_p
+    lay = c.layout
+    # device-indexed entry with page-locked host arrays as "device" pointers (zero-copy), default stream
+    a = {k: binding.pinned_array(L, x.shape) for k, x in dict(q=wl.q, v=wl.v, d=wl.desired, cw=wl.contact_weight, cm=wl.contact_maxnormalforce).items()}
+    for k, x in dict(q=wl.q, v=wl.v, d=wl.desired, cw=wl.contact_weight, cm=wl.contact_maxnormalforce).items():
+        a[k][...] = x
+    tau, vd = binding.pinned_array(L, (256, lay.nv)), binding.pinned_array(L, (256, lay.nv))
+    st = binding.pinned_array(L, (256,), np.int32)
+    st[...] = -1
+    P = lambda x: vp(x.ctypes.data)  # noqa: E731
+    assert L.qpc_control_batch_device_on(c.h, 5, 256, P(a["q"]), P(a["v"]), P(a["d"]), P(a["cw"]), P(a["cm"]), vp(0), vp(0), P(tau), P(vd), vp(0),
+                                         P(st), vp(0), vp(0)) != 0  # no such device index
+    rc = L.qpc_control_batch_device_on(c.h, 0, 256, P(a["q"]), P(a["v"]), P(a["d"]), P(a["cw"]), P(a["cm"]), vp(0), vp(0), P(tau), P(vd), vp(0),
+                                       P(st), vp(0), vp(0))
+    assert rc == 0
+    c.wait()  # nothing posted through the host entry: returns at once
+    # the launch went to the default stream without synchronisation: the statuses (written last by each QP, into page-locked
+    # memory) tell when it is done
+    import time
+    t0 = time.time()
+    while (st < 0).any() and time.time() - t0 < 10.0:
+        time.sleep(0.01)
+    time.sleep(0.05)
+    assert (st == 0).all() and np.array_equal(tau, r["tau"])
