@@ -1941,7 +1941,8 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
     } QPC_END_PHASE
     int hpos = 0;
     int direct_adds = 0;
-    (void)direct_adds;
+    bool hist_cleared = false;
+    (void)direct_adds; (void)hist_cleared;
     while (true) {
       if (iters > D.max_as_iters) { status = QPC_STATUS_ITERATION_LIMIT; break; }
       const double gscale = 1.0 + S.last_gmax, tolb = D.tol_bound * (1.0 + S.last_xmax); // U is current (rho_solve)
@@ -2008,13 +2009,42 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       // afterwards, and for the stragglers, the finite Goldfarb-Idnani iteration takes over.  Measured (MI355X, config 3): budget
       // 0: 26.6, 2: 27.1, 4: 27.0, 8: 27.3 M solves/s, but from 4 on a few QPs in 10^4 end on the cycle guard instead of
       // their optimum; 2 keeps every status of configs 3 and 5 (one infeasible QP in 2 048 reports ITERATION_LIMIT instead).
-      if (direct_adds < QPC_DIRECT_ADDS) {
+      if (direct_adds < QPC_DIRECT_ADDS && side < 0.0 && !any_upper) {
         direct_adds++;
         QPC_PHASE(lane) { if (lane == 0) sm[D.lds[L_WS] + p] = side; } QPC_END_PHASE
         iters++;
-        any_upper = any_upper || side > 0.0;
-        S.refactor_solve(any_upper);
+        S.refactor_solve(false);
+        // the pin can leave the wrench rows without a solution on the new set (same test as after phase A): the
+        // Goldfarb-Idnani step would have seen the dependence and dropped a bound first, so undo and leave it to that
+        double incons = 0.0;
+        QPC_PHASE(lane) {
+          double r = 0.0;
+          if (lane < 6) {
+            const double u = sm[MISC + MS_U0 + lane];
+            r = QPC_FABS(u - dotp(sm + D.lds[L_C22] + lane * 6, 1, sm + D.lds[L_LAM] + m1, 1, 6)) / (1.0 + QPC_FABS(u));
+          }
+          QPC_RED_MAX_PUT(0, incons, r);
+        } QPC_END_PHASE
+        incons = QPC_RED_MAX_GET(0, incons);
+        if (incons > 1e-6) {
+          direct_adds = QPC_DIRECT_ADDS;
+          hist_cleared = true; // (the set before the pin comes back: not a cycle)
+          QPC_PHASE(lane) {
+            if (lane == 0) sm[D.lds[L_WS] + p] = 0.0;
+            int *hs = QPC_LI(hist_, lane);
+            hs[0] = hs[1] = hs[2] = hs[3] = -1;
+          } QPC_END_PHASE
+          iters++;
+          S.refactor_solve(false);
+        }
         continue;
+      }
+      if (!hist_cleared) { // sets seen during the direct additions may legitimately come back once: they are not cycles
+        hist_cleared = true;
+        QPC_PHASE(lane) {
+          int *hs = QPC_LI(hist_, lane);
+          hs[0] = hs[1] = hs[2] = hs[3] = -1;
+        } QPC_END_PHASE
       }
 #endif
       bool fail = false;
