@@ -480,6 +480,55 @@ int qpc_compile_program(qpc_controller *c) {
     if (D.nf == 0 && wsize == 0) D.h_static = 0;
   }
 
+  // ---- k_tab: eigen-decompositions of the rho block of the Hessian on every free set of a contact's rays.  With N = 4 rays
+  // the block is 2 w_c B'B, B'B_ij = (1 + mu^2 cos(theta_i - theta_j)) / (1 + mu^2) (contacts.jl:16-23): the same matrix for
+  // every contact when they share mu, whatever the normal and the weight.  Per 4-bit free pattern: lambda[4], V[4][4]
+  // (V[i][k] = component i of eigenvector k; pinned rays have zero rows, unused eigen slots zero columns and lambda = 1).
+  {
+    D.k_tab = 0;
+    if (B.dt.size() & 1) B.dt.push_back(0.0); // 16-byte rows
+    B.dbegin(DT_KTAB);
+    bool ok = D.N == 4 && D.nrho > 0 && D.nrho <= 64 && D.nc <= 16 && !getenv("QPC_NO_KTAB");
+    for (auto &k : c->contacts) if ((k.per_qp & QPC_CONTACT_SURFACE_PER_QP) || k.mu != c->contacts[0].mu || !(k.mu >= 1e-3) || !(k.mu <= 1e3)) ok = false;
+    if (ok) {
+      const double mu = c->contacts[0].mu;
+      double G[4][4];
+      for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) G[i][j] = (1.0 + mu * mu * std::cos((i - j) * 1.5707963267948966)) / (1.0 + mu * mu);
+      for (int pat = 0; pat < 16; pat++) {
+        int idx[4], n = 0;
+        for (int i = 0; i < 4; i++) if (pat & (1 << i)) idx[n++] = i;
+        double A[4][4] = {{0}}, V[4][4] = {{0}};
+        for (int i = 0; i < n; i++) { for (int j = 0; j < n; j++) A[i][j] = G[idx[i]][idx[j]]; V[i][i] = 1.0; }
+        for (int sweep = 0; sweep < 60; sweep++) { // cyclic Jacobi: A -> diag, V = eigenvectors (columns)
+          double offd = 0.0;
+          for (int i = 0; i < n; i++) for (int j = i + 1; j < n; j++) offd += A[i][j] * A[i][j];
+          if (offd < 1e-60) break;
+          for (int pp = 0; pp < n; pp++)
+            for (int q = pp + 1; q < n; q++) {
+              if (std::fabs(A[pp][q]) < 1e-300) continue;
+              const double th = 0.5 * std::atan2(2.0 * A[pp][q], A[q][q] - A[pp][pp]), cs = std::cos(th), sn = std::sin(th);
+              for (int k2 = 0; k2 < n; k2++) { const double a = A[k2][pp], b = A[k2][q]; A[k2][pp] = cs * a - sn * b; A[k2][q] = sn * a + cs * b; }
+              for (int k2 = 0; k2 < n; k2++) { const double a = A[pp][k2], b = A[q][k2]; A[pp][k2] = cs * a - sn * b; A[q][k2] = sn * a + cs * b; }
+              for (int k2 = 0; k2 < n; k2++) { const double a = V[k2][pp], b = V[k2][q]; V[k2][pp] = cs * a - sn * b; V[k2][q] = sn * a + cs * b; }
+            }
+        }
+        double lmax = 0.0;
+        for (int e = 0; e < n; e++) lmax = std::max(lmax, A[e][e]);
+        for (int e = 0; e < 4; e++) { // B'B is PSD: the null direction of the all-free block gets exactly 0 (-> K = 1 / eps along it)
+          double l = e < n ? A[e][e] : 1.0;
+          if (e < n && l < 1e-12 * lmax) l = 0.0;
+          B.dt.push_back(l);
+        }
+        double Vf[4][4] = {{0}};
+        for (int i = 0; i < n; i++) for (int e = 0; e < n; e++) Vf[idx[i]][e] = V[i][e];
+        for (int i = 0; i < 4; i++) for (int e = 0; e < 4; e++) B.dt.push_back(Vf[i][e]);
+      }
+      D.k_tab = 1;
+    }
+    B.dt.push_back(0.0);
+  }
+
   // ---- LDS layout with lifetime overlays (regions that are never live together share bytes).
   //   [ persistent | small assembly outputs | A | B ]
   //   A = { kinematics-only scratch: RL->IC, TJ->HB, CR }  U  { big assembly outputs: M, G, HR, HI, WS }

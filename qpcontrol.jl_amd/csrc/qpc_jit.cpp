@@ -55,7 +55,7 @@ std::string qpc_jit_source(const QpcDims &D, bool warm) {
   o << "static constexpr QpcDims kD = {" << D.nb << "," << D.nq << "," << D.nv << "," << D.nf << "," << D.npin << ","
     << D.nsj << "," << D.ntask << "," << D.nc << "," << D.N << "," << D.nrho << "," << D.ne << "," << D.m << ","
     << D.m1 << "," << D.nw << "," << D.floating << "," << D.fv0 << "," << D.n_desired << "," << D.n_tw << ","
-    << D.n_surf << "," << D.maxdepth << "," << D.n_items << "," << D.ve_exact_ok << "," << D.n_des_inputs << "," << D.n_des_late << "," << D.maxd << "," << D.crb_full_body << "," << D.nfs << "," << D.ms << "," << D.m1s << "," << D.wsize << "," << D.h_static << ",";
+    << D.n_surf << "," << D.maxdepth << "," << D.n_items << "," << D.ve_exact_ok << "," << D.n_des_inputs << "," << D.n_des_late << "," << D.maxd << "," << D.crb_full_body << "," << D.nfs << "," << D.ms << "," << D.m1s << "," << D.wsize << "," << D.h_static << "," << D.k_tab << ",";
   put_ints(o, D.it, IT_COUNT); o << ",";
   put_ints(o, D.dt, DT_COUNT); o << ",";
   put_ints(o, D.lds, L_COUNT); o << ",";
@@ -91,9 +91,13 @@ std::string qpc_jit_source(const QpcDims &D, bool warm) {
          "    io.status = A.status + b; io.iters = A.iters ? A.iters + b : nullptr; io.prof = A.prof ? A.prof + b * PS_COUNT : nullptr;\n"
          "    io.wset = " << (variant ? "A.wsets ? A.wsets + 2 * b : nullptr" : "nullptr") << ";\n"
          "    // opaque copies of the table pointers: keeps the compiler from hoisting dozens of per-lane table\n"
-         "    // addresses out of this loop (they would stay live across the whole tick and spill)\n"
-         "    const int *ITq = IT; const double *DTq = DT;\n"
-         "    asm volatile(\"\" : \"+s\"(ITq), \"+s\"(DTq));\n"
+         "    // addresses out of this loop (they would stay live across the whole tick and spill).  The copies are made in\n"
+         "    // the GLOBAL address space and cast back, so that address-space inference still sees where they point: table\n"
+         "    // reads stay global_load (vmcnt only) instead of flat_load, which also counts on lgkmcnt and serialises with LDS\n"
+         "    const __attribute__((address_space(1))) int *ITg = (const __attribute__((address_space(1))) int *)IT;\n"
+         "    const __attribute__((address_space(1))) double *DTg = (const __attribute__((address_space(1))) double *)DT;\n"
+         "    asm volatile(\"\" : \"+s\"(ITg), \"+s\"(DTg));\n"
+         "    const int *ITq = (const int *)ITg; const double *DTq = (const double *)DTg;\n"
          "    qpc::qpc_tick<LdsP, " << (variant ? "true" : "false") << ">(kD, ITq, DTq, qpc_lds, io);\n"
          "    __syncthreads();\n"
          "  }\n"
@@ -110,8 +114,10 @@ std::string qpc_jit_source(const QpcDims &D, bool warm) {
        "    io.status = A.status ? A.status + b : nullptr;\n"
        "    io.q_out = A.q + b * kD.nq; io.v_out = A.v + b * kD.nv;\n"
        "    io.bad = A.bad ? A.bad + b : nullptr;\n"
-       "    const int *ITq = IT; const double *DTq = DT;\n"
-       "    asm volatile(\"\" : \"+s\"(ITq), \"+s\"(DTq));\n"
+       "    const __attribute__((address_space(1))) int *ITg = (const __attribute__((address_space(1))) int *)IT;\n"
+       "    const __attribute__((address_space(1))) double *DTg = (const __attribute__((address_space(1))) double *)DT;\n"
+       "    asm volatile(\"\" : \"+s\"(ITg), \"+s\"(DTg));\n"
+       "    const int *ITq = (const int *)ITg; const double *DTq = (const double *)DTg;\n"
        "    qpc::qpc_sim_step<double *>(kD, ITq, DTq, qpc_lds, io, A.sp);\n"
        "    __syncthreads();\n"
        "  }\n"

@@ -54,6 +54,7 @@ enum {
   DT_LAW, // [n_desired * 3] kp, kd, ref of the desired law of entry i
   DT_HV0,   // [nf] static Hessian diagonal of the free accelerations: 2 reg + folded soft joint tasks with static weights
   DT_WINV0, // [wsize] inverses of the static slack Hessian blocks 2 sym(W) (no eps), valid when h_static
+  DT_KTAB,  // [16 * 20] k_tab: eigenvalues [4] and eigenvectors [4][4] of B'B on each of the 16 free sets of a contact's four rays
   DT_COUNT
 };
 
@@ -116,7 +117,8 @@ enum {
   MS_WG = 9,       // 6
   MS_EPS = 15, MS_HSCALE = 16,
   MS_U0 = 17,      // 6: wrench-space constant u0 = c2 - Z'c1 of the active-set search
-  MS_COUNT = 24
+  MS_KS = 24,      // 16: k_tab: 2 * contact weight per contact
+  MS_COUNT = 40
 };
 
 // tree-depth bound of the ahead-of-time generic kernel (the JIT-specialised kernel has no such
@@ -136,6 +138,8 @@ struct QpcDims {
   int nfs, ms, m1s;  // padded leading dimensions (odd) of L_M, L_SM, L_X
   int wsize;         // doubles in L_W / L_WINV
   int h_static;      // no per-QP task weights: the v̇ / slack blocks of the Hessian are the same for every QP (DT_HV0, DT_WINV0)
+  int k_tab;         // N = 4, one static friction coefficient for all contacts: the rho blocks of H are 2 w_c B'B with the SAME
+                     // B'B, so (H_rho,FF + eps I)^-1 of every free set follows from a static eigen-decomposition (DT_KTAB)
   int it[IT_COUNT];
   int dt[DT_COUNT];
   int lds[L_COUNT];

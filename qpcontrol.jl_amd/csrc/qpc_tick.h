@@ -349,18 +349,51 @@ template <class P> struct Solver {
     return acc;
   }
 
+  // K blocks of the working set: (H_FF + eps I)^-1 per contact.  General form: Gauss-Jordan in registers, one lane per
+  // contact (kr_block, ~170 dependent instructions per refactorization).  D.k_tab (N = 4, one static mu): H_c = 2 w_c B'B
+  // with the same B'B for every contact, so the eigenvectors of every free set's block are static and the inverse is
+  //   K_F = sum_k v_k v_k' / (2 w_c lambda_k + eps)      (DT_KTAB: per 4-bit free pattern lambda[4], V[4][4])
+  // -- the same matrix to rounding (the null direction of the all-free block gets 1 / eps, as before), computed by one lane
+  // per ray: its row of K from four reciprocals and a 4 x 4 product instead of the serial elimination.
+  QPC_FN void kr_blocks() {
+    const int N = D.N, nc = D.nc, nrho = D.nrho;
+    const double eps = sm[D.lds[L_MISC] + MS_EPS];
+    if (D.k_tab) {
+      QPC_PHASE(lane) {
+        const int j = lane < nrho ? lane : 0, c = j >> 2, jj = j & 3;
+        int pat = 0;
+        QPC_UNROLL_FULL
+        for (int i = 0; i < 4; i++) pat |= (sm[D.lds[L_WS] + 4 * c + i] == 0.0) ? (1 << i) : 0;
+        const double *kt = DT + D.dt[DT_KTAB] + pat * 20;
+        const double w2 = sm[D.lds[L_MISC] + MS_KS + c];
+        double t[4], k[4] = {0.0, 0.0, 0.0, 0.0};
+        QPC_UNROLL_FULL
+        for (int e = 0; e < 4; e++) t[e] = kt[4 + 4 * jj + e] * QPC_RCP(w2 * kt[e] + eps); // v_k(jj) / (2 w lambda_k + eps)
+        QPC_UNROLL_FULL
+        for (int i = 0; i < 4; i++)
+          QPC_UNROLL_FULL
+          for (int e = 0; e < 4; e++) k[i] += t[e] * kt[4 + 4 * i + e];
+        if (lane < nrho) {
+          const int o = D.lds[L_KR] + QPC_CS(4) * c + 4 * jj;
+          sm[o] = k[0]; sm[o + 1] = k[1]; sm[o + 2] = k[2]; sm[o + 3] = k[3];
+        }
+      } QPC_END_PHASE
+      return;
+    }
+    QPC_PHASE(lane) {
+      for (int c = lane; c < nc; c += 64) {
+        if (N <= 4) kr_block<4>(sm, D, c, eps); else kr_block<8>(sm, D, c, eps);
+      }
+    } QPC_END_PHASE
+  }
+
   // Kr (block inverse of Hrho+eps on the free set), S22 = B22 + G Kr G', T22 = S22^-1
   QPC_FN void refactor_rho() {
     const int N = D.N, nc = D.nc, nrho = D.nrho, m1 = D.m1;
-    const double eps = sm[D.lds[L_MISC] + MS_EPS];
     if (!use_rho && D.nw == 0) return;
     QPC_PROF_ACC(PS_LOGIC);
     if (use_rho) {
-      QPC_PHASE(lane) {
-        for (int c = lane; c < nc; c += 64) {
-          if (N <= 4) kr_block<4>(sm, D, c, eps); else kr_block<8>(sm, D, c, eps);
-        }
-      } QPC_END_PHASE
+      kr_blocks();
       QPC_PHASE(lane) {
         for (int idx = lane; idx < nrho * 6; idx += 64) {
           int j = idx / 6, b = idx % 6, c = j / N, jj = j % N;
@@ -397,13 +430,8 @@ template <class P> struct Solver {
   QPC_FN void refactor_solve(bool any_upper) {
     if (any_upper) { refactor_rho(); rho_solve(true, 0, 0.0, true); return; }
     const int N = D.N, nc = D.nc, nrho = D.nrho, m1 = D.m1;
-    const double eps = sm[D.lds[L_MISC] + MS_EPS];
     QPC_PROF_ACC(PS_LOGIC);
-    QPC_PHASE(lane) {
-      for (int c = lane; c < nc; c += 64) {
-        if (N <= 4) kr_block<4>(sm, D, c, eps); else kr_block<8>(sm, D, c, eps);
-      }
-    } QPC_END_PHASE
+    kr_blocks();
     QPC_PROF_ACC(PS_S_KR);
     QPC_PHASE(lane) {
       for (int idx = lane; idx < nrho * 6; idx += 64) {
@@ -1082,6 +1110,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       const double cwi = io.cw[i], cmi = io.cmax[i];
       sm[D.lds[L_CW] + i] = cwi; sm[D.lds[L_CMAX] + i] = cmi;
       if (use_rho && cmi > 0.0 && 2.0 * QPC_FABS(cwi) > hc) hc = 2.0 * QPC_FABS(cwi);
+      if (D.k_tab) sm[MISC + MS_KS + i] = 2.0 * cwi; // scale of this contact's rho block of the Hessian (kr_blocks)
     }
     for (int i = lane; i < D.n_tw; i += 64) sm[D.lds[L_TW] + i] = io.tw[i];
     for (int i = lane; i < D.n_surf; i += 64) sm[D.lds[L_SURF] + i] = io.surf[i];
