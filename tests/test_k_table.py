@@ -1,0 +1,52 @@
+"""K blocks from the static eigen-decomposition table (qpc_tick.h Solver::kr_blocks, D.k_tab) against the general
+Gauss-Jordan form of the same matrices ((H_FF + eps I)^-1 per contact): QPC_NO_KTAB=1 at finalize selects the latter.
+Both are the same matrix to rounding, so the working-set search takes the same path: statuses and change counts are
+equal, change counts equal up to ties decided by rounding, and tau agrees to 1e-10 of its scale.  Controllers the table does not cover (N != 4, per-QP surfaces, different mu per
+contact) must not select it."""
+import os
+
+import numpy as np
+import pytest
+
+import emu
+from qpcontrol_jl_amd import binding
+from qpcontrol_jl_amd import workloads as W
+
+
+def _run(factory, B, config, no_table):
+    old = os.environ.pop("QPC_NO_KTAB", None)
+    if no_table:
+        os.environ["QPC_NO_KTAB"] = "1"
+    try:
+        c, wl = W.atlas_workload(factory, B, config)
+    finally:
+        os.environ.pop("QPC_NO_KTAB", None)
+        if old is not None:
+            os.environ["QPC_NO_KTAB"] = old
+    return c.control_batch(wl.q, wl.v, wl.desired, wl.contact_weight, wl.contact_maxnormalforce)
+
+
+def _same(a, b):
+    assert np.array_equal(a["status"], b["status"])
+    ok = a["status"] == 0
+    assert ok.sum() >= len(ok) // 2
+    # the same sequence of working sets (a tie decided differently by rounding is allowed for a few QPs)
+    assert np.mean(a["iters"][ok] % 1000 != b["iters"][ok] % 1000) <= 0.05
+    scale = np.maximum(1.0, np.abs(b["tau"][ok]).max(axis=1, keepdims=True))
+    assert np.all(np.abs(a["tau"][ok] - b["tau"][ok]) <= 1e-10 * scale), np.abs((a["tau"][ok] - b["tau"][ok]) / scale).max()
+
+
+@pytest.mark.parametrize("config", [3, 4, 5])
+def test_table_equals_gauss_jordan_emulated(config):
+    emu.build()
+    emu.race_report()
+    _same(_run(emu.factory, 48, config, False), _run(emu.factory, 48, config, True))
+    races, uninit, outside, first = emu.race_report()
+    assert (races, uninit, outside) == (0, 0, 0), first
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", [3, 5])
+def test_table_equals_gauss_jordan_gpu(config):
+    f = lambda mech, N, fl: binding.Controller(binding.Model(mech), N, fl)  # noqa: E731
+    _same(_run(f, 4096, config, False), _run(f, 4096, config, True))
