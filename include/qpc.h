@@ -94,8 +94,11 @@ enum {
   QPC_STATUS_INFEASIBLE = 2,
   QPC_STATUS_DUAL_INFEASIBLE = 3,
   QPC_STATUS_ITERATION_LIMIT = 4,
-  QPC_STATUS_NUMERICAL_ERROR = 5
+  QPC_STATUS_NUMERICAL_ERROR = 5 /* also: NaN / Inf anywhere in this QP's record (q, v, desired, contact weights and caps) */
 };
+/* A bad record never affects the other QPs of the batch and never keeps the kernel from terminating
+ * (tests/test_bad_inputs.py).  Degenerate but legal records solve: zero contact weights, a zero cap (= disable!,
+ * contacts.jl:72).  A negative cap reads as disabled; a negative weight makes the QP non-convex (typically INFEASIBLE). */
 
 typedef struct qpc_model qpc_model;
 typedef struct qpc_controller qpc_controller;
