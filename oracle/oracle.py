@@ -46,7 +46,11 @@ class TickInfo(ctypes.Structure):
 def build(native=False):
     """Compile the oracle with the committed Makefile (gcc, seconds)."""
     target = "_build/liboracle_native.so" if native else "_build/liboracle.so"
-    subprocess.run(["make", "-s", "-C", _HERE, target], check=True)
+    import fcntl
+    os.makedirs(os.path.join(_HERE, "_build"), exist_ok=True)
+    with open(os.path.join(_HERE, "_build", ".build.lock"), "w") as lk:  # one builder at a time (pytest-xdist workers)
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        subprocess.run(["make", "-s", "-C", _HERE, target], check=True)
     return os.path.join(_HERE, target)
 
 

@@ -9,7 +9,12 @@ EMU_LIB = os.path.join(HERE, "_build", "libqpc_emul.so")
 
 
 def build():
-    subprocess.run(["make", "-s", "-C", os.path.join(HERE, "emul")], check=True)
+    # one builder at a time: pytest-xdist workers would otherwise relink the library under each other's feet
+    import fcntl
+    os.makedirs(os.path.join(HERE, "_build"), exist_ok=True)
+    with open(os.path.join(HERE, "_build", ".build.lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        subprocess.run(["make", "-s", "-C", os.path.join(HERE, "emul")], check=True)
     return EMU_LIB
 
 
