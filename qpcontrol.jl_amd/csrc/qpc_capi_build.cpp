@@ -225,3 +225,9 @@ const char *qpc_status_string(int32_t s) {
 const char *qpc_version(void) { return "qpcontrol_hip 0.1.0 (gfx950)"; }
 
 } // extern "C"
+
+// diagnostic: number of K tables of the compiled program (0: Gauss-Jordan form; tests/test_k_table.py)
+extern "C" int32_t qpc_debug_k_tables(qpc_controller *c) {
+  if (!c || !c->finalized) return -1;
+  return c->prog.dims.k_tab ? c->prog.dims.k_classes : 0;
+}

@@ -489,9 +489,25 @@ int qpc_compile_program(qpc_controller *c) {
     if (B.dt.size() & 1) B.dt.push_back(0.0); // 16-byte rows
     B.dbegin(DT_KTAB);
     bool ok = D.N == 4 && D.nrho > 0 && D.nrho <= 64 && D.nc <= 16 && !getenv("QPC_NO_KTAB");
-    for (auto &k : c->contacts) if ((k.per_qp & QPC_CONTACT_SURFACE_PER_QP) || k.mu != c->contacts[0].mu || !(k.mu >= 1e-3) || !(k.mu <= 1e3)) ok = false;
+    // one table per distinct friction coefficient; with several, the per-contact table index needs the upper 8 slots of MS_KS
+    std::vector<double> mus;
+    std::vector<int> cls;
+    for (auto &k : c->contacts) {
+      if ((k.per_qp & QPC_CONTACT_SURFACE_PER_QP) || !(k.mu >= 1e-3) || !(k.mu <= 1e3)) ok = false;
+      size_t m = 0;
+      while (m < mus.size() && mus[m] != k.mu) m++;
+      if (m == mus.size()) mus.push_back(k.mu);
+      cls.push_back((int)m);
+    }
+    if (mus.size() > 1 && D.nc > 8) ok = false;
+    D.k_classes = 0;
+    for (int i = 0; i < 16; i++) D.k_class[i] = 0;
     if (ok) {
-      const double mu = c->contacts[0].mu;
+      D.k_classes = (int)mus.size();
+      for (int i = 0; i < D.nc; i++) D.k_class[i] = cls[(size_t)i];
+    }
+    for (size_t mi = 0; ok && mi < mus.size(); mi++) {
+      const double mu = mus[mi];
       double G[4][4];
       for (int i = 0; i < 4; i++)
         for (int j = 0; j < 4; j++) G[i][j] = (1.0 + mu * mu * std::cos((i - j) * 1.5707963267948966)) / (1.0 + mu * mu);

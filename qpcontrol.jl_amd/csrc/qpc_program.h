@@ -54,7 +54,7 @@ enum {
   DT_LAW, // [n_desired * 3] kp, kd, ref of the desired law of entry i
   DT_HV0,   // [nf] static Hessian diagonal of the free accelerations: 2 reg + folded soft joint tasks with static weights
   DT_WINV0, // [wsize] inverses of the static slack Hessian blocks 2 sym(W) (no eps), valid when h_static
-  DT_KTAB,  // [16 * 20] k_tab: eigenvalues [4] and eigenvectors [4][4] of B'B on each of the 16 free sets of a contact's four rays
+  DT_KTAB,  // [k_classes * 16 * 20] k_tab: eigenvalues [4] and eigenvectors [4][4] of B'B on each of the 16 free sets of a contact's four rays
   DT_COUNT
 };
 
@@ -117,7 +117,7 @@ enum {
   MS_WG = 9,       // 6
   MS_EPS = 15, MS_HSCALE = 16,
   MS_U0 = 17,      // 6: wrench-space constant u0 = c2 - Z'c1 of the active-set search
-  MS_KS = 24,      // 16: k_tab: 2 * contact weight per contact
+  MS_KS = 24,      // 16: k_tab: 2 * contact weight per contact; with k_classes > 1 (nc <= 8) slots 8.. hold the contacts' table offsets
   MS_COUNT = 40
 };
 
@@ -138,8 +138,10 @@ struct QpcDims {
   int nfs, ms, m1s;  // padded leading dimensions (odd) of L_M, L_SM, L_X
   int wsize;         // doubles in L_W / L_WINV
   int h_static;      // no per-QP task weights: the v̇ / slack blocks of the Hessian are the same for every QP (DT_HV0, DT_WINV0)
-  int k_tab;         // N = 4, one static friction coefficient for all contacts: the rho blocks of H are 2 w_c B'B with the SAME
-                     // B'B, so (H_rho,FF + eps I)^-1 of every free set follows from a static eigen-decomposition (DT_KTAB)
+  int k_tab;         // N = 4, static friction coefficients: the rho block of a contact is 2 w_c B'B with a B'B that only depends on
+                     // mu, so (H_rho,FF + eps I)^-1 of every free set follows from a static eigen-decomposition (DT_KTAB)
+  int k_classes;     // number of distinct mu (one 16 x 20 table each)
+  int k_class[16];   // table of contact c
   int it[IT_COUNT];
   int dt[DT_COUNT];
   int lds[L_COUNT];

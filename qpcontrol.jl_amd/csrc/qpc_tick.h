@@ -364,7 +364,8 @@ template <class P> struct Solver {
         int pat = 0;
         QPC_UNROLL_FULL
         for (int i = 0; i < 4; i++) pat |= (sm[D.lds[L_WS] + 4 * c + i] == 0.0) ? (1 << i) : 0;
-        const double *kt = DT + D.dt[DT_KTAB] + pat * 20;
+        const int koff = D.k_classes > 1 ? (int)(double)sm[D.lds[L_MISC] + MS_KS + 8 + c] : 0; // this contact's table (its mu)
+        const double *kt = DT + D.dt[DT_KTAB] + koff + pat * 20;
         const double w2 = sm[D.lds[L_MISC] + MS_KS + c];
         double t[4], k[4] = {0.0, 0.0, 0.0, 0.0};
         QPC_UNROLL_FULL
@@ -1114,7 +1115,10 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       bad_in = bad_in || !(cwi == cwi) || !(cmi == cmi);
       sm[D.lds[L_CW] + i] = cwi; sm[D.lds[L_CMAX] + i] = cmi;
       if (use_rho && cmi > 0.0 && 2.0 * QPC_FABS(cwi) > hc) hc = 2.0 * QPC_FABS(cwi);
-      if (D.k_tab) sm[MISC + MS_KS + i] = 2.0 * cwi; // scale of this contact's rho block of the Hessian (kr_blocks)
+      if (D.k_tab) {
+        sm[MISC + MS_KS + i] = 2.0 * cwi; // scale of this contact's rho block of the Hessian (kr_blocks)
+        if (D.k_classes > 1) sm[MISC + MS_KS + 8 + i] = (double)(D.k_class[i] * 320);
+      }
     }
     for (int i = lane; i < D.n_tw; i += 64) sm[D.lds[L_TW] + i] = io.tw[i];
     for (int i = lane; i < D.n_surf; i += 64) sm[D.lds[L_SURF] + i] = io.surf[i];

@@ -23,10 +23,13 @@ def _run(factory, B, config, no_table):
         os.environ.pop("QPC_NO_KTAB", None)
         if old is not None:
             os.environ["QPC_NO_KTAB"] = old
-    return c.control_batch(wl.q, wl.v, wl.desired, wl.contact_weight, wl.contact_maxnormalforce)
+    r = c.control_batch(wl.q, wl.v, wl.desired, wl.contact_weight, wl.contact_maxnormalforce)
+    r["k_tables"] = c.L.qpc_debug_k_tables(c.h)
+    return r
 
 
 def _same(a, b):
+    assert a["k_tables"] >= 1 and b["k_tables"] == 0
     # the same QPs are solved; HOW an infeasible one fails (INFEASIBLE / ITERATION_LIMIT on the cycle guard) may depend on rounding
     assert np.array_equal(a["status"] == 0, b["status"] == 0), (np.where((a["status"] == 0) != (b["status"] == 0))[0], a["status"][a["status"] != b["status"]], b["status"][a["status"] != b["status"]])
     assert np.mean(a["status"] != b["status"]) <= 0.01
@@ -49,6 +52,39 @@ def test_table_equals_gauss_jordan_emulated(config):
     _same(_run(emu.factory, 48, config, False), _run(emu.factory, 48, config, True))
     races, uninit, outside, first = emu.race_report()
     assert (races, uninit, outside) == (0, 0, 0), first
+
+
+def _mixed_mu(factory):
+    """controllers whose contacts alternate between two friction coefficients (one table per distinct mu)"""
+    def make(mech, N, fl):
+        c = factory(mech, N, fl)
+        real, count = c.add_contact, [0]
+
+        def add_contact(body, position, normal, mu, *a, **kw):
+            count[0] += 1
+            return real(body, position, normal, mu * (0.5 if count[0] % 2 else 1.0), *a, **kw)
+        c.add_contact = add_contact
+        return c
+    return make
+
+
+def test_two_friction_coefficients_emulated():
+    emu.build()
+    emu.race_report()
+    f = _mixed_mu(emu.factory)
+    a, b = _run(f, 48, 5, False), _run(f, 48, 5, True)
+    assert a["k_tables"] == 2
+    _same(a, b)
+    plain = _run(emu.factory, 48, 5, False)
+    assert not np.allclose(a["tau"][a["status"] == 0], plain["tau"][a["status"] == 0])  # the second mu really is in effect
+    races, uninit, outside, first = emu.race_report()
+    assert (races, uninit, outside) == (0, 0, 0), first
+
+
+@pytest.mark.gpu
+def test_two_friction_coefficients_gpu():
+    f = _mixed_mu(lambda mech, N, fl: binding.Controller(binding.Model(mech), N, fl))
+    _same(_run(f, 2048, 5, False), _run(f, 2048, 5, True))
 
 
 @pytest.mark.gpu
