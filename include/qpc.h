@@ -98,7 +98,8 @@ enum {
 };
 /* A bad record never affects the other QPs of the batch and never keeps the kernel from terminating
  * (tests/test_bad_inputs.py).  Degenerate but legal records solve: zero contact weights, a zero cap (= disable!,
- * contacts.jl:72).  A negative cap reads as disabled; a negative weight makes the QP non-convex (typically INFEASIBLE). */
+ * contacts.jl:72).  A negative cap is INFEASIBLE (0 <= rho <= rho_max < 0, contacts.jl:57); a negative weight makes the QP
+ * non-convex (typically INFEASIBLE). */
 
 typedef struct qpc_model qpc_model;
 typedef struct qpc_controller qpc_controller;

@@ -1091,7 +1091,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
   QPC_LANE_ARRAY(keep_iw_, 16);
   QPC_LANE_ARRAY(keep_sk_, 6);
   double hscale = 0.0, hinvmax = 0.0, eps = 0.0, eps_ve = 0.0;
-  unsigned long long bbad_in = 0ull;
+  unsigned long long bbad_in = 0ull, bneg_cap = 0ull;
   bool exact_ve = false, h_fast = false;
   const bool h_static_path = D.h_static && D.n_des_late == 0;
   QPC_PHASE(lane) {
@@ -1108,11 +1108,13 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
     for (int i = lane; i < nv; i += 64) sm[D.lds[L_V] + i] = io.v[i];
     for (int i = lane; i < D.n_desired; i += 64) sm[D.lds[L_DES] + i] = desired_early(D, IT, DT, io, i);
     double hc = 0.0; // this lane's share of the regularisation scale: 2 |weight| of its enabled contacts
+    bool neg_cap = false;
     bool bad_in = false; // a NaN contact weight or cap: a NaN cap would otherwise read as "disabled" (hi > 0 is false) and
                          // the QP would be solved as if the caller had meant that
     for (int i = lane; i < nc; i += 64) {
       const double cwi = io.cw[i], cmi = io.cmax[i];
       bad_in = bad_in || !(cwi == cwi) || !(cmi == cmi);
+      neg_cap = neg_cap || cmi < 0.0; // 0 <= rho <= rho_max < 0 (contacts.jl:57) has no solution
       sm[D.lds[L_CW] + i] = cwi; sm[D.lds[L_CMAX] + i] = cmi;
       if (use_rho && cmi > 0.0 && 2.0 * QPC_FABS(cwi) > hc) hc = 2.0 * QPC_FABS(cwi);
       if (D.k_tab) {
@@ -1123,9 +1125,9 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
     for (int i = lane; i < D.n_tw; i += 64) sm[D.lds[L_TW] + i] = io.tw[i];
     for (int i = lane; i < D.n_surf; i += 64) sm[D.lds[L_SURF] + i] = io.surf[i];
     if (h_static_path) { QPC_RED_MAX_PUT(0, hscale, hc); }
-    if (nc) { QPC_BALLOT_PUT(2, bbad_in, bad_in); }
+    if (nc) { QPC_BALLOT_PUT(2, bbad_in, bad_in); QPC_BALLOT_PUT(3, bneg_cap, neg_cap); }
   } QPC_END_PHASE
-  if (nc) { QPC_BALLOT_GET(2, bbad_in); }
+  if (nc) { QPC_BALLOT_GET(2, bbad_in); QPC_BALLOT_GET(3, bneg_cap); }
   // Static Hessian blocks (D.h_static: no per-QP task weights): the regularisation scale is max(static diagonal,
   // contact weights of THIS QP), known right after the input phase -- the two phases that used to derive it from the LDS
   // copies of H (a max reduction over HV / W, then rsqrt / block inverses: 4 % of the tick) are only run in the general case
@@ -2331,7 +2333,8 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
     if (io.cwrench)
       for (int idx = lane; idx < nc * 6; idx += 64) io.cwrench[idx] = sm[D.lds[L_CWR] + idx];
     if (lane == 0) {
-      io.status[0] = (bbad_in != 0ull && (status == QPC_STATUS_OPTIMAL || status == QPC_STATUS_ALMOST_OPTIMAL)) ? QPC_STATUS_NUMERICAL_ERROR : status;
+      const bool good = status == QPC_STATUS_OPTIMAL || status == QPC_STATUS_ALMOST_OPTIMAL;
+      io.status[0] = (good && bbad_in != 0ull) ? QPC_STATUS_NUMERICAL_ERROR : ((good && bneg_cap != 0ull) ? QPC_STATUS_INFEASIBLE : status);
       if (io.iters) io.iters[0] = iters + 1000 * refine;
     }
   } QPC_END_PHASE

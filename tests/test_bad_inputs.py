@@ -26,6 +26,7 @@ def _run(factory, B):
     v[6, :] = 1e200; bad[6] = "absurd velocity"
     d[7, :] = -1e300; bad[7] = "absurd desired"
     cw[8, :] = -1.0; bad[8] = "negative contact weights"
+    cm[11, 3] = -5.0; bad[11] = "negative contact cap"
     legal = {}
     cw[9, :] = 0.0; legal[9] = "zero contact weights"
     cm[10, :4] = 0.0; legal[10] = "half of the contacts disabled"
@@ -42,6 +43,7 @@ def _run(factory, B):
     rest = [b for b in range(B) if b not in bad and b not in legal]
     assert np.array_equal(r["tau"][rest], clean["tau"][rest])
     assert np.array_equal(r["status"][rest], clean["status"][rest])
+    assert r["status"][11] == 2  # 0 <= rho <= rho_max < 0: INFEASIBLE, as the reference's solver would say
     nan_rows = [b for b, what in bad.items() if "nan" in what or "inf" in what]
     assert all(r["status"][b] not in (0, 1) for b in nan_rows), r["status"][nan_rows]
     return r
@@ -55,4 +57,4 @@ def test_bad_inputs_emulated():
 @pytest.mark.gpu
 def test_bad_inputs_gpu():
     r = _run(lambda mech, N, fl: binding.Controller(binding.Model(mech), N, fl), 4096)
-    print("statuses of the poisoned records:", r["status"][:11])
+    print("statuses of the poisoned records:", r["status"][:12])
