@@ -388,12 +388,6 @@ class QpcHipBackend : public QpcChunkBackend {
     if (job.status_pinned) all_out_pageable = false; else any_out_pageable = true;
     if (job.iters) { if (job.iters_pinned) all_out_pageable = false; else any_out_pageable = true; }
     if (job.working_set) { if (job.ws_pinned) { all_out_pageable = false; all_in_pageable = false; } else { any_out_pageable = true; any_in_pageable = true; } }
-    if (off > sl.d_stage_bytes) {
-      if (sl.d_stage) HIP_TRY(hipFree(sl.d_stage));
-      sl.d_stage = nullptr; sl.d_stage_bytes = 0;
-      HIP_TRY(hipMalloc(&sl.d_stage, off));
-      sl.d_stage_bytes = off;
-    }
     if ((any_in_pageable || any_out_pageable) && off > sl.h_stage_bytes) {
       if (sl.h_stage) HIP_TRY(hipHostFree(sl.h_stage));
       sl.h_stage = nullptr; sl.h_stage_bytes = 0;
@@ -402,6 +396,12 @@ class QpcHipBackend : public QpcChunkBackend {
     }
     hipStream_t st = sl.stream;
     if (c_->rt->stage_zero_copy && all_in_pageable && all_out_pageable) return run_on_staging(S, sl, job, lo, n, in_off, out_off, st_off, it_off, ws_off);
+    if (off > sl.d_stage_bytes) { // (the device slab is only needed by the DMA form below)
+      if (sl.d_stage) HIP_TRY(hipFree(sl.d_stage));
+      sl.d_stage = nullptr; sl.d_stage_bytes = 0;
+      HIP_TRY(hipMalloc(&sl.d_stage, off));
+      sl.d_stage_bytes = off;
+    }
     // ---- inputs
     for (int i = 0; i < QpcHostJob::N_IN; i++) {
       const size_t bytes = job.in[i] ? job.in_dim[i] * (size_t)n * sizeof(double) : 0;
