@@ -29,6 +29,12 @@ static std::string dbl(double x) {
   return s;
 }
 
+int qpc_jit_sim_rpw(const QpcDims &D) {
+  if (const char *e = getenv("QPC_SIM_RPW")) { if (e[0] == '1') return 1; }
+  const int slab = qpc_sim_layout(D).total + (qpc_sim_layout(D).total & 1);
+  return (D.nb <= 32 && D.nc <= 32 && (size_t)2 * slab * sizeof(double) <= 64 * 1024) ? 2 : 1;
+}
+
 std::string qpc_jit_source(const QpcDims &D, bool warm) {
   std::ostringstream o;
   o << "typedef int int32_t;\ntypedef unsigned int uint32_t;\ntypedef long long int64_t;\ntypedef unsigned long long uint64_t;\n";
@@ -105,21 +111,26 @@ std::string qpc_jit_source(const QpcDims &D, bool warm) {
          "}\n";
   }
   // f-2: the simulation step specialised on the same dims (qpc_sim.h)
+  const int rpw = qpc_jit_sim_rpw(D);
+  const int slab = qpc_sim_layout(D).total + (qpc_sim_layout(D).total & 1);
   o << "struct QpcSimArgs { long long B; double *q, *v; const double *tau; const int32_t *status; int32_t *bad; qpc_sim_params sp; };\n";
-  o << "extern \"C\" __global__ void __launch_bounds__(64, 2) qpc_sim_kernel_jit(const int *__restrict__ IT, "
+  o << "extern \"C\" __global__ void __launch_bounds__(64, " << (rpw == 2 ? 1 : 2) << ") qpc_sim_kernel_jit(const int *__restrict__ IT, "
        "const double *__restrict__ DT, const QpcSimArgs A) {\n"
-       "  __shared__ __attribute__((aligned(16))) double qpc_lds[" << qpc_sim_layout(D).total << "];\n"
-       "  for (long long b = blockIdx.x; b < A.B; b += gridDim.x) {\n"
-       "    qpc::SimIO io;\n"
-       "    io.q = A.q + b * kD.nq; io.v = A.v + b * kD.nv; io.tau = A.tau + b * kD.nv;\n"
-       "    io.status = A.status ? A.status + b : nullptr;\n"
-       "    io.q_out = A.q + b * kD.nq; io.v_out = A.v + b * kD.nv;\n"
-       "    io.bad = A.bad ? A.bad + b : nullptr;\n"
+       "  __shared__ __attribute__((aligned(16))) double qpc_lds[" << rpw * slab << "];\n"
+       "  for (long long b0 = (long long)blockIdx.x * " << rpw << "; b0 < A.B; b0 += (long long)gridDim.x * " << rpw << ") {\n"
+       "    qpc::SimIO io[" << rpw << "];\n"
+       "    for (int r = 0; r < " << rpw << "; r++) {\n"
+       "      const long long b = b0 + r < A.B ? b0 + r : A.B - 1; // an odd batch: the last robot is stepped by both halves (same result twice)\n"
+       "      io[r].q = A.q + b * kD.nq; io[r].v = A.v + b * kD.nv; io[r].tau = A.tau + b * kD.nv;\n"
+       "      io[r].status = A.status ? A.status + b : nullptr;\n"
+       "      io[r].q_out = A.q + b * kD.nq; io[r].v_out = A.v + b * kD.nv;\n"
+       "      io[r].bad = (A.bad && b0 + r < A.B) ? A.bad + b : nullptr;\n"
+       "    }\n"
        "    const __attribute__((address_space(1))) int *ITg = (const __attribute__((address_space(1))) int *)IT;\n"
        "    const __attribute__((address_space(1))) double *DTg = (const __attribute__((address_space(1))) double *)DT;\n"
        "    asm volatile(\"\" : \"+s\"(ITg), \"+s\"(DTg));\n"
        "    const int *ITq = (const int *)ITg; const double *DTq = (const double *)DTg;\n"
-       "    qpc::qpc_sim_step<double *>(kD, ITq, DTq, qpc_lds, io, A.sp);\n"
+       "    qpc::qpc_sim_step<double *, " << rpw << ">(kD, ITq, DTq, qpc_lds, io, A.sp, " << slab << ");\n"
        "    __syncthreads();\n"
        "  }\n"
        "}\n";

@@ -126,7 +126,7 @@ qpc_sim_kernel(const QpcDims D, const int *__restrict__ IT, const double *__rest
     io.status = A.status ? A.status + b : nullptr;
     io.q_out = A.q + b * D.nq; io.v_out = A.v + b * D.nv;
     io.bad = A.bad ? A.bad + b : nullptr;
-    qpc::qpc_sim_step<double *>(D, IT, DT, qpc_lds, io, A.sp);
+    qpc::qpc_sim_step<double *>(D, IT, DT, qpc_lds, &io, A.sp);
     __syncthreads();
   }
 }
@@ -249,6 +249,14 @@ static int launch(qpc_controller *c, QpcDeviceState *S, QpcSlot &sl, const QpcBa
 static int launch_sim(qpc_controller *c, QpcDeviceState *S, const QpcSimArgs &a, hipStream_t stream) {
   const QpcDims &D = c->prog.dims;
   long long grid = (long long)S->n_cu * S->sim_blocks_per_cu;
+  if (S->jit_sim_func) { // the specialised step may run two robots per wavefront (qpc_jit_sim_rpw)
+    const int rpw = qpc_jit_sim_rpw(D);
+    const size_t slab = ((size_t)qpc_sim_layout(D).total + 1) / 2 * 2 * sizeof(double) * rpw;
+    long long per_cu = (long long)((160 * 1024) / (slab > 0 ? slab : 1));
+    per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
+    grid = (long long)S->n_cu * per_cu;
+    if (grid > (a.B + rpw - 1) / rpw) grid = (a.B + rpw - 1) / rpw;
+  }
   if (grid > a.B) grid = a.B;
   if (grid < 1) return QPC_OK;
   if (S->jit_sim_func) {

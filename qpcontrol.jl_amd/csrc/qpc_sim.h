@@ -39,36 +39,47 @@ struct SimIO {
 // packed lower triangle of a symmetric 6x6: entry (r, c), r >= c
 #define QPC_SYM6(r, c) ((r) * ((r) + 1) / 2 + (c))
 
-template <class P>
-QPC_FN void qpc_sim_step(const QpcDims &D, const int *IT, const double *DT, P sm, const SimIO &io, const qpc_sim_params &sp) {
+// RPW = robots per wavefront.  1: lane = body (or velocity index, contact, ...) of ONE robot.  2 (mechanisms of at most 32
+// bodies): lanes 0-31 work robot ios[0] on the LDS slab at sm0, lanes 32-63 robot ios[1] on the slab at sm0 + slab -- the
+// step is bound by instruction issue (every level of the articulated-body passes runs the whole phase for two or three
+// active lanes), and one instruction stream then advances two robots.  Inside a phase `lane` is the lane WITHIN the robot.
+#define QPC_SIM_LOCAL \
+  const int sub_ = (RPW == 2) ? (lane_ >> 5) : 0; \
+  const int lane = (RPW == 2) ? (lane_ & 31) : lane_; \
+  P sm = sm0 + sub_ * slab; \
+  const SimIO io = (RPW == 2 && sub_) ? ios[RPW - 1] : ios[0]; /* selects on constant indices: no private-memory array */ \
+  (void)sub_; (void)lane; (void)sm; (void)io;
+template <class P, int RPW = 1>
+QPC_FN void qpc_sim_step(const QpcDims &D, const int *IT, const double *DT, P sm0, const SimIO *ios, const qpc_sim_params &sp, int slab = 0) {
   QPC_LANE_SCOPE
+  constexpr int LW = 64 / RPW; // lanes per robot
   const int nb = D.nb, nq = D.nq, nv = D.nv, nc = D.nc;
   const SimLayout L = sim_layout(D);
-  // a failed QP (checkstatus, momentum.jl:83-91) applies no torque for this step and is counted
-  const bool failed = io.status && io.status[0] > QPC_STATUS_ALMOST_OPTIMAL;
   const int maxh = IT[D.it[IT_SIM_TREE] + 4 * nb], maxdp = IT[D.it[IT_SIM_TREE] + 4 * nb + 1];
 
   // per-lane static metadata in registers, as in the tick (TickMeta): joint type / offsets / ancestor chain of
   // body `lane`; plus its children mask, height above the leaves and depth below the roots
   TickMeta M;
   QPC_LANE_INTS(tr_, 4);
-  QPC_PHASE(lane) {
-    int *mt = QPC_LI(M.v, lane);
+  QPC_PHASE(lane_) { QPC_SIM_LOCAL
+    int *mt = QPC_LI(M.v, lane_);
     {
       const int aw = (D.maxd + 3) / 4, rowlen = 6 + aw;
       QPC_UNROLL_JIT
       for (int e = 0; e < QPC_META_WORDS; e++) mt[e] = e < rowlen ? IT[D.it[IT_META] + e * 64 + lane] : 0;
     }
-    int *tr = QPC_LI(tr_, lane);
+    int *tr = QPC_LI(tr_, lane_);
     for (int e = 0; e < 4; e++) tr[e] = lane < nb ? IT[D.it[IT_SIM_TREE] + 4 * lane + e] : (e < 2 ? 0 : -1);
-    for (int i = lane; i < nq; i += 64) sm[L.q + i] = io.q[i];
-    for (int i = lane; i < nv; i += 64) { sm[L.v + i] = io.v[i]; sm[L.tau + i] = failed ? 0.0 : io.tau[i]; }
+    // a failed QP (checkstatus, momentum.jl:83-91) applies no torque for this step and is counted
+    const bool failed = io.status && io.status[0] > QPC_STATUS_ALMOST_OPTIMAL;
+    for (int i = lane; i < nq; i += LW) sm[L.q + i] = io.q[i];
+    for (int i = lane; i < nv; i += LW) { sm[L.v + i] = io.v[i]; sm[L.tau + i] = failed ? 0.0 : io.tau[i]; }
   } QPC_END_PHASE
 
-  QPC_PHASE(lane) { // joint transforms  x_parent = Rf (Rj x + pj) + pf
+  QPC_PHASE(lane_) { QPC_SIM_LOCAL // joint transforms  x_parent = Rf (Rj x + pj) + pf
     if (lane < nb) {
       const int i = lane;
-      const int *mt = QPC_LI(M.v, lane);
+      const int *mt = QPC_LI(M.v, lane_);
       const int jt = MT_JT(mt), q0 = MT_Q0(mt);
       double ax[3], Rf[9], pf[3]; // per-body constants, stored [component][body]
       for (int k = 0; k < 3; k++) { ax[k] = DT[D.dt[DT_AXIS] + k * nb + i]; pf[k] = DT[D.dt[DT_PF] + k * nb + i]; }
@@ -100,10 +111,10 @@ QPC_FN void qpc_sim_step(const QpcDims &D, const int *IT, const double *DT, P sm
   } QPC_END_PHASE
 
   QPC_LANE_ARRAY(hreg_, 12); // world transform of body `lane` (the floating-joint lanes need it after LDS has moved on)
-  QPC_PHASE(lane) { // transform_to_root along the (register-resident) ancestor chain, nearest first
+  QPC_PHASE(lane_) { QPC_SIM_LOCAL // transform_to_root along the (register-resident) ancestor chain, nearest first
     if (lane < nb) {
-      const int *mt = QPC_LI(M.v, lane);
-      double *H = QPC_LA(hreg_, lane);
+      const int *mt = QPC_LI(M.v, lane_);
+      double *H = QPC_LA(hreg_, lane_);
       double A[12], t[3];
       ld(sm + L.rl + 12 * lane, 12, H);
       QPC_UNROLL_JIT
@@ -120,12 +131,12 @@ QPC_FN void qpc_sim_step(const QpcDims &D, const int *IT, const double *DT, P sm
     }
   } QPC_END_PHASE
 
-  QPC_PHASE(lane) { // motion subspace columns (world), joint twist, world inertia
+  QPC_PHASE(lane_) { QPC_SIM_LOCAL // motion subspace columns (world), joint twist, world inertia
     if (lane < nb) {
       const int i = lane;
-      const int *mt = QPC_LI(M.v, lane);
+      const int *mt = QPC_LI(M.v, lane_);
       const int jt = MT_JT(mt), v0 = MT_V0(mt), n = MT_NVJ(mt);
-      const double *H = QPC_LA(hreg_, lane);
+      const double *H = QPC_LA(hreg_, lane_);
       double tj[6] = {0, 0, 0, 0, 0, 0};
       const double ax[3] = {DT[D.dt[DT_AXIS] + i], DT[D.dt[DT_AXIS] + nb + i], DT[D.dt[DT_AXIS] + 2 * nb + i]};
       for (int c = 0; c < n; c++) {
@@ -161,10 +172,10 @@ QPC_FN void qpc_sim_step(const QpcDims &D, const int *IT, const double *DT, P sm
     }
   } QPC_END_PHASE
 
-  QPC_PHASE(lane) { // twist_wrt_world, velocity-product acceleration c_i = T_i x (S_i v_i)
+  QPC_PHASE(lane_) { QPC_SIM_LOCAL // twist_wrt_world, velocity-product acceleration c_i = T_i x (S_i v_i)
     if (lane < nb) {
       const int i = lane;
-      const int *mt = QPC_LI(M.v, lane);
+      const int *mt = QPC_LI(M.v, lane_);
       double T[6], tj[6], cr[6];
       ld(sm + L.tj + 6 * i, 6, tj);
       for (int a = 0; a < 6; a++) T[a] = tj[a];
@@ -180,8 +191,8 @@ QPC_FN void qpc_sim_step(const QpcDims &D, const int *IT, const double *DT, P sm
     }
   } QPC_END_PHASE
 
-  QPC_PHASE(lane) { // ground reaction per contact point
-    for (int c = lane; c < nc; c += 64) {
+  QPC_PHASE(lane_) { QPC_SIM_LOCAL // ground reaction per contact point
+    for (int c = lane; c < nc; c += LW) {
       // compliant half space z <= ground_z: normal spring/damper (unilateral), viscous tangential
       // friction capped at mu * normal force; wrench about the world origin
       const int body = IT[D.it[IT_C_BODY] + c];
@@ -217,8 +228,8 @@ QPC_FN void qpc_sim_step(const QpcDims &D, const int *IT, const double *DT, P sm
   //   floating joint (S invertible): the subtree decouples, Ia = 0, pa = S^-T tau (the joint "torque" as a world wrench)
   // The lane keeps U, 1/d, u (or IA, pA - S^-T tau for a floating joint) in registers for the second pass.
   QPC_LANE_ARRAY(ab_, 29); // [0..5] U, [6] 1/d, [7] u   |  floating: [0..20] IA packed, [21..26] S^-T tau - pA ; [28] failure
-  QPC_PHASE(lane) { // bias forces pA0_i = T_i x* I_i T_i - f_ext,i for all bodies at once (parked in the acceleration slots)
-    QPC_LA(ab_, lane)[28] = 0.0;
+  QPC_PHASE(lane_) { QPC_SIM_LOCAL // bias forces pA0_i = T_i x* I_i T_i - f_ext,i for all bodies at once (parked in the acceleration slots)
+    QPC_LA(ab_, lane_)[28] = 0.0;
     if (lane < nb) {
       const int i = lane;
       double T[6], I[10], h[6], pA[6];
@@ -234,13 +245,13 @@ QPC_FN void qpc_sim_step(const QpcDims &D, const int *IT, const double *DT, P sm
     }
   } QPC_END_PHASE
   for (int lvl = 0; lvl <= maxh; lvl++) {
-    QPC_PHASE(lane) {
-      const int *tr = QPC_LI(tr_, lane);
+    QPC_PHASE(lane_) { QPC_SIM_LOCAL
+      const int *tr = QPC_LI(tr_, lane_);
       if (lane < nb && tr[2] == lvl) {
         const int i = lane;
-        const int *mt = QPC_LI(M.v, lane);
+        const int *mt = QPC_LI(M.v, lane_);
         const int jt = MT_JT(mt), v0 = MT_V0(mt);
-        double *ab = QPC_LA(ab_, lane);
+        double *ab = QPC_LA(ab_, lane_);
         double IA[21], pA[6], I[10], c[6];
         ld(sm + L.iw + 10 * i, 10, I);
         ld(sm + L.acc + 6 * i, 6, pA);
@@ -265,7 +276,7 @@ QPC_FN void qpc_sim_step(const QpcDims &D, const int *IT, const double *DT, P sm
         double Ia[21], pa[6];
         if (jt == QPC_JOINT_QUAT_FLOATING) {
           // tau (body-frame wrench [n; f] dual to v = [omega_body; v_body]) as a world wrench: S^-T tau
-          const double *H = QPC_LA(hreg_, lane);
+          const double *H = QPC_LA(hreg_, lane_);
           double tb[6], fw[3], nw[3], pxf[3];
           for (int a = 0; a < 6; a++) tb[a] = sm[L.tau + v0 + a];
           mv3(H, tb, nw); mv3(H, tb + 3, fw);
@@ -313,13 +324,13 @@ QPC_FN void qpc_sim_step(const QpcDims &D, const int *IT, const double *DT, P sm
   // ---- acceleration pass, roots -> leaves, one phase per depth: a' = a_parent + c_i (a_world = -g),
   //   1-DoF: qdd = (u - U.a')/d, a = a' + S qdd;  fixed: a = a';  floating: a = IA^-1 (S^-T tau - pA), qdd = S^-1 (a - a')
   for (int lvl = 0; lvl <= maxdp; lvl++) {
-    QPC_PHASE(lane) {
-      const int *tr = QPC_LI(tr_, lane);
+    QPC_PHASE(lane_) { QPC_SIM_LOCAL
+      const int *tr = QPC_LI(tr_, lane_);
       if (lane < nb && tr[3] == lvl) {
         const int i = lane;
-        const int *mt = QPC_LI(M.v, lane);
+        const int *mt = QPC_LI(M.v, lane_);
         const int jt = MT_JT(mt), v0 = MT_V0(mt), par = MT_ANC(mt, 0);
-        const double *ab = QPC_LA(ab_, lane);
+        const double *ab = QPC_LA(ab_, lane_);
         double ap[6], a[6];
         ld(sm + L.cr + 6 * i, 6, ap);
         if (par >= 0) { for (int k = 0; k < 6; k++) ap[k] += sm[L.acc + 6 * par + k]; }
@@ -331,7 +342,7 @@ QPC_FN void qpc_sim_step(const QpcDims &D, const int *IT, const double *DT, P sm
           for (int r = 0; r < 6; r++) { sref[r] = S6[7 * r]; rhs[r] = ab[21 + r]; }
           chol6_solve(S6, sref, 1e-14, rhs, a);
           for (int k = 0; k < 6; k++) d[k] = a[k] - ap[k];
-          motion_to_frame(QPC_LA(hreg_, lane), d, qdd);
+          motion_to_frame(QPC_LA(hreg_, lane_), d, qdd);
           for (int k = 0; k < 6; k++) sm[L.x + v0 + k] = qdd[k];
         } else if (jt == QPC_JOINT_FIXED) {
           for (int k = 0; k < 6; k++) a[k] = ap[k];
@@ -348,24 +359,31 @@ QPC_FN void qpc_sim_step(const QpcDims &D, const int *IT, const double *DT, P sm
     } QPC_END_PHASE
   }
 
-  double rej = 0.0;
-  QPC_PHASE(lane) {
-    QPC_RED_MAX_PUT(0, rej, QPC_LA(ab_, lane)[28]);
-  } QPC_END_PHASE
-  rej = QPC_RED_MAX_GET(0, rej);
-  const bool reject = rej > 0.0;
-  QPC_PHASE(lane) { // semi-implicit Euler: the new velocity moves the configuration
-    for (int k = lane; k < nv; k += 64) {
+  unsigned long long brej = 0ull; // lanes whose articulated inertia was not positive: their robot's step is rejected
+  { // (a wave-wide ballot over the PHYSICAL lanes: the emulator's form of the macros addresses its scratch through `sm` and `lane`)
+    P sm = sm0;
+    (void)sm;
+    QPC_PHASE(lane) {
+      QPC_BALLOT_PUT(0, brej, QPC_LA(ab_, lane)[28] != 0.0);
+    } QPC_END_PHASE
+    QPC_BALLOT_GET(0, brej);
+  }
+#define QPC_SIM_REJECT const bool reject = (RPW == 2) ? ((brej >> (32 * sub_)) & 0xffffffffull) != 0ull : brej != 0ull;
+  QPC_PHASE(lane_) { QPC_SIM_LOCAL // semi-implicit Euler: the new velocity moves the configuration
+    QPC_SIM_REJECT
+    const bool failed = io.status && io.status[0] > QPC_STATUS_ALMOST_OPTIMAL;
+    for (int k = lane; k < nv; k += LW) {
       const double vn = reject ? (double)sm[L.v + k] : sm[L.v + k] + sp.dt * sm[L.x + k];
       sm[L.tau + k] = vn; // tau is dead: reuse as the new velocity
       io.v_out[k] = vn;
     }
     if (lane == 0 && io.bad && (failed || reject)) io.bad[0] = io.bad[0] + 1;
   } QPC_END_PHASE
-  QPC_PHASE(lane) { // configuration update on the manifold (revolute / prismatic: q += v dt; floating joint:
+  QPC_PHASE(lane_) { QPC_SIM_LOCAL // configuration update on the manifold (revolute / prismatic: q += v dt; floating joint:
                     // quat <- quat * exp(w_body dt / 2) renormalised, pos += R(quat) v_body dt)
+    QPC_SIM_REJECT
     if (lane < nb) {
-      const int *mt = QPC_LI(M.v, lane);
+      const int *mt = QPC_LI(M.v, lane_);
       const int jt = MT_JT(mt), q0 = MT_Q0(mt), v0 = MT_V0(mt);
       const double dt = reject ? 0.0 : sp.dt;
       if (jt == QPC_JOINT_REVOLUTE || jt == QPC_JOINT_PRISMATIC) {

@@ -47,6 +47,7 @@ struct EmuState {
   }
 };
 static thread_local EmuState *g_emu = nullptr;
+static inline void emu_enter_lane(int l) { g_emu->lane = l; }
 
 struct Ref {
   int i;
@@ -63,7 +64,7 @@ struct Lds {
 #define QPC_PROF_T0()
 #define QPC_PROF_ACC(i) (g_emu->section = (i)) // the last section marker passed: locates a report in the source
 #define QPC_FN inline
-#define QPC_PHASE(lane) for (int lane = 0; lane < 64; ++lane) { g_emu->lane = lane;
+#define QPC_PHASE(lane) for (int lane = 0; lane < 64; ++lane) { emu_enter_lane(lane);
 #define QPC_END_PHASE } g_emu->lane = -1; g_emu->phase++;
 #define QPC_LANE_SCOPE
 #define QPC_SINCOS(x, s, c) do { double x__ = (x); s = std::sin(x__); c = std::cos(x__); } while (0)
@@ -338,12 +339,20 @@ int32_t qpc_sim_step_batch(qpc_controller *c, int64_t B, double *q, double *v, c
   const QpcDims &D = c->prog.dims;
   EmuState emu;
   g_emu = &emu;
-  for (int64_t b = 0; b < B; b++) {
-    emu.reset((qpc_sim_layout(D).total > D.lds_doubles ? qpc_sim_layout(D).total : D.lds_doubles) + 128 * 8); // + reduction scratch
-    qpc::SimIO io;
-    io.q = q + b * D.nq; io.v = v + b * D.nv; io.tau = tau + b * D.nv; io.status = status ? status + b : nullptr;
-    io.q_out = q + b * D.nq; io.v_out = v + b * D.nv; io.bad = bad ? bad + b : nullptr;
-    qpc::qpc_sim_step<Lds>(D, c->prog.itab.data(), c->prog.dtab.data(), Lds{0}, io, *params);
+  // like the device (qpc_jit.cpp qpc_jit_sim_rpw): two robots per wavefront when a robot fits half a wave
+  const char *e1 = getenv("QPC_SIM_RPW");
+  const int rpw = (D.nb <= 32 && D.nc <= 32 && !(e1 && e1[0] == '1')) ? 2 : 1;
+  const int slab = (qpc_sim_layout(D).total > D.lds_doubles ? qpc_sim_layout(D).total : D.lds_doubles) + 128 * 8; // + reduction scratch
+  for (int64_t b0 = 0; b0 < B; b0 += rpw) {
+    emu.reset(slab * rpw);
+    qpc::SimIO io[2];
+    for (int r = 0; r < rpw; r++) {
+      const int64_t b = b0 + r < B ? b0 + r : B - 1;
+      io[r].q = q + b * D.nq; io[r].v = v + b * D.nv; io[r].tau = tau + b * D.nv; io[r].status = status ? status + b : nullptr;
+      io[r].q_out = q + b * D.nq; io[r].v_out = v + b * D.nv; io[r].bad = (bad && b0 + r < B) ? bad + b : nullptr;
+    }
+    if (rpw == 2) qpc::qpc_sim_step<Lds, 2>(D, c->prog.itab.data(), c->prog.dtab.data(), Lds{0}, io, *params, slab);
+    else qpc::qpc_sim_step<Lds, 1>(D, c->prog.itab.data(), c->prog.dtab.data(), Lds{0}, io, *params, 0);
     g_races += emu.races; g_uninit += emu.uninit; g_outside += emu.outside;
     if (g_first.empty()) g_first = emu.first;
   }

@@ -94,6 +94,33 @@ def test_sim_step_atlas_emulated():
     assert (races, uninit, outside) == (0, 0, 0), first
 
 
+def _packed_vs_single(factory, B, monkeypatch):
+    """two robots per wavefront (lanes 0-31 / 32-63, mechanisms of at most 32 bodies) against one per wavefront
+    (QPC_SIM_RPW=1): the same arithmetic in the same order per robot, so bitwise equal -- also for an odd batch, whose
+    last robot is stepped by both halves"""
+    monkeypatch.delenv("QPC_SIM_RPW", raising=False)
+    mech, c, q, v, tau, ground, cps = atlas_case(factory, B)
+    a = c.sim_step(q, v, tau, params(ground, 1e-3))
+    monkeypatch.setenv("QPC_SIM_RPW", "1")
+    mech, c1, q, v, tau, ground, cps = atlas_case(factory, B)
+    b = c1.sim_step(q, v, tau, params(ground, 1e-3))
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+def test_sim_two_robots_per_wave_emulated(monkeypatch):
+    emu.build()
+    emu.race_report()
+    _packed_vs_single(emu.factory, 7, monkeypatch)
+    races, uninit, outside, first = emu.race_report()
+    assert (races, uninit, outside) == (0, 0, 0), first
+
+
+@pytest.mark.gpu
+def test_sim_two_robots_per_wave_gpu(monkeypatch):
+    _packed_vs_single(gpu_factory, 1025, monkeypatch)
+
+
 @pytest.mark.parametrize("floating", [False, True])
 def test_sim_step_random_trees_emulated(floating):
     emu.build()
