@@ -30,7 +30,7 @@ def main():
     os.environ["QPC_REQUIRE_JIT"] = "1"
     lib = binding.DEFAULT_LIB
     cfg = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 3
-    B = 8192
+    B = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 8192  # 1024: one wave per SIMD (a QP alone)
 
     def factory(mech, N, fl):
         return binding.Controller(binding.Model(mech, lib), N, fl)
