@@ -14,6 +14,7 @@ Prints ONE JSON line on rank 0.  Beside the headline (device-resident, timed reg
   config.secondary   the literal BASELINE batches on the same GPU, measured after the timed region:
                      config 2 @ 1024, config 3 @ 8192, config 5 @ 32768, config 3 @ 262144
   config.host_pointer_path_*   the host-pointer entry point the Julia shim binds (PCIe inclusive; never `value`)
+  config.closed_loop controller tick + simulation step on the device, robot-steps/s
   roofline           HBM (algorithmic bytes) + fp64 (algorithmic flops) fractions of the tick kernel, live HIP events
   cpu_baseline       the oracle (CPU restatement of the reference path) on the host cores: cold start, the
                      reference's operating regime (same model every tick: warm start), notebook tolerances
@@ -23,6 +24,7 @@ import ctypes
 import glob
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -238,6 +240,19 @@ def secondary_points(torch, binding, W, device_index):
     return out
 
 
+def closed_loop_point():
+    """SURVEY.md 8 f-2, outside the headline's timed region: tools/bench_rollout.py (32 768 robots x 50 controller ticks with
+    fused PD laws + simulation steps on the device) in a child process; robot-steps/s or None"""
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_rollout.py")], capture_output=True, text=True, timeout=240)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        d = json.loads(line)
+        return {"robot_steps_per_s": d["value"], "robots": d["robots"], "steps": d["steps"], "ms_per_step": d["ms_per_step"],
+                "failed_qps": d["failed_qps"]}
+    except Exception as e:  # noqa: BLE001 -- a diagnostic extra must never take the bench line down
+        return {"error": repr(e)}
+
+
 def host_pointer_path(binding, run, reps=5):
     """PCIe-inclusive rate of the host-pointer entry qpc_control_batch on the headline workload (never `value`):
     with the caller's arrays page-locked (qpc_host_alloc / qpc_host_register, what the Julia shim does with the buffers
@@ -372,11 +387,12 @@ def main():
             fp64_measured = ctypes.c_double(0.0)
     n_opt = int((st == 0).sum())
 
-    host_rates, secondary = None, None
+    host_rates, secondary, closed_loop = None, None, None
     if rank == 0 and world == 1 and not args.no_secondary:
         if not args.fused_laws:
             host_rates = host_pointer_path(binding, run)
         secondary = secondary_points(torch, binding, W, local_rank)
+        closed_loop = closed_loop_point()
 
     if rank == 0:
         total = B * world * args.steps
@@ -412,6 +428,7 @@ def main():
                                                  "arrays are read / written in place by the kernel (what QPControlHIP.jl does with the "
                                                  "buffers it owns); pageable arrays are staged chunk by chunk by worker threads",
                        "secondary": secondary,
+                       "closed_loop": closed_loop,
                        "kernel_fingerprint": fingerprint},
             "roofline": {"bound": "hbm", "achieved": ach_bytes / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": ach_bytes / HBM_PEAK,
