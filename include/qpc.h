@@ -240,8 +240,10 @@ int32_t qpc_get_layout(const qpc_controller *ctrl, qpc_layout *out_layout);
 
 /* Host-pointer pipeline (before or after qpc_finalize*; not while a job is in flight): every device's
  * shard of a batch is cut into chunks of `chunk_qps` QPs (<= 0: keep; default 4096) that flow through
- * `slots_per_device` pipeline slots per device (<= 0: keep; default 6; only before qpc_finalize*), one
- * worker thread each -- staging one chunk, the kernel of another and un-staging a third overlap.  Batches of at
+ * `slots_per_device` pipeline slots per device (<= 0: keep; default 6, at most 8; only before qpc_finalize*), one
+ * worker thread each -- staging one chunk, the kernel of another and un-staging a third overlap.  (Measured on MI355X with
+ * pageable arrays: 6 slots 16.7-17.0 M solves/s, 8: 13-16 M, 10: 4.5-5.6 M -- every slot's launch is a persistent grid that
+ * fills the device, and beyond 8 they starve each other.)  Batches of at
  * most `inline_qps` QPs (< 0: keep; default 2048) are run on the caller's thread without a hand-off. */
 int32_t qpc_set_host_pipeline(qpc_controller *ctrl, int64_t chunk_qps, int32_t slots_per_device,
                               int64_t inline_qps);

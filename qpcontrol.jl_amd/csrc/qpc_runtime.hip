@@ -647,7 +647,7 @@ int32_t qpc_finalize_devices(qpc_controller *c, int32_t n_devices, const int32_t
   }
   QpcRuntime *rt = new QpcRuntime();
   rt->slots = c->pipe_slots > 0 ? c->pipe_slots : 6; // measured 4: 13.0, 6: 15.6, 8: 15.6, 12: 14.8 M solves/s (pageable, 32768 QPs)
-  if (const char *es = getenv("QPC_HOST_SLOTS")) { const int v = atoi(es); if (v >= 1 && v <= 16) rt->slots = v; }
+  if (const char *es = getenv("QPC_HOST_SLOTS")) { const int v = atoi(es); if (v >= 1 && v <= 8) rt->slots = v; }
   auto fail = [&](int code_) { for (auto *S : rt->devs) destroy_device_state(S); delete rt; return code_; };
   for (int i = 0; i < n_devices; i++) {
     hipDeviceProp_t prop;
@@ -691,7 +691,7 @@ int32_t qpc_set_host_pipeline(qpc_controller *c, int64_t chunk_qps, int32_t slot
   if (!c) return QPC_ERR_INVALID_ARGUMENT;
   if (slots_per_device > 0) {
     if (c->finalized) { qpc_set_error("qpc_set_host_pipeline: the number of slots is fixed by qpc_finalize"); return QPC_ERR_ALREADY_FINALIZED; }
-    if (slots_per_device > 16) { qpc_set_error("qpc_set_host_pipeline: at most 16 slots per device"); return QPC_ERR_INVALID_ARGUMENT; }
+    if (slots_per_device > 8) { qpc_set_error("qpc_set_host_pipeline: at most 8 slots per device (more persistent grids in flight starve each other)"); return QPC_ERR_INVALID_ARGUMENT; }
     c->pipe_slots = slots_per_device;
   }
   if (chunk_qps > 0) c->pipe_chunk = chunk_qps;
