@@ -114,7 +114,7 @@ std::string qpc_jit_source(const QpcDims &D, bool warm) {
   const int rpw = qpc_jit_sim_rpw(D);
   const int slab = qpc_sim_layout(D).total + (qpc_sim_layout(D).total & 1);
   o << "struct QpcSimArgs { long long B; double *q, *v; const double *tau; const int32_t *status; int32_t *bad; qpc_sim_params sp; };\n";
-  o << "extern \"C\" __global__ void __launch_bounds__(64, " << (rpw == 2 ? 1 : 2) << ") qpc_sim_kernel_jit(const int *__restrict__ IT, "
+  o << "extern \"C\" __global__ void __launch_bounds__(64, 2) qpc_sim_kernel_jit(const int *__restrict__ IT, "
        "const double *__restrict__ DT, const QpcSimArgs A) {\n"
        "  __shared__ __attribute__((aligned(16))) double qpc_lds[" << rpw * slab << "];\n"
        "  for (long long b0 = (long long)blockIdx.x * " << rpw << "; b0 < A.B; b0 += (long long)gridDim.x * " << rpw << ") {\n"

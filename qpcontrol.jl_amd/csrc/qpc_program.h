@@ -169,15 +169,15 @@ QPC_HOST_DEVICE inline QpcSimLayout qpc_sim_layout(const QpcDims &D) {
   QPC_SIM_TAKE(q, D.nq); QPC_SIM_TAKE(v, D.nv); QPC_SIM_TAKE(tau, D.nv);
   QPC_SIM_TAKE(rl, 12 * D.nb); // local and world transforms are dead once the ground reactions exist (the floating-joint
   QPC_SIM_TAKE(h, 12 * D.nb);  // lanes keep their own transform in registers): the articulated inertias overlay both
-  QPC_SIM_TAKE(s, 6 * D.nv);
-  QPC_SIM_TAKE(tj, 6 * D.nb); QPC_SIM_TAKE(t, 6 * D.nb); QPC_SIM_TAKE(cr, 6 * D.nb);
-  QPC_SIM_TAKE(iw, 10 * D.nb);
-  QPC_SIM_TAKE(cf, 6 * (D.nc > 0 ? D.nc : 1));
+  QPC_SIM_TAKE(tj, 6 * D.nb); QPC_SIM_TAKE(t, 6 * D.nb);
+  { const int ncf = 6 * (D.nc > 0 ? D.nc : 1); QPC_SIM_TAKE(cf, ncf > D.nv ? ncf : D.nv); }
+  // what only the body's own lane reads again (world inertia, 1-DoF motion subspace column, c_i) lives in its registers
+  L.s = L.cr = L.iw = -1;
   // articulated-body contributions to the parent: 21 (packed symmetric 6x6, over rl + h) + 6 (over tj) per body
   L.ia = L.rl;
   L.pa = L.tj;
-  QPC_SIM_TAKE(acc, 6 * D.nb);
-  QPC_SIM_TAKE(x, D.nv);
+  L.acc = L.t; // pA0_i is parked where T_i was, by the lane that read it
+  L.x = L.cf;  // the contact wrenches are consumed before the first acceleration is written
 #undef QPC_SIM_TAKE
   L.total = o;
   return L;

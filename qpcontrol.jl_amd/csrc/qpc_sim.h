@@ -111,6 +111,9 @@ QPC_FN void qpc_sim_step(const QpcDims &D, const int *IT, const double *DT, P sm
   } QPC_END_PHASE
 
   QPC_LANE_ARRAY(hreg_, 12); // world transform of body `lane` (the floating-joint lanes need it after LDS has moved on)
+  // what only the body's OWN lane reads again stays in its registers instead of LDS (10 KB per robot instead of 17.6: two
+  // packed workgroups per SIMD): [0..9] world inertia, [10..15] motion subspace column of a 1-DoF joint, [16..21] c_i
+  QPC_LANE_ARRAY(own_, 22);
   QPC_PHASE(lane_) { QPC_SIM_LOCAL // transform_to_root along the (register-resident) ancestor chain, nearest first
     if (lane < nb) {
       const int *mt = QPC_LI(M.v, lane_);
@@ -149,7 +152,7 @@ QPC_FN void qpc_sim_step(const QpcDims &D, const int *IT, const double *DT, P sm
           if (c < 3) { S[0] = col[0]; S[1] = col[1]; S[2] = col[2]; cross3(H + 9, col, S + 3); }
           else { S[3] = col[0]; S[4] = col[1]; S[5] = col[2]; }
         }
-        st(sm + L.s + 6 * (v0 + c), 6, S);
+        if (n == 1) { for (int a = 0; a < 6; a++) QPC_LA(own_, lane_)[10 + a] = S[a]; }
         const double vv = sm[L.v + v0 + c];
         for (int a = 0; a < 6; a++) tj[a] += S[a] * vv;
       }
@@ -168,7 +171,7 @@ QPC_FN void qpc_sim_step(const QpcDims &D, const int *IT, const double *DT, P sm
       double o[10] = {mm, mm * cw[0], mm * cw[1], mm * cw[2],
                       Iw[0] + mm * (cc - cw[0] * cw[0]), Iw[4] + mm * (cc - cw[1] * cw[1]), Iw[8] + mm * (cc - cw[2] * cw[2]),
                       Iw[1] - mm * cw[0] * cw[1], Iw[2] - mm * cw[0] * cw[2], Iw[5] - mm * cw[1] * cw[2]};
-      st(sm + L.iw + 10 * i, 10, o);
+      for (int a = 0; a < 10; a++) QPC_LA(own_, lane_)[a] = o[a];
     }
   } QPC_END_PHASE
 
@@ -187,7 +190,7 @@ QPC_FN void qpc_sim_step(const QpcDims &D, const int *IT, const double *DT, P sm
       }
       crm(T, tj, cr);
       st(sm + L.t + 6 * i, 6, T);
-      st(sm + L.cr + 6 * i, 6, cr);
+      for (int a = 0; a < 6; a++) QPC_LA(own_, lane_)[16 + a] = cr[a];
     }
   } QPC_END_PHASE
 
@@ -233,8 +236,8 @@ QPC_FN void qpc_sim_step(const QpcDims &D, const int *IT, const double *DT, P sm
     if (lane < nb) {
       const int i = lane;
       double T[6], I[10], h[6], pA[6];
-      ld(sm + L.iw + 10 * i, 10, I);
-      ld(sm + L.t + 6 * i, 6, T);
+      for (int a = 0; a < 10; a++) I[a] = QPC_LA(own_, lane_)[a];
+      ld(sm + L.t + 6 * i, 6, T); // (L.acc overlays L.t: this lane reads its twist before it parks pA0 in the same slot)
       inertia_mul(I, T, h);
       crf(T, h, pA);
       for (int e = IT[D.it[IT_BC_PTR] + i]; e < IT[D.it[IT_BC_PTR] + i + 1]; e++) {
@@ -253,9 +256,9 @@ QPC_FN void qpc_sim_step(const QpcDims &D, const int *IT, const double *DT, P sm
         const int jt = MT_JT(mt), v0 = MT_V0(mt);
         double *ab = QPC_LA(ab_, lane_);
         double IA[21], pA[6], I[10], c[6];
-        ld(sm + L.iw + 10 * i, 10, I);
+        for (int a = 0; a < 10; a++) I[a] = QPC_LA(own_, lane_)[a];
         ld(sm + L.acc + 6 * i, 6, pA);
-        ld(sm + L.cr + 6 * i, 6, c);
+        for (int a = 0; a < 6; a++) c[a] = QPC_LA(own_, lane_)[16 + a];
         { // spatial inertia {m, h, J} as a packed symmetric 6x6 in [angular; linear] order: [[J, h^], [h^', m 1]]
           const double m_ = I[0], hx = I[1], hy = I[2], hz = I[3];
           IA[QPC_SYM6(0, 0)] = I[4]; IA[QPC_SYM6(1, 0)] = I[7]; IA[QPC_SYM6(1, 1)] = I[5];
@@ -293,7 +296,7 @@ QPC_FN void qpc_sim_step(const QpcDims &D, const int *IT, const double *DT, P sm
           }
         } else {
           double S[6], U[6];
-          ld(sm + L.s + 6 * v0, 6, S);
+          for (int a = 0; a < 6; a++) S[a] = QPC_LA(own_, lane_)[10 + a];
           double d = 0.0, u = sm[L.tau + v0];
           for (int r = 0; r < 6; r++) {
             double acc = 0.0;
@@ -332,7 +335,7 @@ QPC_FN void qpc_sim_step(const QpcDims &D, const int *IT, const double *DT, P sm
         const int jt = MT_JT(mt), v0 = MT_V0(mt), par = MT_ANC(mt, 0);
         const double *ab = QPC_LA(ab_, lane_);
         double ap[6], a[6];
-        ld(sm + L.cr + 6 * i, 6, ap);
+        for (int a = 0; a < 6; a++) ap[a] = QPC_LA(own_, lane_)[16 + a];
         if (par >= 0) { for (int k = 0; k < 6; k++) ap[k] += sm[L.acc + 6 * par + k]; }
         else { for (int k = 0; k < 3; k++) ap[3 + k] -= DT[D.dt[DT_GRAV] + k]; }
         if (jt == QPC_JOINT_QUAT_FLOATING) {
@@ -348,7 +351,7 @@ QPC_FN void qpc_sim_step(const QpcDims &D, const int *IT, const double *DT, P sm
           for (int k = 0; k < 6; k++) a[k] = ap[k];
         } else {
           double S[6], ua = ab[7];
-          ld(sm + L.s + 6 * v0, 6, S);
+          for (int a = 0; a < 6; a++) S[a] = QPC_LA(own_, lane_)[10 + a];
           for (int k = 0; k < 6; k++) ua -= ab[k] * ap[k];
           const double qdd = ua * ab[6];
           for (int k = 0; k < 6; k++) a[k] = ap[k] + S[k] * qdd;
