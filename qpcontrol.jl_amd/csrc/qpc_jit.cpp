@@ -170,14 +170,23 @@ int qpc_jit_compile(const QpcDims &D, const std::string &arch, bool warm, std::v
   return 0;
 }
 
-// identity of the device code this library was built from (FNV-1a over the embedded device headers): profiles under
+// identity of the device code this library was built from (FNV-1a over the embedded device headers, code only): profiles under
 // profiles/ record it, and bench.py only quotes a measured-traffic figure whose fingerprint equals the built kernel's
 extern "C" const char *qpc_kernel_fingerprint(void) {
   static char buf[24];
   if (!buf[0]) {
+    // comments and white space are skipped, so that a reworded comment in a header does not orphan the profiles
     unsigned long long h = 1469598103934665603ull;
-    for (int i = 0; i < qpc_src_count; i++)
-      for (const char *p = qpc_src_texts[i]; *p; p++) { h ^= (unsigned char)*p; h *= 1099511628211ull; }
+    for (int i = 0; i < qpc_src_count; i++) {
+      const char *p = qpc_src_texts[i];
+      while (*p) {
+        if (p[0] == '/' && p[1] == '/') { while (*p && *p != '\n') p++; continue; }
+        if (p[0] == '/' && p[1] == '*') { p += 2; while (*p && !(p[0] == '*' && p[1] == '/')) p++; if (*p) p += 2; continue; }
+        if (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r') { p++; continue; }
+        h ^= (unsigned char)*p; h *= 1099511628211ull;
+        p++;
+      }
+    }
     snprintf(buf, sizeof buf, "%016llx", h);
   }
   return buf;
