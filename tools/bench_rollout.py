@@ -29,6 +29,9 @@ def main():
         pt = low.addcontact(cp.body, cp.position, cp.normal, cp.mu)
         pt.maxnormalforce, pt.weight = 1e6, 1e-3
     ctrl = api.StandingController(low, ["l_foot", "r_foot"], "pelvis", M.atlas_nominal_configuration(mech))
+    warm = os.environ.get("QPC_ROLLOUT_WARM") == "1"  # qpc_rollout_batch_device warm-starts its ticks when the controller allows it
+    if warm:
+        low._c.enable_warm_start()
     lay = low.finalize(0)
     q, v = W.standing_states(mech, B, 3, dq=0.02, drot=0.01, vstd=0.0)
     v[:, 3] = np.linspace(-0.08, 0.08, B)
@@ -61,7 +64,7 @@ def main():
     print(json.dumps({"metric": "closed-loop robot-steps/s (tick + simulation step, Atlas standing, fused PD laws)",
                       "value": B * K / el, "robots": B, "steps": K, "ms_per_step": 1e3 * el / K, "failed_qps": int(bad.sum().item()),
                       "pelvis_z_min": float(qf[:, 6].min()), "pelvis_z_max": float(qf[:, 6].max()),
-                      "simulated_seconds_per_wall_second": B * K * sp.dt / el}))
+                      "simulated_seconds_per_wall_second": B * K * sp.dt / el, "warm_started_ticks": warm}))
 
 
 if __name__ == "__main__":
