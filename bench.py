@@ -280,7 +280,7 @@ def host_pointer_path(binding, run, reps=5):
         for _ in range(reps):
             c.control_batch(arr["q"], arr["v"], arr["d"], arr["cw"], arr["cm"], out=out)
         res[mode] = B * reps / (time.perf_counter() - t0)
-        assert (out["status"] == 0).mean() > 0.9
+        res[mode + "_optimal_fraction"] = float((out["status"] == 0).mean())
     return res
 
 
@@ -389,9 +389,16 @@ def main():
 
     host_rates, secondary, closed_loop = None, None, None
     if rank == 0 and world == 1 and not args.no_secondary:
+        # diagnostic extras, measured after the headline's timed region: none of them may take the bench line down
         if not args.fused_laws:
-            host_rates = host_pointer_path(binding, run)
-        secondary = secondary_points(torch, binding, W, local_rank)
+            try:
+                host_rates = host_pointer_path(binding, run)
+            except Exception as e:  # noqa: BLE001
+                host_rates = {"error": repr(e)}
+        try:
+            secondary = secondary_points(torch, binding, W, local_rank)
+        except Exception as e:  # noqa: BLE001
+            secondary = {"error": repr(e)}
         closed_loop = closed_loop_point()
 
     if rank == 0:
@@ -422,8 +429,11 @@ def main():
                        "optimal_fraction": n_opt / B, "mean_active_set_iters": float(it.mean()),
                        "lds_bytes_per_qp": int(lay.lds_bytes_per_qp),
                        "desired": "device PD laws (standing.jl:58-89 fused)" if args.fused_laws else "input record",
-                       "host_pointer_path_solves_per_s": host_rates["pinned"] if host_rates else None,
-                       "host_pointer_path_pageable_solves_per_s": host_rates["pageable"] if host_rates else None,
+                       "host_pointer_path_solves_per_s": host_rates.get("pinned") if host_rates else None,
+                       "host_pointer_path_pageable_solves_per_s": host_rates.get("pageable") if host_rates else None,
+                       "host_pointer_path_optimal_fraction": ([host_rates.get("pinned_optimal_fraction"), host_rates.get("pageable_optimal_fraction")]
+                                                              if host_rates else None),
+                       "host_pointer_path_error": host_rates.get("error") if host_rates else None,
                        "host_pointer_path_note": "qpc_control_batch on this workload, PCIe inclusive, synchronous calls: page-locked caller "
                                                  "arrays are read / written in place by the kernel (what QPControlHIP.jl does with the "
                                                  "buffers it owns); pageable arrays are staged chunk by chunk by worker threads",

@@ -290,7 +290,10 @@ int32_t qpc_control_batch(qpc_controller *ctrl, int64_t B, const double *q, cons
 /* Same, but returns as soon as the job is posted to the controller's worker threads; every array
  * must stay valid and untouched until qpc_wait(ctrl) returns.  One job in flight per controller: a
  * second *_async call first waits for the previous job.  qpc_wait returns the error of the job
- * (QPC_OK if there is none in flight). */
+ * (QPC_OK if there is none in flight).  The error of an async job is reported by qpc_wait ONLY: any other
+ * host-pointer call on the controller (synchronous tick, another *_async, rollout, L1) first lets the job in
+ * flight finish, drops its error if nobody waited for it, and then runs and reports its OWN batch -- a
+ * synchronous call never returns an error for work it did not attempt. */
 int32_t qpc_control_batch_async(qpc_controller *ctrl, int64_t B, const double *q, const double *v,
                                 const double *desired, const double *contact_weight,
                                 const double *contact_maxnormalforce, const double *task_weights,

@@ -116,8 +116,9 @@ class QpcHostPipeline {
   // synchronous run; small jobs on the caller's thread
   int run(const QpcHostJob &job, std::string &err) {
     if (job.B <= inline_) {
-      int rc = wait(err);
-      if (rc) return rc;
+      (void)wait(err); // an async job nobody waited for: its error was that job's (see submit), this job still runs
+      err.clear();
+      int rc = 0;
       be_->bind_thread(0);
       for (int64_t lo = 0; lo < job.B; lo += chunk_) {
         const int64_t n = job.B - lo < chunk_ ? job.B - lo : chunk_;

@@ -793,8 +793,11 @@ static int host_wait(qpc_controller *c) { // everything the host-pointer entry p
 
 // run a filled job: zero-copy when every array is page-locked, else the staged pipeline
 static int run_job(qpc_controller *c, const QpcHostJob &job, bool async) {
-  int rc = host_wait(c); // one job in flight per controller
-  if (rc != QPC_OK && !async) return rc;
+  // one job in flight per controller.  The error of an async job that was never waited for was THAT job's: it is
+  // dropped here (qpc.h), the new job runs and reports its own outcome -- a caller must never get an error code for
+  // a batch that was not even attempted
+  int rc = host_wait(c);
+  (void)rc;
   if (c->rt->zero_copy && job_all_pinned(job)) {
     rc = zero_copy_launch(c, job);
     if (rc == QPC_OK) return async ? QPC_OK : zero_copy_wait(c);
@@ -814,7 +817,7 @@ int32_t qpc_control_batch(qpc_controller *c, int64_t B, const double *q, const d
   QpcHostJob job;
   int rc = fill_job(c, job, B, q, v, desired, cw, cmax, tw, surf, tau, vdot, cwrench, status, iters, nullptr, "qpc_control_batch");
   if (rc != QPC_OK) return rc;
-  if (B == 0) return host_wait(c);
+  if (B == 0) { (void)host_wait(c); return QPC_OK; }
   return run_job(c, job, false);
 }
 
@@ -836,7 +839,7 @@ int32_t qpc_control_batch_warm(qpc_controller *c, int64_t B, const double *q, co
   QpcHostJob job;
   int rc = fill_job(c, job, B, q, v, desired, cw, cmax, tw, surf, tau, vdot, cwrench, status, iters, working_set, "qpc_control_batch_warm");
   if (rc != QPC_OK) return rc;
-  if (B == 0) return host_wait(c);
+  if (B == 0) { (void)host_wait(c); return QPC_OK; }
   return run_job(c, job, false);
 }
 
@@ -860,8 +863,8 @@ int32_t qpc_assemble_solve_batch(qpc_controller *c, int64_t B, const double *tas
   if (c->N > 8) { qpc_set_error("qpc_assemble_solve_batch: friction basis larger than 8"); return QPC_ERR_UNSUPPORTED; }
   for (auto &t : c->tasks)
     if (t.law == QPC_LAW_SE3_PD) { qpc_set_error("qpc_assemble_solve_batch: tasks with a trajectory-record law are not supported by the L1 path"); return QPC_ERR_UNSUPPORTED; }
-  int rc = host_wait(c); // the inline slot's stream is shared with small host-pointer jobs
-  if (rc != QPC_OK) return rc;
+  (void)host_wait(c); // the inline slot's stream is shared with small host-pointer jobs (a stale async error is that job's)
+  int rc = QPC_OK;
   QpcDeviceState *S = c->rt->devs[0];
   hipStream_t st = S->slots[c->rt->inline_slot()].stream;
   HIP_TRY(hipSetDevice(S->device));
@@ -1082,8 +1085,8 @@ static int rollout_host(qpc_controller *c, int64_t B, int64_t n_steps, bool tick
                         double *tau, int32_t *status, int32_t *bad) {
   const QpcDims &D = c->prog.dims;
   if (B == 0) return QPC_OK;
-  int rc = host_wait(c);
-  if (rc != QPC_OK) return rc;
+  (void)host_wait(c); // a stale error of an un-waited async job is that job's (qpc.h)
+  int rc = QPC_OK;
   enum { A_Q, A_V, A_TAU, A_VDOT, A_DES, A_CW, A_CMAX, A_TW, A_SURF, A_COUNT };
   const size_t dim[A_COUNT] = {(size_t)D.nq, (size_t)D.nv, (size_t)D.nv, (size_t)D.nv, desired ? (size_t)D.n_desired : 0,
                                (size_t)D.nc, (size_t)D.nc, (size_t)D.n_tw, (size_t)D.n_surf};
@@ -1106,7 +1109,6 @@ static int rollout_host(qpc_controller *c, int64_t B, int64_t n_steps, bool tick
     for (int i = 0; i < A_COUNT; i++) total += padded(i);
     if (total > S->roll_bytes) {
       if (S->roll_buf) (void)hipFree(S->roll_buf);
-  if (S->roll_ws) (void)hipFree(S->roll_ws);
       S->roll_buf = nullptr; S->roll_bytes = 0;
       if (hipMalloc(&S->roll_buf, total) != hipSuccess) { (void)hipGetLastError(); qpc_set_error("rollout: out of device memory"); rc = QPC_ERR_OUT_OF_MEMORY; break; }
       S->roll_bytes = total;

@@ -978,7 +978,8 @@ QPC_FN void se3_pd_law(PR rec, const double *Hb, const double *Ha, const double 
   // qd = inv(y0) * yf
   double dw = w0 * w1 + x0q * x1 + y0q * y1 + z0q * z1;
   double dv[3] = {w0 * x1 - x0q * w1 - y0q * z1 + z0q * y1, w0 * y1 + x0q * z1 - y0q * w1 - z0q * x1, w0 * z1 - x0q * y1 + y0q * x1 - z0q * w1};
-  if (dw < 0.0) { dw = -dw; dv[0] = -dv[0]; dv[1] = -dv[1]; dv[2] = -dv[2]; }
+  // no hemisphere flip: Rotations 0.13.0 (Manifest.toml:136-140) converts with theta = 2 atan(|v|, w), so a relative
+  // quaternion with w < 0 gives an angle in (pi, 2 pi] about v / |v| -- the LONG arc, same end point
   const double sn = QPC_SQRT(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2]);
   const double angle = 2.0 * QPC_ATAN2(sn, dw);
   double axis[3] = {1.0, 0.0, 0.0};

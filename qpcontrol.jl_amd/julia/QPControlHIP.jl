@@ -12,7 +12,7 @@
 module QPControlHIP
 
 export qp_solve_batch, setlaw!, simulate!, SimParams, LAW_INPUT, LAW_CONSTANT, LAW_JOINT_PD, LAW_COM_PD, LAW_ORIENTATION_PD,
-       LAW_SE3_PD, SE3_RECORD, QPCOptimizer, pin!, pinned_zeros, enable_warm_start!, control_async!, wait!, desired_range,
+       LAW_SE3_PD, SE3_RECORD, load_moi!, pin!, pinned_zeros, enable_warm_start!, control_async!, wait!, desired_range,
        BatchedMomentumBasedController, QPCModel, addtask!, addcontact!, regularize!, finalize!,
        QPSolveFailure, SpatialAccelerationTask, AngularAccelerationTask, LinearAccelerationTask,
        PointAccelerationTask, JointAccelerationTask, MomentumRateTask, LinearMomentumRateTask
@@ -321,8 +321,8 @@ end
 # ---------------------------------------------------------------------------------------------
 # b-1: solver-level plug.  `MomentumBasedController{N}(mechanism, optimizer)` (reference
 # src/lowlevel/momentum.jl:15-16,27) accepts any MOI.AbstractOptimizer; the reference's tests build
-# an OSQP one (test/runtests.jl:35-43).  `qp_solve_batch` is the ccall that `QPCOptimizer` (end of this
-# file) forwards `MOI.optimize!` to with B = 1: dense OSQP-form data in, (x, y, status) out.
+# an OSQP one (test/runtests.jl:35-43).  `qp_solve_batch` is the ccall that `QPCOptimizer`
+# (QPControlHIPMOI.jl, loaded by `load_moi!()`) forwards `MOI.optimize!` to with B = 1: dense OSQP-form data in, (x, y, status) out.
 struct Settings
     max_active_set_iters::Int32
     max_refine_iters::Int32
@@ -358,171 +358,19 @@ function qp_solve_batch(P::Array{Float64, 3}, q::Matrix{Float64}, At::Array{Floa
 end
 
 # ---------------------------------------------------------------------------------------------
-# f-3: `QPCOptimizer <: MOI.AbstractOptimizer` -- lets UNMODIFIED QPControl.jl run its QP on the GPU:
-#
-#     controller = MomentumBasedController{4}(mechanism, QPControlHIP.QPCOptimizer(), floatingjoint = ...)
-#
-# Parametron (0.9, MathOptInterface 0.8) drives an optimizer like this (momentum.jl:27,58):
-#   * once:        MOI.copy_to(optimizer, backend_model)         -- variables, ONE ScalarQuadraticFunction objective,
-#                  VectorAffineFunction-in-{Zeros, Nonnegatives, Nonpositives} constraints
-#   * every tick:  MOI.set(optimizer, MOI.ObjectiveFunction{F}(), f)   and
-#                  MOI.set(optimizer, MOI.ConstraintFunction(), ci, f)  -- same terms, new coefficients
-#                  MOI.optimize!(optimizer)
-#   * afterwards:  MOI.get(optimizer, MOI.VariablePrimal(), vi), MOI.TerminationStatus(), MOI.PrimalStatus(),
-#                  MOI.DualStatus() (checkstatus, momentum.jl:83-91)
-# The optimizer keeps the problem dense (P n x n, q, A' n x m so that the C side sees row-major A, l, u) and
-# forwards optimize! to qp_solve_batch with B = 1.  Assembly stays on the CPU here: this is the compatibility
-# plug (SURVEY.md 8 b-1); the performance path is BatchedMomentumBasedController.
-#
-# Written against the MOI 0.8 API from memory -- there is no `julia` in the build image, so this block is
-# UNTESTED there; its Python twin (qpcontrol.jl_amd/moi.py) replays the same life cycle against the same
-# L0 entry in tests/test_moi_optimizer.py.  MathOptInterface (already a dependency of QPControl.jl, Project.toml)
-# is the only package this file needs.
-import MathOptInterface
-const MOI = MathOptInterface
-using LinearAlgebra: dot
+# f-3: `QPCOptimizer <: MOI.AbstractOptimizer` lives in QPControlHIPMOI.jl (sub-module QPControlHIPMOI), loaded on
+# demand: it is the only part of the shim that needs MathOptInterface, it was written against the MOI 0.8 API
+# without a Julia toolchain, and a mismatch there must not take `using QPControlHIP` down with it.
+"""
+    load_moi!() -> Module
 
-mutable struct QPCOptimizer <: MOI.AbstractOptimizer
-    device::Int32
-    settings::Settings
-    n::Int
-    m::Int
-    P::Matrix{Float64}          # n x n symmetric
-    q::Vector{Float64}
-    At::Matrix{Float64}         # n x m (column j = row j of A): row-major A for the C ABI
-    l::Vector{Float64}
-    u::Vector{Float64}
-    objconstant::Float64
-    sense::MOI.OptimizationSense
-    rowranges::Dict{Any, UnitRange{Int}}   # constraint index -> rows of A
-    rowsets::Dict{Any, Any}                 # constraint index -> its set (Zeros / Nonnegatives / Nonpositives)
-    x::Vector{Float64}
-    y::Vector{Float64}
-    status::Int32                           # QPC_STATUS_* of the last optimize!, -1 before
-    QPCOptimizer(; device::Integer = 0, settings::Settings = default_settings()) =
-        new(device, settings, 0, 0, zeros(0, 0), Float64[], zeros(0, 0), Float64[], Float64[], 0.0,
-            MOI.MIN_SENSE, Dict{Any, UnitRange{Int}}(), Dict{Any, Any}(), Float64[], Float64[], Int32(-1))
+Include the experimental `QPCOptimizer <: MOI.AbstractOptimizer` (QPControlHIPMOI.jl next to this file) into this module
+and return the sub-module; `QPControlHIP.load_moi!().QPCOptimizer()` is what `MomentumBasedController{N}(mechanism,
+optimizer)` (reference momentum.jl:15-16) takes.  Requires MathOptInterface in the active environment.
+"""
+function load_moi!()
+    isdefined(@__MODULE__, :QPControlHIPMOI) || Base.include(@__MODULE__, joinpath(@__DIR__, "QPControlHIPMOI.jl"))
+    getfield(@__MODULE__, :QPControlHIPMOI)
 end
 
-MOI.get(::QPCOptimizer, ::MOI.SolverName) = "qpcontrol_hip (gfx950)"
-MOI.is_empty(o::QPCOptimizer) = o.n == 0
-function MOI.empty!(o::QPCOptimizer)
-    o.n = o.m = 0; o.P = zeros(0, 0); o.q = Float64[]; o.At = zeros(0, 0); o.l = Float64[]; o.u = Float64[]
-    o.objconstant = 0.0; empty!(o.rowranges); empty!(o.rowsets); o.x = Float64[]; o.y = Float64[]; o.status = Int32(-1)
-    nothing
-end
-
-const _QPCSets = Union{MOI.Zeros, MOI.Nonnegatives, MOI.Nonpositives}
-MOI.supports(::QPCOptimizer, ::MOI.ObjectiveSense) = true
-MOI.supports(::QPCOptimizer, ::MOI.ObjectiveFunction{MOI.ScalarQuadraticFunction{Float64}}) = true
-MOI.supports(::QPCOptimizer, ::MOI.ObjectiveFunction{MOI.ScalarAffineFunction{Float64}}) = true
-MOI.supports_constraint(::QPCOptimizer, ::Type{MOI.VectorAffineFunction{Float64}}, ::Type{<:_QPCSets}) = true
-
-# rows of one vector constraint: A x + b in set  ->  l <= A x <= u
-function _setrows!(o::QPCOptimizer, rows::UnitRange{Int}, f::MOI.VectorAffineFunction{Float64}, set)
-    o.At[:, rows] .= 0.0
-    for t in f.terms
-        o.At[t.scalar_term.variable_index.value, rows[t.output_index]] += t.scalar_term.coefficient
-    end
-    for (k, r) in enumerate(rows)
-        b = f.constants[k]
-        if set isa MOI.Zeros
-            o.l[r] = -b; o.u[r] = -b
-        elseif set isa MOI.Nonnegatives
-            o.l[r] = -b; o.u[r] = Inf
-        else
-            o.l[r] = -Inf; o.u[r] = -b
-        end
-    end
-end
-function _setobjective!(o::QPCOptimizer, f::MOI.ScalarQuadraticFunction{Float64})
-    o.P .= 0.0; o.q .= 0.0
-    for t in f.quadratic_terms   # MOI: 1/2 x'Qx; an off-diagonal term appears once and stands for both entries
-        i, j = t.variable_index_1.value, t.variable_index_2.value
-        o.P[i, j] += t.coefficient
-        i == j || (o.P[j, i] += t.coefficient)
-    end
-    for t in f.affine_terms
-        o.q[t.variable_index.value] += t.coefficient
-    end
-    o.objconstant = f.constant
-end
-function _setobjective!(o::QPCOptimizer, f::MOI.ScalarAffineFunction{Float64})
-    o.P .= 0.0; o.q .= 0.0
-    for t in f.terms
-        o.q[t.variable_index.value] += t.coefficient
-    end
-    o.objconstant = f.constant
-end
-
-# MOI.copy_to: variables keep their indices (Parametron creates them 1:n), constraints are laid out in
-# the order of ListOfConstraints / ListOfConstraintIndices
-function MOI.copy_to(dest::QPCOptimizer, src::MOI.ModelLike; copy_names::Bool = false)
-    MOI.empty!(dest)
-    vis = MOI.get(src, MOI.ListOfVariableIndices())
-    n = length(vis)
-    idxmap = MOI.Utilities.IndexMap()
-    for (k, vi) in enumerate(vis)
-        idxmap[vi] = MOI.VariableIndex(k)
-    end
-    cons = Any[]
-    m = 0
-    for (F, S) in MOI.get(src, MOI.ListOfConstraints())
-        (F == MOI.VectorAffineFunction{Float64} && S <: _QPCSets) || throw(MOI.UnsupportedConstraint{F, S}())
-        for ci in MOI.get(src, MOI.ListOfConstraintIndices{F, S}())
-            f = MOI.get(src, MOI.ConstraintFunction(), ci)
-            s = MOI.get(src, MOI.ConstraintSet(), ci)
-            push!(cons, (ci, f, s, (m + 1):(m + MOI.dimension(s))))
-            m += MOI.dimension(s)
-        end
-    end
-    dest.n = n; dest.m = m
-    dest.P = zeros(n, n); dest.q = zeros(n); dest.At = zeros(n, m); dest.l = zeros(m); dest.u = zeros(m)
-    for (ci, f, s, rows) in cons
-        fm = MOI.Utilities.mapvariables(idxmap, f)
-        dest.rowranges[ci] = rows; dest.rowsets[ci] = s
-        idxmap[ci] = ci
-        _setrows!(dest, rows, fm, s)
-    end
-    dest.sense = MOI.get(src, MOI.ObjectiveSense())
-    dest.sense == MOI.MAX_SENSE && error("QPCOptimizer: minimisation only (momentum.jl:158-160 uses Minimize)")
-    F = MOI.get(src, MOI.ObjectiveFunctionType())
-    _setobjective!(dest, MOI.Utilities.mapvariables(idxmap, MOI.get(src, MOI.ObjectiveFunction{F}())))
-    idxmap
-end
-
-# per-tick coefficient updates (Parametron update!)
-MOI.set(o::QPCOptimizer, ::MOI.ObjectiveFunction{F}, f::F) where {F <: Union{MOI.ScalarQuadraticFunction{Float64}, MOI.ScalarAffineFunction{Float64}}} =
-    _setobjective!(o, f)
-MOI.set(o::QPCOptimizer, ::MOI.ObjectiveSense, s::MOI.OptimizationSense) = (o.sense = s)
-function MOI.set(o::QPCOptimizer, ::MOI.ConstraintFunction, ci::MOI.ConstraintIndex, f::MOI.VectorAffineFunction{Float64})
-    _setrows!(o, o.rowranges[ci], f, o.rowsets[ci])
-end
-MOI.set(o::QPCOptimizer, ::MOI.ConstraintSet, ci::MOI.ConstraintIndex, s) = (o.rowsets[ci] = s)
-
-function MOI.optimize!(o::QPCOptimizer)
-    lc = clamp.(o.l, -1e20, 1e20); uc = clamp.(o.u, -1e20, 1e20)   # +-1e20 = unbounded (include/qpc.h L0)
-    x, y, status, _ = qp_solve_batch(reshape(o.P, o.n, o.n, 1), reshape(o.q, o.n, 1), reshape(o.At, o.n, o.m, 1),
-                                     reshape(lc, o.m, 1), reshape(uc, o.m, 1); device = o.device, settings = o.settings)
-    o.x = vec(x); o.y = vec(y); o.status = status[1]
-    nothing
-end
-
-# results: exactly what checkstatus reads (momentum.jl:83-91)
-function MOI.get(o::QPCOptimizer, ::MOI.TerminationStatus)
-    s = o.status
-    s == -1 ? MOI.OPTIMIZE_NOT_CALLED : s == 0 ? MOI.OPTIMAL : s == 1 ? MOI.ALMOST_OPTIMAL : s == 2 ? MOI.INFEASIBLE :
-    s == 3 ? MOI.DUAL_INFEASIBLE : s == 4 ? MOI.ITERATION_LIMIT : MOI.NUMERICAL_ERROR
-end
-MOI.get(o::QPCOptimizer, ::MOI.PrimalStatus) =
-    o.status == 0 ? MOI.FEASIBLE_POINT : o.status == 2 ? MOI.NO_SOLUTION : o.status == 3 ? MOI.INFEASIBILITY_CERTIFICATE :
-    o.status == -1 ? MOI.NO_SOLUTION : MOI.UNKNOWN_RESULT_STATUS
-MOI.get(o::QPCOptimizer, ::MOI.DualStatus) =
-    o.status == 0 ? MOI.FEASIBLE_POINT : o.status == 2 ? MOI.INFEASIBILITY_CERTIFICATE : o.status == -1 ? MOI.NO_SOLUTION :
-    MOI.UNKNOWN_RESULT_STATUS
-MOI.get(o::QPCOptimizer, ::MOI.ResultCount) = o.status == -1 ? 0 : 1
-MOI.get(o::QPCOptimizer, ::MOI.VariablePrimal, vi::MOI.VariableIndex) = o.x[vi.value]
-MOI.get(o::QPCOptimizer, ::MOI.ObjectiveValue) = 0.5 * dot(o.x, o.P * o.x) + dot(o.q, o.x) + o.objconstant
-MOI.get(o::QPCOptimizer, ::MOI.ConstraintDual, ci::MOI.ConstraintIndex) = -o.y[o.rowranges[ci]]  # OSQP sign convention
-MOI.get(o::QPCOptimizer, ::MOI.ConstraintPrimal, ci::MOI.ConstraintIndex) = (o.At' * o.x)[o.rowranges[ci]]
 end # module

@@ -139,9 +139,10 @@ class Quat:
         return Quat(w, -x, -y, -z)
 
     def angle_axis(self):
+        # AngleAxis(::Quat) of Rotations 0.13.0 (the version pinned in the reference's Manifest.toml:136-140):
+        # theta = 2 atan(|v|, w), axis = v / |v| -- NO flip to the w >= 0 hemisphere, so w < 0 yields an angle in
+        # (pi, 2 pi] and interpolate(::Quat, ::Quat, alpha) (interpolated.jl:76-83) then takes the long arc
         w, v = self.q[0], self.q[1:]
-        if w < 0:
-            w, v = -w, -v
         s = np.linalg.norm(v)
         angle = 2.0 * np.arctan2(s, w)
         axis = v / s if s > 1e-300 else np.array([1.0, 0.0, 0.0])

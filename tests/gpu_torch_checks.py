@@ -85,6 +85,58 @@ def graph():
     assert np.array_equal(r["tau"], ref["tau"])
 
 
+def warm_mixed_rollouts():
+    """on a warm-start controller the host rollout (qpc_rollout_batch) used to free the working-set buffer of
+    the device rollout when its own slab grew; device rollout -> larger host rollout -> device rollout -> destroy must
+    leave the device rollout's results unchanged (and nothing freed twice)."""
+    from qpcontrol_jl_amd import api, models as M
+    mech = M.atlas()
+    low = api.MomentumBasedController(mech, n_basis=4, floatingjoint="pelvis_to_world")
+    for cp in mech.contact_points:
+        pt = low.addcontact(cp.body, cp.position, cp.normal, cp.mu)
+        pt.maxnormalforce, pt.weight = 1e6, 1e-3
+    api.StandingController(low, ["l_foot", "r_foot"], "pelvis", M.atlas_nominal_configuration(mech))
+    low._c.enable_warm_start()
+    lay = low.finalize(0)
+    assert low._c.L.qpc_debug_warm_active(low._c.h) == 1
+    B, K = 1024, 4
+    q, v = W.standing_states(mech, 4 * B, 3, dq=0.02, drot=0.01, vstd=0.0)
+    k = 6.0e4
+    sp = binding.SimParams(1e-3, 0.01308714 + mech.total_mass() * 9.81 / (8 * k), k, 400.0, 300.0)
+    dev = torch.device("cuda", 0)
+    L, h = low._c.L, low._c.h
+
+    def device_rollout():
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+        dq, dv = t(q[:B]), t(v[:B])
+        cw, cm = t(np.full((B, lay.n_contacts), 1e-3)), t(np.full((B, lay.n_contacts), 1e6))
+        tau = torch.zeros((B, lay.nv), dtype=torch.float64, device=dev)
+        vd = torch.zeros((B, lay.nv), dtype=torch.float64, device=dev)
+        st, bad = torch.zeros(B, dtype=torch.int32, device=dev), torch.zeros(B, dtype=torch.int32, device=dev)
+        p = lambda x: vp(x.data_ptr())  # noqa: E731
+        torch.cuda.synchronize(dev)
+        rc = L.qpc_rollout_batch_device(h, B, K, p(dq), p(dv), vp(0), p(cw), p(cm), vp(0), vp(0), ctypes.byref(sp), p(tau), p(vd),
+                                        p(st), p(bad), vp(torch.cuda.current_stream(dev).cuda_stream))
+        assert rc == 0, L.qpc_last_error()
+        torch.cuda.synchronize(dev)
+        assert int(bad.sum().item()) == 0
+        return dq.cpu().numpy(), dv.cpu().numpy(), tau.cpu().numpy()
+
+    first = device_rollout()
+    for Bh in (2 * B, 4 * B):  # the host slab grows twice
+        r = low._c.rollout(q[:Bh], v[:Bh], K, sp, contact_weight=np.full((Bh, lay.n_contacts), 1e-3),
+                           contact_maxnormalforce=np.full((Bh, lay.n_contacts), 1e6))
+        assert not r["bad"].any()
+        assert np.array_equal(r["q"][:B], first[0]) and np.array_equal(r["tau"][:B], first[2])
+        again = device_rollout()
+        for a, b in zip(first, again):
+            assert np.array_equal(a, b)
+    del low
+    import gc
+    gc.collect()
+    torch.cuda.synchronize(dev)
+
+
 if __name__ == "__main__":
-    {"streams": streams, "graph": graph}[sys.argv[1]]()
+    {"streams": streams, "graph": graph, "warm_mixed_rollouts": warm_mixed_rollouts}[sys.argv[1]]()
     print("CHECK_OK")

@@ -8,6 +8,8 @@ exactly once, results bitwise equal to the single-shard call, a job in flight is
 failing chunk surfaces as the call's error.  The `-m gpu` twin runs the HIP backend."""
 import ctypes
 
+import time
+
 import numpy as np
 import pytest
 
@@ -112,6 +114,21 @@ def test_worker_error_reaches_the_caller():
     p = _tick(c, wl, asynchronous=True)  # async: the error is the job's, reported by wait
     with pytest.raises(binding.QpcError, match="injected failure"):
         p.wait()
+    # an async job that failed and was never waited for must not make the NEXT synchronous call return that
+    # stale error without running its own batch (threaded path and inline path)
+    ref = None
+    for inline in (0, 64):
+        c.set_host_pipeline(inline_qps=inline)
+        L.emu_fail_at(c.h, 11)
+        pending = _tick(c, wl, asynchronous=True)  # fails in the background; nobody waits (its arrays stay alive)
+        time.sleep(0.05)
+        L.emu_fail_at(c.h, -1)
+        r = _tick(c, wl)  # runs its own job and reports its own outcome
+        del pending
+        assert (r["status"] == 0).all() and np.isfinite(r["tau"]).all()
+        ref = r if ref is None else ref
+        assert np.array_equal(r["tau"], ref["tau"])
+        c.wait()  # the stale error is gone
     L.emu_fail_at(c.h, -1)
     r = _tick(c, wl)  # the controller stays usable
     assert (r["status"] == 0).all()
@@ -204,6 +221,12 @@ def test_gpu_user_streams_are_serialised():
 def test_gpu_graph_replay_of_the_tick():
     """the work counter re-arms itself on the device, so a captured tick can be replayed (hipGraph)"""
     _run_torch_check("graph")
+
+
+@pytest.mark.gpu
+def test_gpu_warm_controller_mixes_device_and_host_rollouts():
+    """the host rollout must not free the device rollout's working-set buffer (tests/gpu_torch_checks.py)"""
+    _run_torch_check("warm_mixed_rollouts")
 
 
 @pytest.mark.gpu

@@ -1,5 +1,5 @@
 """Solver-level plug: the MOI-optimizer twin (qpcontrol.jl_amd/moi.py, mirrored by
-`QPCOptimizer <: MOI.AbstractOptimizer` in julia/QPControlHIP.jl) driven the way Parametron drives its optimizer
+`QPCOptimizer <: MOI.AbstractOptimizer` in julia/QPControlHIPMOI.jl) driven the way Parametron drives its optimizer
 (momentum.jl:27,58): copy the 143 x 178 reference-layout Atlas problem ONCE, then per tick rewrite the coefficients in
 place (same sparsity pattern) and optimize -- a 20-tick closed-loop sequence, every tick against the oracle's solve of
 the same problem; statuses through checkstatus (momentum.jl:83-91)."""

@@ -49,9 +49,12 @@ def _run(factory, B=10, seed=5):
     q, v = np.array(qs), np.array(vs)
     nc = len(mech.contact_points)
     cw, cm = np.full((B, nc), 1e-3), np.full((B, nc), 1e6)
-    for warp in (None, "quintic"):
-        f = None if warp is None else T.fit_quintic(x0=0.0, xf=1.0, y0=0.0, yd0=0.0, ydd0=0.0, yf=1.0, ydf=0.0, yddf=0.0)
-        ang = T.Interpolated(0.2, 1.7, T.Quat.identity(), T.Quat.from_angle_axis(np.pi / 2, [1.0, 0.3, -0.2]), f, min_num_derivs=2)
+    for warp in (None, "quintic", "antipodal"):
+        f = None if warp in (None, "antipodal") else T.fit_quintic(x0=0.0, xf=1.0, y0=0.0, yd0=0.0, ydd0=0.0, yf=1.0, ydf=0.0, yddf=0.0)
+        yf = T.Quat.from_angle_axis(np.pi / 2, [1.0, 0.3, -0.2])
+        if warp == "antipodal":  # same rotation, opposite sign: inv(y0) * yf has w < 0 -> the reference takes the long arc (3 pi / 2)
+            yf = T.Quat(*(-yf.q))
+        ang = T.Interpolated(0.2, 1.7, T.Quat.identity(), yf, f, min_num_derivs=2)
         lin = T.Interpolated(0.2, 1.7, np.array([0.0, 1.0, 2.0]) * 0.2, np.array([2.0, 3.0, 4.0]) * 0.15, f, min_num_derivs=2)
         traj = T.SE3Trajectory(body, base, ang, lin)
         ctl = api.SE3PDController(mech, base, body, traj, np.diag([0, 0, 0, 10.0, 10, 10]), gains)

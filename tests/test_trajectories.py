@@ -164,3 +164,21 @@ def test_se3pd_controller():
     fb = ctrl(0.5, (qd, vv))[0] - Td["v"]
     np.testing.assert_allclose(H["R"] @ fb[3:], [-1000.0 * 0.01, 0.0, 0.0], atol=1e-6)
     np.testing.assert_allclose(fb[:3], 0.0, atol=1e-9)
+
+
+def test_quat_interpolation_takes_the_long_arc_for_antipodal_signs():
+    """interpolated.jl:76-83 with Rotations 0.13.0's AngleAxis(::Quat) (theta = 2 atan(|v|, w), no hemisphere flip): when
+    inv(y0) * yf has w < 0 the angle is 2 pi - a about -n; same end point, different path and Lie derivative"""
+    a, n = np.pi / 2, np.array([1.0, 0.0, 0.0])
+    y0 = T.Quat.identity()
+    yf_short = T.Quat.from_angle_axis(a, n)
+    yf_long = T.Quat(*(-yf_short.q))
+    for yf, angle, axis in ((yf_short, a, n), (yf_long, 2 * np.pi - a, -n)):
+        ang, ax = (y0.inv() * yf).angle_axis()
+        assert abs(ang - angle) < 1e-15 and np.allclose(ax, axis, atol=1e-15)
+        traj = T.Interpolated(0.0, 1.0, y0, yf, min_num_derivs=2)
+        y, yd, ydd = traj(0.5, 2)
+        assert y.isapprox(T.Quat.from_angle_axis(0.5 * angle, axis), atol=1e-15)
+        assert np.allclose(yd, axis * angle, atol=1e-14) and np.allclose(ydd, 0.0, atol=1e-14)
+        y1 = traj(1.0, 2)[0]
+        assert np.allclose(y1.matrix(), yf_short.matrix(), atol=1e-15)  # both arcs end on the same rotation
