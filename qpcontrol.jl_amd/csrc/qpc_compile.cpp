@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -604,6 +605,12 @@ int qpc_compile_program(qpc_controller *c) {
   D.lds[L_RED] = off; // unused on the device (wave reductions); the emulator has its own scratch
   if (early_end > off) off = early_end;
   D.lds_doubles = off;
+  if (const char *e = getenv("QPC_DUMP_LDS")) { // diagnostic: the overlay map (offsets in doubles)
+    if (e[0] == '1') {
+      fprintf(stderr, "[qpc] LDS map: total %d doubles; a_base %d a_kin_end %d b_base %d early_end %d xbase %d vec_end %d\n", off, a_base, a_kin_end, b_base, early_end, xbase, vec_end);
+      for (int i = 0; i < L_COUNT; i++) fprintf(stderr, "[qpc]   lds[%d] = %d\n", i, D.lds[i]);
+    }
+  }
   D.n_int = (int)B.it.size(); D.n_dbl = (int)B.dt.size();
   // settings
   D.max_as_iters = c->settings.max_active_set_iters;
