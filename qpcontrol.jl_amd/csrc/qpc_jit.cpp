@@ -29,6 +29,11 @@ static std::string dbl(double x) {
   return s;
 }
 
+bool qpc_jit_dynamic_lds() {
+  const char *e = getenv("QPC_EXP_DYN_LDS");
+  return e && e[0] == '1';
+}
+
 int qpc_jit_sim_rpw(const QpcDims &D) {
   if (const char *e = getenv("QPC_SIM_RPW")) { if (e[0] == '1') return 1; }
   const int slab = qpc_sim_layout(D).total + (qpc_sim_layout(D).total & 1);
@@ -68,16 +73,24 @@ std::string qpc_jit_source(const QpcDims &D, bool warm) {
   put_ints(o, D.lds, L_COUNT); o << ",";
   o << D.lds_doubles << "," << D.n_int << "," << D.n_dbl << "," << D.max_as_iters << "," << D.max_refine << ","
     << D.max_pdas << "," << dbl(D.eps_primal) << "," << dbl(D.tau_pivot) << "," << dbl(D.tol_bound) << ","
-    << dbl(D.tol_accept) << "," << dbl(D.h_static_max) << "," << dbl(D.h_static_min) << "};\n";
+    << dbl(D.tol_accept) << "," << dbl(D.h_static_max) << "," << dbl(D.h_static_min) << "," << dbl(D.k_mu2) << "};\n";
   o << "struct QpcBatchArgs { long long B; const double *q, *v, *desired, *cw, *cmax, *tw, *surf; double *tau, *vdot, "
        "*cwrench; int32_t *status, *iters; unsigned long long *prof; unsigned long long *ticket; unsigned long long *wsets; };\n";
   // the tick kernel (cold start) and, on request, its warm-started twin: same loop, qpc_tick<P, true>
   const char *f32e = getenv("QPC_F32_LDS"); // experiment: fp32 LDS storage (qpc_device.h F32Ptr)
   const bool f32 = f32e && f32e[0] == '1';
+  // experiments (tools/ + DESIGN 8.1): QPC_EXP_DYN_LDS=1 declares the slab as DYNAMIC shared memory (the compiler then does not
+  // derive an occupancy bound from it), QPC_EXP_WAVES=n is the second __launch_bounds__ argument (waves per SIMD to allocate for)
+  const bool dyn_lds = qpc_jit_dynamic_lds();
+  int waves = 2;
+  if (const char *e = getenv("QPC_EXP_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 8) waves = v; }
+  if (dyn_lds) o << "extern __shared__ __attribute__((aligned(16))) double qpc_lds_dyn[];\n";
   for (int variant = 0; variant < (warm ? 2 : 1); variant++) {
-    o << "extern \"C\" __global__ void __launch_bounds__(64, 2) " << (variant ? "qpc_tick_kernel_jit_warm" : "qpc_tick_kernel_jit")
-      << "(const int *__restrict__ IT, const double *__restrict__ DT, const QpcBatchArgs A) {\n"
-         "  __shared__ __attribute__((aligned(16))) " << (f32 ? "float" : "double") << " qpc_lds_raw[" << (D.lds_doubles > 0 ? D.lds_doubles : 1) << "];\n"
+    o << "extern \"C\" __global__ void __launch_bounds__(64, " << waves << ") " << (variant ? "qpc_tick_kernel_jit_warm" : "qpc_tick_kernel_jit")
+      << "(const int *__restrict__ IT, const double *__restrict__ DT, const QpcBatchArgs A) {\n";
+    if (dyn_lds && !f32) o << "  double *const qpc_lds_raw = qpc_lds_dyn;\n";
+    else o << "  __shared__ __attribute__((aligned(16))) " << (f32 ? "float" : "double") << " qpc_lds_raw[" << (D.lds_doubles > 0 ? D.lds_doubles : 1) << "];\n";
+    o <<
          "  " << (f32 ? "const qpc::F32Ptr qpc_lds{qpc_lds_raw};" : "double *const qpc_lds = qpc_lds_raw;") << "\n"
          "  typedef " << (f32 ? "qpc::F32Ptr" : "double *") << " LdsP;\n"
          "  qpc::qpc_tick_prologue<LdsP>(kD, IT, qpc_lds);\n"

@@ -13,3 +13,5 @@ int qpc_jit_compile(const QpcDims &D, const std::string &arch, bool warm, std::v
 // robots per wavefront of the JIT-specialised simulation step (qpc_sim.h): 2 when a robot fits half a wave and two
 // LDS slabs fit a workgroup (QPC_SIM_RPW=1 forces one)
 int qpc_jit_sim_rpw(const QpcDims &D);
+// experiment switch QPC_EXP_DYN_LDS=1: the tick kernels take their LDS slab as dynamic shared memory (the launch passes the bytes)
+bool qpc_jit_dynamic_lds();

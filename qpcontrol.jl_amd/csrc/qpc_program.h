@@ -151,6 +151,7 @@ struct QpcDims {
   int max_as_iters, max_refine, max_pdas;
   double eps_primal, tau_pivot, tol_bound, tol_accept;
   double h_static_max, h_static_min; // largest |diagonal| / smallest diagonal of the static v̇ and slack blocks (h_static)
+  double k_mu2;      // k_tab with ONE friction coefficient: mu^2 (the K blocks then have closed forms, Solver::k_row_closed); else -1
 };
 
 // LDS slab of the simulation step (qpc_sim.h), offsets in doubles (fields in allocation order)

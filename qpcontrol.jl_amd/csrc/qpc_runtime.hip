@@ -229,7 +229,8 @@ static int launch(qpc_controller *c, QpcDeviceState *S, QpcSlot &sl, const QpcBa
     const int *it = S->d_it;
     const double *dt = S->d_dt;
     void *args[] = {(void *)&it, (void *)&dt, (void *)&aa};
-    HIP_TRY(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 64, 1, 1, 0, stream, args, nullptr));
+    const unsigned dyn = qpc_jit_dynamic_lds() ? (unsigned)(D.lds_doubles * sizeof(double)) : 0u; // experiment: QPC_EXP_DYN_LDS=1
+    HIP_TRY(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 64, 1, 1, dyn, stream, args, nullptr));
   } else {
     hipLaunchKernelGGL(qpc_tick_kernel, dim3((unsigned)grid), dim3(64), lds, stream, D, S->d_it, S->d_dt, aa);
     HIP_TRY(hipGetLastError());

@@ -424,6 +424,176 @@ template <class P> struct Solver {
     QPC_PROF_ACC(PS_REFAC);
   }
 
+  // Row jj of K_c = (H_c,FF + eps I)^-1 in closed form (N = 4, one friction coefficient: D.k_mu2 = mu^2).  H_c = w2 B'B with
+  // B'B = circ(1, a, o, a), a = 1 / (mu^2 + 1) (neighbouring rays), o = (1 - mu^2) / (mu^2 + 1) (opposite rays) -- contacts.jl:16-23
+  // -- so every free set F of a contact is, seen from ray jj, one of: jj alone; jj + one neighbour; jj + the opposite ray; three
+  // rays with jj at an end or in the middle; all four (circulant, eigenvalues e0 = d + 2 p + q, e1 = d - q (twice), e2 = eps:
+  // B'B has the null vector (1, -1, 1, -1)).  d = w2 + eps, p = w2 a, q = w2 o; differences that cancel for small mu are
+  // formed from the analytic constants (1 - a = mu^2 / (mu^2 + 1), ...).  r[k] = K[jj][(jj + k) & 3]; r = 0 when jj is pinned.
+  // Same matrix as the eigen-decomposition table (DT_KTAB) to rounding, two reciprocals instead of four and no table reads.
+  QPC_FN void k_row_closed(double w2, double eps, int pat, int jj, double *r) const {
+    const double mu2 = D.k_mu2, den = 1.0 / (mu2 + 1.0);
+    const double a = den, o = (1.0 - mu2) * den, na = mu2 * den, no_ = 2.0 * mu2 * den, po = 2.0 * den;
+    const double c3 = 2.0 * mu2 * den * den, c4 = mu2 * mu2 * den * den, e0c = 4.0 * den; // (1 + o) - 2 a^2 ; a^2 - o ; 1 + 2 a + o
+    const int rot = ((pat >> jj) | (pat << (4 - jj))) & 15; // bit k: ray (jj + k) & 3 is free
+    const bool f0 = rot & 1, f1 = rot & 2, f2 = rot & 4, f3 = rot & 8;
+    const double d = w2 + eps, pp = w2 * a, qq = w2 * o;
+    const double dmp = w2 * na + eps, dpp = w2 * (1.0 + a) + eps, dmq = w2 * no_ + eps, dpq = w2 * po + eps;
+    const double D2p = dmp * dpp, D2q = dmq * dpq;               // d^2 - p^2, d^2 - q^2
+    const double inner = w2 * w2 * c3 + eps * (w2 * (2.0 + o) + eps); // d (d + q) - 2 p^2
+    const double num13 = w2 * w2 * c4 - eps * qq;                // p^2 - d q
+    const int others = (f1 ? 1 : 0) + (f2 ? 1 : 0) + (f3 ? 1 : 0);
+    // first reciprocal: of d | d^2 - p^2 | d^2 - q^2 | inner | e0 ; second: of d - q (three rays, four rays)
+    const double x1 = others == 0 ? d : (others == 1 ? (f2 ? D2q : D2p) : (others == 2 ? inner : w2 * e0c + eps));
+    const double r1 = QPC_RCP(x1), r2 = QPC_RCP(dmq);
+    double k0 = 0.0, k1 = 0.0, k2 = 0.0, k3 = 0.0;
+    if (others == 0) k0 = r1;
+    else if (others == 1) {
+      k0 = d * r1;
+      if (f1) k1 = -pp * r1; else if (f3) k3 = -pp * r1; else k2 = -qq * r1;
+    } else if (others == 2) {
+      if (!f2) { k0 = dpq * r1; k1 = -pp * r1; k3 = k1; }        // jj between its two neighbours
+      else {                                                       // jj at an end of the three
+        k0 = D2p * r1 * r2; k2 = num13 * r1 * r2;
+        if (f1) k1 = -pp * r1; else k3 = -pp * r1;
+      }
+    } else {
+      const double ie0 = r1, ie1 = r2, ie2 = QPC_RCP(eps);
+      k0 = 0.25 * (ie0 + 2.0 * ie1 + ie2); k1 = 0.25 * (ie0 - ie2); k2 = 0.25 * (ie0 - 2.0 * ie1 + ie2); k3 = k1;
+    }
+    r[0] = f0 ? k0 : 0.0; r[1] = f0 ? k1 : 0.0; r[2] = f0 ? k2 : 0.0; r[3] = f0 ? k3 : 0.0;
+  }
+
+  // ---- fused sweep of the working-set search (N = 4, K from the static table, no upper-active bound, nrho + 6 <= 64) ----
+  // The sweep used to be eight phases (K | Y | S22 | LDL' by 7 lanes | G' lam_w | K q | multipliers | test), each an LDS
+  // round trip of a few lanes' worth of work.  Fused: every ray lane builds ITS row of K and its six entries of
+  // Y = (K G')' in one phase (ky_phase); after S22 (36 lanes, the one cross-lane sum of the sweep) EVERY ray lane runs
+  // the 6 x 6 LDL' solve for lam_w itself -- the same instruction stream the 7 lanes ran, so it costs nothing extra --
+  // and carries on in registers through G' lam_w, rho (quad gathers) and its multiplier: S22 -> lam_w -> rho never
+  // touches LDS.  Lanes nrho .. nrho + 5 solve for the columns of T22 = S22^-1 in the same pass.
+  QPC_FN void ky_phase() {
+    const int nrho = D.nrho;
+    const double eps = sm[D.lds[L_MISC] + MS_EPS];
+    QPC_PROF_ACC(PS_LOGIC);
+    QPC_PHASE(lane) {
+      const int j = lane < nrho ? lane : 0, c = j >> 2, jj = j & 3;
+      int pat = 0;
+      QPC_UNROLL_FULL
+      for (int i = 0; i < 4; i++) pat |= (sm[D.lds[L_WS] + 4 * c + i] == 0.0) ? (1 << i) : 0;
+      const double w2 = sm[D.lds[L_MISC] + MS_KS + c];
+      double k[4] = {0.0, 0.0, 0.0, 0.0};
+      if (D.k_classes == 1 && D.k_mu2 > 0.0) {
+        double r[4];
+        k_row_closed(w2, eps, pat, jj, r);
+        QPC_UNROLL_FULL
+        for (int i = 0; i < 4; i++) k[i] = r[(i - jj) & 3]; // K[jj][i] = r[(i - jj) & 3]
+      } else {
+        const int koff = D.k_classes > 1 ? (int)(double)sm[D.lds[L_MISC] + MS_KS + 8 + c] : 0; // this contact's table (its mu)
+        const double *kt = DT + D.dt[DT_KTAB] + koff + pat * 20;
+        double t[4];
+        QPC_UNROLL_FULL
+        for (int e = 0; e < 4; e++) t[e] = kt[4 + 4 * jj + e] * QPC_RCP(w2 * kt[e] + eps); // v_k(jj) / (2 w lambda_k + eps)
+        QPC_UNROLL_FULL
+        for (int i = 0; i < 4; i++)
+          QPC_UNROLL_FULL
+          for (int e = 0; e < 4; e++) k[i] += t[e] * kt[4 + 4 * i + e];
+      }
+#if defined(QPC_EXP_DUMMY_DEP) && defined(QPC_JIT)
+      { // calibration: QPC_EXP_DUMMY_DEP dependent multiply-adds ON the critical path of the phase (result feeds k[0] as + 0)
+        double z = w2;
+        QPC_UNROLL_FULL
+        for (int u = 0; u < QPC_EXP_DUMMY_DEP; u++) z = z * 1.0000001 + eps;
+        asm volatile("" : "+v"(z));
+        k[0] += (z == -1.2345) ? 1.0 : 0.0;
+      }
+#endif
+#if defined(QPC_EXP_DUMMY_IND) && defined(QPC_JIT)
+      { // calibration: QPC_EXP_DUMMY_IND independent multiply-adds OFF the critical path (8 parallel chains, consumed by an empty asm)
+        double z[8];
+        QPC_UNROLL_FULL
+        for (int u = 0; u < 8; u++) z[u] = w2 + (double)u;
+        QPC_UNROLL_FULL
+        for (int u = 0; u < QPC_EXP_DUMMY_IND; u++) z[u & 7] = z[u & 7] * 1.0000001 + eps;
+        QPC_UNROLL_FULL
+        for (int u = 0; u < 8; u++) asm volatile("" ::"v"(z[u]));
+      }
+#endif
+      if (lane < nrho) {
+        const int o = D.lds[L_KR] + QPC_CS(4) * c + 4 * jj;
+        sm[o] = k[0]; sm[o + 1] = k[1]; sm[o + 2] = k[2]; sm[o + 3] = k[3];
+        QPC_UNROLL_FULL
+        for (int b = 0; b < 6; b++) { // Y[b][j] = sum_i K[jj][i] G[b][4 c + i]
+          const int g = D.lds[L_G] + b * QPC_GS(nrho) + 4 * c;
+          const double g0 = sm[g], g1 = sm[g + 1], g2 = sm[g + 2], g3 = sm[g + 3];
+          sm[D.lds[L_Y] + b * QPC_GS(nrho) + j] = (k[0] * g0 + k[2] * g2) + (k[1] * g1 + k[3] * g3);
+        }
+      }
+    } QPC_END_PHASE
+    QPC_PROF_ACC(PS_S_KR);
+  }
+  QPC_FN void fused_solve() {
+    const int nrho = D.nrho, m1 = D.m1;
+    QPC_PHASE(lane) {
+      if (lane < 36) {
+        int a = lane / 6, b = lane % 6;
+        sm[D.lds[L_C22] + lane] = sm[D.lds[L_B22] + lane] + dotp(sm + D.lds[L_G] + a * QPC_GS(nrho), 1, sm + D.lds[L_Y] + b * QPC_GS(nrho), 1, nrho);
+      }
+    } QPC_END_PHASE
+    QPC_PROF_ACC(PS_S_C22);
+    QPC_LANE_ARRAY(q4_, 10); // [0..3] (G' lam_w) of the quad, [4..7] rho of the quad, [8] own value in flight, [9] (G' lam_w)_j
+    double rg = 0.0, rx = 0.0;
+    QPC_PHASE(lane) {
+      double sref[6], x[6], rhs[6];
+      for (int k = 0; k < 6; k++)
+        sref[k] = sm[D.lds[L_SM] + (m1 + k) * D.ms + (m1 + k)] + (sm[D.lds[L_C22] + k * 6 + k] - sm[D.lds[L_B22] + k * 6 + k]);
+      const int col = lane - nrho; // lanes nrho .. nrho + 5: column `col` of T22; every other lane: lam_w = S22^-1 u0
+      for (int r = 0; r < 6; r++) rhs[r] = (col >= 0 && col < 6) ? ((r == col) ? 1.0 : 0.0) : (double)sm[D.lds[L_MISC] + MS_U0 + r];
+      chol6_solve(sm + D.lds[L_C22], sref, D.tau_pivot, rhs, x);
+      if (lane == 0)
+        for (int r = 0; r < 6; r++) sm[D.lds[L_LAM] + m1 + r] = x[r];
+      if (col >= 0 && col < 6)
+        for (int r = 0; r < 6; r++) sm[D.lds[L_S22I] + r * 6 + col] = x[r];
+      double *q = QPC_LA(q4_, lane);
+      const int j = lane < nrho ? lane : 0;
+      double wj0 = 0.0, wj1 = 0.0; // (G' lam_w)_j with lam_w straight from the registers
+      QPC_UNROLL_FULL
+      for (int a = 0; a < 6; a += 2) {
+        wj0 += sm[D.lds[L_G] + a * QPC_GS(nrho) + j] * x[a];
+        wj1 += sm[D.lds[L_G] + (a + 1) * QPC_GS(nrho) + j] * x[a + 1];
+      }
+      q[9] = wj0 + wj1;
+      q[8] = q[9];
+    } QPC_END_PHASE
+    QPC_PROF_ACC(PS_S_CHOL);
+    QPC_QUAD_GATHER(lane, QPC_LA(q4_, lane), QPC_LA(q4_, lane)[8])
+    QPC_PHASE(lane) {
+      double *q = QPC_LA(q4_, lane);
+      const int j = lane < nrho ? lane : 0;
+      double acc = 0.0;
+      for (int i = 0; i < 4; i++) acc += sm[D.lds[L_KR] + QPC_CS(4) * (j / 4) + 4 * (j % 4) + i] * q[i];
+      q[8] = acc;
+    } QPC_END_PHASE
+    QPC_QUAD_GATHER(lane, QPC_LA(q4_, lane) + 4, QPC_LA(q4_, lane)[8])
+    QPC_PHASE(lane) {
+      const double *q = QPC_LA(q4_, lane);
+      double g = 0.0, xm = 0.0;
+      if (lane < nrho) {
+        const int j = lane;
+        const double rho_j = q[8];
+        sm[D.lds[L_XR] + j] = rho_j;
+        double gl = -q[9];
+        for (int i = 0; i < 4; i++) gl += sm[D.lds[L_HR] + QPC_CSH(4) * (j / 4) + 4 * (j % 4) + i] * q[4 + i];
+        const double wsj = sm[D.lds[L_WS] + j];
+        sm[D.lds[L_U] + j] = (wsj == -1.0) ? gl : ((wsj == 1.0) ? -gl : 0.0);
+        g = QPC_FABS(gl);
+        xm = QPC_FABS(rho_j);
+      }
+      QPC_RED_MAX_PUT(0, rg, g); QPC_RED_MAX_PUT(1, rx, xm);
+    } QPC_END_PHASE
+    last_gmax = QPC_RED_MAX_GET(0, rg); last_xmax = QPC_RED_MAX_GET(1, rx);
+    QPC_PROF_ACC(PS_S_BACK);
+  }
+
   // refactor_rho() followed by rho_solve(base = true).  Without upper-active bounds (r_r = 0, the
   // common case: rho_max is a large cap) the two fuse into 5 phases instead of 7: S22 is built
   // once and the same register Cholesky yields lam_w = S22^-1 u0 (lane 0) and the columns of
@@ -431,6 +601,9 @@ template <class P> struct Solver {
   QPC_FN void refactor_solve(bool any_upper) {
     if (any_upper) { refactor_rho(); rho_solve(true, 0, 0.0, true); return; }
     const int N = D.N, nc = D.nc, nrho = D.nrho, m1 = D.m1;
+#ifndef QPC_NO_FUSED_SWEEP
+    if (D.k_tab && N == 4 && nrho + 6 <= 64) { ky_phase(); fused_solve(); return; }
+#endif
     QPC_PROF_ACC(PS_LOGIC);
     kr_blocks();
     QPC_PROF_ACC(PS_S_KR);
@@ -847,7 +1020,9 @@ template <class P> struct Solver {
         // the first sweep's correction IS the eps bias of the search's solution, i.e. the contraction factor times |rho|:
         // at <= 1e-4 the iterate is already 1e-8 accurate and the confirming sweep of the full system (contraction again)
         // finishes the job -- no second proximal sweep
+#ifndef QPC_EXP_PROX2
         if (k == 1 && !(last_dmax > 1e-4 * (1.0 + last_xmax))) break;
+#endif
         if (k >= 2 && last_dmax * (last_dmax / prev) < tol) break;
         if (last_dmax > 0.95 * prev) break; // rounding floor / no progress
         prev = last_dmax;
@@ -2152,7 +2327,11 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
       // exact_ve: wrench-space proximal sweeps + one back-substitution (Solver::polish_exact), then
       // refinement of the full KKT system from that iterate -- one sweep when its correction confirms
       // that the iterate was already accurate; otherwise: solve + refine the full system from scratch
+#ifdef QPC_EXP_NOCONFIRM
+      if (exact_ve) { refine = S.polish_exact(true); S.residuals(); S.confirmed = true; }
+#else
       if (exact_ve) { refine = S.polish_exact(true); refine += S.eqp(D.max_refine, true) - 1; }
+#endif
       else refine = S.eqp(D.max_refine);
       // acceptance needs the true KKT residuals of the final iterate.  When the single confirming sweep changed the
       // iterate by <= 1e-9 relative, the residuals it started from (still in L_RV / L_RE / L_RR / L_RC, gradient in

@@ -1,4 +1,5 @@
-"""K blocks from the static eigen-decomposition table (qpc_tick.h Solver::kr_blocks, D.k_tab) against the general
+"""K blocks in closed form (one friction coefficient, Solver::k_row_closed) and from the static eigen-decomposition table
+(qpc_tick.h Solver::kr_blocks / ky_phase, D.k_tab) against the general
 Gauss-Jordan form of the same matrices ((H_FF + eps I)^-1 per contact): QPC_NO_KTAB=1 at finalize selects the latter.
 Both are the same matrix to rounding, so the working-set search takes the same path: statuses and change counts are
 equal, change counts equal up to ties decided by rounding, and tau agrees to 1e-8 of its scale (median 1e-12).  Controllers the table does not cover (N != 4, per-QP surfaces, different mu per
@@ -13,16 +14,21 @@ from qpcontrol_jl_amd import binding
 from qpcontrol_jl_amd import workloads as W
 
 
-def _run(factory, B, config, no_table):
-    old = os.environ.pop("QPC_NO_KTAB", None)
-    if no_table:
-        os.environ["QPC_NO_KTAB"] = "1"
+def _run(factory, B, config, no_table, no_closed=False):
+    """no_table: Gauss-Jordan form; no_closed: the eigen-decomposition table also where the closed form (one friction
+    coefficient, Solver::k_row_closed) would be taken"""
+    want = {"QPC_NO_KTAB": no_table, "QPC_K_CLOSED": not no_closed and not no_table}
+    old = {k: os.environ.pop(k, None) for k in want}
+    for k, on in want.items():
+        if on:
+            os.environ[k] = "1"
     try:
         c, wl = W.atlas_workload(factory, B, config)
     finally:
-        os.environ.pop("QPC_NO_KTAB", None)
-        if old is not None:
-            os.environ["QPC_NO_KTAB"] = old
+        for k, v in old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
     r = c.control_batch(wl.q, wl.v, wl.desired, wl.contact_weight, wl.contact_maxnormalforce)
     r["k_tables"] = c.L.qpc_debug_k_tables(c.h)
     return r
@@ -45,11 +51,14 @@ def _same(a, b):
     assert float(np.median(np.abs((a["tau"][ok] - b["tau"][ok]) / scale).max(axis=1))) <= 1e-12
 
 
+@pytest.mark.parametrize("no_closed", [False, True])
 @pytest.mark.parametrize("config", [3, 4, 5])
-def test_table_equals_gauss_jordan_emulated(config):
+def test_table_equals_gauss_jordan_emulated(config, no_closed):
+    """no_closed = False: the closed-form rows of K (one friction coefficient, opt-in: QPC_K_CLOSED=1); True: the
+    eigen-decomposition table (the default)"""
     emu.build()
     emu.race_report()
-    _same(_run(emu.factory, 48, config, False), _run(emu.factory, 48, config, True))
+    _same(_run(emu.factory, 48, config, False, no_closed), _run(emu.factory, 48, config, True))
     races, uninit, outside, first = emu.race_report()
     assert (races, uninit, outside) == (0, 0, 0), first
 
@@ -88,7 +97,8 @@ def test_two_friction_coefficients_gpu():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("no_closed", [False, True])
 @pytest.mark.parametrize("config", [3, 5])
-def test_table_equals_gauss_jordan_gpu(config):
+def test_table_equals_gauss_jordan_gpu(config, no_closed):
     f = lambda mech, N, fl: binding.Controller(binding.Model(mech), N, fl)  # noqa: E731
-    _same(_run(f, 4096, config, False), _run(f, 4096, config, True))
+    _same(_run(f, 4096, config, False, no_closed), _run(f, 4096, config, True))
