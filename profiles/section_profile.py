@@ -34,7 +34,8 @@ def main():
 
     def factory(mech, N, fl):
         return binding.Controller(binding.Model(mech, lib), N, fl)
-    ctrl, wl = W.atlas_workload(factory, B, cfg)
+    fused = "--fused-laws" in sys.argv  # StandingController laws evaluated in the kernel (no `desired` input)
+    ctrl, wl = W.atlas_workload(factory, B, cfg, fused_laws=fused)
     prof = torch.zeros((B, len(NAMES)), dtype=torch.int64, device="cuda")
     ctrl.L.qpc_debug_set_profile_buffer.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     ctrl.L.qpc_debug_set_profile_buffer(ctrl.h, ctypes.c_void_p(prof.data_ptr()))
@@ -48,7 +49,7 @@ def main():
     st = torch.zeros((B,), dtype=torch.int32, device=dev)
     its = torch.zeros((B,), dtype=torch.int32, device=dev)
     vp = ctypes.c_void_p
-    rc = ctrl.L.qpc_control_batch_device(ctrl.h, B, vp(t["q"].data_ptr()), vp(t["v"].data_ptr()), vp(t["d"].data_ptr()),
+    rc = ctrl.L.qpc_control_batch_device(ctrl.h, B, vp(t["q"].data_ptr()), vp(t["v"].data_ptr()), vp(0) if fused else vp(t["d"].data_ptr()),
                                          vp(t["cw"].data_ptr()) if lay.n_contacts else vp(0), vp(t["cm"].data_ptr()) if lay.n_contacts else vp(0),
                                          vp(0), vp(0), vp(tau.data_ptr()), vp(vd.data_ptr()), vp(0), vp(st.data_ptr()), vp(its.data_ptr()), vp(0))
     assert rc == 0
@@ -57,7 +58,7 @@ def main():
     torch.cuda.synchronize()
     p = prof.cpu().numpy().astype(np.float64)
     tot = p.sum(1)
-    out = {"config": cfg, "B": B, "mean_cycles_per_qp": float(tot.mean()), "p99_cycles": float(np.percentile(tot, 99)),
+    out = {"config": cfg, "B": B, "fused_laws": fused, "mean_cycles_per_qp": float(tot.mean()), "p99_cycles": float(np.percentile(tot, 99)),
            "mean_iters": float((r["iters"] % 1000).mean()),
            "sections": {n: {"mean_cycles": float(p[:, i].mean()), "share": float(p[:, i].sum() / tot.sum())}
                         for i, n in enumerate(NAMES)}}

@@ -351,10 +351,11 @@ int qpc_compile_program(qpc_controller *c) {
   {
     std::vector<int> law_i(3 * (size_t)c->n_desired, 0);
     std::vector<double> law_d(3 * (size_t)c->n_desired, 0.0);
-    D.n_des_inputs = 0; D.n_des_late = 0;
+    D.n_des_inputs = 0; D.n_des_late = 0; D.law_mask = 0;
     for (auto &t : c->tasks)
       for (int a = 0; a < t.dim; a++) {
         const int i = t.des_off + a;
+        D.law_mask |= 1 << t.law;
         law_i[3 * i] = t.law; law_d[3 * i] = t.kp; law_d[3 * i + 1] = t.kd;
         switch (t.law) {
           case QPC_LAW_INPUT: D.n_des_inputs++; break;

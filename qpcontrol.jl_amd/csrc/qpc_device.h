@@ -35,28 +35,8 @@ __device__ __forceinline__ int qpc_opaque_lane() {
 #define QPC_SINCOS(x, s, c) qpc_sincos((double)(x), (s), (c))
 #define QPC_SQRT(x) sqrt((double)(x))
 #define QPC_FABS(x) fabs((double)(x))
-#define QPC_ATAN2(y, x) atan2((double)(y), (double)(x))
-// sin and cos of a joint angle together: three-term Cody-Waite reduction by pi/2 (exact products up to |x| ~ 1.6e6 rad)
-// and the fdlibm kernel polynomials on [-pi/4, pi/4] -- about 40 straight-line fp64 instructions, < 1 ulp-ish (1e-16
-// absolute), against several hundred for the library sincos, whose Payne-Hanek path for huge arguments also needs
-// private (scratch) memory.  Beyond ~1e6 rad the reduction loses accuracy gracefully (no joint angle lives there).
-__device__ __forceinline__ void qpc_sincos(double x, double &s, double &c) {
-  const double kf = rint(x * 6.36619772367581382433e-01); // x * 2/pi
-  double r = fma(-kf, 1.57079632673412561417e+00, x);     // pi/2 in three 33-bit pieces (fdlibm pio2_1..3)
-  r = fma(-kf, 6.07710050630396597660e-11, r);
-  r = fma(-kf, 2.02226624871116645580e-21, r);
-  const int q = (int)kf & 3;
-  const double z = r * r;
-  const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06),
-                                          -1.98412698298579493134e-04), 8.33333333332248946124e-03), -1.66666666666666324348e-01);
-  const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07),
-                                          2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
-  const double sr = fma(r * z, ps, r);
-  const double cr = fma(z * z, pc, fma(-0.5, z, 1.0));
-  const double s0 = (q & 1) ? cr : sr, c0 = (q & 1) ? sr : cr;
-  s = (q & 2) ? -s0 : s0;
-  c = ((q + 1) & 2) ? -c0 : c0;
-}
+#define QPC_ATAN2(y, x) qpc_atan2((double)(y), (double)(x))
+#include "qpc_math.h" // qpc_sincos, qpc_atan2: straight-line fp64 elementary functions (no scratch, few registers)
 // Pivot reciprocals on the serial chains of the small factorizations: hardware seed (v_rcp_f64 /
 // v_rsq_f64, ~24 bits) + two Newton steps (~1 ulp) instead of the IEEE sqrt + divide sequences
 // (about a third of the dependent instructions per pivot).

@@ -66,7 +66,7 @@ std::string qpc_jit_source(const QpcDims &D, bool warm) {
   o << "static constexpr QpcDims kD = {" << D.nb << "," << D.nq << "," << D.nv << "," << D.nf << "," << D.npin << ","
     << D.nsj << "," << D.ntask << "," << D.nc << "," << D.N << "," << D.nrho << "," << D.ne << "," << D.m << ","
     << D.m1 << "," << D.nw << "," << D.floating << "," << D.fv0 << "," << D.n_desired << "," << D.n_tw << ","
-    << D.n_surf << "," << D.maxdepth << "," << D.n_items << "," << D.ve_exact_ok << "," << D.n_des_inputs << "," << D.n_des_late << "," << D.maxd << "," << D.crb_full_body << "," << D.nfs << "," << D.ms << "," << D.m1s << "," << D.wsize << "," << D.h_static << "," << D.k_tab << "," << D.k_classes << ",";
+    << D.n_surf << "," << D.maxdepth << "," << D.n_items << "," << D.ve_exact_ok << "," << D.n_des_inputs << "," << D.n_des_late << "," << D.law_mask << "," << D.maxd << "," << D.crb_full_body << "," << D.nfs << "," << D.ms << "," << D.m1s << "," << D.wsize << "," << D.h_static << "," << D.k_tab << "," << D.k_classes << ",";
   put_ints(o, D.k_class, 16); o << ",";
   put_ints(o, D.it, IT_COUNT); o << ",";
   put_ints(o, D.dt, DT_COUNT); o << ",";

@@ -133,6 +133,7 @@ struct QpcDims {
   int n_items; // (row block, free column) items of the constraint-matrix assembly (IT_MCODE)
   int ve_exact_ok; // no matrix-weighted slack block: the v̇ / slack blocks of H may be used unregularised (exact polish)
   int n_des_inputs, n_des_late; // desired entries read from the caller / computed after the kinematics (COM, orientation laws)
+  int law_mask;      // bit k: some desired entry follows law kind k (QPC_LAW_*): the specialised kernel only carries the laws in use
   int maxd; // row length of IT_ANC_TAB
   int crb_full_body; // body whose subtree is the whole mechanism and owns free columns (its composite inertia = total), or -1
   int nfs, ms, m1s;  // padded leading dimensions (odd) of L_M, L_SM, L_X

@@ -1204,6 +1204,41 @@ QPC_FN void se3_pd_law(PR rec, const double *Hb, const double *Ha, const double 
   }
 }
 
+// Desired entries from laws that need the kinematics (standing.jl:60-77: centre-of-mass PD, pelvis orientation PD; SE3PDController
+// on the device), lane = desired entry: runs after the momentum phase (it reads L_AMOM, MS_COM, L_H, L_T) and before the rows of the
+// assembly read L_DES
+template <class P> QPC_FN void desired_late(const QpcDims &D, const int *IT, const double *DT, P sm, int lane) {
+  const int nv = D.nv, MISC = D.lds[L_MISC];
+  for (int i = lane; i < D.n_desired; i += 64) {
+    const int *li = IT + D.it[IT_LAW] + 3 * i;
+    const double *lw = DT + D.dt[DT_LAW] + 3 * i;
+    // (D.law_mask: the JIT-specialised kernel drops the laws this controller does not use -- the SE(3) law alone is ~1.4 k
+    //  instructions and its live values used to push the register allocation of the whole tick into scratch)
+    if (((D.law_mask >> QPC_LAW_COM_PD) & 1) && li[0] == QPC_LAW_COM_PD) { // m c̈,  c̈ = -kp (c - c_ref) - kd h_lin / m
+      const int a = li[1];
+      const double hl = dotp(sm + D.lds[L_AMOM] + (3 + a) * nv, 1, sm + D.lds[L_V], 1, nv); // linear momentum
+      const double mt = DT[D.dt[DT_GRAV] + 3];
+      sm[D.lds[L_DES] + i] = mt * (-lw[0] * (sm[MISC + MS_COM + a] - lw[2])) - lw[1] * hl;
+    } else if (((D.law_mask >> QPC_LAW_ORIENTATION_PD) & 1) && li[0] == QPC_LAW_ORIENTATION_PD) { // -kp rotation_vector(R) - kd R' omega (body frame)
+      const int body = li[1], a = li[2];
+      double H[12], rv[3];
+      ldH(sm, D, body, H);
+      rotation_vector(H, rv);
+      double wb = 0.0;
+      for (int r = 0; r < 3; r++) wb += H[3 * r + a] * sm[D.lds[L_T] + 6 * body + r];
+      sm[D.lds[L_DES] + i] = -lw[0] * rv[a] - lw[1] * wb;
+    } else if (((D.law_mask >> QPC_LAW_SE3_PD) & 1) && li[0] == QPC_LAW_SE3_PD) { // SE3PDController on the device (se3pdcontroller.jl:13-18), lane = component
+      const int body = (li[1] & 255) - 1, base = ((li[1] >> 8) & 255) - 1, a = (li[1] >> 16) & 7, rec0 = li[2] + 6;
+      double Hb[12], Ha[12], Tb[6], Ta[6], out[6];
+      ldH(sm, D, body, Hb); ldH(sm, D, base, Ha);
+      ld6(sm, D.lds[L_T], body, Tb); ld6(sm, D.lds[L_T], base, Ta);
+      const double *lwa = DT + D.dt[DT_LAW] + 3 * li[2], *lwl = lwa + 9; // gains of entries 0 (angular) and 3 (linear)
+      se3_pd_law(sm + D.lds[L_DES] + rec0, Hb, Ha, Tb, Ta, lwa[0], lwa[1], lwl[0], lwl[1], out);
+      sm[D.lds[L_DES] + i] = out[a];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // the tick
 // ------------------------------------------------------------------------------------------
@@ -1269,7 +1304,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
   double hscale = 0.0, hinvmax = 0.0, eps = 0.0, eps_ve = 0.0;
   unsigned long long bbad_in = 0ull, bneg_cap = 0ull;
   bool exact_ve = false, h_fast = false;
-  const bool h_static_path = D.h_static && D.n_des_late == 0;
+  const bool h_static_path = D.h_static;
   QPC_PHASE(lane) {
     int *mt = QPC_LI(M.v, lane);
     {
@@ -1576,6 +1611,10 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
 
   QPC_PROF_ACC(PS_KIN);
   QPC_STOP(1)
+  if (h_fast && D.n_des_late) { // static Hessian blocks: the laws get a phase of their own (the general path evaluates them in its
+                                // regularisation-scale phase below)
+    QPC_PHASE(lane) { desired_late(D, IT, DT, sm, lane); } QPC_END_PHASE
+  }
   // regularisation scale: eps = eps_primal * max diagonal of the Hessian
   if (!h_fast) {
   QPC_PHASE(lane) {
@@ -1593,34 +1632,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
         double w = (sm[D.lds[L_CMAX] + c] > 0.0) ? 2.0 * QPC_FABS(sm[D.lds[L_CW] + c]) : 0.0;
         h = w > h ? w : h;
       }
-    if (D.n_des_late) { // desired laws that need the kinematics (standing.jl:60-77), lane = desired entry
-      for (int i = lane; i < D.n_desired; i += 64) {
-        const int *li = IT + D.it[IT_LAW] + 3 * i;
-        const double *lw = DT + D.dt[DT_LAW] + 3 * i;
-        if (li[0] == QPC_LAW_COM_PD) { // m c̈,  c̈ = -kp (c - c_ref) - kd h_lin / m
-          const int a = li[1];
-          const double hl = dotp(sm + D.lds[L_AMOM] + (3 + a) * nv, 1, sm + D.lds[L_V], 1, nv); // linear momentum
-          const double mt = DT[D.dt[DT_GRAV] + 3];
-          sm[D.lds[L_DES] + i] = mt * (-lw[0] * (sm[MISC + MS_COM + a] - lw[2])) - lw[1] * hl;
-        } else if (li[0] == QPC_LAW_ORIENTATION_PD) { // -kp rotation_vector(R) - kd R' omega (body frame)
-          const int body = li[1], a = li[2];
-          double H[12], rv[3];
-          ldH(sm, D, body, H);
-          rotation_vector(H, rv);
-          double wb = 0.0;
-          for (int r = 0; r < 3; r++) wb += H[3 * r + a] * sm[D.lds[L_T] + 6 * body + r];
-          sm[D.lds[L_DES] + i] = -lw[0] * rv[a] - lw[1] * wb;
-        } else if (li[0] == QPC_LAW_SE3_PD) { // SE3PDController on the device (se3pdcontroller.jl:13-18), lane = component
-          const int body = (li[1] & 255) - 1, base = ((li[1] >> 8) & 255) - 1, a = (li[1] >> 16) & 7, rec0 = li[2] + 6;
-          double Hb[12], Ha[12], Tb[6], Ta[6], out[6];
-          ldH(sm, D, body, Hb); ldH(sm, D, base, Ha);
-          ld6(sm, D.lds[L_T], body, Tb); ld6(sm, D.lds[L_T], base, Ta);
-          const double *lwa = DT + D.dt[DT_LAW] + 3 * li[2], *lwl = lwa + 9; // gains of entries 0 (angular) and 3 (linear)
-          se3_pd_law(sm + D.lds[L_DES] + rec0, Hb, Ha, Tb, Ta, lwa[0], lwa[1], lwl[0], lwl[1], out);
-          sm[D.lds[L_DES] + i] = out[a];
-        }
-      }
-    }
+    if (D.n_des_late) desired_late(D, IT, DT, sm, lane); // desired laws that need the kinematics (standing.jl:60-77), lane = desired entry
     QPC_RED_MAX_PUT(0, hscale, h);
   } QPC_END_PHASE
   hscale = QPC_RED_MAX_GET(0, hscale);

@@ -34,7 +34,8 @@ def main():
         raise StopIteration
     binding.Controller.finalize = fin
     try:
-        W.atlas_workload(lambda mech, N, fl: binding.Controller(binding.Model(mech), N, fl), 4, config)
+        W.atlas_workload(lambda mech, N, fl: binding.Controller(binding.Model(mech), N, fl), 4, config,
+                         fused_laws=os.environ.get("QPC_OFFLINE_FUSED") == "1")
     except StopIteration:
         pass
     binding.Controller.finalize = real
