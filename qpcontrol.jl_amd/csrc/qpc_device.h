@@ -32,6 +32,19 @@ __device__ __forceinline__ int qpc_opaque_lane() {
 #define QPC_MACRO_LANE ((int)(threadIdx.x & 63))
 #endif
 #define QPC_END_PHASE } __syncthreads();
+// SOFT end of a phase: the following block only depends on this one through the lane's own registers, DPP exchanges or LDS
+// words the SAME lane wrote -- no cross-lane LDS traffic in either direction until the next hard end.  Nothing is emitted: the
+// compiler may interleave the two blocks (loads of the next one hoisted over the arithmetic of this one).  The emulator keeps the
+// race detector's phase number across a soft end, so a cross-lane dependency inside such a group is reported as a race.
+// Opt-in (-DQPC_SOFT_PHASES): measured on MI355X with the fused sweeps of the search joined this way, 28.93 against 28.99 M
+// solves/s with hard ends -- the compiler does not turn the freedom into overlap, so the default stays the conservative form.
+#ifdef QPC_SOFT_PHASES
+#define QPC_END_PHASE_SOFT }
+#else
+#define QPC_END_PHASE_SOFT QPC_END_PHASE
+#endif
+// hard boundary without a block (after a group of soft-joined blocks, before code that reads other lanes' LDS words)
+#define QPC_PHASE_SYNC __syncthreads();
 #define QPC_SINCOS(x, s, c) qpc_sincos((double)(x), (s), (c))
 #define QPC_SQRT(x) sqrt((double)(x))
 #define QPC_FABS(x) fabs((double)(x))
@@ -52,6 +65,18 @@ __device__ __forceinline__ double qpc_rsqrt(double x) {
   y = fma(y, 0.5 * fma(-x * y, y, 1.0), y);
   return y;
 }
+// one Newton step (~2^-45): the reciprocals of the working-set SEARCH (pivots of the 6 x 6 wrench-space solve, K rows) -- the
+// search only has to pick the working set; the final solve refines against the true KKT residuals
+__device__ __forceinline__ double qpc_rcp1(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = fma(y, fma(-x, y, 1.0), y);
+  return y;
+}
+#ifdef QPC_RCP_SEARCH_FULL // (measured: 28.80 M solves/s with two steps, 29.01 M with one; same working-set changes)
+#define QPC_RCP_SEARCH(x) qpc_rcp((double)(x))
+#else
+#define QPC_RCP_SEARCH(x) qpc_rcp1((double)(x))
+#endif
 #define QPC_RCP(x) qpc_rcp((double)(x))
 #define QPC_RSQRT(x) qpc_rsqrt((double)(x))
 #define QPC_UNROLL_FULL _Pragma("unroll")

@@ -268,7 +268,7 @@ template <class P> QPC_FN void chol6_solve(P Sin, const double *sref, double tau
     QPC_UNROLL_FULL
     for (int j = 0; j < k; j++) d -= U[k][j] * L[k][j];
     const bool ok = d > tau * (sref[k] > 1e-300 ? sref[k] : 1e-300);
-    invd[k] = ok ? QPC_RCP(d) : 0.0; // 1 / d_k
+    invd[k] = ok ? QPC_RCP_SEARCH(d) : 0.0; // 1 / d_k
     QPC_UNROLL_FULL
     for (int i = k + 1; i < 6; i++) {
       double t = U[i][k];
@@ -369,7 +369,7 @@ template <class P> struct Solver {
         const double w2 = sm[D.lds[L_MISC] + MS_KS + c];
         double t[4], k[4] = {0.0, 0.0, 0.0, 0.0};
         QPC_UNROLL_FULL
-        for (int e = 0; e < 4; e++) t[e] = kt[4 + 4 * jj + e] * QPC_RCP(w2 * kt[e] + eps); // v_k(jj) / (2 w lambda_k + eps)
+        for (int e = 0; e < 4; e++) t[e] = kt[4 + 4 * jj + e] * QPC_RCP_SEARCH(w2 * kt[e] + eps); // v_k(jj) / (2 w lambda_k + eps)
         QPC_UNROLL_FULL
         for (int i = 0; i < 4; i++)
           QPC_UNROLL_FULL
@@ -471,15 +471,27 @@ template <class P> struct Solver {
   // the 6 x 6 LDL' solve for lam_w itself -- the same instruction stream the 7 lanes ran, so it costs nothing extra --
   // and carries on in registers through G' lam_w, rho (quad gathers) and its multiplier: S22 -> lam_w -> rho never
   // touches LDS.  Lanes nrho .. nrho + 5 solve for the columns of T22 = S22^-1 in the same pass.
-  QPC_FN void ky_phase() {
+  // from_mask: the free rays come as a lane mask (bit j: rho_j free) from the ballot of the test that has just changed the
+  // working set -- no LDS traffic between the test and this phase, which may then follow it across a SOFT phase end
+  QPC_FN bool fused_ok() const {
+#ifdef QPC_NO_FUSED_SWEEP
+    return false;
+#else
+    return D.k_tab && D.N == 4 && D.nrho + 6 <= 64;
+#endif
+  }
+  QPC_FN void ky_phase(bool from_mask = false, unsigned long long bfree = 0ull) {
     const int nrho = D.nrho;
     const double eps = sm[D.lds[L_MISC] + MS_EPS];
     QPC_PROF_ACC(PS_LOGIC);
     QPC_PHASE(lane) {
       const int j = lane < nrho ? lane : 0, c = j >> 2, jj = j & 3;
       int pat = 0;
-      QPC_UNROLL_FULL
-      for (int i = 0; i < 4; i++) pat |= (sm[D.lds[L_WS] + 4 * c + i] == 0.0) ? (1 << i) : 0;
+      if (from_mask) pat = (int)((bfree >> (4 * c)) & 15ull);
+      else {
+        QPC_UNROLL_FULL
+        for (int i = 0; i < 4; i++) pat |= (sm[D.lds[L_WS] + 4 * c + i] == 0.0) ? (1 << i) : 0;
+      }
       const double w2 = sm[D.lds[L_MISC] + MS_KS + c];
       double k[4] = {0.0, 0.0, 0.0, 0.0};
       if (D.k_classes == 1 && D.k_mu2 > 0.0) {
@@ -492,7 +504,7 @@ template <class P> struct Solver {
         const double *kt = DT + D.dt[DT_KTAB] + koff + pat * 20;
         double t[4];
         QPC_UNROLL_FULL
-        for (int e = 0; e < 4; e++) t[e] = kt[4 + 4 * jj + e] * QPC_RCP(w2 * kt[e] + eps); // v_k(jj) / (2 w lambda_k + eps)
+        for (int e = 0; e < 4; e++) t[e] = kt[4 + 4 * jj + e] * QPC_RCP_SEARCH(w2 * kt[e] + eps); // v_k(jj) / (2 w lambda_k + eps)
         QPC_UNROLL_FULL
         for (int i = 0; i < 4; i++)
           QPC_UNROLL_FULL
@@ -531,6 +543,7 @@ template <class P> struct Solver {
     } QPC_END_PHASE
     QPC_PROF_ACC(PS_S_KR);
   }
+  // ends SOFT: what follows may only read this lane's own LDS words (rho_j, u_j, ...) until the caller's QPC_PHASE_SYNC
   QPC_FN void fused_solve() {
     const int nrho = D.nrho, m1 = D.m1;
     QPC_PHASE(lane) {
@@ -563,16 +576,18 @@ template <class P> struct Solver {
       }
       q[9] = wj0 + wj1;
       q[8] = q[9];
-    } QPC_END_PHASE
+    } QPC_END_PHASE_SOFT
     QPC_PROF_ACC(PS_S_CHOL);
     QPC_QUAD_GATHER(lane, QPC_LA(q4_, lane), QPC_LA(q4_, lane)[8])
     QPC_PHASE(lane) {
       double *q = QPC_LA(q4_, lane);
-      const int j = lane < nrho ? lane : 0;
       double acc = 0.0;
-      for (int i = 0; i < 4; i++) acc += sm[D.lds[L_KR] + QPC_CS(4) * (j / 4) + 4 * (j % 4) + i] * q[i];
+      if (lane < nrho) { // (idle lanes must not touch K: lane 0 rewrites its row further down this soft-joined group)
+        const int j = lane;
+        for (int i = 0; i < 4; i++) acc += sm[D.lds[L_KR] + QPC_CS(4) * (j / 4) + 4 * (j % 4) + i] * q[i];
+      }
       q[8] = acc;
-    } QPC_END_PHASE
+    } QPC_END_PHASE_SOFT
     QPC_QUAD_GATHER(lane, QPC_LA(q4_, lane) + 4, QPC_LA(q4_, lane)[8])
     QPC_PHASE(lane) {
       const double *q = QPC_LA(q4_, lane);
@@ -589,7 +604,7 @@ template <class P> struct Solver {
         xm = QPC_FABS(rho_j);
       }
       QPC_RED_MAX_PUT(0, rg, g); QPC_RED_MAX_PUT(1, rx, xm);
-    } QPC_END_PHASE
+    } QPC_END_PHASE_SOFT
     last_gmax = QPC_RED_MAX_GET(0, rg); last_xmax = QPC_RED_MAX_GET(1, rx);
     QPC_PROF_ACC(PS_S_BACK);
   }
@@ -602,7 +617,7 @@ template <class P> struct Solver {
     if (any_upper) { refactor_rho(); rho_solve(true, 0, 0.0, true); return; }
     const int N = D.N, nc = D.nc, nrho = D.nrho, m1 = D.m1;
 #ifndef QPC_NO_FUSED_SWEEP
-    if (D.k_tab && N == 4 && nrho + 6 <= 64) { ky_phase(); fused_solve(); return; }
+    if (fused_ok()) { ky_phase(); fused_solve(); QPC_PHASE_SYNC return; }
 #endif
     QPC_PROF_ACC(PS_LOGIC);
     kr_blocks();
@@ -2095,12 +2110,15 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
     QPC_PROF_ACC(PS_L_U0);
     S.refactor_solve(any_upper);
     // ---- phase A: primal-dual active-set sweeps (multi-change)
+    const bool fsearch = S.fused_ok();
+    bool soft_tail = false; // the last sweep ended on a SOFT phase end: a hard one is due before other lanes' words are read
     for (int pd = 0; pd < D.max_pdas; pd++) {
       const double gscale = 1.0 + S.last_gmax, tolb = D.tol_bound * (1.0 + S.last_xmax); // U is current (rho_solve)
       double rchg = 0.0, rup = 0.0;
-      unsigned long long bchg = 0ull, bup = 0ull;
+      unsigned long long bchg = 0ull, bup = 0ull, bfree = 0ull;
       QPC_PHASE(lane) {
         double changed = 0.0, up = 0.0;
+        bool isfree = false; // this lane's ray is free in the NEW working set (fused sweeps: one ray per lane)
         for (int j = lane; j < nrho; j += 64) {
           double w = sm[D.lds[L_WS] + j], hi = sm[D.lds[L_HI] + j], x = sm[D.lds[L_XR] + j], nw_ = w;
           sm[D.lds[L_WSP] + j] = w; // the set this solution belongs to (fallback, see below)
@@ -2110,20 +2128,28 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
           else if (x > hi + tolb) nw_ = 1.0;
           if (nw_ != w) { sm[D.lds[L_WS] + j] = nw_; changed = 1.0; }
           if (nw_ == 1.0) up = 1.0;
+          isfree = nw_ == 0.0;
         }
         QPC_BALLOT_PUT(0, bchg, changed != 0.0); // flags: one compare each instead of a 6-step max reduction
         QPC_BALLOT_PUT(1, bup, up != 0.0);
-      } QPC_END_PHASE
+        if (fsearch) { QPC_BALLOT_PUT(2, bfree, isfree); }
+      } QPC_END_PHASE_SOFT
+      if (!fsearch) { QPC_PHASE_SYNC }
       QPC_BALLOT_GET(0, bchg);
       QPC_BALLOT_GET(1, bup);
+      if (fsearch) { QPC_BALLOT_GET(2, bfree); }
       rchg = bchg ? 1.0 : 0.0;
       rup = bup ? 1.0 : 0.0;
       QPC_PROF_ACC(PS_S_TEST);
       if (!(rchg > 0.0)) { pd_converged = true; break; }
       any_upper = rup > 0.0;
       iters++;
-      S.refactor_solve(any_upper);
+      // fused sweeps: the test above, the K rows / Y of the new set (free pattern from the ballot, not from LDS) and the solve are
+      // joined by SOFT phase ends -- only Y -> S22 and S22 -> lam_w cross lanes through LDS
+      if (fsearch && !any_upper) { S.ky_phase(true, bfree); S.fused_solve(); soft_tail = true; }
+      else { if (fsearch) { QPC_PHASE_SYNC } S.refactor_solve(any_upper); soft_tail = false; }
     }
+    if (soft_tail) { QPC_PHASE_SYNC }
     // The multi-change sweeps can land on a working set with so many rho's pinned that the wrench
     // rows have no solution on it (the EQP is inconsistent although the QP is feasible); its
     // "solution" is meaningless and phase B, which assumes a valid point, must not start from it.

@@ -66,12 +66,17 @@ struct Lds {
 #define QPC_FN inline
 #define QPC_PHASE(lane) for (int lane = 0; lane < 64; ++lane) { emu_enter_lane(lane);
 #define QPC_END_PHASE } g_emu->lane = -1; g_emu->phase++;
+// soft end: the lane loop ends (blocks still run one after the other) but the race detector's phase number stays, so a
+// cross-lane RAW / WAR / WAW between soft-joined blocks is reported like one inside a single phase
+#define QPC_END_PHASE_SOFT } g_emu->lane = -1;
+#define QPC_PHASE_SYNC g_emu->phase++;
 #define QPC_LANE_SCOPE
 #define QPC_SINCOS(x, s, c) do { double x__ = (x); s = std::sin(x__); c = std::cos(x__); } while (0)
 #define QPC_SQRT(x) std::sqrt((double)(x))
 #define QPC_FABS(x) std::fabs((double)(x))
 #define QPC_ATAN2(y, x) std::atan2((double)(y), (double)(x))
 #define QPC_RCP(x) (1.0 / (double)(x))
+#define QPC_RCP_SEARCH(x) (1.0 / (double)(x))
 #define QPC_RSQRT(x) (1.0 / std::sqrt((double)(x)))
 #define QPC_LANE_ARRAY(name, n) double name[64][n]
 #define QPC_LA(name, lane) name[lane]
@@ -92,8 +97,8 @@ static thread_local double emu_mfma_a[64], emu_mfma_b[64];
 // lane-serial model of the DPP quad broadcasts: publish, then gather from the quad
 static thread_local double emu_quad[64];
 #define QPC_QUAD_GATHER(lane, OUT4, XEXPR)                                                    \
-  QPC_PHASE(lane) { emu_quad[lane] = (XEXPR); } QPC_END_PHASE                                  \
-  QPC_PHASE(lane) { double *o__ = (OUT4); for (int i__ = 0; i__ < 4; i__++) o__[i__] = emu_quad[(lane & ~3) + i__]; } QPC_END_PHASE
+  QPC_PHASE(lane) { emu_quad[lane] = (XEXPR); } QPC_END_PHASE_SOFT                              \
+  QPC_PHASE(lane) { double *o__ = (OUT4); for (int i__ = 0; i__ < 4; i__++) o__[i__] = emu_quad[(lane & ~3) + i__]; } QPC_END_PHASE_SOFT
 // reductions across a phase boundary: lane-serial form through the (emulator-only) scratch that
 // follows the kernel's LDS slab
 #define QPC_RED_MAX_PUT(slot, name, val) sm[D.lds_doubles + 128 * (slot) + lane] = (val)
