@@ -52,6 +52,28 @@ class Polynomial:
         return tuple(out)
 
 
+class BezierCurve:
+    """`const BezierCurve = BernsteinPolynomial` (trajectories.jl:26; the type comes from the un-vendored
+    StaticUnivariatePolynomials): b(t) = sum_i c_i C(n, i) t^i (1 - t)^(n - i) on [0, 1], evaluated by de Casteljau's
+    recurrence; `derivative()` is the Bernstein polynomial of degree n - 1 with coefficients n (c_{i+1} - c_i).  Usable
+    as the interpolator of an `Interpolated` trajectory (it maps [0, 1] -> [0, 1] when c_0 = 0 and c_n = 1)."""
+
+    def __init__(self, coeffs):
+        self.c = tuple(float(c) for c in coeffs)
+        if not self.c:
+            raise ValueError("a Bezier curve needs at least one control value")
+
+    def __call__(self, t):
+        b = list(self.c)
+        for k in range(len(b) - 1, 0, -1):
+            b = [(1.0 - t) * b[i] + t * b[i + 1] for i in range(k)]
+        return b[0]
+
+    def derivative(self):
+        n = len(self.c) - 1
+        return BezierCurve([n * (self.c[i + 1] - self.c[i]) for i in range(n)] or [0.0])
+
+
 def _coefficient_gradient(x, num_coeffs, order):
     """d^order/dx^order of [1, x, x^2, ...] (SUP.coefficient_gradient)"""
     row = []
@@ -92,7 +114,7 @@ def fit_quintic(*, x0, xf, y0, yd0, ydd0, yf, ydf, yddf):
 class PolyDerivEvaluator:
     """poly_deriv_evaluator.jl: the derivative polynomials are formed once"""
 
-    def __init__(self, p: Polynomial, num_derivs):
+    def __init__(self, p, num_derivs):  # p: Polynomial or BezierCurve (anything with __call__ and derivative())
         self.f = p
         self.derivs = []
         q = p
@@ -197,7 +219,7 @@ class Interpolated:
 
     def __init__(self, x0, xf, y0, yf, f=None, min_num_derivs=0, clamp=True):
         self.x0, self.xf, self.y0, self.yf, self.clamp = float(x0), float(xf), y0, yf, clamp
-        self.interpolator = PolyDerivEvaluator(f, min_num_derivs) if isinstance(f, Polynomial) else f
+        self.interpolator = PolyDerivEvaluator(f, min_num_derivs) if isinstance(f, (Polynomial, BezierCurve)) else f
 
     def _alpha(self, theta, n):
         if self.interpolator is None:  # identity: nthderiv (interpolated.jl:99)

@@ -182,3 +182,23 @@ def test_quat_interpolation_takes_the_long_arc_for_antipodal_signs():
         assert np.allclose(yd, axis * angle, atol=1e-14) and np.allclose(ydd, 0.0, atol=1e-14)
         y1 = traj(1.0, 2)[0]
         assert np.allclose(y1.matrix(), yf_short.matrix(), atol=1e-15)  # both arcs end on the same rotation
+
+
+def test_bezier_curve_matches_the_power_basis_and_drives_an_interpolated_trajectory():
+    """BezierCurve = BernsteinPolynomial (trajectories.jl:26): the Bernstein form of the smoothstep 3 t^2 - 2 t^3 is
+    (0, 0, 1, 1); value and derivatives agree with the power basis, and as the interpolator of an Interpolated trajectory it
+    gives the same samples as the fit_cubic time warp (interpolated.jl:20-57)."""
+    b = T.BezierCurve([0.0, 0.0, 1.0, 1.0])
+    p = T.Polynomial([0.0, 0.0, 3.0, -2.0])
+    for t in np.linspace(0.0, 1.0, 11):
+        assert abs(b(t) - p(t)) < 1e-15
+        assert abs(b.derivative()(t) - p.derivative()(t)) < 1e-14
+        assert abs(b.derivative().derivative()(t) - p.derivative().derivative()(t)) < 1e-13
+    assert T.BezierCurve([2.5]).derivative()(0.3) == 0.0
+    f = T.fit_cubic(x0=0.0, xf=1.0, y0=0.0, yd0=0.0, yf=1.0, ydf=0.0)
+    y0, yf = np.array([1.0, 2.0, 3.0]), np.array([-1.0, 0.5, 4.0])
+    tb = T.Interpolated(2.0, 5.0, y0, yf, b, min_num_derivs=2)
+    tp = T.Interpolated(2.0, 5.0, y0, yf, f, min_num_derivs=2)
+    for x in (1.0, 2.0, 2.7, 4.1, 5.0, 6.0):
+        for u, w in zip(tb(x, 2), tp(x, 2)):
+            np.testing.assert_allclose(u, w, rtol=0, atol=1e-13)
