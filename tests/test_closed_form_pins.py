@@ -87,3 +87,48 @@ def test_rigid_body_on_contacts_closed_form_emulated():
 @pytest.mark.gpu
 def test_rigid_body_on_contacts_closed_form_gpu():
     _check(lambda mech, N, fl: binding.Controller(binding.Model(mech), N, fl), B=64, seed=5)
+
+
+# ---- the cap of contacts.jl:57: rho <= maxnormalforce / (N sqrt(mu^2 + 1)) ---------------------------------------------------------
+def _check_cap(factory, B=5, seed=9):
+    """A box on four SYMMETRIC contact points is asked (soft SpatialAccelerationTask) to jump harder than its contacts allow: every
+    ray then sits on its upper bound rho_max = maxnormalforce / (N sqrt(mu^2 + 1)) (contacts.jl:57), the horizontal components cancel,
+    and each contact pushes with N rho_max / sqrt(mu^2 + 1) = maxnormalforce / (mu^2 + 1) -- NOT maxnormalforce: the reference's
+    quirk, reproduced.  Closed form:  vdot_z = 4 maxnormalforce / ((mu^2 + 1) m) - g , everything else zero."""
+    from qpcontrol_jl_amd.workloads import SCALAR
+    rng = np.random.default_rng(seed)
+    mass, mu = 12.0, 0.6
+    mech = M.Mechanism()
+    mech.add_body("box", M.WORLD, "floating", M.QUAT_FLOATING, mass=mass, com=(0, 0, 0), inertia=(0.5, 0.7, 0.9, 0, 0, 0))
+    c = factory(mech, 4, 0)
+    for sx in (1, -1):
+        for sy in (1, -1):
+            c.add_contact(0, [0.3 * sx, 0.2 * sy, -0.1], [0.0, 0.0, 1.0], mu)
+    c.add_task(SPATIAL, base=M.WORLD, target=0, frame=M.FRAME_DEFAULT, wkind=SCALAR, weight=[10.0])
+    c.regularize(0, 1e-3)
+    c.finalize()
+    q = np.zeros((B, 7)); q[:, 0] = 1.0
+    q[:, 4:7] = rng.normal(scale=0.3, size=(B, 3))
+    v = np.zeros((B, 6))
+    des = np.zeros((B, 6)); des[:, 5] = 50.0
+    cap = rng.uniform(20.0, 60.0, size=(B, 1)) * np.ones((B, 4))
+    w = np.full((B, 4), 1e-3)
+    r = c.control_batch(q, v, des, w, cap)
+    assert (r["status"] == 0).all(), r["status"]
+    az = 4.0 * cap[:, 0] / ((mu * mu + 1.0) * mass) - 9.81
+    assert np.all(az < 50.0)
+    expect = np.zeros((B, 6)); expect[:, 5] = az
+    np.testing.assert_allclose(r["vdot"], expect, rtol=0, atol=1e-8)
+    wr = r["cwrench"].reshape(B, 4, 6)
+    np.testing.assert_allclose(wr[:, :, 5], cap / (mu * mu + 1.0), rtol=0, atol=1e-8)
+    np.testing.assert_allclose(wr[:, :, 3:5], 0.0, rtol=0, atol=1e-8)
+
+
+def test_contact_cap_closed_form_emulated():
+    emu.build()
+    _check_cap(emu.factory)
+
+
+@pytest.mark.gpu
+def test_contact_cap_closed_form_gpu():
+    _check_cap(lambda mech, N, fl: binding.Controller(binding.Model(mech), N, fl), B=32)

@@ -182,3 +182,151 @@ def test_atlas_inverse_dynamics_against_energies_emulated():
 def test_atlas_inverse_dynamics_against_energies_gpu():
     err = _check(lambda mech, N, fl: binding.Controller(binding.Model(mech), N, fl), 16)
     print(f"max |tau - Lagrange(T, V)| = {err:.2e}")
+
+
+# ---- Newton-Euler of the WHOLE robot on the BASELINE config-3 workload (floating base, 8 contact points) --------------------------
+def _momenta(mech, q, v):
+    """linear momentum and angular momentum about the world origin from the independent numpy kinematics"""
+    k = W.batch_kinematics(mech, q, v)
+    Bn = np.atleast_2d(q).shape[0]
+    L = np.zeros((Bn, 3)); K = np.zeros((Bn, 3))
+    for i in range(mech.nbodies):
+        R, p, w, vl = k["R"][i], k["p"][i], k["w"][i], k["v"][i]
+        cw = np.einsum("bij,j->bi", R, mech.com[i]) + p
+        vc = vl + np.cross(w, cw)
+        Ixx, Iyy, Izz, Ixy, Ixz, Iyz = mech.inertia[i]
+        Ib = np.array([[Ixx, Ixy, Ixz], [Ixy, Iyy, Iyz], [Ixz, Iyz, Izz]])
+        Iw_w = np.einsum("bij,bj->bi", R, np.einsum("ij,bj->bi", Ib, np.einsum("bji,bj->bi", R, w)))
+        L += mech.mass[i] * vc
+        K += np.cross(cw, mech.mass[i] * vc) + Iw_w
+    return L, K, k["com"], k["mass"]
+
+
+def _advance(mech, q, v, t):
+    """q (+) v t: revolute / prismatic coordinates linearly, the floating base on SE(3) (v = body-frame twist)"""
+    qn = q.copy()
+    qo = vo = 0
+    for i in range(mech.nbodies):
+        ty = mech.joint_type[i]
+        if ty in (M.REVOLUTE, M.PRISMATIC):
+            qn[:, qo] = q[:, qo] + t * v[:, vo]
+        elif ty == M.QUAT_FLOATING:
+            w, x, y, z = q[:, qo], q[:, qo + 1], q[:, qo + 2], q[:, qo + 3]
+            R = np.stack([np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], -1),
+                          np.stack([2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)], -1),
+                          np.stack([2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], -1)], -2)
+            om = v[:, vo:vo + 3] * t
+            th = np.linalg.norm(om, axis=1)
+            half = 0.5 * th
+            sc = np.where(th > 1e-12, np.sin(half) / np.where(th > 1e-12, th, 1.0), 0.5)
+            dq = np.concatenate([np.cos(half)[:, None], sc[:, None] * om], axis=1)  # exp of the body-frame rotation vector
+            a, b, c_, d = dq[:, 0], dq[:, 1], dq[:, 2], dq[:, 3]
+            qn[:, qo] = w * a - x * b - y * c_ - z * d
+            qn[:, qo + 1] = w * b + x * a + y * d - z * c_
+            qn[:, qo + 2] = w * c_ - x * d + y * a + z * b
+            qn[:, qo + 3] = w * d + x * c_ - y * b + z * a
+            qn[:, qo + 4:qo + 7] = q[:, qo + 4:qo + 7] + t * np.einsum("bij,bj->bi", R, v[:, vo + 3:vo + 6])
+        qo += M._NQ[ty]; vo += M._NV[ty]
+    return qn
+
+
+def _check_momentum_balance(factory, B, config=3):
+    """a8 / a11 / a15 at once: with the kernel's vdot, the robot's momentum (independent kinematics, differentiated in time along
+    q (+) v t, v + vdot t) must change at the rate of the wrench its own contact forces and gravity apply:
+        dL/dt = m g + sum_c f_c ,     dK/dt = c x m g + sum_c n_c     (moments about the world origin; momentum.jl:162-193)"""
+    c, wl = W.atlas_workload(factory, B, config)
+    mech = M.atlas()
+    r = c.control_batch(wl.q, wl.v, wl.desired, wl.contact_weight, wl.contact_maxnormalforce)
+    ok = r["status"] == 0
+    assert ok.mean() > 0.8
+    q, v, vd = wl.q[ok], wl.v[ok], r["vdot"][ok]
+    wr = r["cwrench"][ok].reshape(ok.sum(), -1, 6)
+    h = 1e-4
+
+    def mom(t):
+        L, K, _, _ = _momenta(mech, _advance(mech, q, v, t), v + t * vd)
+        return np.concatenate([L, K], axis=1)
+    d = lambda hh: (mom(hh) - mom(-hh)) / (2 * hh)  # noqa: E731
+    rate = (4.0 * d(h / 2) - d(h)) / 3.0
+    _, _, com, mtot = _momenta(mech, q, v)
+    g = np.asarray(mech.gravity)
+    force = mtot * g[None, :] + wr[:, :, 3:].sum(axis=1)
+    moment = np.cross(com, mtot * g[None, :]) + wr[:, :, :3].sum(axis=1)
+    scale = mtot * 9.81
+    err = float(np.abs(rate - np.concatenate([force, moment], axis=1)).max() / scale)
+    assert err < 1e-7, err
+    return err
+
+
+def test_whole_robot_momentum_balance_emulated():
+    emu.build()
+    err = _check_momentum_balance(emu.factory, 8)
+    print(f"max |d/dt momentum - applied wrench| / (m g) = {err:.2e}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", [3, 5])
+def test_whole_robot_momentum_balance_gpu(config):
+    err = _check_momentum_balance(lambda mech, N, fl: binding.Controller(binding.Model(mech), N, fl), 256, config)
+    print(f"config {config}: max |d/dt momentum - applied wrench| / (m g) = {err:.2e}")
+
+
+def _check_torques_with_contacts(factory, B, config=3):
+    """a16 (inverse_dynamics! with the contact wrenches as external wrenches, momentum.jl:65-75) on the config-3 workload: for every
+    revolute joint, Lagrange's equation with the generalised force of the contact forces,
+        tau_j = d/dt (M v)_j - dT/dq_j + dV/dq_j - sum_c f_c . dp_c/dq_j ,
+    the base moving on SE(3) (its velocity coordinates are quasi-velocities; the Hamel coefficients only couple the base rows, so
+    the revolute rows keep the classical form).  Energies, momenta and contact points from the independent numpy kinematics,
+    vdot and f_c from the kernel."""
+    c, wl = W.atlas_workload(factory, B, config)
+    mech = M.atlas()
+    r = c.control_batch(wl.q, wl.v, wl.desired, wl.contact_weight, wl.contact_maxnormalforce)
+    ok = r["status"] == 0
+    assert ok.mean() > 0.8
+    q, v, vd, tau = wl.q[ok], wl.v[ok], r["vdot"][ok], r["tau"][ok]
+    n = int(ok.sum())
+    wr = r["cwrench"][ok].reshape(n, -1, 6)
+    assert np.all(tau[:, :6] == 0.0)  # zero_floating_joint_torques! (momentum.jl:93-97)
+    h = 1e-4
+
+    def rich(f):
+        d = lambda hh: (f(hh) - f(-hh)) / (2 * hh)  # noqa: E731
+        return (4.0 * d(h / 2) - d(h)) / 3.0
+
+    def contact_points(qq):
+        k = W.batch_kinematics(mech, qq, np.zeros((n, mech.nv)))
+        return np.stack([np.einsum("bij,j->bi", k["R"][cp.body], np.asarray(cp.position)) + k["p"][cp.body] for cp in mech.contact_points], axis=1)
+    err = 0.0
+    qo = vo = 0
+    for i in range(mech.nbodies):
+        ty = mech.joint_type[i]
+        if ty == M.REVOLUTE:
+            e = np.zeros((n, mech.nv)); e[:, vo] = 1.0
+
+            def shifted(hh, qo=qo):
+                qq = q.copy(); qq[:, qo] += hh
+                return qq
+
+            def pj(t, e=e):  # (M v)_j along the motion, by polarisation of the kinetic energy
+                qt, vt = _advance(mech, q, v, t), v + t * vd
+                return _kinetic(mech, qt, vt + e) - _kinetic(mech, qt, vt) - _kinetic(mech, qt, e)
+            lag = rich(pj) - rich(lambda hh: _kinetic(mech, shifted(hh), v)) + rich(lambda hh: _potential(mech, shifted(hh)))
+            dp = rich(lambda hh: contact_points(shifted(hh)))       # [n, nc, 3]
+            gen = np.einsum("bci,bci->b", dp, wr[:, :, 3:])
+            err = max(err, float(np.abs(tau[:, vo] - (lag - gen)).max()))
+        qo += M._NQ[ty]; vo += M._NV[ty]
+    assert np.abs(tau).max() > 10.0
+    assert err < 1e-6, err
+    return err
+
+
+def test_torques_with_contacts_against_lagrange_emulated():
+    emu.build()
+    err = _check_torques_with_contacts(emu.factory, 4)
+    print(f"max |tau - (Lagrange - J_c' f_c)| = {err:.2e}")
+
+
+@pytest.mark.gpu
+def test_torques_with_contacts_against_lagrange_gpu():
+    err = _check_torques_with_contacts(lambda mech, N, fl: binding.Controller(binding.Model(mech), N, fl), 32)
+    print(f"max |tau - (Lagrange - J_c' f_c)| = {err:.2e}")
