@@ -16,7 +16,7 @@ from qpcontrol_jl_amd import trajectories as T
 from qpcontrol_jl_amd.workloads import HARD, JOINT, SCALAR, SPATIAL
 
 
-def _controller(factory, with_law, gains):
+def _controller(factory, with_law, gains, pelvis_law=None):
     mech = M.atlas()
     fl = mech.findbody("pelvis")
     c = factory(mech, 4, fl)
@@ -29,17 +29,23 @@ def _controller(factory, with_law, gains):
     t_hand = c.add_task(SPATIAL, base=base, target=body, frame=M.FRAME_DEFAULT, wkind=SCALAR, weight=[10.0])
     t_foot = c.add_task(SPATIAL, base=M.WORLD, target=mech.findbody("l_foot"), frame=M.FRAME_DEFAULT, wkind=HARD)
     t_j = c.add_task(JOINT, joint=mech.findbody("r_hand") - 1, wkind=SCALAR, weight=[0.5])  # a task AFTER the record slice
+    t_pel = None
+    if pelvis_law is not None:  # a second kind of state-dependent law in the same controller (QpcDims::law_mask carries both)
+        from qpcontrol_jl_amd.workloads import ANGULAR
+        t_pel = c.add_task(ANGULAR, base=M.WORLD, target=mech.findbody("pelvis"), frame=M.FRAME_DEFAULT, wkind=SCALAR, weight=[3.0])
+        if with_law:
+            c.set_task_law(t_pel, binding.LAW_ORIENTATION_PD, pelvis_law[0], pelvis_law[1])
     if with_law:
         c.set_task_law(t_hand, binding.LAW_SE3_PD, gains.angular.k, gains.angular.d, [gains.linear.k, gains.linear.d])
     c.finalize()
-    return mech, c, base, body, (t_hand, t_foot, t_j)
+    return mech, c, base, body, (t_hand, t_foot, t_j) + ((t_pel,) if t_pel is not None else ())
 
 
-def _run(factory, B=10, seed=5):
+def _run(factory, B=10, seed=5, pelvis_law=None):
     rng = np.random.default_rng(seed)
     gains = api.SE3PDGains(api.PDGains(100.0, 20.0), api.PDGains(1000.0, 200.0))  # test/controller.jl:13
-    mech, claw, base, body, tids = _controller(factory, True, gains)
-    _, cref, _, _, _ = _controller(factory, False, gains)
+    mech, claw, base, body, tids = _controller(factory, True, gains, pelvis_law)
+    _, cref, _, _, _ = _controller(factory, False, gains, pelvis_law)
     off_law = [claw.task_desired_range(t) for t in tids]
     off_ref = [cref.task_desired_range(t) for t in tids]
     assert off_law[0][1] == binding.SE3_RECORD and off_ref[0][1] == 6
@@ -47,6 +53,13 @@ def _run(factory, B=10, seed=5):
     assert claw.layout.n_desired == cref.layout.n_desired + 23
     qs, vs = zip(*(M.rand_state(mech, rng, 0.3) for _ in range(B)))
     q, v = np.array(qs), np.array(vs)
+    pel_des = None
+    if pelvis_law is not None:  # -kp rotation_vector(R) - kd R' omega of the pelvis (standing.jl:72-77), host evaluation
+        from qpcontrol_jl_amd import workloads as W
+        kin = W.batch_kinematics(mech, q, v)
+        pb = mech.findbody("pelvis")
+        Rp = kin["R"][pb]
+        pel_des = -pelvis_law[0] * W.rotation_vector(Rp) - pelvis_law[1] * np.einsum("bji,bj->bi", Rp, kin["w"][pb])
     nc = len(mech.contact_points)
     cw, cm = np.full((B, nc), 1e-3), np.full((B, nc), 1e6)
     for warp in (None, "quintic", "antipodal"):
@@ -70,6 +83,8 @@ def _run(factory, B=10, seed=5):
         for dl, offs in ((des_law, off_law), (des_ref, off_ref)):
             dl[:, offs[1][0]:offs[1][0] + 6] = foot_des
             dl[:, offs[2][0]:offs[2][0] + 1] = jd
+        if pel_des is not None:
+            des_ref[:, off_ref[3][0]:off_ref[3][0] + 3] = pel_des  # the law controller ignores its slice
         rl = claw.control_batch(q, v, des_law, cw, cm)
         rr = cref.control_batch(q, v, des_ref, cw, cm)
         assert np.array_equal(rl["status"], rr["status"]) and (rr["status"] == 0).all(), (rl["status"], rr["status"])
@@ -86,6 +101,16 @@ def test_se3_pd_law_emulated():
     assert (races, uninit, outside) == (0, 0, 0), first
 
 
+def test_se3_and_orientation_laws_in_one_controller_emulated():
+    """two kinds of state-dependent laws (SE(3) PD on the hand, orientation PD on the pelvis) in one controller: the specialised
+    kernel carries exactly the kinds in use (QpcDims::law_mask)"""
+    emu.build()
+    emu.race_report()
+    _run(emu.factory, pelvis_law=(20.0, 9.0))
+    races, uninit, outside, first = emu.race_report()
+    assert (races, uninit, outside) == (0, 0, 0), first
+
+
 def test_se3_law_needs_a_body_frame_spatial_task():
     emu.build()
     mech = M.atlas()
@@ -98,3 +123,8 @@ def test_se3_law_needs_a_body_frame_spatial_task():
 @pytest.mark.gpu
 def test_se3_pd_law_gpu():
     _run(lambda mech, N, fl: binding.Controller(binding.Model(mech), N, fl), B=10)
+
+
+@pytest.mark.gpu
+def test_se3_and_orientation_laws_in_one_controller_gpu():
+    _run(lambda mech, N, fl: binding.Controller(binding.Model(mech), N, fl), B=10, pelvis_law=(20.0, 9.0))
