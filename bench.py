@@ -304,6 +304,35 @@ def measured_traffic(fingerprint):
                               f"{d.get('qps_per_launch', 32768)} QPs per launch, kernel fingerprint {fingerprint} == built kernel")
 
 
+def measured_issue(fingerprint):
+    """What actually bounds the tick: the instructions it issues.  Per-solve instruction counts from the newest
+    rocprofv3 SQ counter summary under profiles/ taken on the built kernel (same fingerprint rule as the traffic), and the
+    share of a QP slot (one QP on each of the two waves of a SIMD) that their issue time accounts for."""
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            t = json.load(open(f.replace("_pmc_summary.json", "_traffic_summary.json")))
+        except (OSError, ValueError):
+            continue
+        pl = d.get("per_launch", {})
+        if t.get("kernel_fingerprint") != fingerprint or "SQ_INSTS_VALU" not in pl:
+            continue
+        n = float(d.get("qps_per_launch", 32768))
+        valu, lds, salu = pl["SQ_INSTS_VALU"] / n, pl.get("SQ_INSTS_LDS", 0.0) / n, pl.get("SQ_INSTS_SALU", 0.0) / n
+        out = {"valu_per_solve": valu, "lds_per_solve": lds, "salu_per_solve": salu, "source": os.path.relpath(f, ROOT)}
+        if "SQ_ACTIVE_INST_ANY" in pl and "SQ_WAVE_CYCLES" in pl and pl["SQ_WAVE_CYCLES"] > 0:
+            # both counters are in quad-cycles summed over waves: the share of its life a wave spends executing an instruction;
+            # the two waves of a SIMD do not overlap each other's instructions (calibrated, DESIGN.md 7b), so twice that share is
+            # how full the SIMD's issue is
+            share = pl["SQ_ACTIVE_INST_ANY"] / pl["SQ_WAVE_CYCLES"]
+            out["wave_active_share"] = share
+            out["simd_issue_busy"] = min(1.0, 2.0 * share)
+        out["note"] = ("the tick is bound by the number of instructions it issues: every added VALU instruction costs 8 cycles of QP-slot "
+                       "time whether dependent or not (DESIGN.md 7b)")
+        return out
+    return None
+
+
 # ------------------------------------------------------------------------------------------ main
 def main():
     if len(sys.argv) >= 5 and sys.argv[1] == "--cpu-worker":
@@ -445,8 +474,9 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "qpc_tick_kernel_jit", "kernel_avg_ms": avg_ms.value, "launches": int(nl.value),
                          "algorithmic_bytes_per_solve": alg_bytes,
-                         "note": "path is fp64-VALU / LDS-latency bound, not HBM bound (SURVEY.md 8d); "
-                                 "fp64 fraction reported beside it",
+                         "note": "path is bound by instruction issue (fp64 VALU + LDS + scalar), not by HBM (SURVEY.md 8d, DESIGN.md 7b); "
+                                 "fp64 fraction and the instruction counts reported beside it",
+                         "issue": measured_issue(fingerprint) if args.config == 3 and not args.fused_laws else None,
                          "fp64": {"achieved_tflops": ALG_FLOPS_PER_SOLVE * B / kern_s / 1e12 if kern_s > 0 else 0.0,
                                   "peak_tflops": FP64_PEAK / 1e12,
                                   "frac": (ALG_FLOPS_PER_SOLVE * B / kern_s) / FP64_PEAK if kern_s > 0 else 0.0,
