@@ -77,6 +77,25 @@ int qpc_compile_program(qpc_controller *c) {
     for (int k = 0; k < t.dim; k++) pin_des[m->voff[t.joint] + k] = t.des_off + k;
     task_is_pin[ti] = 1;
   }
+  // A hard AngularAccelerationTask of the FLOATING body w.r.t. the world, expressed in that body's own frame (the pelvis task of
+  // StandingController, standing.jl:43-44), is a pin too: the angular velocity coordinates of a QuaternionFloating joint ARE the
+  // body-frame angular velocity, so the task's Jacobian is [I3 0 ... 0] for every state and its bias vanishes (the body's twist
+  // is its own joint twist: T x T = 0, and d/dt (R w_b) = R w_b' + R (w_b x w_b)): vdot[fv0 .. fv0 + 2] = desired.  Three rows
+  // and three free columns fewer (Atlas: the leading Schur block 18 -> 15 fits ONE 16 x 16 matrix-core tile).  Only when the
+  // desired value is known before the kinematics (caller input or a constant, not a state-dependent law).
+  if (c->floating >= 0 && !getenv("QPC_NO_BASE_PIN")) {
+    for (size_t ti = 0; ti < c->tasks.size(); ti++) {
+      const QpcTask &t = c->tasks[ti];
+      if (t.kind != QPC_TASK_ANGULAR_ACCELERATION || t.wkind != QPC_WEIGHT_HARD || t.base != QPC_WORLD || t.target != c->floating ||
+          t.frame != t.target || !(t.law == QPC_LAW_INPUT || t.law == QPC_LAW_CONSTANT))
+        continue;
+      bool fresh = true;
+      for (int k = 0; k < 3; k++) fresh = fresh && pin_des[D.fv0 + k] < 0;
+      if (!fresh) continue;
+      for (int k = 0; k < 3; k++) pin_des[D.fv0 + k] = t.des_off + k;
+      task_is_pin[ti] = 1;
+    }
+  }
   std::vector<int> free_of(nv, -1), free_k, pin_k, pin_d;
   for (int k = 0; k < nv; k++) {
     if (pin_des[k] >= 0) { pin_k.push_back(k); pin_d.push_back(pin_des[k]); }
