@@ -87,8 +87,11 @@ int qpc_compile_program(qpc_controller *c) {
     for (size_t ti = 0; ti < c->tasks.size(); ti++) {
       const QpcTask &t = c->tasks[ti];
       if (t.kind != QPC_TASK_ANGULAR_ACCELERATION || t.wkind != QPC_WEIGHT_HARD || t.base != QPC_WORLD || t.target != c->floating ||
-          t.frame != t.target || !(t.law == QPC_LAW_INPUT || t.law == QPC_LAW_CONSTANT))
+          t.frame != t.target)
         continue;
+      // ... or follows the orientation PD law of this very body hanging on the world (evaluated from q, v alone: desired_early)
+      const bool root_law = t.law == QPC_LAW_ORIENTATION_PD && m->parent[t.target] < 0;
+      if (!(t.law == QPC_LAW_INPUT || t.law == QPC_LAW_CONSTANT || root_law)) continue;
       bool fresh = true;
       for (int k = 0; k < 3; k++) fresh = fresh && pin_des[D.fv0 + k] < 0;
       if (!fresh) continue;
@@ -374,14 +377,20 @@ int qpc_compile_program(qpc_controller *c) {
     for (auto &t : c->tasks)
       for (int a = 0; a < t.dim; a++) {
         const int i = t.des_off + a;
-        D.law_mask |= 1 << t.law;
+        D.law_mask |= 1 << t.law; // (refined below for the root orientation law)
         law_i[3 * i] = t.law; law_d[3 * i] = t.kp; law_d[3 * i + 1] = t.kd;
         switch (t.law) {
           case QPC_LAW_INPUT: D.n_des_inputs++; break;
           case QPC_LAW_CONSTANT: law_d[3 * i + 2] = t.ref[a]; break;
           case QPC_LAW_JOINT_PD: law_i[3 * i + 1] = m->qoff[t.joint]; law_i[3 * i + 2] = m->voff[t.joint]; law_d[3 * i + 2] = t.ref[0]; break;
           case QPC_LAW_COM_PD: law_i[3 * i + 1] = a; law_d[3 * i + 2] = t.ref[a]; D.n_des_late++; break;
-          case QPC_LAW_ORIENTATION_PD: law_i[3 * i + 1] = t.target; law_i[3 * i + 2] = a; D.n_des_late++; break;
+          case QPC_LAW_ORIENTATION_PD:
+            law_i[3 * i + 1] = t.target; law_i[3 * i + 2] = a;
+            if (t.target == c->floating && c->floating >= 0 && m->parent[t.target] < 0 && !getenv("QPC_NO_BASE_PIN")) {
+              law_i[3 * i] = QPC_LAW_ORIENTATION_PD_ROOT; // from the joint's own coordinates, before the kinematics
+              D.law_mask |= 1 << QPC_LAW_ORIENTATION_PD_ROOT;
+            } else D.n_des_late++;
+            break;
           case QPC_LAW_SE3_PD: // entry a: body / base / component packed, offset of the task's record; per-entry gains
             law_i[3 * i + 1] = (t.target + 1) | ((t.base + 1) << 8) | (a << 16);
             law_i[3 * i + 2] = t.des_off;
@@ -390,6 +399,8 @@ int qpc_compile_program(qpc_controller *c) {
             break;
         }
       }
+    D.law_mask = 0;
+    for (size_t i = 0; i < (size_t)c->n_desired; i++) D.law_mask |= 1 << law_i[3 * i];
     for (auto &t : c->tasks) // the rest of a trajectory record are plain per-QP inputs
       if (t.law == QPC_LAW_SE3_PD) D.n_des_inputs += QPC_SE3_RECORD - t.dim;
     B.ibegin(IT_LAW); B.it.insert(B.it.end(), law_i.begin(), law_i.end());

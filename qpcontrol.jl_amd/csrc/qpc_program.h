@@ -99,6 +99,11 @@ enum {
   L_COUNT
 };
 
+// internal law code (not part of include/qpc.h): QPC_LAW_ORIENTATION_PD on the FLOATING body of a mechanism whose floating joint hangs on
+// the world -- its orientation and body-frame angular velocity are the joint's own coordinates, so the law is evaluated in the input
+// phase (before the kinematics) and the task can be a pin of the joint's angular accelerations (qpc_compile.cpp pass 1)
+#define QPC_LAW_ORIENTATION_PD_ROOT 16
+
 // Row stride of G (6 x nrho, L_G): nrho is typically a multiple of 32 doubles, which would put the six rows -- read
 // side by side by the lanes (a, b) of the S22 build and by the wrench-row mat-vecs -- on the same LDS banks; two extra
 // doubles per row shift each row by four banks and keep 16-byte alignment

@@ -1103,20 +1103,6 @@ template <class P> struct Solver {
   }
 };
 
-// desired entry i from the caller (setdesired!) or from a law that only needs (q, v):
-// constant, joint-space PD kp (ref - q) - kd v (standing.jl:80-86).  COM / orientation laws need
-// the kinematics and are filled in later (desired_late); until then the entry is 0.
-QPC_FN double desired_early(const QpcDims &D, const int *IT, const double *DT, const TickIO &io, int i) {
-  if (D.n_des_inputs == D.n_desired) return io.desired[i];
-  const int *li = IT + D.it[IT_LAW] + 3 * i;
-  const double *ld_ = DT + D.dt[DT_LAW] + 3 * i;
-  const int kind = li[0];
-  if (kind == QPC_LAW_INPUT) return io.desired[i];
-  if (kind == QPC_LAW_CONSTANT) return ld_[2];
-  if (kind == QPC_LAW_JOINT_PD) return ld_[0] * (ld_[2] - io.q[li[1]]) - ld_[1] * io.v[li[2]];
-  return 0.0;
-}
-
 // rotation_vector(R) (angle * axis), the error term of the orientation PD law (standing.jl:74-76).
 // Branch on the angle like a robust log map: sin-based formula away from pi, diagonal-based near pi.
 QPC_FN void rotation_vector(const double *R, double *rv) {
@@ -1136,6 +1122,35 @@ QPC_FN void rotation_vector(const double *R, double *rv) {
   else { if (R[2] + R[6] < 0.0) x = -x; if (R[5] + R[7] < 0.0) y = -y; if (az < 0.0) { x = -x; y = -y; z = -z; } }
   rv[0] = th * x; rv[1] = th * y; rv[2] = th * z;
 }
+
+// desired entry i from the caller (setdesired!) or from a law that only needs (q, v):
+// constant, joint-space PD kp (ref - q) - kd v (standing.jl:80-86).  COM / orientation laws need
+// the kinematics and are filled in later (desired_late); until then the entry is 0.
+QPC_FN double desired_early(const QpcDims &D, const int *IT, const double *DT, const TickIO &io, int i) {
+  if (D.n_des_inputs == D.n_desired) return io.desired[i];
+  const int *li = IT + D.it[IT_LAW] + 3 * i;
+  const double *ld_ = DT + D.dt[DT_LAW] + 3 * i;
+  const int kind = li[0];
+  if (kind == QPC_LAW_INPUT) return io.desired[i];
+  if (kind == QPC_LAW_CONSTANT) return ld_[2];
+  if (kind == QPC_LAW_JOINT_PD) return ld_[0] * (ld_[2] - io.q[li[1]]) - ld_[1] * io.v[li[2]];
+  if (((D.law_mask >> QPC_LAW_ORIENTATION_PD_ROOT) & 1) && kind == QPC_LAW_ORIENTATION_PD_ROOT) {
+    // orientation PD of the floating body on the world (standing.jl:72-77): R = Rf R(quaternion), omega_body = v[v0 .. v0 + 2]
+    const int body = li[1], a = li[2], nb = D.nb;
+    const int q0 = IT[D.it[IT_QOFF] + body], v0 = IT[D.it[IT_VOFF] + body];
+    const double w = io.q[q0], x = io.q[q0 + 1], y = io.q[q0 + 2], z = io.q[q0 + 3];
+    const double Rj[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                          2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                          2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)};
+    double Rf[9], H[9], rv[3];
+    for (int k = 0; k < 9; k++) Rf[k] = DT[D.dt[DT_RF] + k * nb + body];
+    mm3(Rf, Rj, H);
+    rotation_vector(H, rv);
+    return -ld_[0] * rv[a] - ld_[1] * io.v[v0 + a];
+  }
+  return 0.0;
+}
+
 
 // SE3PDController (src/lowlevel/se3pdcontroller.jl:13-18) with its SE3Trajectory (src/trajectories/se3.jl:8-27) made of
 // two Interpolated trajectories (src/trajectories/interpolated.jl:20-83), evaluated for ONE state:
