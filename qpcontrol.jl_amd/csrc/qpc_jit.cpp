@@ -10,6 +10,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <map>
+#include <mutex>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -150,8 +152,23 @@ std::string qpc_jit_source(const QpcDims &D, bool warm) {
   return o.str();
 }
 
+// code objects of this process by (translation unit, architecture, options): controllers with the same task program (a test-suite,
+// one controller per device thread, ...) compile once.  QPC_JIT_CACHE=0 disables it.
+static std::mutex g_jit_mu;
+static std::map<std::string, std::vector<char>> g_jit_cache;
+
 int qpc_jit_compile(const QpcDims &D, const std::string &arch, bool warm, std::vector<char> &code, std::string &log) {
   std::string src = qpc_jit_source(D, warm);
+  std::string key;
+  {
+    const char *ce = getenv("QPC_JIT_CACHE"), *xe = getenv("QPC_JIT_EXTRA_FLAGS");
+    if (!(ce && ce[0] == '0')) {
+      key = arch + "\n" + (xe ? xe : "") + "\n" + src;
+      std::lock_guard<std::mutex> lk(g_jit_mu);
+      auto it = g_jit_cache.find(key);
+      if (it != g_jit_cache.end()) { code = it->second; log.clear(); return 0; }
+    }
+  }
   hiprtcProgram prog;
   if (hiprtcCreateProgram(&prog, src.c_str(), "qpc_tick_jit.hip", qpc_src_count, qpc_src_texts, qpc_src_names) != HIPRTC_SUCCESS) {
     log = "hiprtcCreateProgram failed";
@@ -180,6 +197,11 @@ int qpc_jit_compile(const QpcDims &D, const std::string &arch, bool warm, std::v
   code.resize(cs);
   hiprtcGetCode(prog, code.data());
   hiprtcDestroyProgram(&prog);
+  if (!key.empty()) {
+    std::lock_guard<std::mutex> lk(g_jit_mu);
+    if (g_jit_cache.size() >= 64) g_jit_cache.clear(); // (bounded: a code object is ~1 MB)
+    g_jit_cache[key] = code;
+  }
   return 0;
 }
 
