@@ -77,25 +77,26 @@ int qpc_compile_program(qpc_controller *c) {
     for (int k = 0; k < t.dim; k++) pin_des[m->voff[t.joint] + k] = t.des_off + k;
     task_is_pin[ti] = 1;
   }
-  // A hard AngularAccelerationTask of the FLOATING body w.r.t. the world, expressed in that body's own frame (the pelvis task of
-  // StandingController, standing.jl:43-44), is a pin too: the angular velocity coordinates of a QuaternionFloating joint ARE the
-  // body-frame angular velocity, so the task's Jacobian is [I3 0 ... 0] for every state and its bias vanishes (the body's twist
-  // is its own joint twist: T x T = 0, and d/dt (R w_b) = R w_b' + R (w_b x w_b)): vdot[fv0 .. fv0 + 2] = desired.  Three rows
-  // and three free columns fewer (Atlas: the leading Schur block 18 -> 15 fits ONE 16 x 16 matrix-core tile).  Only when the
-  // desired value is known before the kinematics (caller input or a constant, not a state-dependent law).
+  // A hard Angular / Linear / SpatialAccelerationTask of the FLOATING body w.r.t. the world, expressed in that body's own frame (the
+  // pelvis task of StandingController, standing.jl:43-44), is a pin too: the velocity coordinates of a QuaternionFloating joint ARE
+  // the body-frame twist, so the task's Jacobian is the matching rows of [I6 0 ... 0] for every state and its bias vanishes (the
+  // body's twist is its own joint twist: T x T = 0): vdot[fv0 + r] = desired_r.  For Atlas: three rows and three free columns fewer,
+  // the leading Schur block 18 -> 15 fits ONE 16 x 16 matrix-core tile.  Only when the desired value is known before the kinematics
+  // (caller input, a constant, or the orientation law of this very body on the world, which desired_early evaluates from q, v alone).
   if (c->floating >= 0 && !getenv("QPC_NO_BASE_PIN")) {
     for (size_t ti = 0; ti < c->tasks.size(); ti++) {
       const QpcTask &t = c->tasks[ti];
-      if (t.kind != QPC_TASK_ANGULAR_ACCELERATION || t.wkind != QPC_WEIGHT_HARD || t.base != QPC_WORLD || t.target != c->floating ||
-          t.frame != t.target)
+      const bool ang = t.kind == QPC_TASK_ANGULAR_ACCELERATION, lin = t.kind == QPC_TASK_LINEAR_ACCELERATION,
+                 spa = t.kind == QPC_TASK_SPATIAL_ACCELERATION;
+      if (!(ang || lin || spa) || t.wkind != QPC_WEIGHT_HARD || t.base != QPC_WORLD || t.target != c->floating || t.frame != t.target)
         continue;
-      // ... or follows the orientation PD law of this very body hanging on the world (evaluated from q, v alone: desired_early)
-      const bool root_law = t.law == QPC_LAW_ORIENTATION_PD && m->parent[t.target] < 0;
+      const bool root_law = ang && t.law == QPC_LAW_ORIENTATION_PD && m->parent[t.target] < 0;
       if (!(t.law == QPC_LAW_INPUT || t.law == QPC_LAW_CONSTANT || root_law)) continue;
+      const int v0 = D.fv0 + (lin ? 3 : 0); // rows of a spatial task: angular first, like the joint's velocity coordinates
       bool fresh = true;
-      for (int k = 0; k < 3; k++) fresh = fresh && pin_des[D.fv0 + k] < 0;
+      for (int k = 0; k < t.dim; k++) fresh = fresh && pin_des[v0 + k] < 0;
       if (!fresh) continue;
-      for (int k = 0; k < 3; k++) pin_des[D.fv0 + k] = t.des_off + k;
+      for (int k = 0; k < t.dim; k++) pin_des[v0 + k] = t.des_off + k;
       task_is_pin[ti] = 1;
     }
   }
