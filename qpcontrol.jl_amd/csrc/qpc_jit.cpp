@@ -87,6 +87,12 @@ std::string qpc_jit_source(const QpcDims &D, bool warm) {
   int waves = 2;
   if (const char *e = getenv("QPC_EXP_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 8) waves = v; }
   if (dyn_lds) o << "extern __shared__ __attribute__((aligned(16))) double qpc_lds_dyn[];\n";
+  o << "#ifdef QPC_KERNARG_RELOAD\n"
+       "template <class T> __device__ __forceinline__ T qpc_karg(const __attribute__((address_space(4))) T *p) { asm volatile(\"\" : \"+s\"(p)); return *p; }\n"
+       "#define KA(f) qpc_karg(&Ak->f)\n"
+       "#else\n"
+       "#define KA(f) A.f\n"
+       "#endif\n";
   for (int variant = 0; variant < (warm ? 2 : 1); variant++) {
     o << "extern \"C\" __global__ void __launch_bounds__(64, " << waves << ") " << (variant ? "qpc_tick_kernel_jit_warm" : "qpc_tick_kernel_jit")
       << "(const int *__restrict__ IT, const double *__restrict__ DT, const QpcBatchArgs A) {\n";
@@ -97,21 +103,29 @@ std::string qpc_jit_source(const QpcDims &D, bool warm) {
          "  typedef " << (f32 ? "qpc::F32Ptr" : "double *") << " LdsP;\n"
          "  qpc::qpc_tick_prologue<LdsP>(kD, IT, qpc_lds);\n"
          "  while (true) {\n"
+         "#ifdef QPC_KERNARG_RELOAD\n"
+         "    // the launch arguments are re-read from the kernarg segment (scalar loads, scalar cache) where they are used: kept in\n"
+         "    // scalar registers across the persistent loop the 16-dword block is spilled to VGPR lanes and restored with 16\n"
+         "    // v_readlane per use (96 VALU instructions in the input phase alone)\n"
+         "    const __attribute__((address_space(4))) QpcBatchArgs *Ak = (const __attribute__((address_space(4))) QpcBatchArgs *)\n"
+         "        ((const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr() + 16);\n"
+         "    asm volatile(\"\" : \"+s\"(Ak));\n"
+         "#endif\n"
          "    unsigned long long t = 0;\n"
-         "    if ((threadIdx.x & 63) == 0) t = atomicAdd(A.ticket, 1ull);\n"
+         "    if ((threadIdx.x & 63) == 0) t = atomicAdd(KA(ticket), 1ull);\n"
          "    const long long b = (long long)__shfl(t, 0, 64);\n"
-         "    if (b >= A.B) {\n"
+         "    if (b >= KA(B)) {\n"
          "      // a launch draws exactly B + gridDim.x tickets; whoever draws the last one re-arms the counter\n"
-         "      if ((threadIdx.x & 63) == 0 && b == A.B + (long long)gridDim.x - 1) atomicExch(A.ticket, 0ull);\n"
+         "      if ((threadIdx.x & 63) == 0 && b == KA(B) + (long long)gridDim.x - 1) atomicExch(KA(ticket), 0ull);\n"
          "      break;\n"
          "    }\n"
          "    qpc::TickIO io;\n"
-         "    io.q = A.q + b * kD.nq; io.v = A.v + b * kD.nv; io.desired = A.desired + b * kD.n_desired;\n"
-         "    io.cw = A.cw + b * kD.nc; io.cmax = A.cmax + b * kD.nc; io.tw = A.tw + b * kD.n_tw; io.surf = A.surf + b * kD.n_surf;\n"
-         "    io.tau = A.tau + b * kD.nv; io.vdot = A.vdot + b * kD.nv;\n"
-         "    io.cwrench = A.cwrench ? A.cwrench + b * 6 * kD.nc : nullptr;\n"
-         "    io.status = A.status + b; io.iters = A.iters ? A.iters + b : nullptr; io.prof = A.prof ? A.prof + b * PS_COUNT : nullptr;\n"
-         "    io.wset = " << (variant ? "A.wsets ? A.wsets + 2 * b : nullptr" : "nullptr") << ";\n"
+         "    io.q = KA(q) + b * kD.nq; io.v = KA(v) + b * kD.nv; io.desired = KA(desired) + b * kD.n_desired;\n"
+         "    io.cw = KA(cw) + b * kD.nc; io.cmax = KA(cmax) + b * kD.nc; io.tw = KA(tw) + b * kD.n_tw; io.surf = KA(surf) + b * kD.n_surf;\n"
+         "    io.tau = KA(tau) + b * kD.nv; io.vdot = KA(vdot) + b * kD.nv;\n"
+         "    io.cwrench = KA(cwrench) ? KA(cwrench) + b * 6 * kD.nc : nullptr;\n"
+         "    io.status = KA(status) + b; io.iters = KA(iters) ? KA(iters) + b : nullptr; io.prof = KA(prof) ? KA(prof) + b * PS_COUNT : nullptr;\n"
+         "    io.wset = " << (variant ? "KA(wsets) ? KA(wsets) + 2 * b : nullptr" : "nullptr") << ";\n"
          "    // opaque copies of the table pointers: keeps the compiler from hoisting dozens of per-lane table\n"
          "    // addresses out of this loop (they would stay live across the whole tick and spill).  The copies are made in\n"
          "    // the GLOBAL address space and cast back, so that address-space inference still sees where they point: table\n"
@@ -122,6 +136,7 @@ std::string qpc_jit_source(const QpcDims &D, bool warm) {
          "    const int *ITq = (const int *)ITg; const double *DTq = (const double *)DTg;\n"
          "    qpc::qpc_tick<LdsP, " << (variant ? "true" : "false") << ">(kD, ITq, DTq, qpc_lds, io);\n"
          "    __syncthreads();\n"
+
          "  }\n"
          "}\n";
   }
