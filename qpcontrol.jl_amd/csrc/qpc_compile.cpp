@@ -88,9 +88,10 @@ int qpc_compile_program(qpc_controller *c) {
       const QpcTask &t = c->tasks[ti];
       const bool ang = t.kind == QPC_TASK_ANGULAR_ACCELERATION, lin = t.kind == QPC_TASK_LINEAR_ACCELERATION,
                  spa = t.kind == QPC_TASK_SPATIAL_ACCELERATION;
-      if (!(ang || lin || spa) || t.wkind != QPC_WEIGHT_HARD || t.base != QPC_WORLD || t.target != c->floating || t.frame != t.target)
+      if (!(ang || lin || spa) || t.wkind != QPC_WEIGHT_HARD || t.base != QPC_WORLD || t.target != c->floating || t.frame != t.target ||
+          m->parent[t.target] >= 0) // (a floating joint hanging on a moving body: its ancestors' joints enter the Jacobian)
         continue;
-      const bool root_law = ang && t.law == QPC_LAW_ORIENTATION_PD && m->parent[t.target] < 0;
+      const bool root_law = ang && t.law == QPC_LAW_ORIENTATION_PD;
       if (!(t.law == QPC_LAW_INPUT || t.law == QPC_LAW_CONSTANT || root_law)) continue;
       const int v0 = D.fv0 + (lin ? 3 : 0); // rows of a spatial task: angular first, like the joint's velocity coordinates
       bool fresh = true;
