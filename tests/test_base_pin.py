@@ -94,3 +94,32 @@ def test_base_tasks_of_all_three_kinds_emulated(kind, v0):
 @pytest.mark.parametrize("fused", [False, True])
 def test_pelvis_task_is_a_pin_gpu(fused):
     _atlas(lambda mech, N, fl: binding.Controller(binding.Model(mech), N, fl), 512, 3, fused)
+
+
+def test_floating_joint_on_a_moving_parent_is_not_pinned_emulated():
+    """the pin needs the floating joint to hang on the world: on a moving platform the platform's joints enter the task's Jacobian, so
+    the task stays a row block of the QP -- and the tick still agrees with the oracle"""
+    from oracle import oracle as O
+    emu.build()
+    mech = M.rand_tree([M.REVOLUTE, M.QUAT_FLOATING, M.REVOLUTE, M.REVOLUTE], seed=5, chain=True)
+
+    def make(factory):
+        c = factory(mech, 4, 1)
+        for k, b in enumerate((2, 3)):
+            c.add_contact(b, [0.1 * k, 0.05, -0.1], [0.0, 0.1, 1.0], 0.8)
+        for j in range(mech.nbodies):
+            c.regularize(j, 0.2)
+        c.add_task(ANGULAR, base=M.WORLD, target=1, frame=M.FRAME_DEFAULT, wkind=HARD)
+        c.add_task(JOINT, joint=0, wkind=HARD)
+        return c, c.finalize()
+    c, lay = make(emu.factory)
+    assert lay.n_pinned == 1  # the platform's joint task only
+    oc, _ = make(lambda m, N, fl: O.OracleController(O.OracleModel(m), N, fl))
+    rng = np.random.default_rng(1)
+    B = 4
+    qs, vs = zip(*(M.rand_state(mech, rng, 0.5) for _ in range(B)))
+    des = rng.normal(size=(B, lay.n_desired)) * 0.3
+    args = (np.array(qs), np.array(vs), des, np.full((B, 2), 1e-2), np.full((B, 2), 1e5))
+    r, ro = c.control_batch(*args), oc.tick_batch(*args)
+    assert (r["status"] == 0).all() and (ro["status"] == 0).all()
+    np.testing.assert_allclose(r["tau"], ro["tau"], rtol=0, atol=1e-8)
