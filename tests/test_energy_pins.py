@@ -330,3 +330,118 @@ def test_torques_with_contacts_against_lagrange_emulated():
 def test_torques_with_contacts_against_lagrange_gpu():
     err = _check_torques_with_contacts(lambda mech, N, fl: binding.Controller(binding.Model(mech), N, fl), 32)
     print(f"max |tau - (Lagrange - J_c' f_c)| = {err:.2e}")
+
+
+# ---- a6 PointAccelerationTask and a8 MomentumRateTask against differentiated kinematics ---------------------------------------------
+def _check_point_task(factory, B, seed=13):
+    """PointAccelerationTask (src/tasks.jl:125-171) with base = world: the CLASSICAL acceleration of a point fixed in the hand, i.e. the
+    second time derivative of its world position along q(t) = q + v t + vdot t^2 / 2 (base and every joint off the arm pinned)."""
+    from qpcontrol_jl_amd.workloads import POINT
+    mech = M.atlas()
+    hand = mech.findbody("r_hand")
+    arm = []
+    b = hand
+    while mech.body_names[b] != "utorso" and mech.joint_type[b] != M.QUAT_FLOATING:
+        arm.append(b)
+        b = mech.parent[b]
+    assert 5 <= len(arm) <= 8
+    pt = np.array([0.05, -0.1, 0.02])
+    c = factory(mech, 4, M.WORLD)
+    t_pt = c.add_task(POINT, base=M.WORLD, target=hand, point=pt, wkind=HARD)
+    pinned = []
+    for j in range(mech.nbodies):
+        if mech.joint_type[j] == M.FIXED:
+            continue
+        c.regularize(j, 0.1)
+        if j not in arm:
+            pinned.append((j, c.add_task(JOINT, joint=j, wkind=HARD)))
+    c.finalize()
+    rng = np.random.default_rng(seed)
+    qs, _ = zip(*(M.rand_state(mech, rng, 0.0) for _ in range(B)))
+    q = np.array(qs)
+    v = np.zeros((B, mech.nv)); v[:, 6:] = rng.normal(scale=0.5, size=(B, mech.nv - 6))
+    des = np.zeros((B, c.layout.n_desired))
+    a_des = rng.normal(size=(B, 3))
+    o, n = c.task_desired_range(t_pt)
+    des[:, o:o + n] = a_des
+    voff = {}
+    qo = vo = 0
+    for i in range(mech.nbodies):
+        voff[i] = (qo, vo)
+        qo += M._NQ[mech.joint_type[i]]; vo += M._NV[mech.joint_type[i]]
+    acc = rng.normal(scale=0.5, size=(B, mech.nv)); acc[:, :6] = 0.0
+    for j, tid in pinned:
+        o, n = c.task_desired_range(tid)
+        des[:, o:o + n] = acc[:, voff[j][1]:voff[j][1] + n]
+    r = c.control_batch(q, v, des)
+    assert (r["status"] == 0).all(), r["status"]
+    vd = r["vdot"]
+    qdot = np.zeros_like(q); qdd = np.zeros_like(q)
+    for i in range(mech.nbodies):
+        if mech.joint_type[i] == M.REVOLUTE:
+            qdot[:, voff[i][0]] = v[:, voff[i][1]]; qdd[:, voff[i][0]] = vd[:, voff[i][1]]
+
+    def pos(t):
+        k = W.batch_kinematics(mech, q + t * qdot + 0.5 * t * t * qdd, v)
+        return np.einsum("bij,j->bi", k["R"][hand], pt) + k["p"][hand]
+    h = 2e-3
+    d2 = lambda hh: (pos(hh) - 2.0 * pos(0.0) + pos(-hh)) / (hh * hh)  # noqa: E731
+    acc_fd = (4.0 * d2(h / 2) - d2(h)) / 3.0
+    err = float(np.abs(acc_fd - a_des).max())
+    assert err < 1e-6, err  # (second differences: 1e-16 |p| / h^2 of rounding; measured 7e-10)
+    return err
+
+
+def _check_momentum_rate_task(factory, B, seed=17):
+    """MomentumRateTask (src/tasks.jl:192-236) as a HARD task on the floating Atlas with its contacts: the rate of change of the momentum
+    (independent kinematics, differentiated along the motion), moved to the centre of mass WITHOUT differentiating the transform
+    (k_c' = K_O' - c x L', src/tasks.jl:208-219), must be the desired 6-vector [angular; linear]."""
+    from qpcontrol_jl_amd.workloads import MOMENTUM_RATE
+    mech = M.atlas()
+    c = factory(mech, 4, mech.findbody("pelvis"))
+    for cp in mech.contact_points:
+        c.add_contact(cp.body, cp.position, cp.normal, cp.mu)
+    for j in range(mech.nbodies):
+        if mech.joint_type[j] != M.FIXED:
+            c.regularize(j, 0.05)
+    t_m = c.add_task(MOMENTUM_RATE, wkind=HARD)
+    c.finalize()
+    q, v = W.standing_states(mech, B, seed, dq=0.1, drot=0.05, vstd=0.2)
+    mtot = mech.total_mass()
+    des = np.zeros((B, c.layout.n_desired))
+    rng = np.random.default_rng(seed)
+    o, n = c.task_desired_range(t_m)
+    des[:, o:o + 3] = rng.normal(scale=5.0, size=(B, 3))            # angular momentum rate about the centre of mass
+    des[:, o + 3:o + 6] = rng.normal(scale=0.05 * mtot, size=(B, 3))  # linear momentum rate (a few % of the weight)
+    nc = len(mech.contact_points)
+    r = c.control_batch(q, v, des, np.full((B, nc), 1e-3), np.full((B, nc), 1e6))
+    ok = r["status"] == 0
+    assert ok.mean() > 0.7, r["status"]
+    q, v, vd, want = q[ok], v[ok], r["vdot"][ok], des[ok]
+    h = 1e-4
+
+    def mom(t):
+        L, K, _, _ = _momenta(mech, _advance(mech, q, v, t), v + t * vd)
+        return np.concatenate([L, K], axis=1)
+    d = lambda hh: (mom(hh) - mom(-hh)) / (2 * hh)  # noqa: E731
+    rate = (4.0 * d(h / 2) - d(h)) / 3.0
+    _, _, com, _ = _momenta(mech, q, v)
+    kc = rate[:, 3:] - np.cross(com, rate[:, :3])
+    err = float(max(np.abs(kc - want[:, o:o + 3]).max(), np.abs(rate[:, :3] - want[:, o + 3:o + 6]).max()) / (mtot * 9.81))
+    assert err < 1e-7, err
+    return err
+
+
+def test_point_and_momentum_rate_tasks_against_differentiated_kinematics_emulated():
+    emu.build()
+    e1 = _check_point_task(emu.factory, 3)
+    e2 = _check_momentum_rate_task(emu.factory, 6)
+    print(f"point task {e1:.2e} m/s^2, momentum-rate task {e2:.2e} of m g")
+
+
+@pytest.mark.gpu
+def test_point_and_momentum_rate_tasks_against_differentiated_kinematics_gpu():
+    f = lambda mech, N, fl: binding.Controller(binding.Model(mech), N, fl)  # noqa: E731
+    e1 = _check_point_task(f, 16)
+    e2 = _check_momentum_rate_task(f, 64)
+    print(f"point task {e1:.2e} m/s^2, momentum-rate task {e2:.2e} of m g")
