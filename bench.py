@@ -240,6 +240,46 @@ def secondary_points(torch, binding, W, device_index):
     return out
 
 
+def pipelined_points(torch, binding, W, device_index):
+    """Two INDEPENDENT batches in flight on two launch slots / streams of the device (qpc_control_batch_device_slot): the workgroups of
+    one launch fill the ~110 us tail of the other.  Not the headline (a step there is one launch at a time): what a caller with several
+    independent batches gets.  Config 3 at BASELINE's literal batch (8 192) and at the headline batch (32 768); distinct output arrays."""
+    import ctypes as ct
+    out = []
+    vp = ct.c_void_p
+    for B, steps in ((8192, 60), (32768, 30)):
+        run = DeviceRun(torch, binding, W, B, 3, 2025, device_index)
+        L, lay, dev = run.ctrl.L, run.lay, run.dev
+        if not hasattr(L, "qpc_control_batch_device_slot"):
+            return None
+        sets = []
+        for k in range(2):
+            sets.append(dict(stream=torch.cuda.Stream(dev), tau=torch.empty_like(run.tau), vd=torch.empty_like(run.vd), cwr=torch.empty_like(run.cwr),
+                             status=torch.empty_like(run.status), iters=torch.empty_like(run.iters)))
+        torch.cuda.synchronize(dev)
+
+        def launch(k):
+            o = sets[k]
+            p = lambda t: vp(t.data_ptr())  # noqa: E731
+            rc = L.qpc_control_batch_device_slot(run.ctrl.h, 0, k, B, p(run.q), p(run.v), p(run.des), p(run.cw), p(run.cm), vp(0), vp(0), p(o["tau"]),
+                                                 p(o["vd"]), p(o["cwr"]), p(o["status"]), p(o["iters"]), vp(o["stream"].cuda_stream))
+            if rc != 0:
+                raise RuntimeError(L.qpc_last_error().decode())
+        for i in range(4):
+            launch(i & 1)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            launch(i & 1)
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        same = all(bool(torch.equal(sets[0][k], sets[1][k])) for k in ("tau", "status"))
+        out.append({"config": 3, "batch": B, "launches": steps, "slots": 2, "solves_per_s": B * steps / el, "ms_per_launch": 1e3 * el / steps,
+                    "optimal_fraction": float((sets[0]["status"] == 0).float().mean().item()), "both_slots_bitwise_equal": same})
+        del run, sets
+    return out
+
+
 def closed_loop_point():
     """SURVEY.md 8 f-2, outside the headline's timed region: tools/bench_rollout.py (32 768 robots x 50 controller ticks with
     fused PD laws + simulation steps on the device) in a child process; robot-steps/s or None"""
@@ -416,7 +456,7 @@ def main():
             fp64_measured = ctypes.c_double(0.0)
     n_opt = int((st == 0).sum())
 
-    host_rates, secondary, closed_loop = None, None, None
+    host_rates, secondary, closed_loop, pipelined = None, None, None, None
     if rank == 0 and world == 1 and not args.no_secondary:
         # diagnostic extras, measured after the headline's timed region: none of them may take the bench line down
         if not args.fused_laws:
@@ -428,6 +468,10 @@ def main():
             secondary = secondary_points(torch, binding, W, local_rank)
         except Exception as e:  # noqa: BLE001
             secondary = {"error": repr(e)}
+        try:
+            pipelined = pipelined_points(torch, binding, W, local_rank)
+        except Exception as e:  # noqa: BLE001
+            pipelined = {"error": repr(e)}
         closed_loop = closed_loop_point()
 
     if rank == 0:
@@ -467,6 +511,7 @@ def main():
                                                  "arrays are read / written in place by the kernel (what QPControlHIP.jl does with the "
                                                  "buffers it owns); pageable arrays are staged chunk by chunk by worker threads",
                        "secondary": secondary,
+                       "pipelined": pipelined,
                        "closed_loop": closed_loop,
                        "kernel_fingerprint": fingerprint},
             "roofline": {"bound": "hbm", "achieved": ach_bytes / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",

@@ -319,6 +319,20 @@ int32_t qpc_control_batch_device_on(qpc_controller *ctrl, int32_t device_index, 
                                     double *tau, double *vdot, double *contact_wrench,
                                     int32_t *status, int32_t *iters, void *hip_stream);
 
+/* Same on launch slot `slot` (0 .. QPC_USER_SLOTS - 1) of that device.  Every slot has its own work counter, so launches of
+ * DIFFERENT slots on different streams may overlap; launches of one slot are serialised (a change of stream becomes an event
+ * dependency).  The entry points above use slot 0.  A persistent launch drains over the duration of its longest QP (about 110 us
+ * for the Atlas controller): with two independent batches in flight on two slots the workgroups of one fill the tail of the
+ * other (bench.py config.pipelined).  The batches must use distinct output arrays. */
+#define QPC_USER_SLOTS 4
+int32_t qpc_control_batch_device_slot(qpc_controller *ctrl, int32_t device_index, int32_t slot, int64_t B,
+                                      const double *q, const double *v, const double *desired,
+                                      const double *contact_weight,
+                                      const double *contact_maxnormalforce,
+                                      const double *task_weights, const double *surfaces,
+                                      double *tau, double *vdot, double *contact_wrench,
+                                      int32_t *status, int32_t *iters, void *hip_stream);
+
 /* Warm start -- the counterpart of the reference's persistent OSQP workspace (momentum.jl:58 calls
  * solve! on the SAME model every tick, so OSQP starts from the previous tick's iterate).  Here the
  * carried state is the working set of the active-set search: per QP two 64-bit masks,

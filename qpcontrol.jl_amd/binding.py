@@ -107,6 +107,8 @@ def load_library(path=None):
         L.qpc_host_register.argtypes = [vp, u64]
         L.qpc_host_unregister.argtypes = [vp]
         L.qpc_control_batch_device_on.argtypes = [vp, i32, i64] + [vp] * 12 + [vp]
+        if hasattr(L, "qpc_control_batch_device_slot"):
+            L.qpc_control_batch_device_slot.argtypes = [vp, i32, i32, i64] + [vp] * 12 + [vp]
         L.qpc_control_batch_device_warm.argtypes = [vp, i32, i64] + [vp] * 12 + [vp, vp]
         L.qpc_qp_workspace_bytes.argtypes = [i32, i32, i64]
         L.qpc_qp_workspace_bytes.restype = u64

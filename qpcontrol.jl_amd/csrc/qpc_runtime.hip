@@ -187,7 +187,7 @@ struct QpcRuntime {
   bool stage_zero_copy = true; // pageable arrays: the kernel reads / writes the chunk's pinned staging slab in place over PCIe
                                // (QPC_STAGE_ZEROCOPY=0: DMA the slab to / from device memory instead; measured 10.7 vs 13.2 M solves/s)
   int inline_slot() const { return slots; }
-  int user_slot() const { return slots + 1; }
+  int user_slot(int k = 0) const { return slots + 1 + k; } // QPC_USER_SLOTS launch slots of the *_device entry points
 };
 
 // dynamic-LDS limit of the generic kernels is a per-function attribute shared by every controller of the
@@ -329,11 +329,11 @@ static int init_device_state(qpc_controller *c, QpcDeviceState *S, int device_id
   HIP_TRY(hipMalloc(&S->d_dt, sizeof(double) * c->prog.dtab.size()));
   HIP_TRY(hipMemcpy(S->d_it, c->prog.itab.data(), sizeof(int) * c->prog.itab.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(S->d_dt, c->prog.dtab.data(), sizeof(double) * c->prog.dtab.size(), hipMemcpyHostToDevice));
-  S->slots.resize((size_t)n_slots + 2);
+  S->slots.resize((size_t)n_slots + 1 + QPC_USER_SLOTS);
   for (size_t i = 0; i < S->slots.size(); i++) {
     QpcSlot &sl = S->slots[i];
-    if (i + 1 < S->slots.size()) HIP_TRY(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
-    else HIP_TRY(hipEventCreateWithFlags(&sl.last_event, hipEventDisableTiming));
+    if (i <= (size_t)n_slots) HIP_TRY(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking)); // workers and the inline slot own a stream
+    else HIP_TRY(hipEventCreateWithFlags(&sl.last_event, hipEventDisableTiming));                  // user slots run on the caller's
     HIP_TRY(hipMalloc(&sl.d_ticket, sizeof(unsigned long long)));
     HIP_TRY(hipMemset(sl.d_ticket, 0, sizeof(unsigned long long)));
   }
@@ -741,9 +741,10 @@ void qpc_controller_destroy(qpc_controller *c) {
 static int control_device(qpc_controller *c, int device_index, int64_t B, const double *q, const double *v, const double *desired,
                           const double *cw, const double *cmax, const double *tw, const double *surf, double *tau, double *vdot,
                           double *cwrench, int32_t *status, int32_t *iters, unsigned long long *wsets, void *hip_stream,
-                          const char *who) {
+                          const char *who, int slot = 0) {
   if (!c || !c->finalized || !c->rt) { qpc_set_error("controller not finalized"); return QPC_ERR_NOT_FINALIZED; }
   if (device_index < 0 || device_index >= (int)c->rt->devs.size()) { qpc_set_error(std::string(who) + ": device index out of range"); return QPC_ERR_INVALID_ARGUMENT; }
+  if (slot < 0 || slot >= QPC_USER_SLOTS) { qpc_set_error(std::string(who) + ": launch slot out of range"); return QPC_ERR_INVALID_ARGUMENT; }
   const QpcDims &D = c->prog.dims;
   if (B < 0 || !q || !v || !tau || !vdot || !status || (D.n_des_inputs && !desired) || (D.nc && (!cw || !cmax)) ||
       (D.n_tw && !tw) || (D.n_surf && !surf)) {
@@ -755,7 +756,7 @@ static int control_device(qpc_controller *c, int device_index, int64_t B, const 
   a.tau = tau; a.vdot = vdot; a.cwrench = cwrench; a.status = status; a.iters = iters;
   a.prof = S->prof; a.wsets = wsets;
   HIP_TRY(hipSetDevice(S->device));
-  return launch(c, S, S->slots[c->rt->user_slot()], a, (hipStream_t)hip_stream, wsets != nullptr);
+  return launch(c, S, S->slots[c->rt->user_slot(slot)], a, (hipStream_t)hip_stream, wsets != nullptr);
 }
 
 int32_t qpc_control_batch_device(qpc_controller *c, int64_t B, const double *q, const double *v,
@@ -772,6 +773,14 @@ int32_t qpc_control_batch_device_on(qpc_controller *c, int32_t device_index, int
                                     int32_t *iters, void *hip_stream) {
   return control_device(c, device_index, B, q, v, desired, cw, cmax, tw, surf, tau, vdot, cwrench, status, iters, nullptr,
                         hip_stream, "qpc_control_batch_device_on");
+}
+
+int32_t qpc_control_batch_device_slot(qpc_controller *c, int32_t device_index, int32_t slot, int64_t B, const double *q, const double *v,
+                                      const double *desired, const double *cw, const double *cmax, const double *tw,
+                                      const double *surf, double *tau, double *vdot, double *cwrench, int32_t *status,
+                                      int32_t *iters, void *hip_stream) {
+  return control_device(c, device_index, B, q, v, desired, cw, cmax, tw, surf, tau, vdot, cwrench, status, iters, nullptr,
+                        hip_stream, "qpc_control_batch_device_slot", slot);
 }
 
 int32_t qpc_control_batch_device_warm(qpc_controller *c, int32_t device_index, int64_t B, const double *q, const double *v,

@@ -137,6 +137,38 @@ def warm_mixed_rollouts():
     torch.cuda.synchronize(dev)
 
 
+def slots():
+    """qpc_control_batch_device_slot: launches of DIFFERENT slots on different streams overlap (own work counters) -- every result
+    complete and equal to the reference, also when the same slot is reused across streams and when batches differ in size"""
+    B = 4096
+    c, ref, dev, t = setup(B)
+    lay = c.layout
+    L = c.L
+    ss = [torch.cuda.Stream(dev) for _ in range(4)]
+    outs = []
+    for rep in range(12):
+        tau = torch.full((B, lay.nv), float("nan"), dtype=torch.float64, device=dev)
+        vd = torch.empty((B, lay.nv), dtype=torch.float64, device=dev)
+        st = torch.full((B,), -1, dtype=torch.int32, device=dev)
+        outs.append((tau, vd, st))
+    torch.cuda.synchronize(dev)
+    for rep, (tau, vd, st) in enumerate(outs):
+        slot = rep % 4
+        n = B if rep % 3 else B // 2 + 7  # some launches only solve a prefix of the batch
+        rc = L.qpc_control_batch_device_slot(c.h, 0, slot, n, vp(t["q"].data_ptr()), vp(t["v"].data_ptr()), vp(t["d"].data_ptr()),
+                                             vp(t["cw"].data_ptr()), vp(t["cm"].data_ptr()), vp(0), vp(0), vp(tau.data_ptr()), vp(vd.data_ptr()), vp(0),
+                                             vp(st.data_ptr()), vp(0), vp(ss[(rep + rep // 4) % 4].cuda_stream))
+        assert rc == 0, L.qpc_last_error()
+    torch.cuda.synchronize(dev)
+    for rep, (tau, vd, st) in enumerate(outs):
+        n = B if rep % 3 else B // 2 + 7
+        assert np.array_equal(st.cpu().numpy()[:n], ref["status"][:n])
+        assert np.array_equal(tau.cpu().numpy()[:n], ref["tau"][:n])
+        assert np.isnan(tau.cpu().numpy()[n:]).all()
+    rc = L.qpc_control_batch_device_slot(c.h, 0, 4, B, *([vp(0)] * 12), vp(0))  # slot out of range
+    assert rc != 0
+
+
 if __name__ == "__main__":
-    {"streams": streams, "graph": graph, "warm_mixed_rollouts": warm_mixed_rollouts}[sys.argv[1]]()
+    {"streams": streams, "graph": graph, "warm_mixed_rollouts": warm_mixed_rollouts, "slots": slots}[sys.argv[1]]()
     print("CHECK_OK")

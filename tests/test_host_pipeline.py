@@ -224,6 +224,12 @@ def test_gpu_graph_replay_of_the_tick():
 
 
 @pytest.mark.gpu
+def test_gpu_launch_slots_overlap_safely():
+    """qpc_control_batch_device_slot: four slots on four streams in flight at once, slots reused across streams, prefix batches"""
+    _run_torch_check("slots")
+
+
+@pytest.mark.gpu
 def test_gpu_warm_controller_mixes_device_and_host_rollouts():
     """the host rollout must not free the device rollout's working-set buffer (tests/gpu_torch_checks.py)"""
     _run_torch_check("warm_mixed_rollouts")
