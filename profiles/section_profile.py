@@ -62,6 +62,10 @@ def main():
            "mean_iters": float((r["iters"] % 1000).mean()),
            "sections": {n: {"mean_cycles": float(p[:, i].mean()), "share": float(p[:, i].sum() / tot.sum())}
                         for i, n in enumerate(NAMES)}}
+    if "--by-ticket" in sys.argv:  # how a section's cycles depend on when the QP was drawn (eighths of the batch, in ticket order)
+        names = [a for a in sys.argv if a in NAMES] or ["k_input"]
+        out["by_ticket_eighth"] = {n: [float(c.mean()) for c in np.array_split(p[:, NAMES.index(n)], 8)] for n in names}
+        out["by_ticket_eighth"]["total"] = [float(c.mean()) for c in np.array_split(tot, 8)]
     print(json.dumps(out, indent=1))
 
 
