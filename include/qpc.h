@@ -279,7 +279,9 @@ int32_t qpc_set_settings(qpc_controller *ctrl, const qpc_settings *s);
  *        surfaces[n_surface*B] or NULL
  *   out: tau[nv*B], vdot[nv*B] (result.vdot, momentum.jl:62-64),
  *        contact_wrench[6*nc*B] (value(wrench_world) per contact, world frame, [ang;lin],
- *        contacts.jl:82-89) or NULL, status[B] (QPC_STATUS_*), iters[B] or NULL
+ *        contacts.jl:82-89) or NULL, status[B] (QPC_STATUS_*), iters[B] or NULL (diagnostic: working-set changes of the
+ *        search + 1000 x refinement sweeps of the final solve + 1000000 if the QP was solved in the reduced dimensions of
+ *        the null-space presolve)
  * Host-pointer variant: synchronous; the batch is sharded over the controller's devices and
  * pipelined in chunks (H2D || kernel || D2H, qpc_set_host_pipeline). */
 int32_t qpc_control_batch(qpc_controller *ctrl, int64_t B, const double *q, const double *v,

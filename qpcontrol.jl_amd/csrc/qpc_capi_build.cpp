@@ -231,3 +231,9 @@ extern "C" int32_t qpc_debug_k_tables(qpc_controller *c) {
   if (!c || !c->finalized) return -1;
   return c->prog.dims.k_tab ? c->prog.dims.k_classes : 0;
 }
+
+// diagnostic: number of row blocks the null-space presolve eliminates (0: the program has none; tests/test_presolve.py)
+extern "C" int32_t qpc_debug_presolve_blocks(qpc_controller *c) {
+  if (!c || !c->finalized) return -1;
+  return c->prog.dims.presolve;
+}

@@ -640,6 +640,89 @@ int qpc_compile_program(qpc_controller *c) {
   { int xe = xbase + even(m1 * D.m1s), ye = xbase + even(QPC_GS(nrho) * 6); off = vec_end; if (xe > off) off = xe; if (ye > off) off = ye; }
   D.lds[L_RED] = off; // unused on the device (wave reductions); the emulator has its own scratch
   if (early_end > off) off = early_end;
+  // ---- null-space presolve (QpcDims::presolve): hard 6-row SpatialAccelerationTask blocks whose path holds exactly six free 1-DoF
+  // columns outside the floating joint that no other eliminated block claims -- their rows are then [A_e (6 x 6, those columns) | B_e
+  // (columns that stay)] and nothing else, and v_e = A_e^-1 (b_e - B_e v_b) for every state in which A_e is well conditioned.
+  // The device code indexes by arithmetic, not by tables, so the layout has to be the regular one: the eliminated blocks are the first
+  // row blocks, their columns follow each other in block order, the columns that stay are consecutive (a standing controller's two foot
+  // tasks registered first, as StandingController does, on a model whose legs are listed one after the other).
+  D.presolve = 0; D.pre_nf = D.nf; D.pre_m = D.m; D.pre_c0 = D.pre_b0 = 0;
+  D.it[IT_HOT_S] = 0;
+  D.lds[L_PA] = D.lds[L_PZ] = D.lds[L_PH] = D.lds[L_PC] = 0;
+  QpcDims DS; // finished below (a copy of D with the solver's dimensions and array places)
+  int s_lds[7] = {0, 0, 0, 0, 0, 0, 0}; // places of M, d, HV, SQH, GV, XV, HOT of the reduced problem
+  if (!getenv("QPC_NO_PRESOLVE") && D.nw == 6 && D.nrho > 0 && D.ve_exact_ok && c->floating >= 0) {
+    struct Elim { int g, row0; int cols[6]; };
+    std::vector<Elim> el;
+    std::vector<char> col_taken(D.nf, 0);
+    for (size_t g = 0; g < generic.size() && el.size() < 4; g++) {
+      const QpcTask &t = c->tasks[generic[g]];
+      if (t.kind != QPC_TASK_SPATIAL_ACCELERATION || t.wkind != QPC_WEIGHT_HARD || t.dim != 6 || row0[g] != 6 * (int)el.size()) break;
+      // path columns (as IT_T_SGN): joints between the lowest common ancestor of base and target and either of them
+      std::vector<char> mark(nb, 0);
+      for (int b = t.target; b >= 0; b = m->parent[b]) mark[b] = 1;
+      int lca = -1;
+      for (int b = t.base; b >= 0; b = m->parent[b]) if (mark[b]) { lca = b; break; }
+      std::vector<int> priv;
+      bool ok = true;
+      auto visit = [&](int b) {
+        if (b == c->floating) return; // its free columns stay
+        for (int k = 0; k < m->nvj[b]; k++) {
+          const int f = free_of[m->voff[b] + k];
+          if (f < 0) continue;              // pinned: a constant of the row
+          if (m->nvj[b] != 1 || col_taken[f]) ok = false;
+          priv.push_back(f);
+        }
+      };
+      for (int b = t.base; b >= 0 && b != lca; b = m->parent[b]) visit(b);
+      for (int b = t.target; b >= 0 && b != lca; b = m->parent[b]) visit(b);
+      if (!ok || priv.size() != 6) break;
+      std::sort(priv.begin(), priv.end());
+      if (priv[5] != priv[0] + 5 || (!el.empty() && priv[0] != el.back().cols[5] + 1)) break;
+      Elim e; e.g = (int)g; e.row0 = row0[g];
+      for (int i = 0; i < 6; i++) { e.cols[i] = priv[i]; col_taken[priv[i]] = 1; }
+      el.push_back(e);
+    }
+    const int n_e = (int)el.size(), nf_s = D.nf - 6 * n_e, m1_s = m1 - 6 * n_e, m_s = m1_s + D.nw;
+    std::vector<int> bcols;
+    for (int f = 0; f < D.nf; f++) if (!col_taken[f]) bcols.push_back(f);
+    bool regular = n_e > 0 && nf_s >= 1 && nf_s <= 4 && n_e <= 4 && m_s * nf_s + m_s + nf_s * (nf_s + 1) / 2 + nf_s <= 64;
+    for (int b = 1; b < (int)bcols.size(); b++) regular = regular && bcols[b] == bcols[0] + b;
+    if (regular) {
+      std::vector<int> hot_s;
+      { // hot lookups of the reduced problem: the slack tables with the rows renumbered (row r -> r - 6 n_e)
+        std::vector<int> row_slack(m_s, -1), srow, swoff, sdim, ss0;
+        for (size_t g = 0; g < generic.size(); g++) {
+          const QpcTask &t = c->tasks[generic[g]];
+          if (slack0[g] < 0) continue;
+          for (int a = 0; a < t.dim; a++) {
+            row_slack[row0[g] + a - 6 * n_e] = slack0[g] + a;
+            srow.push_back(row0[g] + a - 6 * n_e); swoff.push_back(woff[g] + a * t.dim); sdim.push_back(t.dim); ss0.push_back(slack0[g]);
+          }
+        }
+        hot_s.insert(hot_s.end(), row_slack.begin(), row_slack.end());
+        hot_s.insert(hot_s.end(), srow.begin(), srow.end());
+        hot_s.insert(hot_s.end(), swoff.begin(), swoff.end());
+        hot_s.insert(hot_s.end(), sdim.begin(), sdim.end());
+        hot_s.insert(hot_s.end(), ss0.begin(), ss0.end());
+      }
+      auto lead2 = [](int n) { int s_ = (n > 0 ? n : 1); s_ += s_ & 1; if (s_ % 8 == 0) s_ += 2; return s_; };
+      const int nfs_s = lead2(nf_s), nr = 6 * n_e;
+      const int need = even(nr * (nf_s + 2)) + even(nf_s * (nf_s + 1) / 2 + nf_s) + even(nf_s * nf_s) + even(m_s * nfs_s) + even(m_s) +
+                       4 * even(nf_s) + even(m_s + 4 * ne);
+      auto per_cu = [](int doubles) { const int n = doubles > 0 ? (160 * 1024) / (doubles * 8) : 8; return n > 8 ? 8 : n; };
+      if (per_cu(off + need) >= 1 && per_cu(off + need) >= per_cu(off) && b_base + even(m_s * nf_s) <= off) {
+        D.presolve = n_e; D.pre_nf = nf_s; D.pre_m = m_s; D.pre_c0 = el[0].cols[0]; D.pre_b0 = bcols[0];
+        D.lds[L_PA] = b_base; // region B is idle between the assembly and the solve
+        L(L_PZ, nr * (nf_s + 2)); L(L_PH, nf_s * (nf_s + 1) / 2 + nf_s); L(L_PC, nf_s * nf_s);
+        s_lds[0] = off; off = even(off + m_s * nfs_s);
+        s_lds[1] = off; off = even(off + m_s);
+        for (int k = 2; k < 6; k++) { s_lds[k] = off; off = even(off + nf_s); }
+        s_lds[6] = off; off = even(off + m_s + 4 * ne);
+        B.ibegin(IT_HOT_S); B.it.insert(B.it.end(), hot_s.begin(), hot_s.end()); B.it.push_back(0);
+      }
+    }
+  }
   D.lds_doubles = off;
   if (const char *e = getenv("QPC_DUMP_LDS")) { // diagnostic: the overlay map (offsets in doubles)
     if (e[0] == '1') {
@@ -660,6 +743,16 @@ int qpc_compile_program(qpc_controller *c) {
   D.tau_pivot = c->settings.eps_dual_reg;
   D.tol_bound = c->settings.tol_bound;
   D.tol_accept = 1e-7;
+  DS = D;
+  if (D.presolve) {
+    auto lead2 = [](int n) { int s_ = (n > 0 ? n : 1); s_ += s_ & 1; if (s_ % 8 == 0) s_ += 2; return s_; };
+    DS.nf = D.pre_nf; DS.m = D.pre_m; DS.m1 = D.pre_m - D.nw;
+    DS.nfs = lead2(DS.nf); DS.ms = lead2(DS.m); DS.m1s = odd(DS.m1 > 0 ? DS.m1 : 1);
+    DS.lds[L_M] = s_lds[0]; DS.lds[L_D] = s_lds[1]; DS.lds[L_HV] = s_lds[2]; DS.lds[L_SQH] = s_lds[3]; DS.lds[L_GV] = s_lds[4];
+    DS.lds[L_XV] = s_lds[5]; DS.lds[L_HOT] = s_lds[6];
+    DS.it[IT_HOT] = D.it[IT_HOT_S];
+  }
+  P.dims_s = DS;
   P.itab.swap(B.it);
   P.dtab.swap(B.dt);
 

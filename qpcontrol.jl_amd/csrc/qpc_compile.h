@@ -31,6 +31,8 @@ struct QpcContact {
 
 struct QpcProgram {
   QpcDims dims;
+  QpcDims dims_s; // dims.presolve: the reduced problem the solver runs on (same tables and slab; other nf, m1, m, leading
+                  // dimensions, and its own places for M, d, the Hessian vectors, the iterate's v̇ part and the hot lookups)
   std::vector<int> itab;
   std::vector<double> dtab;
 };

@@ -3,6 +3,7 @@
 #pragma once
 
 #define QPC_FN __device__ __forceinline__
+#define QPC_LAMBDA_INLINE __attribute__((always_inline))
 // The lane index is made OPAQUE once per QP (per function scope that runs phases: QPC_LANE_SCOPE).  Without it the compiler
 // treats everything derived from the lane (table addresses, lane-dependent constants of the unrolled factorization phases,
 // ...) as invariant of the persistent per-QP loop, hoists dozens of such values out of it and, out of registers, spills
@@ -205,6 +206,27 @@ __device__ __forceinline__ double qpc_quad_bcast(double x, int i) {
     const double x__ = (XEXPR);                                                                  \
     out__[0] = qpc_quad_bcast(x__, 0); out__[1] = qpc_quad_bcast(x__, 1);                        \
     out__[2] = qpc_quad_bcast(x__, 2); out__[3] = qpc_quad_bcast(x__, 3);                        \
+  }
+
+// OUT[i] = X[i] of lane 16 * (lane / 16) + K, i = 0 .. N - 1: DPP row_share broadcasts inside the rows of 16 lanes (no LDS).
+// Phase level only (all 64 lanes), like QPC_QUAD_GATHER.
+__device__ __forceinline__ double qpc_row_share(double x, int k) {
+  const int lo = __double2loint(x), hi = __double2hiint(x);
+  int l, h;
+#define QPC_RS_CASE(K) case K: l = __builtin_amdgcn_update_dpp(lo, lo, 0x150 + K, 0xf, 0xf, false); h = __builtin_amdgcn_update_dpp(hi, hi, 0x150 + K, 0xf, 0xf, false); break;
+  switch (k & 15) {
+    QPC_RS_CASE(0) QPC_RS_CASE(1) QPC_RS_CASE(2) QPC_RS_CASE(3) QPC_RS_CASE(4) QPC_RS_CASE(5) QPC_RS_CASE(6) QPC_RS_CASE(7)
+    QPC_RS_CASE(8) QPC_RS_CASE(9) QPC_RS_CASE(10) QPC_RS_CASE(11) QPC_RS_CASE(12) QPC_RS_CASE(13) QPC_RS_CASE(14)
+    default: l = __builtin_amdgcn_update_dpp(lo, lo, 0x15f, 0xf, 0xf, false); h = __builtin_amdgcn_update_dpp(hi, hi, 0x15f, 0xf, 0xf, false); break;
+  }
+#undef QPC_RS_CASE
+  return __hiloint2double(h, l);
+}
+#define QPC_ROW_SHARE(lane, OUT, N, X, K)                                                         \
+  {                                                                                              \
+    double *out__ = (OUT);                                                                       \
+    const double *x__ = (X);                                                                     \
+    for (int i__ = 0; i__ < (N); i__++) out__[i__] = qpc_row_share(x__[i__], (K));               \
   }
 
 // fp64 matrix core: acc(16x16 tile, 4 f64 per lane) += A(16x4) * B(4x16) with v_mfma_f64_16x16x4_f64.

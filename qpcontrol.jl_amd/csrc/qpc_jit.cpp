@@ -42,7 +42,21 @@ int qpc_jit_sim_rpw(const QpcDims &D) {
   return (D.nb <= 32 && D.nc <= 32 && (size_t)2 * slab * sizeof(double) <= 64 * 1024) ? 2 : 1;
 }
 
-std::string qpc_jit_source(const QpcDims &D, bool warm) {
+static void put_dims(std::ostringstream &o, const char *name, const QpcDims &D) {
+  o << "static constexpr QpcDims " << name << " = {" << D.nb << "," << D.nq << "," << D.nv << "," << D.nf << "," << D.npin << ","
+    << D.nsj << "," << D.ntask << "," << D.nc << "," << D.N << "," << D.nrho << "," << D.ne << "," << D.m << ","
+    << D.m1 << "," << D.nw << "," << D.floating << "," << D.fv0 << "," << D.n_desired << "," << D.n_tw << ","
+    << D.n_surf << "," << D.maxdepth << "," << D.n_items << "," << D.ve_exact_ok << "," << D.n_des_inputs << "," << D.n_des_late << "," << D.law_mask << "," << D.maxd << "," << D.crb_full_body << "," << D.nfs << "," << D.ms << "," << D.m1s << "," << D.wsize << "," << D.h_static << "," << D.k_tab << "," << D.k_classes << ",";
+  put_ints(o, D.k_class, 16); o << ",";
+  put_ints(o, D.it, IT_COUNT); o << ",";
+  put_ints(o, D.dt, DT_COUNT); o << ",";
+  put_ints(o, D.lds, L_COUNT); o << ",";
+  o << D.lds_doubles << "," << D.n_int << "," << D.n_dbl << "," << D.presolve << "," << D.pre_nf << "," << D.pre_m << "," << D.pre_c0 << "," << D.pre_b0 << "," << D.max_as_iters << "," << D.max_refine << ","
+    << D.max_pdas << "," << dbl(D.eps_primal) << "," << dbl(D.tau_pivot) << "," << dbl(D.tol_bound) << ","
+    << dbl(D.tol_accept) << "," << dbl(D.h_static_max) << "," << dbl(D.h_static_min) << "," << dbl(D.k_mu2) << "};\n";
+}
+
+std::string qpc_jit_source(const QpcDims &D, const QpcDims &DS, bool warm) {
   std::ostringstream o;
   o << "typedef int int32_t;\ntypedef unsigned int uint32_t;\ntypedef long long int64_t;\ntypedef unsigned long long uint64_t;\n";
   o << "#define QPC_JIT 1\n#define QPC_M1_MAX " << (D.m1 > 0 ? D.m1 : 1) << "\n#define QPC_MAXD " << D.maxd << "\n#define QPC_NTILE_MAX " << (((D.m + 15) / 16) * (((D.m + 15) / 16) + 1) / 2 > 0 ? ((D.m + 15) / 16) * (((D.m + 15) / 16) + 1) / 2 : 1) << "\n#define QPC_XTILE_MAX " << (((D.m1 + 15) / 16) * (((D.m1 + 15) / 16) + 1) / 2 + (D.m1 + 15) / 16 > 0 ? ((D.m1 + 15) / 16) * (((D.m1 + 15) / 16) + 1) / 2 + (D.m1 + 15) / 16 : 1)
@@ -65,17 +79,8 @@ std::string qpc_jit_source(const QpcDims &D, bool warm) {
        "#include \"qpc_sim.h\"\n";
   // field order == struct QpcDims (qpc_program.h)
   o << "static_assert(sizeof(QpcDims) == " << sizeof(QpcDims) << ", \"QpcDims layout differs between host and JIT source\");\n";
-  o << "static constexpr QpcDims kD = {" << D.nb << "," << D.nq << "," << D.nv << "," << D.nf << "," << D.npin << ","
-    << D.nsj << "," << D.ntask << "," << D.nc << "," << D.N << "," << D.nrho << "," << D.ne << "," << D.m << ","
-    << D.m1 << "," << D.nw << "," << D.floating << "," << D.fv0 << "," << D.n_desired << "," << D.n_tw << ","
-    << D.n_surf << "," << D.maxdepth << "," << D.n_items << "," << D.ve_exact_ok << "," << D.n_des_inputs << "," << D.n_des_late << "," << D.law_mask << "," << D.maxd << "," << D.crb_full_body << "," << D.nfs << "," << D.ms << "," << D.m1s << "," << D.wsize << "," << D.h_static << "," << D.k_tab << "," << D.k_classes << ",";
-  put_ints(o, D.k_class, 16); o << ",";
-  put_ints(o, D.it, IT_COUNT); o << ",";
-  put_ints(o, D.dt, DT_COUNT); o << ",";
-  put_ints(o, D.lds, L_COUNT); o << ",";
-  o << D.lds_doubles << "," << D.n_int << "," << D.n_dbl << "," << D.max_as_iters << "," << D.max_refine << ","
-    << D.max_pdas << "," << dbl(D.eps_primal) << "," << dbl(D.tau_pivot) << "," << dbl(D.tol_bound) << ","
-    << dbl(D.tol_accept) << "," << dbl(D.h_static_max) << "," << dbl(D.h_static_min) << "," << dbl(D.k_mu2) << "};\n";
+  put_dims(o, "kD", D);
+  put_dims(o, "kDS", DS);
   o << "struct QpcBatchArgs { long long B; const double *q, *v, *desired, *cw, *cmax, *tw, *surf; double *tau, *vdot, "
        "*cwrench; int32_t *status, *iters; unsigned long long *prof; unsigned long long *ticket; unsigned long long *wsets; };\n";
   // the tick kernel (cold start) and, on request, its warm-started twin: same loop, qpc_tick<P, true>
@@ -101,7 +106,7 @@ std::string qpc_jit_source(const QpcDims &D, bool warm) {
     o <<
          "  " << (f32 ? "const qpc::F32Ptr qpc_lds{qpc_lds_raw};" : "double *const qpc_lds = qpc_lds_raw;") << "\n"
          "  typedef " << (f32 ? "qpc::F32Ptr" : "double *") << " LdsP;\n"
-         "  qpc::qpc_tick_prologue<LdsP>(kD, IT, qpc_lds);\n"
+         "  qpc::qpc_tick_prologue<LdsP>(kD, kDS, IT, qpc_lds);\n"
          "  while (true) {\n"
          "#ifdef QPC_KERNARG_RELOAD\n"
          "    // the launch arguments are re-read from the kernarg segment (scalar loads, scalar cache) where they are used: kept in\n"
@@ -134,7 +139,7 @@ std::string qpc_jit_source(const QpcDims &D, bool warm) {
          "    const __attribute__((address_space(1))) double *DTg = (const __attribute__((address_space(1))) double *)DT;\n"
          "    asm volatile(\"\" : \"+s\"(ITg), \"+s\"(DTg));\n"
          "    const int *ITq = (const int *)ITg; const double *DTq = (const double *)DTg;\n"
-         "    qpc::qpc_tick<LdsP, " << (variant ? "true" : "false") << ">(kD, ITq, DTq, qpc_lds, io);\n"
+         "    qpc::qpc_tick<LdsP, " << (variant ? "true" : "false") << ">(kD, kDS, ITq, DTq, qpc_lds, io);\n"
          "    __syncthreads();\n"
 
          "  }\n"
@@ -172,8 +177,8 @@ std::string qpc_jit_source(const QpcDims &D, bool warm) {
 static std::mutex g_jit_mu;
 static std::map<std::string, std::vector<char>> g_jit_cache;
 
-int qpc_jit_compile(const QpcDims &D, const std::string &arch, bool warm, std::vector<char> &code, std::string &log) {
-  std::string src = qpc_jit_source(D, warm);
+int qpc_jit_compile(const QpcDims &D, const QpcDims &DS, const std::string &arch, bool warm, std::vector<char> &code, std::string &log) {
+  std::string src = qpc_jit_source(D, DS, warm);
   std::string key;
   {
     const char *ce = getenv("QPC_JIT_CACHE"), *xe = getenv("QPC_JIT_EXTRA_FLAGS");
@@ -249,7 +254,7 @@ extern "C" int32_t qpc_debug_jit_compile(qpc_controller *c, const char *arch, co
   if (!c->finalized) { int rc = qpc_compile_program(c); if (rc != QPC_OK) return rc; }
   std::vector<char> code;
   std::string log;
-  int rc = qpc_jit_compile(c->prog.dims, arch ? arch : "gfx950", c->warm_start != 0, code, log);
+  int rc = qpc_jit_compile(c->prog.dims, c->prog.dims_s, arch ? arch : "gfx950", c->warm_start != 0, code, log);
   if (logbuf && logn > 0) snprintf(logbuf, logn, "%s", log.c_str());
   if (rc != 0) { qpc_set_error("JIT compile failed: " + log); return QPC_ERR_HIP; }
   if (out_path) { FILE *f = fopen(out_path, "wb"); if (f) { fwrite(code.data(), 1, code.size(), f); fclose(f); } }
@@ -260,7 +265,7 @@ extern "C" int32_t qpc_debug_jit_compile(qpc_controller *c, const char *arch, co
 extern "C" int32_t qpc_debug_jit_source(qpc_controller *c, const char *out_path) {
   if (!c || !out_path) return QPC_ERR_INVALID_ARGUMENT;
   if (!c->finalized) { int rc = qpc_compile_program(c); if (rc != QPC_OK) return rc; }
-  std::string src = qpc_jit_source(c->prog.dims, c->warm_start != 0);
+  std::string src = qpc_jit_source(c->prog.dims, c->prog.dims_s, c->warm_start != 0);
   FILE *f = fopen(out_path, "wb");
   if (!f) return QPC_ERR_INVALID_ARGUMENT;
   fwrite(src.data(), 1, src.size(), f);

@@ -7,9 +7,9 @@
 
 // source of the specialised translation unit (QpcDims baked in as a constexpr object)
 // warm: also emit qpc_tick_kernel_jit_warm (the warm-started variant, qpc_enable_warm_start)
-std::string qpc_jit_source(const QpcDims &D, bool warm);
+std::string qpc_jit_source(const QpcDims &D, const QpcDims &DS, bool warm);
 // compile for `arch` (e.g. "gfx950"); returns 0 and fills `code` on success, else fills `log`
-int qpc_jit_compile(const QpcDims &D, const std::string &arch, bool warm, std::vector<char> &code, std::string &log);
+int qpc_jit_compile(const QpcDims &D, const QpcDims &DS, const std::string &arch, bool warm, std::vector<char> &code, std::string &log);
 // robots per wavefront of the JIT-specialised simulation step (qpc_sim.h): 2 when a robot fits half a wave and two
 // LDS slabs fit a workgroup (QPC_SIM_RPW=1 forces one)
 int qpc_jit_sim_rpw(const QpcDims &D);

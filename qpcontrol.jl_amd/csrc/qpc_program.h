@@ -41,6 +41,7 @@ enum {
           //   JOINT_PD: q index, v index;  COM_PD: component, -;  ORIENTATION_PD: body, component
   IT_SIM_TREE, // [(nb + 1) * 4] simulation step: per body {children mask lo, hi, height, depth}; last row {max height, max depth}
   IT_HOT, // solver lookups staged into LDS per QP: row_slack[m], slack_row[ne], slack_woff[ne], slack_dim[ne], slack_s0[ne]
+  IT_HOT_S, // IT_HOT of the reduced problem of the presolve (rows renumbered)
   IT_COUNT
 };
 
@@ -96,6 +97,11 @@ enum {
   L_BW,                  // nb*6 body wrenches (RNEA)
   L_SVK,                 // nv*6 S_k * vdot_k (RNEA)
   L_WSP,                 // nrho working set before the last primal-dual update (fallback of the search)
+  // ---- presolve (QpcDims::presolve; qpc_tick.h presolve / postsolve)
+  L_PA,                  // m_s x nf_s: M^ before the whitening, overlays the solver scratch
+  L_PZ,                  // (nf_s + 2) x 6 n_e: P, the columns of Q, P + g~ of the eliminated unknowns (persistent: the postsolve reads it)
+  L_PH,                  // nf_s (nf_s + 1) / 2 + nf_s: H' = I + Q'Q (packed lower) and the linear term h
+  L_PC,                  // nf_s x nf_s: C^-1 (lower), H' = C C'
   L_COUNT
 };
 
@@ -153,6 +159,13 @@ struct QpcDims {
   int lds[L_COUNT];
   int lds_doubles;   // per-QP LDS slab size
   int n_int, n_dbl;  // table sizes
+  // Null-space presolve of hard 6-row task blocks with six private free columns (the foot tasks of a standing controller: the six joint
+  // accelerations of a leg are determined by the task and the base acceleration): v_L = P - Q v_b is substituted into the remaining rows
+  // and the objective, the solver runs on nf_s columns / m_s rows (QpcProgram::dims_s), the postsolve restores the eliminated columns.
+  // A QP whose elimination is ill-conditioned (a leg near a singularity) is solved as assembled, by the same kernel.
+  int presolve;      // number of eliminated blocks n_e (0: none).  Block e is rows 6 e .. 6 e + 5 and free columns pre_c0 + 6 e .. + 5
+  int pre_nf, pre_m; // nf_s, m_s: the free columns pre_b0 .. pre_b0 + nf_s - 1 and the rows 6 n_e .. m - 1 stay
+  int pre_c0, pre_b0;
   // solver settings (qpc_settings)
   int max_as_iters, max_refine, max_pdas;
   double eps_primal, tau_pivot, tol_bound, tol_accept;

@@ -79,9 +79,9 @@ struct QpcBatchArgs {
 };
 
 extern "C" __global__ void __launch_bounds__(64, 1)
-qpc_tick_kernel(const QpcDims D, const int *__restrict__ IT, const double *__restrict__ DT, const QpcBatchArgs A) {
+qpc_tick_kernel(const QpcDims D, const QpcDims DS, const int *__restrict__ IT, const double *__restrict__ DT, const QpcBatchArgs A) {
   extern __shared__ __attribute__((aligned(16))) double qpc_lds[];
-  qpc::qpc_tick_prologue<double *>(D, IT, qpc_lds);
+  qpc::qpc_tick_prologue<double *>(D, DS, IT, qpc_lds);
   // active-set iteration counts differ per QP (p99 ~ 3x mean): QPs are handed out through one
   // device-scope ticket counter instead of a static grid-stride, so no workgroup idles at the tail
   while (true) {
@@ -102,7 +102,7 @@ qpc_tick_kernel(const QpcDims D, const int *__restrict__ IT, const double *__res
     io.status = A.status + b; io.iters = A.iters ? A.iters + b : nullptr;
     io.prof = A.prof ? A.prof + b * PS_COUNT : nullptr;
     io.wset = A.wsets ? A.wsets + 2 * b : nullptr;
-    qpc::qpc_tick<double *>(D, IT, DT, qpc_lds, io);
+    qpc::qpc_tick<double *>(D, DS, IT, DT, qpc_lds, io);
     __syncthreads(); // the slab is reused by the next QP of this workgroup
   }
 }
@@ -233,7 +233,7 @@ static int launch(qpc_controller *c, QpcDeviceState *S, QpcSlot &sl, const QpcBa
     if (dyn) if (const char *e = getenv("QPC_EXP_LDS_PAD")) dyn += (unsigned)atoi(e); // ... QPC_EXP_LDS_PAD=bytes: occupancy at will
     HIP_TRY(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 64, 1, 1, dyn, stream, args, nullptr));
   } else {
-    hipLaunchKernelGGL(qpc_tick_kernel, dim3((unsigned)grid), dim3(64), lds, stream, D, S->d_it, S->d_dt, aa);
+    hipLaunchKernelGGL(qpc_tick_kernel, dim3((unsigned)grid), dim3(64), lds, stream, D, c->prog.dims_s, S->d_it, S->d_dt, aa);
     HIP_TRY(hipGetLastError());
   }
   if (e0) {
@@ -636,7 +636,7 @@ int32_t qpc_finalize_devices(qpc_controller *c, int32_t n_devices, const int32_t
   }
   if (!jit_off) {
     std::string log;
-    const int jrc = qpc_jit_compile(D, prop0.gcnArchName, c->warm_start != 0, code, log);
+    const int jrc = qpc_jit_compile(D, c->prog.dims_s, prop0.gcnArchName, c->warm_start != 0, code, log);
     if (jrc != 0) {
       code.clear();
       const char *strict = getenv("QPC_REQUIRE_JIT");

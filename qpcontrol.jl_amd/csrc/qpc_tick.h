@@ -118,6 +118,9 @@ template <class P> QPC_FN void ld6(P sm, int off, int body, double *x) {
 // Strided LDS dot product with the loads issued in explicit batches of 8 operand pairs BEFORE the
 // FMAs: hipcc keeps LDS loads in source order inside this (huge, fully inlined) kernel, so the
 // naive `acc += a[i]*b[i]` loop pays one full LDS latency per term; batched, it pays one per 8.
+#ifndef QPC_LAMBDA_INLINE
+#define QPC_LAMBDA_INLINE
+#endif
 #ifndef QPC_UNROLL_FULL
 #define QPC_UNROLL_FULL
 #endif
@@ -1292,12 +1295,208 @@ struct TickMeta {
 #define MT_CMASK(mt) ((unsigned)(mt)[3] >> 8) /* contacts 0..23 attached to body `lane` */
 #define MT_ANC(mt, s) ((int)(((unsigned)(mt)[6 + ((s) >> 2)] >> (8 * ((s) & 3))) & 255u) - 1)
 
+// ------------------------------------------------------------------------------------------
+// Null-space presolve (QpcDims::presolve, layout checked by qpc_compile.cpp): hard 6-row task blocks e whose rows read
+//   A_e x_e + B_e x_b = b_e        (x_e: six free columns that only this block claims, x_b: the free columns that stay)
+// determine x_e = P_e - Q_e x_b, [P_e | Q_e] = A_e^-1 [b_e | B_e].  Substituted into the rows that stay (M^ = M_b - M_e Q, d^ = d -
+// M_e P) and into the objective 1/2 |x|^2 + g~'x of the scaled unknowns (H' = I + sum Q'Q, h = g~_b - sum Q'(P + g~_e)), and with
+// y = C'x_b, H' = C C', the solver sees a problem of the SAME form (unit Hessian, linear term C^-1 h, rows M^ C^-T) in nf_s columns and
+// m_s rows: DS.  Returns false -- and leaves everything as assembled -- when an elimination is ill conditioned (a leg near a
+// singularity): that QP is solved in the full dimensions.
+//   A_e^-1 by Householder QR in REGISTERS: block e lives in DPP row e (lanes 16 e ..), lane 16 e + c holds column c of
+//   [A_e | b_e | B_e]; a reflection needs column k's lower part in every lane of the row (row_share broadcasts, no LDS, no pivoting),
+//   the back-substitution the columns of R the same way.
+template <class P> QPC_FN bool qpc_presolve(const QpcDims &D, const QpcDims &DS, P sm) {
+  QPC_LANE_SCOPE
+  const int n_e = D.presolve, nf_s = D.pre_nf, m_s = D.pre_m, nr = 6 * n_e, c0 = D.pre_c0, b0 = D.pre_b0;
+  const int PZ = D.lds[L_PZ];
+  QPC_LANE_ARRAY(qc_, 6); // this lane's column; after the back-substitution: the solution for this right-hand side
+  QPC_LANE_ARRAY(qv_, 6); // what the row shares
+  QPC_PHASE(lane) {
+    double *col = QPC_LA(qc_, lane);
+    const int e = lane >> 4, cc = lane & 15;
+    QPC_UNROLL_FULL
+    for (int i = 0; i < 6; i++) {
+      double v = 0.0;
+      if (e < n_e && cc < 7 + nf_s) {
+        const int r = 6 * e + i;
+        v = cc == 6 ? (double)sm[D.lds[L_D] + r] : (double)sm[D.lds[L_M] + r * D.nfs + (cc < 6 ? c0 + 6 * e + cc : b0 + cc - 7)];
+      }
+      col[i] = v;
+    }
+  } QPC_END_PHASE_SOFT
+  QPC_UNROLL_JIT
+  for (int k = 0; k < 5; k++) { // H_k = I - v v' / (alpha (alpha - x_k)), v = x - alpha e_k, alpha = -sign(x_k) |x|
+    QPC_ROW_SHARE(lane, QPC_LA(qv_, lane), 6 - k, QPC_LA(qc_, lane) + k, k)
+    QPC_PHASE(lane) {
+      double *col = QPC_LA(qc_, lane);
+      const double *x = QPC_LA(qv_, lane);
+      double nn = 0.0;
+      QPC_UNROLL_FULL
+      for (int i = 0; i < 6 - k; i++) nn += x[i] * x[i];
+      const double nrm = nn > 0.0 ? nn * QPC_RSQRT(nn) : 0.0;
+      const double alpha = x[0] > 0.0 ? -nrm : nrm;
+      const double den = alpha * (alpha - x[0]);       // = v'v / 2 > 0 unless the column is zero
+      const double tinv = den > 0.0 ? QPC_RCP(den) : 0.0;
+      double w = (x[0] - alpha) * col[k];
+      QPC_UNROLL_FULL
+      for (int i = 1; i < 6 - k; i++) w += x[i] * col[k + i];
+      w *= tinv;
+      // (the reflected column itself comes out as alpha e_k up to rounding: w = 1 for it; what is left below its diagonal,
+      // ~1e-16 of the entries, is never read again -- the back-substitution only uses the upper triangle)
+      col[k] -= w * (x[0] - alpha);
+      QPC_UNROLL_FULL
+      for (int i = 1; i < 6 - k; i++) col[k + i] -= w * x[i];
+    } QPC_END_PHASE_SOFT
+  }
+  unsigned long long bbad = 0ull;
+  QPC_LANE_ARRAY(qd_, 2); // smallest / largest |R_jj| of my block
+  QPC_UNROLL_JIT
+  for (int j = 5; j >= 0; j--) { // R z = Q'rhs: z_j = y_j / R_jj, y_i -= R_ij z_j (column j of R from lane j of the row)
+    QPC_ROW_SHARE(lane, QPC_LA(qv_, lane), j + 1, QPC_LA(qc_, lane), j)
+    QPC_PHASE(lane) {
+      double *col = QPC_LA(qc_, lane), *dd = QPC_LA(qd_, lane);
+      const double *rj = QPC_LA(qv_, lane);
+      if (j == 5) { dd[0] = 1e300; dd[1] = 0.0; }
+      const double a = QPC_FABS(rj[j]);
+      dd[0] = a < dd[0] ? a : dd[0];
+      dd[1] = a > dd[1] ? a : dd[1];
+      { // (only the right-hand-side lanes' results are used)
+        const double z = a > 0.0 ? col[j] * QPC_RCP(rj[j]) : 0.0;
+        col[j] = z;
+        QPC_UNROLL_FULL
+        for (int i = 0; i < j; i++) col[i] -= rj[i] * z;
+      }
+      if (j == 0) {
+        const int e = lane >> 4, cc = (lane & 15) - 6;
+        const bool mine = e < n_e && cc >= 0 && cc <= nf_s;
+        QPC_BALLOT_PUT(0, bbad, mine && !(dd[0] > 1e-4 * dd[1])); // (measured: the torques lose ~1e-14 / ratio^2; 1e-4 keeps them at 1e-11)
+        if (mine) { // columns of Z': P, then the columns of Q, then P + g~ of the eliminated unknowns
+          for (int i = 0; i < 6; i++) sm[PZ + cc * nr + 6 * e + i] = col[i];
+          if (cc == 0)
+            for (int i = 0; i < 6; i++) {
+              const int f = c0 + 6 * e + i;
+              sm[PZ + (nf_s + 1) * nr + 6 * e + i] = col[i] + sm[D.lds[L_SQH] + f] * sm[D.lds[L_GV] + f];
+            }
+        }
+      }
+    } QPC_END_PHASE_SOFT
+  }
+  QPC_PHASE_SYNC
+  QPC_BALLOT_GET(0, bbad);
+  if (bbad) return false;
+  QPC_PHASE(lane) { // M^, d^, H', h: one dot product of two nr-vectors per lane
+    const int nh = nf_s * (nf_s + 1) / 2, n1 = m_s * nf_s, n2 = n1 + m_s, n3 = n2 + nh, n_red = n3 + nf_s;
+    if (lane < n_red) {
+      int left, right, out;
+      double base, sgn = -1.0;
+      if (lane < n2) { // a row that stays: its part in the eliminated columns against a column of Q (M^) or P (d^)
+        const int rr = lane < n1 ? lane / nf_s : lane - n1, b = lane < n1 ? lane % nf_s : -1;
+        left = D.lds[L_M] + (nr + rr) * D.nfs + c0;
+        right = PZ + (1 + b) * nr;
+        base = b >= 0 ? (double)sm[D.lds[L_M] + (nr + rr) * D.nfs + b0 + b] : (double)sm[D.lds[L_D] + nr + rr];
+        out = b >= 0 ? D.lds[L_PA] + rr * nf_s + b : DS.lds[L_D] + rr;
+      } else if (lane < n3) { // H'[a][b] = delta + <Q_a, Q_b>, packed lower
+        int a = 0, b = lane - n2;
+        while (b > a) { a++; b -= a; }
+        left = PZ + (1 + a) * nr; right = PZ + (1 + b) * nr;
+        base = a == b ? 1.0 : 0.0; sgn = 1.0;
+        out = D.lds[L_PH] + lane - n2;
+      } else { // h_b = g~_b - <Q_b, P + g~_e>
+        const int b = lane - n3;
+        left = PZ + (1 + b) * nr; right = PZ + (nf_s + 1) * nr;
+        base = sm[D.lds[L_SQH] + b0 + b] * sm[D.lds[L_GV] + b0 + b];
+        out = D.lds[L_PH] + nh + b;
+      }
+      sm[out] = base + sgn * dotp(sm + left, 1, sm + right, 1, nr);
+    }
+  } QPC_END_PHASE
+  QPC_PHASE(lane) { // H' = C C' (every lane, in registers), C^-1; rows M^ C^-T, linear term C^-1 h
+    double c[10], ci[10], dinv[4]; // packed lower triangles (nf_s <= 4), 1 / C_aa
+    const int PH = D.lds[L_PH], nh = nf_s * (nf_s + 1) / 2;
+    QPC_UNROLL_FULL
+    for (int a = 0; a < 4; a++) {
+      QPC_UNROLL_FULL
+      for (int b = 0; b <= a; b++) {
+        if (a < nf_s) {
+          double acc = sm[PH + a * (a + 1) / 2 + b];
+          QPC_UNROLL_FULL
+          for (int j = 0; j < b; j++) acc -= c[a * (a + 1) / 2 + j] * c[b * (b + 1) / 2 + j];
+          if (a == b) { dinv[a] = QPC_RSQRT(acc); c[a * (a + 1) / 2 + b] = acc * dinv[a]; } // H' >= I: no pivot can vanish
+          else c[a * (a + 1) / 2 + b] = acc * dinv[b];
+        }
+      }
+    }
+    QPC_UNROLL_FULL
+    for (int a = 0; a < 4; a++) {
+      QPC_UNROLL_FULL
+      for (int b = 0; b <= a; b++) { // row a of C^-1 by forward substitution on column b of the identity
+        if (a < nf_s) {
+          double acc = a == b ? 1.0 : 0.0;
+          QPC_UNROLL_FULL
+          for (int j = b; j < a; j++) acc -= c[a * (a + 1) / 2 + j] * ci[j * (j + 1) / 2 + b];
+          ci[a * (a + 1) / 2 + b] = acc * dinv[a];
+        }
+      }
+    }
+    const int MH = D.lds[L_PA];
+    // lane (rr, cc) of M^ C^-T and lane cc of C^-1 h are the same sum over j <= cc of (row of M^ | h) against row cc of C^-1
+    if (lane < m_s * nf_s + nf_s) {
+      const bool isg = lane >= m_s * nf_s;
+      const int rr = isg ? 0 : lane / nf_s, cc = isg ? lane - m_s * nf_s : lane % nf_s;
+      const int src = isg ? PH + nh : MH + rr * nf_s;
+      double acc = 0.0;
+      QPC_UNROLL_FULL
+      for (int j = 0; j < 4; j++) {
+        double cij = 0.0; // C^-1[cc][j] picked with selects (cc is a lane value)
+        QPC_UNROLL_FULL
+        for (int a = 0; a < 4; a++)
+          if (a < nf_s && j <= a) cij = a == cc ? ci[a * (a + 1) / 2 + j] : cij;
+        if (j < nf_s) {
+          acc += (j <= cc ? (double)sm[src + j] : 0.0) * cij;
+          if (isg) sm[D.lds[L_PC] + cc * nf_s + j] = j <= cc ? cij : 0.0;
+        }
+      }
+      if (isg) { sm[DS.lds[L_GV] + cc] = acc; sm[DS.lds[L_HV] + cc] = 1.0; sm[DS.lds[L_SQH] + cc] = 1.0; }
+      else sm[DS.lds[L_M] + rr * DS.nfs + cc] = acc;
+    }
+  } QPC_END_PHASE
+  return true;
+}
+
+// the eliminated and the whitened unknowns back from the solution y of the reduced problem: x_b = C^-T y, x_e = P_e - Q_e x_b
+template <class P> QPC_FN void qpc_postsolve(const QpcDims &D, const QpcDims &DS, P sm) {
+  QPC_LANE_SCOPE
+  const int n_e = D.presolve, nf_s = D.pre_nf, nr = 6 * n_e;
+  QPC_PHASE(lane) {
+    if (lane < nr + nf_s) {
+      double xb[4] = {0.0, 0.0, 0.0, 0.0};
+      QPC_UNROLL_FULL
+      for (int b = 0; b < 4; b++) {
+        double acc = 0.0;
+        QPC_UNROLL_FULL
+        for (int cc = b; cc < 4; cc++)
+          if (cc < nf_s) acc += sm[D.lds[L_PC] + cc * nf_s + b] * sm[DS.lds[L_XV] + cc];
+        xb[b] = acc;
+      }
+      const bool elim = lane < nr;
+      double acc = elim ? (double)sm[D.lds[L_PZ] + lane] : 0.0;
+      QPC_UNROLL_FULL
+      for (int b = 0; b < 4; b++)
+        if (b < nf_s) acc += elim ? -sm[D.lds[L_PZ] + (1 + b) * nr + lane] * xb[b] : (lane - nr == b ? xb[b] : 0.0);
+      sm[D.lds[L_XV] + (elim ? D.pre_c0 + lane : D.pre_b0 + lane - nr)] = acc;
+    }
+  } QPC_END_PHASE
+}
+
 // once per workgroup (before its first QP): hot solver lookups -> the persistent L_HOT region of
 // the LDS slab (never overlaid, so it survives from QP to QP)
-template <class P> QPC_FN void qpc_tick_prologue(const QpcDims &D, const int *IT, P sm) {
+template <class P> QPC_FN void qpc_tick_prologue(const QpcDims &D, const QpcDims &DS, const int *IT, P sm) {
   QPC_LANE_SCOPE
   QPC_PHASE(lane) {
     for (int i = lane; i < D.m + 4 * D.ne; i += 64) sm[D.lds[L_HOT] + i] = (double)IT[D.it[IT_HOT] + i];
+    if (D.presolve)
+      for (int i = lane; i < DS.m + 4 * DS.ne; i += 64) sm[DS.lds[L_HOT] + i] = (double)IT[DS.it[IT_HOT] + i];
   } QPC_END_PHASE
 }
 
@@ -1306,7 +1505,7 @@ template <class P> QPC_FN void qpc_tick_prologue(const QpcDims &D, const int *IT
 // persists between ticks (momentum.jl:58 calls solve! on the same model every tick) -- and hands the final one back.
 // A search that fails from a warm set is repeated once from the cold start, so the answer never depends on the hint.
 template <class P, bool WARM = false>
-QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, const TickIO &io) {
+QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const double *DT, P sm, const TickIO &io) {
   QPC_LANE_SCOPE
   const int nb = D.nb, nq = D.nq, nv = D.nv, nf = D.nf, nc = D.nc, N = D.N, nrho = D.nrho, ne = D.ne;
   const int m = D.m, m1 = D.m1, nw = D.nw, ntask = D.ntask;
@@ -1878,6 +2077,14 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
 
   QPC_PROF_ACC(PS_ASM);
   QPC_STOP(2)
+  int status = QPC_STATUS_OPTIMAL, iters = 0;
+  int refine = 0;
+  // Everything from the Schur complement to the accepted solution is written against the dimensions of ITS argument, so that the
+  // same code solves the problem as assembled (D) or a reduced one (fewer free columns and rows, other leading dimensions)
+  auto solve_part = [&](const QpcDims &D) QPC_LAMBDA_INLINE {
+  const int nf = D.nf, nrho = D.nrho, ne = D.ne, m = D.m, m1 = D.m1, nw = D.nw;
+  const int MISC = D.lds[L_MISC];
+  (void)nf; (void)ne; (void)nw;
   // ======================================================================== Schur complement S = M M' + W^-1 blocks
   // The one GEMM-shaped step of the tick (a12: the J'J small GEMM): lower-triangular 16x16 tiles of
   // S = M M' on the fp64 matrix core (v_mfma_f64_16x16x4_f64), operands straight from the LDS copy of
@@ -2084,8 +2291,6 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
   QPC_STOP(5)
   // ======================================================================== active-set solve (a13)
   Solver<P> S(D, IT, DT, sm, PA, PT);
-  int status = QPC_STATUS_OPTIMAL, iters = 0;
-  int refine = 0;
   bool warm_hint = false; // WARM: the search below starts from a non-trivial working set
   for (int attempt = 0; attempt < (WARM ? 2 : 1); attempt++) {
   if (WARM && attempt == 1) {
@@ -2459,6 +2664,16 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
   }
 
   } // attempt (WARM: warm start, then cold start if that failed)
+  }; // solve_part
+  bool reduced = false; // this QP went through the null-space presolve
+  if (D.presolve && exact_ve && qpc_presolve(D, DS, sm)) {
+    QPC_PROF_ACC(PS_ASM);
+    reduced = true;
+    solve_part(DS);
+    qpc_postsolve(D, DS, sm);
+  } else {
+    solve_part(D);
+  }
   if (WARM && io.wset) { // the working set goes back to the caller (zeros = "start cold" after a failed solve)
     unsigned long long blo = 0ull, bupf = 0ull;
     QPC_PHASE(lane) {
@@ -2568,7 +2783,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const int *IT, const double *DT, P sm, co
     if (lane == 0) {
       const bool good = status == QPC_STATUS_OPTIMAL || status == QPC_STATUS_ALMOST_OPTIMAL;
       io.status[0] = (good && bbad_in != 0ull) ? QPC_STATUS_NUMERICAL_ERROR : ((good && bneg_cap != 0ull) ? QPC_STATUS_INFEASIBLE : status);
-      if (io.iters) io.iters[0] = iters + 1000 * refine;
+      if (io.iters) io.iters[0] = iters + 1000 * refine + (reduced ? 1000000 : 0);
     }
   } QPC_END_PHASE
   QPC_PROF_ACC(PS_RNEA);

@@ -99,6 +99,11 @@ static thread_local double emu_quad[64];
 #define QPC_QUAD_GATHER(lane, OUT4, XEXPR)                                                    \
   QPC_PHASE(lane) { emu_quad[lane] = (XEXPR); } QPC_END_PHASE_SOFT                              \
   QPC_PHASE(lane) { double *o__ = (OUT4); for (int i__ = 0; i__ < 4; i__++) o__[i__] = emu_quad[(lane & ~3) + i__]; } QPC_END_PHASE_SOFT
+// lane-serial model of the DPP row_share broadcasts: publish, then gather from lane K of the row of 16
+static thread_local double emu_row[64][8];
+#define QPC_ROW_SHARE(lane, OUT, N, X, K)                                                                              \
+  QPC_PHASE(lane) { const double *x__ = (X); for (int i__ = 0; i__ < (N); i__++) emu_row[lane][i__] = x__[i__]; } QPC_END_PHASE_SOFT \
+  QPC_PHASE(lane) { double *o__ = (OUT); for (int i__ = 0; i__ < (N); i__++) o__[i__] = emu_row[(lane & ~15) + (K)][i__]; } QPC_END_PHASE_SOFT
 // reductions across a phase boundary: lane-serial form through the (emulator-only) scratch that
 // follows the kernel's LDS slab
 #define QPC_RED_MAX_PUT(slot, name, val) sm[D.lds_doubles + 128 * (slot) + lane] = (val)
@@ -148,9 +153,9 @@ static void emu_ticks(qpc_controller *c, const QpcHostJob &job, int64_t lo, int6
     io.cwrench = job.out[QpcHostJob::OUT_CWRENCH] ? job.out[QpcHostJob::OUT_CWRENCH] + b * 6 * D.nc : nullptr;
     io.status = job.status + b; io.iters = job.iters ? job.iters + b : nullptr; io.prof = nullptr;
     io.wset = job.working_set ? (unsigned long long *)job.working_set + 2 * b : nullptr;
-    qpc::qpc_tick_prologue<Lds>(D, c->prog.itab.data(), Lds{0});
-    if (job.working_set) qpc::qpc_tick<Lds, true>(D, c->prog.itab.data(), c->prog.dtab.data(), Lds{0}, io);
-    else qpc::qpc_tick<Lds, false>(D, c->prog.itab.data(), c->prog.dtab.data(), Lds{0}, io);
+    qpc::qpc_tick_prologue<Lds>(D, c->prog.dims_s, c->prog.itab.data(), Lds{0});
+    if (job.working_set) qpc::qpc_tick<Lds, true>(D, c->prog.dims_s, c->prog.itab.data(), c->prog.dtab.data(), Lds{0}, io);
+    else qpc::qpc_tick<Lds, false>(D, c->prog.dims_s, c->prog.itab.data(), c->prog.dtab.data(), Lds{0}, io);
     races += emu.races; uninit += emu.uninit; outside += emu.outside;
     if (first.empty()) first = emu.first;
   }

@@ -1,0 +1,175 @@
+"""Null-space presolve of the hard foot tasks (qpc_compile.cpp QpcDims::presolve, qpc_tick.h qpc_presolve / qpc_postsolve): the six
+joint accelerations of a leg are eliminated through its foot's SpatialAccelerationTask, the solver runs on 3 free columns and 9 rows
+instead of 15 and 21, the eliminated accelerations are restored afterwards.  Same QP, so against the controller built with
+QPC_NO_PRESOLVE=1: equal statuses, tau and vdot to 1e-10 of the torque scale, the same working-set changes; a QP whose leg is
+near a singularity (straight knee) is solved in the full dimensions BY THE SAME KERNEL, bitwise equal to the plain controller; a task
+set the layout rules do not cover is left alone.  iters carries 1 000 000 for a QP that went through the reduced problem."""
+import os
+
+import numpy as np
+import pytest
+
+import emu
+from qpcontrol_jl_amd import binding
+from qpcontrol_jl_amd import models as M
+from qpcontrol_jl_amd import workloads as W
+
+
+def _build(factory, B, config, presolve, fused=False):
+    old = os.environ.pop("QPC_NO_PRESOLVE", None)
+    if not presolve:
+        os.environ["QPC_NO_PRESOLVE"] = "1"
+    try:
+        c, wl = W.atlas_workload(factory, B, config, fused_laws=fused)
+    finally:
+        os.environ.pop("QPC_NO_PRESOLVE", None)
+        if old is not None:
+            os.environ["QPC_NO_PRESOLVE"] = old
+    return c, wl
+
+
+def _tick(c, wl, q=None, v=None):
+    q = wl.q if q is None else q
+    v = wl.v if v is None else v
+    des = W.standing_desired(wl.setup, q, v)
+    return c.control_batch(q, v, des, wl.contact_weight, wl.contact_maxnormalforce)
+
+
+def _compare(a, b):
+    # the same QPs are solved; HOW an infeasible one fails (INFEASIBLE / ITERATION_LIMIT on the cycle guard) may depend on rounding
+    assert np.array_equal(a["status"] == 0, b["status"] == 0), (a["status"][a["status"] != b["status"]], b["status"][a["status"] != b["status"]])
+    assert np.mean(a["status"] != b["status"]) <= 0.01
+    ok = a["status"] == 0
+    assert ok.sum() >= len(ok) // 2
+    scale = np.maximum(1.0, np.abs(b["tau"][ok]).max(axis=1, keepdims=True))
+    assert float(np.abs((a["tau"][ok] - b["tau"][ok]) / scale).max()) <= 1e-10
+    vs = np.maximum(1.0, np.abs(b["vdot"][ok]).max(axis=1, keepdims=True))
+    assert float(np.abs((a["vdot"][ok] - b["vdot"][ok]) / vs).max()) <= 1e-10
+    assert np.mean(a["iters"][ok] % 1000 != b["iters"][ok] % 1000) <= 0.05  # same search (ties by rounding aside)
+
+
+@pytest.mark.parametrize("config", [3, 4, 5])
+def test_presolve_equals_full_problem_emulated(config):
+    emu.build()
+    emu.race_report()
+    cp, wl = _build(emu.factory, 48, config, True)
+    cf, _ = _build(emu.factory, 48, config, False)
+    assert cp.L.qpc_debug_presolve_blocks(cp.h) == 2 and cf.L.qpc_debug_presolve_blocks(cf.h) == 0
+    a, b = _tick(cp, wl), _tick(cf, wl)
+    _compare(a, b)
+    assert np.all(a["iters"] >= 1000000) and np.all(b["iters"] < 1000000)  # every QP went through the reduced problem
+    races, uninit, outside, first = emu.race_report()
+    assert (races, uninit, outside) == (0, 0, 0), first
+
+
+def _leg_det(mech, q, side="l"):
+    """determinant of the 6 x 6 block of the foot Jacobian that belongs to the six joints of a leg (world frame, per state)"""
+    kin = W.batch_kinematics(mech, q, np.zeros((q.shape[0], mech.nv)))
+    cols = []
+    for name in ("hpz", "hpx", "hpy", "kny", "aky", "akx"):
+        j = mech.findjoint(f"{side}_leg_{name}")
+        w = np.einsum("bij,j->bi", kin["R"][j], mech.joint_axis[j])
+        cols.append(np.concatenate([w, np.cross(kin["p"][j], w)], axis=1))
+    return np.linalg.det(np.stack(cols, axis=2))
+
+
+def _straight_knees(wl, which):
+    """states `which` get the knee angle at which their left leg is singular (the three pitch axes in one plane: found by bisection
+    on the determinant of the leg block -- the link offsets put it near, not at, a zero knee angle)"""
+    q = wl.q.copy()
+    m = wl.mech
+    k = m.configuration_range(m.findjoint("l_leg_kny"))[0]
+    lo, hi = np.full(q.shape[0], -0.6), np.full(q.shape[0], 0.6)
+    qa, qb = q.copy(), q.copy()
+    qa[:, k], qb[:, k] = lo, hi
+    dlo, dhi = _leg_det(m, qa), _leg_det(m, qb)
+    assert np.all(dlo[which] * dhi[which] < 0)
+    for _ in range(60):
+        mid = 0.5 * (lo + hi)
+        qa[:, k] = mid
+        dm = _leg_det(m, qa)
+        left = dlo * dm <= 0
+        hi = np.where(left, mid, hi)
+        lo = np.where(left, lo, mid); dlo = np.where(left, dlo, dm)
+    q[which, k] = (0.5 * (lo + hi))[which]
+    return q
+
+
+def test_singular_leg_is_solved_in_full_dimensions_emulated():
+    emu.build()
+    emu.race_report()
+    cp, wl = _build(emu.factory, 32, 3, True)
+    cf, _ = _build(emu.factory, 32, 3, False)
+    which = np.arange(32) % 2 == 0
+    q = _straight_knees(wl, which)
+    a, b = _tick(cp, wl, q=q), _tick(cf, wl, q=q)
+    assert np.all(a["iters"][which] < 1000000) and np.all(a["iters"][~which] >= 1000000)
+    # the same kernel solved them as assembled: bit for bit what the plain controller does
+    assert np.array_equal(a["status"][which], b["status"][which])
+    assert np.array_equal(a["tau"][which], b["tau"][which]) and np.array_equal(a["vdot"][which], b["vdot"][which])
+    _compare({k: x[~which] for k, x in a.items()}, {k: x[~which] for k, x in b.items()})
+    races, uninit, outside, first = emu.race_report()
+    assert (races, uninit, outside) == (0, 0, 0), first
+
+
+@pytest.mark.parametrize("off", [1e-1, 1e-2, 1e-3, 1e-4, 1e-5, 1e-6, 1e-8])
+def test_nearly_singular_legs_emulated(off):
+    """knee angles `off` away from the singular one: whichever way the conditioning test decides, the answer is the one of the
+    full problem (the elimination loses cond(A_e) eps; the test lets a ratio of 1e-4 between the smallest and the largest diagonal entry of R through)"""
+    emu.build()
+    cp, wl = _build(emu.factory, 16, 3, True)
+    cf, _ = _build(emu.factory, 16, 3, False)
+    q = _straight_knees(wl, np.ones(16, dtype=bool))
+    q[:, wl.mech.configuration_range(wl.mech.findjoint("l_leg_kny"))[0]] += off
+    a, b = _tick(cp, wl, q=q), _tick(cf, wl, q=q)
+    assert np.array_equal(a["status"] == 0, b["status"] == 0)
+    ok = a["status"] == 0
+    if ok.any():
+        scale = np.maximum(1.0, np.abs(b["tau"][ok]).max(axis=1, keepdims=True))
+        err = float(np.abs((a["tau"][ok] - b["tau"][ok]) / scale).max())
+        assert err <= 1e-10, (err, np.mean(a["iters"] >= 1000000))
+
+
+def test_other_task_orders_are_left_alone_emulated():
+    """the layout rules (foot tasks first, hard, six private joint columns each) decide at qpc_finalize"""
+    emu.build()
+    mech = M.atlas()
+    q0 = M.atlas_nominal_configuration(mech)
+
+    def blocks(**kw):
+        c = emu.factory(mech, 4, mech.findbody("pelvis"))
+        W.standing_setup(c, mech, q0, **kw)
+        c.finalize()
+        return c.L.qpc_debug_presolve_blocks(c.h)
+    assert blocks() == 2
+    assert blocks(feet=("l_foot",)) == 1      # one foot task: one block (the other leg's joints are pinned by their joint tasks)
+    assert blocks(contacts=False) == 0        # no contacts: no wrench rows to reduce
+    # a fixed-base arm: nothing to eliminate
+    c, _ = W.atlas_workload(emu.factory, 2, 2)
+    assert c.L.qpc_debug_presolve_blocks(c.h) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", [3, 5])
+def test_presolve_equals_full_problem_gpu(config):
+    f = lambda mech, N, fl: binding.Controller(binding.Model(mech), N, fl)  # noqa: E731
+    cp, wl = _build(f, 4096, config, True)
+    cf, _ = _build(f, 4096, config, False)
+    assert cp.L.qpc_debug_presolve_blocks(cp.h) == 2 and cf.L.qpc_debug_presolve_blocks(cf.h) == 0
+    a, b = _tick(cp, wl), _tick(cf, wl)
+    _compare(a, b)
+    assert np.all(a["iters"] >= 1000000)
+
+
+@pytest.mark.gpu
+def test_singular_leg_is_solved_in_full_dimensions_gpu():
+    f = lambda mech, N, fl: binding.Controller(binding.Model(mech), N, fl)  # noqa: E731
+    cp, wl = _build(f, 2048, 3, True)
+    cf, _ = _build(f, 2048, 3, False)
+    which = np.arange(2048) % 4 == 0
+    q = _straight_knees(wl, which)
+    a, b = _tick(cp, wl, q=q), _tick(cf, wl, q=q)
+    assert np.all(a["iters"][which] < 1000000) and np.all(a["iters"][~which] >= 1000000)
+    # (bit for bit in the emulator; two compilations of the full-dimension solver on the device differ in their last bits)
+    _compare({k: x[which] for k, x in a.items()}, {k: x[which] for k, x in b.items()})
+    _compare({k: x[~which] for k, x in a.items()}, {k: x[~which] for k, x in b.items()})
