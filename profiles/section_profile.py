@@ -16,7 +16,8 @@ NAMES = ["kinematics", "assembly", "schur_build", "cholesky", "x_inverse", "refa
          "update", "logic", "final_refine", "rnea", "k_input", "k_joint", "k_world", "k_subspace_inertia", "k_twist",
          "k_bias_crb", "sweep_kr", "sweep_y", "sweep_c22", "sweep_chol", "sweep_back", "sweep_test",
          "l_u0", "l_guard", "l_gi_check", "l_gi_step", "polish_prox", "polish_back", "accept", "rnea_reload",
-         "asm_pre", "asm_items", "asm_rows", "xinv_x", "xinv_mfma", "rnea_sv", "rnea_bw"]
+         "asm_pre", "asm_items", "asm_rows", "xinv_x", "xinv_mfma", "rnea_sv", "rnea_bw", "presolve_qr", "presolve_reduce",
+         "postsolve"]
 
 
 def main():

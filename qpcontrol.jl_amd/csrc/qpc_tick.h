@@ -40,7 +40,7 @@ enum { PS_KIN, PS_ASM, PS_SBUILD, PS_CHOL, PS_XINV, PS_REFAC, PS_RESID, PS_KKT, 
        PS_K_INPUT, PS_K_JOINT, PS_K_WORLD, PS_K_SUBSP, PS_K_TWIST, PS_K_BIAS,
        PS_S_KR, PS_S_Y, PS_S_C22, PS_S_CHOL, PS_S_BACK, PS_S_TEST,
        PS_L_U0, PS_L_GUARD, PS_L_GICHECK, PS_L_GISTEP, PS_P_PROX, PS_P_BACK, PS_F_ACCEPT, PS_R_LOAD,
-       PS_A_PRE, PS_A_ITEMS, PS_A_ROWS, PS_X_X, PS_X_MFMA, PS_R_SV, PS_R_BW, PS_COUNT };
+       PS_A_PRE, PS_A_ITEMS, PS_A_ROWS, PS_X_X, PS_X_MFMA, PS_R_SV, PS_R_BW, PS_P_QR, PS_P_RED, PS_P_POST, PS_COUNT };
 
 namespace qpc {
 
@@ -1306,7 +1306,8 @@ struct TickMeta {
 //   A_e^-1 by Householder QR in REGISTERS: block e lives in DPP row e (lanes 16 e ..), lane 16 e + c holds column c of
 //   [A_e | b_e | B_e]; a reflection needs column k's lower part in every lane of the row (row_share broadcasts, no LDS, no pivoting),
 //   the back-substitution the columns of R the same way.
-template <class P> QPC_FN bool qpc_presolve(const QpcDims &D, const QpcDims &DS, P sm) {
+template <class P> QPC_FN bool qpc_presolve(const QpcDims &D, const QpcDims &DS, P sm, unsigned long long *PA, unsigned long long *PT) {
+  (void)PA; (void)PT;
   QPC_LANE_SCOPE
   const int n_e = D.presolve, nf_s = D.pre_nf, m_s = D.pre_m, nr = 6 * n_e, c0 = D.pre_c0, b0 = D.pre_b0;
   const int PZ = D.lds[L_PZ];
@@ -1384,6 +1385,7 @@ template <class P> QPC_FN bool qpc_presolve(const QpcDims &D, const QpcDims &DS,
   }
   QPC_PHASE_SYNC
   QPC_BALLOT_GET(0, bbad);
+  QPC_PROF_ACC(PS_P_QR);
   if (bbad) return false;
   QPC_PHASE(lane) { // M^, d^, H', h: one dot product of two nr-vectors per lane
     const int nh = nf_s * (nf_s + 1) / 2, n1 = m_s * nf_s, n2 = n1 + m_s, n3 = n2 + nh, n_red = n3 + nf_s;
@@ -1411,6 +1413,7 @@ template <class P> QPC_FN bool qpc_presolve(const QpcDims &D, const QpcDims &DS,
       sm[out] = base + sgn * dotp(sm + left, 1, sm + right, 1, nr);
     }
   } QPC_END_PHASE
+  QPC_PROF_ACC(PS_P_RED);
   QPC_PHASE(lane) { // H' = C C' (every lane, in registers), C^-1; rows M^ C^-T, linear term C^-1 h
     double c[10], ci[10], dinv[4]; // packed lower triangles (nf_s <= 4), 1 / C_aa
     const int PH = D.lds[L_PH], nh = nf_s * (nf_s + 1) / 2;
@@ -2666,11 +2669,13 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
   } // attempt (WARM: warm start, then cold start if that failed)
   }; // solve_part
   bool reduced = false; // this QP went through the null-space presolve
-  if (D.presolve && exact_ve && qpc_presolve(D, DS, sm)) {
+  if (D.presolve && exact_ve && qpc_presolve(D, DS, sm, PA, PT)) {
     QPC_PROF_ACC(PS_ASM);
     reduced = true;
     solve_part(DS);
+    QPC_PROF_ACC(PS_FINAL);
     qpc_postsolve(D, DS, sm);
+    QPC_PROF_ACC(PS_P_POST);
   } else {
     solve_part(D);
   }
