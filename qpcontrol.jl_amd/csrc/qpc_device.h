@@ -181,6 +181,11 @@ struct F32Ptr {
 #define QPC_RED_ARGMIN_PUT(slot, name, iname, val, idx) \
   do { double v__ = (val); name = qpc::wave_min(v__); iname = qpc::wave_min_int(v__ == name ? (int)(idx) : 0x3fffffff); } while (0)
 #define QPC_RED_ARGMIN_GET(slot, name, iname) ((void)0)
+// ... when idx is the lane of every real candidate (other lanes pass a value that can only win if nobody has a candidate, in which
+// case the caller discards the index): minimum, then the first lane that holds it -- no second reduction for the index
+#define QPC_RED_ARGMIN_LANE_PUT(slot, name, iname, val, idx) \
+  do { double v__ = (val); name = qpc::wave_min(v__); const unsigned long long b__ = __ballot(v__ == name ? 1 : 0); \
+       iname = b__ ? (int)__builtin_ctzll(b__) : 0x3fffffff; } while (0)
 // 64-bit lane mask of a predicate (one scalar compare); same PUT / GET protocol
 #define QPC_BALLOT_PUT(slot, name, pred) name = __ballot((pred) ? 1 : 0)
 #define QPC_BALLOT_GET(slot, name) ((void)0)

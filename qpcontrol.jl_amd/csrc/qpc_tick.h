@@ -2438,8 +2438,9 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
           if (w != 0.0) { double u = sm[D.lds[L_U] + j]; if (u < bu) { bu = u; ju = j; } }
           else { double vl = -x > x - hi ? -x : x - hi; if (-vl < bv) { bv = -vl; jv = j; } }
         }
-        QPC_RED_ARGMIN_PUT(0, ubad, jbad, bu, ju);
-        QPC_RED_ARGMIN_PUT(1, vneg, pviol, bv, jv);
+        // (at most one rho per lane: the index of a candidate IS its lane, so the argmin is a minimum and a ballot)
+        if (nrho <= 64) { QPC_RED_ARGMIN_LANE_PUT(0, ubad, jbad, bu, ju); QPC_RED_ARGMIN_LANE_PUT(1, vneg, pviol, bv, jv); }
+        else { QPC_RED_ARGMIN_PUT(0, ubad, jbad, bu, ju); QPC_RED_ARGMIN_PUT(1, vneg, pviol, bv, jv); }
         QPC_BALLOT_PUT(2, bnan, bad != 0.0);
         const double wl_ = lane < nrho ? (double)sm[D.lds[L_WS] + (lane < nrho ? lane : 0)] : 0.0;
         QPC_BALLOT_PUT(3, lo_now, wl_ == -1.0);
@@ -2548,7 +2549,8 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
             }
             sm[D.lds[L_TR2] + j] = rj;
           }
-          QPC_RED_ARGMIN_PUT(0, t1, jdrop, best, bestj < 0.0 ? 0x3fffffff : (int)bestj);
+          if (nrho <= 64) { QPC_RED_ARGMIN_LANE_PUT(0, t1, jdrop, best, bestj < 0.0 ? 0x3fffffff : (int)bestj); }
+          else { QPC_RED_ARGMIN_PUT(0, t1, jdrop, best, bestj < 0.0 ? 0x3fffffff : (int)bestj); }
         } QPC_END_PHASE
         QPC_RED_ARGMIN_GET(0, t1, jdrop);
         if (!(t1 < 1e299)) jdrop = -1;

@@ -121,6 +121,7 @@ static inline double emu_scale_trunc(double x) {
   do { name = 0ull; for (int l__ = 0; l__ < 64; l__++) if ((double)sm[D.lds_doubles + 128 * (slot) + l__] != 0.0) name |= 1ull << l__; } while (0)
 #define QPC_RED_ARGMIN_PUT(slot, name, iname, val, idx) \
   do { sm[D.lds_doubles + 128 * (slot) + lane] = (val); sm[D.lds_doubles + 128 * (slot) + 64 + lane] = (double)(idx); } while (0)
+#define QPC_RED_ARGMIN_LANE_PUT(slot, name, iname, val, idx) QPC_RED_ARGMIN_PUT(slot, name, iname, val, idx)
 #define QPC_RED_ARGMIN_GET(slot, name, iname) \
   do { name = 1e308; iname = 0x3fffffff; \
        for (int l__ = 0; l__ < 64; l__++) { double v__ = sm[D.lds_doubles + 128 * (slot) + l__]; \
