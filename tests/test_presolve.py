@@ -130,6 +130,82 @@ def test_nearly_singular_legs_emulated(off):
         assert err <= 1e-10, (err, np.mean(a["iters"] >= 1000000))
 
 
+def _random_biped(seed):
+    """floating pelvis + two chains of six revolute joints with random axes, offsets and inertias, four contact points per foot"""
+    rng = np.random.default_rng(seed)
+    m = M.Mechanism()
+
+    def inertia(mass):
+        a = rng.normal(size=(3, 3))
+        i = (a @ a.T * 0.02 + np.eye(3) * 0.01) * mass
+        return (i[0, 0], i[1, 1], i[2, 2], i[0, 1], i[0, 2], i[1, 2])
+    m.add_body("pelvis", M.WORLD, "pelvis_to_world", M.QUAT_FLOATING, mass=40.0, com=rng.normal(size=3) * 0.03, inertia=inertia(40.0))
+    for s, sg in (("l", 1.0), ("r", -1.0)):
+        parent = "pelvis"
+        for k in range(6):
+            mass = float(rng.uniform(0.5, 6.0))
+            m.add_body(f"{s}{k}", parent, f"{s}_j{k}", M.REVOLUTE, axis=rng.normal(size=3),
+                       p=np.array([0.05 * rng.normal(), sg * 0.1 * (k == 0) + 0.03 * rng.normal(), -0.15 * rng.uniform(0.3, 1.5)]),
+                       mass=mass, com=rng.normal(size=3) * 0.05, inertia=inertia(mass))
+            parent = f"{s}{k}"
+        foot = m.findbody(f"{s}5")
+        for x, y in ((-0.08, 0.05), (-0.08, -0.05), (0.15, 0.05), (0.15, -0.05)):
+            m.contact_points.append(M.ContactSpec(foot, np.array([x, y, -0.05]), np.array([0.0, 0.0, 1.0]), 0.7))
+    return m
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_bipeds_against_the_oracle_emulated(seed):
+    """not only Atlas: random leg geometries, the reduced problem against the full one AND against the oracle"""
+    from oracle import oracle as O
+    emu.build()
+    emu.race_report()
+    mech = _random_biped(seed)
+    rng = np.random.default_rng(100 + seed)
+    B = 12
+    q = np.zeros((B, mech.nq)); q[:, 0] = 1.0
+    rv = rng.uniform(-0.1, 0.1, size=(B, 3))
+    th = np.linalg.norm(rv, axis=1)
+    q[:, 0] = np.cos(th / 2); q[:, 1:4] = rv / th[:, None] * np.sin(th / 2)[:, None]
+    q[:, 4:7] = rng.normal(size=(B, 3)) * 0.1 + np.array([0.0, 0.0, 0.9])
+    q[:, 7:] = rng.uniform(-0.4, 0.4, size=(B, mech.nq - 7))
+    v = rng.normal(size=(B, mech.nv)) * 0.2
+
+    def run(factory, presolve):
+        old = os.environ.pop("QPC_NO_PRESOLVE", None)
+        if not presolve:
+            os.environ["QPC_NO_PRESOLVE"] = "1"
+        try:
+            c = factory(mech, 4, mech.findbody("pelvis"))
+            st = W.standing_setup(c, mech, q[0], feet=("l5", "r5"))
+            c.finalize()
+        finally:
+            os.environ.pop("QPC_NO_PRESOLVE", None)
+            if old is not None:
+                os.environ["QPC_NO_PRESOLVE"] = old
+        des = W.standing_desired(st, q, v)
+        nc = len(st.contact_ids)
+        return c, des, np.full((B, nc), 1e-3), np.full((B, nc), 1e6)
+    cp, des, cw, cm = run(emu.factory, True)
+    cf, _, _, _ = run(emu.factory, False)
+    assert cp.L.qpc_debug_presolve_blocks(cp.h) == 2
+    a, b = cp.control_batch(q, v, des, cw, cm), cf.control_batch(q, v, des, cw, cm)
+    assert np.array_equal(a["status"] == 0, b["status"] == 0)
+    ok = a["status"] == 0
+    assert ok.sum() >= B // 2, a["status"]
+    scale = np.maximum(1.0, np.abs(b["tau"][ok]).max(axis=1, keepdims=True))
+    assert float(np.abs((a["tau"][ok] - b["tau"][ok]) / scale).max()) <= 1e-9
+    oc = O.OracleController(O.OracleModel(mech), 4, mech.findbody("pelvis"))
+    W.standing_setup(oc, mech, q[0], feet=("l5", "r5"))
+    oc.finalize()
+    ro = oc.tick_batch(q, v, des, cw, cm)
+    both = ok & (ro["status"] == 0)
+    assert both.sum() >= 1
+    assert float(np.abs(a["tau"][both] - ro["tau"][both]).max()) <= 1e-8 * float(scale.max())
+    races, uninit, outside, first = emu.race_report()
+    assert (races, uninit, outside) == (0, 0, 0), first
+
+
 def test_other_task_orders_are_left_alone_emulated():
     """the layout rules (foot tasks first, hard, six private joint columns each) decide at qpc_finalize"""
     emu.build()
