@@ -646,7 +646,7 @@ int qpc_compile_program(qpc_controller *c) {
   // The device code indexes by arithmetic, not by tables, so the layout has to be the regular one: the eliminated blocks are the first
   // row blocks, their columns follow each other in block order, the columns that stay are consecutive (a standing controller's two foot
   // tasks registered first, as StandingController does, on a model whose legs are listed one after the other).
-  D.presolve = 0; D.pre_nf = D.nf; D.pre_m = D.m; D.pre_c0 = D.pre_b0 = 0;
+  D.presolve = 0; D.pre_nf = D.nf; D.pre_m = D.m; D.pre_c0 = D.pre_b0 = 0; D.pre_fold = 0;
   D.it[IT_HOT_S] = 0;
   D.lds[L_PA] = D.lds[L_PZ] = D.lds[L_PH] = D.lds[L_PC] = 0;
   QpcDims DS; // finished below (a copy of D with the solver's dimensions and array places)
@@ -686,10 +686,18 @@ int qpc_compile_program(qpc_controller *c) {
     const int n_e = (int)el.size(), nf_s = D.nf - 6 * n_e, m1_s = m1 - 6 * n_e, m_s = m1_s + D.nw;
     std::vector<int> bcols;
     for (int f = 0; f < D.nf; f++) if (!col_taken[f]) bcols.push_back(f);
-    bool regular = n_e > 0 && nf_s >= 1 && nf_s <= 4 && n_e <= 4 && m_s * nf_s + m_s + nf_s * (nf_s + 1) / 2 + nf_s <= 64;
+    bool regular = n_e > 0 && nf_s >= 1 && nf_s <= 4 && n_e <= 4 && m_s * nf_s + m_s + nf_s * (nf_s + 1) / 2 + nf_s <= 64 &&
+                   m_s * nf_s + nf_s <= 48 && m_s <= 16; // (lanes of the reduction phase; lanes of the whitening phase: M rows below 48, d from 48 on)
     for (int b = 1; b < (int)bcols.size(); b++) regular = regular && bcols[b] == bcols[0] + b;
     if (regular) {
+      // the task rows that stay are all soft, their slack blocks are the first ones (slack s = row - 6 n_e), and no weight is a
+      // per-QP matrix: fold them into the objective of the (few) unknowns that are left
+      bool fold = m1_s > 0 && m1_s <= 6 && ne == m1_s && !getenv("QPC_NO_PRESOLVE_FOLD");
+      for (size_t g = 0; g < generic.size(); g++)
+        if (row0[g] >= 6 * n_e) fold = fold && slack0[g] == row0[g] - 6 * n_e;
       std::vector<int> hot_s;
+      if (fold) hot_s.assign(D.nw, -1); // wrench rows only: no slacks
+      else
       { // hot lookups of the reduced problem: the slack tables with the rows renumbered (row r -> r - 6 n_e)
         std::vector<int> row_slack(m_s, -1), srow, swoff, sdim, ss0;
         for (size_t g = 0; g < generic.size(); g++) {
@@ -711,8 +719,9 @@ int qpc_compile_program(qpc_controller *c) {
       const int need = even(nr * (nf_s + 2)) + even(nf_s * (nf_s + 1) / 2 + nf_s) + even(nf_s * nf_s) + even(m_s * nfs_s) + even(m_s) +
                        4 * even(nf_s) + even(m_s + 4 * ne);
       auto per_cu = [](int doubles) { const int n = doubles > 0 ? (160 * 1024) / (doubles * 8) : 8; return n > 8 ? 8 : n; };
-      if (per_cu(off + need) >= 1 && per_cu(off + need) >= per_cu(off) && b_base + even(m_s * nf_s) <= off) {
+      if (per_cu(off + need) >= 1 && per_cu(off + need) >= per_cu(off) && b_base + even(m_s * nf_s) + even(m_s) <= off) {
         D.presolve = n_e; D.pre_nf = nf_s; D.pre_m = m_s; D.pre_c0 = el[0].cols[0]; D.pre_b0 = bcols[0];
+        D.pre_fold = fold ? m1_s : 0;
         D.lds[L_PA] = b_base; // region B is idle between the assembly and the solve
         L(L_PZ, nr * (nf_s + 2)); L(L_PH, nf_s * (nf_s + 1) / 2 + nf_s); L(L_PC, nf_s * nf_s);
         s_lds[0] = off; off = even(off + m_s * nfs_s);
@@ -746,7 +755,8 @@ int qpc_compile_program(qpc_controller *c) {
   DS = D;
   if (D.presolve) {
     auto lead2 = [](int n) { int s_ = (n > 0 ? n : 1); s_ += s_ & 1; if (s_ % 8 == 0) s_ += 2; return s_; };
-    DS.nf = D.pre_nf; DS.m = D.pre_m; DS.m1 = D.pre_m - D.nw;
+    DS.nf = D.pre_nf; DS.m = D.pre_m - D.pre_fold; DS.m1 = DS.m - D.nw;
+    if (D.pre_fold) { DS.ne = 0; DS.wsize = 0; }
     DS.nfs = lead2(DS.nf); DS.ms = lead2(DS.m); DS.m1s = odd(DS.m1 > 0 ? DS.m1 : 1);
     DS.lds[L_M] = s_lds[0]; DS.lds[L_D] = s_lds[1]; DS.lds[L_HV] = s_lds[2]; DS.lds[L_SQH] = s_lds[3]; DS.lds[L_GV] = s_lds[4];
     DS.lds[L_XV] = s_lds[5]; DS.lds[L_HOT] = s_lds[6];

@@ -166,6 +166,9 @@ struct QpcDims {
   int presolve;      // number of eliminated blocks n_e (0: none).  Block e is rows 6 e .. 6 e + 5 and free columns pre_c0 + 6 e .. + 5
   int pre_nf, pre_m; // nf_s, m_s: the free columns pre_b0 .. pre_b0 + nf_s - 1 and the rows 6 n_e .. m - 1 stay
   int pre_c0, pre_b0;
+  int pre_fold;      // rows 6 n_e .. 6 n_e + pre_fold - 1 that stay are all SOFT task rows (slack s = row - 6 n_e): with so few unknowns left
+                     // their terms 1/2 (M^ x_b - d^)' W2 (M^ x_b - d^) go into H' and h before the whitening, and the solver sees
+                     // neither these rows nor their slacks -- only the wrench rows (0: rows and slacks are kept)
   // solver settings (qpc_settings)
   int max_as_iters, max_refine, max_pdas;
   double eps_primal, tau_pivot, tol_bound, tol_accept;

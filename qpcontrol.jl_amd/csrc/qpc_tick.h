@@ -1397,7 +1397,7 @@ template <class P> QPC_FN bool qpc_presolve(const QpcDims &D, const QpcDims &DS,
         left = D.lds[L_M] + (nr + rr) * D.nfs + c0;
         right = PZ + (1 + b) * nr;
         base = b >= 0 ? (double)sm[D.lds[L_M] + (nr + rr) * D.nfs + b0 + b] : (double)sm[D.lds[L_D] + nr + rr];
-        out = b >= 0 ? D.lds[L_PA] + rr * nf_s + b : DS.lds[L_D] + rr;
+        out = D.lds[L_PA] + (b >= 0 ? rr * nf_s + b : m_s * nf_s + rr); // M^ (m_s x nf_s), then d^
       } else if (lane < n3) { // H'[a][b] = delta + <Q_a, Q_b>, packed lower
         int a = 0, b = lane - n2;
         while (b > a) { a++; b -= a; }
@@ -1414,6 +1414,25 @@ template <class P> QPC_FN bool qpc_presolve(const QpcDims &D, const QpcDims &DS,
     }
   } QPC_END_PHASE
   QPC_PROF_ACC(PS_P_RED);
+  const int F = D.pre_fold; // soft task rows that become part of the objective (0: they stay rows with slacks)
+  if (F > 0) { // H' += M^_F' W2 M^_F, h -= M^_F' W2 d^_F  (W2: the slack Hessian blocks, slack s = row s of the rows that stay)
+    QPC_PHASE(lane) {
+      const int nh = nf_s * (nf_s + 1) / 2, MH = D.lds[L_PA], DH = D.lds[L_PA] + m_s * nf_s, HOT = D.lds[L_HOT];
+      if (lane < nh + nf_s) {
+        int a = 0, b = lane;
+        if (lane < nh) { while (b > a) { a++; b -= a; } } else { a = lane - nh; b = -1; }
+        double acc = 0.0;
+        for (int s_ = 0; s_ < F; s_++) {
+          const int wr = (int)(double)sm[HOT + D.m + D.ne + s_], d = (int)(double)sm[HOT + D.m + 2 * D.ne + s_], s0 = (int)(double)sm[HOT + D.m + 3 * D.ne + s_];
+          double wv = 0.0; // (W2 M^[:, b])_s or (W2 d^)_s
+          for (int i = 0; i < d; i++) wv += sm[D.lds[L_W] + wr + i] * (b >= 0 ? (double)sm[MH + (s0 + i) * nf_s + b] : (double)sm[DH + s0 + i]);
+          acc += sm[MH + s_ * nf_s + a] * wv;
+        }
+        const int o = D.lds[L_PH] + lane;
+        sm[o] = sm[o] + (b >= 0 ? acc : -acc);
+      }
+    } QPC_END_PHASE
+  }
   QPC_PHASE(lane) { // H' = C C' (every lane, in registers), C^-1; rows M^ C^-T, linear term C^-1 h
     double c[10], ci[10], dinv[4]; // packed lower triangles (nf_s <= 4), 1 / C_aa
     const int PH = D.lds[L_PH], nh = nf_s * (nf_s + 1) / 2;
@@ -1444,10 +1463,12 @@ template <class P> QPC_FN bool qpc_presolve(const QpcDims &D, const QpcDims &DS,
     }
     const int MH = D.lds[L_PA];
     // lane (rr, cc) of M^ C^-T and lane cc of C^-1 h are the same sum over j <= cc of (row of M^ | h) against row cc of C^-1
-    if (lane < m_s * nf_s + nf_s) {
-      const bool isg = lane >= m_s * nf_s;
-      const int rr = isg ? 0 : lane / nf_s, cc = isg ? lane - m_s * nf_s : lane % nf_s;
-      const int src = isg ? PH + nh : MH + rr * nf_s;
+    const int m_f = m_s - F; // rows of the reduced problem: the rows that stay minus the folded ones
+    if (lane >= 48 && lane < 48 + m_f) sm[DS.lds[L_D] + lane - 48] = sm[MH + m_s * nf_s + F + lane - 48];
+    if (lane < m_f * nf_s + nf_s) {
+      const bool isg = lane >= m_f * nf_s;
+      const int rr = isg ? 0 : lane / nf_s, cc = isg ? lane - m_f * nf_s : lane % nf_s;
+      const int src = isg ? PH + nh : MH + (F + rr) * nf_s;
       double acc = 0.0;
       QPC_UNROLL_FULL
       for (int j = 0; j < 4; j++) {
