@@ -647,6 +647,7 @@ int qpc_compile_program(qpc_controller *c) {
   // row blocks, their columns follow each other in block order, the columns that stay are consecutive (a standing controller's two foot
   // tasks registered first, as StandingController does, on a model whose legs are listed one after the other).
   D.presolve = 0; D.pre_nf = D.nf; D.pre_m = D.m; D.pre_c0 = D.pre_b0 = 0; D.pre_fold = 0;
+  for (int k = 0; k < 6; k++) D.pre_wd[k] = 0;
   D.it[IT_HOT_S] = 0;
   D.lds[L_PA] = D.lds[L_PZ] = D.lds[L_PH] = D.lds[L_PC] = 0;
   QpcDims DS; // finished below (a copy of D with the solver's dimensions and array places)
@@ -722,6 +723,9 @@ int qpc_compile_program(qpc_controller *c) {
       if (per_cu(off + need) >= 1 && per_cu(off + need) >= per_cu(off) && b_base + even(m_s * nf_s) + even(m_s) <= off) {
         D.presolve = n_e; D.pre_nf = nf_s; D.pre_m = m_s; D.pre_c0 = el[0].cols[0]; D.pre_b0 = bcols[0];
         D.pre_fold = fold ? m1_s : 0;
+        for (size_t g = 0; g < generic.size() && fold; g++)
+          if (row0[g] >= 6 * n_e)
+            for (int a = 0; a < c->tasks[generic[g]].dim; a++) D.pre_wd[row0[g] + a - 6 * n_e] = woff[g] + a * c->tasks[generic[g]].dim + a;
         D.lds[L_PA] = b_base; // region B is idle between the assembly and the solve
         L(L_PZ, nr * (nf_s + 2)); L(L_PH, nf_s * (nf_s + 1) / 2 + nf_s); L(L_PC, nf_s * nf_s);
         s_lds[0] = off; off = even(off + m_s * nfs_s);

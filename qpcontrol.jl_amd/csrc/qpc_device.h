@@ -44,6 +44,8 @@ __device__ __forceinline__ int qpc_opaque_lane() {
 #else
 #define QPC_END_PHASE_SOFT QPC_END_PHASE
 #endif
+// end of a block after which nothing is exchanged through LDS until the next hard end (registers and DPP only): never a fence
+#define QPC_END_PHASE_REG }
 // hard boundary without a block (after a group of soft-joined blocks, before code that reads other lanes' LDS words)
 #define QPC_PHASE_SYNC __syncthreads();
 #define QPC_SINCOS(x, s, c) qpc_sincos((double)(x), (s), (c))

@@ -169,6 +169,7 @@ struct QpcDims {
   int pre_fold;      // rows 6 n_e .. 6 n_e + pre_fold - 1 that stay are all SOFT task rows (slack s = row - 6 n_e): with so few unknowns left
                      // their terms 1/2 (M^ x_b - d^)' W2 (M^ x_b - d^) go into H' and h before the whitening, and the solver sees
                      // neither these rows nor their slacks -- only the wrench rows (0: rows and slacks are kept)
+  int pre_wd[6];     // ... where the weight of folded row s sits in L_W (the diagonal entry of its slack block: no matrix weights here)
   // solver settings (qpc_settings)
   int max_as_iters, max_refine, max_pdas;
   double eps_primal, tau_pivot, tol_bound, tol_accept;

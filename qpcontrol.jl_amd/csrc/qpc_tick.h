@@ -1325,7 +1325,7 @@ template <class P> QPC_FN bool qpc_presolve(const QpcDims &D, const QpcDims &DS,
       }
       col[i] = v;
     }
-  } QPC_END_PHASE_SOFT
+  } QPC_END_PHASE_REG
   QPC_UNROLL_JIT
   for (int k = 0; k < 5; k++) { // H_k = I - v v' / (alpha (alpha - x_k)), v = x - alpha e_k, alpha = -sign(x_k) |x|
     QPC_ROW_SHARE(lane, QPC_LA(qv_, lane), 6 - k, QPC_LA(qc_, lane) + k, k)
@@ -1348,7 +1348,7 @@ template <class P> QPC_FN bool qpc_presolve(const QpcDims &D, const QpcDims &DS,
       col[k] -= w * (x[0] - alpha);
       QPC_UNROLL_FULL
       for (int i = 1; i < 6 - k; i++) col[k + i] -= w * x[i];
-    } QPC_END_PHASE_SOFT
+    } QPC_END_PHASE_REG
   }
   unsigned long long bbad = 0ull;
   QPC_LANE_ARRAY(qd_, 2); // smallest / largest |R_jj| of my block
@@ -1381,7 +1381,7 @@ template <class P> QPC_FN bool qpc_presolve(const QpcDims &D, const QpcDims &DS,
             }
         }
       }
-    } QPC_END_PHASE_SOFT
+    } QPC_END_PHASE_REG
   }
   QPC_PHASE_SYNC
   QPC_BALLOT_GET(0, bbad);
@@ -1415,19 +1415,16 @@ template <class P> QPC_FN bool qpc_presolve(const QpcDims &D, const QpcDims &DS,
   } QPC_END_PHASE
   QPC_PROF_ACC(PS_P_RED);
   const int F = D.pre_fold; // soft task rows that become part of the objective (0: they stay rows with slacks)
-  if (F > 0) { // H' += M^_F' W2 M^_F, h -= M^_F' W2 d^_F  (W2: the slack Hessian blocks, slack s = row s of the rows that stay)
+  if (F > 0) { // H' += M^_F' W2 M^_F, h -= M^_F' W2 d^_F  (W2: the slack Hessian blocks -- diagonal: weights are scalars here)
     QPC_PHASE(lane) {
-      const int nh = nf_s * (nf_s + 1) / 2, MH = D.lds[L_PA], DH = D.lds[L_PA] + m_s * nf_s, HOT = D.lds[L_HOT];
+      const int nh = nf_s * (nf_s + 1) / 2, MH = D.lds[L_PA], DH = D.lds[L_PA] + m_s * nf_s;
       if (lane < nh + nf_s) {
         int a = 0, b = lane;
         if (lane < nh) { while (b > a) { a++; b -= a; } } else { a = lane - nh; b = -1; }
         double acc = 0.0;
-        for (int s_ = 0; s_ < F; s_++) {
-          const int wr = (int)(double)sm[HOT + D.m + D.ne + s_], d = (int)(double)sm[HOT + D.m + 2 * D.ne + s_], s0 = (int)(double)sm[HOT + D.m + 3 * D.ne + s_];
-          double wv = 0.0; // (W2 M^[:, b])_s or (W2 d^)_s
-          for (int i = 0; i < d; i++) wv += sm[D.lds[L_W] + wr + i] * (b >= 0 ? (double)sm[MH + (s0 + i) * nf_s + b] : (double)sm[DH + s0 + i]);
-          acc += sm[MH + s_ * nf_s + a] * wv;
-        }
+        QPC_UNROLL_FULL
+        for (int s_ = 0; s_ < 6; s_++)
+          if (s_ < F) acc += sm[MH + s_ * nf_s + a] * sm[D.lds[L_W] + D.pre_wd[s_]] * (b >= 0 ? (double)sm[MH + s_ * nf_s + b] : (double)sm[DH + s_]);
         const int o = D.lds[L_PH] + lane;
         sm[o] = sm[o] + (b >= 0 ? acc : -acc);
       }

@@ -69,6 +69,7 @@ struct Lds {
 // soft end: the lane loop ends (blocks still run one after the other) but the race detector's phase number stays, so a
 // cross-lane RAW / WAR / WAW between soft-joined blocks is reported like one inside a single phase
 #define QPC_END_PHASE_SOFT } g_emu->lane = -1;
+#define QPC_END_PHASE_REG QPC_END_PHASE_SOFT
 #define QPC_PHASE_SYNC g_emu->phase++;
 #define QPC_LANE_SCOPE
 #define QPC_SINCOS(x, s, c) do { double x__ = (x); s = std::sin(x__); c = std::cos(x__); } while (0)
