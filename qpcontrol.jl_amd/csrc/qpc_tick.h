@@ -661,6 +661,12 @@ template <class P> struct Solver {
   //   Z = S11^-1 S12 in L_X2, T22 = (B22 + C22)^-1 in L_S22I) -- no serial chain.
   QPC_FN void solve_S(int out) {
     const int m1 = D.m1, nw = D.nw;
+    if (nw && m1 == 0) { // wrench rows only: lam_w = T22 t, one phase
+      QPC_PHASE(lane) {
+        if (lane < 6) sm[out + lane] = dotp(sm + D.lds[L_S22I] + lane * 6, 1, sm + D.lds[L_T1], 1, 6);
+      } QPC_END_PHASE
+      return;
+    }
     if (nw) {
       QPC_PHASE(lane) { // u = t2 - Z' t1  (temporary in L_C22, free outside refactor_rho)
         if (lane < 6) sm[D.lds[L_C22] + lane] = sm[D.lds[L_T1] + m1 + lane] - dotp(sm + D.lds[L_X2] + lane, 6, sm + D.lds[L_T1], 1, m1);
@@ -1045,6 +1051,7 @@ template <class P> struct Solver {
         if (last_dmax > 0.95 * prev) break; // rounding floor / no progress
         prev = last_dmax;
       }
+      if (m1 > 0) {
       QPC_PHASE(lane) { // lam_1 = S11^-1 c_1 - Z lam_w
         for (int r = lane; r < m1; r += 64) {
           double acc = dotp(sm + D.lds[L_SM] + r * D.ms, 1, sm + D.lds[L_T1], 1, m1);
@@ -1052,6 +1059,7 @@ template <class P> struct Solver {
           sm[D.lds[L_LAM] + r] = acc;
         }
       } QPC_END_PHASE
+      }
     } else {
       solve_S(D.lds[L_LAM]); // lam = S^-1 c (no rho: S22 = B22)
     }
@@ -2240,7 +2248,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
   // copy of X (lower triangular: tile row ti only needs k >= 16 ti), two LDS reads per lane and k-step
   // instead of the ~2 x 13 per entry of the dot-product form.  Z = X' L21' = S11^-1 S12 is one more column of
   // tiles of the same product, X' [X | L21'] (it used to be 6 m1 strided dot products in the write-out phase).
-  {
+  if (m1 > 0) { // (no leading block -- the reduced problem of the presolve with its soft rows folded --: nothing to invert)
     const int nt1 = (m1 + 15) / 16, nk1 = (m1 + 3) / 4, ntri = nt1 * (nt1 + 1) / 2;
     QPC_LANE_ARRAY(xacc_, 4 * QPC_XTILE_MAX);
     QPC_PHASE(lane) {
