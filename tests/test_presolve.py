@@ -206,6 +206,39 @@ def test_random_bipeds_against_the_oracle_emulated(seed):
     assert (races, uninit, outside) == (0, 0, 0), first
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 3])
+def test_random_bipeds_gpu(seed):
+    mech = _random_biped(seed)
+    rng = np.random.default_rng(200 + seed)
+    B = 512
+    q = np.zeros((B, mech.nq))
+    rv = rng.uniform(-0.1, 0.1, size=(B, 3))
+    th = np.linalg.norm(rv, axis=1)
+    q[:, 0] = np.cos(th / 2); q[:, 1:4] = rv / th[:, None] * np.sin(th / 2)[:, None]
+    q[:, 4:7] = rng.normal(size=(B, 3)) * 0.1 + np.array([0.0, 0.0, 0.9])
+    q[:, 7:] = rng.uniform(-0.4, 0.4, size=(B, mech.nq - 7))
+    v = rng.normal(size=(B, mech.nv)) * 0.2
+    res = []
+    for presolve in (True, False):
+        old = os.environ.pop("QPC_NO_PRESOLVE", None)
+        if not presolve:
+            os.environ["QPC_NO_PRESOLVE"] = "1"
+        try:
+            c = binding.Controller(binding.Model(mech), 4, mech.findbody("pelvis"))
+            st = W.standing_setup(c, mech, q[0], feet=("l5", "r5"))
+            c.finalize()
+        finally:
+            os.environ.pop("QPC_NO_PRESOLVE", None)
+            if old is not None:
+                os.environ["QPC_NO_PRESOLVE"] = old
+        assert c.L.qpc_debug_presolve_blocks(c.h) == (2 if presolve else 0)
+        nc = len(st.contact_ids)
+        res.append(c.control_batch(q, v, W.standing_desired(st, q, v), np.full((B, nc), 1e-3), np.full((B, nc), 1e6)))
+    _compare(res[0], res[1])
+    assert np.mean(res[0]["iters"] >= 1000000) > 0.9
+
+
 def test_other_task_orders_are_left_alone_emulated():
     """the layout rules (foot tasks first, hard, six private joint columns each) decide at qpc_finalize"""
     emu.build()
@@ -249,3 +282,53 @@ def test_singular_leg_is_solved_in_full_dimensions_gpu():
     # (bit for bit in the emulator; two compilations of the full-dimension solver on the device differ in their last bits)
     _compare({k: x[which] for k, x in a.items()}, {k: x[which] for k, x in b.items()})
     _compare({k: x[~which] for k, x in a.items()}, {k: x[~which] for k, x in b.items()})
+
+
+def test_per_qp_momentum_weight_emulated():
+    """the folded rows take their weights from the slab (per-QP scalar weight of the momentum task: no static Hessian tables),
+    and a matrix weight keeps the presolve off"""
+    from qpcontrol_jl_amd.workloads import LINEAR_MOMENTUM_RATE, SCALAR, SCALAR_PER_QP
+    emu.build()
+    emu.race_report()
+    mech = M.atlas()
+    q0 = M.atlas_nominal_configuration(mech)
+
+    def build(presolve, wkind, weight):
+        old = os.environ.pop("QPC_NO_PRESOLVE", None)
+        if not presolve:
+            os.environ["QPC_NO_PRESOLVE"] = "1"
+        try:
+            c = emu.factory(mech, 4, mech.findbody("pelvis"))
+            real = c.add_task
+
+            def add_task(kind, *a, **kw):
+                if kind == LINEAR_MOMENTUM_RATE:
+                    kw["wkind"], kw["weight"] = wkind, weight
+                return real(kind, *a, **kw)
+            c.add_task = add_task
+            st = W.standing_setup(c, mech, q0)
+            c.finalize()
+        finally:
+            os.environ.pop("QPC_NO_PRESOLVE", None)
+            if old is not None:
+                os.environ["QPC_NO_PRESOLVE"] = old
+        return c, st
+    B = 16
+    q, v = W.standing_states(mech, B, 77)
+    rng = np.random.default_rng(5)
+    tw = rng.uniform(0.3, 3.0, size=(B, 1))
+    cp, st = build(True, SCALAR_PER_QP, None)
+    cf, _ = build(False, SCALAR_PER_QP, None)
+    assert cp.L.qpc_debug_presolve_blocks(cp.h) == 2 and cp.layout.n_task_weights == 1
+    des = W.standing_desired(st, q, v)
+    cw, cm = np.full((B, 8), 1e-3), np.full((B, 8), 1e6)
+    a = cp.control_batch(q, v, des, cw, cm, task_weights=tw)
+    b = cf.control_batch(q, v, des, cw, cm, task_weights=tw)
+    _compare(a, b)
+    assert np.all(a["iters"] >= 1000000)
+    # the weight matters (otherwise the comparison above proves nothing about where it is read from)
+    c1, _ = build(True, SCALAR, [1.0])
+    r1 = c1.control_batch(q, v, des, cw, cm)
+    assert float(np.abs(r1["tau"] - a["tau"]).max()) > 1e-3
+    races, uninit, outside, first = emu.race_report()
+    assert (races, uninit, outside) == (0, 0, 0), first
