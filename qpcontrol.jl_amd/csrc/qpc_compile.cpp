@@ -643,10 +643,11 @@ int qpc_compile_program(qpc_controller *c) {
   // ---- null-space presolve (QpcDims::presolve): hard 6-row SpatialAccelerationTask blocks whose path holds exactly six free 1-DoF
   // columns outside the floating joint that no other eliminated block claims -- their rows are then [A_e (6 x 6, those columns) | B_e
   // (columns that stay)] and nothing else, and v_e = A_e^-1 (b_e - B_e v_b) for every state in which A_e is well conditioned.
-  // The device code indexes by arithmetic, not by tables, so the layout has to be the regular one: the eliminated blocks are the first
-  // row blocks, their columns follow each other in block order, the columns that stay are consecutive (a standing controller's two foot
-  // tasks registered first, as StandingController does, on a model whose legs are listed one after the other).
-  D.presolve = 0; D.pre_nf = D.nf; D.pre_m = D.m; D.pre_c0 = D.pre_b0 = 0; D.pre_fold = 0;
+  // The device code indexes by arithmetic, not by tables, so the layout has to be a regular one: the eliminated blocks are the first
+  // row blocks, the six columns of a block are consecutive, the columns that stay are consecutive (a standing controller's foot tasks
+  // registered first, as StandingController does, in either order, on a model that lists the joints of a leg one after the other).
+  D.presolve = 0; D.pre_nf = D.nf; D.pre_m = D.m; D.pre_b0 = 0; D.pre_fold = 0;
+  for (int k = 0; k < 4; k++) D.pre_c0[k] = 0;
   for (int k = 0; k < 6; k++) D.pre_wd[k] = 0;
   D.it[IT_HOT_S] = 0;
   D.lds[L_PA] = D.lds[L_PZ] = D.lds[L_PH] = D.lds[L_PC] = 0;
@@ -679,7 +680,7 @@ int qpc_compile_program(qpc_controller *c) {
       for (int b = t.target; b >= 0 && b != lca; b = m->parent[b]) visit(b);
       if (!ok || priv.size() != 6) break;
       std::sort(priv.begin(), priv.end());
-      if (priv[5] != priv[0] + 5 || (!el.empty() && priv[0] != el.back().cols[5] + 1)) break;
+      if (priv[5] != priv[0] + 5) break;
       Elim e; e.g = (int)g; e.row0 = row0[g];
       for (int i = 0; i < 6; i++) { e.cols[i] = priv[i]; col_taken[priv[i]] = 1; }
       el.push_back(e);
@@ -721,7 +722,8 @@ int qpc_compile_program(qpc_controller *c) {
                        4 * even(nf_s) + even(m_s + 4 * ne);
       auto per_cu = [](int doubles) { const int n = doubles > 0 ? (160 * 1024) / (doubles * 8) : 8; return n > 8 ? 8 : n; };
       if (per_cu(off + need) >= 1 && per_cu(off + need) >= per_cu(off) && b_base + even(m_s * nf_s) + even(m_s) <= off) {
-        D.presolve = n_e; D.pre_nf = nf_s; D.pre_m = m_s; D.pre_c0 = el[0].cols[0]; D.pre_b0 = bcols[0];
+        D.presolve = n_e; D.pre_nf = nf_s; D.pre_m = m_s; D.pre_b0 = bcols[0];
+        for (int e = 0; e < n_e; e++) D.pre_c0[e] = el[e].cols[0];
         D.pre_fold = fold ? m1_s : 0;
         for (size_t g = 0; g < generic.size() && fold; g++)
           if (row0[g] >= 6 * n_e)

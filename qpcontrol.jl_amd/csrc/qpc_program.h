@@ -163,9 +163,9 @@ struct QpcDims {
   // accelerations of a leg are determined by the task and the base acceleration): v_L = P - Q v_b is substituted into the remaining rows
   // and the objective, the solver runs on nf_s columns / m_s rows (QpcProgram::dims_s), the postsolve restores the eliminated columns.
   // A QP whose elimination is ill-conditioned (a leg near a singularity) is solved as assembled, by the same kernel.
-  int presolve;      // number of eliminated blocks n_e (0: none).  Block e is rows 6 e .. 6 e + 5 and free columns pre_c0 + 6 e .. + 5
+  int presolve;      // number of eliminated blocks n_e (0: none).  Block e is rows 6 e .. 6 e + 5 and free columns pre_c0[e] .. + 5
   int pre_nf, pre_m; // nf_s, m_s: the free columns pre_b0 .. pre_b0 + nf_s - 1 and the rows 6 n_e .. m - 1 stay
-  int pre_c0, pre_b0;
+  int pre_c0[4], pre_b0;
   int pre_fold;      // rows 6 n_e .. 6 n_e + pre_fold - 1 that stay are all SOFT task rows (slack s = row - 6 n_e): with so few unknowns left
                      // their terms 1/2 (M^ x_b - d^)' W2 (M^ x_b - d^) go into H' and h before the whitening, and the solver sees
                      // neither these rows nor their slacks -- only the wrench rows (0: rows and slacks are kept)

@@ -1317,19 +1317,20 @@ struct TickMeta {
 template <class P> QPC_FN bool qpc_presolve(const QpcDims &D, const QpcDims &DS, P sm, unsigned long long *PA, unsigned long long *PT) {
   (void)PA; (void)PT;
   QPC_LANE_SCOPE
-  const int n_e = D.presolve, nf_s = D.pre_nf, m_s = D.pre_m, nr = 6 * n_e, c0 = D.pre_c0, b0 = D.pre_b0;
+  const int n_e = D.presolve, nf_s = D.pre_nf, m_s = D.pre_m, nr = 6 * n_e, b0 = D.pre_b0;
   const int PZ = D.lds[L_PZ];
   QPC_LANE_ARRAY(qc_, 6); // this lane's column; after the back-substitution: the solution for this right-hand side
   QPC_LANE_ARRAY(qv_, 6); // what the row shares
   QPC_PHASE(lane) {
     double *col = QPC_LA(qc_, lane);
     const int e = lane >> 4, cc = lane & 15;
+    const int c0 = e == 1 ? D.pre_c0[1] : (e == 2 ? D.pre_c0[2] : (e == 3 ? D.pre_c0[3] : D.pre_c0[0])); // first column of my block
     QPC_UNROLL_FULL
     for (int i = 0; i < 6; i++) {
       double v = 0.0;
       if (e < n_e && cc < 7 + nf_s) {
         const int r = 6 * e + i;
-        v = cc == 6 ? (double)sm[D.lds[L_D] + r] : (double)sm[D.lds[L_M] + r * D.nfs + (cc < 6 ? c0 + 6 * e + cc : b0 + cc - 7)];
+        v = cc == 6 ? (double)sm[D.lds[L_D] + r] : (double)sm[D.lds[L_M] + r * D.nfs + (cc < 6 ? c0 + cc : b0 + cc - 7)];
       }
       col[i] = v;
     }
@@ -1384,7 +1385,7 @@ template <class P> QPC_FN bool qpc_presolve(const QpcDims &D, const QpcDims &DS,
           for (int i = 0; i < 6; i++) sm[PZ + cc * nr + 6 * e + i] = col[i];
           if (cc == 0)
             for (int i = 0; i < 6; i++) {
-              const int f = c0 + 6 * e + i;
+              const int f = (e == 1 ? D.pre_c0[1] : (e == 2 ? D.pre_c0[2] : (e == 3 ? D.pre_c0[3] : D.pre_c0[0]))) + i;
               sm[PZ + (nf_s + 1) * nr + 6 * e + i] = col[i] + sm[D.lds[L_SQH] + f] * sm[D.lds[L_GV] + f];
             }
         }
@@ -1400,9 +1401,11 @@ template <class P> QPC_FN bool qpc_presolve(const QpcDims &D, const QpcDims &DS,
     if (lane < n_red) {
       int left, right, out;
       double base, sgn = -1.0;
+      bool isrow = false; // left operand: a row of M, whose eliminated columns sit block by block at pre_c0[e] (not one after the other)
       if (lane < n2) { // a row that stays: its part in the eliminated columns against a column of Q (M^) or P (d^)
         const int rr = lane < n1 ? lane / nf_s : lane - n1, b = lane < n1 ? lane % nf_s : -1;
-        left = D.lds[L_M] + (nr + rr) * D.nfs + c0;
+        left = D.lds[L_M] + (nr + rr) * D.nfs;
+        isrow = true;
         right = PZ + (1 + b) * nr;
         base = b >= 0 ? (double)sm[D.lds[L_M] + (nr + rr) * D.nfs + b0 + b] : (double)sm[D.lds[L_D] + nr + rr];
         out = D.lds[L_PA] + (b >= 0 ? rr * nf_s + b : m_s * nf_s + rr); // M^ (m_s x nf_s), then d^
@@ -1418,7 +1421,11 @@ template <class P> QPC_FN bool qpc_presolve(const QpcDims &D, const QpcDims &DS,
         base = sm[D.lds[L_SQH] + b0 + b] * sm[D.lds[L_GV] + b0 + b];
         out = D.lds[L_PH] + nh + b;
       }
-      sm[out] = base + sgn * dotp(sm + left, 1, sm + right, 1, nr);
+      double dot = 0.0;
+      QPC_UNROLL_FULL
+      for (int e = 0; e < 4; e++)
+        if (e < n_e) dot += dotp(sm + left + (isrow ? D.pre_c0[e] : 6 * e), 1, sm + right + 6 * e, 1, 6);
+      sm[out] = base + sgn * dot;
     }
   } QPC_END_PHASE
   QPC_PROF_ACC(PS_P_RED);
@@ -1513,7 +1520,8 @@ template <class P> QPC_FN void qpc_postsolve(const QpcDims &D, const QpcDims &DS
       QPC_UNROLL_FULL
       for (int b = 0; b < 4; b++)
         if (b < nf_s) acc += elim ? -sm[D.lds[L_PZ] + (1 + b) * nr + lane] * xb[b] : (lane - nr == b ? xb[b] : 0.0);
-      sm[D.lds[L_XV] + (elim ? D.pre_c0 + lane : D.pre_b0 + lane - nr)] = acc;
+      const int e = lane / 6, c0 = e == 1 ? D.pre_c0[1] : (e == 2 ? D.pre_c0[2] : (e == 3 ? D.pre_c0[3] : D.pre_c0[0]));
+      sm[D.lds[L_XV] + (elim ? c0 + lane - 6 * e : D.pre_b0 + lane - nr)] = acc;
     }
   } QPC_END_PHASE
 }

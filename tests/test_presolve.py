@@ -239,6 +239,35 @@ def test_random_bipeds_gpu(seed):
     assert np.mean(res[0]["iters"] >= 1000000) > 0.9
 
 
+def test_feet_in_either_order_emulated():
+    """the right foot's task registered first: its block's columns come AFTER the other block's (per-block first columns)"""
+    emu.build()
+    emu.race_report()
+    mech = M.atlas()
+    q0 = M.atlas_nominal_configuration(mech)
+    B = 24
+    q, v = W.standing_states(mech, B, 31)
+    res = []
+    for presolve in (True, False):
+        old = os.environ.pop("QPC_NO_PRESOLVE", None)
+        if not presolve:
+            os.environ["QPC_NO_PRESOLVE"] = "1"
+        try:
+            c = emu.factory(mech, 4, mech.findbody("pelvis"))
+            st = W.standing_setup(c, mech, q0, feet=("r_foot", "l_foot"))
+            c.finalize()
+        finally:
+            os.environ.pop("QPC_NO_PRESOLVE", None)
+            if old is not None:
+                os.environ["QPC_NO_PRESOLVE"] = old
+        assert c.L.qpc_debug_presolve_blocks(c.h) == (2 if presolve else 0)
+        res.append(c.control_batch(q, v, W.standing_desired(st, q, v), np.full((B, 8), 1e-3), np.full((B, 8), 1e6)))
+    _compare(res[0], res[1])
+    assert np.all(res[0]["iters"] >= 1000000)
+    races, uninit, outside, first = emu.race_report()
+    assert (races, uninit, outside) == (0, 0, 0), first
+
+
 def test_other_task_orders_are_left_alone_emulated():
     """the layout rules (foot tasks first, hard, six private joint columns each) decide at qpc_finalize"""
     emu.build()
