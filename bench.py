@@ -448,7 +448,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st = run.status.cpu().numpy()
-    it = run.iters.cpu().numpy() % 1000
+    it_raw = run.iters.cpu().numpy()
+    it = it_raw % 1000
+    presolved = float((it_raw >= 1000000).mean())  # QPs solved in the reduced dimensions of the null-space presolve
     fp64_measured = ctypes.c_double(0.0)  # vector-fp64 FMA peak measured on this box, outside the timed region
     if rank == 0 and hasattr(L, "qpc_debug_measure_fp64_peak"):
         L.qpc_debug_measure_fp64_peak.argtypes = [ctypes.c_int32, ctypes.POINTER(ctypes.c_double)]
@@ -500,6 +502,7 @@ def main():
                                       else "no contacts (39 vars / 36 eq)"),
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"shard{world} (independent QPs, no collective)",
                        "optimal_fraction": n_opt / B, "mean_active_set_iters": float(it.mean()),
+                       "presolved_fraction": presolved,
                        "lds_bytes_per_qp": int(lay.lds_bytes_per_qp),
                        "desired": "device PD laws (standing.jl:58-89 fused)" if args.fused_laws else "input record",
                        "host_pointer_path_solves_per_s": host_rates.get("pinned") if host_rates else None,
