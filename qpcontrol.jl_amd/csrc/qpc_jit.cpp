@@ -185,7 +185,8 @@ int qpc_jit_compile(const QpcDims &D, const QpcDims &DS, const std::string &arch
   {
     const char *ce = getenv("QPC_JIT_CACHE"), *xe = getenv("QPC_JIT_EXTRA_FLAGS");
     if (!(ce && ce[0] == '0')) {
-      key = arch + "\n" + (xe ? xe : "") + "\n" + src;
+      const char *oe_ = getenv("QPC_JIT_OPT"), *se_ = getenv("QPC_JIT_SCHED");
+      key = arch + "\n" + (xe ? xe : "") + "\n" + (oe_ ? oe_ : "") + "\n" + (se_ ? se_ : "") + "\n" + src;
       std::lock_guard<std::mutex> lk(g_jit_mu);
       auto it = g_jit_cache.find(key);
       if (it != g_jit_cache.end()) { code = it->second; log.clear(); return 0; }
@@ -206,7 +207,12 @@ int qpc_jit_compile(const QpcDims &D, const QpcDims &DS, const std::string &arch
   // iterative-ilp 26.4-26.5 M, with -O2 26.7 M; max-ilp 25.5, iterative-maxocc 25.4, iterative-minreg 23.2, -ffp-contract=on 24.8.
   // The phases are long straight-line blocks of dependent LDS -> FMA chains: a scheduler that looks for ILP inside them
   // pays.  Both kernels of the module pass the whole GPU test-suite with it.  QPC_JIT_EXTRA_FLAGS is appended and wins.
-  std::vector<const char *> opts = {archopt.c_str(), "-O2", "-std=c++17", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"};
+  // (experiments: QPC_JIT_OPT replaces -O2, QPC_JIT_SCHED the scheduler strategy, "default" = none given)
+  const char *oe = getenv("QPC_JIT_OPT"), *se = getenv("QPC_JIT_SCHED");
+  const std::string optlevel = oe && oe[0] ? oe : "-O2";
+  const std::string sched = std::string("-amdgpu-sched-strategy=") + (se && se[0] ? se : "iterative-ilp");
+  std::vector<const char *> opts = {archopt.c_str(), optlevel.c_str(), "-std=c++17"};
+  if (!(se && std::string(se) == "default")) { opts.push_back("-mllvm"); opts.push_back(sched.c_str()); }
   for (auto &x : extra) opts.push_back(x.c_str());
   hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
   size_t ls = 0;
