@@ -226,7 +226,11 @@ int32_t qpc_add_contact(qpc_controller *ctrl, int32_t body, const double positio
 
 /* initialize! (momentum.jl:150-156): freeze the layout, add the wrench-balance rows when a
  * floating joint was given (momentum.jl:162-193), compile the task program and upload it to
- * HIP device `device_id`. */
+ * HIP device `device_id`.  What the compile step decides once (qpc_compile.cpp): hard JointAccelerationTasks
+ * and hard body-frame tasks of the floating body become pinned accelerations; hard 6-row SpatialAccelerationTasks whose path
+ * holds six free one-DoF joints (the foot tasks of a StandingController, registered first) are eliminated per QP by a
+ * null-space presolve, and the soft task rows that remain are folded into the objective -- the same QP, solved in fewer
+ * dimensions (layout.n_free / n_eq_rows report the problem as assembled). */
 int32_t qpc_finalize(qpc_controller *ctrl, int32_t device_id, qpc_layout *out_layout);
 /* Same for SEVERAL devices of this process: the task program is replicated on every
  * device of device_ids[0..n_devices) and the host-pointer entry points (qpc_control_batch,
