@@ -164,6 +164,9 @@ int qpc_compile_program(qpc_controller *c) {
     std::vector<std::vector<int>> desc(nb);
     for (int i = 0; i < nb; i++)
       for (int a = i; a >= 0; a = m->parent[a]) desc[a].push_back(i);
+    D.dfs = (nb <= 32 && !getenv("QPC_NO_DFS_SCAN")) ? 1 : 0; // (desc[a] is ascending: contiguous iff last - first + 1 == size)
+    for (int i = 0; i < nb; i++)
+      if (desc[i].front() != i || desc[i].back() - i + 1 != (int)desc[i].size()) D.dfs = 0;
     std::vector<int> dptr(nb + 1, 0), didx;
     for (int i = 0; i < nb; i++) { didx.insert(didx.end(), desc[i].begin(), desc[i].end()); dptr[i + 1] = (int)didx.size(); }
     B.ibegin(IT_DESC_PTR); B.it.insert(B.it.end(), dptr.begin(), dptr.end());

@@ -89,6 +89,7 @@ __device__ __forceinline__ double qpc_rcp1(double x) {
 #define QPC_LANE_INTS(name, n) int name[n]
 #define QPC_LI(name, lane) name
 #define QPC_CTZ64(x) (__ffsll((unsigned long long)(x)) - 1)
+#define QPC_POPC64(x) __popcll((unsigned long long)(x))
 #ifdef QPC_JIT
 #define QPC_UNROLL_JIT _Pragma("unroll")
 #define QPC_UNROLL _Pragma("unroll")
@@ -234,6 +235,28 @@ __device__ __forceinline__ double qpc_row_share(double x, int k) {
     double *out__ = (OUT);                                                                       \
     const double *x__ = (X);                                                                     \
     for (int i__ = 0; i__ < (N); i__++) out__[i__] = qpc_row_share(x__[i__], (K));               \
+  }
+
+// inclusive prefix sum over the lanes of the wave (lane l: x_0 + ... + x_l): Hillis-Steele inside the DPP rows of 16 (row_shr with
+// zero fill), then the totals of the rows before (row_bcast:15 / :31) -- 6 steps of two moves and an add per double, no LDS
+__device__ __forceinline__ double qpc_wave_prefix_sum(double x) {
+#define QPC_PS_STEP(ctrl, rmask)                                                           \
+  {                                                                                        \
+    const int lo__ = __double2loint(x), hi__ = __double2hiint(x);                          \
+    const int tl__ = __builtin_amdgcn_update_dpp(0, lo__, ctrl, rmask, 0xf, false);        \
+    const int th__ = __builtin_amdgcn_update_dpp(0, hi__, ctrl, rmask, 0xf, false);        \
+    x += __hiloint2double(th__, tl__);                                                     \
+  }
+  QPC_PS_STEP(0x111, 0xf) QPC_PS_STEP(0x112, 0xf) QPC_PS_STEP(0x114, 0xf) QPC_PS_STEP(0x118, 0xf)
+  QPC_PS_STEP(0x142, 0xa) QPC_PS_STEP(0x143, 0xc)
+#undef QPC_PS_STEP
+  return x;
+}
+// phase level (all 64 lanes): ARR[i] of every lane becomes the sum of ARR[i] over the lanes up to and including it
+#define QPC_WAVE_INCL_SCAN(lane, ARR, N)                                                          \
+  {                                                                                              \
+    double *a__ = (ARR);                                                                         \
+    for (int i__ = 0; i__ < (N); i__++) a__[i__] = qpc_wave_prefix_sum(a__[i__]);                \
   }
 
 // fp64 matrix core: acc(16x16 tile, 4 f64 per lane) += A(16x4) * B(4x16) with v_mfma_f64_16x16x4_f64.

@@ -51,7 +51,7 @@ static void put_dims(std::ostringstream &o, const char *name, const QpcDims &D) 
   put_ints(o, D.it, IT_COUNT); o << ",";
   put_ints(o, D.dt, DT_COUNT); o << ",";
   put_ints(o, D.lds, L_COUNT); o << ",";
-  o << D.lds_doubles << "," << D.n_int << "," << D.n_dbl << "," << D.presolve << "," << D.pre_nf << "," << D.pre_m << "," << D.pre_c0[0] << "," << D.pre_c0[1] << "," << D.pre_c0[2] << "," << D.pre_c0[3] << "," << D.pre_b0 << "," << D.pre_fold << ",";
+  o << D.lds_doubles << "," << D.n_int << "," << D.n_dbl << "," << D.dfs << "," << D.presolve << "," << D.pre_nf << "," << D.pre_m << "," << D.pre_c0[0] << "," << D.pre_c0[1] << "," << D.pre_c0[2] << "," << D.pre_c0[3] << "," << D.pre_b0 << "," << D.pre_fold << ",";
   put_ints(o, D.pre_wd, 6); o << ",";
   o  << D.max_as_iters << "," << D.max_refine << ","
     << D.max_pdas << "," << dbl(D.eps_primal) << "," << dbl(D.tau_pivot) << "," << dbl(D.tol_bound) << ","

@@ -159,6 +159,8 @@ struct QpcDims {
   int lds[L_COUNT];
   int lds_doubles;   // per-QP LDS slab size
   int n_int, n_dbl;  // table sizes
+  int dfs;           // the bodies are numbered in depth-first order (every subtree is a contiguous index range, at most 32 bodies):
+                     // sums over a subtree are differences of a wave prefix sum (qpc_tick.h, inverse dynamics)
   // Null-space presolve of hard 6-row task blocks with six private free columns (the foot tasks of a standing controller: the six joint
   // accelerations of a leg are determined by the task and the base acceleration): v_L = P - Q v_b is substituted into the remaining rows
   // and the objective, the solver runs on nf_s columns / m_s rows (QpcProgram::dims_s), the postsolve restores the eliminated columns.

@@ -2767,7 +2767,9 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
     }
   } QPC_END_PHASE
   QPC_PROF_ACC(PS_R_SV);
+  QPC_LANE_ARRAY(bwp_, 6); // D.dfs: this body's wrench, then the sum of the wrenches of bodies 0 .. lane
   QPC_PHASE(lane) { // body wrench: I A_free + W0 - external (contact) wrench,  W0 = I (Ab - g) + T x* I T
+    for (int a = 0; a < 6; a++) QPC_LA(bwp_, lane)[a] = 0.0;
     if (lane < nb) {
       const int i = lane;
       const int *mt = QPC_LI(M.v, lane);
@@ -2796,9 +2798,16 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
           for (int a = 0; a < 6; a++) ia[a] -= sm[D.lds[L_CWR] + 6 * c + a];
         }
       }
-      st(sm + D.lds[L_BW] + 6 * i, 6, ia);
+      if (D.dfs) { for (int a = 0; a < 6; a++) QPC_LA(bwp_, lane)[a] = ia[a]; }
+      else st(sm + D.lds[L_BW] + 6 * i, 6, ia);
     }
   } QPC_END_PHASE
+  if (D.dfs) { // depth-first numbering: a subtree is an index range, its wrench the difference of two prefix sums
+    QPC_WAVE_INCL_SCAN(lane, QPC_LA(bwp_, lane), 6)
+    QPC_PHASE(lane) {
+      if (lane < nb) st(sm + D.lds[L_BW] + 6 * lane, 6, QPC_LA(bwp_, lane));
+    } QPC_END_PHASE
+  }
   QPC_PROF_ACC(PS_R_BW);
   QPC_PHASE(lane) { // tau_k = S_k . (sum of subtree wrenches); floating joint torques exactly 0
     if (lane < nv) {
@@ -2808,6 +2817,10 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
       if (MT_VBODY(mt) != D.floating) {
         double F[6] = {0, 0, 0, 0, 0, 0};
         unsigned long long msk = ((unsigned long long)(unsigned)mt[5] << 32) | (unsigned long long)(unsigned)mt[4];
+        if (D.dfs) { // subtree = bodies first .. last: prefix[last] - prefix[first - 1]
+          const int first = QPC_CTZ64(msk), last = first + QPC_POPC64(msk) - 1;
+          for (int a = 0; a < 6; a++) F[a] = sm[D.lds[L_BW] + 6 * last + a] - (first > 0 ? (double)sm[D.lds[L_BW] + 6 * (first > 0 ? first - 1 : 0) + a] : 0.0);
+        } else
         while (msk) {
           const int b = QPC_CTZ64(msk);
           msk &= msk - 1;

@@ -84,6 +84,7 @@ struct Lds {
 #define QPC_LANE_INTS(name, n) int name[64][n]
 #define QPC_LI(name, lane) name[lane]
 #define QPC_CTZ64(x) __builtin_ctzll((unsigned long long)(x))
+#define QPC_POPC64(x) __builtin_popcountll((unsigned long long)(x))
 // lane-serial model of v_mfma_f64_16x16x4_f64 (operand / accumulator lane maps of the guide)
 static thread_local double emu_mfma_a[64], emu_mfma_b[64];
 #define QPC_MFMA_F64_16x16x4(lane, ACC, AEXPR, BEXPR)                                                    \
@@ -105,6 +106,10 @@ static thread_local double emu_row[64][8];
 #define QPC_ROW_SHARE(lane, OUT, N, X, K)                                                                              \
   QPC_PHASE(lane) { const double *x__ = (X); for (int i__ = 0; i__ < (N); i__++) emu_row[lane][i__] = x__[i__]; } QPC_END_PHASE_SOFT \
   QPC_PHASE(lane) { double *o__ = (OUT); for (int i__ = 0; i__ < (N); i__++) o__[i__] = emu_row[(lane & ~15) + (K)][i__]; } QPC_END_PHASE_SOFT
+// lane-serial model of the wave prefix sum (the device adds in tree order: results agree to rounding, not bit for bit)
+#define QPC_WAVE_INCL_SCAN(lane, ARR, N)                                                                                \
+  QPC_PHASE(lane) { const double *x__ = (ARR); for (int i__ = 0; i__ < (N); i__++) emu_row[lane][i__] = x__[i__]; } QPC_END_PHASE_SOFT \
+  QPC_PHASE(lane) { double *o__ = (ARR); for (int i__ = 0; i__ < (N); i__++) { double s__ = 0.0; for (int l__ = 0; l__ <= lane; l__++) s__ += emu_row[l__][i__]; o__[i__] = s__; } } QPC_END_PHASE_SOFT
 // reductions across a phase boundary: lane-serial form through the (emulator-only) scratch that
 // follows the kernel's LDS slab
 #define QPC_RED_MAX_PUT(slot, name, val) sm[D.lds_doubles + 128 * (slot) + lane] = (val)
