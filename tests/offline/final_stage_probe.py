@@ -10,7 +10,13 @@ Why the sweep stays (512 config-3 states, |dtau| / max(1, |tau|_max), round 3):
   ... + X = L11^-1 applied as an operator for u0 = c2 - L21 (X c1) and lam_1 = X'(X c1 - L21' lam_w) instead of the
       explicit S11^-1 = X'X and Z = S11^-1 S12                  3.9e-11       6.3e-10      1.74e-9
 The floor that is left is in the DATA of the reduced system (B22 = S22 - L21 L21' cancels), which only a residual of the full
-system -- computed from M, G and H, i.e. the confirming sweep -- can see.  The two experimental variants were removed again."""
+system -- computed from M, G and H, i.e. the confirming sweep -- can see.  The two experimental variants were removed again.
+
+Asked once more after the presolve with folded rows (no leading block: B22 = S22 exactly, no Z): no confirming sweep 8e-11 / 5.7e-9 /
+1.3e-8; with the wrench-space refinement step 6e-13 / 6.5e-11 / 1.1e-10 on config 3 -- much better, as predicted -- but 3.8e-5 at the
+worst single-contact state of config 5, and relative to a torque scale of 900 N m even 1e-10 is 1e-7 N m.  Skipping the sweep only
+where the true residuals are small does not separate the cases: at 1e-14 a third of the QPs skip it (errors <= 3e-12) and the other
+two thirds pay for the test; at 1e-13 half skip it with errors up to 1e-10.  The sweep stays unconditional."""
 import os
 import subprocess
 import sys
