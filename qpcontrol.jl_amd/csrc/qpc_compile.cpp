@@ -263,7 +263,8 @@ int qpc_compile_program(qpc_controller *c) {
       bool com_law = false;
       for (auto &t : c->tasks) com_law = com_law || t.law == QPC_LAW_COM_PD;
       for (int i = 0; i < nb; i++) {
-        bool has_free = com_law; // a COM law needs the whole momentum matrix (h = A v), pinned columns included
+        bool has_free = false;   // (a COM law takes the linear momentum from the bodies' own momenta, not from A v: no pinned columns)
+        (void)com_law;
         for (int k = 0; k < m->nvj[i]; k++) has_free = has_free || free_of[m->voff[i] + k] >= 0;
         unsigned long long mk = ((unsigned long long)(unsigned)mask[2 * i + 1] << 32) | (unsigned)mask[2 * i];
         const unsigned long long all = nb >= 64 ? ~0ull : ((1ull << nb) - 1);

@@ -252,6 +252,13 @@ __device__ __forceinline__ double qpc_wave_prefix_sum(double x) {
 #undef QPC_PS_STEP
   return x;
 }
+// sum over the 64 lanes (the last lane's prefix sum), same PUT / GET protocol as the max reductions
+__device__ __forceinline__ double qpc_wave_sum(double x) {
+  x = qpc_wave_prefix_sum(x);
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 63), __builtin_amdgcn_readlane(__double2loint(x), 63));
+}
+#define QPC_RED_SUM_PUT(slot, name, val) name = qpc_wave_sum(val)
+#define QPC_RED_SUM_GET(slot, name) (name)
 // phase level (all 64 lanes): ARR[i] of every lane becomes the sum of ARR[i] over the lanes up to and including it
 #define QPC_WAVE_INCL_SCAN(lane, ARR, N)                                                          \
   {                                                                                              \

@@ -1248,8 +1248,8 @@ QPC_FN void se3_pd_law(PR rec, const double *Hb, const double *Ha, const double 
 // Desired entries from laws that need the kinematics (standing.jl:60-77: centre-of-mass PD, pelvis orientation PD; SE3PDController
 // on the device), lane = desired entry: runs after the momentum phase (it reads L_AMOM, MS_COM, L_H, L_T) and before the rows of the
 // assembly read L_DES
-template <class P> QPC_FN void desired_late(const QpcDims &D, const int *IT, const double *DT, P sm, int lane) {
-  const int nv = D.nv, MISC = D.lds[L_MISC];
+template <class P> QPC_FN void desired_late(const QpcDims &D, const int *IT, const double *DT, P sm, int lane, const double *hlin) {
+  const int MISC = D.lds[L_MISC];
   for (int i = lane; i < D.n_desired; i += 64) {
     const int *li = IT + D.it[IT_LAW] + 3 * i;
     const double *lw = DT + D.dt[DT_LAW] + 3 * i;
@@ -1257,7 +1257,7 @@ template <class P> QPC_FN void desired_late(const QpcDims &D, const int *IT, con
     //  instructions and its live values used to push the register allocation of the whole tick into scratch)
     if (((D.law_mask >> QPC_LAW_COM_PD) & 1) && li[0] == QPC_LAW_COM_PD) { // m c̈,  c̈ = -kp (c - c_ref) - kd h_lin / m
       const int a = li[1];
-      const double hl = dotp(sm + D.lds[L_AMOM] + (3 + a) * nv, 1, sm + D.lds[L_V], 1, nv); // linear momentum
+      const double hl = hlin[a]; // linear momentum of the robot: the sum of the bodies' own momenta (kinematics phase)
       const double mt = DT[D.dt[DT_GRAV] + 3];
       sm[D.lds[L_DES] + i] = mt * (-lw[0] * (sm[MISC + MS_COM + a] - lw[2])) - lw[1] * hl;
     } else if (((D.law_mask >> QPC_LAW_ORIENTATION_PD) & 1) && li[0] == QPC_LAW_ORIENTATION_PD) { // -kp rotation_vector(R) - kd R' omega (body frame)
@@ -1745,7 +1745,10 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
     }
   } QPC_END_PHASE
   QPC_PROF_ACC(PS_K_TWIST);
+  double hlin[3] = {0.0, 0.0, 0.0}; // linear momentum of the whole robot (wave sum; only a centre-of-mass law reads it)
+  const bool com_law = ((D.law_mask >> QPC_LAW_COM_PD) & 1) != 0;
   QPC_PHASE(lane) { // bias_acceleration (+ pinned), composite inertias (subtree mask), momentum-rate bias
+    double hl_[3] = {0.0, 0.0, 0.0};
     if (lane < nb) {
       const int i = lane;
       const int *mt = QPC_LI(M.v, lane);
@@ -1769,6 +1772,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
       ld(sm + D.lds[L_IW] + 10 * i, 10, I);
       ld(sm + D.lds[L_T] + 6 * i, 6, T);
       inertia_mul(I, T, h);
+      for (int a = 0; a < 3; a++) hl_[a] = h[3 + a]; // this body's linear momentum (for a centre-of-mass law)
       inertia_mul(I, Ab, ia);
       crf(T, h, cf);
       for (int a = 0; a < 6; a++) ia[a] += cf[a];
@@ -1802,7 +1806,9 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
       }
       sm[D.lds[L_IC] + 10 * D.crb_full_body + a] = acc;
     }
+    if (com_law) { QPC_RED_SUM_PUT(0, hlin[0], hl_[0]); QPC_RED_SUM_PUT(1, hlin[1], hl_[1]); QPC_RED_SUM_PUT(2, hlin[2], hl_[2]); }
   } QPC_END_PHASE
+  if (com_law) { hlin[0] = QPC_RED_SUM_GET(0, hlin[0]); hlin[1] = QPC_RED_SUM_GET(1, hlin[1]); hlin[2] = QPC_RED_SUM_GET(2, hlin[2]); }
   QPC_PROF_ACC(PS_K_BIAS);
   QPC_PHASE(lane) { // momentum matrix, CoM, momentum-rate bias, Hessian diagonal
     // static-Hessian path: its table reads are issued FIRST, so that they travel while the momentum matrix is computed
@@ -1879,7 +1885,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
   QPC_STOP(1)
   if (h_fast && D.n_des_late) { // static Hessian blocks: the laws get a phase of their own (the general path evaluates them in its
                                 // regularisation-scale phase below)
-    QPC_PHASE(lane) { desired_late(D, IT, DT, sm, lane); } QPC_END_PHASE
+    QPC_PHASE(lane) { desired_late(D, IT, DT, sm, lane, hlin); } QPC_END_PHASE
   }
   // regularisation scale: eps = eps_primal * max diagonal of the Hessian
   if (!h_fast) {
@@ -1898,7 +1904,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
         double w = (sm[D.lds[L_CMAX] + c] > 0.0) ? 2.0 * QPC_FABS(sm[D.lds[L_CW] + c]) : 0.0;
         h = w > h ? w : h;
       }
-    if (D.n_des_late) desired_late(D, IT, DT, sm, lane); // desired laws that need the kinematics (standing.jl:60-77), lane = desired entry
+    if (D.n_des_late) desired_late(D, IT, DT, sm, lane, hlin); // desired laws that need the kinematics (standing.jl:60-77), lane = desired entry
     QPC_RED_MAX_PUT(0, hscale, h);
   } QPC_END_PHASE
   hscale = QPC_RED_MAX_GET(0, hscale);

@@ -122,6 +122,9 @@ static inline double emu_scale_trunc(double x) {
   return x;
 }
 #define QPC_RED_MAX_GET(slot, name) emu_scale_trunc(qpc::umax(sm, D.lds_doubles + 128 * (slot), 64))
+#define QPC_RED_SUM_PUT(slot, name, val) sm[D.lds_doubles + 128 * (slot) + lane] = (val)
+static inline double emu_sum64(const double *x) { double s = 0.0; for (int l = 0; l < 64; l++) s += x[l]; return s; }
+#define QPC_RED_SUM_GET(slot, name) ([&]() { double x__[64]; for (int l__ = 0; l__ < 64; l__++) x__[l__] = sm[D.lds_doubles + 128 * (slot) + l__]; return emu_sum64(x__); }())
 #define QPC_BALLOT_PUT(slot, name, pred) sm[D.lds_doubles + 128 * (slot) + lane] = (pred) ? 1.0 : 0.0
 #define QPC_BALLOT_GET(slot, name) \
   do { name = 0ull; for (int l__ = 0; l__ < 64; l__++) if ((double)sm[D.lds_doubles + 128 * (slot) + l__] != 0.0) name |= 1ull << l__; } while (0)
