@@ -367,6 +367,9 @@ def measured_issue(fingerprint):
             share = pl["SQ_ACTIVE_INST_ANY"] / pl["SQ_WAVE_CYCLES"]
             out["wave_active_share"] = share
             out["simd_issue_busy"] = min(1.0, 2.0 * share)
+        if "valu_lane_utilisation" in pl:
+            out["valu_lane_utilisation"] = pl["valu_lane_utilisation"]
+            out["valu_active_lanes_per_instruction"] = 64.0 * pl["valu_lane_utilisation"]
         out["note"] = ("the tick is bound by the number of instructions it issues: every added VALU instruction costs 8 cycles of QP-slot "
                        "time whether dependent or not (DESIGN.md 7b)")
         return out

@@ -208,6 +208,11 @@ int32_t qpc_task_desired_range(const qpc_controller *ctrl, int32_t task_id, int3
 
 /* regularize!(c, joint, w): obj += w * |vdot_joint|^2 ; weights add up (momentum.jl:128-131) */
 int32_t qpc_regularize(qpc_controller *ctrl, int32_t joint_body, double weight);
+/* regularize!(c, joint, weight) with a Parametron `Parameter` as the weight (momentum.jl:128-131 takes any `weight`; the
+ * Parameter is re-evaluated every tick): the weight is a per-QP input, entry *out_weight_index of `task_weights`.  At most one
+ * per-QP weight per joint; static weights (qpc_regularize) still add to it.  Like every per-QP task weight it switches the
+ * static-Hessian fast path of the tick off. */
+int32_t qpc_regularize_per_qp(qpc_controller *ctrl, int32_t joint_body, int32_t *out_weight_index);
 
 /* addcontact!(c, body, position, normal, mu) (momentum.jl:133-148, contacts.jl:38-69).
  * position/normal in the frame of `body`.  The reference lets position, normal and mu be Parameters
@@ -306,6 +311,9 @@ int32_t qpc_control_batch_async(qpc_controller *ctrl, int64_t B, const double *q
                                 const double *surfaces, double *tau, double *vdot,
                                 double *contact_wrench, int32_t *status, int32_t *iters);
 int32_t qpc_wait(qpc_controller *ctrl);
+/* The error such a dropped job had (QPC_OK if none): the code is returned, the text copied to `message` (may be NULL), and
+ * the record is cleared.  A dropped failure is also announced once on stderr; the outputs of that batch are not valid. */
+int32_t qpc_last_async_error(qpc_controller *ctrl, char *message, int32_t message_bytes);
 
 /* Same, but every pointer is a DEVICE pointer on the controller's device and the work is
  * enqueued on `hip_stream` (a hipStream_t, NULL = default stream) without synchronising. */
@@ -456,6 +464,19 @@ int32_t qpc_rollout_batch_device(qpc_controller *ctrl, int64_t B, int64_t n_step
 
 /* QPSolveFailure text (exceptions.jl:7-11) */
 const char *qpc_status_string(int32_t status);
+/* The three fields of QPSolveFailure (exceptions.jl:1-5: terminationstatus, primalstatus, dualstatus -- what checkstatus,
+ * momentum.jl:83-91, reads back from the optimizer) for a QPC_STATUS_* code, as the names of the MOI 0.8 enum values
+ * (MOI.TerminationStatusCode / MOI.ResultStatusCode) the OSQP wrapper of the reference reports in the same situation:
+ *   OPTIMAL          -> OPTIMAL,          FEASIBLE_POINT,            FEASIBLE_POINT
+ *   ALMOST_OPTIMAL   -> ALMOST_OPTIMAL,   UNKNOWN_RESULT_STATUS,     UNKNOWN_RESULT_STATUS   (accepted by checkstatus)
+ *   INFEASIBLE       -> INFEASIBLE,       NO_SOLUTION,               INFEASIBILITY_CERTIFICATE
+ *   DUAL_INFEASIBLE  -> DUAL_INFEASIBLE,  INFEASIBILITY_CERTIFICATE, NO_SOLUTION
+ *   ITERATION_LIMIT  -> ITERATION_LIMIT,  UNKNOWN_RESULT_STATUS,     UNKNOWN_RESULT_STATUS
+ *   NUMERICAL_ERROR  -> NUMERICAL_ERROR,  UNKNOWN_RESULT_STATUS,     UNKNOWN_RESULT_STATUS
+ * (the active-set solver proves infeasibility by an inconsistent equality block / an unbounded Goldfarb-Idnani step and
+ * does not form a Farkas vector: the dual status names what OSQP would report, the certificate itself is not returned).
+ * Any of the three output pointers may be NULL; returns QPC_ERR_INVALID_ARGUMENT for an unknown code. */
+int32_t qpc_status_triple(int32_t status, const char **termination, const char **primal, const char **dual);
 const char *qpc_last_error(void);
 const char *qpc_version(void);
 /* 16 hex digits identifying the device code of this build (hash of the kernel sources): stored with every

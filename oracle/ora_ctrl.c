@@ -40,6 +40,7 @@ struct ora_ctrl {
   ora_contact contacts[ORA_MAXCONTACT];
   int nc;
   double reg[ORA_MAXV];
+  int reg_tw[ORA_MAXV]; /* regularize! with a Parameter weight (momentum.jl:128-131 takes any `weight`): index into tw or -1 */
   int nvar, nrow, neq, nineq, n_desired, n_tw, n_surf, wb_row0, finalized;
   ora_state *s;
   ora_osqp_settings st;
@@ -129,6 +130,15 @@ int ora_regularize(ora_ctrl *c, int joint, double w) {
   if (c->finalized) return -1;
   for (int k = 0; k < c->m->nvj[joint]; k++) c->reg[c->m->voff[joint] + k] += w;
   return 0;
+}
+/* regularize!(c, joint, weight::Parameter) (momentum.jl:128-131): the weight is re-evaluated every tick; here it is entry
+ * `return value` of the per-tick task-weight record.  One parametric weight per joint (static ones still add up). */
+int ora_regularize_per_qp(ora_ctrl *c, int joint) {
+  if (c->finalized || c->reg_tw[c->m->voff[joint]] > 0) return -1;
+  const int off = c->n_tw;
+  for (int k = 0; k < c->m->nvj[joint]; k++) c->reg_tw[c->m->voff[joint] + k] = off + 1; /* 0 = none (calloc) */
+  c->n_tw += 1;
+  return off;
 }
 /* ContactPoint{N}: rho[N], force_local[3], wrench_world angular[3], linear[3] (contacts.jl:46-48)
  * and 3 + N + N + 3 + 3 rows (contacts.jl:63-67) */
@@ -358,7 +368,7 @@ static void build_values(ora_ctrl *c, const double *q, const double *v, const do
   memset(c->q, 0, sizeof(double) * n);
   memset(c->A, 0, sizeof(double) * (size_t)mr * n);
   /* objective: regularize! terms, P = 2 * weight */
-  for (int k = 0; k < nv; k++) c->P[k * n + k] = 2.0 * c->reg[k];
+  for (int k = 0; k < nv; k++) c->P[k * n + k] = 2.0 * (c->reg[k] + (c->reg_tw[k] > 0 ? tw[c->reg_tw[k] - 1] : 0.0));
   double J[6 * ORA_MAXV], bias[6];
   for (int ti = 0; ti < c->nt; ti++) {
     ora_task *t = &c->tasks[ti];

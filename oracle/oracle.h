@@ -125,6 +125,7 @@ void ora_ctrl_destroy(ora_ctrl *c);
 int ora_add_task(ora_ctrl *c, int kind, int base, int target, int frame, const double *point,
                  int joint, int wkind, const double *weight);
 int ora_regularize(ora_ctrl *c, int joint, double w);
+int ora_regularize_per_qp(ora_ctrl *c, int joint); /* -> index of the weight in the per-tick task-weight record, or -1 */
 int ora_add_contact(ora_ctrl *c, int body, const double pos[3], const double normal[3], double mu,
                     int per_qp_surface);
 int ora_finalize(ora_ctrl *c, qpc_layout *out);

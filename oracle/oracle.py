@@ -244,6 +244,12 @@ class OracleController:
     def regularize(self, joint, w):
         assert self.L.ora_regularize(self.h, int(joint), ctypes.c_double(w)) == 0
 
+    def regularize_per_qp(self, joint):
+        """regularize!(c, joint, weight::Parameter): -> index of the weight in the per-QP task-weight record"""
+        off = self.L.ora_regularize_per_qp(self.h, int(joint))
+        assert off >= 0
+        return off
+
     def add_contact(self, body, pos, normal, mu, per_qp_surface=0):
         cid = self.L.ora_add_contact(self.h, int(body), _p(_arr(pos, 3)), _p(_arr(normal, 3)),
                                      ctypes.c_double(mu), int(per_qp_surface))

@@ -24,7 +24,10 @@ class QPSolveFailure(RuntimeError):
 
     def __init__(self, index, status):
         self.index, self.status = index, status
-        super().__init__(f"QP solve unsuccessful for batch element {index}: {binding.STATUS_NAMES[status]}")
+        # the reference's three fields (terminationstatus, primalstatus, dualstatus), from qpc_status_triple
+        self.terminationstatus, self.primalstatus, self.dualstatus = binding.status_triple(status)
+        super().__init__(f"QP solve unsuccessful (batch element {index}). Termination status: {self.terminationstatus}. "
+                         f"Primal status: {self.primalstatus}. Dual status: {self.dualstatus}.")
 
 
 def _body(mech: Mechanism, b):

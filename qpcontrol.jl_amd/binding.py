@@ -192,6 +192,12 @@ class Controller:
     def regularize(self, joint, w):
         _check(self.L, self.L.qpc_regularize(self.h, int(joint), float(w)), "qpc_regularize")
 
+    def regularize_per_qp(self, joint):
+        """regularize!(c, joint, weight::Parameter): -> index of the weight in the per-QP task-weight record"""
+        off = ctypes.c_int32(-1)
+        _check(self.L, self.L.qpc_regularize_per_qp(self.h, int(joint), ctypes.byref(off)), "qpc_regularize_per_qp")
+        return off.value
+
     def add_contact(self, body, pos, normal, mu, per_qp_surface=0):
         p = np.ascontiguousarray(pos, dtype=np.float64)
         n = np.ascontiguousarray(normal, dtype=np.float64)
@@ -373,6 +379,17 @@ def assemble_solve_batch(ctrl: Controller, task_J, task_bias, desired, momentum_
                                          iters.ctypes.data_as(c_int32_p))
     _check(ctrl.L, rc, "qpc_assemble_solve_batch")
     return dict(vdot=vd, cwrench=wr[:, :6 * lay.n_contacts].reshape(B, lay.n_contacts, 6), status=status, iters=iters)
+
+
+def status_triple(status, lib_path=None):
+    """(terminationstatus, primalstatus, dualstatus) names of a QPC_STATUS_* code: the fields of QPSolveFailure (exceptions.jl:1-5)"""
+    L = load_library(lib_path)
+    t, p, d = ctypes.c_char_p(), ctypes.c_char_p(), ctypes.c_char_p()
+    L.qpc_status_triple.argtypes = [ctypes.c_int32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_char_p)]
+    rc = L.qpc_status_triple(int(status), ctypes.byref(t), ctypes.byref(p), ctypes.byref(d))
+    if rc != 0:
+        return ("UNKNOWN", "UNKNOWN_RESULT_STATUS", "UNKNOWN_RESULT_STATUS")
+    return t.value.decode(), p.value.decode(), d.value.decode()
 
 
 def qp_solve_batch(P, q, A, l, u, device_id=0, lib_path=None, **settings):

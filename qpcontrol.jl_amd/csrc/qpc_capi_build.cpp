@@ -70,6 +70,7 @@ int32_t qpc_controller_create(const qpc_model *model, int32_t n_basis, int32_t f
   if (!c) return QPC_ERR_OUT_OF_MEMORY;
   c->model = model; c->N = n_basis; c->floating = floating_body;
   c->reg.assign(model->nv, 0.0);
+  c->reg_tw.assign(model->nv, -1);
   qpc_default_settings(&c->settings);
   std::memset(&c->layout, 0, sizeof(c->layout));
   *out = c;
@@ -182,6 +183,16 @@ int32_t qpc_regularize(qpc_controller *c, int32_t joint, double w) {
   return QPC_OK;
 }
 
+int32_t qpc_regularize_per_qp(qpc_controller *c, int32_t joint, int32_t *out_weight_index) {
+  if (!c || joint < 0 || joint >= c->model->nb || c->model->nvj[joint] < 1) return QPC_ERR_INVALID_ARGUMENT;
+  if (c->finalized) { qpc_set_error("regularize! must be called before the first tick"); return QPC_ERR_ALREADY_FINALIZED; }
+  if (c->reg_tw[c->model->voff[joint]] >= 0) { qpc_set_error("qpc_regularize_per_qp: this joint already has a per-QP weight"); return QPC_ERR_INVALID_ARGUMENT; }
+  for (int k = 0; k < c->model->nvj[joint]; k++) c->reg_tw[c->model->voff[joint] + k] = c->n_tw;
+  if (out_weight_index) *out_weight_index = c->n_tw;
+  c->n_tw += 1;
+  return QPC_OK;
+}
+
 int32_t qpc_add_contact(qpc_controller *c, int32_t body, const double position[3], const double normal[3], double mu,
                         int32_t per_qp_surface, int32_t *out_contact_id) {
   if (!c || !position || !normal || body < -1 || body >= c->model->nb) return QPC_ERR_INVALID_ARGUMENT;
@@ -221,6 +232,20 @@ const char *qpc_status_string(int32_t s) {
     case QPC_STATUS_NUMERICAL_ERROR: return "NUMERICAL_ERROR";
   }
   return "UNKNOWN";
+}
+int32_t qpc_status_triple(int32_t s, const char **termination, const char **primal, const char **dual) {
+  static const char *const T[6][3] = {
+      {"OPTIMAL", "FEASIBLE_POINT", "FEASIBLE_POINT"},
+      {"ALMOST_OPTIMAL", "UNKNOWN_RESULT_STATUS", "UNKNOWN_RESULT_STATUS"},
+      {"INFEASIBLE", "NO_SOLUTION", "INFEASIBILITY_CERTIFICATE"},
+      {"DUAL_INFEASIBLE", "INFEASIBILITY_CERTIFICATE", "NO_SOLUTION"},
+      {"ITERATION_LIMIT", "UNKNOWN_RESULT_STATUS", "UNKNOWN_RESULT_STATUS"},
+      {"NUMERICAL_ERROR", "UNKNOWN_RESULT_STATUS", "UNKNOWN_RESULT_STATUS"}};
+  if (s < 0 || s > 5) return QPC_ERR_INVALID_ARGUMENT;
+  if (termination) *termination = T[s][0];
+  if (primal) *primal = T[s][1];
+  if (dual) *dual = T[s][2];
+  return QPC_OK;
 }
 const char *qpc_version(void) { return "qpcontrol_hip 0.1.0 (gfx950)"; }
 

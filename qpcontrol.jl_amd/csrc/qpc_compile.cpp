@@ -127,6 +127,10 @@ int qpc_compile_program(qpc_controller *c) {
     }
     generic.push_back((int)ti);
   }
+  // regularize!(c, joint, weight::Parameter) (qpc_regularize_per_qp): w |vdot_k|^2 is a folded soft joint task with desired 0
+  // (IT_SJ_DES = -1) and a per-QP weight; on a pinned acceleration it is a constant of the objective
+  for (int k = 0; k < nv; k++)
+    if (c->reg_tw[k] >= 0 && free_of[k] >= 0) { sj_f.push_back(free_of[k]); sj_des.push_back(-1); sj_tw.push_back(c->reg_tw[k]); sj_w.push_back(0.0); }
   D.nsj = (int)sj_f.size(); D.ntask = (int)generic.size();
   // rows and slacks
   int m1 = 0, ne = 0, wsize = 0;

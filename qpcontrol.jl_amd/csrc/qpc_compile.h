@@ -45,6 +45,7 @@ struct qpc_controller {
   std::vector<QpcTask> tasks;
   std::vector<QpcContact> contacts;
   std::vector<double> reg;
+  std::vector<int> reg_tw; // per velocity index: entry of task_weights that holds its per-QP regularisation weight, or -1
   int n_desired = 0, n_tw = 0, n_surf = 0;
   bool finalized = false;
   qpc_settings settings;

@@ -18,6 +18,7 @@
 #pragma once
 #include <atomic>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdint>
 #include <memory>
 #include <mutex>
@@ -90,7 +91,7 @@ class QpcHostPipeline {
   int submit(const QpcHostJob &job) {
     std::string e;
     int rc = wait(e);
-    (void)rc; // the error of an earlier job was that job's: reported by its own wait (or dropped if never waited for)
+    if (rc) note_dropped(rc, e); // the error of an earlier job was that job's: reported by its own wait, or -- never waited for -- parked
     {
       std::lock_guard<std::mutex> lk(mu_);
       job_ = job;
@@ -116,7 +117,7 @@ class QpcHostPipeline {
   // synchronous run; small jobs on the caller's thread
   int run(const QpcHostJob &job, std::string &err) {
     if (job.B <= inline_) {
-      (void)wait(err); // an async job nobody waited for: its error was that job's (see submit), this job still runs
+      { const int rd = wait(err); if (rd) note_dropped(rd, err); } // an async job nobody waited for: its error was that job's (see submit), this job still runs
       err.clear();
       int rc = 0;
       be_->bind_thread(0);
@@ -131,7 +132,26 @@ class QpcHostPipeline {
     return wait(err);
   }
 
+  // The error of an async job that nobody waited for is not the next call's error (that call reports its own batch), but it must
+  // not vanish either: it is parked here until take_dropped reads it (qpc_last_async_error), and announced once on stderr.
+  void note_dropped(int rc, const std::string &msg) {
+    std::lock_guard<std::mutex> lk(drop_mu_);
+    dropped_rc_ = rc; dropped_msg_ = msg;
+    fprintf(stderr, "qpcontrol_hip: an asynchronous batch failed and nobody called qpc_wait for it (code %d: %s); its outputs are "
+                    "not valid -- see qpc_last_async_error\n", rc, msg.c_str());
+  }
+  int take_dropped(std::string &msg) {
+    std::lock_guard<std::mutex> lk(drop_mu_);
+    const int rc = dropped_rc_;
+    msg = dropped_msg_;
+    dropped_rc_ = 0; dropped_msg_.clear();
+    return rc;
+  }
+
  private:
+  std::mutex drop_mu_;
+  int dropped_rc_ = 0;
+  std::string dropped_msg_;
   void worker(int d, int s) {
     bool bound = false;
     uint64_t seen = 0;

@@ -756,7 +756,8 @@ static int control_device(qpc_controller *c, int device_index, int64_t B, const 
   QpcBatchArgs a;
   a.B = B; a.q = q; a.v = v; a.desired = desired; a.cw = cw; a.cmax = cmax; a.tw = tw; a.surf = surf;
   a.tau = tau; a.vdot = vdot; a.cwrench = cwrench; a.status = status; a.iters = iters;
-  a.prof = S->prof; a.wsets = wsets;
+  a.prof = slot == 0 ? S->prof : nullptr; // the (diagnostic) section-profile buffer is indexed by QP: overlapping launches on other slots must not write it
+  a.wsets = wsets;
   HIP_TRY(hipSetDevice(S->device));
   return launch(c, S, S->slots[c->rt->user_slot(slot)], a, (hipStream_t)hip_stream, wsets != nullptr);
 }
@@ -802,14 +803,20 @@ static int host_wait(qpc_controller *c) { // everything the host-pointer entry p
   if (rc == QPC_OK) rc = rz;
   return rc;
 }
+// ... on behalf of a call that is NOT qpc_wait: the error of a job in flight is that job's, not the new call's (qpc.h) -- it is
+// parked where qpc_last_async_error finds it instead of being lost, and announced once on stderr
+static void host_wait_drop(qpc_controller *c) {
+  const int rc = host_wait(c);
+  if (rc != QPC_OK) c->rt->pipe->note_dropped(rc, qpc_last_error());
+}
 
 // run a filled job: zero-copy when every array is page-locked, else the staged pipeline
 static int run_job(qpc_controller *c, const QpcHostJob &job, bool async) {
   // one job in flight per controller.  The error of an async job that was never waited for was THAT job's: it is
   // dropped here (qpc.h), the new job runs and reports its own outcome -- a caller must never get an error code for
   // a batch that was not even attempted
-  int rc = host_wait(c);
-  (void)rc;
+  host_wait_drop(c);
+  int rc = QPC_OK;
   if (c->rt->zero_copy && job_all_pinned(job)) {
     rc = zero_copy_launch(c, job);
     if (rc == QPC_OK) return async ? QPC_OK : zero_copy_wait(c);
@@ -829,7 +836,7 @@ int32_t qpc_control_batch(qpc_controller *c, int64_t B, const double *q, const d
   QpcHostJob job;
   int rc = fill_job(c, job, B, q, v, desired, cw, cmax, tw, surf, tau, vdot, cwrench, status, iters, nullptr, "qpc_control_batch");
   if (rc != QPC_OK) return rc;
-  if (B == 0) { (void)host_wait(c); return QPC_OK; }
+  if (B == 0) { host_wait_drop(c); return QPC_OK; }
   return run_job(c, job, false);
 }
 
@@ -851,13 +858,21 @@ int32_t qpc_control_batch_warm(qpc_controller *c, int64_t B, const double *q, co
   QpcHostJob job;
   int rc = fill_job(c, job, B, q, v, desired, cw, cmax, tw, surf, tau, vdot, cwrench, status, iters, working_set, "qpc_control_batch_warm");
   if (rc != QPC_OK) return rc;
-  if (B == 0) { (void)host_wait(c); return QPC_OK; }
+  if (B == 0) { host_wait_drop(c); return QPC_OK; }
   return run_job(c, job, false);
 }
 
 int32_t qpc_wait(qpc_controller *c) {
   if (!c || !c->finalized || !c->rt) { qpc_set_error("controller not finalized"); return QPC_ERR_NOT_FINALIZED; }
   return host_wait(c);
+}
+
+int32_t qpc_last_async_error(qpc_controller *c, char *message, int32_t message_bytes) {
+  if (!c || !c->finalized || !c->rt) return QPC_ERR_NOT_FINALIZED;
+  std::string msg;
+  const int rc = c->rt->pipe->take_dropped(msg);
+  if (message && message_bytes > 0) snprintf(message, (size_t)message_bytes, "%s", msg.c_str());
+  return rc;
 }
 
 int32_t qpc_assemble_solve_batch(qpc_controller *c, int64_t B, const double *task_J, const double *task_bias,
@@ -875,7 +890,7 @@ int32_t qpc_assemble_solve_batch(qpc_controller *c, int64_t B, const double *tas
   if (c->N > 8) { qpc_set_error("qpc_assemble_solve_batch: friction basis larger than 8"); return QPC_ERR_UNSUPPORTED; }
   for (auto &t : c->tasks)
     if (t.law == QPC_LAW_SE3_PD) { qpc_set_error("qpc_assemble_solve_batch: tasks with a trajectory-record law are not supported by the L1 path"); return QPC_ERR_UNSUPPORTED; }
-  (void)host_wait(c); // the inline slot's stream is shared with small host-pointer jobs (a stale async error is that job's)
+  host_wait_drop(c); // the inline slot's stream is shared with small host-pointer jobs (a stale async error is that job's)
   int rc = QPC_OK;
   QpcDeviceState *S = c->rt->devs[0];
   hipStream_t st = S->slots[c->rt->inline_slot()].stream;
@@ -1097,7 +1112,7 @@ static int rollout_host(qpc_controller *c, int64_t B, int64_t n_steps, bool tick
                         double *tau, int32_t *status, int32_t *bad) {
   const QpcDims &D = c->prog.dims;
   if (B == 0) return QPC_OK;
-  (void)host_wait(c); // a stale error of an un-waited async job is that job's (qpc.h)
+  host_wait_drop(c); // a stale error of an un-waited async job is that job's (qpc.h)
   int rc = QPC_OK;
   enum { A_Q, A_V, A_TAU, A_VDOT, A_DES, A_CW, A_CMAX, A_TW, A_SURF, A_COUNT };
   const size_t dim[A_COUNT] = {(size_t)D.nq, (size_t)D.nv, (size_t)D.nv, (size_t)D.nv, desired ? (size_t)D.n_desired : 0,

@@ -1380,7 +1380,9 @@ template <class P> QPC_FN bool qpc_presolve(const QpcDims &D, const QpcDims &DS,
       if (j == 0) {
         const int e = lane >> 4, cc = (lane & 15) - 6;
         const bool mine = e < n_e && cc >= 0 && cc <= nf_s;
-        QPC_BALLOT_PUT(0, bbad, mine && !(dd[0] > 1e-4 * dd[1])); // (measured: the torques lose ~1e-14 / ratio^2; 1e-4 keeps them at 1e-11)
+        // (measured: the torques lose ~1e-14 / ratio^2; 1e-4 keeps them at 1e-11).  The running min / max ignore a NaN (both
+        // comparisons are false), so the last diagonal entry is tested by itself and a NaN anywhere shows up in the solution
+        QPC_BALLOT_PUT(0, bbad, mine && (!(dd[0] > 1e-4 * dd[1]) || !(a == a) || !(col[0] == col[0]) || !(col[5] == col[5])));
         if (mine) { // columns of Z': P, then the columns of Q, then P + g~ of the eliminated unknowns
           for (int i = 0; i < 6; i++) sm[PZ + cc * nr + 6 * e + i] = col[i];
           if (cc == 0)
@@ -1500,8 +1502,12 @@ template <class P> QPC_FN bool qpc_presolve(const QpcDims &D, const QpcDims &DS,
   return true;
 }
 
-// the eliminated and the whitened unknowns back from the solution y of the reduced problem: x_b = C^-T y, x_e = P_e - Q_e x_b
-template <class P> QPC_FN void qpc_postsolve(const QpcDims &D, const QpcDims &DS, P sm) {
+// the eliminated and the whitened unknowns back from the solution y of the reduced problem: x_b = C^-T y, x_e = P_e - Q_e x_b.
+// Returns a lane mask of the eliminated hard rows A_e x_e + B_e x_b = b_e that the restored solution violates by more than
+// tol_accept (relative to 1 + |b|), or whose residual is not a number: the acceptance test of the reduced problem never sees these
+// rows, and the conditioning test of the elimination (smallest / largest |R_jj| of an unpivoted QR) is a heuristic, not a bound
+//  -- the caller downgrades the status.  The rows are read from the problem as assembled (L_M, L_D: untouched).
+template <class P> QPC_FN unsigned long long qpc_postsolve(const QpcDims &D, const QpcDims &DS, P sm) {
   QPC_LANE_SCOPE
   const int n_e = D.presolve, nf_s = D.pre_nf, nr = 6 * n_e;
   QPC_PHASE(lane) {
@@ -1524,6 +1530,21 @@ template <class P> QPC_FN void qpc_postsolve(const QpcDims &D, const QpcDims &DS
       sm[D.lds[L_XV] + (elim ? c0 + lane - 6 * e : D.pre_b0 + lane - nr)] = acc;
     }
   } QPC_END_PHASE
+  unsigned long long bviol = 0ull, bnan = 0ull;
+  QPC_PHASE(lane) {
+    bool viol = false, isnan_ = false;
+    if (lane < nr) {
+      const double d = sm[D.lds[L_D] + lane];
+      const double res = d - dotp(sm + D.lds[L_M] + lane * D.nfs, 1, sm + D.lds[L_XV], 1, D.nf);
+      isnan_ = !(res == res);
+      viol = !(QPC_FABS(res) <= D.tol_accept * (1.0 + QPC_FABS(d)));
+    }
+    QPC_BALLOT_PUT(0, bviol, viol);
+    QPC_BALLOT_PUT(1, bnan, isnan_);
+  } QPC_END_PHASE
+  QPC_BALLOT_GET(0, bviol);
+  QPC_BALLOT_GET(1, bnan);
+  return bnan != 0ull ? ~0ull : bviol; // all ones: not a number
 }
 
 // once per workgroup (before its first QP): hot solver lookups -> the persistent L_HOT region of
@@ -1847,7 +1868,8 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
           int twi = IT[D.it[IT_SJ_TW] + s];
           double w = twi >= 0 ? sm[D.lds[L_TW] + twi] : DT[D.dt[DT_SJ_W] + s];
           if (!h_fast) hv += 2.0 * w;
-          gv -= 2.0 * w * sm[D.lds[L_DES] + IT[D.it[IT_SJ_DES] + s]];
+          const int sd = IT[D.it[IT_SJ_DES] + s]; // -1: a per-QP regularisation weight (desired acceleration 0)
+          if (sd >= 0) gv -= 2.0 * w * sm[D.lds[L_DES] + sd];
         }
       sm[D.lds[L_HV] + f] = hv;
       sm[D.lds[L_GV] + f] = gv;
@@ -2404,7 +2426,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
       rchg = bchg ? 1.0 : 0.0;
       rup = bup ? 1.0 : 0.0;
       QPC_PROF_ACC(PS_S_TEST);
-      if (!(rchg > 0.0)) { pd_converged = true; break; }
+      if (!(rchg > 0.0)) { pd_converged = true; if (fsearch) soft_tail = true; break; } // (the test phase itself ended soft)
       any_upper = rup > 0.0;
       iters++;
       // fused sweeps: the test above, the K rows / Y of the new set (free pattern from the ballot, not from LDS) and the solve are
@@ -2716,7 +2738,11 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
     reduced = true;
     solve_part(DS);
     QPC_PROF_ACC(PS_FINAL);
-    qpc_postsolve(D, DS, sm);
+    const unsigned long long bviol = qpc_postsolve(D, DS, sm);
+    if (status == QPC_STATUS_OPTIMAL || status == QPC_STATUS_ALMOST_OPTIMAL) { // an eliminated foot-task row is off by > tol_accept / not a number
+      if (bviol == ~0ull) status = QPC_STATUS_NUMERICAL_ERROR;
+      else if (bviol != 0ull) status = QPC_STATUS_ALMOST_OPTIMAL;
+    }
     QPC_PROF_ACC(PS_P_POST);
   } else {
     solve_part(D);

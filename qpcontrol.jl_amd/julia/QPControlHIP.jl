@@ -25,12 +25,25 @@ const QPC_FRAME_DEFAULT = Int32(-2)
 @enum WeightKind::Int32 HARD=0 SCALAR=1 MATRIX=2 SCALAR_PER_QP=3 MATRIX_PER_QP=4
 
 # exceptions.jl:1-11
+# (the reference's three fields -- names of the MOI enum values, from qpc_status_triple -- plus the batch element)
 struct QPSolveFailure <: Exception
+    terminationstatus::Symbol
+    primalstatus::Symbol
+    dualstatus::Symbol
     index::Int
     status::Int32
 end
-Base.showerror(io::IO, e::QPSolveFailure) = print(io, "QP solve unsuccessful for batch element ",
-    e.index, ": ", unsafe_string(ccall((:qpc_status_string, libqpc), Cstring, (Int32,), e.status)))
+function QPSolveFailure(index::Integer, status::Integer)
+    t = Ref{Cstring}(C_NULL); p = Ref{Cstring}(C_NULL); d = Ref{Cstring}(C_NULL)
+    rc = ccall((:qpc_status_triple, libqpc), Int32, (Int32, Ref{Cstring}, Ref{Cstring}, Ref{Cstring}), Int32(status), t, p, d)
+    rc == 0 || return QPSolveFailure(:UNKNOWN, :UNKNOWN_RESULT_STATUS, :UNKNOWN_RESULT_STATUS, Int(index), Int32(status))
+    QPSolveFailure(Symbol(unsafe_string(t[])), Symbol(unsafe_string(p[])), Symbol(unsafe_string(d[])), Int(index), Int32(status))
+end
+Base.showerror(io::IO, e::QPSolveFailure) = print(io, """
+    QP solve unsuccessful (batch element $(e.index)).
+    Termination status: $(e.terminationstatus)
+    Primal status: $(e.primalstatus)
+    Dual status: $(e.dualstatus)""")
 
 lasterror() = unsafe_string(ccall((:qpc_last_error, libqpc), Cstring, ()))
 check(rc, what) = rc == 0 ? nothing : error("$what failed (code $rc): $(lasterror())")

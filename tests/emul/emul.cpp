@@ -298,6 +298,13 @@ int32_t qpc_wait(qpc_controller *c) {
   if (rc != QPC_OK) qpc_set_error(err);
   return rc;
 }
+int32_t qpc_last_async_error(qpc_controller *c, char *message, int32_t message_bytes) {
+  if (!c || !c->finalized || !c->rt) return QPC_ERR_NOT_FINALIZED;
+  std::string msg;
+  const int rc = c->rt->pipe->take_dropped(msg);
+  if (message && message_bytes > 0) snprintf(message, (size_t)message_bytes, "%s", msg.c_str());
+  return rc;
+}
 // test hooks of the fake-device backend: which (device, slot) ran which chunk; inject a failure into the chunk holding QP b
 int32_t emu_chunk_log(qpc_controller *c, int64_t *out, int32_t max_rows) {
   std::lock_guard<std::mutex> lk(c->rt->backend->mu);

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/l0/atlas_143x178.npz: the 143 x 178 reference-layout QPs (what
+Parametron hands to its optimizer for the Atlas standing controller, `momentum.jl:27,58`) of a few seeded config-3
+states, as the CPU ORACLE builds them (oracle/ora_ctrl.c), with the oracle's exact solution -- inputs and expected
+outputs of the L0 entry `qpc_qp_solve_batch`, so that tools/bench_latency.py --l0 and the GPU tests can exercise the
+b-1 plug without importing the oracle.  Regression data of this repository, not reference output (the reference is
+Julia).  Stored sparse (the dense matrices are 98 % zeros).
+
+    python tests/golden/l0/make_l0_fixture.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+TESTS = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, TESTS)
+sys.path.insert(0, os.path.dirname(TESTS))
+import qpc_pkg  # noqa: E402
+
+qpc_pkg.load()
+import scenarios as SC  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+
+def main(B=8):
+    O.build()
+    case = SC.atlas_config(lambda mech, N, fl: O.OracleController(O.OracleModel(mech), N, fl), 3, B)
+    oc = case.ctrl
+    Ps, qs, As, ls, us, xs = [], [], [], [], [], []
+    for b in range(case.B):
+        P, q, A, l, u = oc.build_qp(case.q[b], case.v[b], case.desired[b], case.cweight[b], case.cmaxf[b])
+        r = oc.tick(case.q[b], case.v[b], case.desired[b], case.cweight[b], case.cmaxf[b])
+        if r["status"] != 0:
+            continue
+        Ps.append(P); qs.append(q); As.append(A); ls.append(l); us.append(u); xs.append(r["x"])
+    P, A = np.array(Ps), np.array(As)
+    pat_P, pat_A = np.any(P != 0.0, axis=0), np.any(A != 0.0, axis=0)
+    np.savez_compressed(os.path.join(HERE, "atlas_143x178.npz"), n=np.int32(P.shape[1]), m=np.int32(A.shape[1]),
+                        P_idx=np.argwhere(pat_P).astype(np.int16), P_val=P[:, pat_P], A_idx=np.argwhere(pat_A).astype(np.int16),
+                        A_val=A[:, pat_A], q=np.array(qs), l=np.array(ls), u=np.array(us), x=np.array(xs), nv=np.int32(case.mech.nv))
+    print(f"{len(Ps)} QPs, n = {P.shape[1]}, m = {A.shape[1]}, nnz(P) = {int(pat_P.sum())}, nnz(A) = {int(pat_A.sum())}")
+
+
+if __name__ == "__main__":
+    main()

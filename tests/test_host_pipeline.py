@@ -129,6 +129,11 @@ def test_worker_error_reaches_the_caller():
         ref = r if ref is None else ref
         assert np.array_equal(r["tau"], ref["tau"])
         c.wait()  # the stale error is gone
+        # ... but not lost: qpc_last_async_error hands it over once
+        L.qpc_last_async_error.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int32]
+        buf = ctypes.create_string_buffer(200)
+        assert L.qpc_last_async_error(c.h, buf, 200) != 0 and b"injected failure" in buf.value
+        assert L.qpc_last_async_error(c.h, buf, 200) == 0 and buf.value == b""
     L.emu_fail_at(c.h, -1)
     r = _tick(c, wl)  # the controller stays usable
     assert (r["status"] == 0).all()

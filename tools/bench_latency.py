@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Latency of one controller tick through the host-pointer entry point (qpc_control_batch: H2D, kernel, D2H,
 synchronous) for small batches -- the regime of the reference itself (ONE robot, one tick per millisecond).
-python tools/bench_latency.py  -> one JSON line (median / p99 microseconds per call; not the headline metric)"""
+python tools/bench_latency.py  -> one JSON line (median / p99 microseconds per call; not the headline metric)
+python tools/bench_latency.py --l0 [B ...]  -> the same for the solver-level plug (b-1: qpc_qp_solve_batch, what the reference's
+    own optimizer slot sees: the dense 143 x 178 Atlas problem of tests/golden/l0/atlas_143x178.npz), latency at B = 1 and rate at
+    larger batches"""
 import json
 import os
 import sys
@@ -17,7 +20,42 @@ qpc_pkg.load()
 from qpcontrol_jl_amd import binding, workloads as W  # noqa: E402
 
 
+def load_l0_fixture():
+    """The committed reference-layout problems (inputs + expected x), densified: P[k,n,n], q, A[k,m,n], l, u, x, nv"""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "l0", "atlas_143x178.npz"))
+    n, m, k = int(g["n"]), int(g["m"]), g["q"].shape[0]
+    P, A = np.zeros((k, n, n)), np.zeros((k, m, n))
+    P[:, g["P_idx"][:, 0], g["P_idx"][:, 1]] = g["P_val"]
+    A[:, g["A_idx"][:, 0], g["A_idx"][:, 1]] = g["A_val"]
+    return P, g["q"], A, g["l"], g["u"], g["x"], int(g["nv"])
+
+
+def l0_main(batches):
+    P, q, A, l, u, x, nv = load_l0_fixture()
+    k = P.shape[0]
+    out = {"metric": "L0 qpc_qp_solve_batch on the dense 143 x 178 Atlas reference-layout QP (host pointers, synchronous, through ctypes)",
+           "unit": "us", "n": int(P.shape[1]), "m": int(A.shape[1])}
+    for B in batches:
+        idx = np.arange(B) % k
+        a = (P[idx], q[idx], A[idx], l[idx], u[idx])
+        r = binding.qp_solve_batch(*a)  # first call: workspace allocation, module load
+        assert (r["status"] == 0).all(), r["status"]
+        err = float(np.abs(r["x"][:, :nv] - x[idx][:, :nv]).max())
+        reps = 20 if B == 1 else 3
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            r = binding.qp_solve_batch(*a)
+            ts.append(time.perf_counter() - t0)
+        ts = np.array(ts) * 1e6
+        out[str(B)] = {"median_us": float(np.median(ts)), "max_us": float(ts.max()), "solves_per_s": float(B / np.median(ts) * 1e6),
+                       "max_abs_err_vdot_vs_fixture": err}
+    print(json.dumps(out))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--l0":
+        return l0_main([int(a) for a in sys.argv[2:]] or [1, 64, 8192])
     def factory(mech, n_basis, floating):
         return binding.Controller(binding.Model(mech), n_basis, floating)
     ctrl, wl = W.atlas_workload(factory, 2048, 3)

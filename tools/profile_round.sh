@@ -15,5 +15,7 @@ rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o k --output-format csv -- $BENCH > /d
 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o k --output-format csv -- $BENCH > /dev/null 2> $OUT/write.log
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS -d $OUT/sq_a -o k --output-format csv -- $BENCH > /dev/null 2> $OUT/sq_a.log
 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY -d $OUT/sq_b -o k --output-format csv -- $BENCH > /dev/null 2> $OUT/sq_b.log
+# lane utilisation of the vector instructions: thread-cycles / (instruction-cycles x 64) = rocprofiler's VALUUtilization
+rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F64 -d $OUT/sq_c -o k --output-format csv -- $BENCH > /dev/null 2> $OUT/sq_c.log || echo "sq_c pass failed (see sq_c.log)"
 python3 $ROOT/bench.py --steps 20 --warmup 3 > $OUT/bench_full.json 2> $OUT/bench_full.err
 find $OUT -name "*.csv" | head -20

@@ -48,10 +48,14 @@ def main():
         traffic["kernel_fingerprint"] = None
     json.dump(traffic, open(dst + "_traffic_summary.json", "w"), indent=1)
     sq = {}
-    for sub in ("sq_a", "sq_b"):
+    for sub in ("sq_a", "sq_b", "sq_c"):
         for k, v in counters(os.path.join(src, sub)).items():
             v = v[3:] if len(v) > 3 else v
             sq[k] = sum(v) / max(len(v), 1)
+    if sq.get("SQ_THREAD_CYCLES_VALU") and sq.get("SQ_ACTIVE_INST_VALU"):
+        # rocprofiler's VALUUtilization: active lanes per vector instruction / 64 (lanes switched off by the exec mask do not
+        # count; lanes that compute a value nobody uses do)
+        sq["valu_lane_utilisation"] = sq["SQ_THREAD_CYCLES_VALU"] / (64.0 * sq["SQ_ACTIVE_INST_VALU"])
     tick = [r for r in stats if r["Name"].startswith("qpc_tick_kernel")]
     json.dump({"kernel": tick[0]["Name"] if tick else None, "qps_per_launch": 32768,
                "kernel_avg_ms_under_rocprof": float(tick[0]["AverageNs"]) / 1e6 if tick else None, "per_launch": sq},
