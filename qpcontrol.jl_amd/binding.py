@@ -16,6 +16,8 @@ from .models import Mechanism, ModelDesc
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "libqpcontrol_hip.so")
+# the same sources built with -DQPC_EXPERIMENTS: the only build that reads the A/B switches of csrc/qpc_env.h (tests, tools)
+EXPERIMENTS_LIB = os.path.join(_HERE, "libqpcontrol_hip_exp.so")
 
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_int32_p = ctypes.POINTER(ctypes.c_int32)

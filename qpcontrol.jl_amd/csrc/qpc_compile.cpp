@@ -83,7 +83,7 @@ int qpc_compile_program(qpc_controller *c) {
   // body's twist is its own joint twist: T x T = 0): vdot[fv0 + r] = desired_r.  For Atlas: three rows and three free columns fewer,
   // the leading Schur block 18 -> 15 fits ONE 16 x 16 matrix-core tile.  Only when the desired value is known before the kinematics
   // (caller input, a constant, or the orientation law of this very body on the world, which desired_early evaluates from q, v alone).
-  if (c->floating >= 0 && !getenv("QPC_NO_BASE_PIN")) {
+  if (c->floating >= 0 && !QPC_EXP_ENV("QPC_NO_BASE_PIN")) {
     for (size_t ti = 0; ti < c->tasks.size(); ti++) {
       const QpcTask &t = c->tasks[ti];
       const bool ang = t.kind == QPC_TASK_ANGULAR_ACCELERATION, lin = t.kind == QPC_TASK_LINEAR_ACCELERATION,
@@ -171,7 +171,7 @@ int qpc_compile_program(qpc_controller *c) {
     // opt-in (QPC_DFS_SCAN=1): +1.4 % throughput, but the difference of two prefix sums that both hold the wrenches of the heavy
     // bodies cancels ~1e-12 N m into the torque of a light distal link, which forward dynamics turns into 2e-9 rad/s^2 there
     // (tests/test_physical_consistency.py asserts 5e-10)
-    D.dfs = (nb <= 32 && getenv("QPC_DFS_SCAN")) ? 1 : 0; // (desc[a] is ascending: contiguous iff last - first + 1 == size)
+    D.dfs = (nb <= 32 && QPC_EXP_ENV("QPC_DFS_SCAN")) ? 1 : 0; // (desc[a] is ascending: contiguous iff last - first + 1 == size)
     for (int i = 0; i < nb; i++)
       if (desc[i].front() != i || desc[i].back() - i + 1 != (int)desc[i].size()) D.dfs = 0;
     std::vector<int> dptr(nb + 1, 0), didx;
@@ -399,7 +399,7 @@ int qpc_compile_program(qpc_controller *c) {
           case QPC_LAW_COM_PD: law_i[3 * i + 1] = a; law_d[3 * i + 2] = t.ref[a]; D.n_des_late++; break;
           case QPC_LAW_ORIENTATION_PD:
             law_i[3 * i + 1] = t.target; law_i[3 * i + 2] = a;
-            if (t.target == c->floating && c->floating >= 0 && m->parent[t.target] < 0 && !getenv("QPC_NO_BASE_PIN")) {
+            if (t.target == c->floating && c->floating >= 0 && m->parent[t.target] < 0 && !QPC_EXP_ENV("QPC_NO_BASE_PIN")) {
               law_i[3 * i] = QPC_LAW_ORIENTATION_PD_ROOT; // from the joint's own coordinates, before the kinematics
               D.law_mask |= 1 << QPC_LAW_ORIENTATION_PD_ROOT;
             } else D.n_des_late++;
@@ -533,7 +533,7 @@ int qpc_compile_program(qpc_controller *c) {
     D.k_tab = 0;
     if (B.dt.size() & 1) B.dt.push_back(0.0); // 16-byte rows
     B.dbegin(DT_KTAB);
-    bool ok = D.N == 4 && D.nrho > 0 && D.nrho <= 64 && D.nc <= 16 && !getenv("QPC_NO_KTAB");
+    bool ok = D.N == 4 && D.nrho > 0 && D.nrho <= 64 && D.nc <= 16 && !QPC_EXP_ENV("QPC_NO_KTAB");
     // one table per distinct friction coefficient; with several, the per-contact table index needs the upper 8 slots of MS_KS
     std::vector<double> mus;
     std::vector<int> cls;
@@ -589,7 +589,7 @@ int qpc_compile_program(qpc_controller *c) {
     }
     // closed-form K rows (Solver::k_row_closed) instead of the table: opt-in.  Measured on MI355X: 27.8 against 28.8 M solves/s --
     // the table's four reciprocals run side by side and its loads hide behind them, the closed form is one longer dependent chain
-    D.k_mu2 = (D.k_tab && D.k_classes == 1 && getenv("QPC_K_CLOSED")) ? mus[0] * mus[0] : -1.0;
+    D.k_mu2 = (D.k_tab && D.k_classes == 1 && QPC_EXP_ENV("QPC_K_CLOSED")) ? mus[0] * mus[0] : -1.0;
     B.dt.push_back(0.0);
   }
 
@@ -705,7 +705,7 @@ int qpc_compile_program(qpc_controller *c) {
     if (regular) {
       // the task rows that stay are all soft, their slack blocks are the first ones (slack s = row - 6 n_e), and no weight is a
       // per-QP matrix: fold them into the objective of the (few) unknowns that are left
-      bool fold = m1_s > 0 && m1_s <= 6 && ne == m1_s && !getenv("QPC_NO_PRESOLVE_FOLD");
+      bool fold = m1_s > 0 && m1_s <= 6 && ne == m1_s && !QPC_EXP_ENV("QPC_NO_PRESOLVE_FOLD");
       for (size_t g = 0; g < generic.size(); g++)
         if (row0[g] >= 6 * n_e) fold = fold && slack0[g] == row0[g] - 6 * n_e;
       std::vector<int> hot_s;
@@ -764,7 +764,7 @@ int qpc_compile_program(qpc_controller *c) {
   // changes per QP / p99): 12 sweeps 6.92 / 36, 6: 6.74, 5: 6.41, 4: 6.08 / 18, 3: 6.82 -- QPs that have
   // not converged after 4 sweeps rarely do, and Goldfarb-Idnani from their working set is cheaper
   D.max_pdas = 4;
-  if (const char *e = getenv("QPC_MAX_PDAS")) { const int v = atoi(e); if (v >= 0 && v <= 64) D.max_pdas = v; } // experiments
+  if (const char *e = QPC_EXP_ENV("QPC_MAX_PDAS")) { const int v = atoi(e); if (v >= 0 && v <= 64) D.max_pdas = v; } // experiments
   D.eps_primal = c->settings.eps_primal_reg;
   D.tau_pivot = c->settings.eps_dual_reg;
   D.tol_bound = c->settings.tol_bound;

@@ -2,6 +2,7 @@
 // no HIP): mirrors Mechanism + MomentumBasedController construction of the reference
 // (momentum.jl:15-33,99-160) and freezes it into a QpcDims + flat tables (qpc_program.h).
 #pragma once
+#include "qpc_env.h"
 #include <string>
 #include <vector>
 

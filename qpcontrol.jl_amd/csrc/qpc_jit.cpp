@@ -32,12 +32,12 @@ static std::string dbl(double x) {
 }
 
 bool qpc_jit_dynamic_lds() {
-  const char *e = getenv("QPC_EXP_DYN_LDS");
+  const char *e = QPC_EXP_ENV("QPC_EXP_DYN_LDS");
   return e && e[0] == '1';
 }
 
 int qpc_jit_sim_rpw(const QpcDims &D) {
-  if (const char *e = getenv("QPC_SIM_RPW")) { if (e[0] == '1') return 1; }
+  if (const char *e = QPC_EXP_ENV("QPC_SIM_RPW")) { if (e[0] == '1') return 1; }
   const int slab = qpc_sim_layout(D).total + (qpc_sim_layout(D).total & 1);
   return (D.nb <= 32 && D.nc <= 32 && (size_t)2 * slab * sizeof(double) <= 64 * 1024) ? 2 : 1;
 }
@@ -86,13 +86,13 @@ std::string qpc_jit_source(const QpcDims &D, const QpcDims &DS, bool warm) {
   o << "struct QpcBatchArgs { long long B; const double *q, *v, *desired, *cw, *cmax, *tw, *surf; double *tau, *vdot, "
        "*cwrench; int32_t *status, *iters; unsigned long long *prof; unsigned long long *ticket; unsigned long long *wsets; };\n";
   // the tick kernel (cold start) and, on request, its warm-started twin: same loop, qpc_tick<P, true>
-  const char *f32e = getenv("QPC_F32_LDS"); // experiment: fp32 LDS storage (qpc_device.h F32Ptr)
+  const char *f32e = QPC_EXP_ENV("QPC_F32_LDS"); // experiment: fp32 LDS storage (qpc_device.h F32Ptr)
   const bool f32 = f32e && f32e[0] == '1';
   // experiments (tools/ + DESIGN 8.1): QPC_EXP_DYN_LDS=1 declares the slab as DYNAMIC shared memory (the compiler then does not
   // derive an occupancy bound from it), QPC_EXP_WAVES=n is the second __launch_bounds__ argument (waves per SIMD to allocate for)
   const bool dyn_lds = qpc_jit_dynamic_lds();
   int waves = 2;
-  if (const char *e = getenv("QPC_EXP_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 8) waves = v; }
+  if (const char *e = QPC_EXP_ENV("QPC_EXP_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 8) waves = v; }
   if (dyn_lds) o << "extern __shared__ __attribute__((aligned(16))) double qpc_lds_dyn[];\n";
   o << "#ifdef QPC_KERNARG_RELOAD\n"
        "template <class T> __device__ __forceinline__ T qpc_karg(const __attribute__((address_space(4))) T *p) { asm volatile(\"\" : \"+s\"(p)); return *p; }\n"
@@ -183,9 +183,9 @@ int qpc_jit_compile(const QpcDims &D, const QpcDims &DS, const std::string &arch
   std::string src = qpc_jit_source(D, DS, warm);
   std::string key;
   {
-    const char *ce = getenv("QPC_JIT_CACHE"), *xe = getenv("QPC_JIT_EXTRA_FLAGS");
+    const char *ce = getenv("QPC_JIT_CACHE"), *xe = QPC_EXP_ENV("QPC_JIT_EXTRA_FLAGS");
     if (!(ce && ce[0] == '0')) {
-      const char *oe_ = getenv("QPC_JIT_OPT"), *se_ = getenv("QPC_JIT_SCHED");
+      const char *oe_ = QPC_EXP_ENV("QPC_JIT_OPT"), *se_ = QPC_EXP_ENV("QPC_JIT_SCHED");
       key = arch + "\n" + (xe ? xe : "") + "\n" + (oe_ ? oe_ : "") + "\n" + (se_ ? se_ : "") + "\n" + src;
       std::lock_guard<std::mutex> lk(g_jit_mu);
       auto it = g_jit_cache.find(key);
@@ -199,7 +199,7 @@ int qpc_jit_compile(const QpcDims &D, const QpcDims &DS, const std::string &arch
   }
   std::string archopt = "--offload-arch=" + arch;
   std::vector<std::string> extra; // QPC_JIT_EXTRA_FLAGS="-mllvm -foo ...": compiler experiments without a rebuild
-  if (const char *e = getenv("QPC_JIT_EXTRA_FLAGS")) {
+  if (const char *e = QPC_EXP_ENV("QPC_JIT_EXTRA_FLAGS")) {
     std::istringstream is(e);
     for (std::string tok; is >> tok;) extra.push_back(tok);
   }
@@ -208,7 +208,7 @@ int qpc_jit_compile(const QpcDims &D, const QpcDims &DS, const std::string &arch
   // The phases are long straight-line blocks of dependent LDS -> FMA chains: a scheduler that looks for ILP inside them
   // pays.  Both kernels of the module pass the whole GPU test-suite with it.  QPC_JIT_EXTRA_FLAGS is appended and wins.
   // (experiments: QPC_JIT_OPT replaces -O2, QPC_JIT_SCHED the scheduler strategy, "default" = none given)
-  const char *oe = getenv("QPC_JIT_OPT"), *se = getenv("QPC_JIT_SCHED");
+  const char *oe = QPC_EXP_ENV("QPC_JIT_OPT"), *se = QPC_EXP_ENV("QPC_JIT_SCHED");
   const std::string optlevel = oe && oe[0] ? oe : "-O2";
   const std::string sched = std::string("-amdgpu-sched-strategy=") + (se && se[0] ? se : "iterative-ilp");
   std::vector<const char *> opts = {archopt.c_str(), optlevel.c_str(), "-std=c++17"};

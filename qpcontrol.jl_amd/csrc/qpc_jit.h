@@ -3,6 +3,7 @@
 #include <string>
 #include <vector>
 
+#include "qpc_env.h"
 #include "qpc_program.h"
 
 // source of the specialised translation unit (QpcDims baked in as a constexpr object)

@@ -230,7 +230,7 @@ static int launch(qpc_controller *c, QpcDeviceState *S, QpcSlot &sl, const QpcBa
     const double *dt = S->d_dt;
     void *args[] = {(void *)&it, (void *)&dt, (void *)&aa};
     unsigned dyn = qpc_jit_dynamic_lds() ? (unsigned)(D.lds_doubles * sizeof(double)) : 0u; // experiment: QPC_EXP_DYN_LDS=1
-    if (dyn) if (const char *e = getenv("QPC_EXP_LDS_PAD")) dyn += (unsigned)atoi(e); // ... QPC_EXP_LDS_PAD=bytes: occupancy at will
+    if (dyn) if (const char *e = QPC_EXP_ENV("QPC_EXP_LDS_PAD")) dyn += (unsigned)atoi(e); // ... QPC_EXP_LDS_PAD=bytes: occupancy at will
     HIP_TRY(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 64, 1, 1, dyn, stream, args, nullptr));
   } else {
     hipLaunchKernelGGL(qpc_tick_kernel, dim3((unsigned)grid), dim3(64), lds, stream, D, c->prog.dims_s, S->d_it, S->d_dt, aa);
@@ -323,7 +323,7 @@ static int init_device_state(qpc_controller *c, QpcDeviceState *S, int device_id
   int per_cu = (int)((160 * 1024) / (lds > 0 ? lds : 1));
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 16) per_cu = 16; // 32 waves/CU cap; leave room for registers
-  if (const char *e = getenv("QPC_EXP_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 16) per_cu = v; } // experiment
+  if (const char *e = QPC_EXP_ENV("QPC_EXP_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 16) per_cu = v; } // experiment
   S->blocks_per_cu = per_cu;
   int sper = (int)((160 * 1024) / (slds > 0 ? slds : 1));
   S->sim_blocks_per_cu = sper < 1 ? 1 : (sper > 8 ? 8 : sper);
@@ -678,7 +678,7 @@ int32_t qpc_finalize_devices(qpc_controller *c, int32_t n_devices, const int32_t
   if (const char *ec = getenv("QPC_HOST_CHUNK")) { const long long v = atoll(ec); if (v >= 1) chunk = v; }
   rt->pipe = new QpcHostPipeline(rt->backend, rt->slots, chunk, inl);
   if (const char *ez = getenv("QPC_ZERO_COPY")) rt->zero_copy = ez[0] != '0';
-  if (const char *ez = getenv("QPC_STAGE_ZEROCOPY")) rt->stage_zero_copy = ez[0] != '0';
+  if (const char *ez = QPC_EXP_ENV("QPC_STAGE_ZEROCOPY")) rt->stage_zero_copy = ez[0] != '0';
   c->finalized = true;
   if (out) *out = c->layout;
   return QPC_OK;

@@ -136,6 +136,9 @@ static inline double emu_sum64(const double *x) { double s = 0.0; for (int l = 0
        for (int l__ = 0; l__ < 64; l__++) { double v__ = sm[D.lds_doubles + 128 * (slot) + l__]; \
          int i__ = (int)(double)sm[D.lds_doubles + 128 * (slot) + 64 + l__]; \
          if (v__ < name || (v__ == name && i__ < iname)) { name = v__; iname = i__; } } } while (0)
+// ancestor-chain bound of the tick: the library's limit (tree depth <= 32, checked by qpc_compile_program) -- the device gets the actual
+// depth from the JIT; QPC_GENERIC_MAXD = 16 is a workaround for a hipcc miscompile of the ahead-of-time kernel only
+#define QPC_MAXD 32
 #include "../../qpcontrol.jl_amd/csrc/qpc_tick.h"
 #include "../../qpcontrol.jl_amd/csrc/qpc_sim.h"
 #include "../../qpcontrol.jl_amd/csrc/qpc_qp_dense.h"

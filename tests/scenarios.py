@@ -210,6 +210,21 @@ def mixed_tasks(factory, B=6, seed=77, floating=True):
     return Case("mixed_tasks" if floating else "mixed_tasks_fixed", mech, c, q, v, des, cw, cmax, tw=tw, floating=fl)
 
 
+def deep_chain(factory, B=4, depth=22, seed=3):
+    """a serial chain deeper than the generic kernel's ancestor bound (QPC_GENERIC_MAXD = 16: with 32 hipcc -O3 miscompiles the
+    ancestor sums of the ahead-of-time kernel on gfx950; the hiprtc-specialised kernel has no such bound)"""
+    rng = np.random.default_rng(seed)
+    mech = M.rand_tree([M.REVOLUTE] * depth, seed=seed, chain=True)
+    c = factory(mech, 4, -1)
+    for j in range(mech.nbodies):
+        c.regularize(j, 0.1)
+    c.add_task(JOINT, joint=depth - 1, wkind=HARD)
+    c.add_task(POINT, base=M.WORLD, target=depth - 2, point=[0.1, 0.0, -0.2], wkind=SCALAR, weight=[2.0])
+    c.finalize()
+    q, v = _states(mech, B, rng, 0.3)
+    return Case("deep_chain", mech, c, q, v, rng.normal(size=(B, 4)), np.zeros((B, 0)), np.zeros((B, 0)))
+
+
 def atlas_config(factory, config, B):
     """BASELINE configs 2, 3, 5 (4 = config 3 with a larger batch)."""
     ctrl, wl = W.atlas_workload(factory, B, config)

@@ -78,4 +78,6 @@ def test_bench_cpu_worker_cli():
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-500:]
     r = json.loads(out.stdout.strip().splitlines()[-1])
-    assert r["done"] >= 16 and sum(r["iters"]) > 0 and r["seconds"] > 0 and r["warm_done"] > 0
+    for leg in ("nbw", "nbc", "tc", "tw"):  # notebook warm / cold, tight cold / warm
+        assert r[leg]["done"] > 0 and sum(r[leg]["iters"]) > 0 and r[leg]["seconds"] > 0, leg
+    assert r["tc"]["done"] >= 16

@@ -93,7 +93,7 @@ def test_base_tasks_of_all_three_kinds_emulated(kind, v0):
 @pytest.mark.gpu
 @pytest.mark.parametrize("fused", [False, True])
 def test_pelvis_task_is_a_pin_gpu(fused):
-    _atlas(lambda mech, N, fl: binding.Controller(binding.Model(mech), N, fl), 512, 3, fused)
+    _atlas(lambda mech, N, fl: binding.Controller(binding.Model(mech, binding.EXPERIMENTS_LIB), N, fl), 512, 3, fused)
 
 
 def test_floating_joint_on_a_moving_parent_is_not_pinned_emulated():

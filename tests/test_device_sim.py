@@ -118,7 +118,8 @@ def test_sim_two_robots_per_wave_emulated(monkeypatch):
 
 @pytest.mark.gpu
 def test_sim_two_robots_per_wave_gpu(monkeypatch):
-    _packed_vs_single(gpu_factory, 1025, monkeypatch)
+    # (QPC_SIM_RPW is an experiment switch: only the -DQPC_EXPERIMENTS build of the library reads it)
+    _packed_vs_single(lambda mech, N, fl: binding.Controller(binding.Model(mech, binding.EXPERIMENTS_LIB), N, fl), 1025, monkeypatch)
 
 
 @pytest.mark.parametrize("floating", [False, True])

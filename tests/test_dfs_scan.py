@@ -44,5 +44,5 @@ def test_prefix_scan_equals_subtree_loop_emulated(config):
 
 @pytest.mark.gpu
 def test_prefix_scan_equals_subtree_loop_gpu():
-    f = lambda mech, N, fl: binding.Controller(binding.Model(mech), N, fl)  # noqa: E731
+    f = lambda mech, N, fl: binding.Controller(binding.Model(mech, binding.EXPERIMENTS_LIB), N, fl)  # noqa: E731
     _same(_run(f, 2048, 3, True), _run(f, 2048, 3, False))

@@ -92,7 +92,7 @@ def test_two_friction_coefficients_emulated():
 
 @pytest.mark.gpu
 def test_two_friction_coefficients_gpu():
-    f = _mixed_mu(lambda mech, N, fl: binding.Controller(binding.Model(mech), N, fl))
+    f = _mixed_mu(lambda mech, N, fl: binding.Controller(binding.Model(mech, binding.EXPERIMENTS_LIB), N, fl))
     _same(_run(f, 2048, 5, False), _run(f, 2048, 5, True))
 
 
@@ -100,5 +100,5 @@ def test_two_friction_coefficients_gpu():
 @pytest.mark.parametrize("no_closed", [False, True])
 @pytest.mark.parametrize("config", [3, 5])
 def test_table_equals_gauss_jordan_gpu(config, no_closed):
-    f = lambda mech, N, fl: binding.Controller(binding.Model(mech), N, fl)  # noqa: E731
+    f = lambda mech, N, fl: binding.Controller(binding.Model(mech, binding.EXPERIMENTS_LIB), N, fl)  # noqa: E731
     _same(_run(f, 4096, config, False, no_closed), _run(f, 4096, config, True))

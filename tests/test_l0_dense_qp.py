@@ -54,7 +54,7 @@ def _check_reference_layout(backend_lib, device_id=0):
         assert np.all(r["status"] == 0), r["status"]
         nv = case.mech.nv
         for b in range(case.B):  # v̇ is unique (regularised); rho of the N = 4 basis is not
-            np.testing.assert_allclose(r["x"][b][:nv], xs[b][:nv], atol=1e-7)
+            np.testing.assert_allclose(r["x"][b][:nv], xs[b][:nv], atol=1e-8)
 
 
 def test_l0_emulated_random():

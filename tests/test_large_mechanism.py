@@ -67,6 +67,16 @@ def test_large_mechanism_emulated(big):
     print("rows", lay.n_eq_rows, "lds", lay.lds_bytes_per_qp)
 
 
+def test_deep_chain_emulated():
+    """22 bodies in a row: deeper than the ahead-of-time kernel's ancestor bound (16), inside the library's (32)"""
+    emu.build()
+    emu.race_report()
+    g, o = SC.deep_chain(emu.factory), SC.deep_chain(ora_factory)
+    parity.compare(g, g.ctrl.control_batch(g.q, g.v, g.desired, g.cweight, g.cmaxf), o, o.ctrl.tick_batch(o.q, o.v, o.desired, o.cweight, o.cmaxf))
+    races, uninit, outside, first = emu.race_report()
+    assert (races, uninit, outside) == (0, 0, 0), first
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("big", [False, True])
 def test_large_mechanism_gpu(big):
