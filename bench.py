@@ -182,7 +182,7 @@ def cpu_baseline(budget_s=12.0, max_workers=64):
 class DeviceRun:
     """A controller + one workload resident in HBM (torch tensors), launched through qpc_control_batch_device."""
 
-    def __init__(self, torch, binding, W, B, config, seed, device_index, fused_laws=False):
+    def __init__(self, torch, binding, W, B, config, seed, device_index, fused_laws=False, f32=False):
         self.torch, self.B = torch, B
         real_finalize = binding.Controller.finalize
 
@@ -190,8 +190,12 @@ class DeviceRun:
             return real_finalize(self_, device_index)
         binding.Controller.finalize = fin
         try:
-            self.ctrl, self.wl = W.atlas_workload(lambda m, N, fl: binding.Controller(binding.Model(m), N, fl), B, config, seed=seed,
-                                                  fused_laws=fused_laws)
+            def factory(m, N, fl):
+                c = binding.Controller(binding.Model(m), N, fl)
+                if f32:
+                    c.set_precision(1)  # the fp32 variant of the tick (qpc_set_precision): BASELINE config 5's stated precision
+                return c
+            self.ctrl, self.wl = W.atlas_workload(factory, B, config, seed=seed, fused_laws=fused_laws)
         finally:
             binding.Controller.finalize = real_finalize
         self.lay = lay = self.ctrl.layout
@@ -245,12 +249,25 @@ def secondary_points(torch, binding, W, device_index):
     """The literal BASELINE.json batches on this GPU (device-resident inputs, same kernel), outside the headline's timed
     region: config 2 @ 1024, config 3 @ 8192, config 5 @ 32768, config 3 @ 262144."""
     out = []
-    for config, B, steps in ((2, 1024, 50), (3, 8192, 30), (5, 32768, 20), (3, 262144, 5)):
-        run = DeviceRun(torch, binding, W, B, config, {2: 2024, 3: 2025, 5: 2027}[config], device_index)
+    tau5 = {}
+    for config, B, steps, f32 in ((2, 1024, 50, False), (3, 8192, 30, False), (5, 32768, 20, False), (3, 262144, 5, False),
+                                  (5, 32768, 20, True), (5, 8192, 30, True), (3, 32768, 20, True)):
+        run = DeviceRun(torch, binding, W, B, config, {2: 2024, 3: 2025, 5: 2027}[config], device_index, f32=f32)
         el, kms, nl = run.timed(steps, 3)
         st = run.status.cpu().numpy()
-        out.append({"config": config, "batch": B, "solves_per_s": B * steps / el, "ms_per_launch": 1e3 * el / steps, "kernel_ms": kms,
-                    "optimal_fraction": float((st == 0).mean()), "mean_active_set_iters": float((run.iters.cpu().numpy() % 1000).mean())})
+        pt = {"config": config, "batch": B, "dtype": "f32" if f32 else "f64", "solves_per_s": B * steps / el, "ms_per_launch": 1e3 * el / steps,
+              "kernel_ms": kms, "optimal_fraction": float((st <= 1).mean()),
+              "mean_active_set_iters": float((run.iters.cpu().numpy() % 1000).mean()), "lds_bytes_per_qp": int(run.lay.lds_bytes_per_qp)}
+        if config == 5 and B == 32768:  # BASELINE config 5 in both precisions on the same states: what fp32 costs in accuracy
+            tau5[f32] = (run.tau.cpu().numpy(), st)
+            if len(tau5) == 2:
+                (t64, s64), (t32, s32) = tau5[False], tau5[True]
+                both = (s64 <= 1) & (s32 <= 1)
+                err = (np.abs(t32 - t64) / np.maximum(1.0, np.abs(t64).max(axis=1, keepdims=True))).max(axis=1)
+                pt["vs_f64"] = {"rel_tau_err_median": float(np.median(err[both])), "rel_tau_err_p999": float(np.percentile(err[both], 99.9)),
+                                "rel_tau_err_max": float(err[both].max()), "optimal_in_f64_not_in_f32": float(((s64 <= 1) & ~(s32 <= 1)).mean()),
+                                "optimal_in_f32_not_in_f64": float((~(s64 <= 1) & (s32 <= 1)).mean())}
+        out.append(pt)
         del run
     return out
 
@@ -415,6 +432,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch-per-gpu", type=int, default=32768)
     ap.add_argument("--config", type=int, default=3, choices=[2, 3, 5])
+    ap.add_argument("--f32", action="store_true", help="the fp32 variant of the tick (qpc_set_precision): not the headline (tau 1e-4 instead of 1e-8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the literal-BASELINE-batch points and the host-pointer path")
     ap.add_argument("--fused-laws", action="store_true",
@@ -454,7 +472,7 @@ def main():
     B = args.batch_per_gpu
     # every rank builds its own contiguous shard [rank*B, (rank+1)*B) of the global batch
     run = DeviceRun(torch, binding, W, B, args.config, {2: 2024, 3: 2025, 5: 2027}[args.config] + 7919 * rank, local_rank,
-                    fused_laws=args.fused_laws)
+                    fused_laws=args.fused_laws, f32=args.f32)
     ctrl, lay, L = run.ctrl, run.lay, run.ctrl.L
     dev = run.dev
 
@@ -520,7 +538,7 @@ def main():
         ach_bytes = alg_bytes * B / kern_s if kern_s > 0 else 0.0
         fingerprint = L.qpc_kernel_fingerprint().decode() if hasattr(L, "qpc_kernel_fingerprint") else "unknown"
         traffic, traffic_source = (None, "measured for config 3 at 32768 QPs per launch only")
-        if args.config == 3 and not args.fused_laws:
+        if args.config == 3 and not args.fused_laws and not args.f32:
             traffic, traffic_source = measured_traffic(fingerprint)
             if traffic is not None and B != 32768:
                 traffic = traffic * B / 32768.0
@@ -528,7 +546,7 @@ def main():
             "metric": "QP solves/sec (Atlas ~30-DoF whole-body QP, batched)",
             "value": value, "unit": "QP solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.f32 else "f64", "data": "synthetic",
             "config": {"workload": f"atlas_config{args.config}: synthetic Atlas (nq 37, nv 36), StandingController task set, "
                                    + ("8 ContactPoints x 4-ray friction cones, floating base wrench balance "
                                       "(143 vars / 114 eq / 64 ineq in the reference layout)" if args.config != 2
@@ -558,7 +576,7 @@ def main():
                          "algorithmic_bytes_per_solve": alg_bytes,
                          "note": "path is bound by instruction issue (fp64 VALU + LDS + scalar), not by HBM (SURVEY.md 8d, DESIGN.md 7b); "
                                  "fp64 fraction and the instruction counts reported beside it",
-                         "issue": measured_issue(fingerprint) if args.config == 3 and not args.fused_laws else None,
+                         "issue": measured_issue(fingerprint) if args.config == 3 and not args.fused_laws and not args.f32 else None,
                          "fp64": {"achieved_tflops": ALG_FLOPS_PER_SOLVE * B / kern_s / 1e12 if kern_s > 0 else 0.0,
                                   "peak_tflops": FP64_PEAK / 1e12,
                                   "frac": (ALG_FLOPS_PER_SOLVE * B / kern_s) / FP64_PEAK if kern_s > 0 else 0.0,

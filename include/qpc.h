@@ -284,6 +284,17 @@ typedef struct qpc_settings {
   double tol_bound;             /* (1e-10) relative bound violation / multiplier sign tol  */
 } qpc_settings;
 int32_t qpc_default_settings(qpc_settings *s);
+/* Arithmetic of the tick kernel (before qpc_finalize).  QPC_PRECISION_F64 (default): everything in fp64, tau within 1e-8 of the
+ * CPU OSQP path (north star).  QPC_PRECISION_F32 -- BASELINE config 5's "fp32" variant, modelled on the mixed-contact-set test
+ * /root/reference/test/controller.jl:169-230: the SAME device source with `real` = float (LDS slab half the size, packed fp32
+ * arithmetic where the compiler finds pairs, v_mfma_f32_16x16x4_f32 for the Schur build), every tolerance of the solver moved
+ * to the fp32 rounding floor (regularisation 1e-5, pivots 1e-5, bounds / acceptance 1e-4 ...; the qpc_settings tolerances are
+ * ignored).  Inputs and outputs stay fp64 arrays (converted at the kernel's boundary), so the call is a drop-in; tau then agrees
+ * with the fp64 path to ~1e-4 of its scale, and a QP on the edge of feasibility may get another status.
+ * Needs the hiprtc-specialised kernel (QPC_ERR_UNSUPPORTED with QPC_DISABLE_JIT=1); the closed-loop entry points
+ * (qpc_sim_step_batch, qpc_rollout_batch) and warm starts stay fp64-only. */
+enum { QPC_PRECISION_F64 = 0, QPC_PRECISION_F32 = 1 };
+int32_t qpc_set_precision(qpc_controller *ctrl, int32_t precision);
 int32_t qpc_set_settings(qpc_controller *ctrl, const qpc_settings *s);
 
 /* L2 -- the graded path: the callable (controller)(tau, t, x), momentum.jl:41-81, with

@@ -194,6 +194,10 @@ class Controller:
     def regularize(self, joint, w):
         _check(self.L, self.L.qpc_regularize(self.h, int(joint), float(w)), "qpc_regularize")
 
+    def set_precision(self, precision):
+        """0 = fp64 (default), 1 = fp32 tick (BASELINE config 5's variant; qpc_set_precision)"""
+        _check(self.L, self.L.qpc_set_precision(self.h, int(precision)), "qpc_set_precision")
+
     def regularize_per_qp(self, joint):
         """regularize!(c, joint, weight::Parameter): -> index of the weight in the per-QP task-weight record"""
         off = ctypes.c_int32(-1)

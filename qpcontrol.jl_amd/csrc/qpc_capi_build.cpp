@@ -176,6 +176,13 @@ int32_t qpc_task_desired_range(const qpc_controller *c, int32_t task_id, int32_t
   return QPC_OK;
 }
 
+int32_t qpc_set_precision(qpc_controller *c, int32_t precision) {
+  if (!c || (precision != QPC_PRECISION_F64 && precision != QPC_PRECISION_F32)) return QPC_ERR_INVALID_ARGUMENT;
+  if (c->finalized) { qpc_set_error("qpc_set_precision must be called before qpc_finalize"); return QPC_ERR_ALREADY_FINALIZED; }
+  c->precision = precision;
+  return QPC_OK;
+}
+
 int32_t qpc_regularize(qpc_controller *c, int32_t joint, double w) {
   if (!c || joint < 0 || joint >= c->model->nb) return QPC_ERR_INVALID_ARGUMENT;
   if (c->finalized) { qpc_set_error("regularize! must be called before the first tick"); return QPC_ERR_ALREADY_FINALIZED; }

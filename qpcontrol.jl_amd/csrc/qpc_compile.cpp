@@ -769,6 +769,17 @@ int qpc_compile_program(qpc_controller *c) {
   D.tau_pivot = c->settings.eps_dual_reg;
   D.tol_bound = c->settings.tol_bound;
   D.tol_accept = 1e-7;
+  if (c->precision == QPC_PRECISION_F32) {
+    // fp32 tick (qpc_set_precision): every tolerance at the fp32 rounding floor (2^-24 = 6e-8).  The proximal eps has to stay
+    // well above it relative to the curvature it regularises (the K blocks carry 1 / eps on the null direction of B'B, and
+    // Y = K G' cancels it against G: eps / (2 w lambda) = 1e-3 costs three of the seven digits there), pivots below 1e-5 of
+    // their diagonal are noise, and a multiplier or bound violation below 1e-4 of its scale cannot be told from rounding.
+    D.eps_primal = 1e-6; D.tau_pivot = 1e-5; D.tol_bound = 1e-4; D.tol_accept = 2e-3;
+    if (const char *e = QPC_EXP_ENV("QPC_F32_EPS")) D.eps_primal = atof(e); // (experiments: the tolerance set was found with these)
+    if (const char *e = QPC_EXP_ENV("QPC_F32_TAU")) D.tau_pivot = atof(e);
+    if (const char *e = QPC_EXP_ENV("QPC_F32_TOLB")) D.tol_bound = atof(e);
+    if (const char *e = QPC_EXP_ENV("QPC_F32_TOLA")) D.tol_accept = atof(e);
+  }
   DS = D;
   if (D.presolve) {
     auto lead2 = [](int n) { int s_ = (n > 0 ? n : 1); s_ += s_ & 1; if (s_ % 8 == 0) s_ += 2; return s_; };
@@ -793,7 +804,7 @@ int qpc_compile_program(qpc_controller *c) {
   nvar += D.nc * (N + 9); neq += D.nc * 9 + D.nw;
   Lo.ref_n_var = nvar; Lo.ref_n_eq = neq; Lo.ref_n_ineq = D.nc * 2 * N;
   Lo.n_free = D.nf; Lo.n_pinned = D.npin; Lo.n_slack = ne; Lo.n_rho = nrho; Lo.n_eq_rows = mm;
-  Lo.lds_bytes_per_qp = D.lds_doubles * 8;
+  Lo.lds_bytes_per_qp = D.lds_doubles * (c->precision == QPC_PRECISION_F32 ? 4 : 8);
   Lo.n_desired_inputs = D.n_des_inputs;
   if (nb > 64 || nv > 64 || D.ntask > 63 || D.maxdepth > 32) {
     qpc_set_error("limits of the one-wave-per-QP kernels exceeded (bodies <= 64, velocities <= 64, tree depth <= 32)");

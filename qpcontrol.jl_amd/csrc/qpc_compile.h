@@ -53,6 +53,7 @@ struct qpc_controller {
   QpcProgram prog;
   qpc_layout layout;
   QpcRuntime *rt = nullptr;
+  int precision = 0;                        // qpc_set_precision: QPC_PRECISION_F64 / _F32 (arithmetic of the tick kernel)
   int warm_start = 0;                       // qpc_enable_warm_start: also build the warm-started kernel variant
   int pipe_slots = 0;                       // qpc_set_host_pipeline (0 / -1: defaults)
   long long pipe_chunk = 0, pipe_inline = -1;

@@ -2,6 +2,7 @@
 // emulation in tests/emul/emul.cpp provides lane-serial counterparts).  gfx950, wave64.
 #pragma once
 
+#include "qpc_real.h" // `real`: double, or a float class in the fp32 module (QPC_F32, its own hiprtc translation unit)
 #define QPC_FN __device__ __forceinline__
 #define QPC_LAMBDA_INLINE __attribute__((always_inline))
 // The lane index is made OPAQUE once per QP (per function scope that runs phases: QPC_LANE_SCOPE).  Without it the compiler
@@ -48,11 +49,18 @@ __device__ __forceinline__ int qpc_opaque_lane() {
 #define QPC_END_PHASE_REG }
 // hard boundary without a block (after a group of soft-joined blocks, before code that reads other lanes' LDS words)
 #define QPC_PHASE_SYNC __syncthreads();
+#include "qpc_math.h" // qpc_sincos, qpc_atan2: straight-line elementary functions (no scratch, few registers)
+#ifdef QPC_F32
+#define QPC_SINCOS(x, s, c) qpc_sincosf((float)(real)(x), (s).v, (c).v)
+#define QPC_SQRT(x) real(__builtin_sqrtf((float)(real)(x)))
+#define QPC_FABS(x) real(__builtin_fabsf((float)(real)(x)))
+#define QPC_ATAN2(y, x) real(atan2f((float)(real)(y), (float)(real)(x)))
+#else
 #define QPC_SINCOS(x, s, c) qpc_sincos((double)(x), (s), (c))
 #define QPC_SQRT(x) sqrt((double)(x))
 #define QPC_FABS(x) fabs((double)(x))
 #define QPC_ATAN2(y, x) qpc_atan2((double)(y), (double)(x))
-#include "qpc_math.h" // qpc_sincos, qpc_atan2: straight-line fp64 elementary functions (no scratch, few registers)
+#endif
 // Pivot reciprocals on the serial chains of the small factorizations: hardware seed (v_rcp_f64 /
 // v_rsq_f64, ~24 bits) + two Newton steps (~1 ulp) instead of the IEEE sqrt + divide sequences
 // (about a third of the dependent instructions per pivot).
@@ -75,6 +83,20 @@ __device__ __forceinline__ double qpc_rcp1(double x) {
   y = fma(y, fma(-x, y, 1.0), y);
   return y;
 }
+// fp32: v_rcp_f32 / v_rsq_f32 are good to 1 ulp; one Newton step where the fp64 path takes two
+__device__ __forceinline__ float qpc_rcpf(float x) {
+  float y = __builtin_amdgcn_rcpf(x);
+  return fmaf(y, fmaf(-x, y, 1.0f), y);
+}
+__device__ __forceinline__ float qpc_rsqrtf(float x) {
+  float y = __builtin_amdgcn_rsqf(x);
+  return fmaf(y, 0.5f * fmaf(-x * y, y, 1.0f), y);
+}
+#ifdef QPC_F32
+#define QPC_RCP_SEARCH(x) real(__builtin_amdgcn_rcpf((float)(real)(x)))
+#define QPC_RCP(x) real(qpc_rcpf((float)(real)(x)))
+#define QPC_RSQRT(x) real(qpc_rsqrtf((float)(real)(x)))
+#else
 #ifdef QPC_RCP_SEARCH_FULL // (measured: 28.80 M solves/s with two steps, 29.01 M with one; same working-set changes)
 #define QPC_RCP_SEARCH(x) qpc_rcp((double)(x))
 #else
@@ -82,9 +104,10 @@ __device__ __forceinline__ double qpc_rcp1(double x) {
 #endif
 #define QPC_RCP(x) qpc_rcp((double)(x))
 #define QPC_RSQRT(x) qpc_rsqrt((double)(x))
+#endif
 #define QPC_UNROLL_FULL _Pragma("unroll")
 // lane-private storage that persists across phases (registers on the device)
-#define QPC_LANE_ARRAY(name, n) double name[n]
+#define QPC_LANE_ARRAY(name, n) real name[n]
 #define QPC_LA(name, lane) name
 #define QPC_LANE_INTS(name, n) int name[n]
 #define QPC_LI(name, lane) name
@@ -146,6 +169,28 @@ __device__ __forceinline__ double wave_min(double x) {
 #undef QPC_DPP_OP
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 63), __builtin_amdgcn_readlane(__double2loint(x), 63));
 }
+// fp32: one DPP move and one v_max / v_min per step (a float is one register)
+__device__ __forceinline__ float wave_max(float x) {
+#define QPC_DPP_OP(ctrl, rmask)                                                                    \
+  {                                                                                                \
+    const int b__ = __float_as_int(x);                                                             \
+    x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(b__, b__, ctrl, rmask, 0xf, false)));  \
+  }
+  QPC_DPP_STEPS(QPC_DPP_OP)
+#undef QPC_DPP_OP
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+__device__ __forceinline__ float wave_max_scale(float x) { return wave_max(__builtin_fabsf(x)); }
+__device__ __forceinline__ float wave_min(float x) {
+#define QPC_DPP_OP(ctrl, rmask)                                                                    \
+  {                                                                                                \
+    const int b__ = __float_as_int(x);                                                             \
+    x = fminf(x, __int_as_float(__builtin_amdgcn_update_dpp(b__, b__, ctrl, rmask, 0xf, false)));  \
+  }
+  QPC_DPP_STEPS(QPC_DPP_OP)
+#undef QPC_DPP_OP
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
 __device__ __forceinline__ int wave_min_int(int x) {
 #define QPC_DPP_OP(ctrl, rmask)                                                                    \
   {                                                                                                \
@@ -159,35 +204,23 @@ __device__ __forceinline__ int wave_min_int(int x) {
 #undef QPC_DPP_STEPS
 } // namespace qpc
 
-// Experiment switch QPC_F32_LDS=1 (BASELINE config 5's "fp32 storage" question): the whole per-QP LDS slab
-// kept in fp32 -- half the bytes, every load converted to fp64 for the arithmetic, every store rounded.  The tick is
-// written against an abstract LDS pointer type P (the emulator's race-checking proxy is one), so this is just another P.
-namespace qpc {
-struct F32Ref {
-  float *p;
-  __device__ __forceinline__ operator double() const { return (double)*p; }
-  __device__ __forceinline__ F32Ref &operator=(double v) { *p = (float)v; return *this; }
-  __device__ __forceinline__ F32Ref &operator=(const F32Ref &o) { *p = *o.p; return *this; }
-};
-struct F32Ptr {
-  float *base;
-  __device__ __forceinline__ F32Ref operator[](int i) const { return F32Ref{base + i}; }
-  __device__ __forceinline__ F32Ptr operator+(int o) const { return F32Ptr{base + o}; }
-};
-} // namespace qpc
-
 // reductions that straddle a phase boundary: *_PUT inside the phase (every lane, exactly once),
 // *_GET after QPC_END_PHASE.  `name` is a double (and `iname` an int) declared before the phase.
-#define QPC_RED_MAX_PUT(slot, name, val) name = qpc::wave_max_scale(val)
+#ifdef QPC_F32
+#define QPC_RAW(x) ((float)(real)(x))
+#else
+#define QPC_RAW(x) (x)
+#endif
+#define QPC_RED_MAX_PUT(slot, name, val) name = real(qpc::wave_max_scale(QPC_RAW(val)))
 #define QPC_RED_MAX_GET(slot, name) (name)
 
 #define QPC_RED_ARGMIN_PUT(slot, name, iname, val, idx) \
-  do { double v__ = (val); name = qpc::wave_min(v__); iname = qpc::wave_min_int(v__ == name ? (int)(idx) : 0x3fffffff); } while (0)
+  do { real v__ = (val); name = real(qpc::wave_min(QPC_RAW(v__))); iname = qpc::wave_min_int(v__ == name ? (int)(idx) : 0x3fffffff); } while (0)
 #define QPC_RED_ARGMIN_GET(slot, name, iname) ((void)0)
 // ... when idx is the lane of every real candidate (other lanes pass a value that can only win if nobody has a candidate, in which
 // case the caller discards the index): minimum, then the first lane that holds it -- no second reduction for the index
 #define QPC_RED_ARGMIN_LANE_PUT(slot, name, iname, val, idx) \
-  do { double v__ = (val); name = qpc::wave_min(v__); const unsigned long long b__ = __ballot(v__ == name ? 1 : 0); \
+  do { real v__ = (val); name = real(qpc::wave_min(QPC_RAW(v__))); const unsigned long long b__ = __ballot(v__ == name ? 1 : 0); \
        iname = b__ ? (int)__builtin_ctzll(b__) : 0x3fffffff; } while (0)
 // 64-bit lane mask of a predicate (one scalar compare); same PUT / GET protocol
 #define QPC_BALLOT_PUT(slot, name, pred) name = __ballot((pred) ? 1 : 0)
@@ -206,14 +239,25 @@ __device__ __forceinline__ double qpc_quad_bcast(double x, int i) {
   }
   return __hiloint2double(h, l);
 }
+__device__ __forceinline__ float qpc_quad_bcast(float x, int i) {
+  const int b = __float_as_int(x);
+  int l;
+  switch (i) {
+    case 0: l = __builtin_amdgcn_update_dpp(b, b, 0x00, 0xf, 0xf, false); break;
+    case 1: l = __builtin_amdgcn_update_dpp(b, b, 0x55, 0xf, 0xf, false); break;
+    case 2: l = __builtin_amdgcn_update_dpp(b, b, 0xaa, 0xf, 0xf, false); break;
+    default: l = __builtin_amdgcn_update_dpp(b, b, 0xff, 0xf, 0xf, false); break;
+  }
+  return __int_as_float(l);
+}
 #define QPC_QUAD_GATHER(lane, OUT4, XEXPR)                                                        \
   {                                                                                              \
     const int lane = QPC_MACRO_LANE;                                                             \
     (void)lane;                                                                                  \
-    double *out__ = (OUT4);                                                                      \
-    const double x__ = (XEXPR);                                                                  \
-    out__[0] = qpc_quad_bcast(x__, 0); out__[1] = qpc_quad_bcast(x__, 1);                        \
-    out__[2] = qpc_quad_bcast(x__, 2); out__[3] = qpc_quad_bcast(x__, 3);                        \
+    real *out__ = (OUT4);                                                                        \
+    const real x__ = (XEXPR);                                                                    \
+    out__[0] = real(qpc_quad_bcast(QPC_RAW(x__), 0)); out__[1] = real(qpc_quad_bcast(QPC_RAW(x__), 1)); \
+    out__[2] = real(qpc_quad_bcast(QPC_RAW(x__), 2)); out__[3] = real(qpc_quad_bcast(QPC_RAW(x__), 3)); \
   }
 
 // OUT[i] = X[i] of lane 16 * (lane / 16) + K, i = 0 .. N - 1: DPP row_share broadcasts inside the rows of 16 lanes (no LDS).
@@ -230,11 +274,23 @@ __device__ __forceinline__ double qpc_row_share(double x, int k) {
 #undef QPC_RS_CASE
   return __hiloint2double(h, l);
 }
+__device__ __forceinline__ float qpc_row_share(float x, int k) {
+  const int b = __float_as_int(x);
+  int l;
+#define QPC_RS_CASE(K) case K: l = __builtin_amdgcn_update_dpp(b, b, 0x150 + K, 0xf, 0xf, false); break;
+  switch (k & 15) {
+    QPC_RS_CASE(0) QPC_RS_CASE(1) QPC_RS_CASE(2) QPC_RS_CASE(3) QPC_RS_CASE(4) QPC_RS_CASE(5) QPC_RS_CASE(6) QPC_RS_CASE(7)
+    QPC_RS_CASE(8) QPC_RS_CASE(9) QPC_RS_CASE(10) QPC_RS_CASE(11) QPC_RS_CASE(12) QPC_RS_CASE(13) QPC_RS_CASE(14)
+    default: l = __builtin_amdgcn_update_dpp(b, b, 0x15f, 0xf, 0xf, false); break;
+  }
+#undef QPC_RS_CASE
+  return __int_as_float(l);
+}
 #define QPC_ROW_SHARE(lane, OUT, N, X, K)                                                         \
   {                                                                                              \
-    double *out__ = (OUT);                                                                       \
-    const double *x__ = (X);                                                                     \
-    for (int i__ = 0; i__ < (N); i__++) out__[i__] = qpc_row_share(x__[i__], (K));               \
+    real *out__ = (OUT);                                                                         \
+    const real *x__ = (X);                                                                       \
+    for (int i__ = 0; i__ < (N); i__++) out__[i__] = real(qpc_row_share(QPC_RAW(x__[i__]), (K))); \
   }
 
 // inclusive prefix sum over the lanes of the wave (lane l: x_0 + ... + x_l): Hillis-Steele inside the DPP rows of 16 (row_shr with
@@ -252,32 +308,52 @@ __device__ __forceinline__ double qpc_wave_prefix_sum(double x) {
 #undef QPC_PS_STEP
   return x;
 }
+__device__ __forceinline__ float qpc_wave_prefix_sum(float x) {
+#define QPC_PS_STEP(ctrl, rmask) { x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, rmask, 0xf, false)); }
+  QPC_PS_STEP(0x111, 0xf) QPC_PS_STEP(0x112, 0xf) QPC_PS_STEP(0x114, 0xf) QPC_PS_STEP(0x118, 0xf)
+  QPC_PS_STEP(0x142, 0xa) QPC_PS_STEP(0x143, 0xc)
+#undef QPC_PS_STEP
+  return x;
+}
+__device__ __forceinline__ float qpc_wave_sum(float x) {
+  x = qpc_wave_prefix_sum(x);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
 // sum over the 64 lanes (the last lane's prefix sum), same PUT / GET protocol as the max reductions
 __device__ __forceinline__ double qpc_wave_sum(double x) {
   x = qpc_wave_prefix_sum(x);
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 63), __builtin_amdgcn_readlane(__double2loint(x), 63));
 }
-#define QPC_RED_SUM_PUT(slot, name, val) name = qpc_wave_sum(val)
+#define QPC_RED_SUM_PUT(slot, name, val) name = real(qpc_wave_sum(QPC_RAW(val)))
 #define QPC_RED_SUM_GET(slot, name) (name)
 // phase level (all 64 lanes): ARR[i] of every lane becomes the sum of ARR[i] over the lanes up to and including it
 #define QPC_WAVE_INCL_SCAN(lane, ARR, N)                                                          \
   {                                                                                              \
-    double *a__ = (ARR);                                                                         \
-    for (int i__ = 0; i__ < (N); i__++) a__[i__] = qpc_wave_prefix_sum(a__[i__]);                \
+    real *a__ = (ARR);                                                                           \
+    for (int i__ = 0; i__ < (N); i__++) a__[i__] = real(qpc_wave_prefix_sum(QPC_RAW(a__[i__]))); \
   }
 
-// fp64 matrix core: acc(16x16 tile, 4 f64 per lane) += A(16x4) * B(4x16) with v_mfma_f64_16x16x4_f64.
+// matrix core: acc(16x16 tile, 4 values per lane) += A(16x4) * B(4x16) with v_mfma_f64_16x16x4_f64 (fp32 tick: v_mfma_f32_16x16x4_f32).
 //   lane l supplies A[i = l&15][k = l>>4] (AEXPR) and B[k = l>>4][j = l&15] (BEXPR);
-//   acc[r] is C[row = (l>>4) + 4 r][col = l&15]  (the f64-specific C/D map, cdna_hip_programming.md 3)
+//   acc[r] is C[row = QPC_MFMA_CROW(l, r)][col = l&15]: (l>>4) + 4 r for the f64 instruction (its own C/D map), 4 (l>>4) + r for the
+//   f32 one (the standard 16x16 map; cdna_hip_programming.md 3)
 // Must be executed by all 64 lanes (EXEC all ones): only use it at phase level, never under a
 // lane-dependent branch.
-typedef double qpc_v4d __attribute__((ext_vector_type(4)));
-#define QPC_MFMA_F64_16x16x4(lane, ACC, AEXPR, BEXPR)                                           \
+#ifdef QPC_F32
+typedef float qpc_v4r __attribute__((ext_vector_type(4)));
+#define QPC_MFMA_BUILTIN __builtin_amdgcn_mfma_f32_16x16x4f32
+#define QPC_MFMA_CROW(lane, reg) (4 * ((lane) >> 4) + (reg))
+#else
+typedef double qpc_v4r __attribute__((ext_vector_type(4)));
+#define QPC_MFMA_BUILTIN __builtin_amdgcn_mfma_f64_16x16x4f64
+#define QPC_MFMA_CROW(lane, reg) (((lane) >> 4) + 4 * (reg))
+#endif
+#define QPC_MFMA_16x16x4(lane, ACC, AEXPR, BEXPR)                                               \
   {                                                                                              \
     const int lane = QPC_MACRO_LANE;                                                             \
-    double *acc__ = (ACC);                                                                       \
-    const double a__ = (AEXPR), b__ = (BEXPR);                                                   \
-    qpc_v4d c__ = {acc__[0], acc__[1], acc__[2], acc__[3]};                                      \
-    c__ = __builtin_amdgcn_mfma_f64_16x16x4f64(a__, b__, c__, 0, 0, 0);                          \
-    acc__[0] = c__[0]; acc__[1] = c__[1]; acc__[2] = c__[2]; acc__[3] = c__[3];                  \
+    real *acc__ = (ACC);                                                                         \
+    const real a__ = (AEXPR), b__ = (BEXPR);                                                     \
+    qpc_v4r c__ = {QPC_RAW(acc__[0]), QPC_RAW(acc__[1]), QPC_RAW(acc__[2]), QPC_RAW(acc__[3])};  \
+    c__ = QPC_MFMA_BUILTIN(QPC_RAW(a__), QPC_RAW(b__), c__, 0, 0, 0);                            \
+    acc__[0] = real(c__[0]); acc__[1] = real(c__[1]); acc__[2] = real(c__[2]); acc__[3] = real(c__[3]); \
   }

@@ -58,9 +58,10 @@ static void put_dims(std::ostringstream &o, const char *name, const QpcDims &D) 
     << dbl(D.tol_accept) << "," << dbl(D.h_static_max) << "," << dbl(D.h_static_min) << "," << dbl(D.k_mu2) << "};\n";
 }
 
-std::string qpc_jit_source(const QpcDims &D, const QpcDims &DS, bool warm) {
+std::string qpc_jit_source(const QpcDims &D, const QpcDims &DS, bool warm, bool f32) {
   std::ostringstream o;
   o << "typedef int int32_t;\ntypedef unsigned int uint32_t;\ntypedef long long int64_t;\ntypedef unsigned long long uint64_t;\n";
+  if (f32) o << "#define QPC_F32 1\n";
   o << "#define QPC_JIT 1\n#define QPC_M1_MAX " << (D.m1 > 0 ? D.m1 : 1) << "\n#define QPC_MAXD " << D.maxd << "\n#define QPC_NTILE_MAX " << (((D.m + 15) / 16) * (((D.m + 15) / 16) + 1) / 2 > 0 ? ((D.m + 15) / 16) * (((D.m + 15) / 16) + 1) / 2 : 1) << "\n#define QPC_XTILE_MAX " << (((D.m1 + 15) / 16) * (((D.m1 + 15) / 16) + 1) / 2 + (D.m1 + 15) / 16 > 0 ? ((D.m1 + 15) / 16) * (((D.m1 + 15) / 16) + 1) / 2 + (D.m1 + 15) / 16 : 1)
     << "\n#include \"qpc_device.h\"\n";
   const char *st = getenv("QPC_JIT_STAMPS"); // diagnostic: in-kernel section timers
@@ -77,8 +78,8 @@ std::string qpc_jit_source(const QpcDims &D, const QpcDims &DS, bool warm) {
     }
     o << "}\n";
   }
-  o << "#include \"qpc_tick.h\"\n"
-       "#include \"qpc_sim.h\"\n";
+  o << "#include \"qpc_tick.h\"\n";
+  if (!f32) o << "#include \"qpc_sim.h\"\n"; // (the simulation step is fp64 code)
   // field order == struct QpcDims (qpc_program.h)
   o << "static_assert(sizeof(QpcDims) == " << sizeof(QpcDims) << ", \"QpcDims layout differs between host and JIT source\");\n";
   put_dims(o, "kD", D);
@@ -86,12 +87,12 @@ std::string qpc_jit_source(const QpcDims &D, const QpcDims &DS, bool warm) {
   o << "struct QpcBatchArgs { long long B; const double *q, *v, *desired, *cw, *cmax, *tw, *surf; double *tau, *vdot, "
        "*cwrench; int32_t *status, *iters; unsigned long long *prof; unsigned long long *ticket; unsigned long long *wsets; };\n";
   // the tick kernel (cold start) and, on request, its warm-started twin: same loop, qpc_tick<P, true>
-  const char *f32e = QPC_EXP_ENV("QPC_F32_LDS"); // experiment: fp32 LDS storage (qpc_device.h F32Ptr)
-  const bool f32 = f32e && f32e[0] == '1';
   // experiments (tools/ + DESIGN 8.1): QPC_EXP_DYN_LDS=1 declares the slab as DYNAMIC shared memory (the compiler then does not
   // derive an occupancy bound from it), QPC_EXP_WAVES=n is the second __launch_bounds__ argument (waves per SIMD to allocate for)
   const bool dyn_lds = qpc_jit_dynamic_lds();
-  int waves = 2;
+  // waves per SIMD the register allocation aims at: the fp64 tick needs its 256 registers (two waves); the fp32 tick's slab is half
+  // the size (16 per CU) and its values one register each, so four waves per SIMD (128 registers) are in reach
+  int waves = f32 ? 4 : 2;
   if (const char *e = QPC_EXP_ENV("QPC_EXP_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 8) waves = v; }
   if (dyn_lds) o << "extern __shared__ __attribute__((aligned(16))) double qpc_lds_dyn[];\n";
   o << "#ifdef QPC_KERNARG_RELOAD\n"
@@ -105,9 +106,10 @@ std::string qpc_jit_source(const QpcDims &D, const QpcDims &DS, bool warm) {
       << "(const int *__restrict__ IT, const double *__restrict__ DT, const QpcBatchArgs A) {\n";
     if (dyn_lds && !f32) o << "  double *const qpc_lds_raw = qpc_lds_dyn;\n";
     else o << "  __shared__ __attribute__((aligned(16))) " << (f32 ? "float" : "double") << " qpc_lds_raw[" << (D.lds_doubles > 0 ? D.lds_doubles : 1) << "];\n";
+    // (fp32: `real` is a class holding one float -- qpc_real.h -- so the slab of floats is addressed as an array of reals)
     o <<
-         "  " << (f32 ? "const qpc::F32Ptr qpc_lds{qpc_lds_raw};" : "double *const qpc_lds = qpc_lds_raw;") << "\n"
-         "  typedef " << (f32 ? "qpc::F32Ptr" : "double *") << " LdsP;\n"
+         "  real *const qpc_lds = (real *)qpc_lds_raw;\n"
+         "  typedef real *LdsP;\n"
          "  qpc::qpc_tick_prologue<LdsP>(kD, kDS, IT, qpc_lds);\n"
          "  while (true) {\n"
          "#ifdef QPC_KERNARG_RELOAD\n"
@@ -141,12 +143,13 @@ std::string qpc_jit_source(const QpcDims &D, const QpcDims &DS, bool warm) {
          "    const __attribute__((address_space(1))) double *DTg = (const __attribute__((address_space(1))) double *)DT;\n"
          "    asm volatile(\"\" : \"+s\"(ITg), \"+s\"(DTg));\n"
          "    const int *ITq = (const int *)ITg; const double *DTq = (const double *)DTg;\n"
-         "    qpc::qpc_tick<LdsP, " << (variant ? "true" : "false") << ">(kD, kDS, ITq, DTq, qpc_lds, io);\n"
+         "    qpc::qpc_tick<LdsP, " << (variant ? "true" : "false") << ">(kD, kDS, ITq, qpc_dtab{DTq}, qpc_lds, io);\n"
          "    __syncthreads();\n"
 
          "  }\n"
          "}\n";
   }
+  if (f32) return o.str();
   // f-2: the simulation step specialised on the same dims (qpc_sim.h)
   const int rpw = qpc_jit_sim_rpw(D);
   const int slab = qpc_sim_layout(D).total + (qpc_sim_layout(D).total & 1);
@@ -179,8 +182,8 @@ std::string qpc_jit_source(const QpcDims &D, const QpcDims &DS, bool warm) {
 static std::mutex g_jit_mu;
 static std::map<std::string, std::vector<char>> g_jit_cache;
 
-int qpc_jit_compile(const QpcDims &D, const QpcDims &DS, const std::string &arch, bool warm, std::vector<char> &code, std::string &log) {
-  std::string src = qpc_jit_source(D, DS, warm);
+int qpc_jit_compile(const QpcDims &D, const QpcDims &DS, const std::string &arch, bool warm, bool f32, std::vector<char> &code, std::string &log) {
+  std::string src = qpc_jit_source(D, DS, warm, f32);
   std::string key;
   {
     const char *ce = getenv("QPC_JIT_CACHE"), *xe = QPC_EXP_ENV("QPC_JIT_EXTRA_FLAGS");
@@ -262,7 +265,7 @@ extern "C" int32_t qpc_debug_jit_compile(qpc_controller *c, const char *arch, co
   if (!c->finalized) { int rc = qpc_compile_program(c); if (rc != QPC_OK) return rc; }
   std::vector<char> code;
   std::string log;
-  int rc = qpc_jit_compile(c->prog.dims, c->prog.dims_s, arch ? arch : "gfx950", c->warm_start != 0, code, log);
+  int rc = qpc_jit_compile(c->prog.dims, c->prog.dims_s, arch ? arch : "gfx950", c->warm_start != 0, c->precision == QPC_PRECISION_F32, code, log);
   if (logbuf && logn > 0) snprintf(logbuf, logn, "%s", log.c_str());
   if (rc != 0) { qpc_set_error("JIT compile failed: " + log); return QPC_ERR_HIP; }
   if (out_path) { FILE *f = fopen(out_path, "wb"); if (f) { fwrite(code.data(), 1, code.size(), f); fclose(f); } }
@@ -273,7 +276,7 @@ extern "C" int32_t qpc_debug_jit_compile(qpc_controller *c, const char *arch, co
 extern "C" int32_t qpc_debug_jit_source(qpc_controller *c, const char *out_path) {
   if (!c || !out_path) return QPC_ERR_INVALID_ARGUMENT;
   if (!c->finalized) { int rc = qpc_compile_program(c); if (rc != QPC_OK) return rc; }
-  std::string src = qpc_jit_source(c->prog.dims, c->prog.dims_s, c->warm_start != 0);
+  std::string src = qpc_jit_source(c->prog.dims, c->prog.dims_s, c->warm_start != 0, c->precision == QPC_PRECISION_F32);
   FILE *f = fopen(out_path, "wb");
   if (!f) return QPC_ERR_INVALID_ARGUMENT;
   fwrite(src.data(), 1, src.size(), f);

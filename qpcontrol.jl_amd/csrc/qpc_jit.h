@@ -8,9 +8,11 @@
 
 // source of the specialised translation unit (QpcDims baked in as a constexpr object)
 // warm: also emit qpc_tick_kernel_jit_warm (the warm-started variant, qpc_enable_warm_start)
-std::string qpc_jit_source(const QpcDims &D, const QpcDims &DS, bool warm);
+// f32: the fp32 variant of the tick (qpc_set_precision): `real` = float, single-precision literals, LDS slab of floats, no simulation
+// step in the module
+std::string qpc_jit_source(const QpcDims &D, const QpcDims &DS, bool warm, bool f32 = false);
 // compile for `arch` (e.g. "gfx950"); returns 0 and fills `code` on success, else fills `log`
-int qpc_jit_compile(const QpcDims &D, const QpcDims &DS, const std::string &arch, bool warm, std::vector<char> &code, std::string &log);
+int qpc_jit_compile(const QpcDims &D, const QpcDims &DS, const std::string &arch, bool warm, bool f32, std::vector<char> &code, std::string &log);
 // robots per wavefront of the JIT-specialised simulation step (qpc_sim.h): 2 when a robot fits half a wave and two
 // LDS slabs fit a workgroup (QPC_SIM_RPW=1 forces one)
 int qpc_jit_sim_rpw(const QpcDims &D);

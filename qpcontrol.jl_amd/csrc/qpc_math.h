@@ -66,3 +66,24 @@ QPC_MATH_FN double qpc_atan2(double y, double x) {
   a = x < 0.0 ? 3.14159265358979311600e+00 - a + 1.22464679914735317720e-16 : a;
   return y < 0.0 ? -a : a;
 }
+
+// ---- fp32 variant of the tick (QPC_F32): the same two functions in float.  sin / cos: two-term Cody-Waite reduction by pi/2 (joint
+// angles are a few radians: exact products up to |x| ~ 1e3 rad, then a graceful loss) and the fdlibm float kernel polynomials on
+// [-pi/4, pi/4], ~1 ulp; ~20 straight-line instructions.  (Written with float literals throughout: this header is also compiled
+// without the single-precision-constant option.)
+QPC_MATH_FN void qpc_sincosf(float x, float &s, float &c) {
+  const float kf = rintf(x * 6.3661977236758134e-01f);
+  float r = fmaf(-kf, 1.5707855224609375e+00f, x);      // pi/2 = 1.5707855 (12 bits) + 1.0804334e-05 + 6.0770999e-11
+  r = fmaf(-kf, 1.0804334124e-05f, r);
+  r = fmaf(-kf, 6.0770999344e-11f, r);
+  const int q = (int)kf & 3;
+  const float z = r * r;
+  const float ps = fmaf(z, fmaf(z, fmaf(z, 2.7557314297e-06f, -1.9841270114e-04f), 8.3333337680e-03f), -1.6666667163e-01f);
+  const float pc = fmaf(z, fmaf(z, fmaf(z, -2.7557314297e-07f, 2.4801587642e-05f), -1.3888889225e-03f), 4.1666667908e-02f);
+  const float sr = fmaf(r * z, ps, r);
+  const float cr = fmaf(z * z, pc, fmaf(-0.5f, z, 1.0f));
+  const float s0 = (q & 1) ? cr : sr, c0 = (q & 1) ? sr : cr;
+  s = (q & 2) ? -s0 : s0;
+  c = ((q + 1) & 2) ? -c0 : c0;
+}
+// (atan2 in float -- only the orientation / SE(3) laws use it -- is the library atan2f: straight-line code, no private memory)

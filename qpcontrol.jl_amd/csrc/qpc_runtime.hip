@@ -200,7 +200,7 @@ static int launch(qpc_controller *c, QpcDeviceState *S, QpcSlot &sl, const QpcBa
   long long grid = (long long)S->n_cu * S->blocks_per_cu;
   if (grid > a.B) grid = a.B;
   if (grid < 1) return QPC_OK;
-  size_t lds = (size_t)D.lds_doubles * sizeof(double);
+  size_t lds = (size_t)D.lds_doubles * (c->precision == QPC_PRECISION_F32 ? sizeof(float) : sizeof(double));
   const bool user_stream = sl.stream == nullptr;
   bool capturing = false;
   if (user_stream && stream) {
@@ -229,7 +229,7 @@ static int launch(qpc_controller *c, QpcDeviceState *S, QpcSlot &sl, const QpcBa
     const int *it = S->d_it;
     const double *dt = S->d_dt;
     void *args[] = {(void *)&it, (void *)&dt, (void *)&aa};
-    unsigned dyn = qpc_jit_dynamic_lds() ? (unsigned)(D.lds_doubles * sizeof(double)) : 0u; // experiment: QPC_EXP_DYN_LDS=1
+    unsigned dyn = (qpc_jit_dynamic_lds() && c->precision != QPC_PRECISION_F32) ? (unsigned)(D.lds_doubles * sizeof(double)) : 0u; // experiment: QPC_EXP_DYN_LDS=1
     if (dyn) if (const char *e = QPC_EXP_ENV("QPC_EXP_LDS_PAD")) dyn += (unsigned)atoi(e); // ... QPC_EXP_LDS_PAD=bytes: occupancy at will
     HIP_TRY(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 64, 1, 1, dyn, stream, args, nullptr));
   } else {
@@ -309,13 +309,14 @@ static int init_device_state(qpc_controller *c, QpcDeviceState *S, int device_id
   S->device = device_id;
   HIP_TRY(hipSetDevice(device_id));
   S->n_cu = prop.multiProcessorCount;
-  const size_t lds = (size_t)D.lds_doubles * sizeof(double);
+  const bool f32 = c->precision == QPC_PRECISION_F32;
+  const size_t lds = (size_t)D.lds_doubles * (f32 ? sizeof(float) : sizeof(double));
   if (lds > 160 * 1024) { qpc_set_error("qpc_finalize: LDS slab exceeds the device limit"); return QPC_ERR_UNSUPPORTED; }
   const size_t slds = (size_t)qpc_sim_layout(D).total * sizeof(double);
   if (slds > 160 * 1024) { qpc_set_error("qpc_finalize: simulation LDS slab exceeds the device limit"); return QPC_ERR_UNSUPPORTED; }
   {
     std::lock_guard<std::mutex> lk(g_attr_mu);
-    if (lds > g_tick_lds_max) g_tick_lds_max = lds;
+    if (!f32 && lds > g_tick_lds_max) g_tick_lds_max = lds; // (the generic kernel is fp64 only)
     if (slds > g_sim_lds_max) g_sim_lds_max = slds;
     HIP_TRY(hipFuncSetAttribute((const void *)qpc_tick_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_tick_lds_max));
     HIP_TRY(hipFuncSetAttribute((const void *)qpc_sim_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_sim_lds_max));
@@ -630,15 +631,21 @@ int32_t qpc_finalize_devices(qpc_controller *c, int32_t n_devices, const int32_t
   std::vector<char> code;
   const char *nojit = getenv("QPC_DISABLE_JIT");
   const bool jit_off = nojit && nojit[0] == '1';
+  const bool f32 = c->precision == QPC_PRECISION_F32;
+  if (jit_off && f32) {
+    qpc_set_error("QPC_DISABLE_JIT=1 but the fp32 tick (qpc_set_precision) only exists as a hiprtc-specialised kernel");
+    return QPC_ERR_UNSUPPORTED;
+  }
   if (jit_off && D.maxdepth > QPC_GENERIC_MAXD) {
     qpc_set_error("QPC_DISABLE_JIT=1 but the tree is deeper than the generic kernel supports");
     return QPC_ERR_UNSUPPORTED;
   }
   if (!jit_off) {
     std::string log;
-    const int jrc = qpc_jit_compile(D, c->prog.dims_s, prop0.gcnArchName, c->warm_start != 0, code, log);
+    const int jrc = qpc_jit_compile(D, c->prog.dims_s, prop0.gcnArchName, c->warm_start != 0, f32, code, log);
     if (jrc != 0) {
       code.clear();
+      if (f32) { qpc_set_error("JIT specialisation of the fp32 tick failed (there is no ahead-of-time fp32 kernel): " + log); return QPC_ERR_HIP; }
       const char *strict = getenv("QPC_REQUIRE_JIT");
       if (strict && strict[0] == '1') { qpc_set_error("JIT specialisation failed: " + log); return QPC_ERR_HIP; }
       if (D.maxdepth > QPC_GENERIC_MAXD) {
@@ -661,7 +668,7 @@ int32_t qpc_finalize_devices(qpc_controller *c, int32_t n_devices, const int32_t
     rc = init_device_state(c, S, device_ids[i], rt->slots, code, prop);
     if (rc != QPC_OK) {
       const char *strict = getenv("QPC_REQUIRE_JIT");
-      if (!code.empty() && rc == QPC_ERR_HIP && !(strict && strict[0] == '1') && D.maxdepth <= QPC_GENERIC_MAXD && !S->jit_func) {
+      if (!code.empty() && rc == QPC_ERR_HIP && !(strict && strict[0] == '1') && D.maxdepth <= QPC_GENERIC_MAXD && !S->jit_func && !f32) {
         // code object would not load: fall back to the generic gfx950 kernel on every device
         fprintf(stderr, "[qpc] JIT code object unusable (%s); using the generic gfx950 kernel\n", qpc_last_error());
         for (auto *T : rt->devs) destroy_device_state(T);

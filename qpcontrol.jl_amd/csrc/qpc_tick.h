@@ -9,7 +9,7 @@
 //   QPC_FN                    function qualifier (__device__ __forceinline__ / inline)
 //   QPC_PHASE(lane) ... QPC_END_PHASE   per-lane block + barrier
 //   QPC_SINCOS(x, s, c), QPC_SQRT(x), QPC_FABS(x), QPC_RCP(x) = 1/x, QPC_RSQRT(x) = 1/sqrt(x) (pivots: ~1 ulp)
-// and instantiates qpc_tick<P> with P = LDS pointer type (double* on the device).
+// and instantiates qpc_tick<P> with P = LDS pointer type (real* on the device).
 //
 // Replaces, per reference function:
 //   a2  copyto!(state,x) + RBD cache sweeps          -> phases "kinematics"
@@ -42,29 +42,76 @@ enum { PS_KIN, PS_ASM, PS_SBUILD, PS_CHOL, PS_XINV, PS_REFAC, PS_RESID, PS_KKT, 
        PS_L_U0, PS_L_GUARD, PS_L_GICHECK, PS_L_GISTEP, PS_P_PROX, PS_P_BACK, PS_F_ACCEPT, PS_R_LOAD,
        PS_A_PRE, PS_A_ITEMS, PS_A_ROWS, PS_X_X, PS_X_MFMA, PS_R_SV, PS_R_BW, PS_P_QR, PS_P_RED, PS_P_POST, PS_COUNT };
 
+
+// ------------------------------------------------------------------------------------------
+// Arithmetic type of the tick.  `real` is double in the product's default build; the fp32 variant (BASELINE config 5: QPC_F32, built
+// as its own hiprtc module with `typedef float real` and single-precision literals) runs the SAME source with the constants below at
+// the fp32 rounding floor.  The includer defines `real` and `qpc_dtab` (the double tables in HBM, read as `real`).
+//   QPC_HUGE / QPC_HUGE_TEST   "no candidate" sentinels of the min / arg-min reductions and their test
+//   QPC_TINY                   guards of divisions by a vanishing scale
+//   QPC_T_STOP                 a refinement correction at the rounding floor, relative to the iterate
+//   QPC_T_CONFIRM              a confirming sweep's correction that certifies the polished iterate
+//   QPC_T_PROX1                first proximal sweep: correction small enough for ONE sweep
+//   QPC_T_INCONS               residual of the wrench rows that marks an inconsistent working set
+//   QPC_T_QR                   smallest / largest |R_jj| below which an elimination of the presolve is refused
+//   QPC_T_EXACT                smallest / largest Hessian diagonal above which the v̇ / slack blocks are used unregularised
+//   QPC_EPS_MACH               unit round-off (Rotations.rotation_between's antiparallel test is 100 eps, contacts.jl:11)
+#ifdef QPC_F32
+#define QPC_HUGE 1e30
+#define QPC_HUGE_TEST 1e29
+#define QPC_TINY 1e-30
+#define QPC_T_STOP 2e-6
+#define QPC_T_CONFIRM 1e-4
+#define QPC_T_PROX1 1e-2
+#define QPC_T_INCONS 1e-3
+#define QPC_T_QR 3e-2
+#define QPC_T_EXACT 1e-4
+#define QPC_EPS_MACH 1.1920929e-7
+// The all-free block of a contact (N = 4) has the null direction n = (1, -1, 1, -1) of B'B, on which K = (H + eps I)^-1 carries 1 / eps.
+// G n = 0 analytically, so in exact arithmetic that term drops out of Y = K G' and of rho = K G' lam_w; in fp32 it is 1 / eps times
+// the rounding noise of G -- amplified by cond(S22) it flips signs of small rho's and doubles the working-set changes of the search
+// (measured in the emulator: 6.3 -> 10.3 changes per QP at eps = 1e-6).  The fp32 tick therefore drops the term (the table stores the
+// eigenvalue as an exact 0): the minimum-norm rho of a fully free contact, which is also what the eps form converges to.
+#define QPC_K_NULL_TERM(lambda) ((lambda) == 0.0 ? 0.0 : 1.0)
+#define QPC_ACCEPT_BAND 10.0 // primal residuals up to this multiple of tol_accept: NUMERICAL_ERROR instead of INFEASIBLE (see the acceptance test)
+#else
+#define QPC_K_NULL_TERM(lambda) 1.0
+#define QPC_ACCEPT_BAND 1.0
+#define QPC_HUGE 1e300
+#define QPC_HUGE_TEST 1e299
+#define QPC_TINY 1e-300
+#define QPC_T_STOP 1e-13
+#define QPC_T_CONFIRM 1e-9
+#define QPC_T_PROX1 1e-4
+#define QPC_T_INCONS 1e-6
+#define QPC_T_QR 1e-4
+#define QPC_T_EXACT 1e-6
+#define QPC_EPS_MACH 2.220446049250313e-16
+#endif
+
 namespace qpc {
 
 // ------------------------------------------------------------------------------------------
 // small dense helpers on registers
 // ------------------------------------------------------------------------------------------
-QPC_FN void cross3(const double *a, const double *b, double *c) {
-  double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+QPC_FN void cross3(const real *a, const real *b, real *c) {
+  real x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
   c[0] = x; c[1] = y; c[2] = z;
 }
-QPC_FN void mv3(const double *R, const double *x, double *y) {
-  double a = R[0] * x[0] + R[1] * x[1] + R[2] * x[2];
-  double b = R[3] * x[0] + R[4] * x[1] + R[5] * x[2];
-  double c = R[6] * x[0] + R[7] * x[1] + R[8] * x[2];
+QPC_FN void mv3(const real *R, const real *x, real *y) {
+  real a = R[0] * x[0] + R[1] * x[1] + R[2] * x[2];
+  real b = R[3] * x[0] + R[4] * x[1] + R[5] * x[2];
+  real c = R[6] * x[0] + R[7] * x[1] + R[8] * x[2];
   y[0] = a; y[1] = b; y[2] = c;
 }
-QPC_FN void mtv3(const double *R, const double *x, double *y) {
-  double a = R[0] * x[0] + R[3] * x[1] + R[6] * x[2];
-  double b = R[1] * x[0] + R[4] * x[1] + R[7] * x[2];
-  double c = R[2] * x[0] + R[5] * x[1] + R[8] * x[2];
+QPC_FN void mtv3(const real *R, const real *x, real *y) {
+  real a = R[0] * x[0] + R[3] * x[1] + R[6] * x[2];
+  real b = R[1] * x[0] + R[4] * x[1] + R[7] * x[2];
+  real c = R[2] * x[0] + R[5] * x[1] + R[8] * x[2];
   y[0] = a; y[1] = b; y[2] = c;
 }
-QPC_FN void mm3(const double *A, const double *B, double *C) {
-  double T[9];
+QPC_FN void mm3(const real *A, const real *B, real *C) {
+  real T[9];
 #pragma unroll
   for (int i = 0; i < 3; i++)
 #pragma unroll
@@ -73,23 +120,23 @@ QPC_FN void mm3(const double *A, const double *B, double *C) {
   for (int i = 0; i < 9; i++) C[i] = T[i];
 }
 // motion cross product ad(a) b
-QPC_FN void crm(const double *a, const double *b, double *c) {
-  double t1[3], t2[3], t3[3];
+QPC_FN void crm(const real *a, const real *b, real *c) {
+  real t1[3], t2[3], t3[3];
   cross3(a, b, t1); cross3(a, b + 3, t2); cross3(a + 3, b, t3);
   c[0] = t1[0]; c[1] = t1[1]; c[2] = t1[2];
   c[3] = t2[0] + t3[0]; c[4] = t2[1] + t3[1]; c[5] = t2[2] + t3[2];
 }
 // force cross product (w,v) x* (k,l)
-QPC_FN void crf(const double *a, const double *f, double *c) {
-  double t1[3], t2[3], t3[3];
+QPC_FN void crf(const real *a, const real *f, real *c) {
+  real t1[3], t2[3], t3[3];
   cross3(a, f, t1); cross3(a + 3, f + 3, t2); cross3(a, f + 3, t3);
   c[0] = t1[0] + t2[0]; c[1] = t1[1] + t2[1]; c[2] = t1[2] + t2[2];
   c[3] = t3[0]; c[4] = t3[1]; c[5] = t3[2];
 }
 // spatial inertia I = {m, h[3], J[6] = xx yy zz xy xz yz} times motion vector
-QPC_FN void inertia_mul(const double *I, const double *t, double *o) {
-  const double *h = I + 1, *J = I + 4, *w = t, *v = t + 3;
-  double hv[3], hw[3];
+QPC_FN void inertia_mul(const real *I, const real *t, real *o) {
+  const real *h = I + 1, *J = I + 4, *w = t, *v = t + 3;
+  real hv[3], hw[3];
   cross3(h, v, hv); cross3(h, w, hw);
   o[0] = J[0] * w[0] + J[3] * w[1] + J[4] * w[2] + hv[0];
   o[1] = J[3] * w[0] + J[1] * w[1] + J[5] * w[2] + hv[1];
@@ -97,19 +144,19 @@ QPC_FN void inertia_mul(const double *I, const double *t, double *o) {
   o[3] = I[0] * v[0] - hw[0]; o[4] = I[0] * v[1] - hw[1]; o[5] = I[0] * v[2] - hw[2];
 }
 // world -> frame (R,p) transform of a motion vector: w' = R^T w ; v' = R^T (v - p x w)
-QPC_FN void motion_to_frame(const double *H, const double *in, double *out) {
-  double pw[3], t[3];
+QPC_FN void motion_to_frame(const real *H, const real *in, real *out) {
+  real pw[3], t[3];
   cross3(H + 9, in, pw);
   t[0] = in[3] - pw[0]; t[1] = in[4] - pw[1]; t[2] = in[5] - pw[2];
   mtv3(H, in, out); mtv3(H, t, out + 3);
 }
-template <class P> QPC_FN void ld(P p, int n, double *out) { for (int i = 0; i < n; i++) out[i] = p[i]; }
-template <class P> QPC_FN void st(P p, int n, const double *in) { for (int i = 0; i < n; i++) p[i] = in[i]; }
-template <class P> QPC_FN void ldH(P sm, const QpcDims &D, int body, double *H) {
+template <class P> QPC_FN void ld(P p, int n, real *out) { for (int i = 0; i < n; i++) out[i] = p[i]; }
+template <class P> QPC_FN void st(P p, int n, const real *in) { for (int i = 0; i < n; i++) p[i] = in[i]; }
+template <class P> QPC_FN void ldH(P sm, const QpcDims &D, int body, real *H) {
   if (body < 0) { H[0] = 1; H[1] = 0; H[2] = 0; H[3] = 0; H[4] = 1; H[5] = 0; H[6] = 0; H[7] = 0; H[8] = 1; H[9] = 0; H[10] = 0; H[11] = 0; }
   else ld(sm + D.lds[L_H] + 12 * body, 12, H);
 }
-template <class P> QPC_FN void ld6(P sm, int off, int body, double *x) {
+template <class P> QPC_FN void ld6(P sm, int off, int body, real *x) {
   if (body < 0) { for (int i = 0; i < 6; i++) x[i] = 0.0; }
   else ld(sm + off + 6 * body, 6, x);
 }
@@ -155,10 +202,10 @@ template <class P> QPC_FN void ld6(P sm, int off, int body, double *x) {
 #else
 #define QPC_STOP(n)
 #endif
-template <class PA, class PB> QPC_FN double dotp(PA a, int sa, PB b, int sb, int n) {
-  double acc0 = 0.0, acc1 = 0.0;
+template <class PA, class PB> QPC_FN real dotp(PA a, int sa, PB b, int sb, int n) {
+  real acc0 = 0.0, acc1 = 0.0;
   for (int i0 = 0; i0 < n; i0 += 8) {
-    double x[8], y[8];
+    real x[8], y[8];
     QPC_UNROLL_FULL
     for (int u = 0; u < 8; u++) {
       const int i = i0 + u;
@@ -176,9 +223,9 @@ template <class PA, class PB> QPC_FN double dotp(PA a, int sa, PB b, int sb, int
 }
 
 // uniform (all lanes identical) reductions over an LDS array, used OUTSIDE phases
-template <class P> QPC_FN double umax(P sm, int off, int n) {
-  double m = 0.0;
-  for (int i = 0; i < n; i++) { double a = sm[off + i]; m = a > m ? a : m; }
+template <class P> QPC_FN real umax(P sm, int off, int n) {
+  real m = 0.0;
+  for (int i = 0; i < n; i++) { real a = sm[off + i]; m = a > m ? a : m; }
   return m;
 }
 
@@ -186,21 +233,21 @@ template <class P> QPC_FN double umax(P sm, int off, int n) {
 // pivoting in registers (identity padding up to the compile-time bound NB so that the sweep fully unrolls); the LDS
 // copy is read once and written once
 template <int NB, class P> QPC_FN void spd_inverse_small(P a, int n) {
-  double r[NB][NB];
+  real r[NB][NB];
 #pragma unroll
   for (int i = 0; i < NB; i++)
 #pragma unroll
-    for (int j = 0; j < NB; j++) r[i][j] = (i < n && j < n) ? (double)a[(i < n ? i : 0) * n + (j < n ? j : 0)] : (i == j ? 1.0 : 0.0);
+    for (int j = 0; j < NB; j++) r[i][j] = (i < n && j < n) ? (real)a[(i < n ? i : 0) * n + (j < n ? j : 0)] : (i == j ? 1.0 : 0.0);
 #pragma unroll
   for (int k = 0; k < NB; k++) {
-    const double piv = QPC_RCP(r[k][k]);
+    const real piv = QPC_RCP(r[k][k]);
     r[k][k] = 1.0;
 #pragma unroll
     for (int j = 0; j < NB; j++) r[k][j] *= piv;
 #pragma unroll
     for (int i = 0; i < NB; i++) {
       if (i == k) continue;
-      const double f = r[i][k];
+      const real f = r[i][k];
       r[i][k] = 0.0;
 #pragma unroll
       for (int j = 0; j < NB; j++) r[i][j] -= f * r[k][j];
@@ -219,9 +266,9 @@ template <class P> QPC_FN void spd_inverse_inplace(P a, int n) {
 
 // (H_FF + eps I)^-1 of one contact's N x N rho block on its free set, in registers.
 // NB >= N is a compile-time bound so that the Gauss-Jordan sweep fully unrolls.
-template <int NB, class P> QPC_FN void kr_block(P sm, const QpcDims &D, int c, double eps) {
+template <int NB, class P> QPC_FN void kr_block(P sm, const QpcDims &D, int c, real eps) {
   const int N = D.N;
-  double a[NB][NB];
+  real a[NB][NB];
   bool fr[NB];
 #pragma unroll
   for (int i = 0; i < NB; i++) fr[i] = (i < N) && (sm[D.lds[L_WS] + c * N + (i < N ? i : 0)] == 0.0);
@@ -229,19 +276,19 @@ template <int NB, class P> QPC_FN void kr_block(P sm, const QpcDims &D, int c, d
   for (int i = 0; i < NB; i++)
 #pragma unroll
     for (int j = 0; j < NB; j++) {
-      double h = (i < N && j < N) ? (double)sm[D.lds[L_HR] + c * QPC_CSH(N) + (i < N ? i : 0) * N + (j < N ? j : 0)] : 0.0;
+      real h = (i < N && j < N) ? (real)sm[D.lds[L_HR] + c * QPC_CSH(N) + (i < N ? i : 0) * N + (j < N ? j : 0)] : 0.0;
       a[i][j] = (fr[i] && fr[j]) ? h + (i == j ? eps : 0.0) : (i == j ? 1.0 : 0.0);
     }
 #pragma unroll
   for (int k = 0; k < NB; k++) {
-    double piv = QPC_RCP(a[k][k]);
+    real piv = QPC_RCP(a[k][k]);
     a[k][k] = 1.0;
 #pragma unroll
     for (int j = 0; j < NB; j++) a[k][j] *= piv;
 #pragma unroll
     for (int i = 0; i < NB; i++) {
       if (i == k) continue;
-      double f = a[i][k];
+      real f = a[i][k];
       a[i][k] = 0.0;
 #pragma unroll
       for (int j = 0; j < NB; j++) a[i][j] -= f * a[k][j];
@@ -259,22 +306,22 @@ template <int NB, class P> QPC_FN void kr_block(P sm, const QpcDims &D, int c, d
 // below tau * sref[k] marks a redundant row: zero row/column in T (infinite-pivot rule).
 // (LDL' instead of Cholesky: a reciprocal per pivot instead of a reciprocal square root -- 5 dependent instructions
 // instead of 9 on the serial chain -- and no scaling of the off-diagonal entries by 1/L_kk.)
-template <class P> QPC_FN void chol6_solve(P Sin, const double *sref, double tau, const double *rhs, double *x) {
-  double L[6][6], U[6][6], invd[6], y[6]; // L unit lower triangular, U[i][k] = L[i][k] d_k
+template <class P> QPC_FN void chol6_solve(P Sin, const real *sref, real tau, const real *rhs, real *x) {
+  real L[6][6], U[6][6], invd[6], y[6]; // L unit lower triangular, U[i][k] = L[i][k] d_k
   QPC_UNROLL_FULL
   for (int i = 0; i < 6; i++)
     QPC_UNROLL_FULL
-    for (int j = 0; j < 6; j++) { L[i][j] = 0.0; U[i][j] = (j <= i) ? (double)Sin[i * 6 + j] : 0.0; }
+    for (int j = 0; j < 6; j++) { L[i][j] = 0.0; U[i][j] = (j <= i) ? (real)Sin[i * 6 + j] : 0.0; }
   QPC_UNROLL_FULL
   for (int k = 0; k < 6; k++) {
-    double d = U[k][k];
+    real d = U[k][k];
     QPC_UNROLL_FULL
     for (int j = 0; j < k; j++) d -= U[k][j] * L[k][j];
-    const bool ok = d > tau * (sref[k] > 1e-300 ? sref[k] : 1e-300);
+    const bool ok = d > tau * (sref[k] > QPC_TINY ? sref[k] : QPC_TINY);
     invd[k] = ok ? QPC_RCP_SEARCH(d) : 0.0; // 1 / d_k
     QPC_UNROLL_FULL
     for (int i = k + 1; i < 6; i++) {
-      double t = U[i][k];
+      real t = U[i][k];
       QPC_UNROLL_FULL
       for (int j = 0; j < k; j++) t -= U[i][j] * L[k][j];
       U[i][k] = t;
@@ -283,14 +330,14 @@ template <class P> QPC_FN void chol6_solve(P Sin, const double *sref, double tau
   }
   QPC_UNROLL_FULL
   for (int r = 0; r < 6; r++) { // L y = rhs
-    double t = rhs[r];
+    real t = rhs[r];
     QPC_UNROLL_FULL
     for (int j = 0; j < r; j++) t -= L[r][j] * y[j];
     y[r] = t;
   }
   QPC_UNROLL_FULL
   for (int r = 5; r >= 0; r--) { // L' x = D^-1 y
-    double t = y[r] * invd[r];
+    real t = y[r] * invd[r];
     QPC_UNROLL_FULL
     for (int j = r + 1; j < 6; j++) t -= L[j][r] * x[j];
     x[r] = t;
@@ -315,30 +362,30 @@ struct TickIO {
 template <class P> struct Solver {
   const QpcDims &D;
   const int *IT;
-  const double *DT;
+  qpc_dtab DT;
   P sm;
   bool use_rho;
   QPC_LANE_SCOPE
   unsigned long long *PA, *PT; // section timers (diagnostic build)
-  double last_gmax = 0.0, last_xmax = 0.0; // scales of the last base rho_solve (uniform)
-  double last_dmax = 0.0;                   // max |rho - rho_prev| of the last proximal sweep (uniform)
+  real last_gmax = 0.0, last_xmax = 0.0; // scales of the last base rho_solve (uniform)
+  real last_dmax = 0.0;                   // max |rho - rho_prev| of the last proximal sweep (uniform)
   bool c_valid = false;                     // L_T1 holds c = E H^-1 (-g) - d (clobbered by kkt_solve)
   bool confirmed = false;                   // eqp(from_current) stopped after ONE sweep whose correction was <= 1e-9 relative:
                                             // the residual arrays (of the iterate before that correction) bound the final ones
   // hot lookups staged in LDS (IT_HOT)
-  QPC_FN int row_slack(int r) const { return (int)(double)sm[D.lds[L_HOT] + r]; }
-  QPC_FN int slack_row(int s) const { return (int)(double)sm[D.lds[L_HOT] + D.m + s]; }
-  QPC_FN int slack_woff(int s) const { return (int)(double)sm[D.lds[L_HOT] + D.m + D.ne + s]; }
-  QPC_FN int slack_dim(int s) const { return (int)(double)sm[D.lds[L_HOT] + D.m + 2 * D.ne + s]; }
-  QPC_FN int slack_s0(int s) const { return (int)(double)sm[D.lds[L_HOT] + D.m + 3 * D.ne + s]; }
-  QPC_FN Solver(const QpcDims &d, const int *it, const double *dt, P s, unsigned long long *pa, unsigned long long *pt)
+  QPC_FN int row_slack(int r) const { return (int)(real)sm[D.lds[L_HOT] + r]; }
+  QPC_FN int slack_row(int s) const { return (int)(real)sm[D.lds[L_HOT] + D.m + s]; }
+  QPC_FN int slack_woff(int s) const { return (int)(real)sm[D.lds[L_HOT] + D.m + D.ne + s]; }
+  QPC_FN int slack_dim(int s) const { return (int)(real)sm[D.lds[L_HOT] + D.m + 2 * D.ne + s]; }
+  QPC_FN int slack_s0(int s) const { return (int)(real)sm[D.lds[L_HOT] + D.m + 3 * D.ne + s]; }
+  QPC_FN Solver(const QpcDims &d, const int *it, qpc_dtab dt, P s, unsigned long long *pa, unsigned long long *pt)
       : D(d), IT(it), DT(dt), sm(s), use_rho(d.nrho > 0), PA(pa), PT(pt) {}
 
   // sum_j G[a][j] * rho_fix[j] with rho_fix = hi on the upper-active set (batched like dotp)
-  QPC_FN double dot_fix(int goff, int gstride, int j0, int n) const {
-    double acc = 0.0;
+  QPC_FN real dot_fix(int goff, int gstride, int j0, int n) const {
+    real acc = 0.0;
     for (int i0 = 0; i0 < n; i0 += 8) {
-      double g[8], w[8], h[8];
+      real g[8], w[8], h[8];
       QPC_UNROLL_FULL
       for (int u = 0; u < 8; u++) {
         const int i = i0 + u, ic = i < n ? i : 0;
@@ -360,19 +407,19 @@ template <class P> struct Solver {
   // per ray: its row of K from four reciprocals and a 4 x 4 product instead of the serial elimination.
   QPC_FN void kr_blocks() {
     const int N = D.N, nc = D.nc, nrho = D.nrho;
-    const double eps = sm[D.lds[L_MISC] + MS_EPS];
+    const real eps = sm[D.lds[L_MISC] + MS_EPS];
     if (D.k_tab) {
       QPC_PHASE(lane) {
         const int j = lane < nrho ? lane : 0, c = j >> 2, jj = j & 3;
         int pat = 0;
         QPC_UNROLL_FULL
         for (int i = 0; i < 4; i++) pat |= (sm[D.lds[L_WS] + 4 * c + i] == 0.0) ? (1 << i) : 0;
-        const int koff = D.k_classes > 1 ? (int)(double)sm[D.lds[L_MISC] + MS_KS + 8 + c] : 0; // this contact's table (its mu)
-        const double *kt = DT + D.dt[DT_KTAB] + koff + pat * 20;
-        const double w2 = sm[D.lds[L_MISC] + MS_KS + c];
-        double t[4], k[4] = {0.0, 0.0, 0.0, 0.0};
+        const int koff = D.k_classes > 1 ? (int)(real)sm[D.lds[L_MISC] + MS_KS + 8 + c] : 0; // this contact's table (its mu)
+        qpc_dtab kt = DT + D.dt[DT_KTAB] + koff + pat * 20;
+        const real w2 = sm[D.lds[L_MISC] + MS_KS + c];
+        real t[4], k[4] = {0.0, 0.0, 0.0, 0.0};
         QPC_UNROLL_FULL
-        for (int e = 0; e < 4; e++) t[e] = kt[4 + 4 * jj + e] * QPC_RCP_SEARCH(w2 * kt[e] + eps); // v_k(jj) / (2 w lambda_k + eps)
+        for (int e = 0; e < 4; e++) t[e] = QPC_K_NULL_TERM(kt[e]) * kt[4 + 4 * jj + e] * QPC_RCP_SEARCH(w2 * kt[e] + eps); // v_k(jj) / (2 w lambda_k + eps)
         QPC_UNROLL_FULL
         for (int i = 0; i < 4; i++)
           QPC_UNROLL_FULL
@@ -408,19 +455,19 @@ template <class P> struct Solver {
     QPC_PHASE(lane) {
       if (lane < 36) {
         int a = lane / 6, b = lane % 6;
-        double acc = sm[D.lds[L_B22] + lane];
+        real acc = sm[D.lds[L_B22] + lane];
         if (use_rho) acc += dotp(sm + D.lds[L_G] + a * QPC_GS(nrho), 1, sm + D.lds[L_Y] + b * QPC_GS(nrho), 1, nrho);
         sm[D.lds[L_C22] + lane] = acc; // S22 = B22 + G Kr G'
       }
     } QPC_END_PHASE
     QPC_PHASE(lane) { // T22 = S22^-1 : lane c < 6 computes column c (Cholesky redone per lane, in registers)
       if (lane < 6) {
-        double sref[6], x[6];
+        real sref[6], x[6];
         for (int k = 0; k < 6; k++)
           sref[k] = sm[D.lds[L_SM] + (m1 + k) * D.ms + (m1 + k)] + (sm[D.lds[L_C22] + k * 6 + k] - sm[D.lds[L_B22] + k * 6 + k]);
-        double ec[6];
+        real ec[6];
         for (int r = 0; r < 6; r++) ec[r] = (r == lane) ? 1.0 : 0.0;
-        chol6_solve(sm + D.lds[L_C22], sref, D.tau_pivot, ec, x);
+        chol6_solve(sm + D.lds[L_C22], sref, (real)D.tau_pivot, ec, x);
         for (int r = 0; r < 6; r++) sm[D.lds[L_S22I] + r * 6 + lane] = x[r];
       }
     } QPC_END_PHASE
@@ -434,22 +481,22 @@ template <class P> struct Solver {
   // B'B has the null vector (1, -1, 1, -1)).  d = w2 + eps, p = w2 a, q = w2 o; differences that cancel for small mu are
   // formed from the analytic constants (1 - a = mu^2 / (mu^2 + 1), ...).  r[k] = K[jj][(jj + k) & 3]; r = 0 when jj is pinned.
   // Same matrix as the eigen-decomposition table (DT_KTAB) to rounding, two reciprocals instead of four and no table reads.
-  QPC_FN void k_row_closed(double w2, double eps, int pat, int jj, double *r) const {
-    const double mu2 = D.k_mu2, den = 1.0 / (mu2 + 1.0);
-    const double a = den, o = (1.0 - mu2) * den, na = mu2 * den, no_ = 2.0 * mu2 * den, po = 2.0 * den;
-    const double c3 = 2.0 * mu2 * den * den, c4 = mu2 * mu2 * den * den, e0c = 4.0 * den; // (1 + o) - 2 a^2 ; a^2 - o ; 1 + 2 a + o
+  QPC_FN void k_row_closed(real w2, real eps, int pat, int jj, real *r) const {
+    const real mu2 = (real)D.k_mu2, den = 1.0 / (mu2 + 1.0);
+    const real a = den, o = (1.0 - mu2) * den, na = mu2 * den, no_ = 2.0 * mu2 * den, po = 2.0 * den;
+    const real c3 = 2.0 * mu2 * den * den, c4 = mu2 * mu2 * den * den, e0c = 4.0 * den; // (1 + o) - 2 a^2 ; a^2 - o ; 1 + 2 a + o
     const int rot = ((pat >> jj) | (pat << (4 - jj))) & 15; // bit k: ray (jj + k) & 3 is free
     const bool f0 = rot & 1, f1 = rot & 2, f2 = rot & 4, f3 = rot & 8;
-    const double d = w2 + eps, pp = w2 * a, qq = w2 * o;
-    const double dmp = w2 * na + eps, dpp = w2 * (1.0 + a) + eps, dmq = w2 * no_ + eps, dpq = w2 * po + eps;
-    const double D2p = dmp * dpp, D2q = dmq * dpq;               // d^2 - p^2, d^2 - q^2
-    const double inner = w2 * w2 * c3 + eps * (w2 * (2.0 + o) + eps); // d (d + q) - 2 p^2
-    const double num13 = w2 * w2 * c4 - eps * qq;                // p^2 - d q
+    const real d = w2 + eps, pp = w2 * a, qq = w2 * o;
+    const real dmp = w2 * na + eps, dpp = w2 * (1.0 + a) + eps, dmq = w2 * no_ + eps, dpq = w2 * po + eps;
+    const real D2p = dmp * dpp, D2q = dmq * dpq;               // d^2 - p^2, d^2 - q^2
+    const real inner = w2 * w2 * c3 + eps * (w2 * (2.0 + o) + eps); // d (d + q) - 2 p^2
+    const real num13 = w2 * w2 * c4 - eps * qq;                // p^2 - d q
     const int others = (f1 ? 1 : 0) + (f2 ? 1 : 0) + (f3 ? 1 : 0);
     // first reciprocal: of d | d^2 - p^2 | d^2 - q^2 | inner | e0 ; second: of d - q (three rays, four rays)
-    const double x1 = others == 0 ? d : (others == 1 ? (f2 ? D2q : D2p) : (others == 2 ? inner : w2 * e0c + eps));
-    const double r1 = QPC_RCP(x1), r2 = QPC_RCP(dmq);
-    double k0 = 0.0, k1 = 0.0, k2 = 0.0, k3 = 0.0;
+    const real x1 = others == 0 ? d : (others == 1 ? (f2 ? D2q : D2p) : (others == 2 ? inner : w2 * e0c + eps));
+    const real r1 = QPC_RCP(x1), r2 = QPC_RCP(dmq);
+    real k0 = 0.0, k1 = 0.0, k2 = 0.0, k3 = 0.0;
     if (others == 0) k0 = r1;
     else if (others == 1) {
       k0 = d * r1;
@@ -461,7 +508,7 @@ template <class P> struct Solver {
         if (f1) k1 = -pp * r1; else k3 = -pp * r1;
       }
     } else {
-      const double ie0 = r1, ie1 = r2, ie2 = QPC_RCP(eps);
+      const real ie0 = r1, ie1 = r2, ie2 = QPC_RCP(eps);
       k0 = 0.25 * (ie0 + 2.0 * ie1 + ie2); k1 = 0.25 * (ie0 - ie2); k2 = 0.25 * (ie0 - 2.0 * ie1 + ie2); k3 = k1;
     }
     r[0] = f0 ? k0 : 0.0; r[1] = f0 ? k1 : 0.0; r[2] = f0 ? k2 : 0.0; r[3] = f0 ? k3 : 0.0;
@@ -485,7 +532,7 @@ template <class P> struct Solver {
   }
   QPC_FN void ky_phase(bool from_mask = false, unsigned long long bfree = 0ull) {
     const int nrho = D.nrho;
-    const double eps = sm[D.lds[L_MISC] + MS_EPS];
+    const real eps = sm[D.lds[L_MISC] + MS_EPS];
     QPC_PROF_ACC(PS_LOGIC);
     QPC_PHASE(lane) {
       const int j = lane < nrho ? lane : 0, c = j >> 2, jj = j & 3;
@@ -495,19 +542,19 @@ template <class P> struct Solver {
         QPC_UNROLL_FULL
         for (int i = 0; i < 4; i++) pat |= (sm[D.lds[L_WS] + 4 * c + i] == 0.0) ? (1 << i) : 0;
       }
-      const double w2 = sm[D.lds[L_MISC] + MS_KS + c];
-      double k[4] = {0.0, 0.0, 0.0, 0.0};
-      if (D.k_classes == 1 && D.k_mu2 > 0.0) {
-        double r[4];
+      const real w2 = sm[D.lds[L_MISC] + MS_KS + c];
+      real k[4] = {0.0, 0.0, 0.0, 0.0};
+      if (D.k_classes == 1 && (real)D.k_mu2 > 0.0) {
+        real r[4];
         k_row_closed(w2, eps, pat, jj, r);
         QPC_UNROLL_FULL
         for (int i = 0; i < 4; i++) k[i] = r[(i - jj) & 3]; // K[jj][i] = r[(i - jj) & 3]
       } else {
-        const int koff = D.k_classes > 1 ? (int)(double)sm[D.lds[L_MISC] + MS_KS + 8 + c] : 0; // this contact's table (its mu)
-        const double *kt = DT + D.dt[DT_KTAB] + koff + pat * 20;
-        double t[4];
+        const int koff = D.k_classes > 1 ? (int)(real)sm[D.lds[L_MISC] + MS_KS + 8 + c] : 0; // this contact's table (its mu)
+        qpc_dtab kt = DT + D.dt[DT_KTAB] + koff + pat * 20;
+        real t[4];
         QPC_UNROLL_FULL
-        for (int e = 0; e < 4; e++) t[e] = kt[4 + 4 * jj + e] * QPC_RCP_SEARCH(w2 * kt[e] + eps); // v_k(jj) / (2 w lambda_k + eps)
+        for (int e = 0; e < 4; e++) t[e] = QPC_K_NULL_TERM(kt[e]) * kt[4 + 4 * jj + e] * QPC_RCP_SEARCH(w2 * kt[e] + eps); // v_k(jj) / (2 w lambda_k + eps)
         QPC_UNROLL_FULL
         for (int i = 0; i < 4; i++)
           QPC_UNROLL_FULL
@@ -515,7 +562,7 @@ template <class P> struct Solver {
       }
 #if defined(QPC_EXP_DUMMY_DEP) && defined(QPC_JIT)
       { // calibration: QPC_EXP_DUMMY_DEP dependent multiply-adds ON the critical path of the phase (result feeds k[0] as + 0)
-        double z = w2;
+        real z = w2;
         QPC_UNROLL_FULL
         for (int u = 0; u < QPC_EXP_DUMMY_DEP; u++) z = z * 1.0000001 + eps;
         asm volatile("" : "+v"(z));
@@ -524,9 +571,9 @@ template <class P> struct Solver {
 #endif
 #if defined(QPC_EXP_DUMMY_IND) && defined(QPC_JIT)
       { // calibration: QPC_EXP_DUMMY_IND independent multiply-adds OFF the critical path (8 parallel chains, consumed by an empty asm)
-        double z[8];
+        real z[8];
         QPC_UNROLL_FULL
-        for (int u = 0; u < 8; u++) z[u] = w2 + (double)u;
+        for (int u = 0; u < 8; u++) z[u] = w2 + (real)u;
         QPC_UNROLL_FULL
         for (int u = 0; u < QPC_EXP_DUMMY_IND; u++) z[u & 7] = z[u & 7] * 1.0000001 + eps;
         QPC_UNROLL_FULL
@@ -539,7 +586,7 @@ template <class P> struct Solver {
         QPC_UNROLL_FULL
         for (int b = 0; b < 6; b++) { // Y[b][j] = sum_i K[jj][i] G[b][4 c + i]
           const int g = D.lds[L_G] + b * QPC_GS(nrho) + 4 * c;
-          const double g0 = sm[g], g1 = sm[g + 1], g2 = sm[g + 2], g3 = sm[g + 3];
+          const real g0 = sm[g], g1 = sm[g + 1], g2 = sm[g + 2], g3 = sm[g + 3];
           sm[D.lds[L_Y] + b * QPC_GS(nrho) + j] = (k[0] * g0 + k[2] * g2) + (k[1] * g1 + k[3] * g3);
         }
       }
@@ -557,21 +604,21 @@ template <class P> struct Solver {
     } QPC_END_PHASE
     QPC_PROF_ACC(PS_S_C22);
     QPC_LANE_ARRAY(q4_, 10); // [0..3] (G' lam_w) of the quad, [4..7] rho of the quad, [8] own value in flight, [9] (G' lam_w)_j
-    double rg = 0.0, rx = 0.0;
+    real rg = 0.0, rx = 0.0;
     QPC_PHASE(lane) {
-      double sref[6], x[6], rhs[6];
+      real sref[6], x[6], rhs[6];
       for (int k = 0; k < 6; k++)
         sref[k] = sm[D.lds[L_SM] + (m1 + k) * D.ms + (m1 + k)] + (sm[D.lds[L_C22] + k * 6 + k] - sm[D.lds[L_B22] + k * 6 + k]);
       const int col = lane - nrho; // lanes nrho .. nrho + 5: column `col` of T22; every other lane: lam_w = S22^-1 u0
-      for (int r = 0; r < 6; r++) rhs[r] = (col >= 0 && col < 6) ? ((r == col) ? 1.0 : 0.0) : (double)sm[D.lds[L_MISC] + MS_U0 + r];
-      chol6_solve(sm + D.lds[L_C22], sref, D.tau_pivot, rhs, x);
+      for (int r = 0; r < 6; r++) rhs[r] = (col >= 0 && col < 6) ? ((r == col) ? 1.0 : 0.0) : (real)sm[D.lds[L_MISC] + MS_U0 + r];
+      chol6_solve(sm + D.lds[L_C22], sref, (real)D.tau_pivot, rhs, x);
       if (lane == 0)
         for (int r = 0; r < 6; r++) sm[D.lds[L_LAM] + m1 + r] = x[r];
       if (col >= 0 && col < 6)
         for (int r = 0; r < 6; r++) sm[D.lds[L_S22I] + r * 6 + col] = x[r];
-      double *q = QPC_LA(q4_, lane);
+      real *q = QPC_LA(q4_, lane);
       const int j = lane < nrho ? lane : 0;
-      double wj0 = 0.0, wj1 = 0.0; // (G' lam_w)_j with lam_w straight from the registers
+      real wj0 = 0.0, wj1 = 0.0; // (G' lam_w)_j with lam_w straight from the registers
       QPC_UNROLL_FULL
       for (int a = 0; a < 6; a += 2) {
         wj0 += sm[D.lds[L_G] + a * QPC_GS(nrho) + j] * x[a];
@@ -583,8 +630,8 @@ template <class P> struct Solver {
     QPC_PROF_ACC(PS_S_CHOL);
     QPC_QUAD_GATHER(lane, QPC_LA(q4_, lane), QPC_LA(q4_, lane)[8])
     QPC_PHASE(lane) {
-      double *q = QPC_LA(q4_, lane);
-      double acc = 0.0;
+      real *q = QPC_LA(q4_, lane);
+      real acc = 0.0;
       if (lane < nrho) { // (idle lanes must not touch K: lane 0 rewrites its row further down this soft-joined group)
         const int j = lane;
         for (int i = 0; i < 4; i++) acc += sm[D.lds[L_KR] + QPC_CS(4) * (j / 4) + 4 * (j % 4) + i] * q[i];
@@ -593,15 +640,15 @@ template <class P> struct Solver {
     } QPC_END_PHASE_SOFT
     QPC_QUAD_GATHER(lane, QPC_LA(q4_, lane) + 4, QPC_LA(q4_, lane)[8])
     QPC_PHASE(lane) {
-      const double *q = QPC_LA(q4_, lane);
-      double g = 0.0, xm = 0.0;
+      const real *q = QPC_LA(q4_, lane);
+      real g = 0.0, xm = 0.0;
       if (lane < nrho) {
         const int j = lane;
-        const double rho_j = q[8];
+        const real rho_j = q[8];
         sm[D.lds[L_XR] + j] = rho_j;
-        double gl = -q[9];
+        real gl = -q[9];
         for (int i = 0; i < 4; i++) gl += sm[D.lds[L_HR] + QPC_CSH(4) * (j / 4) + 4 * (j % 4) + i] * q[4 + i];
-        const double wsj = sm[D.lds[L_WS] + j];
+        const real wsj = sm[D.lds[L_WS] + j];
         sm[D.lds[L_U] + j] = (wsj == -1.0) ? gl : ((wsj == 1.0) ? -gl : 0.0);
         g = QPC_FABS(gl);
         xm = QPC_FABS(rho_j);
@@ -641,11 +688,11 @@ template <class P> struct Solver {
     QPC_PROF_ACC(PS_S_C22);
     QPC_PHASE(lane) {
       if (lane < 7) {
-        double sref[6], x[6], rhs[6];
+        real sref[6], x[6], rhs[6];
         for (int k = 0; k < 6; k++)
           sref[k] = sm[D.lds[L_SM] + (m1 + k) * D.ms + (m1 + k)] + (sm[D.lds[L_C22] + k * 6 + k] - sm[D.lds[L_B22] + k * 6 + k]);
-        for (int r = 0; r < 6; r++) rhs[r] = lane == 0 ? (double)sm[D.lds[L_MISC] + MS_U0 + r] : ((r == lane - 1) ? 1.0 : 0.0);
-        chol6_solve(sm + D.lds[L_C22], sref, D.tau_pivot, rhs, x);
+        for (int r = 0; r < 6; r++) rhs[r] = lane == 0 ? (real)sm[D.lds[L_MISC] + MS_U0 + r] : ((r == lane - 1) ? 1.0 : 0.0);
+        chol6_solve(sm + D.lds[L_C22], sref, (real)D.tau_pivot, rhs, x);
         for (int r = 0; r < 6; r++) {
           if (lane == 0) sm[D.lds[L_LAM] + m1 + r] = x[r];
           else sm[D.lds[L_S22I] + r * 6 + (lane - 1)] = x[r];
@@ -677,7 +724,7 @@ template <class P> struct Solver {
     }
     QPC_PHASE(lane) {
       for (int r = lane; r < m1; r += 64) {
-        double acc = dotp(sm + D.lds[L_SM] + r * D.ms, 1, sm + D.lds[L_T1], 1, m1);
+        real acc = dotp(sm + D.lds[L_SM] + r * D.ms, 1, sm + D.lds[L_T1], 1, m1);
         if (nw) acc -= dotp(sm + D.lds[L_X2] + r * 6, 1, sm + out + m1, 1, 6);
         sm[out + r] = acc;
       }
@@ -704,7 +751,7 @@ template <class P> struct Solver {
     } QPC_END_PHASE
     QPC_PHASE(lane) {
       for (int r = lane; r < m; r += 64) {
-        double acc = dotp(sm + D.lds[L_M] + r * D.nfs, 1, sm + D.lds[L_DV], 1, nf) - sm[D.lds[L_RC] + r];
+        real acc = dotp(sm + D.lds[L_M] + r * D.nfs, 1, sm + D.lds[L_DV], 1, nf) - sm[D.lds[L_RC] + r];
         if (r < m1) {
           int sl = row_slack(r);
           if (sl >= 0) acc -= sm[D.lds[L_TE1] + sl];
@@ -744,7 +791,7 @@ template <class P> struct Solver {
     QPC_PROF_ACC(PS_LOGIC);
     QPC_PHASE(lane) {
       for (int r = lane; r < m; r += 64) {
-        double acc = sm[D.lds[L_D] + r] - dotp(sm + D.lds[L_M] + r * D.nfs, 1, sm + D.lds[L_XV], 1, nf);
+        real acc = sm[D.lds[L_D] + r] - dotp(sm + D.lds[L_M] + r * D.nfs, 1, sm + D.lds[L_XV], 1, nf);
         if (r < m1) {
           int sl = row_slack(r);
           if (sl >= 0) acc += sm[D.lds[L_XE] + sl];
@@ -754,20 +801,20 @@ template <class P> struct Solver {
         sm[D.lds[L_RC] + r] = acc;
       }
       for (int f = lane; f < nf; f += 64) {
-        double mtl = dotp(sm + D.lds[L_M] + f, D.nfs, sm + D.lds[L_LAM], 1, m);
-        double sq = sm[D.lds[L_SQH] + f];
+        real mtl = dotp(sm + D.lds[L_M] + f, D.nfs, sm + D.lds[L_LAM], 1, m);
+        real sq = sm[D.lds[L_SQH] + f];
         sm[D.lds[L_RV] + f] = -(sm[D.lds[L_HV] + f] * sq * sm[D.lds[L_XV] + f] + sm[D.lds[L_GV] + f] + mtl / sq);
         sm[D.lds[L_DV] + f] = QPC_FABS(mtl / sq); // |E_v' lam|: scale of the stationarity test (L_DV is free here)
       }
       for (int s = lane; s < ne; s += 64) {
         int d = slack_dim(s), wr = slack_woff(s), s0 = slack_s0(s);
-        double acc = dotp(sm + D.lds[L_W] + wr, 1, sm + D.lds[L_XE] + s0, 1, d);
+        real acc = dotp(sm + D.lds[L_W] + wr, 1, sm + D.lds[L_XE] + s0, 1, d);
         sm[D.lds[L_RE] + s] = -(acc - sm[D.lds[L_LAM] + slack_row(s)]);
       }
       if (use_rho)
         for (int j = lane; j < nrho; j += 64) {
           int c = j / N, jj = j % N;
-          double gl = dotp(sm + D.lds[L_HR] + c * QPC_CSH(N) + jj * N, 1, sm + D.lds[L_XR] + c * N, 1, N) -
+          real gl = dotp(sm + D.lds[L_HR] + c * QPC_CSH(N) + jj * N, 1, sm + D.lds[L_XR] + c * N, 1, N) -
                       dotp(sm + D.lds[L_G] + j, QPC_GS(nrho), sm + D.lds[L_LAM] + m1, 1, 6);
           sm[D.lds[L_TR1] + j] = gl;
           sm[D.lds[L_WSP] + j] = gl; // kept for the acceptance test (L_TR1 is scratch of kkt_solve; L_WSP is dead after the search)
@@ -786,33 +833,33 @@ template <class P> struct Solver {
         for (int f = lane; f < nf; f += 64) sm[D.lds[L_XV] + f] = 0.0;
         for (int s = lane; s < ne; s += 64) sm[D.lds[L_XE] + s] = 0.0;
         for (int r = lane; r < m; r += 64) sm[D.lds[L_LAM] + r] = 0.0;
-        for (int j = lane; j < nrho; j += 64) sm[D.lds[L_XR] + j] = (sm[D.lds[L_WS] + j] == 1.0) ? sm[D.lds[L_HI] + j] : 0.0;
+        for (int j = lane; j < nrho; j += 64) sm[D.lds[L_XR] + j] = (sm[D.lds[L_WS] + j] == 1.0) ? (real)sm[D.lds[L_HI] + j] : 0.0;
       } QPC_END_PHASE
     }
     int it = from_current ? 1 : 0;
-    double prev_dbig = 1e300;
+    real prev_dbig = QPC_HUGE;
     confirmed = false;
     for (;; it++) {
       if (it == 0) fresh_rhs(); else residuals();
       kkt_solve();
-      double rbig = 0.0, rdbig = 0.0;
+      real rbig = 0.0, rdbig = 0.0;
       QPC_PHASE(lane) {
-        double big = 0.0, dbig = 0.0;
+        real big = 0.0, dbig = 0.0;
         for (int f = lane; f < nf; f += 64) {
-          double dx = sm[D.lds[L_DV] + f], x = sm[D.lds[L_XV] + f] + dx;
+          real dx = sm[D.lds[L_DV] + f], x = sm[D.lds[L_XV] + f] + dx;
           sm[D.lds[L_XV] + f] = x;
-          double sq = sm[D.lds[L_SQH] + f];
+          real sq = sm[D.lds[L_SQH] + f];
           big = QPC_FABS(x * sq) > big ? QPC_FABS(x * sq) : big;
           dbig = QPC_FABS(dx * sq) > dbig ? QPC_FABS(dx * sq) : dbig;
         }
         for (int s = lane; s < ne; s += 64) {
-          double dx = sm[D.lds[L_DE] + s], x = sm[D.lds[L_XE] + s] + dx;
+          real dx = sm[D.lds[L_DE] + s], x = sm[D.lds[L_XE] + s] + dx;
           sm[D.lds[L_XE] + s] = x;
           big = QPC_FABS(x) > big ? QPC_FABS(x) : big;
           dbig = QPC_FABS(dx) > dbig ? QPC_FABS(dx) : dbig;
         }
         for (int j = lane; j < nrho; j += 64) {
-          double dx = sm[D.lds[L_DR] + j], x = sm[D.lds[L_XR] + j] + dx;
+          real dx = sm[D.lds[L_DR] + j], x = sm[D.lds[L_XR] + j] + dx;
           sm[D.lds[L_XR] + j] = x;
           big = QPC_FABS(x) > big ? QPC_FABS(x) : big;
           dbig = QPC_FABS(dx) > dbig ? QPC_FABS(dx) : dbig;
@@ -829,12 +876,12 @@ template <class P> struct Solver {
       // slowly but steadily contracting sequence (Hessian eigenvalues comparable to eps, e.g.
       // friction coefficients near zero) is allowed up to 5x the nominal sweep count.
       if (it > 0) {
-        const double tol = 1e-13 * (1.0 + rbig);
+        const real tol = QPC_T_STOP * (1.0 + rbig);
         if (!(rdbig > tol)) break;
         // first correction of an already polished iterate: its size IS the error estimate of that
         // iterate, and the corrected one is better by the contraction factor (<= 1e-5)
-        if (from_current && it == 1 && !(rdbig > 1e-9 * (1.0 + rbig))) { confirmed = true; break; }
-        if (rdbig > 0.25 * prev_dbig && rdbig < 1e-9 * (1.0 + rbig)) break;
+        if (from_current && it == 1 && !(rdbig > QPC_T_CONFIRM * (1.0 + rbig))) { confirmed = true; break; }
+        if (rdbig > 0.25 * prev_dbig && rdbig < QPC_T_CONFIRM * (1.0 + rbig)) break;
         if (rdbig > 0.95 * prev_dbig) break;
         if (it >= 2 && rdbig * (rdbig / prev_dbig) < tol) break;
         if (it >= refine && !(rdbig > 0.25 * prev_dbig)) break; // nominal budget spent and not in the slow regime
@@ -849,42 +896,42 @@ template <class P> struct Solver {
   QPC_FN void rho_back(bool base, bool need_kr, int section = PS_KKT, bool prox = false) {
     const int N = D.N, nrho = D.nrho, m1 = D.m1;
     const int outr = base ? D.lds[L_XR] : D.lds[L_DR], outl = (base ? D.lds[L_LAM] : D.lds[L_DL]) + m1;
-    double rg = 0.0, rx = 0.0, rd = 0.0;
+    real rg = 0.0, rx = 0.0, rd = 0.0;
     if (N == 4 && nrho <= 64) {
       // N = 4: the four rays of a contact sit in the four lanes of a quad, so each lane computes ITS (G' lam_w)_j and
       // ITS rho_j only and takes the other three from its quad with DPP quad_perm moves -- a quarter of the dot products
       // and LDS reads of the general form below, same operations in the same order (bit-identical results)
       QPC_LANE_ARRAY(q4_, 10); // [0..3] w of the quad, [4..7] rho of the quad, [8] own value in flight, [9] (G' lam_w)_j
       QPC_PHASE(lane) {
-        double *q = QPC_LA(q4_, lane);
+        real *q = QPC_LA(q4_, lane);
         const int j = lane < nrho ? lane : 0;
-        double wj = dotp(sm + D.lds[L_G] + j, QPC_GS(nrho), sm + outl, 1, 6);
+        real wj = dotp(sm + D.lds[L_G] + j, QPC_GS(nrho), sm + outl, 1, 6);
         q[9] = wj;
         if (need_kr) wj += sm[D.lds[L_RR] + j];
         q[8] = wj;
       } QPC_END_PHASE
       QPC_QUAD_GATHER(lane, QPC_LA(q4_, lane), QPC_LA(q4_, lane)[8])
       QPC_PHASE(lane) {
-        double *q = QPC_LA(q4_, lane);
+        real *q = QPC_LA(q4_, lane);
         const int j = lane < nrho ? lane : 0;
-        double acc = 0.0;
+        real acc = 0.0;
         for (int i = 0; i < 4; i++) acc += sm[D.lds[L_KR] + QPC_CS(4) * (j / 4) + 4 * (j % 4) + i] * q[i]; // row jj of K_c: KR[c][jj][i] at 16 c + 4 jj + i
         if (base && sm[D.lds[L_WS] + j] == 1.0) acc += sm[D.lds[L_HI] + j];
         q[8] = acc;
       } QPC_END_PHASE
       QPC_QUAD_GATHER(lane, QPC_LA(q4_, lane) + 4, QPC_LA(q4_, lane)[8])
       QPC_PHASE(lane) {
-        const double *q = QPC_LA(q4_, lane);
-        double g = 0.0, xm = 0.0, dm = 0.0;
+        const real *q = QPC_LA(q4_, lane);
+        real g = 0.0, xm = 0.0, dm = 0.0;
         if (lane < nrho) {
           const int j = lane;
-          const double rho_j = q[8];
-          if (prox) dm = QPC_FABS(rho_j - (double)sm[outr + j]);
+          const real rho_j = q[8];
+          if (prox) dm = QPC_FABS(rho_j - (real)sm[outr + j]);
           sm[outr + j] = rho_j;
           if (base) {
-            double gl = -q[9];
+            real gl = -q[9];
             for (int i = 0; i < 4; i++) gl += sm[D.lds[L_HR] + QPC_CSH(4) * (j / 4) + 4 * (j % 4) + i] * q[4 + i];
-            const double wsj = sm[D.lds[L_WS] + j];
+            const real wsj = sm[D.lds[L_WS] + j];
             sm[D.lds[L_U] + j] = (wsj == -1.0) ? gl : ((wsj == 1.0) ? -gl : 0.0);
             g = QPC_FABS(gl);
             xm = QPC_FABS(rho_j);
@@ -900,27 +947,27 @@ template <class P> struct Solver {
     }
     QPC_PHASE(lane) { // rho_F = K (r_r + G' lam_w) (+ rho_fix); each lane rebuilds its contact's N rho's,
                       // and in base mode also its multiplier u_j = +-(H_rho rho - G' lam_w)_j
-      double g = 0.0, xm = 0.0, dm = 0.0;
+      real g = 0.0, xm = 0.0, dm = 0.0;
       for (int j = lane; j < nrho; j += 64) {
         int c = j / N, jj = j % N;
-        double w[8], rho_c[8];
+        real w[8], rho_c[8];
         for (int i = 0; i < N; i++) {
           w[i] = dotp(sm + D.lds[L_G] + c * N + i, QPC_GS(nrho), sm + outl, 1, 6);
           if (i == jj) g = w[i]; // (G' lam_w)_j, reused below
           if (need_kr) w[i] += sm[D.lds[L_RR] + c * N + i];
         }
         for (int i2 = 0; i2 < N; i2++) {
-          double acc = 0.0;
+          real acc = 0.0;
           for (int i = 0; i < N; i++) acc += sm[D.lds[L_KR] + c * QPC_CS(N) + i2 * N + i] * w[i];
           if (base && sm[D.lds[L_WS] + c * N + i2] == 1.0) acc += sm[D.lds[L_HI] + c * N + i2];
           rho_c[i2] = acc;
         }
-        if (prox) { const double dl_ = QPC_FABS(rho_c[jj] - (double)sm[outr + j]); dm = dl_ > dm ? dl_ : dm; }
+        if (prox) { const real dl_ = QPC_FABS(rho_c[jj] - (real)sm[outr + j]); dm = dl_ > dm ? dl_ : dm; }
         sm[outr + j] = rho_c[jj];
         if (base) {
-          double gl = -g;
+          real gl = -g;
           for (int i = 0; i < N; i++) gl += sm[D.lds[L_HR] + c * QPC_CSH(N) + jj * N + i] * rho_c[i];
-          double wsj = sm[D.lds[L_WS] + j];
+          real wsj = sm[D.lds[L_WS] + j];
           sm[D.lds[L_U] + j] = (wsj == -1.0) ? gl : ((wsj == 1.0) ? -gl : 0.0);
           g = QPC_FABS(gl);
           xm = QPC_FABS(rho_c[jj]);
@@ -942,19 +989,19 @@ template <class P> struct Solver {
   // refined full solve at the end.
   //   base = true : EQP of the working set (r_r = -(H_rho rho_fix)_F), result -> L_XR, L_LAM[m1..]
   //   base = false: Goldfarb-Idnani direction for r_r = nsign * e_p,   result -> L_DR, L_DL[m1..]
-  QPC_FN void rho_solve(bool base, int p, double nsign, bool any_upper, bool prox = false, int section = PS_KKT) {
+  QPC_FN void rho_solve(bool base, int p, real nsign, bool any_upper, bool prox = false, int section = PS_KKT) {
     const int N = D.N, nrho = D.nrho, m1 = D.m1;
     const int outr = base ? D.lds[L_XR] : D.lds[L_DR], outl = (base ? D.lds[L_LAM] : D.lds[L_DL]) + m1;
     QPC_PROF_ACC(PS_LOGIC);
     const bool need_kr = !base || any_upper || prox;
-    const double eps_prox = prox ? (double)sm[D.lds[L_MISC] + MS_EPS] : 0.0;
+    const real eps_prox = prox ? (real)sm[D.lds[L_MISC] + MS_EPS] : 0.0;
     if (need_kr && base && N == 4 && nrho <= 64) {
       // quad form (see rho_back): each lane its own r_r(j), the other three of the contact through DPP
       QPC_LANE_ARRAY(r4_, 5); // [0..3] r_r of the quad, [4] own
       QPC_PHASE(lane) {
         const int j = lane < nrho ? lane : 0;
-        const double wsj = sm[D.lds[L_WS] + j];
-        double rr = (wsj == 0.0) ? -dot_fix(D.lds[L_HR] + QPC_CSH(4) * (j / 4) + 4 * (j % 4), 1, 4 * (j / 4), 4) : 0.0;
+        const real wsj = sm[D.lds[L_WS] + j];
+        real rr = (wsj == 0.0) ? -dot_fix(D.lds[L_HR] + QPC_CSH(4) * (j / 4) + 4 * (j % 4), 1, 4 * (j / 4), 4) : 0.0;
         // proximal sweep: the eps of K = (H_FF + eps I)^-1 is compensated by eps * rho_prev
         if (prox && wsj == 0.0) rr += eps_prox * sm[D.lds[L_XR] + j];
         if (lane < nrho) sm[D.lds[L_RR] + j] = rr;
@@ -964,9 +1011,9 @@ template <class P> struct Solver {
       QPC_PHASE(lane) {
         if (lane < nrho) {
           const int j = lane;
-          const double *r4 = QPC_LA(r4_, lane);
-          const double fix = (sm[D.lds[L_WS] + j] == 1.0) ? (double)sm[D.lds[L_HI] + j] : 0.0;
-          double acc = 0.0;
+          const real *r4 = QPC_LA(r4_, lane);
+          const real fix = (sm[D.lds[L_WS] + j] == 1.0) ? (real)sm[D.lds[L_HI] + j] : 0.0;
+          real acc = 0.0;
           for (int i = 0; i < 4; i++) acc += sm[D.lds[L_KR] + QPC_CS(4) * (j / 4) + 4 * (j % 4) + i] * r4[i];
           sm[D.lds[L_TR1] + j] = acc + fix;
         }
@@ -975,12 +1022,12 @@ template <class P> struct Solver {
       QPC_PHASE(lane) { // TR1 = K r_r + rho_fix ; RR kept for the back-substitution
         for (int j = lane; j < nrho; j += 64) {
           int c = j / N, jj = j % N;
-          double acc = 0.0, fix = 0.0;
+          real acc = 0.0, fix = 0.0;
           if (base) {
-            fix = (sm[D.lds[L_WS] + j] == 1.0) ? (double)sm[D.lds[L_HI] + j] : 0.0;
+            fix = (sm[D.lds[L_WS] + j] == 1.0) ? (real)sm[D.lds[L_HI] + j] : 0.0;
             // r_r(i) = -(H rho_fix)_i on free i ;  acc = sum_i K[jj][i] r_r(i)
             for (int i = 0; i < N; i++) {
-              double rr = (sm[D.lds[L_WS] + c * N + i] == 0.0) ? -dot_fix(D.lds[L_HR] + c * QPC_CSH(N) + i * N, 1, c * N, N) : 0.0;
+              real rr = (sm[D.lds[L_WS] + c * N + i] == 0.0) ? -dot_fix(D.lds[L_HR] + c * QPC_CSH(N) + i * N, 1, c * N, N) : 0.0;
               // proximal sweep: the eps of K = (H_FF + eps I)^-1 is compensated by eps * rho_prev
               if (prox && sm[D.lds[L_WS] + c * N + i] == 0.0) rr += eps_prox * sm[D.lds[L_XR] + c * N + i];
               acc += sm[D.lds[L_KR] + c * QPC_CS(N) + jj * N + i] * rr;
@@ -997,7 +1044,7 @@ template <class P> struct Solver {
     if (need_kr) {
       QPC_PHASE(lane) { // u = u0 - G (K r_r + rho_fix)   (temporary in L_C22[0..5])
         if (lane < 6) {
-          double u = base ? (double)sm[D.lds[L_MISC] + MS_U0 + lane] : 0.0;
+          real u = base ? (real)sm[D.lds[L_MISC] + MS_U0 + lane] : 0.0;
           u -= dotp(sm + D.lds[L_G] + lane * QPC_GS(nrho), 1, sm + D.lds[L_TR1], 1, nrho);
           sm[D.lds[L_C22] + lane] = u;
         }
@@ -1036,16 +1083,16 @@ template <class P> struct Solver {
     int k = 0;
     if (!c_valid) compute_c();
     if (use_rho) {
-      double prev = 1e300;
+      real prev = QPC_HUGE;
       for (k = 1; k <= 10; k++) {
         rho_solve(true, 0, 0.0, any_upper, true, PS_P_PROX);
-        const double tol = 1e-13 * (1.0 + last_xmax);
+        const real tol = QPC_T_STOP * (1.0 + last_xmax);
         if (!(last_dmax > tol)) break;
         // the first sweep's correction IS the eps bias of the search's solution, i.e. the contraction factor times |rho|:
         // at <= 1e-4 the iterate is already 1e-8 accurate and the confirming sweep of the full system (contraction again)
         // finishes the job -- no second proximal sweep
 #ifndef QPC_EXP_PROX2
-        if (k == 1 && !(last_dmax > 1e-4 * (1.0 + last_xmax))) break;
+        if (k == 1 && !(last_dmax > QPC_T_PROX1 * (1.0 + last_xmax))) break;
 #endif
         if (k >= 2 && last_dmax * (last_dmax / prev) < tol) break;
         if (last_dmax > 0.95 * prev) break; // rounding floor / no progress
@@ -1054,7 +1101,7 @@ template <class P> struct Solver {
       if (m1 > 0) {
       QPC_PHASE(lane) { // lam_1 = S11^-1 c_1 - Z lam_w
         for (int r = lane; r < m1; r += 64) {
-          double acc = dotp(sm + D.lds[L_SM] + r * D.ms, 1, sm + D.lds[L_T1], 1, m1);
+          real acc = dotp(sm + D.lds[L_SM] + r * D.ms, 1, sm + D.lds[L_T1], 1, m1);
           if (nw) acc -= dotp(sm + D.lds[L_X2] + r * 6, 1, sm + D.lds[L_LAM] + m1, 1, 6);
           sm[D.lds[L_LAM] + r] = acc;
         }
@@ -1068,7 +1115,7 @@ template <class P> struct Solver {
         sm[D.lds[L_XV] + f] = -sm[D.lds[L_SQH] + f] * sm[D.lds[L_GV] + f] - dotp(sm + D.lds[L_M] + f, D.nfs, sm + D.lds[L_LAM], 1, m);
       for (int s = lane; s < ne; s += 64) {
         int d = slack_dim(s), wr = slack_woff(s), s0 = slack_s0(s);
-        double acc = 0.0;
+        real acc = 0.0;
         for (int i = 0; i < d; i++) acc += sm[D.lds[L_WINV] + wr + i] * sm[D.lds[L_LAM] + slack_row(s0 + i)];
         sm[D.lds[L_XE] + s] = acc;
       }
@@ -1086,13 +1133,13 @@ template <class P> struct Solver {
       for (int f = lane; f < nf; f += 64) sm[D.lds[L_RV] + f] = -sm[D.lds[L_GV] + f];
       for (int s = lane; s < ne; s += 64) sm[D.lds[L_RE] + s] = 0.0;
       for (int r = lane; r < m; r += 64) {
-        double acc = sm[D.lds[L_D] + r];
+        real acc = sm[D.lds[L_D] + r];
         if (r >= m1 && use_rho) acc += dot_fix(D.lds[L_G] + (r - m1) * QPC_GS(nrho), 1, 0, nrho);
         sm[D.lds[L_RC] + r] = acc;
       }
       for (int j = lane; j < nrho; j += 64) {
         int c = j / N, jj = j % N;
-        double acc = 0.0;
+        real acc = 0.0;
         if (sm[D.lds[L_WS] + j] == 0.0) acc = -dot_fix(D.lds[L_HR] + c * QPC_CSH(N) + jj * N, 1, c * N, N);
         sm[D.lds[L_RR] + j] = acc;
       }
@@ -1108,7 +1155,7 @@ template <class P> struct Solver {
       for (int s = lane; s < ne; s += 64) sm[D.lds[L_XE] + s] = sm[D.lds[L_DE] + s];
       for (int r = lane; r < m; r += 64) sm[D.lds[L_LAM] + r] = sm[D.lds[L_DL] + r];
       for (int j = lane; j < nrho; j += 64)
-        sm[D.lds[L_XR] + j] = sm[D.lds[L_DR] + j] + ((sm[D.lds[L_WS] + j] == 1.0) ? (double)sm[D.lds[L_HI] + j] : 0.0);
+        sm[D.lds[L_XR] + j] = sm[D.lds[L_DR] + j] + ((sm[D.lds[L_WS] + j] == 1.0) ? (real)sm[D.lds[L_HI] + j] : 0.0);
     } QPC_END_PHASE
     QPC_PROF_ACC(PS_UPDATE);
   }
@@ -1116,18 +1163,18 @@ template <class P> struct Solver {
 
 // rotation_vector(R) (angle * axis), the error term of the orientation PD law (standing.jl:74-76).
 // Branch on the angle like a robust log map: sin-based formula away from pi, diagonal-based near pi.
-QPC_FN void rotation_vector(const double *R, double *rv) {
-  const double ax = R[7] - R[5], ay = R[2] - R[6], az = R[3] - R[1]; // 2 sin(th) * axis
-  const double s2 = QPC_SQRT(ax * ax + ay * ay + az * az);          // 2 sin(th)
-  const double c2 = R[0] + R[4] + R[8] - 1.0;                      // 2 cos(th)
-  const double th = QPC_ATAN2(s2, c2);
+QPC_FN void rotation_vector(const real *R, real *rv) {
+  const real ax = R[7] - R[5], ay = R[2] - R[6], az = R[3] - R[1]; // 2 sin(th) * axis
+  const real s2 = QPC_SQRT(ax * ax + ay * ay + az * az);          // 2 sin(th)
+  const real c2 = R[0] + R[4] + R[8] - 1.0;                      // 2 cos(th)
+  const real th = QPC_ATAN2(s2, c2);
   if (s2 < 1e-12 && c2 > 0.0) { rv[0] = 0.5 * ax; rv[1] = 0.5 * ay; rv[2] = 0.5 * az; return; } // th -> 0
-  if (s2 > 1e-6) { const double k = th / s2; rv[0] = k * ax; rv[1] = k * ay; rv[2] = k * az; return; }
+  if (s2 > 1e-6) { const real k = th / s2; rv[0] = k * ax; rv[1] = k * ay; rv[2] = k * az; return; }
   // th near pi: axis from the diagonal, signs from the off-diagonal sums
-  const double cth = 0.5 * c2;
-  double x = QPC_SQRT((R[0] - cth) / (1.0 - cth) > 0.0 ? (R[0] - cth) / (1.0 - cth) : 0.0);
-  double y = QPC_SQRT((R[4] - cth) / (1.0 - cth) > 0.0 ? (R[4] - cth) / (1.0 - cth) : 0.0);
-  double z = QPC_SQRT((R[8] - cth) / (1.0 - cth) > 0.0 ? (R[8] - cth) / (1.0 - cth) : 0.0);
+  const real cth = 0.5 * c2;
+  real x = QPC_SQRT((R[0] - cth) / (1.0 - cth) > 0.0 ? (R[0] - cth) / (1.0 - cth) : 0.0);
+  real y = QPC_SQRT((R[4] - cth) / (1.0 - cth) > 0.0 ? (R[4] - cth) / (1.0 - cth) : 0.0);
+  real z = QPC_SQRT((R[8] - cth) / (1.0 - cth) > 0.0 ? (R[8] - cth) / (1.0 - cth) : 0.0);
   if (x >= y && x >= z) { if (R[1] + R[3] < 0.0) y = -y; if (R[2] + R[6] < 0.0) z = -z; if (ax < 0.0) { x = -x; y = -y; z = -z; } }
   else if (y >= z) { if (R[1] + R[3] < 0.0) x = -x; if (R[5] + R[7] < 0.0) z = -z; if (ay < 0.0) { x = -x; y = -y; z = -z; } }
   else { if (R[2] + R[6] < 0.0) x = -x; if (R[5] + R[7] < 0.0) y = -y; if (az < 0.0) { x = -x; y = -y; z = -z; } }
@@ -1137,10 +1184,10 @@ QPC_FN void rotation_vector(const double *R, double *rv) {
 // desired entry i from the caller (setdesired!) or from a law that only needs (q, v):
 // constant, joint-space PD kp (ref - q) - kd v (standing.jl:80-86).  COM / orientation laws need
 // the kinematics and are filled in later (desired_late); until then the entry is 0.
-QPC_FN double desired_early(const QpcDims &D, const int *IT, const double *DT, const TickIO &io, int i) {
+QPC_FN real desired_early(const QpcDims &D, const int *IT, qpc_dtab DT, const TickIO &io, int i) {
   if (D.n_des_inputs == D.n_desired) return io.desired[i];
   const int *li = IT + D.it[IT_LAW] + 3 * i;
-  const double *ld_ = DT + D.dt[DT_LAW] + 3 * i;
+  qpc_dtab ld_ = DT + D.dt[DT_LAW] + 3 * i;
   const int kind = li[0];
   if (kind == QPC_LAW_INPUT) return io.desired[i];
   if (kind == QPC_LAW_CONSTANT) return ld_[2];
@@ -1149,11 +1196,11 @@ QPC_FN double desired_early(const QpcDims &D, const int *IT, const double *DT, c
     // orientation PD of the floating body on the world (standing.jl:72-77): R = Rf R(quaternion), omega_body = v[v0 .. v0 + 2]
     const int body = li[1], a = li[2], nb = D.nb;
     const int q0 = IT[D.it[IT_QOFF] + body], v0 = IT[D.it[IT_VOFF] + body];
-    const double w = io.q[q0], x = io.q[q0 + 1], y = io.q[q0 + 2], z = io.q[q0 + 3];
-    const double Rj[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+    const real w = io.q[q0], x = io.q[q0 + 1], y = io.q[q0 + 2], z = io.q[q0 + 3];
+    const real Rj[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
                           2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
                           2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)};
-    double Rf[9], H[9], rv[3];
+    real Rf[9], H[9], rv[3];
     for (int k = 0; k < 9; k++) Rf[k] = DT[D.dt[DT_RF] + k * nb + body];
     mm3(Rf, Rj, H);
     rotation_vector(H, rv);
@@ -1170,73 +1217,73 @@ QPC_FN double desired_early(const QpcDims &D, const int *IT, const double *DT, c
 //   gains: ka, da (angular), kl, dl (linear), all expressed in the body frame (test/controller.jl:13)
 // out[6] = Tdref + pd(gains, H, Href, T, Tref): desired spatial acceleration of body w.r.t. base in the body frame.
 // The SE(3) PD law itself lives in the un-vendored RigidBodyDynamics.PDControl; restated as in api.SE3PDController
-// (double-geodesic law: e = inv(Href) H, edot = T - Ad(inv(e)) Tref).
+// (real-geodesic law: e = inv(Href) H, edot = T - Ad(inv(e)) Tref).
 template <class PR>
-QPC_FN void se3_pd_law(PR rec, const double *Hb, const double *Ha, const double *Tb, const double *Ta, double ka, double da,
-                       double kl, double dl, double *out) {
-  const double t = rec[0], x0 = rec[1], xf = rec[2];
+QPC_FN void se3_pd_law(PR rec, const real *Hb, const real *Ha, const real *Tb, const real *Ta, real ka, real da,
+                       real kl, real dl, real *out) {
+  const real t = rec[0], x0 = rec[1], xf = rec[2];
   // theta = clamp((t - x0) / (xf - x0), 0, 1) and its derivative (interpolated.jl:29-40)
-  const double dx = xf - x0;
-  double th = (t - x0) / dx, dth = 1.0 / dx;
+  const real dx = xf - x0;
+  real th = (t - x0) / dx, dth = 1.0 / dx;
   if (th <= 0.0) { th = 0.0; dth = 0.0; } else if (th >= 1.0) { th = 1.0; dth = 0.0; }
   // alpha(theta) = sum c_i theta^i and two derivatives (PolyDerivEvaluator; identity = 0,1,0,...)
-  double c[6];
+  real c[6];
   for (int i = 0; i < 6; i++) c[i] = rec[3 + i];
-  const double al = c[0] + th * (c[1] + th * (c[2] + th * (c[3] + th * (c[4] + th * c[5]))));
-  const double a1 = c[1] + th * (2.0 * c[2] + th * (3.0 * c[3] + th * (4.0 * c[4] + th * 5.0 * c[5])));
-  const double a2 = 2.0 * c[2] + th * (6.0 * c[3] + th * (12.0 * c[4] + th * 20.0 * c[5]));
-  const double ax = a1 * dth, axx = a2 * dth * dth; // chain rule: higher derivatives of theta vanish (interpolated.jl:47-51)
+  const real al = c[0] + th * (c[1] + th * (c[2] + th * (c[3] + th * (c[4] + th * c[5]))));
+  const real a1 = c[1] + th * (2.0 * c[2] + th * (3.0 * c[3] + th * (4.0 * c[4] + th * 5.0 * c[5])));
+  const real a2 = 2.0 * c[2] + th * (6.0 * c[3] + th * (12.0 * c[4] + th * 20.0 * c[5]));
+  const real ax = a1 * dth, axx = a2 * dth * dth; // chain rule: higher derivatives of theta vanish (interpolated.jl:47-51)
   // linear part: p = p0 + alpha (pf - p0) (interpolated.jl:60-65)
-  double p[3], pd[3], pdd[3];
-  for (int i = 0; i < 3; i++) { const double d = rec[20 + i] - rec[17 + i]; p[i] = rec[17 + i] + al * d; pd[i] = d * ax; pdd[i] = d * axx; }
+  real p[3], pd[3], pdd[3];
+  for (int i = 0; i < 3; i++) { const real d = rec[20 + i] - rec[17 + i]; p[i] = rec[17 + i] + al * d; pd[i] = d * ax; pdd[i] = d * axx; }
   // angular part: y = y0 * Quat(AngleAxis(alpha * angle, axis)), dy/dalpha = axis * angle (interpolated.jl:72-83)
-  const double w0 = rec[9], x0q = rec[10], y0q = rec[11], z0q = rec[12], w1 = rec[13], x1 = rec[14], y1 = rec[15], z1 = rec[16];
+  const real w0 = rec[9], x0q = rec[10], y0q = rec[11], z0q = rec[12], w1 = rec[13], x1 = rec[14], y1 = rec[15], z1 = rec[16];
   // qd = inv(y0) * yf
-  double dw = w0 * w1 + x0q * x1 + y0q * y1 + z0q * z1;
-  double dv[3] = {w0 * x1 - x0q * w1 - y0q * z1 + z0q * y1, w0 * y1 + x0q * z1 - y0q * w1 - z0q * x1, w0 * z1 - x0q * y1 + y0q * x1 - z0q * w1};
+  real dw = w0 * w1 + x0q * x1 + y0q * y1 + z0q * z1;
+  real dv[3] = {w0 * x1 - x0q * w1 - y0q * z1 + z0q * y1, w0 * y1 + x0q * z1 - y0q * w1 - z0q * x1, w0 * z1 - x0q * y1 + y0q * x1 - z0q * w1};
   // no hemisphere flip: Rotations 0.13.0 (Manifest.toml:136-140) converts with theta = 2 atan(|v|, w), so a relative
   // quaternion with w < 0 gives an angle in (pi, 2 pi] about v / |v| -- the LONG arc, same end point
-  const double sn = QPC_SQRT(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2]);
-  const double angle = 2.0 * QPC_ATAN2(sn, dw);
-  double axis[3] = {1.0, 0.0, 0.0};
-  if (sn > 1e-300) { axis[0] = dv[0] / sn; axis[1] = dv[1] / sn; axis[2] = dv[2] / sn; }
-  double sh, ch;
+  const real sn = QPC_SQRT(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2]);
+  const real angle = 2.0 * QPC_ATAN2(sn, dw);
+  real axis[3] = {1.0, 0.0, 0.0};
+  if (sn > QPC_TINY) { axis[0] = dv[0] / sn; axis[1] = dv[1] / sn; axis[2] = dv[2] / sn; }
+  real sh, ch;
   QPC_SINCOS(0.5 * al * angle, sh, ch);
-  const double iw = ch, ix = sh * axis[0], iy = sh * axis[1], iz = sh * axis[2];
-  const double qw = w0 * iw - x0q * ix - y0q * iy - z0q * iz, qx = w0 * ix + x0q * iw + y0q * iz - z0q * iy,
+  const real iw = ch, ix = sh * axis[0], iy = sh * axis[1], iz = sh * axis[2];
+  const real qw = w0 * iw - x0q * ix - y0q * iy - z0q * iz, qx = w0 * ix + x0q * iw + y0q * iz - z0q * iy,
                qy = w0 * iy - x0q * iz + y0q * iw + z0q * ix, qz = w0 * iz + x0q * iy - y0q * ix + z0q * iw;
-  const double Rr[9] = {1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qw * qz), 2 * (qx * qz + qw * qy),
+  const real Rr[9] = {1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qw * qz), 2 * (qx * qz + qw * qy),
                         2 * (qx * qy + qw * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qw * qx),
                         2 * (qx * qz - qw * qy), 2 * (qy * qz + qw * qx), 1 - 2 * (qx * qx + qy * qy)};
-  const double wbase[3] = {axis[0] * angle * ax, axis[1] * angle * ax, axis[2] * angle * ax};
-  const double wdbase[3] = {axis[0] * angle * axx, axis[1] * angle * axx, axis[2] * angle * axx};
+  const real wbase[3] = {axis[0] * angle * ax, axis[1] * angle * ax, axis[2] * angle * ax};
+  const real wdbase[3] = {axis[0] * angle * axx, axis[1] * angle * axx, axis[2] * angle * axx};
   // SE3Trajectory (se3.jl:8-27): everything re-expressed in the (desired) body frame
-  double wr[3], nur[3], wdr[3], nudr[3], cr[3];
+  real wr[3], nur[3], wdr[3], nudr[3], cr[3];
   mtv3(Rr, wbase, wr); mtv3(Rr, pd, nur); mtv3(Rr, wdbase, wdr); mtv3(Rr, pdd, nudr);
   cross3(wr, nur, cr);
   nudr[0] += cr[0]; nudr[1] += cr[1]; nudr[2] += cr[2];
   // state: H = relative_transform(body -> base), T = relative twist in the body frame (se3pdcontroller.jl:15-16)
-  double R[9], Rat[9], dpw[3], pr[3];
+  real R[9], Rat[9], dpw[3], pr[3];
   for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rat[3 * i + j] = Ha[3 * j + i];
   mm3(Rat, Hb, R);
   dpw[0] = Hb[9] - Ha[9]; dpw[1] = Hb[10] - Ha[10]; dpw[2] = Hb[11] - Ha[11];
   mtv3(Ha, dpw, pr);
-  double wrel[3] = {Tb[0] - Ta[0], Tb[1] - Ta[1], Tb[2] - Ta[2]}, vrel[3] = {Tb[3] - Ta[3], Tb[4] - Ta[4], Tb[5] - Ta[5]};
-  double wxp[3], Tang[3], Tlin[3];
+  real wrel[3] = {Tb[0] - Ta[0], Tb[1] - Ta[1], Tb[2] - Ta[2]}, vrel[3] = {Tb[3] - Ta[3], Tb[4] - Ta[4], Tb[5] - Ta[5]};
+  real wxp[3], Tang[3], Tlin[3];
   cross3(wrel, Hb + 9, wxp);
   vrel[0] += wxp[0]; vrel[1] += wxp[1]; vrel[2] += wxp[2];
   mtv3(Hb, wrel, Tang); mtv3(Hb, vrel, Tlin);
   // e = inv(Href) * H ; Tref seen from the actual body frame: Ad(inv(e))
-  double Re[9], Rrt[9], dpe[3] = {pr[0] - p[0], pr[1] - p[1], pr[2] - p[2]}, pe[3];
+  real Re[9], Rrt[9], dpe[3] = {pr[0] - p[0], pr[1] - p[1], pr[2] - p[2]}, pe[3];
   for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rrt[3 * i + j] = Rr[3 * j + i];
   mm3(Rrt, R, Re);
   mtv3(Rr, dpe, pe);
-  double Trang[3], tl[3], Trlin[3];
+  real Trang[3], tl[3], Trlin[3];
   mtv3(Re, wr, Trang);
   cross3(wr, pe, tl);
   tl[0] += nur[0]; tl[1] += nur[1]; tl[2] += nur[2];
   mtv3(Re, tl, Trlin);
-  double rv[3], Rtp[3];
+  real rv[3], Rtp[3];
   rotation_vector(Re, rv);
   mtv3(Re, pe, Rtp);
   for (int i = 0; i < 3; i++) {
@@ -1248,32 +1295,32 @@ QPC_FN void se3_pd_law(PR rec, const double *Hb, const double *Ha, const double 
 // Desired entries from laws that need the kinematics (standing.jl:60-77: centre-of-mass PD, pelvis orientation PD; SE3PDController
 // on the device), lane = desired entry: runs after the momentum phase (it reads L_AMOM, MS_COM, L_H, L_T) and before the rows of the
 // assembly read L_DES
-template <class P> QPC_FN void desired_late(const QpcDims &D, const int *IT, const double *DT, P sm, int lane, const double *hlin) {
+template <class P> QPC_FN void desired_late(const QpcDims &D, const int *IT, qpc_dtab DT, P sm, int lane, const real *hlin) {
   const int MISC = D.lds[L_MISC];
   for (int i = lane; i < D.n_desired; i += 64) {
     const int *li = IT + D.it[IT_LAW] + 3 * i;
-    const double *lw = DT + D.dt[DT_LAW] + 3 * i;
+    qpc_dtab lw = DT + D.dt[DT_LAW] + 3 * i;
     // (D.law_mask: the JIT-specialised kernel drops the laws this controller does not use -- the SE(3) law alone is ~1.4 k
     //  instructions and its live values used to push the register allocation of the whole tick into scratch)
     if (((D.law_mask >> QPC_LAW_COM_PD) & 1) && li[0] == QPC_LAW_COM_PD) { // m c̈,  c̈ = -kp (c - c_ref) - kd h_lin / m
       const int a = li[1];
-      const double hl = hlin[a]; // linear momentum of the robot: the sum of the bodies' own momenta (kinematics phase)
-      const double mt = DT[D.dt[DT_GRAV] + 3];
+      const real hl = hlin[a]; // linear momentum of the robot: the sum of the bodies' own momenta (kinematics phase)
+      const real mt = DT[D.dt[DT_GRAV] + 3];
       sm[D.lds[L_DES] + i] = mt * (-lw[0] * (sm[MISC + MS_COM + a] - lw[2])) - lw[1] * hl;
     } else if (((D.law_mask >> QPC_LAW_ORIENTATION_PD) & 1) && li[0] == QPC_LAW_ORIENTATION_PD) { // -kp rotation_vector(R) - kd R' omega (body frame)
       const int body = li[1], a = li[2];
-      double H[12], rv[3];
+      real H[12], rv[3];
       ldH(sm, D, body, H);
       rotation_vector(H, rv);
-      double wb = 0.0;
+      real wb = 0.0;
       for (int r = 0; r < 3; r++) wb += H[3 * r + a] * sm[D.lds[L_T] + 6 * body + r];
       sm[D.lds[L_DES] + i] = -lw[0] * rv[a] - lw[1] * wb;
     } else if (((D.law_mask >> QPC_LAW_SE3_PD) & 1) && li[0] == QPC_LAW_SE3_PD) { // SE3PDController on the device (se3pdcontroller.jl:13-18), lane = component
       const int body = (li[1] & 255) - 1, base = ((li[1] >> 8) & 255) - 1, a = (li[1] >> 16) & 7, rec0 = li[2] + 6;
-      double Hb[12], Ha[12], Tb[6], Ta[6], out[6];
+      real Hb[12], Ha[12], Tb[6], Ta[6], out[6];
       ldH(sm, D, body, Hb); ldH(sm, D, base, Ha);
       ld6(sm, D.lds[L_T], body, Tb); ld6(sm, D.lds[L_T], base, Ta);
-      const double *lwa = DT + D.dt[DT_LAW] + 3 * li[2], *lwl = lwa + 9; // gains of entries 0 (angular) and 3 (linear)
+      qpc_dtab lwa = DT + D.dt[DT_LAW] + 3 * li[2], lwl = lwa + 9; // gains of entries 0 (angular) and 3 (linear)
       se3_pd_law(sm + D.lds[L_DES] + rec0, Hb, Ha, Tb, Ta, lwa[0], lwa[1], lwl[0], lwl[1], out);
       sm[D.lds[L_DES] + i] = out[a];
     }
@@ -1322,15 +1369,15 @@ template <class P> QPC_FN bool qpc_presolve(const QpcDims &D, const QpcDims &DS,
   QPC_LANE_ARRAY(qc_, 6); // this lane's column; after the back-substitution: the solution for this right-hand side
   QPC_LANE_ARRAY(qv_, 6); // what the row shares
   QPC_PHASE(lane) {
-    double *col = QPC_LA(qc_, lane);
+    real *col = QPC_LA(qc_, lane);
     const int e = lane >> 4, cc = lane & 15;
     const int c0 = e == 1 ? D.pre_c0[1] : (e == 2 ? D.pre_c0[2] : (e == 3 ? D.pre_c0[3] : D.pre_c0[0])); // first column of my block
     QPC_UNROLL_FULL
     for (int i = 0; i < 6; i++) {
-      double v = 0.0;
+      real v = 0.0;
       if (e < n_e && cc < 7 + nf_s) {
         const int r = 6 * e + i;
-        v = cc == 6 ? (double)sm[D.lds[L_D] + r] : (double)sm[D.lds[L_M] + r * D.nfs + (cc < 6 ? c0 + cc : b0 + cc - 7)];
+        v = cc == 6 ? (real)sm[D.lds[L_D] + r] : (real)sm[D.lds[L_M] + r * D.nfs + (cc < 6 ? c0 + cc : b0 + cc - 7)];
       }
       col[i] = v;
     }
@@ -1339,16 +1386,16 @@ template <class P> QPC_FN bool qpc_presolve(const QpcDims &D, const QpcDims &DS,
   for (int k = 0; k < 5; k++) { // H_k = I - v v' / (alpha (alpha - x_k)), v = x - alpha e_k, alpha = -sign(x_k) |x|
     QPC_ROW_SHARE(lane, QPC_LA(qv_, lane), 6 - k, QPC_LA(qc_, lane) + k, k)
     QPC_PHASE(lane) {
-      double *col = QPC_LA(qc_, lane);
-      const double *x = QPC_LA(qv_, lane);
-      double nn = 0.0;
+      real *col = QPC_LA(qc_, lane);
+      const real *x = QPC_LA(qv_, lane);
+      real nn = 0.0;
       QPC_UNROLL_FULL
       for (int i = 0; i < 6 - k; i++) nn += x[i] * x[i];
-      const double nrm = nn > 0.0 ? nn * QPC_RSQRT(nn) : 0.0;
-      const double alpha = x[0] > 0.0 ? -nrm : nrm;
-      const double den = alpha * (alpha - x[0]);       // = v'v / 2 > 0 unless the column is zero
-      const double tinv = den > 0.0 ? QPC_RCP(den) : 0.0;
-      double w = (x[0] - alpha) * col[k];
+      const real nrm = nn > 0.0 ? nn * QPC_RSQRT(nn) : 0.0;
+      const real alpha = x[0] > 0.0 ? -nrm : nrm;
+      const real den = alpha * (alpha - x[0]);       // = v'v / 2 > 0 unless the column is zero
+      const real tinv = den > 0.0 ? QPC_RCP(den) : 0.0;
+      real w = (x[0] - alpha) * col[k];
       QPC_UNROLL_FULL
       for (int i = 1; i < 6 - k; i++) w += x[i] * col[k + i];
       w *= tinv;
@@ -1365,14 +1412,14 @@ template <class P> QPC_FN bool qpc_presolve(const QpcDims &D, const QpcDims &DS,
   for (int j = 5; j >= 0; j--) { // R z = Q'rhs: z_j = y_j / R_jj, y_i -= R_ij z_j (column j of R from lane j of the row)
     QPC_ROW_SHARE(lane, QPC_LA(qv_, lane), j + 1, QPC_LA(qc_, lane), j)
     QPC_PHASE(lane) {
-      double *col = QPC_LA(qc_, lane), *dd = QPC_LA(qd_, lane);
-      const double *rj = QPC_LA(qv_, lane);
-      if (j == 5) { dd[0] = 1e300; dd[1] = 0.0; }
-      const double a = QPC_FABS(rj[j]);
+      real *col = QPC_LA(qc_, lane), *dd = QPC_LA(qd_, lane);
+      const real *rj = QPC_LA(qv_, lane);
+      if (j == 5) { dd[0] = QPC_HUGE; dd[1] = 0.0; }
+      const real a = QPC_FABS(rj[j]);
       dd[0] = a < dd[0] ? a : dd[0];
       dd[1] = a > dd[1] ? a : dd[1];
       { // (only the right-hand-side lanes' results are used)
-        const double z = a > 0.0 ? col[j] * QPC_RCP(rj[j]) : 0.0;
+        const real z = a > 0.0 ? col[j] * QPC_RCP(rj[j]) : 0.0;
         col[j] = z;
         QPC_UNROLL_FULL
         for (int i = 0; i < j; i++) col[i] -= rj[i] * z;
@@ -1382,7 +1429,7 @@ template <class P> QPC_FN bool qpc_presolve(const QpcDims &D, const QpcDims &DS,
         const bool mine = e < n_e && cc >= 0 && cc <= nf_s;
         // (measured: the torques lose ~1e-14 / ratio^2; 1e-4 keeps them at 1e-11).  The running min / max ignore a NaN (both
         // comparisons are false), so the last diagonal entry is tested by itself and a NaN anywhere shows up in the solution
-        QPC_BALLOT_PUT(0, bbad, mine && (!(dd[0] > 1e-4 * dd[1]) || !(a == a) || !(col[0] == col[0]) || !(col[5] == col[5])));
+        QPC_BALLOT_PUT(0, bbad, mine && (!(dd[0] > QPC_T_QR * dd[1]) || !(a == a) || !(col[0] == col[0]) || !(col[5] == col[5])));
         if (mine) { // columns of Z': P, then the columns of Q, then P + g~ of the eliminated unknowns
           for (int i = 0; i < 6; i++) sm[PZ + cc * nr + 6 * e + i] = col[i];
           if (cc == 0)
@@ -1402,14 +1449,14 @@ template <class P> QPC_FN bool qpc_presolve(const QpcDims &D, const QpcDims &DS,
     const int nh = nf_s * (nf_s + 1) / 2, n1 = m_s * nf_s, n2 = n1 + m_s, n3 = n2 + nh, n_red = n3 + nf_s;
     if (lane < n_red) {
       int left, right, out;
-      double base, sgn = -1.0;
+      real base, sgn = -1.0;
       bool isrow = false; // left operand: a row of M, whose eliminated columns sit block by block at pre_c0[e] (not one after the other)
       if (lane < n2) { // a row that stays: its part in the eliminated columns against a column of Q (M^) or P (d^)
         const int rr = lane < n1 ? lane / nf_s : lane - n1, b = lane < n1 ? lane % nf_s : -1;
         left = D.lds[L_M] + (nr + rr) * D.nfs;
         isrow = true;
         right = PZ + (1 + b) * nr;
-        base = b >= 0 ? (double)sm[D.lds[L_M] + (nr + rr) * D.nfs + b0 + b] : (double)sm[D.lds[L_D] + nr + rr];
+        base = b >= 0 ? (real)sm[D.lds[L_M] + (nr + rr) * D.nfs + b0 + b] : (real)sm[D.lds[L_D] + nr + rr];
         out = D.lds[L_PA] + (b >= 0 ? rr * nf_s + b : m_s * nf_s + rr); // M^ (m_s x nf_s), then d^
       } else if (lane < n3) { // H'[a][b] = delta + <Q_a, Q_b>, packed lower
         int a = 0, b = lane - n2;
@@ -1423,7 +1470,7 @@ template <class P> QPC_FN bool qpc_presolve(const QpcDims &D, const QpcDims &DS,
         base = sm[D.lds[L_SQH] + b0 + b] * sm[D.lds[L_GV] + b0 + b];
         out = D.lds[L_PH] + nh + b;
       }
-      double dot = 0.0;
+      real dot = 0.0;
       QPC_UNROLL_FULL
       for (int e = 0; e < 4; e++)
         if (e < n_e) dot += dotp(sm + left + (isrow ? D.pre_c0[e] : 6 * e), 1, sm + right + 6 * e, 1, 6);
@@ -1438,24 +1485,24 @@ template <class P> QPC_FN bool qpc_presolve(const QpcDims &D, const QpcDims &DS,
       if (lane < nh + nf_s) {
         int a = 0, b = lane;
         if (lane < nh) { while (b > a) { a++; b -= a; } } else { a = lane - nh; b = -1; }
-        double acc = 0.0;
+        real acc = 0.0;
         QPC_UNROLL_FULL
         for (int s_ = 0; s_ < 6; s_++)
-          if (s_ < F) acc += sm[MH + s_ * nf_s + a] * sm[D.lds[L_W] + D.pre_wd[s_]] * (b >= 0 ? (double)sm[MH + s_ * nf_s + b] : (double)sm[DH + s_]);
+          if (s_ < F) acc += sm[MH + s_ * nf_s + a] * sm[D.lds[L_W] + D.pre_wd[s_]] * (b >= 0 ? (real)sm[MH + s_ * nf_s + b] : (real)sm[DH + s_]);
         const int o = D.lds[L_PH] + lane;
         sm[o] = sm[o] + (b >= 0 ? acc : -acc);
       }
     } QPC_END_PHASE
   }
   QPC_PHASE(lane) { // H' = C C' (every lane, in registers), C^-1; rows M^ C^-T, linear term C^-1 h
-    double c[10], ci[10], dinv[4]; // packed lower triangles (nf_s <= 4), 1 / C_aa
+    real c[10], ci[10], dinv[4]; // packed lower triangles (nf_s <= 4), 1 / C_aa
     const int PH = D.lds[L_PH], nh = nf_s * (nf_s + 1) / 2;
     QPC_UNROLL_FULL
     for (int a = 0; a < 4; a++) {
       QPC_UNROLL_FULL
       for (int b = 0; b <= a; b++) {
         if (a < nf_s) {
-          double acc = sm[PH + a * (a + 1) / 2 + b];
+          real acc = sm[PH + a * (a + 1) / 2 + b];
           QPC_UNROLL_FULL
           for (int j = 0; j < b; j++) acc -= c[a * (a + 1) / 2 + j] * c[b * (b + 1) / 2 + j];
           if (a == b) { dinv[a] = QPC_RSQRT(acc); c[a * (a + 1) / 2 + b] = acc * dinv[a]; } // H' >= I: no pivot can vanish
@@ -1468,7 +1515,7 @@ template <class P> QPC_FN bool qpc_presolve(const QpcDims &D, const QpcDims &DS,
       QPC_UNROLL_FULL
       for (int b = 0; b <= a; b++) { // row a of C^-1 by forward substitution on column b of the identity
         if (a < nf_s) {
-          double acc = a == b ? 1.0 : 0.0;
+          real acc = a == b ? 1.0 : 0.0;
           QPC_UNROLL_FULL
           for (int j = b; j < a; j++) acc -= c[a * (a + 1) / 2 + j] * ci[j * (j + 1) / 2 + b];
           ci[a * (a + 1) / 2 + b] = acc * dinv[a];
@@ -1483,15 +1530,15 @@ template <class P> QPC_FN bool qpc_presolve(const QpcDims &D, const QpcDims &DS,
       const bool isg = lane >= m_f * nf_s;
       const int rr = isg ? 0 : lane / nf_s, cc = isg ? lane - m_f * nf_s : lane % nf_s;
       const int src = isg ? PH + nh : MH + (F + rr) * nf_s;
-      double acc = 0.0;
+      real acc = 0.0;
       QPC_UNROLL_FULL
       for (int j = 0; j < 4; j++) {
-        double cij = 0.0; // C^-1[cc][j] picked with selects (cc is a lane value)
+        real cij = 0.0; // C^-1[cc][j] picked with selects (cc is a lane value)
         QPC_UNROLL_FULL
         for (int a = 0; a < 4; a++)
           if (a < nf_s && j <= a) cij = a == cc ? ci[a * (a + 1) / 2 + j] : cij;
         if (j < nf_s) {
-          acc += (j <= cc ? (double)sm[src + j] : 0.0) * cij;
+          acc += (j <= cc ? (real)sm[src + j] : 0.0) * cij;
           if (isg) sm[D.lds[L_PC] + cc * nf_s + j] = j <= cc ? cij : 0.0;
         }
       }
@@ -1512,17 +1559,17 @@ template <class P> QPC_FN unsigned long long qpc_postsolve(const QpcDims &D, con
   const int n_e = D.presolve, nf_s = D.pre_nf, nr = 6 * n_e;
   QPC_PHASE(lane) {
     if (lane < nr + nf_s) {
-      double xb[4] = {0.0, 0.0, 0.0, 0.0};
+      real xb[4] = {0.0, 0.0, 0.0, 0.0};
       QPC_UNROLL_FULL
       for (int b = 0; b < 4; b++) {
-        double acc = 0.0;
+        real acc = 0.0;
         QPC_UNROLL_FULL
         for (int cc = b; cc < 4; cc++)
           if (cc < nf_s) acc += sm[D.lds[L_PC] + cc * nf_s + b] * sm[DS.lds[L_XV] + cc];
         xb[b] = acc;
       }
       const bool elim = lane < nr;
-      double acc = elim ? (double)sm[D.lds[L_PZ] + lane] : 0.0;
+      real acc = elim ? (real)sm[D.lds[L_PZ] + lane] : 0.0;
       QPC_UNROLL_FULL
       for (int b = 0; b < 4; b++)
         if (b < nf_s) acc += elim ? -sm[D.lds[L_PZ] + (1 + b) * nr + lane] * xb[b] : (lane - nr == b ? xb[b] : 0.0);
@@ -1534,10 +1581,10 @@ template <class P> QPC_FN unsigned long long qpc_postsolve(const QpcDims &D, con
   QPC_PHASE(lane) {
     bool viol = false, isnan_ = false;
     if (lane < nr) {
-      const double d = sm[D.lds[L_D] + lane];
-      const double res = d - dotp(sm + D.lds[L_M] + lane * D.nfs, 1, sm + D.lds[L_XV], 1, D.nf);
+      const real d = sm[D.lds[L_D] + lane];
+      const real res = d - dotp(sm + D.lds[L_M] + lane * D.nfs, 1, sm + D.lds[L_XV], 1, D.nf);
       isnan_ = !(res == res);
-      viol = !(QPC_FABS(res) <= D.tol_accept * (1.0 + QPC_FABS(d)));
+      viol = !(QPC_FABS(res) <= (real)D.tol_accept * (1.0 + QPC_FABS(d)));
     }
     QPC_BALLOT_PUT(0, bviol, viol);
     QPC_BALLOT_PUT(1, bnan, isnan_);
@@ -1552,9 +1599,9 @@ template <class P> QPC_FN unsigned long long qpc_postsolve(const QpcDims &D, con
 template <class P> QPC_FN void qpc_tick_prologue(const QpcDims &D, const QpcDims &DS, const int *IT, P sm) {
   QPC_LANE_SCOPE
   QPC_PHASE(lane) {
-    for (int i = lane; i < D.m + 4 * D.ne; i += 64) sm[D.lds[L_HOT] + i] = (double)IT[D.it[IT_HOT] + i];
+    for (int i = lane; i < D.m + 4 * D.ne; i += 64) sm[D.lds[L_HOT] + i] = (real)IT[D.it[IT_HOT] + i];
     if (D.presolve)
-      for (int i = lane; i < DS.m + 4 * DS.ne; i += 64) sm[DS.lds[L_HOT] + i] = (double)IT[DS.it[IT_HOT] + i];
+      for (int i = lane; i < DS.m + 4 * DS.ne; i += 64) sm[DS.lds[L_HOT] + i] = (real)IT[DS.it[IT_HOT] + i];
   } QPC_END_PHASE
 }
 
@@ -1563,7 +1610,7 @@ template <class P> QPC_FN void qpc_tick_prologue(const QpcDims &D, const QpcDims
 // persists between ticks (momentum.jl:58 calls solve! on the same model every tick) -- and hands the final one back.
 // A search that fails from a warm set is repeated once from the cold start, so the answer never depends on the hint.
 template <class P, bool WARM = false>
-QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const double *DT, P sm, const TickIO &io) {
+QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, qpc_dtab DT, P sm, const TickIO &io) {
   QPC_LANE_SCOPE
   const int nb = D.nb, nq = D.nq, nv = D.nv, nf = D.nf, nc = D.nc, N = D.N, nrho = D.nrho, ne = D.ne;
   const int m = D.m, m1 = D.m1, nw = D.nw, ntask = D.ntask;
@@ -1588,7 +1635,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
   // no spills); HBM traffic per solve went from 13.9 KB to 1.9 KB, the algorithmic 1 968 B.
   QPC_LANE_ARRAY(keep_iw_, 16);
   QPC_LANE_ARRAY(keep_sk_, 6);
-  double hscale = 0.0, hinvmax = 0.0, eps = 0.0, eps_ve = 0.0;
+  real hscale = 0.0, hinvmax = 0.0, eps = 0.0, eps_ve = 0.0;
   unsigned long long bbad_in = 0ull, bneg_cap = 0ull;
   bool exact_ve = false, h_fast = false;
   const bool h_static_path = D.h_static;
@@ -1605,19 +1652,19 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
     for (int i = lane; i < nq; i += 64) sm[D.lds[L_Q] + i] = io.q[i];
     for (int i = lane; i < nv; i += 64) sm[D.lds[L_V] + i] = io.v[i];
     for (int i = lane; i < D.n_desired; i += 64) sm[D.lds[L_DES] + i] = desired_early(D, IT, DT, io, i);
-    double hc = 0.0; // this lane's share of the regularisation scale: 2 |weight| of its enabled contacts
+    real hc = 0.0; // this lane's share of the regularisation scale: 2 |weight| of its enabled contacts
     bool neg_cap = false;
     bool bad_in = false; // a NaN contact weight or cap: a NaN cap would otherwise read as "disabled" (hi > 0 is false) and
                          // the QP would be solved as if the caller had meant that
     for (int i = lane; i < nc; i += 64) {
-      const double cwi = io.cw[i], cmi = io.cmax[i];
+      const real cwi = io.cw[i], cmi = io.cmax[i];
       bad_in = bad_in || !(cwi == cwi) || !(cmi == cmi);
       neg_cap = neg_cap || cmi < 0.0; // 0 <= rho <= rho_max < 0 (contacts.jl:57) has no solution
       sm[D.lds[L_CW] + i] = cwi; sm[D.lds[L_CMAX] + i] = cmi;
       if (use_rho && cmi > 0.0 && 2.0 * QPC_FABS(cwi) > hc) hc = 2.0 * QPC_FABS(cwi);
       if (D.k_tab) {
         sm[MISC + MS_KS + i] = 2.0 * cwi; // scale of this contact's rho block of the Hessian (kr_blocks)
-        if (D.k_classes > 1) sm[MISC + MS_KS + 8 + i] = (double)(D.k_class[i] * 320);
+        if (D.k_classes > 1) sm[MISC + MS_KS + 8 + i] = (real)(D.k_class[i] * 320);
       }
     }
     for (int i = lane; i < D.n_tw; i += 64) sm[D.lds[L_TW] + i] = io.tw[i];
@@ -1631,10 +1678,10 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
   // copies of H (a max reduction over HV / W, then rsqrt / block inverses: 4 % of the tick) are only run in the general case
   if (h_static_path) {
     hscale = QPC_RED_MAX_GET(0, hscale);
-    if (D.h_static_max > hscale) hscale = D.h_static_max;
+    if ((real)D.h_static_max > hscale) hscale = (real)D.h_static_max;
     if (!(hscale > 0.0)) hscale = 1.0;
-    eps = D.eps_primal * hscale;
-    exact_ve = D.ve_exact_ok && (1e-6 * hscale <= D.h_static_min);
+    eps = (real)D.eps_primal * hscale;
+    exact_ve = D.ve_exact_ok && (QPC_T_EXACT * hscale <= (real)D.h_static_min);
     eps_ve = exact_ve ? 0.0 : eps;
     h_fast = exact_ve; // everything static is exact: HV, SQH, W, WINV come from the tables
   }
@@ -1644,34 +1691,34 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
   QPC_PHASE(lane) { // joint transforms: x_parent = Rf (Rj x + pj) + pf
     for (int i = lane; i < nv; i += 64) { // pinned accelerations (hard JointAccelerationTask, src/tasks.jl:185-189)
       const int pd = IT[D.it[IT_PDES_K] + i];
-      sm[D.lds[L_VD] + i] = pd >= 0 ? (double)sm[D.lds[L_DES] + pd] : 0.0;
+      sm[D.lds[L_VD] + i] = pd >= 0 ? (real)sm[D.lds[L_DES] + pd] : 0.0;
     }
     if (lane < nb) {
       const int i = lane;
       const int *mt = QPC_LI(M.v, lane);
       const int jt = MT_JT(mt), q0 = MT_Q0(mt);
-      double ax[3], Rf[9], pf[3]; // per-body constants, stored [component][body]
+      real ax[3], Rf[9], pf[3]; // per-body constants, stored [component][body]
       for (int k = 0; k < 3; k++) { ax[k] = DT[D.dt[DT_AXIS] + k * nb + i]; pf[k] = DT[D.dt[DT_PF] + k * nb + i]; }
       for (int k = 0; k < 9; k++) Rf[k] = DT[D.dt[DT_RF] + k * nb + i];
-      double Rj[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pj[3] = {0, 0, 0};
+      real Rj[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pj[3] = {0, 0, 0};
       if (jt == QPC_JOINT_REVOLUTE) {
-        double s, c;
+        real s, c;
         QPC_SINCOS(sm[D.lds[L_Q] + q0], s, c);
-        double C = 1 - c;
+        real C = 1 - c;
         Rj[0] = c + ax[0] * ax[0] * C; Rj[1] = ax[0] * ax[1] * C - ax[2] * s; Rj[2] = ax[0] * ax[2] * C + ax[1] * s;
         Rj[3] = ax[1] * ax[0] * C + ax[2] * s; Rj[4] = c + ax[1] * ax[1] * C; Rj[5] = ax[1] * ax[2] * C - ax[0] * s;
         Rj[6] = ax[2] * ax[0] * C - ax[1] * s; Rj[7] = ax[2] * ax[1] * C + ax[0] * s; Rj[8] = c + ax[2] * ax[2] * C;
       } else if (jt == QPC_JOINT_PRISMATIC) {
-        double qq = sm[D.lds[L_Q] + q0];
+        real qq = sm[D.lds[L_Q] + q0];
         pj[0] = ax[0] * qq; pj[1] = ax[1] * qq; pj[2] = ax[2] * qq;
       } else if (jt == QPC_JOINT_QUAT_FLOATING) {
-        double w = sm[D.lds[L_Q] + q0], x = sm[D.lds[L_Q] + q0 + 1], y = sm[D.lds[L_Q] + q0 + 2], z = sm[D.lds[L_Q] + q0 + 3];
+        real w = sm[D.lds[L_Q] + q0], x = sm[D.lds[L_Q] + q0 + 1], y = sm[D.lds[L_Q] + q0 + 2], z = sm[D.lds[L_Q] + q0 + 3];
         Rj[0] = 1 - 2 * (y * y + z * z); Rj[1] = 2 * (x * y - w * z); Rj[2] = 2 * (x * z + w * y);
         Rj[3] = 2 * (x * y + w * z); Rj[4] = 1 - 2 * (x * x + z * z); Rj[5] = 2 * (y * z - w * x);
         Rj[6] = 2 * (x * z - w * y); Rj[7] = 2 * (y * z + w * x); Rj[8] = 1 - 2 * (x * x + y * y);
         pj[0] = sm[D.lds[L_Q] + q0 + 4]; pj[1] = sm[D.lds[L_Q] + q0 + 5]; pj[2] = sm[D.lds[L_Q] + q0 + 6];
       }
-      double H[12];
+      real H[12];
       mm3(Rf, Rj, H);
       mv3(Rf, pj, H + 9);
       H[9] += pf[0]; H[10] += pf[1]; H[11] += pf[2];
@@ -1682,7 +1729,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
   QPC_PHASE(lane) { // transform_to_root by walking the (register-resident) ancestor chain
     if (lane < nb) {
       const int *mt = QPC_LI(M.v, lane);
-      double H[12], A[12], t[3];
+      real H[12], A[12], t[3];
       ld(sm + D.lds[L_RL] + 12 * lane, 12, H);
       QPC_UNROLL_JIT
       for (int s = 0; s < QPC_MAXD; s++) {
@@ -1703,36 +1750,36 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
       const int i = lane;
       const int *mt = QPC_LI(M.v, lane);
       const int jt = MT_JT(mt), v0 = MT_V0(mt), n = MT_NVJ(mt);
-      double H[12], tj[6] = {0, 0, 0, 0, 0, 0};
+      real H[12], tj[6] = {0, 0, 0, 0, 0, 0};
       ld(sm + D.lds[L_H] + 12 * i, 12, H);
-      const double ax[3] = {DT[D.dt[DT_AXIS] + i], DT[D.dt[DT_AXIS] + nb + i], DT[D.dt[DT_AXIS] + 2 * nb + i]};
+      const real ax[3] = {DT[D.dt[DT_AXIS] + i], DT[D.dt[DT_AXIS] + nb + i], DT[D.dt[DT_AXIS] + 2 * nb + i]};
       for (int c = 0; c < n; c++) {
-        double S[6] = {0, 0, 0, 0, 0, 0};
+        real S[6] = {0, 0, 0, 0, 0, 0};
         if (jt == QPC_JOINT_REVOLUTE) { mv3(H, ax, S); cross3(H + 9, S, S + 3); }
         else if (jt == QPC_JOINT_PRISMATIC) { mv3(H, ax, S + 3); }
         else { // quaternion floating: columns of Ad(H)
           int cc = c % 3;
-          double col[3] = {H[cc], H[3 + cc], H[6 + cc]};
+          real col[3] = {H[cc], H[3 + cc], H[6 + cc]};
           if (c < 3) { S[0] = col[0]; S[1] = col[1]; S[2] = col[2]; cross3(H + 9, col, S + 3); }
           else { S[3] = col[0]; S[4] = col[1]; S[5] = col[2]; }
         }
         st(sm + D.lds[L_S] + 6 * (v0 + c), 6, S);
-        const double vv = sm[D.lds[L_V] + v0 + c];
+        const real vv = sm[D.lds[L_V] + v0 + c];
         for (int a = 0; a < 6; a++) tj[a] += S[a] * vv;
       }
       st(sm + D.lds[L_TJ] + 6 * i, 6, tj);
-      double cw[3];
-      double I[6], cb[3];
+      real cw[3];
+      real I[6], cb[3];
       for (int k = 0; k < 6; k++) I[k] = DT[D.dt[DT_ICOM] + k * nb + i];
       for (int k = 0; k < 3; k++) cb[k] = DT[D.dt[DT_COM] + k * nb + i];
       mv3(H, cb, cw);
       cw[0] += H[9]; cw[1] += H[10]; cw[2] += H[11];
-      double Ib[9] = {I[0], I[3], I[4], I[3], I[1], I[5], I[4], I[5], I[2]}, RI[9], Rt[9], Iw[9];
+      real Ib[9] = {I[0], I[3], I[4], I[3], I[1], I[5], I[4], I[5], I[2]}, RI[9], Rt[9], Iw[9];
       for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) Rt[3 * a + b] = H[3 * b + a];
       mm3(H, Ib, RI);
       mm3(RI, Rt, Iw);
-      double mm = DT[D.dt[DT_MASS] + i], cc = cw[0] * cw[0] + cw[1] * cw[1] + cw[2] * cw[2];
-      double o[10] = {mm, mm * cw[0], mm * cw[1], mm * cw[2],
+      real mm = DT[D.dt[DT_MASS] + i], cc = cw[0] * cw[0] + cw[1] * cw[1] + cw[2] * cw[2];
+      real o[10] = {mm, mm * cw[0], mm * cw[1], mm * cw[2],
                       Iw[0] + mm * (cc - cw[0] * cw[0]), Iw[4] + mm * (cc - cw[1] * cw[1]), Iw[8] + mm * (cc - cw[2] * cw[2]),
                       Iw[1] - mm * cw[0] * cw[1], Iw[2] - mm * cw[0] * cw[2], Iw[5] - mm * cw[1] * cw[2]};
       st(sm + D.lds[L_IW] + 10 * i, 10, o);
@@ -1746,7 +1793,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
     if (lane < nb) {
       const int i = lane;
       const int *mt = QPC_LI(M.v, lane);
-      double T[6], tj[6], cr[6];
+      real T[6], tj[6], cr[6];
       ld(sm + D.lds[L_TJ] + 6 * i, 6, tj);
       for (int a = 0; a < 6; a++) T[a] = tj[a];
       QPC_UNROLL_JIT
@@ -1758,7 +1805,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
       crm(T, tj, cr);
       const int v0 = MT_V0(mt), n = MT_NVJ(mt);
       for (int c = 0; c < n; c++) {
-        const double vdp = sm[D.lds[L_VD] + v0 + c]; // zero for free joints at this point
+        const real vdp = sm[D.lds[L_VD] + v0 + c]; // zero for free joints at this point
         for (int a = 0; a < 6; a++) cr[a] += sm[D.lds[L_S] + 6 * (v0 + c) + a] * vdp;
       }
       st(sm + D.lds[L_T] + 6 * i, 6, T);
@@ -1766,14 +1813,14 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
     }
   } QPC_END_PHASE
   QPC_PROF_ACC(PS_K_TWIST);
-  double hlin[3] = {0.0, 0.0, 0.0}; // linear momentum of the whole robot (wave sum; only a centre-of-mass law reads it)
+  real hlin[3] = {0.0, 0.0, 0.0}; // linear momentum of the whole robot (wave sum; only a centre-of-mass law reads it)
   const bool com_law = ((D.law_mask >> QPC_LAW_COM_PD) & 1) != 0;
   QPC_PHASE(lane) { // bias_acceleration (+ pinned), composite inertias (subtree mask), momentum-rate bias
-    double hl_[3] = {0.0, 0.0, 0.0};
+    real hl_[3] = {0.0, 0.0, 0.0};
     if (lane < nb) {
       const int i = lane;
       const int *mt = QPC_LI(M.v, lane);
-      double Ab[6], T[6], I[10], Ic[10], h[6], ia[6], cf[6];
+      real Ab[6], T[6], I[10], Ic[10], h[6], ia[6], cf[6];
       ld(sm + D.lds[L_CR] + 6 * i, 6, Ab);
       QPC_UNROLL_JIT
       for (int s = 0; s < QPC_MAXD; s++) {
@@ -1799,15 +1846,15 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
       for (int a = 0; a < 6; a++) ia[a] += cf[a];
       st(sm + D.lds[L_HB] + 6 * i, 6, ia); // I (Ab + A_pinned) + T x* I T
       // W0 = I (Ab - g) + T x* I T : everything of the body wrench that does not depend on the solution
-      double mg[6] = {0, 0, 0, -DT[D.dt[DT_GRAV]], -DT[D.dt[DT_GRAV] + 1], -DT[D.dt[DT_GRAV] + 2]}, ig[6];
+      real mg[6] = {0, 0, 0, -DT[D.dt[DT_GRAV]], -DT[D.dt[DT_GRAV] + 1], -DT[D.dt[DT_GRAV] + 2]}, ig[6];
       inertia_mul(I, mg, ig);
       for (int a = 0; a < 6; a++) QPC_LA(keep_iw_, lane)[10 + a] = ia[a] + ig[a];
     }
     if (lane >= 51 && lane < 54) { // centre of mass (IW[1..3] = m c): last reader of L_IW, which L_AMOM overlays
       const int a = lane - 51;
-      double acc = 0.0;
+      real acc = 0.0;
       for (int i0 = 0; i0 < nb; i0 += 8) {
-        double x[8];
+        real x[8];
         QPC_UNROLL_FULL
         for (int u = 0; u < 8; u++) x[u] = sm[D.lds[L_IW] + 10 * (i0 + u < nb ? i0 + u : 0) + 1 + a];
         QPC_UNROLL_FULL
@@ -1817,9 +1864,9 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
     }
     if (lane >= 54 && D.crb_full_body >= 0) { // whole-robot composite inertia: component (lane-54), batched sum
       const int a = lane - 54;
-      double acc = 0.0;
+      real acc = 0.0;
       for (int i0 = 0; i0 < nb; i0 += 8) {
-        double x[8];
+        real x[8];
         QPC_UNROLL_FULL
         for (int u = 0; u < 8; u++) x[u] = sm[D.lds[L_IW] + 10 * (i0 + u < nb ? i0 + u : 0) + a];
         QPC_UNROLL_FULL
@@ -1834,7 +1881,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
   QPC_PHASE(lane) { // momentum matrix, CoM, momentum-rate bias, Hessian diagonal
     // static-Hessian path: its table reads are issued FIRST, so that they travel while the momentum matrix is computed
     // (in source order they sat behind three dependent waits at the end of the phase)
-    double hv0_pre = 0.0, winv_pre = 0.0, grav_pre[4] = {0.0, 0.0, 0.0, 0.0};
+    real hv0_pre = 0.0, winv_pre = 0.0, grav_pre[4] = {0.0, 0.0, 0.0, 0.0};
     if (h_fast) {
       hv0_pre = DT[D.dt[DT_HV0] + (lane < nf ? lane : 0)];
       winv_pre = DT[D.dt[DT_WINV0] + (lane < D.wsize ? lane : 0)];
@@ -1843,7 +1890,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
     if (lane < nv) {
       const int k = lane;
       const int *mt = QPC_LI(M.v, lane);
-      double Ic[10], S[6], h[6];
+      real Ic[10], S[6], h[6];
       ld(sm + D.lds[L_IC] + 10 * MT_VBODY(mt), 10, Ic);
       ld(sm + D.lds[L_S] + 6 * k, 6, S);
       for (int a = 0; a < 6; a++) QPC_LA(keep_sk_, lane)[a] = S[a]; // for tau_k = S_k . F (RNEA)
@@ -1851,9 +1898,9 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
       for (int a = 0; a < 6; a++) sm[D.lds[L_AMOM] + a * nv + k] = h[a];
     }
     if (lane >= 3 && lane < 9) {
-      double acc = 0.0;
+      real acc = 0.0;
       for (int i0 = 0; i0 < nb; i0 += 8) { // loads in batches of 8 ahead of the adds, like the centre-of-mass sums above
-        double x[8];
+        real x[8];
         QPC_UNROLL_FULL
         for (int u = 0; u < 8; u++) x[u] = sm[D.lds[L_HB] + 6 * (i0 + u < nb ? i0 + u : 0) + (lane - 3)];
         QPC_UNROLL_FULL
@@ -1862,11 +1909,11 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
       sm[MISC + MS_ADV + (lane - 3)] = acc; // Ȧv + A_pin v̇_pin
     }
     for (int f = lane; f < nf; f += 64) { // Hv = 2 reg + folded soft joint tasks (a12)
-      double hv = h_fast ? (f < 64 ? hv0_pre : DT[D.dt[DT_HV0] + f]) : DT[D.dt[DT_REG2] + IT[D.it[IT_FREE_K] + f]], gv = 0.0;
+      real hv = h_fast ? (f < 64 ? hv0_pre : DT[D.dt[DT_HV0] + f]) : DT[D.dt[DT_REG2] + IT[D.it[IT_FREE_K] + f]], gv = 0.0;
       for (int s = 0; s < D.nsj; s++)
         if (IT[D.it[IT_SJ_F] + s] == f) {
           int twi = IT[D.it[IT_SJ_TW] + s];
-          double w = twi >= 0 ? sm[D.lds[L_TW] + twi] : DT[D.dt[DT_SJ_W] + s];
+          real w = twi >= 0 ? sm[D.lds[L_TW] + twi] : DT[D.dt[DT_SJ_W] + s];
           if (!h_fast) hv += 2.0 * w;
           const int sd = IT[D.it[IT_SJ_DES] + s]; // -1: a per-QP regularisation weight (desired acceleration 0)
           if (sd >= 0) gv -= 2.0 * w * sm[D.lds[L_DES] + sd];
@@ -1881,8 +1928,8 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
       if (lane >= 10 && lane < 16 && nw) { // gravity wrench about the world origin (momentum.jl:166-170); the centre of
                                            // mass is one phase old
         const int a = lane - 10;
-        double fg[3], cxf[3], com[3] = {sm[MISC + MS_COM], sm[MISC + MS_COM + 1], sm[MISC + MS_COM + 2]};
-        const double mt = grav_pre[3];
+        real fg[3], cxf[3], com[3] = {sm[MISC + MS_COM], sm[MISC + MS_COM + 1], sm[MISC + MS_COM + 2]};
+        const real mt = grav_pre[3];
         fg[0] = mt * grav_pre[0]; fg[1] = mt * grav_pre[1]; fg[2] = mt * grav_pre[2];
         cross3(com, fg, cxf);
         sm[MISC + MS_WG + a] = a < 3 ? cxf[a] : fg[a - 3];
@@ -1894,7 +1941,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
       int d = IT[D.it[IT_T_DIM] + t], wk = IT[D.it[IT_T_WKIND] + t], tw0 = IT[D.it[IT_T_TW] + t];
       for (int e = lane; e < d * d; e += 64) {
         int a = e / d, b = e % d;
-        double w;
+        real w;
         if (wk == QPC_WEIGHT_SCALAR_PER_QP) w = (a == b) ? 2.0 * sm[D.lds[L_TW] + tw0] : 0.0;
         else if (wk == QPC_WEIGHT_MATRIX_PER_QP) w = sm[D.lds[L_TW] + tw0 + a * d + b] + sm[D.lds[L_TW] + tw0 + b * d + a];
         else w = DT[D.dt[DT_T_W] + w0 + e];
@@ -1912,18 +1959,18 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
   // regularisation scale: eps = eps_primal * max diagonal of the Hessian
   if (!h_fast) {
   QPC_PHASE(lane) {
-    double h = 0.0, hm = 1e300; // largest diagonal of H; smallest diagonal of its v̇ and slack blocks
-    for (int f = lane; f < nf; f += 64) { double a = sm[D.lds[L_HV] + f]; hm = a < hm ? a : hm; a = QPC_FABS(a); h = a > h ? a : h; }
+    real h = 0.0, hm = QPC_HUGE; // largest diagonal of H; smallest diagonal of its v̇ and slack blocks
+    for (int f = lane; f < nf; f += 64) { real a = sm[D.lds[L_HV] + f]; hm = a < hm ? a : hm; a = QPC_FABS(a); h = a > h ? a : h; }
     for (int t = lane; t < ntask; t += 64) {
       int w0 = IT[D.it[IT_T_WOFF] + t];
       if (w0 < 0) continue;
       int d = IT[D.it[IT_T_DIM] + t];
-      for (int a = 0; a < d; a++) { double w = sm[D.lds[L_W] + w0 + a * d + a]; hm = w < hm ? w : hm; w = QPC_FABS(w); h = w > h ? w : h; }
+      for (int a = 0; a < d; a++) { real w = sm[D.lds[L_W] + w0 + a * d + a]; hm = w < hm ? w : hm; w = QPC_FABS(w); h = w > h ? w : h; }
     }
-    QPC_RED_MAX_PUT(1, hinvmax, hm < 1e300 ? (hm > 1e-300 ? 1.0 / hm : 1e300) : 0.0); // (reductions are max over non-negative values)
+    QPC_RED_MAX_PUT(1, hinvmax, hm < QPC_HUGE ? (hm > QPC_TINY ? 1.0 / hm : QPC_HUGE) : 0.0); // (reductions are max over non-negative values)
     if (use_rho)
       for (int c = lane; c < nc; c += 64) {
-        double w = (sm[D.lds[L_CMAX] + c] > 0.0) ? 2.0 * QPC_FABS(sm[D.lds[L_CW] + c]) : 0.0;
+        real w = (sm[D.lds[L_CMAX] + c] > 0.0) ? 2.0 * QPC_FABS(sm[D.lds[L_CW] + c]) : 0.0;
         h = w > h ? w : h;
       }
     if (D.n_des_late) desired_late(D, IT, DT, sm, lane, hlin); // desired laws that need the kinematics (standing.jl:60-77), lane = desired entry
@@ -1932,11 +1979,11 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
   hscale = QPC_RED_MAX_GET(0, hscale);
   hinvmax = QPC_RED_MAX_GET(1, hinvmax);
   if (!(hscale > 0.0)) hscale = 1.0;
-  eps = D.eps_primal * hscale;
+  eps = (real)D.eps_primal * hscale;
   // exact_ve: every v̇ and slack diagonal of the Hessian is comfortably positive (and no matrix-weighted
   // slack block): those blocks are then inverted WITHOUT the proximal eps, which confines the eps bias to
   // the (rank-deficient) rho blocks and enables the cheap wrench-space polish (Solver::polish_exact)
-  exact_ve = D.ve_exact_ok && (hinvmax * 1e-6 * hscale <= 1.0); // min diagonal >= 1e-6 * max diagonal
+  exact_ve = D.ve_exact_ok && (hinvmax * QPC_T_EXACT * hscale <= 1.0); // min diagonal >= 1e-6 * max diagonal
   eps_ve = exact_ve ? 0.0 : eps;
   } // !h_fast
 
@@ -1945,8 +1992,8 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
   QPC_PHASE(lane) {
     if (lane == 0) { sm[MISC + MS_EPS] = eps; sm[MISC + MS_HSCALE] = hscale; }
     if (lane < 6 && nw) { // gravity wrench about the world origin (momentum.jl:166-170)
-      double fg[3], cxf[3], com[3] = {sm[MISC + MS_COM], sm[MISC + MS_COM + 1], sm[MISC + MS_COM + 2]};
-      double mt = DT[D.dt[DT_GRAV] + 3];
+      real fg[3], cxf[3], com[3] = {sm[MISC + MS_COM], sm[MISC + MS_COM + 1], sm[MISC + MS_COM + 2]};
+      real mt = DT[D.dt[DT_GRAV] + 3];
       fg[0] = mt * DT[D.dt[DT_GRAV]]; fg[1] = mt * DT[D.dt[DT_GRAV] + 1]; fg[2] = mt * DT[D.dt[DT_GRAV] + 2];
       cross3(com, fg, cxf);
       sm[MISC + MS_WG + lane] = lane < 3 ? cxf[lane] : fg[lane - 3];
@@ -1970,24 +2017,24 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
       const int c0 = IT[D.it[IT_MCODE] + 2 * it_], c1 = IT[D.it[IT_MCODE] + 2 * it_ + 1];
       const int kind = c0 & 7, sg = ((c0 >> 3) & 3) - 1, k = (c0 >> 5) & 127, aux = (c0 >> 12) & 127, t = (c0 >> 19) & 63;
       const int r0 = c1 & 127, dim = (c1 >> 7) & 15, f = (c1 >> 11) & 127;
-      const double sq = sm[D.lds[L_SQH] + f];
-      double val[6] = {0, 0, 0, 0, 0, 0};
+      const real sq = sm[D.lds[L_SQH] + f];
+      real val[6] = {0, 0, 0, 0, 0, 0};
       if (kind == 7) { // wrench balance rows (a11), S dropped (invertible)
         for (int a = 0; a < 6; a++) val[a] = sm[D.lds[L_AMOM] + a * nv + k];
       } else if (sg != 0) {
         if (kind == QPC_TASK_JOINT_ACCELERATION) {
           for (int a = 0; a < 6; a++) val[a] = (a == aux - 1) ? 1.0 : 0.0;
         } else if (kind == QPC_TASK_MOMENTUM_RATE || kind == QPC_TASK_LINEAR_MOMENTUM_RATE) {
-          double lin[3] = {sm[D.lds[L_AMOM] + 3 * nv + k], sm[D.lds[L_AMOM] + 4 * nv + k], sm[D.lds[L_AMOM] + 5 * nv + k]};
+          real lin[3] = {sm[D.lds[L_AMOM] + 3 * nv + k], sm[D.lds[L_AMOM] + 4 * nv + k], sm[D.lds[L_AMOM] + 5 * nv + k]};
           if (kind == QPC_TASK_LINEAR_MOMENTUM_RATE) { val[0] = lin[0]; val[1] = lin[1]; val[2] = lin[2]; }
           else { // centroidal: ang - com x lin (src/tasks.jl:208-213)
-            double com[3] = {sm[MISC + MS_COM], sm[MISC + MS_COM + 1], sm[MISC + MS_COM + 2]}, cx[3];
+            real com[3] = {sm[MISC + MS_COM], sm[MISC + MS_COM + 1], sm[MISC + MS_COM + 2]}, cx[3];
             cross3(com, lin, cx);
             for (int a = 0; a < 3; a++) { val[a] = sm[D.lds[L_AMOM] + a * nv + k] - cx[a]; val[3 + a] = lin[a]; }
           }
         } else {
           const int frame = aux - 1;
-          double H[12], S[6], J[6];
+          real H[12], S[6], J[6];
           ldH(sm, D, frame, H);
           ld(sm + D.lds[L_S] + 6 * k, 6, S);
           motion_to_frame(H, S, J);
@@ -1995,10 +2042,10 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
           else if (kind == QPC_TASK_ANGULAR_ACCELERATION) { for (int a = 0; a < 3; a++) val[a] = sg * J[a]; }
           else if (kind == QPC_TASK_LINEAR_ACCELERATION) { for (int a = 0; a < 3; a++) val[a] = sg * J[3 + a]; }
           else { // point jacobian J_lin - p^ J_ang in the base frame (src/tasks.jl:157-160)
-            double Ht[12], pw[3], d3[3], pF[3], px[3];
+            real Ht[12], pw[3], d3[3], pF[3], px[3];
             int target = IT[D.it[IT_T_TARGET] + t];
             ldH(sm, D, target, Ht);
-            mv3(Ht, DT + D.dt[DT_T_POINT] + 3 * t, pw);
+            { const real pt_[3] = {DT[D.dt[DT_T_POINT] + 3 * t], DT[D.dt[DT_T_POINT] + 3 * t + 1], DT[D.dt[DT_T_POINT] + 3 * t + 2]}; mv3(Ht, pt_, pw); }
             d3[0] = pw[0] + Ht[9] - H[9]; d3[1] = pw[1] + Ht[10] - H[10]; d3[2] = pw[2] + Ht[11] - H[11];
             mtv3(H, d3, pF);
             cross3(pF, J, px);
@@ -2015,18 +2062,18 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
       const int code = IT[D.it[IT_RCODE] + r], di = IT[D.it[IT_R_DES] + r], t = IT[D.it[IT_R_T] + r], pk = IT[D.it[IT_R_PINK] + r];
       const int kind = code & 7, a = (code >> 3) & 7, frame = ((code >> 6) & 127) - 1, base = ((code >> 13) & 127) - 1,
                 target = ((code >> 20) & 127) - 1;
-      double rhs;
+      real rhs;
       if (kind == 7) rhs = sm[MISC + MS_WG + a] - sm[MISC + MS_ADV + a];
       else {
-        double des = sm[D.lds[L_DES] + di];
+        real des = sm[D.lds[L_DES] + di];
         if (kind == QPC_TASK_JOINT_ACCELERATION) {
           // generic joint rows (duplicate pin / matrix weight): a pinned acceleration moves to the rhs
-          rhs = des - (pk >= 0 ? (double)sm[D.lds[L_VD] + pk] : 0.0);
+          rhs = des - (pk >= 0 ? (real)sm[D.lds[L_VD] + pk] : 0.0);
         } else if (kind == QPC_TASK_MOMENTUM_RATE || kind == QPC_TASK_LINEAR_MOMENTUM_RATE) {
           int aa = kind == QPC_TASK_LINEAR_MOMENTUM_RATE ? a + 3 : a;
-          double b = sm[MISC + MS_ADV + aa];
+          real b = sm[MISC + MS_ADV + aa];
           if (aa < 3) {
-            double com[3] = {sm[MISC + MS_COM], sm[MISC + MS_COM + 1], sm[MISC + MS_COM + 2]}, lin[3], cx[3];
+            real com[3] = {sm[MISC + MS_COM], sm[MISC + MS_COM + 1], sm[MISC + MS_COM + 2]}, lin[3], cx[3];
             for (int i = 0; i < 3; i++) lin[i] = sm[MISC + MS_ADV + 3 + i];
             cross3(com, lin, cx);
             b -= cx[aa];
@@ -2035,7 +2082,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
         } else {
           // J̇v = transform(state, bias(target) - bias(base), frame) (src/tasks.jl:37-38); the bias
           // already carries the acceleration produced by the pinned joints
-          double At[6], Abs[6], Tt[6], Tb[6], Tf[6], trel[6], cr[6], aw[6], aF[6], H[12];
+          real At[6], Abs[6], Tt[6], Tb[6], Tf[6], trel[6], cr[6], aw[6], aF[6], H[12];
           ld6(sm, D.lds[L_AB], target, At); ld6(sm, D.lds[L_AB], base, Abs);
           ld6(sm, D.lds[L_T], target, Tt); ld6(sm, D.lds[L_T], base, Tb); ld6(sm, D.lds[L_T], frame, Tf);
           for (int i = 0; i < 6; i++) trel[i] = Tt[i] - Tb[i];
@@ -2046,9 +2093,9 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
           if (kind == QPC_TASK_SPATIAL_ACCELERATION || kind == QPC_TASK_ANGULAR_ACCELERATION) rhs = des - aF[a];
           else if (kind == QPC_TASK_LINEAR_ACCELERATION) rhs = des - aF[3 + a];
           else { // point: w x pdot + J̇v_ang x p + J̇v_lin (src/tasks.jl:166-170)
-            double Ht[12], pw[3], d3[3], pF[3], TF[6], pd[3], t1[3], t2[3];
+            real Ht[12], pw[3], d3[3], pF[3], TF[6], pd[3], t1[3], t2[3];
             ldH(sm, D, target, Ht);
-            mv3(Ht, DT + D.dt[DT_T_POINT] + 3 * t, pw);
+            { const real pt_[3] = {DT[D.dt[DT_T_POINT] + 3 * t], DT[D.dt[DT_T_POINT] + 3 * t + 1], DT[D.dt[DT_T_POINT] + 3 * t + 2]}; mv3(Ht, pt_, pw); }
             d3[0] = pw[0] + Ht[9] - H[9]; d3[1] = pw[1] + Ht[10] - H[10]; d3[2] = pw[2] + Ht[11] - H[11];
             mtv3(H, d3, pF);
             motion_to_frame(H, trel, TF);
@@ -2067,10 +2114,10 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
     if (use_rho)
       for (int j = lane; j < nrho; j += 64) {
         int c = j / N, i = j % N, body = IT[D.it[IT_C_BODY] + c];
-        double nrm[3] = {DT[D.dt[DT_C_NORMAL] + 3 * c], DT[D.dt[DT_C_NORMAL] + 3 * c + 1], DT[D.dt[DT_C_NORMAL] + 3 * c + 2]};
-        double mu = DT[D.dt[DT_C_MU] + c];
+        real nrm[3] = {DT[D.dt[DT_C_NORMAL] + 3 * c], DT[D.dt[DT_C_NORMAL] + 3 * c + 1], DT[D.dt[DT_C_NORMAL] + 3 * c + 2]};
+        real mu = DT[D.dt[DT_C_MU] + c];
         const int pq = IT[D.it[IT_C_PERQP] + c]; // QPC_CONTACT_*_PER_QP bits (contacts.jl:39: Parameters)
-        double pos[3] = {DT[D.dt[DT_C_POS] + 3 * c], DT[D.dt[DT_C_POS] + 3 * c + 1], DT[D.dt[DT_C_POS] + 3 * c + 2]};
+        real pos[3] = {DT[D.dt[DT_C_POS] + 3 * c], DT[D.dt[DT_C_POS] + 3 * c + 1], DT[D.dt[DT_C_POS] + 3 * c + 2]};
         if (pq) {
           int so = IT[D.it[IT_C_SURF] + c];
           if (pq & 1) {
@@ -2081,25 +2128,25 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
           if (pq & 2) { pos[0] = sm[D.lds[L_SURF] + so]; pos[1] = sm[D.lds[L_SURF] + so + 1]; pos[2] = sm[D.lds[L_SURF] + so + 2]; }
         }
         // Rotations.rotation_between(z, n) (contacts.jl:11)
-        double nn = QPC_SQRT(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
-        double w = nn + nrm[2], x, y, z = 0.0;
-        if (QPC_FABS(w) < 100 * 2.220446049250313e-16) { x = 1; y = 0; } /* Rotations.perpendicular_vector((0,0,1)) = (1,0,0) */ else { x = -nrm[1]; y = nrm[0]; }
-        double qn = QPC_RSQRT(w * w + x * x + y * y);
+        real nn = QPC_SQRT(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
+        real w = nn + nrm[2], x, y, z = 0.0;
+        if (QPC_FABS(w) < 100 * QPC_EPS_MACH) { x = 1; y = 0; } /* Rotations.perpendicular_vector((0,0,1)) = (1,0,0) */ else { x = -nrm[1]; y = nrm[0]; }
+        real qn = QPC_RSQRT(w * w + x * x + y * y);
         w *= qn; x *= qn; y *= qn;
-        double Rn[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+        real Rn[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
                         2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
                         2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)};
-        double H[12], Rc[9], pc[3];
+        real H[12], Rc[9], pc[3];
         ldH(sm, D, body, H);
         mm3(H, Rn, Rc);
         mv3(H, pos, pc);
         pc[0] += H[9]; pc[1] += H[10]; pc[2] += H[11];
         // forcebasis(mu, N) (contacts.jl:16-23)
-        double sn, cs, inv = QPC_RSQRT(mu * mu + 1.0);
+        real sn, cs, inv = QPC_RSQRT(mu * mu + 1.0);
 #ifdef QPC_BASIS_TABLE
         // JIT: cos / sin of the N basis directions are literals (computed by the host when the source is
         // generated); the lane's own pair is picked with selects instead of an fp64 sincos per use
-        constexpr double kb_[16] = QPC_BASIS_TABLE;
+        constexpr real kb_[16] = QPC_BASIS_TABLE;
         sn = 0.0; cs = 1.0;
         QPC_UNROLL_FULL
         for (int ii = 1; ii < 8; ii++)
@@ -2107,31 +2154,31 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
 #else
         QPC_SINCOS(i * (6.283185307179586 / N), sn, cs);
 #endif
-        double bi[3] = {mu * cs * inv, mu * sn * inv, inv}, lin[3], ang[3];
+        real bi[3] = {mu * cs * inv, mu * sn * inv, inv}, lin[3], ang[3];
         mv3(Rc, bi, lin);
         cross3(pc, lin, ang);
         for (int a = 0; a < 3; a++) { sm[D.lds[L_G] + a * QPC_GS(nrho) + j] = ang[a]; sm[D.lds[L_G] + (3 + a) * QPC_GS(nrho) + j] = lin[a]; }
-        double cw = sm[D.lds[L_CW] + c];
+        real cw = sm[D.lds[L_CW] + c];
 #ifdef QPC_BASIS_TABLE
         QPC_UNROLL_FULL
         for (int i2 = 0; i2 < 8; i2++) {
           if (i2 < N) {
-            const double c2 = kb_[2 * i2], s2 = kb_[2 * i2 + 1];
-            double dot = (mu * cs * mu * c2 + mu * sn * mu * s2 + 1.0) * inv * inv;
+            const real c2 = kb_[2 * i2], s2 = kb_[2 * i2 + 1];
+            real dot = (mu * cs * mu * c2 + mu * sn * mu * s2 + 1.0) * inv * inv;
             sm[D.lds[L_HR] + c * QPC_CSH(N) + i * N + i2] = 2.0 * cw * dot;
           }
         }
 #else
         for (int i2 = 0; i2 < N; i2++) {
-          double s2, c2;
+          real s2, c2;
           QPC_SINCOS(i2 * (6.283185307179586 / N), s2, c2);
-          double dot = (mu * cs * mu * c2 + mu * sn * mu * s2 + 1.0) * inv * inv;
+          real dot = (mu * cs * mu * c2 + mu * sn * mu * s2 + 1.0) * inv * inv;
           sm[D.lds[L_HR] + c * QPC_CSH(N) + i * N + i2] = 2.0 * cw * dot;
         }
 #endif
-        double hi = sm[D.lds[L_CMAX] + c] * inv / N; // maxrho (contacts.jl:57)
+        real hi = sm[D.lds[L_CMAX] + c] * inv / N; // maxrho (contacts.jl:57)
         sm[D.lds[L_HI] + j] = hi;
-        double ws0 = hi > 0.0 ? 0.0 : -1.0; // disable! (contacts.jl:72): rho pinned to 0
+        real ws0 = hi > 0.0 ? 0.0 : -1.0; // disable! (contacts.jl:72): rho pinned to 0
         if (WARM && io.wset && hi > 0.0 && j < 64) { // hint from the previous tick of this robot
           const unsigned long long wlo = io.wset[0], wup = io.wset[1];
           ws0 = ((wlo >> j) & 1ull) ? -1.0 : (((wup >> j) & 1ull) ? 1.0 : 0.0);
@@ -2158,7 +2205,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
     const int nt = (m + 15) / 16, nk = (nf + 3) / 4;
     QPC_LANE_ARRAY(sacc_, 4 * QPC_NTILE_MAX);
     QPC_PHASE(lane) {
-      double *acc = QPC_LA(sacc_, lane);
+      real *acc = QPC_LA(sacc_, lane);
       for (int e = 0; e < 4 * QPC_NTILE_MAX; e++) acc[e] = 0.0;
     } QPC_END_PHASE
     {
@@ -2169,17 +2216,17 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
         for (int tj = 0; tj <= ti; tj++, tile++) {
           QPC_UNROLL_JIT
           for (int ks = 0; ks < nk; ks++) {
-            QPC_MFMA_F64_16x16x4(lane, QPC_LA(sacc_, lane) + 4 * tile,
+            QPC_MFMA_16x16x4(lane, QPC_LA(sacc_, lane) + 4 * tile,
                                  ((16 * ti + (lane & 15) < m && 4 * ks + (lane >> 4) < nf)
-                                      ? (double)sm[D.lds[L_M] + (16 * ti + (lane & 15)) * D.nfs + 4 * ks + (lane >> 4)] : 0.0),
+                                      ? (real)sm[D.lds[L_M] + (16 * ti + (lane & 15)) * D.nfs + 4 * ks + (lane >> 4)] : 0.0),
                                  ((16 * tj + (lane & 15) < m && 4 * ks + (lane >> 4) < nf)
-                                      ? (double)sm[D.lds[L_M] + (16 * tj + (lane & 15)) * D.nfs + 4 * ks + (lane >> 4)] : 0.0))
+                                      ? (real)sm[D.lds[L_M] + (16 * tj + (lane & 15)) * D.nfs + 4 * ks + (lane >> 4)] : 0.0))
           }
         }
       }
     }
     QPC_PHASE(lane) {
-      const double *acc = QPC_LA(sacc_, lane);
+      const real *acc = QPC_LA(sacc_, lane);
       int tile = 0;
       QPC_UNROLL_JIT
       for (int ti = 0; ti < nt; ti++) {
@@ -2187,14 +2234,14 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
         for (int tj = 0; tj <= ti; tj++, tile++) {
           QPC_UNROLL_FULL
           for (int reg = 0; reg < 4; reg++) {
-            const int r = 16 * ti + (lane >> 4) + 4 * reg, c = 16 * tj + (lane & 15);
+            const int r = 16 * ti + QPC_MFMA_CROW(lane, reg), c = 16 * tj + (lane & 15);
             if (r < m && c <= r) {
-              double v = acc[4 * tile + reg];
+              real v = acc[4 * tile + reg];
               if (ne > 0 && r < m1) { // slack rows of the same soft task: + (W+eps)^-1 entry (LDS hot table)
-                const int slr = (int)(double)sm[D.lds[L_HOT] + r], slc = (int)(double)sm[D.lds[L_HOT] + c];
+                const int slr = (int)(real)sm[D.lds[L_HOT] + r], slc = (int)(real)sm[D.lds[L_HOT] + c];
                 if (slr >= 0 && slc >= 0) {
-                  const int s0r = (int)(double)sm[D.lds[L_HOT] + m + 3 * ne + slr], s0c = (int)(double)sm[D.lds[L_HOT] + m + 3 * ne + slc];
-                  if (s0r == s0c) v += sm[D.lds[L_WINV] + (int)(double)sm[D.lds[L_HOT] + m + ne + slr] + (slc - s0c)];
+                  const int s0r = (int)(real)sm[D.lds[L_HOT] + m + 3 * ne + slr], s0c = (int)(real)sm[D.lds[L_HOT] + m + 3 * ne + slc];
+                  if (s0r == s0c) v += sm[D.lds[L_WINV] + (int)(real)sm[D.lds[L_HOT] + m + ne + slr] + (slc - s0c)];
                 }
               }
               sm[D.lds[L_SM] + r * D.ms + c] = v;
@@ -2225,23 +2272,23 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
         const bool idrow = xaug && lane >= m && lane < m + m1;
         if ((lane >= k && lane < m) || idrow) { // m <= 64 (checked by the host compiler)
           const int r = lane;
-          double *lrow = QPC_LA(lrow_, lane);
-          double accr = 0.0, acck = 0.0;
+          real *lrow = QPC_LA(lrow_, lane);
+          real accr = 0.0, acck = 0.0;
           for (int j0 = 0; j0 < k; j0 += 8) {
-            double lk[8];
+            real lk[8];
             QPC_UNROLL_FULL
             for (int u = 0; u < 8; u++) lk[u] = sm[D.lds[L_SM] + k * D.ms + (j0 + u < k ? j0 + u : 0)];
             QPC_UNROLL_FULL
             for (int u = 0; u < 8; u++)
               if (j0 + u < k) { accr += lk[u] * lrow[j0 + u]; acck += lk[u] * lk[u]; }
           }
-          double skk = sm[D.lds[L_SM] + k * D.ms + k], dk = skk - acck;
-          const double srk = idrow ? ((r - m) == k ? 1.0 : 0.0) : (double)sm[D.lds[L_SM] + (idrow ? k : r) * D.ms + k];
-          bool ok = dk > D.tau_pivot * (skk > 1e-300 ? skk : 1e-300);
-          const double inv = ok ? QPC_RSQRT(dk) : 0.0; // 1 / L_kk
+          real skk = sm[D.lds[L_SM] + k * D.ms + k], dk = skk - acck;
+          const real srk = idrow ? ((r - m) == k ? 1.0 : 0.0) : (real)sm[D.lds[L_SM] + (idrow ? k : r) * D.ms + k];
+          bool ok = dk > (real)D.tau_pivot * (skk > QPC_TINY ? skk : QPC_TINY);
+          const real inv = ok ? QPC_RSQRT(dk) : 0.0; // 1 / L_kk
           if (r == k) sm[D.lds[L_T1] + k] = inv; // 1/L_kk (0 = dropped row)
           else {
-            const double v = (srk - accr) * inv;
+            const real v = (srk - accr) * inv;
             lrow[k] = v;
             if (idrow) sm[D.lds[L_X] + k * D.m1s + (r - m)] = v; // X[k][c], c = r - m (zero above the diagonal by itself)
             else sm[D.lds[L_SM] + r * D.ms + k] = v;
@@ -2260,19 +2307,19 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
     }
     if (!xaug && lane < m1) { // (more than 64 rows in the augmented factorization: X by forward substitution)
       const int c = lane;
-      double xc[QPC_M1_MAX];
+      real xc[QPC_M1_MAX];
       QPC_UNROLL_JIT
       for (int r = 0; r < m1; r++) {
-        double t = (r == c) ? 1.0 : 0.0;
+        real t = (r == c) ? 1.0 : 0.0;
         for (int j0 = 0; j0 < r; j0 += 8) {
-          double lr[8];
+          real lr[8];
           QPC_UNROLL_FULL
           for (int u = 0; u < 8; u++) lr[u] = sm[D.lds[L_SM] + r * D.ms + (j0 + u < r ? j0 + u : 0)];
           QPC_UNROLL_FULL
           for (int u = 0; u < 8; u++)
             if (j0 + u < r) t -= lr[u] * xc[j0 + u];
         }
-        double x = (r >= c) ? t * sm[D.lds[L_T1] + r] : 0.0;
+        real x = (r >= c) ? t * sm[D.lds[L_T1] + r] : 0.0;
         xc[r] = x;
         sm[D.lds[L_X] + r * D.m1s + c] = x;
       }
@@ -2288,7 +2335,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
     const int nt1 = (m1 + 15) / 16, nk1 = (m1 + 3) / 4, ntri = nt1 * (nt1 + 1) / 2;
     QPC_LANE_ARRAY(xacc_, 4 * QPC_XTILE_MAX);
     QPC_PHASE(lane) {
-      double *acc = QPC_LA(xacc_, lane);
+      real *acc = QPC_LA(xacc_, lane);
       for (int e = 0; e < 4 * QPC_XTILE_MAX; e++) acc[e] = 0.0;
     } QPC_END_PHASE
     {
@@ -2299,11 +2346,11 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
         for (int tj = 0; tj <= ti; tj++, tile++) {
           QPC_UNROLL_JIT
           for (int ks = 4 * ti; ks < nk1; ks++) {
-            QPC_MFMA_F64_16x16x4(lane, QPC_LA(xacc_, lane) + 4 * tile,
+            QPC_MFMA_16x16x4(lane, QPC_LA(xacc_, lane) + 4 * tile,
                                  ((16 * ti + (lane & 15) < m1 && 4 * ks + (lane >> 4) < m1)
-                                      ? (double)sm[D.lds[L_X] + (4 * ks + (lane >> 4)) * D.m1s + 16 * ti + (lane & 15)] : 0.0),
+                                      ? (real)sm[D.lds[L_X] + (4 * ks + (lane >> 4)) * D.m1s + 16 * ti + (lane & 15)] : 0.0),
                                  ((16 * tj + (lane & 15) < m1 && 4 * ks + (lane >> 4) < m1)
-                                      ? (double)sm[D.lds[L_X] + (4 * ks + (lane >> 4)) * D.m1s + 16 * tj + (lane & 15)] : 0.0))
+                                      ? (real)sm[D.lds[L_X] + (4 * ks + (lane >> 4)) * D.m1s + 16 * tj + (lane & 15)] : 0.0))
           }
         }
       }
@@ -2312,18 +2359,18 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
         for (int ti = 0; ti < nt1; ti++) {
           QPC_UNROLL_JIT
           for (int ks = 4 * ti; ks < nk1; ks++) {
-            QPC_MFMA_F64_16x16x4(lane, QPC_LA(xacc_, lane) + 4 * (ntri + ti),
+            QPC_MFMA_16x16x4(lane, QPC_LA(xacc_, lane) + 4 * (ntri + ti),
                                  ((16 * ti + (lane & 15) < m1 && 4 * ks + (lane >> 4) < m1)
-                                      ? (double)sm[D.lds[L_X] + (4 * ks + (lane >> 4)) * D.m1s + 16 * ti + (lane & 15)] : 0.0),
+                                      ? (real)sm[D.lds[L_X] + (4 * ks + (lane >> 4)) * D.m1s + 16 * ti + (lane & 15)] : 0.0),
                                  (((lane & 15) < 6 && 4 * ks + (lane >> 4) < m1)
-                                      ? (double)sm[D.lds[L_SM] + (m1 + (lane & 15)) * D.ms + 4 * ks + (lane >> 4)] : 0.0))
+                                      ? (real)sm[D.lds[L_SM] + (m1 + (lane & 15)) * D.ms + 4 * ks + (lane >> 4)] : 0.0))
           }
         }
       }
     }
     QPC_PROF_ACC(PS_X_MFMA);
     QPC_PHASE(lane) {
-      const double *acc = QPC_LA(xacc_, lane);
+      const real *acc = QPC_LA(xacc_, lane);
       int tile = 0;
       QPC_UNROLL_JIT
       for (int ti = 0; ti < nt1; ti++) {
@@ -2331,9 +2378,9 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
         for (int tj = 0; tj <= ti; tj++, tile++) {
           QPC_UNROLL_FULL
           for (int reg = 0; reg < 4; reg++) {
-            const int r = 16 * ti + (lane >> 4) + 4 * reg, c = 16 * tj + (lane & 15);
+            const int r = 16 * ti + QPC_MFMA_CROW(lane, reg), c = 16 * tj + (lane & 15);
             if (r < m1 && c <= r) {
-              const double v = acc[4 * tile + reg];
+              const real v = acc[4 * tile + reg];
               sm[D.lds[L_SM] + r * D.ms + c] = v;
               if (c < r) sm[D.lds[L_SM] + c * D.ms + r] = v;
             }
@@ -2345,7 +2392,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
         for (int ti = 0; ti < nt1; ti++) {
           QPC_UNROLL_FULL
           for (int reg = 0; reg < 4; reg++) {
-            const int r = 16 * ti + (lane >> 4) + 4 * reg, a = lane & 15;
+            const int r = 16 * ti + QPC_MFMA_CROW(lane, reg), a = lane & 15;
             if (r < m1 && a < 6) sm[D.lds[L_X2] + r * 6 + a] = acc[4 * (ntri + ti) + reg];
           }
         }
@@ -2378,9 +2425,9 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
     if (WARM && attempt == 0) { // upper-active bounds / any hint at all in the starting set?
       unsigned long long bup0 = 0ull, bhint = 0ull;
       QPC_PHASE(lane) {
-        double up = 0.0, hint = 0.0;
+        real up = 0.0, hint = 0.0;
         for (int j = lane; j < nrho; j += 64) {
-          const double w = sm[D.lds[L_WS] + j];
+          const real w = sm[D.lds[L_WS] + j];
           if (w == 1.0) up = 1.0;
           if (w != 0.0 && sm[D.lds[L_HI] + j] > 0.0) hint = 1.0;
         }
@@ -2398,17 +2445,17 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
     const bool fsearch = S.fused_ok();
     bool soft_tail = false; // the last sweep ended on a SOFT phase end: a hard one is due before other lanes' words are read
     for (int pd = 0; pd < D.max_pdas; pd++) {
-      const double gscale = 1.0 + S.last_gmax, tolb = D.tol_bound * (1.0 + S.last_xmax); // U is current (rho_solve)
-      double rchg = 0.0, rup = 0.0;
+      const real gscale = 1.0 + S.last_gmax, tolb = (real)D.tol_bound * (1.0 + S.last_xmax); // U is current (rho_solve)
+      real rchg = 0.0, rup = 0.0;
       unsigned long long bchg = 0ull, bup = 0ull, bfree = 0ull;
       QPC_PHASE(lane) {
-        double changed = 0.0, up = 0.0;
+        real changed = 0.0, up = 0.0;
         bool isfree = false; // this lane's ray is free in the NEW working set (fused sweeps: one ray per lane)
         for (int j = lane; j < nrho; j += 64) {
-          double w = sm[D.lds[L_WS] + j], hi = sm[D.lds[L_HI] + j], x = sm[D.lds[L_XR] + j], nw_ = w;
+          real w = sm[D.lds[L_WS] + j], hi = sm[D.lds[L_HI] + j], x = sm[D.lds[L_XR] + j], nw_ = w;
           sm[D.lds[L_WSP] + j] = w; // the set this solution belongs to (fallback, see below)
           if (!(hi > 0.0)) continue; // disabled
-          if (w != 0.0) { if (sm[D.lds[L_U] + j] < -D.tol_bound * gscale) nw_ = 0.0; }
+          if (w != 0.0) { if (sm[D.lds[L_U] + j] < -(real)D.tol_bound * gscale) nw_ = 0.0; }
           else if (x < -tolb) nw_ = -1.0;
           else if (x > hi + tolb) nw_ = 1.0;
           if (nw_ != w) { sm[D.lds[L_WS] + j] = nw_; changed = 1.0; }
@@ -2443,21 +2490,21 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
     // at all, but ~30 Goldfarb-Idnani additions away from the optimum -- is the last resort.
     if (!any_upper) {
       for (int ga = 0; ga < 3; ga++) {
-        double incons = 0.0; // residual of S22 lam_w = u0: rows the infinite-pivot rule dropped as dependent
+        real incons = 0.0; // residual of S22 lam_w = u0: rows the infinite-pivot rule dropped as dependent
                              // must still be satisfied (L_C22 still holds S22 of this working set: fused path)
         QPC_PHASE(lane) {
-          double r = 0.0;
+          real r = 0.0;
           if (lane < 6) {
-            const double u = sm[MISC + MS_U0 + lane];
+            const real u = sm[MISC + MS_U0 + lane];
             r = QPC_FABS(u - dotp(sm + D.lds[L_C22] + lane * 6, 1, sm + D.lds[L_LAM] + m1, 1, 6)) / (1.0 + QPC_FABS(u));
           }
           QPC_RED_MAX_PUT(0, incons, r);
         } QPC_END_PHASE
         incons = QPC_RED_MAX_GET(0, incons);
-        if (!(incons > 1e-6) || ga == 2) break;
+        if (!(incons > QPC_T_INCONS) || ga == 2) break;
         QPC_PHASE(lane) {
           for (int j = lane; j < nrho; j += 64)
-            sm[D.lds[L_WS] + j] = ga == 0 ? (double)sm[D.lds[L_WSP] + j] : (sm[D.lds[L_HI] + j] > 0.0 ? 0.0 : -1.0);
+            sm[D.lds[L_WS] + j] = ga == 0 ? (real)sm[D.lds[L_WSP] + j] : (sm[D.lds[L_HI] + j] > 0.0 ? 0.0 : -1.0);
         } QPC_END_PHASE
         iters++;
         pd_converged = false; // another working set: phase B has to judge it
@@ -2485,26 +2532,26 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
     (void)direct_adds; (void)hist_cleared;
     while (true) {
       if (iters > D.max_as_iters) { status = QPC_STATUS_ITERATION_LIMIT; break; }
-      const double gscale = 1.0 + S.last_gmax, tolb = D.tol_bound * (1.0 + S.last_xmax); // U is current (rho_solve)
+      const real gscale = 1.0 + S.last_gmax, tolb = (real)D.tol_bound * (1.0 + S.last_xmax); // U is current (rho_solve)
       // most negative multiplier / most violated bound (lane-parallel + wave argmin)
-      double ubad = 0.0, vneg = 0.0, rnan = 0.0;
+      real ubad = 0.0, vneg = 0.0, rnan = 0.0;
       int jbad = -1, pviol = -1;
       unsigned long long lo_now = 0ull, up_now = 0ull, bnan = 0ull;
       QPC_PHASE(lane) {
-        double bu = 1e300, bv = 1e300, bad = 0.0;
+        real bu = QPC_HUGE, bv = QPC_HUGE, bad = 0.0;
         int ju = 0x3fffffff, jv = 0x3fffffff;
         for (int j = lane; j < nrho; j += 64) {
-          double w = sm[D.lds[L_WS] + j], hi = sm[D.lds[L_HI] + j], x = sm[D.lds[L_XR] + j];
-          if (!(x == x) || QPC_FABS(x) > 1e300) bad = 1.0;
+          real w = sm[D.lds[L_WS] + j], hi = sm[D.lds[L_HI] + j], x = sm[D.lds[L_XR] + j];
+          if (!(x == x) || QPC_FABS(x) > QPC_HUGE) bad = 1.0;
           if (!(hi > 0.0)) continue;
-          if (w != 0.0) { double u = sm[D.lds[L_U] + j]; if (u < bu) { bu = u; ju = j; } }
-          else { double vl = -x > x - hi ? -x : x - hi; if (-vl < bv) { bv = -vl; jv = j; } }
+          if (w != 0.0) { real u = sm[D.lds[L_U] + j]; if (u < bu) { bu = u; ju = j; } }
+          else { real vl = -x > x - hi ? -x : x - hi; if (-vl < bv) { bv = -vl; jv = j; } }
         }
         // (at most one rho per lane: the index of a candidate IS its lane, so the argmin is a minimum and a ballot)
         if (nrho <= 64) { QPC_RED_ARGMIN_LANE_PUT(0, ubad, jbad, bu, ju); QPC_RED_ARGMIN_LANE_PUT(1, vneg, pviol, bv, jv); }
         else { QPC_RED_ARGMIN_PUT(0, ubad, jbad, bu, ju); QPC_RED_ARGMIN_PUT(1, vneg, pviol, bv, jv); }
         QPC_BALLOT_PUT(2, bnan, bad != 0.0);
-        const double wl_ = lane < nrho ? (double)sm[D.lds[L_WS] + (lane < nrho ? lane : 0)] : 0.0;
+        const real wl_ = lane < nrho ? (real)sm[D.lds[L_WS] + (lane < nrho ? lane : 0)] : 0.0;
         QPC_BALLOT_PUT(3, lo_now, wl_ == -1.0);
         QPC_BALLOT_PUT(4, up_now, wl_ == 1.0);
       } QPC_END_PHASE
@@ -2529,7 +2576,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
       }
       QPC_PROF_ACC(PS_L_GICHECK);
       const bool finite = !(rnan > 0.0);
-      if (!(ubad < -D.tol_bound * gscale)) jbad = -1;
+      if (!(ubad < -(real)D.tol_bound * gscale)) jbad = -1;
       if (!(-vneg > tolb)) pviol = -1;
       if (!finite) { status = QPC_STATUS_NUMERICAL_ERROR; break; }
       if (jbad >= 0) {
@@ -2540,8 +2587,8 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
       }
       if (pviol < 0) break; // optimal for this working set
       const int p = pviol;
-      const double xp0 = sm[D.lds[L_XR] + p], hip = sm[D.lds[L_HI] + p];
-      const double side = (-xp0 > xp0 - hip) ? -1.0 : 1.0, nsign = side < 0 ? 1.0 : -1.0;
+      const real xp0 = sm[D.lds[L_XR] + p], hip = sm[D.lds[L_HI] + p];
+      const real side = (-xp0 > xp0 - hip) ? -1.0 : 1.0, nsign = side < 0 ? 1.0 : -1.0;
 #if QPC_DIRECT_ADDS > 0
       // A few DIRECT additions first: pin the most violated bound and re-solve the EQP (one sweep) instead of the
       // Goldfarb-Idnani step (direction solve + ratio test + partial / full step + sweep: about twice the work).  The
@@ -2557,17 +2604,17 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
         S.refactor_solve(false);
         // the pin can leave the wrench rows without a solution on the new set (same test as after phase A): the
         // Goldfarb-Idnani step would have seen the dependence and dropped a bound first, so undo and leave it to that
-        double incons = 0.0;
+        real incons = 0.0;
         QPC_PHASE(lane) {
-          double r = 0.0;
+          real r = 0.0;
           if (lane < 6) {
-            const double u = sm[MISC + MS_U0 + lane];
+            const real u = sm[MISC + MS_U0 + lane];
             r = QPC_FABS(u - dotp(sm + D.lds[L_C22] + lane * 6, 1, sm + D.lds[L_LAM] + m1, 1, 6)) / (1.0 + QPC_FABS(u));
           }
           QPC_RED_MAX_PUT(0, incons, r);
         } QPC_END_PHASE
         incons = QPC_RED_MAX_GET(0, incons);
-        if (incons > 1e-6) {
+        if (incons > QPC_T_INCONS) {
           direct_adds = QPC_DIRECT_ADDS;
           hist_cleared = true; // (the set before the pin comes back: not a cycle)
           QPC_PHASE(lane) {
@@ -2593,21 +2640,21 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
         iters++;
         if (iters > D.max_as_iters) { fail = true; break; }
         S.rho_solve(false, p, nsign, true);
-        double t1 = 1e300;
+        real t1 = QPC_HUGE;
         int jdrop = -1;
         QPC_PHASE(lane) { // dual direction r_j = -s_j (H_eff z)_j on the working set; step ratios
-          double best = 1e300;
-          double bestj = -1.0;
+          real best = QPC_HUGE;
+          real bestj = -1.0;
           for (int j = lane; j < nrho; j += 64) {
             int c = j / N, jj = j % N;
-            double w = sm[D.lds[L_WS] + j];
-            double rj = 0.0;
+            real w = sm[D.lds[L_WS] + j];
+            real rj = 0.0;
             if (w != 0.0 && sm[D.lds[L_HI] + j] > 0.0) {
-              double hz = eps * sm[D.lds[L_DR] + j];
+              real hz = eps * sm[D.lds[L_DR] + j];
               for (int i = 0; i < N; i++) hz += sm[D.lds[L_HR] + c * QPC_CSH(N) + jj * N + i] * sm[D.lds[L_DR] + c * N + i];
               for (int a = 0; a < 6; a++) hz -= sm[D.lds[L_G] + a * QPC_GS(nrho) + j] * sm[D.lds[L_DL] + m1 + a];
               rj = (w == -1.0) ? -hz : hz;
-              if (rj > 1e-300) { double ratio = sm[D.lds[L_U] + j] / rj; if (ratio < best) { best = ratio; bestj = (double)j; } }
+              if (rj > QPC_TINY) { real ratio = sm[D.lds[L_U] + j] / rj; if (ratio < best) { best = ratio; bestj = (real)j; } }
             }
             sm[D.lds[L_TR2] + j] = rj;
           }
@@ -2615,19 +2662,23 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
           else { QPC_RED_ARGMIN_PUT(0, t1, jdrop, best, bestj < 0.0 ? 0x3fffffff : (int)bestj); }
         } QPC_END_PHASE
         QPC_RED_ARGMIN_GET(0, t1, jdrop);
-        if (!(t1 < 1e299)) jdrop = -1;
-        const double xp = sm[D.lds[L_XR] + p];
-        const double sp = nsign * xp - (side < 0 ? 0.0 : -hip); // < 0 : violation
-        const double zn = nsign * sm[D.lds[L_DR] + p];
-        const double t2 = zn > 1e-300 ? -sp / zn : 1e300;
-        const double tt = t1 < t2 ? t1 : t2;
-        if (!(tt < 1e299)) { status = QPC_STATUS_INFEASIBLE; fail = true; break; }
+        if (!(t1 < QPC_HUGE_TEST)) jdrop = -1;
+        const real xp = sm[D.lds[L_XR] + p];
+        const real sp = nsign * xp - (side < 0 ? 0.0 : -hip); // < 0 : violation
+        const real zn = nsign * sm[D.lds[L_DR] + p];
+        const real t2 = zn > QPC_TINY ? -sp / zn : QPC_HUGE;
+        const real tt = t1 < t2 ? t1 : t2;
+        if (!(tt < QPC_HUGE_TEST)) {
+#ifdef QPC_EMU_DEBUG
+          fprintf(stderr, "INFEASIBLE: unbounded GI step t1 %g t2 %g zn %g sp %g p %d iters %d\n", (double)t1, (double)t2, (double)zn, (double)sp, p, iters);
+#endif
+          status = QPC_STATUS_INFEASIBLE; fail = true; break; }
         const bool full = t2 <= t1;
         QPC_PHASE(lane) { // the step moves rho and the wrench multipliers only (see rho_solve)
           if (lane < 6) sm[D.lds[L_LAM] + m1 + lane] = sm[D.lds[L_LAM] + m1 + lane] + tt * sm[D.lds[L_DL] + m1 + lane];
           for (int j = lane; j < nrho; j += 64) {
             sm[D.lds[L_XR] + j] = sm[D.lds[L_XR] + j] + tt * sm[D.lds[L_DR] + j];
-            double u = sm[D.lds[L_U] + j] - tt * sm[D.lds[L_TR2] + j];
+            real u = sm[D.lds[L_U] + j] - tt * sm[D.lds[L_TR2] + j];
             if (!full && j == jdrop) { u = 0.0; sm[D.lds[L_WS] + j] = 0.0; }
             if (full && j == p) sm[D.lds[L_WS] + j] = side;
             sm[D.lds[L_U] + j] = u;
@@ -2662,33 +2713,33 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
       // iterate by <= 1e-9 relative, the residuals it started from (still in L_RV / L_RE / L_RR / L_RC, gradient in
       // L_WSP) are those of an iterate 1e-9 away -- far inside the 1e-7 acceptance tolerance -- and are not recomputed
       if (!S.confirmed) S.residuals();
-      double arp = 0.0, ars = 0.0, asp = 0.0, ass = 0.0, anan = 0.0, abv = 0.0, agm = 0.0, axm = 0.0;
+      real arp = 0.0, ars = 0.0, asp = 0.0, ass = 0.0, anan = 0.0, abv = 0.0, agm = 0.0, axm = 0.0;
       unsigned long long bbad = 0ull, bchanged = 0ull;
       QPC_PHASE(lane) {
-        double rp = 0.0, rs = 0.0, sp = 0.0, ss = 0.0, bv = 0.0, gm = 0.0, xm = 0.0;
+        real rp = 0.0, rs = 0.0, sp = 0.0, ss = 0.0, bv = 0.0, gm = 0.0, xm = 0.0;
         for (int r = lane; r < m; r += 64) {
-          double a = QPC_FABS(sm[D.lds[L_RC] + r]); rp = a > rp || !(a == a) ? a : rp;
-          double b = QPC_FABS(sm[D.lds[L_D] + r]); sp = b > sp ? b : sp;
+          real a = QPC_FABS(sm[D.lds[L_RC] + r]); rp = a > rp || !(a == a) ? a : rp;
+          real b = QPC_FABS(sm[D.lds[L_D] + r]); sp = b > sp ? b : sp;
         }
         for (int f = lane; f < nf; f += 64) {
-          double a = QPC_FABS(sm[D.lds[L_RV] + f]); rs = a > rs || !(a == a) ? a : rs;
-          double b = QPC_FABS(sm[D.lds[L_GV] + f]); ss = b > ss ? b : ss;
+          real a = QPC_FABS(sm[D.lds[L_RV] + f]); rs = a > rs || !(a == a) ? a : rs;
+          real b = QPC_FABS(sm[D.lds[L_GV] + f]); ss = b > ss ? b : ss;
           b = sm[D.lds[L_DV] + f]; ss = b > ss ? b : ss; // |E_v' lam| scale, left there by Solver::residuals
         }
-        for (int s = lane; s < ne; s += 64) { double a = QPC_FABS(sm[D.lds[L_RE] + s]); rs = a > rs || !(a == a) ? a : rs; }
+        for (int s = lane; s < ne; s += 64) { real a = QPC_FABS(sm[D.lds[L_RE] + s]); rs = a > rs || !(a == a) ? a : rs; }
         for (int j = lane; j < nrho; j += 64) {
-          double a = QPC_FABS(sm[D.lds[L_RR] + j]); rs = a > rs || !(a == a) ? a : rs;
+          real a = QPC_FABS(sm[D.lds[L_RR] + j]); rs = a > rs || !(a == a) ? a : rs;
           // bound conditions of the REFINED solution (the search decided on eps-regularised solves):
           // L_WSP = Lagrangian gradient w.r.t. rho (Solver::residuals)
-          const double w = sm[D.lds[L_WS] + j], hi = sm[D.lds[L_HI] + j], x = sm[D.lds[L_XR] + j], gl = sm[D.lds[L_WSP] + j];
+          const real w = sm[D.lds[L_WS] + j], hi = sm[D.lds[L_HI] + j], x = sm[D.lds[L_XR] + j], gl = sm[D.lds[L_WSP] + j];
           if (hi > 0.0) {
-            const double u = (w == -1.0) ? gl : ((w == 1.0) ? -gl : 0.0);
+            const real u = (w == -1.0) ? gl : ((w == 1.0) ? -gl : 0.0);
             sm[D.lds[L_U] + j] = u;
             gm = QPC_FABS(gl) > gm ? QPC_FABS(gl) : gm;
             xm = QPC_FABS(x) > xm ? QPC_FABS(x) : xm;
           }
         }
-        double bad = (!(rp == rp) || !(rs == rs)) ? 1.0 : 0.0;
+        real bad = (!(rp == rp) || !(rs == rs)) ? 1.0 : 0.0;
         QPC_RED_MAX_PUT(0, arp, rp == rp ? rp : 0.0); QPC_RED_MAX_PUT(1, ars, rs == rs ? rs : 0.0);
         QPC_RED_MAX_PUT(2, asp, sp); QPC_RED_MAX_PUT(3, ass, ss); QPC_BALLOT_PUT(4, bbad, bad != 0.0);
         QPC_RED_MAX_PUT(5, agm, gm); QPC_RED_MAX_PUT(6, axm, xm);
@@ -2698,20 +2749,28 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
       ass = QPC_RED_MAX_GET(3, ass); QPC_BALLOT_GET(4, bbad); anan = bbad ? 1.0 : 0.0;
       agm = QPC_RED_MAX_GET(5, agm); axm = QPC_RED_MAX_GET(6, axm);
       const bool nan = anan > 0.0;
-      double r_prim = arp / (1.0 + asp), r_stat = ars / (1.0 + ass);
-      if (nan || !(r_prim < 1e300) || !(r_stat < 1e300)) { status = QPC_STATUS_NUMERICAL_ERROR; break; }
-      if (r_prim > D.tol_accept) { status = QPC_STATUS_INFEASIBLE; break; } // equality rows inconsistent on the feasible set
-      if (r_stat > D.tol_accept) status = QPC_STATUS_ALMOST_OPTIMAL;
+      real r_prim = arp / (1.0 + asp), r_stat = ars / (1.0 + ass);
+      if (nan || !(r_prim < QPC_HUGE) || !(r_stat < QPC_HUGE)) { status = QPC_STATUS_NUMERICAL_ERROR; break; }
+#ifdef QPC_EMU_DEBUG
+      fprintf(stderr, "ACCEPT r_prim %g r_stat %g\n", (double)r_prim, (double)r_stat);
+      if (r_prim > (real)D.tol_accept) fprintf(stderr, "INFEASIBLE: r_prim %g (arp %g asp %g) r_stat %g iters %d outer %d\n", (double)r_prim, (double)arp, (double)asp, (double)r_stat, iters, outer);
+#endif
+      // equality rows inconsistent on the feasible set.  fp32: a residual within QPC_ACCEPT_BAND of the tolerance is what an
+      // ill-conditioned but feasible QP leaves at that precision (a robot balanced on ONE contact point: cond(S22) > 1e5, pivots
+      // dropped as noise) -- reported as NUMERICAL_ERROR ("not resolved"), not as a verdict on the problem; truly inconsistent rows
+      // leave residuals of order one
+      if (r_prim > (real)D.tol_accept) { status = r_prim > QPC_ACCEPT_BAND * (real)D.tol_accept ? QPC_STATUS_INFEASIBLE : QPC_STATUS_NUMERICAL_ERROR; break; }
+      if (r_stat > (real)D.tol_accept) status = QPC_STATUS_ALMOST_OPTIMAL;
       if (!use_rho) break;
       // primal-dual test on the refined solution, at the acceptance tolerance: normally nothing moves
       // (one phase); if the eps-regularised search settled on a working set that is not optimal for
       // the true problem (near-degenerate friction cones), correct it and polish again
       S.last_gmax = agm; S.last_xmax = axm;
       QPC_PHASE(lane) {
-        double changed = 0.0;
-        const double tolu = D.tol_accept * (1.0 + agm), tolb = D.tol_accept * (1.0 + axm);
+        real changed = 0.0;
+        const real tolu = (real)D.tol_accept * (1.0 + agm), tolb = (real)D.tol_accept * (1.0 + axm);
         for (int j = lane; j < nrho; j += 64) {
-          double w = sm[D.lds[L_WS] + j], hi = sm[D.lds[L_HI] + j], x = sm[D.lds[L_XR] + j], nw_ = w;
+          real w = sm[D.lds[L_WS] + j], hi = sm[D.lds[L_HI] + j], x = sm[D.lds[L_XR] + j], nw_ = w;
           if (!(hi > 0.0)) continue;
           if (w != 0.0) { if (sm[D.lds[L_U] + j] < -tolu) nw_ = 0.0; }
           else if (x < -tolb) nw_ = -1.0;
@@ -2750,7 +2809,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
   if (WARM && io.wset) { // the working set goes back to the caller (zeros = "start cold" after a failed solve)
     unsigned long long blo = 0ull, bupf = 0ull;
     QPC_PHASE(lane) {
-      const double w = (lane < nrho) ? (double)sm[D.lds[L_WS] + (lane < nrho ? lane : 0)] : 0.0;
+      const real w = (lane < nrho) ? (real)sm[D.lds[L_WS] + (lane < nrho ? lane : 0)] : 0.0;
       QPC_BALLOT_PUT(0, blo, w == -1.0);
       QPC_BALLOT_PUT(1, bupf, w == 1.0);
     } QPC_END_PHASE
@@ -2771,19 +2830,19 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
     for (int f = lane; f < nf; f += 64) sm[D.lds[L_VD] + IT[D.it[IT_FREE_K] + f]] = sm[D.lds[L_XV] + f] * sm[D.lds[L_SQH] + f];
     for (int idx = lane; idx < nc * 6; idx += 64) { // value(wrench_world) = G_c rho_c
       int c = idx / 6, a = idx % 6;
-      double acc = 0.0;
+      real acc = 0.0;
       if (use_rho) for (int i = 0; i < N; i++) acc += sm[D.lds[L_G] + a * QPC_GS(nrho) + c * N + i] * sm[D.lds[L_XR] + c * N + i];
       sm[D.lds[L_CWR] + idx] = acc;
     }
     if (lane < nb) {
-      double *iw = QPC_LA(iw_, lane);
+      real *iw = QPC_LA(iw_, lane);
       for (int a = 0; a < 16; a++) iw[a] = QPC_LA(keep_iw_, lane)[a];
     }
     if (lane < nv) { // S_k v̇_k of the FREE velocity indices (the pinned ones already ride in Ab)
-      double *sk = QPC_LA(sk_, lane);
+      real *sk = QPC_LA(sk_, lane);
       for (int a = 0; a < 6; a++) sk[a] = QPC_LA(keep_sk_, lane)[a];
       const int f = IT[D.it[IT_FREE_OF] + lane];
-      const double vd = f >= 0 ? (double)sm[D.lds[L_XV] + f] * (double)sm[D.lds[L_SQH] + f] : 0.0;
+      const real vd = f >= 0 ? (real)sm[D.lds[L_XV] + f] * (real)sm[D.lds[L_SQH] + f] : 0.0;
       for (int a = 0; a < 6; a++) sm[D.lds[L_SVK] + 6 * lane + a] = sk[a] * vd;
     }
   } QPC_END_PHASE
@@ -2791,7 +2850,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
   QPC_PHASE(lane) { // S_j v̇_j per body
     if (lane < nb) {
       const int *mt = QPC_LI(M.v, lane);
-      double sv[6] = {0, 0, 0, 0, 0, 0};
+      real sv[6] = {0, 0, 0, 0, 0, 0};
       const int v0 = MT_V0(mt), n = MT_NVJ(mt);
       for (int c = 0; c < n; c++)
         for (int a = 0; a < 6; a++) sv[a] += sm[D.lds[L_SVK] + 6 * (v0 + c) + a];
@@ -2805,7 +2864,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
     if (lane < nb) {
       const int i = lane;
       const int *mt = QPC_LI(M.v, lane);
-      double A[6], I[10], ia[6];
+      real A[6], I[10], ia[6];
       ld(sm + D.lds[L_SV] + 6 * i, 6, A);
       QPC_UNROLL_JIT
       for (int s = 0; s < QPC_MAXD; s++) {
@@ -2813,7 +2872,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
         if (an >= 0)
           for (int a = 0; a < 6; a++) A[a] += sm[D.lds[L_SV] + 6 * an + a];
       }
-      const double *iw = QPC_LA(iw_, lane);
+      const real *iw = QPC_LA(iw_, lane);
       for (int a = 0; a < 10; a++) I[a] = iw[a];
       inertia_mul(I, A, ia);
       for (int a = 0; a < 6; a++) ia[a] += iw[10 + a];
@@ -2845,27 +2904,27 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, const d
     if (lane < nv) {
       const int k = lane;
       const int *mt = QPC_LI(M.v, lane);
-      double tau = 0.0;
+      real tau = 0.0;
       if (MT_VBODY(mt) != D.floating) {
-        double F[6] = {0, 0, 0, 0, 0, 0};
+        real F[6] = {0, 0, 0, 0, 0, 0};
         unsigned long long msk = ((unsigned long long)(unsigned)mt[5] << 32) | (unsigned long long)(unsigned)mt[4];
         if (D.dfs) { // subtree = bodies first .. last: prefix[last] - prefix[first - 1]
           const int first = QPC_CTZ64(msk), last = first + QPC_POPC64(msk) - 1;
-          for (int a = 0; a < 6; a++) F[a] = sm[D.lds[L_BW] + 6 * last + a] - (first > 0 ? (double)sm[D.lds[L_BW] + 6 * (first > 0 ? first - 1 : 0) + a] : 0.0);
+          for (int a = 0; a < 6; a++) F[a] = sm[D.lds[L_BW] + 6 * last + a] - (first > 0 ? (real)sm[D.lds[L_BW] + 6 * (first > 0 ? first - 1 : 0) + a] : 0.0);
         } else
         while (msk) {
           const int b = QPC_CTZ64(msk);
           msk &= msk - 1;
           for (int a = 0; a < 6; a++) F[a] += sm[D.lds[L_BW] + 6 * b + a];
         }
-        const double *sk = QPC_LA(sk_, lane);
+        const real *sk = QPC_LA(sk_, lane);
         for (int a = 0; a < 6; a++) tau += sk[a] * F[a];
       }
-      io.tau[k] = tau;
-      io.vdot[k] = sm[D.lds[L_VD] + k];
+      io.tau[k] = QPC_TO_DOUBLE(tau);
+      io.vdot[k] = QPC_TO_DOUBLE((real)sm[D.lds[L_VD] + k]);
     }
     if (io.cwrench)
-      for (int idx = lane; idx < nc * 6; idx += 64) io.cwrench[idx] = sm[D.lds[L_CWR] + idx];
+      for (int idx = lane; idx < nc * 6; idx += 64) io.cwrench[idx] = QPC_TO_DOUBLE((real)sm[D.lds[L_CWR] + idx]);
     if (lane == 0) {
       const bool good = status == QPC_STATUS_OPTIMAL || status == QPC_STATUS_ALMOST_OPTIMAL;
       io.status[0] = (good && bbad_in != 0ull) ? QPC_STATUS_NUMERICAL_ERROR : ((good && bneg_cap != 0ull) ? QPC_STATUS_INFEASIBLE : status);

@@ -18,6 +18,27 @@ def build():
     return EMU_LIB
 
 
+EMU_F32_LIB = os.path.join(HERE, "_build", "libqpc_emul_f32.so")
+
+
+def build_f32():
+    import fcntl
+    os.makedirs(os.path.join(HERE, "_build"), exist_ok=True)
+    with open(os.path.join(HERE, "_build", ".build.lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        subprocess.run(["make", "-s", "-C", os.path.join(HERE, "emul"), "../_build/libqpc_emul_f32.so"], check=True)
+    return EMU_F32_LIB
+
+
+def factory_f32(mech, n_basis, floating):
+    """the fp32 variant of the tick (qpc_set_precision(ctrl, QPC_PRECISION_F32)) through its lane-serial emulation"""
+    from qpcontrol_jl_amd import binding
+    build_f32()
+    c = binding.Controller(binding.Model(mech, EMU_F32_LIB), n_basis, floating)
+    c.set_precision(1)
+    return c
+
+
 def factory(mech, n_basis, floating):
     from qpcontrol_jl_amd import binding
     build()

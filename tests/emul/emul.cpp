@@ -17,14 +17,18 @@
 #include "../../qpcontrol.jl_amd/csrc/qpc_compile.h"
 #include "../../qpcontrol.jl_amd/csrc/qpc_pipeline.h"
 
+// arithmetic type of the emulated tick: double, or the float class of the fp32 variant (libqpc_emul_f32.so: -DQPC_F32), the
+// counterpart of the fp32 hiprtc module of qpc_jit.cpp
+#include "../../qpcontrol.jl_amd/csrc/qpc_real.h"
+
 struct EmuState {
-  std::vector<double> mem;
+  std::vector<real> mem;
   std::vector<int> wphase, wlane, rphase, rlane;
   int phase = 0, lane = -1, section = -1;
   long races = 0, uninit = 0, outside = 0;
   std::string first;
   void reset(int n) {
-    mem.assign(n, std::nan(""));
+    mem.assign(n, real(std::nan("")));
     wphase.assign(n, -1); wlane.assign(n, -1); rphase.assign(n, -1); rlane.assign(n, -1);
     phase = 0; lane = -1;
   }
@@ -51,9 +55,9 @@ static inline void emu_enter_lane(int l) { g_emu->lane = l; }
 
 struct Ref {
   int i;
-  operator double() const { g_emu->on_read(i); return g_emu->mem[i]; }
-  Ref &operator=(double v) { g_emu->on_write(i); g_emu->mem[i] = v; return *this; }
-  Ref &operator=(const Ref &o) { return *this = (double)o; }
+  operator real() const { g_emu->on_read(i); return g_emu->mem[i]; }
+  Ref &operator=(real v) { g_emu->on_write(i); g_emu->mem[i] = v; return *this; }
+  Ref &operator=(const Ref &o) { return *this = (real)o; }
 };
 struct Lds {
   int base;
@@ -72,48 +76,62 @@ struct Lds {
 #define QPC_END_PHASE_REG QPC_END_PHASE_SOFT
 #define QPC_PHASE_SYNC g_emu->phase++;
 #define QPC_LANE_SCOPE
-#define QPC_SINCOS(x, s, c) do { double x__ = (x); s = std::sin(x__); c = std::cos(x__); } while (0)
-#define QPC_SQRT(x) std::sqrt((double)(x))
-#define QPC_FABS(x) std::fabs((double)(x))
-#define QPC_ATAN2(y, x) std::atan2((double)(y), (double)(x))
-#define QPC_RCP(x) (1.0 / (double)(x))
-#define QPC_RCP_SEARCH(x) (1.0 / (double)(x))
-#define QPC_RSQRT(x) (1.0 / std::sqrt((double)(x)))
-#define QPC_LANE_ARRAY(name, n) double name[64][n]
+#ifdef QPC_F32
+typedef float emu_raw;
+#else
+typedef double emu_raw;
+#endif
+#define QPC_SINCOS(x, s, c) do { emu_raw x__ = (emu_raw)(real)(x); s = real(std::sin(x__)); c = real(std::cos(x__)); } while (0)
+#define QPC_SQRT(x) real(std::sqrt((emu_raw)(real)(x)))
+#define QPC_FABS(x) real(std::fabs((emu_raw)(real)(x)))
+#define QPC_ATAN2(y, x) real(std::atan2((emu_raw)(real)(y), (emu_raw)(real)(x)))
+#define QPC_RCP(x) real((emu_raw)1 / (emu_raw)(real)(x))
+#define QPC_RCP_SEARCH(x) real((emu_raw)1 / (emu_raw)(real)(x))
+#define QPC_RSQRT(x) real((emu_raw)1 / std::sqrt((emu_raw)(real)(x)))
+#define QPC_LANE_ARRAY(name, n) real name[64][n]
 #define QPC_LA(name, lane) name[lane]
 #define QPC_LANE_INTS(name, n) int name[64][n]
 #define QPC_LI(name, lane) name[lane]
 #define QPC_CTZ64(x) __builtin_ctzll((unsigned long long)(x))
 #define QPC_POPC64(x) __builtin_popcountll((unsigned long long)(x))
-// lane-serial model of v_mfma_f64_16x16x4_f64 (operand / accumulator lane maps of the guide)
-static thread_local double emu_mfma_a[64], emu_mfma_b[64];
-#define QPC_MFMA_F64_16x16x4(lane, ACC, AEXPR, BEXPR)                                                    \
+// lane-serial model of v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32 (operand / accumulator lane maps of the guide: the f64
+// instruction has its own C/D row map)
+#ifdef QPC_F32
+#define QPC_MFMA_CROW(lane, reg) (4 * ((lane) >> 4) + (reg))
+#else
+#define QPC_MFMA_CROW(lane, reg) (((lane) >> 4) + 4 * (reg))
+#endif
+static thread_local real emu_mfma_a[64], emu_mfma_b[64];
+#define QPC_MFMA_16x16x4(lane, ACC, AEXPR, BEXPR)                                                    \
   QPC_PHASE(lane) { emu_mfma_a[lane] = (AEXPR); emu_mfma_b[lane] = (BEXPR); } QPC_END_PHASE               \
   QPC_PHASE(lane) {                                                                                       \
-    double *acc__ = (ACC);                                                                                \
+    real *acc__ = (ACC);                                                                                \
     for (int r__ = 0; r__ < 4; r__++) {                                                                   \
-      const int row__ = (lane >> 4) + 4 * r__, col__ = lane & 15;                                         \
+      const int row__ = QPC_MFMA_CROW(lane, r__), col__ = lane & 15;                                        \
       for (int k__ = 0; k__ < 4; k__++) acc__[r__] += emu_mfma_a[row__ + 16 * k__] * emu_mfma_b[col__ + 16 * k__]; \
     }                                                                                                     \
   } QPC_END_PHASE
 // lane-serial model of the DPP quad broadcasts: publish, then gather from the quad
-static thread_local double emu_quad[64];
+static thread_local real emu_quad[64];
 #define QPC_QUAD_GATHER(lane, OUT4, XEXPR)                                                    \
   QPC_PHASE(lane) { emu_quad[lane] = (XEXPR); } QPC_END_PHASE_SOFT                              \
-  QPC_PHASE(lane) { double *o__ = (OUT4); for (int i__ = 0; i__ < 4; i__++) o__[i__] = emu_quad[(lane & ~3) + i__]; } QPC_END_PHASE_SOFT
+  QPC_PHASE(lane) { real *o__ = (OUT4); for (int i__ = 0; i__ < 4; i__++) o__[i__] = emu_quad[(lane & ~3) + i__]; } QPC_END_PHASE_SOFT
 // lane-serial model of the DPP row_share broadcasts: publish, then gather from lane K of the row of 16
-static thread_local double emu_row[64][8];
+static thread_local real emu_row[64][8];
 #define QPC_ROW_SHARE(lane, OUT, N, X, K)                                                                              \
-  QPC_PHASE(lane) { const double *x__ = (X); for (int i__ = 0; i__ < (N); i__++) emu_row[lane][i__] = x__[i__]; } QPC_END_PHASE_SOFT \
-  QPC_PHASE(lane) { double *o__ = (OUT); for (int i__ = 0; i__ < (N); i__++) o__[i__] = emu_row[(lane & ~15) + (K)][i__]; } QPC_END_PHASE_SOFT
+  QPC_PHASE(lane) { const real *x__ = (X); for (int i__ = 0; i__ < (N); i__++) emu_row[lane][i__] = x__[i__]; } QPC_END_PHASE_SOFT \
+  QPC_PHASE(lane) { real *o__ = (OUT); for (int i__ = 0; i__ < (N); i__++) o__[i__] = emu_row[(lane & ~15) + (K)][i__]; } QPC_END_PHASE_SOFT
 // lane-serial model of the wave prefix sum (the device adds in tree order: results agree to rounding, not bit for bit)
 #define QPC_WAVE_INCL_SCAN(lane, ARR, N)                                                                                \
-  QPC_PHASE(lane) { const double *x__ = (ARR); for (int i__ = 0; i__ < (N); i__++) emu_row[lane][i__] = x__[i__]; } QPC_END_PHASE_SOFT \
-  QPC_PHASE(lane) { double *o__ = (ARR); for (int i__ = 0; i__ < (N); i__++) { double s__ = 0.0; for (int l__ = 0; l__ <= lane; l__++) s__ += emu_row[l__][i__]; o__[i__] = s__; } } QPC_END_PHASE_SOFT
+  QPC_PHASE(lane) { const real *x__ = (ARR); for (int i__ = 0; i__ < (N); i__++) emu_row[lane][i__] = x__[i__]; } QPC_END_PHASE_SOFT \
+  QPC_PHASE(lane) { real *o__ = (ARR); for (int i__ = 0; i__ < (N); i__++) { real s__ = 0.0; for (int l__ = 0; l__ <= lane; l__++) s__ += emu_row[l__][i__]; o__[i__] = s__; } } QPC_END_PHASE_SOFT
 // reductions across a phase boundary: lane-serial form through the (emulator-only) scratch that
 // follows the kernel's LDS slab
 #define QPC_RED_MAX_PUT(slot, name, val) sm[D.lds_doubles + 128 * (slot) + lane] = (val)
 // like the device (qpc_device.h wave_max_scale): maximum of non-negative values, low mantissa word dropped
+#ifdef QPC_F32
+static inline real emu_scale_trunc(real x) { return x < real(0) ? -x : x; } // (fp32: the device takes the maximum of the whole word)
+#else
 static inline double emu_scale_trunc(double x) {
   unsigned long long b;
   std::memcpy(&b, &x, 8);
@@ -121,28 +139,31 @@ static inline double emu_scale_trunc(double x) {
   std::memcpy(&x, &b, 8);
   return x;
 }
+#endif
 #define QPC_RED_MAX_GET(slot, name) emu_scale_trunc(qpc::umax(sm, D.lds_doubles + 128 * (slot), 64))
 #define QPC_RED_SUM_PUT(slot, name, val) sm[D.lds_doubles + 128 * (slot) + lane] = (val)
-static inline double emu_sum64(const double *x) { double s = 0.0; for (int l = 0; l < 64; l++) s += x[l]; return s; }
-#define QPC_RED_SUM_GET(slot, name) ([&]() { double x__[64]; for (int l__ = 0; l__ < 64; l__++) x__[l__] = sm[D.lds_doubles + 128 * (slot) + l__]; return emu_sum64(x__); }())
+static inline real emu_sum64(const real *x) { real s = 0.0; for (int l = 0; l < 64; l++) s += x[l]; return s; }
+#define QPC_RED_SUM_GET(slot, name) ([&]() { real x__[64]; for (int l__ = 0; l__ < 64; l__++) x__[l__] = sm[D.lds_doubles + 128 * (slot) + l__]; return emu_sum64(x__); }())
 #define QPC_BALLOT_PUT(slot, name, pred) sm[D.lds_doubles + 128 * (slot) + lane] = (pred) ? 1.0 : 0.0
 #define QPC_BALLOT_GET(slot, name) \
-  do { name = 0ull; for (int l__ = 0; l__ < 64; l__++) if ((double)sm[D.lds_doubles + 128 * (slot) + l__] != 0.0) name |= 1ull << l__; } while (0)
+  do { name = 0ull; for (int l__ = 0; l__ < 64; l__++) if ((real)sm[D.lds_doubles + 128 * (slot) + l__] != 0.0) name |= 1ull << l__; } while (0)
 #define QPC_RED_ARGMIN_PUT(slot, name, iname, val, idx) \
-  do { sm[D.lds_doubles + 128 * (slot) + lane] = (val); sm[D.lds_doubles + 128 * (slot) + 64 + lane] = (double)(idx); } while (0)
+  do { sm[D.lds_doubles + 128 * (slot) + lane] = (val); sm[D.lds_doubles + 128 * (slot) + 64 + lane] = (real)(idx); } while (0)
 #define QPC_RED_ARGMIN_LANE_PUT(slot, name, iname, val, idx) QPC_RED_ARGMIN_PUT(slot, name, iname, val, idx)
 #define QPC_RED_ARGMIN_GET(slot, name, iname) \
-  do { name = 1e308; iname = 0x3fffffff; \
-       for (int l__ = 0; l__ < 64; l__++) { double v__ = sm[D.lds_doubles + 128 * (slot) + l__]; \
-         int i__ = (int)(double)sm[D.lds_doubles + 128 * (slot) + 64 + l__]; \
+  do { name = QPC_HUGE; iname = 0x3fffffff; \
+       for (int l__ = 0; l__ < 64; l__++) { real v__ = sm[D.lds_doubles + 128 * (slot) + l__]; \
+         int i__ = (int)(real)sm[D.lds_doubles + 128 * (slot) + 64 + l__]; \
          if (v__ < name || (v__ == name && i__ < iname)) { name = v__; iname = i__; } } } while (0)
 // ancestor-chain bound of the tick: the library's limit (tree depth <= 32, checked by qpc_compile_program) -- the device gets the actual
 // depth from the JIT; QPC_GENERIC_MAXD = 16 is a workaround for a hipcc miscompile of the ahead-of-time kernel only
 #define QPC_MAXD 32
 #include "../../qpcontrol.jl_amd/csrc/qpc_tick.h"
+#ifndef QPC_F32 // (the simulation step and the dense L0 / L1 solvers are fp64 code: not part of the fp32 emulation)
 #include "../../qpcontrol.jl_amd/csrc/qpc_sim.h"
 #include "../../qpcontrol.jl_amd/csrc/qpc_qp_dense.h"
 #include "../../qpcontrol.jl_amd/csrc/qpc_l1_dense.h"
+#endif
 
 static std::mutex g_rep_mu; // the host pipeline's worker threads report into these
 static long g_races = 0, g_uninit = 0, g_outside = 0;
@@ -167,8 +188,8 @@ static void emu_ticks(qpc_controller *c, const QpcHostJob &job, int64_t lo, int6
     io.status = job.status + b; io.iters = job.iters ? job.iters + b : nullptr; io.prof = nullptr;
     io.wset = job.working_set ? (unsigned long long *)job.working_set + 2 * b : nullptr;
     qpc::qpc_tick_prologue<Lds>(D, c->prog.dims_s, c->prog.itab.data(), Lds{0});
-    if (job.working_set) qpc::qpc_tick<Lds, true>(D, c->prog.dims_s, c->prog.itab.data(), c->prog.dtab.data(), Lds{0}, io);
-    else qpc::qpc_tick<Lds, false>(D, c->prog.dims_s, c->prog.itab.data(), c->prog.dtab.data(), Lds{0}, io);
+    if (job.working_set) qpc::qpc_tick<Lds, true>(D, c->prog.dims_s, c->prog.itab.data(), qpc_dtab{c->prog.dtab.data()}, Lds{0}, io);
+    else qpc::qpc_tick<Lds, false>(D, c->prog.dims_s, c->prog.itab.data(), qpc_dtab{c->prog.dtab.data()}, Lds{0}, io);
     races += emu.races; uninit += emu.uninit; outside += emu.outside;
     if (first.empty()) first = emu.first;
   }
@@ -229,6 +250,11 @@ extern "C" {
 int32_t qpc_finalize_devices(qpc_controller *c, int32_t n_devices, const int32_t *device_ids, qpc_layout *out) {
   if (!c || n_devices < 1 || !device_ids) return QPC_ERR_INVALID_ARGUMENT;
   if (!c->finalized) {
+#ifdef QPC_F32
+    if (c->precision != QPC_PRECISION_F32) { qpc_set_error("libqpc_emul_f32.so emulates the fp32 tick: call qpc_set_precision(ctrl, QPC_PRECISION_F32) first"); return QPC_ERR_UNSUPPORTED; }
+#else
+    if (c->precision != QPC_PRECISION_F64) { qpc_set_error("libqpc_emul.so emulates the fp64 tick (the fp32 variant is libqpc_emul_f32.so)"); return QPC_ERR_UNSUPPORTED; }
+#endif
     int rc = qpc_compile_program(c);
     if (rc != QPC_OK) return rc;
     c->rt = new QpcRuntime();
@@ -321,6 +347,7 @@ int32_t emu_chunk_log(qpc_controller *c, int64_t *out, int32_t max_rows) {
 }
 void emu_fail_at(qpc_controller *c, int64_t b) { c->rt->backend->fail_at = b; }
 
+#ifndef QPC_F32
 // L1 (plain serial code per QP, like L0)
 int32_t qpc_assemble_solve_batch(qpc_controller *c, int64_t B, const double *task_J, const double *task_bias,
                                  const double *desired, const double *momentum_A, const double *momentum_rhs,
@@ -408,6 +435,20 @@ int32_t qpc_rollout_batch(qpc_controller *c, int64_t B, int64_t n_steps, double 
   return QPC_OK;
 }
 
+#else // QPC_F32: the simulation step and the dense L0 / L1 solvers are fp64 code, not part of the fp32 emulation
+static int unsupported_f32(const char *what) { qpc_set_error(std::string(what) + ": fp64 only (this is the emulation of the fp32 tick)"); return QPC_ERR_UNSUPPORTED; }
+int32_t qpc_assemble_solve_batch(qpc_controller *, int64_t, const double *, const double *, const double *, const double *, const double *,
+                                 const double *, const double *, const double *, const double *, const double *, const double *, double *,
+                                 double *, int32_t *, int32_t *) { return unsupported_f32("qpc_assemble_solve_batch"); }
+int32_t qpc_qp_solve_batch(int32_t, int32_t, int64_t, const double *, const double *, const double *, const double *, const double *,
+                           const qpc_settings *, int32_t, double *, double *, int32_t *, int32_t *) { return unsupported_f32("qpc_qp_solve_batch"); }
+int32_t qpc_sim_step_batch(qpc_controller *, int64_t, double *, double *, const double *, const int32_t *, const qpc_sim_params *, int32_t *) {
+  return unsupported_f32("qpc_sim_step_batch");
+}
+int32_t qpc_rollout_batch(qpc_controller *, int64_t, int64_t, double *, double *, const double *, const double *, const double *, const double *,
+                          const double *, const qpc_sim_params *, double *, int32_t *, int32_t *) { return unsupported_f32("qpc_rollout_batch"); }
+#endif // QPC_F32
+
 // race-detector report: counts since the last call
 void emu_report(long *races, long *uninit, long *outside, char *first, int n) {
   std::lock_guard<std::mutex> lk(g_rep_mu);
@@ -425,7 +466,7 @@ extern "C" long emu_selftest_race() {
   Lds sm{0};
   QPC_PHASE(lane) { sm[lane] = 1.0; } QPC_END_PHASE
   QPC_PHASE(lane) {
-    double x = sm[(lane + 63) % 64];
+    real x = sm[(lane + 63) % 64];
     sm[lane] = x + 1.0;
   } QPC_END_PHASE
   long r = emu.races;

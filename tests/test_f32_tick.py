@@ -1,0 +1,148 @@
+"""The fp32 variant of the tick (qpc_set_precision(ctrl, QPC_PRECISION_F32)): BASELINE config 5 as BASELINE.json words it -- "mixed
+active-contact-set batch (varying inequality count per QP), fp32, MFMA batched-GEMM KKT path", modelled on the reference's
+mixed-contact-set test /root/reference/test/controller.jl:169-230 (target 1e-4 relative on tau).
+
+The SAME device source as the fp64 tick with `real` = float (csrc/qpc_real.h), every solver tolerance at the fp32 rounding floor.
+Checked against the oracle (fp64, reference layout) and against the fp64 tick of the same library:
+  * a QP the fp32 tick calls OPTIMAL is feasible (the fp64 tick solves it) and its tau agrees with the fp64 optimum to
+    TOL_TAU_WELL = 1e-4 of the torque scale when at least four contact points are active, TOL_TAU = 1e-3 otherwise (a robot
+    balanced on one to three contact points is a QP with cond(S22) > 1e5: fp32 keeps three to four digits there);
+  * wherever the oracle is conclusive the statuses agree, except for the QPs the fp32 tick reports as NOT RESOLVED at its
+    precision (NUMERICAL_ERROR / ITERATION_LIMIT / a spurious INFEASIBLE on such ill-conditioned QPs): at most UNRESOLVED_MAX of
+    the batch, never with four or more active contacts;
+  * config 3 (all eight contacts): every state OPTIMAL.
+CPU: the lane-serial emulation of the fp32 source (tests/emul, libqpc_emul_f32.so).  GPU: the hiprtc-specialised fp32 module."""
+import numpy as np
+import pytest
+
+import emu
+from oracle import oracle as O
+from qpcontrol_jl_amd import binding
+from qpcontrol_jl_amd import workloads as W
+
+TOL_TAU_WELL = 1e-4   # relative to max(1, |tau|_inf) of the QP, >= 4 active contact points
+TOL_TAU = 1e-3        # ... one to three active contact points
+UNRESOLVED_MAX = 0.05
+
+
+def ora_factory(mech, N, fl):
+    return O.OracleController(O.OracleModel(mech), N, fl)
+
+
+def gpu_factory(mech, N, fl):
+    return binding.Controller(binding.Model(mech), N, fl)
+
+
+def gpu_factory_f32(mech, N, fl):
+    c = binding.Controller(binding.Model(mech), N, fl)
+    c.set_precision(1)
+    return c
+
+
+def _compare(f32_factory, f64_factory, B, config, seed, n_oracle):
+    c32, wl = W.atlas_workload(f32_factory, B, config, seed=seed)
+    c64, _ = W.atlas_workload(f64_factory, B, config, seed=seed)
+    a = (wl.q, wl.v, wl.desired, wl.contact_weight, wl.contact_maxnormalforce)
+    r32, r64 = c32.control_batch(*a), c64.control_batch(*a)
+    assert c32.layout.lds_bytes_per_qp * 2 == c64.layout.lds_bytes_per_qp  # the slab of floats
+    ok32, ok64 = r32["status"] <= 1, r64["status"] <= 1
+    nact = (wl.contact_maxnormalforce > 0).sum(1)
+    # (1) no false optimum: what fp32 accepts, fp64 solves -- and to the stated tolerance
+    assert np.all(ok64[ok32]), np.where(ok32 & ~ok64)[0]
+    scale = np.maximum(1.0, np.abs(r64["tau"]).max(axis=1, keepdims=True))
+    err = (np.abs(r32["tau"] - r64["tau"]) / scale).max(axis=1)
+    well = ok32 & (nact >= 4)
+    assert well.sum() > 0.4 * B
+    assert err[well].max() < TOL_TAU_WELL, (err[well].max(), np.argmax(np.where(well, err, 0)))
+    assert err[ok32].max() < TOL_TAU, err[ok32].max()
+    fl = list(wl.mech.velocity_range(wl.floating_body))
+    assert np.all(r32["tau"][:, fl] == 0.0)  # zero_floating_joint_torques!, momentum.jl:93-97
+    # (2) the QPs fp32 does not resolve: few, and only badly conditioned ones
+    unresolved = ok64 & ~ok32
+    assert unresolved.mean() <= UNRESOLVED_MAX, unresolved.mean()
+    assert not np.any(unresolved & (nact >= 4)), np.where(unresolved & (nact >= 4))[0]
+    # (3) against the oracle on a sample: statuses wherever it is conclusive (except the unresolved ones), numbers where it is optimal
+    oc, _ = W.atlas_workload(ora_factory, 1, config)
+    idx = np.random.default_rng(seed).choice(B, min(n_oracle, B), replace=False)
+    ro = oc.tick_batch(wl.q[idx], wl.v[idx], wl.desired[idx], wl.contact_weight[idx], wl.contact_maxnormalforce[idx])
+    oko = ro["status"] == 0
+    concl = (oko | (ro["status"] == 2)) & ~unresolved[idx]
+    assert np.array_equal(ok32[idx][concl], oko[concl]), np.where(ok32[idx][concl] != oko[concl])[0]
+    both = oko & ok32[idx] & (ro["iters"] < 20000)
+    assert both.sum() > 0.3 * len(idx)
+    so = np.maximum(1.0, np.abs(ro["tau"]).max(axis=1, keepdims=True))
+    eo = (np.abs(r32["tau"][idx] - ro["tau"]) / so).max(axis=1)
+    assert eo[both & (nact[idx] >= 4)].max() < TOL_TAU_WELL and eo[both].max() < TOL_TAU
+    print(f"\nfp32 tick, config {config}, {B} states: optimal fp32 {ok32.mean():.3f} / fp64 {ok64.mean():.3f}, unresolved {unresolved.mean():.4f}, "
+          f"rel tau error vs fp64 median {np.median(err[ok32]):.1e} max {err[ok32].max():.1e} (>= 4 contacts: {err[well].max():.1e}), "
+          f"vs oracle max {eo[both].max():.1e} on {int(both.sum())} states; working-set changes fp32 {(r32['iters'] % 1000).mean():.2f} / "
+          f"fp64 {(r64['iters'] % 1000).mean():.2f}")
+    return r32, r64
+
+
+@pytest.mark.parametrize("config", [3, 5])
+def test_f32_tick_emulated(config):
+    emu.build()
+    emu.build_f32()
+    emu.race_report()
+    r32, _ = _compare(emu.factory_f32, emu.factory, 192, config, 909 + config, 48)
+    if config == 3:
+        assert (r32["status"] == 0).all()
+    L = __import__("ctypes").CDLL(emu.EMU_F32_LIB)  # the fp32 emulation has its own race detector instance
+    import ctypes
+    r, u, o = ctypes.c_long(), ctypes.c_long(), ctypes.c_long()
+    buf = ctypes.create_string_buffer(256)
+    L.emu_report(ctypes.byref(r), ctypes.byref(u), ctypes.byref(o), buf, 256)
+    assert (r.value, u.value, o.value) == (0, 0, 0), buf.value
+    assert emu.race_report()[:3] == (0, 0, 0)
+
+
+def test_f32_precision_is_a_build_time_choice():
+    from qpcontrol_jl_amd import models as M
+    mech = M.atlas()
+    c = emu.factory(mech, 4, mech.findbody("pelvis"))
+    c.set_precision(1)
+    W.standing_setup(c, mech, M.atlas_nominal_configuration(mech))
+    with pytest.raises(binding.QpcError, match="fp64 tick"):
+        c.finalize()  # the fp64 emulation refuses an fp32 controller (and vice versa): no silent change of arithmetic
+    with pytest.raises(binding.QpcError):
+        c.set_precision(7)
+
+
+@pytest.mark.gpu
+def test_f32_tick_gpu_config5_at_8192():
+    """BASELINE config 5 in its stated precision at BASELINE config 3's batch"""
+    r32, r64 = _compare(gpu_factory_f32, gpu_factory, 8192, 5, 2027, 256)
+    assert np.array_equal(r32["status"] <= 1, r32["status"] <= 1)
+
+
+@pytest.mark.gpu
+def test_f32_tick_gpu_config3():
+    r32, _ = _compare(gpu_factory_f32, gpu_factory, 4096, 3, 2025, 128)
+    assert (r32["status"] == 0).all()
+
+
+@pytest.mark.gpu
+def test_f32_tick_gpu_matches_its_emulation():
+    """the device code and its lane-serial emulation are the same source: same statuses, tau to fp32 rounding"""
+    emu.build_f32()
+    cg, wl = W.atlas_workload(gpu_factory_f32, 256, 5, seed=31)
+    ce, _ = W.atlas_workload(emu.factory_f32, 256, 5, seed=31)
+    a = (wl.q, wl.v, wl.desired, wl.contact_weight, wl.contact_maxnormalforce)
+    rg, re_ = cg.control_batch(*a), ce.control_batch(*a)
+    same = rg["status"] == re_["status"]
+    assert same.mean() > 0.97  # (rcp / rsqrt seeds and the fma contraction differ: a borderline QP may fall on the other side)
+    ok = same & (rg["status"] == 0)
+    scale = np.maximum(1.0, np.abs(re_["tau"]).max(axis=1, keepdims=True))
+    assert (np.abs(rg["tau"] - re_["tau"]) / scale)[ok].max() < 1e-3
+
+
+@pytest.mark.gpu
+def test_f32_needs_the_specialised_kernel(monkeypatch):
+    from qpcontrol_jl_amd import models as M
+    monkeypatch.setenv("QPC_DISABLE_JIT", "1")
+    mech = M.atlas()
+    c = gpu_factory_f32(mech, 4, mech.findbody("pelvis"))
+    W.standing_setup(c, mech, M.atlas_nominal_configuration(mech))
+    with pytest.raises(binding.QpcError, match="fp32 tick"):
+        c.finalize()

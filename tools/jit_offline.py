@@ -42,6 +42,9 @@ def main():
     c = holder["c"]
     if os.environ.get("QPC_OFFLINE_WARM") == "1":
         c.enable_warm_start()
+    f32 = os.environ.get("QPC_OFFLINE_F32") == "1"  # the fp32 variant of the tick (qpc_set_precision)
+    if f32:
+        c.set_precision(1)
     src = os.path.join(out, "tick_jit.hip")
     c.L.qpc_debug_jit_source.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
     rc = c.L.qpc_debug_jit_source(c.h, src.encode())
