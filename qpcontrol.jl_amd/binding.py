@@ -55,7 +55,7 @@ _LIBS = {}
 
 def load_library(path=None):
     """Load the shared library and declare the prototypes of every symbol in include/qpc.h."""
-    path = path or DEFAULT_LIB
+    path = path or os.environ.get("QPC_LIB") or DEFAULT_LIB  # (QPC_LIB: tools / experiments pick another build, e.g. EXPERIMENTS_LIB)
     if path in _LIBS:
         return _LIBS[path]
     if not os.path.exists(path):

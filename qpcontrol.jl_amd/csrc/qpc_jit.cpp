@@ -90,9 +90,10 @@ std::string qpc_jit_source(const QpcDims &D, const QpcDims &DS, bool warm, bool 
   // experiments (tools/ + DESIGN 8.1): QPC_EXP_DYN_LDS=1 declares the slab as DYNAMIC shared memory (the compiler then does not
   // derive an occupancy bound from it), QPC_EXP_WAVES=n is the second __launch_bounds__ argument (waves per SIMD to allocate for)
   const bool dyn_lds = qpc_jit_dynamic_lds();
-  // waves per SIMD the register allocation aims at: the fp64 tick needs its 256 registers (two waves); the fp32 tick's slab is half
-  // the size (16 per CU) and its values one register each, so four waves per SIMD (128 registers) are in reach
-  int waves = f32 ? 4 : 2;
+  // waves per SIMD the register allocation aims at: the fp64 tick needs its 256 registers (two waves).  The fp32 tick's slab is half
+  // the size (16 fit a CU), but measured on MI355X (config 5, 32 768 QPs): 2 waves / 256 registers 36.7 M solves/s, 3 waves / 168
+  // registers (272 B of scratch per lane) 37.1 M, 4 waves / 128 registers (368 B of scratch) 33.9 M -- three it is
+  int waves = f32 ? QPC_F32_WAVES_PER_SIMD : 2;
   if (const char *e = QPC_EXP_ENV("QPC_EXP_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 8) waves = v; }
   if (dyn_lds) o << "extern __shared__ __attribute__((aligned(16))) double qpc_lds_dyn[];\n";
   o << "#ifdef QPC_KERNARG_RELOAD\n"

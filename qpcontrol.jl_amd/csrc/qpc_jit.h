@@ -8,6 +8,7 @@
 
 // source of the specialised translation unit (QpcDims baked in as a constexpr object)
 // warm: also emit qpc_tick_kernel_jit_warm (the warm-started variant, qpc_enable_warm_start)
+#define QPC_F32_WAVES_PER_SIMD 3 // register budget of the fp32 tick kernel (qpc_jit.cpp) = workgroups per CU / 4 of its launches (qpc_runtime.hip)
 // f32: the fp32 variant of the tick (qpc_set_precision): `real` = float, single-precision literals, LDS slab of floats, no simulation
 // step in the module
 std::string qpc_jit_source(const QpcDims &D, const QpcDims &DS, bool warm, bool f32 = false);

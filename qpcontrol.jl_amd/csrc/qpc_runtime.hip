@@ -324,6 +324,7 @@ static int init_device_state(qpc_controller *c, QpcDeviceState *S, int device_id
   int per_cu = (int)((160 * 1024) / (lds > 0 ? lds : 1));
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 16) per_cu = 16; // 32 waves/CU cap; leave room for registers
+  if (f32 && per_cu > 4 * QPC_F32_WAVES_PER_SIMD) per_cu = 4 * QPC_F32_WAVES_PER_SIMD; // the persistent grid must be resident at once
   if (const char *e = QPC_EXP_ENV("QPC_EXP_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 16) per_cu = v; } // experiment
   S->blocks_per_cu = per_cu;
   int sper = (int)((160 * 1024) / (slds > 0 ? slds : 1));

@@ -2669,9 +2669,6 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, qpc_dta
         const real t2 = zn > QPC_TINY ? -sp / zn : QPC_HUGE;
         const real tt = t1 < t2 ? t1 : t2;
         if (!(tt < QPC_HUGE_TEST)) {
-#ifdef QPC_EMU_DEBUG
-          fprintf(stderr, "INFEASIBLE: unbounded GI step t1 %g t2 %g zn %g sp %g p %d iters %d\n", (double)t1, (double)t2, (double)zn, (double)sp, p, iters);
-#endif
           status = QPC_STATUS_INFEASIBLE; fail = true; break; }
         const bool full = t2 <= t1;
         QPC_PHASE(lane) { // the step moves rho and the wrench multipliers only (see rho_solve)
@@ -2751,10 +2748,6 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, qpc_dta
       const bool nan = anan > 0.0;
       real r_prim = arp / (1.0 + asp), r_stat = ars / (1.0 + ass);
       if (nan || !(r_prim < QPC_HUGE) || !(r_stat < QPC_HUGE)) { status = QPC_STATUS_NUMERICAL_ERROR; break; }
-#ifdef QPC_EMU_DEBUG
-      fprintf(stderr, "ACCEPT r_prim %g r_stat %g\n", (double)r_prim, (double)r_stat);
-      if (r_prim > (real)D.tol_accept) fprintf(stderr, "INFEASIBLE: r_prim %g (arp %g asp %g) r_stat %g iters %d outer %d\n", (double)r_prim, (double)arp, (double)asp, (double)r_stat, iters, outer);
-#endif
       // equality rows inconsistent on the feasible set.  fp32: a residual within QPC_ACCEPT_BAND of the tolerance is what an
       // ill-conditioned but feasible QP leaves at that precision (a robot balanced on ONE contact point: cond(S22) > 1e5, pivots
       // dropped as noise) -- reported as NUMERICAL_ERROR ("not resolved"), not as a verdict on the problem; truly inconsistent rows

@@ -1,11 +1,11 @@
 #!/bin/bash
-# usage: pmc_probe.sh <tag> <counters...>   (run from repo root on the GPU box)
+# usage: [PMC_BENCH_ARGS="--f32 --config 5"] pmc_probe.sh <tag> <counters...>   (run from repo root on the GPU box)
 TAG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc "$@" -d $OUT -o k --output-format csv -- python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary > /dev/null 2> $OUT/log.txt
+rocprofv3 --pmc "$@" -d $OUT -o k --output-format csv -- python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary $PMC_BENCH_ARGS > /dev/null 2> $OUT/log.txt
 python3 - <<PY
 import csv,glob,collections
 acc=collections.defaultdict(list)
