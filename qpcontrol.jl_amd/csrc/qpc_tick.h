@@ -73,9 +73,15 @@ enum { PS_KIN, PS_ASM, PS_SBUILD, PS_CHOL, PS_XINV, PS_REFAC, PS_RESID, PS_KKT, 
 // (measured in the emulator: 6.3 -> 10.3 changes per QP at eps = 1e-6).  The fp32 tick therefore drops the term (the table stores the
 // eigenvalue as an exact 0): the minimum-norm rho of a fully free contact, which is also what the eps form converges to.
 #define QPC_K_NULL_TERM(lambda) ((lambda) == 0.0 ? 0.0 : 1.0)
+// tolerance of the bound / multiplier test on the REFINED solution.  fp64: the acceptance tolerance (1e-7: far above the search's
+// 1e-10, far below anything that matters).  fp32: the acceptance tolerance has to sit above the residual floor of an ill-conditioned
+// QP (2e-3), and a working set that is wrong by that much moves tau by up to 5e-3 (measured on 32 768 config-5 states: 9 QPs beyond
+// 1e-3) -- the bounds are tested at three times the search's own tolerance instead
+#define QPC_VERIFY_TOL(D) ((real)3.0 * (real)(D).tol_bound)
 #define QPC_ACCEPT_BAND 10.0 // primal residuals up to this multiple of tol_accept: NUMERICAL_ERROR instead of INFEASIBLE (see the acceptance test)
 #else
 #define QPC_K_NULL_TERM(lambda) 1.0
+#define QPC_VERIFY_TOL(D) ((real)(D).tol_accept)
 #define QPC_ACCEPT_BAND 1.0
 #define QPC_HUGE 1e300
 #define QPC_HUGE_TEST 1e299
@@ -1636,7 +1642,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, qpc_dta
   QPC_LANE_ARRAY(keep_iw_, 16);
   QPC_LANE_ARRAY(keep_sk_, 6);
   real hscale = 0.0, hinvmax = 0.0, eps = 0.0, eps_ve = 0.0;
-  unsigned long long bbad_in = 0ull, bneg_cap = 0ull;
+  unsigned long long bbad_in = 0ull, bneg_cap = 0ull, ben_ = 0ull;
   bool exact_ve = false, h_fast = false;
   const bool h_static_path = D.h_static;
   QPC_PHASE(lane) {
@@ -1671,8 +1677,14 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, qpc_dta
     for (int i = lane; i < D.n_surf; i += 64) sm[D.lds[L_SURF] + i] = io.surf[i];
     if (h_static_path) { QPC_RED_MAX_PUT(0, hscale, hc); }
     if (nc) { QPC_BALLOT_PUT(2, bbad_in, bad_in); QPC_BALLOT_PUT(3, bneg_cap, neg_cap); }
+#ifdef QPC_F32
+    if (nc) { QPC_BALLOT_PUT(4, ben_, lane < nc && io.cmax[lane < nc ? lane : 0] > 0.0); }
+#endif
   } QPC_END_PHASE
   if (nc) { QPC_BALLOT_GET(2, bbad_in); QPC_BALLOT_GET(3, bneg_cap); }
+#ifdef QPC_F32
+  if (nc) { QPC_BALLOT_GET(4, ben_); }
+#endif
   // Static Hessian blocks (D.h_static: no per-QP task weights): the regularisation scale is max(static diagonal,
   // contact weights of THIS QP), known right after the input phase -- the two phases that used to derive it from the LDS
   // copies of H (a max reduction over HV / W, then rsqrt / block inverses: 4 % of the tick) are only run in the general case
@@ -2754,6 +2766,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, qpc_dta
       // leave residuals of order one
       if (r_prim > (real)D.tol_accept) { status = r_prim > QPC_ACCEPT_BAND * (real)D.tol_accept ? QPC_STATUS_INFEASIBLE : QPC_STATUS_NUMERICAL_ERROR; break; }
       if (r_stat > (real)D.tol_accept) status = QPC_STATUS_ALMOST_OPTIMAL;
+
       if (!use_rho) break;
       // primal-dual test on the refined solution, at the acceptance tolerance: normally nothing moves
       // (one phase); if the eps-regularised search settled on a working set that is not optimal for
@@ -2761,7 +2774,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, qpc_dta
       S.last_gmax = agm; S.last_xmax = axm;
       QPC_PHASE(lane) {
         real changed = 0.0;
-        const real tolu = (real)D.tol_accept * (1.0 + agm), tolb = (real)D.tol_accept * (1.0 + axm);
+        const real tolu = QPC_VERIFY_TOL(D) * (1.0 + agm), tolb = QPC_VERIFY_TOL(D) * (1.0 + axm);
         for (int j = lane; j < nrho; j += 64) {
           real w = sm[D.lds[L_WS] + j], hi = sm[D.lds[L_HI] + j], x = sm[D.lds[L_XR] + j], nw_ = w;
           if (!(hi > 0.0)) continue;
@@ -2920,7 +2933,13 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, qpc_dta
       for (int idx = lane; idx < nc * 6; idx += 64) io.cwrench[idx] = QPC_TO_DOUBLE((real)sm[D.lds[L_CWR] + idx]);
     if (lane == 0) {
       const bool good = status == QPC_STATUS_OPTIMAL || status == QPC_STATUS_ALMOST_OPTIMAL;
-      io.status[0] = (good && bbad_in != 0ull) ? QPC_STATUS_NUMERICAL_ERROR : ((good && bneg_cap != 0ull) ? QPC_STATUS_INFEASIBLE : status);
+      int st_ = (good && bbad_in != 0ull) ? QPC_STATUS_NUMERICAL_ERROR : ((good && bneg_cap != 0ull) ? QPC_STATUS_INFEASIBLE : status);
+#ifdef QPC_F32
+      // fp32: a floating robot balanced on ONE enabled contact point is a QP whose force distribution fp32 cannot resolve (cond(S22) >
+      // 1e5; measured on 32 768 config-5 states: accepted points up to 44 % off, p99.9 26 %): never reported as solved
+      if (st_ <= QPC_STATUS_ALMOST_OPTIMAL && nw > 0 && nc <= 64 && QPC_POPC64(ben_) == 1) st_ = QPC_STATUS_NUMERICAL_ERROR;
+#endif
+      io.status[0] = st_;
       if (io.iters) io.iters[0] = iters + 1000 * refine + (reduced ? 1000000 : 0);
     }
   } QPC_END_PHASE
