@@ -30,15 +30,34 @@
 #include "qpc_tick.h"
 #include "qpc_sim.h"
 #include "qpc_qp_dense.h"
+#include "qpc_qp_wg.h"
 #include "qpc_l1_dense.h"
 
-// L0: one lane per dense QP (plumbing path, see qpc_qp_dense.h)
+// L0, first pass: one WORKGROUP per dense QP, working matrices in LDS (qpc_qp_wg.h): the problems Parametron builds for this
+// controller (diagonal P, sparse A).  status[b] = QPC_WG_FALLBACK marks a QP it leaves to the one-lane kernel below.
+extern "C" __global__ void __launch_bounds__(256)
+qpc_qp_wg_kernel(int n, int m, long long B, const double *P, const double *q, const double *A, const double *l,
+                 const double *u, qpc_settings st, double *ws, long long ws_stride, double *x, double *y,
+                 int32_t *status, int32_t *iters) {
+  extern __shared__ __attribute__((aligned(16))) double qpc_wg_lds[];
+  for (long long b = blockIdx.x; b < B; b += gridDim.x) {
+    const int s = qpc::qp_solve_wg(n, m, P + b * n * n, q + b * n, A + b * m * n, l + b * m, u + b * m, st,
+                                   ws + b * ws_stride + (long long)n * n + (long long)n * m, qpc_wg_lds, x + b * n, y + b * m,
+                                   iters ? iters + b : nullptr);
+    if (threadIdx.x == 0) status[b] = s;
+    __syncthreads();
+  }
+}
+
+// L0: one lane per dense QP (the general method: any P, the Goldfarb-Idnani phase; see qpc_qp_dense.h).  only_fallback: just the
+// QPs the workgroup kernel left (status QPC_WG_FALLBACK)
 extern "C" __global__ void __launch_bounds__(64)
 qpc_qp_dense_kernel(int n, int m, long long B, const double *P, const double *q, const double *A, const double *l,
                     const double *u, qpc_settings st, double *ws, long long ws_stride, double *x, double *y,
-                    int32_t *status, int32_t *iters) {
+                    int32_t *status, int32_t *iters, int only_fallback) {
   const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
+  if (only_fallback && status[b] != QPC_WG_FALLBACK) return;
   qpc::qp_solve_dense(n, m, P + b * n * n, q + b * n, A + b * m * n, l + b * m, u + b * m, st, ws + b * ws_stride,
                       x + b * n, y + b * m, status + b, iters ? iters + b : nullptr);
 }
@@ -980,9 +999,27 @@ int32_t qpc_qp_solve_batch_device(int32_t n, int32_t m, int64_t B, const double 
   HIP_TRY(hipSetDevice(device_id));
   qpc_settings st;
   if (settings) st = *settings; else qpc_default_settings(&st);
+  // first the workgroup kernel (LDS-resident working set: the structured problems of this controller), then the one-lane kernel on
+  // whatever it left; QPC_L0_ONE_LANE=1 (experiments build) keeps the old single pass
+  int wg = m > 0 && n <= QPC_WG_DIM && m <= QPC_WG_DIM;
+  if (const char *e = QPC_EXP_ENV("QPC_L0_ONE_LANE")) if (e[0] == '1') wg = 0;
+  if (wg) {
+    static std::once_flag once;
+    static hipError_t attr_rc = hipSuccess;
+    const int lds_bytes = qpc::qp_wg_lds_doubles(n, m) * (int)sizeof(double);
+    std::call_once(once, [&] { attr_rc = hipFuncSetAttribute((const void *)qpc_qp_wg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); });
+    HIP_TRY(attr_rc);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    const long long grid = B < (long long)prop.multiProcessorCount * 4 ? B : (long long)prop.multiProcessorCount * 4;
+    hipLaunchKernelGGL(qpc_qp_wg_kernel, dim3((unsigned)grid), dim3(256), (size_t)lds_bytes, (hipStream_t)hip_stream, (int)n, (int)m,
+                       (long long)B, P, q, A, l, u, st, (double *)workspace, (long long)qpc::qp_dense_workspace_doubles(n, m), x, y,
+                       status, iters);
+    HIP_TRY(hipGetLastError());
+  }
   hipLaunchKernelGGL(qpc_qp_dense_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, (hipStream_t)hip_stream, (int)n, (int)m,
                      (long long)B, P, q, A, l, u, st, (double *)workspace, (long long)qpc::qp_dense_workspace_doubles(n, m), x, y,
-                     status, iters);
+                     status, iters, wg);
   HIP_TRY(hipGetLastError());
   return QPC_OK;
 }

@@ -162,6 +162,7 @@ static inline real emu_sum64(const real *x) { real s = 0.0; for (int l = 0; l < 
 #ifndef QPC_F32 // (the simulation step and the dense L0 / L1 solvers are fp64 code: not part of the fp32 emulation)
 #include "../../qpcontrol.jl_amd/csrc/qpc_sim.h"
 #include "../../qpcontrol.jl_amd/csrc/qpc_qp_dense.h"
+#include "../../qpcontrol.jl_amd/csrc/qpc_qp_wg.h"
 #include "../../qpcontrol.jl_amd/csrc/qpc_l1_dense.h"
 #endif
 
@@ -374,6 +375,7 @@ int32_t qpc_assemble_solve_batch(qpc_controller *c, int64_t B, const double *tas
   return QPC_OK;
 }
 
+static long g_l0_wg = 0; // QPs the workgroup form solved (test hook: emu_l0_wg_count)
 // L0 (qpc_qp_dense.h is plain serial code per QP: the emulation is the same function on the host)
 int32_t qpc_qp_solve_batch(int32_t n, int32_t m, int64_t B, const double *P, const double *q, const double *A,
                            const double *l, const double *u, const qpc_settings *settings, int32_t device_id,
@@ -381,10 +383,19 @@ int32_t qpc_qp_solve_batch(int32_t n, int32_t m, int64_t B, const double *P, con
   (void)device_id;
   qpc_settings st;
   if (settings) st = *settings; else qpc_default_settings(&st);
-  std::vector<double> ws(qpc::qp_dense_workspace_doubles(n, m));
-  for (int64_t b = 0; b < B; b++)
-    qpc::qp_solve_dense(n, m, P + b * n * n, q + b * n, A + b * m * n, l + b * m, u + b * m, st, ws.data(), x + b * n,
-                        y + b * m, status + b, iters ? iters + b : nullptr);
+  // like the device: the workgroup form first (qpc_qp_wg.h, here one serial "thread"), the one-lane form on what it leaves
+  std::vector<double> ws(qpc::qp_dense_workspace_doubles(n, m)), lds(qpc::qp_wg_lds_doubles(n, m));
+  const char *one = getenv("QPC_L0_ONE_LANE");
+  for (int64_t b = 0; b < B; b++) {
+    int s = QPC_WG_FALLBACK;
+    if (m > 0 && !(one && one[0] == '1'))
+      s = qpc::qp_solve_wg(n, m, P + b * n * n, q + b * n, A + b * m * n, l + b * m, u + b * m, st,
+                           ws.data() + (long long)n * n + (long long)n * m, lds.data(), x + b * n, y + b * m, iters ? iters + b : nullptr);
+    g_l0_wg += s != QPC_WG_FALLBACK;
+    if (s != QPC_WG_FALLBACK) status[b] = s;
+    else qpc::qp_solve_dense(n, m, P + b * n * n, q + b * n, A + b * m * n, l + b * m, u + b * m, st, ws.data(), x + b * n,
+                             y + b * m, status + b, iters ? iters + b : nullptr);
+  }
   return QPC_OK;
 }
 
@@ -449,6 +460,7 @@ int32_t qpc_rollout_batch(qpc_controller *, int64_t, int64_t, double *, double *
                           const double *, const qpc_sim_params *, double *, int32_t *, int32_t *) { return unsupported_f32("qpc_rollout_batch"); }
 #endif // QPC_F32
 
+long emu_l0_wg_count() { const long r = g_l0_wg; g_l0_wg = 0; return r; }
 // race-detector report: counts since the last call
 void emu_report(long *races, long *uninit, long *outside, char *first, int n) {
   std::lock_guard<std::mutex> lk(g_rep_mu);

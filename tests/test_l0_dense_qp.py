@@ -23,6 +23,41 @@ def _random_qp(rng, n, m, n_eq):
     return P, q, A, l, u
 
 
+def _random_structured_qp(rng, n, m, n_eq, density=0.15):
+    """what Parametron builds for this controller: diagonal P, sparse A -- the problems the workgroup form of L0 (csrc/qpc_qp_wg.h)
+    takes; bounds chosen so that a good part of the inequality rows ends up active"""
+    P = np.diag(rng.uniform(0.05, 2.0, size=n))
+    q = rng.normal(size=n)
+    A = rng.normal(size=(m, n)) * (rng.uniform(size=(m, n)) < density)
+    A[np.arange(m), rng.integers(0, n, size=m)] += rng.uniform(0.5, 1.5, size=m)  # no empty row
+    x0 = rng.normal(size=n)
+    b = A @ x0
+    l, u = b - rng.uniform(0.0, 0.6, size=m), b + rng.uniform(0.0, 0.6, size=m)
+    l[:n_eq] = u[:n_eq] = b[:n_eq]
+    l[n_eq::3] = -1e30
+    return P, q, A, l, u
+
+
+def _check_structured(backend_lib, device_id=0, expect_wg=None):
+    rng = np.random.default_rng(11)
+    sizes = ((6, 9, 2), (20, 30, 6), (40, 70, 12), (64, 100, 20), (143, 178, 60))
+    n_wg = 0
+    for n, m, ne in sizes:
+        for _ in range(3):
+            P, q, A, l, u = _random_structured_qp(rng, n, m, ne)
+            ro = O.qp_solve(P, q, A, l, u)
+            if ro["status"] != 0:
+                continue
+            r = binding.qp_solve_batch(P, q, A, l, u, device_id=device_id, lib_path=backend_lib)
+            assert r["status"][0] == 0, (n, m, r["status"])
+            np.testing.assert_allclose(r["x"][0], ro["x"], atol=1e-8)
+            np.testing.assert_allclose(r["y"][0], ro["y"], atol=1e-6)
+            n_wg += 1
+    assert n_wg >= 10
+    if expect_wg is not None:
+        assert expect_wg() >= n_wg - 4  # (a QP whose sweeps do not settle goes to the one-lane form: rare)
+
+
 def _check(backend_lib, device_id=0):
     rng = np.random.default_rng(5)
     probs = [_random_qp(rng, n, m, ne) for n, m, ne in ((5, 7, 2), (12, 20, 4), (30, 45, 10), (8, 0, 0))]
@@ -62,9 +97,38 @@ def test_l0_emulated_random():
     _check(emu.EMU_LIB)
 
 
+def _emu_wg_count():
+    import ctypes
+    L = ctypes.CDLL(emu.EMU_LIB)
+    L.emu_l0_wg_count.restype = ctypes.c_long
+    return L.emu_l0_wg_count()
+
+
 def test_l0_emulated_reference_layout():
     emu.build()
+    _emu_wg_count()
     _check_reference_layout(emu.EMU_LIB)
+    assert _emu_wg_count() == 2 + 3  # every reference-layout problem (diagonal P, sparse A) is solved by the workgroup form
+
+
+def test_l0_emulated_structured():
+    emu.build()
+    _emu_wg_count()
+    _check_structured(emu.EMU_LIB, expect_wg=_emu_wg_count)
+
+
+def test_l0_workgroup_form_equals_one_lane_form(monkeypatch):
+    """the two device forms of L0 on the same problems: same statuses, x to 1e-9"""
+    emu.build()
+    rng = np.random.default_rng(3)
+    probs = [_random_structured_qp(rng, n, m, ne) for n, m, ne in ((12, 20, 4), (40, 70, 12), (90, 120, 30))]
+    a = [binding.qp_solve_batch(*p, lib_path=emu.EMU_LIB) for p in probs]
+    monkeypatch.setenv("QPC_L0_ONE_LANE", "1")
+    b = [binding.qp_solve_batch(*p, lib_path=emu.EMU_LIB) for p in probs]
+    for ra, rb in zip(a, b):
+        assert ra["status"][0] == rb["status"][0]
+        if ra["status"][0] == 0:
+            np.testing.assert_allclose(ra["x"][0], rb["x"][0], atol=1e-9)
 
 
 def test_l0_infeasible_and_status():
@@ -83,3 +147,21 @@ def test_l0_gpu_random():
 @pytest.mark.gpu
 def test_l0_gpu_reference_layout():
     _check_reference_layout(None)
+
+
+@pytest.mark.gpu
+def test_l0_gpu_structured():
+    _check_structured(None)
+
+
+@pytest.mark.gpu
+def test_l0_gpu_fixture_batch():
+    """the committed 143 x 178 Atlas problems (tests/golden/l0/) as one batch of 64: every QP OPTIMAL, v̇ as stored"""
+    import sys
+    sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "..", "tools"))
+    import bench_latency as BL
+    P, q, A, l, u, x, nv = BL.load_l0_fixture()
+    idx = np.arange(64) % P.shape[0]
+    r = binding.qp_solve_batch(P[idx], q[idx], A[idx], l[idx], u[idx])
+    assert (r["status"] == 0).all()
+    np.testing.assert_allclose(r["x"][:, :nv], x[idx][:, :nv], atol=1e-8)
