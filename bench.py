@@ -332,7 +332,8 @@ def l0_plugin_point():
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_latency.py"), "--l0", "1", "1024"], capture_output=True, text=True,
                            timeout=300)
         d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-        return {"n": d["n"], "m": d["m"], "latency_us_B1": d["1"]["median_us"], "solves_per_s_B1024": d["1024"]["solves_per_s"],
+        return {"n": d["n"], "m": d["m"], "latency_us_B1": d["1"]["median_us"], "latency_us_B1_median_over_problems": d.get("B1_median_over_problems_us"),
+                "latency_us_B1_worst_problem": d.get("B1_worst_problem_us"), "solves_per_s_B1024": d["1024"]["solves_per_s"],
                 "max_abs_err_vdot_vs_fixture": max(d["1"]["max_abs_err_vdot_vs_fixture"], d["1024"]["max_abs_err_vdot_vs_fixture"]),
                 "kernel": d.get("kernel")}
     except Exception as e:  # noqa: BLE001 -- a diagnostic extra must never take the bench line down

@@ -101,10 +101,52 @@ int qpc_compile_program(qpc_controller *c) {
       task_is_pin[ti] = 1;
     }
   }
+  // ---- pass 1.5: which hard 6-row SpatialAccelerationTasks can the null-space presolve eliminate (QpcDims::presolve; the layout is
+  // set up further down)?  Exactly six free one-DoF velocity coordinates on the task's path outside the floating joint, claimed by no
+  // other block.  The host owns the ORDER of the free columns and of the row blocks -- neither is visible at the ABI -- so it lists
+  // the columns that stay first, then the six columns of every eliminated block side by side, and puts the eliminated tasks first
+  // among the row blocks: the regular layout the device code indexes by arithmetic, whatever the model's joint numbering and the
+  // order in which the tasks were registered (standing.jl:37-38 iterates a Dict: unspecified).
+  std::vector<size_t> elim_task;
+  std::vector<std::vector<int>> elim_k;
+  if (!getenv("QPC_NO_PRESOLVE") && c->floating >= 0 && !c->contacts.empty() && D.ve_exact_ok) {
+    std::vector<char> claimed(nv, 0);
+    for (size_t ti = 0; ti < c->tasks.size() && elim_task.size() < 4; ti++) {
+      const QpcTask &t = c->tasks[ti];
+      if (task_is_pin[ti] || t.kind != QPC_TASK_SPATIAL_ACCELERATION || t.wkind != QPC_WEIGHT_HARD || t.dim != 6) continue;
+      std::vector<char> mark(nb, 0);
+      for (int b = t.target; b >= 0; b = m->parent[b]) mark[b] = 1;
+      int lca = -1;
+      for (int b = t.base; b >= 0; b = m->parent[b]) if (mark[b]) { lca = b; break; }
+      std::vector<int> priv;
+      bool ok = true;
+      auto visit = [&](int b) {
+        if (b == c->floating) return; // its free columns stay
+        for (int k = 0; k < m->nvj[b]; k++) {
+          const int kv = m->voff[b] + k;
+          if (pin_des[kv] >= 0) continue; // pinned: a constant of the row
+          if (m->nvj[b] != 1 || claimed[kv]) ok = false;
+          priv.push_back(kv);
+        }
+      };
+      for (int b = t.base; b >= 0 && b != lca; b = m->parent[b]) visit(b);
+      for (int b = t.target; b >= 0 && b != lca; b = m->parent[b]) visit(b);
+      if (!ok || priv.size() != 6) continue;
+      std::sort(priv.begin(), priv.end());
+      for (int kv : priv) claimed[kv] = 1;
+      elim_task.push_back(ti);
+      elim_k.push_back(priv);
+    }
+  }
   std::vector<int> free_of(nv, -1), free_k, pin_k, pin_d;
-  for (int k = 0; k < nv; k++) {
-    if (pin_des[k] >= 0) { pin_k.push_back(k); pin_d.push_back(pin_des[k]); }
-    else { free_of[k] = (int)free_k.size(); free_k.push_back(k); }
+  {
+    std::vector<char> in_block(nv, 0);
+    for (auto &blk : elim_k) for (int kv : blk) in_block[kv] = 1;
+    for (int k = 0; k < nv; k++) {
+      if (pin_des[k] >= 0) { pin_k.push_back(k); pin_d.push_back(pin_des[k]); }
+      else if (!in_block[k]) { free_of[k] = (int)free_k.size(); free_k.push_back(k); }
+    }
+    for (auto &blk : elim_k) for (int kv : blk) { free_of[kv] = (int)free_k.size(); free_k.push_back(kv); }
   }
   D.nf = (int)free_k.size(); D.npin = (int)pin_k.size();
   // ---- pass 2: folded soft joint tasks and generic tasks
@@ -126,6 +168,12 @@ int qpc_compile_program(qpc_controller *c) {
       continue;
     }
     generic.push_back((int)ti);
+  }
+  { // the eliminable tasks first (in block order), the others behind them in registration order
+    std::vector<int> g2;
+    for (size_t ti : elim_task) g2.push_back((int)ti);
+    for (int ti : generic) if (std::find(elim_task.begin(), elim_task.end(), (size_t)ti) == elim_task.end()) g2.push_back(ti);
+    generic.swap(g2);
   }
   // regularize!(c, joint, weight::Parameter) (qpc_regularize_per_qp): w |vdot_k|^2 is a folded soft joint task with desired 0
   // (IT_SJ_DES = -1) and a per-QP weight; on a pinned acceleration it is a constant of the objective

@@ -460,7 +460,9 @@ int32_t qpc_rollout_batch(qpc_controller *, int64_t, int64_t, double *, double *
                           const double *, const qpc_sim_params *, double *, int32_t *, int32_t *) { return unsupported_f32("qpc_rollout_batch"); }
 #endif // QPC_F32
 
+#ifndef QPC_F32
 long emu_l0_wg_count() { const long r = g_l0_wg; g_l0_wg = 0; return r; }
+#endif
 // race-detector report: counts since the last call
 void emu_report(long *races, long *uninit, long *outside, char *first, int n) {
   std::lock_guard<std::mutex> lk(g_rep_mu);

@@ -361,3 +361,113 @@ def test_per_qp_momentum_weight_emulated():
     assert float(np.abs(r1["tau"] - a["tau"]).max()) > 1e-3
     races, uninit, outside, first = emu.race_report()
     assert (races, uninit, outside) == (0, 0, 0), first
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The presolve must not depend on how the model numbers its bodies nor on the order in which the tasks were registered
+# (StandingController iterates a Dict of feet, /root/reference/src/highlevel/standing.jl:35-49: unspecified order): the host
+# compiler owns the order of the free columns and of the row blocks and arranges them itself (qpc_compile.cpp pass 1.5).
+def _shuffled_atlas(rng):
+    """the synthetic Atlas with its bodies listed in another (still topological) order: same tree, same inertias"""
+    m0 = M.atlas()
+    nb = m0.nbodies
+    order, placed = [], set()
+    remaining = list(range(nb))
+    while remaining:  # random topological order: any body whose parent is placed may come next
+        ready = [b for b in remaining if m0.parent[b] < 0 or m0.parent[b] in placed]
+        b = ready[int(rng.integers(0, len(ready)))]
+        order.append(b); placed.add(b); remaining.remove(b)
+    new_of = {old: new for new, old in enumerate(order)}
+    m = M.Mechanism()
+    for old in order:
+        par = m0.parent[old]
+        m.add_body(m0.body_names[old], M.WORLD if par < 0 else new_of[par], m0.joint_names[old], m0.joint_type[old], axis=m0.joint_axis[old],
+                   R=m0.joint_R[old], p=m0.joint_p[old], mass=m0.mass[old], com=m0.com[old], inertia=m0.inertia[old])
+    for cp in m0.contact_points:
+        m.contact_points.append(M.ContactSpec(new_of[cp.body], cp.position, cp.normal, cp.mu))
+    return m0, m, order
+
+
+def _map_state(m0, m, q0, v0):
+    """states of the original numbering -> the shuffled model's coordinate order"""
+    q, v = np.zeros((q0.shape[0], m.nq)), np.zeros((v0.shape[0], m.nv))
+    for j, name in enumerate(m.joint_names):
+        j0 = m0.findjoint(name)
+        q[:, list(m.configuration_range(j))] = q0[:, list(m0.configuration_range(j0))]
+        v[:, list(m.velocity_range(j))] = v0[:, list(m0.velocity_range(j0))]
+    return q, v
+
+
+def _standing_shuffled_tasks(ctrl, mech, nominal_q, rng):
+    """the StandingController task set with the registration order shuffled: joint tasks, pelvis, momentum and foot tasks mixed,
+    right foot before left"""
+    from qpcontrol_jl_amd.workloads import ANGULAR, HARD, JOINT, LINEAR_MOMENTUM_RATE, SCALAR, SPATIAL, StandingSetup
+    feet = [mech.findbody("r_foot"), mech.findbody("l_foot")]
+    st = StandingSetup(mech, feet, mech.findbody("pelvis"))
+    for cp in mech.contact_points:
+        st.contact_ids.append(ctrl.add_contact(cp.body, cp.position, cp.normal, cp.mu))
+    for j in range(mech.nbodies):
+        ctrl.regularize(j, 0.05)
+    on_foot_path = set()
+    for f in feet:
+        on_foot_path.update(mech.path_joints(M.WORLD, f))
+    jobs = [("foot", f) for f in feet] + [("mom", None), ("pelvis", None)] + \
+           [("joint", j) for j in range(mech.nbodies) if mech.joint_type[j] == M.REVOLUTE and j not in on_foot_path]
+    jobs = [jobs[i] for i in rng.permutation(len(jobs))]
+    off = 0
+    for kind, arg in jobs:
+        if kind == "foot":
+            tid = ctrl.add_task(SPATIAL, base=M.WORLD, target=arg, frame=M.FRAME_DEFAULT, wkind=HARD); st.foot_tasks.append(tid); dim = 6
+        elif kind == "mom":
+            tid = ctrl.add_task(LINEAR_MOMENTUM_RATE, wkind=SCALAR, weight=[1.0]); st.linmom_task = tid; dim = 3
+        elif kind == "pelvis":
+            tid = ctrl.add_task(ANGULAR, base=M.WORLD, target=st.pelvis, frame=M.FRAME_DEFAULT, wkind=HARD); st.pelvis_task = tid; dim = 3
+        else:
+            tid = ctrl.add_task(JOINT, joint=arg, wkind=HARD); st.joint_tasks[arg] = tid; dim = 1
+        st.offsets[tid] = off
+        off += dim
+    st.n_desired = off
+    kin = W.batch_kinematics(mech, nominal_q, np.zeros(mech.nv))
+    st.comref = kin["com"][0] - np.array([0.0, 0.0, 0.05])
+    for j in range(mech.nbodies):
+        if mech.joint_type[j] == M.REVOLUTE:
+            st.jointrefs[j] = float(nominal_q[mech.configuration_range(j)[0]])
+    return st
+
+
+def _shuffled_vs_plain(factory, B, seed):
+    rng = np.random.default_rng(seed)
+    cp, wl = W.atlas_workload(factory, B, 3, seed=400 + seed)
+    ref = cp.control_batch(wl.q, wl.v, wl.desired, wl.contact_weight, wl.contact_maxnormalforce)
+    m0, m, order = _shuffled_atlas(rng)
+    assert order != list(range(m0.nbodies))
+    c = factory(m, 4, m.findbody("pelvis"))
+    q0n = M.atlas_nominal_configuration(m)
+    st = _standing_shuffled_tasks(c, m, q0n, rng)
+    c.finalize()
+    assert c.L.qpc_debug_presolve_blocks(c.h) == 2  # both foot tasks eliminated whatever the numbering and the task order
+    q, v = _map_state(m0, m, wl.q, wl.v)
+    des = W.standing_desired(st, q, v)
+    r = c.control_batch(q, v, des, wl.contact_weight, wl.contact_maxnormalforce)
+    assert np.all(r["iters"] >= 1000000)  # presolved fraction 1.0
+    assert np.array_equal(r["status"], ref["status"]) and (ref["status"] == 0).all()
+    # tau per joint NAME must agree with the plain model's
+    tau_back = np.zeros_like(ref["tau"])
+    for j, name in enumerate(m.joint_names):
+        tau_back[:, list(m0.velocity_range(m0.findjoint(name)))] = r["tau"][:, list(m.velocity_range(j))]
+    scale = np.maximum(1.0, np.abs(ref["tau"]).max(axis=1, keepdims=True))
+    assert float(np.abs((tau_back - ref["tau"]) / scale).max()) <= 1e-10
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_presolve_with_shuffled_bodies_and_tasks_emulated(seed):
+    emu.build()
+    emu.race_report()
+    _shuffled_vs_plain(emu.factory, 24, seed)
+    races, uninit, outside, first = emu.race_report()
+    assert (races, uninit, outside) == (0, 0, 0), first
+
+
+@pytest.mark.gpu
+def test_presolve_with_shuffled_bodies_and_tasks_gpu():
+    _shuffled_vs_plain(lambda mech, N, fl: binding.Controller(binding.Model(mech), N, fl), 512, 5)

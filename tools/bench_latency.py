@@ -35,6 +35,20 @@ def l0_main(batches):
     k = P.shape[0]
     out = {"metric": "L0 qpc_qp_solve_batch on the dense 143 x 178 Atlas reference-layout QP (host pointers, synchronous, through ctypes)",
            "unit": "us", "n": int(P.shape[1]), "m": int(A.shape[1])}
+    # B = 1 on each of the committed problems by itself: the latency depends on the working-set iterations the QP needs
+    per_qp = []
+    for b in range(k):
+        a = (P[b], q[b], A[b], l[b], u[b])
+        r = binding.qp_solve_batch(*a)
+        ts = []
+        for _ in range(10):
+            t0 = time.perf_counter()
+            r = binding.qp_solve_batch(*a)
+            ts.append(time.perf_counter() - t0)
+        per_qp.append({"iters": int(r["iters"][0]), "median_us": float(np.median(ts) * 1e6)})
+    out["B1_per_problem"] = per_qp
+    out["B1_median_over_problems_us"] = float(np.median([p["median_us"] for p in per_qp]))
+    out["B1_worst_problem_us"] = float(max(p["median_us"] for p in per_qp))
     for B in batches:
         idx = np.arange(B) % k
         a = (P[idx], q[idx], A[idx], l[idx], u[idx])
