@@ -272,6 +272,42 @@ def secondary_points(torch, binding, W, device_index):
     return out
 
 
+def ordered_point(torch, binding, W, device_index):
+    """Cost-ordered tickets (qpc_ticket_order_device / qpc_control_batch_device_ordered): config 3 at BASELINE's literal batch, ONE launch
+    at a time, the QPs handed out by descending working-set changes of the previous tick of the same batch (what a control loop has:
+    momentum.jl:58 solves the same model every tick).  Outputs are bit-identical to the batch order."""
+    vp = ctypes.c_void_p
+    B, steps = 8192, 30
+    run = DeviceRun(torch, binding, W, B, 3, 2025, device_index)
+    L = run.ctrl.L
+    if not hasattr(L, "qpc_control_batch_device_ordered"):
+        return None
+    order = torch.zeros(B, dtype=torch.int32, device=run.dev)
+    p = lambda t: vp(t.data_ptr())  # noqa: E731
+
+    def launch(o):
+        rc = L.qpc_control_batch_device_ordered(run.ctrl.h, 0, 0, B, p(run.q), p(run.v), p(run.des), p(run.cw), p(run.cm), vp(0), vp(0), p(run.tau),
+                                                p(run.vd), p(run.cwr), p(run.status), p(run.iters), o, vp(run.stream.cuda_stream))
+        if rc != 0:
+            raise RuntimeError(L.qpc_last_error().decode())
+    launch(vp(0))
+    tau0 = run.tau.clone()
+    if L.qpc_ticket_order_device(run.ctrl.h, 0, B, p(run.iters), 1000, p(order), vp(run.stream.cuda_stream)) != 0:
+        raise RuntimeError(L.qpc_last_error().decode())
+    out = {"config": 3, "batch": B, "launches": steps}
+    for name, o in (("batch_order", vp(0)), ("cost_order", p(order))):
+        for _ in range(3):
+            launch(o)
+        torch.cuda.synchronize(run.dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            launch(o)
+        torch.cuda.synchronize(run.dev)
+        out[name + "_solves_per_s"] = B * steps / (time.perf_counter() - t0)
+    out["bitwise_equal"] = bool(torch.equal(run.tau, tau0))
+    return out
+
+
 def pipelined_points(torch, binding, W, device_index):
     """Two INDEPENDENT batches in flight on two launch slots / streams of the device (qpc_control_batch_device_slot): the workgroups of
     one launch fill the ~110 us tail of the other.  Not the headline (a step there is one launch at a time): what a caller with several
@@ -509,7 +545,7 @@ def main():
             fp64_measured = ctypes.c_double(0.0)
     n_opt = int((st == 0).sum())
 
-    host_rates, secondary, closed_loop, pipelined, l0_plugin = None, None, None, None, None
+    host_rates, secondary, closed_loop, pipelined, l0_plugin, ordered = None, None, None, None, None, None
     if rank == 0 and world == 1 and not args.no_secondary:
         # diagnostic extras, measured after the headline's timed region: none of them may take the bench line down
         if not args.fused_laws:
@@ -525,6 +561,10 @@ def main():
             pipelined = pipelined_points(torch, binding, W, local_rank)
         except Exception as e:  # noqa: BLE001
             pipelined = {"error": repr(e)}
+        try:
+            ordered = ordered_point(torch, binding, W, local_rank)
+        except Exception as e:  # noqa: BLE001
+            ordered = {"error": repr(e)}
         closed_loop = closed_loop_point()
         l0_plugin = l0_plugin_point()
 
@@ -567,6 +607,7 @@ def main():
                                                  "buffers it owns); pageable arrays are staged chunk by chunk by worker threads",
                        "secondary": secondary,
                        "pipelined": pipelined,
+                       "cost_ordered_tickets": ordered,
                        "closed_loop": closed_loop,
                        "l0_plugin": l0_plugin,
                        "kernel_fingerprint": fingerprint},
@@ -591,7 +632,7 @@ def main():
         if n_opt / B < 0.9:
             why.append(f"headline optimal_fraction {n_opt / B:.3f}")
         for name, x in (("host_pointer_path", host_rates), ("secondary", secondary), ("pipelined", pipelined), ("closed_loop", closed_loop),
-                        ("l0_plugin", l0_plugin)):
+                        ("l0_plugin", l0_plugin), ("cost_ordered_tickets", ordered)):
             if isinstance(x, dict) and x.get("error"):
                 why.append(f"{name}: {x['error']}")
         if isinstance(host_rates, dict):

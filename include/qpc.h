@@ -344,6 +344,21 @@ int32_t qpc_control_batch_device(qpc_controller *ctrl, int64_t B, const double *
                                  const double *task_weights, const double *surfaces, double *tau,
                                  double *vdot, double *contact_wrench, int32_t *status,
                                  int32_t *iters, void *hip_stream);
+/* ---- cost-ordered tickets.  A launch hands its QPs out in batch order and drains over the duration of its longest working-set
+ *      search (~110 us: 9 % of a 32 768-QP launch, a quarter of an 8 192-QP one).  Nothing can know a QP's cost before it is
+ *      solved -- except a control loop, which solves (nearly) the same model every tick (momentum.jl:58: solve! on the same model):
+ *      the previous tick's `iters` of robot b predicts this tick's.  qpc_ticket_order_device sorts the QP indices by descending
+ *      key (key = cost[b] % modulus if modulus > 0 else cost[b], clamped to 0 .. 255; pass the `iters` output with modulus 1000,
+ *      or any static predictor such as the number of enabled contacts) into order[B] (device memory, on `hip_stream`);
+ *      qpc_control_batch_device_ordered then starts the expensive QPs first.  Outputs are bit-identical to the unordered call
+ *      (every QP is independent); order == NULL is the unordered call. */
+int32_t qpc_ticket_order_device(qpc_controller *ctrl, int32_t device_index, int64_t B, const int32_t *cost, int32_t modulus,
+                                int32_t *order, void *hip_stream);
+int32_t qpc_control_batch_device_ordered(qpc_controller *ctrl, int32_t device_index, int32_t slot, int64_t B, const double *q,
+                                         const double *v, const double *desired, const double *contact_weight,
+                                         const double *contact_maxnormalforce, const double *task_weights,
+                                         const double *surfaces, double *tau, double *vdot, double *contact_wrench,
+                                         int32_t *status, int32_t *iters, const int32_t *order, void *hip_stream);
 /* Same on device device_ids[device_index] of a multi-device controller (qpc_finalize_devices). */
 int32_t qpc_control_batch_device_on(qpc_controller *ctrl, int32_t device_index, int64_t B,
                                     const double *q, const double *v, const double *desired,

@@ -85,7 +85,7 @@ std::string qpc_jit_source(const QpcDims &D, const QpcDims &DS, bool warm, bool 
   put_dims(o, "kD", D);
   put_dims(o, "kDS", DS);
   o << "struct QpcBatchArgs { long long B; const double *q, *v, *desired, *cw, *cmax, *tw, *surf; double *tau, *vdot, "
-       "*cwrench; int32_t *status, *iters; unsigned long long *prof; unsigned long long *ticket; unsigned long long *wsets; };\n";
+       "*cwrench; int32_t *status, *iters; unsigned long long *prof; unsigned long long *ticket; unsigned long long *wsets; const int32_t *order; };\n";
   // the tick kernel (cold start) and, on request, its warm-started twin: same loop, qpc_tick<P, true>
   // experiments (tools/ + DESIGN 8.1): QPC_EXP_DYN_LDS=1 declares the slab as DYNAMIC shared memory (the compiler then does not
   // derive an occupancy bound from it), QPC_EXP_WAVES=n is the second __launch_bounds__ argument (waves per SIMD to allocate for)
@@ -123,12 +123,14 @@ std::string qpc_jit_source(const QpcDims &D, const QpcDims &DS, bool warm, bool 
          "#endif\n"
          "    unsigned long long t = 0;\n"
          "    if ((threadIdx.x & 63) == 0) t = atomicAdd(KA(ticket), 1ull);\n"
-         "    const long long b = (long long)__shfl(t, 0, 64);\n"
-         "    if (b >= KA(B)) {\n"
+         "    const long long tk = (long long)__shfl(t, 0, 64);\n"
+         "    if (tk >= KA(B)) {\n"
          "      // a launch draws exactly B + gridDim.x tickets; whoever draws the last one re-arms the counter\n"
-         "      if ((threadIdx.x & 63) == 0 && b == KA(B) + (long long)gridDim.x - 1) atomicExch(KA(ticket), 0ull);\n"
+         "      if ((threadIdx.x & 63) == 0 && tk == KA(B) + (long long)gridDim.x - 1) atomicExch(KA(ticket), 0ull);\n"
          "      break;\n"
          "    }\n"
+         "    // ticket -> QP: in batch order, or through the caller's cost order (expensive QPs first: qpc_ticket_order_device)\n"
+         "    const long long b = KA(order) ? (long long)KA(order)[tk] : tk;\n"
          "    qpc::TickIO io;\n"
          "    io.q = KA(q) + b * kD.nq; io.v = KA(v) + b * kD.nv; io.desired = KA(desired) + b * kD.n_desired;\n"
          "    io.cw = KA(cw) + b * kD.nc; io.cmax = KA(cmax) + b * kD.nc; io.tw = KA(tw) + b * kD.n_tw; io.surf = KA(surf) + b * kD.n_surf;\n"

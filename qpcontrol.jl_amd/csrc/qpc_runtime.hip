@@ -95,6 +95,7 @@ struct QpcBatchArgs {
                               // bookkeeping, no memset between launches, safe under hipGraph replay.  Launches that share
                               // a counter must not overlap (one counter per pipeline slot, see QpcSlot)
   unsigned long long *wsets;  // warm-start working sets, 2 x uint64 per QP (in/out), or nullptr (cold start)
+  const int32_t *order = nullptr; // ticket t is QP order[t] (a permutation of 0 .. B-1: expensive QPs first, qpc_ticket_order_device), or nullptr
 };
 
 extern "C" __global__ void __launch_bounds__(64, 1)
@@ -106,11 +107,12 @@ qpc_tick_kernel(const QpcDims D, const QpcDims DS, const int *__restrict__ IT, c
   while (true) {
     unsigned long long t = 0;
     if ((threadIdx.x & 63) == 0) t = atomicAdd(A.ticket, 1ull);
-    const long long b = (long long)__shfl(t, 0, 64);
-    if (b >= A.B) {
-      if ((threadIdx.x & 63) == 0 && b == A.B + (long long)gridDim.x - 1) atomicExch(A.ticket, 0ull); // last draw of the launch
+    const long long tk = (long long)__shfl(t, 0, 64);
+    if (tk >= A.B) {
+      if ((threadIdx.x & 63) == 0 && tk == A.B + (long long)gridDim.x - 1) atomicExch(A.ticket, 0ull); // last draw of the launch
       break;
     }
+    const long long b = A.order ? (long long)A.order[tk] : tk;
     qpc::TickIO io;
     io.q = A.q + b * D.nq; io.v = A.v + b * D.nv;
     io.desired = A.desired + b * D.n_desired;
@@ -770,7 +772,7 @@ void qpc_controller_destroy(qpc_controller *c) {
 static int control_device(qpc_controller *c, int device_index, int64_t B, const double *q, const double *v, const double *desired,
                           const double *cw, const double *cmax, const double *tw, const double *surf, double *tau, double *vdot,
                           double *cwrench, int32_t *status, int32_t *iters, unsigned long long *wsets, void *hip_stream,
-                          const char *who, int slot = 0) {
+                          const char *who, int slot = 0, const int32_t *order = nullptr) {
   if (!c || !c->finalized || !c->rt) { qpc_set_error("controller not finalized"); return QPC_ERR_NOT_FINALIZED; }
   if (device_index < 0 || device_index >= (int)c->rt->devs.size()) { qpc_set_error(std::string(who) + ": device index out of range"); return QPC_ERR_INVALID_ARGUMENT; }
   if (slot < 0 || slot >= QPC_USER_SLOTS) { qpc_set_error(std::string(who) + ": launch slot out of range"); return QPC_ERR_INVALID_ARGUMENT; }
@@ -785,6 +787,7 @@ static int control_device(qpc_controller *c, int device_index, int64_t B, const 
   a.tau = tau; a.vdot = vdot; a.cwrench = cwrench; a.status = status; a.iters = iters;
   a.prof = slot == 0 ? S->prof : nullptr; // the (diagnostic) section-profile buffer is indexed by QP: overlapping launches on other slots must not write it
   a.wsets = wsets;
+  a.order = order;
   HIP_TRY(hipSetDevice(S->device));
   return launch(c, S, S->slots[c->rt->user_slot(slot)], a, (hipStream_t)hip_stream, wsets != nullptr);
 }
@@ -811,6 +814,38 @@ int32_t qpc_control_batch_device_slot(qpc_controller *c, int32_t device_index, i
                                       int32_t *iters, void *hip_stream) {
   return control_device(c, device_index, B, q, v, desired, cw, cmax, tw, surf, tau, vdot, cwrench, status, iters, nullptr,
                         hip_stream, "qpc_control_batch_device_slot", slot);
+}
+
+int32_t qpc_control_batch_device_ordered(qpc_controller *c, int32_t device_index, int32_t slot, int64_t B, const double *q, const double *v,
+                                         const double *desired, const double *cw, const double *cmax, const double *tw,
+                                         const double *surf, double *tau, double *vdot, double *cwrench, int32_t *status,
+                                         int32_t *iters, const int32_t *order, void *hip_stream) {
+  return control_device(c, device_index, B, q, v, desired, cw, cmax, tw, surf, tau, vdot, cwrench, status, iters, nullptr,
+                        hip_stream, "qpc_control_batch_device_ordered", slot, order);
+}
+
+// order[0 .. B-1] = the QP indices sorted by descending key (counting sort on 256 buckets, one workgroup): key = cost[b] % modulus
+// (modulus > 0) or cost[b], clamped to 0 .. 255
+extern "C" __global__ void __launch_bounds__(1024) qpc_ticket_order_kernel(long long B, const int32_t *cost, int modulus, int32_t *order) {
+  __shared__ unsigned hist[256], start[256];
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0u;
+  __syncthreads();
+  auto key = [&](long long b) { int k = cost[b]; if (modulus > 0) k %= modulus; return k < 0 ? 0 : (k > 255 ? 255 : k); };
+  for (long long b = threadIdx.x; b < B; b += blockDim.x) atomicAdd(&hist[key(b)], 1u);
+  __syncthreads();
+  if (threadIdx.x == 0) { unsigned o = 0; for (int k = 255; k >= 0; k--) { start[k] = o; o += hist[k]; } }
+  __syncthreads();
+  for (long long b = threadIdx.x; b < B; b += blockDim.x) order[atomicAdd(&start[key(b)], 1u)] = (int32_t)b;
+}
+int32_t qpc_ticket_order_device(qpc_controller *c, int32_t device_index, int64_t B, const int32_t *cost, int32_t modulus, int32_t *order,
+                                void *hip_stream) {
+  if (!c || !c->finalized || !c->rt) { qpc_set_error("controller not finalized"); return QPC_ERR_NOT_FINALIZED; }
+  if (device_index < 0 || device_index >= (int)c->rt->devs.size() || B < 0 || !cost || !order) { qpc_set_error("qpc_ticket_order_device: bad arguments"); return QPC_ERR_INVALID_ARGUMENT; }
+  if (B == 0) return QPC_OK;
+  HIP_TRY(hipSetDevice(c->rt->devs[device_index]->device));
+  hipLaunchKernelGGL(qpc_ticket_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)hip_stream, (long long)B, cost, (int)modulus, order);
+  HIP_TRY(hipGetLastError());
+  return QPC_OK;
 }
 
 int32_t qpc_control_batch_device_warm(qpc_controller *c, int32_t device_index, int64_t B, const double *q, const double *v,

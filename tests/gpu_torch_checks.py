@@ -169,6 +169,52 @@ def slots():
     assert rc != 0
 
 
+def ordered():
+    """cost-ordered tickets (qpc_ticket_order_device + qpc_control_batch_device_ordered): the order is a permutation sorted by the
+    previous tick's working-set changes, the ordered launch returns bit-identical outputs, and it is not slower"""
+    import time
+    B = 8192
+    c, ref, dev, t = setup(B)
+    lay, L = c.layout, c.L
+    s = torch.cuda.Stream(dev)
+    tau = torch.empty((B, lay.nv), dtype=torch.float64, device=dev)
+    vd = torch.empty_like(tau)
+    st = torch.full((B,), -1, dtype=torch.int32, device=dev)
+    it = torch.zeros((B,), dtype=torch.int32, device=dev)
+    order = torch.full((B,), -1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize(dev)
+
+    def run(order_ptr):
+        rc = L.qpc_control_batch_device_ordered(c.h, 0, 0, B, vp(t["q"].data_ptr()), vp(t["v"].data_ptr()), vp(t["d"].data_ptr()),
+                                                vp(t["cw"].data_ptr()), vp(t["cm"].data_ptr()), vp(0), vp(0), vp(tau.data_ptr()), vp(vd.data_ptr()),
+                                                vp(0), vp(st.data_ptr()), vp(it.data_ptr()), order_ptr, vp(s.cuda_stream))
+        assert rc == 0, L.qpc_last_error()
+    run(vp(0))  # unordered: gives the costs
+    rc = L.qpc_ticket_order_device(c.h, 0, B, vp(it.data_ptr()), 1000, vp(order.data_ptr()), vp(s.cuda_stream))
+    assert rc == 0, L.qpc_last_error()
+    torch.cuda.synchronize(dev)
+    o, cost = order.cpu().numpy(), it.cpu().numpy() % 1000
+    assert np.array_equal(np.sort(o), np.arange(B))           # a permutation
+    assert np.all(np.diff(cost[o]) <= 0)                      # sorted by descending cost
+    tau.fill_(float("nan")); st.fill_(-1)
+    torch.cuda.synchronize(dev)
+    run(vp(order.data_ptr()))
+    torch.cuda.synchronize(dev)
+    assert np.array_equal(st.cpu().numpy(), ref["status"]) and np.array_equal(tau.cpu().numpy(), ref["tau"])  # bitwise
+    times = {}
+    for name, ptr in (("plain", vp(0)), ("ordered", vp(order.data_ptr()))):
+        for _ in range(3):
+            run(ptr)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(30):
+            run(ptr)
+        torch.cuda.synchronize(dev)
+        times[name] = (time.perf_counter() - t0) / 30
+    print("ordered tickets @ 8192:", {k: f"{B / v / 1e6:.2f} M solves/s" for k, v in times.items()})
+    assert times["ordered"] < 1.02 * times["plain"]
+
+
 if __name__ == "__main__":
-    {"streams": streams, "graph": graph, "warm_mixed_rollouts": warm_mixed_rollouts, "slots": slots}[sys.argv[1]]()
+    {"streams": streams, "graph": graph, "warm_mixed_rollouts": warm_mixed_rollouts, "slots": slots, "ordered": ordered}[sys.argv[1]]()
     print("CHECK_OK")

@@ -235,6 +235,13 @@ def test_gpu_launch_slots_overlap_safely():
 
 
 @pytest.mark.gpu
+def test_gpu_cost_ordered_tickets():
+    """qpc_ticket_order_device + qpc_control_batch_device_ordered: a permutation sorted by the previous tick's working-set changes,
+    bit-identical outputs, not slower than the batch order (tests/gpu_torch_checks.py)"""
+    _run_torch_check("ordered")
+
+
+@pytest.mark.gpu
 def test_gpu_warm_controller_mixes_device_and_host_rollouts():
     """the host rollout must not free the device rollout's working-set buffer (tests/gpu_torch_checks.py)"""
     _run_torch_check("warm_mixed_rollouts")
