@@ -189,7 +189,6 @@ struct QpcDeviceState {
   char *l1_buf = nullptr; size_t l1_bytes = 0;
   char *roll_buf = nullptr; size_t roll_bytes = 0;
   unsigned long long *roll_ws = nullptr; size_t roll_ws_bytes = 0;
-  int32_t *roll_ord = nullptr; size_t roll_ord_bytes = 0;      // cold device rollouts: iters + ticket order of the previous step (2 B ints)
 };
 
 static int hip_fail(hipError_t e, const char *what) {
@@ -318,7 +317,6 @@ static void destroy_device_state(QpcDeviceState *S) {
   if (S->l1_buf) (void)hipFree(S->l1_buf);
   if (S->roll_buf) (void)hipFree(S->roll_buf);
   if (S->roll_ws) (void)hipFree(S->roll_ws);
-  if (S->roll_ord) (void)hipFree(S->roll_ord);
   if (S->jit_module) (void)hipModuleUnload(S->jit_module);
   delete S;
 }
@@ -1150,19 +1148,12 @@ int32_t qpc_sim_step_batch_device(qpc_controller *c, int64_t B, double *q, doubl
 // from step to step in `wsets`, 2 x uint64 per robot, zero-initialised by the caller = cold first tick)
 static int rollout_device(qpc_controller *c, int di, int64_t B, int64_t n_steps, double *q, double *v, const double *desired,
                           const double *cw, const double *cmax, const double *tw, const double *surf, const qpc_sim_params *params,
-                          double *tau, double *vdot, int32_t *status, int32_t *bad, unsigned long long *wsets, hipStream_t stream,
-                          int32_t *ord = nullptr) {
-  // two kernels per step on one stream, nothing else: the tick's work counter re-arms itself on the device.
-  // ord (2 B ints: iters, order): cold ticks hand their QPs out by descending working-set changes of the PREVIOUS step of the same
-  // robots (cost-ordered tickets, qpc.h) -- one tiny sort kernel per step, the launch tail of every tick shortened
+                          double *tau, double *vdot, int32_t *status, int32_t *bad, unsigned long long *wsets, hipStream_t stream) {
+  // two kernels per step on one stream, nothing else: the tick's work counter re-arms itself on the device
   for (int64_t s = 0; s < n_steps; s++) {
-    int rc = control_device(c, di, B, q, v, desired, cw, cmax, tw, surf, tau, vdot, nullptr, status, ord, wsets, stream,
-                            "qpc_rollout_batch_device", 0, (ord && s > 0) ? ord + B : nullptr);
+    int rc = control_device(c, di, B, q, v, desired, cw, cmax, tw, surf, tau, vdot, nullptr, status, nullptr, wsets, stream,
+                            "qpc_rollout_batch_device");
     if (rc != QPC_OK) return rc;
-    if (ord && s + 1 < n_steps) {
-      hipLaunchKernelGGL(qpc_ticket_order_kernel, dim3(1), dim3(1024), 0, stream, (long long)B, (const int32_t *)ord, 1000, ord + B);
-      HIP_TRY(hipGetLastError());
-    }
     rc = sim_step_device(c, di, B, q, v, tau, status, params, bad, stream);
     if (rc != QPC_OK) return rc;
   }
@@ -1190,20 +1181,7 @@ int32_t qpc_rollout_batch_device(qpc_controller *c, int64_t B, int64_t n_steps, 
     HIP_TRY(hipMemsetAsync(S->roll_ws, 0, need, (hipStream_t)hip_stream));
     wsets = S->roll_ws;
   }
-  int32_t *ord = nullptr;
-  if (!wsets && n_steps > 1 && B >= 1024) { // cold ticks: cost-ordered tickets from the previous step's iteration counts
-    QpcDeviceState *S = c->rt->devs[0];
-    HIP_TRY(hipSetDevice(S->device));
-    const size_t need = 2 * (size_t)B * sizeof(int32_t);
-    if (need > S->roll_ord_bytes) {
-      if (S->roll_ord) HIP_TRY(hipFree(S->roll_ord));
-      S->roll_ord = nullptr; S->roll_ord_bytes = 0;
-      HIP_TRY(hipMalloc(&S->roll_ord, need));
-      S->roll_ord_bytes = need;
-    }
-    ord = S->roll_ord;
-  }
-  return rollout_device(c, 0, B, n_steps, q, v, desired, cw, cmax, tw, surf, params, tau, vdot, status, bad, wsets, (hipStream_t)hip_stream, ord);
+  return rollout_device(c, 0, B, n_steps, q, v, desired, cw, cmax, tw, surf, params, tau, vdot, status, bad, wsets, (hipStream_t)hip_stream);
 }
 
 // host-pointer variants: the batch is sharded over the controller's devices; per device one persistent slab, everything
