@@ -296,6 +296,12 @@ int32_t qpc_default_settings(qpc_settings *s);
  * in 10^4) -> ITERATION_LIMIT; a primal residual within 10x of the tolerance -> NUMERICAL_ERROR instead of INFEASIBLE.
  * Needs the hiprtc-specialised kernel (QPC_ERR_UNSUPPORTED with QPC_DISABLE_JIT=1); the closed-loop entry points
  * (qpc_sim_step_batch, qpc_rollout_batch) and warm starts stay fp64-only. */
+/* Lane packing of the tick kernel (before qpc_finalize).  1 (default): one QP per wavefront.  2: two QPs per wavefront -- lanes 0-31 and
+ * 32-63 each work their own QP on their own LDS slab, one instruction stream advances both (the tick uses at most ~36 of its 64
+ * lanes at a time and is bound by the number of instructions it issues; DESIGN.md 7c has the measurements).  Same results (the
+ * per-QP arithmetic does not change); needs the hiprtc-specialised kernel, a contact basis of four rays and at most two presolved
+ * foot blocks; warm starts and the closed-loop entry points keep one QP per wavefront. */
+int32_t qpc_set_qps_per_wavefront(qpc_controller *ctrl, int32_t qps_per_wavefront);
 enum { QPC_PRECISION_F64 = 0, QPC_PRECISION_F32 = 1 };
 int32_t qpc_set_precision(qpc_controller *ctrl, int32_t precision);
 int32_t qpc_set_settings(qpc_controller *ctrl, const qpc_settings *s);

@@ -198,6 +198,10 @@ class Controller:
         """0 = fp64 (default), 1 = fp32 tick (BASELINE config 5's variant; qpc_set_precision)"""
         _check(self.L, self.L.qpc_set_precision(self.h, int(precision)), "qpc_set_precision")
 
+    def set_qps_per_wavefront(self, n):
+        """1 (default) or 2: two QPs per wavefront, lanes 0-31 / 32-63 (qpc_set_qps_per_wavefront)"""
+        _check(self.L, self.L.qpc_set_qps_per_wavefront(self.h, int(n)), "qpc_set_qps_per_wavefront")
+
     def regularize_per_qp(self, joint):
         """regularize!(c, joint, weight::Parameter): -> index of the weight in the per-QP task-weight record"""
         off = ctypes.c_int32(-1)

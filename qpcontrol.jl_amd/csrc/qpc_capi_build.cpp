@@ -183,6 +183,13 @@ int32_t qpc_set_precision(qpc_controller *c, int32_t precision) {
   return QPC_OK;
 }
 
+int32_t qpc_set_qps_per_wavefront(qpc_controller *c, int32_t n) {
+  if (!c || (n != 1 && n != 2)) return QPC_ERR_INVALID_ARGUMENT;
+  if (c->finalized) { qpc_set_error("qpc_set_qps_per_wavefront must be called before qpc_finalize"); return QPC_ERR_ALREADY_FINALIZED; }
+  c->qps_per_wave = n;
+  return QPC_OK;
+}
+
 int32_t qpc_regularize(qpc_controller *c, int32_t joint, double w) {
   if (!c || joint < 0 || joint >= c->model->nb) return QPC_ERR_INVALID_ARGUMENT;
   if (c->finalized) { qpc_set_error("regularize! must be called before the first tick"); return QPC_ERR_ALREADY_FINALIZED; }

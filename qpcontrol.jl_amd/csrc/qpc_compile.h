@@ -53,6 +53,7 @@ struct qpc_controller {
   QpcProgram prog;
   qpc_layout layout;
   QpcRuntime *rt = nullptr;
+  int qps_per_wave = 1;                     // qpc_set_qps_per_wavefront: 2 = two QPs per wavefront (lanes 0-31 / 32-63), hiprtc kernel only
   int precision = 0;                        // qpc_set_precision: QPC_PRECISION_F64 / _F32 (arithmetic of the tick kernel)
   int warm_start = 0;                       // qpc_enable_warm_start: also build the warm-started kernel variant
   int pipe_slots = 0;                       // qpc_set_host_pipeline (0 / -1: defaults)

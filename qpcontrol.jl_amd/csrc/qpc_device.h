@@ -12,12 +12,31 @@
 // 32768-QP launch).  Opaque per QP the values are recomputed once per QP and shared by its phases: 2 spilled VGPRs,
 // 25.6 M solves/s; opaque per PHASE (-DQPC_LANE_PER_PHASE) nothing is spilled (205 VGPRs before the register-resident RNEA
 // inputs) but every phase redoes its address arithmetic (+18 % VALU instructions): 24.2 M.
+// QPC_PACK2: TWO QPs per wavefront.  The tick uses at most ~36 of its 64 lanes at a time (measured: 56 % of the lanes of an average
+// vector instruction are active, profiles/r04_*_lane_utilisation), and the kernel is bound by the NUMBER of instructions it issues: so
+// lanes 0-31 work one QP and lanes 32-63 another, each on its own LDS slab, and one instruction stream advances both.  The source is
+// written for 64 "virtual" lanes per QP; a half-wave runs a phase in up to two TRIPS (virtual lane = physical lane + 32 trip), and a
+// phase whose virtual lanes 32.. have nothing to do (bodies, rays, rows: all <= 32 for Atlas) takes one.  What used to be
+// wave-uniform (statuses, iteration counts, tolerances from reductions) is uniform per HALF: data-dependent branches diverge between
+// the two QPs and the hardware's exec mask serialises them -- single-wave workgroups have no barrier instruction to deadlock on.
+#ifdef QPC_PACK2
+#define QPC_W 32
+#else
+#define QPC_W 64
+#endif
 __device__ __forceinline__ int qpc_opaque_lane() {
-  int l = (int)(threadIdx.x & 63);
+  int l = (int)(threadIdx.x & (QPC_W - 1));
   asm volatile("" : "+v"(l));
   return l;
 }
-#if defined(QPC_NO_OPAQUE_LANE)
+#if defined(QPC_PACK2)
+#define QPC_TRIPS 2
+#define QPC_LANE_SCOPE const int qpc_lane_q = qpc_opaque_lane();
+#define QPC_LANE_IN_SCOPE 1
+// per-lane block for the virtual lanes below `nact` (a compile-time bound of the lanes that have work in this phase)
+#define QPC_PHASE_N(lane, nact) { _Pragma("unroll") for (int qpc_trip = 0; qpc_trip < QPC_TRIPS; qpc_trip++) { if (QPC_W * qpc_trip >= (nact)) break; const int lane = qpc_lane_q + QPC_W * qpc_trip;
+#define QPC_PHASE(lane) QPC_PHASE_N(lane, 64)
+#elif defined(QPC_NO_OPAQUE_LANE)
 #define QPC_PHASE(lane) { const int lane = (int)(threadIdx.x & 63);
 #define QPC_LANE_SCOPE
 #elif defined(QPC_LANE_PER_PHASE)
@@ -33,7 +52,13 @@ __device__ __forceinline__ int qpc_opaque_lane() {
 #else
 #define QPC_MACRO_LANE ((int)(threadIdx.x & 63))
 #endif
-#define QPC_END_PHASE } __syncthreads();
+#ifndef QPC_PACK2
+#define QPC_PHASE_N(lane, nact) QPC_PHASE(lane)
+#define QPC_BRACE_END }
+#else
+#define QPC_BRACE_END } }
+#endif
+#define QPC_END_PHASE QPC_BRACE_END __syncthreads();
 // SOFT end of a phase: the following block only depends on this one through the lane's own registers, DPP exchanges or LDS
 // words the SAME lane wrote -- no cross-lane LDS traffic in either direction until the next hard end.  Nothing is emitted: the
 // compiler may interleave the two blocks (loads of the next one hoisted over the arithmetic of this one).  The emulator keeps the
@@ -41,12 +66,12 @@ __device__ __forceinline__ int qpc_opaque_lane() {
 // Opt-in (-DQPC_SOFT_PHASES): measured on MI355X with the fused sweeps of the search joined this way, 28.93 against 28.99 M
 // solves/s with hard ends -- the compiler does not turn the freedom into overlap, so the default stays the conservative form.
 #ifdef QPC_SOFT_PHASES
-#define QPC_END_PHASE_SOFT }
+#define QPC_END_PHASE_SOFT QPC_BRACE_END
 #else
 #define QPC_END_PHASE_SOFT QPC_END_PHASE
 #endif
 // end of a block after which nothing is exchanged through LDS until the next hard end (registers and DPP only): never a fence
-#define QPC_END_PHASE_REG }
+#define QPC_END_PHASE_REG QPC_BRACE_END
 // hard boundary without a block (after a group of soft-joined blocks, before code that reads other lanes' LDS words)
 #define QPC_PHASE_SYNC __syncthreads();
 #include "qpc_math.h" // qpc_sincos, qpc_atan2: straight-line elementary functions (no scratch, few registers)
@@ -107,10 +132,17 @@ __device__ __forceinline__ float qpc_rsqrtf(float x) {
 #endif
 #define QPC_UNROLL_FULL _Pragma("unroll")
 // lane-private storage that persists across phases (registers on the device)
+#ifdef QPC_PACK2 // one copy per trip (the trip loop is unrolled: constant indices)
+#define QPC_LANE_ARRAY(name, n) real name[QPC_TRIPS][n]
+#define QPC_LA(name, lane) name[(lane) >> 5]
+#define QPC_LANE_INTS(name, n) int name[QPC_TRIPS][n]
+#define QPC_LI(name, lane) name[(lane) >> 5]
+#else
 #define QPC_LANE_ARRAY(name, n) real name[n]
 #define QPC_LA(name, lane) name
 #define QPC_LANE_INTS(name, n) int name[n]
 #define QPC_LI(name, lane) name
+#endif
 #define QPC_CTZ64(x) (__ffsll((unsigned long long)(x)) - 1)
 #define QPC_POPC64(x) __popcll((unsigned long long)(x))
 #ifdef QPC_JIT
@@ -211,6 +243,84 @@ __device__ __forceinline__ int wave_min_int(int x) {
 #else
 #define QPC_RAW(x) (x)
 #endif
+#ifdef QPC_PACK2
+// reductions over the 32 lanes of a half: DPP row shifts inside the rows of 16, row_bcast:15 into the second row of the half, the
+// result read from lane 31 / 63.  A PUT runs once per trip: the first assigns, the second combines.
+namespace qpc {
+#define QPC_H_STEPS(OP) OP(0x111, 0xf) OP(0x112, 0xf) OP(0x114, 0xf) OP(0x118, 0xf) OP(0x142, 0xa)
+__device__ __forceinline__ int half_pick(int v) {
+  const int a = __builtin_amdgcn_readlane(v, 31), b = __builtin_amdgcn_readlane(v, 63);
+  return (threadIdx.x & 32) ? b : a;
+}
+__device__ __forceinline__ float half_max(float x) {
+#define QPC_DPP_OP(ctrl, rmask) { const int b__ = __float_as_int(x); x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(b__, b__, ctrl, rmask, 0xf, false))); }
+  QPC_H_STEPS(QPC_DPP_OP)
+#undef QPC_DPP_OP
+  return __int_as_float(half_pick(__float_as_int(x)));
+}
+__device__ __forceinline__ float half_min(float x) {
+#define QPC_DPP_OP(ctrl, rmask) { const int b__ = __float_as_int(x); x = fminf(x, __int_as_float(__builtin_amdgcn_update_dpp(b__, b__, ctrl, rmask, 0xf, false))); }
+  QPC_H_STEPS(QPC_DPP_OP)
+#undef QPC_DPP_OP
+  return __int_as_float(half_pick(__float_as_int(x)));
+}
+__device__ __forceinline__ double half_max(double x) {
+#define QPC_DPP_OP(ctrl, rmask) { const int lo__ = __double2loint(x), hi__ = __double2hiint(x); \
+    x = fmax(x, __hiloint2double(__builtin_amdgcn_update_dpp(hi__, hi__, ctrl, rmask, 0xf, false), __builtin_amdgcn_update_dpp(lo__, lo__, ctrl, rmask, 0xf, false))); }
+  QPC_H_STEPS(QPC_DPP_OP)
+#undef QPC_DPP_OP
+  return __hiloint2double(half_pick(__double2hiint(x)), half_pick(__double2loint(x)));
+}
+__device__ __forceinline__ double half_min(double x) {
+#define QPC_DPP_OP(ctrl, rmask) { const int lo__ = __double2loint(x), hi__ = __double2hiint(x); \
+    x = fmin(x, __hiloint2double(__builtin_amdgcn_update_dpp(hi__, hi__, ctrl, rmask, 0xf, false), __builtin_amdgcn_update_dpp(lo__, lo__, ctrl, rmask, 0xf, false))); }
+  QPC_H_STEPS(QPC_DPP_OP)
+#undef QPC_DPP_OP
+  return __hiloint2double(half_pick(__double2hiint(x)), half_pick(__double2loint(x)));
+}
+__device__ __forceinline__ int half_min_int(int x) {
+#define QPC_DPP_OP(ctrl, rmask) { const int t__ = __builtin_amdgcn_update_dpp(x, x, ctrl, rmask, 0xf, false); x = t__ < x ? t__ : x; }
+  QPC_H_STEPS(QPC_DPP_OP)
+#undef QPC_DPP_OP
+  return half_pick(x);
+}
+__device__ __forceinline__ float half_sum(float x) {
+#define QPC_DPP_OP(ctrl, rmask) { x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, rmask, 0xf, false)); }
+  QPC_H_STEPS(QPC_DPP_OP)
+#undef QPC_DPP_OP
+  return __int_as_float(half_pick(__float_as_int(x)));
+}
+__device__ __forceinline__ double half_sum(double x) {
+#define QPC_DPP_OP(ctrl, rmask) { const int lo__ = __double2loint(x), hi__ = __double2hiint(x); \
+    x += __hiloint2double(__builtin_amdgcn_update_dpp(0, hi__, ctrl, rmask, 0xf, false), __builtin_amdgcn_update_dpp(0, lo__, ctrl, rmask, 0xf, false)); }
+  QPC_H_STEPS(QPC_DPP_OP)
+#undef QPC_DPP_OP
+  return __hiloint2double(half_pick(__double2hiint(x)), half_pick(__double2loint(x)));
+}
+#undef QPC_H_STEPS
+// the 32 predicate bits of this half (bit j = physical lane j of the half)
+__device__ __forceinline__ unsigned long long half_ballot(bool pred) {
+  return (unsigned long long)((__ballot(pred ? 1 : 0) >> (threadIdx.x & 32)) & 0xffffffffull);
+}
+} // namespace qpc
+#ifdef QPC_F32
+#define QPC_HABS(x) __builtin_fabsf(x)
+#else
+#define QPC_HABS(x) fabs(x)
+#endif
+#define QPC_RED_MAX_PUT(slot, name, val) { const real r__ = real(qpc::half_max(QPC_HABS(QPC_RAW(val)))); name = (qpc_trip == 0 || r__ > name) ? r__ : name; }
+#define QPC_RED_MAX_GET(slot, name) (name)
+#define QPC_RED_ARGMIN_PUT(slot, name, iname, val, idx) \
+  do { const real v__ = (val); const real m__ = real(qpc::half_min(QPC_RAW(v__))); const int i__ = qpc::half_min_int(v__ == m__ ? (int)(idx) : 0x3fffffff); \
+       if (qpc_trip == 0 || m__ < name || (m__ == name && i__ < iname)) { name = m__; iname = i__; } } while (0)
+#define QPC_RED_ARGMIN_GET(slot, name, iname) ((void)0)
+#define QPC_RED_ARGMIN_LANE_PUT(slot, name, iname, val, idx) \
+  do { const real v__ = (val); const real m__ = real(qpc::half_min(QPC_RAW(v__))); const unsigned long long b__ = qpc::half_ballot(v__ == m__); \
+       const int i__ = b__ ? (int)__builtin_ctzll(b__) + QPC_W * qpc_trip : 0x3fffffff; \
+       if (qpc_trip == 0 || m__ < name) { name = m__; iname = i__; } } while (0)
+#define QPC_BALLOT_PUT(slot, name, pred) { const unsigned long long b__ = qpc::half_ballot(pred); name = qpc_trip == 0 ? b__ : (name | (b__ << 32)); }
+#define QPC_BALLOT_GET(slot, name) ((void)0)
+#else // !QPC_PACK2
 #define QPC_RED_MAX_PUT(slot, name, val) name = real(qpc::wave_max_scale(QPC_RAW(val)))
 #define QPC_RED_MAX_GET(slot, name) (name)
 
@@ -225,6 +335,7 @@ __device__ __forceinline__ int wave_min_int(int x) {
 // 64-bit lane mask of a predicate (one scalar compare); same PUT / GET protocol
 #define QPC_BALLOT_PUT(slot, name, pred) name = __ballot((pred) ? 1 : 0)
 #define QPC_BALLOT_GET(slot, name) ((void)0)
+#endif // QPC_PACK2
 
 // OUT4[i] = XEXPR evaluated in lane 4 * (lane / 4) + i, i = 0..3: DPP quad_perm broadcasts (no LDS).  Must be executed
 // by all 64 lanes (phase level, like the MFMA macro below).
@@ -288,6 +399,8 @@ __device__ __forceinline__ float qpc_row_share(float x, int k) {
 }
 #define QPC_ROW_SHARE(lane, OUT, N, X, K)                                                         \
   {                                                                                              \
+    const int lane = QPC_MACRO_LANE;                                                             \
+    (void)lane;                                                                                  \
     real *out__ = (OUT);                                                                         \
     const real *x__ = (X);                                                                       \
     for (int i__ = 0; i__ < (N); i__++) out__[i__] = real(qpc_row_share(QPC_RAW(x__[i__]), (K))); \
@@ -324,11 +437,17 @@ __device__ __forceinline__ double qpc_wave_sum(double x) {
   x = qpc_wave_prefix_sum(x);
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 63), __builtin_amdgcn_readlane(__double2loint(x), 63));
 }
+#ifdef QPC_PACK2
+#define QPC_RED_SUM_PUT(slot, name, val) { const real r__ = real(qpc::half_sum(QPC_RAW(val))); name = qpc_trip == 0 ? r__ : name + r__; }
+#else
 #define QPC_RED_SUM_PUT(slot, name, val) name = real(qpc_wave_sum(QPC_RAW(val)))
+#endif
 #define QPC_RED_SUM_GET(slot, name) (name)
 // phase level (all 64 lanes): ARR[i] of every lane becomes the sum of ARR[i] over the lanes up to and including it
 #define QPC_WAVE_INCL_SCAN(lane, ARR, N)                                                          \
   {                                                                                              \
+    const int lane = QPC_MACRO_LANE;                                                             \
+    (void)lane;                                                                                  \
     real *a__ = (ARR);                                                                           \
     for (int i__ = 0; i__ < (N); i__++) a__[i__] = real(qpc_wave_prefix_sum(QPC_RAW(a__[i__]))); \
   }

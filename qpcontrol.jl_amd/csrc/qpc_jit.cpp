@@ -58,10 +58,18 @@ static void put_dims(std::ostringstream &o, const char *name, const QpcDims &D) 
     << dbl(D.tol_accept) << "," << dbl(D.h_static_max) << "," << dbl(D.h_static_min) << "," << dbl(D.k_mu2) << "};\n";
 }
 
-std::string qpc_jit_source(const QpcDims &D, const QpcDims &DS, bool warm, bool f32) {
+int qpc_jit_tick_waves(bool f32, bool pack2) {
+  // fp64: 256 registers (two waves); two fp64 QPs per wave need two 20 KB slabs: four workgroups per CU, one wave per SIMD with 512
+  // registers.  fp32: three waves (see below); packed: two 10 KB slabs per workgroup, eight per CU = two waves per SIMD
+  if (pack2) return f32 ? 2 : 1;
+  return f32 ? QPC_F32_WAVES_PER_SIMD : 2;
+}
+
+std::string qpc_jit_source(const QpcDims &D, const QpcDims &DS, bool warm, bool f32, bool pack2) {
   std::ostringstream o;
   o << "typedef int int32_t;\ntypedef unsigned int uint32_t;\ntypedef long long int64_t;\ntypedef unsigned long long uint64_t;\n";
   if (f32) o << "#define QPC_F32 1\n";
+  if (pack2) o << "#define QPC_PACK2 1\n#define QPC_NO_MFMA 1\n";
   o << "#define QPC_JIT 1\n#define QPC_M1_MAX " << (D.m1 > 0 ? D.m1 : 1) << "\n#define QPC_MAXD " << D.maxd << "\n#define QPC_NTILE_MAX " << (((D.m + 15) / 16) * (((D.m + 15) / 16) + 1) / 2 > 0 ? ((D.m + 15) / 16) * (((D.m + 15) / 16) + 1) / 2 : 1) << "\n#define QPC_XTILE_MAX " << (((D.m1 + 15) / 16) * (((D.m1 + 15) / 16) + 1) / 2 + (D.m1 + 15) / 16 > 0 ? ((D.m1 + 15) / 16) * (((D.m1 + 15) / 16) + 1) / 2 + (D.m1 + 15) / 16 : 1)
     << "\n#include \"qpc_device.h\"\n";
   const char *st = getenv("QPC_JIT_STAMPS"); // diagnostic: in-kernel section timers
@@ -93,7 +101,7 @@ std::string qpc_jit_source(const QpcDims &D, const QpcDims &DS, bool warm, bool 
   // waves per SIMD the register allocation aims at: the fp64 tick needs its 256 registers (two waves).  The fp32 tick's slab is half
   // the size (16 fit a CU), but measured on MI355X (config 5, 32 768 QPs): 2 waves / 256 registers 36.7 M solves/s, 3 waves / 168
   // registers (272 B of scratch per lane) 37.1 M, 4 waves / 128 registers (368 B of scratch) 33.9 M -- three it is
-  int waves = f32 ? QPC_F32_WAVES_PER_SIMD : 2;
+  int waves = qpc_jit_tick_waves(f32, pack2);
   if (const char *e = QPC_EXP_ENV("QPC_EXP_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 8) waves = v; }
   if (dyn_lds) o << "extern __shared__ __attribute__((aligned(16))) double qpc_lds_dyn[];\n";
   o << "#ifdef QPC_KERNARG_RELOAD\n"
@@ -106,10 +114,11 @@ std::string qpc_jit_source(const QpcDims &D, const QpcDims &DS, bool warm, bool 
     o << "extern \"C\" __global__ void __launch_bounds__(64, " << waves << ") " << (variant ? "qpc_tick_kernel_jit_warm" : "qpc_tick_kernel_jit")
       << "(const int *__restrict__ IT, const double *__restrict__ DT, const QpcBatchArgs A) {\n";
     if (dyn_lds && !f32) o << "  double *const qpc_lds_raw = qpc_lds_dyn;\n";
-    else o << "  __shared__ __attribute__((aligned(16))) " << (f32 ? "float" : "double") << " qpc_lds_raw[" << (D.lds_doubles > 0 ? D.lds_doubles : 1) << "];\n";
+    else o << "  __shared__ __attribute__((aligned(16))) " << (f32 ? "float" : "double") << " qpc_lds_raw[" << (pack2 ? 2 : 1) * (D.lds_doubles > 0 ? D.lds_doubles : 1) << "];\n";
     // (fp32: `real` is a class holding one float -- qpc_real.h -- so the slab of floats is addressed as an array of reals)
     o <<
-         "  real *const qpc_lds = (real *)qpc_lds_raw;\n"
+         "  real *const qpc_lds = (real *)qpc_lds_raw" << (pack2 ? " + (threadIdx.x >> 5) * " + std::to_string(D.lds_doubles) : std::string()) << "; // (packed: one slab per half-wave)\n"
+         "  constexpr int kW = " << (pack2 ? 32 : 64) << ", kQ = " << (pack2 ? 2 : 1) << "; // lanes per QP, QPs per wavefront\n"
          "  typedef real *LdsP;\n"
          "  qpc::qpc_tick_prologue<LdsP>(kD, kDS, IT, qpc_lds);\n"
          "  while (true) {\n"
@@ -122,11 +131,11 @@ std::string qpc_jit_source(const QpcDims &D, const QpcDims &DS, bool warm, bool 
          "    asm volatile(\"\" : \"+s\"(Ak));\n"
          "#endif\n"
          "    unsigned long long t = 0;\n"
-         "    if ((threadIdx.x & 63) == 0) t = atomicAdd(KA(ticket), 1ull);\n"
-         "    const long long tk = (long long)__shfl(t, 0, 64);\n"
+         "    if ((threadIdx.x & (kW - 1)) == 0) t = atomicAdd(KA(ticket), 1ull);\n"
+         "    const long long tk = (long long)__shfl(t, threadIdx.x & (64 - kW), 64);\n"
          "    if (tk >= KA(B)) {\n"
-         "      // a launch draws exactly B + gridDim.x tickets; whoever draws the last one re-arms the counter\n"
-         "      if ((threadIdx.x & 63) == 0 && tk == KA(B) + (long long)gridDim.x - 1) atomicExch(KA(ticket), 0ull);\n"
+         "      // a launch draws exactly B + kQ gridDim.x tickets; whoever draws the last one re-arms the counter\n"
+         "      if ((threadIdx.x & (kW - 1)) == 0 && tk == KA(B) + (long long)kQ * gridDim.x - 1) atomicExch(KA(ticket), 0ull);\n"
          "      break;\n"
          "    }\n"
          "    // ticket -> QP: in batch order, or through the caller's cost order (expensive QPs first: qpc_ticket_order_device)\n"
@@ -185,8 +194,8 @@ std::string qpc_jit_source(const QpcDims &D, const QpcDims &DS, bool warm, bool 
 static std::mutex g_jit_mu;
 static std::map<std::string, std::vector<char>> g_jit_cache;
 
-int qpc_jit_compile(const QpcDims &D, const QpcDims &DS, const std::string &arch, bool warm, bool f32, std::vector<char> &code, std::string &log) {
-  std::string src = qpc_jit_source(D, DS, warm, f32);
+int qpc_jit_compile(const QpcDims &D, const QpcDims &DS, const std::string &arch, bool warm, bool f32, bool pack2, std::vector<char> &code, std::string &log) {
+  std::string src = qpc_jit_source(D, DS, warm, f32, pack2);
   std::string key;
   {
     const char *ce = getenv("QPC_JIT_CACHE"), *xe = QPC_EXP_ENV("QPC_JIT_EXTRA_FLAGS");
@@ -268,7 +277,7 @@ extern "C" int32_t qpc_debug_jit_compile(qpc_controller *c, const char *arch, co
   if (!c->finalized) { int rc = qpc_compile_program(c); if (rc != QPC_OK) return rc; }
   std::vector<char> code;
   std::string log;
-  int rc = qpc_jit_compile(c->prog.dims, c->prog.dims_s, arch ? arch : "gfx950", c->warm_start != 0, c->precision == QPC_PRECISION_F32, code, log);
+  int rc = qpc_jit_compile(c->prog.dims, c->prog.dims_s, arch ? arch : "gfx950", c->warm_start != 0, c->precision == QPC_PRECISION_F32, c->qps_per_wave == 2, code, log);
   if (logbuf && logn > 0) snprintf(logbuf, logn, "%s", log.c_str());
   if (rc != 0) { qpc_set_error("JIT compile failed: " + log); return QPC_ERR_HIP; }
   if (out_path) { FILE *f = fopen(out_path, "wb"); if (f) { fwrite(code.data(), 1, code.size(), f); fclose(f); } }
@@ -279,7 +288,7 @@ extern "C" int32_t qpc_debug_jit_compile(qpc_controller *c, const char *arch, co
 extern "C" int32_t qpc_debug_jit_source(qpc_controller *c, const char *out_path) {
   if (!c || !out_path) return QPC_ERR_INVALID_ARGUMENT;
   if (!c->finalized) { int rc = qpc_compile_program(c); if (rc != QPC_OK) return rc; }
-  std::string src = qpc_jit_source(c->prog.dims, c->prog.dims_s, c->warm_start != 0, c->precision == QPC_PRECISION_F32);
+  std::string src = qpc_jit_source(c->prog.dims, c->prog.dims_s, c->warm_start != 0, c->precision == QPC_PRECISION_F32, c->qps_per_wave == 2);
   FILE *f = fopen(out_path, "wb");
   if (!f) return QPC_ERR_INVALID_ARGUMENT;
   fwrite(src.data(), 1, src.size(), f);

@@ -218,8 +218,9 @@ static size_t g_tick_lds_max = 0, g_sim_lds_max = 0;
 
 static int launch(qpc_controller *c, QpcDeviceState *S, QpcSlot &sl, const QpcBatchArgs &a, hipStream_t stream, bool warm) {
   const QpcDims &D = c->prog.dims;
+  const bool pack2 = c->qps_per_wave == 2 && !warm; // (the warm-started variant keeps one QP per wavefront)
   long long grid = (long long)S->n_cu * S->blocks_per_cu;
-  if (grid > a.B) grid = a.B;
+  if (grid > (a.B + (pack2 ? 1 : 0)) / (pack2 ? 2 : 1)) grid = (a.B + (pack2 ? 1 : 0)) / (pack2 ? 2 : 1);
   if (grid < 1) return QPC_OK;
   size_t lds = (size_t)D.lds_doubles * (c->precision == QPC_PRECISION_F32 ? sizeof(float) : sizeof(double));
   const bool user_stream = sl.stream == nullptr;
@@ -330,9 +331,9 @@ static int init_device_state(qpc_controller *c, QpcDeviceState *S, int device_id
   S->device = device_id;
   HIP_TRY(hipSetDevice(device_id));
   S->n_cu = prop.multiProcessorCount;
-  const bool f32 = c->precision == QPC_PRECISION_F32;
-  const size_t lds = (size_t)D.lds_doubles * (f32 ? sizeof(float) : sizeof(double));
-  if (lds > 160 * 1024) { qpc_set_error("qpc_finalize: LDS slab exceeds the device limit"); return QPC_ERR_UNSUPPORTED; }
+  const bool f32 = c->precision == QPC_PRECISION_F32, pack2 = c->qps_per_wave == 2;
+  const size_t lds = (size_t)D.lds_doubles * (f32 ? sizeof(float) : sizeof(double)) * (pack2 ? 2 : 1);
+  if (lds > 160 * 1024 / (pack2 ? 2 : 1) * (pack2 ? 2 : 1)) { qpc_set_error("qpc_finalize: LDS slab exceeds the device limit"); return QPC_ERR_UNSUPPORTED; }
   const size_t slds = (size_t)qpc_sim_layout(D).total * sizeof(double);
   if (slds > 160 * 1024) { qpc_set_error("qpc_finalize: simulation LDS slab exceeds the device limit"); return QPC_ERR_UNSUPPORTED; }
   {
@@ -345,7 +346,7 @@ static int init_device_state(qpc_controller *c, QpcDeviceState *S, int device_id
   int per_cu = (int)((160 * 1024) / (lds > 0 ? lds : 1));
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 16) per_cu = 16; // 32 waves/CU cap; leave room for registers
-  if (f32 && per_cu > 4 * QPC_F32_WAVES_PER_SIMD) per_cu = 4 * QPC_F32_WAVES_PER_SIMD; // the persistent grid must be resident at once
+  if ((f32 || pack2) && per_cu > 4 * qpc_jit_tick_waves(f32, pack2)) per_cu = 4 * qpc_jit_tick_waves(f32, pack2); // the persistent grid must be resident at once
   if (const char *e = QPC_EXP_ENV("QPC_EXP_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 16) per_cu = v; } // experiment
   S->blocks_per_cu = per_cu;
   int sper = (int)((160 * 1024) / (slds > 0 ? slds : 1));
@@ -653,7 +654,12 @@ int32_t qpc_finalize_devices(qpc_controller *c, int32_t n_devices, const int32_t
   std::vector<char> code;
   const char *nojit = getenv("QPC_DISABLE_JIT");
   const bool jit_off = nojit && nojit[0] == '1';
-  const bool f32 = c->precision == QPC_PRECISION_F32;
+  const bool f32 = c->precision == QPC_PRECISION_F32, pack2 = c->qps_per_wave == 2;
+  if (pack2 && (jit_off || c->warm_start || D.presolve > 2 || (D.nrho > 0 && (D.N != 4 || D.nrho > 32)))) {
+    qpc_set_error("qpc_set_qps_per_wavefront(2): needs the hiprtc-specialised kernel, no warm start, a four-ray contact basis with at most 32 rays "
+                  "and at most two presolved foot blocks");
+    return QPC_ERR_UNSUPPORTED;
+  }
   if (jit_off && f32) {
     qpc_set_error("QPC_DISABLE_JIT=1 but the fp32 tick (qpc_set_precision) only exists as a hiprtc-specialised kernel");
     return QPC_ERR_UNSUPPORTED;
@@ -664,10 +670,10 @@ int32_t qpc_finalize_devices(qpc_controller *c, int32_t n_devices, const int32_t
   }
   if (!jit_off) {
     std::string log;
-    const int jrc = qpc_jit_compile(D, c->prog.dims_s, prop0.gcnArchName, c->warm_start != 0, f32, code, log);
+    const int jrc = qpc_jit_compile(D, c->prog.dims_s, prop0.gcnArchName, c->warm_start != 0, f32, pack2, code, log);
     if (jrc != 0) {
       code.clear();
-      if (f32) { qpc_set_error("JIT specialisation of the fp32 tick failed (there is no ahead-of-time fp32 kernel): " + log); return QPC_ERR_HIP; }
+      if (f32 || pack2) { qpc_set_error("JIT specialisation of the fp32 / packed tick failed (there is no ahead-of-time form of it): " + log); return QPC_ERR_HIP; }
       const char *strict = getenv("QPC_REQUIRE_JIT");
       if (strict && strict[0] == '1') { qpc_set_error("JIT specialisation failed: " + log); return QPC_ERR_HIP; }
       if (D.maxdepth > QPC_GENERIC_MAXD) {
@@ -690,7 +696,7 @@ int32_t qpc_finalize_devices(qpc_controller *c, int32_t n_devices, const int32_t
     rc = init_device_state(c, S, device_ids[i], rt->slots, code, prop);
     if (rc != QPC_OK) {
       const char *strict = getenv("QPC_REQUIRE_JIT");
-      if (!code.empty() && rc == QPC_ERR_HIP && !(strict && strict[0] == '1') && D.maxdepth <= QPC_GENERIC_MAXD && !S->jit_func && !f32) {
+      if (!code.empty() && rc == QPC_ERR_HIP && !(strict && strict[0] == '1') && D.maxdepth <= QPC_GENERIC_MAXD && !S->jit_func && !f32 && !pack2) {
         // code object would not load: fall back to the generic gfx950 kernel on every device
         fprintf(stderr, "[qpc] JIT code object unusable (%s); using the generic gfx950 kernel\n", qpc_last_error());
         for (auto *T : rt->devs) destroy_device_state(T);

@@ -2213,6 +2213,25 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, qpc_dta
   // The one GEMM-shaped step of the tick (a12: the J'J small GEMM): lower-triangular 16x16 tiles of
   // S = M M' on the fp64 matrix core (v_mfma_f64_16x16x4_f64), operands straight from the LDS copy of
   // M (zero padded to multiples of 16 x 4), accumulators in registers, written once to LDS.
+#ifdef QPC_NO_MFMA
+  // (two QPs per wavefront -- QPC_PACK2 -- have no full wave for a matrix-core tile: the dot-product form, one entry of the lower
+  //  triangle per lane and trip)
+  QPC_PHASE(lane) {
+    for (int e = lane; e < m * (m + 1) / 2; e += 64) {
+      int r = 0, c = e;
+      while (c > r) { r++; c -= r; }
+      real v = dotp(sm + D.lds[L_M] + r * D.nfs, 1, sm + D.lds[L_M] + c * D.nfs, 1, nf);
+      if (ne > 0 && r < m1) {
+        const int slr = (int)(real)sm[D.lds[L_HOT] + r], slc = (int)(real)sm[D.lds[L_HOT] + c];
+        if (slr >= 0 && slc >= 0) {
+          const int s0r = (int)(real)sm[D.lds[L_HOT] + m + 3 * ne + slr], s0c = (int)(real)sm[D.lds[L_HOT] + m + 3 * ne + slc];
+          if (s0r == s0c) v += sm[D.lds[L_WINV] + (int)(real)sm[D.lds[L_HOT] + m + ne + slr] + (slc - s0c)];
+        }
+      }
+      sm[D.lds[L_SM] + r * D.ms + c] = v;
+    }
+  } QPC_END_PHASE
+#else
   {
     const int nt = (m + 15) / 16, nk = (nf + 3) / 4;
     QPC_LANE_ARRAY(sacc_, 4 * QPC_NTILE_MAX);
@@ -2263,6 +2282,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, qpc_dta
       }
     } QPC_END_PHASE
   }
+#endif
   QPC_PROF_ACC(PS_SBUILD);
   QPC_STOP(3)
   // left-looking Cholesky of the leading m1 x m1 block (+ the L21 rows), infinite-pivot rule.
@@ -2343,6 +2363,27 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, qpc_dta
   // copy of X (lower triangular: tile row ti only needs k >= 16 ti), two LDS reads per lane and k-step
   // instead of the ~2 x 13 per entry of the dot-product form.  Z = X' L21' = S11^-1 S12 is one more column of
   // tiles of the same product, X' [X | L21'] (it used to be 6 m1 strided dot products in the write-out phase).
+#ifdef QPC_NO_MFMA
+  if (m1 > 0) { // dot-product form (see the Schur build): S11I[r][c] = sum_k X[k][r] X[k][c], Z[r][a] = sum_k X[k][r] L21[a][k]
+    QPC_PHASE(lane) {
+      for (int e = lane; e < m1 * (m1 + 1) / 2 + (nw ? m1 * 6 : 0); e += 64) {
+        if (e < m1 * (m1 + 1) / 2) {
+          int r = 0, c = e;
+          while (c > r) { r++; c -= r; }
+          real acc = 0.0;
+          for (int k = r; k < m1; k++) acc += sm[D.lds[L_X] + k * D.m1s + r] * sm[D.lds[L_X] + k * D.m1s + c]; // (X is lower triangular: k >= r >= c)
+          sm[D.lds[L_SM] + r * D.ms + c] = acc; // (the leading block of L_SM -- L11, dead by now; the Z entries read the L21 rows below it)
+          if (c < r) sm[D.lds[L_SM] + c * D.ms + r] = acc;
+        } else {
+          const int z = e - m1 * (m1 + 1) / 2, r = z / 6, a = z % 6;
+          real acc = 0.0;
+          for (int k = r; k < m1; k++) acc += sm[D.lds[L_X] + k * D.m1s + r] * sm[D.lds[L_SM] + (m1 + a) * D.ms + k];
+          sm[D.lds[L_X2] + r * 6 + a] = acc;
+        }
+      }
+    } QPC_END_PHASE
+  }
+#else
   if (m1 > 0) { // (no leading block -- the reduced problem of the presolve with its soft rows folded --: nothing to invert)
     const int nt1 = (m1 + 15) / 16, nk1 = (m1 + 3) / 4, ntri = nt1 * (nt1 + 1) / 2;
     QPC_LANE_ARRAY(xacc_, 4 * QPC_XTILE_MAX);
@@ -2411,6 +2452,7 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, qpc_dta
       }
     } QPC_END_PHASE
   }
+#endif
   QPC_PROF_ACC(PS_XINV);
   QPC_STOP(5)
   // ======================================================================== active-set solve (a13)

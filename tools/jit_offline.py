@@ -45,6 +45,8 @@ def main():
     f32 = os.environ.get("QPC_OFFLINE_F32") == "1"  # the fp32 variant of the tick (qpc_set_precision)
     if f32:
         c.set_precision(1)
+    if os.environ.get("QPC_OFFLINE_PACK2") == "1":  # two QPs per wavefront (qpc_set_qps_per_wavefront)
+        c.set_qps_per_wavefront(2)
     src = os.path.join(out, "tick_jit.hip")
     c.L.qpc_debug_jit_source.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
     rc = c.L.qpc_debug_jit_source(c.h, src.encode())
