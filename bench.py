@@ -182,7 +182,7 @@ def cpu_baseline(budget_s=12.0, max_workers=64):
 class DeviceRun:
     """A controller + one workload resident in HBM (torch tensors), launched through qpc_control_batch_device."""
 
-    def __init__(self, torch, binding, W, B, config, seed, device_index, fused_laws=False, f32=False):
+    def __init__(self, torch, binding, W, B, config, seed, device_index, fused_laws=False, f32=False, pack2=False):
         self.torch, self.B = torch, B
         real_finalize = binding.Controller.finalize
 
@@ -194,6 +194,8 @@ class DeviceRun:
                 c = binding.Controller(binding.Model(m), N, fl)
                 if f32:
                     c.set_precision(1)  # the fp32 variant of the tick (qpc_set_precision): BASELINE config 5's stated precision
+                if pack2:
+                    c.set_qps_per_wavefront(2)  # two QPs per wavefront (lanes 0-31 / 32-63)
                 return c
             self.ctrl, self.wl = W.atlas_workload(factory, B, config, seed=seed, fused_laws=fused_laws)
         finally:
@@ -470,6 +472,7 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=32768)
     ap.add_argument("--config", type=int, default=3, choices=[2, 3, 5])
     ap.add_argument("--f32", action="store_true", help="the fp32 variant of the tick (qpc_set_precision): not the headline (tau 1e-4 instead of 1e-8)")
+    ap.add_argument("--pack2", action="store_true", help="two QPs per wavefront (qpc_set_qps_per_wavefront(2))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the literal-BASELINE-batch points and the host-pointer path")
     ap.add_argument("--fused-laws", action="store_true",
@@ -509,7 +512,7 @@ def main():
     B = args.batch_per_gpu
     # every rank builds its own contiguous shard [rank*B, (rank+1)*B) of the global batch
     run = DeviceRun(torch, binding, W, B, args.config, {2: 2024, 3: 2025, 5: 2027}[args.config] + 7919 * rank, local_rank,
-                    fused_laws=args.fused_laws, f32=args.f32)
+                    fused_laws=args.fused_laws, f32=args.f32, pack2=args.pack2)
     ctrl, lay, L = run.ctrl, run.lay, run.ctrl.L
     dev = run.dev
 

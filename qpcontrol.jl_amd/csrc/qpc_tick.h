@@ -95,6 +95,19 @@ enum { PS_KIN, PS_ASM, PS_SBUILD, PS_CHOL, PS_XINV, PS_REFAC, PS_RESID, PS_KKT, 
 #define QPC_EPS_MACH 2.220446049250313e-16
 #endif
 
+// QPC_PHASE_N(lane, n): a phase whose virtual lanes n.. have nothing to do (with two QPs per wavefront -- QPC_PACK2 -- a phase is run
+// in trips of 32 lanes, and a compile-time bound saves the empty second trip; everywhere else it is QPC_PHASE)
+#ifndef QPC_PHASE_N
+#define QPC_PHASE_N(lane, n) QPC_PHASE(lane)
+#endif
+// two QPs per wavefront: the columns of T22 = S22^-1 do not ride along with the sweeps of the search (no idle lanes left for them):
+// they are computed when somebody needs them (Solver::ensure_t22)
+#ifdef QPC_PACK2
+#define QPC_LAZY_T22 1
+#else
+#define QPC_LAZY_T22 0
+#endif
+
 namespace qpc {
 
 // ------------------------------------------------------------------------------------------
@@ -375,6 +388,7 @@ template <class P> struct Solver {
   unsigned long long *PA, *PT; // section timers (diagnostic build)
   real last_gmax = 0.0, last_xmax = 0.0; // scales of the last base rho_solve (uniform)
   real last_dmax = 0.0;                   // max |rho - rho_prev| of the last proximal sweep (uniform)
+  bool t22_stale = false;                   // QPC_LAZY_T22: L_S22I does not belong to the S22 in L_C22 yet (ensure_t22)
   bool c_valid = false;                     // L_T1 holds c = E H^-1 (-g) - d (clobbered by kkt_solve)
   bool confirmed = false;                   // eqp(from_current) stopped after ONE sweep whose correction was <= 1e-9 relative:
                                             // the residual arrays (of the iterate before that correction) bound the final ones
@@ -415,7 +429,7 @@ template <class P> struct Solver {
     const int N = D.N, nc = D.nc, nrho = D.nrho;
     const real eps = sm[D.lds[L_MISC] + MS_EPS];
     if (D.k_tab) {
-      QPC_PHASE(lane) {
+      QPC_PHASE_N(lane, nrho) {
         const int j = lane < nrho ? lane : 0, c = j >> 2, jj = j & 3;
         int pat = 0;
         QPC_UNROLL_FULL
@@ -477,6 +491,7 @@ template <class P> struct Solver {
         for (int r = 0; r < 6; r++) sm[D.lds[L_S22I] + r * 6 + lane] = x[r];
       }
     } QPC_END_PHASE
+    t22_stale = false;
     QPC_PROF_ACC(PS_REFAC);
   }
 
@@ -536,11 +551,27 @@ template <class P> struct Solver {
     return D.k_tab && D.N == 4 && D.nrho + 6 <= 64;
 #endif
   }
+  // QPC_LAZY_T22: T22 = S22^-1 of the current working set from the S22 the last fused sweep left in L_C22 (six lanes, one column each)
+  QPC_FN void ensure_t22() {
+    if (!QPC_LAZY_T22 || !t22_stale) return;
+    const int m1 = D.m1;
+    QPC_PHASE_N(lane, 32) {
+      if (lane < 6) {
+        real sref[6], x[6], ec[6];
+        for (int k = 0; k < 6; k++)
+          sref[k] = sm[D.lds[L_SM] + (m1 + k) * D.ms + (m1 + k)] + (sm[D.lds[L_C22] + k * 6 + k] - sm[D.lds[L_B22] + k * 6 + k]);
+        for (int r = 0; r < 6; r++) ec[r] = (r == lane) ? 1.0 : 0.0;
+        chol6_solve(sm + D.lds[L_C22], sref, (real)D.tau_pivot, ec, x);
+        for (int r = 0; r < 6; r++) sm[D.lds[L_S22I] + r * 6 + lane] = x[r];
+      }
+    } QPC_END_PHASE
+    t22_stale = false;
+  }
   QPC_FN void ky_phase(bool from_mask = false, unsigned long long bfree = 0ull) {
     const int nrho = D.nrho;
     const real eps = sm[D.lds[L_MISC] + MS_EPS];
     QPC_PROF_ACC(PS_LOGIC);
-    QPC_PHASE(lane) {
+    QPC_PHASE_N(lane, nrho) {
       const int j = lane < nrho ? lane : 0, c = j >> 2, jj = j & 3;
       int pat = 0;
       if (from_mask) pat = (int)((bfree >> (4 * c)) & 15ull);
@@ -602,20 +633,33 @@ template <class P> struct Solver {
   // ends SOFT: what follows may only read this lane's own LDS words (rho_j, u_j, ...) until the caller's QPC_PHASE_SYNC
   QPC_FN void fused_solve() {
     const int nrho = D.nrho, m1 = D.m1;
+#if QPC_LAZY_T22
+    QPC_PHASE_N(lane, 32) { // S22 = B22 + G Y' is symmetric: the 21 entries of its lower triangle, mirrored (one trip of a half-wave)
+      if (lane < 21) {
+        int a = 0, b = lane;
+        while (b > a) { a++; b -= a; }
+        const real v = sm[D.lds[L_B22] + a * 6 + b] + dotp(sm + D.lds[L_G] + a * QPC_GS(nrho), 1, sm + D.lds[L_Y] + b * QPC_GS(nrho), 1, nrho);
+        sm[D.lds[L_C22] + a * 6 + b] = v;
+        if (a != b) sm[D.lds[L_C22] + b * 6 + a] = v;
+      }
+    } QPC_END_PHASE
+    t22_stale = true;
+#else
     QPC_PHASE(lane) {
       if (lane < 36) {
         int a = lane / 6, b = lane % 6;
         sm[D.lds[L_C22] + lane] = sm[D.lds[L_B22] + lane] + dotp(sm + D.lds[L_G] + a * QPC_GS(nrho), 1, sm + D.lds[L_Y] + b * QPC_GS(nrho), 1, nrho);
       }
     } QPC_END_PHASE
+#endif
     QPC_PROF_ACC(PS_S_C22);
     QPC_LANE_ARRAY(q4_, 10); // [0..3] (G' lam_w) of the quad, [4..7] rho of the quad, [8] own value in flight, [9] (G' lam_w)_j
     real rg = 0.0, rx = 0.0;
-    QPC_PHASE(lane) {
+    QPC_PHASE_N(lane, QPC_LAZY_T22 ? nrho : nrho + 6) {
       real sref[6], x[6], rhs[6];
       for (int k = 0; k < 6; k++)
         sref[k] = sm[D.lds[L_SM] + (m1 + k) * D.ms + (m1 + k)] + (sm[D.lds[L_C22] + k * 6 + k] - sm[D.lds[L_B22] + k * 6 + k]);
-      const int col = lane - nrho; // lanes nrho .. nrho + 5: column `col` of T22; every other lane: lam_w = S22^-1 u0
+      const int col = QPC_LAZY_T22 ? -1 : lane - nrho; // lanes nrho .. nrho + 5: column `col` of T22; every other lane: lam_w = S22^-1 u0
       for (int r = 0; r < 6; r++) rhs[r] = (col >= 0 && col < 6) ? ((r == col) ? 1.0 : 0.0) : (real)sm[D.lds[L_MISC] + MS_U0 + r];
       chol6_solve(sm + D.lds[L_C22], sref, (real)D.tau_pivot, rhs, x);
       if (lane == 0)
@@ -635,7 +679,7 @@ template <class P> struct Solver {
     } QPC_END_PHASE_SOFT
     QPC_PROF_ACC(PS_S_CHOL);
     QPC_QUAD_GATHER(lane, QPC_LA(q4_, lane), QPC_LA(q4_, lane)[8])
-    QPC_PHASE(lane) {
+    QPC_PHASE_N(lane, nrho) {
       real *q = QPC_LA(q4_, lane);
       real acc = 0.0;
       if (lane < nrho) { // (idle lanes must not touch K: lane 0 rewrites its row further down this soft-joined group)
@@ -645,7 +689,7 @@ template <class P> struct Solver {
       q[8] = acc;
     } QPC_END_PHASE_SOFT
     QPC_QUAD_GATHER(lane, QPC_LA(q4_, lane) + 4, QPC_LA(q4_, lane)[8])
-    QPC_PHASE(lane) {
+    QPC_PHASE_N(lane, nrho) {
       const real *q = QPC_LA(q4_, lane);
       real g = 0.0, xm = 0.0;
       if (lane < nrho) {
@@ -705,6 +749,7 @@ template <class P> struct Solver {
         }
       }
     } QPC_END_PHASE
+    t22_stale = false;
     QPC_PROF_ACC(PS_S_CHOL);
     rho_back(true, false, PS_S_BACK);
   }
@@ -714,6 +759,7 @@ template <class P> struct Solver {
   //   Z = S11^-1 S12 in L_X2, T22 = (B22 + C22)^-1 in L_S22I) -- no serial chain.
   QPC_FN void solve_S(int out) {
     const int m1 = D.m1, nw = D.nw;
+    ensure_t22();
     if (nw && m1 == 0) { // wrench rows only: lam_w = T22 t, one phase
       QPC_PHASE(lane) {
         if (lane < 6) sm[out + lane] = dotp(sm + D.lds[L_S22I] + lane * 6, 1, sm + D.lds[L_T1], 1, 6);
@@ -999,6 +1045,7 @@ template <class P> struct Solver {
     const int N = D.N, nrho = D.nrho, m1 = D.m1;
     const int outr = base ? D.lds[L_XR] : D.lds[L_DR], outl = (base ? D.lds[L_LAM] : D.lds[L_DL]) + m1;
     QPC_PROF_ACC(PS_LOGIC);
+    ensure_t22();
     const bool need_kr = !base || any_upper || prox;
     const real eps_prox = prox ? (real)sm[D.lds[L_MISC] + MS_EPS] : 0.0;
     if (need_kr && base && N == 4 && nrho <= 64) {

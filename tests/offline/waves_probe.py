@@ -54,7 +54,16 @@ def workload(factory, B, seed=7):
 def main():
     import torch
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 49152
-    c, lay, mech, q_, v_, des, cw_, cm_ = workload(lambda m, N, fl: binding.Controller(binding.Model(m), N, fl), B)
+    # QPC_PROBE_F32=1 / QPC_PROBE_PACK2=1: the fp32 tick / two QPs per wavefront on this biped (13 bodies, nv 18, 16 rays: every phase
+    # fits the 32 lanes of a half-wave -- the best case of the half-wave packing)
+    def factory(m, N, fl):
+        ctl = binding.Controller(binding.Model(m), N, fl)
+        if os.environ.get("QPC_PROBE_F32") == "1":
+            ctl.set_precision(1)
+        if os.environ.get("QPC_PROBE_PACK2") == "1":
+            ctl.set_qps_per_wavefront(2)
+        return ctl
+    c, lay, mech, q_, v_, des, cw_, cm_ = workload(factory, B)
     dev = torch.device("cuda", 0)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)  # noqa: E731
     q, v, d, cw, cm = t(q_), t(v_), t(des), t(cw_), t(cm_)
@@ -77,7 +86,7 @@ def main():
     torch.cuda.synchronize(dev)
     el = time.perf_counter() - t0
     s = status.cpu().numpy(); it = iters.cpu().numpy() % 1000
-    env = {k: os.environ[k] for k in os.environ if k.startswith("QPC_EXP_")}
+    env = {k: os.environ[k] for k in os.environ if k.startswith("QPC_EXP_") or k.startswith("QPC_PROBE_")}
     print(json.dumps({"solves_per_s": B * n / el, "ms_per_launch": 1e3 * el / n, "B": B, "n_free": lay.n_free, "n_eq_rows": lay.n_eq_rows,
                       "lds_bytes_per_qp": lay.lds_bytes_per_qp, "status_counts": np.bincount(s, minlength=6).tolist(),
                       "mean_working_set_changes": float(it.mean()), "env": env}))

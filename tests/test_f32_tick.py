@@ -154,3 +154,38 @@ def test_f32_needs_the_specialised_kernel(monkeypatch):
     W.standing_setup(c, mech, M.atlas_nominal_configuration(mech))
     with pytest.raises(binding.QpcError, match="fp32 tick"):
         c.finalize()
+
+
+def _packed_vs_plain(f32, B=2048, config=5):
+    def fac(pack):
+        def f(mech, N, fl):
+            c = binding.Controller(binding.Model(mech), N, fl)
+            if f32:
+                c.set_precision(1)
+            if pack:
+                c.set_qps_per_wavefront(2)
+            return c
+        return f
+    ca, wl = W.atlas_workload(fac(False), B, config, seed=77)
+    cb, _ = W.atlas_workload(fac(True), B, config, seed=77)
+    a = (wl.q, wl.v, wl.desired, wl.contact_weight, wl.contact_maxnormalforce)
+    return ca.control_batch(*a), cb.control_batch(*a)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("f32", [False, True])
+def test_two_qps_per_wavefront_gpu(f32):
+    """qpc_set_qps_per_wavefront(2) (csrc/qpc_device.h QPC_PACK2): lanes 0-31 and 32-63 each solve their own QP.  The arithmetic per
+    QP is the same except for the Schur build (dot products instead of a matrix-core tile): fp64 statuses equal and tau to 1e-9 of
+    its scale; fp32 to its rounding.  (Measured slower than one QP per wavefront -- profiles/r04_pack2_ab.json -- and therefore opt-in.)"""
+    ra, rb = _packed_vs_plain(f32)
+    same = ra["status"] == rb["status"]
+    ok = same & (ra["status"] == 0)
+    scale = np.maximum(1.0, np.abs(ra["tau"]).max(axis=1, keepdims=True))
+    err = (np.abs(ra["tau"] - rb["tau"]) / scale).max(axis=1)
+    fl = np.abs(rb["tau"][:, :6]).max()
+    assert fl == 0.0
+    if f32:
+        assert same.mean() > 0.99 and np.median(err[ok]) < 2e-6 and err[ok].max() < 1e-2
+    else:
+        assert same.mean() > 0.999 and err[ok].max() < 1e-9
