@@ -196,7 +196,13 @@ int32_t qpc_add_task(qpc_controller *ctrl, int32_t kind, int32_t base_body, int3
  *                          c0..c5 of the interpolator alpha(theta) = sum c_i theta^i (identity: 0,1,0,0,0,0; a
  *                          fit_quintic warp: its coefficients), [15..18] quaternion y0 (w x y z), [19..22] quaternion
  *                          yf (rotation body -> base at x0 / xf, interpolated.jl:68-83), [23..25] p0, [26..28] pf
- *                          (translation body -> base).  theta = clamp((t - x0) / (xf - x0), 0, 1) (interpolated.jl:29-40). */
+ *                          (translation body -> base).  theta = clamp((t - x0) / (xf - x0), 0, 1) (interpolated.jl:29-40).
+ *                          PIECEWISE trajectories (src/trajectories/piecewise.jl:1-30: `Piecewise(subfunctions, breaks)`, clamped): pass
+ *                          ref[2] = number of pieces np (2 .. QPC_SE3_MAX_PIECES; n_ref = 3).  The record then has
+ *                          QPC_SE3_PW_RECORD(np) = 8 + 23 np doubles: [0..5] unused, [6] t, [7 .. 7+np] the np + 1 breaks, then per
+ *                          piece the 22 doubles [x0 xf | c0..c5 | y0 | yf | p0 | pf] of an Interpolated pair as above, in the piece's
+ *                          LOCAL time (piecewise.jl:25: the piece is evaluated at clamp(t) - breaks[index]); the piece is chosen
+ *                          per QP on the device (index = min(searchsortedlast(breaks, clamp(t)), np)). */
 enum {
   QPC_LAW_INPUT = 0,
   QPC_LAW_CONSTANT = 1,
@@ -206,6 +212,8 @@ enum {
   QPC_LAW_SE3_PD = 5
 };
 #define QPC_SE3_RECORD 29
+#define QPC_SE3_MAX_PIECES 4
+#define QPC_SE3_PW_RECORD(np) (8 + 23 * (np))
 int32_t qpc_task_set_law(qpc_controller *ctrl, int32_t task_id, int32_t law, double kp, double kd,
                          const double *ref, int32_t n_ref);
 /* where task `task_id` lives in one QP's `desired` record (after qpc_finalize): first entry and length

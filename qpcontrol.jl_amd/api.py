@@ -377,10 +377,12 @@ class SE3PDController:
         in the task's slice of `desired` (binding.Controller.task_desired_range) and
         `set_task_law(task, LAW_SE3_PD, k_ang, d_ang, [k_lin, d_lin])`, the tick evaluates this controller per QP on the
         device instead of the host calling it and `setdesired!` before every tick."""
-        from .trajectories import Interpolated, Polynomial, PolyDerivEvaluator, Quat, SE3Trajectory
+        from .trajectories import Interpolated, Piecewise, Polynomial, PolyDerivEvaluator, Quat, SE3Trajectory
         tr = self.trajectory
+        if isinstance(tr, SE3Trajectory) and isinstance(tr.angular, Piecewise) and isinstance(tr.linear, Piecewise):
+            return self._piecewise_record(t)
         if not (isinstance(tr, SE3Trajectory) and isinstance(tr.angular, Interpolated) and isinstance(tr.linear, Interpolated)):
-            raise TypeError("device_record: an SE3Trajectory of two Interpolated trajectories is needed")
+            raise TypeError("device_record: an SE3Trajectory of two Interpolated (or two Piecewise) trajectories is needed")
         a, l = tr.angular, tr.linear
         if (a.x0, a.xf) != (l.x0, l.xf) or not isinstance(a.y0, Quat) or not isinstance(a.yf, Quat):
             raise ValueError("device_record: angular and linear parts must share [x0, xf]; angular end points must be Quat")
@@ -402,6 +404,32 @@ class SE3PDController:
         rec[..., 9:15] = ca
         rec[..., 15:19], rec[..., 19:23] = a.y0.q, a.yf.q
         rec[..., 23:26], rec[..., 26:29] = np.asarray(l.y0, dtype=float), np.asarray(l.yf, dtype=float)
+        return rec
+
+    def n_pieces(self):
+        """pieces of a Piecewise trajectory (the third reference value of `set_task_law(task, LAW_SE3_PD, ...)`), 1 otherwise"""
+        from .trajectories import Piecewise
+        return len(self.trajectory.angular.subfunctions) if isinstance(self.trajectory.angular, Piecewise) else 1
+
+    def _piecewise_record(self, t):
+        """record of a Piecewise SE(3) trajectory (include/qpc.h QPC_SE3_PW_RECORD): [6 unused | t | np + 1 breaks | np x 22]; the
+        piece is chosen per QP on the device (piecewise.jl:14-27)"""
+        from .trajectories import Interpolated, SE3Trajectory
+        tr = self.trajectory
+        a, l = tr.angular, tr.linear
+        npc = len(a.subfunctions)
+        if list(a.breaks) != list(l.breaks) or len(l.subfunctions) != npc or not (2 <= npc <= binding.SE3_MAX_PIECES) or not (a.clamp and l.clamp):
+            raise ValueError("device_record: clamped angular and linear Piecewise parts with the same breaks, 2 .. SE3_MAX_PIECES pieces")
+        t = np.asarray(t, dtype=np.float64)
+        rec = np.zeros(t.shape + (binding.se3_pw_record(npc),))
+        rec[..., 6] = t
+        rec[..., 7:8 + npc] = np.asarray(a.breaks, dtype=float)
+        for i in range(npc):
+            if not (isinstance(a.subfunctions[i], Interpolated) and isinstance(l.subfunctions[i], Interpolated)):
+                raise TypeError("device_record: the pieces must be Interpolated trajectories")
+            one = SE3PDController(self.mechanism, self.base, self.body, SE3Trajectory(tr.body, tr.base, a.subfunctions[i], l.subfunctions[i]),
+                                  self.weight, self.gains).device_record(0.0)
+            rec[..., 8 + npc + 22 * i:8 + npc + 22 * (i + 1)] = one[7:29]
         return rec
 
     def __call__(self, t, x):

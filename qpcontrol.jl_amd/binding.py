@@ -24,6 +24,12 @@ c_int32_p = ctypes.POINTER(ctypes.c_int32)
 
 LAW_INPUT, LAW_CONSTANT, LAW_JOINT_PD, LAW_COM_PD, LAW_ORIENTATION_PD, LAW_SE3_PD = range(6)
 SE3_RECORD = 29  # include/qpc.h QPC_SE3_RECORD
+SE3_MAX_PIECES = 4
+
+
+def se3_pw_record(n_pieces):
+    """include/qpc.h QPC_SE3_PW_RECORD: entries of the record of a Piecewise SE(3) trajectory"""
+    return 8 + 23 * n_pieces
 STATUS_NAMES = ["OPTIMAL", "ALMOST_OPTIMAL", "INFEASIBLE", "DUAL_INFEASIBLE", "ITERATION_LIMIT", "NUMERICAL_ERROR"]
 
 

@@ -158,7 +158,11 @@ int32_t qpc_task_set_law(qpc_controller *c, int32_t task_id, int32_t law, double
         qpc_set_error("QPC_LAW_SE3_PD needs a SpatialAccelerationTask expressed in its target body's frame");
         return QPC_ERR_INVALID_ARGUMENT;
       }
-      need = 2; break; // linear gains (kp, kd); the angular ones are the kp / kd arguments
+      need = n_ref == 3 ? 3 : 2; // linear gains (kp, kd) [+ number of pieces of a Piecewise trajectory]; the angular ones are the kp / kd arguments
+      if (n_ref == 3 && !(ref[2] >= 2.0 && ref[2] <= (double)QPC_SE3_MAX_PIECES && ref[2] == (double)(int)ref[2])) {
+        qpc_set_error("QPC_LAW_SE3_PD: the number of pieces (ref[2]) must be an integer in 2 .. QPC_SE3_MAX_PIECES"); return QPC_ERR_INVALID_ARGUMENT;
+      }
+      break;
     default: qpc_set_error("qpc_task_set_law: unknown law"); return QPC_ERR_INVALID_ARGUMENT;
   }
   if (n_ref != need) { qpc_set_error("qpc_task_set_law: wrong reference length for this law"); return QPC_ERR_INVALID_ARGUMENT; }
@@ -172,7 +176,7 @@ int32_t qpc_task_desired_range(const qpc_controller *c, int32_t task_id, int32_t
   if (!c->finalized) { qpc_set_error("controller not finalized"); return QPC_ERR_NOT_FINALIZED; }
   const QpcTask &t = c->tasks[task_id];
   if (offset) *offset = t.des_off;
-  if (length) *length = t.law == QPC_LAW_SE3_PD ? QPC_SE3_RECORD : t.dim;
+  if (length) *length = qpc_task_desired_len(t);
   return QPC_OK;
 }
 

@@ -49,7 +49,7 @@ int qpc_compile_program(qpc_controller *c) {
   const int nb = m->nb, nv = m->nv, N = c->N;
   { // slices of the per-QP `desired` record: the task dimension, or a trajectory record for a task with the SE3 PD law
     int off = 0;
-    for (auto &t : c->tasks) { t.des_off = off; off += (t.law == QPC_LAW_SE3_PD) ? QPC_SE3_RECORD : t.dim; }
+    for (auto &t : c->tasks) { t.des_off = off; off += qpc_task_desired_len(t); }
     c->n_desired = off;
   }
   D.nb = nb; D.nq = m->nq; D.nv = nv; D.N = N; D.nc = (int)c->contacts.size();
@@ -453,7 +453,7 @@ int qpc_compile_program(qpc_controller *c) {
             } else D.n_des_late++;
             break;
           case QPC_LAW_SE3_PD: // entry a: body / base / component packed, offset of the task's record; per-entry gains
-            law_i[3 * i + 1] = (t.target + 1) | ((t.base + 1) << 8) | (a << 16);
+            law_i[3 * i + 1] = (t.target + 1) | ((t.base + 1) << 8) | (a << 16) | ((t.ref.size() >= 3 ? (int)t.ref[2] : 1) << 20); // (bits 20..: pieces)
             law_i[3 * i + 2] = t.des_off;
             if (a >= 3) { law_d[3 * i] = t.ref[0]; law_d[3 * i + 1] = t.ref[1]; }
             D.n_des_late++;
@@ -463,7 +463,7 @@ int qpc_compile_program(qpc_controller *c) {
     D.law_mask = 0;
     for (size_t i = 0; i < (size_t)c->n_desired; i++) D.law_mask |= 1 << law_i[3 * i];
     for (auto &t : c->tasks) // the rest of a trajectory record are plain per-QP inputs
-      if (t.law == QPC_LAW_SE3_PD) D.n_des_inputs += QPC_SE3_RECORD - t.dim;
+      if (t.law == QPC_LAW_SE3_PD) D.n_des_inputs += qpc_task_desired_len(t) - t.dim;
     B.ibegin(IT_LAW); B.it.insert(B.it.end(), law_i.begin(), law_i.end());
     B.it.push_back(0);
     law_tab.swap(law_d);

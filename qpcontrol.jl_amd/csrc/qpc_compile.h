@@ -60,6 +60,12 @@ struct qpc_controller {
   long long pipe_chunk = 0, pipe_inline = -1;
 };
 
+// entries of a task's slice of the per-QP `desired` record: its dimension, or the trajectory record of a device-side SE(3) law
+inline int qpc_task_desired_len(const QpcTask &t) {
+  if (t.law != QPC_LAW_SE3_PD) return t.dim;
+  const int np = t.ref.size() >= 3 ? (int)t.ref[2] : 1;
+  return np >= 2 ? QPC_SE3_PW_RECORD(np) : QPC_SE3_RECORD;
+}
 void qpc_set_error(const std::string &msg);
 int qpc_task_dim(const qpc_model *m, int kind, int joint);
 // freeze the controller into prog + layout; returns QPC_OK or an error code

@@ -1271,10 +1271,12 @@ QPC_FN real desired_early(const QpcDims &D, const int *IT, qpc_dtab DT, const Ti
 // out[6] = Tdref + pd(gains, H, Href, T, Tref): desired spatial acceleration of body w.r.t. base in the body frame.
 // The SE(3) PD law itself lives in the un-vendored RigidBodyDynamics.PDControl; restated as in api.SE3PDController
 // (real-geodesic law: e = inv(Href) H, edot = T - Ad(inv(e)) Tref).
+//   t = time in the segment's own clock, rec = the segment: rec[1] x0, rec[2] xf, rec[3..8] c, rec[9..16] quaternions, rec[17..22] p
+//   (rec[0] is not read: for a single-segment record it is the slot of t, for a piece of a Piecewise record the word before the piece)
 template <class PR>
-QPC_FN void se3_pd_law(PR rec, const real *Hb, const real *Ha, const real *Tb, const real *Ta, real ka, real da,
+QPC_FN void se3_pd_law(real t, PR rec, const real *Hb, const real *Ha, const real *Tb, const real *Ta, real ka, real da,
                        real kl, real dl, real *out) {
-  const real t = rec[0], x0 = rec[1], xf = rec[2];
+  const real x0 = rec[1], xf = rec[2];
   // theta = clamp((t - x0) / (xf - x0), 0, 1) and its derivative (interpolated.jl:29-40)
   const real dx = xf - x0;
   real th = (t - x0) / dx, dth = 1.0 / dx;
@@ -1369,12 +1371,22 @@ template <class P> QPC_FN void desired_late(const QpcDims &D, const int *IT, qpc
       for (int r = 0; r < 3; r++) wb += H[3 * r + a] * sm[D.lds[L_T] + 6 * body + r];
       sm[D.lds[L_DES] + i] = -lw[0] * rv[a] - lw[1] * wb;
     } else if (((D.law_mask >> QPC_LAW_SE3_PD) & 1) && li[0] == QPC_LAW_SE3_PD) { // SE3PDController on the device (se3pdcontroller.jl:13-18), lane = component
-      const int body = (li[1] & 255) - 1, base = ((li[1] >> 8) & 255) - 1, a = (li[1] >> 16) & 7, rec0 = li[2] + 6;
+      const int body = (li[1] & 255) - 1, base = ((li[1] >> 8) & 255) - 1, a = (li[1] >> 16) & 7, np = (li[1] >> 20) & 15, rec0 = li[2] + 6;
       real Hb[12], Ha[12], Tb[6], Ta[6], out[6];
       ldH(sm, D, body, Hb); ldH(sm, D, base, Ha);
       ld6(sm, D.lds[L_T], body, Tb); ld6(sm, D.lds[L_T], base, Ta);
       qpc_dtab lwa = DT + D.dt[DT_LAW] + 3 * li[2], lwl = lwa + 9; // gains of entries 0 (angular) and 3 (linear)
-      se3_pd_law(sm + D.lds[L_DES] + rec0, Hb, Ha, Tb, Ta, lwa[0], lwa[1], lwl[0], lwl[1], out);
+      if (np <= 1) se3_pd_law((real)sm[D.lds[L_DES] + rec0], sm + D.lds[L_DES] + rec0, Hb, Ha, Tb, Ta, lwa[0], lwa[1], lwl[0], lwl[1], out);
+      else { // Piecewise (piecewise.jl:14-27): clamp to [first break, last break], the last piece whose break is <= t, its local clock
+        const int br = D.lds[L_DES] + rec0 + 1; // breaks[0 .. np]
+        real tc = sm[D.lds[L_DES] + rec0];
+        const real b0 = sm[br], bn = sm[br + np];
+        tc = tc < b0 ? b0 : (tc > bn ? bn : tc);
+        int idx = 0;
+        real bi = b0;
+        for (int k = 1; k < np; k++) { const real bk = sm[br + k]; if (tc >= bk) { idx = k; bi = bk; } }
+        se3_pd_law(tc - bi, sm + br + np + 22 * idx, Hb, Ha, Tb, Ta, lwa[0], lwa[1], lwl[0], lwl[1], out);
+      }
       sm[D.lds[L_DES] + i] = out[a];
     }
   }

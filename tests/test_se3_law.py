@@ -128,3 +128,85 @@ def test_se3_pd_law_gpu():
 @pytest.mark.gpu
 def test_se3_and_orientation_laws_in_one_controller_gpu():
     _run(lambda mech, N, fl: binding.Controller(binding.Model(mech), N, fl), B=10, pelvis_law=(20.0, 9.0))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Piecewise trajectories on the device (/root/reference/src/trajectories/piecewise.jl:1-30): the record carries the breaks
+# and every piece; the piece is chosen per QP on the device.
+def _run_piecewise(factory, B=12, seed=8, n_pieces=3):
+    rng = np.random.default_rng(seed)
+    gains = api.SE3PDGains(api.PDGains(100.0, 20.0), api.PDGains(1000.0, 200.0))
+    mech = M.atlas()
+    fl = mech.findbody("pelvis")
+    base, body = mech.findbody("pelvis"), mech.findbody("r_hand")
+
+    def build(with_law):
+        c = factory(mech, 4, fl)
+        for cp in mech.contact_points:
+            c.add_contact(cp.body, cp.position, cp.normal, cp.mu)
+        for j in range(mech.nbodies):
+            c.regularize(j, 0.05)
+        th = c.add_task(SPATIAL, base=base, target=body, frame=M.FRAME_DEFAULT, wkind=SCALAR, weight=[10.0])
+        tf = c.add_task(SPATIAL, base=M.WORLD, target=mech.findbody("l_foot"), frame=M.FRAME_DEFAULT, wkind=HARD)
+        if with_law:
+            c.set_task_law(th, binding.LAW_SE3_PD, gains.angular.k, gains.angular.d, [gains.linear.k, gains.linear.d, float(n_pieces)])
+        c.finalize()
+        return c, th, tf
+    claw, th, tf = build(True)
+    cref, th2, tf2 = build(False)
+    assert claw.task_desired_range(th)[1] == binding.se3_pw_record(n_pieces) and cref.task_desired_range(th2)[1] == 6
+    # a trajectory of n_pieces Interpolated pieces through random way points; every piece on its own local clock [0, duration]
+    breaks = np.concatenate([[0.3], 0.3 + np.cumsum(rng.uniform(0.3, 0.8, size=n_pieces))])
+    quats = [T.Quat.identity()] + [T.Quat.from_angle_axis(rng.uniform(0.2, 1.2), rng.normal(size=3)) for _ in range(n_pieces)]
+    pts = [rng.normal(size=3) * 0.3 for _ in range(n_pieces + 1)]
+    f = T.fit_quintic(x0=0.0, xf=1.0, y0=0.0, yd0=0.0, ydd0=0.0, yf=1.0, ydf=0.0, yddf=0.0)
+    angs = [T.Interpolated(0.0, breaks[i + 1] - breaks[i], quats[i], quats[i + 1], f if i % 2 == 0 else None, min_num_derivs=2) for i in range(n_pieces)]
+    lins = [T.Interpolated(0.0, breaks[i + 1] - breaks[i], pts[i], pts[i + 1], f if i % 2 == 0 else None, min_num_derivs=2) for i in range(n_pieces)]
+    traj = T.SE3Trajectory(body, base, T.Piecewise(angs, breaks), T.Piecewise(lins, breaks))
+    ctl = api.SE3PDController(mech, base, body, traj, np.eye(6), gains)
+    assert ctl.n_pieces() == n_pieces
+    qs, vs = zip(*(M.rand_state(mech, rng, 0.3) for _ in range(B)))
+    q, v = np.array(qs), np.array(vs)
+    # times before the first break, on every break, inside every piece, after the last break
+    times = np.concatenate([[breaks[0] - 0.4], breaks, 0.5 * (breaks[:-1] + breaks[1:]), [breaks[-1] + 1.0]])
+    times = np.resize(times, B)
+    rec = ctl.device_record(times)
+    ol, orf = claw.task_desired_range(th)[0], cref.task_desired_range(th2)[0]
+    des_law, des_ref = np.zeros((B, claw.layout.n_desired)), np.zeros((B, cref.layout.n_desired))
+    foot = rng.normal(size=(B, 6)) * 0.1
+    for b in range(B):
+        des_law[b, ol:ol + rec.shape[1]] = rec[b]
+        des_ref[b, orf:orf + 6] = ctl(times[b], (q[b:b + 1], v[b:b + 1]))[0]
+    des_law[:, claw.task_desired_range(tf)[0]:claw.task_desired_range(tf)[0] + 6] = foot
+    des_ref[:, cref.task_desired_range(tf2)[0]:cref.task_desired_range(tf2)[0] + 6] = foot
+    nc = len(mech.contact_points)
+    cw, cm = np.full((B, nc), 1e-3), np.full((B, nc), 1e6)
+    rl, rr = claw.control_batch(q, v, des_law, cw, cm), cref.control_batch(q, v, des_ref, cw, cm)
+    assert np.array_equal(rl["status"], rr["status"]) and (rr["status"] == 0).all()
+    np.testing.assert_allclose(rl["tau"], rr["tau"], atol=1e-9 * max(1.0, np.abs(rr["tau"]).max()), rtol=0)
+    # the pieces differ: the same state at two times in different pieces gives different torques
+    assert np.abs(rr["tau"]).max() > 1.0
+
+
+@pytest.mark.parametrize("n_pieces", [2, 4])
+def test_se3_piecewise_law_emulated(n_pieces):
+    emu.build()
+    emu.race_report()
+    _run_piecewise(emu.factory, n_pieces=n_pieces)
+    races, uninit, outside, first = emu.race_report()
+    assert (races, uninit, outside) == (0, 0, 0), first
+
+
+def test_se3_piecewise_law_validation():
+    emu.build()
+    mech = M.atlas()
+    c = emu.factory(mech, 4, mech.findbody("pelvis"))
+    t = c.add_task(SPATIAL, base=mech.findbody("pelvis"), target=mech.findbody("r_hand"), frame=M.FRAME_DEFAULT, wkind=HARD)
+    for bad in (1.0, 5.0, 2.5):
+        with pytest.raises(binding.QpcError, match="number of pieces"):
+            c.set_task_law(t, binding.LAW_SE3_PD, 1.0, 1.0, [1.0, 1.0, bad])
+
+
+@pytest.mark.gpu
+def test_se3_piecewise_law_gpu():
+    _run_piecewise(lambda mech, N, fl: binding.Controller(binding.Model(mech), N, fl), B=12, n_pieces=3)
