@@ -168,6 +168,22 @@ addtask!(c::BatchedMomentumBasedController, task::AbstractMotionTask, ::Val{:mat
 regularize!(c::BatchedMomentumBasedController, joint::Integer, weight::Real) =
     check(ccall((:qpc_regularize, libqpc), Int32, (Ptr{Cvoid}, Int32, Float64), c.handle, joint, weight), "qpc_regularize")
 
+# regularize!(c, joint, weight::Parameter) (momentum.jl:128-131 takes any `weight`): the weight becomes a per-QP input; returns the
+# (0-based) row of `task_weights` that holds it
+function regularize!(c::BatchedMomentumBasedController, joint::Integer, ::Val{:per_qp})
+    idx = Ref{Int32}(-1)
+    check(ccall((:qpc_regularize_per_qp, libqpc), Int32, (Ptr{Cvoid}, Int32, Ref{Int32}), c.handle, joint, idx), "qpc_regularize_per_qp")
+    Int(idx[])
+end
+
+# arithmetic of the tick kernel (before finalize!): :f64 (default, tau within 1e-8 of the CPU OSQP path) or :f32 (BASELINE config 5's
+# variant: the same device source in single precision, tau to ~1e-6 median / 1e-4 at the 99.9th percentile; include/qpc.h)
+set_precision!(c::BatchedMomentumBasedController, p::Symbol) =
+    check(ccall((:qpc_set_precision, libqpc), Int32, (Ptr{Cvoid}, Int32), c.handle, p === :f32 ? 1 : 0), "qpc_set_precision")
+# two QPs per wavefront (opt-in, measured slower on MI355X: DESIGN.md 7c)
+set_qps_per_wavefront!(c::BatchedMomentumBasedController, n::Integer) =
+    check(ccall((:qpc_set_qps_per_wavefront, libqpc), Int32, (Ptr{Cvoid}, Int32), c.handle, n), "qpc_set_qps_per_wavefront")
+
 # addcontact!(controller, body, position, normal, mu) (momentum.jl:142-148); weight[] and
 # maxnormalforce[] (contacts.jl:35-36) are per-QP rows of the tick inputs; disable!(point)
 # (contacts.jl:72) == maxnormalforce = 0 for that QP.
@@ -180,6 +196,10 @@ const LAW_COM_PD = Int32(3); const LAW_ORIENTATION_PD = Int32(4)
 # ref = [kp_linear, kd_linear]; the task's rows of `desired` become a trajectory record of SE3_RECORD entries
 # (include/qpc.h QPC_LAW_SE3_PD; `desired_range(controller, task_id)` tells which rows)
 const LAW_SE3_PD = Int32(5); const SE3_RECORD = 29
+# ... of a Piecewise trajectory (src/trajectories/piecewise.jl) with np pieces: ref = [kp_linear, kd_linear, np], record of
+# se3_pw_record(np) entries = [6 unused | t | np + 1 breaks | np x (x0 xf c0..c5 y0 yf p0 pf)], the piece chosen per QP on the device
+const SE3_MAX_PIECES = 4
+se3_pw_record(np::Integer) = 8 + 23 * np
 function setlaw!(c::BatchedMomentumBasedController, task_id::Integer, law::Int32; kp::Real = 0.0, kd::Real = 0.0,
                  ref::Vector{Float64} = Float64[])
     check(ccall((:qpc_task_set_law, libqpc), Int32, (Ptr{Cvoid}, Int32, Int32, Float64, Float64, Ptr{Float64}, Int32),
@@ -291,6 +311,12 @@ function control_async!(c::BatchedMomentumBasedController, τ::Matrix{Float64}, 
     nothing
 end
 wait!(c::BatchedMomentumBasedController) = check(ccall((:qpc_wait, libqpc), Int32, (Ptr{Cvoid},), c.handle), "qpc_wait")
+# the error of an async batch nobody waited for (dropped by the next call, which reports its own batch): (code, text), cleared on read
+function last_async_error(c::BatchedMomentumBasedController)
+    buf = Vector{UInt8}(undef, 512)
+    rc = ccall((:qpc_last_async_error, libqpc), Int32, (Ptr{Cvoid}, Ptr{UInt8}, Int32), c.handle, buf, length(buf))
+    (rc, unsafe_string(pointer(buf)))
+end
 
 # ---------------------------------------------------------------------------------------------
 # f-2: closed loop on the device.  The reference's acceptance run (notebooks/Standing controller.ipynb
