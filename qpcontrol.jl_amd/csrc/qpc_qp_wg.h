@@ -52,13 +52,21 @@ __host__ __device__
 #endif
 inline int qp_wg_lds_doubles(int n, int m) {
   (void)n; (void)m;
-  return QPC_WG_KMAX * (QPC_WG_KMAX + 1) / 2 + QPC_WG_NNZ + QPC_WG_NNZ / 2 + 4 * QPC_WG_DIM + 12 * QPC_WG_DIM + 64;
+  return QPC_WG_KMAX * (QPC_WG_KMAX + 1) / 2 + QPC_WG_NNZ + QPC_WG_NNZ / 2 + 4 * QPC_WG_DIM + 12 * QPC_WG_DIM + 64 + 8;
 }
 
 struct QpWg {
   int n, m;
   const double *P, *q, *A, *l, *u;
   double *G;      // m x m in global memory (the workspace of qp_solve_dense keeps its G at the same place)
+  // block elimination of the equality rows (they are in EVERY working set): factored once, the working sets only refactor their
+  // active inequality rows.  E = equality rows (ne, first in every compaction), I = the others (mi).
+  bool blk;
+  int ne, mi;
+  double *L21;    // mi x ne in global memory: row i = L11^-1 G_E,i  (the part of an inequality row's factor row that never changes)
+  double *Call;   // mi x mi in global memory: Schur complement G_II - L21 L21' (what a working set factors a sub-block of)
+  double *zE, *a0; // LDS: L11^-1 (g0_E - b_E);  A x at the equality-constrained minimiser for the inequality rows, g0_I - L21 zE
+  int *ipos, *irows; // row -> position among the inequality rows (-1: equality row); position -> row
   // LDS
   double *S;      // packed lower triangle of the working-set matrix / its Cholesky factor
   double *val;    // nonzeros of A, row by row
@@ -69,37 +77,67 @@ struct QpWg {
   double *sc;     // scalars
 };
 
-enum { WGS_FLAG = 0, WGS_HMAX, WGS_EPS, WGS_BSCALE, WGS_K, WGS_CHANGES, WGS_YSC, WGS_XSC, WGS_RP, WGS_RS, WGS_BIG, WGS_DBIG, WGS_T, WGS_P, WGS_VIOL, WGS_SG,
+enum { WGS_FLAG = 0, WGS_HMAX, WGS_EPS, WGS_BSCALE, WGS_K, WGS_CHANGES, WGS_YSC, WGS_XSC, WGS_RP, WGS_RS, WGS_BIG, WGS_DBIG, WGS_T, WGS_P, WGS_VIOL, WGS_SG, WGS_MI,
        WGS_COUNT };
 
 QPC_FN int wg_sidx(int i, int j) { return i * (i + 1) / 2 + j; } // packed lower triangle, i >= j
 
-// Factor the working set in W.wsf and solve one system with it: compaction -> idx, S = G_WW, Cholesky with the right-hand side riding
-// along, back-substitution -> out (compact).  Right-hand side: pcol < 0: g0_W - b_W (the EQP of the working set; b -> W.bw);
-// pcol >= 0: column pcol of G (the Goldfarb-Idnani direction of row pcol).  Returns the number of working rows, or -1 beyond QPC_WG_KMAX.
-QPC_FN int wg_factor(QpWg &W, double tau, int pcol, double *out) {
+// Factor the working set in W.wsf and solve one system with it: compaction -> idx (equality rows first), S = G_WW, Cholesky with the
+// right-hand side riding along, back-substitution -> out (compact).  Right-hand side: pcol < 0: g0_W - b_W (the EQP of the working
+// set; b -> W.bw); pcol >= 0: column pcol of G (the Goldfarb-Idnani direction of row pcol).  Returns the number of working rows, or -1
+// beyond QPC_WG_KMAX.
+// Block mode (W.blk): rows 0 .. ne-1 of S hold L11 for good; a working inequality row gets its first ne factor entries from L21 and
+// its remaining ones from the Schur complement Call, so only the columns ne .. k-1 are eliminated.  full_back = false stops the
+// back-substitution at column ne: out[ne ..] are the multipliers of the inequality rows, out[0 .. ne-1] still L11^-1 of the right-hand
+// side (wg_finish_back completes them).
+// zsave: the right-hand side after the forward part (L^-1 rhs), before the back-substitution.
+QPC_FN int wg_factor(QpWg &W, double tau, int pcol, double *out, bool full_back = true, double *zsave = nullptr) {
   const int m = W.m;
   QPC_WG_T0 {
     int k = 0;
-    for (int i = 0; i < m; i++) if (W.wsf[i] != 0.0) { if (k < QPC_WG_KMAX) W.idx[k] = i; k++; }
+    for (int i = 0; i < m; i++) if (W.wsf[i] == 2.0) { if (k < QPC_WG_KMAX) W.idx[k] = i; k++; }
+    for (int i = 0; i < m; i++) if (W.wsf[i] != 0.0 && W.wsf[i] != 2.0) { if (k < QPC_WG_KMAX) W.idx[k] = i; k++; }
     W.sc[WGS_K] = (double)k;
   }
   QPC_WG_SYNC
   const int k = (int)W.sc[WGS_K];
   if (k > QPC_WG_KMAX) return -1;
-  QPC_WG_FOR(a, k) {
-    const int ia = W.idx[a];
-    for (int b = 0; b <= a; b++) W.S[wg_sidx(a, b)] = W.G[(long long)ia * m + W.idx[b]];
-    if (pcol < 0) {
-      const double w = W.wsf[ia];
-      const double bnd = (w == 1.0) ? W.u[ia] : W.l[ia]; // lower-active and equality rows sit at l
-      W.bw[a] = bnd;
-      out[a] = W.g0[ia] - bnd;
-    } else out[a] = W.G[(long long)ia * m + pcol];
-    W.sdiag[a] = W.G[(long long)ia * m + ia];
+  const int j0 = W.blk ? W.ne : 0; // first column to eliminate
+  if (W.blk) {
+    const int ne = W.ne, pp = pcol >= 0 ? W.ipos[pcol] : -1;
+    QPC_WG_FOR(e, (k - ne) * ne) { // the fixed part of the working inequality rows
+      const int a = ne + e / ne, b = e % ne;
+      W.S[wg_sidx(a, b)] = W.L21[(long long)W.ipos[W.idx[a]] * ne + b];
+    }
+    QPC_WG_FOR(a0_, k - ne) {
+      const int a = ne + a0_, ia = W.idx[a], pa = W.ipos[ia];
+      for (int b = ne; b <= a; b++) W.S[wg_sidx(a, b)] = W.Call[(long long)pa * W.mi + W.ipos[W.idx[b]]];
+      if (pcol < 0) {
+        const double bnd = (W.wsf[ia] == 1.0) ? W.u[ia] : W.l[ia];
+        W.bw[a] = bnd;
+        out[a] = W.a0[pa] - bnd;
+      } else out[a] = W.Call[(long long)pa * W.mi + pp];
+      W.sdiag[a] = W.G[(long long)ia * m + ia];
+    }
+    QPC_WG_FOR(b, ne) {
+      out[b] = pcol < 0 ? W.zE[b] : W.L21[(long long)pp * ne + b];
+      if (pcol < 0) W.bw[b] = W.l[W.idx[b]];
+    }
+  } else {
+    QPC_WG_FOR(a, k) {
+      const int ia = W.idx[a];
+      for (int b = 0; b <= a; b++) W.S[wg_sidx(a, b)] = W.G[(long long)ia * m + W.idx[b]];
+      if (pcol < 0) {
+        const double w = W.wsf[ia];
+        const double bnd = (w == 1.0) ? W.u[ia] : W.l[ia]; // lower-active and equality rows sit at l
+        W.bw[a] = bnd;
+        out[a] = W.g0[ia] - bnd;
+      } else out[a] = W.G[(long long)ia * m + pcol];
+      W.sdiag[a] = W.G[(long long)ia * m + ia];
+    }
   }
   QPC_WG_SYNC
-  for (int j = 0; j < k; j++) { // right-looking Cholesky, infinite-pivot rule; yw <- L^-1 yw on the way
+  for (int j = j0; j < k; j++) { // right-looking Cholesky, infinite-pivot rule; out <- L^-1 out on the way
     QPC_WG_T0 {
       const double d = W.S[wg_sidx(j, j)], ref = W.sdiag[j];
       const bool ok = d > tau * (ref > 1e-300 ? ref : 1e-300);
@@ -124,7 +162,11 @@ QPC_FN int wg_factor(QpWg &W, double tau, int pcol, double *out) {
     }
     QPC_WG_SYNC
   }
-  for (int j = k - 1; j >= 0; j--) { // L' y = z
+  if (zsave) {
+    QPC_WG_FOR(a, k) { zsave[a] = out[a]; }
+    QPC_WG_SYNC
+  }
+  for (int j = k - 1; j >= (full_back ? 0 : j0); j--) { // L' y = z
     QPC_WG_T0 { out[j] = out[j] * W.sinvd[j]; }
     QPC_WG_SYNC
     const double yj = out[j];
@@ -133,15 +175,70 @@ QPC_FN int wg_factor(QpWg &W, double tau, int pcol, double *out) {
   }
   return k;
 }
+// block mode: the equality part of a back-substitution that wg_factor(full_back = false) left at column ne
+QPC_FN void wg_finish_back(QpWg &W, double *out) {
+  if (!W.blk) return;
+  for (int j = W.ne - 1; j >= 0; j--) {
+    QPC_WG_T0 { out[j] = out[j] * W.sinvd[j]; }
+    QPC_WG_SYNC
+    const double yj = out[j];
+    QPC_WG_FOR(i, j) { out[i] -= W.S[wg_sidx(j, i)] * yj; }
+    QPC_WG_SYNC
+  }
+}
+// One-time set-up of the block mode, right after the equality-only working set has been factored (S rows 0 .. ne-1 = L11, W.zE =
+// L11^-1 (g0_E - b_E): the zsave of that factorization).  Every inequality row: its factor row against L11 by forward substitution -- one thread
+// per row, nothing shared but read-only L11 -- in chunks that fit behind L11 in the LDS buffer; then the Schur complement.
+QPC_FN void wg_block_setup(QpWg &W) {
+  const int m = W.m, ne = W.ne, mi = W.mi;
+  const int chunk = QPC_WG_KMAX - ne;
+  for (int c0 = 0; c0 < mi; c0 += chunk) {
+    const int cnt = mi - c0 < chunk ? mi - c0 : chunk;
+    QPC_WG_FOR(a, cnt) {
+      const int row = ne + a, ir = W.irows[c0 + a];
+      double acc0 = W.g0[ir];
+      for (int j = 0; j < ne; j++) {
+        double t = W.G[(long long)ir * m + W.idx[j]];
+        for (int c = 0; c < j; c++) t -= W.S[wg_sidx(row, c)] * W.S[wg_sidx(j, c)];
+        t *= W.sinvd[j];
+        W.S[wg_sidx(row, j)] = t;
+        acc0 -= t * W.zE[j];
+      }
+      for (int j = 0; j < ne; j++) W.L21[(long long)(c0 + a) * ne + j] = W.S[wg_sidx(row, j)];
+      W.a0[c0 + a] = acc0;
+    }
+    QPC_WG_SYNC
+  }
+  QPC_WG_FOR(e, mi * mi) {
+    const int i = e / mi, c = e % mi;
+    if (c <= i) {
+      double t = W.G[(long long)W.irows[i] * m + W.irows[c]];
+      for (int j = 0; j < ne; j++) t -= W.L21[(long long)i * ne + j] * W.L21[(long long)c * ne + j];
+      W.Call[(long long)i * mi + c] = t;
+      W.Call[(long long)c * mi + i] = t;
+    }
+  }
+  QPC_WG_SYNC
+}
 // EQP of the working set: multipliers -> yw (compact), ax = A x for every row
-QPC_FN int wg_solve_ws(QpWg &W, double tau) {
+QPC_FN int wg_solve_ws(QpWg &W, double tau, double *zsave = nullptr) {
   const int m = W.m;
-  const int k = wg_factor(W, tau, -1, W.yw);
+  const int k = wg_factor(W, tau, -1, W.yw, !W.blk, zsave);
   if (k < 0) return -1;
-  QPC_WG_FOR(i, m) {
-    double t = W.g0[i];
-    for (int a = 0; a < k; a++) t -= W.G[(long long)i * m + W.idx[a]] * W.yw[a];
-    W.ax[i] = t;
+  if (W.blk) { // in the space of the inequality rows: A x = a0 - Call[:, W] y_W ; the equality rows hold exactly
+    QPC_WG_FOR(i, m) {
+      const int pi = W.ipos[i];
+      double t = pi < 0 ? W.l[i] : W.a0[pi];
+      if (pi >= 0)
+        for (int a = W.ne; a < k; a++) t -= W.Call[(long long)pi * W.mi + W.ipos[W.idx[a]]] * W.yw[a];
+      W.ax[i] = t;
+    }
+  } else {
+    QPC_WG_FOR(i, m) {
+      double t = W.g0[i];
+      for (int a = 0; a < k; a++) t -= W.G[(long long)i * m + W.idx[a]] * W.yw[a];
+      W.ax[i] = t;
+    }
   }
   QPC_WG_SYNC
   return k;
@@ -167,11 +264,15 @@ QPC_FN void wg_factor_solve(QpWg &W, double *z, int k) {
 
 // returns the status (QPC_STATUS_*), or QPC_WG_FALLBACK when the problem is outside what this kernel handles
 QPC_FN int qp_solve_wg(int n, int m, const double *P, const double *q, const double *A, const double *l, const double *u,
-                       const qpc_settings &st, double *Gglobal, double *lds, double *x, double *y, int32_t *iters_out) {
+                       const qpc_settings &st, double *ws, double *lds, double *x, double *y, int32_t *iters_out) {
   const double INF = 1e19;
   if (n > QPC_WG_DIM || m > QPC_WG_DIM || n < 1) return QPC_WG_FALLBACK;
   QpWg W;
-  W.n = n; W.m = m; W.P = P; W.q = q; W.A = A; W.l = l; W.u = u; W.G = Gglobal;
+  // global workspace = the one of qp_solve_dense (qp_dense_workspace_doubles): [H n x n | Y n x m | G m x m | S m x m | ...]; G sits
+  // where that kernel keeps it, the block mode's L21 (mi x ne) goes where its Y was, Call (mi x mi) where its S was
+  W.n = n; W.m = m; W.P = P; W.q = q; W.A = A; W.l = l; W.u = u; W.G = ws + (long long)n * n + (long long)n * m;
+  W.L21 = ws + (long long)n * n; W.Call = W.G + (long long)m * m;
+  W.blk = false; W.ne = 0; W.mi = m;
   double *p = lds;
   W.S = p; p += QPC_WG_KMAX * (QPC_WG_KMAX + 1) / 2;
   W.val = p; p += QPC_WG_NNZ;
@@ -179,8 +280,9 @@ QPC_FN int qp_solve_wg(int n, int m, const double *P, const double *q, const dou
   W.hinv = p; p += QPC_WG_DIM; W.xu = p; p += QPC_WG_DIM; W.x = p; p += QPC_WG_DIM; W.r1 = p; p += QPC_WG_DIM;
   W.g0 = p; p += QPC_WG_DIM; W.yw = p; p += QPC_WG_DIM; W.bw = p; p += QPC_WG_DIM; W.ax = p; p += QPC_WG_DIM;
   W.wsf = p; p += QPC_WG_DIM; W.sinvd = p; p += QPC_WG_DIM; W.tm = p; p += QPC_WG_DIM; W.sdiag = p; p += QPC_WG_DIM;
-  W.idx = (int *)p; p += QPC_WG_DIM; // (two ints per double: idx and rowptr share two blocks)
-  W.rowptr = (int *)p; p += QPC_WG_DIM;
+  W.idx = (int *)p; W.ipos = W.idx + QPC_WG_DIM; p += QPC_WG_DIM;         // (two ints per double)
+  W.rowptr = (int *)p; W.irows = W.rowptr + QPC_WG_DIM + 1; p += QPC_WG_DIM + 1;
+  W.zE = p; p += QPC_WG_DIM; W.a0 = p; p += QPC_WG_DIM;
   W.sc = p; p += 64;
   // ---- structure: diagonal P, nonzeros of A per row
   QPC_WG_T0 { for (int i = 0; i < WGS_COUNT; i++) W.sc[i] = 0.0; }
@@ -249,8 +351,25 @@ QPC_FN int qp_solve_wg(int n, int m, const double *P, const double *q, const dou
   const double bscale = W.sc[WGS_BSCALE];
   int status = QPC_STATUS_OPTIMAL, iters = 0;
   const int max_it = st.max_active_set_iters > 0 ? st.max_active_set_iters : 200;
-  int nw = wg_solve_ws(W, st.eps_dual_reg);
+  int nw = wg_solve_ws(W, st.eps_dual_reg, W.zE); // the equality-only working set (block mode is not on yet); zE = L11^-1 (g0_E - b_E)
   if (nw < 0) return QPC_WG_FALLBACK;
+  // block mode: worth it when there are equality rows, and possible when L11 leaves room for a chunk of inequality rows behind it
+  QPC_WG_T0 {
+    int mi = 0;
+    for (int i = 0; i < m; i++) { if (W.wsf[i] == 2.0) W.ipos[i] = -1; else { W.ipos[i] = mi; W.irows[mi] = i; mi++; } }
+    W.sc[WGS_MI] = (double)mi;
+  }
+  QPC_WG_SYNC
+  {
+    const int mi = (int)W.sc[WGS_MI], ne = m - mi;
+    if (ne >= 8 && ne + 16 <= QPC_WG_KMAX && (long long)mi * ne <= (long long)n * m && mi >= 1) {
+      W.ne = ne; W.mi = mi;
+      wg_block_setup(W);
+      W.blk = true;
+      nw = wg_solve_ws(W, st.eps_dual_reg);
+      if (nw < 0) return QPC_WG_FALLBACK;
+    }
+  }
   bool converged = false;
   const int max_pdas = 12;
   // ---- primal-dual multi-change sweeps (qpc_qp_dense.h phase A)
@@ -314,12 +433,19 @@ QPC_FN int qp_solve_wg(int n, int m, const double *P, const double *q, const dou
       const double sg = W.sc[WGS_SG];
       bool infeasible = false, bail = false;
       for (int inner = 0; inner <= m; inner++) {
-        const int k = wg_factor(W, st.eps_dual_reg, pr, W.tm); // r = (G_WW)^-1 G_Wp : a_p in terms of the working rows (H^-1 metric)
+        const int k = wg_factor(W, st.eps_dual_reg, pr, W.tm, !W.blk); // r = (G_WW)^-1 G_Wp : a_p in terms of the working rows (H^-1 metric)
         if (k < 0) { bail = true; break; }
         QPC_WG_T0 {
           double viol = W.sc[WGS_VIOL];
-          double d = W.G[(long long)pr * m + pr];
-          for (int a = 0; a < k; a++) d -= W.G[(long long)pr * m + W.idx[a]] * W.tm[a];
+          double d;
+          if (W.blk) { // Schur-complement identity: the same number from the inequality block alone
+            const int pp = W.ipos[pr];
+            d = W.Call[(long long)pp * W.mi + pp];
+            for (int a = W.ne; a < k; a++) d -= W.Call[(long long)pp * W.mi + W.ipos[W.idx[a]]] * W.tm[a];
+          } else {
+            d = W.G[(long long)pr * m + pr];
+            for (int a = 0; a < k; a++) d -= W.G[(long long)pr * m + W.idx[a]] * W.tm[a];
+          }
           const bool dependent = !(d > 1e-11 * W.G[(long long)pr * m + pr]);
           double t1 = 1e300; // dual ratio test: y_W(t) = y_W - t sg r must keep the sign of every working inequality
           int kd = -1;
@@ -361,6 +487,7 @@ QPC_FN int qp_solve_wg(int n, int m, const double *P, const double *q, const dou
     }
   }
   if (!converged && status == QPC_STATUS_OPTIMAL) status = QPC_STATUS_ITERATION_LIMIT;
+  wg_finish_back(W, W.yw); // block mode: the multipliers of the equality rows, once
   // ---- x = xu - Y_W y_W, then iterative refinement on the true KKT residuals of the final working set
   QPC_WG_FOR(i, n) {
     double t = 0.0;

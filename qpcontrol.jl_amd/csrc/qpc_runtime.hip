@@ -42,7 +42,7 @@ qpc_qp_wg_kernel(int n, int m, long long B, const double *P, const double *q, co
   extern __shared__ __attribute__((aligned(16))) double qpc_wg_lds[];
   for (long long b = blockIdx.x; b < B; b += gridDim.x) {
     const int s = qpc::qp_solve_wg(n, m, P + b * n * n, q + b * n, A + b * m * n, l + b * m, u + b * m, st,
-                                   ws + b * ws_stride + (long long)n * n + (long long)n * m, qpc_wg_lds, x + b * n, y + b * m,
+                                   ws + b * ws_stride, qpc_wg_lds, x + b * n, y + b * m,
                                    iters ? iters + b : nullptr);
     if (threadIdx.x == 0) status[b] = s;
     __syncthreads();

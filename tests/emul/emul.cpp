@@ -390,7 +390,7 @@ int32_t qpc_qp_solve_batch(int32_t n, int32_t m, int64_t B, const double *P, con
     int s = QPC_WG_FALLBACK;
     if (m > 0 && !(one && one[0] == '1'))
       s = qpc::qp_solve_wg(n, m, P + b * n * n, q + b * n, A + b * m * n, l + b * m, u + b * m, st,
-                           ws.data() + (long long)n * n + (long long)n * m, lds.data(), x + b * n, y + b * m, iters ? iters + b : nullptr);
+                           ws.data(), lds.data(), x + b * n, y + b * m, iters ? iters + b : nullptr);
     g_l0_wg += s != QPC_WG_FALLBACK;
     if (s != QPC_WG_FALLBACK) status[b] = s;
     else qpc::qp_solve_dense(n, m, P + b * n * n, q + b * n, A + b * m * n, l + b * m, u + b * m, st, ws.data(), x + b * n,
