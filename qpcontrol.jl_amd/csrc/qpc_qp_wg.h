@@ -1,25 +1,35 @@
 // qpc_qp_wg.h -- L0 of the C ABI on a WORKGROUP: one dense convex QP in OSQP problem form
 //       min 1/2 x'Px + q'x   s.t.   l <= A x <= u
-// solved by the 256 threads of one workgroup with its working matrices in LDS -- what makes the solver-level plug of the reference
+// solved by the 512 threads of one workgroup with its working matrices in LDS -- what makes the solver-level plug of the reference
 // (`Parametron.Model(optimizer)`, /root/reference/src/lowlevel/momentum.jl:15-16,27,58; `QPCOptimizer` in julia/QPControlHIPMOI.jl)
 // usable at B = 1: the one-lane-per-QP form of qpc_qp_dense.h needs 0.57 s for the 143 x 178 Atlas problem (measured, MI355X), the
-// reference's own warm-started OSQP 1.3 ms on a CPU core.
+// reference's own warm-started OSQP 0.8 - 1.3 ms on a CPU core.
 //
-// Same method as qpc_qp_dense.h (range-space active set on G = A H^-1 A', primal-dual multi-change sweeps, iterative refinement on
-// the true KKT residuals), for the problems Parametron actually builds for this controller: a DIAGONAL P (regularize!, contact
-// weights, scalar task weights: 63 entries for Atlas) and a sparse A given densely (1 004 of 25 454 entries).  The kernel finds
-// that out by itself:
-//   * P diagonal            -> H^-1 is a vector, Y = H^-1 A' is never formed;
-//   * rows of A compressed  -> G = A H^-1 A' costs (rows x nnz) multiply-adds instead of (rows^2 x columns);
-//   * the working-set matrix S = G_WW (<= QPC_WG_KMAX rows, packed lower triangle) is factored IN LDS by a right-looking Cholesky
-//     (one row per thread, three barriers per column, infinite-pivot rule for dependent rows) with the right-hand side riding
-//     along, so a solve is one factorization + one back-substitution.
-// Anything else -- a dense or matrix-weighted P, more than QPC_WG_NNZ nonzeros, a working set beyond QPC_WG_KMAX rows -- is left to
-// the one-lane kernel: the workgroup reports QPC_WG_FALLBACK and the
-// caller runs qp_solve_dense on that QP.  Both are gfx950 device code; neither is a fallback to anything else.
+// Same method as qpc_qp_dense.h (range-space active set on G = A H^-1 A', primal-dual multi-change sweeps, Goldfarb-Idnani, iterative
+// refinement on the true KKT residuals), for the problems Parametron actually builds for this controller: a DIAGONAL P (regularize!,
+// contact weights, scalar task weights: 63 entries for Atlas) and a sparse A given densely (1 004 of 25 454 entries).
 //
-// Written as parallel loops (QPC_WG_FOR: strided over the workgroup) separated by barriers, so that the same source runs serially on
-// the host inside the test emulation (tests/emul): one "thread", barriers are no-ops.
+//   * ONE elimination does the set-up.  The rows are ordered equalities first (E, ne rows: they are in every working set), the others
+//     after (I, mi rows), and the right-hand side g0 - b rides along as the last ROW of the matrix S = [G ; rhs'] (packed lower
+//     triangle, column-major, in LDS).  Eliminating the first ne columns (LDL' without square roots, in panels of 16 columns: the
+//     trailing matrix is touched once per panel with 16 multiply-adds per element) leaves, in place: L11 D (the factor of G_EE), the
+//     rows G_IE L11^-T of the inequality rows, the Schur complement C = G_II - G_IE G_EE^-1 G_EI in the trailing block,
+//     zE = L11^-1 (g0_E - b_E) and a0 = A x at the equality-constrained minimiser in the last row.
+//   * The working-set iterations live in the space of the inequality rows only: a working set W factors C_WW (its own small packed
+//     triangle, the same elimination routine), A x = a0 - C[:, W] y_W.  The equality multipliers are recovered once, at the end.
+//   * A is compressed by COLUMNS on the way in (a thread per column: coalesced).  G = sum_c h_c a_c a_c' is accumulated column by
+//     column with LDS adds; every wave walks every column and adds only into the entries it owns, so the summation order is fixed.
+//     Products with A' walk the compressed columns; products with A use its transpose by row POSITION (global workspace, coalesced).
+//   * The workgroup runs ONE wave per SIMD: nothing hides a load but the code itself, so every loop over global or LDS data is
+//     written with its loads up front (several chunks in flight).
+// Anything else -- a dense or matrix-weighted P, a working set beyond QPC_WG_KW inequality rows -- is left to the one-lane kernel: the
+// workgroup reports QPC_WG_FALLBACK and the caller runs qp_solve_dense on that QP.  Both are gfx950 device code; neither is a
+// fallback to anything else.  When S does not fit beside the vectors in LDS (m beyond ~180) it lives in the global workspace
+// (L2-resident, slower, same code).
+//
+// Written as parallel loops (QPC_WG_FOR: strided over the workgroup; QPC_WG_FOR_WAVE / lanes: a wave per column, lanes down the
+// column) separated by barriers, so that the same source runs serially on the host inside the test emulation (tests/emul): one
+// "thread", barriers are no-ops.
 #pragma once
 #include "../../include/qpc.h"
 
@@ -28,402 +38,460 @@
 #endif
 
 #define QPC_WG_FALLBACK (-1) // status: not solved here, run the one-lane kernel
-#define QPC_WG_KMAX 160      // rows of a working set the LDS factor holds (packed: 12 880 doubles)
-#define QPC_WG_NNZ 2048      // nonzeros of A held in LDS
+#define QPC_WG_KW 128        // inequality rows of a working set (its factor: (k + 1)(k + 2) / 2 doubles, sized by min(mi, this))
 #define QPC_WG_DIM 256       // n, m <= this
+#define QPC_WG_LDS_DOUBLES 20480 // what the kernel asks for: the 160 KB of a CU
+#define QPC_WG_NB 16         // columns per elimination panel
+#define QPC_WG_THREADS 512   // threads of the workgroup (device)
 
 #if defined(__HIP_DEVICE_COMPILE__)
-#define QPC_WG_NT 256
+#define QPC_WG_NT QPC_WG_THREADS // two waves per SIMD: the second one hides part of the first one's LDS latency
+#define QPC_WG_NWAVE (QPC_WG_THREADS / 64)
+#define QPC_WG_NLANE 64
 #define QPC_WG_TID ((int)threadIdx.x)
 #define QPC_WG_SYNC __syncthreads();
+#define QPC_WG_ADD(ptr, v) atomicAdd((ptr), (v)) // ds_add_f64 / global_atomic_add_f64, result unused: fire and forget, in program order
 #else
 #define QPC_WG_NT 1
+#define QPC_WG_NWAVE 1
+#define QPC_WG_NLANE 1
 #define QPC_WG_TID 0
 #define QPC_WG_SYNC
+#define QPC_WG_ADD(ptr, v) (*(ptr) += (v))
 #endif
+#define QPC_WG_WAVE (QPC_WG_TID / QPC_WG_NLANE)
+#define QPC_WG_LANE (QPC_WG_TID % QPC_WG_NLANE)
 #define QPC_WG_FOR(i, n) for (int i = QPC_WG_TID; i < (n); i += QPC_WG_NT)
+#define QPC_WG_FOR_WAVE(i, n) for (int i = QPC_WG_WAVE; i < (n); i += QPC_WG_NWAVE)
+#define QPC_WG_FOR_LANE(i, n) for (int i = QPC_WG_LANE; i < (n); i += QPC_WG_NLANE)
 #define QPC_WG_T0 if (QPC_WG_TID == 0)
+#if defined(QPC_WG_PROF) && defined(__HIP_DEVICE_COMPILE__)
+#define QPC_WG_STAMP(W, k) do { if (threadIdx.x == 0 && (k) < 16) (W).stamps[k] = wall_clock64(); } while (0)
+#else
+#define QPC_WG_STAMP(W, k) do { } while (0)
+#endif
 
 namespace qpc {
 
-// LDS (or host scratch) needed by qp_solve_wg, in doubles
+// LDS (or host scratch) handed to qp_solve_wg, in doubles
 #ifdef __HIPCC__
 __host__ __device__
 #endif
 inline int qp_wg_lds_doubles(int n, int m) {
   (void)n; (void)m;
-  return QPC_WG_KMAX * (QPC_WG_KMAX + 1) / 2 + QPC_WG_NNZ + QPC_WG_NNZ / 2 + 4 * QPC_WG_DIM + 12 * QPC_WG_DIM + 64 + 8;
+  return QPC_WG_LDS_DOUBLES;
+}
+
+// column-major packed lower triangle of an N1 x N1 matrix: column c holds its rows c .. N1-1
+QPC_FN int wg_cs(int c, int N1) { return c * N1 - (c * (c - 1)) / 2; }
+QPC_FN int wg_sidx(int i, int c, int N1) { return wg_cs(c, N1) + i - c; } // i >= c
+QPC_FN int wg_sym(int a, int b, int N1) { return a >= b ? wg_sidx(a, b, N1) : wg_sidx(b, a, N1); }
+
+// max over the workgroup of a per-thread value (every thread gets the result).  red: QPC_WG_NWAVE doubles of LDS.
+QPC_FN double wg_reduce_max(double v, double *red) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(v, off, 64); v = (o > v || !(o == o)) ? o : v; }
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double r = red[0];
+  for (int w = 1; w < QPC_WG_NWAVE; w++) { const double o = red[w]; r = (o > r || !(o == o)) ? o : r; }
+  __syncthreads();
+  return r;
+#else
+  (void)red;
+  return v;
+#endif
+}
+
+// S[tgt + e] -= S[src + e] * l for e < len: the lanes of the calling wave, four chunks in flight.  Branch-free up to the stores (a
+// chunk past the end re-reads the first one): a conditional load makes the compiler wait for every load by itself.
+QPC_FN void wg_col_axpy(double *S, int tgt, int src, int len, double l) {
+  for (int e0 = QPC_WG_LANE; e0 < len; e0 += 4 * QPC_WG_NLANE) {
+    const int e1 = e0 + QPC_WG_NLANE, e2 = e0 + 2 * QPC_WG_NLANE, e3 = e0 + 3 * QPC_WG_NLANE;
+    const bool h1 = e1 < len, h2 = e2 < len, h3 = e3 < len;
+    const int c1 = h1 ? e1 : e0, c2 = h2 ? e2 : e0, c3 = h3 ? e3 : e0;
+    const double t0 = S[tgt + e0], s0 = S[src + e0], t1 = S[tgt + c1], s1 = S[src + c1];
+    const double t2 = S[tgt + c2], s2 = S[src + c2], t3 = S[tgt + c3], s3 = S[src + c3];
+    const double r0 = t0 - s0 * l, r1 = t1 - s1 * l, r2 = t2 - s2 * l, r3 = t3 - s3 * l;
+    S[tgt + e0] = r0;
+    if (h1) S[tgt + e1] = r1;
+    if (h2) S[tgt + e2] = r2;
+    if (h3) S[tgt + e3] = r3;
+  }
+}
+
+// Eliminate the columns j0 .. j1-1 of S (packed, N1 x N1, the last row is a right-hand side riding along): LDL' without square
+// roots -- the columns keep L D (unscaled), dinv[j] = 1 / d_j, or 0 for a pivot below tau * ref[j] (a dependent row: it drops out of
+// everything, the "infinite pivot" of qpc_qp_dense.h).  Panels of QPC_WG_NB columns: inside a panel one barrier per column (every
+// thread reads the pivot and inverts it itself; the waves update the panel's remaining columns), then the trailing columns take the
+// whole panel at once: a wave takes a PAIR of them (the short one with the long one: every pair has the same length), its lanes run
+// down the column -- the panel's columns and the target are contiguous, the other factors are broadcasts.  A short last panel is
+// padded with zero factors (on the target column itself), so the inner loop is straight-line code: 2 x 17 loads, 32 multiply-adds.
+// Barrier-synchronised on entry and on exit.
+QPC_FN void wg_ldl_eliminate(double *S, int N1, int j0, int j1, const double *ref, double tau, double *dinv) {
+  for (int jp = j0; jp < j1; jp += QPC_WG_NB) {
+    const int nb = j1 - jp < QPC_WG_NB ? j1 - jp : QPC_WG_NB;
+    for (int jj = 0; jj < nb; jj++) {
+      const int j = jp + jj, cj = wg_cs(j, N1);
+      const double d = S[cj], rf = ref[j];
+      const bool ok = d > tau * (rf > 1e-300 ? rf : 1e-300);
+      const double di = ok ? 1.0 / d : 0.0;
+      QPC_WG_T0 { dinv[j] = di; }
+      if (ok) {
+        QPC_WG_FOR_WAVE(cc, nb - 1 - jj) {
+          const int c = j + 1 + cc;
+          const double lc = S[cj + (c - j)] * di;
+          wg_col_axpy(S, wg_cs(c, N1), cj + (c - j), N1 - c, lc);
+        }
+      }
+      QPC_WG_SYNC
+    }
+    const int c0 = jp + nb, R = N1 - 1 - c0; // trailing columns c0 .. N1-2 (column N1-1 would be the corner of the right-hand-side row)
+    if (R > 0) {
+      QPC_WG_FOR_WAVE(p, (R + 1) / 2) {
+        for (int half = 0; half < 2; half++) {
+          const int c = half == 0 ? c0 + p : c0 + R - 1 - p;
+          if (half == 1 && c == c0 + p) break; // the middle column of an odd count
+          const int tgt = wg_cs(c, N1), len = N1 - c;
+          double lc[QPC_WG_NB];
+          int src[QPC_WG_NB];
+#pragma unroll
+          for (int jj = 0; jj < QPC_WG_NB; jj++) {
+            const bool in = jj < nb;
+            const int jc = in ? jp + jj : jp;
+            const int o = wg_cs(jc, N1) + (c - jc);
+            const double v = S[o] * dinv[jc];
+            src[jj] = in ? o : tgt;
+            lc[jj] = in ? v : 0.0;
+          }
+          for (int e0 = QPC_WG_LANE; e0 < len; e0 += 2 * QPC_WG_NLANE) { // two chunks in flight
+            const int e1 = e0 + QPC_WG_NLANE;
+            const bool h1 = e1 < len;
+            const int c1 = h1 ? e1 : e0;
+            double t0 = S[tgt + e0], t1 = S[tgt + c1];
+            double a0[QPC_WG_NB], a1[QPC_WG_NB];
+#pragma unroll
+            for (int jj = 0; jj < QPC_WG_NB; jj++) { a0[jj] = S[src[jj] + e0]; a1[jj] = S[src[jj] + c1]; }
+#pragma unroll
+            for (int jj = 0; jj < QPC_WG_NB; jj++) { t0 -= a0[jj] * lc[jj]; t1 -= a1[jj] * lc[jj]; }
+            S[tgt + e0] = t0;
+            if (h1) S[tgt + e1] = t1;
+          }
+        }
+      }
+      QPC_WG_SYNC
+    }
+  }
+}
+// t <- L^-1 t for the leading nc columns (L unit lower: L_ij = S_ij dinv_j), four columns per barrier: every thread solves the 4 x 4
+// diagonal block itself (ten broadcast loads, a chain of six multiply-adds), then takes the four columns out of its rows below.
+// Thread 0 stores the block's result after the barrier (the others may still be reading t[j .. j+3] before it).
+// Barrier-synchronised on entry and exit.
+QPC_FN void wg_ldl_forward(const double *S, int N1, int nc, const double *dinv, double *t) {
+  for (int j = 0; j < nc; j += 4) {
+    const int nb = nc - j < 4 ? nc - j : 4;
+    const int j1 = nb > 1 ? j + 1 : j, j2 = nb > 2 ? j + 2 : j, j3 = nb > 3 ? j + 3 : j; // (clamped: a short last block re-reads column j)
+    const int c0 = wg_cs(j, N1), c1 = wg_cs(j1, N1), c2 = wg_cs(j2, N1);
+    const double t0 = t[j], t1 = t[j1], t2 = t[j2], t3 = t[j3];
+    const double d0 = dinv[j], d1 = nb > 1 ? dinv[j1] : 0.0, d2 = nb > 2 ? dinv[j2] : 0.0, d3 = nb > 3 ? dinv[j3] : 0.0;
+    const double l10 = S[c0 + (j1 - j)], l20 = S[c0 + (j2 - j)], l30 = S[c0 + (j3 - j)];
+    const double l21 = S[c1 + (j2 - j1)], l31 = S[c1 + (j3 - j1)], l32 = S[c2 + (j3 - j2)];
+    const double z0 = t0, f0 = z0 * d0;
+    double z1 = t1; z1 -= l10 * f0;
+    const double f1 = z1 * d1;
+    double z2 = t2; z2 -= l20 * f0; z2 -= l21 * f1;
+    const double f2 = z2 * d2;
+    double z3 = t3; z3 -= l30 * f0; z3 -= l31 * f1; z3 -= l32 * f2;
+    const double f3 = z3 * d3;
+    const int c3 = wg_cs(j3, N1);
+    QPC_WG_FOR(e, nc - j - nb) {
+      const int i = j + nb + e;
+      const double a0 = S[c0 + (i - j)], a1 = S[c1 + (i - j1)], a2 = S[c2 + (i - j2)], a3 = S[c3 + (i - j3)];
+      double v = t[i];
+      v -= a0 * f0; v -= a1 * f1; v -= a2 * f2; v -= a3 * f3; // (f of a clamped column is 0)
+      t[i] = v;
+    }
+    QPC_WG_SYNC
+    QPC_WG_T0 { if (nb > 1) t[j + 1] = z1; if (nb > 2) t[j + 2] = z2; if (nb > 3) t[j + 3] = z3; }
+  }
+  QPC_WG_SYNC
+}
+// out <- L^-T D^-1 t for the leading nc columns; t is used up (out != t).  Four rows per barrier, like wg_ldl_forward.
+// Barrier-synchronised on entry and exit.
+QPC_FN void wg_ldl_back(const double *S, int N1, int nc, const double *dinv, double *t, double *out) {
+  for (int i0 = nc - 1; i0 >= 0; i0 -= 4) {
+    const int nb = i0 + 1 < 4 ? i0 + 1 : 4;
+    const int i1 = nb > 1 ? i0 - 1 : i0, i2 = nb > 2 ? i0 - 2 : i0, i3 = nb > 3 ? i0 - 3 : i0; // (clamped)
+    const double t0 = t[i0], t1 = t[i1], t2 = t[i2], t3 = t[i3];
+    const double d0 = dinv[i0], d1 = dinv[i1], d2 = dinv[i2], d3 = dinv[i3];
+    const int c1 = wg_cs(i1, N1), c2 = wg_cs(i2, N1), c3 = wg_cs(i3, N1);
+    const double u01 = S[c1 + (i0 - i1)], u02 = S[c2 + (i0 - i2)], u03 = S[c3 + (i0 - i3)]; // S[i0][i1], S[i0][i2], S[i0][i3]
+    const double u12 = S[c2 + (i1 - i2)], u13 = S[c3 + (i1 - i3)], u23 = S[c3 + (i2 - i3)];
+    const double y0 = t0 * d0;
+    double v1 = t1; v1 -= u01 * y0;
+    const double y1 = nb > 1 ? v1 * d1 : 0.0;
+    double v2 = t2; v2 -= u02 * y0; v2 -= u12 * y1;
+    const double y2 = nb > 2 ? v2 * d2 : 0.0;
+    double v3 = t3; v3 -= u03 * y0; v3 -= u13 * y1; v3 -= u23 * y2;
+    const double y3 = nb > 3 ? v3 * d3 : 0.0;
+    QPC_WG_T0 { out[i0] = y0; if (nb > 1) out[i1] = y1; if (nb > 2) out[i2] = y2; if (nb > 3) out[i3] = y3; }
+    QPC_WG_FOR(j, i0 + 1 - nb) {
+      const int cj = wg_cs(j, N1) - j;
+      const double a0 = S[cj + i0], a1 = S[cj + i1], a2 = S[cj + i2], a3 = S[cj + i3];
+      double v = t[j];
+      v -= a0 * y0; v -= a1 * y1; v -= a2 * y2; v -= a3 * y3; // (y of a clamped row is 0)
+      t[j] = v;
+    }
+    QPC_WG_SYNC
+  }
 }
 
 struct QpWg {
-  int n, m;
+  int n, m, ne, mi, N1; // N1 = m + 1: dimension of S with its right-hand-side row
   const double *P, *q, *A, *l, *u;
-  double *G;      // m x m in global memory (the workspace of qp_solve_dense keeps its G at the same place)
-  // block elimination of the equality rows (they are in EVERY working set): factored once, the working sets only refactor their
-  // active inequality rows.  E = equality rows (ne, first in every compaction), I = the others (mi).
-  bool blk;
-  int ne, mi;
-  double *L21;    // mi x ne in global memory: row i = L11^-1 G_E,i  (the part of an inequality row's factor row that never changes)
-  double *Call;   // mi x mi in global memory: Schur complement G_II - L21 L21' (what a working set factors a sub-block of)
-  double *zE, *a0; // LDS: L11^-1 (g0_E - b_E);  A x at the equality-constrained minimiser for the inequality rows, g0_I - L21 zE
-  int *ipos, *irows; // row -> position among the inequality rows (-1: equality row); position -> row
+  // global workspace
+  double *AT;     // n x m: A' by row position, AT[c * m + pos]
+  double *cval;   // nonzeros of A, column by column; crow: the POSITION of the row
+  int *crow;
+  const double *sval; // the same, staged in LDS during the set-up when it fits (else the global copy)
+  const int *srow;
   // LDS
-  double *S;      // packed lower triangle of the working-set matrix / its Cholesky factor
-  double *val;    // nonzeros of A, row by row
-  int *col, *rowptr;
+  double *S;      // (LDS, or the global workspace when it does not fit)
+  double *LW;     // the working set's factor, (k + 1) x (k + 1) packed
+  int *cptr, *perm, *ipos; // column starts; position -> row, row -> position (equality rows first)
   double *hinv, *xu, *x, *r1;              // n
-  double *g0, *yw, *bw, *ax, *wsf, *sinvd, *tm, *sdiag; // m
-  int *idx;       // compacted working set
-  double *sc;     // scalars
+  double *gdiag, *tA;                      // m + 1 (by position): diagonal of G (from the final stage on: y by position); scratch
+  double *dinvE, *yE, *tE;                 // ne
+  double *wsf, *tm, *ax, *lo, *hi, *a0;    // mi (by inequality position)
+  double *yw, *dinvW, *dW, *tW;            // kw + 1
+  int *idxW;
+  double *sc, *red;
+  unsigned long long *stamps;
 };
 
-enum { WGS_FLAG = 0, WGS_HMAX, WGS_EPS, WGS_BSCALE, WGS_K, WGS_CHANGES, WGS_YSC, WGS_XSC, WGS_RP, WGS_RS, WGS_BIG, WGS_DBIG, WGS_T, WGS_P, WGS_VIOL, WGS_SG, WGS_MI,
-       WGS_COUNT };
+enum { WGS_FLAG = 0, WGS_K, WGS_CHANGES, WGS_T, WGS_P, WGS_VIOL, WGS_SG, WGS_NE, WGS_NNZ, WGS_COUNT };
 
-QPC_FN int wg_sidx(int i, int j) { return i * (i + 1) / 2 + j; } // packed lower triangle, i >= j
+// t[pos] = sum_c AT[c * m + pos] * w[c]  (a row of A times w; the loads of eight columns in flight)
+QPC_FN double wg_row_dot(const QpWg &W, int pos, const double *w) {
+  const int n = W.n, m = W.m;
+  double t = 0.0;
+  int c = 0;
+  for (; c + 8 <= n; c += 8) {
+    const double *a = W.AT + (long long)c * m + pos;
+    const double a0 = a[0], a1 = a[m], a2 = a[2 * m], a3 = a[3 * m], a4 = a[4 * m], a5 = a[5 * m], a6 = a[6 * m], a7 = a[7 * m];
+    t += a0 * w[c]; t += a1 * w[c + 1]; t += a2 * w[c + 2]; t += a3 * w[c + 3];
+    t += a4 * w[c + 4]; t += a5 * w[c + 5]; t += a6 * w[c + 6]; t += a7 * w[c + 7];
+  }
+  for (; c < n; c++) t += W.AT[(long long)c * m + pos] * w[c];
+  return t;
+}
+// (A' y)_c for y by position (a compressed column: short)
+QPC_FN double wg_col_dot(const QpWg &W, int c, const double *ypos) {
+  double t = 0.0;
+  for (int o = W.cptr[c]; o < W.cptr[c + 1]; o++) t += W.cval[o] * ypos[W.crow[o]];
+  return t;
+}
 
-// Factor the working set in W.wsf and solve one system with it: compaction -> idx (equality rows first), S = G_WW, Cholesky with the
-// right-hand side riding along, back-substitution -> out (compact).  Right-hand side: pcol < 0: g0_W - b_W (the EQP of the working
-// set; b -> W.bw); pcol >= 0: column pcol of G (the Goldfarb-Idnani direction of row pcol).  Returns the number of working rows, or -1
-// beyond QPC_WG_KMAX.
-// Block mode (W.blk): rows 0 .. ne-1 of S hold L11 for good; a working inequality row gets its first ne factor entries from L21 and
-// its remaining ones from the Schur complement Call, so only the columns ne .. k-1 are eliminated.  full_back = false stops the
-// back-substitution at column ne: out[ne ..] are the multipliers of the inequality rows, out[0 .. ne-1] still L11^-1 of the right-hand
-// side (wg_finish_back completes them).
-// zsave: the right-hand side after the forward part (L^-1 rhs), before the back-substitution.
-QPC_FN int wg_factor(QpWg &W, double tau, int pcol, double *out, bool full_back = true, double *zsave = nullptr) {
-  const int m = W.m;
-  QPC_WG_T0 {
-    int k = 0;
-    for (int i = 0; i < m; i++) if (W.wsf[i] == 2.0) { if (k < QPC_WG_KMAX) W.idx[k] = i; k++; }
-    for (int i = 0; i < m; i++) if (W.wsf[i] != 0.0 && W.wsf[i] != 2.0) { if (k < QPC_WG_KMAX) W.idx[k] = i; k++; }
-    W.sc[WGS_K] = (double)k;
+// Working set in W.wsf (by inequality position) -> idxW (ascending), factor of C_WW in W.LW.  with_rhs: the right-hand side
+// a0_W - b_W rides along and yw <- the multipliers of the working rows.  Returns the number of working inequality rows, or -1 beyond
+// what LW holds.
+QPC_FN int wg_w_factor(QpWg &W, double tau, bool with_rhs, int kw) {
+  const int mi = W.mi, ne = W.ne, N1 = W.N1;
+  int k = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  { // one thread per inequality row (mi <= 256): ranks from the waves' ballots
+    const int p = threadIdx.x, lane = p & 63, wv = p >> 6;
+    const bool f = p < mi && W.wsf[p] != 0.0;
+    const unsigned long long mask = __ballot(f);
+    int *cnt = (int *)W.red;
+    if (lane == 0) cnt[wv] = __popcll(mask);
+    __syncthreads();
+    int off = 0;
+    for (int w = 0; w < QPC_WG_NWAVE; w++) { const int c = cnt[w]; off += w < wv ? c : 0; k += c; }
+    if (f) { const int r = off + __popcll(mask & ((1ull << lane) - 1ull)); if (r < kw) W.idxW[r] = p; }
+    __syncthreads();
+  }
+#else
+  for (int p = 0; p < mi; p++) if (W.wsf[p] != 0.0) { if (k < kw) W.idxW[k] = p; k++; }
+#endif
+  if (k > kw) return -1;
+  const int K1 = k + 1;
+  QPC_WG_FOR_WAVE(b, k) {
+    const int pb = W.idxW[b], sb = wg_cs(b, K1);
+    QPC_WG_FOR_LANE(e, k - b) { W.LW[sb + e] = W.S[wg_sym(ne + W.idxW[b + e], ne + pb, N1)]; }
+  }
+  QPC_WG_FOR(a, k) {
+    const int pa = W.idxW[a];
+    W.tW[a] = W.gdiag[ne + pa];
+    W.LW[wg_sidx(k, a, K1)] = with_rhs ? W.a0[pa] - (W.wsf[pa] > 0.0 ? W.hi[pa] : W.lo[pa]) : 0.0;
   }
   QPC_WG_SYNC
-  const int k = (int)W.sc[WGS_K];
-  if (k > QPC_WG_KMAX) return -1;
-  const int j0 = W.blk ? W.ne : 0; // first column to eliminate
-  if (W.blk) {
-    const int ne = W.ne, pp = pcol >= 0 ? W.ipos[pcol] : -1;
-    QPC_WG_FOR(e, (k - ne) * ne) { // the fixed part of the working inequality rows
-      const int a = ne + e / ne, b = e % ne;
-      W.S[wg_sidx(a, b)] = W.L21[(long long)W.ipos[W.idx[a]] * ne + b];
-    }
-    QPC_WG_FOR(a0_, k - ne) {
-      const int a = ne + a0_, ia = W.idx[a], pa = W.ipos[ia];
-      for (int b = ne; b <= a; b++) W.S[wg_sidx(a, b)] = W.Call[(long long)pa * W.mi + W.ipos[W.idx[b]]];
-      if (pcol < 0) {
-        const double bnd = (W.wsf[ia] == 1.0) ? W.u[ia] : W.l[ia];
-        W.bw[a] = bnd;
-        out[a] = W.a0[pa] - bnd;
-      } else out[a] = W.Call[(long long)pa * W.mi + pp];
-      W.sdiag[a] = W.G[(long long)ia * m + ia];
-    }
-    QPC_WG_FOR(b, ne) {
-      out[b] = pcol < 0 ? W.zE[b] : W.L21[(long long)pp * ne + b];
-      if (pcol < 0) W.bw[b] = W.l[W.idx[b]];
-    }
-  } else {
-    QPC_WG_FOR(a, k) {
-      const int ia = W.idx[a];
-      for (int b = 0; b <= a; b++) W.S[wg_sidx(a, b)] = W.G[(long long)ia * m + W.idx[b]];
-      if (pcol < 0) {
-        const double w = W.wsf[ia];
-        const double bnd = (w == 1.0) ? W.u[ia] : W.l[ia]; // lower-active and equality rows sit at l
-        W.bw[a] = bnd;
-        out[a] = W.g0[ia] - bnd;
-      } else out[a] = W.G[(long long)ia * m + pcol];
-      W.sdiag[a] = W.G[(long long)ia * m + ia];
-    }
-  }
-  QPC_WG_SYNC
-  for (int j = j0; j < k; j++) { // right-looking Cholesky, infinite-pivot rule; out <- L^-1 out on the way
-    QPC_WG_T0 {
-      const double d = W.S[wg_sidx(j, j)], ref = W.sdiag[j];
-      const bool ok = d > tau * (ref > 1e-300 ? ref : 1e-300);
-      const double inv = ok ? 1.0 / QPC_SQRT(d) : 0.0;
-      W.sinvd[j] = inv;
-      out[j] = out[j] * inv;
-    }
+  wg_ldl_eliminate(W.LW, K1, 0, k, W.tW, tau, W.dinvW);
+  if (with_rhs) {
+    QPC_WG_FOR(a, k) { W.tW[a] = W.LW[wg_sidx(k, a, K1)]; }
     QPC_WG_SYNC
-    const double inv = W.sinvd[j], yj = out[j];
-    QPC_WG_FOR(i0, k - j - 1) {
-      const int i = j + 1 + i0;
-      const double lij = W.S[wg_sidx(i, j)] * inv;
-      W.S[wg_sidx(i, j)] = lij;
-      out[i] -= lij * yj;
-    }
-    QPC_WG_SYNC
-    QPC_WG_FOR(i0, k - j - 1) { // trailing update, one row per thread
-      const int i = j + 1 + i0;
-      const double lij = W.S[wg_sidx(i, j)];
-      if (lij != 0.0)
-        for (int c = j + 1; c <= i; c++) W.S[wg_sidx(i, c)] -= lij * W.S[wg_sidx(c, j)];
-    }
-    QPC_WG_SYNC
-  }
-  if (zsave) {
-    QPC_WG_FOR(a, k) { zsave[a] = out[a]; }
-    QPC_WG_SYNC
-  }
-  for (int j = k - 1; j >= (full_back ? 0 : j0); j--) { // L' y = z
-    QPC_WG_T0 { out[j] = out[j] * W.sinvd[j]; }
-    QPC_WG_SYNC
-    const double yj = out[j];
-    QPC_WG_FOR(i, j) { out[i] -= W.S[wg_sidx(j, i)] * yj; }
-    QPC_WG_SYNC
+    wg_ldl_back(W.LW, K1, k, W.dinvW, W.tW, W.yw);
   }
   return k;
 }
-// block mode: the equality part of a back-substitution that wg_factor(full_back = false) left at column ne
-QPC_FN void wg_finish_back(QpWg &W, double *out) {
-  if (!W.blk) return;
-  for (int j = W.ne - 1; j >= 0; j--) {
-    QPC_WG_T0 { out[j] = out[j] * W.sinvd[j]; }
-    QPC_WG_SYNC
-    const double yj = out[j];
-    QPC_WG_FOR(i, j) { out[i] -= W.S[wg_sidx(j, i)] * yj; }
-    QPC_WG_SYNC
-  }
-}
-// One-time set-up of the block mode, right after the equality-only working set has been factored (S rows 0 .. ne-1 = L11, W.zE =
-// L11^-1 (g0_E - b_E): the zsave of that factorization).  Every inequality row: its factor row against L11 by forward substitution -- one thread
-// per row, nothing shared but read-only L11 -- in chunks that fit behind L11 in the LDS buffer; then the Schur complement.
-QPC_FN void wg_block_setup(QpWg &W) {
-  const int m = W.m, ne = W.ne, mi = W.mi;
-  const int chunk = QPC_WG_KMAX - ne;
-  for (int c0 = 0; c0 < mi; c0 += chunk) {
-    const int cnt = mi - c0 < chunk ? mi - c0 : chunk;
-    QPC_WG_FOR(a, cnt) {
-      const int row = ne + a, ir = W.irows[c0 + a];
-      double acc0 = W.g0[ir];
-      for (int j = 0; j < ne; j++) {
-        double t = W.G[(long long)ir * m + W.idx[j]];
-        for (int c = 0; c < j; c++) t -= W.S[wg_sidx(row, c)] * W.S[wg_sidx(j, c)];
-        t *= W.sinvd[j];
-        W.S[wg_sidx(row, j)] = t;
-        acc0 -= t * W.zE[j];
-      }
-      for (int j = 0; j < ne; j++) W.L21[(long long)(c0 + a) * ne + j] = W.S[wg_sidx(row, j)];
-      W.a0[c0 + a] = acc0;
-    }
-    QPC_WG_SYNC
-  }
-  QPC_WG_FOR(e, mi * mi) {
-    const int i = e / mi, c = e % mi;
-    if (c <= i) {
-      double t = W.G[(long long)W.irows[i] * m + W.irows[c]];
-      for (int j = 0; j < ne; j++) t -= W.L21[(long long)i * ne + j] * W.L21[(long long)c * ne + j];
-      W.Call[(long long)i * mi + c] = t;
-      W.Call[(long long)c * mi + i] = t;
-    }
-  }
-  QPC_WG_SYNC
-}
-// EQP of the working set: multipliers -> yw (compact), ax = A x for every row
-QPC_FN int wg_solve_ws(QpWg &W, double tau, double *zsave = nullptr) {
-  const int m = W.m;
-  const int k = wg_factor(W, tau, -1, W.yw, !W.blk, zsave);
+// EQP of the working set: multipliers of its inequality rows -> yw, ax = A x for every inequality row
+QPC_FN int wg_solve_ws(QpWg &W, double tau, int kw) {
+  const int k = wg_w_factor(W, tau, true, kw);
   if (k < 0) return -1;
-  if (W.blk) { // in the space of the inequality rows: A x = a0 - Call[:, W] y_W ; the equality rows hold exactly
-    QPC_WG_FOR(i, m) {
-      const int pi = W.ipos[i];
-      double t = pi < 0 ? W.l[i] : W.a0[pi];
-      if (pi >= 0)
-        for (int a = W.ne; a < k; a++) t -= W.Call[(long long)pi * W.mi + W.ipos[W.idx[a]]] * W.yw[a];
-      W.ax[i] = t;
-    }
-  } else {
-    QPC_WG_FOR(i, m) {
-      double t = W.g0[i];
-      for (int a = 0; a < k; a++) t -= W.G[(long long)i * m + W.idx[a]] * W.yw[a];
-      W.ax[i] = t;
-    }
+  QPC_WG_FOR(p, W.mi) {
+    double t = W.a0[p];
+    for (int a = 0; a < k; a++) t -= W.S[wg_sym(W.ne + p, W.ne + W.idxW[a], W.N1)] * W.yw[a];
+    W.ax[p] = t;
   }
   QPC_WG_SYNC
   return k;
 }
-
-// z <- S^-1 z with the factor left in W.S by wg_solve_ws (z compact, length k)
-QPC_FN void wg_factor_solve(QpWg &W, double *z, int k) {
-  for (int j = 0; j < k; j++) {
-    QPC_WG_T0 { z[j] = z[j] * W.sinvd[j]; }
-    QPC_WG_SYNC
-    const double zj = z[j];
-    QPC_WG_FOR(i0, k - j - 1) { const int i = j + 1 + i0; z[i] -= W.S[wg_sidx(i, j)] * zj; }
-    QPC_WG_SYNC
+// (outE, outW) <- K^-1 (tE, tW) with K = G on (E, W): the block factor [L11 ; rows of the working inequality rows ; LW].
+// in: W.tE (ne), W.tW (k); outE may be W.tE.  W.tA is scratch.
+QPC_FN void wg_block_solve(QpWg &W, int k, double *outE, double *outW) {
+  const int ne = W.ne, N1 = W.N1, K1 = k + 1;
+  wg_ldl_forward(W.S, N1, ne, W.dinvE, W.tE);
+  QPC_WG_FOR(a, k) {
+    const int i = ne + W.idxW[a];
+    double t = W.tW[a];
+    for (int j = 0; j < ne; j++) t -= W.S[wg_sidx(i, j, N1)] * W.dinvE[j] * W.tE[j];
+    W.tW[a] = t;
   }
-  for (int j = k - 1; j >= 0; j--) {
-    QPC_WG_T0 { z[j] = z[j] * W.sinvd[j]; }
-    QPC_WG_SYNC
-    const double zj = z[j];
-    QPC_WG_FOR(i, j) { z[i] -= W.S[wg_sidx(j, i)] * zj; }
-    QPC_WG_SYNC
+  QPC_WG_SYNC
+  wg_ldl_forward(W.LW, K1, k, W.dinvW, W.tW);
+  wg_ldl_back(W.LW, K1, k, W.dinvW, W.tW, outW);
+  QPC_WG_FOR(j, ne) {
+    double t = W.tE[j];
+    for (int a = 0; a < k; a++) t -= W.S[wg_sidx(ne + W.idxW[a], j, N1)] * outW[a];
+    W.tA[j] = t;
   }
+  QPC_WG_SYNC
+  wg_ldl_back(W.S, N1, ne, W.dinvE, W.tA, outE);
 }
 
-// returns the status (QPC_STATUS_*), or QPC_WG_FALLBACK when the problem is outside what this kernel handles
-QPC_FN int qp_solve_wg(int n, int m, const double *P, const double *q, const double *A, const double *l, const double *u,
-                       const qpc_settings &st, double *ws, double *lds, double *x, double *y, int32_t *iters_out) {
+// the solver proper, S placed by the caller (LDS or global)
+QPC_FN int qp_solve_wg_core(QpWg &W, const qpc_settings &st, double bscale, int kw, double *x, double *y, int32_t *iters_out) {
   const double INF = 1e19;
-  if (n > QPC_WG_DIM || m > QPC_WG_DIM || n < 1) return QPC_WG_FALLBACK;
-  QpWg W;
-  // global workspace = the one of qp_solve_dense (qp_dense_workspace_doubles): [H n x n | Y n x m | G m x m | S m x m | ...]; G sits
-  // where that kernel keeps it, the block mode's L21 (mi x ne) goes where its Y was, Call (mi x mi) where its S was
-  W.n = n; W.m = m; W.P = P; W.q = q; W.A = A; W.l = l; W.u = u; W.G = ws + (long long)n * n + (long long)n * m;
-  W.L21 = ws + (long long)n * n; W.Call = W.G + (long long)m * m;
-  W.blk = false; W.ne = 0; W.mi = m;
-  double *p = lds;
-  W.S = p; p += QPC_WG_KMAX * (QPC_WG_KMAX + 1) / 2;
-  W.val = p; p += QPC_WG_NNZ;
-  W.col = (int *)p; p += QPC_WG_NNZ / 2;
-  W.hinv = p; p += QPC_WG_DIM; W.xu = p; p += QPC_WG_DIM; W.x = p; p += QPC_WG_DIM; W.r1 = p; p += QPC_WG_DIM;
-  W.g0 = p; p += QPC_WG_DIM; W.yw = p; p += QPC_WG_DIM; W.bw = p; p += QPC_WG_DIM; W.ax = p; p += QPC_WG_DIM;
-  W.wsf = p; p += QPC_WG_DIM; W.sinvd = p; p += QPC_WG_DIM; W.tm = p; p += QPC_WG_DIM; W.sdiag = p; p += QPC_WG_DIM;
-  W.idx = (int *)p; W.ipos = W.idx + QPC_WG_DIM; p += QPC_WG_DIM;         // (two ints per double)
-  W.rowptr = (int *)p; W.irows = W.rowptr + QPC_WG_DIM + 1; p += QPC_WG_DIM + 1;
-  W.zE = p; p += QPC_WG_DIM; W.a0 = p; p += QPC_WG_DIM;
-  W.sc = p; p += 64;
-  // ---- structure: diagonal P, nonzeros of A per row
-  QPC_WG_T0 { for (int i = 0; i < WGS_COUNT; i++) W.sc[i] = 0.0; }
+  const int n = W.n, m = W.m, ne = W.ne, mi = W.mi, N1 = W.N1;
+  // ---- S = [G ; rhs'] by position, column by column of A: G += h_c a_c a_c', rhs += xu_c a_c'.  Every wave walks every column and
+  //      adds only into the entries it owns (by the smaller position): a fixed summation order without a barrier.
+  QPC_WG_FOR(e, (m + 1) * (m + 2) / 2) { W.S[e] = 0.0; }
   QPC_WG_SYNC
-  QPC_WG_FOR(e, n * n) {
-    const int i = e / n, j = e % n;
-    if (i != j && P[e] != 0.0) W.sc[WGS_FLAG] = 1.0; // (every writer writes the same value)
-  }
-  QPC_WG_FOR(i, m) {
-    int c = 0;
-    for (int k2 = 0; k2 < n; k2++) c += A[(long long)i * n + k2] != 0.0 ? 1 : 0;
-    W.rowptr[i + 1] = c;
-  }
-  QPC_WG_SYNC
-  QPC_WG_T0 {
-    W.rowptr[0] = 0;
-    for (int i = 0; i < m; i++) W.rowptr[i + 1] += W.rowptr[i];
-    if (W.rowptr[m] > QPC_WG_NNZ) W.sc[WGS_FLAG] = 1.0;
-    double hmax = 0.0;
-    for (int i = 0; i < n; i++) { const double a = QPC_FABS(P[(long long)i * n + i]); hmax = a > hmax ? a : hmax; }
-    W.sc[WGS_HMAX] = hmax;
-  }
-  QPC_WG_SYNC
-  if (W.sc[WGS_FLAG] != 0.0) return QPC_WG_FALLBACK;
-  const double eps = st.eps_primal_reg * (W.sc[WGS_HMAX] > 0.0 ? W.sc[WGS_HMAX] : 1.0);
-  QPC_WG_FOR(i, m) {
-    int o = W.rowptr[i];
-    for (int k2 = 0; k2 < n; k2++) {
-      const double a = A[(long long)i * n + k2];
-      if (a != 0.0) { W.val[o] = a; W.col[o] = k2; o++; }
+  for (int cg = 0; cg < n; cg += 4) { // four columns at a time: all their loads first, then their adds, in column order
+    int o0[4], kk[4];
+    double hh[4], xx[4];
+    float rk[4];
+    int k2max = 0, kmax = 0;
+#pragma unroll
+    for (int u4 = 0; u4 < 4; u4++) {
+      const bool in = cg + u4 < n;
+      const int c = in ? cg + u4 : cg;
+      o0[u4] = W.cptr[c];
+      kk[u4] = in ? W.cptr[c + 1] - o0[u4] : 0;
+      hh[u4] = W.hinv[c]; xx[u4] = W.xu[c];
+      rk[u4] = 1.0f / (float)(kk[u4] > 0 ? kk[u4] : 1);
+      k2max = kk[u4] * kk[u4] > k2max ? kk[u4] * kk[u4] : k2max;
+      kmax = kk[u4] > kmax ? kk[u4] : kmax;
+    }
+    QPC_WG_FOR_LANE(e, k2max) {
+      int pa[4], pb[4];
+      double va[4], vb[4];
+      bool act[4];
+#pragma unroll
+      for (int u4 = 0; u4 < 4; u4++) {
+        const int k = kk[u4];
+        const int i1 = (int)(((float)e + 0.5f) * rk[u4]), i2 = e - i1 * k;
+        act[u4] = e < k * k && i2 <= i1;
+        const int oa = act[u4] ? o0[u4] + i1 : 0, ob = act[u4] ? o0[u4] + i2 : 0;
+        pa[u4] = W.srow[oa]; pb[u4] = W.srow[ob]; va[u4] = W.sval[oa]; vb[u4] = W.sval[ob];
+      }
+#pragma unroll
+      for (int u4 = 0; u4 < 4; u4++) {
+        const int hi = pa[u4] > pb[u4] ? pa[u4] : pb[u4], lo = pa[u4] > pb[u4] ? pb[u4] : pa[u4];
+        if (act[u4] && lo % QPC_WG_NWAVE == QPC_WG_WAVE) QPC_WG_ADD(&W.S[wg_sidx(hi, lo, N1)], va[u4] * vb[u4] * hh[u4]);
+      }
+    }
+    QPC_WG_FOR_LANE(e, kmax) {
+      int pa[4];
+      double va[4];
+#pragma unroll
+      for (int u4 = 0; u4 < 4; u4++) {
+        const int oa = e < kk[u4] ? o0[u4] + e : 0;
+        pa[u4] = W.srow[oa]; va[u4] = W.sval[oa];
+      }
+#pragma unroll
+      for (int u4 = 0; u4 < 4; u4++)
+        if (e < kk[u4] && pa[u4] % QPC_WG_NWAVE == QPC_WG_WAVE) QPC_WG_ADD(&W.S[wg_sidx(m, pa[u4], N1)], va[u4] * xx[u4]);
     }
   }
-  QPC_WG_FOR(i, n) {
-    const double h = 1.0 / (P[(long long)i * n + i] + eps);
-    W.hinv[i] = h;
-    W.xu[i] = -q[i] * h;
+  QPC_WG_SYNC
+  QPC_WG_FOR(b, m) { // the right-hand-side row: g0_E - b_E on the equality rows, g0 on the others
+    if (b < ne) W.S[wg_sidx(m, b, N1)] -= W.l[W.perm[b]];
+    W.gdiag[b] = W.S[wg_cs(b, N1)];
   }
   QPC_WG_SYNC
-  // ---- G = A H^-1 A' (lower triangle computed, mirrored), g0 = A xu
-  QPC_WG_FOR(e, m * m) {
-    const int i = e / m, j = e % m;
-    if (j <= i) {
-      double s = 0.0;
-      for (int o = W.rowptr[j]; o < W.rowptr[j + 1]; o++) { const int c = W.col[o]; s += W.val[o] * A[(long long)i * n + c] * W.hinv[c]; }
-      W.G[(long long)i * m + j] = s;
-      W.G[(long long)j * m + i] = s;
-    }
-  }
-  QPC_WG_FOR(i, m) {
-    double t = 0.0;
-    for (int o = W.rowptr[i]; o < W.rowptr[i + 1]; o++) t += W.val[o] * W.xu[W.col[o]];
-    W.g0[i] = t;
-    const bool lo = l[i] > -INF, hi = u[i] < INF;
-    W.wsf[i] = (lo && hi && u[i] - l[i] <= 1e-12 * (1.0 + QPC_FABS(l[i]))) ? 2.0 : 0.0;
+  QPC_WG_STAMP(W, 2);
+  wg_ldl_eliminate(W.S, N1, 0, ne, W.gdiag, st.eps_dual_reg, W.dinvE);
+  QPC_WG_STAMP(W, 3);
+  QPC_WG_FOR(p, mi) {
+    W.a0[p] = W.S[wg_sidx(m, ne + p, N1)];
+    W.wsf[p] = 0.0;
   }
   QPC_WG_SYNC
-  QPC_WG_T0 {
-    double bscale = 1.0;
-    for (int i = 0; i < m; i++) {
-      if (l[i] > -INF) bscale = QPC_FABS(l[i]) > bscale ? QPC_FABS(l[i]) : bscale;
-      if (u[i] < INF) bscale = QPC_FABS(u[i]) > bscale ? QPC_FABS(u[i]) : bscale;
-    }
-    W.sc[WGS_BSCALE] = bscale;
-  }
-  QPC_WG_SYNC
-  const double bscale = W.sc[WGS_BSCALE];
   int status = QPC_STATUS_OPTIMAL, iters = 0;
   const int max_it = st.max_active_set_iters > 0 ? st.max_active_set_iters : 200;
-  int nw = wg_solve_ws(W, st.eps_dual_reg, W.zE); // the equality-only working set (block mode is not on yet); zE = L11^-1 (g0_E - b_E)
-  if (nw < 0) return QPC_WG_FALLBACK;
-  // block mode: worth it when there are equality rows, and possible when L11 leaves room for a chunk of inequality rows behind it
-  QPC_WG_T0 {
-    int mi = 0;
-    for (int i = 0; i < m; i++) { if (W.wsf[i] == 2.0) W.ipos[i] = -1; else { W.ipos[i] = mi; W.irows[mi] = i; mi++; } }
-    W.sc[WGS_MI] = (double)mi;
-  }
-  QPC_WG_SYNC
-  {
-    const int mi = (int)W.sc[WGS_MI], ne = m - mi;
-    if (ne >= 8 && ne + 16 <= QPC_WG_KMAX && (long long)mi * ne <= (long long)n * m && mi >= 1) {
-      W.ne = ne; W.mi = mi;
-      wg_block_setup(W);
-      W.blk = true;
-      nw = wg_solve_ws(W, st.eps_dual_reg);
-      if (nw < 0) return QPC_WG_FALLBACK;
-    }
-  }
+  int nw = wg_solve_ws(W, st.eps_dual_reg, kw); // the equality-only working set
   bool converged = false;
   const int max_pdas = 12;
-  // ---- primal-dual multi-change sweeps (qpc_qp_dense.h phase A)
+  // ---- primal-dual multi-change sweeps (qpc_qp_dense.h phase A), on the inequality rows
   for (; iters < max_pdas && iters < max_it; iters++) {
-    QPC_WG_T0 {
-      double ysc = 1.0, xsc = 1.0;
-      for (int a = 0; a < nw; a++) ysc = QPC_FABS(W.yw[a]) > ysc ? QPC_FABS(W.yw[a]) : ysc;
-      for (int i = 0; i < m; i++) xsc = QPC_FABS(W.ax[i]) > xsc ? QPC_FABS(W.ax[i]) : xsc;
-      W.sc[WGS_YSC] = ysc; W.sc[WGS_XSC] = xsc; W.sc[WGS_CHANGES] = 0.0;
-    }
-    QPC_WG_FOR(i, m) { W.tm[i] = 0.0; }
-    QPC_WG_SYNC
-    const double toly = st.tol_bound * W.sc[WGS_YSC], xsc = W.sc[WGS_XSC], tolx = st.tol_bound * (xsc > bscale ? xsc : bscale);
-    QPC_WG_FOR(a, nw) { // wrong-signed multipliers and dependent (dropped) inequality rows leave
-      const int i = W.idx[a];
-      const double w = W.wsf[i];
-      const double viol = (w == -1.0) ? W.yw[a] : ((w == 1.0) ? -W.yw[a] : 0.0);
-      if (viol > toly || (w != 2.0 && W.sinvd[a] == 0.0)) W.sc[WGS_CHANGES] = 1.0;
-      else W.tm[i] = w;
+    double a_y = 1.0, a_x = 1.0;
+    QPC_WG_FOR(a, nw) { a_y = QPC_FABS(W.yw[a]) > a_y ? QPC_FABS(W.yw[a]) : a_y; }
+    QPC_WG_FOR(p, mi) { a_x = QPC_FABS(W.ax[p]) > a_x ? QPC_FABS(W.ax[p]) : a_x; W.tm[p] = 0.0; }
+    QPC_WG_T0 { W.sc[WGS_CHANGES] = 0.0; }
+    const double ysc = wg_reduce_max(a_y, W.red), xsc = wg_reduce_max(a_x, W.red);
+    const double toly = st.tol_bound * ysc, tolx = st.tol_bound * (xsc > bscale ? xsc : bscale);
+    QPC_WG_FOR(a, nw) { // wrong-signed multipliers and dependent (dropped) rows leave
+      const int p = W.idxW[a];
+      const double w = W.wsf[p];
+      const double viol = w < 0.0 ? W.yw[a] : -W.yw[a];
+      if (viol > toly || W.dinvW[a] == 0.0) W.sc[WGS_CHANGES] = 1.0;
+      else W.tm[p] = w;
     }
     QPC_WG_SYNC
-    QPC_WG_FOR(i, m) {
-      if (W.wsf[i] == 0.0) {
-        const double lo = l[i] > -INF ? l[i] - W.ax[i] : -1.0, hi = u[i] < INF ? W.ax[i] - u[i] : -1.0;
-        if (lo > tolx && lo >= hi) { W.tm[i] = -1.0; W.sc[WGS_CHANGES] = 1.0; }
-        else if (hi > tolx) { W.tm[i] = 1.0; W.sc[WGS_CHANGES] = 1.0; }
+    QPC_WG_FOR(p, mi) {
+      if (W.wsf[p] == 0.0) {
+        const double lo = W.lo[p] > -INF ? W.lo[p] - W.ax[p] : -1.0, hi = W.hi[p] < INF ? W.ax[p] - W.hi[p] : -1.0;
+        if (lo > tolx && lo >= hi) { W.tm[p] = -1.0; W.sc[WGS_CHANGES] = 1.0; }
+        else if (hi > tolx) { W.tm[p] = 1.0; W.sc[WGS_CHANGES] = 1.0; }
       }
     }
     QPC_WG_SYNC
     if (W.sc[WGS_CHANGES] == 0.0) { converged = true; break; }
-    QPC_WG_FOR(i, m) { W.wsf[i] = W.tm[i]; }
+    QPC_WG_FOR(p, mi) { W.wsf[p] = W.tm[p]; }
     QPC_WG_SYNC
-    nw = wg_solve_ws(W, st.eps_dual_reg);
+    nw = wg_solve_ws(W, st.eps_dual_reg, kw);
     if (nw < 0) return QPC_WG_FALLBACK;
   }
+  QPC_WG_STAMP(W, 4);
   // ---- Goldfarb-Idnani dual active set from the equality-only working set (finite; qpc_qp_dense.h phase B).  The scalar logic of an
   //      iteration (most violated row, ratio test, step) is thread 0's, the factorizations the workgroup's.
   if (!converged) {
-    QPC_WG_FOR(i, m) { W.wsf[i] = W.wsf[i] == 2.0 ? 2.0 : 0.0; }
+    QPC_WG_FOR(p, mi) { W.wsf[p] = 0.0; }
     QPC_WG_SYNC
-    nw = wg_solve_ws(W, st.eps_dual_reg);
-    if (nw < 0) return QPC_WG_FALLBACK;
+    nw = wg_solve_ws(W, st.eps_dual_reg, kw);
     for (; iters < max_it; iters++) {
       QPC_WG_T0 {
         double xsc = 1.0;
-        for (int i = 0; i < m; i++) xsc = QPC_FABS(W.ax[i]) > xsc ? QPC_FABS(W.ax[i]) : xsc;
+        for (int p = 0; p < mi; p++) xsc = QPC_FABS(W.ax[p]) > xsc ? QPC_FABS(W.ax[p]) : xsc;
         const double tolx = st.tol_bound * (xsc > bscale ? xsc : bscale);
         int pp = -1;
         double viol = tolx, sg = 0.0;
-        for (int i = 0; i < m; i++) {
-          if (W.wsf[i] != 0.0) continue;
-          const double lo = l[i] > -INF ? l[i] - W.ax[i] : -1.0, hi = u[i] < INF ? W.ax[i] - u[i] : -1.0;
-          if (lo > viol) { viol = lo; pp = i; sg = -1.0; }
-          if (hi > viol) { viol = hi; pp = i; sg = 1.0; }
+        for (int p = 0; p < mi; p++) { // the most violated row (positions of a kind are in row order: ties go to the first row, like the one-lane form)
+          if (W.wsf[p] != 0.0) continue;
+          const double lo = W.lo[p] > -INF ? W.lo[p] - W.ax[p] : -1.0, hi = W.hi[p] < INF ? W.ax[p] - W.hi[p] : -1.0;
+          if (lo > viol) { viol = lo; pp = p; sg = -1.0; }
+          if (hi > viol) { viol = hi; pp = p; sg = 1.0; }
         }
         W.sc[WGS_P] = (double)pp; W.sc[WGS_VIOL] = viol; W.sc[WGS_SG] = sg;
       }
@@ -432,27 +500,24 @@ QPC_FN int qp_solve_wg(int n, int m, const double *P, const double *q, const dou
       if (pr < 0) { converged = true; break; }
       const double sg = W.sc[WGS_SG];
       bool infeasible = false, bail = false;
+      int k = nw; // LW is the factor of the current working set (left by wg_solve_ws)
       for (int inner = 0; inner <= m; inner++) {
-        const int k = wg_factor(W, st.eps_dual_reg, pr, W.tm, !W.blk); // r = (G_WW)^-1 G_Wp : a_p in terms of the working rows (H^-1 metric)
-        if (k < 0) { bail = true; break; }
+        // r = (C_WW)^-1 C_Wp : a_p in terms of the working rows (H^-1 metric, equality rows projected out)
+        QPC_WG_FOR(a, k) { W.tW[a] = W.S[wg_sym(ne + W.idxW[a], ne + pr, N1)]; }
+        QPC_WG_SYNC
+        wg_ldl_forward(W.LW, k + 1, k, W.dinvW, W.tW);
+        wg_ldl_back(W.LW, k + 1, k, W.dinvW, W.tW, W.dW);
         QPC_WG_T0 {
           double viol = W.sc[WGS_VIOL];
-          double d;
-          if (W.blk) { // Schur-complement identity: the same number from the inequality block alone
-            const int pp = W.ipos[pr];
-            d = W.Call[(long long)pp * W.mi + pp];
-            for (int a = W.ne; a < k; a++) d -= W.Call[(long long)pp * W.mi + W.ipos[W.idx[a]]] * W.tm[a];
-          } else {
-            d = W.G[(long long)pr * m + pr];
-            for (int a = 0; a < k; a++) d -= W.G[(long long)pr * m + W.idx[a]] * W.tm[a];
-          }
-          const bool dependent = !(d > 1e-11 * W.G[(long long)pr * m + pr]);
+          double d = W.S[wg_cs(ne + pr, N1)];
+          for (int a = 0; a < k; a++) d -= W.S[wg_sym(ne + pr, ne + W.idxW[a], N1)] * W.dW[a];
+          const bool dependent = !(d > 1e-11 * W.gdiag[ne + pr]);
           double t1 = 1e300; // dual ratio test: y_W(t) = y_W - t sg r must keep the sign of every working inequality
           int kd = -1;
           for (int a = 0; a < k; a++) {
-            const double w = W.wsf[W.idx[a]], sr = sg * W.tm[a];
-            if (w == 2.0 || W.sinvd[a] == 0.0) continue;
-            if ((w == 1.0 && sr > 1e-14) || (w == -1.0 && sr < -1e-14)) {
+            const double w = W.wsf[W.idxW[a]], sr = sg * W.dW[a];
+            if (W.dinvW[a] == 0.0) continue;
+            if ((w > 0.0 && sr > 1e-14) || (w < 0.0 && sr < -1e-14)) {
               double t = W.yw[a] / sr;
               t = t > 0.0 ? t : 0.0;
               if (t < t1) { t1 = t; kd = a; }
@@ -465,9 +530,9 @@ QPC_FN int qp_solve_wg(int n, int m, const double *P, const double *q, const dou
             if (t2 <= t1) outcome = 0;
             else {
               outcome = 1;
-              for (int a = 0; a < k; a++) W.yw[a] -= t1 * sg * W.tm[a];
+              for (int a = 0; a < k; a++) W.yw[a] -= t1 * sg * W.dW[a];
               if (!dependent) viol -= t1 * d;
-              W.wsf[W.idx[kd]] = 0.0;
+              W.wsf[W.idxW[kd]] = 0.0;
               for (int a = kd; a + 1 < k; a++) W.yw[a] = W.yw[a + 1];
             }
           }
@@ -477,96 +542,247 @@ QPC_FN int qp_solve_wg(int n, int m, const double *P, const double *q, const dou
         const int outcome = (int)W.sc[WGS_T];
         if (outcome == 2) { infeasible = true; break; }
         if (outcome == 0) break;
+        k = wg_w_factor(W, st.eps_dual_reg, false, kw); // a row left: the factor of what stays
+        if (k < 0) { bail = true; break; }
       }
       if (bail) return QPC_WG_FALLBACK;
       if (infeasible) { status = QPC_STATUS_INFEASIBLE; break; }
       QPC_WG_T0 { W.wsf[pr] = sg; }
       QPC_WG_SYNC
-      nw = wg_solve_ws(W, st.eps_dual_reg);
+      nw = wg_solve_ws(W, st.eps_dual_reg, kw);
       if (nw < 0) return QPC_WG_FALLBACK;
     }
   }
   if (!converged && status == QPC_STATUS_OPTIMAL) status = QPC_STATUS_ITERATION_LIMIT;
-  wg_finish_back(W, W.yw); // block mode: the multipliers of the equality rows, once
-  // ---- x = xu - Y_W y_W, then iterative refinement on the true KKT residuals of the final working set
-  QPC_WG_FOR(i, n) {
-    double t = 0.0;
-    for (int a = 0; a < nw; a++) t += A[(long long)W.idx[a] * n + i] * W.yw[a];
-    W.x[i] = W.xu[i] - W.hinv[i] * t;
+  QPC_WG_STAMP(W, 5);
+  // ---- the multipliers of the equality rows, once:  L11' yE = D^-1 (zE - (rows of W)' yW)
+  QPC_WG_FOR(j, ne) {
+    double t = W.S[wg_sidx(m, j, N1)];
+    for (int a = 0; a < nw; a++) t -= W.S[wg_sidx(ne + W.idxW[a], j, N1)] * W.yw[a];
+    W.tA[j] = t;
   }
+  QPC_WG_SYNC
+  wg_ldl_back(W.S, N1, ne, W.dinvE, W.tA, W.yE);
+  QPC_WG_STAMP(W, 6);
+  // ---- x = xu - H^-1 A' y, then iterative refinement on the true KKT residuals of the final working set.  yp: y by position
+  //      (the diagonal of G is not needed any more)
+  double *yp = W.gdiag;
+  QPC_WG_FOR(b, m) { yp[b] = b < ne ? W.yE[b] : 0.0; }
+  QPC_WG_SYNC
+  QPC_WG_FOR(a, nw) { yp[ne + W.idxW[a]] = W.yw[a]; }
+  QPC_WG_SYNC
+  QPC_WG_FOR(i, n) { W.x[i] = W.xu[i] - W.hinv[i] * wg_col_dot(W, i, yp); }
   QPC_WG_SYNC
   double rp = 0.0, rs = 0.0;
   for (int sweep = 0; sweep <= st.max_refine_iters; sweep++) {
-    QPC_WG_FOR(i, n) {
-      double t = q[i] + P[(long long)i * n + i] * W.x[i];
-      for (int a = 0; a < nw; a++) t += A[(long long)W.idx[a] * n + i] * W.yw[a];
+    double a_rs = 0.0, a_rp = 0.0;
+    QPC_WG_FOR(i, n) { // r1 = -(q + P x + A' y)
+      const double t = W.q[i] + W.P[(long long)i * n + i] * W.x[i] + wg_col_dot(W, i, yp);
       W.r1[i] = -t;
+      a_rs = (QPC_FABS(t) > a_rs || !(t == t)) ? QPC_FABS(t) : a_rs;
     }
-    QPC_WG_FOR(a, nw) {
-      const int ia = W.idx[a];
-      double t = W.bw[a];
-      for (int o = W.rowptr[ia]; o < W.rowptr[ia + 1]; o++) t -= W.val[o] * W.x[W.col[o]];
-      W.tm[a] = t; // r2
-    }
-    QPC_WG_SYNC
-    QPC_WG_T0 {
-      double a_rs = 0.0, a_rp = 0.0;
-      for (int i = 0; i < n; i++) a_rs = QPC_FABS(W.r1[i]) > a_rs || !(W.r1[i] == W.r1[i]) ? QPC_FABS(W.r1[i]) : a_rs;
-      for (int a = 0; a < nw; a++) a_rp = QPC_FABS(W.tm[a]) > a_rp || !(W.tm[a] == W.tm[a]) ? QPC_FABS(W.tm[a]) : a_rp;
-      W.sc[WGS_RS] = a_rs; W.sc[WGS_RP] = a_rp;
-    }
-    QPC_WG_SYNC
-    rs = W.sc[WGS_RS]; rp = W.sc[WGS_RP];
-    if (sweep == st.max_refine_iters) break;
-    // dy = S^-1 (Y_W' r1 - r2) ; dx = H^-1 (r1 - A_W' dy)
-    QPC_WG_FOR(a, nw) {
-      const int ia = W.idx[a];
-      double t = -W.tm[a];
-      for (int o = W.rowptr[ia]; o < W.rowptr[ia + 1]; o++) { const int c = W.col[o]; t += W.val[o] * W.hinv[c] * W.r1[c]; }
-      W.ax[a] = t;
-    }
-    QPC_WG_SYNC
-    wg_factor_solve(W, W.ax, nw);
-    QPC_WG_FOR(i, n) {
-      double t = W.r1[i];
-      for (int a = 0; a < nw; a++) t -= A[(long long)W.idx[a] * n + i] * W.ax[a];
-      W.r1[i] = W.hinv[i] * t; // dx
-      W.x[i] += W.r1[i];
-    }
-    QPC_WG_FOR(a, nw) { W.yw[a] += W.ax[a]; }
-    QPC_WG_SYNC
-    QPC_WG_T0 {
-      double big = 0.0, dbig = 0.0;
-      for (int i = 0; i < n; i++) {
-        big = QPC_FABS(W.x[i]) > big ? QPC_FABS(W.x[i]) : big;
-        dbig = QPC_FABS(W.r1[i]) > dbig ? QPC_FABS(W.r1[i]) : dbig;
+    QPC_WG_FOR(b, m) { // r2 = b_W - A_W x, by position (the rows outside the working set: 0)
+      const int p = b - ne;
+      double t = 0.0;
+      if (b < ne || W.wsf[p] != 0.0) {
+        t = (b < ne ? W.l[W.perm[b]] : (W.wsf[p] > 0.0 ? W.hi[p] : W.lo[p])) - wg_row_dot(W, b, W.x);
+        a_rp = (QPC_FABS(t) > a_rp || !(t == t)) ? QPC_FABS(t) : a_rp;
       }
-      W.sc[WGS_BIG] = big; W.sc[WGS_DBIG] = dbig;
+      W.tA[b] = t;
     }
     QPC_WG_SYNC
-    if (sweep > 0 && !(W.sc[WGS_DBIG] > 1e-13 * (1.0 + W.sc[WGS_BIG]))) sweep = st.max_refine_iters - 1;
-  }
-  QPC_WG_T0 {
-    double ysc = 1.0, qsc = 1.0;
-    for (int a = 0; a < nw; a++) ysc = QPC_FABS(W.yw[a]) > ysc ? QPC_FABS(W.yw[a]) : ysc;
-    for (int i = 0; i < n; i++) qsc = QPC_FABS(q[i]) > qsc ? QPC_FABS(q[i]) : qsc;
-    W.sc[WGS_YSC] = ysc; W.sc[WGS_XSC] = qsc;
-  }
-  QPC_WG_SYNC
-  {
-    const double ysc = W.sc[WGS_YSC], qsc = W.sc[WGS_XSC];
-    if (status == QPC_STATUS_OPTIMAL) {
-      if (!(rp == rp) || !(rs == rs)) status = QPC_STATUS_NUMERICAL_ERROR;
-      else if (rp > 1e-7 * bscale) status = QPC_STATUS_INFEASIBLE;
-      else if (rs > 1e-7 * (ysc > qsc ? ysc : qsc)) status = QPC_STATUS_ALMOST_OPTIMAL;
+    rs = wg_reduce_max(a_rs, W.red);
+    rp = wg_reduce_max(a_rp, W.red);
+#ifdef QPC_WG_DEBUG_REFINE
+    printf("sweep %d rs %.3e rp %.3e bscale %.3e\n", sweep, rs, rp, bscale);
+#endif
+    if (sweep == st.max_refine_iters) break;
+    // dy = K^-1 (A_W H^-1 r1 - r2) ; dx = H^-1 (r1 - A_W' dy)
+    QPC_WG_FOR(i, n) { W.xu[i] = W.hinv[i] * W.r1[i]; }    // xu is free from here on: H^-1 r1
+    QPC_WG_SYNC
+    QPC_WG_FOR(b, m) {
+      const int p = b - ne;
+      if (b < ne || W.wsf[p] != 0.0) {
+        const double t = wg_row_dot(W, b, W.xu) - W.tA[b];
+        if (b < ne) W.tE[b] = t; else W.tm[p] = t;
+      }
     }
+    QPC_WG_SYNC
+    QPC_WG_FOR(a, nw) { W.tW[a] = W.tm[W.idxW[a]]; }
+    QPC_WG_SYNC
+    wg_block_solve(W, nw, W.tE, W.dW);
+    QPC_WG_FOR(b, m) { W.tA[b] = b < ne ? W.tE[b] : 0.0; } // dy by position
+    QPC_WG_SYNC
+    QPC_WG_FOR(a, nw) { W.tA[ne + W.idxW[a]] = W.dW[a]; }
+    QPC_WG_SYNC
+    double a_big = 0.0, a_dbig = 0.0;
+    QPC_WG_FOR(i, n) {
+      const double dx = W.hinv[i] * (W.r1[i] - wg_col_dot(W, i, W.tA));
+      const double xi = W.x[i] + dx;
+      W.x[i] = xi;
+      a_big = QPC_FABS(xi) > a_big ? QPC_FABS(xi) : a_big;
+      a_dbig = QPC_FABS(dx) > a_dbig ? QPC_FABS(dx) : a_dbig;
+    }
+    QPC_WG_FOR(b, m) { yp[b] += W.tA[b]; }
+    QPC_WG_SYNC
+    const double big = wg_reduce_max(a_big, W.red), dbig = wg_reduce_max(a_dbig, W.red);
+    if (sweep > 0 && !(dbig > 1e-12 * (1.0 + big))) break; // (the residuals of this sweep -- before a correction of that size -- are reported)
+  }
+  QPC_WG_STAMP(W, 7);
+  double a_ysc = 1.0, a_qsc = 1.0;
+  QPC_WG_FOR(b, m) { a_ysc = QPC_FABS(yp[b]) > a_ysc ? QPC_FABS(yp[b]) : a_ysc; }
+  QPC_WG_FOR(i, n) { a_qsc = QPC_FABS(W.q[i]) > a_qsc ? QPC_FABS(W.q[i]) : a_qsc; }
+  const double ysc = wg_reduce_max(a_ysc, W.red), qsc = wg_reduce_max(a_qsc, W.red);
+  if (status == QPC_STATUS_OPTIMAL) {
+    if (!(rp == rp) || !(rs == rs)) status = QPC_STATUS_NUMERICAL_ERROR;
+    else if (rp > 1e-7 * bscale) status = QPC_STATUS_INFEASIBLE;
+    else if (rs > 1e-7 * (ysc > qsc ? ysc : qsc)) status = QPC_STATUS_ALMOST_OPTIMAL;
   }
   QPC_WG_FOR(i, n) { x[i] = W.x[i]; }
-  QPC_WG_FOR(i, m) { y[i] = 0.0; }
-  QPC_WG_SYNC
-  QPC_WG_FOR(a, nw) { y[W.idx[a]] = W.yw[a]; }
+  QPC_WG_FOR(b, m) { y[W.perm[b]] = yp[b]; }
   QPC_WG_T0 { if (iters_out) iters_out[0] = iters; }
+  QPC_WG_STAMP(W, 8);
   return status;
+}
+
+// returns the status (QPC_STATUS_*), or QPC_WG_FALLBACK when the problem is outside what this kernel handles.
+// lds: lds_cap doubles (QPC_WG_LDS_DOUBLES on the device); ws: the global workspace of qp_solve_dense (qp_dense_workspace_doubles).
+QPC_FN int qp_solve_wg(int n, int m, const double *P, const double *q, const double *A, const double *l, const double *u,
+                       const qpc_settings &st, double *ws, double *lds, int lds_cap, double *x, double *y, int32_t *iters_out) {
+  const double INF = 1e19;
+  if (n > QPC_WG_DIM || m > QPC_WG_DIM || n < 1 || m < 1) return QPC_WG_FALLBACK;
+  QpWg W;
+  W.n = n; W.m = m; W.N1 = m + 1; W.P = P; W.q = q; W.A = A; W.l = l; W.u = u;
+  const int nS = (m + 1) * (m + 2) / 2;
+  // global workspace: [AT n x m | S if it does not fit in LDS | cval | crow | stamps]
+  W.AT = ws;
+  double *Sg = ws + (long long)n * m;
+  W.cval = Sg + nS;
+  W.stamps = (unsigned long long *)(ws + qp_dense_workspace_doubles(n, m) - 16);
+  QPC_WG_STAMP(W, 0);
+  // LDS, first part (what does not depend on the number of equality rows)
+  double *p = lds;
+  W.sc = p; p += 16; W.red = p; p += 8;
+  W.hinv = p; p += n; W.xu = p; p += n; W.x = p; p += n; W.r1 = p; p += n;
+  W.gdiag = p; p += m + 1; W.tA = p; p += m + 1;
+  W.perm = (int *)p; W.ipos = W.perm + m; p += m;
+  W.cptr = (int *)p; p += (n + 2) / 2;
+  if ((int)(p - lds) + (n + 2) / 2 > lds_cap) return QPC_WG_FALLBACK;
+  int *ccnt = (int *)p; // (scratch of the set-up: nonzeros per column; in the part carved below)
+  // ---- structure: P diagonal (as many nonzeros in P as on its diagonal); nonzeros of A per column (a thread per column: coalesced,
+  //      eight rows in flight); equality rows
+  QPC_WG_T0 { for (int i = 0; i < WGS_COUNT; i++) W.sc[i] = 0.0; }
+  double a_h = 0.0, a_b = 1.0, a_nz = 0.0;
+  {
+    const int nn = n * n;
+    for (int e0 = QPC_WG_TID; e0 < nn; e0 += 8 * QPC_WG_NT) {
+      double v[8];
+#pragma unroll
+      for (int u8 = 0; u8 < 8; u8++) { const int e = e0 + u8 * QPC_WG_NT; v[u8] = P[e < nn ? e : e0]; }
+#pragma unroll
+      for (int u8 = 0; u8 < 8; u8++) a_nz += (e0 + u8 * QPC_WG_NT < nn && v[u8] != 0.0) ? 1.0 : 0.0;
+    }
+  }
+  QPC_WG_FOR(i, n) {
+    const double d = P[(long long)i * n + i], a = QPC_FABS(d);
+    a_h = a > a_h ? a : a_h;
+    a_nz -= d != 0.0 ? 1.0 : 0.0;
+    int c = 0, r = 0;
+    for (; r + 8 <= m; r += 8) {
+      const double *a8 = A + (long long)r * n + i;
+      const double v0 = a8[0], v1 = a8[n], v2 = a8[2 * n], v3 = a8[3 * n], v4 = a8[4 * n], v5 = a8[5 * n], v6 = a8[6 * n], v7 = a8[7 * n];
+      c += (v0 != 0.0) + (v1 != 0.0) + (v2 != 0.0) + (v3 != 0.0) + (v4 != 0.0) + (v5 != 0.0) + (v6 != 0.0) + (v7 != 0.0);
+    }
+    for (; r < m; r++) c += A[(long long)r * n + i] != 0.0 ? 1 : 0;
+    ccnt[i] = c;
+  }
+  QPC_WG_FOR(i, m) {
+    const double li = l[i], ui = u[i];
+    const bool lo = li > -INF, hi = ui < INF;
+    W.tA[i] = (lo && hi && ui - li <= 1e-12 * (1.0 + QPC_FABS(li))) ? 1.0 : 0.0;
+    if (lo) a_b = QPC_FABS(li) > a_b ? QPC_FABS(li) : a_b;
+    if (hi) a_b = QPC_FABS(ui) > a_b ? QPC_FABS(ui) : a_b;
+  }
+  QPC_WG_SYNC
+  const double hmax = wg_reduce_max(a_h, W.red), bscale = wg_reduce_max(a_b, W.red);
+  // (a_nz: this thread's count of nonzeros of P minus its diagonal ones; the per-thread values need not vanish one by one, their sum must:
+  //  max and min of the partial sums are not enough -- so the threads add them up in LDS, in integers)
+  QPC_WG_ADD(&W.sc[WGS_FLAG], a_nz); // (small integers in doubles: exact in any order)
+  QPC_WG_FOR(i, m) { // equality rows first: the position of a row = the rows of its kind before it
+    int e = 0;
+    for (int o = 0; o < i; o++) e += W.tA[o] != 0.0 ? 1 : 0;
+    const bool eq = W.tA[i] != 0.0;
+    if (i == m - 1) W.sc[WGS_NE] = (double)(e + (eq ? 1 : 0));
+    W.gdiag[i] = (double)(eq ? e : -(i - e) - 1); // position among its kind (the others: encoded negative, shifted by ne below)
+  }
+  QPC_WG_FOR(c, n + 1) { // column starts
+    int o = 0;
+    for (int c2 = 0; c2 < c && c2 < n; c2++) o += ccnt[c2];
+    W.cptr[c] = o;
+    if (c == n) W.sc[WGS_NNZ] = (double)o;
+  }
+  QPC_WG_SYNC
+  if (W.sc[WGS_FLAG] != 0.0) return QPC_WG_FALLBACK;
+  const int ne = (int)W.sc[WGS_NE], mi = m - ne, nnz = (int)W.sc[WGS_NNZ];
+  W.ne = ne; W.mi = mi;
+  W.crow = (int *)(W.cval + nnz);
+  QPC_WG_FOR(i, m) {
+    const double g = W.gdiag[i];
+    const int pos = g >= 0.0 ? (int)g : ne + (int)(-g - 1.0);
+    W.perm[pos] = i; W.ipos[i] = pos;
+  }
+  // LDS, second part
+  W.lo = p; p += mi; W.hi = p; p += mi;
+  double *scratch = p; // from here to the end of LW: free during the set-up (the staged columns of A)
+  W.dinvE = p; p += ne; W.yE = p; p += ne; W.tE = p; p += ne;
+  W.wsf = p; p += mi; W.tm = p; p += mi; W.ax = p; p += mi; W.a0 = p; p += mi;
+  const int kw = mi < QPC_WG_KW ? mi : QPC_WG_KW;
+  W.yw = p; p += kw + 1; W.dinvW = p; p += kw + 1; W.dW = p; p += kw + 1; W.tW = p; p += kw + 1;
+  W.idxW = (int *)p; p += (kw + 2) / 2;
+  W.LW = p; p += (kw + 1) * (kw + 2) / 2;
+  if ((int)(p - lds) > lds_cap) return QPC_WG_FALLBACK;
+  const bool s_in_lds = (int)(p - lds) + nS <= lds_cap;
+  const bool stage = nnz + (nnz + 1) / 2 <= (int)(p - scratch);
+  QPC_WG_SYNC // (ccnt lies in what has just been carved: every thread is past reading it; perm / ipos are complete)
+  const double eps = st.eps_primal_reg * (hmax > 0.0 ? hmax : 1.0);
+  double *lval = scratch;
+  int *lrow = (int *)(scratch + nnz);
+  QPC_WG_FOR(c, n) { // the compressed columns: row POSITIONS and values, in row order
+    int o = W.cptr[c];
+    for (int r = 0; r < m; r += 8) {
+      double v[8];
+#pragma unroll
+      for (int u8 = 0; u8 < 8; u8++) v[u8] = A[(long long)(r + u8 < m ? r + u8 : r) * n + c];
+#pragma unroll
+      for (int u8 = 0; u8 < 8; u8++) {
+        if (r + u8 < m && v[u8] != 0.0) {
+          const int pos = W.ipos[r + u8];
+          W.cval[o] = v[u8]; W.crow[o] = pos;
+          if (stage) { lval[o] = v[u8]; lrow[o] = pos; }
+          o++;
+        }
+      }
+    }
+    const double h = 1.0 / (P[(long long)c * n + c] + eps);
+    W.hinv[c] = h;
+    W.xu[c] = -q[c] * h;
+  }
+  QPC_WG_FOR(i, m) {
+    const int pos = W.ipos[i];
+    if (pos >= ne) { W.lo[pos - ne] = l[i]; W.hi[pos - ne] = u[i]; }
+  }
+  QPC_WG_FOR(e, n * m) { W.AT[e] = 0.0; }
+  QPC_WG_SYNC
+  QPC_WG_FOR(c, n) {
+    for (int o = W.cptr[c]; o < W.cptr[c + 1]; o++) W.AT[(long long)c * m + W.crow[o]] = W.cval[o];
+  }
+  W.sval = stage ? lval : W.cval;
+  W.srow = stage ? lrow : W.crow;
+  QPC_WG_SYNC
+  QPC_WG_STAMP(W, 1);
+  if (s_in_lds) { W.S = p; return qp_solve_wg_core(W, st, bscale, kw, x, y, iters_out); }
+  W.S = Sg;
+  return qp_solve_wg_core(W, st, bscale, kw, x, y, iters_out);
 }
 
 } // namespace qpc

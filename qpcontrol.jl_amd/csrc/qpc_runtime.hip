@@ -35,17 +35,25 @@
 
 // L0, first pass: one WORKGROUP per dense QP, working matrices in LDS (qpc_qp_wg.h): the problems Parametron builds for this
 // controller (diagonal P, sparse A).  status[b] = QPC_WG_FALLBACK marks a QP it leaves to the one-lane kernel below.
-extern "C" __global__ void __launch_bounds__(256)
+extern "C" __global__ void __launch_bounds__(QPC_WG_THREADS)
 qpc_qp_wg_kernel(int n, int m, long long B, const double *P, const double *q, const double *A, const double *l,
                  const double *u, qpc_settings st, double *ws, long long ws_stride, double *x, double *y,
                  int32_t *status, int32_t *iters) {
   extern __shared__ __attribute__((aligned(16))) double qpc_wg_lds[];
   for (long long b = blockIdx.x; b < B; b += gridDim.x) {
     const int s = qpc::qp_solve_wg(n, m, P + b * n * n, q + b * n, A + b * m * n, l + b * m, u + b * m, st,
-                                   ws + b * ws_stride, qpc_wg_lds, x + b * n, y + b * m,
+                                   ws + b * ws_stride, qpc_wg_lds, QPC_WG_LDS_DOUBLES, x + b * n, y + b * m,
                                    iters ? iters + b : nullptr);
     if (threadIdx.x == 0) status[b] = s;
     __syncthreads();
+#ifdef QPC_WG_PROF // phase stamps of the first QP (100 MHz ticks -> us): set-up, S build, elimination, sweeps, Goldfarb-Idnani, yE, refinement
+    if (threadIdx.x == 0 && b == 0) {
+      const unsigned long long *t = (const unsigned long long *)(ws + qpc::qp_dense_workspace_doubles(n, m) - 16);
+      printf("wg_prof status %d us:", s);
+      for (int k = 1; k <= 8; k++) printf(" %.1f", (double)(t[k] - t[k - 1]) * 0.01);
+      printf(" total %.1f\n", (double)(t[8] - t[0]) * 0.01);
+    }
+#endif
   }
 }
 
@@ -1053,7 +1061,7 @@ int32_t qpc_qp_solve_batch_device(int32_t n, int32_t m, int64_t B, const double 
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device_id));
     const long long grid = B < (long long)prop.multiProcessorCount * 4 ? B : (long long)prop.multiProcessorCount * 4;
-    hipLaunchKernelGGL(qpc_qp_wg_kernel, dim3((unsigned)grid), dim3(256), (size_t)lds_bytes, (hipStream_t)hip_stream, (int)n, (int)m,
+    hipLaunchKernelGGL(qpc_qp_wg_kernel, dim3((unsigned)grid), dim3(QPC_WG_THREADS), (size_t)lds_bytes, (hipStream_t)hip_stream, (int)n, (int)m,
                        (long long)B, P, q, A, l, u, st, (double *)workspace, (long long)qpc::qp_dense_workspace_doubles(n, m), x, y,
                        status, iters);
     HIP_TRY(hipGetLastError());

@@ -386,11 +386,13 @@ int32_t qpc_qp_solve_batch(int32_t n, int32_t m, int64_t B, const double *P, con
   // like the device: the workgroup form first (qpc_qp_wg.h, here one serial "thread"), the one-lane form on what it leaves
   std::vector<double> ws(qpc::qp_dense_workspace_doubles(n, m)), lds(qpc::qp_wg_lds_doubles(n, m));
   const char *one = getenv("QPC_L0_ONE_LANE");
+  const char *cap = getenv("QPC_EMU_WG_LDS"); // test hook: a smaller "LDS" sends the big matrix of the workgroup form to its global workspace
+  const int lds_cap = cap ? atoi(cap) : (int)lds.size();
   for (int64_t b = 0; b < B; b++) {
     int s = QPC_WG_FALLBACK;
     if (m > 0 && !(one && one[0] == '1'))
       s = qpc::qp_solve_wg(n, m, P + b * n * n, q + b * n, A + b * m * n, l + b * m, u + b * m, st,
-                           ws.data(), lds.data(), x + b * n, y + b * m, iters ? iters + b : nullptr);
+                           ws.data(), lds.data(), lds_cap, x + b * n, y + b * m, iters ? iters + b : nullptr);
     g_l0_wg += s != QPC_WG_FALLBACK;
     if (s != QPC_WG_FALLBACK) status[b] = s;
     else qpc::qp_solve_dense(n, m, P + b * n * n, q + b * n, A + b * m * n, l + b * m, u + b * m, st, ws.data(), x + b * n,
