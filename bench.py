@@ -20,8 +20,9 @@ Prints ONE JSON line on rank 0.  Beside the headline (device-resident, timed reg
                      itself runs on Atlas: notebook tolerances (1e-5), closed loop at 1 kHz, OSQP warm-started from the
                      previous tick, all cores.  Beside it: `notebook_cold`, `tight_cold` (test-suite tolerances 1e-8, cold: the
                      setting the 1e-8 parity is judged against), `tight_warm_closed_loop`
-  config.l0_plugin   the solver-level plug (b-1, qpc_qp_solve_batch on the dense 143 x 178 problem): latency at B = 1, rate at
-                     a larger batch (tools/bench_latency.py --l0)
+  config.l0_plugin   the solver-level plug (b-1) on the 143 x 178 Atlas problem: latency at B = 1 and rate at a larger batch of the dense
+                     entry qpc_qp_solve_batch and of the prepared entry qpc_qp_setup / qpc_qp_solve (cold and warm-started) that
+                     QPCOptimizer binds (tools/bench_latency.py --l0)
   degraded           true when a secondary measurement failed or solved < 90 % of its QPs (the line itself stays alive)
 """
 import argparse
@@ -373,7 +374,9 @@ def l0_plugin_point():
         return {"n": d["n"], "m": d["m"], "latency_us_B1": d["1"]["median_us"], "latency_us_B1_median_over_problems": d.get("B1_median_over_problems_us"),
                 "latency_us_B1_worst_problem": d.get("B1_worst_problem_us"), "solves_per_s_B1024": d["1024"]["solves_per_s"],
                 "max_abs_err_vdot_vs_fixture": max(d["1"]["max_abs_err_vdot_vs_fixture"], d["1024"]["max_abs_err_vdot_vs_fixture"]),
-                "kernel": d.get("kernel")}
+                # the optimizer's life cycle (qpc_qp_setup once, qpc_qp_solve per tick: values only, warm start): what QPCOptimizer binds
+                "prepared": {k: v for k, v in d.get("prepared", {}).items() if k != "B1_per_problem"},
+                "reference_cpu_osqp_warm_tick_us": "800-1300 (cpu_baseline.warm_start.single_core)"}
     except Exception as e:  # noqa: BLE001 -- a diagnostic extra must never take the bench line down
         return {"error": repr(e)}
 

@@ -464,6 +464,28 @@ int32_t qpc_qp_solve_batch_device(int32_t n, int32_t m, int64_t B, const double 
                                   double *y, int32_t *status, int32_t *iters, void *workspace,
                                   uint64_t workspace_bytes, void *hip_stream);
 
+/* L0 with the OPTIMIZER'S LIFE CYCLE -- what `QPCOptimizer <: MOI.AbstractOptimizer` (julia/QPControlHIPMOI.jl) binds.  Parametron
+ * hands the model to the optimizer once (`MOI.copy_to`: a fixed sparsity pattern) and before every `MOI.optimize!` rewrites the
+ * coefficients in place (momentum.jl:58 `solve!`); OSQP, the reference's optimizer (test/runtests.jl:35-43), splits the work the same
+ * way (osqp_setup / osqp_update_* / osqp_solve, warm-started by the previous solution).
+ *   qpc_qp_setup: the PATTERN, 0-based COO, entries unique.  P: a symmetric matrix, an entry (i, j), i != j, stands for P_ij = P_ji
+ *     (give one triangle, as OSQP does); a pattern with diagonal entries only is what the workgroup solver takes -- what Parametron
+ *     builds for this controller -- anything else runs through the dense entry.  A: m x n.  Everything that depends on the pattern
+ *     alone (compressed columns and rows, the structure of A H^-1 A') is computed here, once, and kept on device `device_id`.
+ *   qpc_qp_solve: B QPs with that pattern: P_vals[nnz_P*B], A_vals[nnz_A*B] in the pattern's order (QP-major), q[n*B], l[m*B],
+ *     u[m*B]; out as qpc_qp_solve_batch.  warm_start != 0: the working set starts from the multipliers of the previous call (QP b
+ *     from QP b; ignored on the first call or when the previous batch was smaller).  Host pointers, synchronous; one call at a
+ *     time per problem.  13 KB per QP cross the bus for the 143 x 178 Atlas problem (dense entry: 368 KB). */
+typedef struct qpc_qp_problem qpc_qp_problem;
+int32_t qpc_qp_setup(int32_t n, int32_t m, int64_t nnz_P, const int32_t *P_rows, const int32_t *P_cols,
+                     int64_t nnz_A, const int32_t *A_rows, const int32_t *A_cols, int32_t device_id,
+                     qpc_qp_problem **out);
+int32_t qpc_qp_solve(qpc_qp_problem *problem, int64_t B, const double *P_vals, const double *q,
+                     const double *A_vals, const double *l, const double *u,
+                     const qpc_settings *settings, int32_t warm_start, double *x, double *y,
+                     int32_t *status, int32_t *iters);
+void qpc_qp_free(qpc_qp_problem *problem);
+
 /* ---- closed loop: what the reference's acceptance test does around the tick,
  *      notebooks/Standing controller.ipynb cells 9-11 -- `Dynamics(mechanism, controller)` with a
  *      soft contact model, stepped by RigidBodySim `simulate` -- for a batch of robots on the device.

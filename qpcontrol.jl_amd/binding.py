@@ -95,6 +95,11 @@ def load_library(path=None):
         L.qpc_kernel_fingerprint.restype = ctypes.c_char_p
     L.qpc_qp_solve_batch.argtypes = [i32, i32, i64] + [c_double_p] * 5 + [ctypes.POINTER(Settings), i32, c_double_p,
                                                                          c_double_p, c_int32_p, c_int32_p]
+    if hasattr(L, "qpc_qp_setup"):
+        L.qpc_qp_setup.argtypes = [i32, i32, i64, c_int32_p, c_int32_p, i64, c_int32_p, c_int32_p, i32, ctypes.POINTER(vp)]
+        L.qpc_qp_solve.argtypes = [vp, i64] + [c_double_p] * 5 + [ctypes.POINTER(Settings), i32, c_double_p, c_double_p, c_int32_p, c_int32_p]
+        L.qpc_qp_free.argtypes = [vp]
+        L.qpc_qp_free.restype = None
     L.qpc_assemble_solve_batch.argtypes = [vp, i64] + [c_double_p] * 11 + [c_double_p, c_double_p, c_int32_p, c_int32_p]
     L.qpc_sim_step_batch.argtypes = [vp, i64, c_double_p, c_double_p, c_double_p, c_int32_p, ctypes.POINTER(SimParams), c_int32_p]
     L.qpc_rollout_batch.argtypes = [vp, i64, i64] + [c_double_p] * 7 + [ctypes.POINTER(SimParams), c_double_p, c_int32_p, c_int32_p]
@@ -431,3 +436,68 @@ def qp_solve_batch(P, q, A, l, u, device_id=0, lib_path=None, **settings):
                               _dp(y), status.ctypes.data_as(c_int32_p), iters.ctypes.data_as(c_int32_p))
     _check(L, rc, "qpc_qp_solve_batch")
     return dict(x=x, y=y[:, :m], status=status, iters=iters)
+
+
+class QpProblem:
+    """L0 with the optimizer's life cycle (qpc_qp_setup / qpc_qp_solve / qpc_qp_free, include/qpc.h): the sparsity pattern once,
+    values every call, warm start from the previous call's multipliers.
+    pattern_P / pattern_A: boolean masks [n,n] / [m,n] of the structural nonzeros (of P the upper triangle is taken), or pairs of
+    index arrays (rows, cols)."""
+
+    def __init__(self, n, m, pattern_P, pattern_A, device_id=0, lib_path=None):
+        self.L = load_library(lib_path)
+        self.n, self.m = int(n), int(m)
+
+        def coo(pat, upper):
+            if isinstance(pat, tuple):
+                r, c = np.asarray(pat[0], dtype=np.int32), np.asarray(pat[1], dtype=np.int32)
+            else:
+                pat = np.asarray(pat, dtype=bool)
+                if upper:
+                    pat = np.triu(pat | pat.T)
+                r, c = np.nonzero(pat)
+            return np.ascontiguousarray(r, dtype=np.int32), np.ascontiguousarray(c, dtype=np.int32)
+
+        self.P_rows, self.P_cols = coo(pattern_P, True)
+        self.A_rows, self.A_cols = coo(pattern_A, False)
+        self.h = ctypes.c_void_p()
+        rc = self.L.qpc_qp_setup(self.n, self.m, len(self.P_rows), self.P_rows.ctypes.data_as(c_int32_p),
+                                 self.P_cols.ctypes.data_as(c_int32_p), len(self.A_rows), self.A_rows.ctypes.data_as(c_int32_p),
+                                 self.A_cols.ctypes.data_as(c_int32_p), int(device_id), ctypes.byref(self.h))
+        _check(self.L, rc, "qpc_qp_setup")
+
+    def values(self, P, A):
+        """the value arrays of dense P[B,n,n], A[B,m,n] in the pattern's order"""
+        P, A = np.asarray(P, dtype=np.float64), np.asarray(A, dtype=np.float64)
+        if P.ndim == 2:
+            P, A = P[None], A[None]
+        return np.ascontiguousarray(P[:, self.P_rows, self.P_cols]), np.ascontiguousarray(A[:, self.A_rows, self.A_cols])
+
+    def solve(self, P_vals, q, A_vals, l, u, warm_start=False, **settings):
+        P_vals = np.ascontiguousarray(P_vals, dtype=np.float64).reshape(-1, len(self.P_rows))
+        B = P_vals.shape[0] if len(self.P_rows) else np.asarray(q).reshape(-1, self.n).shape[0]
+        A_vals = np.ascontiguousarray(A_vals, dtype=np.float64).reshape(B, len(self.A_rows))
+        q = np.ascontiguousarray(q, dtype=np.float64).reshape(B, self.n)
+        l = np.ascontiguousarray(np.clip(l, -1e20, 1e20), dtype=np.float64).reshape(B, self.m)
+        u = np.ascontiguousarray(np.clip(u, -1e20, 1e20), dtype=np.float64).reshape(B, self.m)
+        st = Settings()
+        self.L.qpc_default_settings(ctypes.byref(st))
+        for k, v in settings.items():
+            setattr(st, k, v)
+        x, y = np.zeros((B, self.n)), np.zeros((B, max(self.m, 1)))
+        status, iters = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
+        rc = self.L.qpc_qp_solve(self.h, B, _dp(P_vals), _dp(q), _dp(A_vals), _dp(l), _dp(u), ctypes.byref(st), int(bool(warm_start)),
+                                 _dp(x), _dp(y), status.ctypes.data_as(c_int32_p), iters.ctypes.data_as(c_int32_p))
+        _check(self.L, rc, "qpc_qp_solve")
+        return dict(x=x, y=y[:, :self.m], status=status, iters=iters)
+
+    def close(self):
+        if self.h:
+            self.L.qpc_qp_free(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

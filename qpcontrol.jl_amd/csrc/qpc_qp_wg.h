@@ -32,6 +32,7 @@
 // "thread", barriers are no-ops.
 #pragma once
 #include "../../include/qpc.h"
+#include "qpc_qp_view.h"
 
 #ifndef QPC_FN
 #error "include qpc_device.h (or the emulator's definitions) first"
@@ -267,6 +268,10 @@ struct QpWg {
   int *idxW;
   double *sc, *red;
   unsigned long long *stamps;
+  // prepared problem (qpc_qp_setup): the pattern's tables instead of the dense arrays (V == nullptr: dense input)
+  const QpPrepView *V;
+  const double *Pv;  // the caller's P values
+  const double *y0;  // warm start: multipliers of an earlier solve by ROW (their signs give the first working set), or nullptr
 };
 
 enum { WGS_FLAG = 0, WGS_K, WGS_CHANGES, WGS_T, WGS_P, WGS_VIOL, WGS_SG, WGS_NE, WGS_NNZ, WGS_COUNT };
@@ -275,6 +280,11 @@ enum { WGS_FLAG = 0, WGS_K, WGS_CHANGES, WGS_T, WGS_P, WGS_VIOL, WGS_SG, WGS_NE,
 QPC_FN double wg_row_dot(const QpWg &W, int pos, const double *w) {
   const int n = W.n, m = W.m;
   double t = 0.0;
+  if (W.V) { // prepared problem: the compressed row (short)
+    const int r = W.perm[pos];
+    for (int k = W.V->rptr[r]; k < W.V->rptr[r + 1]; k++) t += W.cval[W.V->ro[k]] * w[W.V->rcol[k]];
+    return t;
+  }
   int c = 0;
   for (; c + 8 <= n; c += 8) {
     const double *a = W.AT + (long long)c * m + pos;
@@ -284,6 +294,10 @@ QPC_FN double wg_row_dot(const QpWg &W, int pos, const double *w) {
   }
   for (; c < n; c++) t += W.AT[(long long)c * m + pos] * w[c];
   return t;
+}
+QPC_FN double wg_pdiag(const QpWg &W, int i) {
+  if (W.V) { const int k = W.V->pdiag[i]; return k >= 0 ? W.Pv[k] : 0.0; }
+  return W.P[(long long)i * W.n + i];
 }
 // (A' y)_c for y by position (a compressed column: short)
 QPC_FN double wg_col_dot(const QpWg &W, int c, const double *ypos) {
@@ -377,6 +391,19 @@ QPC_FN int qp_solve_wg_core(QpWg &W, const qpc_settings &st, double bscale, int 
   //      adds only into the entries it owns (by the smaller position): a fixed summation order without a barrier.
   QPC_WG_FOR(e, (m + 1) * (m + 2) / 2) { W.S[e] = 0.0; }
   QPC_WG_SYNC
+  if (W.V) { // prepared problem: a thread per structurally nonzero G_rs, its terms in the order the host laid down; a thread per row for g0
+    const QpPrepView &V = *W.V;
+    QPC_WG_FOR(pi, V.npairs) {
+      double acc = 0.0;
+      for (int t = V.pptr[pi]; t < V.pptr[pi + 1]; t++) acc += W.sval[V.ta[t]] * W.sval[V.tb[t]] * W.hinv[V.tc[t]];
+      W.S[wg_sym(W.ipos[V.pr[pi]], W.ipos[V.ps[pi]], N1)] = acc;
+    }
+    QPC_WG_FOR(r, m) {
+      double t = 0.0;
+      for (int k = V.rptr[r]; k < V.rptr[r + 1]; k++) t += W.sval[V.ro[k]] * W.xu[V.rcol[k]];
+      W.S[wg_sidx(m, W.ipos[r], N1)] = t;
+    }
+  } else
   for (int cg = 0; cg < n; cg += 4) { // four columns at a time: all their loads first, then their adds, in column order
     int o0[4], kk[4];
     double hh[4], xx[4];
@@ -435,12 +462,22 @@ QPC_FN int qp_solve_wg_core(QpWg &W, const qpc_settings &st, double bscale, int 
   QPC_WG_STAMP(W, 3);
   QPC_WG_FOR(p, mi) {
     W.a0[p] = W.S[wg_sidx(m, ne + p, N1)];
-    W.wsf[p] = 0.0;
+    double w = 0.0;
+    if (W.y0) { // warm start: the rows an earlier solution held at a bound
+      const double y0 = W.y0[W.perm[ne + p]];
+      w = (y0 > 0.0 && W.hi[p] < INF) ? 1.0 : ((y0 < 0.0 && W.lo[p] > -INF) ? -1.0 : 0.0);
+    }
+    W.wsf[p] = w;
   }
   QPC_WG_SYNC
   int status = QPC_STATUS_OPTIMAL, iters = 0;
   const int max_it = st.max_active_set_iters > 0 ? st.max_active_set_iters : 200;
-  int nw = wg_solve_ws(W, st.eps_dual_reg, kw); // the equality-only working set
+  int nw = wg_solve_ws(W, st.eps_dual_reg, kw); // the equality-only working set (or the warm start's)
+  if (nw < 0) { // (a warm start beyond what LW holds: start cold)
+    QPC_WG_FOR(p, mi) { W.wsf[p] = 0.0; }
+    QPC_WG_SYNC
+    nw = wg_solve_ws(W, st.eps_dual_reg, kw);
+  }
   bool converged = false;
   const int max_pdas = 12;
   // ---- primal-dual multi-change sweeps (qpc_qp_dense.h phase A), on the inequality rows
@@ -577,7 +614,7 @@ QPC_FN int qp_solve_wg_core(QpWg &W, const qpc_settings &st, double bscale, int 
   for (int sweep = 0; sweep <= st.max_refine_iters; sweep++) {
     double a_rs = 0.0, a_rp = 0.0;
     QPC_WG_FOR(i, n) { // r1 = -(q + P x + A' y)
-      const double t = W.q[i] + W.P[(long long)i * n + i] * W.x[i] + wg_col_dot(W, i, yp);
+      const double t = W.q[i] + wg_pdiag(W, i) * W.x[i] + wg_col_dot(W, i, yp);
       W.r1[i] = -t;
       a_rs = (QPC_FABS(t) > a_rs || !(t == t)) ? QPC_FABS(t) : a_rs;
     }
@@ -653,6 +690,7 @@ QPC_FN int qp_solve_wg(int n, int m, const double *P, const double *q, const dou
   if (n > QPC_WG_DIM || m > QPC_WG_DIM || n < 1 || m < 1) return QPC_WG_FALLBACK;
   QpWg W;
   W.n = n; W.m = m; W.N1 = m + 1; W.P = P; W.q = q; W.A = A; W.l = l; W.u = u;
+  W.V = nullptr; W.Pv = nullptr; W.y0 = nullptr;
   const int nS = (m + 1) * (m + 2) / 2;
   // global workspace: [AT n x m | S if it does not fit in LDS | cval | crow | stamps]
   W.AT = ws;
@@ -778,6 +816,101 @@ QPC_FN int qp_solve_wg(int n, int m, const double *P, const double *q, const dou
   }
   W.sval = stage ? lval : W.cval;
   W.srow = stage ? lrow : W.crow;
+  QPC_WG_SYNC
+  QPC_WG_STAMP(W, 1);
+  if (s_in_lds) { W.S = p; return qp_solve_wg_core(W, st, bscale, kw, x, y, iters_out); }
+  W.S = Sg;
+  return qp_solve_wg_core(W, st, bscale, kw, x, y, iters_out);
+}
+
+// The same for a PREPARED problem (qpc_qp_setup: the pattern's tables V, built once on the host): Pv / Av are the caller's values in
+// the pattern's order, y0 (or nullptr) the multipliers of an earlier solve for the warm start.  No dense matrix is read or built: the
+// set-up is the classification of the rows and a gather of the values.  V's P must be diagonal (the caller checks).
+QPC_FN int qp_solve_wg_prep(const QpPrepView &V, const double *Pv, const double *q, const double *Av, const double *l, const double *u,
+                            const qpc_settings &st, double *ws, double *lds, int lds_cap, const double *y0, double *x, double *y,
+                            int32_t *iters_out) {
+  const double INF = 1e19;
+  const int n = V.n, m = V.m, nnz = V.nnzA;
+  if (n > QPC_WG_DIM || m > QPC_WG_DIM || n < 1 || m < 1) return QPC_WG_FALLBACK;
+  QpWg W;
+  W.n = n; W.m = m; W.N1 = m + 1; W.P = nullptr; W.q = q; W.A = nullptr; W.l = l; W.u = u;
+  W.V = &V; W.Pv = Pv; W.y0 = y0;
+  const int nS = (m + 1) * (m + 2) / 2;
+  W.AT = ws; // (not used)
+  double *Sg = ws + (long long)n * m;
+  W.cval = Sg + nS;
+  W.crow = (int *)(W.cval + nnz);
+  W.stamps = (unsigned long long *)(ws + qp_dense_workspace_doubles(n, m) - 16);
+  QPC_WG_STAMP(W, 0);
+  double *p = lds;
+  W.sc = p; p += 16; W.red = p; p += 8;
+  W.hinv = p; p += n; W.xu = p; p += n; W.x = p; p += n; W.r1 = p; p += n;
+  W.gdiag = p; p += m + 1; W.tA = p; p += m + 1;
+  W.perm = (int *)p; W.ipos = W.perm + m; p += m;
+  W.cptr = (int *)p; p += (n + 2) / 2;
+  if ((int)(p - lds) > lds_cap) return QPC_WG_FALLBACK;
+  QPC_WG_T0 { for (int i = 0; i < WGS_COUNT; i++) W.sc[i] = 0.0; }
+  double a_h = 0.0, a_b = 1.0;
+  QPC_WG_FOR(i, n) {
+    const int k = V.pdiag[i];
+    const double a = k >= 0 ? QPC_FABS(Pv[k]) : 0.0;
+    a_h = a > a_h ? a : a_h;
+  }
+  QPC_WG_FOR(c, n + 1) { W.cptr[c] = V.cptr[c]; }
+  QPC_WG_FOR(i, m) {
+    const double li = l[i], ui = u[i];
+    const bool lo = li > -INF, hi = ui < INF;
+    W.tA[i] = (lo && hi && ui - li <= 1e-12 * (1.0 + QPC_FABS(li))) ? 1.0 : 0.0;
+    if (lo) a_b = QPC_FABS(li) > a_b ? QPC_FABS(li) : a_b;
+    if (hi) a_b = QPC_FABS(ui) > a_b ? QPC_FABS(ui) : a_b;
+  }
+  QPC_WG_SYNC
+  const double hmax = wg_reduce_max(a_h, W.red), bscale = wg_reduce_max(a_b, W.red);
+  QPC_WG_FOR(i, m) { // equality rows first: the position of a row = the rows of its kind before it
+    int e = 0;
+    for (int o = 0; o < i; o++) e += W.tA[o] != 0.0 ? 1 : 0;
+    const bool eq = W.tA[i] != 0.0;
+    if (i == m - 1) W.sc[WGS_NE] = (double)(e + (eq ? 1 : 0));
+    W.gdiag[i] = (double)(eq ? e : -(i - e) - 1);
+  }
+  QPC_WG_SYNC
+  const int ne = (int)W.sc[WGS_NE], mi = m - ne;
+  W.ne = ne; W.mi = mi;
+  QPC_WG_FOR(i, m) {
+    const double g = W.gdiag[i];
+    const int pos = g >= 0.0 ? (int)g : ne + (int)(-g - 1.0);
+    W.perm[pos] = i; W.ipos[i] = pos;
+  }
+  W.lo = p; p += mi; W.hi = p; p += mi;
+  double *scratch = p;
+  W.dinvE = p; p += ne; W.yE = p; p += ne; W.tE = p; p += ne;
+  W.wsf = p; p += mi; W.tm = p; p += mi; W.ax = p; p += mi; W.a0 = p; p += mi;
+  const int kw = mi < QPC_WG_KW ? mi : QPC_WG_KW;
+  W.yw = p; p += kw + 1; W.dinvW = p; p += kw + 1; W.dW = p; p += kw + 1; W.tW = p; p += kw + 1;
+  W.idxW = (int *)p; p += (kw + 2) / 2;
+  W.LW = p; p += (kw + 1) * (kw + 2) / 2;
+  if ((int)(p - lds) > lds_cap) return QPC_WG_FALLBACK;
+  const bool s_in_lds = (int)(p - lds) + nS <= lds_cap;
+  const bool stage = nnz <= (int)(p - scratch);
+  QPC_WG_SYNC
+  const double eps = st.eps_primal_reg * (hmax > 0.0 ? hmax : 1.0);
+  QPC_WG_FOR(o, nnz) { // the values in column order (global: the products of the final stage; LDS: the S build), rows as positions
+    const double v = Av[V.cperm[o]];
+    W.cval[o] = v; W.crow[o] = W.ipos[V.crow[o]];
+    if (stage) scratch[o] = v;
+  }
+  QPC_WG_FOR(c, n) {
+    const int k = V.pdiag[c];
+    const double h = 1.0 / ((k >= 0 ? Pv[k] : 0.0) + eps);
+    W.hinv[c] = h;
+    W.xu[c] = -q[c] * h;
+  }
+  QPC_WG_FOR(i, m) {
+    const int pos = W.ipos[i];
+    if (pos >= ne) { W.lo[pos - ne] = l[i]; W.hi[pos - ne] = u[i]; }
+  }
+  W.sval = stage ? scratch : W.cval;
+  W.srow = W.crow;
   QPC_WG_SYNC
   QPC_WG_STAMP(W, 1);
   if (s_in_lds) { W.S = p; return qp_solve_wg_core(W, st, bscale, kw, x, y, iters_out); }

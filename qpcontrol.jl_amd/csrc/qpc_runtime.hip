@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -31,6 +32,7 @@
 #include "qpc_sim.h"
 #include "qpc_qp_dense.h"
 #include "qpc_qp_wg.h"
+#include "qpc_qp_prep.h"
 #include "qpc_l1_dense.h"
 
 // L0, first pass: one WORKGROUP per dense QP, working matrices in LDS (qpc_qp_wg.h): the problems Parametron builds for this
@@ -54,6 +56,49 @@ qpc_qp_wg_kernel(int n, int m, long long B, const double *P, const double *q, co
       printf(" total %.1f\n", (double)(t[8] - t[0]) * 0.01);
     }
 #endif
+  }
+}
+
+// L0 for a prepared problem (qpc_qp_setup): the pattern's tables instead of dense matrices; y0: warm-start multipliers or nullptr
+extern "C" __global__ void __launch_bounds__(QPC_WG_THREADS)
+qpc_qp_wg_prep_kernel(qpc::QpPrepView V, long long B, long long nnzP, const double *Pv, const double *q, const double *Av,
+                      const double *l, const double *u, qpc_settings st, double *ws, long long ws_stride, const double *y0,
+                      double *x, double *y, int32_t *status, int32_t *iters) {
+  extern __shared__ __attribute__((aligned(16))) double qpc_wg_lds[];
+  for (long long b = blockIdx.x; b < B; b += gridDim.x) {
+#ifdef QPC_WG_PROF
+    const long long c0__ = clock64(), w0__ = wall_clock64();
+#endif
+    const int s = qpc::qp_solve_wg_prep(V, Pv + b * nnzP, q + b * V.n, Av + b * V.nnzA, l + b * V.m, u + b * V.m, st,
+                                        ws + b * ws_stride, qpc_wg_lds, QPC_WG_LDS_DOUBLES, y0 ? y0 + b * V.m : nullptr,
+                                        x + b * V.n, y + b * V.m, iters ? iters + b : nullptr);
+    if (threadIdx.x == 0) status[b] = s;
+    __syncthreads();
+#ifdef QPC_WG_PROF
+    if (threadIdx.x == 0 && b == 0) {
+      const unsigned long long *t = (const unsigned long long *)(ws + qpc::qp_dense_workspace_doubles(V.n, V.m) - 16);
+      printf("wg_prep_prof (shader clock %.0f MHz) status %d us:", (double)(clock64() - c0__) / ((double)(wall_clock64() - w0__) * 0.01), s);
+      for (int k = 1; k <= 8; k++) printf(" %.1f", (double)(t[k] - t[k - 1]) * 0.01);
+      printf(" total %.1f\n", (double)(t[8] - t[0]) * 0.01);
+    }
+#endif
+  }
+}
+// the dense matrices of the prepared problem's QPs (for the dense path: a P with off-diagonal entries, or a QP the workgroup left)
+extern "C" __global__ void qpc_qp_densify_kernel(int n, int m, long long B, long long nnzP, const int *Prow, const int *Pcol,
+                                                 const double *Pv, long long nnzA, const int *Arow, const int *Acol,
+                                                 const double *Av, double *P, double *A) {
+  const long long per = nnzP + nnzA, tot = per * B;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (long long)gridDim.x * blockDim.x) {
+    const long long b = e / per, k = e % per;
+    if (k < nnzP) {
+      const double v = Pv[b * nnzP + k];
+      P[b * n * n + (long long)Prow[k] * n + Pcol[k]] = v;
+      P[b * n * n + (long long)Pcol[k] * n + Prow[k]] = v;
+    } else {
+      const long long ka = k - nnzP;
+      A[b * m * n + (long long)Arow[ka] * n + Acol[ka]] = Av[b * nnzA + ka];
+    }
   }
 }
 
@@ -1127,6 +1172,163 @@ int32_t qpc_qp_solve_batch(int32_t n, int32_t m, int64_t B, const double *P, con
     if (iters) chk(hipMemcpyAsync(iters, dit, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, C.stream), "copy iters");
   }
   chk(hipStreamSynchronize(C.stream), "qpc_qp_dense_kernel");
+  return rc;
+}
+
+// ---- L0 with the optimizer's life cycle: pattern once (qpc_qp_setup), values every call (qpc_qp_solve), warm start from the previous
+//      call's multipliers (kept on the device)
+struct qpc_qp_problem {
+  qpc::QpPrepHost H;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int *d_ints = nullptr, *d_coo = nullptr; // the pattern's tables; the caller's COO pattern [Prow | Pcol | Arow | Acol]
+  char *buf = nullptr;                     // per-call slab (values, outputs, workspace), grown on demand
+  size_t bytes = 0;
+  double *d_yprev = nullptr;               // multipliers of the previous call, B_prev x m
+  int64_t B_prev = 0, cap_prev = 0;
+  char *dense = nullptr;                   // dense P, A of the batch (only when the dense path is needed)
+  size_t dense_bytes = 0;
+};
+
+int32_t qpc_qp_setup(int32_t n, int32_t m, int64_t nnz_P, const int32_t *P_rows, const int32_t *P_cols, int64_t nnz_A,
+                     const int32_t *A_rows, const int32_t *A_cols, int32_t device_id, qpc_qp_problem **out) {
+  if (!out || (nnz_P && (!P_rows || !P_cols)) || (nnz_A && (!A_rows || !A_cols))) { qpc_set_error("qpc_qp_setup: bad arguments"); return QPC_ERR_INVALID_ARGUMENT; }
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    (void)hipGetLastError();
+    qpc_set_error("qpc_qp_setup: no HIP device available (this library has no CPU fallback)");
+    return QPC_ERR_NO_DEVICE;
+  }
+  if (device_id < 0 || device_id >= ndev) { qpc_set_error("qpc_qp_setup: device_id out of range"); return QPC_ERR_NO_DEVICE; }
+  std::unique_ptr<qpc_qp_problem> p(new qpc_qp_problem);
+  const std::string err = qpc::qp_prep_build(p->H, n, m, nnz_P, P_rows, P_cols, nnz_A, A_rows, A_cols);
+  if (!err.empty()) { qpc_set_error("qpc_qp_setup: " + err); return QPC_ERR_INVALID_ARGUMENT; }
+  p->device = device_id;
+  HIP_TRY(hipSetDevice(device_id));
+  HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+  HIP_TRY(hipMalloc(&p->d_ints, p->H.ints.size() * sizeof(int)));
+  HIP_TRY(hipMemcpy(p->d_ints, p->H.ints.data(), p->H.ints.size() * sizeof(int), hipMemcpyHostToDevice));
+  std::vector<int> coo;
+  coo.insert(coo.end(), p->H.Prow.begin(), p->H.Prow.end()); coo.insert(coo.end(), p->H.Pcol.begin(), p->H.Pcol.end());
+  coo.insert(coo.end(), p->H.Arow.begin(), p->H.Arow.end()); coo.insert(coo.end(), p->H.Acol.begin(), p->H.Acol.end());
+  coo.push_back(0);
+  HIP_TRY(hipMalloc(&p->d_coo, coo.size() * sizeof(int)));
+  HIP_TRY(hipMemcpy(p->d_coo, coo.data(), coo.size() * sizeof(int), hipMemcpyHostToDevice));
+  *out = p.release();
+  return QPC_OK;
+}
+
+void qpc_qp_free(qpc_qp_problem *p) {
+  if (!p) return;
+  (void)hipSetDevice(p->device);
+  if (p->stream) { (void)hipStreamSynchronize(p->stream); (void)hipStreamDestroy(p->stream); }
+  if (p->d_ints) (void)hipFree(p->d_ints);
+  if (p->d_coo) (void)hipFree(p->d_coo);
+  if (p->buf) (void)hipFree(p->buf);
+  if (p->d_yprev) (void)hipFree(p->d_yprev);
+  if (p->dense) (void)hipFree(p->dense);
+  delete p;
+}
+
+int32_t qpc_qp_solve(qpc_qp_problem *p, int64_t B, const double *P_vals, const double *q, const double *A_vals, const double *l,
+                     const double *u, const qpc_settings *settings, int32_t warm_start, double *x, double *y, int32_t *status,
+                     int32_t *iters) {
+  if (!p) { qpc_set_error("qpc_qp_solve: null problem"); return QPC_ERR_INVALID_ARGUMENT; }
+  const int n = p->H.n, m = p->H.m;
+  const long long nnzP = p->H.nnzP, nnzA = p->H.nnzA;
+  if (B < 0 || (nnzP && !P_vals) || !q || (m && ((nnzA && !A_vals) || !l || !u)) || !x || (m && !y) || !status) {
+    qpc_set_error("qpc_qp_solve: bad arguments"); return QPC_ERR_INVALID_ARGUMENT;
+  }
+  if (B == 0) return QPC_OK;
+  HIP_TRY(hipSetDevice(p->device));
+  qpc_settings st;
+  if (settings) st = *settings; else qpc_default_settings(&st);
+  const size_t nPv = (size_t)B * nnzP, nq = (size_t)B * n, nAv = (size_t)B * nnzA, nm = (size_t)B * m;
+  const size_t wsb = (size_t)qpc_qp_workspace_bytes(n, m > 0 ? m : 1, B);
+  const size_t total = pad64(nPv * 8) + 2 * pad64(nq * 8) + pad64(nAv * 8) + 3 * pad64(nm * 8) + pad64(wsb) + 2 * pad64((size_t)B * sizeof(int32_t));
+  if (total > p->bytes) {
+    if (p->buf) (void)hipFree(p->buf);
+    p->buf = nullptr; p->bytes = 0;
+    if (hipMalloc(&p->buf, total) != hipSuccess) { (void)hipGetLastError(); qpc_set_error("qpc_qp_solve: out of device memory"); return QPC_ERR_OUT_OF_MEMORY; }
+    p->bytes = total;
+  }
+  char *c = p->buf;
+  auto take = [&](size_t bytes) { char *r = c; c += pad64(bytes); return r; };
+  double *dPv = (double *)take(nPv * 8), *dq = (double *)take(nq * 8), *dAv = (double *)take(nAv * 8), *dl = (double *)take(nm * 8),
+         *du = (double *)take(nm * 8), *dx = (double *)take(nq * 8), *dy = (double *)take(nm * 8), *dws = (double *)take(wsb);
+  int32_t *dst = (int32_t *)take((size_t)B * sizeof(int32_t)), *dit = (int32_t *)take((size_t)B * sizeof(int32_t));
+  int rc = QPC_OK;
+  auto chk = [&](hipError_t e, const char *w) { if (e != hipSuccess && rc == QPC_OK) rc = hip_fail(e, w); };
+  if (nPv) chk(hipMemcpyAsync(dPv, P_vals, nPv * 8, hipMemcpyHostToDevice, p->stream), "copy P values");
+  chk(hipMemcpyAsync(dq, q, nq * 8, hipMemcpyHostToDevice, p->stream), "copy q");
+  if (m) {
+    if (nAv) chk(hipMemcpyAsync(dAv, A_vals, nAv * 8, hipMemcpyHostToDevice, p->stream), "copy A values");
+    chk(hipMemcpyAsync(dl, l, nm * 8, hipMemcpyHostToDevice, p->stream), "copy l");
+    chk(hipMemcpyAsync(du, u, nm * 8, hipMemcpyHostToDevice, p->stream), "copy u");
+  }
+  const bool warm = warm_start && p->d_yprev && p->B_prev >= B && m > 0;
+  const bool wg = m > 0 && !p->H.p_offdiag && n <= QPC_WG_DIM && m <= QPC_WG_DIM;
+  const long long ws_stride = (long long)qpc::qp_dense_workspace_doubles(n, m > 0 ? m : 1);
+  std::vector<int32_t> hst((size_t)B, QPC_WG_FALLBACK);
+  if (rc == QPC_OK && wg) {
+    static std::once_flag once;
+    static hipError_t attr_rc = hipSuccess;
+    const int lds_bytes = QPC_WG_LDS_DOUBLES * (int)sizeof(double);
+    std::call_once(once, [&] { attr_rc = hipFuncSetAttribute((const void *)qpc_qp_wg_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); });
+    HIP_TRY(attr_rc);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, p->device));
+    const long long grid = B < (long long)prop.multiProcessorCount * 4 ? B : (long long)prop.multiProcessorCount * 4;
+    hipLaunchKernelGGL(qpc_qp_wg_prep_kernel, dim3((unsigned)grid), dim3(QPC_WG_THREADS), (size_t)lds_bytes, p->stream, p->H.view(p->d_ints),
+                       (long long)B, nnzP, dPv, dq, dAv, dl, du, st, dws, ws_stride, warm ? p->d_yprev : (const double *)nullptr, dx, dy, dst, dit);
+    chk(hipGetLastError(), "qpc_qp_wg_prep_kernel");
+    chk(hipMemcpyAsync(hst.data(), dst, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, p->stream), "copy status");
+    chk(hipStreamSynchronize(p->stream), "qpc_qp_wg_prep_kernel");
+  }
+  bool need_dense = !wg;
+  for (int64_t b = 0; b < B && !need_dense; b++) need_dense = hst[(size_t)b] == QPC_WG_FALLBACK;
+  if (rc == QPC_OK && need_dense) { // the dense path: scatter P, A and run the dense entry on what is left
+    const size_t nP = (size_t)B * n * n, nA = (size_t)B * (m > 0 ? m : 1) * n;
+    const size_t need = pad64(nP * 8) + pad64(nA * 8);
+    if (need > p->dense_bytes) {
+      if (p->dense) (void)hipFree(p->dense);
+      p->dense = nullptr; p->dense_bytes = 0;
+      if (hipMalloc(&p->dense, need) != hipSuccess) { (void)hipGetLastError(); qpc_set_error("qpc_qp_solve: out of device memory (dense path)"); return QPC_ERR_OUT_OF_MEMORY; }
+      p->dense_bytes = need;
+    }
+    double *dP = (double *)p->dense, *dA = (double *)(p->dense + pad64(nP * 8));
+    chk(hipMemsetAsync(p->dense, 0, need, p->stream), "clear dense P, A");
+    const int *Prow = p->d_coo, *Pcol = Prow + nnzP, *Arow = Pcol + nnzP, *Acol = Arow + nnzA;
+    if (nnzP + nnzA > 0) {
+      hipLaunchKernelGGL(qpc_qp_densify_kernel, dim3(1024), dim3(256), 0, p->stream, n, m, (long long)B, nnzP, Prow, Pcol, dPv, nnzA, Arow, Acol,
+                         dAv, dP, dA);
+      chk(hipGetLastError(), "qpc_qp_densify_kernel");
+    }
+    if (!wg) { // everything through the dense entry (its own workgroup pass detects what it can take)
+      if (rc == QPC_OK) rc = qpc_qp_solve_batch_device(n, m, B, dP, dq, dA, dl, du, &st, p->device, dx, dy, dst, dit, dws, wsb, p->stream);
+    } else {   // only the QPs the workgroup left: the one-lane kernel
+      hipLaunchKernelGGL(qpc_qp_dense_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, p->stream, n, m, (long long)B, dP, dq, dA, dl, du, st,
+                         dws, ws_stride, dx, dy, dst, dit, 1);
+      chk(hipGetLastError(), "qpc_qp_dense_kernel");
+    }
+    chk(hipMemcpyAsync(hst.data(), dst, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, p->stream), "copy status");
+  }
+  if (rc == QPC_OK) {
+    chk(hipMemcpyAsync(x, dx, nq * 8, hipMemcpyDeviceToHost, p->stream), "copy x");
+    if (m) chk(hipMemcpyAsync(y, dy, nm * 8, hipMemcpyDeviceToHost, p->stream), "copy y");
+    if (iters) chk(hipMemcpyAsync(iters, dit, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, p->stream), "copy iters");
+    if (m) { // keep the multipliers for the next call's warm start
+      if (B > p->cap_prev) {
+        if (p->d_yprev) (void)hipFree(p->d_yprev);
+        p->d_yprev = nullptr; p->cap_prev = 0; p->B_prev = 0;
+        if (hipMalloc(&p->d_yprev, nm * 8) == hipSuccess) p->cap_prev = B; else (void)hipGetLastError();
+      }
+      if (p->d_yprev) { chk(hipMemcpyAsync(p->d_yprev, dy, nm * 8, hipMemcpyDeviceToDevice, p->stream), "keep y"); p->B_prev = B; }
+    }
+  }
+  chk(hipStreamSynchronize(p->stream), "qpc_qp_solve");
+  if (rc == QPC_OK) for (int64_t b = 0; b < B; b++) status[b] = hst[(size_t)b];
   return rc;
 }
 

@@ -12,9 +12,12 @@
 #                  MOI.optimize!(optimizer)
 #   * afterwards:  MOI.get(optimizer, MOI.VariablePrimal(), vi), MOI.TerminationStatus(), MOI.PrimalStatus(),
 #                  MOI.DualStatus() (checkstatus, momentum.jl:83-91)
-# The optimizer keeps the problem dense (P n x n, q, A' n x m so that the C side sees row-major A, l, u) and
-# forwards optimize! to qp_solve_batch with B = 1.  Assembly stays on the CPU here: this is the compatibility
-# plug (SURVEY.md 8 b-1); the performance path is BatchedMomentumBasedController.
+# The optimizer keeps the coefficients dense on the host (P n x n, q, A' n x m, l, u: the MOI terms are added into them) and the
+# PATTERN of the terms as a prepared problem of the C ABI (QpProblem: qpc_qp_setup once after copy_to, again only if a term
+# appears outside the pattern); optimize! gathers the values in the pattern's order and calls qpc_qp_solve with B = 1,
+# warm-started from the previous tick (OSQP's warm start, which the reference relies on: momentum.jl:58 re-solves the same
+# model).  Assembly stays on the CPU here: this is the compatibility plug (SURVEY.md 8 b-1); the performance path is
+# BatchedMomentumBasedController.
 #
 # Written against the MOI 0.8 API from memory -- there is no `julia` in the build image, so this block is
 # UNTESTED there; its Python twin (qpcontrol.jl_amd/moi.py) replays the same life cycle against the same
@@ -28,7 +31,7 @@ export QPCOptimizer
 import MathOptInterface
 const MOI = MathOptInterface
 using LinearAlgebra: dot
-import ..QPControlHIP: qp_solve_batch, Settings, default_settings
+import ..QPControlHIP: qp_solve_batch, QpProblem, solve!, Settings, default_settings
 
 mutable struct QPCOptimizer <: MOI.AbstractOptimizer
     device::Int32
@@ -47,9 +50,15 @@ mutable struct QPCOptimizer <: MOI.AbstractOptimizer
     x::Vector{Float64}
     y::Vector{Float64}
     status::Int32                           # QPC_STATUS_* of the last optimize!, -1 before
+    patP::BitMatrix                         # entries of P / A' that a term has ever touched (the sparsity pattern)
+    patAt::BitMatrix
+    problem::Union{Nothing, QpProblem}      # the prepared problem of that pattern (nothing: set up at the next optimize!)
+    iP::Vector{Int}; jP::Vector{Int}; iA::Vector{Int}; jA::Vector{Int}   # its COO (P: upper triangle; A: row, column)
+    solved::Int                             # optimize! calls on this problem (the first one starts cold)
     QPCOptimizer(; device::Integer = 0, settings::Settings = default_settings()) =
         new(device, settings, 0, 0, zeros(0, 0), Float64[], zeros(0, 0), Float64[], Float64[], 0.0,
-            MOI.MIN_SENSE, Dict{Any, UnitRange{Int}}(), Dict{Any, Any}(), Float64[], Float64[], Int32(-1))
+            MOI.MIN_SENSE, Dict{Any, UnitRange{Int}}(), Dict{Any, Any}(), Float64[], Float64[], Int32(-1),
+            falses(0, 0), falses(0, 0), nothing, Int[], Int[], Int[], Int[], 0)
 end
 
 MOI.get(::QPCOptimizer, ::MOI.SolverName) = "qpcontrol_hip (gfx950)"
@@ -57,6 +66,7 @@ MOI.is_empty(o::QPCOptimizer) = o.n == 0
 function MOI.empty!(o::QPCOptimizer)
     o.n = o.m = 0; o.P = zeros(0, 0); o.q = Float64[]; o.At = zeros(0, 0); o.l = Float64[]; o.u = Float64[]
     o.objconstant = 0.0; empty!(o.rowranges); empty!(o.rowsets); o.x = Float64[]; o.y = Float64[]; o.status = Int32(-1)
+    o.patP = falses(0, 0); o.patAt = falses(0, 0); o.problem = nothing; o.solved = 0
     nothing
 end
 
@@ -70,7 +80,9 @@ MOI.supports_constraint(::QPCOptimizer, ::Type{MOI.VectorAffineFunction{Float64}
 function _setrows!(o::QPCOptimizer, rows::UnitRange{Int}, f::MOI.VectorAffineFunction{Float64}, set)
     o.At[:, rows] .= 0.0
     for t in f.terms
-        o.At[t.scalar_term.variable_index.value, rows[t.output_index]] += t.scalar_term.coefficient
+        i, r = t.scalar_term.variable_index.value, rows[t.output_index]
+        o.At[i, r] += t.scalar_term.coefficient
+        o.patAt[i, r] || (o.patAt[i, r] = true; o.problem = nothing)   # a term outside the pattern: set up again
     end
     for (k, r) in enumerate(rows)
         b = f.constants[k]
@@ -89,6 +101,8 @@ function _setobjective!(o::QPCOptimizer, f::MOI.ScalarQuadraticFunction{Float64}
         i, j = t.variable_index_1.value, t.variable_index_2.value
         o.P[i, j] += t.coefficient
         i == j || (o.P[j, i] += t.coefficient)
+        a, b = minmax(i, j)
+        o.patP[a, b] || (o.patP[a, b] = true; o.problem = nothing)
     end
     for t in f.affine_terms
         o.q[t.variable_index.value] += t.coefficient
@@ -126,6 +140,7 @@ function MOI.copy_to(dest::QPCOptimizer, src::MOI.ModelLike; copy_names::Bool = 
     end
     dest.n = n; dest.m = m
     dest.P = zeros(n, n); dest.q = zeros(n); dest.At = zeros(n, m); dest.l = zeros(m); dest.u = zeros(m)
+    dest.patP = falses(n, n); dest.patAt = falses(n, m)
     for (ci, f, s, rows) in cons
         fm = MOI.Utilities.mapvariables(idxmap, f)
         dest.rowranges[ci] = rows; dest.rowsets[ci] = s
@@ -150,8 +165,24 @@ MOI.set(o::QPCOptimizer, ::MOI.ConstraintSet, ci::MOI.ConstraintIndex, s) = (o.r
 
 function MOI.optimize!(o::QPCOptimizer)
     lc = clamp.(o.l, -1e20, 1e20); uc = clamp.(o.u, -1e20, 1e20)   # +-1e20 = unbounded (include/qpc.h L0)
-    x, y, status, _ = qp_solve_batch(reshape(o.P, o.n, o.n, 1), reshape(o.q, o.n, 1), reshape(o.At, o.n, o.m, 1),
-                                     reshape(lc, o.m, 1), reshape(uc, o.m, 1); device = o.device, settings = o.settings)
+    if o.m == 0   # no constraints: the dense entry
+        x, y, status, _ = qp_solve_batch(reshape(o.P, o.n, o.n, 1), reshape(o.q, o.n, 1), reshape(o.At, o.n, o.m, 1),
+                                         reshape(lc, o.m, 1), reshape(uc, o.m, 1); device = o.device, settings = o.settings)
+        o.x = vec(x); o.y = vec(y); o.status = status[1]
+        return nothing
+    end
+    if o.problem === nothing   # MOI.copy_to has just run (or the pattern grew): qpc_qp_setup
+        cP = findall(o.patP); cA = findall(o.patAt)
+        o.iP = [c[1] for c in cP]; o.jP = [c[2] for c in cP]
+        o.jA = [c[1] for c in cA]; o.iA = [c[2] for c in cA]          # patAt is A' (variable, row)
+        o.problem = QpProblem(o.n, o.m, o.iP, o.jP, o.iA, o.jA; device = o.device)
+        o.solved = 0
+    end
+    Pv = Float64[o.P[i, j] for (i, j) in zip(o.iP, o.jP)]
+    Av = Float64[o.At[j, i] for (i, j) in zip(o.iA, o.jA)]
+    x, y, status, _ = solve!(o.problem, reshape(Pv, :, 1), reshape(o.q, o.n, 1), reshape(Av, :, 1), reshape(lc, o.m, 1),
+                             reshape(uc, o.m, 1); warm_start = o.solved > 0, settings = o.settings)
+    o.solved += 1
     o.x = vec(x); o.y = vec(y); o.status = status[1]
     nothing
 end

@@ -7,8 +7,13 @@ optimizer ONCE (`MOI.copy_to`), then before every `MOI.optimize!` rewrites objec
 place -- same sparsity pattern, new numbers (momentum.jl:58 `solve!` -> `update!`) -- and afterwards reads
 `VariablePrimal`, `TerminationStatus`, `PrimalStatus`, `DualStatus` (momentum.jl:62-64, 83-91).
 
-This class keeps that life cycle with dense storage and forwards `optimize` to the L0 entry
-`qpc_qp_solve_batch` (include/qpc.h) with B = 1:   min 1/2 x'Px + q'x   s.t.  l <= A x <= u.
+This class keeps that life cycle and maps it onto the PREPARED L0 entry of the C ABI (include/qpc.h):
+  MOI.copy_to   -> qpc_qp_setup   (the sparsity pattern: compressed columns / rows and the structure of A H^-1 A', once)
+  MOI.optimize! -> qpc_qp_solve   (B = 1: the values in the pattern's order -- 13 KB for the 143 x 178 Atlas problem --, the
+                                   working set warm-started from the previous tick's multipliers, as OSQP warm-starts)
+  MOI.empty!    -> qpc_qp_free
+`prepared=False` keeps the dense entry `qpc_qp_solve_batch` (368 KB per solve, cold).
+    min 1/2 x'Px + q'x   s.t.  l <= A x <= u.
 It is plumbing / parity (assembly stays on the host); the performance path is the L2 tick."""
 from __future__ import annotations
 
@@ -30,8 +35,10 @@ _STATUS = {
 class QPCOptimizer:
     """Dense QP optimizer with MOI's copy-once / modify-coefficients / optimize / query life cycle."""
 
-    def __init__(self, device_id=0, lib_path=None, **settings):
+    def __init__(self, device_id=0, lib_path=None, prepared=True, warm_start=True, **settings):
         self.device_id, self.lib_path, self.settings = device_id, lib_path, settings
+        self.prepared, self.warm_start = prepared, warm_start
+        self._problem = None
         self.empty()
 
     # ---- MOI.is_empty / MOI.empty!
@@ -39,6 +46,9 @@ class QPCOptimizer:
         return self.n == 0
 
     def empty(self):
+        if self._problem is not None:
+            self._problem.close()
+            self._problem = None
         self.n = self.m = 0
         self.P = self.q = self.A = self.l = self.u = None
         self._pattern_P = self._pattern_A = None
@@ -59,6 +69,12 @@ class QPCOptimizer:
         self._pattern_A = (A != 0.0) if pattern_A is None else np.asarray(pattern_A, dtype=bool)
         self.x = self.y = None
         self.raw_status = None
+        if self._problem is not None:
+            self._problem.close()
+            self._problem = None
+        if self.prepared and self.m > 0:
+            self._problem = binding.QpProblem(self.n, self.m, self._pattern_P, self._pattern_A, device_id=self.device_id,
+                                              lib_path=self.lib_path)
 
     # ---- MOI.set(ObjectiveFunction) / MOI.set(ConstraintFunction / ConstraintSet): coefficient updates, pattern fixed
     def set_objective(self, P=None, q=None, strict_pattern=False):
@@ -89,8 +105,18 @@ class QPCOptimizer:
     def optimize(self):
         if self.is_empty():
             raise RuntimeError("optimize on an empty optimizer")
-        r = binding.qp_solve_batch(self.P, self.q, self.A, self.l, self.u, device_id=self.device_id, lib_path=self.lib_path,
-                                   **self.settings)
+        if self._problem is not None:
+            outside = ((self.P != 0.0) & ~(self._pattern_P | self._pattern_P.T)).any() or ((self.A != 0.0) & ~self._pattern_A).any()
+            if outside:  # a coefficient outside the copied pattern (MOI would need a new copy_to): the dense entry takes it
+                r = binding.qp_solve_batch(self.P, self.q, self.A, self.l, self.u, device_id=self.device_id, lib_path=self.lib_path,
+                                           **self.settings)
+            else:
+                Pv, Av = self._problem.values(self.P, self.A)
+                r = self._problem.solve(Pv, self.q, Av, self.l, self.u, warm_start=self.warm_start and self.n_optimize > 0,
+                                        **self.settings)
+        else:
+            r = binding.qp_solve_batch(self.P, self.q, self.A, self.l, self.u, device_id=self.device_id, lib_path=self.lib_path,
+                                       **self.settings)
         self.x, self.y = r["x"][0], r["y"][0]
         self.raw_status = int(r["status"][0])
         self.iters = int(r["iters"][0])

@@ -163,6 +163,7 @@ static inline real emu_sum64(const real *x) { real s = 0.0; for (int l = 0; l < 
 #include "../../qpcontrol.jl_amd/csrc/qpc_sim.h"
 #include "../../qpcontrol.jl_amd/csrc/qpc_qp_dense.h"
 #include "../../qpcontrol.jl_amd/csrc/qpc_qp_wg.h"
+#include "../../qpcontrol.jl_amd/csrc/qpc_qp_prep.h"
 #include "../../qpcontrol.jl_amd/csrc/qpc_l1_dense.h"
 #endif
 
@@ -463,6 +464,59 @@ int32_t qpc_rollout_batch(qpc_controller *, int64_t, int64_t, double *, double *
 #endif // QPC_F32
 
 #ifndef QPC_F32
+// L0 with the optimizer's life cycle (qpc_qp_setup / qpc_qp_solve): the host tables of qpc_qp_prep.h, the same kernel source
+struct qpc_qp_problem {
+  qpc::QpPrepHost H;
+  std::vector<double> yprev;
+  int64_t B_prev = 0;
+};
+int32_t qpc_qp_setup(int32_t n, int32_t m, int64_t nnz_P, const int32_t *P_rows, const int32_t *P_cols, int64_t nnz_A,
+                     const int32_t *A_rows, const int32_t *A_cols, int32_t device_id, qpc_qp_problem **out) {
+  (void)device_id;
+  if (!out) return QPC_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  qpc_qp_problem *p = new qpc_qp_problem;
+  const std::string err = qpc::qp_prep_build(p->H, n, m, nnz_P, P_rows, P_cols, nnz_A, A_rows, A_cols);
+  if (!err.empty()) { delete p; qpc_set_error("qpc_qp_setup: " + err); return QPC_ERR_INVALID_ARGUMENT; }
+  *out = p;
+  return QPC_OK;
+}
+void qpc_qp_free(qpc_qp_problem *p) { delete p; }
+int32_t qpc_qp_solve(qpc_qp_problem *p, int64_t B, const double *P_vals, const double *q, const double *A_vals, const double *l,
+                     const double *u, const qpc_settings *settings, int32_t warm_start, double *x, double *y, int32_t *status,
+                     int32_t *iters) {
+  if (!p || B < 0) return QPC_ERR_INVALID_ARGUMENT;
+  qpc_settings st;
+  if (settings) st = *settings; else qpc_default_settings(&st);
+  const int n = p->H.n, m = p->H.m;
+  const long long nnzP = p->H.nnzP, nnzA = p->H.nnzA;
+  std::vector<double> ws(qpc::qp_dense_workspace_doubles(n, m > 0 ? m : 1)), lds(qpc::qp_wg_lds_doubles(n, m));
+  const char *cap = getenv("QPC_EMU_WG_LDS");
+  const int lds_cap = cap ? atoi(cap) : (int)lds.size();
+  const bool warm = warm_start && p->B_prev >= B && m > 0;
+  const qpc::QpPrepView V = p->H.view(p->H.ints.data());
+  std::vector<double> ynew((size_t)B * m);
+  for (int64_t b = 0; b < B; b++) {
+    int s = QPC_WG_FALLBACK;
+    if (m > 0 && !p->H.p_offdiag)
+      s = qpc::qp_solve_wg_prep(V, P_vals + b * nnzP, q + b * n, A_vals + b * nnzA, l + b * m, u + b * m, st, ws.data(), lds.data(), lds_cap,
+                                warm ? p->yprev.data() + b * m : nullptr, x + b * n, y + b * m, iters ? iters + b : nullptr);
+    g_l0_wg += s != QPC_WG_FALLBACK;
+    if (s != QPC_WG_FALLBACK) status[b] = s;
+    else { // the dense path
+      std::vector<double> P((size_t)n * n, 0.0), A((size_t)(m > 0 ? m : 1) * n, 0.0);
+      for (long long k = 0; k < nnzP; k++) { P[(size_t)p->H.Prow[k] * n + p->H.Pcol[k]] = P_vals[b * nnzP + k]; P[(size_t)p->H.Pcol[k] * n + p->H.Prow[k]] = P_vals[b * nnzP + k]; }
+      for (long long k = 0; k < nnzA; k++) A[(size_t)p->H.Arow[k] * n + p->H.Acol[k]] = A_vals[b * nnzA + k];
+      int32_t s2 = 0;
+      qpc_qp_solve_batch(n, m, 1, P.data(), q + b * n, A.data(), l + b * m, u + b * m, &st, 0, x + b * n, y + b * m, &s2, iters ? iters + b : nullptr);
+      status[b] = s2;
+    }
+    for (int i = 0; i < m; i++) ynew[(size_t)b * m + i] = y[b * m + i];
+  }
+  p->yprev.swap(ynew);
+  p->B_prev = B;
+  return QPC_OK;
+}
 long emu_l0_wg_count() { const long r = g_l0_wg; g_l0_wg = 0; return r; }
 #endif
 // race-detector report: counts since the last call

@@ -12,13 +12,13 @@ from qpcontrol_jl_amd import moi
 from qpcontrol_jl_amd import workloads as W
 
 
-def _replay(lib_path, n_ticks=20):
+def _replay(lib_path, n_ticks=20, **opt_kw):
     oc, wl = W.atlas_workload(lambda mech, N, fl: O.OracleController(O.OracleModel(mech), N, fl), 4, 3)
     om = oc.model
     nv = wl.mech.nv
     q, v = wl.q[0].copy(), wl.v[0].copy()
     cw, cm = wl.contact_weight[0], wl.contact_maxnormalforce[0]
-    opt = moi.QPCOptimizer(lib_path=lib_path)
+    opt = moi.QPCOptimizer(lib_path=lib_path, **opt_kw)
     assert opt.is_empty() and opt.termination_status() == "OPTIMIZE_NOT_CALLED"
     # structural sparsity pattern (Parametron's terms): union of the nonzeros over random states -- an entry that
     # happens to vanish at one state is still a term (1549 stored nonzeros in A, 63 in P)
@@ -31,7 +31,7 @@ def _replay(lib_path, n_ticks=20):
         pat_P |= Pr != 0.0
         pat_A |= Ar != 0.0
     assert pat_A.sum() <= 1549 and pat_P.sum() == 63
-    worst = 0.0
+    worst, total_iters = 0.0, 0
     for k in range(n_ticks):
         des = W.standing_desired(wl.setup, q[None], v[None])[0]
         P, qv, A, l, u = oc.build_qp(q, v, des, cw, cm)
@@ -42,6 +42,7 @@ def _replay(lib_path, n_ticks=20):
             opt.set_objective(P, qv, strict_pattern=True)     # update!: coefficients only, fixed sparsity
             opt.set_constraints(A, l, u, strict_pattern=True)
         opt.optimize()
+        total_iters += opt.iters
         opt.checkstatus()
         assert (opt.termination_status(), opt.primal_status()) == ("OPTIMAL", "FEASIBLE_POINT")
         r = oc.tick(q, v, des, cw, cm)
@@ -57,12 +58,16 @@ def _replay(lib_path, n_ticks=20):
         v = v + 1e-3 * x[:nv]
         q = om.integrate(q, v, 1e-3)
     assert opt.n_optimize == n_ticks
-    return worst
+    return worst, total_iters
 
 
 def test_moi_twin_replays_20_ticks_emulated():
+    """the prepared entry (qpc_qp_setup once, qpc_qp_solve per tick), warm-started from the previous tick; the same ticks through the
+    dense cold entry need more working-set changes"""
     emu.build()
-    _replay(emu.EMU_LIB)
+    _, warm_iters = _replay(emu.EMU_LIB)
+    _, cold_iters = _replay(emu.EMU_LIB, prepared=False)
+    assert warm_iters <= cold_iters, (warm_iters, cold_iters)
 
 
 def test_moi_twin_reports_failure_like_checkstatus():

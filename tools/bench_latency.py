@@ -64,6 +64,50 @@ def l0_main(batches):
         ts = np.array(ts) * 1e6
         out[str(B)] = {"median_us": float(np.median(ts)), "max_us": float(ts.max()), "solves_per_s": float(B / np.median(ts) * 1e6),
                        "max_abs_err_vdot_vs_fixture": err}
+    # the same problems through the PREPARED entry (qpc_qp_setup once, qpc_qp_solve per call: values only, 13 KB per QP), cold and
+    # warm-started from the previous call's multipliers -- what QPCOptimizer (julia/QPControlHIPMOI.jl, moi.py) does every tick
+    pr = binding.QpProblem(P.shape[1], A.shape[1], (P != 0).any(0), (A != 0).any(0))
+    Pv, Av = pr.values(P, A)
+    prep = {"B1_per_problem": []}
+    for b in range(k):
+        a = (Pv[b], q[b], Av[b], l[b], u[b])
+        r = pr.solve(*a)
+        tc, tw = [], []
+        for _ in range(10):
+            t0 = time.perf_counter()
+            r = pr.solve(*a)
+            tc.append(time.perf_counter() - t0)
+        for _ in range(10):
+            t0 = time.perf_counter()
+            rw = pr.solve(*a, warm_start=True)
+            tw.append(time.perf_counter() - t0)
+        prep["B1_per_problem"].append({"iters": int(r["iters"][0]), "cold_median_us": float(np.median(tc) * 1e6),
+                                       "warm_iters": int(rw["iters"][0]), "warm_median_us": float(np.median(tw) * 1e6)})
+    prep["B1_cold_median_over_problems_us"] = float(np.median([p["cold_median_us"] for p in prep["B1_per_problem"]]))
+    prep["B1_cold_worst_problem_us"] = float(max(p["cold_median_us"] for p in prep["B1_per_problem"]))
+    prep["B1_warm_median_over_problems_us"] = float(np.median([p["warm_median_us"] for p in prep["B1_per_problem"]]))
+    prep["B1_warm_worst_problem_us"] = float(max(p["warm_median_us"] for p in prep["B1_per_problem"]))
+    for B in batches:
+        if B == 1:
+            continue
+        idx = np.arange(B) % k
+        a = (Pv[idx], q[idx], Av[idx], l[idx], u[idx])
+        r = pr.solve(*a)
+        assert (r["status"] == 0).all(), r["status"]
+        err = float(np.abs(r["x"][:, :nv] - x[idx][:, :nv]).max())
+        tc, tw = [], []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            pr.solve(*a)
+            tc.append(time.perf_counter() - t0)
+        for _ in range(3):
+            t0 = time.perf_counter()
+            pr.solve(*a, warm_start=True)
+            tw.append(time.perf_counter() - t0)
+        prep[str(B)] = {"cold_solves_per_s": float(B / np.median(tc)), "warm_solves_per_s": float(B / np.median(tw)),
+                        "max_abs_err_vdot_vs_fixture": err}
+    pr.close()
+    out["prepared"] = prep
     print(json.dumps(out))
 
 

@@ -21,3 +21,9 @@ for b in (0, 2, 6):  # no working-set change / five sweeps / forty Goldfarb-Idna
     for rep in range(2):
         r = binding.qp_solve_batch(P[b], q[b], A[b], l[b], u[b], lib_path=sys.argv[1])
     print("problem", b, "iters", r["iters"], "status", r["status"], flush=True)
+pr = binding.QpProblem(P.shape[1], A.shape[1], (P != 0).any(0), (A != 0).any(0), lib_path=sys.argv[1])
+Pv, Av = pr.values(P, A)
+for b in (0, 2, 6):  # the same through the prepared entry, cold and warm
+    for warm in (False, False, True):
+        r = pr.solve(Pv[b], q[b], Av[b], l[b], u[b], warm_start=warm)
+    print("prepared problem", b, "iters (warm)", r["iters"], "status", r["status"], flush=True)
