@@ -42,7 +42,8 @@
 #define QPC_WG_KW 128        // inequality rows of a working set (its factor: (k + 1)(k + 2) / 2 doubles, sized by min(mi, this))
 #define QPC_WG_DIM 256       // n, m <= this
 #define QPC_WG_LDS_DOUBLES 20480 // what the kernel asks for: the 160 KB of a CU
-#define QPC_WG_NB 16         // columns per elimination panel
+#define QPC_WG_NB 8          // columns per elimination panel
+#define QPC_WG_CB 4          // adjacent trailing columns a wave updates together
 #define QPC_WG_THREADS 512   // threads of the workgroup (device)
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -121,13 +122,48 @@ QPC_FN void wg_col_axpy(double *S, int tgt, int src, int len, double l) {
   }
 }
 
+// One chunk (CH = 1) or two chunks (CH = 2) of 64 rows of a block of QPC_WG_CB adjacent target columns cb .. cb+3 against the NB
+// columns of the panel at jp: the panel's values of a row are loaded once and serve the four columns.  Straight-line code: the
+// loads of an entry that does not exist (above the diagonal, beyond the block) go to an address that does, its store is skipped.
+template <int CH>
+QPC_FN void wg_trail_rows(double *S, int e0, int len, const int *src, const int *tgt, int ncol, const double (*lc)[QPC_WG_NB]) {
+  int e[CH];
+  bool h[CH];
+  double a[CH][QPC_WG_NB], t[CH][QPC_WG_CB];
+  int idx[CH][QPC_WG_CB];
+  bool ok[CH][QPC_WG_CB];
+#pragma unroll
+  for (int ch = 0; ch < CH; ch++) {
+    const int ee = e0 + ch * QPC_WG_NLANE;
+    h[ch] = ee < len;
+    e[ch] = h[ch] ? ee : e0;
+#pragma unroll
+    for (int jj = 0; jj < QPC_WG_NB; jj++) a[ch][jj] = S[src[jj] + e[ch]];
+#pragma unroll
+    for (int cc = 0; cc < QPC_WG_CB; cc++) {
+      ok[ch][cc] = h[ch] && cc < ncol && e[ch] >= cc;
+      idx[ch][cc] = ok[ch][cc] ? tgt[cc] + e[ch] - cc : tgt[0] + e[ch];
+      t[ch][cc] = S[idx[ch][cc]];
+    }
+  }
+#pragma unroll
+  for (int ch = 0; ch < CH; ch++)
+#pragma unroll
+    for (int cc = 0; cc < QPC_WG_CB; cc++) {
+      double v = t[ch][cc];
+#pragma unroll
+      for (int jj = 0; jj < QPC_WG_NB; jj++) v -= a[ch][jj] * lc[cc][jj];
+      if (ok[ch][cc]) S[idx[ch][cc]] = v;
+    }
+}
+
 // Eliminate the columns j0 .. j1-1 of S (packed, N1 x N1, the last row is a right-hand side riding along): LDL' without square
 // roots -- the columns keep L D (unscaled), dinv[j] = 1 / d_j, or 0 for a pivot below tau * ref[j] (a dependent row: it drops out of
 // everything, the "infinite pivot" of qpc_qp_dense.h).  Panels of QPC_WG_NB columns: inside a panel one barrier per column (every
 // thread reads the pivot and inverts it itself; the waves update the panel's remaining columns), then the trailing columns take the
-// whole panel at once: a wave takes a PAIR of them (the short one with the long one: every pair has the same length), its lanes run
-// down the column -- the panel's columns and the target are contiguous, the other factors are broadcasts.  A short last panel is
-// padded with zero factors (on the target column itself), so the inner loop is straight-line code: 2 x 17 loads, 32 multiply-adds.
+// whole panel at once, in blocks of QPC_WG_CB adjacent columns per wave (a block from the front with one from the back: every
+// pair has about the same length), lanes down the rows: 8 + 4 loads and 4 stores for 32 multiply-adds -- the LDS pipe is what
+// bounds this routine.  A short last panel and a short last block are padded with zero factors.
 // Barrier-synchronised on entry and on exit.
 QPC_FN void wg_ldl_eliminate(double *S, int N1, int j0, int j1, const double *ref, double tau, double *dinv) {
   for (int jp = j0; jp < j1; jp += QPC_WG_NB) {
@@ -149,34 +185,37 @@ QPC_FN void wg_ldl_eliminate(double *S, int N1, int j0, int j1, const double *re
     }
     const int c0 = jp + nb, R = N1 - 1 - c0; // trailing columns c0 .. N1-2 (column N1-1 would be the corner of the right-hand-side row)
     if (R > 0) {
-      QPC_WG_FOR_WAVE(p, (R + 1) / 2) {
+      const int nblk = (R + QPC_WG_CB - 1) / QPC_WG_CB;
+      double dv[QPC_WG_NB];
+      int pc[QPC_WG_NB];
+#pragma unroll
+      for (int jj = 0; jj < QPC_WG_NB; jj++) {
+        const int jc = jj < nb ? jp + jj : jp;
+        dv[jj] = jj < nb ? dinv[jc] : 0.0;
+        pc[jj] = wg_cs(jc, N1) - jc; // S[i][jc] = S[pc + i]
+      }
+      QPC_WG_FOR_WAVE(p, (nblk + 1) / 2) {
         for (int half = 0; half < 2; half++) {
-          const int c = half == 0 ? c0 + p : c0 + R - 1 - p;
-          if (half == 1 && c == c0 + p) break; // the middle column of an odd count
-          const int tgt = wg_cs(c, N1), len = N1 - c;
-          double lc[QPC_WG_NB];
-          int src[QPC_WG_NB];
+          const int blk = half == 0 ? p : nblk - 1 - p;
+          if (half == 1 && blk == p) break; // the middle block of an odd count
+          const int cb = c0 + blk * QPC_WG_CB, ncol = c0 + R - cb < QPC_WG_CB ? c0 + R - cb : QPC_WG_CB, len = N1 - cb;
+          double lc[QPC_WG_CB][QPC_WG_NB];
+          int src[QPC_WG_NB], tgt[QPC_WG_CB];
 #pragma unroll
-          for (int jj = 0; jj < QPC_WG_NB; jj++) {
-            const bool in = jj < nb;
-            const int jc = in ? jp + jj : jp;
-            const int o = wg_cs(jc, N1) + (c - jc);
-            const double v = S[o] * dinv[jc];
-            src[jj] = in ? o : tgt;
-            lc[jj] = in ? v : 0.0;
+          for (int cc = 0; cc < QPC_WG_CB; cc++) {
+            const int c = cc < ncol ? cb + cc : cb;
+            tgt[cc] = wg_cs(c, N1);
+#pragma unroll
+            for (int jj = 0; jj < QPC_WG_NB; jj++) {
+              const double v = S[pc[jj] + c] * dv[jj];
+              lc[cc][jj] = cc < ncol ? v : 0.0;
+            }
           }
-          for (int e0 = QPC_WG_LANE; e0 < len; e0 += 2 * QPC_WG_NLANE) { // two chunks in flight
-            const int e1 = e0 + QPC_WG_NLANE;
-            const bool h1 = e1 < len;
-            const int c1 = h1 ? e1 : e0;
-            double t0 = S[tgt + e0], t1 = S[tgt + c1];
-            double a0[QPC_WG_NB], a1[QPC_WG_NB];
 #pragma unroll
-            for (int jj = 0; jj < QPC_WG_NB; jj++) { a0[jj] = S[src[jj] + e0]; a1[jj] = S[src[jj] + c1]; }
-#pragma unroll
-            for (int jj = 0; jj < QPC_WG_NB; jj++) { t0 -= a0[jj] * lc[jj]; t1 -= a1[jj] * lc[jj]; }
-            S[tgt + e0] = t0;
-            if (h1) S[tgt + e1] = t1;
+          for (int jj = 0; jj < QPC_WG_NB; jj++) src[jj] = pc[jj] + cb; // row cb + e of panel column jj: src + e
+          for (int e0 = QPC_WG_LANE; e0 < len; e0 += 2 * QPC_WG_NLANE) {
+            if (e0 - QPC_WG_LANE + QPC_WG_NLANE < len) wg_trail_rows<2>(S, e0, len, src, tgt, ncol, lc); // (the same for every lane)
+            else wg_trail_rows<1>(S, e0, len, src, tgt, ncol, lc);
           }
         }
       }

@@ -86,5 +86,5 @@ def test_moi_twin_reports_failure_like_checkstatus():
 
 @pytest.mark.gpu
 def test_moi_twin_replays_20_ticks_gpu():
-    worst = _replay(None)
-    print(f"max |v̇_L0 - v̇_oracle| over 20 ticks: {worst:.2e}")
+    worst, iters = _replay(None)
+    print(f"max |v̇_L0 - v̇_oracle| over 20 ticks: {worst:.2e}, {iters} working-set changes (prepared entry, warm-started)")
