@@ -68,7 +68,7 @@ int qpc_jit_tick_waves(bool f32, bool pack2) {
 std::string qpc_jit_source(const QpcDims &D, const QpcDims &DS, bool warm, bool f32, bool pack2) {
   std::ostringstream o;
   o << "typedef int int32_t;\ntypedef unsigned int uint32_t;\ntypedef long long int64_t;\ntypedef unsigned long long uint64_t;\n";
-  if (f32) o << "#define QPC_F32 1\n";
+  if (f32) o << "#define QPC_F32 1\n#define QPC_DTAB_F32 1\n"; // (the runtime hands the fp32 kernel a float copy of the double tables)
   if (pack2) o << "#define QPC_PACK2 1\n#define QPC_NO_MFMA 1\n";
   o << "#define QPC_JIT 1\n#define QPC_M1_MAX " << (D.m1 > 0 ? D.m1 : 1) << "\n#define QPC_MAXD " << D.maxd << "\n#define QPC_NTILE_MAX " << (((D.m + 15) / 16) * (((D.m + 15) / 16) + 1) / 2 > 0 ? ((D.m + 15) / 16) * (((D.m + 15) / 16) + 1) / 2 : 1) << "\n#define QPC_XTILE_MAX " << (((D.m1 + 15) / 16) * (((D.m1 + 15) / 16) + 1) / 2 + (D.m1 + 15) / 16 > 0 ? ((D.m1 + 15) / 16) * (((D.m1 + 15) / 16) + 1) / 2 + (D.m1 + 15) / 16 : 1)
     << "\n#include \"qpc_device.h\"\n";
@@ -112,7 +112,7 @@ std::string qpc_jit_source(const QpcDims &D, const QpcDims &DS, bool warm, bool 
        "#endif\n";
   for (int variant = 0; variant < (warm ? 2 : 1); variant++) {
     o << "extern \"C\" __global__ void __launch_bounds__(64, " << waves << ") " << (variant ? "qpc_tick_kernel_jit_warm" : "qpc_tick_kernel_jit")
-      << "(const int *__restrict__ IT, const double *__restrict__ DT, const QpcBatchArgs A) {\n";
+      << "(const int *__restrict__ IT, const " << (f32 ? "float" : "double") << " *__restrict__ DT, const QpcBatchArgs A) {\n";
     if (dyn_lds && !f32) o << "  double *const qpc_lds_raw = qpc_lds_dyn;\n";
     else o << "  __shared__ __attribute__((aligned(16))) " << (f32 ? "float" : "double") << " qpc_lds_raw[" << (pack2 ? 2 : 1) * (D.lds_doubles > 0 ? D.lds_doubles : 1) << "];\n";
     // (fp32: `real` is a class holding one float -- qpc_real.h -- so the slab of floats is addressed as an array of reals)
@@ -152,9 +152,9 @@ std::string qpc_jit_source(const QpcDims &D, const QpcDims &DS, bool warm, bool 
          "    // the GLOBAL address space and cast back, so that address-space inference still sees where they point: table\n"
          "    // reads stay global_load (vmcnt only) instead of flat_load, which also counts on lgkmcnt and serialises with LDS\n"
          "    const __attribute__((address_space(1))) int *ITg = (const __attribute__((address_space(1))) int *)IT;\n"
-         "    const __attribute__((address_space(1))) double *DTg = (const __attribute__((address_space(1))) double *)DT;\n"
+         "    const __attribute__((address_space(1))) " << (f32 ? "float" : "double") << " *DTg = (const __attribute__((address_space(1))) " << (f32 ? "float" : "double") << " *)DT;\n"
          "    asm volatile(\"\" : \"+s\"(ITg), \"+s\"(DTg));\n"
-         "    const int *ITq = (const int *)ITg; const double *DTq = (const double *)DTg;\n"
+         "    const int *ITq = (const int *)ITg; const " << (f32 ? "float" : "double") << " *DTq = (const " << (f32 ? "float" : "double") << " *)DTg;\n"
          "    qpc::qpc_tick<LdsP, " << (variant ? "true" : "false") << ">(kD, kDS, ITq, qpc_dtab{DTq}, qpc_lds, io);\n"
          "    __syncthreads();\n"
 

@@ -41,10 +41,16 @@ QPC_REAL_FN constexpr bool operator<=(real a, real b) { return a.v <= b.v; }
 QPC_REAL_FN constexpr bool operator>=(real a, real b) { return a.v >= b.v; }
 QPC_REAL_FN constexpr bool operator==(real a, real b) { return a.v == b.v; }
 QPC_REAL_FN constexpr bool operator!=(real a, real b) { return a.v != b.v; }
-// the double tables in HBM, read as `real`
+// the tables in HBM, read as `real`: the device's fp32 module gets a float copy of them (QPC_DTAB_F32: no conversion per read, half
+// the bytes); the CPU emulation reads the double tables and narrows -- the same values either way
 struct qpc_dtab {
+#ifdef QPC_DTAB_F32
+  const float *p;
+  QPC_REAL_FN real operator[](int i) const { return real(p[i]); }
+#else
   const double *p;
   QPC_REAL_FN real operator[](int i) const { return real((float)p[i]); }
+#endif
   QPC_REAL_FN qpc_dtab operator+(int o) const { return qpc_dtab{p + o}; }
 };
 #define QPC_TO_DOUBLE(x) ((double)(x))

@@ -225,6 +225,7 @@ struct QpcDeviceState {
   int device = -1;
   int *d_it = nullptr;
   double *d_dt = nullptr;
+  float *d_dtf = nullptr; // the same tables in single precision (the fp32 tick's module reads these)
   int n_cu = 0, blocks_per_cu = 1, sim_blocks_per_cu = 1;
   std::vector<QpcSlot> slots; // [0, P) workers, [P] inline host path, [P + 1] user streams
   // timing (bench.py / roofline): events on the launch stream
@@ -302,7 +303,7 @@ static int launch(qpc_controller *c, QpcDeviceState *S, QpcSlot &sl, const QpcBa
   if (!warm) aa.wsets = nullptr;
   if (fn) {
     const int *it = S->d_it;
-    const double *dt = S->d_dt;
+    const void *dt = c->precision == QPC_PRECISION_F32 ? (const void *)S->d_dtf : (const void *)S->d_dt;
     void *args[] = {(void *)&it, (void *)&dt, (void *)&aa};
     unsigned dyn = (qpc_jit_dynamic_lds() && c->precision != QPC_PRECISION_F32) ? (unsigned)(D.lds_doubles * sizeof(double)) : 0u; // experiment: QPC_EXP_DYN_LDS=1
     if (dyn) if (const char *e = QPC_EXP_ENV("QPC_EXP_LDS_PAD")) dyn += (unsigned)atoi(e); // ... QPC_EXP_LDS_PAD=bytes: occupancy at will
@@ -368,6 +369,7 @@ static void destroy_device_state(QpcDeviceState *S) {
   }
   if (S->d_it) (void)hipFree(S->d_it);
   if (S->d_dt) (void)hipFree(S->d_dt);
+  if (S->d_dtf) (void)hipFree(S->d_dtf);
   if (S->l1_buf) (void)hipFree(S->l1_buf);
   if (S->roll_buf) (void)hipFree(S->roll_buf);
   if (S->roll_ws) (void)hipFree(S->roll_ws);
@@ -408,6 +410,11 @@ static int init_device_state(qpc_controller *c, QpcDeviceState *S, int device_id
   HIP_TRY(hipMalloc(&S->d_dt, sizeof(double) * c->prog.dtab.size()));
   HIP_TRY(hipMemcpy(S->d_it, c->prog.itab.data(), sizeof(int) * c->prog.itab.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(S->d_dt, c->prog.dtab.data(), sizeof(double) * c->prog.dtab.size(), hipMemcpyHostToDevice));
+  {
+    std::vector<float> dtf(c->prog.dtab.begin(), c->prog.dtab.end());
+    HIP_TRY(hipMalloc(&S->d_dtf, sizeof(float) * (dtf.size() + 1)));
+    HIP_TRY(hipMemcpy(S->d_dtf, dtf.data(), sizeof(float) * dtf.size(), hipMemcpyHostToDevice));
+  }
   S->slots.resize((size_t)n_slots + 1 + QPC_USER_SLOTS);
   for (size_t i = 0; i < S->slots.size(); i++) {
     QpcSlot &sl = S->slots[i];
