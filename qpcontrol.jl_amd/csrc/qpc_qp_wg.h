@@ -651,28 +651,36 @@ QPC_FN int qp_solve_wg_core(QpWg &W, const qpc_settings &st, double bscale, int 
   QPC_WG_SYNC
   double rp = 0.0, rs = 0.0;
   for (int sweep = 0; sweep <= st.max_refine_iters; sweep++) {
-    double a_rs = 0.0, a_rp = 0.0;
+    double a_rs = 0.0, a_rp = 0.0, a_ss = 1.0, a_ps = 1.0; // residuals and the scales they are measured against
     QPC_WG_FOR(i, n) { // r1 = -(q + P x + A' y)
-      const double t = W.q[i] + wg_pdiag(W, i) * W.x[i] + wg_col_dot(W, i, yp);
+      const double aty = wg_col_dot(W, i, yp), qi = W.q[i];
+      const double t = qi + wg_pdiag(W, i) * W.x[i] + aty;
       W.r1[i] = -t;
       a_rs = (QPC_FABS(t) > a_rs || !(t == t)) ? QPC_FABS(t) : a_rs;
+      a_ss = QPC_FABS(qi) > a_ss ? QPC_FABS(qi) : a_ss;
+      a_ss = QPC_FABS(aty) > a_ss ? QPC_FABS(aty) : a_ss;
     }
     QPC_WG_FOR(b, m) { // r2 = b_W - A_W x, by position (the rows outside the working set: 0)
       const int p = b - ne;
       double t = 0.0;
       if (b < ne || W.wsf[p] != 0.0) {
-        t = (b < ne ? W.l[W.perm[b]] : (W.wsf[p] > 0.0 ? W.hi[p] : W.lo[p])) - wg_row_dot(W, b, W.x);
+        const double bw = b < ne ? W.l[W.perm[b]] : (W.wsf[p] > 0.0 ? W.hi[p] : W.lo[p]);
+        t = bw - wg_row_dot(W, b, W.x);
         a_rp = (QPC_FABS(t) > a_rp || !(t == t)) ? QPC_FABS(t) : a_rp;
+        a_ps = QPC_FABS(bw) > a_ps ? QPC_FABS(bw) : a_ps;
       }
       W.tA[b] = t;
     }
     QPC_WG_SYNC
     rs = wg_reduce_max(a_rs, W.red);
     rp = wg_reduce_max(a_rp, W.red);
-#ifdef QPC_WG_DEBUG_REFINE
-    printf("sweep %d rs %.3e rp %.3e bscale %.3e\n", sweep, rs, rp, bscale);
-#endif
     if (sweep == st.max_refine_iters) break;
+    // after a correction: residuals at the rounding floor of their own scales (|q|, |A'y|; the working rows' bounds) -- another
+    // correction would change nothing that 1e-8 can see (the eps bias of the first solve is 1e-6: one correction takes it to 1e-12)
+    if (sweep > 0) {
+      const double ss = wg_reduce_max(a_ss, W.red), ps = wg_reduce_max(a_ps, W.red);
+      if (rs <= 1e-12 * ss && rp <= 1e-12 * ps) break;
+    }
     // dy = K^-1 (A_W H^-1 r1 - r2) ; dx = H^-1 (r1 - A_W' dy)
     QPC_WG_FOR(i, n) { W.xu[i] = W.hinv[i] * W.r1[i]; }    // xu is free from here on: H^-1 r1
     QPC_WG_SYNC

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Seeded fuzzing of L0 beyond the suite: random structured QPs (diagonal P with zero-cost variables, sparse A of several densities,
+equality rows anywhere, one-sided rows, structural zeros in the pattern) through the dense entry, the prepared entry and the prepared
+entry warm-started, against the oracle's OSQP restatement.
+  python tests/offline/fuzz_l0.py <seed> <count> [gpu]     (default: the CPU emulation; QPC_EMU_WG_LDS=3000 moves the matrix to global memory)"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import qpc_pkg  # noqa: E402
+
+qpc_pkg.load()
+from qpcontrol_jl_amd import binding  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+import emu  # noqa: E402
+
+LIB = None if (len(sys.argv) > 3 and sys.argv[3] == "gpu") else emu.build()
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+bad = 0
+for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 200):
+    big = rng.uniform() < 0.1
+    n = int(rng.integers(1, 150 if big else 40)); m = int(rng.integers(1, 200 if big else 60))
+    ne = int(rng.integers(0, min(n, m) + 1)) if rng.uniform() < 0.8 else 0
+    dens = rng.choice([0.05, 0.15, 0.4, 1.0])
+    P = np.diag(rng.uniform(0.05, 2.0, size=n))
+    if rng.uniform() < 0.3:
+        P[rng.integers(0, n), :] = 0  # a zero-cost variable
+    q = rng.normal(size=n)
+    A = rng.normal(size=(m, n)) * (rng.uniform(size=(m, n)) < dens)
+    if rng.uniform() < 0.5:
+        A[np.arange(m), rng.integers(0, n, size=m)] += rng.uniform(0.5, 1.5, size=m)
+    x0 = rng.normal(size=n)
+    b = A @ x0
+    l, u = b - rng.uniform(0.0, 0.6, size=m), b + rng.uniform(0.0, 0.6, size=m)
+    l[:ne] = u[:ne] = b[:ne]
+    k = rng.integers(0, 3)
+    if k == 0: l[ne::3] = -1e30
+    if k == 1: u[ne::2] = 1e30
+    perm = rng.permutation(m)  # equality rows anywhere
+    A, l, u = A[perm], l[perm], u[perm]
+    ro = O.qp_solve(P, q, A, l, u)
+    rd = binding.qp_solve_batch(P, q, A, l, u, lib_path=LIB)
+    pat = (A != 0) | (rng.uniform(size=A.shape) < 0.02)
+    pr = binding.QpProblem(n, m, np.eye(n, dtype=bool), pat, lib_path=LIB)
+    Pv, Av = pr.values(P, A)
+    rp = pr.solve(Pv, q, Av, l, u)
+    rw = pr.solve(Pv, q, Av, l, u, warm_start=True)
+    pr.close()
+    ok = True
+    msg = []
+    if rd["status"][0] != rp["status"][0] or rw["status"][0] != rp["status"][0]:
+        ok = False; msg.append(f"status dense {rd['status'][0]} prep {rp['status'][0]} warm {rw['status'][0]}")
+    if ro["status"] == 0:
+        if rp["status"][0] != 0:
+            ok = False; msg.append(f"oracle optimal, kernel {rp['status'][0]}")
+        else:
+            for name, r in (("dense", rd), ("prep", rp), ("warm", rw)):
+                e = np.abs(r["x"][0] - ro["x"]).max()
+                if e > 1e-7:
+                    ok = False; msg.append(f"{name} x err {e:.2e}")
+    if not ok:
+        bad += 1
+        print("trial", trial, "n m ne", n, m, ne, "dens", dens, "oracle", ro["status"], msg, flush=True)
+print("done, bad =", bad)
