@@ -60,6 +60,8 @@ def main():
     json.dump({"kernel": tick[0]["Name"] if tick else None, "qps_per_launch": 32768,
                "kernel_avg_ms_under_rocprof": float(tick[0]["AverageNs"]) / 1e6 if tick else None, "per_launch": sq},
               open(dst + "_pmc_summary.json", "w"), indent=1)
+    for f in glob.glob(os.path.join(src, "l0", "**", "*kernel_stats.csv"), recursive=True):  # the L0 kernels (tools/bench_latency.py --l0)
+        shutil.copy(f, dst + "_l0_kernel_stats.csv")
     for name in ("bench_full.json", "bench_under_rocprof.json"):
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), f"{dst}_{name}")
