@@ -550,12 +550,29 @@ QPC_FN int qp_solve_wg_core(QpWg &W, const qpc_settings &st, double bscale, int 
     if (nw < 0) return QPC_WG_FALLBACK;
   }
   QPC_WG_STAMP(W, 4);
-  // ---- Goldfarb-Idnani dual active set from the equality-only working set (finite; qpc_qp_dense.h phase B).  The scalar logic of an
-  //      iteration (most violated row, ratio test, step) is thread 0's, the factorizations the workgroup's.
+  // ---- Goldfarb-Idnani dual active set (finite; qpc_qp_dense.h phase B).  It may start from any working set whose EQP has
+  //      multipliers of the right signs (the minimiser subject to those rows AS INEQUALITIES): not from the equality-only set, which
+  //      throws the sweeps' work away, but from what is left of their last set once the rows with wrong-signed multipliers have
+  //      been dropped (repeatedly: a drop can turn another sign).  The scalar logic of an iteration (most violated row, ratio test,
+  //      step) is thread 0's, the factorizations the workgroup's.
   if (!converged) {
-    QPC_WG_FOR(p, mi) { W.wsf[p] = 0.0; }
-    QPC_WG_SYNC
-    nw = wg_solve_ws(W, st.eps_dual_reg, kw);
+    for (int pass = 0; pass <= mi; pass++) {
+      double a_y = 1.0;
+      QPC_WG_FOR(a, nw) { a_y = QPC_FABS(W.yw[a]) > a_y ? QPC_FABS(W.yw[a]) : a_y; }
+      QPC_WG_T0 { W.sc[WGS_CHANGES] = 0.0; }
+      const double toly = st.tol_bound * wg_reduce_max(a_y, W.red);
+      QPC_WG_FOR(a, nw) {
+        const int p = W.idxW[a];
+        const double viol = W.wsf[p] < 0.0 ? W.yw[a] : -W.yw[a];
+        if (viol > toly || W.dinvW[a] == 0.0) { W.tm[p] = 0.0; W.sc[WGS_CHANGES] = 1.0; } else W.tm[p] = W.wsf[p];
+      }
+      QPC_WG_SYNC
+      if (W.sc[WGS_CHANGES] == 0.0) break;
+      QPC_WG_FOR(a, nw) { const int p = W.idxW[a]; W.wsf[p] = W.tm[p]; }
+      QPC_WG_SYNC
+      nw = wg_solve_ws(W, st.eps_dual_reg, kw);
+      if (nw < 0) return QPC_WG_FALLBACK;
+    }
     for (; iters < max_it; iters++) {
       QPC_WG_T0 {
         double xsc = 1.0;

@@ -40,9 +40,16 @@
 extern "C" __global__ void __launch_bounds__(QPC_WG_THREADS)
 qpc_qp_wg_kernel(int n, int m, long long B, const double *P, const double *q, const double *A, const double *l,
                  const double *u, qpc_settings st, double *ws, long long ws_stride, double *x, double *y,
-                 int32_t *status, int32_t *iters) {
+                 int32_t *status, int32_t *iters, unsigned long long *ticket) {
   extern __shared__ __attribute__((aligned(16))) double qpc_wg_lds[];
-  for (long long b = blockIdx.x; b < B; b += gridDim.x) {
+  // QPs are handed out by a counter (zeroed by the host before the launch), not by block index: workgroups go to the eight XCDs
+  // round-robin, so any cost pattern with a period of 8 in the batch (measured: the eight committed problems, cycled) would put all
+  // the expensive QPs on ONE XCD -- a mixed batch of 2 048 took as long as 2 048 copies of its slowest member
+  while (true) {
+    if (threadIdx.x == 0) ((unsigned long long *)qpc_wg_lds)[15] = atomicAdd(ticket, 1ull);
+    __syncthreads();
+    const long long b = (long long)((unsigned long long *)qpc_wg_lds)[15];
+    if (b >= B) break;
     const int s = qpc::qp_solve_wg(n, m, P + b * n * n, q + b * n, A + b * m * n, l + b * m, u + b * m, st,
                                    ws + b * ws_stride, qpc_wg_lds, QPC_WG_LDS_DOUBLES, x + b * n, y + b * m,
                                    iters ? iters + b : nullptr);
@@ -63,9 +70,13 @@ qpc_qp_wg_kernel(int n, int m, long long B, const double *P, const double *q, co
 extern "C" __global__ void __launch_bounds__(QPC_WG_THREADS)
 qpc_qp_wg_prep_kernel(qpc::QpPrepView V, long long B, long long nnzP, const double *Pv, const double *q, const double *Av,
                       const double *l, const double *u, qpc_settings st, double *ws, long long ws_stride, const double *y0,
-                      double *x, double *y, int32_t *status, int32_t *iters) {
+                      double *x, double *y, int32_t *status, int32_t *iters, unsigned long long *ticket) {
   extern __shared__ __attribute__((aligned(16))) double qpc_wg_lds[];
-  for (long long b = blockIdx.x; b < B; b += gridDim.x) {
+  while (true) { // (tickets: see qpc_qp_wg_kernel)
+    if (threadIdx.x == 0) ((unsigned long long *)qpc_wg_lds)[15] = atomicAdd(ticket, 1ull);
+    __syncthreads();
+    const long long b = (long long)((unsigned long long *)qpc_wg_lds)[15];
+    if (b >= B) break;
 #ifdef QPC_WG_PROF
     const long long c0__ = clock64(), w0__ = wall_clock64();
 #endif
@@ -1113,9 +1124,12 @@ int32_t qpc_qp_solve_batch_device(int32_t n, int32_t m, int64_t B, const double 
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device_id));
     const long long grid = B < (long long)prop.multiProcessorCount * 4 ? B : (long long)prop.multiProcessorCount * 4;
+    // the ticket counter: the last of the spare doubles at the end of the workspace
+    unsigned long long *ticket = (unsigned long long *)((double *)workspace + (long long)qpc::qp_dense_workspace_doubles(n, m) * B - 1);
+    HIP_TRY(hipMemsetAsync(ticket, 0, sizeof(unsigned long long), (hipStream_t)hip_stream));
     hipLaunchKernelGGL(qpc_qp_wg_kernel, dim3((unsigned)grid), dim3(QPC_WG_THREADS), (size_t)lds_bytes, (hipStream_t)hip_stream, (int)n, (int)m,
                        (long long)B, P, q, A, l, u, st, (double *)workspace, (long long)qpc::qp_dense_workspace_doubles(n, m), x, y,
-                       status, iters);
+                       status, iters, ticket);
     HIP_TRY(hipGetLastError());
   }
   hipLaunchKernelGGL(qpc_qp_dense_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, (hipStream_t)hip_stream, (int)n, (int)m,
@@ -1287,8 +1301,11 @@ int32_t qpc_qp_solve(qpc_qp_problem *p, int64_t B, const double *P_vals, const d
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, p->device));
     const long long grid = B < (long long)prop.multiProcessorCount * 4 ? B : (long long)prop.multiProcessorCount * 4;
+    unsigned long long *ticket = (unsigned long long *)(dws + ws_stride * B - 1); // (the last of the workspace's spare doubles)
+    chk(hipMemsetAsync(ticket, 0, sizeof(unsigned long long), p->stream), "clear the ticket counter");
     hipLaunchKernelGGL(qpc_qp_wg_prep_kernel, dim3((unsigned)grid), dim3(QPC_WG_THREADS), (size_t)lds_bytes, p->stream, p->H.view(p->d_ints),
-                       (long long)B, nnzP, dPv, dq, dAv, dl, du, st, dws, ws_stride, warm ? p->d_yprev : (const double *)nullptr, dx, dy, dst, dit);
+                       (long long)B, nnzP, dPv, dq, dAv, dl, du, st, dws, ws_stride, warm ? p->d_yprev : (const double *)nullptr, dx, dy, dst, dit,
+                       ticket);
     chk(hipGetLastError(), "qpc_qp_wg_prep_kernel");
     chk(hipMemcpyAsync(hst.data(), dst, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, p->stream), "copy status");
     chk(hipStreamSynchronize(p->stream), "qpc_qp_wg_prep_kernel");
