@@ -518,7 +518,7 @@ QPC_FN int qp_solve_wg_core(QpWg &W, const qpc_settings &st, double bscale, int 
     nw = wg_solve_ws(W, st.eps_dual_reg, kw);
   }
   bool converged = false;
-  const int max_pdas = 12;
+  const int max_pdas = 4; // (measured on the committed Atlas problems: 4 / 6 / 8 / 12 sweeps before Goldfarb-Idnani takes over -> 31 / 47 / 39 / 49 iterations in total, the worst problem 8 / 21 / 13 / 23; a sweep and a Goldfarb-Idnani step cost about the same)
   // ---- primal-dual multi-change sweeps (qpc_qp_dense.h phase A), on the inequality rows
   for (; iters < max_pdas && iters < max_it; iters++) {
     double a_y = 1.0, a_x = 1.0;
