@@ -1121,9 +1121,20 @@ int32_t qpc_qp_solve_batch_device(int32_t n, int32_t m, int64_t B, const double 
     const int lds_bytes = qpc::qp_wg_lds_doubles(n, m) * (int)sizeof(double);
     std::call_once(once, [&] { attr_rc = hipFuncSetAttribute((const void *)qpc_qp_wg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); });
     HIP_TRY(attr_rc);
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
-    const long long grid = B < (long long)prop.multiProcessorCount * 4 ? B : (long long)prop.multiProcessorCount * 4;
+    static std::mutex cu_mu;
+    static std::map<int, int> cu_of; // (hipGetDeviceProperties costs tens of microseconds: once per device)
+    int n_cu = 0;
+    {
+      std::lock_guard<std::mutex> lk(cu_mu);
+      auto it = cu_of.find(device_id);
+      if (it == cu_of.end()) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+        it = cu_of.emplace(device_id, prop.multiProcessorCount).first;
+      }
+      n_cu = it->second;
+    }
+    const long long grid = B < (long long)n_cu * 4 ? B : (long long)n_cu * 4;
     // the ticket counter: the last of the spare doubles at the end of the workspace
     unsigned long long *ticket = (unsigned long long *)((double *)workspace + (long long)qpc::qp_dense_workspace_doubles(n, m) * B - 1);
     HIP_TRY(hipMemsetAsync(ticket, 0, sizeof(unsigned long long), (hipStream_t)hip_stream));
@@ -1209,6 +1220,9 @@ struct qpc_qp_problem {
   int64_t B_prev = 0, cap_prev = 0;
   char *dense = nullptr;                   // dense P, A of the batch (only when the dense path is needed)
   size_t dense_bytes = 0;
+  char *h_stage = nullptr;                 // page-locked staging of a SMALL batch: one copy in, one copy out (B = 1 is the reference's regime)
+  size_t h_stage_bytes = 0;
+  int n_cu = 0;
 };
 
 int32_t qpc_qp_setup(int32_t n, int32_t m, int64_t nnz_P, const int32_t *P_rows, const int32_t *P_cols, int64_t nnz_A,
@@ -1227,6 +1241,11 @@ int32_t qpc_qp_setup(int32_t n, int32_t m, int64_t nnz_P, const int32_t *P_rows,
   if (!err.empty()) { qpc_set_error("qpc_qp_setup: " + err); return QPC_ERR_INVALID_ARGUMENT; }
   p->device = device_id;
   HIP_TRY(hipSetDevice(device_id));
+  {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    p->n_cu = prop.multiProcessorCount;
+  }
   HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
   HIP_TRY(hipMalloc(&p->d_ints, p->H.ints.size() * sizeof(int)));
   HIP_TRY(hipMemcpy(p->d_ints, p->H.ints.data(), p->H.ints.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -1249,6 +1268,7 @@ void qpc_qp_free(qpc_qp_problem *p) {
   if (p->buf) (void)hipFree(p->buf);
   if (p->d_yprev) (void)hipFree(p->d_yprev);
   if (p->dense) (void)hipFree(p->dense);
+  if (p->h_stage) (void)hipHostFree(p->h_stage);
   delete p;
 }
 
@@ -1276,39 +1296,87 @@ int32_t qpc_qp_solve(qpc_qp_problem *p, int64_t B, const double *P_vals, const d
   }
   char *c = p->buf;
   auto take = [&](size_t bytes) { char *r = c; c += pad64(bytes); return r; };
+  // inputs side by side, outputs side by side: a small batch moves in ONE copy each way
   double *dPv = (double *)take(nPv * 8), *dq = (double *)take(nq * 8), *dAv = (double *)take(nAv * 8), *dl = (double *)take(nm * 8),
-         *du = (double *)take(nm * 8), *dx = (double *)take(nq * 8), *dy = (double *)take(nm * 8), *dws = (double *)take(wsb);
+         *du = (double *)take(nm * 8);
+  const size_t in_bytes = (size_t)(c - p->buf);
+  char *const out0 = c;
+  double *dx = (double *)take(nq * 8), *dy = (double *)take(nm * 8);
   int32_t *dst = (int32_t *)take((size_t)B * sizeof(int32_t)), *dit = (int32_t *)take((size_t)B * sizeof(int32_t));
+  const size_t out_bytes = (size_t)(c - out0);
+  double *dws = (double *)take(wsb);
   int rc = QPC_OK;
   auto chk = [&](hipError_t e, const char *w) { if (e != hipSuccess && rc == QPC_OK) rc = hip_fail(e, w); };
-  if (nPv) chk(hipMemcpyAsync(dPv, P_vals, nPv * 8, hipMemcpyHostToDevice, p->stream), "copy P values");
-  chk(hipMemcpyAsync(dq, q, nq * 8, hipMemcpyHostToDevice, p->stream), "copy q");
-  if (m) {
-    if (nAv) chk(hipMemcpyAsync(dAv, A_vals, nAv * 8, hipMemcpyHostToDevice, p->stream), "copy A values");
-    chk(hipMemcpyAsync(dl, l, nm * 8, hipMemcpyHostToDevice, p->stream), "copy l");
-    chk(hipMemcpyAsync(du, u, nm * 8, hipMemcpyHostToDevice, p->stream), "copy u");
-  }
   const bool warm = warm_start && p->d_yprev && p->B_prev >= B && m > 0;
   const bool wg = m > 0 && !p->H.p_offdiag && n <= QPC_WG_DIM && m <= QPC_WG_DIM;
+  const bool small = wg && in_bytes + out_bytes <= ((size_t)1 << 20);
+  if (small && in_bytes + out_bytes > p->h_stage_bytes) {
+    if (p->h_stage) (void)hipHostFree(p->h_stage);
+    p->h_stage = nullptr; p->h_stage_bytes = 0;
+    if (hipHostMalloc(&p->h_stage, (size_t)1 << 20, hipHostMallocDefault) == hipSuccess) p->h_stage_bytes = (size_t)1 << 20; else (void)hipGetLastError();
+  }
+  const bool staged = small && p->h_stage != nullptr;
+  if (staged) { // the same layout in the page-locked buffer, one copy
+    char *h = p->h_stage;
+    if (nPv) memcpy(h + ((char *)dPv - p->buf), P_vals, nPv * 8);
+    memcpy(h + ((char *)dq - p->buf), q, nq * 8);
+    if (nAv) memcpy(h + ((char *)dAv - p->buf), A_vals, nAv * 8);
+    memcpy(h + ((char *)dl - p->buf), l, nm * 8);
+    memcpy(h + ((char *)du - p->buf), u, nm * 8);
+    chk(hipMemcpyAsync(p->buf, h, in_bytes, hipMemcpyHostToDevice, p->stream), "copy the inputs");
+  } else {
+    if (nPv) chk(hipMemcpyAsync(dPv, P_vals, nPv * 8, hipMemcpyHostToDevice, p->stream), "copy P values");
+    chk(hipMemcpyAsync(dq, q, nq * 8, hipMemcpyHostToDevice, p->stream), "copy q");
+    if (m) {
+      if (nAv) chk(hipMemcpyAsync(dAv, A_vals, nAv * 8, hipMemcpyHostToDevice, p->stream), "copy A values");
+      chk(hipMemcpyAsync(dl, l, nm * 8, hipMemcpyHostToDevice, p->stream), "copy l");
+      chk(hipMemcpyAsync(du, u, nm * 8, hipMemcpyHostToDevice, p->stream), "copy u");
+    }
+  }
   const long long ws_stride = (long long)qpc::qp_dense_workspace_doubles(n, m > 0 ? m : 1);
   std::vector<int32_t> hst((size_t)B, QPC_WG_FALLBACK);
+  auto keep_y = [&]() { // the multipliers stay on the device for the next call's warm start
+    if (!m) return;
+    if (B > p->cap_prev) {
+      if (p->d_yprev) (void)hipFree(p->d_yprev);
+      p->d_yprev = nullptr; p->cap_prev = 0; p->B_prev = 0;
+      if (hipMalloc(&p->d_yprev, nm * 8) == hipSuccess) p->cap_prev = B; else (void)hipGetLastError();
+    }
+    if (p->d_yprev) { chk(hipMemcpyAsync(p->d_yprev, dy, nm * 8, hipMemcpyDeviceToDevice, p->stream), "keep y"); p->B_prev = B; }
+  };
   if (rc == QPC_OK && wg) {
     static std::once_flag once;
     static hipError_t attr_rc = hipSuccess;
     const int lds_bytes = QPC_WG_LDS_DOUBLES * (int)sizeof(double);
     std::call_once(once, [&] { attr_rc = hipFuncSetAttribute((const void *)qpc_qp_wg_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); });
     HIP_TRY(attr_rc);
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, p->device));
-    const long long grid = B < (long long)prop.multiProcessorCount * 4 ? B : (long long)prop.multiProcessorCount * 4;
+    const long long grid = B < (long long)p->n_cu * 4 ? B : (long long)p->n_cu * 4;
     unsigned long long *ticket = (unsigned long long *)(dws + ws_stride * B - 1); // (the last of the workspace's spare doubles)
+    const double *y0 = warm ? p->d_yprev : (const double *)nullptr;
     chk(hipMemsetAsync(ticket, 0, sizeof(unsigned long long), p->stream), "clear the ticket counter");
     hipLaunchKernelGGL(qpc_qp_wg_prep_kernel, dim3((unsigned)grid), dim3(QPC_WG_THREADS), (size_t)lds_bytes, p->stream, p->H.view(p->d_ints),
-                       (long long)B, nnzP, dPv, dq, dAv, dl, du, st, dws, ws_stride, warm ? p->d_yprev : (const double *)nullptr, dx, dy, dst, dit,
-                       ticket);
+                       (long long)B, nnzP, dPv, dq, dAv, dl, du, st, dws, ws_stride, y0, dx, dy, dst, dit, ticket);
     chk(hipGetLastError(), "qpc_qp_wg_prep_kernel");
-    chk(hipMemcpyAsync(hst.data(), dst, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, p->stream), "copy status");
-    chk(hipStreamSynchronize(p->stream), "qpc_qp_wg_prep_kernel");
+    if (staged) { // outputs in one copy; the multipliers kept right away (a QP the workgroup left is rare and redoes both below)
+      char *ho = p->h_stage + in_bytes;
+      chk(hipMemcpyAsync(ho, out0, out_bytes, hipMemcpyDeviceToHost, p->stream), "copy the outputs");
+      keep_y();
+      chk(hipStreamSynchronize(p->stream), "qpc_qp_wg_prep_kernel");
+      if (rc != QPC_OK) return rc;
+      memcpy(hst.data(), ho + ((char *)dst - out0), (size_t)B * sizeof(int32_t));
+      bool left = false;
+      for (int64_t b = 0; b < B; b++) left = left || hst[(size_t)b] == QPC_WG_FALLBACK;
+      if (!left) {
+        memcpy(x, ho, nq * 8);
+        memcpy(y, ho + ((char *)dy - out0), nm * 8);
+        if (iters) memcpy(iters, ho + ((char *)dit - out0), (size_t)B * sizeof(int32_t));
+        for (int64_t b = 0; b < B; b++) status[b] = hst[(size_t)b];
+        return QPC_OK;
+      }
+    } else {
+      chk(hipMemcpyAsync(hst.data(), dst, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, p->stream), "copy status");
+      chk(hipStreamSynchronize(p->stream), "qpc_qp_wg_prep_kernel");
+    }
   }
   bool need_dense = !wg;
   for (int64_t b = 0; b < B && !need_dense; b++) need_dense = hst[(size_t)b] == QPC_WG_FALLBACK;
@@ -1342,14 +1410,7 @@ int32_t qpc_qp_solve(qpc_qp_problem *p, int64_t B, const double *P_vals, const d
     chk(hipMemcpyAsync(x, dx, nq * 8, hipMemcpyDeviceToHost, p->stream), "copy x");
     if (m) chk(hipMemcpyAsync(y, dy, nm * 8, hipMemcpyDeviceToHost, p->stream), "copy y");
     if (iters) chk(hipMemcpyAsync(iters, dit, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, p->stream), "copy iters");
-    if (m) { // keep the multipliers for the next call's warm start
-      if (B > p->cap_prev) {
-        if (p->d_yprev) (void)hipFree(p->d_yprev);
-        p->d_yprev = nullptr; p->cap_prev = 0; p->B_prev = 0;
-        if (hipMalloc(&p->d_yprev, nm * 8) == hipSuccess) p->cap_prev = B; else (void)hipGetLastError();
-      }
-      if (p->d_yprev) { chk(hipMemcpyAsync(p->d_yprev, dy, nm * 8, hipMemcpyDeviceToDevice, p->stream), "keep y"); p->B_prev = B; }
-    }
+    keep_y();
   }
   chk(hipStreamSynchronize(p->stream), "qpc_qp_solve");
   if (rc == QPC_OK) for (int64_t b = 0; b < B; b++) status[b] = hst[(size_t)b];
