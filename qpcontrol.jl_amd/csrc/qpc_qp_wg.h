@@ -75,6 +75,17 @@
 
 namespace qpc {
 
+#if defined(QPC_WG_PROF) && defined(__HIPCC__)
+__device__ unsigned long long qpc_wg_acc[8]; // (profiling build: time inside the elimination, block 0 only)
+#endif
+#if defined(QPC_WG_PROF) && defined(__HIP_DEVICE_COMPILE__)
+#define QPC_WG_ACC_T0() const unsigned long long acc_t0__ = wall_clock64()
+#define QPC_WG_ACC(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) qpc_wg_acc[k] += wall_clock64() - acc_t0__; } while (0)
+#else
+#define QPC_WG_ACC_T0() do { } while (0)
+#define QPC_WG_ACC(k) do { } while (0)
+#endif
+
 // LDS (or host scratch) handed to qp_solve_wg, in doubles
 #ifdef __HIPCC__
 __host__ __device__
@@ -153,47 +164,91 @@ QPC_FN void wg_trail_rows(double *S, int e0, int len, const int *src, const int 
       double v = t[ch][cc];
 #pragma unroll
       for (int jj = 0; jj < QPC_WG_NB; jj++) v -= a[ch][jj] * lc[cc][jj];
-      if (ok[ch][cc]) S[idx[ch][cc]] = v;
+      t[ch][cc] = v;
     }
+  // every store unconditional (a conditional one makes the compiler sink the arithmetic into a branch per entry): an entry that does
+  // not exist was read from the block's FIRST column at this row (chunk 0's row for a chunk past the end) and gets that entry's new
+  // value again -- the same bits, whichever of the two stores lands last
+#pragma unroll
+  for (int ch = 0; ch < CH; ch++)
+#pragma unroll
+    for (int cc = 0; cc < QPC_WG_CB; cc++) S[idx[ch][cc]] = ok[ch][cc] ? t[ch][cc] : (h[ch] ? t[ch][0] : t[0][0]);
 }
 
 // Eliminate the columns j0 .. j1-1 of S (packed, N1 x N1, the last row is a right-hand side riding along): LDL' without square
 // roots -- the columns keep L D (unscaled), dinv[j] = 1 / d_j, or 0 for a pivot below tau * ref[j] (a dependent row: it drops out of
-// everything, the "infinite pivot" of qpc_qp_dense.h).  Panels of QPC_WG_NB columns: inside a panel one barrier per column (every
-// thread reads the pivot and inverts it itself; the waves update the panel's remaining columns), then the trailing columns take the
-// whole panel at once, in blocks of QPC_WG_CB adjacent columns per wave (a block from the front with one from the back: every
+// everything, the "infinite pivot" of qpc_qp_dense.h).  Panels of QPC_WG_NB columns: the panel itself costs two barriers (below), then
+// the trailing columns take the whole panel at once, in blocks of QPC_WG_CB adjacent columns per wave (a block from the front with one from the back: every
 // pair has about the same length), lanes down the rows: 8 + 4 loads and 4 stores for 32 multiply-adds -- the LDS pipe is what
 // bounds this routine.  A short last panel and a short last block are padded with zero factors.
 // Barrier-synchronised on entry and on exit.
 QPC_FN void wg_ldl_eliminate(double *S, int N1, int j0, int j1, const double *ref, double tau, double *dinv) {
   for (int jp = j0; jp < j1; jp += QPC_WG_NB) {
     const int nb = j1 - jp < QPC_WG_NB ? j1 - jp : QPC_WG_NB;
-    for (int jj = 0; jj < nb; jj++) {
-      const int j = jp + jj, cj = wg_cs(j, N1);
-      const double d = S[cj], rf = ref[j];
-      const bool ok = d > tau * (rf > 1e-300 ? rf : 1e-300);
-      const double di = ok ? 1.0 / d : 0.0;
-      QPC_WG_T0 { dinv[j] = di; }
-      if (ok) {
-        QPC_WG_FOR_WAVE(cc, nb - 1 - jj) {
-          const int c = j + 1 + cc;
-          const double lc = S[cj + (c - j)] * di;
-          wg_col_axpy(S, wg_cs(c, N1), cj + (c - j), N1 - c, lc);
+    // ---- the panel.  Its nb x nb diagonal block is factored by EVERY thread in registers (36 broadcast loads, a chain of pivots):
+    //      nobody waits for anybody, and the rows below the block need no barrier between the panel's columns either -- a row's
+    //      nb values are a little triangular solve against the block's multipliers, which the thread already holds.  Same
+    //      arithmetic in the same order as eliminating the panel column by column.
+    QPC_WG_ACC_T0();
+    int pc[QPC_WG_NB];
+    double blk[QPC_WG_NB][QPC_WG_NB], mul[QPC_WG_NB][QPC_WG_NB], dv[QPC_WG_NB];
+#pragma unroll
+    for (int c = 0; c < QPC_WG_NB; c++) {
+      const int jc = c < nb ? jp + c : jp;
+      pc[c] = wg_cs(jc, N1) - jc; // S[i][jc] = S[pc + i]
+#pragma unroll
+      for (int r = c; r < QPC_WG_NB; r++) {
+        const double v = S[pc[c] + jp + (r < nb ? r : 0)]; // (always a load from a valid address, the choice afterwards)
+        blk[r][c] = (r < nb && c < nb) ? v : (r == c ? 1.0 : 0.0);
+      }
+    }
+    double rfv[QPC_WG_NB];
+#pragma unroll
+    for (int c = 0; c < QPC_WG_NB; c++) rfv[c] = ref[c < nb ? jp + c : jp];
+    QPC_WG_SYNC // (everybody has the block: thread 0 may overwrite it)
+#pragma unroll
+    for (int j = 0; j < QPC_WG_NB; j++) {
+      const double d = blk[j][j], rf = rfv[j];
+      const bool ok = j < nb && d > tau * (rf > 1e-300 ? rf : 1e-300);
+      dv[j] = ok ? 1.0 / d : 0.0;
+#pragma unroll
+      for (int c = j + 1; c < QPC_WG_NB; c++) {
+        const double lc = blk[c][j] * dv[j];
+        mul[c][j] = lc;
+#pragma unroll
+        for (int r = c; r < QPC_WG_NB; r++) blk[r][c] -= blk[r][j] * lc;
+      }
+    }
+    QPC_WG_T0 {
+#pragma unroll
+      for (int c = 0; c < QPC_WG_NB; c++) {
+        if (c < nb) {
+          dinv[jp + c] = dv[c];
+#pragma unroll
+          for (int r = c; r < QPC_WG_NB; r++) if (r < nb) S[pc[c] + jp + r] = blk[r][c];
         }
       }
-      QPC_WG_SYNC
     }
+    QPC_WG_FOR(t, N1 - jp - nb) { // the rows below the block (the right-hand-side row among them): u L1' = a
+      const int i = jp + nb + t;
+      double a[QPC_WG_NB];
+#pragma unroll
+      for (int c = 0; c < QPC_WG_NB; c++) a[c] = S[pc[c] + i]; // (a column beyond nb: pc of the first one, value unused)
+#pragma unroll
+      for (int j = 0; j < QPC_WG_NB; j++) {
+#pragma unroll
+        for (int c = j + 1; c < QPC_WG_NB; c++) a[c] -= a[j] * mul[c][j];
+      }
+#pragma unroll
+      for (int c = 1; c < QPC_WG_NB; c++) if (c < nb) S[pc[c] + i] = a[c];
+    }
+    QPC_WG_SYNC
+    QPC_WG_ACC(N1 > 100 ? 0 : 2);
     const int c0 = jp + nb, R = N1 - 1 - c0; // trailing columns c0 .. N1-2 (column N1-1 would be the corner of the right-hand-side row)
     if (R > 0) {
       const int nblk = (R + QPC_WG_CB - 1) / QPC_WG_CB;
-      double dv[QPC_WG_NB];
-      int pc[QPC_WG_NB];
 #pragma unroll
-      for (int jj = 0; jj < QPC_WG_NB; jj++) {
-        const int jc = jj < nb ? jp + jj : jp;
-        dv[jj] = jj < nb ? dinv[jc] : 0.0;
-        pc[jj] = wg_cs(jc, N1) - jc; // S[i][jc] = S[pc + i]
-      }
+      for (int jj = 0; jj < QPC_WG_NB; jj++) dv[jj] = jj < nb ? dv[jj] : 0.0; // (the padding columns of a short panel)
       QPC_WG_FOR_WAVE(p, (nblk + 1) / 2) {
         for (int half = 0; half < 2; half++) {
           const int blk = half == 0 ? p : nblk - 1 - p;
@@ -220,6 +275,7 @@ QPC_FN void wg_ldl_eliminate(double *S, int N1, int j0, int j1, const double *re
         }
       }
       QPC_WG_SYNC
+      QPC_WG_ACC(N1 > 100 ? 1 : 3);
     }
   }
 }

@@ -91,6 +91,11 @@ qpc_qp_wg_prep_kernel(qpc::QpPrepView V, long long B, long long nnzP, const doub
       printf("wg_prep_prof (shader clock %.0f MHz) status %d us:", (double)(clock64() - c0__) / ((double)(wall_clock64() - w0__) * 0.01), s);
       for (int k = 1; k <= 8; k++) printf(" %.1f", (double)(t[k] - t[k - 1]) * 0.01);
       printf(" total %.1f\n", (double)(t[8] - t[0]) * 0.01);
+      if (blockIdx.x == 0) {
+        printf("  elimination: big matrix panel+rows %.1f (cumulative incl. trailing %.1f) us; small triangles %.1f / %.1f us\n", (double)qpc::qpc_wg_acc[0] * 0.01,
+               (double)qpc::qpc_wg_acc[1] * 0.01, (double)qpc::qpc_wg_acc[2] * 0.01, (double)qpc::qpc_wg_acc[3] * 0.01);
+        for (int k = 0; k < 8; k++) qpc::qpc_wg_acc[k] = 0;
+      }
     }
 #endif
   }
