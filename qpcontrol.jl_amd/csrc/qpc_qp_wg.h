@@ -246,6 +246,61 @@ QPC_FN void wg_ldl_eliminate(double *S, int N1, int j0, int j1, const double *re
     QPC_WG_ACC(N1 > 100 ? 0 : 2);
     const int c0 = jp + nb, R = N1 - 1 - c0; // trailing columns c0 .. N1-2 (column N1-1 would be the corner of the right-hand-side row)
     if (R > 0) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(QPC_WG_NO_MFMA)
+      // ---- on the device the update is what it looks like, a GEMM  C -= (panel rows) (panel rows of the columns)' : 16 x 16 tiles of the
+      //      trailing triangle on the matrix core, two v_mfma_f64_16x16x4_f64 per tile and panel (k = 8).  A wave takes a tile:
+      //      lane l supplies A[i = l & 15][k = l >> 4] and B[k][j = l & 15] and holds C[(l >> 4) + 4 r][l & 15], r = 0 .. 3 (the f64
+      //      instruction's own C/D map).  Tiles on the diagonal and at the edges compute all 256 entries and store the ones that
+      //      exist (rows and columns beyond the matrix read a clamped address).  ~60 instructions per tile instead of ~1 400 on the vector
+      //      unit (which the host emulation below still runs: same sums, another order).
+      {
+        typedef double wg_v4d __attribute__((ext_vector_type(4)));
+        const int lane = threadIdx.x & 63, kq = lane >> 4, ll = lane & 15;
+        const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // (a scalar: the tile loop below branches, it does not mask)
+        const int k0 = kq < nb ? kq : 0, k1 = kq + 4 < nb ? kq + 4 : 0;          // this lane's two panel columns (k and k + 4)
+        const int p0 = wg_cs(jp + k0, N1) - (jp + k0), p1 = wg_cs(jp + k1, N1) - (jp + k1);
+        const double d0 = kq < nb ? dinv[jp + k0] : 0.0, d1 = kq + 4 < nb ? dinv[jp + k1] : 0.0; // (written before the barrier above)
+        const int ntr = (N1 - c0 + 15) / 16, ntc = (R + 15) / 16, cend = c0 + R;
+        // the tiles of the lower triangle, row of tiles by row of tiles (row ti has min(ti + 1, ntc) of them); a wave takes every
+        // QPC_WG_NWAVE-th one and steps straight to its next (walking over the others' tiles cost more than the tiles themselves)
+#if defined(QPC_WG_PROF)
+        const unsigned long long tl0__ = wall_clock64();
+#endif
+        int ti = 0, tj = wave;
+        while (true) {
+          while (ti < ntr && tj >= (ti + 1 < ntc ? ti + 1 : ntc)) { tj -= ti + 1 < ntc ? ti + 1 : ntc; ti++; }
+          if (ti >= ntr) break;
+          {
+            const int R0 = c0 + 16 * ti, C0 = c0 + 16 * tj;
+            const int rA = R0 + ll < N1 ? R0 + ll : N1 - 1, rB = C0 + ll < N1 ? C0 + ll : N1 - 1;
+            const double a0 = -S[p0 + rA], a1 = -S[p1 + rA], b0 = S[p0 + rB] * d0, b1 = S[p1 + rB] * d1;
+            const int col = C0 + ll, colc = col < cend ? col : cend - 1;
+            const int cbase = wg_cs(colc, N1) - colc;
+            int addr[4];
+            bool okc[4];
+            wg_v4d acc;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              const int row = R0 + kq + 4 * r;
+              okc[r] = col < cend && row < N1 && row >= col;
+              addr[r] = cbase + (okc[r] ? row : colc); // (an entry that does not exist: the column's diagonal, value unused)
+              acc[r] = S[addr[r]];
+            }
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; r++) if (okc[r]) S[addr[r]] = acc[r];
+          }
+          tj += QPC_WG_NWAVE;
+        }
+#if defined(QPC_WG_PROF)
+        if (threadIdx.x == 0 && blockIdx.x == 0 && N1 > 100) { qpc_wg_acc[4] += wall_clock64() - tl0__; }
+#endif
+      }
+      QPC_WG_SYNC
+      QPC_WG_ACC(N1 > 100 ? 1 : 3);
+      continue;
+#endif
       const int nblk = (R + QPC_WG_CB - 1) / QPC_WG_CB;
 #pragma unroll
       for (int jj = 0; jj < QPC_WG_NB; jj++) dv[jj] = jj < nb ? dv[jj] : 0.0; // (the padding columns of a short panel)

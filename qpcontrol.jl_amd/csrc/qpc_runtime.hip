@@ -94,6 +94,7 @@ qpc_qp_wg_prep_kernel(qpc::QpPrepView V, long long B, long long nnzP, const doub
       if (blockIdx.x == 0) {
         printf("  elimination: big matrix panel+rows %.1f (cumulative incl. trailing %.1f) us; small triangles %.1f / %.1f us\n", (double)qpc::qpc_wg_acc[0] * 0.01,
                (double)qpc::qpc_wg_acc[1] * 0.01, (double)qpc::qpc_wg_acc[2] * 0.01, (double)qpc::qpc_wg_acc[3] * 0.01);
+        printf("  wave 0 inside its tile loops %.1f us\n", (double)qpc::qpc_wg_acc[4] * 0.01);
         for (int k = 0; k < 8; k++) qpc::qpc_wg_acc[k] = 0;
       }
     }
