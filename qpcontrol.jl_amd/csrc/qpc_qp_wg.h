@@ -61,7 +61,11 @@
 #define QPC_WG_SYNC
 #define QPC_WG_ADD(ptr, v) (*(ptr) += (v))
 #endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define QPC_WG_WAVE __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) // (told to be a scalar: loops over "my wave's" items branch instead of masking)
+#else
 #define QPC_WG_WAVE (QPC_WG_TID / QPC_WG_NLANE)
+#endif
 #define QPC_WG_LANE (QPC_WG_TID % QPC_WG_NLANE)
 #define QPC_WG_FOR(i, n) for (int i = QPC_WG_TID; i < (n); i += QPC_WG_NT)
 #define QPC_WG_FOR_WAVE(i, n) for (int i = QPC_WG_WAVE; i < (n); i += QPC_WG_NWAVE)
