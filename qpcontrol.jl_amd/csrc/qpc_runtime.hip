@@ -1235,6 +1235,9 @@ int32_t qpc_qp_setup(int32_t n, int32_t m, int64_t nnz_P, const int32_t *P_rows,
                      const int32_t *A_rows, const int32_t *A_cols, int32_t device_id, qpc_qp_problem **out) {
   if (!out || (nnz_P && (!P_rows || !P_cols)) || (nnz_A && (!A_rows || !A_cols))) { qpc_set_error("qpc_qp_setup: bad arguments"); return QPC_ERR_INVALID_ARGUMENT; }
   *out = nullptr;
+  std::unique_ptr<qpc_qp_problem> p(new qpc_qp_problem);
+  const std::string err = qpc::qp_prep_build(p->H, n, m, nnz_P, P_rows, P_cols, nnz_A, A_rows, A_cols);
+  if (!err.empty()) { qpc_set_error("qpc_qp_setup: " + err); return QPC_ERR_INVALID_ARGUMENT; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     (void)hipGetLastError();
@@ -1242,9 +1245,6 @@ int32_t qpc_qp_setup(int32_t n, int32_t m, int64_t nnz_P, const int32_t *P_rows,
     return QPC_ERR_NO_DEVICE;
   }
   if (device_id < 0 || device_id >= ndev) { qpc_set_error("qpc_qp_setup: device_id out of range"); return QPC_ERR_NO_DEVICE; }
-  std::unique_ptr<qpc_qp_problem> p(new qpc_qp_problem);
-  const std::string err = qpc::qp_prep_build(p->H, n, m, nnz_P, P_rows, P_cols, nnz_A, A_rows, A_cols);
-  if (!err.empty()) { qpc_set_error("qpc_qp_setup: " + err); return QPC_ERR_INVALID_ARGUMENT; }
   p->device = device_id;
   HIP_TRY(hipSetDevice(device_id));
   {

@@ -43,6 +43,17 @@ def test_construction_and_loud_failure_without_device(lib):
     assert lib.qpc_get_layout(c.h, ctypes.byref(lay)) == 2  # QPC_ERR_NOT_FINALIZED
 
 
+def test_prepared_l0_fails_loudly_without_device(lib):
+    """qpc_qp_setup (the solver-level plug with the optimizer's life cycle): no device, no problem -- QPC_ERR_NO_DEVICE, not a CPU path"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the no-device path cannot be exercised")
+    with pytest.raises(binding.QpcError, match="no HIP device|no CPU fallback|NO_DEVICE|code 4"):
+        binding.QpProblem(2, 1, np.eye(2, dtype=bool), np.ones((1, 2), dtype=bool))
+    with pytest.raises(binding.QpcError, match="out of range"):  # a bad pattern is refused before any device is touched
+        binding.QpProblem(2, 1, np.eye(2, dtype=bool), (np.array([5]), np.array([0])))
+
+
 def test_argument_validation(lib):
     mech = M.acrobot()
     model = binding.Model(mech)
