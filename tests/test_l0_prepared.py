@@ -152,3 +152,22 @@ def test_prepared_batch_gpu():
     assert (rw["status"] == 0).all() and (rw["iters"] <= 1).all()
     np.testing.assert_allclose(rw["x"], r["x"], atol=1e-9)
     pr.close()
+
+
+@pytest.mark.gpu
+def test_matrix_core_elimination_agrees_with_the_vector_unit_form_gpu():
+    """on the device the trailing updates of the elimination run on the matrix core (v_mfma_f64_16x16x4_f64), in the host emulation on
+    the vector-unit loops: the same sums in another order -- x of the committed problems to 1e-10, far inside the 1e-8 against the oracle"""
+    emu.build()
+    P, q, A, l, u, x, nv = _fixture()
+    pat_P, pat_A = (P != 0).any(0), (A != 0).any(0)
+    res = []
+    for lib in (None, emu.EMU_LIB):
+        pr = binding.QpProblem(P.shape[1], A.shape[1], pat_P, pat_A, lib_path=lib)
+        Pv, Av = pr.values(P, A)
+        res.append(pr.solve(Pv, q, Av, l, u))
+        pr.close()
+    assert (res[0]["status"] == 0).all() and (res[1]["status"] == 0).all()
+    np.testing.assert_array_equal(res[0]["iters"], res[1]["iters"])
+    scale = np.abs(res[1]["x"]).max(axis=1, keepdims=True)
+    assert (np.abs(res[0]["x"] - res[1]["x"]) / scale).max() < 1e-10
