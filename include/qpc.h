@@ -32,7 +32,8 @@
  *  - Environment.  The product library reads: QPC_DISABLE_JIT=1 (use the ahead-of-time generic kernel instead of the
  *    hiprtc-specialised one), QPC_REQUIRE_JIT=1 (fail qpc_finalize if the specialisation cannot be compiled), QPC_NO_PRESOLVE=1
  *    (keep the hard foot-task rows in the QP instead of eliminating them), QPC_JIT_CACHE=0 (do not reuse compiled code objects
- *    within the process), QPC_HOST_SLOTS / QPC_HOST_CHUNK / QPC_ZERO_COPY (defaults of qpc_set_host_pipeline), and the
+ *    within the process), QPC_JIT_CACHE_DIR=<directory> (keep them on disk as well: a later process with the same controller and
+ *    library skips the ~5 s of hiprtc in qpc_finalize), QPC_HOST_SLOTS / QPC_HOST_CHUNK / QPC_ZERO_COPY (defaults of qpc_set_host_pipeline), and the
  *    diagnostics QPC_JIT_STAMPS=1 (in-kernel section timers) and QPC_DUMP_LDS=1 (print the LDS overlay map).  The A/B switches
  *    of the development history only exist in builds with -DQPC_EXPERIMENTS (libqpcontrol_hip_exp.so).
  *  - There is NO CPU fallback: every compute entry point needs a HIP device and fails with

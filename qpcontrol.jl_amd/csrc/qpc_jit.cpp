@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <unistd.h>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -191,6 +192,7 @@ std::string qpc_jit_source(const QpcDims &D, const QpcDims &DS, bool warm, bool 
 
 // code objects of this process by (translation unit, architecture, options): controllers with the same task program (a test-suite,
 // one controller per device thread, ...) compile once.  QPC_JIT_CACHE=0 disables it.
+extern "C" const char *qpc_kernel_fingerprint(void);
 static std::mutex g_jit_mu;
 static std::map<std::string, std::vector<char>> g_jit_cache;
 
@@ -205,6 +207,35 @@ int qpc_jit_compile(const QpcDims &D, const QpcDims &DS, const std::string &arch
       std::lock_guard<std::mutex> lk(g_jit_mu);
       auto it = g_jit_cache.find(key);
       if (it != g_jit_cache.end()) { code = it->second; log.clear(); return 0; }
+    }
+  }
+  // on-disk cache (opt-in: QPC_JIT_CACHE_DIR=<directory>): qpc_finalize spends ~5 s in hiprtc per distinct controller; a process that
+  // comes back with the same controller on the same library reads the code object instead.  The file name carries the fingerprint of the
+  // embedded device headers and a hash of everything else that goes into the compile (specialised source, architecture, options).
+  std::string disk_path;
+  if (const char *dir = getenv("QPC_JIT_CACHE_DIR")) {
+    if (dir[0] && !key.empty()) {
+      unsigned long long h = 1469598103934665603ull;
+      for (unsigned char ch : key) { h ^= ch; h *= 1099511628211ull; }
+      char name[96];
+      snprintf(name, sizeof name, "/qpc_%s_%016llx.co", qpc_kernel_fingerprint(), h);
+      disk_path = std::string(dir) + name;
+      if (FILE *f = fopen(disk_path.c_str(), "rb")) {
+        fseek(f, 0, SEEK_END);
+        const long sz = ftell(f);
+        fseek(f, 0, SEEK_SET);
+        std::vector<char> buf(sz > 0 ? (size_t)sz : 0);
+        const bool ok = sz > 0 && fread(buf.data(), 1, (size_t)sz, f) == (size_t)sz;
+        fclose(f);
+        if (ok) {
+          code.swap(buf);
+          log.clear();
+          std::lock_guard<std::mutex> lk(g_jit_mu);
+          if (g_jit_cache.size() >= 64) g_jit_cache.clear();
+          g_jit_cache[key] = code;
+          return 0;
+        }
+      }
     }
   }
   hiprtcProgram prog;
@@ -244,6 +275,14 @@ int qpc_jit_compile(const QpcDims &D, const QpcDims &DS, const std::string &arch
     std::lock_guard<std::mutex> lk(g_jit_mu);
     if (g_jit_cache.size() >= 64) g_jit_cache.clear(); // (bounded: a code object is ~1 MB)
     g_jit_cache[key] = code;
+  }
+  if (!disk_path.empty()) { // written under another name and renamed: a reader never sees half a file
+    const std::string tmp = disk_path + ".tmp" + std::to_string((long long)getpid());
+    if (FILE *f = fopen(tmp.c_str(), "wb")) {
+      const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
+      fclose(f);
+      if (!ok || rename(tmp.c_str(), disk_path.c_str()) != 0) remove(tmp.c_str());
+    }
   }
   return 0;
 }

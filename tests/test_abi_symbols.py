@@ -79,6 +79,48 @@ def test_jit_source_compiles_offline(lib):
     assert rc == 0, buf.value.decode()
 
 
+def test_jit_disk_cache(lib, tmp_path, monkeypatch):
+    """QPC_JIT_CACHE_DIR: the second process-level compile of the same controller reads the code object from disk (qpc_finalize spends
+    ~5 s in hiprtc per distinct controller otherwise); same bytes, and QPC_JIT_CACHE=0 still compiles"""
+    import time
+    mech = M.acrobot()
+    lib.qpc_debug_jit_compile.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int32]
+
+    def compile_once(out):
+        c = binding.Controller(binding.Model(mech), 4, -1)
+        c.add_task(4, joint=1)
+        c.regularize(0, 1e-6)
+        buf = ctypes.create_string_buffer(4000)
+        t0 = time.perf_counter()
+        rc = lib.qpc_debug_jit_compile(c.h, b"gfx950", str(out).encode(), buf, 4000)
+        assert rc == 0, buf.value.decode()
+        return time.perf_counter() - t0
+
+    monkeypatch.setenv("QPC_JIT_CACHE_DIR", str(tmp_path))
+    monkeypatch.setenv("QPC_JIT_CACHE", "0")  # (the in-process cache off: nothing is stored, on disk or in memory)
+    compile_once(tmp_path / "a.co")
+    assert not list(tmp_path.glob("qpc_*.co"))
+    monkeypatch.delenv("QPC_JIT_CACHE")
+    t_cold = compile_once(tmp_path / "b.co")
+    files = list(tmp_path.glob("qpc_*.co"))
+    assert len(files) == 1 and lib.qpc_kernel_fingerprint().decode() in files[0].name
+    assert files[0].read_bytes() == (tmp_path / "b.co").read_bytes() == (tmp_path / "a.co").read_bytes()
+    # a fresh process (empty in-process cache) reads it back: the same bytes
+    import subprocess
+    import sys
+    code = ("import ctypes, sys, time; sys.path.insert(0, %r); import qpc_pkg; qpc_pkg.load()\n"
+            "from qpcontrol_jl_amd import binding, models as M\n"
+            "L = binding.load_library(); c = binding.Controller(binding.Model(M.acrobot()), 4, -1); c.add_task(4, joint=1); c.regularize(0, 1e-6)\n"
+            "L.qpc_debug_jit_compile.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int32]\n"
+            "t0 = time.perf_counter(); rc = L.qpc_debug_jit_compile(c.h, b'gfx950', sys.argv[1].encode(), None, 0); print(rc, time.perf_counter() - t0)\n"
+            % ROOT)
+    out = subprocess.run([sys.executable, "-c", code, str(tmp_path / "c.co")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-500:]
+    rc, t_disk = out.stdout.split()[-2:]
+    assert rc == "0" and (tmp_path / "c.co").read_bytes() == files[0].read_bytes()
+    print(f"hiprtc compile {t_cold:.2f} s, from the disk cache {float(t_disk):.2f} s")  # (no assertion: the toolchain may cache by itself)
+
+
 def test_bench_cpu_worker_cli():
     """bench.py's cpu_baseline leg: a child process (`--cpu-worker`) that only touches the oracle"""
     import json
