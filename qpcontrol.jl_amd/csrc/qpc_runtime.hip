@@ -1099,6 +1099,18 @@ int32_t qpc_assemble_solve_batch(qpc_controller *c, int64_t B, const double *tas
   return rc;
 }
 
+// the workgroup kernels of L0 ask for the whole LDS of a CU: the limit is a per-device function attribute, set once per device
+static int qpc_wg_lds_attr(const void *kernel, int device_id, int lds_bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<const void *, int>, hipError_t> done;
+  std::lock_guard<std::mutex> lk(mu);
+  auto key = std::make_pair(kernel, device_id);
+  auto it = done.find(key);
+  if (it == done.end()) it = done.emplace(key, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)).first;
+  if (it->second != hipSuccess) return hip_fail(it->second, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+  return QPC_OK;
+}
+
 // ---- L0: raw dense QPs.  Workspace per QP in HBM (qpc_qp_dense.h).
 uint64_t qpc_qp_workspace_bytes(int32_t n, int32_t m, int64_t B) {
   if (n <= 0 || m < 0 || B < 0) return 0;
@@ -1122,11 +1134,8 @@ int32_t qpc_qp_solve_batch_device(int32_t n, int32_t m, int64_t B, const double 
   int wg = m > 0 && n <= QPC_WG_DIM && m <= QPC_WG_DIM;
   if (const char *e = QPC_EXP_ENV("QPC_L0_ONE_LANE")) if (e[0] == '1') wg = 0;
   if (wg) {
-    static std::once_flag once;
-    static hipError_t attr_rc = hipSuccess;
     const int lds_bytes = qpc::qp_wg_lds_doubles(n, m) * (int)sizeof(double);
-    std::call_once(once, [&] { attr_rc = hipFuncSetAttribute((const void *)qpc_qp_wg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); });
-    HIP_TRY(attr_rc);
+    if (int arc = qpc_wg_lds_attr((const void *)qpc_qp_wg_kernel, device_id, lds_bytes)) return arc;
     static std::mutex cu_mu;
     static std::map<int, int> cu_of; // (hipGetDeviceProperties costs tens of microseconds: once per device)
     int n_cu = 0;
@@ -1246,21 +1255,23 @@ int32_t qpc_qp_setup(int32_t n, int32_t m, int64_t nnz_P, const int32_t *P_rows,
   }
   if (device_id < 0 || device_id >= ndev) { qpc_set_error("qpc_qp_setup: device_id out of range"); return QPC_ERR_NO_DEVICE; }
   p->device = device_id;
-  HIP_TRY(hipSetDevice(device_id));
-  {
+  auto setup = [&]() -> int { // (a failure half-way: qpc_qp_free below releases what was allocated)
+    HIP_TRY(hipSetDevice(device_id));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device_id));
     p->n_cu = prop.multiProcessorCount;
-  }
-  HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
-  HIP_TRY(hipMalloc(&p->d_ints, p->H.ints.size() * sizeof(int)));
-  HIP_TRY(hipMemcpy(p->d_ints, p->H.ints.data(), p->H.ints.size() * sizeof(int), hipMemcpyHostToDevice));
-  std::vector<int> coo;
-  coo.insert(coo.end(), p->H.Prow.begin(), p->H.Prow.end()); coo.insert(coo.end(), p->H.Pcol.begin(), p->H.Pcol.end());
-  coo.insert(coo.end(), p->H.Arow.begin(), p->H.Arow.end()); coo.insert(coo.end(), p->H.Acol.begin(), p->H.Acol.end());
-  coo.push_back(0);
-  HIP_TRY(hipMalloc(&p->d_coo, coo.size() * sizeof(int)));
-  HIP_TRY(hipMemcpy(p->d_coo, coo.data(), coo.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc(&p->d_ints, p->H.ints.size() * sizeof(int)));
+    HIP_TRY(hipMemcpy(p->d_ints, p->H.ints.data(), p->H.ints.size() * sizeof(int), hipMemcpyHostToDevice));
+    std::vector<int> coo;
+    coo.insert(coo.end(), p->H.Prow.begin(), p->H.Prow.end()); coo.insert(coo.end(), p->H.Pcol.begin(), p->H.Pcol.end());
+    coo.insert(coo.end(), p->H.Arow.begin(), p->H.Arow.end()); coo.insert(coo.end(), p->H.Acol.begin(), p->H.Acol.end());
+    coo.push_back(0);
+    HIP_TRY(hipMalloc(&p->d_coo, coo.size() * sizeof(int)));
+    HIP_TRY(hipMemcpy(p->d_coo, coo.data(), coo.size() * sizeof(int), hipMemcpyHostToDevice));
+    return QPC_OK;
+  };
+  if (int rc = setup()) { qpc_qp_free(p.release()); return rc; }
   *out = p.release();
   return QPC_OK;
 }
@@ -1351,11 +1362,8 @@ int32_t qpc_qp_solve(qpc_qp_problem *p, int64_t B, const double *P_vals, const d
     if (p->d_yprev) { chk(hipMemcpyAsync(p->d_yprev, dy, nm * 8, hipMemcpyDeviceToDevice, p->stream), "keep y"); p->B_prev = B; }
   };
   if (rc == QPC_OK && wg) {
-    static std::once_flag once;
-    static hipError_t attr_rc = hipSuccess;
     const int lds_bytes = QPC_WG_LDS_DOUBLES * (int)sizeof(double);
-    std::call_once(once, [&] { attr_rc = hipFuncSetAttribute((const void *)qpc_qp_wg_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); });
-    HIP_TRY(attr_rc);
+    if (int arc = qpc_wg_lds_attr((const void *)qpc_qp_wg_prep_kernel, p->device, lds_bytes)) return arc;
     const long long grid = B < (long long)p->n_cu * 4 ? B : (long long)p->n_cu * 4;
     unsigned long long *ticket = (unsigned long long *)(dws + ws_stride * B - 1); // (the last of the workspace's spare doubles)
     const double *y0 = warm ? p->d_yprev : (const double *)nullptr;
