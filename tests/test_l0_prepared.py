@@ -146,6 +146,11 @@ def test_prepared_batch_gpu():
     Pv, Av = pr.values(P, A)
     idx = np.arange(256) % P.shape[0]
     r = pr.solve(Pv[idx], q[idx], Av[idx], l[idx], u[idx])
+    # more QPs than workgroups in flight (the grid is 4 per CU): every workgroup draws several tickets from the device counter
+    big = np.arange(4096) % P.shape[0]
+    rb = pr.solve(Pv[big], q[big], Av[big], l[big], u[big])
+    assert (rb["status"] == 0).all()
+    np.testing.assert_array_equal(rb["x"], r["x"][:P.shape[0]][big])  # the same problem gives the same bits wherever it runs
     assert (r["status"] == 0).all()
     np.testing.assert_allclose(r["x"][:, :nv], x[idx][:, :nv], atol=1e-8)
     rw = pr.solve(Pv[idx], q[idx], Av[idx], l[idx], u[idx], warm_start=True)
