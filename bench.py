@@ -365,17 +365,28 @@ def closed_loop_point():
 
 
 def l0_plugin_point():
-    """SURVEY.md 8 b-1, outside the timed region: the solver-level plug qpc_qp_solve_batch on the dense 143 x 178 Atlas problem
-    (what unmodified QPControl.jl would hand to its optimizer slot), tools/bench_latency.py --l0 in a child process"""
+    """SURVEY.md 8 b-1, outside the timed region: the solver-level plug on the 143 x 178 Atlas problem (what unmodified QPControl.jl
+    hands to its optimizer slot) -- the prepared entry QPCOptimizer binds (qpc_qp_setup / qpc_qp_solve, cold and warm-started) and the
+    dense entry qpc_qp_solve_batch; tools/bench_latency.py --l0 in a child process"""
     try:
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_latency.py"), "--l0", "1", "1024"], capture_output=True, text=True,
                            timeout=300)
         d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-        return {"n": d["n"], "m": d["m"], "latency_us_B1": d["1"]["median_us"], "latency_us_B1_median_over_problems": d.get("B1_median_over_problems_us"),
-                "latency_us_B1_worst_problem": d.get("B1_worst_problem_us"), "solves_per_s_B1024": d["1024"]["solves_per_s"],
-                "max_abs_err_vdot_vs_fixture": max(d["1"]["max_abs_err_vdot_vs_fixture"], d["1024"]["max_abs_err_vdot_vs_fixture"]),
+        pr = d.get("prepared", {})
+        dense = {"latency_us_B1": d["1"]["median_us"], "latency_us_B1_median_over_problems": d.get("B1_median_over_problems_us"),
+                 "latency_us_B1_worst_problem": d.get("B1_worst_problem_us"), "solves_per_s_B1024": d["1024"]["solves_per_s"],
+                 "max_abs_err_vdot_vs_fixture": max(d["1"]["max_abs_err_vdot_vs_fixture"], d["1024"]["max_abs_err_vdot_vs_fixture"])}
+        return {"n": d["n"], "m": d["m"],
                 # the optimizer's life cycle (qpc_qp_setup once, qpc_qp_solve per tick: values only, warm start): what QPCOptimizer binds
-                "prepared": {k: v for k, v in d.get("prepared", {}).items() if k != "B1_per_problem"},
+                "entry": "qpc_qp_setup / qpc_qp_solve (pattern once, values per call; host pointers, synchronous, B = 1 unless stated)",
+                "latency_us_B1_cold_median_over_problems": pr.get("B1_cold_median_over_problems_us"),
+                "latency_us_B1_cold_worst_problem": pr.get("B1_cold_worst_problem_us"),
+                "latency_us_B1_warm_median_over_problems": pr.get("B1_warm_median_over_problems_us"),
+                "latency_us_B1_warm_worst_problem": pr.get("B1_warm_worst_problem_us"),
+                "solves_per_s_B1024_cold": pr.get("1024", {}).get("cold_solves_per_s"),
+                "solves_per_s_B1024_warm": pr.get("1024", {}).get("warm_solves_per_s"),
+                "max_abs_err_vdot_vs_fixture": pr.get("1024", {}).get("max_abs_err_vdot_vs_fixture"),
+                "dense_entry_qpc_qp_solve_batch": dense,
                 "reference_cpu_osqp_warm_tick_us": "800-1300 (cpu_baseline.warm_start.single_core)"}
     except Exception as e:  # noqa: BLE001 -- a diagnostic extra must never take the bench line down
         return {"error": repr(e)}
