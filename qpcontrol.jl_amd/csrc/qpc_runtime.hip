@@ -70,13 +70,18 @@ qpc_qp_wg_kernel(int n, int m, long long B, const double *P, const double *q, co
 extern "C" __global__ void __launch_bounds__(QPC_WG_THREADS)
 qpc_qp_wg_prep_kernel(qpc::QpPrepView V, long long B, long long nnzP, const double *Pv, const double *q, const double *Av,
                       const double *l, const double *u, qpc_settings st, double *ws, long long ws_stride, const double *y0,
-                      double *x, double *y, int32_t *status, int32_t *iters, unsigned long long *ticket) {
+                      double *x, double *y, int32_t *status, int32_t *iters, unsigned long long *ticket, double *ykeep) {
   extern __shared__ __attribute__((aligned(16))) double qpc_wg_lds[];
   while (true) { // (tickets: see qpc_qp_wg_kernel)
     if (threadIdx.x == 0) ((unsigned long long *)qpc_wg_lds)[15] = atomicAdd(ticket, 1ull);
     __syncthreads();
     const long long b = (long long)((unsigned long long *)qpc_wg_lds)[15];
-    if (b >= B) break;
+    if (b >= B) {
+      // a launch draws exactly B + gridDim.x tickets (every workgroup one past the end): whoever draws the last of them re-arms the
+      // counter, so that the host neither clears it before a launch nor keeps track of it (the tick's scheme)
+      if (threadIdx.x == 0 && b == B + (long long)gridDim.x - 1) atomicExch(ticket, 0ull);
+      break;
+    }
 #ifdef QPC_WG_PROF
     const long long c0__ = clock64(), w0__ = wall_clock64();
 #endif
@@ -85,6 +90,8 @@ qpc_qp_wg_prep_kernel(qpc::QpPrepView V, long long B, long long nnzP, const doub
                                         x + b * V.n, y + b * V.m, iters ? iters + b : nullptr);
     if (threadIdx.x == 0) status[b] = s;
     __syncthreads();
+    // the multipliers stay on the device for the next call's warm start (this QP's own slot: read at its start, written at its end)
+    if (ykeep && s != QPC_WG_FALLBACK) for (int i = threadIdx.x; i < V.m; i += blockDim.x) ykeep[b * V.m + i] = y[b * V.m + i];
 #ifdef QPC_WG_PROF
     if (threadIdx.x == 0 && b == 0) {
       const unsigned long long *t = (const unsigned long long *)(ws + qpc::qp_dense_workspace_doubles(V.n, V.m) - 16);
@@ -1235,6 +1242,7 @@ struct qpc_qp_problem {
   int64_t B_prev = 0, cap_prev = 0;
   char *dense = nullptr;                   // dense P, A of the batch (only when the dense path is needed)
   size_t dense_bytes = 0;
+  unsigned long long *d_ticket = nullptr;  // the launch's QP counter (zero between launches: the kernel re-arms it)
   char *h_stage = nullptr;                 // page-locked staging of a SMALL batch: one copy in, one copy out (B = 1 is the reference's regime)
   size_t h_stage_bytes = 0;
   int n_cu = 0;
@@ -1267,6 +1275,8 @@ int32_t qpc_qp_setup(int32_t n, int32_t m, int64_t nnz_P, const int32_t *P_rows,
     coo.insert(coo.end(), p->H.Prow.begin(), p->H.Prow.end()); coo.insert(coo.end(), p->H.Pcol.begin(), p->H.Pcol.end());
     coo.insert(coo.end(), p->H.Arow.begin(), p->H.Arow.end()); coo.insert(coo.end(), p->H.Acol.begin(), p->H.Acol.end());
     coo.push_back(0);
+    HIP_TRY(hipMalloc(&p->d_ticket, sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(p->d_ticket, 0, sizeof(unsigned long long)));
     HIP_TRY(hipMalloc(&p->d_coo, coo.size() * sizeof(int)));
     HIP_TRY(hipMemcpy(p->d_coo, coo.data(), coo.size() * sizeof(int), hipMemcpyHostToDevice));
     return QPC_OK;
@@ -1282,6 +1292,7 @@ void qpc_qp_free(qpc_qp_problem *p) {
   if (p->stream) { (void)hipStreamSynchronize(p->stream); (void)hipStreamDestroy(p->stream); }
   if (p->d_ints) (void)hipFree(p->d_ints);
   if (p->d_coo) (void)hipFree(p->d_coo);
+  if (p->d_ticket) (void)hipFree(p->d_ticket);
   if (p->buf) (void)hipFree(p->buf);
   if (p->d_yprev) (void)hipFree(p->d_yprev);
   if (p->dense) (void)hipFree(p->dense);
@@ -1365,18 +1376,22 @@ int32_t qpc_qp_solve(qpc_qp_problem *p, int64_t B, const double *P_vals, const d
     const int lds_bytes = QPC_WG_LDS_DOUBLES * (int)sizeof(double);
     if (int arc = qpc_wg_lds_attr((const void *)qpc_qp_wg_prep_kernel, p->device, lds_bytes)) return arc;
     const long long grid = B < (long long)p->n_cu * 4 ? B : (long long)p->n_cu * 4;
-    unsigned long long *ticket = (unsigned long long *)(dws + ws_stride * B - 1); // (the last of the workspace's spare doubles)
     const double *y0 = warm ? p->d_yprev : (const double *)nullptr;
-    chk(hipMemsetAsync(ticket, 0, sizeof(unsigned long long), p->stream), "clear the ticket counter");
+    if (B > p->cap_prev) { // the kernel leaves every QP's multipliers here for the next call's warm start
+      if (p->d_yprev) (void)hipFree(p->d_yprev);
+      p->d_yprev = nullptr; p->cap_prev = 0; p->B_prev = 0;
+      if (hipMalloc(&p->d_yprev, nm * 8) == hipSuccess) p->cap_prev = B; else (void)hipGetLastError();
+    }
+    // (no memset of the QP counter: the launch's last ticket re-arms it)
     hipLaunchKernelGGL(qpc_qp_wg_prep_kernel, dim3((unsigned)grid), dim3(QPC_WG_THREADS), (size_t)lds_bytes, p->stream, p->H.view(p->d_ints),
-                       (long long)B, nnzP, dPv, dq, dAv, dl, du, st, dws, ws_stride, y0, dx, dy, dst, dit, ticket);
+                       (long long)B, nnzP, dPv, dq, dAv, dl, du, st, dws, ws_stride, y0, dx, dy, dst, dit, p->d_ticket, p->d_yprev);
     chk(hipGetLastError(), "qpc_qp_wg_prep_kernel");
-    if (staged) { // outputs in one copy; the multipliers kept right away (a QP the workgroup left is rare and redoes both below)
+    if (staged) { // outputs in one copy (a QP the workgroup left is rare and redoes it below)
       char *ho = p->h_stage + in_bytes;
       chk(hipMemcpyAsync(ho, out0, out_bytes, hipMemcpyDeviceToHost, p->stream), "copy the outputs");
-      keep_y();
       chk(hipStreamSynchronize(p->stream), "qpc_qp_wg_prep_kernel");
-      if (rc != QPC_OK) return rc;
+      if (rc != QPC_OK) { (void)hipMemset(p->d_ticket, 0, sizeof(unsigned long long)); return rc; }
+      if (p->d_yprev) p->B_prev = B;
       memcpy(hst.data(), ho + ((char *)dst - out0), (size_t)B * sizeof(int32_t));
       bool left = false;
       for (int64_t b = 0; b < B; b++) left = left || hst[(size_t)b] == QPC_WG_FALLBACK;
@@ -1390,6 +1405,8 @@ int32_t qpc_qp_solve(qpc_qp_problem *p, int64_t B, const double *P_vals, const d
     } else {
       chk(hipMemcpyAsync(hst.data(), dst, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, p->stream), "copy status");
       chk(hipStreamSynchronize(p->stream), "qpc_qp_wg_prep_kernel");
+      if (rc != QPC_OK) { (void)hipMemset(p->d_ticket, 0, sizeof(unsigned long long)); return rc; }
+      if (p->d_yprev) p->B_prev = B;
     }
   }
   bool need_dense = !wg;
@@ -1424,7 +1441,7 @@ int32_t qpc_qp_solve(qpc_qp_problem *p, int64_t B, const double *P_vals, const d
     chk(hipMemcpyAsync(x, dx, nq * 8, hipMemcpyDeviceToHost, p->stream), "copy x");
     if (m) chk(hipMemcpyAsync(y, dy, nm * 8, hipMemcpyDeviceToHost, p->stream), "copy y");
     if (iters) chk(hipMemcpyAsync(iters, dit, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, p->stream), "copy iters");
-    keep_y();
+    if (need_dense) keep_y(); // (the workgroup kernel has kept its own; the QPs the dense path re-solved have new multipliers)
   }
   chk(hipStreamSynchronize(p->stream), "qpc_qp_solve");
   if (rc == QPC_OK) for (int64_t b = 0; b < B; b++) status[b] = hst[(size_t)b];
