@@ -11,17 +11,23 @@
 //
 //   * ONE elimination does the set-up.  The rows are ordered equalities first (E, ne rows: they are in every working set), the others
 //     after (I, mi rows), and the right-hand side g0 - b rides along as the last ROW of the matrix S = [G ; rhs'] (packed lower
-//     triangle, column-major, in LDS).  Eliminating the first ne columns (LDL' without square roots, in panels of 16 columns: the
-//     trailing matrix is touched once per panel with 16 multiply-adds per element) leaves, in place: L11 D (the factor of G_EE), the
+//     triangle, column-major, in LDS).  Eliminating the first ne columns (LDL' without square roots, in panels of 8 columns: the
+//     panel's diagonal block factored by every thread in registers, the trailing triangle updated as 16 x 16 tiles on the matrix
+//     core, v_mfma_f64_16x16x4_f64) leaves, in place: L11 D (the factor of G_EE), the
 //     rows G_IE L11^-T of the inequality rows, the Schur complement C = G_II - G_IE G_EE^-1 G_EI in the trailing block,
 //     zE = L11^-1 (g0_E - b_E) and a0 = A x at the equality-constrained minimiser in the last row.
 //   * The working-set iterations live in the space of the inequality rows only: a working set W factors C_WW (its own small packed
 //     triangle, the same elimination routine), A x = a0 - C[:, W] y_W.  The equality multipliers are recovered once, at the end.
-//   * A is compressed by COLUMNS on the way in (a thread per column: coalesced).  G = sum_c h_c a_c a_c' is accumulated column by
-//     column with LDS adds; every wave walks every column and adds only into the entries it owns, so the summation order is fixed.
-//     Products with A' walk the compressed columns; products with A use its transpose by row POSITION (global workspace, coalesced).
-//   * The workgroup runs ONE wave per SIMD: nothing hides a load but the code itself, so every loop over global or LDS data is
-//     written with its loads up front (several chunks in flight).
+//   * Two ways in.  A PREPARED problem (qp_solve_wg_prep: qpc_qp_setup / qpc_qp_solve, the optimizer's life cycle) brings the
+//     pattern's tables, built once on the host (qpc_qp_prep.h): compressed columns and rows, and for every structurally nonzero G_rs
+//     the terms it sums over -- a thread per entry, a fixed order, no atomics; the working set can start from an earlier call's
+//     multipliers.  DENSE matrices (qp_solve_wg) are compressed by columns on the way in (a thread per column: coalesced) and
+//     G = sum_c h_c a_c a_c' is accumulated column by column with LDS adds; every wave walks every column and adds only into the
+//     entries it owns, so the summation order is fixed.  Products with A' walk the compressed columns; products with A the
+//     compressed rows (prepared) or its transpose by row POSITION (dense entry: global workspace, coalesced).
+//   * The workgroup runs two waves per SIMD: little hides a load but the code itself, so every loop over global or LDS data is
+//     written with its loads up front, from addresses that are always valid (a conditional load makes the compiler wait for every
+//     load by itself), and per-wave work is reached by a scalar step, never by walking and skipping.
 // Anything else -- a dense or matrix-weighted P, a working set beyond QPC_WG_KW inequality rows -- is left to the one-lane kernel: the
 // workgroup reports QPC_WG_FALLBACK and the caller runs qp_solve_dense on that QP.  Both are gfx950 device code; neither is a
 // fallback to anything else.  When S does not fit beside the vectors in LDS (m beyond ~180) it lives in the global workspace
