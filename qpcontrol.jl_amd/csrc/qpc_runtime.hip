@@ -1173,7 +1173,7 @@ int32_t qpc_qp_solve_batch_device(int32_t n, int32_t m, int64_t B, const double 
 }
 
 // persistent device slab + stream of the host-pointer L0 entry, one per device of the process
-struct QpcL0Cache { char *buf = nullptr; size_t bytes = 0; hipStream_t stream = nullptr; };
+struct QpcL0Cache { char *buf = nullptr; size_t bytes = 0; hipStream_t stream = nullptr; char *h_stage = nullptr; };
 static std::mutex g_l0_mu;
 static std::map<int, QpcL0Cache> g_l0;
 
@@ -1206,19 +1206,49 @@ int32_t qpc_qp_solve_batch(int32_t n, int32_t m, int64_t B, const double *P, con
   }
   char *p = C.buf;
   auto take = [&](size_t bytes) { char *r = p; p += pad64(bytes); return r; };
+  // inputs side by side, outputs side by side: a SMALL batch (B = 1 is the reference's regime) moves in one copy each way through a
+  // page-locked buffer instead of nine copies of pageable memory
   double *dP = (double *)take(nP * 8), *dq = (double *)take(nq * 8), *dA = (double *)take(nA * 8), *dl = (double *)take(nm * 8),
-         *du = (double *)take(nm * 8), *dx = (double *)take(nq * 8), *dy = (double *)take(nm * 8), *dws = (double *)take(wsb);
+         *du = (double *)take(nm * 8);
+  const size_t in_bytes = (size_t)(p - C.buf);
+  char *const out0 = p;
+  double *dx = (double *)take(nq * 8), *dy = (double *)take(nm * 8);
   int32_t *dst = (int32_t *)take((size_t)B * sizeof(int32_t)), *dit = (int32_t *)take((size_t)B * sizeof(int32_t));
+  const size_t out_bytes = (size_t)(p - out0);
+  double *dws = (double *)take(wsb);
+  const size_t stage_cap = (size_t)2 << 20;
+  if (in_bytes + out_bytes <= stage_cap && !C.h_stage) { if (hipHostMalloc(&C.h_stage, stage_cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); C.h_stage = nullptr; } }
+  const bool staged = in_bytes + out_bytes <= stage_cap && C.h_stage != nullptr;
   int rc = QPC_OK;
   auto chk = [&](hipError_t e, const char *w) { if (e != hipSuccess && rc == QPC_OK) rc = hip_fail(e, w); };
-  chk(hipMemcpyAsync(dP, P, nP * sizeof(double), hipMemcpyHostToDevice, C.stream), "copy P");
-  chk(hipMemcpyAsync(dq, q, nq * sizeof(double), hipMemcpyHostToDevice, C.stream), "copy q");
-  if (m) {
-    chk(hipMemcpyAsync(dA, A, nA * sizeof(double), hipMemcpyHostToDevice, C.stream), "copy A");
-    chk(hipMemcpyAsync(dl, l, nm * sizeof(double), hipMemcpyHostToDevice, C.stream), "copy l");
-    chk(hipMemcpyAsync(du, u, nm * sizeof(double), hipMemcpyHostToDevice, C.stream), "copy u");
+  if (staged) {
+    char *h = C.h_stage;
+    memcpy(h + ((char *)dP - C.buf), P, nP * 8);
+    memcpy(h + ((char *)dq - C.buf), q, nq * 8);
+    if (m) { memcpy(h + ((char *)dA - C.buf), A, nA * 8); memcpy(h + ((char *)dl - C.buf), l, nm * 8); memcpy(h + ((char *)du - C.buf), u, nm * 8); }
+    chk(hipMemcpyAsync(C.buf, h, in_bytes, hipMemcpyHostToDevice, C.stream), "copy the inputs");
+  } else {
+    chk(hipMemcpyAsync(dP, P, nP * sizeof(double), hipMemcpyHostToDevice, C.stream), "copy P");
+    chk(hipMemcpyAsync(dq, q, nq * sizeof(double), hipMemcpyHostToDevice, C.stream), "copy q");
+    if (m) {
+      chk(hipMemcpyAsync(dA, A, nA * sizeof(double), hipMemcpyHostToDevice, C.stream), "copy A");
+      chk(hipMemcpyAsync(dl, l, nm * sizeof(double), hipMemcpyHostToDevice, C.stream), "copy l");
+      chk(hipMemcpyAsync(du, u, nm * sizeof(double), hipMemcpyHostToDevice, C.stream), "copy u");
+    }
   }
   if (rc == QPC_OK) rc = qpc_qp_solve_batch_device(n, m, B, dP, dq, dA, dl, du, settings, device_id, dx, dy, dst, dit, dws, wsb, C.stream);
+  if (rc == QPC_OK && staged) {
+    char *ho = C.h_stage + in_bytes;
+    chk(hipMemcpyAsync(ho, out0, out_bytes, hipMemcpyDeviceToHost, C.stream), "copy the outputs");
+    chk(hipStreamSynchronize(C.stream), "qpc_qp_dense_kernel");
+    if (rc == QPC_OK) {
+      memcpy(x, ho, nq * 8);
+      if (m) memcpy(y, ho + ((char *)dy - out0), nm * 8);
+      memcpy(status, ho + ((char *)dst - out0), (size_t)B * sizeof(int32_t));
+      if (iters) memcpy(iters, ho + ((char *)dit - out0), (size_t)B * sizeof(int32_t));
+    }
+    return rc;
+  }
   if (rc == QPC_OK) {
     chk(hipMemcpyAsync(x, dx, nq * sizeof(double), hipMemcpyDeviceToHost, C.stream), "copy x");
     if (m) chk(hipMemcpyAsync(y, dy, nm * sizeof(double), hipMemcpyDeviceToHost, C.stream), "copy y");
