@@ -126,14 +126,19 @@ class StandingSetup:
     pelvisgains: tuple = (20.0, 2 * math.sqrt(20.0))
     jointgains: tuple = (100.0, 20.0)
     contact_ids: list = field(default_factory=list)
+    linmom_dim: int = 3  # 6: a full MomentumRateTask (angular rows first, src/tasks.jl:204-221)
 
 
 def standing_setup(ctrl, mech: M.Mechanism, nominal_q, contacts=True, joint_regularization=0.05,
-                   linear_momentum_weight=1.0, feet=("l_foot", "r_foot"), pelvis="pelvis", fused_laws=False):
+                   linear_momentum_weight=1.0, feet=("l_foot", "r_foot"), pelvis="pelvis", fused_laws=False,
+                   momentum_weight_matrix=None):
     """Register the standing task set on `ctrl` in the reference's order: contacts first
     (notebook cell 5), then regularize!, foot tasks, linear momentum (soft), pelvis, joints.
     fused_laws: hand the PD laws of standing.jl:58-89 to the controller (`set_task_law`) so that
-    the device evaluates them per QP and no `desired` record is needed."""
+    the device evaluates them per QP and no `desired` record is needed.
+    momentum_weight_matrix: a 6 x 6 W -- the momentum task becomes a full `MomentumRateTask` added with
+    `addtask!(controller, task, W::AbstractMatrix)` (momentum.jl:113-117: e'We on six slack variables; test/controller.jl:232-285
+    modes MATRIX_WEIGHT*), desired angular part 0, linear part as the linear task's."""
     feet_idx = [mech.findbody(f) for f in feet]
     st = StandingSetup(mech, feet_idx, mech.findbody(pelvis))
     if contacts:
@@ -152,8 +157,14 @@ def standing_setup(ctrl, mech: M.Mechanism, nominal_q, contacts=True, joint_regu
     for f in feet_idx:  # standing.jl:37-38
         tid = ctrl.add_task(SPATIAL, base=M.WORLD, target=f, frame=M.FRAME_DEFAULT, wkind=HARD)
         st.foot_tasks.append(tid); reg(tid, 6)
-    st.linmom_task = ctrl.add_task(LINEAR_MOMENTUM_RATE, wkind=SCALAR, weight=[linear_momentum_weight])
-    reg(st.linmom_task, 3)  # standing.jl:40-41
+    if momentum_weight_matrix is None:
+        st.linmom_task = ctrl.add_task(LINEAR_MOMENTUM_RATE, wkind=SCALAR, weight=[linear_momentum_weight])
+        reg(st.linmom_task, 3)  # standing.jl:40-41
+    else:
+        assert not fused_laws
+        st.linmom_task = ctrl.add_task(MOMENTUM_RATE, wkind=MATRIX, weight=np.asarray(momentum_weight_matrix, dtype=float))
+        st.linmom_dim = 6
+        reg(st.linmom_task, 6)
     st.pelvis_task = ctrl.add_task(ANGULAR, base=M.WORLD, target=st.pelvis, frame=M.FRAME_DEFAULT, wkind=HARD)
     reg(st.pelvis_task, 3)  # standing.jl:43-44
     on_foot_path = set()
@@ -192,7 +203,7 @@ def standing_desired(st: StandingSetup, q, v):
     e = kin["com"] - st.comref[None]
     edot = kin["linear_momentum"] / m
     cdd = -st.comgains[0] * e - st.comgains[1] * edot
-    o = st.offsets[st.linmom_task]
+    o = st.offsets[st.linmom_task] + (st.linmom_dim - 3)
     des[:, o:o + 3] = m * cdd
     Rp = kin["R"][st.pelvis]
     w_body = np.einsum("bji,bj->bi", Rp, kin["w"][st.pelvis])
@@ -238,7 +249,7 @@ class Workload:
     n_basis: int = 4
 
 
-def atlas_workload(ctrl_factory, B, config=3, seed=None, fused_laws=False):
+def atlas_workload(ctrl_factory, B, config=3, seed=None, fused_laws=False, momentum_weight_matrix=None):
     """BASELINE.json configs 2-5 on the synthetic Atlas.  `ctrl_factory(mech, n_basis, floating_body)`
     returns a controller object (product binding or oracle) which is populated and finalized."""
     mech = M.atlas()
@@ -247,7 +258,7 @@ def atlas_workload(ctrl_factory, B, config=3, seed=None, fused_laws=False):
     floating = mech.findbody("pelvis") if contacts else M.WORLD
     ctrl = ctrl_factory(mech, 4, floating)
     q0 = M.atlas_nominal_configuration(mech)
-    st = standing_setup(ctrl, mech, q0, contacts=contacts, fused_laws=fused_laws)
+    st = standing_setup(ctrl, mech, q0, contacts=contacts, fused_laws=fused_laws, momentum_weight_matrix=momentum_weight_matrix)
     ctrl.finalize()
     q, v = standing_states(mech, B, seed)
     des = standing_desired(st, q, v)

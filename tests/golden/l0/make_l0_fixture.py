@@ -24,9 +24,27 @@ import scenarios as SC  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
 
+def momentum_weight_matrix():
+    """the 6 x 6 W of the matrix-weighted fixture: symmetric positive definite, NOT diagonal (seeded)"""
+    rng = np.random.default_rng(61)
+    Q = rng.normal(size=(6, 6))
+    return Q @ Q.T / 6.0 + np.diag([0.5, 0.5, 0.5, 1.0, 1.0, 1.0])
+
+
 def main(B=8):
     O.build()
-    case = SC.atlas_config(lambda mech, N, fl: O.OracleController(O.OracleModel(mech), N, fl), 3, B)
+    factory = lambda mech, N, fl: O.OracleController(O.OracleModel(mech), N, fl)  # noqa: E731
+    write(SC.atlas_config(factory, 3, B), "atlas_143x178.npz")
+    # the same controller with `addtask!(controller, MomentumRateTask, W::AbstractMatrix)` (momentum.jl:113-117; the reference's test
+    # modes OBJECTIVE_TERM_MATRIX_WEIGHT*, test/controller.jl:232-285) in place of the scalar-weighted linear momentum task:
+    # six slack variables, a 6 x 6 block in P
+    from qpcontrol_jl_amd import workloads as W
+    ctrl, wl = W.atlas_workload(factory, B, 3, momentum_weight_matrix=momentum_weight_matrix())
+    write(SC.Case("atlas_matrix_weight", wl.mech, ctrl, wl.q, wl.v, wl.desired, wl.contact_weight, wl.contact_maxnormalforce,
+                  floating=wl.floating_body), "atlas_matrix_weight_146x181.npz")
+
+
+def write(case, fname):
     oc = case.ctrl
     Ps, qs, As, ls, us, xs = [], [], [], [], [], []
     for b in range(case.B):
@@ -37,10 +55,10 @@ def main(B=8):
         Ps.append(P); qs.append(q); As.append(A); ls.append(l); us.append(u); xs.append(r["x"])
     P, A = np.array(Ps), np.array(As)
     pat_P, pat_A = np.any(P != 0.0, axis=0), np.any(A != 0.0, axis=0)
-    np.savez_compressed(os.path.join(HERE, "atlas_143x178.npz"), n=np.int32(P.shape[1]), m=np.int32(A.shape[1]),
+    np.savez_compressed(os.path.join(HERE, fname), n=np.int32(P.shape[1]), m=np.int32(A.shape[1]),
                         P_idx=np.argwhere(pat_P).astype(np.int16), P_val=P[:, pat_P], A_idx=np.argwhere(pat_A).astype(np.int16),
                         A_val=A[:, pat_A], q=np.array(qs), l=np.array(ls), u=np.array(us), x=np.array(xs), nv=np.int32(case.mech.nv))
-    print(f"{len(Ps)} QPs, n = {P.shape[1]}, m = {A.shape[1]}, nnz(P) = {int(pat_P.sum())}, nnz(A) = {int(pat_A.sum())}")
+    print(f"{fname}: {len(Ps)} QPs, n = {P.shape[1]}, m = {A.shape[1]}, nnz(P) = {int(pat_P.sum())}, nnz(A) = {int(pat_A.sum())}")
 
 
 if __name__ == "__main__":

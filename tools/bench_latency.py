@@ -20,9 +20,13 @@ qpc_pkg.load()
 from qpcontrol_jl_amd import binding, workloads as W  # noqa: E402
 
 
-def load_l0_fixture():
+L0_FIXTURES = {"diag": "atlas_143x178.npz",                   # the standing controller as the notebook builds it: P diagonal
+               "matrix": "atlas_matrix_weight_146x181.npz"}   # ... with a matrix-weighted MomentumRateTask: a 6 x 6 block in P
+
+
+def load_l0_fixture(which="diag"):
     """The committed reference-layout problems (inputs + expected x), densified: P[k,n,n], q, A[k,m,n], l, u, x, nv"""
-    g = np.load(os.path.join(ROOT, "tests", "golden", "l0", "atlas_143x178.npz"))
+    g = np.load(os.path.join(ROOT, "tests", "golden", "l0", L0_FIXTURES[which]))
     n, m, k = int(g["n"]), int(g["m"]), g["q"].shape[0]
     P, A = np.zeros((k, n, n)), np.zeros((k, m, n))
     P[:, g["P_idx"][:, 0], g["P_idx"][:, 1]] = g["P_val"]
