@@ -1,0 +1,815 @@
+// qpc_qp_sp.h -- L0 for a PREPARED problem with a PLAN (qpc_qp_sym.h): the sparse form of the workgroup solver of qpc_qp_wg.h, what
+// serves the reference's own plug point -- the optimizer slot of `MomentumBasedController{N}(mechanism, optimizer)`,
+// /root/reference/src/lowlevel/momentum.jl:15-16,27,58 -- at B = 1 and in batches.
+//
+// Same method (range-space active set on G = A H^-1 A': ONE elimination of the equality rows leaves their factor, the Schur
+// complement C on the inequality rows and the right-hand sides; primal-dual sweeps and Goldfarb-Idnani in the space of the
+// inequality rows; refinement on the true KKT residuals), but nothing in it is dense any more except C:
+//   * H = P + eps I is block diagonal (blocks of <= 8 variables: the e'We of matrix-weighted tasks, momentum.jl:113-117), inverted
+//     block by block, one wavefront per block;
+//   * G is built entry by entry of its STRUCTURE, into a store that holds only the structure of its factor: the FRONTS of the
+//     elimination tree (small dense rectangles) and C.  For Atlas (143 x 178): 6.2 k doubles instead of 16.1 k;
+//   * the elimination runs level by level of the tree: the fronts of a level are factored concurrently, one wavefront each, without
+//     a workgroup barrier inside a front; their updates of later fronts and of C are 16 x 16 tile jobs on the matrix core
+//     (v_mfma_f64_16x16x4_f64), every target tile summed by one wavefront over all its source columns in a fixed order;
+//   * triangular solves with the equality rows' factor go front by front along the same levels;
+//   * the working-set iterations are ONE wavefront's work (the other wavefronts wait at a barrier): factor of C_WW, multipliers,
+//     A x, ratio tests and the choice of the next row without a single workgroup barrier.
+// A QP whose set of equality rows differs from the plan's returns QPC_WG_FALLBACK (the dense workgroup form takes it).
+//
+// Written like qpc_qp_wg.h as loops over the workgroup / a wavefront's lanes so that the same source runs serially inside the test
+// emulation (one "thread"); the matrix-core tile loop has a scalar twin there (same sums, another order).
+#pragma once
+#include "../../include/qpc.h"
+#include "qpc_qp_spview.h"
+
+#ifndef QPC_FN
+#error "include qpc_device.h (or the emulator's definitions) first"
+#endif
+#ifndef QPC_WG_FALLBACK
+#define QPC_WG_FALLBACK (-1)
+#endif
+
+#ifndef QPC_SP_THREADS
+#define QPC_SP_THREADS 256 // threads of the workgroup (device)
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define QPC_SP_NT QPC_SP_THREADS
+#define QPC_SP_NWAVE (QPC_SP_THREADS / 64)
+#define QPC_SP_NLANE 64
+#define QPC_SP_TID ((int)threadIdx.x)
+#define QPC_SP_SYNC __syncthreads();
+#define QPC_SP_WAVE __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))
+// inside one wavefront LDS operations execute in program order: what a lane has stored, every lane reads afterwards -- the compiler
+// only has to be kept from moving the accesses across this point
+#define QPC_SP_WSYNC do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0);
+#else
+#define QPC_SP_NT 1
+#define QPC_SP_NWAVE 1
+#define QPC_SP_NLANE 1
+#define QPC_SP_TID 0
+#define QPC_SP_SYNC
+#define QPC_SP_WAVE 0
+#define QPC_SP_WSYNC
+#endif
+#define QPC_SP_LANE (QPC_SP_TID % QPC_SP_NLANE)
+#define QPC_SP_FOR(i, n) for (int i = QPC_SP_TID; i < (n); i += QPC_SP_NT)
+#define QPC_SP_FOR_WAVE(i, a, b) for (int i = (a) + QPC_SP_WAVE; i < (b); i += QPC_SP_NWAVE)
+#define QPC_SP_FOR_LANE(i, n) for (int i = QPC_SP_LANE; i < (n); i += QPC_SP_NLANE)
+#define QPC_SP_T0 if (QPC_SP_TID == 0)
+#define QPC_SP_L0 if (QPC_SP_LANE == 0)
+#if defined(QPC_SP_PROF) && defined(__HIP_DEVICE_COMPILE__)
+#define QPC_SP_STAMP(W, k) do { if (threadIdx.x == 0 && (k) < 16) (W).stamps[k] = wall_clock64(); } while (0)
+#else
+#define QPC_SP_STAMP(W, k) do { } while (0)
+#endif
+
+namespace qpc {
+
+QPC_FN int sp_cs(int c, int N1) { return c * N1 - (c * (c - 1)) / 2; }      // packed lower triangle, column-major: start of column c
+QPC_FN int sp_sidx(int i, int c, int N1) { return sp_cs(c, N1) + i - c; }    // i >= c
+QPC_FN int sp_sym(int a, int b, int N1) { return a >= b ? sp_sidx(a, b, N1) : sp_sidx(b, a, N1); }
+
+// max over the workgroup (every thread gets it); red: QPC_SP_NWAVE doubles of LDS.  A NaN wins.
+QPC_FN double sp_wave_max(double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(v, off, 64); v = (o > v || !(o == o)) ? o : v; }
+#endif
+  return v;
+}
+QPC_FN double sp_reduce_max(double v, double *red) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  v = sp_wave_max(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double r = red[0];
+  for (int w = 1; w < QPC_SP_NWAVE; w++) { const double o = red[w]; r = (o > r || !(o == o)) ? o : r; }
+  __syncthreads();
+  return r;
+#else
+  (void)red;
+  return v;
+#endif
+}
+QPC_FN bool sp_wave_any(bool f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __ballot(f) != 0ull;
+#else
+  return f;
+#endif
+}
+// the lane holding the largest v (ties: the smallest idx); idx < 0: no candidate.  Every lane gets (v, idx).
+QPC_FN void sp_wave_argmax(double &v, int &idx) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  for (int off = 32; off > 0; off >>= 1) {
+    const double ov = __shfl_xor(v, off, 64);
+    const int oi = __shfl_xor(idx, off, 64);
+    const bool take = oi >= 0 && (idx < 0 || ov > v || (ov == v && oi < idx));
+    v = take ? ov : v; idx = take ? oi : idx;
+  }
+#endif
+}
+QPC_FN void sp_wave_argmin(double &v, int &idx) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  for (int off = 32; off > 0; off >>= 1) {
+    const double ov = __shfl_xor(v, off, 64);
+    const int oi = __shfl_xor(idx, off, 64);
+    const bool take = oi >= 0 && (idx < 0 || ov < v || (ov == v && oi < idx));
+    v = take ? ov : v; idx = take ? oi : idx;
+  }
+#endif
+}
+
+struct QpSp {
+  const int *pl;  // the plan's LDS part
+  const int *plg; // the whole plan in global memory
+  int n, m, ne, mi, N1, M1, Cb, nfront, nlevel, kw;
+  const double *Pv, *q, *Av, *l, *u, *y0;
+  // LDS, doubles
+  double *sc, *red;
+  double *V;                               // the value store: fronts, then C
+  double *dinv, *gdiag, *t, *yp;           // by position: ne, m + 1, m + 1, m + 1
+  double *hv, *hm;                         // values of H^-1 and of P, block by block
+  double *xu, *x, *r1, *tn;                // n
+  double *lo, *hi, *wsf, *tm, *ax, *a0;    // mi
+  double *yw, *dinvW, *dW, *tW;            // kw + 1
+  int *idxW;
+  double *LW;                              // the working set's factor, (k + 1) x (k + 1) packed
+  double *sval;                            // A's values in column order
+  unsigned long long *stamps;
+};
+enum { SPS_FLAG = 0, SPS_STATUS, SPS_ITERS, SPS_NW, SPS_CONV, SPS_COUNT };
+
+QPC_FN double sp_C(const QpSp &W, int p, int q) { return W.V[W.Cb + sp_sym(p, q, W.M1)]; } // C by inequality position (mi: the right-hand-side row)
+
+// what the kernel asks of LDS for a plan, in doubles (kw: inequality rows a working set may hold)
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+inline int qp_sp_lds_doubles(const int *plan, int kw) {
+  const int n = plan[SP_N], m = plan[SP_M], ne = plan[SP_NE], mi = plan[SP_MI];
+  return (plan[SP_LDS_INTS] + 1) / 2 + 16 + 8 + plan[SP_NVAL] + ne + 3 * (m + 1) + 2 * plan[SP_NHV] + 4 * n + 6 * mi + 4 * (kw + 1) + (kw + 2) / 2 +
+         (kw + 1) * (kw + 2) / 2 + plan[SP_NNZA] + 2;
+}
+
+// ---- a front: LDL' of its w columns without square roots (the columns keep L D, dinv = 1 / d or 0 for a dropped pivot), the rows
+//      below its diagonal block carried along.  One wavefront, lanes down the rows; no workgroup barrier.
+QPC_FN void sp_front_factor(double *V, int base, int r, int w, const double *ref, double tau, double *dinv) {
+  for (int j = 0; j < w; j++) {
+    const double d = V[base + j * r + j], rf = ref[j];
+    const bool ok = d > tau * (rf > 1e-300 ? rf : 1e-300);
+    const double di = ok ? 1.0 / d : 0.0;
+    QPC_SP_L0 { dinv[j] = di; }
+    for (int i = j + 1 + QPC_SP_LANE; i < r; i += QPC_SP_NLANE) {
+      const double lij = V[base + j * r + i];
+      const int cend = i < w ? i : w - 1;
+      for (int c = j + 1; c <= cend; c++) V[base + c * r + i] -= lij * (V[base + j * r + c] * di);
+    }
+    QPC_SP_WSYNC
+  }
+}
+
+// ---- the update jobs of a level: target tile -= sum over its slots of (source column rows) d^-1 (source column rows)'
+QPC_FN void sp_update_jobs(const QpSp &W, int level) {
+  const int *pl = W.pl;
+  const int j0 = pl[pl[SP_O_JOBLV] + level], j1 = pl[pl[SP_O_JOBLV] + level + 1];
+  const int *job = pl + pl[SP_O_JOB], *slot = pl + pl[SP_O_SLOT], *map = pl + pl[SP_O_MAP];
+  double *V = W.V;
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef double sp_v4d __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63, kq = lane >> 4, ll = lane & 15;
+  QPC_SP_FOR_WAVE(jb, j0, j1) {
+    const int *J = job + jb * SP_JOB_INTS;
+    const int tbase = J[0], tstride = J[1], trows = J[2], tcols = J[3], r0 = J[4], c0 = J[5], s0 = J[6], nch = J[7];
+    const int col = c0 + ll, colc = col < tcols ? col : tcols - 1;
+    const int cbase = tstride ? tbase + colc * tstride : tbase + sp_cs(colc, trows) - colc;
+    int addr[4];
+    bool okc[4];
+    sp_v4d acc;
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+      const int row = r0 + kq + 4 * rr;
+      okc[rr] = col < tcols && row < trows && row >= col;
+      addr[rr] = cbase + (okc[rr] ? row : colc); // (an entry that does not exist: the column's diagonal, value unused)
+      acc[rr] = V[addr[rr]];
+    }
+    for (int ch = 0; ch < nch; ch++) {
+      const int *sl = slot + (s0 + 4 * ch + kq) * SP_SLOT_INTS;
+      const int cb = sl[0], dp = sl[1], mp = sl[2];
+      const int mpc = mp < 0 ? 0 : mp;
+      const int ra = map[mpc * 32 + ll], rb = map[mpc * 32 + 16 + ll];
+      const double av = V[cb + (ra < 0 ? 0 : ra)], bv = V[cb + (rb < 0 ? 0 : rb)], dv = W.dinv[dp];
+      const double a = (mp < 0 || ra < 0) ? 0.0 : -av, b = (mp < 0 || rb < 0) ? 0.0 : bv * dv;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) if (okc[rr]) V[addr[rr]] = acc[rr];
+  }
+#else
+  for (int jb = j0; jb < j1; jb++) {
+    const int *J = job + jb * SP_JOB_INTS;
+    const int tbase = J[0], tstride = J[1], trows = J[2], tcols = J[3], r0 = J[4], c0 = J[5], s0 = J[6], nch = J[7];
+    for (int lc = c0; lc < c0 + 16 && lc < tcols; lc++)
+      for (int lr = (r0 > lc ? r0 : lc); lr < r0 + 16 && lr < trows; lr++) {
+        double s = 0.0;
+        for (int k = s0; k < s0 + 4 * nch; k++) {
+          const int *sl = slot + k * SP_SLOT_INTS;
+          if (sl[2] < 0) continue;
+          const int ra = map[sl[2] * 32 + lr - r0], rb = map[sl[2] * 32 + 16 + lc - c0];
+          if (ra >= 0 && rb >= 0) s += V[sl[0] + ra] * (V[sl[0] + rb] * W.dinv[sl[1]]);
+        }
+        V[tstride ? tbase + lc * tstride + lr : tbase + sp_sidx(lr, lc, trows)] -= s;
+      }
+  }
+#endif
+}
+
+// ---- triangular solves with the equality rows' factor, front by front.  L is unit lower with L_ij = S_ij dinv_j.
+// t (by position) <- L^-1 t on the equality positions; with_rows: the inequality positions too (t_I -= L_IE z).
+// Barrier-synchronised on entry and on exit.
+QPC_FN void sp_pull(const QpSp &W, int p, double *t) { // t[p] -= sum over the fronts holding position p below their block
+  const int *pl = W.pl;
+  const int *pullptr = pl + pl[SP_O_PULLPTR], *pull = pl + pl[SP_O_PULL], *ft = pl + pl[SP_O_FRONT];
+  double v = t[p];
+  for (int k = pullptr[p]; k < pullptr[p + 1]; k++) {
+    const int *F = ft + pull[2 * k] * SP_FRONT_INTS;
+    const int base = F[0] + pull[2 * k + 1], r = F[1], w = F[2], c0 = F[3];
+    for (int c = 0; c < w; c++) v -= W.V[base + c * r] * (W.dinv[c0 + c] * t[c0 + c]);
+  }
+  t[p] = v;
+}
+QPC_FN void sp_forward(const QpSp &W, double *t, bool with_rows) {
+  const int *pl = W.pl;
+  const int *lv = pl + pl[SP_O_LEVEL], *ft = pl + pl[SP_O_FRONT];
+  for (int l = 0; l < W.nlevel; l++) {
+    QPC_SP_FOR_WAVE(f, lv[l], lv[l + 1]) {
+      const int *F = ft + f * SP_FRONT_INTS;
+      const int base = F[0], r = F[1], w = F[2], c0 = F[3];
+      QPC_SP_FOR_LANE(c, w) { sp_pull(W, c0 + c, t); }
+      QPC_SP_WSYNC
+      for (int j = 0; j + 1 < w; j++) {
+        const double zj = t[c0 + j] * W.dinv[c0 + j];
+        for (int c = j + 1 + QPC_SP_LANE; c < w; c += QPC_SP_NLANE) t[c0 + c] -= W.V[base + j * r + c] * zj;
+        QPC_SP_WSYNC
+      }
+    }
+    QPC_SP_SYNC
+  }
+  if (with_rows) {
+    QPC_SP_FOR(p, W.mi) { sp_pull(W, W.ne + p, t); }
+    QPC_SP_SYNC
+  }
+}
+// y_E <- L^-T D^-1 z_E - (the rows below)' y, y given on the inequality positions (and 0 at the right-hand-side position); z_E is read
+// from y's equality positions, the result replaces it.  Barrier-synchronised on entry and on exit.
+QPC_FN void sp_back(const QpSp &W, double *y) {
+  const int *pl = W.pl;
+  const int *lv = pl + pl[SP_O_LEVEL], *ft = pl + pl[SP_O_FRONT], *rows = pl + pl[SP_O_ROWS];
+  for (int l = W.nlevel - 1; l >= 0; l--) {
+    QPC_SP_FOR_WAVE(f, lv[l], lv[l + 1]) {
+      const int *F = ft + f * SP_FRONT_INTS;
+      const int base = F[0], r = F[1], w = F[2], c0 = F[3], *rw = rows + F[4];
+      QPC_SP_FOR_LANE(c, w) {
+        double s = y[c0 + c];
+        for (int i = w; i < r; i++) s -= W.V[base + c * r + i] * y[rw[i]];
+        y[c0 + c] = s;
+      }
+      QPC_SP_WSYNC
+      for (int j = w - 1; j >= 0; j--) {
+        const double yj = y[c0 + j] * W.dinv[c0 + j];
+        QPC_SP_WSYNC // (every lane has read y[c0 + j] before lane 0 replaces it)
+        QPC_SP_L0 { y[c0 + j] = yj; }
+        for (int c = QPC_SP_LANE; c < j; c += QPC_SP_NLANE) y[c0 + c] -= W.V[base + c * r + j] * yj;
+        QPC_SP_WSYNC
+      }
+    }
+    QPC_SP_SYNC
+  }
+}
+
+// ---- the working set's own factor, one wavefront.  LDL' of the leading k columns of a packed (k + 1) x (k + 1) triangle (the last
+//      row: a right-hand side riding along)
+QPC_FN void sp_ldl_wave(double *L, int K1, int k, const double *ref, double tau, double *dinv) {
+  for (int j = 0; j < k; j++) {
+    const int cj = sp_cs(j, K1) - j; // L[i][j] = L[cj + i]
+    const double d = L[cj + j], rf = ref[j];
+    const bool ok = d > tau * (rf > 1e-300 ? rf : 1e-300);
+    const double di = ok ? 1.0 / d : 0.0;
+    QPC_SP_L0 { dinv[j] = di; }
+    for (int i = j + 1 + QPC_SP_LANE; i < K1; i += QPC_SP_NLANE) {
+      const double lij = L[cj + i];
+      const int cend = i < k ? i : k - 1;
+      for (int c = j + 1; c <= cend; c++) L[sp_cs(c, K1) - c + i] -= lij * (L[cj + c] * di);
+    }
+    QPC_SP_WSYNC
+  }
+}
+QPC_FN void sp_ldl_forward_wave(const double *L, int K1, int k, const double *dinv, double *t) {
+  for (int j = 0; j + 1 < k; j++) {
+    const int cj = sp_cs(j, K1) - j;
+    const double zj = t[j] * dinv[j];
+    for (int i = j + 1 + QPC_SP_LANE; i < k; i += QPC_SP_NLANE) t[i] -= L[cj + i] * zj;
+    QPC_SP_WSYNC
+  }
+}
+// out <- L^-T D^-1 t (t is used up, out != t)
+QPC_FN void sp_ldl_back_wave(const double *L, int K1, int k, const double *dinv, double *t, double *out) {
+  for (int i = k - 1; i >= 0; i--) {
+    const double yi = t[i] * dinv[i];
+    QPC_SP_L0 { out[i] = yi; }
+    for (int j = QPC_SP_LANE; j < i; j += QPC_SP_NLANE) t[j] -= L[sp_cs(j, K1) - j + i] * yi;
+    QPC_SP_WSYNC
+  }
+}
+
+// Working set in W.wsf (by inequality position) -> idxW (ascending), factor of C_WW in W.LW; with_rhs: the right-hand side a0_W - b_W
+// rides along and yw <- the multipliers of the working rows.  Returns the number of working rows, or -1 beyond what LW holds.
+// One wavefront.
+QPC_FN int sp_w_factor(QpSp &W, double tau, bool with_rhs) {
+  const int mi = W.mi, kw = W.kw;
+  int k = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  for (int p0 = 0; p0 < mi; p0 += 64) {
+    const int p = p0 + (int)(threadIdx.x & 63);
+    const bool f = p < mi && W.wsf[p] != 0.0;
+    const unsigned long long mask = __ballot(f);
+    if (f) { const int r = k + __popcll(mask & ((1ull << (threadIdx.x & 63)) - 1ull)); if (r < kw) W.idxW[r] = p; }
+    k += __popcll(mask);
+  }
+#else
+  for (int p = 0; p < mi; p++) if (W.wsf[p] != 0.0) { if (k < kw) W.idxW[k] = p; k++; }
+#endif
+  if (k > kw) return -1;
+  QPC_SP_WSYNC
+  const int K1 = k + 1;
+  for (int b = 0; b < k; b++) {
+    const int pb = W.idxW[b], sb = sp_cs(b, K1);
+    QPC_SP_FOR_LANE(e, k - b) { W.LW[sb + e] = sp_C(W, W.idxW[b + e], pb); }
+  }
+  QPC_SP_FOR_LANE(a, k) {
+    const int pa = W.idxW[a];
+    W.tW[a] = W.gdiag[W.ne + pa];
+    W.LW[sp_sidx(k, a, K1)] = with_rhs ? W.a0[pa] - (W.wsf[pa] > 0.0 ? W.hi[pa] : W.lo[pa]) : 0.0;
+  }
+  QPC_SP_WSYNC
+  sp_ldl_wave(W.LW, K1, k, W.tW, tau, W.dinvW);
+  if (with_rhs) {
+    QPC_SP_FOR_LANE(a, k) { W.tW[a] = W.LW[sp_sidx(k, a, K1)]; }
+    QPC_SP_WSYNC
+    sp_ldl_back_wave(W.LW, K1, k, W.dinvW, W.tW, W.yw);
+  }
+  return k;
+}
+// EQP of the working set: multipliers of its rows -> yw, ax = A x for every inequality row.  One wavefront.
+QPC_FN int sp_solve_ws(QpSp &W, double tau) {
+  const int k = sp_w_factor(W, tau, true);
+  if (k < 0) return -1;
+  QPC_SP_FOR_LANE(p, W.mi) {
+    double t = W.a0[p];
+    for (int a = 0; a < k; a++) t -= sp_C(W, p, W.idxW[a]) * W.yw[a];
+    W.ax[p] = t;
+  }
+  QPC_SP_WSYNC
+  return k;
+}
+
+// ---- the working-set iterations (qpc_qp_wg.h: the same sweeps, the same Goldfarb-Idnani steps, the same ties), one wavefront.
+//      Leaves status / iters / nw / converged in W.sc.
+QPC_FN void sp_iterate(QpSp &W, const qpc_settings &st, double bscale) {
+  const double INF = 1e19;
+  const int mi = W.mi;
+  int status = QPC_STATUS_OPTIMAL, iters = 0;
+  const int max_it = st.max_active_set_iters > 0 ? st.max_active_set_iters : 200;
+  int nw = sp_solve_ws(W, st.eps_dual_reg);
+  if (nw < 0) { // (a warm start beyond what LW holds: start cold)
+    QPC_SP_FOR_LANE(p, mi) { W.wsf[p] = 0.0; }
+    QPC_SP_WSYNC
+    nw = sp_solve_ws(W, st.eps_dual_reg);
+  }
+  bool converged = false, fallback = false;
+  const int max_pdas = 4;
+  for (; iters < max_pdas && iters < max_it; iters++) {
+    double a_y = 1.0, a_x = 1.0;
+    QPC_SP_FOR_LANE(a, nw) { a_y = QPC_FABS(W.yw[a]) > a_y ? QPC_FABS(W.yw[a]) : a_y; }
+    QPC_SP_FOR_LANE(p, mi) { a_x = QPC_FABS(W.ax[p]) > a_x ? QPC_FABS(W.ax[p]) : a_x; W.tm[p] = 0.0; }
+    const double ysc = sp_wave_max(a_y), xsc = sp_wave_max(a_x);
+    const double toly = st.tol_bound * ysc, tolx = st.tol_bound * (xsc > bscale ? xsc : bscale);
+    bool ch = false;
+    QPC_SP_WSYNC
+    QPC_SP_FOR_LANE(a, nw) { // wrong-signed multipliers and dependent (dropped) rows leave
+      const int p = W.idxW[a];
+      const double w = W.wsf[p];
+      const double viol = w < 0.0 ? W.yw[a] : -W.yw[a];
+      if (viol > toly || W.dinvW[a] == 0.0) ch = true;
+      else W.tm[p] = w;
+    }
+    QPC_SP_WSYNC
+    QPC_SP_FOR_LANE(p, mi) {
+      if (W.wsf[p] == 0.0) {
+        const double lo = W.lo[p] > -INF ? W.lo[p] - W.ax[p] : -1.0, hi = W.hi[p] < INF ? W.ax[p] - W.hi[p] : -1.0;
+        if (lo > tolx && lo >= hi) { W.tm[p] = -1.0; ch = true; }
+        else if (hi > tolx) { W.tm[p] = 1.0; ch = true; }
+      }
+    }
+    if (!sp_wave_any(ch)) { converged = true; break; }
+    QPC_SP_WSYNC
+    QPC_SP_FOR_LANE(p, mi) { W.wsf[p] = W.tm[p]; }
+    QPC_SP_WSYNC
+    nw = sp_solve_ws(W, st.eps_dual_reg);
+    if (nw < 0) { fallback = true; break; }
+  }
+  // ---- Goldfarb-Idnani from what is left of the sweeps' last set once the rows with wrong-signed multipliers are gone
+  if (!converged && !fallback) {
+    for (int pass = 0; pass <= mi; pass++) {
+      double a_y = 1.0;
+      QPC_SP_FOR_LANE(a, nw) { a_y = QPC_FABS(W.yw[a]) > a_y ? QPC_FABS(W.yw[a]) : a_y; }
+      const double toly = st.tol_bound * sp_wave_max(a_y);
+      bool ch = false;
+      QPC_SP_FOR_LANE(a, nw) {
+        const int p = W.idxW[a];
+        const double viol = W.wsf[p] < 0.0 ? W.yw[a] : -W.yw[a];
+        if (viol > toly || W.dinvW[a] == 0.0) { W.tm[p] = 0.0; ch = true; } else W.tm[p] = W.wsf[p];
+      }
+      if (!sp_wave_any(ch)) break;
+      QPC_SP_WSYNC
+      QPC_SP_FOR_LANE(a, nw) { const int p = W.idxW[a]; W.wsf[p] = W.tm[p]; }
+      QPC_SP_WSYNC
+      nw = sp_solve_ws(W, st.eps_dual_reg);
+      if (nw < 0) { fallback = true; break; }
+    }
+    for (; !fallback && iters < max_it; iters++) {
+      double a_x = 1.0;
+      QPC_SP_FOR_LANE(p, mi) { a_x = QPC_FABS(W.ax[p]) > a_x ? QPC_FABS(W.ax[p]) : a_x; }
+      const double xsc = sp_wave_max(a_x);
+      const double tolx = st.tol_bound * (xsc > bscale ? xsc : bscale);
+      // the most violated row (ties: the first row; a row's lower bound before its upper one): candidates numbered 2 p + (upper ? 1 : 0)
+      double bv = 0.0;
+      int bi = -1;
+      QPC_SP_FOR_LANE(p, mi) {
+        if (W.wsf[p] != 0.0) continue;
+        const double lo = W.lo[p] > -INF ? W.lo[p] - W.ax[p] : -1.0, hi = W.hi[p] < INF ? W.ax[p] - W.hi[p] : -1.0;
+        if (lo > tolx && (bi < 0 || lo > bv)) { bv = lo; bi = 2 * p; }
+        if (hi > tolx && (bi < 0 || hi > bv)) { bv = hi; bi = 2 * p + 1; }
+      }
+      sp_wave_argmax(bv, bi);
+      const int bp = bi >> 1; // (-1 stays -1)
+      const double bsg = (bi & 1) ? 1.0 : -1.0;
+      const int pr = bp;
+      if (pr < 0) { converged = true; break; }
+      const double sg = bsg;
+      double viol = bv;
+      bool infeasible = false;
+      int k = nw; // LW is the factor of the current working set
+      for (int inner = 0; inner <= W.m; inner++) {
+        // r = (C_WW)^-1 C_Wp
+        QPC_SP_FOR_LANE(a, k) { W.tW[a] = sp_C(W, W.idxW[a], pr); }
+        QPC_SP_WSYNC
+        sp_ldl_forward_wave(W.LW, k + 1, k, W.dinvW, W.tW);
+        sp_ldl_back_wave(W.LW, k + 1, k, W.dinvW, W.tW, W.dW);
+        double dpart = 0.0;
+        QPC_SP_FOR_LANE(a, k) { dpart += sp_C(W, pr, W.idxW[a]) * W.dW[a]; }
+        // (the sum over the lanes in lane order: a fixed order)
+        double d = W.V[W.Cb + sp_cs(pr, W.M1)];
+#if defined(__HIP_DEVICE_COMPILE__)
+        for (int off = 32; off > 0; off >>= 1) dpart += __shfl_xor(dpart, off, 64);
+#endif
+        d -= dpart;
+        const bool dependent = !(d > 1e-11 * W.gdiag[W.ne + pr]);
+        double t1 = 1e300; // dual ratio test: y_W(t) = y_W - t sg r must keep the sign of every working inequality
+        int kd = -1;
+        QPC_SP_FOR_LANE(a, k) {
+          const double w = W.wsf[W.idxW[a]], sr = sg * W.dW[a];
+          if (W.dinvW[a] == 0.0) continue;
+          if ((w > 0.0 && sr > 1e-14) || (w < 0.0 && sr < -1e-14)) {
+            double t = W.yw[a] / sr;
+            t = t > 0.0 ? t : 0.0;
+            if (kd < 0 || t < t1) { t1 = t; kd = a; }
+          }
+        }
+        sp_wave_argmin(t1, kd);
+        if (kd < 0) t1 = 1e300;
+        int outcome; // 0: full step, p enters; 1: partial step, row kd left; 2: infeasible
+        if (dependent && kd < 0) outcome = 2;
+        else {
+          const double t2 = dependent ? 1e300 : viol / d;
+          if (t2 <= t1) outcome = 0;
+          else {
+            outcome = 1;
+            QPC_SP_WSYNC
+            // y_W -= t1 sg r, row kd leaves, the multipliers close up (through tW: free here)
+            QPC_SP_FOR_LANE(a, k) { const int src = a >= kd ? a + 1 : a; W.tW[a] = src < k ? W.yw[src] - t1 * sg * W.dW[src] : 0.0; }
+            QPC_SP_WSYNC
+            QPC_SP_FOR_LANE(a, k) { if (a + 1 < k) W.yw[a] = W.tW[a]; }
+            if (!dependent) viol -= t1 * d;
+            QPC_SP_L0 { W.wsf[W.idxW[kd]] = 0.0; }
+            QPC_SP_WSYNC
+          }
+        }
+        if (outcome == 2) { infeasible = true; break; }
+        if (outcome == 0) break;
+        k = sp_w_factor(W, st.eps_dual_reg, false); // a row left: the factor of what stays
+        if (k < 0) { fallback = true; break; }
+      }
+      if (fallback) break;
+      if (infeasible) { status = QPC_STATUS_INFEASIBLE; break; }
+      QPC_SP_L0 { W.wsf[pr] = sg; }
+      QPC_SP_WSYNC
+      nw = sp_solve_ws(W, st.eps_dual_reg);
+      if (nw < 0) { fallback = true; break; }
+    }
+  }
+  if (!converged && status == QPC_STATUS_OPTIMAL) status = QPC_STATUS_ITERATION_LIMIT;
+  QPC_SP_L0 {
+    W.sc[SPS_STATUS] = fallback ? (double)QPC_WG_FALLBACK : (double)status;
+    W.sc[SPS_ITERS] = (double)iters; W.sc[SPS_NW] = (double)nw; W.sc[SPS_CONV] = converged ? 1.0 : 0.0;
+  }
+}
+
+// ---- products with A, H, H^-1 (A's compressed columns / rows by position and the blocks' rows from the plan in LDS)
+QPC_FN double sp_col_dot(const QpSp &W, int c, const double *ypos) { // (A' y)_c, y by position
+  const int *cptr = W.pl + W.pl[SP_O_CPTR], *crow = W.pl + W.pl[SP_O_CROW];
+  double t = 0.0;
+  for (int o = cptr[c]; o < cptr[c + 1]; o++) t += W.sval[o] * ypos[crow[o]];
+  return t;
+}
+QPC_FN double sp_row_dot(const QpSp &W, int pos, const double *w) { // (A w) at a position
+  const int *rptr = W.pl + W.pl[SP_O_RPTR], *rcol = W.pl + W.pl[SP_O_RCOL], *ro = W.pl + W.pl[SP_O_RO];
+  double t = 0.0;
+  for (int k = rptr[pos]; k < rptr[pos + 1]; k++) t += W.sval[ro[k]] * w[rcol[k]];
+  return t;
+}
+QPC_FN double sp_h_dot(const QpSp &W, const double *hvals, int i, const double *v) { // (row i of the block matrix) . v
+  const int *hptr = W.pl + W.pl[SP_O_HPTR], *hcol = W.pl + W.pl[SP_O_HCOL], *hidx = W.pl + W.pl[SP_O_HIDX];
+  double t = 0.0;
+  for (int k = hptr[i]; k < hptr[i + 1]; k++) t += hvals[hidx[k]] * v[hcol[k]];
+  return t;
+}
+
+// copies the LDS part of the plan (once per workgroup)
+QPC_FN void qp_sp_load_plan(const int *plan_g, int *plan_lds) {
+  const int nint = plan_g[SP_LDS_INTS];
+  QPC_SP_FOR(i, nint) { plan_lds[i] = plan_g[i]; }
+  QPC_SP_SYNC
+}
+
+// One QP.  plan_lds: the plan's LDS part (qp_sp_load_plan), lds: what follows it, lds_cap doubles.  Returns the status, or
+// QPC_WG_FALLBACK (the set of equality rows is not the plan's; a working set beyond what LDS holds).
+QPC_FN int qp_solve_sp(const int *plan_g, const int *plan_lds, const double *Pv, const double *q, const double *Av, const double *l,
+                       const double *u, const qpc_settings &st, double *lds, int lds_cap, const double *y0, double *x, double *y,
+                       int32_t *iters_out, unsigned long long *stamps) {
+  const double INF = 1e19;
+  const int *pl = plan_lds;
+  QpSp W;
+  W.pl = pl; W.plg = plan_g;
+  const int n = pl[SP_N], m = pl[SP_M], ne = pl[SP_NE], mi = pl[SP_MI], nnzA = pl[SP_NNZA], nhv = pl[SP_NHV], nval = pl[SP_NVAL];
+  W.n = n; W.m = m; W.ne = ne; W.mi = mi; W.N1 = m + 1; W.M1 = mi + 1; W.Cb = pl[SP_CB]; W.nfront = pl[SP_NFRONT]; W.nlevel = pl[SP_NLEVEL];
+  W.Pv = Pv; W.q = q; W.Av = Av; W.l = l; W.u = u; W.y0 = y0; W.stamps = stamps;
+  QPC_SP_STAMP(W, 0);
+  double *p = lds;
+  W.sc = p; p += 16; W.red = p; p += 8;
+  W.V = p; p += nval;
+  W.dinv = p; p += ne; W.gdiag = p; p += m + 1; W.t = p; p += m + 1; W.yp = p; p += m + 1;
+  W.hv = p; p += nhv; W.hm = p; p += nhv;
+  W.xu = p; p += n; W.x = p; p += n; W.r1 = p; p += n; W.tn = p; p += n;
+  W.lo = p; p += mi; W.hi = p; p += mi; W.wsf = p; p += mi; W.tm = p; p += mi; W.ax = p; p += mi; W.a0 = p; p += mi;
+  W.sval = p; p += nnzA;
+  // the working set's factor takes what is left (at most the inequality rows)
+  int kw = mi;
+  while (kw > 0 && (int)(p - lds) + 4 * (kw + 1) + (kw + 2) / 2 + (kw + 1) * (kw + 2) / 2 > lds_cap) kw--;
+  if ((int)(p - lds) + 4 * (kw + 1) + (kw + 2) / 2 + (kw + 1) * (kw + 2) / 2 > lds_cap) return QPC_WG_FALLBACK;
+  W.kw = kw;
+  W.yw = p; p += kw + 1; W.dinvW = p; p += kw + 1; W.dW = p; p += kw + 1; W.tW = p; p += kw + 1;
+  W.idxW = (int *)p; p += (kw + 2) / 2;
+  W.LW = p; p += (kw + 1) * (kw + 2) / 2;
+  const int *perm = pl + pl[SP_O_PERM], *ipos = pl + pl[SP_O_IPOS];
+  // ---- the values; the rows' kinds against the plan's; scales
+  QPC_SP_T0 { for (int i = 0; i < SPS_COUNT; i++) W.sc[i] = 0.0; }
+  {
+    const int *cperm = plan_g + pl[SP_O_CPERM];
+    QPC_SP_FOR(o, nnzA) { W.sval[o] = Av[cperm[o]]; }
+  }
+  {
+    const int *hptr = pl + pl[SP_O_HPTR], *hidx = pl + pl[SP_O_HIDX], *pidx = pl + pl[SP_O_PIDX];
+    QPC_SP_FOR(i, n) {
+      for (int k = hptr[i]; k < hptr[i + 1]; k++) W.hm[hidx[k]] = pidx[k] >= 0 ? Pv[pidx[k]] : 0.0;
+    }
+  }
+  double a_b = 1.0;
+  bool mismatch = false;
+  QPC_SP_FOR(i, m) {
+    const double li = l[i], ui = u[i];
+    const bool lo = li > -INF, hi = ui < INF;
+    const bool eq = lo && hi && ui - li <= 1e-12 * (1.0 + QPC_FABS(li));
+    if (eq != (ipos[i] < ne)) mismatch = true;
+    if (lo) a_b = QPC_FABS(li) > a_b ? QPC_FABS(li) : a_b;
+    if (hi) a_b = QPC_FABS(ui) > a_b ? QPC_FABS(ui) : a_b;
+    const int pos = ipos[i];
+    if (pos >= ne) { W.lo[pos - ne] = li; W.hi[pos - ne] = ui; }
+  }
+  QPC_SP_SYNC
+  double a_h = 0.0;
+  {
+    const int *hptr = pl + pl[SP_O_HPTR], *hcol = pl + pl[SP_O_HCOL], *hidx = pl + pl[SP_O_HIDX];
+    QPC_SP_FOR(i, n) {
+      for (int k = hptr[i]; k < hptr[i + 1]; k++) if (hcol[k] == i) { const double a = QPC_FABS(W.hm[hidx[k]]); a_h = a > a_h ? a : a_h; }
+    }
+  }
+  const double bscale = sp_reduce_max(a_b, W.red), hmax = sp_reduce_max(a_h, W.red);
+  if (sp_reduce_max(mismatch ? 1.0 : 0.0, W.red) != 0.0) return QPC_WG_FALLBACK;
+  const double eps = st.eps_primal_reg * (hmax > 0.0 ? hmax : 1.0);
+  // ---- H^-1, block by block: a single variable by a division, a block by Gauss-Jordan sweeps of one wavefront (lane = entry)
+  {
+    const int nblk = pl[SP_NBLK];
+    const int *bptr = pl + pl[SP_O_BPTR], *bbase = pl + pl[SP_O_BBASE];
+    QPC_SP_FOR(b, nblk) { if (bptr[b + 1] - bptr[b] == 1) W.hv[bbase[b]] = 1.0 / (W.hm[bbase[b]] + eps); }
+    QPC_SP_FOR_WAVE(b, 0, nblk) {
+      const int bs = bptr[b + 1] - bptr[b], hb = bbase[b];
+      if (bs == 1) continue;
+      QPC_SP_FOR_LANE(e, bs * bs) { W.hv[hb + e] = W.hm[hb + e] + ((e / bs == e % bs) ? eps : 0.0); }
+      QPC_SP_WSYNC
+      for (int k = 0; k < bs; k++) {
+        const double pv = 1.0 / W.hv[hb + k * bs + k];
+        double nv[1 + (QPC_SP_MAXBLK * QPC_SP_MAXBLK - 1) / QPC_SP_NLANE];
+        int cnt = 0;
+        for (int e = QPC_SP_LANE; e < bs * bs; e += QPC_SP_NLANE) {
+          const int i = e / bs, j = e % bs;
+          const double aik = W.hv[hb + i * bs + k], akj = W.hv[hb + k * bs + j], aij = W.hv[hb + e];
+          nv[cnt++] = (i == k && j == k) ? pv : (i == k ? akj * pv : (j == k ? -aik * pv : aij - aik * akj * pv));
+        }
+        QPC_SP_WSYNC
+        cnt = 0;
+        for (int e = QPC_SP_LANE; e < bs * bs; e += QPC_SP_NLANE) W.hv[hb + e] = nv[cnt++];
+        QPC_SP_WSYNC
+      }
+    }
+  }
+  QPC_SP_FOR(e, nval) { W.V[e] = 0.0; }
+  QPC_SP_SYNC
+  QPC_SP_FOR(i, n) { W.tn[i] = -q[i]; }
+  QPC_SP_SYNC
+  QPC_SP_FOR(i, n) { W.xu[i] = sp_h_dot(W, W.hv, i, W.tn); }
+  QPC_SP_STAMP(W, 1);
+  // ---- S = [G ; rhs'] into the store: a thread per structural entry of G, its products in the order the host laid down
+  {
+    const int npair = pl[SP_NPAIR];
+    const int *pair = plan_g + pl[SP_O_PAIR], *term = plan_g + pl[SP_O_TERM];
+    QPC_SP_FOR(pi, npair) {
+      const int t0 = pi > 0 ? pair[2 * pi - 1] : 0, t1 = pair[2 * pi + 1];
+      double acc = 0.0;
+      for (int t = t0; t < t1; t++) acc += W.sval[term[3 * t]] * W.sval[term[3 * t + 1]] * W.hv[term[3 * t + 2]];
+      W.V[pair[2 * pi]] = acc;
+    }
+  }
+  QPC_SP_SYNC // (xu complete)
+  {
+    const int *rtaddr = plan_g + pl[SP_O_RTADDR];
+    QPC_SP_FOR(pos, m) { W.V[rtaddr[pos]] = sp_row_dot(W, pos, W.xu) - (pos < ne ? l[perm[pos]] : 0.0); }
+  }
+  QPC_SP_SYNC
+  {
+    const int *colfront = pl + pl[SP_O_COLFRONT], *ft = pl + pl[SP_O_FRONT];
+    QPC_SP_FOR(pos, m) {
+      if (pos < ne) { const int *F = ft + colfront[pos] * SP_FRONT_INTS; const int lc = pos - F[3]; W.gdiag[pos] = W.V[F[0] + lc * F[1] + lc]; }
+      else W.gdiag[pos] = W.V[W.Cb + sp_cs(pos - ne, W.M1)];
+    }
+  }
+  QPC_SP_SYNC
+  QPC_SP_STAMP(W, 2);
+  // ---- the elimination, level by level
+  {
+    const int *lv = pl + pl[SP_O_LEVEL], *ft = pl + pl[SP_O_FRONT];
+    for (int lev = 0; lev < W.nlevel; lev++) {
+      QPC_SP_FOR_WAVE(f, lv[lev], lv[lev + 1]) {
+        const int *F = ft + f * SP_FRONT_INTS;
+        sp_front_factor(W.V, F[0], F[1], F[2], W.gdiag + F[3], st.eps_dual_reg, W.dinv + F[3]);
+      }
+      QPC_SP_SYNC
+      sp_update_jobs(W, lev);
+      QPC_SP_SYNC
+    }
+  }
+  QPC_SP_STAMP(W, 3);
+  QPC_SP_FOR(p2, mi) {
+    W.a0[p2] = W.V[W.Cb + sp_sidx(mi, p2, W.M1)];
+    double w = 0.0;
+    if (y0) { // warm start: the rows an earlier solution held at a bound
+      const double yv = y0[perm[ne + p2]];
+      w = (yv > 0.0 && W.hi[p2] < INF) ? 1.0 : ((yv < 0.0 && W.lo[p2] > -INF) ? -1.0 : 0.0);
+    }
+    W.wsf[p2] = w;
+  }
+  QPC_SP_SYNC
+  // ---- the working-set iterations: one wavefront's work
+  if (QPC_SP_WAVE == 0) sp_iterate(W, st, bscale);
+  QPC_SP_SYNC
+  int status = (int)W.sc[SPS_STATUS];
+  const int iters = (int)W.sc[SPS_ITERS], nw = (int)W.sc[SPS_NW];
+  if (status == QPC_WG_FALLBACK) return QPC_WG_FALLBACK;
+  QPC_SP_STAMP(W, 4);
+  // ---- the multipliers by position: the working rows', then the equality rows' -- L11' yE = D^-1 (zE - (rows of W)' yW)
+  double *yp = W.yp;
+  {
+    const int *colfront = pl + pl[SP_O_COLFRONT], *ft = pl + pl[SP_O_FRONT];
+    QPC_SP_FOR(b, m + 1) {
+      double v = 0.0;
+      if (b < ne) { const int *F = ft + colfront[b] * SP_FRONT_INTS; v = W.V[F[0] + (b - F[3]) * F[1] + F[1] - 1]; } // the right-hand-side row: zE (unscaled)
+      yp[b] = v;
+    }
+  }
+  QPC_SP_SYNC
+  QPC_SP_FOR(a, nw) { yp[ne + W.idxW[a]] = W.yw[a]; }
+  QPC_SP_SYNC
+  sp_back(W, yp);
+  QPC_SP_STAMP(W, 5);
+  // ---- x = xu - H^-1 A' y, then iterative refinement on the true KKT residuals of the final working set
+  QPC_SP_FOR(i, n) { W.tn[i] = sp_col_dot(W, i, yp); }
+  QPC_SP_SYNC
+  QPC_SP_FOR(i, n) { W.x[i] = W.xu[i] - sp_h_dot(W, W.hv, i, W.tn); }
+  QPC_SP_SYNC
+  double rp = 0.0, rs = 0.0;
+  for (int sweep = 0; sweep <= st.max_refine_iters; sweep++) {
+    double a_rs = 0.0, a_rp = 0.0, a_ss = 1.0, a_ps = 1.0;
+    QPC_SP_FOR(i, n) { // r1 = -(q + P x + A' y)
+      const double aty = sp_col_dot(W, i, yp), qi = q[i];
+      const double t = qi + sp_h_dot(W, W.hm, i, W.x) + aty;
+      W.r1[i] = -t;
+      a_rs = (QPC_FABS(t) > a_rs || !(t == t)) ? QPC_FABS(t) : a_rs;
+      a_ss = QPC_FABS(qi) > a_ss ? QPC_FABS(qi) : a_ss;
+      a_ss = QPC_FABS(aty) > a_ss ? QPC_FABS(aty) : a_ss;
+    }
+    QPC_SP_FOR(b, m + 1) { // r2 = b_W - A_W x, by position (the rows outside the working set: 0)
+      const int p2 = b - ne;
+      double t = 0.0;
+      if (b < m && (b < ne || W.wsf[p2] != 0.0)) {
+        const double bw = b < ne ? l[perm[b]] : (W.wsf[p2] > 0.0 ? W.hi[p2] : W.lo[p2]);
+        t = bw - sp_row_dot(W, b, W.x);
+        a_rp = (QPC_FABS(t) > a_rp || !(t == t)) ? QPC_FABS(t) : a_rp;
+        a_ps = QPC_FABS(bw) > a_ps ? QPC_FABS(bw) : a_ps;
+      }
+      W.t[b] = t;
+    }
+    QPC_SP_SYNC
+    rs = sp_reduce_max(a_rs, W.red);
+    rp = sp_reduce_max(a_rp, W.red);
+    if (sweep == st.max_refine_iters) break;
+    if (sweep > 0) {
+      const double ss = sp_reduce_max(a_ss, W.red), ps = sp_reduce_max(a_ps, W.red);
+      if (rs <= 1e-12 * ss && rp <= 1e-12 * ps) break;
+    }
+    // dy = K^-1 (A_W H^-1 r1 - r2) ; dx = H^-1 (r1 - A_W' dy)
+    QPC_SP_FOR(i, n) { W.xu[i] = sp_h_dot(W, W.hv, i, W.r1); } // xu is free from here on: H^-1 r1
+    QPC_SP_SYNC
+    QPC_SP_FOR(b, m) {
+      const int p2 = b - ne;
+      if (b < ne || W.wsf[p2] != 0.0) W.t[b] = sp_row_dot(W, b, W.xu) - W.t[b];
+    }
+    QPC_SP_SYNC
+    // K on (E, W): forward through the fronts (the working rows pulled along), the working set's factor, back through the fronts
+    sp_forward(W, W.t, true);
+    if (QPC_SP_WAVE == 0) {
+      QPC_SP_FOR_LANE(a, nw) { W.tW[a] = W.t[ne + W.idxW[a]]; }
+      QPC_SP_WSYNC
+      sp_ldl_forward_wave(W.LW, nw + 1, nw, W.dinvW, W.tW);
+      sp_ldl_back_wave(W.LW, nw + 1, nw, W.dinvW, W.tW, W.dW);
+    }
+    QPC_SP_SYNC
+    QPC_SP_FOR(b, mi + 1) { W.t[ne + b] = 0.0; }
+    QPC_SP_SYNC
+    QPC_SP_FOR(a, nw) { W.t[ne + W.idxW[a]] = W.dW[a]; }
+    QPC_SP_SYNC
+    sp_back(W, W.t); // W.t: dy by position
+    double a_big = 0.0, a_dbig = 0.0;
+    QPC_SP_FOR(i, n) { W.tn[i] = W.r1[i] - sp_col_dot(W, i, W.t); }
+    QPC_SP_SYNC
+    QPC_SP_FOR(i, n) {
+      const double dx = sp_h_dot(W, W.hv, i, W.tn);
+      const double xi = W.x[i] + dx;
+      W.x[i] = xi;
+      a_big = QPC_FABS(xi) > a_big ? QPC_FABS(xi) : a_big;
+      a_dbig = QPC_FABS(dx) > a_dbig ? QPC_FABS(dx) : a_dbig;
+    }
+    QPC_SP_FOR(b, m) { yp[b] += W.t[b]; }
+    QPC_SP_SYNC
+    const double big = sp_reduce_max(a_big, W.red), dbig = sp_reduce_max(a_dbig, W.red);
+    if (sweep > 0 && !(dbig > 1e-12 * (1.0 + big))) break;
+  }
+  QPC_SP_STAMP(W, 6);
+  double a_ysc = 1.0, a_qsc = 1.0;
+  QPC_SP_FOR(b, m) { a_ysc = QPC_FABS(yp[b]) > a_ysc ? QPC_FABS(yp[b]) : a_ysc; }
+  QPC_SP_FOR(i, n) { a_qsc = QPC_FABS(q[i]) > a_qsc ? QPC_FABS(q[i]) : a_qsc; }
+  const double ysc = sp_reduce_max(a_ysc, W.red), qsc = sp_reduce_max(a_qsc, W.red);
+  if (status == QPC_STATUS_OPTIMAL) {
+    if (!(rp == rp) || !(rs == rs)) status = QPC_STATUS_NUMERICAL_ERROR;
+    else if (rp > 1e-7 * bscale) status = QPC_STATUS_INFEASIBLE;
+    else if (rs > 1e-7 * (ysc > qsc ? ysc : qsc)) status = QPC_STATUS_ALMOST_OPTIMAL;
+  }
+  QPC_SP_FOR(i, n) { x[i] = W.x[i]; }
+  QPC_SP_FOR(b, m) { y[perm[b]] = yp[b]; }
+  QPC_SP_T0 { if (iters_out) iters_out[0] = iters; }
+  QPC_SP_SYNC // (the next QP of this workgroup reuses LDS)
+  QPC_SP_STAMP(W, 7);
+  return status;
+}
+
+} // namespace qpc

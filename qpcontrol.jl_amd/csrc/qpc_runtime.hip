@@ -31,113 +31,7 @@
 #include "qpc_tick.h"
 #include "qpc_sim.h"
 #include "qpc_qp_dense.h"
-#include "qpc_qp_wg.h"
-#include "qpc_qp_prep.h"
 #include "qpc_l1_dense.h"
-
-// L0, first pass: one WORKGROUP per dense QP, working matrices in LDS (qpc_qp_wg.h): the problems Parametron builds for this
-// controller (diagonal P, sparse A).  status[b] = QPC_WG_FALLBACK marks a QP it leaves to the one-lane kernel below.
-extern "C" __global__ void __launch_bounds__(QPC_WG_THREADS)
-qpc_qp_wg_kernel(int n, int m, long long B, const double *P, const double *q, const double *A, const double *l,
-                 const double *u, qpc_settings st, double *ws, long long ws_stride, double *x, double *y,
-                 int32_t *status, int32_t *iters, unsigned long long *ticket) {
-  extern __shared__ __attribute__((aligned(16))) double qpc_wg_lds[];
-  // QPs are handed out by a counter (zeroed by the host before the launch), not by block index: workgroups go to the eight XCDs
-  // round-robin, so any cost pattern with a period of 8 in the batch (measured: the eight committed problems, cycled) would put all
-  // the expensive QPs on ONE XCD -- a mixed batch of 2 048 took as long as 2 048 copies of its slowest member
-  while (true) {
-    if (threadIdx.x == 0) ((unsigned long long *)qpc_wg_lds)[15] = atomicAdd(ticket, 1ull);
-    __syncthreads();
-    const long long b = (long long)((unsigned long long *)qpc_wg_lds)[15];
-    if (b >= B) break;
-    const int s = qpc::qp_solve_wg(n, m, P + b * n * n, q + b * n, A + b * m * n, l + b * m, u + b * m, st,
-                                   ws + b * ws_stride, qpc_wg_lds, QPC_WG_LDS_DOUBLES, x + b * n, y + b * m,
-                                   iters ? iters + b : nullptr);
-    if (threadIdx.x == 0) status[b] = s;
-    __syncthreads();
-#ifdef QPC_WG_PROF // phase stamps of the first QP (100 MHz ticks -> us): set-up, S build, elimination, sweeps, Goldfarb-Idnani, yE, refinement
-    if (threadIdx.x == 0 && b == 0) {
-      const unsigned long long *t = (const unsigned long long *)(ws + qpc::qp_dense_workspace_doubles(n, m) - 16);
-      printf("wg_prof status %d us:", s);
-      for (int k = 1; k <= 8; k++) printf(" %.1f", (double)(t[k] - t[k - 1]) * 0.01);
-      printf(" total %.1f\n", (double)(t[8] - t[0]) * 0.01);
-    }
-#endif
-  }
-}
-
-// L0 for a prepared problem (qpc_qp_setup): the pattern's tables instead of dense matrices; y0: warm-start multipliers or nullptr
-extern "C" __global__ void __launch_bounds__(QPC_WG_THREADS)
-qpc_qp_wg_prep_kernel(qpc::QpPrepView V, long long B, long long nnzP, const double *Pv, const double *q, const double *Av,
-                      const double *l, const double *u, qpc_settings st, double *ws, long long ws_stride, const double *y0,
-                      double *x, double *y, int32_t *status, int32_t *iters, unsigned long long *ticket, double *ykeep) {
-  extern __shared__ __attribute__((aligned(16))) double qpc_wg_lds[];
-  while (true) { // (tickets: see qpc_qp_wg_kernel)
-    if (threadIdx.x == 0) ((unsigned long long *)qpc_wg_lds)[15] = atomicAdd(ticket, 1ull);
-    __syncthreads();
-    const long long b = (long long)((unsigned long long *)qpc_wg_lds)[15];
-    if (b >= B) {
-      // a launch draws exactly B + gridDim.x tickets (every workgroup one past the end): whoever draws the last of them re-arms the
-      // counter, so that the host neither clears it before a launch nor keeps track of it (the tick's scheme)
-      if (threadIdx.x == 0 && b == B + (long long)gridDim.x - 1) atomicExch(ticket, 0ull);
-      break;
-    }
-#ifdef QPC_WG_PROF
-    const long long c0__ = clock64(), w0__ = wall_clock64();
-#endif
-    const int s = qpc::qp_solve_wg_prep(V, Pv + b * nnzP, q + b * V.n, Av + b * V.nnzA, l + b * V.m, u + b * V.m, st,
-                                        ws + b * ws_stride, qpc_wg_lds, QPC_WG_LDS_DOUBLES, y0 ? y0 + b * V.m : nullptr,
-                                        x + b * V.n, y + b * V.m, iters ? iters + b : nullptr);
-    if (threadIdx.x == 0) status[b] = s;
-    __syncthreads();
-    // the multipliers stay on the device for the next call's warm start (this QP's own slot: read at its start, written at its end)
-    if (ykeep && s != QPC_WG_FALLBACK) for (int i = threadIdx.x; i < V.m; i += blockDim.x) ykeep[b * V.m + i] = y[b * V.m + i];
-#ifdef QPC_WG_PROF
-    if (threadIdx.x == 0 && b == 0) {
-      const unsigned long long *t = (const unsigned long long *)(ws + qpc::qp_dense_workspace_doubles(V.n, V.m) - 16);
-      printf("wg_prep_prof (shader clock %.0f MHz) status %d us:", (double)(clock64() - c0__) / ((double)(wall_clock64() - w0__) * 0.01), s);
-      for (int k = 1; k <= 8; k++) printf(" %.1f", (double)(t[k] - t[k - 1]) * 0.01);
-      printf(" total %.1f\n", (double)(t[8] - t[0]) * 0.01);
-      if (blockIdx.x == 0) {
-        printf("  elimination: big matrix panel+rows %.1f (cumulative incl. trailing %.1f) us; small triangles %.1f / %.1f us\n", (double)qpc::qpc_wg_acc[0] * 0.01,
-               (double)qpc::qpc_wg_acc[1] * 0.01, (double)qpc::qpc_wg_acc[2] * 0.01, (double)qpc::qpc_wg_acc[3] * 0.01);
-        printf("  wave 0 inside its tile loops %.1f us\n", (double)qpc::qpc_wg_acc[4] * 0.01);
-        for (int k = 0; k < 8; k++) qpc::qpc_wg_acc[k] = 0;
-      }
-    }
-#endif
-  }
-}
-// the dense matrices of the prepared problem's QPs (for the dense path: a P with off-diagonal entries, or a QP the workgroup left)
-extern "C" __global__ void qpc_qp_densify_kernel(int n, int m, long long B, long long nnzP, const int *Prow, const int *Pcol,
-                                                 const double *Pv, long long nnzA, const int *Arow, const int *Acol,
-                                                 const double *Av, double *P, double *A) {
-  const long long per = nnzP + nnzA, tot = per * B;
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (long long)gridDim.x * blockDim.x) {
-    const long long b = e / per, k = e % per;
-    if (k < nnzP) {
-      const double v = Pv[b * nnzP + k];
-      P[b * n * n + (long long)Prow[k] * n + Pcol[k]] = v;
-      P[b * n * n + (long long)Pcol[k] * n + Prow[k]] = v;
-    } else {
-      const long long ka = k - nnzP;
-      A[b * m * n + (long long)Arow[ka] * n + Acol[ka]] = Av[b * nnzA + ka];
-    }
-  }
-}
-
-// L0: one lane per dense QP (the general method: any P, the Goldfarb-Idnani phase; see qpc_qp_dense.h).  only_fallback: just the
-// QPs the workgroup kernel left (status QPC_WG_FALLBACK)
-extern "C" __global__ void __launch_bounds__(64)
-qpc_qp_dense_kernel(int n, int m, long long B, const double *P, const double *q, const double *A, const double *l,
-                    const double *u, qpc_settings st, double *ws, long long ws_stride, double *x, double *y,
-                    int32_t *status, int32_t *iters, int only_fallback) {
-  const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  if (only_fallback && status[b] != QPC_WG_FALLBACK) return;
-  qpc::qp_solve_dense(n, m, P + b * n * n, q + b * n, A + b * m * n, l + b * m, u + b * m, st, ws + b * ws_stride,
-                      x + b * n, y + b * m, status + b, iters ? iters + b : nullptr);
-}
 
 // L1: one lane per QP, dense assembly from host-evaluated blocks + the L0 solver (qpc_l1_dense.h)
 struct QpcL1Args {
@@ -150,6 +44,7 @@ struct QpcL1Args {
   long long ws_stride;
   int nv, nd, nc, ntw, nsurf;
 };
+
 extern "C" __global__ void __launch_bounds__(64) qpc_l1_kernel(const QpcL1Args a, qpc_settings st) {
   const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= a.B) return;
@@ -1103,378 +998,6 @@ int32_t qpc_assemble_solve_batch(qpc_controller *c, int64_t B, const double *tas
     if (iters) chk(hipMemcpyAsync(iters, a.iters, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, st), "copy iters");
   }
   chk(hipStreamSynchronize(st), "qpc_l1_kernel"); // also on error: `it` / `dt` must outlive the async table copies
-  return rc;
-}
-
-// the workgroup kernels of L0 ask for the whole LDS of a CU: the limit is a per-device function attribute, set once per device
-static int qpc_wg_lds_attr(const void *kernel, int device_id, int lds_bytes) {
-  static std::mutex mu;
-  static std::map<std::pair<const void *, int>, hipError_t> done;
-  std::lock_guard<std::mutex> lk(mu);
-  auto key = std::make_pair(kernel, device_id);
-  auto it = done.find(key);
-  if (it == done.end()) it = done.emplace(key, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)).first;
-  if (it->second != hipSuccess) return hip_fail(it->second, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-  return QPC_OK;
-}
-
-// ---- L0: raw dense QPs.  Workspace per QP in HBM (qpc_qp_dense.h).
-uint64_t qpc_qp_workspace_bytes(int32_t n, int32_t m, int64_t B) {
-  if (n <= 0 || m < 0 || B < 0) return 0;
-  return (uint64_t)qpc::qp_dense_workspace_doubles(n, m) * (uint64_t)B * sizeof(double);
-}
-
-int32_t qpc_qp_solve_batch_device(int32_t n, int32_t m, int64_t B, const double *P, const double *q, const double *A,
-                                  const double *l, const double *u, const qpc_settings *settings, int32_t device_id,
-                                  double *x, double *y, int32_t *status, int32_t *iters, void *workspace,
-                                  uint64_t workspace_bytes, void *hip_stream) {
-  if (n <= 0 || m < 0 || B < 0 || !P || !q || (m && (!A || !l || !u)) || !x || (m && !y) || !status || !workspace) {
-    qpc_set_error("qpc_qp_solve_batch_device: bad arguments"); return QPC_ERR_INVALID_ARGUMENT;
-  }
-  if (workspace_bytes < qpc_qp_workspace_bytes(n, m, B)) { qpc_set_error("qpc_qp_solve_batch_device: workspace smaller than qpc_qp_workspace_bytes(n, m, B)"); return QPC_ERR_INVALID_ARGUMENT; }
-  if (B == 0) return QPC_OK;
-  HIP_TRY(hipSetDevice(device_id));
-  qpc_settings st;
-  if (settings) st = *settings; else qpc_default_settings(&st);
-  // first the workgroup kernel (LDS-resident working set: the structured problems of this controller), then the one-lane kernel on
-  // whatever it left; QPC_L0_ONE_LANE=1 (experiments build) keeps the old single pass
-  int wg = m > 0 && n <= QPC_WG_DIM && m <= QPC_WG_DIM;
-  if (const char *e = QPC_EXP_ENV("QPC_L0_ONE_LANE")) if (e[0] == '1') wg = 0;
-  if (wg) {
-    const int lds_bytes = qpc::qp_wg_lds_doubles(n, m) * (int)sizeof(double);
-    if (int arc = qpc_wg_lds_attr((const void *)qpc_qp_wg_kernel, device_id, lds_bytes)) return arc;
-    static std::mutex cu_mu;
-    static std::map<int, int> cu_of; // (hipGetDeviceProperties costs tens of microseconds: once per device)
-    int n_cu = 0;
-    {
-      std::lock_guard<std::mutex> lk(cu_mu);
-      auto it = cu_of.find(device_id);
-      if (it == cu_of.end()) {
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, device_id));
-        it = cu_of.emplace(device_id, prop.multiProcessorCount).first;
-      }
-      n_cu = it->second;
-    }
-    const long long grid = B < (long long)n_cu * 4 ? B : (long long)n_cu * 4;
-    // the ticket counter: the last of the spare doubles at the end of the workspace
-    unsigned long long *ticket = (unsigned long long *)((double *)workspace + (long long)qpc::qp_dense_workspace_doubles(n, m) * B - 1);
-    HIP_TRY(hipMemsetAsync(ticket, 0, sizeof(unsigned long long), (hipStream_t)hip_stream));
-    hipLaunchKernelGGL(qpc_qp_wg_kernel, dim3((unsigned)grid), dim3(QPC_WG_THREADS), (size_t)lds_bytes, (hipStream_t)hip_stream, (int)n, (int)m,
-                       (long long)B, P, q, A, l, u, st, (double *)workspace, (long long)qpc::qp_dense_workspace_doubles(n, m), x, y,
-                       status, iters, ticket);
-    HIP_TRY(hipGetLastError());
-  }
-  hipLaunchKernelGGL(qpc_qp_dense_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, (hipStream_t)hip_stream, (int)n, (int)m,
-                     (long long)B, P, q, A, l, u, st, (double *)workspace, (long long)qpc::qp_dense_workspace_doubles(n, m), x, y,
-                     status, iters, wg);
-  HIP_TRY(hipGetLastError());
-  return QPC_OK;
-}
-
-// persistent device slab + stream of the host-pointer L0 entry, one per device of the process
-struct QpcL0Cache { char *buf = nullptr; size_t bytes = 0; hipStream_t stream = nullptr; char *h_stage = nullptr; };
-static std::mutex g_l0_mu;
-static std::map<int, QpcL0Cache> g_l0;
-
-int32_t qpc_qp_solve_batch(int32_t n, int32_t m, int64_t B, const double *P, const double *q, const double *A,
-                           const double *l, const double *u, const qpc_settings *settings, int32_t device_id,
-                           double *x, double *y, int32_t *status, int32_t *iters) {
-  if (n <= 0 || m < 0 || B < 0 || !P || !q || (m && (!A || !l || !u)) || !x || (m && !y) || !status) {
-    qpc_set_error("qpc_qp_solve_batch: bad arguments"); return QPC_ERR_INVALID_ARGUMENT;
-  }
-  if (B == 0) return QPC_OK;
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
-    (void)hipGetLastError();
-    qpc_set_error("qpc_qp_solve_batch: no HIP device available (this library has no CPU fallback)");
-    return QPC_ERR_NO_DEVICE;
-  }
-  if (device_id < 0 || device_id >= ndev) { qpc_set_error("qpc_qp_solve_batch: device_id out of range"); return QPC_ERR_NO_DEVICE; }
-  HIP_TRY(hipSetDevice(device_id));
-  std::lock_guard<std::mutex> lk(g_l0_mu); // one L0 call per process at a time (plumbing path)
-  QpcL0Cache &C = g_l0[device_id];
-  if (!C.stream) HIP_TRY(hipStreamCreateWithFlags(&C.stream, hipStreamNonBlocking));
-  const size_t nP = (size_t)B * n * n, nq = (size_t)B * n, nA = (size_t)B * m * n, nm = (size_t)B * m;
-  const size_t wsb = (size_t)qpc_qp_workspace_bytes(n, m, B);
-  const size_t total = pad64(nP * 8) + 2 * pad64(nq * 8) + pad64(nA * 8) + 3 * pad64(nm * 8) + pad64(wsb) + 2 * pad64((size_t)B * sizeof(int32_t));
-  if (total > C.bytes) {
-    if (C.buf) (void)hipFree(C.buf);
-    C.buf = nullptr; C.bytes = 0;
-    if (hipMalloc(&C.buf, total) != hipSuccess) { (void)hipGetLastError(); qpc_set_error("qpc_qp_solve_batch: out of device memory"); return QPC_ERR_OUT_OF_MEMORY; }
-    C.bytes = total;
-  }
-  char *p = C.buf;
-  auto take = [&](size_t bytes) { char *r = p; p += pad64(bytes); return r; };
-  // inputs side by side, outputs side by side: a SMALL batch (B = 1 is the reference's regime) moves in one copy each way through a
-  // page-locked buffer instead of nine copies of pageable memory
-  double *dP = (double *)take(nP * 8), *dq = (double *)take(nq * 8), *dA = (double *)take(nA * 8), *dl = (double *)take(nm * 8),
-         *du = (double *)take(nm * 8);
-  const size_t in_bytes = (size_t)(p - C.buf);
-  char *const out0 = p;
-  double *dx = (double *)take(nq * 8), *dy = (double *)take(nm * 8);
-  int32_t *dst = (int32_t *)take((size_t)B * sizeof(int32_t)), *dit = (int32_t *)take((size_t)B * sizeof(int32_t));
-  const size_t out_bytes = (size_t)(p - out0);
-  double *dws = (double *)take(wsb);
-  const size_t stage_cap = (size_t)2 << 20;
-  if (in_bytes + out_bytes <= stage_cap && !C.h_stage) { if (hipHostMalloc(&C.h_stage, stage_cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); C.h_stage = nullptr; } }
-  const bool staged = in_bytes + out_bytes <= stage_cap && C.h_stage != nullptr;
-  int rc = QPC_OK;
-  auto chk = [&](hipError_t e, const char *w) { if (e != hipSuccess && rc == QPC_OK) rc = hip_fail(e, w); };
-  if (staged) {
-    char *h = C.h_stage;
-    memcpy(h + ((char *)dP - C.buf), P, nP * 8);
-    memcpy(h + ((char *)dq - C.buf), q, nq * 8);
-    if (m) { memcpy(h + ((char *)dA - C.buf), A, nA * 8); memcpy(h + ((char *)dl - C.buf), l, nm * 8); memcpy(h + ((char *)du - C.buf), u, nm * 8); }
-    chk(hipMemcpyAsync(C.buf, h, in_bytes, hipMemcpyHostToDevice, C.stream), "copy the inputs");
-  } else {
-    chk(hipMemcpyAsync(dP, P, nP * sizeof(double), hipMemcpyHostToDevice, C.stream), "copy P");
-    chk(hipMemcpyAsync(dq, q, nq * sizeof(double), hipMemcpyHostToDevice, C.stream), "copy q");
-    if (m) {
-      chk(hipMemcpyAsync(dA, A, nA * sizeof(double), hipMemcpyHostToDevice, C.stream), "copy A");
-      chk(hipMemcpyAsync(dl, l, nm * sizeof(double), hipMemcpyHostToDevice, C.stream), "copy l");
-      chk(hipMemcpyAsync(du, u, nm * sizeof(double), hipMemcpyHostToDevice, C.stream), "copy u");
-    }
-  }
-  if (rc == QPC_OK) rc = qpc_qp_solve_batch_device(n, m, B, dP, dq, dA, dl, du, settings, device_id, dx, dy, dst, dit, dws, wsb, C.stream);
-  if (rc == QPC_OK && staged) {
-    char *ho = C.h_stage + in_bytes;
-    chk(hipMemcpyAsync(ho, out0, out_bytes, hipMemcpyDeviceToHost, C.stream), "copy the outputs");
-    chk(hipStreamSynchronize(C.stream), "qpc_qp_dense_kernel");
-    if (rc == QPC_OK) {
-      memcpy(x, ho, nq * 8);
-      if (m) memcpy(y, ho + ((char *)dy - out0), nm * 8);
-      memcpy(status, ho + ((char *)dst - out0), (size_t)B * sizeof(int32_t));
-      if (iters) memcpy(iters, ho + ((char *)dit - out0), (size_t)B * sizeof(int32_t));
-    }
-    return rc;
-  }
-  if (rc == QPC_OK) {
-    chk(hipMemcpyAsync(x, dx, nq * sizeof(double), hipMemcpyDeviceToHost, C.stream), "copy x");
-    if (m) chk(hipMemcpyAsync(y, dy, nm * sizeof(double), hipMemcpyDeviceToHost, C.stream), "copy y");
-    chk(hipMemcpyAsync(status, dst, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, C.stream), "copy status");
-    if (iters) chk(hipMemcpyAsync(iters, dit, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, C.stream), "copy iters");
-  }
-  chk(hipStreamSynchronize(C.stream), "qpc_qp_dense_kernel");
-  return rc;
-}
-
-// ---- L0 with the optimizer's life cycle: pattern once (qpc_qp_setup), values every call (qpc_qp_solve), warm start from the previous
-//      call's multipliers (kept on the device)
-struct qpc_qp_problem {
-  qpc::QpPrepHost H;
-  int device = 0;
-  hipStream_t stream = nullptr;
-  int *d_ints = nullptr, *d_coo = nullptr; // the pattern's tables; the caller's COO pattern [Prow | Pcol | Arow | Acol]
-  char *buf = nullptr;                     // per-call slab (values, outputs, workspace), grown on demand
-  size_t bytes = 0;
-  double *d_yprev = nullptr;               // multipliers of the previous call, B_prev x m
-  int64_t B_prev = 0, cap_prev = 0;
-  char *dense = nullptr;                   // dense P, A of the batch (only when the dense path is needed)
-  size_t dense_bytes = 0;
-  unsigned long long *d_ticket = nullptr;  // the launch's QP counter (zero between launches: the kernel re-arms it)
-  char *h_stage = nullptr;                 // page-locked staging of a SMALL batch: one copy in, one copy out (B = 1 is the reference's regime)
-  size_t h_stage_bytes = 0;
-  int n_cu = 0;
-};
-
-int32_t qpc_qp_setup(int32_t n, int32_t m, int64_t nnz_P, const int32_t *P_rows, const int32_t *P_cols, int64_t nnz_A,
-                     const int32_t *A_rows, const int32_t *A_cols, int32_t device_id, qpc_qp_problem **out) {
-  if (!out || (nnz_P && (!P_rows || !P_cols)) || (nnz_A && (!A_rows || !A_cols))) { qpc_set_error("qpc_qp_setup: bad arguments"); return QPC_ERR_INVALID_ARGUMENT; }
-  *out = nullptr;
-  std::unique_ptr<qpc_qp_problem> p(new qpc_qp_problem);
-  const std::string err = qpc::qp_prep_build(p->H, n, m, nnz_P, P_rows, P_cols, nnz_A, A_rows, A_cols);
-  if (!err.empty()) { qpc_set_error("qpc_qp_setup: " + err); return QPC_ERR_INVALID_ARGUMENT; }
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
-    (void)hipGetLastError();
-    qpc_set_error("qpc_qp_setup: no HIP device available (this library has no CPU fallback)");
-    return QPC_ERR_NO_DEVICE;
-  }
-  if (device_id < 0 || device_id >= ndev) { qpc_set_error("qpc_qp_setup: device_id out of range"); return QPC_ERR_NO_DEVICE; }
-  p->device = device_id;
-  auto setup = [&]() -> int { // (a failure half-way: qpc_qp_free below releases what was allocated)
-    HIP_TRY(hipSetDevice(device_id));
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
-    p->n_cu = prop.multiProcessorCount;
-    HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
-    HIP_TRY(hipMalloc(&p->d_ints, p->H.ints.size() * sizeof(int)));
-    HIP_TRY(hipMemcpy(p->d_ints, p->H.ints.data(), p->H.ints.size() * sizeof(int), hipMemcpyHostToDevice));
-    std::vector<int> coo;
-    coo.insert(coo.end(), p->H.Prow.begin(), p->H.Prow.end()); coo.insert(coo.end(), p->H.Pcol.begin(), p->H.Pcol.end());
-    coo.insert(coo.end(), p->H.Arow.begin(), p->H.Arow.end()); coo.insert(coo.end(), p->H.Acol.begin(), p->H.Acol.end());
-    coo.push_back(0);
-    HIP_TRY(hipMalloc(&p->d_ticket, sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(p->d_ticket, 0, sizeof(unsigned long long)));
-    HIP_TRY(hipMalloc(&p->d_coo, coo.size() * sizeof(int)));
-    HIP_TRY(hipMemcpy(p->d_coo, coo.data(), coo.size() * sizeof(int), hipMemcpyHostToDevice));
-    return QPC_OK;
-  };
-  if (int rc = setup()) { qpc_qp_free(p.release()); return rc; }
-  *out = p.release();
-  return QPC_OK;
-}
-
-void qpc_qp_free(qpc_qp_problem *p) {
-  if (!p) return;
-  (void)hipSetDevice(p->device);
-  if (p->stream) { (void)hipStreamSynchronize(p->stream); (void)hipStreamDestroy(p->stream); }
-  if (p->d_ints) (void)hipFree(p->d_ints);
-  if (p->d_coo) (void)hipFree(p->d_coo);
-  if (p->d_ticket) (void)hipFree(p->d_ticket);
-  if (p->buf) (void)hipFree(p->buf);
-  if (p->d_yprev) (void)hipFree(p->d_yprev);
-  if (p->dense) (void)hipFree(p->dense);
-  if (p->h_stage) (void)hipHostFree(p->h_stage);
-  delete p;
-}
-
-int32_t qpc_qp_solve(qpc_qp_problem *p, int64_t B, const double *P_vals, const double *q, const double *A_vals, const double *l,
-                     const double *u, const qpc_settings *settings, int32_t warm_start, double *x, double *y, int32_t *status,
-                     int32_t *iters) {
-  if (!p) { qpc_set_error("qpc_qp_solve: null problem"); return QPC_ERR_INVALID_ARGUMENT; }
-  const int n = p->H.n, m = p->H.m;
-  const long long nnzP = p->H.nnzP, nnzA = p->H.nnzA;
-  if (B < 0 || (nnzP && !P_vals) || !q || (m && ((nnzA && !A_vals) || !l || !u)) || !x || (m && !y) || !status) {
-    qpc_set_error("qpc_qp_solve: bad arguments"); return QPC_ERR_INVALID_ARGUMENT;
-  }
-  if (B == 0) return QPC_OK;
-  HIP_TRY(hipSetDevice(p->device));
-  qpc_settings st;
-  if (settings) st = *settings; else qpc_default_settings(&st);
-  const size_t nPv = (size_t)B * nnzP, nq = (size_t)B * n, nAv = (size_t)B * nnzA, nm = (size_t)B * m;
-  const size_t wsb = (size_t)qpc_qp_workspace_bytes(n, m > 0 ? m : 1, B);
-  const size_t total = pad64(nPv * 8) + 2 * pad64(nq * 8) + pad64(nAv * 8) + 3 * pad64(nm * 8) + pad64(wsb) + 2 * pad64((size_t)B * sizeof(int32_t));
-  if (total > p->bytes) {
-    if (p->buf) (void)hipFree(p->buf);
-    p->buf = nullptr; p->bytes = 0;
-    if (hipMalloc(&p->buf, total) != hipSuccess) { (void)hipGetLastError(); qpc_set_error("qpc_qp_solve: out of device memory"); return QPC_ERR_OUT_OF_MEMORY; }
-    p->bytes = total;
-  }
-  char *c = p->buf;
-  auto take = [&](size_t bytes) { char *r = c; c += pad64(bytes); return r; };
-  // inputs side by side, outputs side by side: a small batch moves in ONE copy each way
-  double *dPv = (double *)take(nPv * 8), *dq = (double *)take(nq * 8), *dAv = (double *)take(nAv * 8), *dl = (double *)take(nm * 8),
-         *du = (double *)take(nm * 8);
-  const size_t in_bytes = (size_t)(c - p->buf);
-  char *const out0 = c;
-  double *dx = (double *)take(nq * 8), *dy = (double *)take(nm * 8);
-  int32_t *dst = (int32_t *)take((size_t)B * sizeof(int32_t)), *dit = (int32_t *)take((size_t)B * sizeof(int32_t));
-  const size_t out_bytes = (size_t)(c - out0);
-  double *dws = (double *)take(wsb);
-  int rc = QPC_OK;
-  auto chk = [&](hipError_t e, const char *w) { if (e != hipSuccess && rc == QPC_OK) rc = hip_fail(e, w); };
-  const bool warm = warm_start && p->d_yprev && p->B_prev >= B && m > 0;
-  const bool wg = m > 0 && !p->H.p_offdiag && n <= QPC_WG_DIM && m <= QPC_WG_DIM;
-  const bool small = wg && in_bytes + out_bytes <= ((size_t)1 << 20);
-  if (small && in_bytes + out_bytes > p->h_stage_bytes) {
-    if (p->h_stage) (void)hipHostFree(p->h_stage);
-    p->h_stage = nullptr; p->h_stage_bytes = 0;
-    if (hipHostMalloc(&p->h_stage, (size_t)1 << 20, hipHostMallocDefault) == hipSuccess) p->h_stage_bytes = (size_t)1 << 20; else (void)hipGetLastError();
-  }
-  const bool staged = small && p->h_stage != nullptr;
-  if (staged) { // the same layout in the page-locked buffer, one copy
-    char *h = p->h_stage;
-    if (nPv) memcpy(h + ((char *)dPv - p->buf), P_vals, nPv * 8);
-    memcpy(h + ((char *)dq - p->buf), q, nq * 8);
-    if (nAv) memcpy(h + ((char *)dAv - p->buf), A_vals, nAv * 8);
-    memcpy(h + ((char *)dl - p->buf), l, nm * 8);
-    memcpy(h + ((char *)du - p->buf), u, nm * 8);
-    chk(hipMemcpyAsync(p->buf, h, in_bytes, hipMemcpyHostToDevice, p->stream), "copy the inputs");
-  } else {
-    if (nPv) chk(hipMemcpyAsync(dPv, P_vals, nPv * 8, hipMemcpyHostToDevice, p->stream), "copy P values");
-    chk(hipMemcpyAsync(dq, q, nq * 8, hipMemcpyHostToDevice, p->stream), "copy q");
-    if (m) {
-      if (nAv) chk(hipMemcpyAsync(dAv, A_vals, nAv * 8, hipMemcpyHostToDevice, p->stream), "copy A values");
-      chk(hipMemcpyAsync(dl, l, nm * 8, hipMemcpyHostToDevice, p->stream), "copy l");
-      chk(hipMemcpyAsync(du, u, nm * 8, hipMemcpyHostToDevice, p->stream), "copy u");
-    }
-  }
-  const long long ws_stride = (long long)qpc::qp_dense_workspace_doubles(n, m > 0 ? m : 1);
-  std::vector<int32_t> hst((size_t)B, QPC_WG_FALLBACK);
-  auto keep_y = [&]() { // the multipliers stay on the device for the next call's warm start
-    if (!m) return;
-    if (B > p->cap_prev) {
-      if (p->d_yprev) (void)hipFree(p->d_yprev);
-      p->d_yprev = nullptr; p->cap_prev = 0; p->B_prev = 0;
-      if (hipMalloc(&p->d_yprev, nm * 8) == hipSuccess) p->cap_prev = B; else (void)hipGetLastError();
-    }
-    if (p->d_yprev) { chk(hipMemcpyAsync(p->d_yprev, dy, nm * 8, hipMemcpyDeviceToDevice, p->stream), "keep y"); p->B_prev = B; }
-  };
-  if (rc == QPC_OK && wg) {
-    const int lds_bytes = QPC_WG_LDS_DOUBLES * (int)sizeof(double);
-    if (int arc = qpc_wg_lds_attr((const void *)qpc_qp_wg_prep_kernel, p->device, lds_bytes)) return arc;
-    const long long grid = B < (long long)p->n_cu * 4 ? B : (long long)p->n_cu * 4;
-    const double *y0 = warm ? p->d_yprev : (const double *)nullptr;
-    if (B > p->cap_prev) { // the kernel leaves every QP's multipliers here for the next call's warm start
-      if (p->d_yprev) (void)hipFree(p->d_yprev);
-      p->d_yprev = nullptr; p->cap_prev = 0; p->B_prev = 0;
-      if (hipMalloc(&p->d_yprev, nm * 8) == hipSuccess) p->cap_prev = B; else (void)hipGetLastError();
-    }
-    // (no memset of the QP counter: the launch's last ticket re-arms it)
-    hipLaunchKernelGGL(qpc_qp_wg_prep_kernel, dim3((unsigned)grid), dim3(QPC_WG_THREADS), (size_t)lds_bytes, p->stream, p->H.view(p->d_ints),
-                       (long long)B, nnzP, dPv, dq, dAv, dl, du, st, dws, ws_stride, y0, dx, dy, dst, dit, p->d_ticket, p->d_yprev);
-    chk(hipGetLastError(), "qpc_qp_wg_prep_kernel");
-    if (staged) { // outputs in one copy (a QP the workgroup left is rare and redoes it below)
-      char *ho = p->h_stage + in_bytes;
-      chk(hipMemcpyAsync(ho, out0, out_bytes, hipMemcpyDeviceToHost, p->stream), "copy the outputs");
-      chk(hipStreamSynchronize(p->stream), "qpc_qp_wg_prep_kernel");
-      if (rc != QPC_OK) { (void)hipMemset(p->d_ticket, 0, sizeof(unsigned long long)); return rc; }
-      if (p->d_yprev) p->B_prev = B;
-      memcpy(hst.data(), ho + ((char *)dst - out0), (size_t)B * sizeof(int32_t));
-      bool left = false;
-      for (int64_t b = 0; b < B; b++) left = left || hst[(size_t)b] == QPC_WG_FALLBACK;
-      if (!left) {
-        memcpy(x, ho, nq * 8);
-        memcpy(y, ho + ((char *)dy - out0), nm * 8);
-        if (iters) memcpy(iters, ho + ((char *)dit - out0), (size_t)B * sizeof(int32_t));
-        for (int64_t b = 0; b < B; b++) status[b] = hst[(size_t)b];
-        return QPC_OK;
-      }
-    } else {
-      chk(hipMemcpyAsync(hst.data(), dst, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, p->stream), "copy status");
-      chk(hipStreamSynchronize(p->stream), "qpc_qp_wg_prep_kernel");
-      if (rc != QPC_OK) { (void)hipMemset(p->d_ticket, 0, sizeof(unsigned long long)); return rc; }
-      if (p->d_yprev) p->B_prev = B;
-    }
-  }
-  bool need_dense = !wg;
-  for (int64_t b = 0; b < B && !need_dense; b++) need_dense = hst[(size_t)b] == QPC_WG_FALLBACK;
-  if (rc == QPC_OK && need_dense) { // the dense path: scatter P, A and run the dense entry on what is left
-    const size_t nP = (size_t)B * n * n, nA = (size_t)B * (m > 0 ? m : 1) * n;
-    const size_t need = pad64(nP * 8) + pad64(nA * 8);
-    if (need > p->dense_bytes) {
-      if (p->dense) (void)hipFree(p->dense);
-      p->dense = nullptr; p->dense_bytes = 0;
-      if (hipMalloc(&p->dense, need) != hipSuccess) { (void)hipGetLastError(); qpc_set_error("qpc_qp_solve: out of device memory (dense path)"); return QPC_ERR_OUT_OF_MEMORY; }
-      p->dense_bytes = need;
-    }
-    double *dP = (double *)p->dense, *dA = (double *)(p->dense + pad64(nP * 8));
-    chk(hipMemsetAsync(p->dense, 0, need, p->stream), "clear dense P, A");
-    const int *Prow = p->d_coo, *Pcol = Prow + nnzP, *Arow = Pcol + nnzP, *Acol = Arow + nnzA;
-    if (nnzP + nnzA > 0) {
-      hipLaunchKernelGGL(qpc_qp_densify_kernel, dim3(1024), dim3(256), 0, p->stream, n, m, (long long)B, nnzP, Prow, Pcol, dPv, nnzA, Arow, Acol,
-                         dAv, dP, dA);
-      chk(hipGetLastError(), "qpc_qp_densify_kernel");
-    }
-    if (!wg) { // everything through the dense entry (its own workgroup pass detects what it can take)
-      if (rc == QPC_OK) rc = qpc_qp_solve_batch_device(n, m, B, dP, dq, dA, dl, du, &st, p->device, dx, dy, dst, dit, dws, wsb, p->stream);
-    } else {   // only the QPs the workgroup left: the one-lane kernel
-      hipLaunchKernelGGL(qpc_qp_dense_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, p->stream, n, m, (long long)B, dP, dq, dA, dl, du, st,
-                         dws, ws_stride, dx, dy, dst, dit, 1);
-      chk(hipGetLastError(), "qpc_qp_dense_kernel");
-    }
-    chk(hipMemcpyAsync(hst.data(), dst, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, p->stream), "copy status");
-  }
-  if (rc == QPC_OK) {
-    chk(hipMemcpyAsync(x, dx, nq * 8, hipMemcpyDeviceToHost, p->stream), "copy x");
-    if (m) chk(hipMemcpyAsync(y, dy, nm * 8, hipMemcpyDeviceToHost, p->stream), "copy y");
-    if (iters) chk(hipMemcpyAsync(iters, dit, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, p->stream), "copy iters");
-    if (need_dense) keep_y(); // (the workgroup kernel has kept its own; the QPs the dense path re-solved have new multipliers)
-  }
-  chk(hipStreamSynchronize(p->stream), "qpc_qp_solve");
-  if (rc == QPC_OK) for (int64_t b = 0; b < B; b++) status[b] = hst[(size_t)b];
   return rc;
 }
 

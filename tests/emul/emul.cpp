@@ -164,6 +164,8 @@ static inline real emu_sum64(const real *x) { real s = 0.0; for (int l = 0; l < 
 #include "../../qpcontrol.jl_amd/csrc/qpc_qp_dense.h"
 #include "../../qpcontrol.jl_amd/csrc/qpc_qp_wg.h"
 #include "../../qpcontrol.jl_amd/csrc/qpc_qp_prep.h"
+#include "../../qpcontrol.jl_amd/csrc/qpc_qp_sym.h"
+#include "../../qpcontrol.jl_amd/csrc/qpc_qp_sp.h"
 #include "../../qpcontrol.jl_amd/csrc/qpc_l1_dense.h"
 #endif
 
@@ -467,9 +469,16 @@ int32_t qpc_rollout_batch(qpc_controller *, int64_t, int64_t, double *, double *
 // L0 with the optimizer's life cycle (qpc_qp_setup / qpc_qp_solve): the host tables of qpc_qp_prep.h, the same kernel source
 struct qpc_qp_problem {
   qpc::QpPrepHost H;
+  qpc::QpSpPlanHost plan; // the sparse workgroup solver's plan for the set of equality rows of the last batch's first QP
+  bool plan_tried = false;
   std::vector<double> yprev;
   int64_t B_prev = 0;
 };
+static long g_l0_sp = 0; // QPs solved by the sparse workgroup form since the last emu_l0_sp_count()
+static void emu_eq_rows(int m, const double *l, const double *u, std::vector<uint8_t> &eq) {
+  eq.resize(m);
+  for (int i = 0; i < m; i++) eq[i] = (l[i] > -1e19 && u[i] < 1e19 && u[i] - l[i] <= 1e-12 * (1.0 + std::fabs(l[i]))) ? 1 : 0;
+}
 int32_t qpc_qp_setup(int32_t n, int32_t m, int64_t nnz_P, const int32_t *P_rows, const int32_t *P_cols, int64_t nnz_A,
                      const int32_t *A_rows, const int32_t *A_cols, int32_t device_id, qpc_qp_problem **out) {
   (void)device_id;
@@ -496,9 +505,27 @@ int32_t qpc_qp_solve(qpc_qp_problem *p, int64_t B, const double *P_vals, const d
   const bool warm = warm_start && p->B_prev >= B && m > 0;
   const qpc::QpPrepView V = p->H.view(p->H.ints.data());
   std::vector<double> ynew((size_t)B * m);
+  // the sparse workgroup form (qpc_qp_sp.h) first: its plan is made for the equality rows of the batch's first QP
+  const char *nosp = getenv("QPC_L0_NO_SPARSE");
+  const bool try_sp = m > 0 && B > 0 && !(nosp && nosp[0] == '1');
+  if (try_sp) {
+    std::vector<uint8_t> eq;
+    emu_eq_rows(m, l, u, eq);
+    if (!p->plan_tried || eq != p->plan.eq) { qpc::qp_sp_plan_build(p->H, eq.data(), p->plan); p->plan_tried = true; }
+  }
+  const int wg_total = cap ? atoi(cap) : QPC_WG_LDS_DOUBLES; // doubles of "LDS" (the device's 160 KB)
+  std::vector<double> sp_lds;
+  int sp_cap = 0;
+  if (try_sp && p->plan.valid) { sp_cap = wg_total - (p->plan.lds_ints + 1) / 2; if (sp_cap > 0) sp_lds.assign((size_t)sp_cap, 0.0); }
   for (int64_t b = 0; b < B; b++) {
     int s = QPC_WG_FALLBACK;
-    if (m > 0 && !p->H.p_offdiag)
+    if (sp_cap > 0) {
+      s = qpc::qp_solve_sp(p->plan.ints.data(), p->plan.ints.data(), P_vals + b * nnzP, q + b * n, A_vals + b * nnzA, l + b * m, u + b * m, st,
+                           sp_lds.data(), sp_cap, warm ? p->yprev.data() + b * m : nullptr, x + b * n, y + b * m, iters ? iters + b : nullptr,
+                           nullptr);
+      g_l0_sp += s != QPC_WG_FALLBACK;
+    }
+    if (s == QPC_WG_FALLBACK && m > 0 && !p->H.p_offdiag)
       s = qpc::qp_solve_wg_prep(V, P_vals + b * nnzP, q + b * n, A_vals + b * nnzA, l + b * m, u + b * m, st, ws.data(), lds.data(), lds_cap,
                                 warm ? p->yprev.data() + b * m : nullptr, x + b * n, y + b * m, iters ? iters + b : nullptr);
     g_l0_wg += s != QPC_WG_FALLBACK;
@@ -518,6 +545,16 @@ int32_t qpc_qp_solve(qpc_qp_problem *p, int64_t B, const double *P_vals, const d
   return QPC_OK;
 }
 long emu_l0_wg_count() { const long r = g_l0_wg; g_l0_wg = 0; return r; }
+long emu_l0_sp_count() { const long r = g_l0_sp; g_l0_sp = 0; return r; }
+// the plan of a prepared problem (diagnostics of the tests): out[0..11] = valid, ne, mi, fronts, levels, jobs, value-store doubles, LDS ints,
+// widest front, tallest front, elimination multiply-adds, total ints
+int emu_l0_plan_stats(qpc_qp_problem *p, long long *out) {
+  if (!p || !p->plan_tried) return -1;
+  const qpc::QpSpPlanHost &P = p->plan;
+  const long long v[12] = {P.valid, P.ne, P.mi, P.nfront, P.nlevel, P.njob, P.nval, P.lds_ints, P.maxw, P.maxr, P.flops, (long long)P.ints.size()};
+  for (int i = 0; i < 12; i++) out[i] = v[i];
+  return 0;
+}
 #endif
 // race-detector report: counts since the last call
 void emu_report(long *races, long *uninit, long *outside, char *first, int n) {
