@@ -107,7 +107,7 @@ qpc_qp_wg_prep_kernel(qpc::QpPrepView V, long long B, long long nnzP, const doub
 }
 // L0 for a prepared problem with a PLAN (qpc_qp_sym.h, qpc_qp_sp.h): the sparse workgroup form.  The plan's tables go to LDS once per
 // workgroup; QPs are drawn from the device counter like above.  A QP whose equality rows are not the plan's is left (QPC_WG_FALLBACK).
-extern "C" __global__ void __launch_bounds__(QPC_SP_THREADS)
+extern "C" __global__ void __launch_bounds__(QPC_SP_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2))) // (the register-resident panels want the 256 registers of two wavefronts per SIMD)
 qpc_qp_sp_kernel(const int *plan, int lds_doubles, long long B, long long nnzP, const double *Pv, const double *q, const double *Av,
                  const double *l, const double *u, qpc_settings st, const double *y0, double *x, double *y, int32_t *status,
                  int32_t *iters, unsigned long long *ticket, double *ykeep, unsigned long long *stamps) {
@@ -126,6 +126,9 @@ qpc_qp_sp_kernel(const int *plan, int lds_doubles, long long B, long long nnzP, 
       if (threadIdx.x == 0 && b == B + (long long)gridDim.x - 1) atomicExch(ticket, 0ull); // (the launch's last ticket re-arms the counter)
       break;
     }
+#ifdef QPC_SP_PROF
+    const long long c0__ = clock64(), w0__ = wall_clock64();
+#endif
     const int s = qpc::qp_solve_sp(plan, plan_lds, Pv + b * nnzP, q + b * n, Av + b * nnzA, l + b * m, u + b * m, st, lds,
                                    lds_doubles - (nint + 1) / 2, y0 ? y0 + b * m : nullptr, x + b * n, y + b * m,
                                    iters ? iters + b : nullptr, stamps);
@@ -133,10 +136,15 @@ qpc_qp_sp_kernel(const int *plan, int lds_doubles, long long B, long long nnzP, 
     __syncthreads();
     if (ykeep && s != QPC_WG_FALLBACK) for (int i = threadIdx.x; i < m; i += blockDim.x) ykeep[b * m + i] = y[b * m + i];
 #ifdef QPC_SP_PROF
-    if (threadIdx.x == 0 && b == 0 && stamps) {
-      printf("sp_prof status %d us:", s);
-      for (int k = 1; k <= 7; k++) printf(" %.1f", (double)(stamps[k] - stamps[k - 1]) * 0.01);
-      printf(" total %.1f\n", (double)(stamps[7] - stamps[0]) * 0.01);
+    if (threadIdx.x == 0 && (b == 0 || (b == 1 && gridDim.x == 1)) && stamps) {
+      // set-up (values, H^-1, xu) | G | front / update of the levels 0, 1, 2 | iterations | equality multipliers | refinement | output
+      static const char *nm[13] = {"", "setup", "G", "F0", "U0", "F1", "U1", "F2", "U2", "iter", "yE", "refine", "out"};
+      printf("sp_prof (shader clock %.0f MHz) status %d iters %d us:", (double)(clock64() - c0__) / ((double)(wall_clock64() - w0__) * 0.01), s, iters ? iters[b] : -1);
+      for (int k = 1; k <= 12; k++) printf(" %s %.1f", nm[k], (double)(stamps[k] - stamps[k - 1]) * 0.01);
+      printf(" | total %.1f\n", (double)(stamps[12] - stamps[0]) * 0.01);
+      printf("   working-set factorizations %llu (rows in all %llu): gather %.1f, panels %.1f, multipliers %.1f, A x %.1f us\n", qpc::qpc_sp_acc[8], qpc::qpc_sp_acc[9],
+             (double)qpc::qpc_sp_acc[0] * 0.01, (double)qpc::qpc_sp_acc[1] * 0.01, (double)qpc::qpc_sp_acc[2] * 0.01, (double)qpc::qpc_sp_acc[3] * 0.01);
+      for (int k = 0; k < 16; k++) qpc::qpc_sp_acc[k] = 0;
     }
 #endif
   }
@@ -569,8 +577,9 @@ int32_t qpc_qp_solve(qpc_qp_problem *p, int64_t B, const double *P_vals, const d
     const int lds_bytes = p->sp_lds_doubles * (int)sizeof(double);
     if (int arc = qpc_wg_lds_attr((const void *)qpc_qp_sp_kernel, p->device, lds_bytes)) return arc;
     const long long per_cu = 160 * 1024 / lds_bytes > 0 ? 160 * 1024 / lds_bytes : 1;
-    const long long grid = B < (long long)p->n_cu * per_cu ? B : (long long)p->n_cu * per_cu;
+    long long grid = B < (long long)p->n_cu * per_cu ? B : (long long)p->n_cu * per_cu;
 #ifdef QPC_SP_PROF
+    if (const char *eg = getenv("QPC_L0_GRID")) grid = atoi(eg) > 0 ? atoi(eg) : grid; // (profiling build: several QPs through ONE workgroup)
     if (!p->d_stamps) { if (hipMalloc(&p->d_stamps, 16 * sizeof(unsigned long long)) != hipSuccess) { (void)hipGetLastError(); p->d_stamps = nullptr; } }
 #endif
     hipLaunchKernelGGL(qpc_qp_sp_kernel, dim3((unsigned)grid), dim3(QPC_SP_THREADS), (size_t)lds_bytes, p->stream, (const int *)p->d_plan,

@@ -31,7 +31,7 @@
 #endif
 
 #ifndef QPC_SP_THREADS
-#define QPC_SP_THREADS 256 // threads of the workgroup (device)
+#define QPC_SP_THREADS 512 // threads of the workgroup (device): two wavefronts per SIMD
 #endif
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -66,6 +66,19 @@
 #endif
 
 namespace qpc {
+
+#if defined(QPC_SP_PROF) && defined(__HIPCC__)
+__device__ unsigned long long qpc_sp_acc[16]; // (profiling build: time inside the pieces of the working-set iterations, QP 0's workgroup)
+#endif
+#if defined(QPC_SP_PROF) && defined(__HIP_DEVICE_COMPILE__)
+#define QPC_SP_ACC_T0() unsigned long long acc_t0__ = wall_clock64()
+#define QPC_SP_ACC(k) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) { const unsigned long long n__ = wall_clock64(); qpc_sp_acc[k] += n__ - acc_t0__; acc_t0__ = n__; } } while (0)
+#define QPC_SP_ACC_ADD(k, v) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) qpc_sp_acc[k] += (v); } while (0)
+#else
+#define QPC_SP_ACC_T0() do { } while (0)
+#define QPC_SP_ACC(k) do { } while (0)
+#define QPC_SP_ACC_ADD(k, v) do { } while (0)
+#endif
 
 QPC_FN int sp_cs(int c, int N1) { return c * N1 - (c * (c - 1)) / 2; }      // packed lower triangle, column-major: start of column c
 QPC_FN int sp_sidx(int i, int c, int N1) { return sp_cs(c, N1) + i - c; }    // i >= c
@@ -153,21 +166,222 @@ inline int qp_sp_lds_doubles(const int *plan, int kw) {
          (kw + 1) * (kw + 2) / 2 + plan[SP_NNZA] + 2;
 }
 
-// ---- a front: LDL' of its w columns without square roots (the columns keep L D, dinv = 1 / d or 0 for a dropped pivot), the rows
-//      below its diagonal block carried along.  One wavefront, lanes down the rows; no workgroup barrier.
-QPC_FN void sp_front_factor(double *V, int base, int r, int w, const double *ref, double tau, double *dinv) {
-  for (int j = 0; j < w; j++) {
-    const double d = V[base + j * r + j], rf = ref[j];
-    const bool ok = d > tau * (rf > 1e-300 ? rf : 1e-300);
-    const double di = ok ? 1.0 / d : 0.0;
-    QPC_SP_L0 { dinv[j] = di; }
-    for (int i = j + 1 + QPC_SP_LANE; i < r; i += QPC_SP_NLANE) {
-      const double lij = V[base + j * r + i];
-      const int cend = i < w ? i : w - 1;
-      for (int c = j + 1; c <= cend; c++) V[base + c * r + i] -= lij * (V[base + j * r + c] * di);
+// ---- LDL' without square roots of the leading nc columns of a tall panel, by ONE wavefront (no workgroup barrier).  Entry (i, c) at
+//      S[cb + c * cs1 - (c (c - 1) / 2) * cs2 + i]: a front's rectangle (cs1 = its rows, cs2 = 0) or a packed triangle (cs1 = its
+//      dimension - 1 ... see sp_pcol).  The columns keep L D (unscaled), dinv[j] = 1 / d_j, or 0 for a pivot below tau * ref[j] (a
+//      dependent row drops out of everything).  Eight columns at a time, as qpc_qp_wg.h does it for the whole matrix: every lane factors
+//      the panel's 8 x 8 diagonal block itself, in registers (36 broadcast loads, a chain of pivots); a row below the block is a little
+//      triangular solve against multipliers the lane already holds; then the panel's rank-8 update of the later columns, a lane per
+//      row, the row's eight panel values loaded once.  What bounds it is LDS latency: every loop has its loads first.
+struct SpCols { int cb, cs1, cs2; }; // column c starts (row 0) at cb + c * cs1 - cs2 * (c (c - 1) / 2)
+QPC_FN int sp_pcol(const SpCols &C, int c) { return C.cb + c * C.cs1 - C.cs2 * ((c * (c - 1)) / 2); }
+QPC_FN SpCols sp_cols_rect(int base, int r) { SpCols C; C.cb = base; C.cs1 = r; C.cs2 = 0; return C; }
+QPC_FN SpCols sp_cols_packed(int K1) { SpCols C; C.cb = 0; C.cs1 = K1 - 1; C.cs2 = 1; return C; } // sp_cs(c, K1) - c = c (K1 - 1) - c (c - 1) / 2
+#define QPC_SP_NB 8
+QPC_FN void sp_ldl_panels(double *S, const SpCols C, int nr, int nc, const double *ref, double tau, double *dinv) {
+  for (int jp = 0; jp < nc; jp += QPC_SP_NB) {
+    const int nb = nc - jp < QPC_SP_NB ? nc - jp : QPC_SP_NB;
+    int pc[QPC_SP_NB];
+    double blk[QPC_SP_NB][QPC_SP_NB], mul[QPC_SP_NB][QPC_SP_NB], dv[QPC_SP_NB], rfv[QPC_SP_NB];
+#pragma unroll
+    for (int c = 0; c < QPC_SP_NB; c++) {
+      pc[c] = sp_pcol(C, c < nb ? jp + c : jp); // S[i][jp + c] = S[pc[c] + i]
+#pragma unroll
+      for (int r = c; r < QPC_SP_NB; r++) {
+        const double v = S[pc[c] + jp + (r < nb ? r : 0)]; // (always a load from a valid address, the choice afterwards)
+        blk[r][c] = (r < nb && c < nb) ? v : (r == c ? 1.0 : 0.0);
+      }
+      rfv[c] = ref[c < nb ? jp + c : jp];
+    }
+    QPC_SP_WSYNC // (every lane has the block: lane 0 may overwrite it)
+#pragma unroll
+    for (int j = 0; j < QPC_SP_NB; j++) {
+      const double d = blk[j][j], rf = rfv[j];
+      const bool ok = j < nb && d > tau * (rf > 1e-300 ? rf : 1e-300);
+      dv[j] = ok ? 1.0 / d : 0.0;
+#pragma unroll
+      for (int c = j + 1; c < QPC_SP_NB; c++) {
+        const double lc = blk[c][j] * dv[j];
+        mul[c][j] = lc;
+#pragma unroll
+        for (int r = c; r < QPC_SP_NB; r++) blk[r][c] -= blk[r][j] * lc;
+      }
+    }
+    QPC_SP_L0 {
+#pragma unroll
+      for (int c = 0; c < QPC_SP_NB; c++) {
+        if (c < nb) {
+          dinv[jp + c] = dv[c];
+#pragma unroll
+          for (int r = c; r < QPC_SP_NB; r++) if (r < nb) S[pc[c] + jp + r] = blk[r][c];
+        }
+      }
+    }
+    // the rows below the block: u L1' = a.  Then, while the row's panel values are in registers, the panel's update of the row's
+    // entries in the later columns of this elimination (c2 = jp + nb .. nc - 1, c2 <= i)
+    const int c2a = jp + nb;
+    for (int i = jp + nb + QPC_SP_LANE; i < nr; i += QPC_SP_NLANE) {
+      double a[QPC_SP_NB];
+#pragma unroll
+      for (int c = 0; c < QPC_SP_NB; c++) a[c] = S[pc[c] + i]; // (a column beyond nb: pc of the first one, value unused)
+#pragma unroll
+      for (int j = 0; j < QPC_SP_NB; j++) {
+#pragma unroll
+        for (int c = j + 1; c < QPC_SP_NB; c++) a[c] -= a[j] * mul[c][j];
+      }
+#pragma unroll
+      for (int c = 1; c < QPC_SP_NB; c++) if (c < nb) S[pc[c] + i] = a[c];
     }
     QPC_SP_WSYNC
+    if (c2a < nc) {
+      for (int i = c2a + QPC_SP_LANE; i < nr; i += QPC_SP_NLANE) {
+        double u[QPC_SP_NB];
+#pragma unroll
+        for (int c = 0; c < QPC_SP_NB; c++) u[c] = S[pc[c] + i] * dv[c]; // (dv of a padding column: 0)
+        const int cend = i < nc ? i : nc - 1;
+        int c2 = c2a;
+        for (; c2 + 1 <= cend; c2 += 2) { // two target columns at a time: all their loads first
+          const int t0 = sp_pcol(C, c2) + i, t1 = sp_pcol(C, c2 + 1) + i;
+          double m0[QPC_SP_NB], m1[QPC_SP_NB];
+#pragma unroll
+          for (int c = 0; c < QPC_SP_NB; c++) { m0[c] = S[pc[c] + c2]; m1[c] = S[pc[c] + c2 + 1]; }
+          double v0 = S[t0], v1 = S[t1];
+#pragma unroll
+          for (int c = 0; c < QPC_SP_NB; c++) { v0 -= u[c] * m0[c]; v1 -= u[c] * m1[c]; }
+          S[t0] = v0; S[t1] = v1;
+        }
+        if (c2 <= cend) {
+          const int t0 = sp_pcol(C, c2) + i;
+          double m0[QPC_SP_NB];
+#pragma unroll
+          for (int c = 0; c < QPC_SP_NB; c++) m0[c] = S[pc[c] + c2];
+          double v0 = S[t0];
+#pragma unroll
+          for (int c = 0; c < QPC_SP_NB; c++) v0 -= u[c] * m0[c];
+          S[t0] = v0;
+        }
+      }
+      QPC_SP_WSYNC
+    }
   }
+}
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(QPC_SP_NO_REG)
+// ---- the same elimination with the panel in REGISTERS (device): lane = row, column c of the row in a[c] (static indices), a pivot
+//      row's multipliers broadcast with v_readlane -- no LDS round trip inside the elimination: what bounds the LDS forms is the
+//      latency of their dependent loads (~60 ns each), several per pivot.  Straight-line code for KR = 8, 16, 24, 32 columns, NO
+//      conditions inside: the columns beyond the real ones are zero, their pivots fail the test and drop out like dependent rows do
+//      (a skipped block costs a taken branch, measured at ~40 ns -- more than the block).
+QPC_FN double sp_readlane(double v, int lane) { // (lane: a constant)
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+// one pass over <= 64 rows.  first: the lanes 0 .. KR-1 hold the diagonal block (lane c = its row c): the pivots are taken,
+// mul[j] <- a[j] / d_j (lane c: L_cj), dv (lane j) = 1 / d_j or 0; refv (lane j): the pivot's reference.  Later passes (further rows
+// of the same panel) reuse mul.
+template <int KR>
+QPC_FN void sp_reg_elim(double (&a)[KR], double (&mul)[KR], bool first, double refv, double tau, double &dv) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int j = 0; j < KR; j++) {
+    if (first) {
+      const double d = sp_readlane(a[j], j), rf = sp_readlane(refv, j);
+      const bool ok = d > tau * (rf > 1e-300 ? rf : 1e-300);
+      const double di = ok ? qpc_rcp(d) : 0.0;
+      mul[j] = a[j] * di;
+      dv = lane == j ? di : dv;
+    }
+#pragma unroll
+    for (int c = j + 1; c < KR; c++) a[c] -= a[j] * sp_readlane(mul[j], c);
+  }
+}
+// (not inlined: a register allocation of its own -- inlined into the kernel the four sizes cost it 1 268 spilled scalar registers)
+template <int KR>
+__device__ __attribute__((noinline)) void sp_front_factor_reg(double *V, int base, int r, int w, const double *ref, double tau, double *dinv) {
+  const int lane = threadIdx.x & 63;
+  double a[KR], mul[KR], dv = 0.0;
+  const double refv = lane < w ? ref[lane] : 1.0;
+  for (int p0 = 0; p0 < r; p0 += 64) {
+    const int i = p0 + lane, ic = i < r ? i : r - 1;
+#pragma unroll
+    for (int c = 0; c < KR; c++) { const double v = V[base + (c < w ? c : 0) * r + ic]; a[c] = (c < w && i < r) ? v : 0.0; }
+    sp_reg_elim<KR>(a, mul, p0 == 0, refv, tau, dv);
+#pragma unroll
+    for (int c = 1; c < KR; c++) { if (c < w && i < r && i >= c) V[base + c * r + i] = a[c]; }
+    if (p0 == 0 && lane < w) dinv[lane] = dv;
+  }
+}
+#endif
+// t <- L^-1 t on the leading nc columns (L unit lower: L_ij = S_ij dinv_j), four columns per step: every lane solves the 4 x 4
+// diagonal block itself (ten broadcast loads), then takes the four columns out of its rows below.  One wavefront.
+QPC_FN void sp_tri_forward(const double *S, const SpCols C, int nc, const double *dinv, double *t) {
+  for (int j = 0; j < nc; j += 4) {
+    const int nb = nc - j < 4 ? nc - j : 4;
+    const int j1 = nb > 1 ? j + 1 : j, j2 = nb > 2 ? j + 2 : j, j3 = nb > 3 ? j + 3 : j; // (clamped: a short last block re-reads column j)
+    const int c0 = sp_pcol(C, j), c1 = sp_pcol(C, j1), c2 = sp_pcol(C, j2), c3 = sp_pcol(C, j3);
+    const double t0 = t[j], t1 = t[j1], t2 = t[j2], t3 = t[j3];
+    const double d0 = dinv[j], d1 = nb > 1 ? dinv[j1] : 0.0, d2 = nb > 2 ? dinv[j2] : 0.0, d3 = nb > 3 ? dinv[j3] : 0.0;
+    const double l10 = S[c0 + j1], l20 = S[c0 + j2], l30 = S[c0 + j3], l21 = S[c1 + j2], l31 = S[c1 + j3], l32 = S[c2 + j3];
+    const double f0 = t0 * d0;
+    double z1 = t1; z1 -= l10 * f0;
+    const double f1 = z1 * d1;
+    double z2 = t2; z2 -= l20 * f0; z2 -= l21 * f1;
+    const double f2 = z2 * d2;
+    double z3 = t3; z3 -= l30 * f0; z3 -= l31 * f1; z3 -= l32 * f2;
+    const double f3 = z3 * d3;
+    QPC_SP_WSYNC // (everybody has t[j .. j+3])
+    for (int i = j + nb + QPC_SP_LANE; i < nc; i += QPC_SP_NLANE) {
+      const double a0 = S[c0 + i], a1 = S[c1 + i], a2 = S[c2 + i], a3 = S[c3 + i];
+      double v = t[i];
+      v -= a0 * f0; v -= a1 * f1; v -= a2 * f2; v -= a3 * f3; // (f of a clamped column is 0)
+      t[i] = v;
+    }
+    QPC_SP_L0 { if (nb > 1) t[j + 1] = z1; if (nb > 2) t[j + 2] = z2; if (nb > 3) t[j + 3] = z3; }
+    QPC_SP_WSYNC
+  }
+}
+// out <- L^-T D^-1 t on the leading nc columns; t is used up (out may be t).  Four rows per step.  One wavefront.
+QPC_FN void sp_tri_back(const double *S, const SpCols C, int nc, const double *dinv, double *t, double *out) {
+  for (int i0 = nc - 1; i0 >= 0; i0 -= 4) {
+    const int nb = i0 + 1 < 4 ? i0 + 1 : 4;
+    const int i1 = nb > 1 ? i0 - 1 : i0, i2 = nb > 2 ? i0 - 2 : i0, i3 = nb > 3 ? i0 - 3 : i0; // (clamped)
+    const double t0 = t[i0], t1 = t[i1], t2 = t[i2], t3 = t[i3];
+    const double d0 = dinv[i0], d1 = dinv[i1], d2 = dinv[i2], d3 = dinv[i3];
+    const int c1 = sp_pcol(C, i1), c2 = sp_pcol(C, i2), c3 = sp_pcol(C, i3);
+    const double u01 = S[c1 + i0], u02 = S[c2 + i0], u03 = S[c3 + i0], u12 = S[c2 + i1], u13 = S[c3 + i1], u23 = S[c3 + i2];
+    const double y0 = t0 * d0;
+    double v1 = t1; v1 -= u01 * y0;
+    const double y1 = nb > 1 ? v1 * d1 : 0.0;
+    double v2 = t2; v2 -= u02 * y0; v2 -= u12 * y1;
+    const double y2 = nb > 2 ? v2 * d2 : 0.0;
+    double v3 = t3; v3 -= u03 * y0; v3 -= u13 * y1; v3 -= u23 * y2;
+    const double y3 = nb > 3 ? v3 * d3 : 0.0;
+    QPC_SP_WSYNC // (everybody has t[i0 - 3 .. i0])
+    for (int j = QPC_SP_LANE; j < i0 + 1 - nb; j += QPC_SP_NLANE) {
+      const int cj = sp_pcol(C, j);
+      const double a0 = S[cj + i0], a1 = S[cj + i1], a2 = S[cj + i2], a3 = S[cj + i3];
+      double v = t[j];
+      v -= a0 * y0; v -= a1 * y1; v -= a2 * y2; v -= a3 * y3; // (y of a clamped row is 0)
+      t[j] = v;
+    }
+    QPC_SP_L0 { out[i0] = y0; if (nb > 1) out[i1] = y1; if (nb > 2) out[i2] = y2; if (nb > 3) out[i3] = y3; }
+    QPC_SP_WSYNC
+  }
+}
+
+// a front: its w columns eliminated, the rows below carried along (one wavefront)
+QPC_FN void sp_front_factor(double *V, int base, int r, int w, const double *ref, double tau, double *dinv) {
+  if (w == 1) { // a single column: its pivot, nothing else (the rows below keep L D)
+    const double d = V[base], rf = ref[0];
+    const bool ok = d > tau * (rf > 1e-300 ? rf : 1e-300);
+    QPC_SP_L0 { dinv[0] = ok ? 1.0 / d : 0.0; }
+    return;
+  }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(QPC_SP_NO_REG)
+  if (w <= 8) { sp_front_factor_reg<8>(V, base, r, w, ref, tau, dinv); return; }
+  if (w <= 16) { sp_front_factor_reg<16>(V, base, r, w, ref, tau, dinv); return; }
+  if (w <= 24) { sp_front_factor_reg<24>(V, base, r, w, ref, tau, dinv); return; }
+  if (w <= 32) { sp_front_factor_reg<32>(V, base, r, w, ref, tau, dinv); return; }
+#endif
+  sp_ldl_panels(V, sp_cols_rect(base, r), r, w, ref, tau, dinv);
 }
 
 // ---- the update jobs of a level: target tile -= sum over its slots of (source column rows) d^-1 (source column rows)'
@@ -248,11 +462,7 @@ QPC_FN void sp_forward(const QpSp &W, double *t, bool with_rows) {
       const int base = F[0], r = F[1], w = F[2], c0 = F[3];
       QPC_SP_FOR_LANE(c, w) { sp_pull(W, c0 + c, t); }
       QPC_SP_WSYNC
-      for (int j = 0; j + 1 < w; j++) {
-        const double zj = t[c0 + j] * W.dinv[c0 + j];
-        for (int c = j + 1 + QPC_SP_LANE; c < w; c += QPC_SP_NLANE) t[c0 + c] -= W.V[base + j * r + c] * zj;
-        QPC_SP_WSYNC
-      }
+      sp_tri_forward(W.V, sp_cols_rect(base, r), w, W.dinv + c0, t + c0);
     }
     QPC_SP_SYNC
   }
@@ -276,52 +486,60 @@ QPC_FN void sp_back(const QpSp &W, double *y) {
         y[c0 + c] = s;
       }
       QPC_SP_WSYNC
-      for (int j = w - 1; j >= 0; j--) {
-        const double yj = y[c0 + j] * W.dinv[c0 + j];
-        QPC_SP_WSYNC // (every lane has read y[c0 + j] before lane 0 replaces it)
-        QPC_SP_L0 { y[c0 + j] = yj; }
-        for (int c = QPC_SP_LANE; c < j; c += QPC_SP_NLANE) y[c0 + c] -= W.V[base + c * r + j] * yj;
-        QPC_SP_WSYNC
-      }
+      sp_tri_back(W.V, sp_cols_rect(base, r), w, W.dinv + c0, y + c0, y + c0);
     }
     QPC_SP_SYNC
   }
 }
 
-// ---- the working set's own factor, one wavefront.  LDL' of the leading k columns of a packed (k + 1) x (k + 1) triangle (the last
-//      row: a right-hand side riding along)
-QPC_FN void sp_ldl_wave(double *L, int K1, int k, const double *ref, double tau, double *dinv) {
-  for (int j = 0; j < k; j++) {
-    const int cj = sp_cs(j, K1) - j; // L[i][j] = L[cj + i]
-    const double d = L[cj + j], rf = ref[j];
-    const bool ok = d > tau * (rf > 1e-300 ? rf : 1e-300);
-    const double di = ok ? 1.0 / d : 0.0;
-    QPC_SP_L0 { dinv[j] = di; }
-    for (int i = j + 1 + QPC_SP_LANE; i < K1; i += QPC_SP_NLANE) {
-      const double lij = L[cj + i];
-      const int cend = i < k ? i : k - 1;
-      for (int c = j + 1; c <= cend; c++) L[sp_cs(c, K1) - c + i] -= lij * (L[cj + c] * di);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(QPC_SP_NO_REG)
+// the working set's factor in registers (k <= KR <= 32 rows, idxW filled): lane i = row i of C_WW, lane k = the right-hand side.
+// Leaves LW and dinvW in LDS like the panel form (the Goldfarb-Idnani steps and the refinement solve with them) and, with_rhs, yw.
+struct SpWArgs { // (plain pointers: the routine is not inlined)
+  const double *C; int M1;
+  const int *idxW;
+  const double *a0, *wsf, *hi, *lo, *gdiagI;
+  double *tW, *LW, *dinvW, *yw;
+};
+template <int KR>
+__device__ __attribute__((noinline)) void sp_w_factor_reg(const SpWArgs A, int k, double tau, bool with_rhs) {
+  const int lane = threadIdx.x & 63, K1 = k + 1;
+  const int pi = A.idxW[lane < k ? lane : 0];
+  if (with_rhs && lane < k) A.tW[lane] = A.a0[pi] - (A.wsf[pi] > 0.0 ? A.hi[pi] : A.lo[pi]);
+  const double refv = lane < k ? A.gdiagI[pi] : 1.0;
+  int pc[KR];
+#pragma unroll
+  for (int c = 0; c < KR; c++) pc[c] = A.idxW[c < k ? c : 0];
+  QPC_SP_WSYNC
+  double a[KR], mul[KR], dv = 0.0;
+#pragma unroll
+  for (int c = 0; c < KR; c++) {
+    const double cv = A.C[sp_sym(pi, pc[c], A.M1)], rv = with_rhs ? A.tW[c < k ? c : 0] : 0.0;
+    a[c] = c < k ? (lane < k ? cv : (lane == k ? rv : 0.0)) : 0.0;
+  }
+  sp_reg_elim<KR>(a, mul, true, refv, tau, dv);
+#pragma unroll
+  for (int c = 0; c < KR; c++) { if (c < k && lane <= k && lane >= c) A.LW[sp_cs(c, K1) + lane - c] = a[c]; }
+  if (lane < k) A.dinvW[lane] = dv;
+  QPC_SP_WSYNC
+  if (with_rhs) { // y_W = L^-T D^-1 z: lane c takes its COLUMN of the factor back from LW, the substitution runs in registers
+    double col[KR];
+    const int cc = lane < k ? lane : 0, cb = sp_cs(cc, K1) - cc;
+#pragma unroll
+    for (int rr = 1; rr < KR; rr++) { const double v = A.LW[cb + (rr > cc && rr < k ? rr : cc)]; col[rr] = (rr < k && lane < rr) ? v : 0.0; }
+    double t = lane < k ? A.LW[cb + k] : 0.0; // z_c (the right-hand-side row)
+    double yv = 0.0;
+#pragma unroll
+    for (int rr = KR - 1; rr >= 0; rr--) {
+      const double yr = sp_readlane(t, rr) * sp_readlane(dv, rr); // (a row beyond k: dv = 0)
+      yv = lane == rr ? yr : yv;
+      if (rr > 0) t -= col[rr] * yr;
     }
+    if (lane < k) A.yw[lane] = yv;
     QPC_SP_WSYNC
   }
 }
-QPC_FN void sp_ldl_forward_wave(const double *L, int K1, int k, const double *dinv, double *t) {
-  for (int j = 0; j + 1 < k; j++) {
-    const int cj = sp_cs(j, K1) - j;
-    const double zj = t[j] * dinv[j];
-    for (int i = j + 1 + QPC_SP_LANE; i < k; i += QPC_SP_NLANE) t[i] -= L[cj + i] * zj;
-    QPC_SP_WSYNC
-  }
-}
-// out <- L^-T D^-1 t (t is used up, out != t)
-QPC_FN void sp_ldl_back_wave(const double *L, int K1, int k, const double *dinv, double *t, double *out) {
-  for (int i = k - 1; i >= 0; i--) {
-    const double yi = t[i] * dinv[i];
-    QPC_SP_L0 { out[i] = yi; }
-    for (int j = QPC_SP_LANE; j < i; j += QPC_SP_NLANE) t[j] -= L[sp_cs(j, K1) - j + i] * yi;
-    QPC_SP_WSYNC
-  }
-}
+#endif
 
 // Working set in W.wsf (by inequality position) -> idxW (ascending), factor of C_WW in W.LW; with_rhs: the right-hand side a0_W - b_W
 // rides along and yw <- the multipliers of the working rows.  Returns the number of working rows, or -1 beyond what LW holds.
@@ -343,34 +561,67 @@ QPC_FN int sp_w_factor(QpSp &W, double tau, bool with_rhs) {
   if (k > kw) return -1;
   QPC_SP_WSYNC
   const int K1 = k + 1;
-  for (int b = 0; b < k; b++) {
-    const int pb = W.idxW[b], sb = sp_cs(b, K1);
-    QPC_SP_FOR_LANE(e, k - b) { W.LW[sb + e] = sp_C(W, W.idxW[b + e], pb); }
+  if (k == 0) return 0;
+  QPC_SP_ACC_T0();
+  QPC_SP_ACC_ADD(8, 1); QPC_SP_ACC_ADD(9, k);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(QPC_SP_NO_REG)
+  if (k <= 32) {
+    SpWArgs A;
+    A.C = W.V + W.Cb; A.M1 = W.M1; A.idxW = W.idxW; A.a0 = W.a0; A.wsf = W.wsf; A.hi = W.hi; A.lo = W.lo; A.gdiagI = W.gdiag + W.ne;
+    A.tW = W.tW; A.LW = W.LW; A.dinvW = W.dinvW; A.yw = W.yw;
+    if (k <= 8) sp_w_factor_reg<8>(A, k, tau, with_rhs);
+    else if (k <= 16) sp_w_factor_reg<16>(A, k, tau, with_rhs);
+    else if (k <= 24) sp_w_factor_reg<24>(A, k, tau, with_rhs);
+    else sp_w_factor_reg<32>(A, k, tau, with_rhs);
+    QPC_SP_ACC(1);
+    return k;
   }
-  QPC_SP_FOR_LANE(a, k) {
-    const int pa = W.idxW[a];
-    W.tW[a] = W.gdiag[W.ne + pa];
-    W.LW[sp_sidx(k, a, K1)] = with_rhs ? W.a0[pa] - (W.wsf[pa] > 0.0 ? W.hi[pa] : W.lo[pa]) : 0.0;
+#endif
+  // lane i gathers ROW i of C_WW (lane k: the right-hand side), four columns at a time: the index loads, then the loads of C
+  for (int i = QPC_SP_LANE; i <= k; i += QPC_SP_NLANE) {
+    const int pi = i < k ? W.idxW[i] : 0;
+    for (int c0 = 0; c0 < k && c0 <= i; c0 += 4) {
+      int pc[4];
+      double v[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) pc[e] = W.idxW[c0 + e < k ? c0 + e : c0];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const double cv = sp_C(W, pi, pc[e]);
+        const double rv = (with_rhs && i == k) ? W.a0[pc[e]] - (W.wsf[pc[e]] > 0.0 ? W.hi[pc[e]] : W.lo[pc[e]]) : 0.0;
+        v[e] = i == k ? rv : cv;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; e++) if (c0 + e < k && c0 + e <= i) W.LW[sp_cs(c0 + e, K1) + i - (c0 + e)] = v[e];
+    }
+    if (i < k) W.tW[i] = W.gdiag[W.ne + pi];
   }
   QPC_SP_WSYNC
-  sp_ldl_wave(W.LW, K1, k, W.tW, tau, W.dinvW);
+  QPC_SP_ACC(0);
+  const SpCols LC = sp_cols_packed(K1);
+  sp_ldl_panels(W.LW, LC, K1, k, W.tW, tau, W.dinvW);
+  QPC_SP_ACC(1);
   if (with_rhs) {
     QPC_SP_FOR_LANE(a, k) { W.tW[a] = W.LW[sp_sidx(k, a, K1)]; }
     QPC_SP_WSYNC
-    sp_ldl_back_wave(W.LW, K1, k, W.dinvW, W.tW, W.yw);
+    sp_tri_back(W.LW, LC, k, W.dinvW, W.tW, W.yw);
   }
+  QPC_SP_ACC(2);
   return k;
 }
 // EQP of the working set: multipliers of its rows -> yw, ax = A x for every inequality row.  One wavefront.
 QPC_FN int sp_solve_ws(QpSp &W, double tau) {
   const int k = sp_w_factor(W, tau, true);
   if (k < 0) return -1;
+  QPC_SP_ACC_T0();
   QPC_SP_FOR_LANE(p, W.mi) {
     double t = W.a0[p];
+#pragma unroll 8
     for (int a = 0; a < k; a++) t -= sp_C(W, p, W.idxW[a]) * W.yw[a];
     W.ax[p] = t;
   }
   QPC_SP_WSYNC
+  QPC_SP_ACC(3);
   return k;
 }
 
@@ -465,8 +716,8 @@ QPC_FN void sp_iterate(QpSp &W, const qpc_settings &st, double bscale) {
         // r = (C_WW)^-1 C_Wp
         QPC_SP_FOR_LANE(a, k) { W.tW[a] = sp_C(W, W.idxW[a], pr); }
         QPC_SP_WSYNC
-        sp_ldl_forward_wave(W.LW, k + 1, k, W.dinvW, W.tW);
-        sp_ldl_back_wave(W.LW, k + 1, k, W.dinvW, W.tW, W.dW);
+        sp_tri_forward(W.LW, sp_cols_packed(k + 1), k, W.dinvW, W.tW);
+        sp_tri_back(W.LW, sp_cols_packed(k + 1), k, W.dinvW, W.tW, W.dW);
         double dpart = 0.0;
         QPC_SP_FOR_LANE(a, k) { dpart += sp_C(W, pr, W.idxW[a]) * W.dW[a]; }
         // (the sum over the lanes in lane order: a fixed order)
@@ -685,11 +936,12 @@ QPC_FN int qp_solve_sp(const int *plan_g, const int *plan_lds, const double *Pv,
         sp_front_factor(W.V, F[0], F[1], F[2], W.gdiag + F[3], st.eps_dual_reg, W.dinv + F[3]);
       }
       QPC_SP_SYNC
+      QPC_SP_STAMP(W, lev < 3 ? 3 + 2 * lev : 7);
       sp_update_jobs(W, lev);
       QPC_SP_SYNC
+      QPC_SP_STAMP(W, lev < 3 ? 4 + 2 * lev : 8);
     }
   }
-  QPC_SP_STAMP(W, 3);
   QPC_SP_FOR(p2, mi) {
     W.a0[p2] = W.V[W.Cb + sp_sidx(mi, p2, W.M1)];
     double w = 0.0;
@@ -706,7 +958,7 @@ QPC_FN int qp_solve_sp(const int *plan_g, const int *plan_lds, const double *Pv,
   int status = (int)W.sc[SPS_STATUS];
   const int iters = (int)W.sc[SPS_ITERS], nw = (int)W.sc[SPS_NW];
   if (status == QPC_WG_FALLBACK) return QPC_WG_FALLBACK;
-  QPC_SP_STAMP(W, 4);
+  QPC_SP_STAMP(W, 9);
   // ---- the multipliers by position: the working rows', then the equality rows' -- L11' yE = D^-1 (zE - (rows of W)' yW)
   double *yp = W.yp;
   {
@@ -721,7 +973,7 @@ QPC_FN int qp_solve_sp(const int *plan_g, const int *plan_lds, const double *Pv,
   QPC_SP_FOR(a, nw) { yp[ne + W.idxW[a]] = W.yw[a]; }
   QPC_SP_SYNC
   sp_back(W, yp);
-  QPC_SP_STAMP(W, 5);
+  QPC_SP_STAMP(W, 10);
   // ---- x = xu - H^-1 A' y, then iterative refinement on the true KKT residuals of the final working set
   QPC_SP_FOR(i, n) { W.tn[i] = sp_col_dot(W, i, yp); }
   QPC_SP_SYNC
@@ -770,8 +1022,8 @@ QPC_FN int qp_solve_sp(const int *plan_g, const int *plan_lds, const double *Pv,
     if (QPC_SP_WAVE == 0) {
       QPC_SP_FOR_LANE(a, nw) { W.tW[a] = W.t[ne + W.idxW[a]]; }
       QPC_SP_WSYNC
-      sp_ldl_forward_wave(W.LW, nw + 1, nw, W.dinvW, W.tW);
-      sp_ldl_back_wave(W.LW, nw + 1, nw, W.dinvW, W.tW, W.dW);
+      sp_tri_forward(W.LW, sp_cols_packed(nw + 1), nw, W.dinvW, W.tW);
+      sp_tri_back(W.LW, sp_cols_packed(nw + 1), nw, W.dinvW, W.tW, W.dW);
     }
     QPC_SP_SYNC
     QPC_SP_FOR(b, mi + 1) { W.t[ne + b] = 0.0; }
@@ -794,7 +1046,7 @@ QPC_FN int qp_solve_sp(const int *plan_g, const int *plan_lds, const double *Pv,
     const double big = sp_reduce_max(a_big, W.red), dbig = sp_reduce_max(a_dbig, W.red);
     if (sweep > 0 && !(dbig > 1e-12 * (1.0 + big))) break;
   }
-  QPC_SP_STAMP(W, 6);
+  QPC_SP_STAMP(W, 11);
   double a_ysc = 1.0, a_qsc = 1.0;
   QPC_SP_FOR(b, m) { a_ysc = QPC_FABS(yp[b]) > a_ysc ? QPC_FABS(yp[b]) : a_ysc; }
   QPC_SP_FOR(i, n) { a_qsc = QPC_FABS(q[i]) > a_qsc ? QPC_FABS(q[i]) : a_qsc; }
@@ -808,7 +1060,7 @@ QPC_FN int qp_solve_sp(const int *plan_g, const int *plan_lds, const double *Pv,
   QPC_SP_FOR(b, m) { y[perm[b]] = yp[b]; }
   QPC_SP_T0 { if (iters_out) iters_out[0] = iters; }
   QPC_SP_SYNC // (the next QP of this workgroup reuses LDS)
-  QPC_SP_STAMP(W, 7);
+  QPC_SP_STAMP(W, 12);
   return status;
 }
 

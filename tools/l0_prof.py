@@ -16,8 +16,8 @@ qpc_pkg.load()
 from qpcontrol_jl_amd import binding  # noqa: E402
 import bench_latency as BL  # noqa: E402
 
-P, q, A, l, u, x, nv = BL.load_l0_fixture()
-for b in (0, 2, 6):  # no working-set change / five sweeps / forty Goldfarb-Idnani steps
+P, q, A, l, u, x, nv = BL.load_l0_fixture(sys.argv[2] if len(sys.argv) > 2 else "diag")
+for b in (() if os.environ.get("QPC_PROF_SKIP_DENSE") else (0, 2, 6)):  # no working-set change / five sweeps / forty Goldfarb-Idnani steps
     for rep in range(2):
         r = binding.qp_solve_batch(P[b], q[b], A[b], l[b], u[b], lib_path=sys.argv[1])
     print("problem", b, "iters", r["iters"], "status", r["status"], flush=True)
