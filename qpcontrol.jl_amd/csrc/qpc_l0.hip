@@ -137,11 +137,15 @@ qpc_qp_sp_kernel(const int *plan, int lds_doubles, long long B, long long nnzP, 
     if (ykeep && s != QPC_WG_FALLBACK) for (int i = threadIdx.x; i < m; i += blockDim.x) ykeep[b * m + i] = y[b * m + i];
 #ifdef QPC_SP_PROF
     if (threadIdx.x == 0 && (b == 0 || (b == 1 && gridDim.x == 1)) && stamps) {
-      // set-up (values, H^-1, xu) | G | front / update of the levels 0, 1, 2 | iterations | equality multipliers | refinement | output
-      static const char *nm[13] = {"", "setup", "G", "F0", "U0", "F1", "U1", "F2", "U2", "iter", "yE", "refine", "out"};
+      // set-up (values, H^-1, xu) | G | fronts of level 0 | its urgent updates | fronts of level 1 beside the other updates | ... | iterations |
+      // equality multipliers | refinement | output
+      static const char *nm[13] = {"", "setup", "G", "F0", "U0u", "F1+U0", "U1u", "F2+U1", "rest", "iter", "yE", "refine", "out"};
       printf("sp_prof (shader clock %.0f MHz) status %d iters %d us:", (double)(clock64() - c0__) / ((double)(wall_clock64() - w0__) * 0.01), s, iters ? iters[b] : -1);
       for (int k = 1; k <= 12; k++) printf(" %s %.1f", nm[k], (double)(stamps[k] - stamps[k - 1]) * 0.01);
       printf(" | total %.1f\n", (double)(stamps[12] - stamps[0]) * 0.01);
+      printf("   refinement: x %.1f, residuals %.1f, right-hand side %.1f, forward %.1f, working rows %.1f, back %.1f, update %.1f, residuals again %.1f us\n",
+             (double)(stamps[15] - stamps[10]) * 0.01, (double)(stamps[16] - stamps[15]) * 0.01, (double)(stamps[17] - stamps[16]) * 0.01, (double)(stamps[18] - stamps[17]) * 0.01,
+             (double)(stamps[19] - stamps[18]) * 0.01, (double)(stamps[20] - stamps[19]) * 0.01, (double)(stamps[21] - stamps[20]) * 0.01, (double)(stamps[22] - stamps[21]) * 0.01);
       printf("   working-set factorizations %llu (rows in all %llu): gather %.1f, panels %.1f, multipliers %.1f, A x %.1f us\n", qpc::qpc_sp_acc[8], qpc::qpc_sp_acc[9],
              (double)qpc::qpc_sp_acc[0] * 0.01, (double)qpc::qpc_sp_acc[1] * 0.01, (double)qpc::qpc_sp_acc[2] * 0.01, (double)qpc::qpc_sp_acc[3] * 0.01);
       for (int k = 0; k < 16; k++) qpc::qpc_sp_acc[k] = 0;
@@ -580,7 +584,7 @@ int32_t qpc_qp_solve(qpc_qp_problem *p, int64_t B, const double *P_vals, const d
     long long grid = B < (long long)p->n_cu * per_cu ? B : (long long)p->n_cu * per_cu;
 #ifdef QPC_SP_PROF
     if (const char *eg = getenv("QPC_L0_GRID")) grid = atoi(eg) > 0 ? atoi(eg) : grid; // (profiling build: several QPs through ONE workgroup)
-    if (!p->d_stamps) { if (hipMalloc(&p->d_stamps, 16 * sizeof(unsigned long long)) != hipSuccess) { (void)hipGetLastError(); p->d_stamps = nullptr; } }
+    if (!p->d_stamps) { if (hipMalloc(&p->d_stamps, 32 * sizeof(unsigned long long)) != hipSuccess) { (void)hipGetLastError(); p->d_stamps = nullptr; } }
 #endif
     hipLaunchKernelGGL(qpc_qp_sp_kernel, dim3((unsigned)grid), dim3(QPC_SP_THREADS), (size_t)lds_bytes, p->stream, (const int *)p->d_plan,
                        p->sp_lds_doubles, (long long)B, nnzP, dPv, dq, dAv, dl, du, st, y0, dx, dy, dst, dit, p->d_ticket, p->d_yprev, p->d_stamps);

@@ -60,7 +60,7 @@
 #define QPC_SP_T0 if (QPC_SP_TID == 0)
 #define QPC_SP_L0 if (QPC_SP_LANE == 0)
 #if defined(QPC_SP_PROF) && defined(__HIP_DEVICE_COMPILE__)
-#define QPC_SP_STAMP(W, k) do { if (threadIdx.x == 0 && (k) < 16) (W).stamps[k] = wall_clock64(); } while (0)
+#define QPC_SP_STAMP(W, k) do { if (threadIdx.x == 0 && (k) < 32) (W).stamps[k] = wall_clock64(); } while (0)
 #else
 #define QPC_SP_STAMP(W, k) do { } while (0)
 #endif
@@ -84,24 +84,12 @@ QPC_FN int sp_cs(int c, int N1) { return c * N1 - (c * (c - 1)) / 2; }      // p
 QPC_FN int sp_sidx(int i, int c, int N1) { return sp_cs(c, N1) + i - c; }    // i >= c
 QPC_FN int sp_sym(int a, int b, int N1) { return a >= b ? sp_sidx(a, b, N1) : sp_sidx(b, a, N1); }
 
-// max over the workgroup (every thread gets it); red: QPC_SP_NWAVE doubles of LDS.  A NaN wins.
+// reductions over one wavefront (every lane gets the result; all 64 lanes active): DPP row shifts (qpc_device.h) -- a __shfl_xor butterfly
+// is twelve dependent LDS-crossbar round trips for a double
 QPC_FN double sp_wave_max(double v) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(v, off, 64); v = (o > v || !(o == o)) ? o : v; }
-#endif
-  return v;
-}
-QPC_FN double sp_reduce_max(double v, double *red) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  v = sp_wave_max(v);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  double r = red[0];
-  for (int w = 1; w < QPC_SP_NWAVE; w++) { const double o = red[w]; r = (o > r || !(o == o)) ? o : r; }
-  __syncthreads();
-  return r;
+  return qpc::wave_max(v);
 #else
-  (void)red;
   return v;
 #endif
 }
@@ -112,25 +100,46 @@ QPC_FN bool sp_wave_any(bool f) {
   return f;
 #endif
 }
-// the lane holding the largest v (ties: the smallest idx); idx < 0: no candidate.  Every lane gets (v, idx).
+// the candidate (idx >= 0) with the largest v, ties to the smallest idx; idx < 0: no candidate.  Every lane gets (v, idx).
 QPC_FN void sp_wave_argmax(double &v, int &idx) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  for (int off = 32; off > 0; off >>= 1) {
-    const double ov = __shfl_xor(v, off, 64);
-    const int oi = __shfl_xor(idx, off, 64);
-    const bool take = oi >= 0 && (idx < 0 || ov > v || (ov == v && oi < idx));
-    v = take ? ov : v; idx = take ? oi : idx;
-  }
+  const double m = qpc::wave_max(idx >= 0 ? v : -1e308);
+  const int i = qpc::wave_min_int((idx >= 0 && v == m) ? idx : 0x7fffffff);
+  v = m; idx = i == 0x7fffffff ? -1 : i;
 #endif
 }
 QPC_FN void sp_wave_argmin(double &v, int &idx) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  for (int off = 32; off > 0; off >>= 1) {
-    const double ov = __shfl_xor(v, off, 64);
-    const int oi = __shfl_xor(idx, off, 64);
-    const bool take = oi >= 0 && (idx < 0 || ov < v || (ov == v && oi < idx));
-    v = take ? ov : v; idx = take ? oi : idx;
+  const double m = qpc::wave_min(idx >= 0 ? v : 1e308);
+  const int i = qpc::wave_min_int((idx >= 0 && v == m) ? idx : 0x7fffffff);
+  v = m; idx = i == 0x7fffffff ? -1 : i;
+#endif
+}
+// max over the workgroup of N per-thread values at once (every thread gets them); red: N * QPC_SP_NWAVE doubles of LDS.  A NaN counts
+// as +infinity (the callers test for "not finite").  Two barriers whatever N.
+template <int N>
+QPC_FN void sp_reduce_max(double (&v)[N], double *red) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    const double x = v[k] == v[k] ? v[k] : __builtin_inf();
+    v[k] = qpc::wave_max(x);
   }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < N; k++) red[(threadIdx.x >> 6) * N + k] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    double r = red[k];
+    for (int w = 1; w < QPC_SP_NWAVE; w++) { const double o = red[w * N + k]; r = o > r ? o : r; }
+    v[k] = r;
+  }
+  __syncthreads();
+#else
+  (void)red;
+  for (int k = 0; k < N; k++) v[k] = v[k] == v[k] ? v[k] : __builtin_inf();
 #endif
 }
 
@@ -143,6 +152,7 @@ struct QpSp {
   double *sc, *red;
   double *V;                               // the value store: fronts, then C
   double *dinv, *gdiag, *t, *yp;           // by position: ne, m + 1, m + 1, m + 1
+  double *zs, *part, *part2;               // ne: the scaled solution of a forward solve; the sparse products' segment sums (two products in flight)
   double *hv, *hm;                         // values of H^-1 and of P, block by block
   double *xu, *x, *r1, *tn;                // n
   double *lo, *hi, *wsf, *tm, *ax, *a0;    // mi
@@ -162,7 +172,7 @@ __host__ __device__
 #endif
 inline int qp_sp_lds_doubles(const int *plan, int kw) {
   const int n = plan[SP_N], m = plan[SP_M], ne = plan[SP_NE], mi = plan[SP_MI];
-  return (plan[SP_LDS_INTS] + 1) / 2 + 16 + 8 + plan[SP_NVAL] + ne + 3 * (m + 1) + 2 * plan[SP_NHV] + 4 * n + 6 * mi + 4 * (kw + 1) + (kw + 2) / 2 +
+  return (plan[SP_LDS_INTS] + 1) / 2 + 16 + 32 + plan[SP_NVAL] + 2 * ne + 2 * plan[SP_MAXSEG] + 3 * (m + 1) + 2 * plan[SP_NHV] + 4 * n + 6 * mi + 4 * (kw + 1) + (kw + 2) / 2 +
          (kw + 1) * (kw + 2) / 2 + plan[SP_NNZA] + 2;
 }
 
@@ -271,6 +281,9 @@ QPC_FN void sp_ldl_panels(double *S, const SpCols C, int nr, int nc, const doubl
 //      latency of their dependent loads (~60 ns each), several per pivot.  Straight-line code for KR = 8, 16, 24, 32 columns, NO
 //      conditions inside: the columns beyond the real ones are zero, their pivots fail the test and drop out like dependent rows do
 //      (a skipped block costs a taken branch, measured at ~40 ns -- more than the block).
+// (the routines below are not inlined -- a register allocation of their own --, so their pointers say that they point into LDS: a plain
+//  pointer argument is a generic one, and its loads are flat_load instructions with the latency of global memory)
+#define QPC_LDS __attribute__((address_space(3)))
 QPC_FN double sp_readlane(double v, int lane) { // (lane: a constant)
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
@@ -295,7 +308,7 @@ QPC_FN void sp_reg_elim(double (&a)[KR], double (&mul)[KR], bool first, double r
 }
 // (not inlined: a register allocation of its own -- inlined into the kernel the four sizes cost it 1 268 spilled scalar registers)
 template <int KR>
-__device__ __attribute__((noinline)) void sp_front_factor_reg(double *V, int base, int r, int w, const double *ref, double tau, double *dinv) {
+__device__ __attribute__((noinline)) void sp_front_factor_reg(QPC_LDS double *V, int base, int r, int w, QPC_LDS const double *ref, double tau, QPC_LDS double *dinv) {
   const int lane = threadIdx.x & 63;
   double a[KR], mul[KR], dv = 0.0;
   const double refv = lane < w ? ref[lane] : 1.0;
@@ -308,6 +321,39 @@ __device__ __attribute__((noinline)) void sp_front_factor_reg(double *V, int bas
     for (int c = 1; c < KR; c++) { if (c < w && i < r && i >= c) V[base + c * r + i] = a[c]; }
     if (p0 == 0 && lane < w) dinv[lane] = dv;
   }
+}
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(QPC_SP_NO_REG)
+// the small triangular solves of a front's own block (w <= KR columns, a rectangle at base with r rows) in registers: lane c holds
+// row c (forward) or column c (back) of the block, a step is two broadcasts and a multiply-add instead of the LDS round trips of the
+// four-column form.  t: the w values at the front's columns, solved in place.
+template <int KR>
+QPC_FN void sp_front_forward_reg(const double *V, int base, int r, int w, const double *dinv, double *t) {
+  const int lane = threadIdx.x & 63, c = lane < w ? lane : 0;
+  double row[KR];
+#pragma unroll
+  for (int j = 0; j < KR - 1; j++) { const double v = V[base + (j < w ? j : 0) * r + c]; row[j] = (j < c && lane < w) ? v : 0.0; } // L_cj d_j (unscaled)
+  double tv = lane < w ? t[c] : 0.0;
+  const double dv = lane < w ? dinv[c] : 0.0;
+#pragma unroll
+  for (int j = 0; j < KR - 1; j++) tv -= row[j] * (sp_readlane(tv, j) * sp_readlane(dv, j)); // (rows <= j: row[j] = 0; a column beyond w: dv = 0)
+  if (lane < w) t[c] = tv;
+}
+template <int KR>
+QPC_FN void sp_front_back_reg(const double *V, int base, int r, int w, const double *dinv, double *t) {
+  const int lane = threadIdx.x & 63, c = lane < w ? lane : 0;
+  double col[KR];
+#pragma unroll
+  for (int j = 1; j < KR; j++) { const double v = V[base + c * r + (j < w ? j : 0)]; col[j] = (j > c && j < w && lane < w) ? v : 0.0; } // S_jc
+  double tv = lane < w ? t[c] : 0.0, yv = 0.0;
+  const double dv = lane < w ? dinv[c] : 0.0;
+#pragma unroll
+  for (int j = KR - 1; j >= 0; j--) {
+    const double yj = sp_readlane(tv, j) * sp_readlane(dv, j);
+    yv = lane == j ? yj : yv;
+    if (j > 0) tv -= col[j] * yj;
+  }
+  if (lane < w) t[c] = yv;
 }
 #endif
 // t <- L^-1 t on the leading nc columns (L unit lower: L_ij = S_ij dinv_j), four columns per step: every lane solves the 4 x 4
@@ -376,24 +422,35 @@ QPC_FN void sp_front_factor(double *V, int base, int r, int w, const double *ref
     return;
   }
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(QPC_SP_NO_REG)
-  if (w <= 8) { sp_front_factor_reg<8>(V, base, r, w, ref, tau, dinv); return; }
-  if (w <= 16) { sp_front_factor_reg<16>(V, base, r, w, ref, tau, dinv); return; }
-  if (w <= 24) { sp_front_factor_reg<24>(V, base, r, w, ref, tau, dinv); return; }
-  if (w <= 32) { sp_front_factor_reg<32>(V, base, r, w, ref, tau, dinv); return; }
+  if (w <= 8) { sp_front_factor_reg<8>((QPC_LDS double *)V, base, r, w, (QPC_LDS const double *)ref, tau, (QPC_LDS double *)dinv); return; }
+  if (w <= 12) { sp_front_factor_reg<12>((QPC_LDS double *)V, base, r, w, (QPC_LDS const double *)ref, tau, (QPC_LDS double *)dinv); return; }
+  if (w <= 16) { sp_front_factor_reg<16>((QPC_LDS double *)V, base, r, w, (QPC_LDS const double *)ref, tau, (QPC_LDS double *)dinv); return; }
+  if (w <= 20) { sp_front_factor_reg<20>((QPC_LDS double *)V, base, r, w, (QPC_LDS const double *)ref, tau, (QPC_LDS double *)dinv); return; }
+  if (w <= 24) { sp_front_factor_reg<24>((QPC_LDS double *)V, base, r, w, (QPC_LDS const double *)ref, tau, (QPC_LDS double *)dinv); return; }
+  if (w <= 32) { sp_front_factor_reg<32>((QPC_LDS double *)V, base, r, w, (QPC_LDS const double *)ref, tau, (QPC_LDS double *)dinv); return; }
 #endif
   sp_ldl_panels(V, sp_cols_rect(base, r), r, w, ref, tau, dinv);
 }
 
 // ---- the update jobs of a level: target tile -= sum over its slots of (source column rows) d^-1 (source column rows)'
-QPC_FN void sp_update_jobs(const QpSp &W, int level) {
+// jobs j0 .. j1-1, the wavefronts wave0 .. QPC_SP_NWAVE-1 taking them in turn
+QPC_FN void sp_update_jobs(const QpSp &W, int j0, int j1, int wave0) {
   const int *pl = W.pl;
-  const int j0 = pl[pl[SP_O_JOBLV] + level], j1 = pl[pl[SP_O_JOBLV] + level + 1];
   const int *job = pl + pl[SP_O_JOB], *slot = pl + pl[SP_O_SLOT], *map = pl + pl[SP_O_MAP];
   double *V = W.V;
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef double sp_v4d __attribute__((ext_vector_type(4)));
   const int lane = threadIdx.x & 63, kq = lane >> 4, ll = lane & 15;
-  QPC_SP_FOR_WAVE(jb, j0, j1) {
+  // wave0 > 0: the first wave0 wavefronts are busy with fronts -- the jobs go to the others, and (fewer fronts than SIMDs) not to the
+  // wavefronts that share a SIMD with one of them: a front's elimination is the critical path, alone on its SIMD it issues twice as fast
+  int nwv = 0, mine = -1;
+  for (int w = 0; w < QPC_SP_NWAVE; w++) {
+    const bool elig = w >= wave0 && (wave0 >= 4 || wave0 == 0 || (w & 3) >= wave0);
+    if (w == QPC_SP_WAVE && elig) mine = nwv;
+    nwv += elig ? 1 : 0;
+  }
+  if (nwv == 0) { nwv = 1; mine = QPC_SP_WAVE == QPC_SP_NWAVE - 1 ? 0 : -1; }
+  for (int jb = j0 + mine; mine >= 0 && jb < j1; jb += nwv) {
     const int *J = job + jb * SP_JOB_INTS;
     const int tbase = J[0], tstride = J[1], trows = J[2], tcols = J[3], r0 = J[4], c0 = J[5], s0 = J[6], nch = J[7];
     const int col = c0 + ll, colc = col < tcols ? col : tcols - 1;
@@ -439,54 +496,160 @@ QPC_FN void sp_update_jobs(const QpSp &W, int level) {
 #endif
 }
 
-// ---- triangular solves with the equality rows' factor, front by front.  L is unit lower with L_ij = S_ij dinv_j.
-// t (by position) <- L^-1 t on the equality positions; with_rows: the inequality positions too (t_I -= L_IE z).
-// Barrier-synchronised on entry and on exit.
-QPC_FN void sp_pull(const QpSp &W, int p, double *t) { // t[p] -= sum over the fronts holding position p below their block
-  const int *pl = W.pl;
-  const int *pullptr = pl + pl[SP_O_PULLPTR], *pull = pl + pl[SP_O_PULL], *ft = pl + pl[SP_O_FRONT];
-  double v = t[p];
-  for (int k = pullptr[p]; k < pullptr[p + 1]; k++) {
-    const int *F = ft + pull[2 * k] * SP_FRONT_INTS;
-    const int base = F[0] + pull[2 * k + 1], r = F[1], w = F[2], c0 = F[3];
-    for (int c = 0; c < w; c++) v -= W.V[base + c * r] * (W.dinv[c0 + c] * t[c0 + c]);
+// the solves with a front's own block, in place at its columns (one wavefront)
+QPC_FN void sp_front_forward(const double *V, int base, int r, int w, const double *dinv, double *t) {
+  if (w == 1) return;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(QPC_SP_NO_REG)
+  if (w <= 8) { sp_front_forward_reg<8>(V, base, r, w, dinv, t); return; }
+  if (w <= 16) { sp_front_forward_reg<16>(V, base, r, w, dinv, t); return; }
+  if (w <= 32) { sp_front_forward_reg<32>(V, base, r, w, dinv, t); return; }
+#endif
+  sp_tri_forward(V, sp_cols_rect(base, r), w, dinv, t);
+}
+QPC_FN void sp_front_back(const double *V, int base, int r, int w, const double *dinv, double *y) {
+  if (w == 1) { QPC_SP_L0 { y[0] *= dinv[0]; } return; }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(QPC_SP_NO_REG)
+  if (w <= 8) { sp_front_back_reg<8>(V, base, r, w, dinv, y); return; }
+  if (w <= 16) { sp_front_back_reg<16>(V, base, r, w, dinv, y); return; }
+  if (w <= 32) { sp_front_back_reg<32>(V, base, r, w, dinv, y); return; }
+#endif
+  sp_tri_back(V, sp_cols_rect(base, r), w, dinv, y, y);
+}
+
+// ---- the sparse products (qpc_qp_spview.h): a thread per segment of at most SP_SEG terms, then a thread per target
+struct SpOpView { int nt, nseg; const int *tpos, *sptr, *segs, *terms; };
+QPC_FN SpOpView sp_op(const QpSp &W, int op) {
+  const int *pl = W.pl, *O = pl + pl[SP_O_OPS] + op * SP_OP_INTS, *D = pl + pl[SP_O_OPDATA];
+  SpOpView V;
+  V.nt = O[0]; V.nseg = O[1]; V.tpos = D + O[2]; V.sptr = D + O[3]; V.segs = D + O[4]; V.terms = D + O[5];
+  return V;
+}
+// the segments' sums -> part (a barrier before the targets read them): a segment's packed indices all at once, then all its values
+QPC_FN void sp_op_partials(const QpSp &W, const SpOpView &O, const double *val, const double *vec, double *part) {
+  (void)W;
+  QPC_SP_FOR(sg, O.nseg) {
+    const int t0 = O.segs[sg], t1 = O.segs[sg + 1];
+    int k[SP_SEG];
+#pragma unroll
+    for (int e = 0; e < SP_SEG; e++) k[e] = O.terms[t0 + e < t1 ? t0 + e : t0];
+    double a[SP_SEG], b[SP_SEG];
+#pragma unroll
+    for (int e = 0; e < SP_SEG; e++) { a[e] = val[k[e] >> 9]; b[e] = vec[k[e] & 511]; }
+    double acc = 0.0;
+#pragma unroll
+    for (int e = 0; e < SP_SEG; e++) acc += t0 + e < t1 ? a[e] * b[e] : 0.0;
+    part[sg] = acc;
   }
-  t[p] = v;
+}
+QPC_FN double sp_op_sum(const SpOpView &O, int tg, const double *part) {
+  double s = 0.0;
+  for (int sg = O.sptr[tg]; sg < O.sptr[tg + 1]; sg++) s += part[sg];
+  return s;
+}
+
+// ---- triangular solves with the equality rows' factor, front by front.  L is unit lower with L_ij = S_ij dinv_j.
+// t (by position) <- L^-1 t on the equality positions; with_rows: the inequality positions too (t_I -= L_IE z).  A level's columns
+// first take what the earlier levels' solutions leave in them (a sparse product), then every front solves with its own block.
+// Barrier-synchronised on entry and on exit.
+// the sums of the targets tg0 .. tg0 + w - 1 of a product, by ONE wavefront: a lane per segment, then (after the wavefront's own sync) lane
+// c adds up target tg0 + c.  part: scratch of this wavefront's own (the segments of these targets).
+QPC_FN double sp_op_wave_sums(const SpOpView &O, int tg0, int w, const double *val, const double *vec, double *part) {
+  const int s0 = O.sptr[tg0], s1 = O.sptr[tg0 + w];
+  for (int sg = s0 + QPC_SP_LANE; sg < s1; sg += QPC_SP_NLANE) {
+    const int t0 = O.segs[sg], t1 = O.segs[sg + 1];
+    int k[SP_SEG];
+#pragma unroll
+    for (int e = 0; e < SP_SEG; e++) k[e] = O.terms[t0 + e < t1 ? t0 + e : t0];
+    double a[SP_SEG], b[SP_SEG];
+#pragma unroll
+    for (int e = 0; e < SP_SEG; e++) { a[e] = val[k[e] >> 9]; b[e] = vec[k[e] & 511]; }
+    double acc = 0.0;
+#pragma unroll
+    for (int e = 0; e < SP_SEG; e++) acc += t0 + e < t1 ? a[e] * b[e] : 0.0;
+    part[sg] = acc;
+  }
+  QPC_SP_WSYNC
+  double s = 0.0;
+  if (QPC_SP_LANE < w) s = sp_op_sum(O, tg0 + QPC_SP_LANE, part);
+  return s; // (lane c < w: the sum of target tg0 + c; on the host, w = 1 per call -- see the callers)
+}
+// a single target's sum by one thread (the single-column fronts: a thread each)
+QPC_FN double sp_op_thread_sum(const SpOpView &O, int tg, const double *val, const double *vec) {
+  double s = 0.0;
+  for (int sg = O.sptr[tg]; sg < O.sptr[tg + 1]; sg++) {
+    const int t0 = O.segs[sg], t1 = O.segs[sg + 1];
+    int k[SP_SEG];
+#pragma unroll
+    for (int e = 0; e < SP_SEG; e++) k[e] = O.terms[t0 + e < t1 ? t0 + e : t0];
+    double a[SP_SEG], b[SP_SEG];
+#pragma unroll
+    for (int e = 0; e < SP_SEG; e++) { a[e] = val[k[e] >> 9]; b[e] = vec[k[e] & 511]; }
+    double acc = 0.0;
+#pragma unroll
+    for (int e = 0; e < SP_SEG; e++) acc += t0 + e < t1 ? a[e] * b[e] : 0.0;
+    s += acc;
+  }
+  return s;
 }
 QPC_FN void sp_forward(const QpSp &W, double *t, bool with_rows) {
   const int *pl = W.pl;
   const int *lv = pl + pl[SP_O_LEVEL], *ft = pl + pl[SP_O_FRONT];
   for (int l = 0; l < W.nlevel; l++) {
-    QPC_SP_FOR_WAVE(f, lv[l], lv[l + 1]) {
+    const SpOpView O = sp_op(W, SP_OP_FWD0 + l);
+    QPC_SP_FOR_WAVE(f, lv[2 * l], lv[2 * l + 1]) { // the fronts of several columns: a wavefront each
       const int *F = ft + f * SP_FRONT_INTS;
-      const int base = F[0], r = F[1], w = F[2], c0 = F[3];
-      QPC_SP_FOR_LANE(c, w) { sp_pull(W, c0 + c, t); }
+      const int base = F[0], r = F[1], w = F[2], c0 = F[3], tg0 = F[5];
+      if (l > 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        for (int cb = 0; cb < w; cb += 64) { const int wc = w - cb < 64 ? w - cb : 64; const double sm = sp_op_wave_sums(O, tg0 + cb, wc, W.V, W.zs, W.part); if ((int)(threadIdx.x & 63) < wc) t[c0 + cb + (threadIdx.x & 63)] -= sm; }
+#else
+        for (int c = 0; c < w; c++) t[c0 + c] -= sp_op_wave_sums(O, tg0 + c, 1, W.V, W.zs, W.part);
+#endif
+        QPC_SP_WSYNC
+      }
+      sp_front_forward(W.V, base, r, w, W.dinv + c0, t + c0);
       QPC_SP_WSYNC
-      sp_tri_forward(W.V, sp_cols_rect(base, r), w, W.dinv + c0, t + c0);
+      QPC_SP_FOR_LANE(c, w) { W.zs[c0 + c] = t[c0 + c] * W.dinv[c0 + c]; }
+    }
+    QPC_SP_FOR(e, lv[2 * l + 2] - lv[2 * l + 1]) { // the single columns: a thread each
+      const int *F = ft + (lv[2 * l + 1] + e) * SP_FRONT_INTS;
+      const int c0 = F[3];
+      double v = t[c0];
+      if (l > 0) { v -= sp_op_thread_sum(O, F[5], W.V, W.zs); t[c0] = v; }
+      W.zs[c0] = v * W.dinv[c0];
     }
     QPC_SP_SYNC
   }
   if (with_rows) {
-    QPC_SP_FOR(p, W.mi) { sp_pull(W, W.ne + p, t); }
+    const SpOpView O = sp_op(W, SP_OP_FWDROWS);
+    sp_op_partials(W, O, W.V, W.zs, W.part);
+    QPC_SP_SYNC
+    QPC_SP_FOR(tg, O.nt) { t[O.tpos[tg]] -= sp_op_sum(O, tg, W.part); }
     QPC_SP_SYNC
   }
 }
-// y_E <- L^-T D^-1 z_E - (the rows below)' y, y given on the inequality positions (and 0 at the right-hand-side position); z_E is read
-// from y's equality positions, the result replaces it.  Barrier-synchronised on entry and on exit.
+// y_E <- L^-T D^-1 z_E - (the rows below)' y, y given on the inequality positions; z_E is read from y's equality positions, the
+// result replaces it.  Barrier-synchronised on entry and on exit.
 QPC_FN void sp_back(const QpSp &W, double *y) {
   const int *pl = W.pl;
-  const int *lv = pl + pl[SP_O_LEVEL], *ft = pl + pl[SP_O_FRONT], *rows = pl + pl[SP_O_ROWS];
+  const int *lv = pl + pl[SP_O_LEVEL], *ft = pl + pl[SP_O_FRONT];
   for (int l = W.nlevel - 1; l >= 0; l--) {
-    QPC_SP_FOR_WAVE(f, lv[l], lv[l + 1]) {
+    const SpOpView O = sp_op(W, SP_OP_FWD0 + W.nlevel + l);
+    QPC_SP_FOR_WAVE(f, lv[2 * l], lv[2 * l + 1]) {
       const int *F = ft + f * SP_FRONT_INTS;
-      const int base = F[0], r = F[1], w = F[2], c0 = F[3], *rw = rows + F[4];
-      QPC_SP_FOR_LANE(c, w) {
-        double s = y[c0 + c];
-        for (int i = w; i < r; i++) s -= W.V[base + c * r + i] * y[rw[i]];
-        y[c0 + c] = s;
-      }
+      const int base = F[0], r = F[1], w = F[2], c0 = F[3], tg0 = F[5];
+#if defined(__HIP_DEVICE_COMPILE__)
+      for (int cb = 0; cb < w; cb += 64) { const int wc = w - cb < 64 ? w - cb : 64; const double sm = sp_op_wave_sums(O, tg0 + cb, wc, W.V, y, W.part); if ((int)(threadIdx.x & 63) < wc) y[c0 + cb + (threadIdx.x & 63)] -= sm; }
+#else
+      for (int c = 0; c < w; c++) y[c0 + c] -= sp_op_wave_sums(O, tg0 + c, 1, W.V, y, W.part);
+#endif
       QPC_SP_WSYNC
-      sp_tri_back(W.V, sp_cols_rect(base, r), w, W.dinv + c0, y + c0, y + c0);
+      sp_front_back(W.V, base, r, w, W.dinv + c0, y + c0);
+    }
+    QPC_SP_FOR(e, lv[2 * l + 2] - lv[2 * l + 1]) {
+      const int *F = ft + (lv[2 * l + 1] + e) * SP_FRONT_INTS;
+      const int c0 = F[3];
+      y[c0] = (y[c0] - sp_op_thread_sum(O, F[5], W.V, y)) * W.dinv[c0];
     }
     QPC_SP_SYNC
   }
@@ -495,11 +658,11 @@ QPC_FN void sp_back(const QpSp &W, double *y) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(QPC_SP_NO_REG)
 // the working set's factor in registers (k <= KR <= 32 rows, idxW filled): lane i = row i of C_WW, lane k = the right-hand side.
 // Leaves LW and dinvW in LDS like the panel form (the Goldfarb-Idnani steps and the refinement solve with them) and, with_rhs, yw.
-struct SpWArgs { // (plain pointers: the routine is not inlined)
-  const double *C; int M1;
-  const int *idxW;
-  const double *a0, *wsf, *hi, *lo, *gdiagI;
-  double *tW, *LW, *dinvW, *yw;
+struct SpWArgs { // (the routine is not inlined)
+  QPC_LDS const double *C; int M1;
+  QPC_LDS const int *idxW;
+  QPC_LDS const double *a0, *wsf, *hi, *lo, *gdiagI;
+  QPC_LDS double *tW, *LW, *dinvW, *yw;
 };
 template <int KR>
 __device__ __attribute__((noinline)) void sp_w_factor_reg(const SpWArgs A, int k, double tau, bool with_rhs) {
@@ -567,11 +730,15 @@ QPC_FN int sp_w_factor(QpSp &W, double tau, bool with_rhs) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(QPC_SP_NO_REG)
   if (k <= 32) {
     SpWArgs A;
-    A.C = W.V + W.Cb; A.M1 = W.M1; A.idxW = W.idxW; A.a0 = W.a0; A.wsf = W.wsf; A.hi = W.hi; A.lo = W.lo; A.gdiagI = W.gdiag + W.ne;
-    A.tW = W.tW; A.LW = W.LW; A.dinvW = W.dinvW; A.yw = W.yw;
+    A.C = (QPC_LDS const double *)(W.V + W.Cb); A.M1 = W.M1; A.idxW = (QPC_LDS const int *)W.idxW; A.a0 = (QPC_LDS const double *)W.a0;
+    A.wsf = (QPC_LDS const double *)W.wsf; A.hi = (QPC_LDS const double *)W.hi; A.lo = (QPC_LDS const double *)W.lo; A.gdiagI = (QPC_LDS const double *)(W.gdiag + W.ne);
+    A.tW = (QPC_LDS double *)W.tW; A.LW = (QPC_LDS double *)W.LW; A.dinvW = (QPC_LDS double *)W.dinvW; A.yw = (QPC_LDS double *)W.yw;
     if (k <= 8) sp_w_factor_reg<8>(A, k, tau, with_rhs);
+    else if (k <= 12) sp_w_factor_reg<12>(A, k, tau, with_rhs);
     else if (k <= 16) sp_w_factor_reg<16>(A, k, tau, with_rhs);
+    else if (k <= 20) sp_w_factor_reg<20>(A, k, tau, with_rhs);
     else if (k <= 24) sp_w_factor_reg<24>(A, k, tau, with_rhs);
+    else if (k <= 28) sp_w_factor_reg<28>(A, k, tau, with_rhs);
     else sp_w_factor_reg<32>(A, k, tau, with_rhs);
     QPC_SP_ACC(1);
     return k;
@@ -778,18 +945,6 @@ QPC_FN void sp_iterate(QpSp &W, const qpc_settings &st, double bscale) {
 }
 
 // ---- products with A, H, H^-1 (A's compressed columns / rows by position and the blocks' rows from the plan in LDS)
-QPC_FN double sp_col_dot(const QpSp &W, int c, const double *ypos) { // (A' y)_c, y by position
-  const int *cptr = W.pl + W.pl[SP_O_CPTR], *crow = W.pl + W.pl[SP_O_CROW];
-  double t = 0.0;
-  for (int o = cptr[c]; o < cptr[c + 1]; o++) t += W.sval[o] * ypos[crow[o]];
-  return t;
-}
-QPC_FN double sp_row_dot(const QpSp &W, int pos, const double *w) { // (A w) at a position
-  const int *rptr = W.pl + W.pl[SP_O_RPTR], *rcol = W.pl + W.pl[SP_O_RCOL], *ro = W.pl + W.pl[SP_O_RO];
-  double t = 0.0;
-  for (int k = rptr[pos]; k < rptr[pos + 1]; k++) t += W.sval[ro[k]] * w[rcol[k]];
-  return t;
-}
 QPC_FN double sp_h_dot(const QpSp &W, const double *hvals, int i, const double *v) { // (row i of the block matrix) . v
   const int *hptr = W.pl + W.pl[SP_O_HPTR], *hcol = W.pl + W.pl[SP_O_HCOL], *hidx = W.pl + W.pl[SP_O_HIDX];
   double t = 0.0;
@@ -818,9 +973,10 @@ QPC_FN int qp_solve_sp(const int *plan_g, const int *plan_lds, const double *Pv,
   W.Pv = Pv; W.q = q; W.Av = Av; W.l = l; W.u = u; W.y0 = y0; W.stamps = stamps;
   QPC_SP_STAMP(W, 0);
   double *p = lds;
-  W.sc = p; p += 16; W.red = p; p += 8;
+  W.sc = p; p += 16; W.red = p; p += 32;
   W.V = p; p += nval;
   W.dinv = p; p += ne; W.gdiag = p; p += m + 1; W.t = p; p += m + 1; W.yp = p; p += m + 1;
+  W.zs = p; p += ne; W.part = p; p += pl[SP_MAXSEG]; W.part2 = p; p += pl[SP_MAXSEG];
   W.hv = p; p += nhv; W.hm = p; p += nhv;
   W.xu = p; p += n; W.x = p; p += n; W.r1 = p; p += n; W.tn = p; p += n;
   W.lo = p; p += mi; W.hi = p; p += mi; W.wsf = p; p += mi; W.tm = p; p += mi; W.ax = p; p += mi; W.a0 = p; p += mi;
@@ -836,10 +992,7 @@ QPC_FN int qp_solve_sp(const int *plan_g, const int *plan_lds, const double *Pv,
   const int *perm = pl + pl[SP_O_PERM], *ipos = pl + pl[SP_O_IPOS];
   // ---- the values; the rows' kinds against the plan's; scales
   QPC_SP_T0 { for (int i = 0; i < SPS_COUNT; i++) W.sc[i] = 0.0; }
-  {
-    const int *cperm = plan_g + pl[SP_O_CPERM];
-    QPC_SP_FOR(o, nnzA) { W.sval[o] = Av[cperm[o]]; }
-  }
+  QPC_SP_FOR(o, nnzA) { W.sval[o] = Av[o]; } // (the plan's tables index the caller's order)
   {
     const int *hptr = pl + pl[SP_O_HPTR], *hidx = pl + pl[SP_O_HIDX], *pidx = pl + pl[SP_O_PIDX];
     QPC_SP_FOR(i, n) {
@@ -866,8 +1019,10 @@ QPC_FN int qp_solve_sp(const int *plan_g, const int *plan_lds, const double *Pv,
       for (int k = hptr[i]; k < hptr[i + 1]; k++) if (hcol[k] == i) { const double a = QPC_FABS(W.hm[hidx[k]]); a_h = a > a_h ? a : a_h; }
     }
   }
-  const double bscale = sp_reduce_max(a_b, W.red), hmax = sp_reduce_max(a_h, W.red);
-  if (sp_reduce_max(mismatch ? 1.0 : 0.0, W.red) != 0.0) return QPC_WG_FALLBACK;
+  double red3[3] = {a_b, a_h, mismatch ? 1.0 : 0.0};
+  sp_reduce_max<3>(red3, W.red);
+  const double bscale = red3[0], hmax = red3[1];
+  if (red3[2] != 0.0) return QPC_WG_FALLBACK;
   const double eps = st.eps_primal_reg * (hmax > 0.0 ? hmax : 1.0);
   // ---- H^-1, block by block: a single variable by a division, a block by Gauss-Jordan sweeps of one wavefront (lane = entry)
   {
@@ -901,21 +1056,46 @@ QPC_FN int qp_solve_sp(const int *plan_g, const int *plan_lds, const double *Pv,
   QPC_SP_SYNC
   QPC_SP_FOR(i, n) { W.xu[i] = sp_h_dot(W, W.hv, i, W.tn); }
   QPC_SP_STAMP(W, 1);
-  // ---- S = [G ; rhs'] into the store: a thread per structural entry of G, its products in the order the host laid down
+  // ---- S = [G ; rhs'] into the store: a thread per SEGMENT (at most SP_SEG products) of a structural entry of G, its products in the
+  //      order the host laid down; an entry with several segments is summed from their sums afterwards.  The term lists stream from
+  //      global memory: a segment's are loaded up front, eight at a time.
   {
-    const int npair = pl[SP_NPAIR];
-    const int *pair = plan_g + pl[SP_O_PAIR], *term = plan_g + pl[SP_O_TERM];
-    QPC_SP_FOR(pi, npair) {
-      const int t0 = pi > 0 ? pair[2 * pi - 1] : 0, t1 = pair[2 * pi + 1];
+    const int ngseg = pl[SP_NGSEG];
+    const int *gseg = plan_g + pl[SP_O_GSEG], *term = plan_g + pl[SP_O_TERM];
+    QPC_SP_FOR(sg, ngseg) {
+      const int dst = gseg[2 * sg], t0 = gseg[2 * sg + 1], t1 = gseg[2 * sg + 3];
       double acc = 0.0;
-      for (int t = t0; t < t1; t++) acc += W.sval[term[3 * t]] * W.sval[term[3 * t + 1]] * W.hv[term[3 * t + 2]];
-      W.V[pair[2 * pi]] = acc;
+      for (int t = t0; t < t1; t += 8) {
+        int ka[8], kh[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) { const int tt = t + e < t1 ? t + e : t0; ka[e] = term[2 * tt]; kh[e] = term[2 * tt + 1]; }
+        double a[8], b[8], h[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) { a[e] = W.sval[ka[e] & 0xffff]; b[e] = W.sval[(ka[e] >> 16) & 0xffff]; h[e] = W.hv[kh[e]]; }
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc += t + e < t1 ? a[e] * b[e] * h[e] : 0.0;
+      }
+      if (dst >= 0) W.V[dst] = acc; else W.part[-dst - 1] = acc;
     }
   }
   QPC_SP_SYNC // (xu complete)
   {
+    const int ngsum = pl[SP_NGSUM];
+    const int *gsum = plan_g + pl[SP_O_GSUM];
+    QPC_SP_FOR(e, ngsum) {
+      double acc = 0.0;
+      for (int k = gsum[3 * e + 1]; k < gsum[3 * e + 2]; k++) acc += W.part[k];
+      W.V[gsum[3 * e]] = acc;
+    }
+  }
+  QPC_SP_SYNC // (the segments' sums are used up: the products below reuse the array)
+  const SpOpView Orow = sp_op(W, SP_OP_ROWDOT);
+  const SpOpView Ocol = sp_op(W, SP_OP_COLDOT);
+  sp_op_partials(W, Orow, W.sval, W.xu, W.part);
+  QPC_SP_SYNC
+  {
     const int *rtaddr = plan_g + pl[SP_O_RTADDR];
-    QPC_SP_FOR(pos, m) { W.V[rtaddr[pos]] = sp_row_dot(W, pos, W.xu) - (pos < ne ? l[perm[pos]] : 0.0); }
+    QPC_SP_FOR(pos, m) { W.V[rtaddr[pos]] = sp_op_sum(Orow, pos, W.part) - (pos < ne ? l[perm[pos]] : 0.0); }
   }
   QPC_SP_SYNC
   {
@@ -927,19 +1107,34 @@ QPC_FN int qp_solve_sp(const int *plan_g, const int *plan_lds, const double *Pv,
   }
   QPC_SP_SYNC
   QPC_SP_STAMP(W, 2);
-  // ---- the elimination, level by level
+  // ---- the elimination, level by level: a level's fronts (a wavefront each), then their updates of later fronts and of C (tile
+  //      jobs).  Only the jobs into the NEXT level's fronts have somebody waiting: the others run beside those fronts, on the
+  //      wavefronts the fronts leave free (when the level has fewer fronts than the workgroup wavefronts).
   {
-    const int *lv = pl + pl[SP_O_LEVEL], *ft = pl + pl[SP_O_FRONT];
-    for (int lev = 0; lev < W.nlevel; lev++) {
-      QPC_SP_FOR_WAVE(f, lv[lev], lv[lev + 1]) {
+    const int *lv = pl + pl[SP_O_LEVEL], *ft = pl + pl[SP_O_FRONT], *jl = pl + pl[SP_O_JOBLV];
+    auto fronts = [&](int lev) {
+      QPC_SP_FOR_WAVE(f, lv[2 * lev], lv[2 * lev + 1]) {
         const int *F = ft + f * SP_FRONT_INTS;
         sp_front_factor(W.V, F[0], F[1], F[2], W.gdiag + F[3], st.eps_dual_reg, W.dinv + F[3]);
       }
+      QPC_SP_FOR(e, lv[2 * lev + 2] - lv[2 * lev + 1]) { // a single column: its pivot, nothing else (the rows below keep L D); a thread each
+        const int *F = ft + (lv[2 * lev + 1] + e) * SP_FRONT_INTS;
+        const double d = W.V[F[0]], rf = W.gdiag[F[3]];
+        W.dinv[F[3]] = d > st.eps_dual_reg * (rf > 1e-300 ? rf : 1e-300) ? 1.0 / d : 0.0;
+      }
+    };
+    if (W.nlevel > 0) fronts(0);
+    QPC_SP_SYNC
+    QPC_SP_STAMP(W, 3);
+    for (int lev = 0; lev < W.nlevel; lev++) {
+      sp_update_jobs(W, jl[2 * lev], jl[2 * lev + 1], 0);
       QPC_SP_SYNC
-      QPC_SP_STAMP(W, lev < 3 ? 3 + 2 * lev : 7);
-      sp_update_jobs(W, lev);
+      QPC_SP_STAMP(W, lev < 2 ? 4 + 2 * lev : 8);
+      const int nf = lev + 1 < W.nlevel ? lv[2 * lev + 3] - lv[2 * lev + 2] : 0; // (the next level's fronts of several columns: its single columns cost nothing)
+      if (nf > 0) fronts(lev + 1);
+      sp_update_jobs(W, jl[2 * lev + 1], jl[2 * lev + 2], nf < QPC_SP_NWAVE ? nf : 0);
       QPC_SP_SYNC
-      QPC_SP_STAMP(W, lev < 3 ? 4 + 2 * lev : 8);
+      QPC_SP_STAMP(W, lev < 2 ? 5 + 2 * lev : 8);
     }
   }
   QPC_SP_FOR(p2, mi) {
@@ -975,15 +1170,21 @@ QPC_FN int qp_solve_sp(const int *plan_g, const int *plan_lds, const double *Pv,
   sp_back(W, yp);
   QPC_SP_STAMP(W, 10);
   // ---- x = xu - H^-1 A' y, then iterative refinement on the true KKT residuals of the final working set
-  QPC_SP_FOR(i, n) { W.tn[i] = sp_col_dot(W, i, yp); }
+  sp_op_partials(W, Ocol, W.sval, yp, W.part2);
+  QPC_SP_SYNC
+  QPC_SP_FOR(i, n) { W.tn[i] = sp_op_sum(Ocol, i, W.part2); } // A' y: kept in tn for the first residual
   QPC_SP_SYNC
   QPC_SP_FOR(i, n) { W.x[i] = W.xu[i] - sp_h_dot(W, W.hv, i, W.tn); }
   QPC_SP_SYNC
+  QPC_SP_STAMP(W, 15);
   double rp = 0.0, rs = 0.0;
   for (int sweep = 0; sweep <= st.max_refine_iters; sweep++) {
     double a_rs = 0.0, a_rp = 0.0, a_ss = 1.0, a_ps = 1.0;
+    sp_op_partials(W, Ocol, W.sval, yp, W.part2);
+    sp_op_partials(W, Orow, W.sval, W.x, W.part);
+    QPC_SP_SYNC
     QPC_SP_FOR(i, n) { // r1 = -(q + P x + A' y)
-      const double aty = sp_col_dot(W, i, yp), qi = q[i];
+      const double aty = sp_op_sum(Ocol, i, W.part2), qi = q[i];
       const double t = qi + sp_h_dot(W, W.hm, i, W.x) + aty;
       W.r1[i] = -t;
       a_rs = (QPC_FABS(t) > a_rs || !(t == t)) ? QPC_FABS(t) : a_rs;
@@ -995,44 +1196,52 @@ QPC_FN int qp_solve_sp(const int *plan_g, const int *plan_lds, const double *Pv,
       double t = 0.0;
       if (b < m && (b < ne || W.wsf[p2] != 0.0)) {
         const double bw = b < ne ? l[perm[b]] : (W.wsf[p2] > 0.0 ? W.hi[p2] : W.lo[p2]);
-        t = bw - sp_row_dot(W, b, W.x);
+        t = bw - sp_op_sum(Orow, b, W.part);
         a_rp = (QPC_FABS(t) > a_rp || !(t == t)) ? QPC_FABS(t) : a_rp;
         a_ps = QPC_FABS(bw) > a_ps ? QPC_FABS(bw) : a_ps;
       }
       W.t[b] = t;
     }
     QPC_SP_SYNC
-    rs = sp_reduce_max(a_rs, W.red);
-    rp = sp_reduce_max(a_rp, W.red);
+    double red4[4] = {a_rs, a_rp, a_ss, a_ps};
+    sp_reduce_max<4>(red4, W.red);
+    rs = red4[0]; rp = red4[1];
+    QPC_SP_STAMP(W, sweep == 0 ? 16 : 22);
     if (sweep == st.max_refine_iters) break;
-    if (sweep > 0) {
-      const double ss = sp_reduce_max(a_ss, W.red), ps = sp_reduce_max(a_ps, W.red);
-      if (rs <= 1e-12 * ss && rp <= 1e-12 * ps) break;
-    }
+    // after a correction: residuals at the rounding floor of their own scales (|q|, |A'y|; the working rows' bounds) -- another
+    // correction would change nothing that 1e-8 can see (the eps bias of the first solve is 1e-6: one correction takes it to 1e-12)
+    if (sweep > 0 && rs <= 1e-12 * red4[2] && rp <= 1e-12 * red4[3]) break;
     // dy = K^-1 (A_W H^-1 r1 - r2) ; dx = H^-1 (r1 - A_W' dy)
     QPC_SP_FOR(i, n) { W.xu[i] = sp_h_dot(W, W.hv, i, W.r1); } // xu is free from here on: H^-1 r1
     QPC_SP_SYNC
+    sp_op_partials(W, Orow, W.sval, W.xu, W.part);
+    QPC_SP_SYNC
     QPC_SP_FOR(b, m) {
       const int p2 = b - ne;
-      if (b < ne || W.wsf[p2] != 0.0) W.t[b] = sp_row_dot(W, b, W.xu) - W.t[b];
+      if (b < ne || W.wsf[p2] != 0.0) W.t[b] = sp_op_sum(Orow, b, W.part) - W.t[b];
     }
     QPC_SP_SYNC
     // K on (E, W): forward through the fronts (the working rows pulled along), the working set's factor, back through the fronts
+    if (sweep == 0) QPC_SP_STAMP(W, 17);
     sp_forward(W, W.t, true);
-    if (QPC_SP_WAVE == 0) {
+    if (sweep == 0) QPC_SP_STAMP(W, 18);
+    if (QPC_SP_WAVE == 0) { // the working rows' block, then dy on the inequality positions: the working rows' solution, 0 elsewhere
       QPC_SP_FOR_LANE(a, nw) { W.tW[a] = W.t[ne + W.idxW[a]]; }
       QPC_SP_WSYNC
       sp_tri_forward(W.LW, sp_cols_packed(nw + 1), nw, W.dinvW, W.tW);
       sp_tri_back(W.LW, sp_cols_packed(nw + 1), nw, W.dinvW, W.tW, W.dW);
+      QPC_SP_FOR_LANE(b, mi + 1) { W.t[ne + b] = 0.0; }
+      QPC_SP_WSYNC
+      QPC_SP_FOR_LANE(a, nw) { W.t[ne + W.idxW[a]] = W.dW[a]; }
     }
     QPC_SP_SYNC
-    QPC_SP_FOR(b, mi + 1) { W.t[ne + b] = 0.0; }
-    QPC_SP_SYNC
-    QPC_SP_FOR(a, nw) { W.t[ne + W.idxW[a]] = W.dW[a]; }
-    QPC_SP_SYNC
+    if (sweep == 0) QPC_SP_STAMP(W, 19);
     sp_back(W, W.t); // W.t: dy by position
+    if (sweep == 0) QPC_SP_STAMP(W, 20);
     double a_big = 0.0, a_dbig = 0.0;
-    QPC_SP_FOR(i, n) { W.tn[i] = W.r1[i] - sp_col_dot(W, i, W.t); }
+    sp_op_partials(W, Ocol, W.sval, W.t, W.part2);
+    QPC_SP_SYNC
+    QPC_SP_FOR(i, n) { W.tn[i] = W.r1[i] - sp_op_sum(Ocol, i, W.part2); }
     QPC_SP_SYNC
     QPC_SP_FOR(i, n) {
       const double dx = sp_h_dot(W, W.hv, i, W.tn);
@@ -1043,16 +1252,20 @@ QPC_FN int qp_solve_sp(const int *plan_g, const int *plan_lds, const double *Pv,
     }
     QPC_SP_FOR(b, m) { yp[b] += W.t[b]; }
     QPC_SP_SYNC
-    const double big = sp_reduce_max(a_big, W.red), dbig = sp_reduce_max(a_dbig, W.red);
-    if (sweep > 0 && !(dbig > 1e-12 * (1.0 + big))) break;
+    double red2[2] = {a_big, a_dbig};
+    sp_reduce_max<2>(red2, W.red);
+    if (sweep == 0) QPC_SP_STAMP(W, 21);
+    if (sweep > 0 && !(red2[1] > 1e-12 * (1.0 + red2[0]))) break;
   }
   QPC_SP_STAMP(W, 11);
   double a_ysc = 1.0, a_qsc = 1.0;
   QPC_SP_FOR(b, m) { a_ysc = QPC_FABS(yp[b]) > a_ysc ? QPC_FABS(yp[b]) : a_ysc; }
   QPC_SP_FOR(i, n) { a_qsc = QPC_FABS(q[i]) > a_qsc ? QPC_FABS(q[i]) : a_qsc; }
-  const double ysc = sp_reduce_max(a_ysc, W.red), qsc = sp_reduce_max(a_qsc, W.red);
+  double redq[2] = {a_ysc, a_qsc};
+  sp_reduce_max<2>(redq, W.red);
+  const double ysc = redq[0], qsc = redq[1];
   if (status == QPC_STATUS_OPTIMAL) {
-    if (!(rp == rp) || !(rs == rs)) status = QPC_STATUS_NUMERICAL_ERROR;
+    if (!(rp < 1e300) || !(rs < 1e300)) status = QPC_STATUS_NUMERICAL_ERROR; // (a NaN residual was reduced as +infinity)
     else if (rp > 1e-7 * bscale) status = QPC_STATUS_INFEASIBLE;
     else if (rs > 1e-7 * (ysc > qsc ? ysc : qsc)) status = QPC_STATUS_ALMOST_OPTIMAL;
   }

@@ -221,7 +221,11 @@ inline bool qp_sp_plan_build(const QpPrepHost &H, const uint8_t *eq, QpSpPlanHos
   for (auto &f : fr) nlevel = std::max(nlevel, f.level + 1);
   std::vector<int> forder(nfront);
   std::iota(forder.begin(), forder.end(), 0);
-  std::stable_sort(forder.begin(), forder.end(), [&](int a, int b) { return fr[a].level != fr[b].level ? fr[a].level < fr[b].level : fr[a].nnz() * fr[a].w > fr[b].nnz() * fr[b].w; });
+  std::stable_sort(forder.begin(), forder.end(), [&](int a, int b) { // by level; the wide fronts first, the costly ones first; single columns last
+    if (fr[a].level != fr[b].level) return fr[a].level < fr[b].level;
+    if ((fr[a].w == 1) != (fr[b].w == 1)) return fr[b].w == 1;
+    return fr[a].nnz() * fr[a].w > fr[b].nnz() * fr[b].w;
+  });
   { // renumber the fronts by (level, cost descending)
     std::vector<Front> g(nfront);
     std::vector<int> newid(nfront);
@@ -251,7 +255,7 @@ inline bool qp_sp_plan_build(const QpPrepHost &H, const uint8_t *eq, QpSpPlanHos
     return lr < 0 ? -1 : f.base + (pc - f.c0) * f.r() + lr;
   };
   // ---- update jobs: target tiles, each with the source columns (slots) it sums over, in a fixed order
-  struct Job { int tbase, tstride, trows, tcols, r0, c0; std::vector<int> srcs; std::vector<std::vector<int>> maps; long long cost = 0; };
+  struct Job { int tbase, tstride, trows, tcols, r0, c0; std::vector<int> srcs; std::vector<std::vector<int>> maps; long long cost = 0; bool urgent = false; };
   std::vector<std::vector<Job>> jobs(nlevel);
   for (int l = 0; l < nlevel; l++) {
     std::map<std::tuple<int, int, int>, int> index; // (target, tile row, tile column) -> job
@@ -270,7 +274,7 @@ inline bool qp_sp_plan_build(const QpPrepHost &H, const uint8_t *eq, QpSpPlanHos
           auto it = index.find(key);
           if (it == index.end()) {
             Job J;
-            if (tg >= 0) { J.tbase = fr[tg].base; J.tstride = fr[tg].r(); J.trows = fr[tg].r(); J.tcols = fr[tg].w; }
+            if (tg >= 0) { J.tbase = fr[tg].base; J.tstride = fr[tg].r(); J.trows = fr[tg].r(); J.tcols = fr[tg].w; J.urgent = fr[tg].level == l + 1; }
             else { J.tbase = Cb; J.tstride = 0; J.trows = M1; J.tcols = M1; }
             J.r0 = 16 * (lr / 16); J.c0 = 16 * (lc / 16);
             it = index.emplace(key, (int)jobs[l].size()).first;
@@ -284,17 +288,62 @@ inline bool qp_sp_plan_build(const QpPrepHost &H, const uint8_t *eq, QpSpPlanHos
       }
     }
     for (auto &J : jobs[l]) for (int f : J.srcs) J.cost += (fr[f].w + 3) / 4;
-    std::stable_sort(jobs[l].begin(), jobs[l].end(), [](const Job &a, const Job &b) { return a.cost > b.cost; });
+    // the jobs into the NEXT level's fronts first (those fronts wait for them; the others run beside them), the long ones first
+    std::stable_sort(jobs[l].begin(), jobs[l].end(), [](const Job &a, const Job &b) { return a.urgent != b.urgent ? a.urgent : a.cost > b.cost; });
   }
-  // ---- for a position: the fronts that hold it among their rows below (the triangular solves pull along these)
-  std::vector<int> pullptr(N1 + 1, 0), pull;
-  for (int p = 0; p < N1; p++) {
+  // ---- the sparse products of the solves (qpc_qp_spview.h): targets with their terms, cut into segments
+  struct Op { std::vector<int> tpos; std::vector<std::vector<int>> terms; };
+  auto pack = [](int addr, int idx) { return (addr << 9) | idx; };
+  if (nval >= (1 << 22) || N1 > 511 || nnzA >= (1 << 22)) return fail("too large for the packed terms");
+  std::vector<Op> ops(SP_OP_FWD0 + 2 * nlevel);
+  for (int p = 0; p < m; p++) { // A w by row position
+    const int r = perm[p];
+    std::vector<int> t;
+    for (int k = rptr[r]; k < rptr[r + 1]; k++) t.push_back(pack(cperm[ro[k]], rcol[k])); // (values are indexed in the CALLER's order: no permutation in the kernel)
+    ops[SP_OP_ROWDOT].tpos.push_back(p); ops[SP_OP_ROWDOT].terms.push_back(t);
+  }
+  for (int c = 0; c < n; c++) { // A' y by column: (value, row position)
+    std::vector<int> t;
+    for (int o = cptr[c]; o < cptr[c + 1]; o++) t.push_back(pack(cperm[o], ipos[crow[o]]));
+    ops[SP_OP_COLDOT].tpos.push_back(c); ops[SP_OP_COLDOT].terms.push_back(t);
+  }
+  auto below_terms_of_row = [&](int p) { // the entries of L in row p left of its own front: (address, column position), fronts in order
+    std::vector<int> t;
     for (int f = 0; f < nfront; f++) {
       if (p >= fr[f].c0 && p < fr[f].c0 + fr[f].w) continue;
       const int lr = f_local(fr[f], p);
-      if (lr >= 0) { pull.push_back(f); pull.push_back(lr); }
+      if (lr >= 0) for (int c = 0; c < fr[f].w; c++) t.push_back(pack(fr[f].base + c * fr[f].r() + lr, fr[f].c0 + c));
     }
-    pullptr[p + 1] = (int)pull.size() / 2;
+    return t;
+  };
+  for (int p = ne; p < m; p++) { ops[SP_OP_FWDROWS].tpos.push_back(p); ops[SP_OP_FWDROWS].terms.push_back(below_terms_of_row(p)); }
+  for (int l = 0; l < nlevel; l++)
+    for (int f = level_ptr[l]; f < level_ptr[l + 1]; f++)
+      for (int c = 0; c < fr[f].w; c++) {
+        const int p = fr[f].c0 + c;
+        Op &F = ops[SP_OP_FWD0 + l], &B = ops[SP_OP_FWD0 + nlevel + l];
+        F.tpos.push_back(p); F.terms.push_back(below_terms_of_row(p));
+        std::vector<int> t; // the column's entries below its front's block: (address, row position)
+        for (int i = fr[f].w; i < fr[f].r(); i++) if (fr[f].rows[i] < m) t.push_back(pack(fr[f].base + c * fr[f].r() + i, fr[f].rows[i])); // (the right-hand-side row is no unknown)
+        B.tpos.push_back(p); B.terms.push_back(t);
+      }
+  std::vector<int> optab, opdata;
+  int maxseg = 1;
+  for (auto &O : ops) {
+    const int nt = (int)O.tpos.size();
+    std::vector<int> sptr(1, 0), segs(1, 0), terms;
+    for (int t = 0; t < nt; t++) {
+      const int len = (int)O.terms[t].size();
+      for (int k = 0; k < len; k += SP_SEG) { terms.insert(terms.end(), O.terms[t].begin() + k, O.terms[t].begin() + std::min(len, k + SP_SEG)); segs.push_back((int)terms.size()); }
+      sptr.push_back((int)segs.size() - 1);
+    }
+    const int nseg = (int)segs.size() - 1;
+    maxseg = std::max(maxseg, nseg);
+    optab.push_back(nt); optab.push_back(nseg);
+    optab.push_back((int)opdata.size()); opdata.insert(opdata.end(), O.tpos.begin(), O.tpos.end());
+    optab.push_back((int)opdata.size()); opdata.insert(opdata.end(), sptr.begin(), sptr.end());
+    optab.push_back((int)opdata.size()); opdata.insert(opdata.end(), segs.begin(), segs.end());
+    optab.push_back((int)opdata.size()); opdata.insert(opdata.end(), terms.begin(), terms.end());
   }
   // ---- G: its structural entries (r >= s by position) with the products they sum over, the longest lists first
   struct Pair { int addr; std::vector<int> t; };
@@ -314,7 +363,7 @@ inline bool qp_sp_plan_build(const QpPrepHost &H, const uint8_t *eq, QpSpPlanHos
             auto it = index.find(addr);
             if (it == index.end()) { it = index.emplace(addr, (int)pairs.size()).first; pairs.push_back(Pair{addr, {}}); }
             std::vector<int> &t = pairs[it->second].t;
-            t.push_back(o1); t.push_back(o2); t.push_back(hv);
+            t.push_back(cperm[o1]); t.push_back(cperm[o2]); t.push_back(hv);
           }
       }
     std::stable_sort(pairs.begin(), pairs.end(), [](const Pair &a, const Pair &b) { return a.t.size() > b.t.size(); });
@@ -327,11 +376,26 @@ inline bool qp_sp_plan_build(const QpPrepHost &H, const uint8_t *eq, QpSpPlanHos
   put(SP_O_IPOS, std::vector<int>(ipos.begin(), ipos.begin() + m));
   {
     std::vector<int> ft, rows;
-    for (auto &f : fr) { ft.insert(ft.end(), {f.base, f.r(), f.w, f.c0, f.rowoff, f.level}); rows.insert(rows.end(), f.rows.begin(), f.rows.end()); }
+    int lev = -1, coloff = 0;
+    for (auto &f : fr) { // (the last entry: where the front's columns start among its level's targets of the solves' sparse products)
+      if (f.level != lev) { lev = f.level; coloff = 0; }
+      ft.insert(ft.end(), {f.base, f.r(), f.w, f.c0, f.rowoff, coloff});
+      coloff += f.w;
+      rows.insert(rows.end(), f.rows.begin(), f.rows.end());
+    }
     put(SP_O_FRONT, ft);
     put(SP_O_ROWS, rows);
   }
-  put(SP_O_LEVEL, level_ptr);
+  {
+    std::vector<int> lv2; // per level: its first front, its first single-column front; then the end
+    for (int l = 0; l < nlevel; l++) {
+      int fs = level_ptr[l];
+      while (fs < level_ptr[l + 1] && fr[fs].w > 1) fs++;
+      lv2.push_back(level_ptr[l]); lv2.push_back(fs);
+    }
+    lv2.push_back(nfront);
+    put(SP_O_LEVEL, lv2);
+  }
   {
     std::vector<int> joblv(1, 0), jt, slots, maps;
     int njob = 0;
@@ -348,6 +412,10 @@ inline bool qp_sp_plan_build(const QpPrepHost &H, const uint8_t *eq, QpSpPlanHos
         jt.insert(jt.end(), {J.tbase, J.tstride, J.trows, J.tcols, J.r0, J.c0, s0, (int)(slots.size() / SP_SLOT_INTS - s0) / 4});
         njob++;
       }
+      int nurgent = 0;
+      for (auto &J : jobs[l]) nurgent += J.urgent;
+      joblv.back() = njob - (int)jobs[l].size(); // (start of the level's jobs)
+      joblv.push_back(njob - (int)jobs[l].size() + nurgent); // start of its jobs that nobody waits for
       joblv.push_back(njob);
     }
     out.njob = njob;
@@ -356,29 +424,31 @@ inline bool qp_sp_plan_build(const QpPrepHost &H, const uint8_t *eq, QpSpPlanHos
     put(SP_O_SLOT, slots);
     put(SP_O_MAP, maps);
   }
-  put(SP_O_PULLPTR, pullptr);
-  put(SP_O_PULL, pull);
+  put(SP_O_OPS, optab);
+  put(SP_O_OPDATA, opdata);
   put(SP_O_COLFRONT, colfront);
   put(SP_O_HPTR, hptr); put(SP_O_HCOL, hcol); put(SP_O_HIDX, hidx); put(SP_O_PIDX, pidx);
   put(SP_O_BPTR, bptr); put(SP_O_BVAR, bvar); put(SP_O_BBASE, bbase);
-  {
-    std::vector<int> cp(cptr, cptr + n + 1), crp(nnzA), rp(m + 1, 0), rc, rov;
-    for (long long o = 0; o < nnzA; o++) crp[o] = ipos[crow[o]];
-    for (int p = 0; p < m; p++) { // rows by position
-      const int r = perm[p];
-      for (int k = rptr[r]; k < rptr[r + 1]; k++) { rc.push_back(rcol[k]); rov.push_back(ro[k]); }
-      rp[p + 1] = (int)rc.size();
-    }
-    put(SP_O_CPTR, cp); put(SP_O_CROW, crp); put(SP_O_RPTR, rp); put(SP_O_RCOL, rc); put(SP_O_RO, rov);
-  }
   I[SP_LDS_INTS] = (int)I.size();
-  put(SP_O_CPERM, std::vector<int>(cperm, cperm + nnzA));
-  {
-    std::vector<int> pt, tt;
-    int nterm = 0;
-    for (auto &p : pairs) { nterm += (int)p.t.size() / 3; pt.push_back(p.addr); pt.push_back(nterm); tt.insert(tt.end(), p.t.begin(), p.t.end()); }
-    I[SP_NPAIR] = (int)pairs.size(); I[SP_NTERM] = nterm;
-    put(SP_O_PAIR, pt);
+  { // the entries' term lists cut into segments of at most SP_SEG terms (a thread each): an entry with one segment is stored by that
+    // thread, an entry with several is summed from the segments' sums by a second pass
+    std::vector<int> gseg, gsum, tt;
+    int nterm = 0, npart = 0;
+    for (auto &p : pairs) {
+      const int len = (int)p.t.size() / 3, nsg = (len + SP_SEG - 1) / SP_SEG;
+      if (nsg > 1) { gsum.push_back(p.addr); gsum.push_back(npart); gsum.push_back(npart + nsg); }
+      for (int k = 0; k < len; k += SP_SEG) {
+        gseg.push_back(nsg > 1 ? -(npart++) - 1 : p.addr);
+        gseg.push_back(nterm + k);
+      }
+      for (int k = 0; k < len; k++) { tt.push_back(p.t[3 * k] | (p.t[3 * k + 1] << 16)); tt.push_back(p.t[3 * k + 2]); }
+      nterm += len;
+    }
+    gseg.push_back(0); gseg.push_back(nterm);
+    I[SP_NPAIR] = (int)pairs.size(); I[SP_NTERM] = nterm; I[SP_NGSEG] = (int)gseg.size() / 2 - 1; I[SP_NGSUM] = (int)gsum.size() / 3;
+    maxseg = std::max(maxseg, npart);
+    put(SP_O_GSEG, gseg);
+    put(SP_O_GSUM, gsum);
     put(SP_O_TERM, tt);
   }
   {
@@ -389,6 +459,7 @@ inline bool qp_sp_plan_build(const QpPrepHost &H, const uint8_t *eq, QpSpPlanHos
   I[SP_MAGIC] = QPC_SP_MAGIC;
   I[SP_N] = n; I[SP_M] = m; I[SP_NE] = ne; I[SP_MI] = mi; I[SP_NNZA] = (int)nnzA; I[SP_NNZP] = (int)nnzP;
   I[SP_NFRONT] = nfront; I[SP_NLEVEL] = nlevel; I[SP_NJOB] = out.njob; I[SP_NVAL] = nval; I[SP_CB] = Cb; I[SP_NHV] = nhv; I[SP_NBLK] = nblk;
+  I[SP_NOPS] = (int)ops.size(); I[SP_MAXSEG] = maxseg;
   I[SP_NRT] = (int)nnzA; I[SP_TOTAL_INTS] = (int)I.size(); I[SP_MAXW] = maxw; I[SP_MAXR] = maxr;
   out.nval = nval; out.nhv = nhv; out.nfront = nfront; out.nlevel = nlevel; out.lds_ints = I[SP_LDS_INTS]; out.maxw = maxw; out.maxr = maxr;
   out.valid = true;
