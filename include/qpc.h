@@ -470,13 +470,27 @@ int32_t qpc_qp_solve_batch_device(int32_t n, int32_t m, int64_t B, const double 
  * coefficients in place (momentum.jl:58 `solve!`); OSQP, the reference's optimizer (test/runtests.jl:35-43), splits the work the same
  * way (osqp_setup / osqp_update_* / osqp_solve, warm-started by the previous solution).
  *   qpc_qp_setup: the PATTERN, 0-based COO, entries unique.  P: a symmetric matrix, an entry (i, j), i != j, stands for P_ij = P_ji
- *     (give one triangle, as OSQP does); a pattern with diagonal entries only is what the workgroup solver takes -- what Parametron
- *     builds for this controller -- anything else runs through the dense entry.  A: m x n.  Everything that depends on the pattern
- *     alone (compressed columns and rows, the structure of A H^-1 A') is computed here, once, and kept on device `device_id`.
+ *     (give one triangle, as OSQP does).  A: m x n.  What depends on the pattern alone is computed here, once, and kept on device
+ *     `device_id`.
  *   qpc_qp_solve: B QPs with that pattern: P_vals[nnz_P*B], A_vals[nnz_A*B] in the pattern's order (QP-major), q[n*B], l[m*B],
  *     u[m*B]; out as qpc_qp_solve_batch.  warm_start != 0: the working set starts from the multipliers of the previous call (QP b
  *     from QP b; ignored on the first call or when the previous batch was smaller).  Host pointers, synchronous; one call at a
- *     time per problem.  13 KB per QP cross the bus for the 143 x 178 Atlas problem (dense entry: 368 KB). */
+ *     time per problem.  13 KB per QP cross the bus for the 143 x 178 Atlas problem (dense entry: 368 KB).
+ *   Three solvers stand behind qpc_qp_solve, each taking what the one before leaves (all gfx950 device code):
+ *     1. the SPARSE workgroup form (csrc/qpc_qp_sp.h): n, m <= 256 and P block diagonal with blocks of at most 8 variables (diagonal P;
+ *        the e'We of a matrix-weighted task, momentum.jl:113-117).  It follows a PLAN: the symbolic analysis of G = A H^-1 A' for
+ *        one set of equality rows (rows with l == u) -- fill-reducing order, elimination tree, fronts, update schedule
+ *        (csrc/qpc_qp_sym.h) -- made on the host at the first qpc_qp_solve from the batch's first QP (a few milliseconds), or
+ *        ahead of it by qpc_qp_analyze, and redone when a batch's first QP has other equality rows.  A QP of a batch whose
+ *        equality rows differ from the plan's is left to
+ *     2. the dense workgroup form (csrc/qpc_qp_wg.h): diagonal P, n, m <= 256; and
+ *     3. one lane per QP (csrc/qpc_qp_dense.h): anything -- a dense P among it -- at 0.6 s per Atlas-sized problem.
+ *   qpc_qp_analyze: makes the plan now, for the equality rows of one QP's bounds l[m], u[m] (`MOI.copy_to` knows the constraint
+ *     sets: an optimizer calls it once after qpc_qp_setup so that the first tick is not the slow one).  QPC_OK also when the
+ *     pattern is outside the sparse form (qpc_qp_plan_info tells).
+ *   qpc_qp_plan_info: out[0 .. n_out-1] <- { plan in use (0 / 1), equality rows, other rows, fronts, levels of the elimination
+ *     tree, update jobs, doubles of the value store, bytes of LDS per workgroup, widest front, tallest front, multiply-adds of the
+ *     elimination, multiply-adds of the dense elimination of the same rows }; missing trailing entries are not written. */
 typedef struct qpc_qp_problem qpc_qp_problem;
 int32_t qpc_qp_setup(int32_t n, int32_t m, int64_t nnz_P, const int32_t *P_rows, const int32_t *P_cols,
                      int64_t nnz_A, const int32_t *A_rows, const int32_t *A_cols, int32_t device_id,
@@ -485,6 +499,8 @@ int32_t qpc_qp_solve(qpc_qp_problem *problem, int64_t B, const double *P_vals, c
                      const double *A_vals, const double *l, const double *u,
                      const qpc_settings *settings, int32_t warm_start, double *x, double *y,
                      int32_t *status, int32_t *iters);
+int32_t qpc_qp_analyze(qpc_qp_problem *problem, const double *l, const double *u);
+int32_t qpc_qp_plan_info(const qpc_qp_problem *problem, int64_t *out, int32_t n_out);
 void qpc_qp_free(qpc_qp_problem *problem);
 
 /* ---- closed loop: what the reference's acceptance test does around the tick,

@@ -100,6 +100,8 @@ def load_library(path=None):
         L.qpc_qp_solve.argtypes = [vp, i64] + [c_double_p] * 5 + [ctypes.POINTER(Settings), i32, c_double_p, c_double_p, c_int32_p, c_int32_p]
         L.qpc_qp_free.argtypes = [vp]
         L.qpc_qp_free.restype = None
+        L.qpc_qp_analyze.argtypes = [vp, c_double_p, c_double_p]
+        L.qpc_qp_plan_info.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), i32]
     L.qpc_assemble_solve_batch.argtypes = [vp, i64] + [c_double_p] * 11 + [c_double_p, c_double_p, c_int32_p, c_int32_p]
     L.qpc_sim_step_batch.argtypes = [vp, i64, c_double_p, c_double_p, c_double_p, c_int32_p, ctypes.POINTER(SimParams), c_int32_p]
     L.qpc_rollout_batch.argtypes = [vp, i64, i64] + [c_double_p] * 7 + [ctypes.POINTER(SimParams), c_double_p, c_int32_p, c_int32_p]
@@ -490,6 +492,20 @@ class QpProblem:
                                  _dp(x), _dp(y), status.ctypes.data_as(c_int32_p), iters.ctypes.data_as(c_int32_p))
         _check(self.L, rc, "qpc_qp_solve")
         return dict(x=x, y=y[:, :self.m], status=status, iters=iters)
+
+    def analyze(self, l, u):
+        """the plan of the sparse workgroup solver for the equality rows of one QP's bounds, ahead of the first solve (qpc_qp_analyze)"""
+        l = np.ascontiguousarray(np.clip(l, -1e20, 1e20), dtype=np.float64).reshape(-1)[:self.m]
+        u = np.ascontiguousarray(np.clip(u, -1e20, 1e20), dtype=np.float64).reshape(-1)[:self.m]
+        _check(self.L, self.L.qpc_qp_analyze(self.h, _dp(l), _dp(u)), "qpc_qp_analyze")
+        return self.plan_info()
+
+    def plan_info(self):
+        out = np.zeros(12, dtype=np.int64)
+        _check(self.L, self.L.qpc_qp_plan_info(self.h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), 12), "qpc_qp_plan_info")
+        keys = ("in_use", "equality_rows", "other_rows", "fronts", "levels", "update_jobs", "store_doubles", "lds_bytes", "widest_front",
+                "tallest_front", "elimination_madds", "dense_elimination_madds")
+        return dict(zip(keys, (int(v) for v in out)))
 
     def close(self):
         if self.h:

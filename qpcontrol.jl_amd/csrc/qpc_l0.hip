@@ -377,7 +377,11 @@ static int qpc_qp_plan(qpc_qp_problem *p, const std::vector<uint8_t> &eq) {
   if (p->plan_tried && eq == p->plan.eq) return QPC_OK;
   p->plan_tried = true;
   p->sp_lds_doubles = 0;
-  qpc::qp_sp_plan_build(p->H, eq.data(), p->plan);
+  try {
+    qpc::qp_sp_plan_build(p->H, eq.data(), p->plan);
+  } catch (const std::bad_alloc &) {
+    p->plan = qpc::QpSpPlanHost();
+  }
   if (!p->plan.valid) { p->plan.eq = eq; return QPC_OK; } // (remembered: not tried again for the same rows)
   // LDS: the plan's tables and the working arrays, the working set's factor sized for as many inequality rows as fit
   const int total = 160 * 1024 / 8;
@@ -401,9 +405,15 @@ int32_t qpc_qp_setup(int32_t n, int32_t m, int64_t nnz_P, const int32_t *P_rows,
                      const int32_t *A_rows, const int32_t *A_cols, int32_t device_id, qpc_qp_problem **out) {
   if (!out || (nnz_P && (!P_rows || !P_cols)) || (nnz_A && (!A_rows || !A_cols))) { qpc_set_error("qpc_qp_setup: bad arguments"); return QPC_ERR_INVALID_ARGUMENT; }
   *out = nullptr;
-  std::unique_ptr<qpc_qp_problem> p(new qpc_qp_problem);
-  const std::string err = qpc::qp_prep_build(p->H, n, m, nnz_P, P_rows, P_cols, nnz_A, A_rows, A_cols);
-  if (!err.empty()) { qpc_set_error("qpc_qp_setup: " + err); return QPC_ERR_INVALID_ARGUMENT; }
+  std::unique_ptr<qpc_qp_problem> p;
+  try {
+    p.reset(new qpc_qp_problem);
+    const std::string err = qpc::qp_prep_build(p->H, n, m, nnz_P, P_rows, P_cols, nnz_A, A_rows, A_cols);
+    if (!err.empty()) { qpc_set_error("qpc_qp_setup: " + err); return QPC_ERR_INVALID_ARGUMENT; }
+  } catch (const std::bad_alloc &) { // (an exception must not cross the C boundary)
+    qpc_set_error("qpc_qp_setup: out of host memory while analysing the pattern");
+    return QPC_ERR_OUT_OF_MEMORY;
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     (void)hipGetLastError();
@@ -432,6 +442,26 @@ int32_t qpc_qp_setup(int32_t n, int32_t m, int64_t nnz_P, const int32_t *P_rows,
   };
   if (int rc = setup()) { qpc_qp_free(p.release()); return rc; }
   *out = p.release();
+  return QPC_OK;
+}
+
+int32_t qpc_qp_analyze(qpc_qp_problem *p, const double *l, const double *u) {
+  if (!p || (p->H.m > 0 && (!l || !u))) { qpc_set_error("qpc_qp_analyze: bad arguments"); return QPC_ERR_INVALID_ARGUMENT; }
+  if (p->H.m <= 0) return QPC_OK;
+  HIP_TRY(hipSetDevice(p->device));
+  std::vector<uint8_t> eq;
+  qpc_eq_rows(p->H.m, l, u, eq);
+  return qpc_qp_plan(p, eq);
+}
+
+int32_t qpc_qp_plan_info(const qpc_qp_problem *p, int64_t *out, int32_t n_out) {
+  if (!p || !out || n_out < 0) { qpc_set_error("qpc_qp_plan_info: bad arguments"); return QPC_ERR_INVALID_ARGUMENT; }
+  const qpc::QpSpPlanHost &P = p->plan;
+  const bool on = p->plan_tried && P.valid && p->sp_lds_doubles > 0;
+  long long dense = 0;
+  for (int j = 0; j < P.ne; j++) dense += (long long)(P.m + 1 - j) * (P.m + 2 - j) / 2;
+  const int64_t v[12] = {on ? 1 : 0, P.ne, P.mi, P.nfront, P.nlevel, P.njob, P.nval, (int64_t)p->sp_lds_doubles * 8, P.maxw, P.maxr, P.flops, dense};
+  for (int i = 0; i < 12 && i < n_out; i++) out[i] = v[i];
   return QPC_OK;
 }
 
@@ -498,7 +528,7 @@ int32_t qpc_qp_solve(qpc_qp_problem *p, int64_t B, const double *P_vals, const d
   int rc = QPC_OK;
   auto chk = [&](hipError_t e, const char *w) { if (e != hipSuccess && rc == QPC_OK) rc = hip_fail(e, w); };
   const bool warm = warm_start && p->d_yprev && p->B_prev >= B && m > 0;
-  const bool wg = m > 0 && !p->H.p_offdiag && n <= QPC_WG_DIM && m <= QPC_WG_DIM;
+  const bool wg = m > 0 && p->H.wg_tables; // (diagonal P, n, m <= QPC_WG_DIM: qp_prep_build)
   // the sparse workgroup form first (qpc_qp_sp.h): its plan is made for the equality rows of the batch's first QP (kept while they stay)
   bool sp = false;
   if (m > 0 && n <= QPC_SP_DIM && m <= QPC_SP_DIM) {

@@ -21,6 +21,7 @@ struct QpPrepHost {
   int n = 0, m = 0;
   long long nnzP = 0, nnzA = 0;
   bool p_offdiag = false;
+  bool wg_tables = false; // the term tables of the dense workgroup kernel are there
   int npairs = 0, ntrip = 0;
   std::vector<int> ints; // [pdiag | cptr | crow | cperm | rptr | rcol | ro | pptr | pr | ps | ta | tb | tc]
   std::vector<int> Prow, Pcol, Arow, Acol; // the caller's pattern (the dense path scatters with it)
@@ -75,9 +76,19 @@ inline std::string qp_prep_build(QpPrepHost &H, int n, int m, long long nnzP, co
   std::sort(ro.begin(), ro.end(), [&](int a, int b) { return crow[a] != crow[b] ? crow[a] < crow[b] : ccol[a] < ccol[b]; });
   for (long long k = 0; k < nnzA; k++) { rcol[k] = ccol[ro[k]]; rptr[crow[ro[k]] + 1]++; }
   for (int r = 0; r < m; r++) rptr[r + 1] += rptr[r];
-  // structure of G = A H^-1 A' (lower triangle by row index): terms (r, s, c, o_r, o_s), sorted by (r, s, c)
+  // structure of G = A H^-1 A' (lower triangle by row index): terms (r, s, c, o_r, o_s), sorted by (r, s, c) -- only when the dense
+  // workgroup kernel (qpc_qp_wg.h: diagonal P, n, m <= 256) can run on this pattern: nobody else reads these tables, and for a
+  // dense 300 x 400 pattern they take seconds and gigabytes
   struct Term { int r, s, c, a, b; };
   std::vector<Term> terms;
+  H.wg_tables = !H.p_offdiag && n <= 256 && m <= 256;
+  if (H.wg_tables) {
+    long long nt = 0;
+    for (int c = 0; c < n; c++) { const long long k = cptr[c + 1] - cptr[c]; nt += k * (k + 1) / 2; }
+    if (nt > (1LL << 26)) return "pattern too dense for the workgroup solver's tables";
+    terms.reserve((size_t)nt);
+  }
+  if (H.wg_tables)
   for (int c = 0; c < n; c++)
     for (int o1 = cptr[c]; o1 < cptr[c + 1]; o1++)
       for (int o2 = cptr[c]; o2 <= o1; o2++) terms.push_back(Term{crow[o1], crow[o2], c, o1, o2}); // (rows ascend inside a column: r >= s)

@@ -491,6 +491,24 @@ int32_t qpc_qp_setup(int32_t n, int32_t m, int64_t nnz_P, const int32_t *P_rows,
   return QPC_OK;
 }
 void qpc_qp_free(qpc_qp_problem *p) { delete p; }
+int32_t qpc_qp_analyze(qpc_qp_problem *p, const double *l, const double *u) {
+  if (!p || (p->H.m > 0 && (!l || !u))) return QPC_ERR_INVALID_ARGUMENT;
+  if (p->H.m <= 0) return QPC_OK;
+  std::vector<uint8_t> eq;
+  emu_eq_rows(p->H.m, l, u, eq);
+  if (!p->plan_tried || eq != p->plan.eq) { qpc::qp_sp_plan_build(p->H, eq.data(), p->plan); p->plan_tried = true; if (!p->plan.valid) p->plan.eq = eq; }
+  return QPC_OK;
+}
+int32_t qpc_qp_plan_info(const qpc_qp_problem *p, int64_t *out, int32_t n_out) {
+  if (!p || !out || n_out < 0) return QPC_ERR_INVALID_ARGUMENT;
+  const qpc::QpSpPlanHost &P = p->plan;
+  const bool on = p->plan_tried && P.valid;
+  long long dense = 0;
+  for (int j = 0; j < P.ne; j++) dense += (long long)(P.m + 1 - j) * (P.m + 2 - j) / 2;
+  const int64_t v[12] = {on ? 1 : 0, P.ne, P.mi, P.nfront, P.nlevel, P.njob, P.nval, on ? (int64_t)qpc::qp_sp_lds_doubles(P.ints.data(), P.mi) * 8 : 0, P.maxw, P.maxr, P.flops, dense};
+  for (int i = 0; i < 12 && i < n_out; i++) out[i] = v[i];
+  return QPC_OK;
+}
 int32_t qpc_qp_solve(qpc_qp_problem *p, int64_t B, const double *P_vals, const double *q, const double *A_vals, const double *l,
                      const double *u, const qpc_settings *settings, int32_t warm_start, double *x, double *y, int32_t *status,
                      int32_t *iters) {
@@ -511,7 +529,7 @@ int32_t qpc_qp_solve(qpc_qp_problem *p, int64_t B, const double *P_vals, const d
   if (try_sp) {
     std::vector<uint8_t> eq;
     emu_eq_rows(m, l, u, eq);
-    if (!p->plan_tried || eq != p->plan.eq) { qpc::qp_sp_plan_build(p->H, eq.data(), p->plan); p->plan_tried = true; }
+    if (!p->plan_tried || eq != p->plan.eq) { qpc::qp_sp_plan_build(p->H, eq.data(), p->plan); p->plan_tried = true; if (!p->plan.valid) p->plan.eq = eq; }
   }
   const int wg_total = cap ? atoi(cap) : QPC_WG_LDS_DOUBLES; // doubles of "LDS" (the device's 160 KB)
   std::vector<double> sp_lds;
@@ -525,7 +543,7 @@ int32_t qpc_qp_solve(qpc_qp_problem *p, int64_t B, const double *P_vals, const d
                            nullptr);
       g_l0_sp += s != QPC_WG_FALLBACK;
     }
-    if (s == QPC_WG_FALLBACK && m > 0 && !p->H.p_offdiag)
+    if (s == QPC_WG_FALLBACK && m > 0 && p->H.wg_tables)
       s = qpc::qp_solve_wg_prep(V, P_vals + b * nnzP, q + b * n, A_vals + b * nnzA, l + b * m, u + b * m, st, ws.data(), lds.data(), lds_cap,
                                 warm ? p->yprev.data() + b * m : nullptr, x + b * n, y + b * m, iters ? iters + b : nullptr);
     g_l0_wg += s != QPC_WG_FALLBACK;
@@ -546,15 +564,6 @@ int32_t qpc_qp_solve(qpc_qp_problem *p, int64_t B, const double *P_vals, const d
 }
 long emu_l0_wg_count() { const long r = g_l0_wg; g_l0_wg = 0; return r; }
 long emu_l0_sp_count() { const long r = g_l0_sp; g_l0_sp = 0; return r; }
-// the plan of a prepared problem (diagnostics of the tests): out[0..11] = valid, ne, mi, fronts, levels, jobs, value-store doubles, LDS ints,
-// widest front, tallest front, elimination multiply-adds, total ints
-int emu_l0_plan_stats(qpc_qp_problem *p, long long *out) {
-  if (!p || !p->plan_tried) return -1;
-  const qpc::QpSpPlanHost &P = p->plan;
-  const long long v[12] = {P.valid, P.ne, P.mi, P.nfront, P.nlevel, P.njob, P.nval, P.lds_ints, P.maxw, P.maxr, P.flops, (long long)P.ints.size()};
-  for (int i = 0; i < 12; i++) out[i] = v[i];
-  return 0;
-}
 #endif
 // race-detector report: counts since the last call
 void emu_report(long *races, long *uninit, long *outside, char *first, int n) {

@@ -1,0 +1,242 @@
+"""The sparse workgroup form of L0 (csrc/qpc_qp_sym.h: the plan, on the host; csrc/qpc_qp_sp.h: the kernel) -- what stands behind
+qpc_qp_setup / qpc_qp_solve for a block-diagonal P: the reference's own plug point (the optimizer slot of `MomentumBasedController`,
+momentum.jl:15-16,27,58) including `addtask!(controller, task, W::AbstractMatrix)` (momentum.jl:113-117; the reference's test modes
+OBJECTIVE_TERM_MATRIX_WEIGHT*, test/controller.jl:232-285).  Checked against the oracle-made fixtures of tests/golden/l0, the oracle's
+OSQP restatement, the dense workgroup form and the one-lane form; CPU emulation and GPU."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import emu
+from oracle import oracle as O
+from qpcontrol_jl_amd import binding
+from test_l0_dense_qp import _random_structured_qp
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+
+
+def _fixture(which):
+    import bench_latency as BL
+    return BL.load_l0_fixture(which)
+
+
+def _sp_count():
+    L = ctypes.CDLL(emu.EMU_LIB)
+    L.emu_l0_sp_count.restype = ctypes.c_long
+    return L.emu_l0_sp_count()
+
+
+def _problem(P, A, lib):
+    pr = binding.QpProblem(P.shape[-1], A.shape[-2], (P != 0).any(0) if P.ndim == 3 else P != 0, (A != 0).any(0) if A.ndim == 3 else A != 0,
+                           lib_path=lib)
+    return pr, pr.values(P, A)
+
+
+def test_plan_of_the_atlas_problem():
+    """the symbolic analysis: 114 equality rows in three levels of fronts, 39 times fewer multiply-adds than the dense elimination"""
+    emu.build()
+    P, q, A, l, u, x, nv = _fixture("diag")
+    pr, _ = _problem(P, A, emu.EMU_LIB)
+    assert pr.plan_info()["in_use"] == 0  # (nothing analysed yet)
+    info = pr.analyze(l[0], u[0])
+    assert info["in_use"] == 1 and info["equality_rows"] == 114 and info["other_rows"] == 64
+    assert info["levels"] <= 3 and info["widest_front"] <= 32
+    assert info["elimination_madds"] * 20 < info["dense_elimination_madds"]
+    assert info["lds_bytes"] <= 160 * 1024
+    pr.close()
+
+
+@pytest.mark.parametrize("which", ["diag", "matrix"])
+def test_fixture_emulated(which, monkeypatch):
+    """the committed problems (diagonal P; a 6 x 6 block in P): every QP in the sparse form, v̇ as stored, the same answer as the
+    dense workgroup form / the one-lane form behind the same calls, warm start"""
+    emu.build()
+    P, q, A, l, u, x, nv = _fixture(which)
+    pr, (Pv, Av) = _problem(P, A, emu.EMU_LIB)
+    _sp_count()
+    r = pr.solve(Pv, q, Av, l, u)
+    assert _sp_count() == P.shape[0]
+    assert (r["status"] == 0).all()
+    np.testing.assert_allclose(r["x"][:, :nv], x[:, :nv], atol=1e-8)
+    monkeypatch.setenv("QPC_L0_NO_SPARSE", "1")
+    r0 = pr.solve(Pv, q, Av, l, u)
+    monkeypatch.delenv("QPC_L0_NO_SPARSE")
+    assert _sp_count() == 0 and (r0["status"] == 0).all()
+    if which == "diag":  # (same method, same ties: the dense workgroup form takes the same steps)
+        np.testing.assert_array_equal(r["iters"], r0["iters"])
+    # (the basis multipliers rho of a contact are not unique -- four rays for a three-dimensional force --: what the two forms must
+    #  agree on is the objective, feasibility, and everything the objective determines: v̇, the contact forces)
+    obj = lambda xx: 0.5 * np.einsum("bi,bij,bj->b", xx, P, xx) + np.einsum("bi,bi->b", q, xx)  # noqa: E731
+    np.testing.assert_allclose(obj(r["x"]), obj(r0["x"]), rtol=1e-9, atol=1e-9)
+    for rr in (r, r0):
+        Ax = np.einsum("bij,bj->bi", A, rr["x"])
+        sc = max(1.0, np.abs(Ax).max())
+        assert (Ax >= l - 1e-8 * sc).all() and (Ax <= u + 1e-8 * sc).all()
+    np.testing.assert_allclose(r["x"][:, :nv], r0["x"][:, :nv], atol=1e-9)
+    rw = pr.solve(Pv, q, Av, l, u, warm_start=True)
+    assert (rw["status"] == 0).all() and (rw["iters"] <= 1).all()
+    np.testing.assert_allclose(rw["x"][:, :nv], x[:, :nv], atol=1e-8)
+    pr.close()
+
+
+def _random_block_qp(rng, n, m, n_eq, nblocks, bs):
+    """a structured QP whose P has `nblocks` dense positive definite blocks of `bs` variables (scattered), diagonal elsewhere"""
+    P, q, A, l, u = _random_structured_qp(rng, n, m, n_eq)
+    free = list(rng.permutation(n))
+    for _ in range(nblocks):
+        idx = np.array(sorted(free[:bs])); free = free[bs:]
+        M = rng.normal(size=(bs, bs))
+        P[np.ix_(idx, idx)] = M @ M.T / bs + np.diag(rng.uniform(0.1, 1.0, size=bs))
+    return P, q, A, l, u
+
+
+def _check_random_blocks(lib, seeds=range(12)):
+    n_checked = 0
+    for seed in seeds:
+        rng = np.random.default_rng(100 + seed)
+        n, m, ne = [(20, 26, 5), (24, 36, 8), (48, 80, 14), (72, 110, 30)][seed % 4]
+        P, q, A, l, u = _random_block_qp(rng, n, m, ne, nblocks=1 + seed % 3, bs=2 + seed % 5)
+        ro = O.qp_solve(P, q, A, l, u)
+        if ro["status"] != 0:
+            continue
+        pr, (Pv, Av) = _problem(P, A, lib)
+        r = pr.solve(Pv, q, Av, l, u)
+        assert pr.plan_info()["in_use"] == 1
+        assert r["status"][0] == 0, (seed, r["status"])
+        np.testing.assert_allclose(r["x"][0], ro["x"], atol=1e-8)
+        pr.close()
+        n_checked += 1
+    assert n_checked >= 8
+
+
+def test_random_block_diagonal_p_emulated():
+    emu.build()
+    _sp_count()
+    _check_random_blocks(emu.EMU_LIB)
+    assert _sp_count() >= 8
+
+
+def test_a_block_beyond_eight_variables_takes_the_one_lane_form():
+    emu.build()
+    rng = np.random.default_rng(5)
+    P, q, A, l, u = _random_block_qp(rng, 20, 30, 5, nblocks=1, bs=9)
+    pr, (Pv, Av) = _problem(P, A, emu.EMU_LIB)
+    ro = O.qp_solve(P, q, A, l, u)
+    _sp_count()
+    r = pr.solve(Pv, q, Av, l, u)
+    assert pr.plan_info()["in_use"] == 0 and _sp_count() == 0
+    assert ro["status"] == 0 and r["status"][0] == 0
+    np.testing.assert_allclose(r["x"][0], ro["x"], atol=1e-8)
+    pr.close()
+
+
+def _mask_change(lib, count=None):
+    """a batch whose second QP has OTHER equality rows than the plan's (made for the first): that QP is left to the dense workgroup
+    form; a later batch led by such a QP gets a plan of its own"""
+    rng = np.random.default_rng(9)
+    P, q, A, l, u = _random_structured_qp(rng, 30, 44, 8)
+    l2, u2 = l.copy(), u.copy()
+    l2[9] = u2[9] = 0.5 * (l[10] + u[10]) if np.isfinite(l[10]) and l[10] > -1e19 else u[9]  # row 9 becomes an equality row
+    l2[9] = u2[9]
+    pr, (Pv, Av) = _problem(P, A, lib)
+    ro1, ro2 = O.qp_solve(P, q, A, l, u), O.qp_solve(P, q, A, l2, u2)
+    if count:
+        count()
+    r = pr.solve(np.stack([Pv[0]] * 2), np.stack([q] * 2), np.stack([Av[0]] * 2), np.stack([l, l2]), np.stack([u, u2]))
+    if count:
+        assert count() == 1  # (the first QP only)
+    for k, ro in enumerate((ro1, ro2)):
+        if ro["status"] == 0:
+            assert r["status"][k] == 0
+            np.testing.assert_allclose(r["x"][k], ro["x"], atol=1e-8)
+    assert pr.plan_info()["equality_rows"] == 8
+    r2 = pr.solve(Pv[0], q, Av[0], l2, u2)
+    assert pr.plan_info()["equality_rows"] == 9 and pr.plan_info()["in_use"] == 1
+    if count:
+        assert count() == 1
+    if ro2["status"] == 0:
+        np.testing.assert_allclose(r2["x"][0], ro2["x"], atol=1e-8)
+    pr.close()
+
+
+def test_other_equality_rows_than_the_plans_emulated():
+    emu.build()
+    _mask_change(emu.EMU_LIB, _sp_count)
+
+
+def test_no_equality_rows_and_no_inequality_rows_emulated():
+    """the edges of the row classification: every row an inequality (no fronts at all); every row an equality (C is the corner)"""
+    emu.build()
+    rng = np.random.default_rng(3)
+    for n, m, ne in ((12, 18, 0), (12, 7, 7)):
+        P, q, A, l, u = _random_structured_qp(rng, n, m, ne)
+        ro = O.qp_solve(P, q, A, l, u)
+        pr, (Pv, Av) = _problem(P, A, emu.EMU_LIB)
+        _sp_count()
+        r = pr.solve(Pv, q, Av, l, u)
+        assert _sp_count() == 1 and pr.plan_info()["equality_rows"] == ne
+        assert ro["status"] == 0 and r["status"][0] == 0
+        np.testing.assert_allclose(r["x"][0], ro["x"], atol=1e-8)
+        pr.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["diag", "matrix"])
+def test_fixture_gpu(which):
+    """the committed problems on the device, in the sparse form: v̇ as stored (1e-8), the same steps and answer as the lane-serial
+    emulation of the same source (matrix core against the scalar twin of the tile jobs: another summation order)"""
+    emu.build()
+    P, q, A, l, u, x, nv = _fixture(which)
+    res = []
+    for lib in (None, emu.EMU_LIB):
+        pr, (Pv, Av) = _problem(P, A, lib)
+        r = pr.solve(Pv, q, Av, l, u)
+        assert pr.plan_info()["in_use"] == 1
+        res.append(r)
+        if lib is None:
+            rw = pr.solve(Pv, q, Av, l, u, warm_start=True)
+            assert (rw["status"] == 0).all() and (rw["iters"] <= 1).all()
+            np.testing.assert_allclose(rw["x"][:, :nv], x[:, :nv], atol=1e-8)
+        pr.close()
+    assert (res[0]["status"] == 0).all()
+    np.testing.assert_allclose(res[0]["x"][:, :nv], x[:, :nv], atol=1e-8)
+    np.testing.assert_array_equal(res[0]["iters"], res[1]["iters"])
+    np.testing.assert_allclose(res[0]["x"][:, :nv], res[1]["x"][:, :nv], atol=1e-10)
+
+
+@pytest.mark.gpu
+def test_random_block_diagonal_p_gpu():
+    _check_random_blocks(None)
+
+
+@pytest.mark.gpu
+def test_other_equality_rows_than_the_plans_gpu():
+    _mask_change(None)
+
+
+@pytest.mark.gpu
+def test_working_set_beyond_lds_goes_down_the_chain_gpu():
+    """150 box rows, all of them active at the solution: the working set's factor does not fit beside the plan in LDS -- the sparse
+    form leaves the QP, the dense workgroup form (at most 128 working rows) leaves it too, the one-lane form solves it; mixed into a
+    batch of problems the sparse form keeps (the statuses' round trip, `only_fallback`), cold and warm"""
+    rng = np.random.default_rng(12)
+    n = 150
+    P = np.diag(rng.uniform(0.5, 2.0, size=n))
+    xt = rng.normal(size=n)
+    A = np.eye(n)
+    lo, hi = xt - 0.05, xt + 0.05
+    q = -P @ (xt + np.where(rng.uniform(size=n) < 0.5, 1.0, -1.0))  # the unconstrained minimiser lies one unit outside every box
+    q2 = -P @ xt                                                      # ... inside every box
+    pr, (Pv, Av) = _problem(P, A, None)
+    B = 6
+    qs = np.stack([q2, q, q2, q2, q, q2])
+    for warm in (False, True):
+        r = pr.solve(np.stack([Pv[0]] * B), qs, np.stack([Av[0]] * B), np.stack([lo] * B), np.stack([hi] * B), warm_start=warm)
+        assert (r["status"] == 0).all(), r["status"]
+        for b in range(B):
+            xe = np.clip(-qs[b] / np.diag(P), lo, hi)
+            np.testing.assert_allclose(r["x"][b], xe, atol=1e-8)
+    pr.close()
