@@ -20,9 +20,11 @@ Prints ONE JSON line on rank 0.  Beside the headline (device-resident, timed reg
                      itself runs on Atlas: notebook tolerances (1e-5), closed loop at 1 kHz, OSQP warm-started from the
                      previous tick, all cores.  Beside it: `notebook_cold`, `tight_cold` (test-suite tolerances 1e-8, cold: the
                      setting the 1e-8 parity is judged against), `tight_warm_closed_loop`
-  config.l0_plugin   the solver-level plug (b-1) on the 143 x 178 Atlas problem: latency at B = 1 and rate at a larger batch of the dense
-                     entry qpc_qp_solve_batch and of the prepared entry qpc_qp_setup / qpc_qp_solve (cold and warm-started) that
-                     QPCOptimizer binds (tools/bench_latency.py --l0)
+  config.l0_plugin   the solver-level plug (b-1) on the committed Atlas problems (143 x 178; 146 x 181 with a matrix-weighted task): latency at
+                     B = 1 and rate at 8 192 of the prepared entry qpc_qp_setup / qpc_qp_solve (cold and warm-started) that QPCOptimizer
+                     binds, and of the dense entry qpc_qp_solve_batch (tools/bench_latency.py --l0); the CPU beside it is
+                     cpu_baseline.l0_fixture_osqp: the oracle's OSQP on the same problems, measured in the same run
+  roofline_l0        the sparse workgroup kernel of that entry (qpc_qp_sp_kernel) at 8 192 problems per launch, from live HIP events
   degraded           true when a secondary measurement failed or solved < 90 % of its QPs (the line itself stays alive)
 """
 import argparse
@@ -364,31 +366,81 @@ def closed_loop_point():
         return {"error": repr(e)}
 
 
+L0_ALG_NOTE = ("algorithmic bytes per problem at the boundary of qpc_qp_solve: in 8 (nnz P + n + nnz A + 2 m), out 8 (n + m) + 8 (status, iters); "
+               "the path is bound by the LATENCY of its dependent steps (pivots, LDS round trips), not by memory or arithmetic: DESIGN.md 7d")
+
+
 def l0_plugin_point():
-    """SURVEY.md 8 b-1, outside the timed region: the solver-level plug on the 143 x 178 Atlas problem (what unmodified QPControl.jl
-    hands to its optimizer slot) -- the prepared entry QPCOptimizer binds (qpc_qp_setup / qpc_qp_solve, cold and warm-started) and the
-    dense entry qpc_qp_solve_batch; tools/bench_latency.py --l0 in a child process"""
+    """SURVEY.md 8 b-1, outside the timed region: the solver-level plug on the committed Atlas problems (what unmodified QPControl.jl
+    hands to its optimizer slot: 143 x 178 with a diagonal P, 146 x 181 with a matrix-weighted MomentumRateTask) -- the prepared entry
+    QPCOptimizer binds (qpc_qp_setup / qpc_qp_solve, cold and warm-started) and the dense entry qpc_qp_solve_batch;
+    tools/bench_latency.py --l0 in a child process.  -> (config.l0_plugin, roofline_l0)"""
     try:
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_latency.py"), "--l0", "1", "1024"], capture_output=True, text=True,
-                           timeout=300)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_latency.py"), "--l0", "1", "8192"], capture_output=True, text=True,
+                           timeout=400)
         d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-        pr = d.get("prepared", {})
+        pr, pm = d.get("prepared", {}), d.get("prepared_matrix_weight", {})
+        big = pr.get("8192", {})
         dense = {"latency_us_B1": d["1"]["median_us"], "latency_us_B1_median_over_problems": d.get("B1_median_over_problems_us"),
-                 "latency_us_B1_worst_problem": d.get("B1_worst_problem_us"), "solves_per_s_B1024": d["1024"]["solves_per_s"],
-                 "max_abs_err_vdot_vs_fixture": max(d["1"]["max_abs_err_vdot_vs_fixture"], d["1024"]["max_abs_err_vdot_vs_fixture"])}
-        return {"n": d["n"], "m": d["m"],
-                # the optimizer's life cycle (qpc_qp_setup once, qpc_qp_solve per tick: values only, warm start): what QPCOptimizer binds
-                "entry": "qpc_qp_setup / qpc_qp_solve (pattern once, values per call; host pointers, synchronous, B = 1 unless stated)",
-                "latency_us_B1_cold_median_over_problems": pr.get("B1_cold_median_over_problems_us"),
-                "latency_us_B1_cold_worst_problem": pr.get("B1_cold_worst_problem_us"),
-                "latency_us_B1_warm_median_over_problems": pr.get("B1_warm_median_over_problems_us"),
-                "latency_us_B1_warm_worst_problem": pr.get("B1_warm_worst_problem_us"),
-                "solves_per_s_B1024_cold": pr.get("1024", {}).get("cold_solves_per_s"),
-                "solves_per_s_B1024_warm": pr.get("1024", {}).get("warm_solves_per_s"),
-                "max_abs_err_vdot_vs_fixture": pr.get("1024", {}).get("max_abs_err_vdot_vs_fixture"),
-                "dense_entry_qpc_qp_solve_batch": dense,
-                "reference_cpu_osqp_warm_tick_us": "800-1300 (cpu_baseline.warm_start.single_core)"}
+                 "latency_us_B1_worst_problem": d.get("B1_worst_problem_us"), "solves_per_s_B8192": d["8192"]["solves_per_s"],
+                 "max_abs_err_vdot_vs_fixture": max(d["1"]["max_abs_err_vdot_vs_fixture"], d["8192"]["max_abs_err_vdot_vs_fixture"])}
+        point = {"n": d["n"], "m": d["m"],
+                 # the optimizer's life cycle (qpc_qp_setup once, qpc_qp_solve per tick: values only, warm start): what QPCOptimizer binds
+                 "entry": "qpc_qp_setup / qpc_qp_solve (pattern once, values per call; host pointers, synchronous, B = 1 unless stated)",
+                 "plan": pr.get("plan"),
+                 "latency_us_B1_cold_median_over_problems": pr.get("B1_cold_median_over_problems_us"),
+                 "latency_us_B1_cold_worst_problem": pr.get("B1_cold_worst_problem_us"),
+                 "latency_us_B1_warm_median_over_problems": pr.get("B1_warm_median_over_problems_us"),
+                 "latency_us_B1_warm_worst_problem": pr.get("B1_warm_worst_problem_us"),
+                 "warm_means": pr.get("warm_means"),
+                 "solves_per_s_B8192_cold": big.get("cold_solves_per_s"), "solves_per_s_B8192_warm": big.get("warm_solves_per_s"),
+                 "max_abs_err_vdot_vs_fixture": big.get("max_abs_err_vdot_vs_fixture"),
+                 "matrix_weighted_task_146x181": {"plan": pm.get("plan"),
+                                                  "latency_us_B1_cold_median_over_problems": pm.get("B1_cold_median_over_problems_us"),
+                                                  "latency_us_B1_cold_worst_problem": pm.get("B1_cold_worst_problem_us"),
+                                                  "latency_us_B1_warm_median_over_problems": pm.get("B1_warm_median_over_problems_us"),
+                                                  "max_abs_err_vdot_vs_fixture": max([p["max_abs_err_vdot_vs_fixture"] for p in pm.get("B1_per_problem", [])] or [None])},
+                 "dense_entry_qpc_qp_solve_batch": dense,
+                 "reference_cpu": "cpu_baseline.l0_fixture_osqp: the oracle's OSQP on the same committed problems, one core, measured in this run"}
+        roof = None
+        if big.get("cold_kernel_ms"):
+            n, m, nnzP, nnzA = d["n"], d["m"], 63, 1004
+            alg = 8 * (nnzP + n + nnzA + 2 * m) + 8 * (n + m) + 8
+            ach = alg * 8192 / (big["cold_kernel_ms"] * 1e-3)
+            madds = (pr.get("plan") or {}).get("elimination_madds")
+            roof = {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": None,
+                    "kernel": "qpc_qp_sp_kernel", "kernel_ms": big["cold_kernel_ms"], "kernel_ms_warm": big.get("warm_kernel_ms"), "problems_per_launch": 8192,
+                    "problems_per_s_of_device_time": 8192 / (big["cold_kernel_ms"] * 1e-3), "algorithmic_bytes_per_problem": alg,
+                    "elimination_multiply_adds_per_problem": madds,
+                    "dense_elimination_multiply_adds_per_problem": (pr.get("plan") or {}).get("dense_elimination_madds"),
+                    "timing": "HIP events on the problem's stream around the kernels of one qpc_qp_solve (qpc_qp_enable_timing), live in this run",
+                    "note": L0_ALG_NOTE}
+        return point, roof
     except Exception as e:  # noqa: BLE001 -- a diagnostic extra must never take the bench line down
+        return {"error": repr(e)}, None
+
+
+def l0_cpu_leg():
+    """cpu_baseline leg for the solver-level plug: the oracle's OSQP restatement on the SAME committed problems the device entry is
+    timed on (tests/golden/l0), one core, setup once and then update + solve per call as `Parametron.solve!` does (momentum.jl:58):
+    microseconds per solve at the notebook's tolerances (Standing controller.ipynb:68-71) and at the test suite's (test/runtests.jl:35-43),
+    cold and warm-started from the same problem's previous solution (how tools/bench_latency.py times the device's warm start)."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_latency as BL
+        from oracle import oracle as O
+        out = {"unit": "us per solve, one core", "warm_means": "the same problem solved again from its previous solution"}
+        for which in ("diag", "matrix"):
+            P, q, A, l, u, x, nv = BL.load_l0_fixture(which)
+            res = {}
+            for name, st in (("notebook_tolerances", O.notebook_settings(0)), ("test_suite_tolerances", O.test_settings(0))):
+                for warm in (False, True):
+                    r = O.qp_time(P, q, A, l, u, st, reps=3, warm=warm)
+                    res[name + ("_warm" if warm else "_cold")] = {"median_over_problems": float(np.median(r["us"])), "worst_problem": float(r["us"].max()),
+                                                                  "best_problem": float(r["us"].min()), "admm_iterations": [int(i) for i in r["iters"]]}
+            out["atlas_143x178" if which == "diag" else "atlas_matrix_weight_146x181"] = res
+        return out
+    except Exception as e:  # noqa: BLE001
         return {"error": repr(e)}
 
 
@@ -562,7 +614,7 @@ def main():
             fp64_measured = ctypes.c_double(0.0)
     n_opt = int((st == 0).sum())
 
-    host_rates, secondary, closed_loop, pipelined, l0_plugin, ordered = None, None, None, None, None, None
+    host_rates, secondary, closed_loop, pipelined, l0_plugin, ordered, roofline_l0 = None, None, None, None, None, None, None
     if rank == 0 and world == 1 and not args.no_secondary:
         # diagnostic extras, measured after the headline's timed region: none of them may take the bench line down
         if not args.fused_laws:
@@ -583,7 +635,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             ordered = {"error": repr(e)}
         closed_loop = closed_loop_point()
-        l0_plugin = l0_plugin_point()
+        l0_plugin, roofline_l0 = l0_plugin_point()
 
     if rank == 0:
         total = B * world * args.steps
@@ -644,6 +696,7 @@ def main():
                                   "frac_of_measured_peak": ((ALG_FLOPS_PER_SOLVE * B / kern_s) / (fp64_measured.value * 1e12)
                                                             if kern_s > 0 and fp64_measured.value > 0 else None)}},
         }
+        out["roofline_l0"] = roofline_l0
         # a regression in a secondary path must not hide in a JSON field: flagged at the top level
         why = []
         if n_opt / B < 0.9:
@@ -666,6 +719,7 @@ def main():
             out["degraded_why"] = why
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"]["l0_fixture_osqp"] = l0_cpu_leg()
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -501,6 +501,11 @@ int32_t qpc_qp_solve(qpc_qp_problem *problem, int64_t B, const double *P_vals, c
                      int32_t *status, int32_t *iters);
 int32_t qpc_qp_analyze(qpc_qp_problem *problem, const double *l, const double *u);
 int32_t qpc_qp_plan_info(const qpc_qp_problem *problem, int64_t *out, int32_t n_out);
+/* Measurement: with `on` != 0 every qpc_qp_solve brackets its kernels with HIP events on the problem's own stream;
+ * qpc_qp_last_kernel_ms: the device time of the last call's kernels (all three forms together), milliseconds.  bench.py's
+ * `roofline_l0` is computed from it. */
+int32_t qpc_qp_enable_timing(qpc_qp_problem *problem, int32_t on);
+int32_t qpc_qp_last_kernel_ms(const qpc_qp_problem *problem, double *ms);
 void qpc_qp_free(qpc_qp_problem *problem);
 
 /* ---- closed loop: what the reference's acceptance test does around the tick,

@@ -691,3 +691,58 @@ int ora_qp_solve(int n, int m, const double *P, const double *q, const double *A
   free(Pp); free(Ap); free(Pi); free(Ai); free(Px); free(Ax);
   return rc;
 }
+
+/* Timing of the OSQP restatement at the solver-level boundary (bench.py's cpu_baseline leg for the L0 plug: the same committed
+ * problems the device entry qpc_qp_setup / qpc_qp_solve is timed on): k dense problems that share a sparsity pattern (the union of
+ * their nonzeros) -- osqp_setup once, then for every problem `reps` x (osqp_update of all coefficients + osqp_solve), as
+ * `Parametron.solve!` does every tick (momentum.jl:58).  warm = 0: every solve from a cold start; warm = 1: from the previous
+ * solution of the SAME problem (its first solve, cold, is not counted).  us[k]: mean microseconds per solve; iters[k], status[k]: of
+ * the last one.  Returns 0, or -1 when the set-up fails. */
+#include <time.h>
+int ora_qp_time(int n, int m, int k, const double *P, const double *q, const double *A, const double *l, const double *u,
+                const ora_osqp_settings *st, int reps, int warm, double *us, int *iters, int *status) {
+  int *Pp = ialloc(n + 1), *Ap = ialloc(n + 1);
+  int pn = 0, an = 0;
+  const long long nn = (long long)n * n, mn = (long long)m * n;
+#define ANY_P(i, j) ({ int f__ = (i) == (j); for (int b__ = 0; b__ < k && !f__; b__++) f__ = P[b__ * nn + (i) * n + (j)] != 0.0 || P[b__ * nn + (j) * n + (i)] != 0.0; f__; })
+#define ANY_A(i, j) ({ int f__ = 0; for (int b__ = 0; b__ < k && !f__; b__++) f__ = A[b__ * mn + (long long)(i) * n + (j)] != 0.0; f__; })
+  for (int j = 0; j < n; j++) {
+    for (int i = 0; i <= j; i++) if (ANY_P(i, j)) pn++;
+    Pp[j + 1] = pn;
+    for (int i = 0; i < m; i++) if (ANY_A(i, j)) an++;
+    Ap[j + 1] = an;
+  }
+  int *Pi = ialloc(pn), *Ai = ialloc(an);
+  double *Px = dalloc(pn), *Ax = dalloc(an), *x = dalloc(n), *y = dalloc(m > 0 ? m : 1);
+  pn = an = 0;
+  for (int j = 0; j < n; j++) {
+    for (int i = 0; i <= j; i++) if (ANY_P(i, j)) Pi[pn++] = i;
+    for (int i = 0; i < m; i++) if (ANY_A(i, j)) Ai[an++] = i;
+  }
+  ora_osqp_settings s2 = *st;
+  s2.warm_start = warm ? 1 : 0;
+  ora_osqp *w = ora_osqp_setup(n, m, Pp, Pi, Ap, Ai, &s2);
+  int rc = w ? 0 : -1;
+  for (int b = 0; b < k && w; b++) {
+    for (int e = 0; e < Pp[n]; e++) { int j = 0; while (Pp[j + 1] <= e) j++; Px[e] = 0.5 * (P[b * nn + Pi[e] * n + j] + P[b * nn + j * n + Pi[e]]); }
+    for (int e = 0; e < Ap[n]; e++) { int j = 0; while (Ap[j + 1] <= e) j++; Ax[e] = A[b * mn + (long long)Ai[e] * n + j]; }
+    ora_tick_info info;
+    ora_osqp_cold_start(w);
+    if (warm) { ora_osqp_update(w, Px, q + b * n, Ax, l + b * m, u + b * m); ora_osqp_solve(w, x, y, &info); }
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int r = 0; r < reps; r++) {
+      if (!warm) ora_osqp_cold_start(w);
+      ora_osqp_update(w, Px, q + b * n, Ax, l + b * m, u + b * m);
+      status[b] = ora_osqp_solve(w, x, y, &info);
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    us[b] = ((t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3) / (reps > 0 ? reps : 1);
+    iters[b] = info.iters;
+  }
+#undef ANY_P
+#undef ANY_A
+  if (w) ora_osqp_free(w);
+  free(Pp); free(Ap); free(Pi); free(Ai); free(Px); free(Ax); free(x); free(y);
+  return rc;
+}

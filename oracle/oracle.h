@@ -169,6 +169,9 @@ int ora_tick_batch(ora_ctrl *c, int64_t B, const double *q, const double *v, con
 /* ------------------------------------------------------------------------------------------
  * generic dense-input QP solve in OSQP form (backs the L0 parity tests)
  * ---------------------------------------------------------------------------------------- */
+/* timing of the OSQP restatement on k dense problems of one pattern (setup once; update + solve `reps` times each), ora_osqp.c */
+int ora_qp_time(int n, int m, int k, const double *P, const double *q, const double *A, const double *l, const double *u,
+                const ora_osqp_settings *st, int reps, int warm, double *us, int *iters, int *status);
 int ora_qp_solve(int n, int m, const double *P, const double *q, const double *A, const double *l,
                  const double *u, const ora_osqp_settings *st, double *x, double *y,
                  ora_tick_info *info);

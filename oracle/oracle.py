@@ -345,3 +345,19 @@ def qp_solve(P, q, A, l, u, settings=None):
     rc = L.ora_qp_solve(n, m, _p(P), _p(q), _p(A), _p(l), _p(u), ctypes.byref(st), _p(x), _p(y),
                         ctypes.byref(info))
     return dict(status=rc, x=x, y=y[:m], info=info)
+
+
+def qp_time(P, q, A, l, u, settings, reps=5, warm=False):
+    """Microseconds per solve of the OSQP restatement on k dense problems of one pattern: setup once, then per problem `reps` x
+    (update of all coefficients + solve) -- what `Parametron.solve!` costs the reference's optimizer every tick (momentum.jl:58).
+    warm: from the previous solution of the same problem.  -> dict(us[k], iters[k], status[k])"""
+    L = lib()
+    P, A = np.ascontiguousarray(P, dtype=np.float64), np.ascontiguousarray(A, dtype=np.float64)
+    k, n, m = P.shape[0], P.shape[1], A.shape[1]
+    q = np.ascontiguousarray(q, dtype=np.float64); l = np.ascontiguousarray(np.clip(l, -1e30, 1e30)); u = np.ascontiguousarray(np.clip(u, -1e30, 1e30))
+    us = np.zeros(k); iters = np.zeros(k, dtype=np.int32); status = np.zeros(k, dtype=np.int32)
+    L.ora_qp_time.restype = ctypes.c_int
+    rc = L.ora_qp_time(ctypes.c_int(n), ctypes.c_int(m), ctypes.c_int(k), _p(P), _p(q), _p(A), _p(l), _p(u), ctypes.byref(settings), ctypes.c_int(reps),
+                       ctypes.c_int(int(warm)), _p(us), iters.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), status.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+    assert rc == 0
+    return dict(us=us, iters=iters, status=status)

@@ -102,6 +102,8 @@ def load_library(path=None):
         L.qpc_qp_free.restype = None
         L.qpc_qp_analyze.argtypes = [vp, c_double_p, c_double_p]
         L.qpc_qp_plan_info.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), i32]
+        L.qpc_qp_enable_timing.argtypes = [vp, i32]
+        L.qpc_qp_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
     L.qpc_assemble_solve_batch.argtypes = [vp, i64] + [c_double_p] * 11 + [c_double_p, c_double_p, c_int32_p, c_int32_p]
     L.qpc_sim_step_batch.argtypes = [vp, i64, c_double_p, c_double_p, c_double_p, c_int32_p, ctypes.POINTER(SimParams), c_int32_p]
     L.qpc_rollout_batch.argtypes = [vp, i64, i64] + [c_double_p] * 7 + [ctypes.POINTER(SimParams), c_double_p, c_int32_p, c_int32_p]
@@ -499,6 +501,14 @@ class QpProblem:
         u = np.ascontiguousarray(np.clip(u, -1e20, 1e20), dtype=np.float64).reshape(-1)[:self.m]
         _check(self.L, self.L.qpc_qp_analyze(self.h, _dp(l), _dp(u)), "qpc_qp_analyze")
         return self.plan_info()
+
+    def enable_timing(self, on=True):
+        _check(self.L, self.L.qpc_qp_enable_timing(self.h, int(bool(on))), "qpc_qp_enable_timing")
+
+    def last_kernel_ms(self):
+        ms = ctypes.c_double(0.0)
+        _check(self.L, self.L.qpc_qp_last_kernel_ms(self.h, ctypes.byref(ms)), "qpc_qp_last_kernel_ms")
+        return ms.value
 
     def plan_info(self):
         out = np.zeros(12, dtype=np.int64)

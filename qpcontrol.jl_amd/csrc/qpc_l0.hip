@@ -365,6 +365,9 @@ struct qpc_qp_problem {
   size_t d_plan_ints = 0;
   int sp_lds_doubles = 0;                  // LDS the kernel is launched with (0: the plan does not fit)
   unsigned long long *d_stamps = nullptr;
+  bool timing = false;                     // qpc_qp_enable_timing: events around the kernels of a solve
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double last_kernel_ms = 0.0;
 };
 
 // the rows of a QP that are equalities (l == u): the kernel's own test
@@ -454,6 +457,19 @@ int32_t qpc_qp_analyze(qpc_qp_problem *p, const double *l, const double *u) {
   return qpc_qp_plan(p, eq);
 }
 
+int32_t qpc_qp_enable_timing(qpc_qp_problem *p, int32_t on) {
+  if (!p) { qpc_set_error("qpc_qp_enable_timing: null problem"); return QPC_ERR_INVALID_ARGUMENT; }
+  HIP_TRY(hipSetDevice(p->device));
+  if (on && !p->ev0) { HIP_TRY(hipEventCreate(&p->ev0)); HIP_TRY(hipEventCreate(&p->ev1)); }
+  p->timing = on != 0;
+  return QPC_OK;
+}
+int32_t qpc_qp_last_kernel_ms(const qpc_qp_problem *p, double *ms) {
+  if (!p || !ms) { qpc_set_error("qpc_qp_last_kernel_ms: bad arguments"); return QPC_ERR_INVALID_ARGUMENT; }
+  *ms = p->last_kernel_ms;
+  return QPC_OK;
+}
+
 int32_t qpc_qp_plan_info(const qpc_qp_problem *p, int64_t *out, int32_t n_out) {
   if (!p || !out || n_out < 0) { qpc_set_error("qpc_qp_plan_info: bad arguments"); return QPC_ERR_INVALID_ARGUMENT; }
   const qpc::QpSpPlanHost &P = p->plan;
@@ -479,6 +495,7 @@ void qpc_qp_free(qpc_qp_problem *p) {
   if (p->d_plan) (void)hipFree(p->d_plan);
   if (p->ws) (void)hipFree(p->ws);
   if (p->d_stamps) (void)hipFree(p->d_stamps);
+  if (p->ev0) { (void)hipEventDestroy(p->ev0); (void)hipEventDestroy(p->ev1); }
   delete p;
 }
 
@@ -583,12 +600,19 @@ int32_t qpc_qp_solve(qpc_qp_problem *p, int64_t B, const double *P_vals, const d
   }
   // after a workgroup kernel: the statuses (a small batch: all the outputs, in one copy); returns true when every QP is solved and
   // the outputs have been handed over
+  auto timed = [&]() { // after the stream has been synchronised
+    if (!p->timing) return;
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, p->ev0, p->ev1) == hipSuccess) p->last_kernel_ms = (double)ms; else (void)hipGetLastError();
+  };
   auto collect = [&](const char *who) -> bool {
+    if (p->timing) chk(hipEventRecord(p->ev1, p->stream), "hipEventRecord");
     if (staged) {
       char *ho = p->h_stage + in_bytes;
       chk(hipMemcpyAsync(ho, out0, out_bytes, hipMemcpyDeviceToHost, p->stream), "copy the outputs");
       chk(hipStreamSynchronize(p->stream), who);
       if (rc != QPC_OK) { (void)hipMemset(p->d_ticket, 0, sizeof(unsigned long long)); return false; }
+      timed();
       if (p->d_yprev) p->B_prev = B;
       memcpy(hst.data(), ho + ((char *)dst - out0), (size_t)B * sizeof(int32_t));
       bool left = false;
@@ -603,9 +627,12 @@ int32_t qpc_qp_solve(qpc_qp_problem *p, int64_t B, const double *P_vals, const d
     chk(hipMemcpyAsync(hst.data(), dst, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, p->stream), "copy status");
     chk(hipStreamSynchronize(p->stream), who);
     if (rc != QPC_OK) { (void)hipMemset(p->d_ticket, 0, sizeof(unsigned long long)); return false; }
+    timed();
     if (p->d_yprev) p->B_prev = B;
     return false;
   };
+  // (timing: the events bracket everything between the copies in and the copies out -- the kernels of the three forms)
+  if (p->timing) chk(hipEventRecord(p->ev0, p->stream), "hipEventRecord");
   bool left = true;
   if (rc == QPC_OK && sp) {
     const int lds_bytes = p->sp_lds_doubles * (int)sizeof(double);

@@ -68,11 +68,24 @@ def l0_main(batches):
         ts = np.array(ts) * 1e6
         out[str(B)] = {"median_us": float(np.median(ts)), "max_us": float(ts.max()), "solves_per_s": float(B / np.median(ts) * 1e6),
                        "max_abs_err_vdot_vs_fixture": err}
-    # the same problems through the PREPARED entry (qpc_qp_setup once, qpc_qp_solve per call: values only, 13 KB per QP), cold and
-    # warm-started from the previous call's multipliers -- what QPCOptimizer (julia/QPControlHIPMOI.jl, moi.py) does every tick
+    out["prepared"] = prepared_entry(P, q, A, l, u, x, nv, batches)
+    # the problems with a matrix-weighted MomentumRateTask (a 6 x 6 block in P: momentum.jl:113-117, test/controller.jl:232-285)
+    Pm, qm, Am, lm, um, xm, nvm = load_l0_fixture("matrix")
+    out["prepared_matrix_weight"] = prepared_entry(Pm, qm, Am, lm, um, xm, nvm, [b for b in batches if b == 1])
+    print(json.dumps(out))
+
+
+def prepared_entry(P, q, A, l, u, x, nv, batches):
+    """the PREPARED entry (qpc_qp_setup once, qpc_qp_solve per call: values only, 13 KB per QP), cold and warm-started from the previous
+    call's multipliers -- what QPCOptimizer (julia/QPControlHIPMOI.jl, moi.py) does every tick.  "warm" here = the same problem solved
+    again from its own multipliers: the best case of a warm start (bench.py times the CPU's OSQP in the same way beside it)"""
+    k = P.shape[0]
     pr = binding.QpProblem(P.shape[1], A.shape[1], (P != 0).any(0), (A != 0).any(0))
     Pv, Av = pr.values(P, A)
-    prep = {"B1_per_problem": []}
+    pr.analyze(l[0], u[0])  # (what an optimizer does once after `MOI.copy_to`: the first solve is then not the slow one)
+    pr.enable_timing(True)
+    prep = {"n": int(P.shape[1]), "m": int(A.shape[1]), "plan": pr.plan_info(), "B1_per_problem": [],
+            "warm_means": "the same problem solved again from its own multipliers"}
     for b in range(k):
         a = (Pv[b], q[b], Av[b], l[b], u[b])
         r = pr.solve(*a)
@@ -85,8 +98,10 @@ def l0_main(batches):
             t0 = time.perf_counter()
             rw = pr.solve(*a, warm_start=True)
             tw.append(time.perf_counter() - t0)
+        assert r["status"][0] == 0 and rw["status"][0] == 0
         prep["B1_per_problem"].append({"iters": int(r["iters"][0]), "cold_median_us": float(np.median(tc) * 1e6),
-                                       "warm_iters": int(rw["iters"][0]), "warm_median_us": float(np.median(tw) * 1e6)})
+                                       "warm_iters": int(rw["iters"][0]), "warm_median_us": float(np.median(tw) * 1e6),
+                                       "max_abs_err_vdot_vs_fixture": float(np.abs(r["x"][0, :nv] - x[b, :nv]).max())})
     prep["B1_cold_median_over_problems_us"] = float(np.median([p["cold_median_us"] for p in prep["B1_per_problem"]]))
     prep["B1_cold_worst_problem_us"] = float(max(p["cold_median_us"] for p in prep["B1_per_problem"]))
     prep["B1_warm_median_over_problems_us"] = float(np.median([p["warm_median_us"] for p in prep["B1_per_problem"]]))
@@ -99,20 +114,20 @@ def l0_main(batches):
         r = pr.solve(*a)
         assert (r["status"] == 0).all(), r["status"]
         err = float(np.abs(r["x"][:, :nv] - x[idx][:, :nv]).max())
-        tc, tw = [], []
+        tc, tw, kc, kw = [], [], [], []
         for _ in range(3):
             t0 = time.perf_counter()
             pr.solve(*a)
-            tc.append(time.perf_counter() - t0)
+            tc.append(time.perf_counter() - t0); kc.append(pr.last_kernel_ms())
         for _ in range(3):
             t0 = time.perf_counter()
             pr.solve(*a, warm_start=True)
-            tw.append(time.perf_counter() - t0)
+            tw.append(time.perf_counter() - t0); kw.append(pr.last_kernel_ms())
         prep[str(B)] = {"cold_solves_per_s": float(B / np.median(tc)), "warm_solves_per_s": float(B / np.median(tw)),
+                        "cold_kernel_ms": float(np.median(kc)), "warm_kernel_ms": float(np.median(kw)),  # HIP events around the kernels
                         "max_abs_err_vdot_vs_fixture": err}
     pr.close()
-    out["prepared"] = prep
-    print(json.dumps(out))
+    return prep
 
 
 def main():
