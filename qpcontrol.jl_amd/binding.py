@@ -495,6 +495,21 @@ class QpProblem:
         _check(self.L, rc, "qpc_qp_solve")
         return dict(x=x, y=y[:, :self.m], status=status, iters=iters)
 
+    def solve_raw(self, P_vals, q, A_vals, l, u, out=None, warm_start=False):
+        """qpc_qp_solve on arrays the caller has prepared -- C-contiguous float64 [B, .] with infinite bounds already clipped to +-1e20 --
+        and (optionally) into the caller's own output arrays `out` = dict(x, y, status, iters): nothing is copied or allocated on the way
+        (what a caller with preallocated buffers -- the Julia shim -- pays per call); page-locked arrays (`pinned_array`) let a large
+        batch move in chunks beside the kernels"""
+        B = q.shape[0]
+        if out is None:
+            out = dict(x=np.zeros((B, self.n)), y=np.zeros((B, max(self.m, 1))), status=np.zeros(B, dtype=np.int32), iters=np.zeros(B, dtype=np.int32))
+        for a in (P_vals, q, A_vals, l, u, out["x"], out["y"]):
+            assert a.dtype == np.float64 and a.flags.c_contiguous
+        rc = self.L.qpc_qp_solve(self.h, B, _dp(P_vals), _dp(q), _dp(A_vals), _dp(l), _dp(u), None, int(bool(warm_start)), _dp(out["x"]), _dp(out["y"]),
+                                 out["status"].ctypes.data_as(c_int32_p), out["iters"].ctypes.data_as(c_int32_p))
+        _check(self.L, rc, "qpc_qp_solve")
+        return out
+
     def analyze(self, l, u):
         """the plan of the sparse workgroup solver for the equality rows of one QP's bounds, ahead of the first solve (qpc_qp_analyze)"""
         l = np.ascontiguousarray(np.clip(l, -1e20, 1e20), dtype=np.float64).reshape(-1)[:self.m]

@@ -365,6 +365,8 @@ struct qpc_qp_problem {
   size_t d_plan_ints = 0;
   int sp_lds_doubles = 0;                  // LDS the kernel is launched with (0: the plan does not fit)
   unsigned long long *d_stamps = nullptr;
+  hipStream_t stream2 = nullptr;           // a LARGE batch goes in chunks over two streams: a chunk's copies beside the other's kernel
+  unsigned long long *d_ticket2 = nullptr;
   bool timing = false;                     // qpc_qp_enable_timing: events around the kernels of a solve
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double last_kernel_ms = 0.0;
@@ -496,6 +498,8 @@ void qpc_qp_free(qpc_qp_problem *p) {
   if (p->ws) (void)hipFree(p->ws);
   if (p->d_stamps) (void)hipFree(p->d_stamps);
   if (p->ev0) { (void)hipEventDestroy(p->ev0); (void)hipEventDestroy(p->ev1); }
+  if (p->stream2) { (void)hipStreamSynchronize(p->stream2); (void)hipStreamDestroy(p->stream2); }
+  if (p->d_ticket2) (void)hipFree(p->d_ticket2);
   delete p;
 }
 
@@ -564,7 +568,20 @@ int32_t qpc_qp_solve(qpc_qp_problem *p, int64_t B, const double *P_vals, const d
     if (hipHostMalloc(&p->h_stage, (size_t)1 << 20, hipHostMallocDefault) == hipSuccess) p->h_stage_bytes = (size_t)1 << 20; else (void)hipGetLastError();
   }
   const bool staged = small && p->h_stage != nullptr;
-  if (staged) { // the same layout in the page-locked buffer, one copy
+  // a LARGE batch through the sparse form moves in chunks over two streams: what bounds the call is the copy of the values over PCIe
+  // (13 KB per Atlas problem: 106 MB for 8 192) -- the kernel of one chunk runs while the host stages the next one's inputs
+  const int64_t chunk = 1024;
+  bool piped = sp && !staged && B >= 4 * chunk && !p->timing;
+  if (piped) {
+    const char *e = getenv("QPC_L0_NO_CHUNKS");
+    if (e && e[0] == '1') piped = false;
+    if (piped && !p->stream2) {
+      if (hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking) != hipSuccess || hipMalloc(&p->d_ticket2, sizeof(unsigned long long)) != hipSuccess ||
+          hipMemset(p->d_ticket2, 0, sizeof(unsigned long long)) != hipSuccess) { (void)hipGetLastError(); piped = false; }
+    }
+  }
+  if (piped) { // (the copies are part of the chunk loop below)
+  } else if (staged) { // the same layout in the page-locked buffer, one copy
     char *h = p->h_stage;
     if (nPv) memcpy(h + ((char *)dPv - p->buf), P_vals, nPv * 8);
     memcpy(h + ((char *)dq - p->buf), q, nq * 8);
@@ -643,10 +660,47 @@ int32_t qpc_qp_solve(qpc_qp_problem *p, int64_t B, const double *P_vals, const d
     if (const char *eg = getenv("QPC_L0_GRID")) grid = atoi(eg) > 0 ? atoi(eg) : grid; // (profiling build: several QPs through ONE workgroup)
     if (!p->d_stamps) { if (hipMalloc(&p->d_stamps, 32 * sizeof(unsigned long long)) != hipSuccess) { (void)hipGetLastError(); p->d_stamps = nullptr; } }
 #endif
-    hipLaunchKernelGGL(qpc_qp_sp_kernel, dim3((unsigned)grid), dim3(QPC_SP_THREADS), (size_t)lds_bytes, p->stream, (const int *)p->d_plan,
-                       p->sp_lds_doubles, (long long)B, nnzP, dPv, dq, dAv, dl, du, st, y0, dx, dy, dst, dit, p->d_ticket, p->d_yprev, p->d_stamps);
-    chk(hipGetLastError(), "qpc_qp_sp_kernel");
-    if (collect("qpc_qp_sp_kernel")) return QPC_OK;
+    if (piped) {
+      hipStream_t strm[2] = {p->stream, p->stream2};
+      unsigned long long *tick[2] = {p->d_ticket, p->d_ticket2};
+      const int64_t nchunk = (B + chunk - 1) / chunk;
+      auto out_copy = [&](int64_t c) { // (a copy into pageable memory returns when it is done: issued one chunk late, it waits beside the next kernel)
+        const int64_t b0 = c * chunk, nb = std::min(chunk, B - b0);
+        hipStream_t sm = strm[c & 1];
+        chk(hipMemcpyAsync(x + b0 * n, dx + b0 * n, (size_t)nb * n * 8, hipMemcpyDeviceToHost, sm), "copy x");
+        chk(hipMemcpyAsync(y + b0 * m, dy + b0 * m, (size_t)nb * m * 8, hipMemcpyDeviceToHost, sm), "copy y");
+        chk(hipMemcpyAsync(hst.data() + b0, dst + b0, (size_t)nb * sizeof(int32_t), hipMemcpyDeviceToHost, sm), "copy status");
+        if (iters) chk(hipMemcpyAsync(iters + b0, dit + b0, (size_t)nb * sizeof(int32_t), hipMemcpyDeviceToHost, sm), "copy iters");
+      };
+      for (int64_t c = 0; c < nchunk && rc == QPC_OK; c++) {
+        const int64_t b0 = c * chunk, nb = std::min(chunk, B - b0);
+        hipStream_t sm = strm[c & 1];
+        if (nnzP) chk(hipMemcpyAsync(dPv + b0 * nnzP, P_vals + b0 * nnzP, (size_t)nb * nnzP * 8, hipMemcpyHostToDevice, sm), "copy P values");
+        chk(hipMemcpyAsync(dq + b0 * n, q + b0 * n, (size_t)nb * n * 8, hipMemcpyHostToDevice, sm), "copy q");
+        if (nnzA) chk(hipMemcpyAsync(dAv + b0 * nnzA, A_vals + b0 * nnzA, (size_t)nb * nnzA * 8, hipMemcpyHostToDevice, sm), "copy A values");
+        chk(hipMemcpyAsync(dl + b0 * m, l + b0 * m, (size_t)nb * m * 8, hipMemcpyHostToDevice, sm), "copy l");
+        chk(hipMemcpyAsync(du + b0 * m, u + b0 * m, (size_t)nb * m * 8, hipMemcpyHostToDevice, sm), "copy u");
+        const long long g = nb < grid ? nb : grid;
+        hipLaunchKernelGGL(qpc_qp_sp_kernel, dim3((unsigned)g), dim3(QPC_SP_THREADS), (size_t)lds_bytes, sm, (const int *)p->d_plan, p->sp_lds_doubles,
+                           (long long)nb, nnzP, dPv + b0 * nnzP, dq + b0 * n, dAv + b0 * nnzA, dl + b0 * m, du + b0 * m, st, y0 ? y0 + b0 * m : nullptr,
+                           dx + b0 * n, dy + b0 * m, dst + b0, dit + b0, tick[c & 1], p->d_yprev ? p->d_yprev + b0 * m : nullptr, p->d_stamps);
+        chk(hipGetLastError(), "qpc_qp_sp_kernel");
+        if (c >= 1) out_copy(c - 1);
+      }
+      if (rc == QPC_OK) out_copy(nchunk - 1);
+      chk(hipStreamSynchronize(p->stream), "qpc_qp_sp_kernel");
+      chk(hipStreamSynchronize(p->stream2), "qpc_qp_sp_kernel");
+      if (rc != QPC_OK) { (void)hipMemset(p->d_ticket, 0, sizeof(unsigned long long)); (void)hipMemset(p->d_ticket2, 0, sizeof(unsigned long long)); return rc; }
+      if (p->d_yprev) p->B_prev = B;
+      bool any_left = false;
+      for (int64_t b = 0; b < B; b++) any_left = any_left || hst[(size_t)b] == QPC_WG_FALLBACK;
+      if (!any_left) { for (int64_t b = 0; b < B; b++) status[b] = hst[(size_t)b]; return QPC_OK; }
+    } else {
+      hipLaunchKernelGGL(qpc_qp_sp_kernel, dim3((unsigned)grid), dim3(QPC_SP_THREADS), (size_t)lds_bytes, p->stream, (const int *)p->d_plan,
+                         p->sp_lds_doubles, (long long)B, nnzP, dPv, dq, dAv, dl, du, st, y0, dx, dy, dst, dit, p->d_ticket, p->d_yprev, p->d_stamps);
+      chk(hipGetLastError(), "qpc_qp_sp_kernel");
+      if (collect("qpc_qp_sp_kernel")) return QPC_OK;
+    }
     if (rc != QPC_OK) return rc;
     left = false;
     for (int64_t b = 0; b < B; b++) left = left || hst[(size_t)b] == QPC_WG_FALLBACK;

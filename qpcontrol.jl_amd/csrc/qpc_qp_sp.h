@@ -436,7 +436,8 @@ QPC_FN void sp_front_factor(double *V, int base, int r, int w, const double *ref
 // jobs j0 .. j1-1, the wavefronts wave0 .. QPC_SP_NWAVE-1 taking them in turn
 QPC_FN void sp_update_jobs(const QpSp &W, int j0, int j1, int wave0) {
   const int *pl = W.pl;
-  const int *job = pl + pl[SP_O_JOB], *slot = pl + pl[SP_O_SLOT], *map = pl + pl[SP_O_MAP];
+  const int *job = pl + pl[SP_O_JOB], *slot = pl + pl[SP_O_SLOT];
+  const short *map = (const short *)(pl + pl[SP_O_MAP]);
   double *V = W.V;
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef double sp_v4d __attribute__((ext_vector_type(4)));
@@ -467,7 +468,7 @@ QPC_FN void sp_update_jobs(const QpSp &W, int j0, int j1, int wave0) {
     }
     for (int ch = 0; ch < nch; ch++) {
       const int *sl = slot + (s0 + 4 * ch + kq) * SP_SLOT_INTS;
-      const int cb = sl[0], dp = sl[1], mp = sl[2];
+      const int cb = sl[0] & 0xfffff, dp = sl[0] >> 20, mp = sl[1];
       const int mpc = mp < 0 ? 0 : mp;
       const int ra = map[mpc * 32 + ll], rb = map[mpc * 32 + 16 + ll];
       const double av = V[cb + (ra < 0 ? 0 : ra)], bv = V[cb + (rb < 0 ? 0 : rb)], dv = W.dinv[dp];
@@ -486,9 +487,9 @@ QPC_FN void sp_update_jobs(const QpSp &W, int j0, int j1, int wave0) {
         double s = 0.0;
         for (int k = s0; k < s0 + 4 * nch; k++) {
           const int *sl = slot + k * SP_SLOT_INTS;
-          if (sl[2] < 0) continue;
-          const int ra = map[sl[2] * 32 + lr - r0], rb = map[sl[2] * 32 + 16 + lc - c0];
-          if (ra >= 0 && rb >= 0) s += V[sl[0] + ra] * (V[sl[0] + rb] * W.dinv[sl[1]]);
+          if (sl[1] < 0) continue;
+          const int ra = map[sl[1] * 32 + lr - r0], rb = map[sl[1] * 32 + 16 + lc - c0], cb = sl[0] & 0xfffff;
+          if (ra >= 0 && rb >= 0) s += V[cb + ra] * (V[cb + rb] * W.dinv[sl[0] >> 20]);
         }
         V[tstride ? tbase + lc * tstride + lr : tbase + sp_sidx(lr, lc, trows)] -= s;
       }

@@ -30,7 +30,7 @@ enum QpSpHeader {
   SP_O_JOBLV,   // 2 nlevel + 1: update jobs of level l: [2 l] .. [2 l + 1] into the fronts of level l + 1, [2 l + 1] .. [2 l + 2] the others
   SP_O_JOB,     // njob x SP_JOB_INTS
   SP_O_SLOT,    // x SP_SLOT_INTS: the columns an update job sums over, padded to multiples of four per job
-  SP_O_MAP,     // x 32: target row / column of a job's tile -> row of the source front (or -1)
+  SP_O_MAP,     // x 16 (32 x 16 bits): target row / column of a job's tile -> row of the source front (or -1)
   SP_O_OPS,     // SP_NOPS x SP_OP_INTS: the sparse products (below)
   SP_O_OPDATA,  // their tables
   SP_O_COLFRONT,// ne: the front of an equality position
@@ -51,7 +51,7 @@ enum QpSpHeader {
 };
 enum { SP_FRONT_INTS = 6 }; // base, rows, width, first position, offset of its row positions, first target among its level's in the solves' products
 enum { SP_JOB_INTS = 8 };   // target base, target stride (0: packed C), target rows, target columns, first row, first column, first slot, chunks
-enum { SP_SLOT_INTS = 3 };  // address of the source column, position of its pivot, map (-1: a padding slot)
+enum { SP_SLOT_INTS = 2 };  // address of the source column | position of its pivot << 20, map (-1: a padding slot)
 // A sparse product: out[target] = sum of val[addr] * vec[idx] over the target's terms, a term packed as (addr << 9) | idx.  What bounds
 // such a sum on one thread is the latency of its dependent LDS loads (index -> value), so a target's terms are cut into SEGMENTS of at
 // most SP_SEG terms: a thread per segment, then a thread per target adds its segments' sums in order -- the 76 terms of a wrench

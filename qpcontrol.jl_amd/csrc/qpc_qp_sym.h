@@ -294,7 +294,7 @@ inline bool qp_sp_plan_build(const QpPrepHost &H, const uint8_t *eq, QpSpPlanHos
   // ---- the sparse products of the solves (qpc_qp_spview.h): targets with their terms, cut into segments
   struct Op { std::vector<int> tpos; std::vector<std::vector<int>> terms; };
   auto pack = [](int addr, int idx) { return (addr << 9) | idx; };
-  if (nval >= (1 << 22) || N1 > 511 || nnzA >= (1 << 22)) return fail("too large for the packed terms");
+  if (nval >= (1 << 20) || N1 > 511 || nnzA >= (1 << 22)) return fail("too large for the packed terms");
   std::vector<Op> ops(SP_OP_FWD0 + 2 * nlevel);
   for (int p = 0; p < m; p++) { // A w by row position
     const int r = perm[p];
@@ -404,11 +404,11 @@ inline bool qp_sp_plan_build(const QpPrepHost &H, const uint8_t *eq, QpSpPlanHos
         const int s0 = (int)slots.size() / SP_SLOT_INTS;
         for (size_t k = 0; k < J.srcs.size(); k++) {
           const Front &F = fr[J.srcs[k]];
-          const int mp = (int)maps.size() / 32;
-          maps.insert(maps.end(), J.maps[k].begin(), J.maps[k].end());
-          for (int c = 0; c < F.w; c++) slots.insert(slots.end(), {F.base + c * F.r(), F.c0 + c, mp});
+          const int mp = (int)maps.size() / 16;
+          for (int e = 0; e < 32; e += 2) maps.push_back((J.maps[k][e] & 0xffff) | (J.maps[k][e + 1] << 16)); // (16 bits each: a front has at most 2 QPC_SP_DIM rows; -1 stays -1)
+          for (int c = 0; c < F.w; c++) slots.insert(slots.end(), {(F.base + c * F.r()) | ((F.c0 + c) << 20), mp});
         }
-        while ((slots.size() / SP_SLOT_INTS - s0) % 4) slots.insert(slots.end(), {0, 0, -1});
+        while ((slots.size() / SP_SLOT_INTS - s0) % 4) slots.insert(slots.end(), {0, -1});
         jt.insert(jt.end(), {J.tbase, J.tstride, J.trows, J.tcols, J.r0, J.c0, s0, (int)(slots.size() / SP_SLOT_INTS - s0) / 4});
         njob++;
       }

@@ -499,6 +499,12 @@ int32_t qpc_qp_analyze(qpc_qp_problem *p, const double *l, const double *u) {
   if (!p->plan_tried || eq != p->plan.eq) { qpc::qp_sp_plan_build(p->H, eq.data(), p->plan); p->plan_tried = true; if (!p->plan.valid) p->plan.eq = eq; }
   return QPC_OK;
 }
+// the plan's int array (diagnostics of the tests): returns its length, copies at most n ints
+int emu_l0_plan_ints(qpc_qp_problem *p, int *out, int n) {
+  if (!p || !p->plan_tried || !p->plan.valid) return 0;
+  for (int i = 0; i < n && i < (int)p->plan.ints.size(); i++) out[i] = p->plan.ints[i];
+  return (int)p->plan.ints.size();
+}
 int32_t qpc_qp_enable_timing(qpc_qp_problem *, int32_t) { return QPC_OK; }
 int32_t qpc_qp_last_kernel_ms(const qpc_qp_problem *, double *ms) { if (ms) *ms = 0.0; return QPC_OK; }
 int32_t qpc_qp_plan_info(const qpc_qp_problem *p, int64_t *out, int32_t n_out) {

@@ -83,25 +83,29 @@ def prepared_entry(P, q, A, l, u, x, nv, batches):
     pr = binding.QpProblem(P.shape[1], A.shape[1], (P != 0).any(0), (A != 0).any(0))
     Pv, Av = pr.values(P, A)
     pr.analyze(l[0], u[0])  # (what an optimizer does once after `MOI.copy_to`: the first solve is then not the slow one)
-    pr.enable_timing(True)
     prep = {"n": int(P.shape[1]), "m": int(A.shape[1]), "plan": pr.plan_info(), "B1_per_problem": [],
             "warm_means": "the same problem solved again from its own multipliers"}
+    # (timed: the call itself on arrays prepared beforehand -- contiguous, bounds clipped, outputs preallocated: what a caller with its
+    #  own buffers pays, the Julia shim among them; `QpProblem.solve` clips and allocates on every call, a millisecond at B = 8 192)
+    lc, uc = np.clip(l, -1e20, 1e20), np.clip(u, -1e20, 1e20)
     for b in range(k):
-        a = (Pv[b], q[b], Av[b], l[b], u[b])
-        r = pr.solve(*a)
+        a = tuple(np.ascontiguousarray(z[b:b + 1]) for z in (Pv, q, Av, lc, uc))
+        o = pr.solve_raw(*a)
         tc, tw = [], []
         for _ in range(10):
             t0 = time.perf_counter()
-            r = pr.solve(*a)
+            r = pr.solve_raw(*a, out=o)
             tc.append(time.perf_counter() - t0)
+        itc, xc = int(r["iters"][0]), r["x"][0, :nv].copy()
+        assert r["status"][0] == 0
         for _ in range(10):
             t0 = time.perf_counter()
-            rw = pr.solve(*a, warm_start=True)
+            rw = pr.solve_raw(*a, out=o, warm_start=True)
             tw.append(time.perf_counter() - t0)
-        assert r["status"][0] == 0 and rw["status"][0] == 0
-        prep["B1_per_problem"].append({"iters": int(r["iters"][0]), "cold_median_us": float(np.median(tc) * 1e6),
+        assert rw["status"][0] == 0
+        prep["B1_per_problem"].append({"iters": itc, "cold_median_us": float(np.median(tc) * 1e6),
                                        "warm_iters": int(rw["iters"][0]), "warm_median_us": float(np.median(tw) * 1e6),
-                                       "max_abs_err_vdot_vs_fixture": float(np.abs(r["x"][0, :nv] - x[b, :nv]).max())})
+                                       "max_abs_err_vdot_vs_fixture": float(np.abs(xc - x[b, :nv]).max())})
     prep["B1_cold_median_over_problems_us"] = float(np.median([p["cold_median_us"] for p in prep["B1_per_problem"]]))
     prep["B1_cold_worst_problem_us"] = float(max(p["cold_median_us"] for p in prep["B1_per_problem"]))
     prep["B1_warm_median_over_problems_us"] = float(np.median([p["warm_median_us"] for p in prep["B1_per_problem"]]))
@@ -110,22 +114,42 @@ def prepared_entry(P, q, A, l, u, x, nv, batches):
         if B == 1:
             continue
         idx = np.arange(B) % k
-        a = (Pv[idx], q[idx], Av[idx], l[idx], u[idx])
-        r = pr.solve(*a)
-        assert (r["status"] == 0).all(), r["status"]
-        err = float(np.abs(r["x"][:, :nv] - x[idx][:, :nv]).max())
-        tc, tw, kc, kw = [], [], [], []
-        for _ in range(3):
-            t0 = time.perf_counter()
-            pr.solve(*a)
-            tc.append(time.perf_counter() - t0); kc.append(pr.last_kernel_ms())
-        for _ in range(3):
-            t0 = time.perf_counter()
-            pr.solve(*a, warm_start=True)
-            tw.append(time.perf_counter() - t0); kw.append(pr.last_kernel_ms())
-        prep[str(B)] = {"cold_solves_per_s": float(B / np.median(tc)), "warm_solves_per_s": float(B / np.median(tw)),
-                        "cold_kernel_ms": float(np.median(kc)), "warm_kernel_ms": float(np.median(kw)),  # HIP events around the kernels
-                        "max_abs_err_vdot_vs_fixture": err}
+        res, kc, kw = {}, [], []
+        for mode in ("pageable", "page_locked"):  # the caller's arrays: plain numpy, or qpc_host_alloc'ed (what QPControlHIP.jl does with the buffers it owns)
+            mk = (lambda shape, dt=np.float64: binding.pinned_array(pr.L, shape, dt)) if mode == "page_locked" else (lambda shape, dt=np.float64: np.zeros(shape, dtype=dt))
+            a = []
+            for z in (Pv, q, Av, lc, uc):
+                zz = mk((B,) + z.shape[1:])
+                zz[...] = z[idx]
+                a.append(zz)
+            o = dict(x=mk((B, pr.n)), y=mk((B, max(pr.m, 1))), status=mk((B,), np.int32), iters=mk((B,), np.int32))
+            r = pr.solve_raw(*a, out=o)
+            assert (r["status"] == 0).all(), r["status"]
+            err = float(np.abs(r["x"][:, :nv] - x[idx][:, :nv]).max())
+            tc, tw = [], []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                pr.solve_raw(*a, out=o)
+                tc.append(time.perf_counter() - t0)
+            for _ in range(5):
+                t0 = time.perf_counter()
+                pr.solve_raw(*a, out=o, warm_start=True)
+                tw.append(time.perf_counter() - t0)
+            res[mode] = {"cold_solves_per_s": float(B / np.median(tc)), "warm_solves_per_s": float(B / np.median(tw)), "max_abs_err_vdot_vs_fixture": err}
+            if mode == "pageable":
+                pr.enable_timing(True)  # the kernel by itself: one launch for the whole batch between two HIP events (a timed call does not go in chunks)
+                for _ in range(3):
+                    pr.solve_raw(*a, out=o)
+                    kc.append(pr.last_kernel_ms())
+                for _ in range(3):
+                    pr.solve_raw(*a, out=o, warm_start=True)
+                    kw.append(pr.last_kernel_ms())
+                pr.enable_timing(False)
+        prep[str(B)] = {"cold_solves_per_s": res["pageable"]["cold_solves_per_s"], "warm_solves_per_s": res["pageable"]["warm_solves_per_s"],
+                        "page_locked_cold_solves_per_s": res["page_locked"]["cold_solves_per_s"],
+                        "page_locked_warm_solves_per_s": res["page_locked"]["warm_solves_per_s"],
+                        "cold_kernel_ms": float(np.median(kc)), "warm_kernel_ms": float(np.median(kw)),  # HIP events around the kernel
+                        "max_abs_err_vdot_vs_fixture": max(res["pageable"]["max_abs_err_vdot_vs_fixture"], res["page_locked"]["max_abs_err_vdot_vs_fixture"])}
     pr.close()
     return prep
 
