@@ -1132,12 +1132,18 @@ QPC_FN int qp_solve_sp(const int *plan_g, const int *plan_lds, const double *Pv,
       QPC_SP_SYNC
       QPC_SP_STAMP(W, lev < 2 ? 4 + 2 * lev : 8);
       const int nf = lev + 1 < W.nlevel ? lv[2 * lev + 3] - lv[2 * lev + 2] : 0; // (the next level's fronts of several columns: its single columns cost nothing)
-      if (nf > 0) fronts(lev + 1);
+      if (lev + 1 < W.nlevel) fronts(lev + 1);
       sp_update_jobs(W, jl[2 * lev + 1], jl[2 * lev + 2], nf < QPC_SP_NWAVE ? nf : 0);
       QPC_SP_SYNC
       QPC_SP_STAMP(W, lev < 2 ? 5 + 2 * lev : 8);
     }
   }
+#if defined(QPC_SP_DEBUG_DUMP) && !defined(__HIP_DEVICE_COMPILE__)
+  if (const char *dump = getenv("QPC_SP_DUMP")) { // (test emulation only: the store after the elimination)
+    FILE *f = fopen(dump, "wb");
+    if (f) { fwrite(W.V, 8, nval, f); fwrite(W.dinv, 8, ne, f); fwrite(W.gdiag, 8, m + 1, f); fclose(f); }
+  }
+#endif
   QPC_SP_FOR(p2, mi) {
     W.a0[p2] = W.V[W.Cb + sp_sidx(mi, p2, W.M1)];
     double w = 0.0;
