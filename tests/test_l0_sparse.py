@@ -183,6 +183,58 @@ def test_no_equality_rows_and_no_inequality_rows_emulated():
         pr.close()
 
 
+def _mini_fuzz(lib, seeds):
+    """small random problems of many shapes (sparse and dense rows, few and many equality rows, rank-deficient ones, blocks in P):
+    elimination trees of every kind -- chains, stars, levels that hold single-column fronts only -- against the oracle"""
+    n_ok = 0
+    for seed in seeds:
+        rng = np.random.default_rng(7000 + seed)
+        n, m = int(rng.integers(2, 40)), int(rng.integers(2, 60))
+        ne = int(rng.integers(0, min(n, m) + 1))
+        dens = rng.choice([0.05, 0.15, 0.4, 1.0])
+        P = np.diag(rng.uniform(0.05, 2.0, size=n))
+        if rng.uniform() < 0.4 and n >= 6:
+            idx = np.sort(rng.permutation(n)[:int(rng.integers(2, 6))])
+            M = rng.normal(size=(len(idx), len(idx)))
+            P[np.ix_(idx, idx)] = M @ M.T / len(idx) + np.diag(rng.uniform(0.1, 1.0, size=len(idx)))
+        q = rng.normal(size=n)
+        A = rng.normal(size=(m, n)) * (rng.uniform(size=(m, n)) < dens)
+        if rng.uniform() < 0.5:
+            A[np.arange(m), rng.integers(0, n, size=m)] += rng.uniform(0.5, 1.5, size=m)
+        b = A @ rng.normal(size=n)
+        l, u = b - rng.uniform(0.0, 0.6, size=m), b + rng.uniform(0.0, 0.6, size=m)
+        l[:ne] = u[:ne] = b[:ne]
+        l[ne::3] = -1e30
+        perm = rng.permutation(m)
+        A, l, u = A[perm], l[perm], u[perm]
+        ro = O.qp_solve(P, q, A, l, u)
+        if ro["status"] != 0:
+            continue
+        pr = binding.QpProblem(n, m, P != 0, (A != 0) | (rng.uniform(size=A.shape) < 0.02), lib_path=lib)
+        Pv, Av = pr.values(P, A)
+        r = pr.solve(Pv, q, Av, l, u)
+        assert pr.plan_info()["in_use"] == 1
+        assert r["status"][0] == 0, (seed, n, m, ne, r["status"])
+        np.testing.assert_allclose(r["x"][0], ro["x"], atol=2e-7, err_msg=f"seed {seed}")
+        pr.close()
+        n_ok += 1
+    return n_ok
+
+
+# (seeds 198, 226, 856, 1383: trees whose upper level holds single-column fronts only -- once never factored)
+MINI_FUZZ_SEEDS = list(range(150)) + [198, 226, 856, 1383]
+
+
+def test_mini_fuzz_emulated():
+    emu.build()
+    assert _mini_fuzz(emu.EMU_LIB, MINI_FUZZ_SEEDS) >= 100
+
+
+@pytest.mark.gpu
+def test_mini_fuzz_gpu():
+    assert _mini_fuzz(None, MINI_FUZZ_SEEDS) >= 100
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("which", ["diag", "matrix"])
 def test_fixture_gpu(which):
