@@ -12,7 +12,7 @@ import csv, glob, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if r["Kernel_Name"].startswith("qpc_qp_wg"):
+        if r["Kernel_Name"].startswith("qpc_qp_"):
             acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in acc.items():
     # the launch with the most wave cycles = the cold batch of 8 192
