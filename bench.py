@@ -7,13 +7,15 @@ states with inputs already resident in HBM.  Workload = BASELINE.json config 3 (
 ContactPoints, linearised friction cones, fp64) at 32768 QPs per GPU, so that `--gpus 8`
 reproduces config 4 (B = 262144 sharded over 8 GPUs, no collective in the data path) exactly.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (N > 1 without a launcher: this process starts the N ranks itself -- launch_ranks --
+                                                          and adds config.in_library_devices: one process driving N devices)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0.  Beside the headline (device-resident, timed region = K launches):
   config.secondary   the literal BASELINE batches on the same GPU, measured after the timed region:
                      config 2 @ 1024, config 3 @ 8192, config 5 @ 32768, config 3 @ 262144
   config.host_pointer_path_*   the host-pointer entry point the Julia shim binds (PCIe inclusive; never `value`)
+  config.per_rank    (N > 1) every rank's kernel time and wall time per step
   config.closed_loop controller tick + simulation step on the device, robot-steps/s
   roofline           HBM (algorithmic bytes) + fp64 (algorithmic flops) fractions of the tick kernel, live HIP events
   cpu_baseline       the oracle (CPU restatement of the reference path) on the host cores.  `value` = the regime the reference
@@ -528,9 +530,124 @@ def measured_issue(fingerprint):
 
 
 # ------------------------------------------------------------------------------------------ main
+def in_library_leg(n_dev, B, steps, warmup, config, ids=None, lib_path=None):
+    """BASELINE config 4's split the way `QPControlHIP.jl`'s `finalize!(...; devices = ...)` does it: ONE process,
+    qpc_finalize_devices(ctrl, N, ids), a device-resident shard of B QPs on every device, the same timed loop
+    (W untimed + K timed steps; a step = one launch per device through qpc_control_batch_device_on, then every device synchronised).
+    ids: the devices (default 0 .. N-1; the test hook QPC_BENCH_TEST_ONE_DEVICE=1 puts every shard on device 0).  lib_path: another
+    build of the library -- the CPU test runs this leg on the emulation's fake devices (numpy arrays instead of torch tensors).  -> dict"""
+    torch = None
+    if lib_path is None:
+        import torch
+    import qpc_pkg
+    qpc_pkg.load()
+    from qpcontrol_jl_amd import binding
+    from qpcontrol_jl_amd import workloads as W
+    if ids is None:
+        ids = [0] * n_dev if os.environ.get("QPC_BENCH_TEST_ONE_DEVICE") == "1" else list(range(n_dev))
+    real_finalize = binding.Controller.finalize
+
+    def fin(self_, device_id=0):
+        return real_finalize(self_, devices=ids)
+    binding.Controller.finalize = fin
+    try:
+        ctrl, wl0 = W.atlas_workload(lambda m, N, fl: binding.Controller(binding.Model(m, lib_path), N, fl), B, config, seed={2: 2024, 3: 2025, 5: 2027}[config])
+    finally:
+        binding.Controller.finalize = real_finalize
+    L, lay = ctrl.L, ctrl.layout
+    vp = ctypes.c_void_p
+    shards = []
+    for g, dev_id in enumerate(ids):
+        if g == 0:
+            wl = wl0
+        else:  # every shard its own seeded states (shard g of the global batch)
+            q, v = W.standing_states(wl0.mech, B, {2: 2024, 3: 2025, 5: 2027}[config] + 7919 * g)
+            wl = W.Workload(wl0.name, wl0.mech, wl0.setup, q, v, W.standing_desired(wl0.setup, q, v), wl0.contact_weight, wl0.contact_maxnormalforce,
+                            wl0.floating_body)
+        if torch is not None:
+            dev = torch.device("cuda", dev_id)
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)  # noqa: E731
+            mk = lambda shape, dt: torch.empty(shape, dtype=torch.float64 if dt == np.float64 else torch.int32, device=dev)  # noqa: E731
+        else:
+            t = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+            mk = lambda shape, dt: np.zeros(shape, dtype=dt)  # noqa: E731
+        sh = dict(q=t(wl.q), v=t(wl.v), des=t(wl.desired), cw=t(wl.contact_weight), cm=t(wl.contact_maxnormalforce),
+                  tau=mk((B, lay.nv), np.float64), vd=mk((B, lay.nv), np.float64), cwr=mk((B, max(lay.n_contacts, 1) * 6), np.float64),
+                  status=mk((B,), np.int32), iters=mk((B,), np.int32))
+        sh["stream"] = torch.cuda.Stream(device=dev) if torch is not None else None
+        shards.append(sh)
+
+    def step():
+        nc = lay.n_contacts
+        for g, sh in enumerate(shards):
+            p = (lambda x: vp(x.data_ptr()) if x.numel() else vp(0)) if torch is not None else (lambda x: vp(x.ctypes.data) if x.size else vp(0))  # noqa: E731
+            rc = L.qpc_control_batch_device_on(ctrl.h, g, B, p(sh["q"]), p(sh["v"]), p(sh["des"]), p(sh["cw"]) if nc else vp(0), p(sh["cm"]) if nc else vp(0),
+                                               vp(0), vp(0), p(sh["tau"]), p(sh["vd"]), p(sh["cwr"]) if nc else vp(0), p(sh["status"]), p(sh["iters"]),
+                                               vp(sh["stream"].cuda_stream) if sh["stream"] is not None else vp(0))
+            if rc != 0:
+                raise RuntimeError(L.qpc_last_error().decode())
+
+    def sync():
+        for sh in shards:
+            if sh["stream"] is not None:
+                sh["stream"].synchronize()
+    for _ in range(warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    el = time.perf_counter() - t0
+    opt = [float(((sh["status"].cpu().numpy() if torch is not None else sh["status"]) == 0).mean()) for sh in shards]
+    return {"n_devices": n_dev, "device_ids": ids, "batch_per_device": B, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * el / steps,
+            "solves_per_s": n_dev * B * steps / el, "optimal_fraction_per_device": opt,
+            "entry": "one process: qpc_finalize_devices + qpc_control_batch_device_on per device (device-resident shards, one stream per device)"}
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: the parent -- before anything here has touched the GPU -- starts N fresh child
+    processes of itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR = 127.0.0.1 / MASTER_PORT in their environment: the same
+    contract torch.distributed.run fulfils), lets rank 0's JSON line through, then adds the in-library leg (one process, N devices)
+    to it.  Exit code: non-zero when a child fails."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    line = None
+    for ln in (out0 or "").splitlines():
+        if ln.startswith("{"):
+            line = ln
+    if any(rcs) or line is None:
+        sys.stderr.write(f"bench.py: ranks exited with {rcs}\n")
+        if out0:
+            sys.stdout.write(out0)
+        raise SystemExit(1)
+    d = json.loads(line)
+    # the in-library leg in a process of its own (this one must stay clear of the GPU: it may be asked to launch again)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--in-library-leg", str(args.gpus), str(args.batch_per_gpu), str(args.steps), str(args.warmup),
+                        str(args.config)], capture_output=True, text=True)
+    try:
+        d["config"]["in_library_devices"] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    except Exception:  # noqa: BLE001
+        d["config"]["in_library_devices"] = {"error": (r.stderr or "no output")[-400:]}
+        d["degraded"] = True
+        d.setdefault("degraded_why", []).append("in_library_devices leg failed")
+    print(json.dumps(d))
+
+
 def main():
     if len(sys.argv) >= 5 and sys.argv[1] == "--cpu-worker":
         return _cpu_worker(int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]))
+    if len(sys.argv) >= 7 and sys.argv[1] == "--in-library-leg":
+        print(json.dumps(in_library_leg(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]))))
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -545,6 +662,8 @@ def main():
                     help="SURVEY 8 f-1: StandingController PD laws (standing.jl:58-89) evaluated in the kernel, no `desired` "
                          "input (a pure (q, v) -> tau map); default is the reference boundary with desireds as inputs")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args, sys.argv[1:])  # (no launcher: this process starts the ranks itself, before it touches the GPU)
 
     import torch
     import qpc_pkg
@@ -556,8 +675,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"WORLD_SIZE = {world} but --gpus {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     # QPC_BENCH_TEST_ONE_DEVICE=1 (test hook): every rank uses cuda:0 and the process group is gloo, so that the
@@ -599,8 +717,13 @@ def main():
     avg_ms, nl = ctypes.c_double(0), ctypes.c_int64(0)
     L.qpc_timing_read(ctrl.h, ctypes.byref(avg_ms), ctypes.byref(nl))
     L.qpc_timing_enable(ctrl.h, 0)
+    per_rank = None
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_device else dev)
+        mine = torch.tensor([avg_ms.value, elapsed * 1e3 / args.steps], dtype=torch.float64, device="cpu" if one_device else dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)  # (every rank's kernel time and wall time per step: a straggler GPU shows up here)
+        per_rank = [{"rank": r, "kernel_avg_ms": float(x[0]), "ms_per_step": float(x[1])} for r, x in enumerate(allr)]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st = run.status.cpu().numpy()
@@ -662,6 +785,7 @@ def main():
                                       "(143 vars / 114 eq / 64 ineq in the reference layout)" if args.config != 2
                                       else "no contacts (39 vars / 36 eq)"),
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"shard{world} (independent QPs, no collective)",
+                       "per_rank": per_rank,
                        "optimal_fraction": n_opt / B, "mean_active_set_iters": float(it.mean()),
                        "presolved_fraction": presolved,
                        "lds_bytes_per_qp": int(lay.lds_bytes_per_qp),

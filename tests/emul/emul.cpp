@@ -306,6 +306,18 @@ int32_t qpc_control_batch(qpc_controller *c, int64_t B, const double *q, const d
   int rc = fill_job(c, job, B, q, v, desired, cw, cmax, tw, surf, tau, vdot, cwrench, status, iters, nullptr);
   return rc != QPC_OK ? rc : run_job(c, job);
 }
+// the device-pointer entry of a multi-device controller, emulated: "device" memory is host memory, the shard is ticked on the caller's
+// thread (bench.py's in-library leg runs through this on emulated devices)
+int32_t qpc_control_batch_device_on(qpc_controller *c, int32_t device_index, int64_t B, const double *q, const double *v, const double *desired,
+                                    const double *cw, const double *cmax, const double *tw, const double *surf, double *tau, double *vdot,
+                                    double *cwrench, int32_t *status, int32_t *iters, void *) {
+  if (!c || device_index < 0 || device_index >= qpc_n_devices(c)) { qpc_set_error("qpc_control_batch_device_on: device index out of range"); return QPC_ERR_INVALID_ARGUMENT; }
+  QpcHostJob job;
+  int rc = fill_job(c, job, B, q, v, desired, cw, cmax, tw, surf, tau, vdot, cwrench, status, iters, nullptr);
+  if (rc != QPC_OK) return rc;
+  emu_ticks(c, job, 0, B);
+  return QPC_OK;
+}
 int32_t qpc_control_batch_warm(qpc_controller *c, int64_t B, const double *q, const double *v, const double *desired,
                                const double *cw, const double *cmax, const double *tw, const double *surf, double *tau,
                                double *vdot, double *cwrench, int32_t *status, int32_t *iters, uint64_t *working_set) {

@@ -89,3 +89,38 @@ def test_bench_two_ranks_on_one_device():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4096 and d["scaling"] == "weak" and d["value"] > 0
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only
+
+
+def test_in_library_leg_on_emulated_devices():
+    """bench.py's second multi-GPU leg -- ONE process, qpc_finalize_devices(ctrl, N, ids), a resident shard per device, a launch per device
+    and step through qpc_control_batch_device_on (what QPControlHIP.jl's `finalize!(...; devices = ...)` drives) -- on three fake devices of
+    the CPU emulation"""
+    import emu
+    emu.build()
+    sys.path.insert(0, ROOT)
+    import bench
+    r = bench.in_library_leg(3, 5, steps=2, warmup=1, config=3, ids=[0, 1, 2], lib_path=emu.EMU_LIB)
+    assert r["n_devices"] == 3 and r["batch_per_device"] == 5 and r["solves_per_s"] > 0
+    assert all(f >= 0.8 for f in r["optimal_fraction_per_device"]), r
+
+
+@pytest.mark.gpu
+def test_bench_without_a_launcher_two_ranks_on_one_device():
+    """`python bench.py --gpus 2` with NO launcher: the process starts its two ranks itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in
+    their environment), passes rank 0's line on with every rank's kernel time in it, and adds the in-library leg (one process, two
+    "devices": both cuda:0 through the QPC_BENCH_TEST_ONE_DEVICE hook).  The numbers mean nothing, the plumbing does."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, QPC_BENCH_TEST_ONE_DEVICE="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch-per-gpu", "2048"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4096 and d["value"] > 0
+    assert len(d["config"]["per_rank"]) == 2 and all(r["kernel_avg_ms"] > 0 for r in d["config"]["per_rank"])
+    lib = d["config"]["in_library_devices"]
+    assert lib["n_devices"] == 2 and lib["solves_per_s"] > 0 and all(f > 0.9 for f in lib["optimal_fraction_per_device"]), lib
