@@ -570,6 +570,19 @@ const char *qpc_status_string(int32_t status);
  * does not form a Farkas vector: the dual status names what OSQP would report, the certificate itself is not returned).
  * Any of the three output pointers may be NULL; returns QPC_ERR_INVALID_ARGUMENT for an unknown code. */
 int32_t qpc_status_triple(int32_t status, const char **termination, const char **primal, const char **dual);
+
+/* ---- `contactwrenches[BodyID(body)]` (momentum.jl:64-72): the reference hands inverse_dynamics! -- and leaves in its result -- ONE
+ *      wrench per body that carries contact points, the SUM of its points' wrenches (world frame, about the world origin); the tick's
+ *      `contact_wrench` output is per contact point (6 nc per QP).
+ * qpc_contact_bodies: *n_bodies <- bodies with contact points; bodies[n] <- their ids in the order of their first
+ *   qpc_add_contact (`keys(controller.contacts)`), body_of_contact[nc] <- index of each contact's body in that list.  Either array
+ *   may be NULL.
+ * qpc_contact_wrench_per_body: body_wrench[6 n_bodies * B] <- sums of contact_wrench[6 nc * B] (host arrays; `_device`: device arrays
+ *   on the controller's device device_ids[device_index], enqueued on `hip_stream`). */
+int32_t qpc_contact_bodies(const qpc_controller *ctrl, int32_t *n_bodies, int32_t *bodies, int32_t *body_of_contact);
+int32_t qpc_contact_wrench_per_body(const qpc_controller *ctrl, int64_t B, const double *contact_wrench, double *body_wrench);
+int32_t qpc_contact_wrench_per_body_device(qpc_controller *ctrl, int32_t device_index, int64_t B, const double *contact_wrench,
+                                           double *body_wrench, void *hip_stream);
 const char *qpc_last_error(void);
 const char *qpc_version(void);
 /* 16 hex digits identifying the device code of this build (hash of the kernel sources): stored with every

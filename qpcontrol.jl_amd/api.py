@@ -169,7 +169,8 @@ class MomentumBasedController:
         self.tasks, self.contacts, self._weights = [], [], []
         self.initialized = False
         self.result_vdot = None
-        self.contactwrenches = None
+        self.contactwrenches = None  # {body: [B, 6]} after a tick: the reference's per-body sums
+        self.pointwrenches = None    # [B, nc, 6]: per contact point
         self.status = None
 
     # -- construction ------------------------------------------------------------------------
@@ -242,7 +243,14 @@ class MomentumBasedController:
         v = np.atleast_2d(np.asarray(v, dtype=np.float64))
         des, cw, cm, tw = self._inputs(q.shape[0])
         r = self._c.control_batch(q, v, des, cw, cm, tw, surfaces)
-        self.result_vdot, self.contactwrenches, self.status = r["vdot"], r["cwrench"], r["status"]
+        self.result_vdot, self.pointwrenches, self.status = r["vdot"], r["cwrench"], r["status"]
+        # contactwrenches[BodyID(body)] (momentum.jl:64-72): per body that carries contact points, the sum of its points' wrenches
+        if self.contacts:
+            bodies, _ = self._c.contact_bodies()
+            sums = self._c.contact_wrench_per_body(r["cwrench"])
+            self.contactwrenches = {b: sums[:, i] for i, b in enumerate(bodies)}
+        else:
+            self.contactwrenches = {}
         self.iters = r["iters"]
         if throw_on_failure:
             bad = np.where(r["status"] > 1)[0]

@@ -130,6 +130,12 @@ def load_library(path=None):
         L.qpc_qp_workspace_bytes.argtypes = [i32, i32, i64]
         L.qpc_qp_workspace_bytes.restype = u64
         L.qpc_qp_solve_batch_device.argtypes = [i32, i32, i64] + [vp] * 5 + [ctypes.POINTER(Settings), i32] + [vp] * 4 + [vp, u64, vp]
+    if hasattr(L, "qpc_control_batch_device_on"):  # (the emulation has it too: its "devices" are host memory)
+        L.qpc_control_batch_device_on.argtypes = [vp, i32, i64] + [vp] * 12 + [vp]
+    if hasattr(L, "qpc_contact_bodies"):
+        L.qpc_contact_bodies.argtypes = [vp, c_int32_p, c_int32_p, c_int32_p]
+        L.qpc_contact_wrench_per_body.argtypes = [vp, i64, c_double_p, c_double_p]
+        L.qpc_contact_wrench_per_body_device.argtypes = [vp, i32, i64, vp, vp, vp]
     if hasattr(L, "qpc_sim_step_batch_device"):
         L.qpc_sim_step_batch_device.argtypes = [vp, i64, vp, vp, vp, vp, ctypes.POINTER(SimParams), vp, vp]
         L.qpc_rollout_batch_device.argtypes = [vp, i64, i64] + [vp] * 7 + [ctypes.POINTER(SimParams)] + [vp] * 5
@@ -250,6 +256,26 @@ class Controller:
                    "qpc_finalize_devices")
         self.layout = lay
         return lay
+
+    def contact_bodies(self):
+        """(bodies that carry contact points, in the order of their first addcontact!; index of every contact's body in that list) --
+        `keys(controller.contacts)` of the reference (momentum.jl:64-72)"""
+        n = ctypes.c_int32(0)
+        nc = max(self.layout.n_contacts, 1) if getattr(self, "layout", None) is not None else 64
+        of = np.zeros(max(nc, 64), dtype=np.int32)
+        bodies = np.zeros(max(nc, 64), dtype=np.int32)
+        _check(self.L, self.L.qpc_contact_bodies(self.h, ctypes.byref(n), bodies.ctypes.data_as(c_int32_p), of.ctypes.data_as(c_int32_p)),
+               "qpc_contact_bodies")
+        return [int(b) for b in bodies[:n.value]], of
+
+    def contact_wrench_per_body(self, contact_wrench):
+        """contactwrenches[BodyID(body)] (momentum.jl:64-72): [B, n_bodies, 6] sums of the per-contact wrenches [B, nc, 6] (or [B, 6 nc])"""
+        bodies, _ = self.contact_bodies()
+        cw = np.ascontiguousarray(contact_wrench, dtype=np.float64)
+        B = cw.shape[0]
+        out = np.zeros((B, max(len(bodies), 1) * 6))
+        _check(self.L, self.L.qpc_contact_wrench_per_body(self.h, B, _dp(cw), _dp(out)), "qpc_contact_wrench_per_body")
+        return out.reshape(B, -1, 6)[:, :len(bodies)]
 
     def set_host_pipeline(self, chunk_qps=0, slots_per_device=0, inline_qps=-1):
         _check(self.L, self.L.qpc_set_host_pipeline(self.h, int(chunk_qps), int(slots_per_device), int(inline_qps)),

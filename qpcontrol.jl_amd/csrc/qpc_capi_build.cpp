@@ -240,6 +240,33 @@ int32_t qpc_get_layout(const qpc_controller *c, qpc_layout *out) {
   return QPC_OK;
 }
 
+int32_t qpc_contact_bodies(const qpc_controller *c, int32_t *n_bodies, int32_t *bodies, int32_t *body_of_contact) {
+  if (!c || !n_bodies) return QPC_ERR_INVALID_ARGUMENT;
+  std::vector<int> list;
+  for (size_t k = 0; k < c->contacts.size(); k++) {
+    size_t i = 0;
+    while (i < list.size() && list[i] != c->contacts[k].body) i++;
+    if (i == list.size()) list.push_back(c->contacts[k].body);
+    if (body_of_contact) body_of_contact[k] = (int32_t)i;
+  }
+  *n_bodies = (int32_t)list.size();
+  if (bodies) for (size_t i = 0; i < list.size(); i++) bodies[i] = list[i];
+  return QPC_OK;
+}
+int32_t qpc_contact_wrench_per_body(const qpc_controller *c, int64_t B, const double *cw, double *bw) {
+  if (!c || B < 0 || (B > 0 && (!cw || !bw))) return QPC_ERR_INVALID_ARGUMENT;
+  const int nc = (int)c->contacts.size();
+  int32_t nb = 0;
+  std::vector<int32_t> of(nc > 0 ? nc : 1);
+  qpc_contact_bodies(c, &nb, nullptr, of.data());
+  for (int64_t b = 0; b < B; b++) {
+    double *o = bw + b * 6 * nb;
+    for (int i = 0; i < 6 * nb; i++) o[i] = 0.0;
+    for (int k = 0; k < nc; k++) for (int e = 0; e < 6; e++) o[6 * of[k] + e] += cw[(b * nc + k) * 6 + e]; // (contact order: a fixed summation order)
+  }
+  return QPC_OK;
+}
+
 const char *qpc_status_string(int32_t s) {
   switch (s) {
     case QPC_STATUS_OPTIMAL: return "OPTIMAL";

@@ -833,6 +833,37 @@ int32_t qpc_ticket_order_device(qpc_controller *c, int32_t device_index, int64_t
   return QPC_OK;
 }
 
+// contactwrenches[BodyID(body)] (momentum.jl:64-72): the per-body sums of the per-contact wrenches; a thread per (QP, body, component),
+// the contacts of a body added in contact order.  of[k] (<= 64 contacts: by value) = index of contact k's body
+struct QpcBodyOf { int nc, nb; unsigned char of[64]; };
+extern "C" __global__ void __launch_bounds__(256) qpc_body_wrench_kernel(long long B, QpcBodyOf M, const double *cw, double *bw) {
+  const long long tot = B * 6 * M.nb;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (long long)gridDim.x * blockDim.x) {
+    const long long b = e / (6 * M.nb);
+    const int r = (int)(e % (6 * M.nb)), body = r / 6, comp = r % 6;
+    double s = 0.0;
+    for (int k = 0; k < M.nc; k++) if (M.of[k] == body) s += cw[(b * M.nc + k) * 6 + comp];
+    bw[e] = s;
+  }
+}
+int32_t qpc_contact_wrench_per_body_device(qpc_controller *c, int32_t device_index, int64_t B, const double *cw, double *bw, void *hip_stream) {
+  if (!c || !c->finalized || !c->rt) { qpc_set_error("controller not finalized"); return QPC_ERR_NOT_FINALIZED; }
+  if (device_index < 0 || device_index >= (int)c->rt->devs.size() || B < 0 || (B > 0 && (!cw || !bw))) { qpc_set_error("qpc_contact_wrench_per_body_device: bad arguments"); return QPC_ERR_INVALID_ARGUMENT; }
+  QpcBodyOf M;
+  M.nc = (int)c->contacts.size();
+  if (M.nc > 64) { qpc_set_error("qpc_contact_wrench_per_body_device: more than 64 contact points"); return QPC_ERR_UNSUPPORTED; }
+  int32_t nb = 0, of[64];
+  qpc_contact_bodies(c, &nb, nullptr, of);
+  M.nb = nb;
+  for (int k = 0; k < M.nc; k++) M.of[k] = (unsigned char)of[k];
+  if (B == 0 || nb == 0) return QPC_OK;
+  HIP_TRY(hipSetDevice(c->rt->devs[device_index]->device));
+  const long long tot = B * 6 * nb;
+  hipLaunchKernelGGL(qpc_body_wrench_kernel, dim3((unsigned)std::min<long long>((tot + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)hip_stream, (long long)B, M, cw, bw);
+  HIP_TRY(hipGetLastError());
+  return QPC_OK;
+}
+
 int32_t qpc_control_batch_device_warm(qpc_controller *c, int32_t device_index, int64_t B, const double *q, const double *v,
                                       const double *desired, const double *cw, const double *cmax, const double *tw,
                                       const double *surf, double *tau, double *vdot, double *cwrench, int32_t *status,

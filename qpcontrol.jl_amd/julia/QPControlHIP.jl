@@ -127,7 +127,9 @@ mutable struct BatchedMomentumBasedController{N}
     layout::Union{Nothing, Layout}
     desired_offsets::Vector{Int}   # task id -> first row in `desired`
     vdot::Matrix{Float64}          # result.v̇ of the last tick (momentum.jl:62-64)
-    contactwrenches::Matrix{Float64}
+    pointwrenches::Matrix{Float64} # per contact point: 6·nc × B (world frame, about the world origin)
+    contactwrenches::Dict{Int32, Matrix{Float64}} # body => 6 × B: the SUM over the body's contact points, what the reference's
+                                   # `contactwrenches[BodyID(body)]` holds (momentum.jl:64-72); filled by `contactwrenches!`
     status::Vector{Int32}
 end
 
@@ -263,7 +265,8 @@ pinned_zeros(::Type{T}, dims...) where {T} = pin!(zeros(T, dims...))
 
 The callable of momentum.jl:41-81 for a batch: `q` is nq×B, `v` nv×B, `desired` n_desired×B
 (what `setdesired!` would have stored), `τ` nv×B is overwritten and returned.  After the call
-`controller.vdot` (== `result.v̇`) and `controller.contactwrenches` (6·nc × B) are available.
+`controller.vdot` (== `result.v̇`), `controller.pointwrenches` (6·nc × B, per contact point) and -- after `contactwrenches!(controller)` --
+`controller.contactwrenches` (body => 6 × B, the reference's per-body sums) are available.
 Throws `QPSolveFailure` for the first element whose status is not OPTIMAL / ALMOST_OPTIMAL
 (checkstatus, momentum.jl:83-91) unless `throw_on_failure = false`.
 """
@@ -276,7 +279,7 @@ function (c::BatchedMomentumBasedController)(τ::Matrix{Float64}, t::Number, q::
     lay === nothing && error("call finalize!(controller) first")
     B = size(q, 2)
     size(c.vdot) == (lay.nv, B) || (c.vdot = zeros(lay.nv, B))
-    size(c.contactwrenches) == (6 * lay.n_contacts, B) || (c.contactwrenches = zeros(6 * lay.n_contacts, B))
+    size(c.pointwrenches) == (6 * lay.n_contacts, B) || (c.pointwrenches = zeros(6 * lay.n_contacts, B))
     length(c.status) == B || (c.status = zeros(Int32, B))
     ptr(x) = x === nothing || isempty(x) ? Ptr{Float64}(C_NULL) : pointer(x)
     GC.@preserve q v desired contact_weight contact_maxnormalforce task_weights surfaces τ check(ccall(
@@ -284,7 +287,7 @@ function (c::BatchedMomentumBasedController)(τ::Matrix{Float64}, t::Number, q::
         (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
          Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}),
         c.handle, B, q, v, ptr(desired), ptr(contact_weight), ptr(contact_maxnormalforce), ptr(task_weights),
-        ptr(surfaces), τ, c.vdot, ptr(c.contactwrenches), c.status, Ptr{Int32}(C_NULL)), "qpc_control_batch")
+        ptr(surfaces), τ, c.vdot, ptr(c.pointwrenches), c.status, Ptr{Int32}(C_NULL)), "qpc_control_batch")
     if throw_on_failure
         bad = findfirst(s -> s > 1, c.status)
         bad === nothing || throw(QPSolveFailure(bad, c.status[bad]))
@@ -300,14 +303,14 @@ function control_async!(c::BatchedMomentumBasedController, τ::Matrix{Float64}, 
     lay = c.layout
     B = size(q, 2)
     size(c.vdot) == (lay.nv, B) || (c.vdot = zeros(lay.nv, B))
-    size(c.contactwrenches) == (6 * lay.n_contacts, B) || (c.contactwrenches = zeros(6 * lay.n_contacts, B))
+    size(c.pointwrenches) == (6 * lay.n_contacts, B) || (c.pointwrenches = zeros(6 * lay.n_contacts, B))
     length(c.status) == B || (c.status = zeros(Int32, B))
     ptr(x) = isempty(x) ? Ptr{Float64}(C_NULL) : pointer(x)
     check(ccall((:qpc_control_batch_async, libqpc), Int32,
         (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
          Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}),
         c.handle, B, q, v, ptr(desired), ptr(contact_weight), ptr(contact_maxnormalforce), Ptr{Float64}(C_NULL),
-        Ptr{Float64}(C_NULL), τ, c.vdot, ptr(c.contactwrenches), c.status, Ptr{Int32}(C_NULL)), "qpc_control_batch_async")
+        Ptr{Float64}(C_NULL), τ, c.vdot, ptr(c.pointwrenches), c.status, Ptr{Int32}(C_NULL)), "qpc_control_batch_async")
     nothing
 end
 wait!(c::BatchedMomentumBasedController) = check(ccall((:qpc_wait, libqpc), Int32, (Ptr{Cvoid},), c.handle), "qpc_wait")

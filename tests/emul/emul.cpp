@@ -318,6 +318,10 @@ int32_t qpc_control_batch_device_on(qpc_controller *c, int32_t device_index, int
   emu_ticks(c, job, 0, B);
   return QPC_OK;
 }
+int32_t qpc_contact_wrench_per_body_device(qpc_controller *c, int32_t device_index, int64_t B, const double *cw, double *bw, void *) {
+  if (!c || device_index < 0 || device_index >= qpc_n_devices(c)) return QPC_ERR_INVALID_ARGUMENT;
+  return qpc_contact_wrench_per_body(c, B, cw, bw);
+}
 int32_t qpc_control_batch_warm(qpc_controller *c, int64_t B, const double *q, const double *v, const double *desired,
                                const double *cw, const double *cmax, const double *tw, const double *surf, double *tau,
                                double *vdot, double *cwrench, int32_t *status, int32_t *iters, uint64_t *working_set) {

@@ -55,10 +55,21 @@ def test_standing_tick_matches_oracle(controller):
         api.setdesired(t, des[:, st.offsets[st.joint_tasks[j]]:st.offsets[st.joint_tasks[j]] + 1])
     tau = np.zeros((B, mech.nv))
     out = c(tau, 0.0, (q, v))
-    assert out is tau and c.result_vdot.shape == (B, mech.nv) and c.contactwrenches.shape == (B, 8, 6)
+    assert out is tau and c.result_vdot.shape == (B, mech.nv) and c.pointwrenches.shape == (B, 8, 6)
     ro = oc.tick_batch(q, v, des, np.full((B, 8), 1e-3), np.full((B, 8), 1e6))
     ok = ro["status"] == 0
     np.testing.assert_allclose(tau[ok], ro["tau"][ok], atol=1e-8, rtol=0)
+    # contactwrenches[BodyID(body)] (momentum.jl:64-72): one wrench per foot, the sum over the foot's four contact points -- against
+    # the oracle's per-contact wrenches summed by body
+    feet_ids = [mech.findbody("l_foot"), mech.findbody("r_foot")]
+    assert sorted(c.contactwrenches) == sorted(feet_ids) and all(w.shape == (B, 6) for w in c.contactwrenches.values())
+    body_of = [cp.body for cp in mech.contact_points]
+    for f in feet_ids:
+        want = sum(ro["cwrench"][:, k] for k in range(8) if body_of[k] == f)
+        np.testing.assert_allclose(c.contactwrenches[f][ok], want[ok], atol=1e-8 * max(1.0, np.abs(want[ok]).max()), rtol=0)
+    # ... and Newton-Euler: the bodies' wrenches together balance gravity and the momentum rate -- the forces' sum has the robot's weight's size
+    total = sum(c.contactwrenches.values())
+    assert np.all(total[ok][:, 5] > 0.5 * mech.total_mass() * 9.81)
 
 
 def test_disable_and_failure(controller):
