@@ -385,7 +385,8 @@ class SE3PDController:
         in the task's slice of `desired` (binding.Controller.task_desired_range) and
         `set_task_law(task, LAW_SE3_PD, k_ang, d_ang, [k_lin, d_lin])`, the tick evaluates this controller per QP on the
         device instead of the host calling it and `setdesired!` before every tick."""
-        from .trajectories import Interpolated, Piecewise, Polynomial, PolyDerivEvaluator, Quat, SE3Trajectory
+        from math import comb
+        from .trajectories import BezierCurve, Interpolated, Piecewise, Polynomial, PolyDerivEvaluator, Quat, SE3Trajectory
         tr = self.trajectory
         if isinstance(tr, SE3Trajectory) and isinstance(tr.angular, Piecewise) and isinstance(tr.linear, Piecewise):
             return self._piecewise_record(t)
@@ -399,8 +400,17 @@ class SE3PDController:
             if f is None:
                 return (0.0, 1.0, 0.0, 0.0, 0.0, 0.0)
             p = f.f if isinstance(f, PolyDerivEvaluator) else f
+            if isinstance(p, BezierCurve):
+                # `const BezierCurve = BernsteinPolynomial` (trajectories.jl:26): b(t) = sum_i c_i C(n, i) t^i (1 - t)^(n - i); the device
+                # record holds monomial coefficients: a_j = C(n, j) sum_{i <= j} (-1)^(j - i) C(j, i) c_i (exact for the small
+                # integers involved: degree <= 5)
+                n = len(p.c) - 1
+                if n > 5:
+                    raise ValueError("device_record: a Bezier interpolator of degree <= 5 is needed")
+                mono = [comb(n, j) * sum((-1) ** (j - i) * comb(j, i) * p.c[i] for i in range(j + 1)) for j in range(n + 1)]
+                return tuple(mono) + (0.0,) * (5 - n)
             if not isinstance(p, Polynomial) or p.shift != 0.0 or p.scale != 1.0 or len(p.c) > 6:
-                raise ValueError("device_record: the interpolator must be a monomial Polynomial of degree <= 5 on [0, 1]")
+                raise ValueError("device_record: the interpolator must be a monomial Polynomial or a BezierCurve of degree <= 5 on [0, 1]")
             return tuple(p.c) + (0.0,) * (6 - len(p.c))
         ca = coeffs(a.interpolator)
         if ca != coeffs(l.interpolator):

@@ -5,7 +5,7 @@ The host mirror (qpcontrol.jl_amd/api.SE3PDController over trajectories.py) is p
 answers (tests/test_trajectories.py transcribes test/trajectories.jl).  Here: a controller whose hand task carries the
 device law and receives the per-QP trajectory RECORD must produce the same tau as a twin whose task receives the desired
 spatial acceleration the host mirror computed for the same state and time -- for times before, inside and after
-[x0, xf], the identity interpolator and a fit_quintic time warp."""
+[x0, xf], the identity interpolator and a fit_quintic time warp and a degree-5 Bezier one."""
 import numpy as np
 import pytest
 
@@ -62,8 +62,10 @@ def _run(factory, B=10, seed=5, pelvis_law=None):
         pel_des = -pelvis_law[0] * W.rotation_vector(Rp) - pelvis_law[1] * np.einsum("bji,bj->bi", Rp, kin["w"][pb])
     nc = len(mech.contact_points)
     cw, cm = np.full((B, nc), 1e-3), np.full((B, nc), 1e6)
-    for warp in (None, "quintic", "antipodal"):
+    for warp in (None, "quintic", "antipodal", "bezier"):
         f = None if warp in (None, "antipodal") else T.fit_quintic(x0=0.0, xf=1.0, y0=0.0, yd0=0.0, ydd0=0.0, yf=1.0, ydf=0.0, yddf=0.0)
+        if warp == "bezier":  # `const BezierCurve = BernsteinPolynomial` (trajectories.jl:26), degree 5: the device record takes its monomial form
+            f = T.BezierCurve([0.0, 0.0, 0.15, 0.7, 1.0, 1.0])
         yf = T.Quat.from_angle_axis(np.pi / 2, [1.0, 0.3, -0.2])
         if warp == "antipodal":  # same rotation, opposite sign: inv(y0) * yf has w < 0 -> the reference takes the long arc (3 pi / 2)
             yf = T.Quat(*(-yf.q))
