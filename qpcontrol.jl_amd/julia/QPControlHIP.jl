@@ -426,6 +426,24 @@ mutable struct QpProblem
         p
     end
 end
+"""
+    analyze!(prob, l, u) -> plan_info(prob)
+
+The symbolic analysis of the sparse workgroup solver (`qpc_qp_analyze`) for the equality rows of one QP's bounds `l[m]`, `u[m]`: an
+optimizer calls it once after `MOI.copy_to` -- the constraint sets are known then -- so that the first tick is not the slow one.
+"""
+function analyze!(p::QpProblem, l::Vector{Float64}, u::Vector{Float64})
+    rc = ccall((:qpc_qp_analyze, libqpc), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), p.handle, l, u)
+    rc == 0 || error(unsafe_string(ccall((:qpc_last_error, libqpc), Cstring, ())))
+    plan_info(p)
+end
+"(plan in use, equality rows, other rows, fronts, levels, update jobs, store doubles, LDS bytes, widest front, tallest front, multiply-adds, dense multiply-adds)"
+function plan_info(p::QpProblem)
+    out = zeros(Int64, 12)
+    rc = ccall((:qpc_qp_plan_info, libqpc), Int32, (Ptr{Cvoid}, Ptr{Int64}, Int32), p.handle, out, length(out))
+    rc == 0 || error(unsafe_string(ccall((:qpc_last_error, libqpc), Cstring, ())))
+    out
+end
 "`Pvals[nnzP, B]`, `q[n, B]`, `Avals[nnzA, B]`, `l[m, B]`, `u[m, B]` -> `(x[n, B], y[m, B], status[B], iters[B])`"
 function solve!(p::QpProblem, Pvals::Matrix{Float64}, q::Matrix{Float64}, Avals::Matrix{Float64}, l::Matrix{Float64},
                 u::Matrix{Float64}; warm_start::Bool = false, settings::Settings = default_settings())

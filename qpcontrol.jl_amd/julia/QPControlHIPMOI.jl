@@ -176,6 +176,7 @@ function MOI.optimize!(o::QPCOptimizer)
         o.iP = [c[1] for c in cP]; o.jP = [c[2] for c in cP]
         o.jA = [c[1] for c in cA]; o.iA = [c[2] for c in cA]          # patAt is A' (variable, row)
         o.problem = QpProblem(o.n, o.m, o.iP, o.jP, o.iA, o.jA; device = o.device)
+        analyze!(o.problem, lc, uc)   # the plan of the sparse workgroup solver for these constraint sets (rows with l == u: MOI.Zeros)
         o.solved = 0
     end
     Pv = Float64[o.P[i, j] for (i, j) in zip(o.iP, o.jP)]

@@ -75,6 +75,7 @@ class QPCOptimizer:
         if self.prepared and self.m > 0:
             self._problem = binding.QpProblem(self.n, self.m, self._pattern_P, self._pattern_A, device_id=self.device_id,
                                               lib_path=self.lib_path)
+            self._problem.analyze(self.l, self.u)  # (the constraint sets are known at copy_to: the plan of the sparse solver now, not at the first tick)
 
     # ---- MOI.set(ObjectiveFunction) / MOI.set(ConstraintFunction / ConstraintSet): coefficient updates, pattern fixed
     def set_objective(self, P=None, q=None, strict_pattern=False):
