@@ -309,7 +309,8 @@ int32_t qpc_default_settings(qpc_settings *s);
  * 32-63 each work their own QP on their own LDS slab, one instruction stream advances both (the tick uses at most ~36 of its 64
  * lanes at a time and is bound by the number of instructions it issues; DESIGN.md 7c has the measurements).  Same results (the
  * per-QP arithmetic does not change); needs the hiprtc-specialised kernel, a contact basis of four rays and at most two presolved
- * foot blocks; warm starts and the closed-loop entry points keep one QP per wavefront. */
+ * foot blocks and no warm start (qpc_finalize refuses the combination with qpc_enable_warm_start); the closed-loop entry points
+ * (qpc_rollout_batch*) run the packed tick. */
 int32_t qpc_set_qps_per_wavefront(qpc_controller *ctrl, int32_t qps_per_wavefront);
 enum { QPC_PRECISION_F64 = 0, QPC_PRECISION_F32 = 1 };
 int32_t qpc_set_precision(qpc_controller *ctrl, int32_t precision);

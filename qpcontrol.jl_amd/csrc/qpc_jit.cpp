@@ -196,7 +196,15 @@ extern "C" const char *qpc_kernel_fingerprint(void);
 static std::mutex g_jit_mu;
 static std::map<std::string, std::vector<char>> g_jit_cache;
 
-int qpc_jit_compile(const QpcDims &D, const QpcDims &DS, const std::string &arch, bool warm, bool f32, bool pack2, std::vector<char> &code, std::string &log) {
+void qpc_jit_forget(const std::string &disk_path) {
+  if (!disk_path.empty()) (void)remove(disk_path.c_str());
+  std::lock_guard<std::mutex> lk(g_jit_mu);
+  g_jit_cache.clear();
+}
+
+int qpc_jit_compile(const QpcDims &D, const QpcDims &DS, const std::string &arch, bool warm, bool f32, bool pack2, std::vector<char> &code, std::string &log,
+                    std::string *disk_hit) {
+  if (disk_hit) disk_hit->clear();
   std::string src = qpc_jit_source(D, DS, warm, f32, pack2);
   std::string key;
   {
@@ -215,8 +223,12 @@ int qpc_jit_compile(const QpcDims &D, const QpcDims &DS, const std::string &arch
   std::string disk_path;
   if (const char *dir = getenv("QPC_JIT_CACHE_DIR")) {
     if (dir[0] && !key.empty()) {
+      // (the compiler's version is part of the name: a code object of another ROCm is another file -- ADVICE r4)
+      int vmaj = 0, vmin = 0;
+      (void)hiprtcVersion(&vmaj, &vmin);
+      const std::string vkey = "hiprtc " + std::to_string(vmaj) + "." + std::to_string(vmin) + "\n" + key;
       unsigned long long h = 1469598103934665603ull;
-      for (unsigned char ch : key) { h ^= ch; h *= 1099511628211ull; }
+      for (unsigned char ch : vkey) { h ^= ch; h *= 1099511628211ull; }
       char name[96];
       snprintf(name, sizeof name, "/qpc_%s_%016llx.co", qpc_kernel_fingerprint(), h);
       disk_path = std::string(dir) + name;
@@ -225,11 +237,13 @@ int qpc_jit_compile(const QpcDims &D, const QpcDims &DS, const std::string &arch
         const long sz = ftell(f);
         fseek(f, 0, SEEK_SET);
         std::vector<char> buf(sz > 0 ? (size_t)sz : 0);
-        const bool ok = sz > 0 && fread(buf.data(), 1, (size_t)sz, f) == (size_t)sz;
+        bool ok = sz > 64 && fread(buf.data(), 1, (size_t)sz, f) == (size_t)sz;
         fclose(f);
+        ok = ok && buf[0] == 0x7f && buf[1] == 'E' && buf[2] == 'L' && buf[3] == 'F'; // (a code object is an ELF file; anything else is recompiled)
         if (ok) {
           code.swap(buf);
           log.clear();
+          if (disk_hit) *disk_hit = disk_path;
           std::lock_guard<std::mutex> lk(g_jit_mu);
           if (g_jit_cache.size() >= 64) g_jit_cache.clear();
           g_jit_cache[key] = code;

@@ -631,6 +631,7 @@ int32_t qpc_finalize_devices(qpc_controller *c, int32_t n_devices, const int32_t
   HIP_TRY(hipGetDeviceProperties(&prop0, device_ids[0]));
   // JIT specialisation on this controller's program, once for all devices (QPC_DISABLE_JIT=1 keeps the generic kernel)
   std::vector<char> code;
+  std::string jit_disk_hit; // the code object came from this file of the disk cache
   const char *nojit = getenv("QPC_DISABLE_JIT");
   const bool jit_off = nojit && nojit[0] == '1';
   const bool f32 = c->precision == QPC_PRECISION_F32, pack2 = c->qps_per_wave == 2;
@@ -643,13 +644,17 @@ int32_t qpc_finalize_devices(qpc_controller *c, int32_t n_devices, const int32_t
     qpc_set_error("QPC_DISABLE_JIT=1 but the fp32 tick (qpc_set_precision) only exists as a hiprtc-specialised kernel");
     return QPC_ERR_UNSUPPORTED;
   }
+  if (f32 && c->warm_start) { // (the header says so, nothing enforced it -- an untested fp32 warm kernel would have been compiled and launched)
+    qpc_set_error("qpc_enable_warm_start with QPC_PRECISION_F32: warm starts are fp64-only (qpc_set_precision, include/qpc.h)");
+    return QPC_ERR_UNSUPPORTED;
+  }
   if (jit_off && D.maxdepth > QPC_GENERIC_MAXD) {
     qpc_set_error("QPC_DISABLE_JIT=1 but the tree is deeper than the generic kernel supports");
     return QPC_ERR_UNSUPPORTED;
   }
   if (!jit_off) {
     std::string log;
-    const int jrc = qpc_jit_compile(D, c->prog.dims_s, prop0.gcnArchName, c->warm_start != 0, f32, pack2, code, log);
+    const int jrc = qpc_jit_compile(D, c->prog.dims_s, prop0.gcnArchName, c->warm_start != 0, f32, pack2, code, log, &jit_disk_hit);
     if (jrc != 0) {
       code.clear();
       if (f32 || pack2) { qpc_set_error("JIT specialisation of the fp32 / packed tick failed (there is no ahead-of-time form of it): " + log); return QPC_ERR_HIP; }
@@ -673,6 +678,19 @@ int32_t qpc_finalize_devices(qpc_controller *c, int32_t n_devices, const int32_t
     QpcDeviceState *S = new QpcDeviceState();
     rt->devs.push_back(S); // owned by rt from here on: released by fail() on any error below
     rc = init_device_state(c, S, device_ids[i], rt->slots, code, prop);
+    if (rc != QPC_OK && rc == QPC_ERR_HIP && !code.empty() && !jit_disk_hit.empty() && !S->jit_func) {
+      // a code object from the DISK cache that does not load (another ROCm, a damaged file): the file goes, the kernel is compiled
+      // afresh, once -- instead of every start of the process falling to the generic kernel (or, fp32 / packed, failing) for good
+      fprintf(stderr, "[qpc] cached code object %s unusable (%s); recompiling\n", jit_disk_hit.c_str(), qpc_last_error());
+      qpc_jit_forget(jit_disk_hit);
+      jit_disk_hit.clear();
+      std::string log;
+      for (auto *T : rt->devs) destroy_device_state(T);
+      rt->devs.clear(); i = -1;
+      if (qpc_jit_compile(D, c->prog.dims_s, prop0.gcnArchName, c->warm_start != 0, f32, pack2, code, log) != 0) code.clear();
+      if (code.empty() && (f32 || pack2)) { qpc_set_error("JIT specialisation of the fp32 / packed tick failed: " + log); return fail(QPC_ERR_HIP); }
+      continue;
+    }
     if (rc != QPC_OK) {
       const char *strict = getenv("QPC_REQUIRE_JIT");
       if (!code.empty() && rc == QPC_ERR_HIP && !(strict && strict[0] == '1') && D.maxdepth <= QPC_GENERIC_MAXD && !S->jit_func && !f32 && !pack2) {
@@ -1035,6 +1053,9 @@ int32_t qpc_assemble_solve_batch(qpc_controller *c, int64_t B, const double *tas
 static int sim_check(qpc_controller *c, int64_t B, const void *q, const void *v, const void *tau, const qpc_sim_params *p, const char *who) {
   if (!c || !c->finalized || !c->rt) { qpc_set_error("controller not finalized"); return QPC_ERR_NOT_FINALIZED; }
   if (B < 0 || !q || !v || !tau || !p) { qpc_set_error(std::string(who) + ": missing array"); return QPC_ERR_INVALID_ARGUMENT; }
+  if (c->precision == QPC_PRECISION_F32) { // (the fp32 module carries no simulation kernel: the fp32 tick would be paired with the generic fp64 step)
+    qpc_set_error(std::string(who) + ": the closed-loop entry points are fp64-only (the controller was finalized with QPC_PRECISION_F32)"); return QPC_ERR_UNSUPPORTED;
+  }
   if (!c->rt->devs[0]->jit_sim_func && c->prog.dims.maxdepth > QPC_GENERIC_MAXD) {
     qpc_set_error(std::string(who) + ": tree deeper than the generic kernel supports and no JIT kernel"); return QPC_ERR_UNSUPPORTED;
   }

@@ -119,6 +119,13 @@ def test_jit_disk_cache(lib, tmp_path, monkeypatch):
     rc, t_disk = out.stdout.split()[-2:]
     assert rc == "0" and (tmp_path / "c.co").read_bytes() == files[0].read_bytes()
     print(f"hiprtc compile {t_cold:.2f} s, from the disk cache {float(t_disk):.2f} s")  # (no assertion: the toolchain may cache by itself)
+    # a damaged file is not a code object: the next compile ignores it and writes a good one in its place
+    good = files[0].read_bytes()
+    files[0].write_bytes(b"not an ELF file" * 20)
+    out = subprocess.run([sys.executable, "-c", code, str(tmp_path / "d.co")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.split()[-2] == "0", out.stderr[-500:]
+    fresh = (tmp_path / "d.co").read_bytes()  # (a compile in another process need not reproduce the first one's bytes)
+    assert fresh[:4] == b"\x7fELF" and len(fresh) == len(good) and files[0].read_bytes() == fresh
 
 
 def test_bench_cpu_worker_cli():
