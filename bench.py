@@ -544,7 +544,9 @@ def in_library_leg(n_dev, B, steps, warmup, config, ids=None, lib_path=None):
     from qpcontrol_jl_amd import binding
     from qpcontrol_jl_amd import workloads as W
     if ids is None:
-        ids = [0] * n_dev if os.environ.get("QPC_BENCH_TEST_ONE_DEVICE") == "1" else list(range(n_dev))
+        # (the test hook of a one-GPU box: qpc_finalize_devices takes every device once, so the leg runs on device 0 alone)
+        ids = [0] if os.environ.get("QPC_BENCH_TEST_ONE_DEVICE") == "1" else list(range(n_dev))
+    n_dev = len(ids)
     real_finalize = binding.Controller.finalize
 
     def fin(self_, device_id=0):

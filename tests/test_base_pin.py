@@ -91,7 +91,7 @@ def test_base_tasks_of_all_three_kinds_emulated(kind, v0):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("fused", [False, pytest.param(True, marks=pytest.mark.gpu_slow)])
 def test_pelvis_task_is_a_pin_gpu(fused):
     _atlas(lambda mech, N, fl: binding.Controller(binding.Model(mech, binding.EXPERIMENTS_LIB), N, fl), 512, 3, fused)
 

@@ -263,7 +263,7 @@ def test_sim_step_fuzz_emulated(seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("jit", [True, False])
+@pytest.mark.parametrize("jit", [pytest.param(True, marks=pytest.mark.gpu_slow), False])
 def test_sim_step_fuzz_gpu(jit, monkeypatch):
     """8 random mechanisms through the JIT-specialised kernel (a hiprtc compile each), 24 through the generic one"""
     if not jit:

@@ -79,8 +79,11 @@ def test_edge_contacts_emulated(kw):
     assert (races, uninit, outside) == (0, 0, 0), first
 
 
+GPU_SLOW_CASES = (dict(n_basis=6), dict(n_basis=8), dict(mu=1e-3), dict(n_basis=5, one_foot=True))  # (a hiprtc compile and an oracle run each; the fast set keeps the odd basis, the frictionless cone, the single foot and the dense form)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("kw", CASES, ids=[str(k) for k in CASES])
+@pytest.mark.parametrize("kw", [pytest.param(k, marks=pytest.mark.gpu_slow) if k in GPU_SLOW_CASES else k for k in CASES], ids=[str(k) for k in CASES])
 def test_edge_contacts_gpu(kw):
     from qpcontrol_jl_amd import binding
     _run(lambda mech, N, fl: binding.Controller(binding.Model(mech), N, fl), kw)

@@ -119,9 +119,16 @@ def test_f32_precision_is_a_build_time_choice():
 
 
 @pytest.mark.gpu
+@pytest.mark.gpu_slow
 def test_f32_tick_gpu_config5_at_8192():
     """BASELINE config 5 in its stated precision at BASELINE config 3's batch"""
     _compare(gpu_factory_f32, gpu_factory, 8192, 5, 2027, 256)
+
+
+@pytest.mark.gpu
+def test_f32_tick_gpu_config5():
+    """BASELINE config 5 in its stated precision (2 048 states, 64 of them against the oracle; `-m gpu_slow`: 8 192 / 256)"""
+    _compare(gpu_factory_f32, gpu_factory, 2048, 5, 2027, 64)
 
 
 @pytest.mark.gpu
@@ -173,7 +180,7 @@ def _packed_vs_plain(f32, B=2048, config=5):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("f32", [False, True])
+@pytest.mark.parametrize("f32", [pytest.param(False, marks=pytest.mark.gpu_slow), True])
 def test_two_qps_per_wavefront_gpu(f32):
     """qpc_set_qps_per_wavefront(2) (csrc/qpc_device.h QPC_PACK2): lanes 0-31 and 32-63 each solve their own QP.  The arithmetic per
     QP is the same except for the Schur build (dot products instead of a matrix-core tile): fp64 statuses equal and tau to 1e-9 of

@@ -111,7 +111,7 @@ def test_fuzz_emulated(seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(100, 112))
+@pytest.mark.parametrize("seed", [s if s < 106 else pytest.param(s, marks=pytest.mark.gpu_slow) for s in range(100, 112)])
 def test_fuzz_gpu(seed):
     from qpcontrol_jl_amd import binding
     g, o = build(lambda mech, N, fl: binding.Controller(binding.Model(mech), N, fl), seed, B=4), build(ora_factory, seed, B=4)

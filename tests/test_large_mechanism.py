@@ -78,7 +78,7 @@ def test_deep_chain_emulated():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("big", [False, True])
+@pytest.mark.parametrize("big", [pytest.param(False, marks=pytest.mark.gpu_slow), True])
 def test_large_mechanism_gpu(big):
     from qpcontrol_jl_amd import binding
     _run(lambda mech, N, fl: binding.Controller(binding.Model(mech), N, fl), big)

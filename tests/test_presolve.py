@@ -207,7 +207,7 @@ def test_random_bipeds_against_the_oracle_emulated(seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", [0, 3])
+@pytest.mark.parametrize("seed", [0, pytest.param(3, marks=pytest.mark.gpu_slow)])
 def test_random_bipeds_gpu(seed):
     mech = _random_biped(seed)
     rng = np.random.default_rng(200 + seed)

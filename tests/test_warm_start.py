@@ -86,7 +86,7 @@ def test_warm_entry_needs_the_flag():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("config", [3, 5])
+@pytest.mark.parametrize("config", [pytest.param(3, marks=pytest.mark.gpu_slow), 5])
 def test_warm_start_gpu(config):
     it_cold, it_warm = _check(lambda mech, N, fl: binding.Controller(binding.Model(mech), N, fl), 2048, config)
     print(f"config {config}: working-set changes per QP cold {it_cold:.2f} -> warm {it_warm:.2f}")
