@@ -274,6 +274,14 @@ def secondary_points(torch, binding, W, device_index):
                 pt["vs_f64"] = {"rel_tau_err_median": float(np.median(err[both])), "rel_tau_err_p999": float(np.percentile(err[both], 99.9)),
                                 "rel_tau_err_max": float(err[both].max()), "optimal_in_f64_not_in_f32": float(((s64 <= 1) & ~(s32 <= 1)).mean()),
                                 "optimal_in_f32_not_in_f64": float((~(s64 <= 1) & (s32 <= 1)).mean())}
+                # the same over the QPs the fp32 tick reports as OPTIMAL (status 0 only: what `checkstatus`, momentum.jl:83-91, licenses without a remark)
+                opt = (s32 == 0) & (s64 <= 1)
+                if opt.any():
+                    pt["vs_f64"]["of_status_optimal_only"] = {
+                        "qps": int(opt.sum()), "rel_tau_err_median": float(np.median(err[opt])), "rel_tau_err_p99": float(np.percentile(err[opt], 99)),
+                        "rel_tau_err_p999": float(np.percentile(err[opt], 99.9)), "rel_tau_err_max": float(err[opt].max()),
+                        "beyond_1e-4": int((err[opt] > 1e-4).sum()), "beyond_1e-3": int((err[opt] > 1e-3).sum())}
+                pt["vs_f64"]["unresolved_fraction"] = float(((s64 <= 1) & ~(s32 <= 1)).mean())
         out.append(pt)
         del run
     return out
