@@ -398,14 +398,20 @@ inline bool qp_sp_plan_build(const QpPrepHost &H, const uint8_t *eq, QpSpPlanHos
   }
   {
     std::vector<int> joblv(1, 0), jt, slots, maps;
+    std::map<std::vector<int>, int> map_ids;
     int njob = 0;
     for (int l = 0; l < nlevel; l++) {
       for (auto &J : jobs[l]) {
         const int s0 = (int)slots.size() / SP_SLOT_INTS;
         for (size_t k = 0; k < J.srcs.size(); k++) {
           const Front &F = fr[J.srcs[k]];
-          const int mp = (int)maps.size() / 16;
-          for (int e = 0; e < 32; e += 2) maps.push_back((J.maps[k][e] & 0xffff) | (J.maps[k][e + 1] << 16)); // (16 bits each: a front has at most 2 QPC_SP_DIM rows; -1 stays -1)
+          // (fronts with the same row structure -- the joint rows of a humanoid, its contacts -- map a tile alike: a map is stored once)
+          auto seen = map_ids.find(J.maps[k]);
+          if (seen == map_ids.end()) {
+            seen = map_ids.emplace(J.maps[k], (int)maps.size() / 16).first;
+            for (int e = 0; e < 32; e += 2) maps.push_back((J.maps[k][e] & 0xffff) | (J.maps[k][e + 1] << 16)); // (16 bits each: a front has at most 2 QPC_SP_DIM rows; -1 stays -1)
+          }
+          const int mp = seen->second;
           for (int c = 0; c < F.w; c++) slots.insert(slots.end(), {(F.base + c * F.r()) | ((F.c0 + c) << 20), mp});
         }
         while ((slots.size() / SP_SLOT_INTS - s0) % 4) slots.insert(slots.end(), {0, -1});

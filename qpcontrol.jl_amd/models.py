@@ -231,6 +231,55 @@ def atlas():
     return m
 
 
+def valkyrie():
+    """Synthetic Valkyrie-sized humanoid (the robot of the reference's own integration tests, /root/reference/test/controller.jl:99-126:
+    `ValkyrieRobot.Valkyrie()`; its URDF is not in the tree): the topology of NASA's Valkyrie with fingers -- pelvis, three torso
+    joints, three neck joints, two seven-joint arms with thirteen finger joints each, two six-joint legs -- 59 bodies, nv = 64 =
+    the kernel's limit, plausible link lengths and masses (~125 kg), 4 contact points per foot, mu = 0.8.  Names follow the robot's."""
+    m = Mechanism()
+    A = m.add_body
+    A("pelvis", WORLD, "pelvis_to_world", QUAT_FLOATING, mass=8.22, com=(-0.005, 0.0, -0.016), inertia=_box_inertia(8.22, 0.25, 0.3, 0.2))
+    A("torsoYawLink", "pelvis", "torsoYaw", REVOLUTE, (0, 0, 1), p=(0, 0, 0), mass=0.5, com=(0, 0, -0.01), inertia=_box_inertia(0.5, 0.08, 0.08, 0.06))
+    A("torsoPitchLink", "torsoYawLink", "torsoPitch", REVOLUTE, (0, 1, 0), p=(0.04, 0, 0), mass=0.1, com=(0, 0, 0.005), inertia=_box_inertia(0.1, 0.04, 0.04, 0.04))
+    A("torso", "torsoPitchLink", "torsoRoll", REVOLUTE, (1, 0, 0), p=(0, 0, 0.02), mass=39.47, com=(-0.095, 0, 0.183), inertia=_box_inertia(39.47, 0.3, 0.45, 0.5))
+    A("lowerNeckPitchLink", "torso", "lowerNeckPitch", REVOLUTE, (0, 1, 0), p=(0.02, 0, 0.34), mass=1.05, com=(-0.02, 0, 0.04), inertia=_box_inertia(1.05, 0.08, 0.08, 0.1))
+    A("neckYawLink", "lowerNeckPitchLink", "neckYaw", REVOLUTE, (0, 0, 1), p=(-0.05, 0, 0.2), mass=1.4, com=(-0.02, 0, 0.04), inertia=_box_inertia(1.4, 0.08, 0.08, 0.1))
+    A("head", "neckYawLink", "upperNeckPitch", REVOLUTE, (0, 1, 0), p=(-0.06, 0, 0), mass=3.89, com=(0.075, 0, 0.02), inertia=_box_inertia(3.89, 0.2, 0.18, 0.2))
+    for s, sg in (("left", 1.0), ("right", -1.0)):
+        A(f"{s}ShoulderPitchLink", "torso", f"{s}ShoulderPitch", REVOLUTE, (0, 1, 0), p=(-0.03, sg * 0.25, 0.25), mass=2.65, com=(0.01, sg * 0.07, 0), inertia=_box_inertia(2.65, 0.1, 0.15, 0.1))
+        A(f"{s}ShoulderRollLink", f"{s}ShoulderPitchLink", f"{s}ShoulderRoll", REVOLUTE, (1, 0, 0), p=(0, sg * 0.25, 0), mass=3.97, com=(0, sg * 0.02, 0), inertia=_box_inertia(3.97, 0.12, 0.2, 0.12))
+        A(f"{s}ShoulderYawLink", f"{s}ShoulderRollLink", f"{s}ShoulderYaw", REVOLUTE, (0, 1, 0), p=(0, sg * 0.06, 0), mass=3.085, com=(0, sg * 0.12, 0), inertia=_box_inertia(3.085, 0.1, 0.25, 0.1))
+        A(f"{s}ElbowPitchLink", f"{s}ShoulderYawLink", f"{s}ElbowPitch", REVOLUTE, (0, 0, 1), p=(0.025, sg * 0.25, 0), mass=1.83, com=(-0.01, sg * 0.04, 0), inertia=_box_inertia(1.83, 0.09, 0.15, 0.09))
+        A(f"{s}ForearmLink", f"{s}ElbowPitchLink", f"{s}ForearmYaw", REVOLUTE, (0, 1, 0), p=(-0.025, sg * 0.04, 0), mass=2.476, com=(0, sg * 0.13, 0), inertia=_box_inertia(2.476, 0.09, 0.25, 0.09))
+        A(f"{s}WristRollLink", f"{s}ForearmLink", f"{s}WristRoll", REVOLUTE, (1, 0, 0), p=(0, sg * 0.28, 0), mass=0.14, com=(0, 0, 0), inertia=_box_inertia(0.14, 0.04, 0.04, 0.04))
+        A(f"{s}Palm", f"{s}WristRollLink", f"{s}WristPitch", REVOLUTE, (0, 0, 1), p=(0, 0, 0), mass=0.712, com=(0, sg * 0.05, 0), inertia=_box_inertia(0.712, 0.09, 0.1, 0.03))
+        A(f"{s}ThumbRollLink", f"{s}Palm", f"{s}ThumbRoll", REVOLUTE, (0, 1, 0), p=(0.005, sg * 0.03, -0.03), mass=0.017, com=(0, 0, -0.01), inertia=_box_inertia(0.017, 0.02, 0.02, 0.03))
+        prev = f"{s}ThumbRollLink"
+        for k in (1, 2, 3):
+            A(f"{s}ThumbPitch{k}Link", prev, f"{s}ThumbPitch{k}", REVOLUTE, (1, 0, 0), p=(0, sg * 0.005, -0.03), mass=0.02 - 0.004 * k, com=(0, 0, -0.012),
+              inertia=_box_inertia(0.02 - 0.004 * k, 0.015, 0.015, 0.03))
+            prev = f"{s}ThumbPitch{k}Link"
+        for fi, (name, fx) in enumerate((("Index", 0.03), ("Middle", 0.0), ("Pinky", -0.03))):
+            prev = f"{s}Palm"
+            for k in (1, 2, 3):
+                A(f"{s}{name}FingerPitch{k}Link", prev, f"{s}{name}FingerPitch{k}", REVOLUTE, (1, 0, 0), p=(fx if k == 1 else 0.0, sg * (0.1 if k == 1 else 0.035), 0.0),
+                  mass=0.02 - 0.004 * k, com=(0, sg * 0.012, 0), inertia=_box_inertia(0.02 - 0.004 * k, 0.015, 0.03, 0.015))
+                prev = f"{s}{name}FingerPitch{k}Link"
+    for s, sg in (("left", 1.0), ("right", -1.0)):
+        A(f"{s}HipYawLink", "pelvis", f"{s}HipYaw", REVOLUTE, (0, 0, 1), p=(0, sg * 0.1016, -0.1853), mass=2.39, com=(0.02, 0, 0.03), inertia=_box_inertia(2.39, 0.12, 0.12, 0.1))
+        A(f"{s}HipRollLink", f"{s}HipYawLink", f"{s}HipRoll", REVOLUTE, (1, 0, 0), p=(0, 0, 0), mass=3.665, com=(0.012, 0, 0), inertia=_box_inertia(3.665, 0.15, 0.12, 0.12))
+        A(f"{s}HipPitchLink", f"{s}HipRollLink", f"{s}HipPitch", REVOLUTE, (0, 1, 0), p=(0, sg * 0.0609, -0.0609), mass=10.2, com=(0.016, sg * 0.09, -0.207), inertia=_box_inertia(10.2, 0.18, 0.18, 0.45))
+        A(f"{s}KneePitchLink", f"{s}HipPitchLink", f"{s}KneePitch", REVOLUTE, (0, 1, 0), p=(0.000112, sg * 0.0361, -0.431), mass=6.2, com=(-0.005, sg * 0.005, -0.15), inertia=_box_inertia(6.2, 0.12, 0.12, 0.42))
+        A(f"{s}AnklePitchLink", f"{s}KneePitchLink", f"{s}AnklePitch", REVOLUTE, (0, 1, 0), p=(-0.0102, 0, -0.406), mass=0.03, com=(0, 0, 0), inertia=_box_inertia(0.03, 0.03, 0.03, 0.03))
+        A(f"{s}Foot", f"{s}AnklePitchLink", f"{s}AnkleRoll", REVOLUTE, (1, 0, 0), p=(0, 0, 0), mass=2.37, com=(0.037, 0.005, -0.047), inertia=_box_inertia(2.37, 0.27, 0.16, 0.06))
+    for s in ("left", "right"):
+        foot = m.findbody(f"{s}Foot")
+        for x, y in ((-0.0676, 0.0624), (-0.0676, -0.0624), (0.1928, 0.0624), (0.1928, -0.0624)):
+            m.contact_points.append(ContactSpec(foot, np.array([x, y, -0.0902]), np.array([0.0, 0.0, 1.0]), 0.8))
+    assert m.nbodies == 59 and m.nq == 65 and m.nv == 64, (m.nbodies, m.nq, m.nv)
+    return m
+
+
 def atlas_nominal_configuration(m):
     """initialize!(state) of notebooks/Standing controller.ipynb cell 6 (raw lines 104-121)."""
     q = m.zero_configuration()

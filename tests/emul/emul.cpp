@@ -529,7 +529,9 @@ int32_t qpc_qp_plan_info(const qpc_qp_problem *p, int64_t *out, int32_t n_out) {
   const bool on = p->plan_tried && P.valid;
   long long dense = 0;
   for (int j = 0; j < P.ne; j++) dense += (long long)(P.m + 1 - j) * (P.m + 2 - j) / 2;
-  const int64_t v[12] = {on ? 1 : 0, P.ne, P.mi, P.nfront, P.nlevel, P.njob, P.nval, on ? (int64_t)qpc::qp_sp_lds_doubles(P.ints.data(), P.mi) * 8 : 0, P.maxw, P.maxr, P.flops, dense};
+  int kw = P.mi; // (like the runtime: the working set's factor takes what is left of the 160 KB)
+  while (on && kw > 0 && qpc::qp_sp_lds_doubles(P.ints.data(), kw) > QPC_WG_LDS_DOUBLES) kw--;
+  const int64_t v[12] = {on ? 1 : 0, P.ne, P.mi, P.nfront, P.nlevel, P.njob, P.nval, on ? (int64_t)qpc::qp_sp_lds_doubles(P.ints.data(), kw) * 8 : 0, P.maxw, P.maxr, P.flops, dense};
   for (int i = 0; i < 12 && i < n_out; i++) out[i] = v[i];
   return QPC_OK;
 }

@@ -102,12 +102,12 @@ def free_fall(factory, B=3, seed=5354):
                 np.zeros((B, nc)), floating=fl)
 
 
-def momentum_rate(factory, seed=533454):
+def momentum_rate(factory, seed=533454, mech=None, name="momentum_rate"):
     """test/controller.jl:169-230: hard MomentumRateTask, per-QP contact normals/mu, random active
-    sets p in {0,.25,.5,.75,1} with achievable desired momentum rates."""
+    sets p in {0,.25,.5,.75,1} with achievable desired momentum rates.  mech: another humanoid than Atlas (its floating body is `pelvis`)"""
     from oracle import oracle as O
     rng = np.random.default_rng(seed)
-    mech = M.atlas()
+    mech = M.atlas() if mech is None else mech
     om = O.OracleModel(mech)  # only to generate the achievable desired wrench
     fl = mech.findbody("pelvis")
     c = factory(mech, 4, fl)
@@ -142,17 +142,17 @@ def momentum_rate(factory, seed=533454):
                 hdes += np.concatenate([np.cross(pw - com, fw), fw])
         qs.append(q); vs.append(v); des.append(hdes); cws.append(cw); cmaxs.append(cmax)
     B = len(qs)
-    return Case("momentum_rate", mech, c, np.array(qs), np.array(vs), np.array(des), np.array(cws),
+    return Case(name, mech, c, np.array(qs), np.array(vs), np.array(des), np.array(cws),
                 np.array(cmaxs), surf=np.tile(surf1, (B, 1)), floating=fl)
 
 
-def spatial_acceleration(factory, mode, B=2, seed=533):
+def spatial_acceleration(factory, mode, B=2, seed=533, mech=None, body="l_foot", base="r_hand", name=None):
     """test/controller.jl:232-285: foot w.r.t. palm SpatialAccelerationTask in palm frame, 5 modes."""
     rng = np.random.default_rng(seed)
-    mech = M.atlas()
+    mech = M.atlas() if mech is None else mech
     fl = mech.findbody("pelvis")
     c = factory(mech, 4, fl)
-    body, base = mech.findbody("l_foot"), mech.findbody("r_hand")
+    body, base = mech.findbody(body), mech.findbody(base)
     tw = None
     kw = dict(base=base, target=body, frame=base)
     if mode == "constraint":
@@ -174,7 +174,7 @@ def spatial_acceleration(factory, mode, B=2, seed=533):
     c.finalize()
     q, v = _states(mech, B, rng)
     # non-unique v̇ in the soft modes (no regularisation): only the task acceleration is compared
-    return Case(f"spatial_{mode}", mech, c, q, v, rng.uniform(size=(B, 6)), np.zeros((B, 0)),
+    return Case(name or f"spatial_{mode}", mech, c, q, v, rng.uniform(size=(B, 6)), np.zeros((B, 0)),
                 np.zeros((B, 0)), tw=tw, floating=fl, tol_tau=1e-8 if mode == "constraint" else np.inf)
 
 
