@@ -390,7 +390,6 @@ template <class P> struct Solver {
   real last_dmax = 0.0;                   // max |rho - rho_prev| of the last proximal sweep (uniform)
   bool t22_stale = false;                   // QPC_LAZY_T22: L_S22I does not belong to the S22 in L_C22 yet (ensure_t22)
   bool c_valid = false;                     // L_T1 holds c = E H^-1 (-g) - d (clobbered by kkt_solve)
-  real last_corr = 0.0;                     // size of the last refinement correction relative to the iterate (uniform): the a-posteriori error estimate
   bool confirmed = false;                   // eqp(from_current) stopped after ONE sweep whose correction was <= 1e-9 relative:
                                             // the residual arrays (of the iterate before that correction) bound the final ones
   // hot lookups staged in LDS (IT_HOT)
@@ -930,7 +929,6 @@ template <class P> struct Solver {
       // friction coefficients near zero) is allowed up to 5x the nominal sweep count.
       if (it > 0) {
         const real tol = QPC_T_STOP * (1.0 + rbig);
-        last_corr = rdbig / (1.0 + rbig);
         if (!(rdbig > tol)) break;
         // first correction of an already polished iterate: its size IS the error estimate of that
         // iterate, and the corrected one is better by the contraction factor (<= 1e-5)
@@ -2264,7 +2262,6 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, qpc_dta
   QPC_STOP(2)
   int status = QPC_STATUS_OPTIMAL, iters = 0;
   int refine = 0;
-  real final_corr = 0.0; // Solver::last_corr of the final refinement
   // Everything from the Schur complement to the accepted solution is written against the dimensions of ITS argument, so that the
   // same code solves the problem as assembled (D) or a reduced one (fewer free columns and rows, other leading dimensions)
   auto solve_part = [&](const QpcDims &D) QPC_LAMBDA_INLINE {
@@ -2825,7 +2822,6 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, qpc_dta
       // acceptance needs the true KKT residuals of the final iterate.  When the single confirming sweep changed the
       // iterate by <= 1e-9 relative, the residuals it started from (still in L_RV / L_RE / L_RR / L_RC, gradient in
       // L_WSP) are those of an iterate 1e-9 away -- far inside the 1e-7 acceptance tolerance -- and are not recomputed
-      final_corr = S.last_corr;
       if (!S.confirmed) S.residuals();
       real arp = 0.0, ars = 0.0, asp = 0.0, ass = 0.0, anan = 0.0, abv = 0.0, agm = 0.0, axm = 0.0;
       unsigned long long bbad = 0ull, bchanged = 0ull;
@@ -3046,9 +3042,6 @@ QPC_FN void qpc_tick(const QpcDims &D, const QpcDims &DS, const int *IT, qpc_dta
 #endif
       io.status[0] = st_;
       if (io.iters) io.iters[0] = iters + 1000 * refine + (reduced ? 1000000 : 0);
-#if defined(QPC_EXPERIMENTS) && !defined(__HIP_DEVICE_COMPILE__)
-      if (io.iters && getenv("QPC_EXP_CORR_IN_ITERS")) io.iters[0] = (int)(-1000.0 * std::log10((double)QPC_TO_DOUBLE(final_corr) + 1e-30)); // (emulation: the estimate, for its calibration)
-#endif
     }
   } QPC_END_PHASE
   QPC_PROF_ACC(PS_RNEA);
