@@ -23,6 +23,13 @@
  *    bodies <= 64, velocity coordinates nv <= 64, generic (non-pinned) tasks <= 63, tree depth <= 32
  *    (<= 16 without the hiprtc-specialised kernel), equality rows of the reduced QP (task rows that
  *    are not pins + 6 wrench-balance rows) <= 64, friction basis N <= 8, per-QP LDS slab <= 160 KiB.
+ *    Exercised AT these limits (tests/test_valkyrie.py, MI355X): a Valkyrie-sized humanoid of 59 bodies, nv = 64, tree depth 15, eight
+ *    contact points -- the reference's own integration tests (test/controller.jl:169-285) at their tolerances, 34 KB of LDS per QP,
+ *    92 us per tick at B = 1 and 8.4 M ticks/s at B = 2 048 (profiles/r05_valkyrie_latency.json); beyond Atlas in other directions:
+ *    44 bodies with 72 friction rays and 45 equality rows (tests/test_large_mechanism.py).  The solver-level plug (qpc_qp_setup /
+ *    qpc_qp_solve) takes n, m <= 256; the Valkyrie standing controller's reference-layout problem (171 x 206) runs in its sparse
+ *    form at 0.13 ms (B = 1, median) with 148 KB of LDS -- what bounds that form is LDS: plan tables + the factor's structure +
+ *    the working set's factor must fit 160 KB, otherwise the dense forms take the problem (qpc_qp_plan_info tells).
  *  - Streams: the *_device entry points enqueue on the caller's stream.  All launches of one
  *    controller on one device share a work counter, so they are serialised: when consecutive calls
  *    use DIFFERENT streams the library inserts an event dependency between them (no overlap, no
