@@ -187,8 +187,9 @@ def cpu_baseline(budget_s=12.0, max_workers=64):
 class DeviceRun:
     """A controller + one workload resident in HBM (torch tensors), launched through qpc_control_batch_device."""
 
-    def __init__(self, torch, binding, W, B, config, seed, device_index, fused_laws=False, f32=False, pack2=False):
+    def __init__(self, torch, binding, W, B, config, seed, device_index, fused_laws=False, f32=False, pack2=False, rotate=1):
         self.torch, self.B = torch, B
+        self.rotate, self.nstep = max(1, rotate), 0
         real_finalize = binding.Controller.finalize
 
         def fin(self_, device_id=0):
@@ -214,6 +215,12 @@ class DeviceRun:
         self.q, self.v = dev_t(wl.q), dev_t(wl.v)
         self.des = None if fused_laws else dev_t(wl.desired)
         self.cw, self.cm = dev_t(wl.contact_weight), dev_t(wl.contact_maxnormalforce)
+        # rotate > 1 (measurement only, --rotate-inputs): that many distinct copies of the input record, taken in turn -- consecutive
+        # launches then read different memory, so that no cache between the shader and HBM (the 256 MB MALL) can serve a launch from the
+        # previous one's reads
+        self.in_sets = [(self.q, self.v, self.des, self.cw, self.cm)]
+        for _ in range(self.rotate - 1):
+            self.in_sets.append(tuple(None if t is None else t.clone() for t in self.in_sets[0]))
         self.tau = torch.empty((B, lay.nv), dtype=torch.float64, device=dev)
         self.vd = torch.empty((B, lay.nv), dtype=torch.float64, device=dev)
         self.cwr = torch.empty((B, max(lay.n_contacts, 1) * 6), dtype=torch.float64, device=dev)
@@ -228,8 +235,10 @@ class DeviceRun:
         def ptr(t):
             return vp(t.data_ptr()) if t is not None and t.numel() else vp(0)
         nc = lay.n_contacts
-        rc = L.qpc_control_batch_device(self.ctrl.h, self.B, ptr(self.q), ptr(self.v), ptr(self.des), ptr(self.cw) if nc else vp(0),
-                                        ptr(self.cm) if nc else vp(0), vp(0), vp(0), ptr(self.tau), ptr(self.vd),
+        q_, v_, des_, cw_, cm_ = self.in_sets[self.nstep % self.rotate]
+        self.nstep += 1
+        rc = L.qpc_control_batch_device(self.ctrl.h, self.B, ptr(q_), ptr(v_), ptr(des_), ptr(cw_) if nc else vp(0),
+                                        ptr(cm_) if nc else vp(0), vp(0), vp(0), ptr(self.tau), ptr(self.vd),
                                         ptr(self.cwr) if nc else vp(0), ptr(self.status), ptr(self.iters), vp(self.stream.cuda_stream))
         if rc != 0:
             raise RuntimeError(L.qpc_last_error().decode())
@@ -499,10 +508,24 @@ def measured_traffic(fingerprint):
     if best is None:
         return None, "no profile under profiles/ carries the fingerprint of the built kernel (" + fingerprint + "): traffic not quoted"
     f, d = best
-    bytes_per_launch = (d["FETCH_SIZE"]["per_launch_KiB"] + d["WRITE_SIZE"]["per_launch_KiB"]) * 1024.0
-    return bytes_per_launch, (f"{os.path.relpath(f, ROOT)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, KiB as reported on gfx950; "
-                              f"8-byte-per-lane accesses, so the x2 wide-read correction of MI355X_MICROARCH.md does not apply), "
-                              f"{d.get('qps_per_launch', 32768)} QPs per launch, kernel fingerprint {fingerprint} == built kernel")
+    qps = d.get("qps_per_launch", 32768)
+    src = f"{os.path.relpath(f, ROOT)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, KiB as reported on gfx950), {qps} QPs per launch, kernel fingerprint {fingerprint} == built kernel"
+    fetch, write = d["FETCH_SIZE"]["per_launch_KiB"] * 1024.0, d["WRITE_SIZE"]["per_launch_KiB"] * 1024.0
+    fr, wr = d.get("FETCH_SIZE_inputs_rotated"), d.get("WRITE_SIZE_inputs_rotated")
+    if not fr or not fr.get("launches"):
+        return fetch + write, src + "; no pass with rotated inputs in this profile: FETCH as counted (identical inputs of consecutive launches may have been served by the memory-side cache)"
+    # the plain pass counted FEWER bytes fetched than the kernel must read.  The second pair of passes cycles the inputs through
+    # 9 distinct copies (295 MB, more than the 256 MB memory-side cache), so that no launch can be served from its predecessor's reads:
+    must_read = (ALG_BYTES_PER_SOLVE - 968) * qps  # the input half of the algorithmic bytes (1 000 B in, 968 B out per solve)
+    fetch_r = fr["per_launch_KiB"] * 1024.0
+    write_r = wr["per_launch_KiB"] * 1024.0 if wr and wr.get("launches") else write
+    if fetch_r >= 0.97 * must_read:
+        return fetch_r + write_r, (src + f"; inputs ROTATED through 9 copies: FETCH {fetch_r / 1e6:.1f} MB per launch >= the {must_read / 1e6:.1f} MB the kernel must read "
+                                   f"(plain pass, identical inputs every launch: {fetch / 1e6:.1f} MB -- the shortfall was reuse between launches in the memory-side cache, "
+                                   f"not under-counting: no x2 correction); traffic = FETCH + WRITE of the rotated passes")
+    return 2.0 * fetch_r + write_r, (src + f"; inputs ROTATED through 9 copies: FETCH still {fetch_r / 1e6:.1f} MB per launch < the {must_read / 1e6:.1f} MB the kernel must read "
+                                     f"(plain pass {fetch / 1e6:.1f} MB): the counter under-reports these reads -- FETCH doubled as MI355X_MICROARCH.md prescribes; "
+                                     f"traffic = 2 FETCH + WRITE of the rotated passes")
 
 
 def measured_issue(fingerprint):
@@ -666,6 +689,8 @@ def main():
     ap.add_argument("--config", type=int, default=3, choices=[2, 3, 5])
     ap.add_argument("--f32", action="store_true", help="the fp32 variant of the tick (qpc_set_precision): not the headline (tau 1e-4 instead of 1e-8)")
     ap.add_argument("--pack2", action="store_true", help="two QPs per wavefront (qpc_set_qps_per_wavefront(2))")
+    ap.add_argument("--rotate-inputs", type=int, default=1, help="measurement only: cycle through that many distinct copies of the input record "
+                    "(9 copies of config 3 at 32 768 are 295 MB: more than the 256 MB MALL) -- tools/profile_round.sh's traffic pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the literal-BASELINE-batch points and the host-pointer path")
     ap.add_argument("--fused-laws", action="store_true",
@@ -706,7 +731,7 @@ def main():
     B = args.batch_per_gpu
     # every rank builds its own contiguous shard [rank*B, (rank+1)*B) of the global batch
     run = DeviceRun(torch, binding, W, B, args.config, {2: 2024, 3: 2025, 5: 2027}[args.config] + 7919 * rank, local_rank,
-                    fused_laws=args.fused_laws, f32=args.f32, pack2=args.pack2)
+                    fused_laws=args.fused_laws, f32=args.f32, pack2=args.pack2, rotate=args.rotate_inputs)
     ctrl, lay, L = run.ctrl, run.lay, run.ctrl.L
     dev = run.dev
 
@@ -813,6 +838,7 @@ def main():
                        "cost_ordered_tickets": ordered,
                        "closed_loop": closed_loop,
                        "l0_plugin": l0_plugin,
+                       "rotate_inputs": args.rotate_inputs,
                        "kernel_fingerprint": fingerprint},
             "roofline": {"bound": "hbm", "achieved": ach_bytes / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": ach_bytes / HBM_PEAK,

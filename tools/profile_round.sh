@@ -13,6 +13,10 @@ BENCH="python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secon
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o k --output-format csv -- $BENCH > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o k --output-format csv -- $BENCH > /dev/null 2> $OUT/fetch.log
 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o k --output-format csv -- $BENCH > /dev/null 2> $OUT/write.log
+# the same two counters with the inputs ROTATED through 9 distinct copies (295 MB > the 256 MB MALL): consecutive launches read different
+# memory -- if FETCH_SIZE then rises to the compulsory bytes, the shortfall of the plain pass was cache reuse between launches
+rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch_rot -o k --output-format csv -- $BENCH --rotate-inputs 9 > /dev/null 2> $OUT/fetch_rot.log || echo "fetch_rot pass failed"
+rocprofv3 --pmc WRITE_SIZE -d $OUT/write_rot -o k --output-format csv -- $BENCH --rotate-inputs 9 > /dev/null 2> $OUT/write_rot.log || echo "write_rot pass failed"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS -d $OUT/sq_a -o k --output-format csv -- $BENCH > /dev/null 2> $OUT/sq_a.log
 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY -d $OUT/sq_b -o k --output-format csv -- $BENCH > /dev/null 2> $OUT/sq_b.log
 # lane utilisation of the vector instructions: thread-cycles / (instruction-cycles x 64) = rocprofiler's VALUUtilization

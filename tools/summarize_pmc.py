@@ -33,12 +33,15 @@ def main():
     for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True):
         shutil.copy(f, dst + "_kernel_stats.csv")
     traffic = {}
-    for name, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+    for name, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write"), ("FETCH_SIZE", "fetch_rot"), ("WRITE_SIZE", "write_rot")):
         v = counters(os.path.join(src, sub)).get(name, [])
         v = v[3:] if len(v) > 3 else v  # drop the warm-up launches
-        for f in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
-            shutil.copy(f, f"{dst}_pmc_{name.lower()}.csv")
-        traffic[name] = {"per_launch_KiB": sum(v) / max(len(v), 1), "launches": len(v), "min": min(v, default=0), "max": max(v, default=0)}
+        rot = sub.endswith("_rot")  # (the passes with the inputs rotated through 9 distinct copies: no reuse between launches)
+        if not rot:
+            for f in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
+                shutil.copy(f, f"{dst}_pmc_{name.lower()}.csv")
+        if v or not rot:
+            traffic[name + ("_inputs_rotated" if rot else "")] = {"per_launch_KiB": sum(v) / max(len(v), 1), "launches": len(v), "min": min(v, default=0), "max": max(v, default=0)}
     # identity of the kernel these counters belong to: bench.py quotes the traffic only for the kernel it was measured on
     try:
         bj = json.loads(open(os.path.join(src, "bench_under_rocprof.json")).read().strip().splitlines()[-1])
