@@ -2,8 +2,10 @@
 //       min 1/2 x'Px + q'x   s.t.   l <= A x <= u
 // solved by the 512 threads of one workgroup with its working matrices in LDS -- what makes the solver-level plug of the reference
 // (`Parametron.Model(optimizer)`, /root/reference/src/lowlevel/momentum.jl:15-16,27,58; `QPCOptimizer` in julia/QPControlHIPMOI.jl)
-// usable at B = 1: the one-lane-per-QP form of qpc_qp_dense.h needs 0.57 s for the 143 x 178 Atlas problem (measured, MI355X), the
-// reference's own warm-started OSQP 0.8 - 1.3 ms on a CPU core.
+// usable at B = 1: the one-lane-per-QP form of qpc_qp_dense.h needs 0.57 s for the 143 x 178 Atlas problem (measured, MI355X); the oracle's
+// OSQP on one CPU core: 0.15 ms warm-started from the same problem's solution, 0.27 - 0.80 ms cold at the notebook's tolerances,
+// 0.44 - 3.4 ms at the test suite's (bench.py cpu_baseline.l0_fixture_osqp measures them in every run).  Since round 5 this DENSE form
+// stands behind the dense entry qpc_qp_solve_batch and takes what the sparse form (qpc_qp_sp.h) leaves of a prepared problem.
 //
 // Same method as qpc_qp_dense.h (range-space active set on G = A H^-1 A', primal-dual multi-change sweeps, Goldfarb-Idnani, iterative
 // refinement on the true KKT residuals), for the problems Parametron actually builds for this controller: a DIAGONAL P (regularize!,

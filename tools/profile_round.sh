@@ -23,5 +23,6 @@ rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLI
 rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F64 -d $OUT/sq_c -o k --output-format csv -- $BENCH > /dev/null 2> $OUT/sq_c.log || echo "sq_c pass failed (see sq_c.log)"
 # the solver-level plug (L0): kernel durations of the dense and the prepared entry at B = 1 and B = 8192 (device time without PCIe)
 rocprofv3 --kernel-trace --stats -d $OUT/l0 -o k --output-format csv -- python3 $ROOT/tools/bench_latency.py --l0 1 8192 > $OUT/l0_latency_under_rocprof.json 2> $OUT/l0.log || echo "l0 pass failed (see l0.log)"
-python3 $ROOT/bench.py --steps 20 --warmup 3 > $OUT/bench_full.json 2> $OUT/bench_full.err
+# (SKIP_FULL=1: the full bench line -- cpu_baseline, secondary points, L0 -- is taken in a gpurun call of its own)
+[ -n "$SKIP_FULL" ] || python3 $ROOT/bench.py --steps 20 --warmup 3 > $OUT/bench_full.json 2> $OUT/bench_full.err
 find $OUT -name "*.csv" | head -20
