@@ -523,9 +523,23 @@ def measured_traffic(fingerprint):
         return fetch_r + write_r, (src + f"; inputs ROTATED through 9 copies: FETCH {fetch_r / 1e6:.1f} MB per launch >= the {must_read / 1e6:.1f} MB the kernel must read "
                                    f"(plain pass, identical inputs every launch: {fetch / 1e6:.1f} MB -- the shortfall was reuse between launches in the memory-side cache, "
                                    f"not under-counting: no x2 correction); traffic = FETCH + WRITE of the rotated passes")
-    return 2.0 * fetch_r + write_r, (src + f"; inputs ROTATED through 9 copies: FETCH still {fetch_r / 1e6:.1f} MB per launch < the {must_read / 1e6:.1f} MB the kernel must read "
-                                     f"(plain pass {fetch / 1e6:.1f} MB): the counter under-reports these reads -- FETCH doubled as MI355X_MICROARCH.md prescribes; "
-                                     f"traffic = 2 FETCH + WRITE of the rotated passes")
+    # ... it did not.  tools/fetch_calib.hip read KNOWN byte counts in the tick's access pattern (profiles/r05_fetch_calibration.json): FETCH_SIZE is
+    # TCC_EA0_RDREQ x 64 B while every request is a 128-B line -- exactly half the bytes for streams of 16 and 8 B per lane and for aligned
+    # records alike -- and unaligned per-QP records fetched by wavefronts on different XCDs bring their shared lines in more than once
+    # (x 1.38 for 296-B records, x 1.94 for 64-B ones).  So: FETCH doubled, and what then exceeds the compulsory bytes is partial lines.
+    calib = ""
+    try:
+        cj = json.load(open(os.path.join(ROOT, "profiles", "r05_fetch_calibration.json")))["kernels"]
+        calib = (f"; calibration on known byte counts (profiles/r05_fetch_calibration.json): counted / known = {cj['calib_stream16']['factor']:.2f} for a 16 B/lane stream, "
+                 f"{cj['calib_stream8']['factor']:.2f} for 8 B/lane, {cj['calib_records<64>']['factor']:.2f} for aligned 512-B records, i.e. every 128-B request tallied at 64 B; "
+                 f"unaligned records drawn by wavefronts on different XCDs fetch shared lines more than once: 2 x counted / known = {2 * cj['calib_records<37>']['factor']:.2f} for 296-B records, "
+                 f"{2 * cj['calib_records<8>']['factor']:.2f} for 64-B records")
+    except (OSError, ValueError, KeyError):
+        pass
+    return 2.0 * fetch_r + write_r, (src + f"; inputs ROTATED through 9 copies: FETCH still {fetch_r / 1e6:.1f} MB per launch (plain pass {fetch / 1e6:.1f} MB) < the {must_read / 1e6:.1f} MB the kernel must read: "
+                                     f"not reuse between launches, the counter under-reports -- FETCH doubled as MI355X_MICROARCH.md prescribes" + calib +
+                                     f"; traffic = 2 FETCH + WRITE of the rotated passes = {(2.0 * fetch_r + write_r) / 1e6:.1f} MB per launch against {ALG_BYTES_PER_SOLVE * qps / 1e6:.1f} MB algorithmic "
+                                     f"(the excess is partial 128-B lines of the per-QP records; at < 2 % of the HBM rate it costs no time)")
 
 
 def measured_issue(fingerprint):
