@@ -69,7 +69,10 @@ def _compare(f32_factory, f64_factory, B, config, seed, n_oracle):
     unresolved = ok64 & ~ok32
     assert unresolved.mean() <= UNRESOLVED_MAX, unresolved.mean()
     assert (unresolved & (nact >= 4)).mean() <= UNRESOLVED_WELL_MAX, np.where(unresolved & (nact >= 4))[0]
-    assert np.all(r32["status"][unresolved & (nact >= 4)] == 4)  # ... all of them reported as ITERATION_LIMIT
+    # ... every one of them reported as a FAILURE (ITERATION_LIMIT mostly; NUMERICAL_ERROR or a spurious INFEASIBLE where the residual floor
+    # of fp32 is above the acceptance band: seen once in 2 048 config-5 states on the GPU, never in the emulation) -- `checkstatus`
+    # (momentum.jl:83-91) throws on all three alike
+    assert np.all(np.isin(r32["status"][unresolved & (nact >= 4)], (2, 3, 4)))
     # (3) against the oracle on a sample: statuses wherever it is conclusive (except the unresolved ones), numbers where it is optimal
     oc, _ = W.atlas_workload(ora_factory, 1, config)
     idx = np.random.default_rng(seed).choice(B, min(n_oracle, B), replace=False)
