@@ -12,10 +12,30 @@ import qpc_pkg  # noqa: E402
 qpc_pkg.load()
 
 
+_SESSION_JIT_DIR = None
+
+
 def pytest_configure(config):
+    # One code-object cache for the SESSION (qpc_jit.cpp, QPC_JIT_CACHE_DIR): a fresh, empty directory, removed at the end.  Every distinct
+    # controller is still compiled by hiprtc once per run; the checks that start child processes (tests/gpu_torch_checks.py, the bench
+    # ranks) and repeat a controller the session has built read it back instead of spending 5 s each on the same compilation.
+    global _SESSION_JIT_DIR
+    if "QPC_JIT_CACHE_DIR" not in os.environ:
+        import tempfile
+        _SESSION_JIT_DIR = tempfile.mkdtemp(prefix="qpc_jit_session_")
+        os.environ["QPC_JIT_CACHE_DIR"] = _SESSION_JIT_DIR
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "gpu_slow: a LONG gpu test (a larger sample, more seeds, a second variant of something the fast set covers): "
                                        "left out of `-m gpu`, run with `-m gpu_slow` (or `-m \"gpu or gpu_slow\"`); always marked gpu as well")
+
+
+def pytest_unconfigure(config):
+    global _SESSION_JIT_DIR
+    if _SESSION_JIT_DIR:
+        import shutil
+        shutil.rmtree(_SESSION_JIT_DIR, ignore_errors=True)
+        os.environ.pop("QPC_JIT_CACHE_DIR", None)
+        _SESSION_JIT_DIR = None
 
 
 def pytest_collection_modifyitems(config, items):
