@@ -261,6 +261,48 @@ class DeviceRun:
         return el, avg_ms.value, int(nl.value)
 
 
+_ACCURACY_SAMPLE = {}
+
+
+def accuracy_leg():
+    """cpu_baseline leg: what the reference's own regime delivers in ACCURACY on BASELINE config 5 -- the oracle's OSQP at the notebook's
+    tolerances (eps_abs = eps_rel = 1e-5, Standing controller.ipynb:68-71; cold start) on a sample of the states the fp32 tick was run on,
+    its tau against the fp64 tick's (exact to 1e-8 against the oracle at the test suite's tolerances: tests/test_gpu_parity.py), in the
+    same measure as `vs_f64` (relative to max(1, |tau|_inf)), with the fp32 tick's error on the SAME sample beside it.  An answer either
+    of them calls OPTIMAL is what `checkstatus` (momentum.jl:83-91) lets through."""
+    S = _ACCURACY_SAMPLE
+    if not S:
+        return None
+    try:
+        from oracle import oracle as O
+        from qpcontrol_jl_amd import workloads as W
+
+        def ora_factory(mech, N, fl):
+            return O.OracleController(O.OracleModel(mech), N, fl)
+        oc, _ = W.atlas_workload(ora_factory, 1, S["config"])
+        oc.set_settings(O.notebook_settings(polish=0))
+        t0 = time.perf_counter()
+        ro = oc.tick_batch(S["q"], S["v"], S["desired"], S["cw"], S["cm"])
+        sec = time.perf_counter() - t0
+        ok64 = S["s64"] <= 1
+        scale = np.maximum(1.0, np.abs(S["tau64"]).max(axis=1, keepdims=True))
+        eo = (np.abs(ro["tau"] - S["tau64"]) / scale).max(axis=1)
+
+        def dist(e):
+            if not len(e):
+                return None
+            return {"qps": int(len(e)), "rel_tau_err_median": float(np.median(e)), "rel_tau_err_p99": float(np.percentile(e, 99)),
+                    "rel_tau_err_p999": float(np.percentile(e, 99.9)), "rel_tau_err_max": float(e.max()),
+                    "fraction_beyond_1e-4": float((e > 1e-4).mean()), "fraction_beyond_1e-3": float((e > 1e-3).mean())}
+        return {"sample": f"the first {len(eo)} states of BASELINE config 5 (seed {S['seed']}), one core, {sec:.1f} s",
+                "reference_regime_osqp_eps_1e-5_status_optimal": dist(eo[(ro["status"] == 0) & ok64]),
+                "fp32_tick_status_optimal_same_sample": dist(S["err32"][(S["s32"] == 0) & ok64]),
+                "note": "tau against the fp64 tick of the same states, relative to max(1, |tau|_inf); the reference runs Atlas at these tolerances and "
+                        "accepts every such answer (momentum.jl:83-91)"}
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)}
+
+
 def secondary_points(torch, binding, W, device_index):
     """The literal BASELINE.json batches on this GPU (device-resident inputs, same kernel), outside the headline's timed
     region: config 2 @ 1024, config 3 @ 8192, config 5 @ 32768, config 3 @ 262144."""
@@ -291,6 +333,11 @@ def secondary_points(torch, binding, W, device_index):
                         "rel_tau_err_p999": float(np.percentile(err[opt], 99.9)), "rel_tau_err_max": float(err[opt].max()),
                         "beyond_1e-4": int((err[opt] > 1e-4).sum()), "beyond_1e-3": int((err[opt] > 1e-3).sum())}
                 pt["vs_f64"]["unresolved_fraction"] = float(((s64 <= 1) & ~(s32 <= 1)).mean())
+                # a sample of the same states for cpu_baseline's accuracy leg (what the REFERENCE's own regime delivers on them)
+                ns = 1024
+                wl = run.wl
+                _ACCURACY_SAMPLE.update(config=5, seed=2027, q=wl.q[:ns].copy(), v=wl.v[:ns].copy(), desired=wl.desired[:ns].copy(), cw=wl.contact_weight[:ns].copy(),
+                                        cm=wl.contact_maxnormalforce[:ns].copy(), tau64=t64[:ns].copy(), s64=s64[:ns].copy(), err32=err[:ns].copy(), s32=s32[:ns].copy())
         out.append(pt)
         del run
     return out
@@ -894,6 +941,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["cpu_baseline"]["l0_fixture_osqp"] = l0_cpu_leg()
+            acc = accuracy_leg()
+            if acc is not None:
+                out["cpu_baseline"]["accuracy_config5"] = acc
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

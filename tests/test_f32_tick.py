@@ -14,7 +14,10 @@ Checked against the oracle (fp64, reference layout) and against the fp64 tick of
     precision (NUMERICAL_ERROR / ITERATION_LIMIT / a spurious INFEASIBLE on such ill-conditioned QPs): at most UNRESOLVED_MAX of
     the batch, and at most UNRESOLVED_WELL_MAX of it with four or more active contacts (stragglers of the working-set search --
     optima that pin 25+ of the 32 rays -- whose sign tests cycle on fp32 rounding noise: ITERATION_LIMIT after 48 changes);
-  * config 3 (all eight contacts): > 99.8 % of the states OPTIMAL (fp64: all).
+  * config 3 (all eight contacts): > 99.8 % of the states OPTIMAL (fp64: all);
+  * in the reference's own terms: on the same states the fp32 tick's accepted answers are closer to the optimum than what the reference
+    accepts in the regime it runs Atlas in (OSQP at eps 1e-5): fp32's 90th percentile a tenth of OSQP's median, fp32's worst below
+    OSQP's worst.
 CPU: the lane-serial emulation of the fp32 source (tests/emul, libqpc_emul_f32.so).  GPU: the hiprtc-specialised fp32 module."""
 import numpy as np
 import pytest
@@ -85,7 +88,21 @@ def _compare(f32_factory, f64_factory, B, config, seed, n_oracle):
     so = np.maximum(1.0, np.abs(ro["tau"]).max(axis=1, keepdims=True))
     eo = (np.abs(r32["tau"][idx] - ro["tau"]) / so).max(axis=1)
     assert np.median(eo[both]) < TOL_MEDIAN and eo[both].max() < TOL_MAX
-    print(f"\nfp32 tick, config {config}, {B} states: optimal fp32 {ok32.mean():.3f} / fp64 {ok64.mean():.3f}, unresolved {unresolved.mean():.4f}, "
+    # (4) the contract in the reference's own terms: the reference runs Atlas with OSQP at eps_abs = eps_rel = 1e-5 (Standing
+    # controller.ipynb:68-71) and `checkstatus` (momentum.jl:83-91) accepts every such answer.  On the same sample, against the same fp64
+    # optimum, the fp32 tick's accepted answers are closer by two orders of magnitude (measured on 1 024 config-5 states: OSQP at 1e-5
+    # median 8e-5, p99 8e-3, worst 1.7e-2; fp32 tick median 5e-7, p99 6e-6, worst 7e-5)
+    oc.set_settings(O.notebook_settings(polish=0))
+    rn = oc.tick_batch(wl.q[idx], wl.v[idx], wl.desired[idx], wl.contact_weight[idx], wl.contact_maxnormalforce[idx])
+    okn = (rn["status"] == 0) & ok64[idx]
+    en = (np.abs(rn["tau"] - r64["tau"][idx]) / scale[idx]).max(axis=1)[okn]
+    e32 = err[idx][ok32[idx]]
+    assert okn.sum() > 0.5 * len(idx)
+    assert np.percentile(e32, 90) < 0.1 * np.median(en), (np.percentile(e32, 90), np.median(en))  # (samples of 48 ... 256 states: percentiles a sample of that size resolves)
+    assert e32.max() < en.max(), (e32.max(), en.max())
+    print(f"\nthe reference's notebook regime (OSQP at 1e-5) on the sample: rel tau error median {np.median(en):.1e} p99 {np.percentile(en, 99):.1e} max {en.max():.1e}; "
+          f"fp32 tick on the same states: median {np.median(e32):.1e} p99 {np.percentile(e32, 99):.1e} max {e32.max():.1e}")
+    print(f"fp32 tick, config {config}, {B} states: optimal fp32 {ok32.mean():.3f} / fp64 {ok64.mean():.3f}, unresolved {unresolved.mean():.4f}, "
           f"rel tau error vs fp64 median {np.median(err[ok32]):.1e} p99.9 {np.percentile(err[well], 99.9):.1e} max {err[ok32].max():.1e}, "
           f"vs oracle max {eo[both].max():.1e} on {int(both.sum())} states; working-set changes fp32 {(r32['iters'] % 1000).mean():.2f} / "
           f"fp64 {(r64['iters'] % 1000).mean():.2f}")
