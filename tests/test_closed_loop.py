@@ -50,8 +50,9 @@ def test_closed_loop_emulated():
 
 
 @pytest.mark.gpu
-def test_closed_loop_gpu():
-    ctrl, log = run(None, 16, 2000)  # 2 s of simulated time, 16 robots
+@pytest.mark.parametrize("steps", [1500, pytest.param(2500, marks=pytest.mark.gpu_slow)])
+def test_closed_loop_gpu(steps):
+    ctrl, log = run(None, 16, steps)  # 1.5 s of simulated time (as the emulated test), 16 robots; `-m gpu_slow`: 2.5 s
     com = log["com"][-1]
     assert np.all(np.abs(com[:, :2] - ctrl.comref[:2]) < 0.02), com[:, :2] - ctrl.comref[:2]
     assert np.all(np.abs(com[:, 2] - ctrl.comref[2]) < 0.03), com[:, 2] - ctrl.comref[2]
