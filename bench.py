@@ -460,6 +460,10 @@ def l0_plugin_point():
                  "latency_us_B1_warm_worst_problem": pr.get("B1_warm_worst_problem_us"),
                  "warm_means": pr.get("warm_means"),
                  "solves_per_s_B8192_cold": big.get("cold_solves_per_s"), "solves_per_s_B8192_warm": big.get("warm_solves_per_s"),
+                 "solves_per_s_B8192_page_locked_cold": big.get("page_locked_cold_solves_per_s"), "solves_per_s_B8192_page_locked_warm": big.get("page_locked_warm_solves_per_s"),
+                 # values, bounds and results resident in HBM (qpc_qp_solve_device): the rate of the path without PCIe
+                 "solves_per_s_B8192_device_resident_cold": big.get("device_resident_cold_solves_per_s"),
+                 "solves_per_s_B8192_device_resident_warm": big.get("device_resident_warm_solves_per_s"),
                  "max_abs_err_vdot_vs_fixture": big.get("max_abs_err_vdot_vs_fixture"),
                  "matrix_weighted_task_146x181": {"plan": pm.get("plan"),
                                                   "latency_us_B1_cold_median_over_problems": pm.get("B1_cold_median_over_problems_us"),

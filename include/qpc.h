@@ -508,6 +508,16 @@ int32_t qpc_qp_solve(qpc_qp_problem *problem, int64_t B, const double *P_vals, c
                      const qpc_settings *settings, int32_t warm_start, double *x, double *y,
                      int32_t *status, int32_t *iters);
 int32_t qpc_qp_analyze(qpc_qp_problem *problem, const double *l, const double *u);
+/* qpc_qp_solve on DEVICE pointers (memory of the problem's device): values, bounds and results stay in HBM -- for a caller that builds
+ * its QPs on the GPU, and the rate of the path without the 13 KB per problem over PCIe.  Same arguments, same three forms in the same
+ * order, same results bit for bit.  The plan must exist (qpc_qp_analyze with one QP's bounds from the host, or an earlier
+ * qpc_qp_solve): without one the dense forms take the whole batch.  Work is queued on `hip_stream` (0: the default stream); the call
+ * returns after it has synchronised that stream -- once per form that ran, normally once: between the forms the host learns how many
+ * QPs are left.  One call at a time per problem (the forms share the problem's counter and its warm-start multipliers). */
+int32_t qpc_qp_solve_device(qpc_qp_problem *problem, int64_t B, const double *P_vals, const double *q,
+                            const double *A_vals, const double *l, const double *u,
+                            const qpc_settings *settings, int32_t warm_start, double *x, double *y,
+                            int32_t *status, int32_t *iters, void *hip_stream);
 int32_t qpc_qp_plan_info(const qpc_qp_problem *problem, int64_t *out, int32_t n_out);
 /* Measurement: with `on` != 0 every qpc_qp_solve brackets its kernels with HIP events on the problem's own stream;
  * qpc_qp_last_kernel_ms: the device time of the last call's kernels (all three forms together), milliseconds.  bench.py's

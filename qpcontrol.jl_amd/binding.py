@@ -104,6 +104,8 @@ def load_library(path=None):
         L.qpc_qp_plan_info.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), i32]
         L.qpc_qp_enable_timing.argtypes = [vp, i32]
         L.qpc_qp_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
+        if hasattr(L, "qpc_qp_solve_device"):
+            L.qpc_qp_solve_device.argtypes = [vp, i64] + [vp] * 5 + [ctypes.POINTER(Settings), i32, vp, vp, vp, vp, vp]
     L.qpc_assemble_solve_batch.argtypes = [vp, i64] + [c_double_p] * 11 + [c_double_p, c_double_p, c_int32_p, c_int32_p]
     L.qpc_sim_step_batch.argtypes = [vp, i64, c_double_p, c_double_p, c_double_p, c_int32_p, ctypes.POINTER(SimParams), c_int32_p]
     L.qpc_rollout_batch.argtypes = [vp, i64, i64] + [c_double_p] * 7 + [ctypes.POINTER(SimParams), c_double_p, c_int32_p, c_int32_p]
@@ -535,6 +537,14 @@ class QpProblem:
                                  out["status"].ctypes.data_as(c_int32_p), out["iters"].ctypes.data_as(c_int32_p))
         _check(self.L, rc, "qpc_qp_solve")
         return out
+
+    def solve_device(self, B, P_vals, q, A_vals, l, u, x, y, status, iters=0, warm_start=False, stream=0):
+        """qpc_qp_solve_device: every array argument is a DEVICE address (an int, e.g. torch.Tensor.data_ptr()) on the problem's device;
+        the plan must exist (`analyze`).  Returns when `stream` has been synchronised."""
+        vp = ctypes.c_void_p
+        rc = self.L.qpc_qp_solve_device(self.h, int(B), vp(P_vals), vp(q), vp(A_vals), vp(l), vp(u), None, int(bool(warm_start)), vp(x), vp(y), vp(status),
+                                        vp(iters), vp(stream))
+        _check(self.L, rc, "qpc_qp_solve_device")
 
     def analyze(self, l, u):
         """the plan of the sparse workgroup solver for the equality rows of one QP's bounds, ahead of the first solve (qpc_qp_analyze)"""

@@ -154,6 +154,14 @@ qpc_qp_sp_kernel(const int *plan, int lds_doubles, long long B, long long nnzP, 
   }
 }
 // the dense matrices of the prepared problem's QPs (for the dense path: a P with off-diagonal entries, or a QP the workgroup left)
+// how many QPs of a batch a workgroup form has left to the next one (status == QPC_WG_FALLBACK): qpc_qp_solve_device decides on the host
+// whether the next form runs at all
+extern "C" __global__ void __launch_bounds__(256) qpc_qp_count_left_kernel(const int32_t *status, long long B, int *count) {
+  const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long left = __ballot(b < B && status[b] == QPC_WG_FALLBACK);
+  if ((threadIdx.x & 63) == 0 && left) atomicAdd(count, (int)__popcll(left));
+}
+
 extern "C" __global__ void qpc_qp_densify_kernel(int n, int m, long long B, long long nnzP, const int *Prow, const int *Pcol,
                                                  const double *Pv, long long nnzA, const int *Arow, const int *Acol,
                                                  const double *Av, double *P, double *A) {
@@ -367,6 +375,7 @@ struct qpc_qp_problem {
   unsigned long long *d_stamps = nullptr;
   hipStream_t stream2 = nullptr;           // a LARGE batch goes in chunks over two streams: a chunk's copies beside the other's kernel
   unsigned long long *d_ticket2 = nullptr;
+  int *d_left = nullptr, *h_left = nullptr; // qpc_qp_solve_device: how many QPs a workgroup form has left (device counter, page-locked copy)
   bool timing = false;                     // qpc_qp_enable_timing: events around the kernels of a solve
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double last_kernel_ms = 0.0;
@@ -500,6 +509,8 @@ void qpc_qp_free(qpc_qp_problem *p) {
   if (p->ev0) { (void)hipEventDestroy(p->ev0); (void)hipEventDestroy(p->ev1); }
   if (p->stream2) { (void)hipStreamSynchronize(p->stream2); (void)hipStreamDestroy(p->stream2); }
   if (p->d_ticket2) (void)hipFree(p->d_ticket2);
+  if (p->d_left) (void)hipFree(p->d_left);
+  if (p->h_left) (void)hipHostFree(p->h_left);
   delete p;
 }
 
@@ -754,6 +765,122 @@ int32_t qpc_qp_solve(qpc_qp_problem *p, int64_t B, const double *P_vals, const d
   }
   chk(hipStreamSynchronize(p->stream), "qpc_qp_solve");
   if (rc == QPC_OK) for (int64_t b = 0; b < B; b++) status[b] = hst[(size_t)b];
+  return rc;
+}
+
+// ---- the prepared entry on DEVICE pointers: values, bounds and results stay in HBM (a caller that builds its QPs on the GPU; the rate
+//      without the 13 KB per problem over PCIe).  The same three forms in the same order; between them the host learns how many QPs are
+//      left (one 4-byte copy and one synchronisation of `hip_stream` per form that ran) -- normally the sparse form takes them all.
+int32_t qpc_qp_solve_device(qpc_qp_problem *p, int64_t B, const double *dPv, const double *dq, const double *dAv, const double *dl,
+                            const double *du, const qpc_settings *settings, int32_t warm_start, double *dx, double *dy, int32_t *dst,
+                            int32_t *dit, void *hip_stream) {
+  if (!p) { qpc_set_error("qpc_qp_solve_device: null problem"); return QPC_ERR_INVALID_ARGUMENT; }
+  const int n = p->H.n, m = p->H.m;
+  const long long nnzP = p->H.nnzP, nnzA = p->H.nnzA;
+  if (B < 0 || (nnzP && !dPv) || !dq || (m && ((nnzA && !dAv) || !dl || !du)) || !dx || (m && !dy) || !dst) {
+    qpc_set_error("qpc_qp_solve_device: bad arguments"); return QPC_ERR_INVALID_ARGUMENT;
+  }
+  if (B == 0) return QPC_OK;
+  HIP_TRY(hipSetDevice(p->device));
+  hipStream_t sm = (hipStream_t)hip_stream;
+  qpc_settings st;
+  if (settings) st = *settings; else qpc_default_settings(&st);
+  if (!p->d_left) {
+    HIP_TRY(hipMalloc(&p->d_left, sizeof(int)));
+    if (hipHostMalloc(&p->h_left, sizeof(int), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p->d_left); p->d_left = nullptr; qpc_set_error("qpc_qp_solve_device: out of page-locked memory"); return QPC_ERR_OUT_OF_MEMORY; }
+  }
+  const size_t nm = (size_t)B * m;
+  const bool sp = m > 0 && p->plan_tried && p->plan.valid && p->sp_lds_doubles > 0; // (the plan: qpc_qp_analyze, or an earlier qpc_qp_solve)
+  const bool wg = m > 0 && p->H.wg_tables;
+  const bool warm = warm_start && p->d_yprev && p->B_prev >= B && m > 0;
+  if ((wg || sp) && B > p->cap_prev) { // the kernels leave every QP's multipliers here for the next call's warm start
+    HIP_TRY(hipStreamSynchronize(sm));
+    if (p->d_yprev) (void)hipFree(p->d_yprev);
+    p->d_yprev = nullptr; p->cap_prev = 0; p->B_prev = 0;
+    if (hipMalloc(&p->d_yprev, nm * 8) == hipSuccess) p->cap_prev = B; else (void)hipGetLastError();
+  }
+  const double *y0 = warm ? p->d_yprev : (const double *)nullptr;
+  int rc = QPC_OK;
+  auto chk = [&](hipError_t e, const char *w) { if (e != hipSuccess && rc == QPC_OK) rc = hip_fail(e, w); };
+  auto left_after = [&](const char *who) -> long long { // synchronises: how many QPs the form that just ran has left
+    chk(hipMemsetAsync(p->d_left, 0, sizeof(int), sm), "clear the counter");
+    hipLaunchKernelGGL(qpc_qp_count_left_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, sm, (const int32_t *)dst, (long long)B, p->d_left);
+    chk(hipGetLastError(), "qpc_qp_count_left_kernel");
+    chk(hipMemcpyAsync(p->h_left, p->d_left, sizeof(int), hipMemcpyDeviceToHost, sm), "copy the counter");
+    chk(hipStreamSynchronize(sm), who);
+    if (rc != QPC_OK) { (void)hipMemset(p->d_ticket, 0, sizeof(unsigned long long)); return -1; }
+    return (long long)*p->h_left;
+  };
+  long long left = B;
+  if (sp) {
+    const int lds_bytes = p->sp_lds_doubles * (int)sizeof(double);
+    if (int arc = qpc_wg_lds_attr((const void *)qpc_qp_sp_kernel, p->device, lds_bytes)) return arc;
+    const long long per_cu = 160 * 1024 / lds_bytes > 0 ? 160 * 1024 / lds_bytes : 1;
+    const long long grid = B < (long long)p->n_cu * per_cu ? B : (long long)p->n_cu * per_cu;
+    hipLaunchKernelGGL(qpc_qp_sp_kernel, dim3((unsigned)grid), dim3(QPC_SP_THREADS), (size_t)lds_bytes, sm, (const int *)p->d_plan, p->sp_lds_doubles,
+                       (long long)B, nnzP, dPv, dq, dAv, dl, du, st, y0, dx, dy, dst, dit, p->d_ticket, p->d_yprev, (unsigned long long *)nullptr);
+    chk(hipGetLastError(), "qpc_qp_sp_kernel");
+    left = left_after("qpc_qp_sp_kernel");
+    if (rc != QPC_OK) return rc;
+    if (p->d_yprev) p->B_prev = B;
+    if (left == 0) return QPC_OK;
+  }
+  // what is left (other equality rows than the plan's; no plan at all): the dense forms and their workspace in HBM
+  const size_t wsb = (size_t)qpc_qp_workspace_bytes(n, m > 0 ? m : 1, B);
+  if (wsb > p->ws_bytes) {
+    if (p->ws) (void)hipFree(p->ws);
+    p->ws = nullptr; p->ws_bytes = 0;
+    if (hipMalloc(&p->ws, wsb) != hipSuccess) { (void)hipGetLastError(); qpc_set_error("qpc_qp_solve_device: out of device memory (workspace of the dense forms)"); return QPC_ERR_OUT_OF_MEMORY; }
+    p->ws_bytes = wsb;
+  }
+  double *dws = (double *)p->ws;
+  const long long ws_stride = (long long)qpc::qp_dense_workspace_doubles(n, m > 0 ? m : 1);
+  if (wg) {
+    const int lds_bytes = QPC_WG_LDS_DOUBLES * (int)sizeof(double);
+    if (int arc = qpc_wg_lds_attr((const void *)qpc_qp_wg_prep_kernel, p->device, lds_bytes)) return arc;
+    const long long grid = B < (long long)p->n_cu * 4 ? B : (long long)p->n_cu * 4;
+    hipLaunchKernelGGL(qpc_qp_wg_prep_kernel, dim3((unsigned)grid), dim3(QPC_WG_THREADS), (size_t)lds_bytes, sm, p->H.view(p->d_ints), (long long)B, nnzP,
+                       dPv, dq, dAv, dl, du, st, dws, ws_stride, y0, dx, dy, dst, dit, p->d_ticket, p->d_yprev, sp ? 1 : 0);
+    chk(hipGetLastError(), "qpc_qp_wg_prep_kernel");
+    left = left_after("qpc_qp_wg_prep_kernel");
+    if (rc != QPC_OK) return rc;
+    if (p->d_yprev) p->B_prev = B;
+    if (left == 0) return QPC_OK;
+  }
+  { // the dense path: scatter P, A and run the dense entry on what is left
+    const size_t nP = (size_t)B * n * n, nA = (size_t)B * (m > 0 ? m : 1) * n;
+    const size_t need = pad64(nP * 8) + pad64(nA * 8);
+    if (need > p->dense_bytes) {
+      if (p->dense) (void)hipFree(p->dense);
+      p->dense = nullptr; p->dense_bytes = 0;
+      if (hipMalloc(&p->dense, need) != hipSuccess) { (void)hipGetLastError(); qpc_set_error("qpc_qp_solve_device: out of device memory (dense path)"); return QPC_ERR_OUT_OF_MEMORY; }
+      p->dense_bytes = need;
+    }
+    double *dP = (double *)p->dense, *dA = (double *)(p->dense + pad64(nP * 8));
+    chk(hipMemsetAsync(p->dense, 0, need, sm), "clear dense P, A");
+    const int *Prow = p->d_coo, *Pcol = Prow + nnzP, *Arow = Pcol + nnzP, *Acol = Arow + nnzA;
+    if (nnzP + nnzA > 0) {
+      hipLaunchKernelGGL(qpc_qp_densify_kernel, dim3(1024), dim3(256), 0, sm, n, m, (long long)B, nnzP, Prow, Pcol, dPv, nnzA, Arow, Acol, dAv, dP, dA);
+      chk(hipGetLastError(), "qpc_qp_densify_kernel");
+    }
+    if (!wg && !sp) {
+      if (rc == QPC_OK) rc = qpc_qp_solve_batch_device(n, m, B, dP, dq, dA, dl, du, &st, p->device, dx, dy, dst, dit, dws, wsb, sm);
+    } else {
+      hipLaunchKernelGGL(qpc_qp_dense_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, sm, n, m, (long long)B, dP, dq, dA, dl, du, st, dws, ws_stride,
+                         dx, dy, dst, dit, 1);
+      chk(hipGetLastError(), "qpc_qp_dense_kernel");
+    }
+    if (m && rc == QPC_OK) { // the multipliers for the next call's warm start (the workgroup kernels keep their own)
+      if (B > p->cap_prev) {
+        chk(hipStreamSynchronize(sm), "qpc_qp_solve_device");
+        if (p->d_yprev) (void)hipFree(p->d_yprev);
+        p->d_yprev = nullptr; p->cap_prev = 0; p->B_prev = 0;
+        if (hipMalloc(&p->d_yprev, nm * 8) == hipSuccess) p->cap_prev = B; else (void)hipGetLastError();
+      }
+      if (p->d_yprev) { chk(hipMemcpyAsync(p->d_yprev, dy, nm * 8, hipMemcpyDeviceToDevice, sm), "keep y"); p->B_prev = B; }
+    }
+    chk(hipStreamSynchronize(sm), "qpc_qp_solve_device");
+  }
   return rc;
 }
 

@@ -515,6 +515,16 @@ int32_t qpc_qp_analyze(qpc_qp_problem *p, const double *l, const double *u) {
   if (!p->plan_tried || eq != p->plan.eq) { qpc::qp_sp_plan_build(p->H, eq.data(), p->plan); p->plan_tried = true; if (!p->plan.valid) p->plan.eq = eq; }
   return QPC_OK;
 }
+// (the emulation's "device" memory is host memory: the device-pointer entry is the host entry; the stream is ignored)
+int32_t qpc_qp_solve(qpc_qp_problem *p, int64_t B, const double *P_vals, const double *q, const double *A_vals, const double *l,
+                     const double *u, const qpc_settings *settings, int32_t warm_start, double *x, double *y, int32_t *status,
+                     int32_t *iters);
+int32_t qpc_qp_solve_device(qpc_qp_problem *p, int64_t B, const double *P_vals, const double *q, const double *A_vals, const double *l,
+                            const double *u, const qpc_settings *settings, int32_t warm_start, double *x, double *y, int32_t *status,
+                            int32_t *iters, void *hip_stream) {
+  (void)hip_stream;
+  return qpc_qp_solve(p, B, P_vals, q, A_vals, l, u, settings, warm_start, x, y, status, iters);
+}
 // the plan's int array (diagnostics of the tests): returns its length, copies at most n ints
 int emu_l0_plan_ints(qpc_qp_problem *p, int *out, int n) {
   if (!p || !p->plan_tried || !p->plan.valid) return 0;

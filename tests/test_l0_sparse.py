@@ -292,3 +292,59 @@ def test_working_set_beyond_lds_goes_down_the_chain_gpu():
             xe = np.clip(-qs[b] / np.diag(P), lo, hi)
             np.testing.assert_allclose(r["x"][b], xe, atol=1e-8)
     pr.close()
+
+
+# ---- the device-pointer entry (qpc_qp_solve_device): same forms, same order, same bits as the host entry
+def _device_entry(lib, to_dev, from_dev, stream=0):
+    """`to_dev(array) -> (holder, address)`, `from_dev(holder) -> numpy`: torch on the GPU, numpy itself on the emulation"""
+    P, q, A, l, u, x_ref, nv = _fixture("diag")
+    rep = 3
+    Pb, qb, Ab, lb, ub = (np.concatenate([a] * rep) for a in (P, q, A, l, u))
+    l2, u2 = lb.copy(), ub.copy()
+    row = int(np.where(l[0] < u[0] - 1.0)[0][0])  # an inequality row of QP 5 turned into an equality: not the plan's rows, left to the next form
+    u2[5, row] = l2[5, row] = 0.5 * (max(l[5, row], -10.0) + min(u[5, row], 10.0))
+    B = Pb.shape[0]
+    for lo, hi in ((lb, ub), (l2, u2)):
+        host, dev = _problem(P, A, lib)[0], _problem(P, A, lib)[0]
+        Pv, Av = host.values(Pb, Ab)
+        lc, uc = np.clip(lo, -1e20, 1e20), np.clip(hi, -1e20, 1e20)
+        dev.analyze(lc[0], uc[0])
+        ins = [to_dev(np.ascontiguousarray(a, dtype=np.float64)) for a in (Pv, qb, Av, lc, uc)]
+        outs = [to_dev(np.zeros((B, host.n))), to_dev(np.zeros((B, host.m))), to_dev(np.full(B, -7, dtype=np.int32)), to_dev(np.zeros(B, dtype=np.int32))]
+        for warm in (False, True):
+            rh = host.solve(Pv, qb, Av, lo, hi, warm_start=warm)
+            assert host.plan_info() == dev.plan_info()
+            dev.solve_device(B, *(a[1] for a in ins), *(o[1] for o in outs), warm_start=warm, stream=stream)
+            xd, yd, sd, itd = (from_dev(o[0]) for o in outs)
+            assert np.array_equal(sd, rh["status"]), (sd, rh["status"])
+            assert np.array_equal(xd, rh["x"]) and np.array_equal(yd, rh["y"]) and np.array_equal(itd, rh["iters"])  # bit for bit
+            assert np.all(sd[np.arange(B) != 5] == 0)
+            np.testing.assert_allclose(xd[np.arange(B) != 5][:, :nv], np.concatenate([x_ref] * rep)[np.arange(B) != 5][:, :nv], atol=1e-8, rtol=0)
+
+
+def test_device_pointer_entry_emulated():
+    emu.build()
+    _device_entry(emu.EMU_LIB, lambda a: (a, a.ctypes.data), lambda h: h)
+
+
+@pytest.mark.gpu
+def test_device_pointer_entry_gpu():
+    import torch
+    dev = torch.device("cuda", 0)
+    s = torch.cuda.Stream(dev)
+    def to_dev(a):
+        t = torch.from_numpy(a).to(dev)
+        return t, t.data_ptr()
+    torch.cuda.synchronize(dev)
+    _device_entry(None, to_dev, lambda t: t.cpu().numpy(), stream=s.cuda_stream)
+    # without a plan (no analyze, no earlier solve) the dense forms take the batch: still the same answers
+    P, q, A, l, u, x_ref, nv = _fixture("diag")
+    pr = _problem(P, A, None)[0]
+    Pv, Av = pr.values(P[:2], A[:2])
+    ins = [to_dev(np.ascontiguousarray(a, dtype=np.float64)) for a in (Pv, q[:2], Av, np.clip(l[:2], -1e20, 1e20), np.clip(u[:2], -1e20, 1e20))]
+    outs = [to_dev(np.zeros((2, pr.n))), to_dev(np.zeros((2, pr.m))), to_dev(np.full(2, -7, dtype=np.int32)), to_dev(np.zeros(2, dtype=np.int32))]
+    torch.cuda.synchronize(dev)
+    pr.solve_device(2, *(a[1] for a in ins), *(o[1] for o in outs), stream=s.cuda_stream)
+    assert pr.plan_info()["in_use"] == 0
+    assert np.all(outs[2][0].cpu().numpy() == 0)
+    np.testing.assert_allclose(outs[0][0].cpu().numpy()[:, :nv], x_ref[:2, :nv], atol=1e-8, rtol=0)

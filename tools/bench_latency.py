@@ -145,7 +145,35 @@ def prepared_entry(P, q, A, l, u, x, nv, batches):
                     pr.solve_raw(*a, out=o, warm_start=True)
                     kw.append(pr.last_kernel_ms())
                 pr.enable_timing(False)
-        prep[str(B)] = {"cold_solves_per_s": res["pageable"]["cold_solves_per_s"], "warm_solves_per_s": res["pageable"]["warm_solves_per_s"],
+        dres = {}
+        if hasattr(pr.L, "qpc_qp_solve_device"):  # the same batch with values, bounds and results resident in HBM (qpc_qp_solve_device)
+            try:
+                import torch
+                dev = torch.device("cuda", 0)
+                di = [torch.from_numpy(np.ascontiguousarray(z[idx])).to(dev) for z in (Pv, q, Av, lc, uc)]
+                do = [torch.zeros((B, pr.n), dtype=torch.float64, device=dev), torch.zeros((B, max(pr.m, 1)), dtype=torch.float64, device=dev),
+                      torch.zeros(B, dtype=torch.int32, device=dev), torch.zeros(B, dtype=torch.int32, device=dev)]
+                strm = torch.cuda.Stream(dev)
+                torch.cuda.synchronize(dev)
+                call = lambda warm: pr.solve_device(B, *(t.data_ptr() for t in di), *(t.data_ptr() for t in do), warm_start=warm, stream=strm.cuda_stream)  # noqa: E731
+                call(False)
+                assert (do[2].cpu().numpy() == 0).all()
+                derr = float(np.abs(do[0].cpu().numpy()[:, :nv] - x[idx][:, :nv]).max())
+                tc, tw = [], []
+                for _ in range(5):
+                    t0 = time.perf_counter()
+                    call(False)
+                    tc.append(time.perf_counter() - t0)
+                for _ in range(5):
+                    t0 = time.perf_counter()
+                    call(True)
+                    tw.append(time.perf_counter() - t0)
+                dres = {"device_resident_cold_solves_per_s": float(B / np.median(tc)), "device_resident_warm_solves_per_s": float(B / np.median(tw)),
+                        "device_resident_max_abs_err_vdot_vs_fixture": derr}
+                del di, do
+            except Exception as e:  # noqa: BLE001
+                dres = {"device_resident_error": repr(e)}
+        prep[str(B)] = {**dres, "cold_solves_per_s": res["pageable"]["cold_solves_per_s"], "warm_solves_per_s": res["pageable"]["warm_solves_per_s"],
                         "page_locked_cold_solves_per_s": res["page_locked"]["cold_solves_per_s"],
                         "page_locked_warm_solves_per_s": res["page_locked"]["warm_solves_per_s"],
                         "cold_kernel_ms": float(np.median(kc)), "warm_kernel_ms": float(np.median(kw)),  # HIP events around the kernel
