@@ -217,6 +217,12 @@ def ordered():
     assert times["ordered"] < 1.5 * times["plain"]
 
 
+def l0_device():
+    """qpc_qp_solve_device (tests/test_l0_sparse.py)"""
+    import test_l0_sparse
+    test_l0_sparse.gpu_device_entry_check()
+
+
 if __name__ == "__main__":
-    {"streams": streams, "graph": graph, "warm_mixed_rollouts": warm_mixed_rollouts, "slots": slots, "ordered": ordered}[sys.argv[1]]()
+    {"l0_device": l0_device, "streams": streams, "graph": graph, "warm_mixed_rollouts": warm_mixed_rollouts, "slots": slots, "ordered": ordered}[sys.argv[1]]()
     print("CHECK_OK")

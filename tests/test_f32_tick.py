@@ -200,7 +200,7 @@ def _packed_vs_plain(f32, B=2048, config=5):
 
 
 @pytest.mark.gpu
-@pytest.mark.gpu_slow  # (a variant that lost in every configuration, DESIGN.md 7c: kept correct, not kept in the timed set; the emulated test covers it on the CPU)
+@pytest.mark.gpu_slow  # (a variant that lost in every configuration, DESIGN.md 7c: kept correct under `-m gpu_slow`, not in the timed set)
 @pytest.mark.parametrize("f32", [False, True])
 def test_two_qps_per_wavefront_gpu(f32):
     """qpc_set_qps_per_wavefront(2) (csrc/qpc_device.h QPC_PACK2): lanes 0-31 and 32-63 each solve their own QP.  The arithmetic per

@@ -327,11 +327,13 @@ def test_device_pointer_entry_emulated():
     _device_entry(emu.EMU_LIB, lambda a: (a, a.ctypes.data), lambda h: h)
 
 
-@pytest.mark.gpu
-def test_device_pointer_entry_gpu():
+def gpu_device_entry_check():
+    """body of test_device_pointer_entry_gpu: runs in a child process (tests/gpu_torch_checks.py l0_device) in which torch's HIP runtime
+    was initialised before the library's, as in bench.py"""
     import torch
     dev = torch.device("cuda", 0)
     s = torch.cuda.Stream(dev)
+
     def to_dev(a):
         t = torch.from_numpy(a).to(dev)
         return t, t.data_ptr()
@@ -348,3 +350,14 @@ def test_device_pointer_entry_gpu():
     assert pr.plan_info()["in_use"] == 0
     assert np.all(outs[2][0].cpu().numpy() == 0)
     np.testing.assert_allclose(outs[0][0].cpu().numpy()[:, :nv], x_ref[:2, :nv], atol=1e-8, rtol=0)
+
+
+@pytest.mark.gpu
+def test_device_pointer_entry_gpu():
+    """qpc_qp_solve_device on torch tensors: bit for bit the host entry, cold and warm, with a QP the sparse form leaves in the batch, and
+    without a plan"""
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, os.path.join(here, "gpu_torch_checks.py"), "l0_device"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "CHECK_OK" in out.stdout

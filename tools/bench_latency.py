@@ -35,6 +35,12 @@ def load_l0_fixture(which="diag"):
 
 
 def l0_main(batches):
+    try:  # the device-resident leg hands torch tensors to the library: torch's HIP runtime has to be initialised first (as in bench.py)
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:  # noqa: BLE001
+        pass
     P, q, A, l, u, x, nv = load_l0_fixture()
     k = P.shape[0]
     out = {"metric": "L0 qpc_qp_solve_batch on the dense 143 x 178 Atlas reference-layout QP (host pointers, synchronous, through ctypes)",
