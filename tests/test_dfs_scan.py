@@ -43,6 +43,7 @@ def test_prefix_scan_equals_subtree_loop_emulated(config):
 
 
 @pytest.mark.gpu
+@pytest.mark.gpu_slow  # (5 s; an internal property of the kinematics sweep that every parity scenario exercises; its emulated twin runs on the CPU)
 def test_prefix_scan_equals_subtree_loop_gpu():
     f = lambda mech, N, fl: binding.Controller(binding.Model(mech, binding.EXPERIMENTS_LIB), N, fl)  # noqa: E731
     _same(_run(f, 2048, 3, True), _run(f, 2048, 3, False))

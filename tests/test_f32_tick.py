@@ -158,6 +158,7 @@ def test_f32_tick_gpu_config3():
 
 
 @pytest.mark.gpu
+@pytest.mark.gpu_slow  # (7 s; the fast set checks the fp32 tick against the fp64 tick and the oracle on configs 3 and 5)
 def test_f32_tick_gpu_matches_its_emulation():
     """the device code and its lane-serial emulation are the same source: same statuses, tau to fp32 rounding"""
     emu.build_f32()

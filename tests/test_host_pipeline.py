@@ -242,6 +242,7 @@ def test_gpu_cost_ordered_tickets():
 
 
 @pytest.mark.gpu
+@pytest.mark.gpu_slow  # (12 s: a regression test of a buffer lifetime; warm start and rollouts each keep a fast test)
 def test_gpu_warm_controller_mixes_device_and_host_rollouts():
     """the host rollout must not free the device rollout's working-set buffer (tests/gpu_torch_checks.py)"""
     _run_torch_check("warm_mixed_rollouts")

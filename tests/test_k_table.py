@@ -91,6 +91,7 @@ def test_two_friction_coefficients_emulated():
 
 
 @pytest.mark.gpu
+@pytest.mark.gpu_slow  # (5 s of hiprtc; the emulated twin runs on the CPU, the fast set keeps test_table_equals_gauss_jordan_gpu)
 def test_two_friction_coefficients_gpu():
     f = _mixed_mu(lambda mech, N, fl: binding.Controller(binding.Model(mech, binding.EXPERIMENTS_LIB), N, fl))
     _same(_run(f, 2048, 5, False), _run(f, 2048, 5, True))
