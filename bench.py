@@ -470,6 +470,8 @@ def l0_plugin_point():
                                                   "latency_us_B1_cold_worst_problem": pm.get("B1_cold_worst_problem_us"),
                                                   "latency_us_B1_warm_median_over_problems": pm.get("B1_warm_median_over_problems_us"),
                                                   "max_abs_err_vdot_vs_fixture": max([p["max_abs_err_vdot_vs_fixture"] for p in pm.get("B1_per_problem", [])] or [None])},
+                 # ONE robot, 1 kHz, every solve warm-started from the tick before: the regime the reference runs the slot in (cpu_baseline.l0_fixture_osqp.closed_loop_sequence beside it)
+                 "closed_loop": d.get("closed_loop"),
                  "dense_entry_qpc_qp_solve_batch": dense,
                  "reference_cpu": "cpu_baseline.l0_fixture_osqp: the oracle's OSQP on the same committed problems, one core, measured in this run"}
         roof = None
@@ -509,6 +511,18 @@ def l0_cpu_leg():
                     res[name + ("_warm" if warm else "_cold")] = {"median_over_problems": float(np.median(r["us"])), "worst_problem": float(r["us"].max()),
                                                                   "best_problem": float(r["us"].min()), "admm_iterations": [int(i) for i in r["iters"]]}
             out["atlas_143x178" if which == "diag" else "atlas_matrix_weight_146x181"] = res
+        # the regime the reference runs its optimizer in: consecutive ticks of ONE closed loop, each solve warm-started from the tick before
+        # (the same committed sequence config.l0_plugin.closed_loop times the device on)
+        P, q, A, l, u, x, nv = BL.load_l0_fixture("closed_loop")
+        cl = {"ticks": int(P.shape[0] - 1), "what": "tests/golden/l0/atlas_closed_loop_143x178.npz: every problem solved once from the previous problem's solution (update + solve)"}
+        for name, st in (("notebook_tolerances", O.notebook_settings(0)), ("test_suite_tolerances", O.test_settings(0))):
+            r = O.qp_time(P, q, A, l, u, st, reps=1, warm=2)
+            us, it = r["us"][1:], r["iters"][1:]
+            scale = np.maximum(1.0, np.abs(x[1:, :nv]).max(axis=1))
+            cl[name] = {"median_us": float(np.median(us)), "p90_us": float(np.percentile(us, 90)), "worst_tick_us": float(us.max()), "mean_us": float(us.mean()),
+                        "admm_iterations": {"mean": float(it.mean()), "median": float(np.median(it)), "max": int(it.max())},
+                        "not_optimal": int((r["status"][1:] != 0).sum())}
+        out["closed_loop_sequence"] = cl
         return out
     except Exception as e:  # noqa: BLE001
         return {"error": repr(e)}

@@ -696,7 +696,8 @@ int ora_qp_solve(int n, int m, const double *P, const double *q, const double *A
  * problems the device entry qpc_qp_setup / qpc_qp_solve is timed on): k dense problems that share a sparsity pattern (the union of
  * their nonzeros) -- osqp_setup once, then for every problem `reps` x (osqp_update of all coefficients + osqp_solve), as
  * `Parametron.solve!` does every tick (momentum.jl:58).  warm = 0: every solve from a cold start; warm = 1: from the previous
- * solution of the SAME problem (its first solve, cold, is not counted).  us[k]: mean microseconds per solve; iters[k], status[k]: of
+ * solution of the SAME problem (its first solve, cold, is not counted); warm == 2: the k problems are a SEQUENCE -- problem b > 0 is
+ * solved once from the solution of problem b - 1 (values updated in place, as Parametron does every tick: momentum.jl:58).  us[k]: mean microseconds per solve; iters[k], status[k]: of
  * the last one.  Returns 0, or -1 when the set-up fails. */
 #include <time.h>
 int ora_qp_time(int n, int m, int k, const double *P, const double *q, const double *A, const double *l, const double *u,
@@ -727,9 +728,18 @@ int ora_qp_time(int n, int m, int k, const double *P, const double *q, const dou
     for (int e = 0; e < Pp[n]; e++) { int j = 0; while (Pp[j + 1] <= e) j++; Px[e] = 0.5 * (P[b * nn + Pi[e] * n + j] + P[b * nn + j * n + Pi[e]]); }
     for (int e = 0; e < Ap[n]; e++) { int j = 0; while (Ap[j + 1] <= e) j++; Ax[e] = A[b * mn + (long long)Ai[e] * n + j]; }
     ora_tick_info info;
+    struct timespec t0, t1;
+    if (warm == 2 && b > 0) { // a SEQUENCE (consecutive ticks of one closed loop): this problem from the previous problem's solution, once
+      clock_gettime(CLOCK_MONOTONIC, &t0);
+      ora_osqp_update(w, Px, q + b * n, Ax, l + b * m, u + b * m);
+      status[b] = ora_osqp_solve(w, x, y, &info);
+      clock_gettime(CLOCK_MONOTONIC, &t1);
+      us[b] = (t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3;
+      iters[b] = info.iters;
+      continue;
+    }
     ora_osqp_cold_start(w);
     if (warm) { ora_osqp_update(w, Px, q + b * n, Ax, l + b * m, u + b * m); ora_osqp_solve(w, x, y, &info); }
-    struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     for (int r = 0; r < reps; r++) {
       if (!warm) ora_osqp_cold_start(w);

@@ -350,7 +350,8 @@ def qp_solve(P, q, A, l, u, settings=None):
 def qp_time(P, q, A, l, u, settings, reps=5, warm=False):
     """Microseconds per solve of the OSQP restatement on k dense problems of one pattern: setup once, then per problem `reps` x
     (update of all coefficients + solve) -- what `Parametron.solve!` costs the reference's optimizer every tick (momentum.jl:58).
-    warm: from the previous solution of the same problem.  -> dict(us[k], iters[k], status[k])"""
+    warm: from the previous solution of the same problem; warm = 2: the k problems are consecutive ticks of one closed loop, problem
+    b > 0 is solved ONCE from the solution of problem b - 1.  -> dict(us[k], iters[k], status[k])"""
     L = lib()
     P, A = np.ascontiguousarray(P, dtype=np.float64), np.ascontiguousarray(A, dtype=np.float64)
     k, n, m = P.shape[0], P.shape[1], A.shape[1]

@@ -44,6 +44,43 @@ def main(B=8):
                   floating=wl.floating_body), "atlas_matrix_weight_146x181.npz")
 
 
+def closed_loop(K=96, fname="atlas_closed_loop_143x178.npz"):
+    """The regime the reference runs its optimizer in (notebooks/Standing controller.ipynb: ONE Atlas, a tick every millisecond, the
+    optimizer warm-started from the previous tick): K CONSECUTIVE reference-layout problems of a closed loop -- a perturbed standing
+    state, the StandingController laws re-evaluated every tick, the state stepped with the QP's own v̇ (explicit Euler at 1 kHz, as
+    tests/test_moi_optimizer.py does), a push of 6 cm/s on the pelvis at tick K/3 and a contact whose force limit drops to zero at tick
+    2K/3 (so that the working set changes along the way).  Same file layout as the other fixtures; the problems are in tick order."""
+    from qpcontrol_jl_amd import workloads as W
+    factory = lambda mech, N, fl: O.OracleController(O.OracleModel(mech), N, fl)  # noqa: E731
+    oc, wl = W.atlas_workload(factory, 4, 3)
+    om = oc.model
+    nv = wl.mech.nv
+    q, v = wl.q[0].copy(), wl.v[0].copy()
+    cw, cm = wl.contact_weight[0].copy(), wl.contact_maxnormalforce[0].copy()
+    Ps, qs, As, ls, us, xs = [], [], [], [], [], []
+    for k in range(K):
+        if k == K // 3:
+            v[3:6] += np.array([0.06, -0.03, 0.0])
+        if k == (2 * K) // 3:
+            cm[1] = 0.0
+        des = W.standing_desired(wl.setup, q[None], v[None])[0]
+        P, qv, A, l, u = oc.build_qp(q, v, des, cw, cm)
+        r = oc.tick(q, v, des, cw, cm)
+        assert r["status"] == 0, (k, r["status"])
+        Ps.append(P); qs.append(qv); As.append(A); ls.append(l); us.append(u); xs.append(r["x"])
+        v = v + 1e-3 * r["x"][:nv]
+        q = om.integrate(q, v, 1e-3)
+    save(np.array(Ps), np.array(As), qs, ls, us, xs, nv, fname)
+
+
+def save(P, A, qs, ls, us, xs, nv, fname):
+    pat_P, pat_A = np.any(P != 0.0, axis=0), np.any(A != 0.0, axis=0)
+    np.savez_compressed(os.path.join(HERE, fname), n=np.int32(P.shape[1]), m=np.int32(A.shape[1]),
+                        P_idx=np.argwhere(pat_P).astype(np.int16), P_val=P[:, pat_P], A_idx=np.argwhere(pat_A).astype(np.int16),
+                        A_val=A[:, pat_A], q=np.array(qs), l=np.array(ls), u=np.array(us), x=np.array(xs), nv=np.int32(nv))
+    print(f"{fname}: {P.shape[0]} QPs, n = {P.shape[1]}, m = {A.shape[1]}, nnz(P) = {int(pat_P.sum())}, nnz(A) = {int(pat_A.sum())}")
+
+
 def write(case, fname):
     oc = case.ctrl
     Ps, qs, As, ls, us, xs = [], [], [], [], [], []
@@ -53,13 +90,12 @@ def write(case, fname):
         if r["status"] != 0:
             continue
         Ps.append(P); qs.append(q); As.append(A); ls.append(l); us.append(u); xs.append(r["x"])
-    P, A = np.array(Ps), np.array(As)
-    pat_P, pat_A = np.any(P != 0.0, axis=0), np.any(A != 0.0, axis=0)
-    np.savez_compressed(os.path.join(HERE, fname), n=np.int32(P.shape[1]), m=np.int32(A.shape[1]),
-                        P_idx=np.argwhere(pat_P).astype(np.int16), P_val=P[:, pat_P], A_idx=np.argwhere(pat_A).astype(np.int16),
-                        A_val=A[:, pat_A], q=np.array(qs), l=np.array(ls), u=np.array(us), x=np.array(xs), nv=np.int32(case.mech.nv))
-    print(f"{fname}: {len(Ps)} QPs, n = {P.shape[1]}, m = {A.shape[1]}, nnz(P) = {int(pat_P.sum())}, nnz(A) = {int(pat_A.sum())}")
+    save(np.array(Ps), np.array(As), qs, ls, us, xs, case.mech.nv, fname)
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "closed_loop":  # (by itself: the eight-state fixtures stay byte for byte what they are)
+        O.build()
+        closed_loop()
+    else:
+        main()

@@ -361,3 +361,36 @@ def test_device_pointer_entry_gpu():
     out = subprocess.run([sys.executable, os.path.join(here, "gpu_torch_checks.py"), "l0_device"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "CHECK_OK" in out.stdout
+
+
+# ---- the reference's regime for the slot: consecutive ticks of one closed loop, each solve warm-started from the tick before
+def _closed_loop(lib):
+    P, q, A, l, u, x, nv = _fixture("closed_loop")
+    K = P.shape[0]
+    assert K == 96
+    pr, (Pv, Av) = _problem(P, A, lib)
+    pr.analyze(l[0], u[0])
+    assert pr.plan_info()["in_use"] == 1
+    iters = []
+    for k in range(K):
+        r = pr.solve(Pv[k], q[k], Av[k], l[k], u[k], warm_start=k > 0)
+        assert r["status"][0] == 0, (k, r["status"])
+        np.testing.assert_allclose(r["x"][0, :nv], x[k, :nv], atol=1e-8, rtol=0, err_msg=f"tick {k}")
+        iters.append(int(r["iters"][0]))
+    assert pr.plan_info()["in_use"] == 1 and pr.plan_info()["equality_rows"] == 114  # (the lost contact changes bounds, not the kind of any row)
+    pr.close()
+    iters = np.array(iters[1:])
+    # warm-started from the tick before, most ticks need no change of the working set; the push and the lost contact need a few
+    assert (iters == 0).mean() > 0.6 and iters.max() <= 12, iters
+    return iters
+
+
+def test_closed_loop_sequence_emulated():
+    emu.build()
+    _closed_loop(emu.EMU_LIB)
+
+
+@pytest.mark.gpu
+def test_closed_loop_sequence_gpu():
+    it = _closed_loop(None)
+    print(f"\nclosed-loop sequence: working-set changes per tick mean {it.mean():.2f} max {it.max()}, {int((it == 0).sum())} of {len(it)} ticks without a change")

@@ -21,7 +21,8 @@ from qpcontrol_jl_amd import binding, workloads as W  # noqa: E402
 
 
 L0_FIXTURES = {"diag": "atlas_143x178.npz",                   # the standing controller as the notebook builds it: P diagonal
-               "matrix": "atlas_matrix_weight_146x181.npz"}   # ... with a matrix-weighted MomentumRateTask: a 6 x 6 block in P
+               "matrix": "atlas_matrix_weight_146x181.npz",   # ... with a matrix-weighted MomentumRateTask: a 6 x 6 block in P
+               "closed_loop": "atlas_closed_loop_143x178.npz"}  # 96 CONSECUTIVE ticks of one robot at 1 kHz (a push at tick 32, a contact lost at 64)
 
 
 def load_l0_fixture(which="diag"):
@@ -78,6 +79,10 @@ def l0_main(batches):
     # the problems with a matrix-weighted MomentumRateTask (a 6 x 6 block in P: momentum.jl:113-117, test/controller.jl:232-285)
     Pm, qm, Am, lm, um, xm, nvm = load_l0_fixture("matrix")
     out["prepared_matrix_weight"] = prepared_entry(Pm, qm, Am, lm, um, xm, nvm, [b for b in batches if b == 1])
+    try:
+        out["closed_loop"] = closed_loop_entry()
+    except Exception as e:  # noqa: BLE001
+        out["closed_loop"] = {"error": repr(e)}
     print(json.dumps(out))
 
 
@@ -188,7 +193,42 @@ def prepared_entry(P, q, A, l, u, x, nv, batches):
     return prep
 
 
+def closed_loop_entry(reps=5):
+    """The reference's own regime for its optimizer slot: ONE robot, a tick every millisecond, every solve warm-started from the tick before
+    (Standing controller.ipynb; momentum.jl:58).  The committed sequence of consecutive problems through qpc_qp_setup / qpc_qp_analyze once and
+    qpc_qp_solve(warm_start = 1) per tick, B = 1, host pointers, synchronous; per tick the median over `reps` passes (a pass starts cold)."""
+    P, q, A, l, u, x, nv = load_l0_fixture("closed_loop")
+    K = P.shape[0]
+    pr = binding.QpProblem(P.shape[1], A.shape[1], (P != 0).any(0), (A != 0).any(0))
+    Pv, Av = pr.values(P, A)
+    lc, uc = np.clip(l, -1e20, 1e20), np.clip(u, -1e20, 1e20)
+    pr.analyze(lc[0], uc[0])
+    args = [tuple(np.ascontiguousarray(z[k:k + 1]) for z in (Pv, q, Av, lc, uc)) for k in range(K)]
+    o = pr.solve_raw(*args[0])
+    t = np.zeros((reps, K))
+    iters = np.zeros(K, dtype=int)
+    err = 0.0
+    for r in range(reps):
+        for k in range(K):
+            t0 = time.perf_counter()
+            pr.solve_raw(*args[k], out=o, warm_start=k > 0)
+            t[r, k] = time.perf_counter() - t0
+            assert o["status"][0] == 0, (k, o["status"][0])
+            iters[k] = int(o["iters"][0])
+            err = max(err, float(np.abs(o["x"][0, :nv] - x[k, :nv]).max()))
+    us = np.median(t, axis=0)[1:] * 1e6  # (the first tick of a pass is the cold one)
+    info = pr.plan_info()
+    pr.close()
+    return {"ticks": int(K - 1), "what": "consecutive ticks of one closed loop (tests/golden/l0/atlas_closed_loop_143x178.npz), each warm-started from the tick before",
+            "median_us": float(np.median(us)), "p90_us": float(np.percentile(us, 90)), "worst_tick_us": float(us.max()), "mean_us": float(us.mean()),
+            "working_set_iterations_per_tick": {"mean": float(iters[1:].mean()), "max": int(iters[1:].max()), "ticks_without_a_change": int((iters[1:] == 0).sum())},
+            "first_tick_cold_us": float(np.median(t, axis=0)[0] * 1e6), "max_abs_err_vdot_vs_fixture": err, "plan_in_use": info["in_use"]}
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--l0-closed-loop":
+        print(json.dumps(closed_loop_entry()))
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "--l0":
         return l0_main([int(a) for a in sys.argv[2:]] or [1, 64, 8192])
     def factory(mech, n_basis, floating):
