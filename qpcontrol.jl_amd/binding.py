@@ -538,6 +538,27 @@ class QpProblem:
         _check(self.L, rc, "qpc_qp_solve")
         return out
 
+    def bind_call(self, P_vals, q, A_vals, l, u, out, warm_start=False):
+        """-> a function of no arguments that makes ONE qpc_qp_solve call on these arrays (they are read and written in place at every
+        call; keep them alive and do not reallocate them).  The pointers are converted once, here: a call then costs what the C ABI
+        costs -- `solve_raw` spends 10 us per call in numpy's `.ctypes` conversions, a fifth of a B = 1 solve.  Returns the status code."""
+        B = q.shape[0]
+        for a in (P_vals, q, A_vals, l, u, out["x"], out["y"]):
+            assert a.dtype == np.float64 and a.flags.c_contiguous
+        assert out["status"].dtype == np.int32 and out["iters"].dtype == np.int32
+        keep = (P_vals, q, A_vals, l, u, out)
+        vp = ctypes.c_void_p
+        fn = self.L.qpc_qp_solve
+        a = (vp(self.h.value if hasattr(self.h, "value") else self.h), ctypes.c_int64(B), vp(P_vals.ctypes.data), vp(q.ctypes.data), vp(A_vals.ctypes.data),
+             vp(l.ctypes.data), vp(u.ctypes.data), None, ctypes.c_int32(int(bool(warm_start))), vp(out["x"].ctypes.data), vp(out["y"].ctypes.data),
+             vp(out["status"].ctypes.data), vp(out["iters"].ctypes.data))
+        raw = ctypes.CFUNCTYPE(ctypes.c_int32, vp, ctypes.c_int64, vp, vp, vp, vp, vp, vp, ctypes.c_int32, vp, vp, vp, vp)(
+            ctypes.cast(fn, vp).value)
+
+        def call(_keep=keep):
+            return raw(*a)
+        return call
+
     def solve_device(self, B, P_vals, q, A_vals, l, u, x, y, status, iters=0, warm_start=False, stream=0):
         """qpc_qp_solve_device: every array argument is a DEVICE address (an int, e.g. torch.Tensor.data_ptr()) on the problem's device;
         the plan must exist (`analyze`).  Returns when `stream` has been synchronised."""

@@ -524,7 +524,23 @@ int32_t qpc_qp_solve(qpc_qp_problem *p, int64_t B, const double *P_vals, const d
     qpc_set_error("qpc_qp_solve: bad arguments"); return QPC_ERR_INVALID_ARGUMENT;
   }
   if (B == 0) return QPC_OK;
+#ifdef QPC_EXPERIMENTS // QPC_L0_HOST_PROF=1 (experiments library): where the host side of a small call spends its time (stderr, microseconds)
+  static const bool host_prof = [] { const char *e = getenv("QPC_L0_HOST_PROF"); return e && e[0] == '1'; }();
+  struct timespec hp0__;
+  clock_gettime(CLOCK_MONOTONIC, &hp0__);
+  double hp_last__ = 0.0;
+  auto HP = [&](const char *what) {
+    if (!host_prof) return;
+    struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
+    const double us = (t.tv_sec - hp0__.tv_sec) * 1e6 + (t.tv_nsec - hp0__.tv_nsec) * 1e-3;
+    fprintf(stderr, "l0_host_prof %-28s +%7.2f us (at %7.2f)\n", what, us - hp_last__, us);
+    hp_last__ = us;
+  };
+#else
+  auto HP = [](const char *) {};
+#endif
   HIP_TRY(hipSetDevice(p->device));
+  HP("hipSetDevice");
   qpc_settings st;
   if (settings) st = *settings; else qpc_default_settings(&st);
   const size_t nPv = (size_t)B * nnzP, nq = (size_t)B * n, nAv = (size_t)B * nnzA, nm = (size_t)B * m;
@@ -572,6 +588,7 @@ int32_t qpc_qp_solve(qpc_qp_problem *p, int64_t B, const double *P_vals, const d
       sp = p->plan.valid && p->sp_lds_doubles > 0;
     }
   }
+  HP("plan check");
   const bool small = (wg || sp) && in_bytes + out_bytes <= ((size_t)1 << 20);
   if (small && in_bytes + out_bytes > p->h_stage_bytes) {
     if (p->h_stage) (void)hipHostFree(p->h_stage);
@@ -599,7 +616,9 @@ int32_t qpc_qp_solve(qpc_qp_problem *p, int64_t B, const double *P_vals, const d
     if (nAv) memcpy(h + ((char *)dAv - p->buf), A_vals, nAv * 8);
     memcpy(h + ((char *)dl - p->buf), l, nm * 8);
     memcpy(h + ((char *)du - p->buf), u, nm * 8);
+    HP("stage inputs (memcpy)");
     chk(hipMemcpyAsync(p->buf, h, in_bytes, hipMemcpyHostToDevice, p->stream), "copy the inputs");
+    HP("hipMemcpyAsync H2D");
   } else {
     if (nPv) chk(hipMemcpyAsync(dPv, P_vals, nPv * 8, hipMemcpyHostToDevice, p->stream), "copy P values");
     chk(hipMemcpyAsync(dq, q, nq * 8, hipMemcpyHostToDevice, p->stream), "copy q");
@@ -638,7 +657,9 @@ int32_t qpc_qp_solve(qpc_qp_problem *p, int64_t B, const double *P_vals, const d
     if (staged) {
       char *ho = p->h_stage + in_bytes;
       chk(hipMemcpyAsync(ho, out0, out_bytes, hipMemcpyDeviceToHost, p->stream), "copy the outputs");
+      HP("hipMemcpyAsync D2H");
       chk(hipStreamSynchronize(p->stream), who);
+      HP("hipStreamSynchronize");
       if (rc != QPC_OK) { (void)hipMemset(p->d_ticket, 0, sizeof(unsigned long long)); return false; }
       timed();
       if (p->d_yprev) p->B_prev = B;
@@ -707,9 +728,11 @@ int32_t qpc_qp_solve(qpc_qp_problem *p, int64_t B, const double *P_vals, const d
       for (int64_t b = 0; b < B; b++) any_left = any_left || hst[(size_t)b] == QPC_WG_FALLBACK;
       if (!any_left) { for (int64_t b = 0; b < B; b++) status[b] = hst[(size_t)b]; return QPC_OK; }
     } else {
+      HP("before launch");
       hipLaunchKernelGGL(qpc_qp_sp_kernel, dim3((unsigned)grid), dim3(QPC_SP_THREADS), (size_t)lds_bytes, p->stream, (const int *)p->d_plan,
                          p->sp_lds_doubles, (long long)B, nnzP, dPv, dq, dAv, dl, du, st, y0, dx, dy, dst, dit, p->d_ticket, p->d_yprev, p->d_stamps);
       chk(hipGetLastError(), "qpc_qp_sp_kernel");
+      HP("launch");
       if (collect("qpc_qp_sp_kernel")) return QPC_OK;
     }
     if (rc != QPC_OK) return rc;

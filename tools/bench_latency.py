@@ -96,23 +96,27 @@ def prepared_entry(P, q, A, l, u, x, nv, batches):
     pr.analyze(l[0], u[0])  # (what an optimizer does once after `MOI.copy_to`: the first solve is then not the slow one)
     prep = {"n": int(P.shape[1]), "m": int(A.shape[1]), "plan": pr.plan_info(), "B1_per_problem": [],
             "warm_means": "the same problem solved again from its own multipliers"}
-    # (timed: the call itself on arrays prepared beforehand -- contiguous, bounds clipped, outputs preallocated: what a caller with its
-    #  own buffers pays, the Julia shim among them; `QpProblem.solve` clips and allocates on every call, a millisecond at B = 8 192)
+    # (timed: the call itself on arrays prepared beforehand -- contiguous, bounds clipped, outputs preallocated, pointers converted once
+    #  (`QpProblem.bind_call`): what a caller with its own buffers pays, the Julia shim among them; `QpProblem.solve` clips and allocates
+    #  on every call, a millisecond at B = 8 192, and numpy's `.ctypes` conversions alone cost `solve_raw` 10 us per call)
     lc, uc = np.clip(l, -1e20, 1e20), np.clip(u, -1e20, 1e20)
     for b in range(k):
         a = tuple(np.ascontiguousarray(z[b:b + 1]) for z in (Pv, q, Av, lc, uc))
-        o = pr.solve_raw(*a)
+        r = rw = o = pr.solve_raw(*a)
+        cold, warm = pr.bind_call(*a, o), pr.bind_call(*a, o, warm_start=True)  # (pointers converted once: the call is the C ABI's)
         tc, tw = [], []
         for _ in range(10):
             t0 = time.perf_counter()
-            r = pr.solve_raw(*a, out=o)
+            rc = cold()
             tc.append(time.perf_counter() - t0)
+            assert rc == 0
         itc, xc = int(r["iters"][0]), r["x"][0, :nv].copy()
         assert r["status"][0] == 0
         for _ in range(10):
             t0 = time.perf_counter()
-            rw = pr.solve_raw(*a, out=o, warm_start=True)
+            rc = warm()
             tw.append(time.perf_counter() - t0)
+            assert rc == 0
         assert rw["status"][0] == 0
         prep["B1_per_problem"].append({"iters": itc, "cold_median_us": float(np.median(tc) * 1e6),
                                        "warm_iters": int(rw["iters"][0]), "warm_median_us": float(np.median(tw) * 1e6),
@@ -205,14 +209,16 @@ def closed_loop_entry(reps=5):
     pr.analyze(lc[0], uc[0])
     args = [tuple(np.ascontiguousarray(z[k:k + 1]) for z in (Pv, q, Av, lc, uc)) for k in range(K)]
     o = pr.solve_raw(*args[0])
+    calls = [pr.bind_call(*args[k], o, warm_start=k > 0) for k in range(K)]  # (pointers converted once: the call is the C ABI's, as a Julia `ccall` is)
     t = np.zeros((reps, K))
     iters = np.zeros(K, dtype=int)
     err = 0.0
     for r in range(reps):
         for k in range(K):
             t0 = time.perf_counter()
-            pr.solve_raw(*args[k], out=o, warm_start=k > 0)
+            rc = calls[k]()
             t[r, k] = time.perf_counter() - t0
+            assert rc == 0
             assert o["status"][0] == 0, (k, o["status"][0])
             iters[k] = int(o["iters"][0])
             err = max(err, float(np.abs(o["x"][0, :nv] - x[k, :nv]).max()))
