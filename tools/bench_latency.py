@@ -240,7 +240,7 @@ def main():
     def factory(mech, n_basis, floating):
         return binding.Controller(binding.Model(mech), n_basis, floating)
     ctrl, wl = W.atlas_workload(factory, 2048, 3)
-    out = {"metric": "tick latency, host pointers in / out, synchronous call through ctypes (Atlas config 3)", "unit": "us"}
+    out = {"metric": "tick latency, host pointers in / out, synchronous call (Atlas config 3): at the C ABI (pointers converted once); through_control_batch_*: through the Python method, numpy conversions included", "unit": "us"}
     lay = ctrl.layout
     for mode in ("pageable", "pinned"):
         res = {}
@@ -265,8 +265,19 @@ def main():
                 ts.append(time.perf_counter() - t0)
             assert (r["status"] <= 1).all()
             ts = np.array(ts) * 1e6
-            res[str(B)] = {"median_us": float(np.median(ts)), "p99_us": float(np.percentile(ts, 99)),
-                           "solves_per_s": float(B / np.median(ts) * 1e6)}
+            # the same call at the C ABI: pointers converted once (Controller.bind_call) -- what a C caller or a Julia `ccall` pays
+            call = ctrl.bind_call(*a, o)
+            tc = []
+            for _ in range(300):
+                t0 = time.perf_counter()
+                rc = call()
+                tc.append(time.perf_counter() - t0)
+                assert rc == 0
+            assert (o["status"] <= 1).all()
+            tc = np.array(tc) * 1e6
+            res[str(B)] = {"median_us": float(np.median(tc)), "p99_us": float(np.percentile(tc, 99)),
+                           "solves_per_s": float(B / np.median(tc) * 1e6),
+                           "through_control_batch_median_us": float(np.median(ts)), "through_control_batch_p99_us": float(np.percentile(ts, 99))}
         out["batches_" + mode] = res
     print(json.dumps(out))
 
