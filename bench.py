@@ -25,7 +25,12 @@ Prints ONE JSON line on rank 0.  Beside the headline (device-resident, timed reg
   config.l0_plugin   the solver-level plug (b-1) on the committed Atlas problems (143 x 178; 146 x 181 with a matrix-weighted task): latency at
                      B = 1 and rate at 8 192 of the prepared entry qpc_qp_setup / qpc_qp_solve (cold and warm-started) that QPCOptimizer
                      binds, and of the dense entry qpc_qp_solve_batch (tools/bench_latency.py --l0); the CPU beside it is
-                     cpu_baseline.l0_fixture_osqp: the oracle's OSQP on the same problems, measured in the same run
+                     cpu_baseline.l0_fixture_osqp: the oracle's OSQP on the same problems, measured in the same run;
+                     .closed_loop: 95 consecutive ticks of one closed loop, each solve warm-started from the tick before (the regime the
+                     reference runs the slot in; the CPU on the same sequence: cpu_baseline.l0_fixture_osqp.closed_loop_sequence);
+                     solves_per_s_B8192_device_resident_*: qpc_qp_solve_device (values, bounds and results resident in HBM)
+  config.tick_latency  one qpc_control_batch call on 1 / 8 / 64 states, host pointers, synchronous, timed at the C ABI (the reference's regime: one robot)
+  cpu_baseline.accuracy_config5   tau of the oracle's OSQP at the notebook's tolerances and of the fp32 tick against the fp64 tick, same states
   roofline_l0        the sparse workgroup kernel of that entry (qpc_qp_sp_kernel) at 8 192 problems per launch, from live HIP events
   degraded           true when a secondary measurement failed or solved < 90 % of its QPs (the line itself stays alive)
 """
@@ -492,6 +497,20 @@ def l0_plugin_point():
         return {"error": repr(e)}, None
 
 
+def tick_latency_point():
+    """The tick in the reference's own regime -- ONE robot, one call per tick: qpc_control_batch on host pointers, synchronous, timed at the
+    C ABI (tools/bench_latency.py in a child process, outside the timed region).  Microseconds per call for 1 / 8 / 64 states."""
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_latency.py")], capture_output=True, text=True, timeout=300)
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        out = {"entry": "qpc_control_batch, host pointers in / out, synchronous, one call; Atlas config 3; caller arrays pageable / page-locked"}
+        for mode in ("pageable", "pinned"):
+            out[mode] = {f"B{B}": {"median_us": v["median_us"], "p99_us": v["p99_us"]} for B, v in d["batches_" + mode].items() if B in ("1", "8", "64")}
+        return out
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)}
+
+
 def l0_cpu_leg():
     """cpu_baseline leg for the solver-level plug: the oracle's OSQP restatement on the SAME committed problems the device entry is
     timed on (tests/golden/l0), one core, setup once and then update + solve per call as `Parametron.solve!` does (momentum.jl:58):
@@ -852,6 +871,7 @@ def main():
     n_opt = int((st == 0).sum())
 
     host_rates, secondary, closed_loop, pipelined, l0_plugin, ordered, roofline_l0 = None, None, None, None, None, None, None
+    tick_latency = None
     if rank == 0 and world == 1 and not args.no_secondary:
         # diagnostic extras, measured after the headline's timed region: none of them may take the bench line down
         if not args.fused_laws:
@@ -873,6 +893,7 @@ def main():
             ordered = {"error": repr(e)}
         closed_loop = closed_loop_point()
         l0_plugin, roofline_l0 = l0_plugin_point()
+        tick_latency = tick_latency_point()
 
     if rank == 0:
         total = B * world * args.steps
@@ -917,6 +938,7 @@ def main():
                        "cost_ordered_tickets": ordered,
                        "closed_loop": closed_loop,
                        "l0_plugin": l0_plugin,
+                       "tick_latency": tick_latency,
                        "rotate_inputs": args.rotate_inputs,
                        "kernel_fingerprint": fingerprint},
             "roofline": {"bound": "hbm", "achieved": ach_bytes / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
