@@ -398,7 +398,9 @@ static int qpc_qp_plan(qpc_qp_problem *p, const std::vector<uint8_t> &eq) {
   }
   if (!p->plan.valid) { p->plan.eq = eq; return QPC_OK; } // (remembered: not tried again for the same rows)
   // LDS: the plan's tables and the working arrays, the working set's factor sized for as many inequality rows as fit
-  const int total = 160 * 1024 / 8;
+  // (the kernel also holds 8 bytes of STATIC LDS -- its ticket word -- which count against the same 160 KB: a plan that took the last
+  //  byte made the dispatch fail with HSA_STATUS_ERROR_INVALID_ALLOCATION; found by tests/offline/fuzz_l0.py seed 7003 on the GPU)
+  const int total = QPC_SP_LDS_CAP_DOUBLES;
   int kw = p->plan.mi;
   while (kw > 0 && qpc::qp_sp_lds_doubles(p->plan.ints.data(), kw) > total) kw--;
   const int need = qpc::qp_sp_lds_doubles(p->plan.ints.data(), kw);

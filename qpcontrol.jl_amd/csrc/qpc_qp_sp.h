@@ -170,6 +170,8 @@ QPC_FN double sp_C(const QpSp &W, int p, int q) { return W.V[W.Cb + sp_sym(p, q,
 #ifdef __HIPCC__
 __host__ __device__
 #endif
+// what the host may ask for as DYNAMIC LDS (doubles): the CU's 160 KB less the kernel's static LDS (qpc_qp_sp_kernel's ticket word) and a margin
+#define QPC_SP_LDS_CAP_DOUBLES (160 * 1024 / 8 - 8)
 inline int qp_sp_lds_doubles(const int *plan, int kw) {
   const int n = plan[SP_N], m = plan[SP_M], ne = plan[SP_NE], mi = plan[SP_MI];
   return (plan[SP_LDS_INTS] + 1) / 2 + 16 + 32 + plan[SP_NVAL] + 2 * ne + 2 * plan[SP_MAXSEG] + 3 * (m + 1) + 2 * plan[SP_NHV] + 4 * n + 6 * mi + 4 * (kw + 1) + (kw + 2) / 2 +

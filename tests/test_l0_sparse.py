@@ -394,3 +394,32 @@ def test_closed_loop_sequence_emulated():
 def test_closed_loop_sequence_gpu():
     it = _closed_loop(None)
     print(f"\nclosed-loop sequence: working-set changes per tick mean {it.mean():.2f} max {it.max()}, {int((it == 0).sum())} of {len(it)} ticks without a change")
+
+
+# ---- a plan whose LDS need comes out at exactly 160 KB (the kernel holds 8 more bytes of static LDS: the dispatch failed with
+#      HSA_STATUS_ERROR_INVALID_ALLOCATION and took the process down; found by tests/offline/fuzz_l0.py seed 7003 on the GPU)
+def _last_byte_of_lds(lib):
+    for n in (129, 151, 168):  # box problems whose plan + working-set factor filled 20 473 / 20 479 / 20 480 of the 20 480 doubles
+        rng = np.random.default_rng(n)
+        P = np.diag(rng.uniform(0.5, 2.0, size=n))
+        xt = rng.normal(size=n)
+        A = np.eye(n)
+        lo, hi = xt - 0.05, xt + 0.05
+        q = -P @ (xt + np.where(np.arange(n) < 20, 1.0, 0.0))  # twenty boxes active at the solution, the others not
+        pr, (Pv, Av) = _problem(P, A, lib)
+        info = pr.analyze(lo, hi)
+        assert info["in_use"] == 1 and info["lds_bytes"] <= 160 * 1024 - 64, info
+        r = pr.solve(Pv[0], q, Av[0], lo, hi)
+        assert r["status"][0] == 0
+        np.testing.assert_allclose(r["x"][0], np.clip(-q / np.diag(P), lo, hi), atol=1e-8)
+        pr.close()
+
+
+def test_plan_that_takes_the_last_byte_of_lds_emulated():
+    emu.build()
+    _last_byte_of_lds(emu.EMU_LIB)
+
+
+@pytest.mark.gpu
+def test_plan_that_takes_the_last_byte_of_lds_gpu():
+    _last_byte_of_lds(None)
