@@ -423,3 +423,28 @@ def test_plan_that_takes_the_last_byte_of_lds_emulated():
 @pytest.mark.gpu
 def test_plan_that_takes_the_last_byte_of_lds_gpu():
     _last_byte_of_lds(None)
+
+
+# ---- the workgroup forms' dimension limit (n, m <= 256: QPC_SP_DIM, QPC_WG_DIM) at it and one beyond
+def _dimension_limits(lib):
+    for (n, m, ne, planned) in ((256, 256, 40, 1), (257, 200, 30, 0)):
+        rng = np.random.default_rng(n * 1000 + m)
+        P, q, A, l, u = _random_structured_qp(rng, n, m, ne)
+        ro = O.qp_solve(P, q, A, l, u)
+        assert ro["status"] == 0
+        pr, (Pv, Av) = _problem(P, A, lib)
+        r = pr.solve(Pv[0], q, Av[0], l, u)
+        assert pr.plan_info()["in_use"] == planned  # (257 variables: neither workgroup form, the one-lane form solves it)
+        assert r["status"][0] == 0
+        np.testing.assert_allclose(r["x"][0], ro["x"], atol=1e-8)
+        pr.close()
+
+
+def test_dimension_limits_emulated():
+    emu.build()
+    _dimension_limits(emu.EMU_LIB)
+
+
+@pytest.mark.gpu
+def test_dimension_limits_gpu():
+    _dimension_limits(None)

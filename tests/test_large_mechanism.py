@@ -82,3 +82,50 @@ def test_deep_chain_emulated():
 def test_large_mechanism_gpu(big):
     from qpcontrol_jl_amd import binding
     _run(lambda mech, N, fl: binding.Controller(binding.Model(mech), N, fl), big)
+
+
+# ---- the kernels' limits themselves (include/qpc.h: bodies <= 64, velocities <= 64): exactly at them, and one body beyond
+def make_at_the_limit(factory, n_fixed, B=2, seed=5):
+    rng = np.random.default_rng(seed)
+    types = [M.QUAT_FLOATING] + [M.REVOLUTE] * 58 + [M.FIXED] * n_fixed  # nv = 6 + 58 = 64; 59 + n_fixed bodies
+    mech = M.rand_tree(types, seed=seed)
+    nb = mech.nbodies
+    c = factory(mech, 4, 0)
+    for b in (nb - 1, nb - 2, 20, 33):
+        for sx in (-0.1, 0.1):
+            c.add_contact(b, [sx, 0.02, -0.1], [0.0, 0.1, 1.0], 0.9)
+    for j in range(nb):
+        if mech.joint_type[j] != M.FIXED:
+            c.regularize(j, 0.05)  # (64 velocities and nine task rows: without it v̇ is not unique)
+    c.add_task(SPATIAL, base=M.WORLD, target=nb - 1, frame=M.FRAME_DEFAULT, wkind=SCALAR, weight=[5.0])
+    c.add_task(LINEAR_MOMENTUM_RATE, wkind=SCALAR, weight=[1.0])
+    c.finalize()
+    qs, vs = zip(*(M.rand_state(mech, rng, 0.2) for _ in range(B)))
+    des = rng.normal(size=(B, 6 + 3)) * 0.5
+    return SC.Case(f"limit_{nb}_bodies", mech, c, np.array(qs), np.array(vs), des, np.full((B, 8), 1e-2), np.full((B, 8), 1e4), floating=0, n_basis=4)
+
+
+def _at_the_limit(factory):
+    from qpcontrol_jl_amd import binding
+    g, o = make_at_the_limit(factory, 5), make_at_the_limit(ora_factory, 5)
+    assert g.mech.nbodies == 64 and g.mech.nv == 64  # every lane of the wavefront is a body, and a velocity coordinate
+    rg = g.ctrl.control_batch(g.q, g.v, g.desired, g.cweight, g.cmaxf)
+    ro = o.ctrl.tick_batch(o.q, o.v, o.desired, o.cweight, o.cmaxf)
+    assert (ro["status"] == 0).all()
+    parity.compare(g, rg, o, ro)
+    with pytest.raises(binding.QpcError, match="limits of the one-wave-per-QP kernels"):
+        make_at_the_limit(factory, 6)  # 65 bodies: refused at qpc_finalize, not wrong
+
+
+def test_exactly_64_bodies_and_64_velocities_emulated():
+    emu.build()
+    emu.race_report()
+    _at_the_limit(emu.factory)
+    races, uninit, outside, first = emu.race_report()
+    assert (races, uninit, outside) == (0, 0, 0), first
+
+
+@pytest.mark.gpu
+def test_exactly_64_bodies_and_64_velocities_gpu():
+    from qpcontrol_jl_amd import binding
+    _at_the_limit(lambda mech, N, fl: binding.Controller(binding.Model(mech), N, fl))
