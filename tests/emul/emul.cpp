@@ -536,11 +536,13 @@ int32_t qpc_qp_last_kernel_ms(const qpc_qp_problem *, double *ms) { if (ms) *ms 
 int32_t qpc_qp_plan_info(const qpc_qp_problem *p, int64_t *out, int32_t n_out) {
   if (!p || !out || n_out < 0) return QPC_ERR_INVALID_ARGUMENT;
   const qpc::QpSpPlanHost &P = p->plan;
-  const bool on = p->plan_tried && P.valid;
+  bool on = p->plan_tried && P.valid;
   long long dense = 0;
   for (int j = 0; j < P.ne; j++) dense += (long long)(P.m + 1 - j) * (P.m + 2 - j) / 2;
-  int kw = P.mi; // (like the runtime: the working set's factor takes what is left of the 160 KB)
+  int kw = P.mi; // (like the runtime, qpc_l0.hip qpc_qp_plan: the working set's factor takes what is left of the 160 KB, and a plan that leaves
+                 //  room for fewer than 32 working rows -- or none -- is not used)
   while (on && kw > 0 && qpc::qp_sp_lds_doubles(P.ints.data(), kw) > QPC_SP_LDS_CAP_DOUBLES) kw--;
+  if (on && (qpc::qp_sp_lds_doubles(P.ints.data(), kw) > QPC_SP_LDS_CAP_DOUBLES || (kw < P.mi && kw < 32))) on = false;
   const int64_t v[12] = {on ? 1 : 0, P.ne, P.mi, P.nfront, P.nlevel, P.njob, P.nval, on ? (int64_t)qpc::qp_sp_lds_doubles(P.ints.data(), kw) * 8 : 0, P.maxw, P.maxr, P.flops, dense};
   for (int i = 0; i < 12 && i < n_out; i++) out[i] = v[i];
   return QPC_OK;
@@ -570,7 +572,13 @@ int32_t qpc_qp_solve(qpc_qp_problem *p, int64_t B, const double *P_vals, const d
   const int wg_total = cap ? atoi(cap) : QPC_WG_LDS_DOUBLES; // doubles of "LDS" (the device's 160 KB)
   std::vector<double> sp_lds;
   int sp_cap = 0;
-  if (try_sp && p->plan.valid) { sp_cap = (cap ? wg_total : QPC_SP_LDS_CAP_DOUBLES) - (p->plan.lds_ints + 1) / 2; // (the runtime's cap: qpc_l0.hip qpc_qp_plan)
+  bool sp_fits = try_sp && p->plan.valid;
+  if (sp_fits && !cap) { // the runtime's rule (qpc_l0.hip qpc_qp_plan): room for at least 32 working rows, or for all of them
+    int kw = p->plan.mi;
+    while (kw > 0 && qpc::qp_sp_lds_doubles(p->plan.ints.data(), kw) > QPC_SP_LDS_CAP_DOUBLES) kw--;
+    if (qpc::qp_sp_lds_doubles(p->plan.ints.data(), kw) > QPC_SP_LDS_CAP_DOUBLES || (kw < p->plan.mi && kw < 32)) sp_fits = false;
+  }
+  if (sp_fits) { sp_cap = (cap ? wg_total : QPC_SP_LDS_CAP_DOUBLES) - (p->plan.lds_ints + 1) / 2; // (the runtime's cap)
     if (sp_cap > 0) sp_lds.assign((size_t)sp_cap, 0.0); }
   for (int64_t b = 0; b < B; b++) {
     int s = QPC_WG_FALLBACK;

@@ -427,14 +427,32 @@ def test_plan_that_takes_the_last_byte_of_lds_gpu():
 
 # ---- the workgroup forms' dimension limit (n, m <= 256: QPC_SP_DIM, QPC_WG_DIM) at it and one beyond
 def _dimension_limits(lib):
-    for (n, m, ne, planned) in ((256, 256, 40, 1), (257, 200, 30, 0)):
+    # 256 variables and 256 rows in the sparse form: 200 rows pin a variable each (equalities), 56 are boxes -- small enough a value store for LDS
+    n = 256
+    rng = np.random.default_rng(256)
+    P = np.diag(rng.uniform(0.5, 2.0, size=n))
+    xt = rng.normal(size=n)
+    A = np.eye(n)[rng.permutation(n)]
+    lo, hi = A @ xt - 0.05, A @ xt + 0.05
+    lo[:200] = hi[:200] = (A @ xt)[:200] + 0.01
+    q = -P @ (xt + 1.0)  # the unconstrained minimiser lies outside every box
+    pr, (Pv, Av) = _problem(P, A, lib)
+    r = pr.solve(Pv[0], q, Av[0], lo, hi)
+    assert pr.plan_info()["in_use"] == 1 and pr.plan_info()["equality_rows"] == 200, pr.plan_info()
+    assert r["status"][0] == 0
+    xe = A.T @ np.where(np.arange(n) < 200, lo, np.clip(A @ (-q / np.diag(P)), lo, hi))
+    np.testing.assert_allclose(r["x"][0], xe, atol=1e-8)
+    pr.close()
+    # random structured problems: 256 x 256 with 216 inequality rows -- a plan that leaves no room for a working set in LDS: the dense
+    # workgroup form takes it --, and 257 variables: neither workgroup form, the one-lane form solves it
+    for (n, m, ne) in ((256, 256, 40), (257, 200, 30)):
         rng = np.random.default_rng(n * 1000 + m)
         P, q, A, l, u = _random_structured_qp(rng, n, m, ne)
         ro = O.qp_solve(P, q, A, l, u)
         assert ro["status"] == 0
         pr, (Pv, Av) = _problem(P, A, lib)
         r = pr.solve(Pv[0], q, Av[0], l, u)
-        assert pr.plan_info()["in_use"] == planned  # (257 variables: neither workgroup form, the one-lane form solves it)
+        assert pr.plan_info()["in_use"] == 0, (n, m, ne, pr.plan_info())
         assert r["status"][0] == 0
         np.testing.assert_allclose(r["x"][0], ro["x"], atol=1e-8)
         pr.close()
