@@ -26,7 +26,10 @@
  *    Exercised AT these limits (tests/test_valkyrie.py, MI355X): a Valkyrie-sized humanoid of 59 bodies, nv = 64, tree depth 15, eight
  *    contact points -- the reference's own integration tests (test/controller.jl:169-285) at their tolerances, 34 KB of LDS per QP,
  *    92 us per tick at B = 1 and 8.4 M ticks/s at B = 2 048 (profiles/r05_valkyrie_latency.json); beyond Atlas in other directions:
- *    44 bodies with 72 friction rays and 45 equality rows (tests/test_large_mechanism.py).  The solver-level plug (qpc_qp_setup /
+ *    44 bodies with 72 friction rays and 45 equality rows, and a tree of exactly 64 bodies and 64 velocity coordinates -- 65 bodies are
+ *    refused -- (tests/test_large_mechanism.py).  The number of contact points has no limit of its own (the slab has): 33 points x 8 rays
+ *    = 264 rho's against the oracle in tests/test_edge_contacts.py, 80 points (320 rho's, 83 KB of LDS) offline; the warm start's two
+ *    64-bit masks hold at most 64 rho's (qpc_enable_warm_start is refused beyond).  The solver-level plug (qpc_qp_setup /
  *    qpc_qp_solve) takes n, m <= 256; the Valkyrie standing controller's reference-layout problem (171 x 206) runs in its sparse
  *    form at 0.13 ms (B = 1, median) with 148 KB of LDS -- what bounds that form is LDS: plan tables + the factor's structure +
  *    the working set's factor must fit 160 KB, otherwise the dense forms take the problem (qpc_qp_plan_info tells).

@@ -27,7 +27,7 @@ extern "C" {
 #define ORA_MAXV 96   /* max velocity dimension */
 #define ORA_MAXQ 104
 #define ORA_MAXTASK 96
-#define ORA_MAXCONTACT 32
+#define ORA_MAXCONTACT 96
 #define ORA_MAXBASIS 8
 
 typedef struct ora_model {

@@ -18,8 +18,17 @@ def ora_factory(mech, n_basis, floating):
     return O.OracleController(O.OracleModel(mech), n_basis, floating)
 
 
-def make(factory, n_basis=4, mu=None, one_foot=False, B=4, seed=5, dense=False):
+def make(factory, n_basis=4, mu=None, one_foot=False, B=4, seed=5, dense=False, many=0):
     mech = M.atlas()
+    if many:  # `many` contact points (copies of the eight, shrunk towards the feet's centres): beyond 32 contacts / 128 / 256 rho's the
+        import copy  # working set's bit masks take a third, a fifth 64-bit word (the warm start's two words are refused there: test_warm_start.py)
+        base, pts = list(mech.contact_points), []
+        while len(pts) < many:
+            cp = copy.deepcopy(base[len(pts) % len(base)])
+            cp.position = np.array(cp.position) * np.array([1.0 - 0.05 * (len(pts) // len(base))] * 2 + [1.0])
+            pts.append(cp)
+        mech.contact_points = pts
+        B = 2
     if mu is not None:
         for cp in mech.contact_points:
             cp.mu = mu
@@ -41,12 +50,12 @@ def make(factory, n_basis=4, mu=None, one_foot=False, B=4, seed=5, dense=False):
     q, v = W.standing_states(mech, B, seed, dq=0.05, drot=0.02, vstd=0.05)
     des = W.standing_desired(st, q, v)
     nc = len(st.contact_ids)
-    return SC.Case(f"edge_N{n_basis}_mu{mu}_{'one' if one_foot else 'two'}{'_dense' if dense else ''}", mech, c, q, v, des, np.full((B, nc), 1e-3),
+    return SC.Case(f"edge_N{n_basis}_mu{mu}_{'one' if one_foot else 'two'}{'_dense' if dense else ''}{'_many%d' % many if many else ''}", mech, c, q, v, des, np.full((B, nc), 1e-3),
                    np.full((B, nc), 1e6), floating=floating, n_basis=n_basis)
 
 
 CASES = [dict(n_basis=3), dict(n_basis=6), dict(n_basis=8), dict(mu=0.0), dict(mu=1e-3), dict(one_foot=True),
-         dict(n_basis=5, one_foot=True), dict(dense=True)]
+         dict(n_basis=5, one_foot=True), dict(dense=True), dict(many=33), dict(many=33, n_basis=8)]  # (132 and 264 rho's)
 
 
 def _run(factory, kw):
@@ -79,7 +88,7 @@ def test_edge_contacts_emulated(kw):
     assert (races, uninit, outside) == (0, 0, 0), first
 
 
-GPU_SLOW_CASES = (dict(n_basis=6), dict(n_basis=8), dict(mu=1e-3), dict(n_basis=5, one_foot=True))  # (a hiprtc compile and an oracle run each; the fast set keeps the odd basis, the frictionless cone, the single foot and the dense form)
+GPU_SLOW_CASES = (dict(n_basis=6), dict(n_basis=8), dict(mu=1e-3), dict(n_basis=5, one_foot=True), dict(many=33))  # (a hiprtc compile and an oracle run each; the fast set keeps the odd basis, the frictionless cone, the single foot and the dense form)
 
 
 @pytest.mark.gpu
