@@ -466,3 +466,37 @@ def test_dimension_limits_emulated():
 @pytest.mark.gpu
 def test_dimension_limits_gpu():
     _dimension_limits(None)
+
+
+@pytest.mark.gpu
+def test_large_batch_in_chunks_with_leftovers_gpu():
+    """B = 4 608: the batch goes through the sparse form in 1 024-problem chunks over two streams (qpc_l0.hip `piped`); three QPs with other
+    equality rows than the plan's are left by it and taken by the dense workgroup form afterwards -- every QP's answer as if solved alone,
+    cold and warm-started"""
+    P, q, A, l, u, x_ref, nv = _fixture("diag")
+    k = P.shape[0]
+    B = 4608
+    idx = np.arange(B) % k
+    lb, ub = l[idx].copy(), u[idx].copy()
+    row = int(np.where(l[0] < u[0] - 1.0)[0][0])
+    odd = [5, 2049, 4600]  # (one in the first chunk, one in the middle, one in the last, partial chunk)
+    for b in odd:
+        ub[b, row] = lb[b, row] = 0.5 * (max(l[idx[b], row], -10.0) + min(u[idx[b], row], 10.0))
+    pr, (Pv, Av) = _problem(P, A, None)
+    Pb, Ab, qb = Pv[idx], Av[idx], q[idx]
+    single = {}
+    for b in odd:
+        p1, _ = _problem(P, A, None)
+        single[b] = p1.solve(Pb[b], qb[b], Ab[b], lb[b], ub[b])
+        p1.close()
+    for warm in (False, True):
+        r = pr.solve(Pb, qb, Ab, lb, ub, warm_start=warm)
+        assert pr.plan_info()["in_use"] == 1 and pr.plan_info()["equality_rows"] == 114
+        ok = np.ones(B, dtype=bool); ok[odd] = False
+        assert (r["status"][ok] == 0).all()
+        np.testing.assert_allclose(r["x"][ok][:, :nv], x_ref[idx][ok][:, :nv], atol=1e-8, rtol=0)
+        for b in odd:
+            assert r["status"][b] == single[b]["status"][0]
+            if single[b]["status"][0] == 0:
+                np.testing.assert_allclose(r["x"][b, :nv], single[b]["x"][0, :nv], atol=1e-8, rtol=0)
+    pr.close()
