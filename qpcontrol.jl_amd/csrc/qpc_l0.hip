@@ -30,6 +30,7 @@ static int hip_fail(hipError_t e, const char *what) {
 }
 #define HIP_TRY(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return hip_fail(e__, #call); } while (0)
 static inline size_t pad64(size_t b) { return (b + 63) & ~(size_t)63; }
+#define QPC_L0_LEFT_CHUNK 2048 // QPs per launch of the dense forms behind qpc_qp_solve (their per-QP workspace and dense P, A are sized for this many)
 
 // L0, first pass: one WORKGROUP per dense QP, working matrices in LDS (qpc_qp_wg.h): the problems Parametron builds for this
 // controller (diagonal P, sparse A).  status[b] = QPC_WG_FALLBACK marks a QP it leaves to the one-lane kernel below.
@@ -546,7 +547,10 @@ int32_t qpc_qp_solve(qpc_qp_problem *p, int64_t B, const double *P_vals, const d
   qpc_settings st;
   if (settings) st = *settings; else qpc_default_settings(&st);
   const size_t nPv = (size_t)B * nnzP, nq = (size_t)B * n, nAv = (size_t)B * nnzA, nm = (size_t)B * m;
-  const size_t wsb = (size_t)qpc_qp_workspace_bytes(n, m > 0 ? m : 1, B);
+  // the dense forms (what the sparse form leaves) work through the batch in chunks of QPC_L0_LEFT_CHUNK QPs: their workspace (875 KB per
+  // Atlas-sized QP) and the dense copies of P and A are sized for a chunk, not for the batch
+  const int64_t lch = B < QPC_L0_LEFT_CHUNK ? B : (int64_t)QPC_L0_LEFT_CHUNK;
+  const size_t wsb = (size_t)qpc_qp_workspace_bytes(n, m > 0 ? m : 1, lch);
   const size_t total = pad64(nPv * 8) + 2 * pad64(nq * 8) + pad64(nAv * 8) + 3 * pad64(nm * 8) + 2 * pad64((size_t)B * sizeof(int32_t));
   if (total > p->bytes) {
     if (p->buf) (void)hipFree(p->buf);
@@ -741,23 +745,33 @@ int32_t qpc_qp_solve(qpc_qp_problem *p, int64_t B, const double *P_vals, const d
     left = false;
     for (int64_t b = 0; b < B; b++) left = left || hst[(size_t)b] == QPC_WG_FALLBACK;
   }
+  auto chunk_has_left = [&](int64_t b0, int64_t nb) { // (hst: FALLBACK everywhere before any form has run)
+    for (int64_t b = b0; b < b0 + nb; b++) if (hst[(size_t)b] == QPC_WG_FALLBACK) return true;
+    return false;
+  };
   if (rc == QPC_OK && wg && left) { // the dense workgroup form: everything, or what the sparse form left
     if (int wrc = want_ws()) return wrc;
     const int lds_bytes = QPC_WG_LDS_DOUBLES * (int)sizeof(double);
     if (int arc = qpc_wg_lds_attr((const void *)qpc_qp_wg_prep_kernel, p->device, lds_bytes)) return arc;
-    const long long grid = B < (long long)p->n_cu * 4 ? B : (long long)p->n_cu * 4;
-    // (no memset of the QP counter: the launch's last ticket re-arms it)
-    hipLaunchKernelGGL(qpc_qp_wg_prep_kernel, dim3((unsigned)grid), dim3(QPC_WG_THREADS), (size_t)lds_bytes, p->stream, p->H.view(p->d_ints),
-                       (long long)B, nnzP, dPv, dq, dAv, dl, du, st, dws, ws_stride, y0, dx, dy, dst, dit, p->d_ticket, p->d_yprev, sp ? 1 : 0);
-    chk(hipGetLastError(), "qpc_qp_wg_prep_kernel");
+    for (int64_t b0 = 0; b0 < B && rc == QPC_OK; b0 += lch) {
+      const int64_t nb = std::min(lch, B - b0);
+      if (!chunk_has_left(b0, nb)) continue;
+      const long long grid = nb < (long long)p->n_cu * 4 ? nb : (long long)p->n_cu * 4;
+      // (no memset of the QP counter: the launch's last ticket re-arms it; the chunks follow each other on the stream and share the workspace)
+      hipLaunchKernelGGL(qpc_qp_wg_prep_kernel, dim3((unsigned)grid), dim3(QPC_WG_THREADS), (size_t)lds_bytes, p->stream, p->H.view(p->d_ints),
+                         (long long)nb, nnzP, dPv + b0 * nnzP, dq + b0 * n, dAv + b0 * nnzA, dl + b0 * m, du + b0 * m, st, dws, ws_stride,
+                         y0 ? y0 + b0 * m : nullptr, dx + b0 * n, dy + b0 * m, dst + b0, dit + b0, p->d_ticket, p->d_yprev ? p->d_yprev + b0 * m : nullptr,
+                         sp ? 1 : 0);
+      chk(hipGetLastError(), "qpc_qp_wg_prep_kernel");
+    }
     if (collect("qpc_qp_wg_prep_kernel")) return QPC_OK;
     if (rc != QPC_OK) return rc;
   }
   bool need_dense = false;
   for (int64_t b = 0; b < B && !need_dense; b++) need_dense = hst[(size_t)b] == QPC_WG_FALLBACK;
-  if (rc == QPC_OK && need_dense) { // the dense path: scatter P, A and run the dense entry on what is left
+  if (rc == QPC_OK && need_dense) { // the dense path: scatter P, A and run the dense entry on what is left, chunk by chunk
     if (int wrc = want_ws()) return wrc;
-    const size_t nP = (size_t)B * n * n, nA = (size_t)B * (m > 0 ? m : 1) * n;
+    const size_t nP = (size_t)lch * n * n, nA = (size_t)lch * (m > 0 ? m : 1) * n;
     const size_t need = pad64(nP * 8) + pad64(nA * 8);
     if (need > p->dense_bytes) {
       if (p->dense) (void)hipFree(p->dense);
@@ -766,19 +780,24 @@ int32_t qpc_qp_solve(qpc_qp_problem *p, int64_t B, const double *P_vals, const d
       p->dense_bytes = need;
     }
     double *dP = (double *)p->dense, *dA = (double *)(p->dense + pad64(nP * 8));
-    chk(hipMemsetAsync(p->dense, 0, need, p->stream), "clear dense P, A");
     const int *Prow = p->d_coo, *Pcol = Prow + nnzP, *Arow = Pcol + nnzP, *Acol = Arow + nnzA;
-    if (nnzP + nnzA > 0) {
-      hipLaunchKernelGGL(qpc_qp_densify_kernel, dim3(1024), dim3(256), 0, p->stream, n, m, (long long)B, nnzP, Prow, Pcol, dPv, nnzA, Arow, Acol,
-                         dAv, dP, dA);
-      chk(hipGetLastError(), "qpc_qp_densify_kernel");
-    }
-    if (!wg && !sp) { // everything through the dense entry (its own workgroup pass detects what it can take)
-      if (rc == QPC_OK) rc = qpc_qp_solve_batch_device(n, m, B, dP, dq, dA, dl, du, &st, p->device, dx, dy, dst, dit, dws, wsb, p->stream);
-    } else {   // only the QPs the workgroup left: the one-lane kernel
-      hipLaunchKernelGGL(qpc_qp_dense_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, p->stream, n, m, (long long)B, dP, dq, dA, dl, du, st,
-                         dws, ws_stride, dx, dy, dst, dit, 1);
-      chk(hipGetLastError(), "qpc_qp_dense_kernel");
+    for (int64_t b0 = 0; b0 < B && rc == QPC_OK; b0 += lch) {
+      const int64_t nb = std::min(lch, B - b0);
+      if (!chunk_has_left(b0, nb)) continue;
+      chk(hipMemsetAsync(p->dense, 0, need, p->stream), "clear dense P, A");
+      if (nnzP + nnzA > 0) {
+        hipLaunchKernelGGL(qpc_qp_densify_kernel, dim3(1024), dim3(256), 0, p->stream, n, m, (long long)nb, nnzP, Prow, Pcol, dPv + b0 * nnzP, nnzA, Arow,
+                           Acol, dAv + b0 * nnzA, dP, dA);
+        chk(hipGetLastError(), "qpc_qp_densify_kernel");
+      }
+      if (!wg && !sp) { // everything through the dense entry (its own workgroup pass detects what it can take)
+        if (rc == QPC_OK) rc = qpc_qp_solve_batch_device(n, m, nb, dP, dq + b0 * n, dA, dl + b0 * m, du + b0 * m, &st, p->device, dx + b0 * n, dy + b0 * m,
+                                                         dst + b0, dit + b0, dws, wsb, p->stream);
+      } else {   // only the QPs the workgroup forms left: the one-lane kernel
+        hipLaunchKernelGGL(qpc_qp_dense_kernel, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, p->stream, n, m, (long long)nb, dP, dq + b0 * n, dA,
+                           dl + b0 * m, du + b0 * m, st, dws, ws_stride, dx + b0 * n, dy + b0 * m, dst + b0, dit + b0, 1);
+        chk(hipGetLastError(), "qpc_qp_dense_kernel");
+      }
     }
     chk(hipMemcpyAsync(hst.data(), dst, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, p->stream), "copy status");
   }
@@ -850,8 +869,10 @@ int32_t qpc_qp_solve_device(qpc_qp_problem *p, int64_t B, const double *dPv, con
     if (p->d_yprev) p->B_prev = B;
     if (left == 0) return QPC_OK;
   }
-  // what is left (other equality rows than the plan's; no plan at all): the dense forms and their workspace in HBM
-  const size_t wsb = (size_t)qpc_qp_workspace_bytes(n, m > 0 ? m : 1, B);
+  // what is left (other equality rows than the plan's; no plan at all): the dense forms, chunk by chunk (the host does not know WHICH QPs are
+  // left, only how many: every chunk is launched, a workgroup skips a solved QP after one load)
+  const int64_t lch = B < QPC_L0_LEFT_CHUNK ? B : (int64_t)QPC_L0_LEFT_CHUNK;
+  const size_t wsb = (size_t)qpc_qp_workspace_bytes(n, m > 0 ? m : 1, lch);
   if (wsb > p->ws_bytes) {
     if (p->ws) (void)hipFree(p->ws);
     p->ws = nullptr; p->ws_bytes = 0;
@@ -863,17 +884,21 @@ int32_t qpc_qp_solve_device(qpc_qp_problem *p, int64_t B, const double *dPv, con
   if (wg) {
     const int lds_bytes = QPC_WG_LDS_DOUBLES * (int)sizeof(double);
     if (int arc = qpc_wg_lds_attr((const void *)qpc_qp_wg_prep_kernel, p->device, lds_bytes)) return arc;
-    const long long grid = B < (long long)p->n_cu * 4 ? B : (long long)p->n_cu * 4;
-    hipLaunchKernelGGL(qpc_qp_wg_prep_kernel, dim3((unsigned)grid), dim3(QPC_WG_THREADS), (size_t)lds_bytes, sm, p->H.view(p->d_ints), (long long)B, nnzP,
-                       dPv, dq, dAv, dl, du, st, dws, ws_stride, y0, dx, dy, dst, dit, p->d_ticket, p->d_yprev, sp ? 1 : 0);
-    chk(hipGetLastError(), "qpc_qp_wg_prep_kernel");
+    for (int64_t b0 = 0; b0 < B && rc == QPC_OK; b0 += lch) {
+      const int64_t nb = std::min(lch, B - b0);
+      const long long grid = nb < (long long)p->n_cu * 4 ? nb : (long long)p->n_cu * 4;
+      hipLaunchKernelGGL(qpc_qp_wg_prep_kernel, dim3((unsigned)grid), dim3(QPC_WG_THREADS), (size_t)lds_bytes, sm, p->H.view(p->d_ints), (long long)nb, nnzP,
+                         dPv + b0 * nnzP, dq + b0 * n, dAv + b0 * nnzA, dl + b0 * m, du + b0 * m, st, dws, ws_stride, y0 ? y0 + b0 * m : nullptr,
+                         dx + b0 * n, dy + b0 * m, dst + b0, dit ? dit + b0 : nullptr, p->d_ticket, p->d_yprev ? p->d_yprev + b0 * m : nullptr, sp ? 1 : 0);
+      chk(hipGetLastError(), "qpc_qp_wg_prep_kernel");
+    }
     left = left_after("qpc_qp_wg_prep_kernel");
     if (rc != QPC_OK) return rc;
     if (p->d_yprev) p->B_prev = B;
     if (left == 0) return QPC_OK;
   }
   { // the dense path: scatter P, A and run the dense entry on what is left
-    const size_t nP = (size_t)B * n * n, nA = (size_t)B * (m > 0 ? m : 1) * n;
+    const size_t nP = (size_t)lch * n * n, nA = (size_t)lch * (m > 0 ? m : 1) * n;
     const size_t need = pad64(nP * 8) + pad64(nA * 8);
     if (need > p->dense_bytes) {
       if (p->dense) (void)hipFree(p->dense);
@@ -882,18 +907,23 @@ int32_t qpc_qp_solve_device(qpc_qp_problem *p, int64_t B, const double *dPv, con
       p->dense_bytes = need;
     }
     double *dP = (double *)p->dense, *dA = (double *)(p->dense + pad64(nP * 8));
-    chk(hipMemsetAsync(p->dense, 0, need, sm), "clear dense P, A");
     const int *Prow = p->d_coo, *Pcol = Prow + nnzP, *Arow = Pcol + nnzP, *Acol = Arow + nnzA;
-    if (nnzP + nnzA > 0) {
-      hipLaunchKernelGGL(qpc_qp_densify_kernel, dim3(1024), dim3(256), 0, sm, n, m, (long long)B, nnzP, Prow, Pcol, dPv, nnzA, Arow, Acol, dAv, dP, dA);
-      chk(hipGetLastError(), "qpc_qp_densify_kernel");
-    }
-    if (!wg && !sp) {
-      if (rc == QPC_OK) rc = qpc_qp_solve_batch_device(n, m, B, dP, dq, dA, dl, du, &st, p->device, dx, dy, dst, dit, dws, wsb, sm);
-    } else {
-      hipLaunchKernelGGL(qpc_qp_dense_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, sm, n, m, (long long)B, dP, dq, dA, dl, du, st, dws, ws_stride,
-                         dx, dy, dst, dit, 1);
-      chk(hipGetLastError(), "qpc_qp_dense_kernel");
+    for (int64_t b0 = 0; b0 < B && rc == QPC_OK; b0 += lch) {
+      const int64_t nb = std::min(lch, B - b0);
+      chk(hipMemsetAsync(p->dense, 0, need, sm), "clear dense P, A");
+      if (nnzP + nnzA > 0) {
+        hipLaunchKernelGGL(qpc_qp_densify_kernel, dim3(1024), dim3(256), 0, sm, n, m, (long long)nb, nnzP, Prow, Pcol, dPv + b0 * nnzP, nnzA, Arow, Acol,
+                           dAv + b0 * nnzA, dP, dA);
+        chk(hipGetLastError(), "qpc_qp_densify_kernel");
+      }
+      if (!wg && !sp) {
+        if (rc == QPC_OK) rc = qpc_qp_solve_batch_device(n, m, nb, dP, dq + b0 * n, dA, dl + b0 * m, du + b0 * m, &st, p->device, dx + b0 * n, dy + b0 * m,
+                                                         dst + b0, dit ? dit + b0 : nullptr, dws, wsb, sm);
+      } else {
+        hipLaunchKernelGGL(qpc_qp_dense_kernel, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, sm, n, m, (long long)nb, dP, dq + b0 * n, dA, dl + b0 * m,
+                           du + b0 * m, st, dws, ws_stride, dx + b0 * n, dy + b0 * m, dst + b0, dit ? dit + b0 : nullptr, 1);
+        chk(hipGetLastError(), "qpc_qp_dense_kernel");
+      }
     }
     if (m && rc == QPC_OK) { // the multipliers for the next call's warm start (the workgroup kernels keep their own)
       if (B > p->cap_prev) {

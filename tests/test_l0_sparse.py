@@ -295,14 +295,16 @@ def test_working_set_beyond_lds_goes_down_the_chain_gpu():
 
 
 # ---- the device-pointer entry (qpc_qp_solve_device): same forms, same order, same bits as the host entry
-def _device_entry(lib, to_dev, from_dev, stream=0):
-    """`to_dev(array) -> (holder, address)`, `from_dev(holder) -> numpy`: torch on the GPU, numpy itself on the emulation"""
+def _device_entry(lib, to_dev, from_dev, stream=0, rep=3):
+    """`to_dev(array) -> (holder, address)`, `from_dev(holder) -> numpy`: torch on the GPU, numpy itself on the emulation.
+    rep: copies of the eight committed problems (GPU: 300 -- 2 400 QPs, more than one chunk of the dense forms behind the sparse one)"""
     P, q, A, l, u, x_ref, nv = _fixture("diag")
-    rep = 3
     Pb, qb, Ab, lb, ub = (np.concatenate([a] * rep) for a in (P, q, A, l, u))
     l2, u2 = lb.copy(), ub.copy()
     row = int(np.where(l[0] < u[0] - 1.0)[0][0])  # an inequality row of QP 5 turned into an equality: not the plan's rows, left to the next form
-    u2[5, row] = l2[5, row] = 0.5 * (max(l[5, row], -10.0) + min(u[5, row], 10.0))
+    odd = [5] + ([2100] if rep * 8 > 2100 else [])
+    for b in odd:
+        u2[b, row] = l2[b, row] = 0.5 * (max(l[b % 8, row], -10.0) + min(u[b % 8, row], 10.0))
     B = Pb.shape[0]
     for lo, hi in ((lb, ub), (l2, u2)):
         host, dev = _problem(P, A, lib)[0], _problem(P, A, lib)[0]
@@ -318,8 +320,9 @@ def _device_entry(lib, to_dev, from_dev, stream=0):
             xd, yd, sd, itd = (from_dev(o[0]) for o in outs)
             assert np.array_equal(sd, rh["status"]), (sd, rh["status"])
             assert np.array_equal(xd, rh["x"]) and np.array_equal(yd, rh["y"]) and np.array_equal(itd, rh["iters"])  # bit for bit
-            assert np.all(sd[np.arange(B) != 5] == 0)
-            np.testing.assert_allclose(xd[np.arange(B) != 5][:, :nv], np.concatenate([x_ref] * rep)[np.arange(B) != 5][:, :nv], atol=1e-8, rtol=0)
+            plain = ~np.isin(np.arange(B), odd)
+            assert np.all(sd[plain] == 0)
+            np.testing.assert_allclose(xd[plain][:, :nv], np.concatenate([x_ref] * rep)[plain][:, :nv], atol=1e-8, rtol=0)
 
 
 def test_device_pointer_entry_emulated():
@@ -339,6 +342,7 @@ def gpu_device_entry_check():
         return t, t.data_ptr()
     torch.cuda.synchronize(dev)
     _device_entry(None, to_dev, lambda t: t.cpu().numpy(), stream=s.cuda_stream)
+    _device_entry(None, to_dev, lambda t: t.cpu().numpy(), stream=s.cuda_stream, rep=300)
     # without a plan (no analyze, no earlier solve) the dense forms take the batch: still the same answers
     P, q, A, l, u, x_ref, nv = _fixture("diag")
     pr = _problem(P, A, None)[0]
