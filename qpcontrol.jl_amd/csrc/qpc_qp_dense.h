@@ -110,8 +110,12 @@ QPC_FN void qp_solve_dense(int n, int m, const double *P, const double *q, const
   int status = QPC_STATUS_OPTIMAL, iters = 0, nw = 0;
   const int max_it = st.max_active_set_iters > 0 ? st.max_active_set_iters : 200;
   auto solve_ws = [&]() { // EQP of the current working set -> yw (compact), x, ax ; returns nw
+    // the equality rows FIRST: the infinite-pivot rule drops the LATER of two dependent rows, and of an equality row and an active bound that
+    // say the same thing it is the bound that may go (in the caller's order an equality row behind such a bound was dropped, the answer violated
+    // it and the QP was called INFEASIBLE: tests/offline/fuzz_l0_big.py seed 11)
     int k = 0;
-    for (int i = 0; i < m; i++) if (wsf[i] != 0.0) { idx[k] = (double)i; k++; }
+    for (int i = 0; i < m; i++) if (wsf[i] == 2.0) { idx[k] = (double)i; k++; }
+    for (int i = 0; i < m; i++) if (wsf[i] != 0.0 && wsf[i] != 2.0) { idx[k] = (double)i; k++; }
     for (int a = 0; a < k; a++) {
       int ia = (int)idx[a];
       for (int b = 0; b <= a; b++) S[a * m + b] = G[ia * m + (int)idx[b]];
@@ -181,8 +185,9 @@ QPC_FN void qp_solve_dense(int n, int m, const double *P, const double *q, const
       bool infeasible = false;
       for (int inner = 0; inner <= m; inner++) {
         // r = (G_WW)^-1 G_Wp : a_p in terms of the working rows (H^-1 metric)
-        int k = 0;
-        for (int i = 0; i < m; i++) if (wsf[i] != 0.0) { idx[k] = (double)i; k++; }
+        int k = 0; // (the order of solve_ws: equality rows first)
+        for (int i = 0; i < m; i++) if (wsf[i] == 2.0) { idx[k] = (double)i; k++; }
+        for (int i = 0; i < m; i++) if (wsf[i] != 0.0 && wsf[i] != 2.0) { idx[k] = (double)i; k++; }
         for (int a = 0; a < k; a++) {
           int ia = (int)idx[a];
           for (int b = 0; b <= a; b++) S[a * m + b] = G[ia * m + (int)idx[b]];

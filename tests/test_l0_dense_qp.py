@@ -165,3 +165,31 @@ def test_l0_gpu_fixture_batch():
     r = binding.qp_solve_batch(P[idx], q[idx], A[idx], l[idx], u[idx])
     assert (r["status"] == 0).all()
     np.testing.assert_allclose(r["x"][:, :nv], x[idx][:, :nv], atol=1e-8)
+
+
+def test_one_lane_form_keeps_equality_rows_before_active_bounds():
+    """A 231 x 246 block-arrow problem with blocks in P (no plan fits LDS, P is not diagonal: the one-lane form) whose sweeps put a bound into the
+    working set that, with the equality rows before it, says what an equality row BEHIND it in the caller's order says.  The infinite-pivot
+    factorization drops the later of two dependent rows -- it has to be the bound: in the caller's order the equality row went, the answer
+    violated it by 0.17 and the QP was called INFEASIBLE (tests/offline/fuzz_l0_big.py seed 11, trial 29; the oracle and the dense
+    workgroup form on the diagonal of P solve it)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "offline"))
+    import fuzz_l0_big
+    emu.build()
+    rng = np.random.default_rng(11)
+    for _ in range(30):
+        P, q, A, l, u, n, m, ne = fuzz_l0_big.gen(rng)
+    assert (n, m, ne) == (231, 246, 160) and np.any(P - np.diag(np.diag(P)) != 0.0)
+    ro = O.qp_solve(P, q, A, l, u)
+    assert ro["status"] == 0
+    pr = binding.QpProblem(n, m, P != 0, A != 0, lib_path=emu.EMU_LIB)
+    Pv, Av = pr.values(P, A)
+    r = pr.solve(Pv[0], q, Av[0], l, u)
+    assert pr.plan_info()["in_use"] == 0
+    pr.close()
+    assert r["status"][0] == 0, r["status"]
+    Ax = A @ r["x"][0]
+    assert max(np.maximum(l - Ax, 0).max(), np.maximum(Ax - u, 0).max()) < 1e-10
+    np.testing.assert_allclose(r["x"][0], ro["x"], atol=1e-7)
