@@ -18,24 +18,26 @@ def ora_factory(mech, n_basis, floating):
     return O.OracleController(O.OracleModel(mech), n_basis, floating)
 
 
-def build(factory, seed, B=2):
+def build(factory, seed, B=2, big=False):
+    """big: mechanisms near the kernels' limits (30 ... 58 joints behind a floating base: up to 59 bodies and 64 velocity coordinates; up to
+    20 contact points with bases of up to 8 rays; up to 12 tasks) -- tests/offline/fuzz_more.py; the default sizes are the suite's"""
     rng = np.random.default_rng(seed)
-    floating = bool(rng.integers(0, 2))
-    n = int(rng.integers(4, 12))
+    floating = bool(rng.integers(0, 2)) or big
+    n = int(rng.integers(30, 59)) if big else int(rng.integers(4, 12))
     types = ([M.QUAT_FLOATING] if floating else []) + [int(rng.choice([M.REVOLUTE, M.REVOLUTE, M.PRISMATIC, M.FIXED])) for _ in range(n)]
-    mech = M.rand_tree(types, seed=seed + 1000, chain=bool(rng.integers(0, 2)))
+    mech = M.rand_tree(types, seed=seed + 1000, chain=bool(rng.integers(0, 2)) and not big)  # (a chain of 40 bodies is beyond the depth limit of 32)
     nb = mech.nbodies
-    N = int(rng.choice([3, 4, 4, 5]))
+    N = int(rng.choice([3, 4, 4, 5, 6, 8] if big else [3, 4, 4, 5]))
     fl = 0 if floating else -1
     c = factory(mech, N, fl)
-    nc = int(rng.integers(0, 4)) if floating else 0
+    nc = (int(rng.integers(0, 21)) if big else int(rng.integers(0, 4))) if floating else 0
     for _ in range(nc):
         c.add_contact(int(rng.integers(1, nb)), rng.normal(size=3) * 0.2, [rng.normal() * 0.2, rng.normal() * 0.2, 1.0], float(rng.uniform(0.3, 1.0)))
     for j in range(nb):
         c.regularize(j, float(rng.uniform(0.02, 0.2)))
     dims, ntw = [], 0
     moving = [j for j in range(nb) if mech.joint_type[j] != M.FIXED]
-    for _ in range(int(rng.integers(1, 5))):
+    for _ in range(int(rng.integers(3, 13)) if big else int(rng.integers(1, 5))):
         kind = int(rng.choice([SPATIAL, ANGULAR, LINEAR, POINT, JOINT, JOINT, LINEAR_MOMENTUM_RATE, MOMENTUM_RATE]))
         wsel = int(rng.integers(0, 5))
         dim = {SPATIAL: 6, ANGULAR: 3, LINEAR: 3, POINT: 3, LINEAR_MOMENTUM_RATE: 3, MOMENTUM_RATE: 6}.get(kind)
