@@ -227,19 +227,20 @@ def test_rollout_standing_acceptance_gpu():
     assert r["q"][:, 6].min() > 0.70 and r["q"][:, 6].max() < 0.95
 
 
-def fuzz_case(factory, seed, B=3):
+def fuzz_case(factory, seed, B=3, big=False):
     """random mechanism (floating or fixed base, mixed joint types, random tree shape) with random contact
-    points, random ground height and gains"""
+    points, random ground height and gains.  big (tests/offline/fuzz_sim.py): 30 ... 57 joints behind a floating base -- up to 58 bodies --, trees
+    only (a chain that long is beyond the depth limit), up to 16 contact points"""
     rng = np.random.default_rng(seed)
-    floating = bool(rng.integers(2))
+    floating = bool(rng.integers(2)) or big
     kinds = [M.REVOLUTE, M.REVOLUTE, M.REVOLUTE, M.PRISMATIC, M.FIXED]
-    types = ([M.QUAT_FLOATING] if floating else []) + [kinds[int(k)] for k in rng.integers(len(kinds), size=int(rng.integers(3, 14)))]
-    mech = M.rand_tree(types, seed=seed, chain=bool(rng.integers(2)))
+    types = ([M.QUAT_FLOATING] if floating else []) + [kinds[int(k)] for k in rng.integers(len(kinds), size=int(rng.integers(30, 58)) if big else int(rng.integers(3, 14)))]
+    mech = M.rand_tree(types, seed=seed, chain=bool(rng.integers(2)) and not big)
     nb = mech.nbodies
     c = factory(mech, 4, 0 if floating else -1)
     cps = []
     if floating:
-        for _ in range(int(rng.integers(1, 6))):
+        for _ in range(int(rng.integers(1, 17)) if big else int(rng.integers(1, 6))):
             cp = SimpleNamespace(body=int(rng.integers(nb)), position=rng.normal(scale=0.2, size=3), mu=float(rng.uniform(0.2, 1.2)))
             cps.append(cp)
             c.add_contact(cp.body, cp.position, [0.0, 0.0, 1.0], cp.mu)
