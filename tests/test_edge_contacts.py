@@ -88,7 +88,7 @@ def test_edge_contacts_emulated(kw):
     assert (races, uninit, outside) == (0, 0, 0), first
 
 
-GPU_SLOW_CASES = (dict(n_basis=6), dict(n_basis=8), dict(mu=1e-3), dict(n_basis=5, one_foot=True), dict(many=33, n_basis=8))  # (a hiprtc compile and an oracle run each; the fast set keeps the odd basis, the frictionless cone, the single foot and the dense form)
+GPU_SLOW_CASES = (dict(n_basis=6), dict(n_basis=8), dict(mu=0.0), dict(mu=1e-3), dict(n_basis=5, one_foot=True), dict(many=33, n_basis=8))  # (a hiprtc compile and an oracle run each; the fast set keeps the odd basis, the single foot, the dense form and the 33-point case; the frictionless cones run on the CPU emulation and under -m gpu_slow)
 
 
 @pytest.mark.gpu

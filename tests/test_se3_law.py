@@ -128,6 +128,7 @@ def test_se3_pd_law_gpu():
 
 
 @pytest.mark.gpu
+@pytest.mark.gpu_slow  # (6 s of hiprtc; each law keeps a fast GPU test of its own, the combination its emulated twin)
 def test_se3_and_orientation_laws_in_one_controller_gpu():
     _run(lambda mech, N, fl: binding.Controller(binding.Model(mech), N, fl), B=10, pelvis_law=(20.0, 9.0))
 
