@@ -105,7 +105,7 @@ def test_generic_kernel_takes_the_valkyrie_tree(monkeypatch):
     parity.compare(g, r, o, o.ctrl.tick_batch(o.q, o.v, o.desired, o.cweight, o.cmaxf, o.tw, o.surf))
 
 
-def valkyrie_standing(factory, B, seed=77):
+def valkyrie_standing(factory, B, seed=77, momentum_weight_matrix=None):
     """the StandingController task set (standing.jl:18-56) on the Valkyrie-sized robot: contacts, regularisation, hard foot tasks, the
     soft linear momentum task, the pelvis orientation task, joint tasks off the legs' paths"""
     mech = M.valkyrie()
@@ -122,7 +122,7 @@ def valkyrie_standing(factory, B, seed=77):
         q0[mech.configuration_range(mech.findbody(f"{s}KneePitchLink"))[0]] = 0.9
         q0[mech.configuration_range(mech.findbody(f"{s}HipPitchLink"))[0]] = -0.45
         q0[mech.configuration_range(mech.findbody(f"{s}AnklePitchLink"))[0]] = -0.45
-    st = W.standing_setup(ctrl, mech, q0, feet=("leftFoot", "rightFoot"))
+    st = W.standing_setup(ctrl, mech, q0, feet=("leftFoot", "rightFoot"), momentum_weight_matrix=momentum_weight_matrix)
     ctrl.finalize()
     q = np.tile(q0, (B, 1))
     for j in range(mech.nbodies):
@@ -146,10 +146,16 @@ def test_standing_tick_matches_the_oracle(backend):
     np.testing.assert_allclose(r["vdot"][ok], ro["vdot"][ok], atol=1e-8 * max(1.0, np.abs(ro["vdot"][ok]).max()), rtol=0)
 
 
-def valkyrie_l0_problems(B=4):
+def momentum_weight_matrix():
+    """a 6 x 6 symmetric positive definite W that is not diagonal (seeded): `addtask!(controller, MomentumRateTask, W::AbstractMatrix)`"""
+    Q = np.random.default_rng(61).normal(size=(6, 6))
+    return Q @ Q.T / 6.0 + np.diag([0.5, 0.5, 0.5, 1.0, 1.0, 1.0])
+
+
+def valkyrie_l0_problems(B=4, matrix=False):
     """the reference-layout QPs of the Valkyrie standing controller as the oracle builds them (what Parametron would hand to the
     optimizer slot, momentum.jl:27,58), with the oracle's solution"""
-    mech, oc, q, v, des, cw, cm = valkyrie_standing(ora_factory, B)
+    mech, oc, q, v, des, cw, cm = valkyrie_standing(ora_factory, B, momentum_weight_matrix=momentum_weight_matrix() if matrix else None)
     Ps, qs, As, ls, us, xs = [], [], [], [], [], []
     for b in range(B):
         P, qq, A, l, u = oc.build_qp(q[b], v[b], des[b], cw[b], cm[b])
@@ -159,10 +165,12 @@ def valkyrie_l0_problems(B=4):
     return np.array(Ps), np.array(qs), np.array(As), np.array(ls), np.array(us), np.array(xs), mech.nv
 
 
-def _l0(lib):
-    P, q, A, l, u, x, nv = valkyrie_l0_problems()
+def _l0(lib, matrix=False):
+    P, q, A, l, u, x, nv = valkyrie_l0_problems(matrix=matrix)
     n, m = P.shape[1], A.shape[1]
     assert n > 160 and m > 190  # (171 x 206: beyond what the dense workgroup form holds in LDS)
+    if matrix:  # the reference's OBJECTIVE_TERM_MATRIX_WEIGHT mode (test/controller.jl:232-285) on this robot: six slack variables, a 6 x 6 block in P
+        assert (n, m) == (174, 209) and np.any(P[0] - np.diag(np.diag(P[0])) != 0.0)
     pr = binding.QpProblem(n, m, (P != 0).any(0), (A != 0).any(0), lib_path=lib)
     Pv, Av = pr.values(P, A)
     info = pr.analyze(l[0], u[0])
@@ -188,3 +196,15 @@ def test_l0_plug_on_the_valkyrie_problem_emulated():
 @pytest.mark.gpu
 def test_l0_plug_on_the_valkyrie_problem_gpu():
     _l0(None)
+
+
+def test_l0_plug_on_the_valkyrie_problem_with_a_matrix_weight_emulated():
+    """174 x 209 with a block in P: 158 KB of the 160 KB of LDS -- still the sparse form (the alternative for a P with blocks is the one-lane form)"""
+    emu.build()
+    info = _l0(emu.EMU_LIB, matrix=True)
+    assert 150 * 1024 < info["lds_bytes"] <= 160 * 1024 - 64
+
+
+@pytest.mark.gpu
+def test_l0_plug_on_the_valkyrie_problem_with_a_matrix_weight_gpu():
+    _l0(None, matrix=True)
