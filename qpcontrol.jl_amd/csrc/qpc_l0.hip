@@ -586,7 +586,7 @@ int32_t qpc_qp_solve(qpc_qp_problem *p, int64_t B, const double *P_vals, const d
   // the sparse workgroup form first (qpc_qp_sp.h): its plan is made for the equality rows of the batch's first QP (kept while they stay)
   bool sp = false;
   if (m > 0 && n <= QPC_SP_DIM && m <= QPC_SP_DIM) {
-    const char *e = getenv("QPC_L0_NO_SPARSE");
+    const char *e = QPC_EXP_ENV("QPC_L0_NO_SPARSE"); // (experiments library only: the product has no switches)
     if (!(e && e[0] == '1')) {
       std::vector<uint8_t> eq;
       qpc_eq_rows(m, l, u, eq);
@@ -607,7 +607,7 @@ int32_t qpc_qp_solve(qpc_qp_problem *p, int64_t B, const double *P_vals, const d
   const int64_t chunk = 1024;
   bool piped = sp && !staged && B >= 4 * chunk && !p->timing;
   if (piped) {
-    const char *e = getenv("QPC_L0_NO_CHUNKS");
+    const char *e = QPC_EXP_ENV("QPC_L0_NO_CHUNKS");
     if (e && e[0] == '1') piped = false;
     if (piped && !p->stream2) {
       if (hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking) != hipSuccess || hipMalloc(&p->d_ticket2, sizeof(unsigned long long)) != hipSuccess ||
