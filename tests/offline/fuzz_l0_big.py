@@ -5,6 +5,7 @@ beside the plan -- through the prepared entry (cold and warm-started) against th
   python tests/offline/fuzz_l0_big.py <seed> <count> [gpu]"""
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -65,8 +66,11 @@ def main():
         ro = O.qp_solve(P, q, A, l, u)
         pr = binding.QpProblem(n, m, P != 0, A != 0, lib_path=LIB)
         Pv, Av = pr.values(P, A)
+        t0_ = time.perf_counter()
         rp = pr.solve(Pv[0], q, Av[0], l, u)
         rw = pr.solve(Pv[0], q, Av[0], l, u, warm_start=True)
+        if time.perf_counter() - t0_ > 5.0:
+            print(f"(trial {trial}: n {n} m {m} ne {ne}, {time.perf_counter() - t0_:.1f} s for the two solves, iterations {int(rp['iters'][0])} / {int(rw['iters'][0])}, plan {pr.plan_info()['in_use']})", flush=True)
         info = pr.plan_info()
         pr.close()
         planned += info["in_use"]
