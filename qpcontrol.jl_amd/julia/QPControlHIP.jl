@@ -457,6 +457,23 @@ function solve!(p::QpProblem, Pvals::Matrix{Float64}, q::Matrix{Float64}, Avals:
     x, y[1:p.m, :], status, iters
 end
 
+"""
+    solve_device!(p, B, Pvals, q, Avals, l, u, x, y, status, iters; warm_start = false, stream = C_NULL)
+
+`qpc_qp_solve_device`: the same solve on DEVICE pointers (e.g. `pointer(::ROCArray)` of AMDGPU.jl) -- values, bounds and results stay in HBM;
+work is queued on `stream` (a `hipStream_t`), the call returns once it has synchronised it.  The plan must exist (`analyze!`).
+"""
+function solve_device!(p::QpProblem, B::Integer, Pvals::Ptr{Float64}, q::Ptr{Float64}, Avals::Ptr{Float64}, l::Ptr{Float64}, u::Ptr{Float64},
+                       x::Ptr{Float64}, y::Ptr{Float64}, status::Ptr{Int32}, iters::Ptr{Int32}; warm_start::Bool = false,
+                       stream::Ptr{Cvoid} = C_NULL, settings::Settings = default_settings())
+    rc = ccall((:qpc_qp_solve_device, libqpc), Int32,
+               (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Settings}, Int32,
+                Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}, Ptr{Cvoid}),
+               p.handle, B, Pvals, q, Avals, l, u, Ref(settings), warm_start ? 1 : 0, x, y, status, iters, stream)
+    rc == 0 || error(unsafe_string(ccall((:qpc_last_error, libqpc), Cstring, ())))
+    nothing
+end
+
 # ---------------------------------------------------------------------------------------------
 # f-3: `QPCOptimizer <: MOI.AbstractOptimizer` lives in QPControlHIPMOI.jl (sub-module QPControlHIPMOI), loaded on
 # demand: it is the only part of the shim that needs MathOptInterface, it was written against the MOI 0.8 API
