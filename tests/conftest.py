@@ -22,8 +22,11 @@ def pytest_configure(config):
     global _SESSION_JIT_DIR
     if "QPC_JIT_CACHE_DIR" not in os.environ:
         import tempfile
-        _SESSION_JIT_DIR = tempfile.mkdtemp(prefix="qpc_jit_session_")
-        os.environ["QPC_JIT_CACHE_DIR"] = _SESSION_JIT_DIR
+        try:
+            _SESSION_JIT_DIR = tempfile.mkdtemp(prefix="qpc_jit_session_")
+            os.environ["QPC_JIT_CACHE_DIR"] = _SESSION_JIT_DIR
+        except OSError:
+            _SESSION_JIT_DIR = None  # (no writable temporary directory: every process compiles for itself, as before)
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "gpu_slow: a LONG gpu test (a larger sample, more seeds, a second variant of something the fast set covers): "
                                        "left out of `-m gpu`, run with `-m gpu_slow` (or `-m \"gpu or gpu_slow\"`); always marked gpu as well")
