@@ -504,3 +504,33 @@ def test_large_batch_in_chunks_with_leftovers_gpu():
             if single[b]["status"][0] == 0:
                 np.testing.assert_allclose(r["x"][b, :nv], single[b]["x"][0, :nv], atol=1e-8, rtol=0)
     pr.close()
+
+
+def test_bind_call_is_the_same_call_emulated():
+    """QpProblem.bind_call / Controller.bind_call (pointers converted once: what the latency tools time) make the same calls as solve_raw /
+    control_batch: bit-identical results, in place"""
+    emu.build()
+    P, q, A, l, u, x, nv = _fixture("diag")
+    pr, (Pv, Av) = _problem(P, A, emu.EMU_LIB)
+    lc, uc = np.clip(l, -1e20, 1e20), np.clip(u, -1e20, 1e20)
+    a = tuple(np.ascontiguousarray(z[2:5]) for z in (Pv, q, Av, lc, uc))
+    ref = pr.solve_raw(*a)
+    out = dict(x=np.zeros_like(ref["x"]), y=np.zeros_like(ref["y"]), status=np.full(3, -9, dtype=np.int32), iters=np.zeros(3, dtype=np.int32))
+    call = pr.bind_call(*a, out)
+    assert call() == 0
+    for k in ("x", "y", "status", "iters"):
+        assert np.array_equal(out[k], ref[k]), k
+    warm = pr.bind_call(*a, out, warm_start=True)
+    assert warm() == 0 and (out["status"] == 0).all() and (out["iters"] <= 1).all()
+    pr.close()
+    from qpcontrol_jl_amd import workloads as W
+    c, wl = W.atlas_workload(emu.factory, 2, 3)
+    b = tuple(np.ascontiguousarray(z) for z in (wl.q, wl.v, wl.desired, wl.contact_weight, wl.contact_maxnormalforce))
+    r = c.control_batch(*b)
+    lay = c.layout
+    o = dict(tau=np.zeros((2, lay.nv)), vdot=np.zeros((2, lay.nv)), cwrench_flat=np.zeros((2, 6 * lay.n_contacts)), status=np.full(2, -9, dtype=np.int32),
+             iters=np.zeros(2, dtype=np.int32))
+    tick = c.bind_call(*b, o)
+    assert tick() == 0
+    assert np.array_equal(o["tau"], r["tau"]) and np.array_equal(o["vdot"], r["vdot"]) and np.array_equal(o["status"], r["status"])
+    assert np.array_equal(o["cwrench_flat"].reshape(2, lay.n_contacts, 6), r["cwrench"])
