@@ -97,8 +97,9 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 200):
             for name, r in (("dense", rd), ("prep", rp), ("warm", rw)):
                 if r["status"][0] != 0:
                     continue  # (a disagreement of the statuses is judged above)
-                if np.all(np.diag(P) > 0) and certified(r):
-                    continue  # (strictly convex and certified: this point IS the optimum, whatever the oracle's says)
+                if certified(r):
+                    continue  # (a KKT point of a convex QP is a minimiser: no feasible point has a lower objective, whatever the oracle's says;
+                              #  where P is positive definite it is THE minimiser)
                 xx = r["x"][0]
                 Ax = A @ xx
                 viol = max(np.max(l - Ax, initial=0.0), np.max(Ax - u, initial=0.0))

@@ -5,6 +5,9 @@
 //   c  hipMemcpyAsync H2D 15 KB + launch + hipMemcpyAsync D2H 3 KB + hipStreamSynchronize            (the call as it is today)
 //   d  launch of a kernel that READS 15 KB from page-locked host memory and WRITES 3 KB + flag to it, host spins  (no copies, no synchronize)
 //   e  as d but hipStreamSynchronize instead of the spin
+//   f  launch + polling hipStreamQuery until it is no longer hipErrorNotReady            (a host-side spin: no protocol with the kernel)
+//   g  as c with the polling instead of hipStreamSynchronize
+//   h  as c with hipEventRecord + hipEventSynchronize on a default (spinning) event
 //   hipcc -O2 --offload-arch=gfx950 tests/offline/launch_latency_probe.hip -o /tmp/llp && /tmp/llp
 #include <hip/hip_runtime.h>
 
@@ -63,7 +66,9 @@ int main() {
   using clk = std::chrono::steady_clock;
   auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
   std::vector<double> t(N);
-  for (int form = 0; form < 5; form++) {
+  hipEvent_t ev;
+  CK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  for (int form = 0; form < 8; form++) {
     for (int it = -50; it < N; it++) {
       const unsigned long long v = (unsigned long long)(form * 100000 + it + 100);
       const auto t0 = clk::now();
@@ -81,9 +86,27 @@ int main() {
       } else if (form == 3) {
         hipLaunchKernelGGL(k_io, dim3(1), dim3(512), 0, st, h_in, nin, h_out, nout, h_flag, v);
         while (__atomic_load_n(h_flag, __ATOMIC_ACQUIRE) != v) {}
-      } else {
+      } else if (form == 4) {
         hipLaunchKernelGGL(k_io, dim3(1), dim3(512), 0, st, h_in, nin, h_out, nout, h_flag, v);
         CK(hipStreamSynchronize(st));
+      } else if (form == 5) {
+        hipLaunchKernelGGL(k_nothing, dim3(1), dim3(512), 0, st, d_out);
+        hipError_t e;
+        while ((e = hipStreamQuery(st)) == hipErrorNotReady) {}
+        CK(e);
+      } else if (form == 6) {
+        CK(hipMemcpyAsync(d_in, h_in, nin * 8, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_io, dim3(1), dim3(512), 0, st, d_in, nin, d_out, nout, (unsigned long long *)nullptr, v);
+        CK(hipMemcpyAsync(h_out, d_out, nout * 8, hipMemcpyDeviceToHost, st));
+        hipError_t e;
+        while ((e = hipStreamQuery(st)) == hipErrorNotReady) {}
+        CK(e);
+      } else {
+        CK(hipMemcpyAsync(d_in, h_in, nin * 8, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_io, dim3(1), dim3(512), 0, st, d_in, nin, d_out, nout, (unsigned long long *)nullptr, v);
+        CK(hipMemcpyAsync(h_out, d_out, nout * 8, hipMemcpyDeviceToHost, st));
+        CK(hipEventRecord(ev, st));
+        CK(hipEventSynchronize(ev));
       }
       const auto t1 = clk::now();
       if (it >= 0) t[it] = us(t0, t1);
@@ -92,7 +115,8 @@ int main() {
     std::vector<double> s = t;
     const double med = median(s);
     static const char *names[] = {"a launch + synchronize", "b launch + spin on a host flag", "c H2D 15 KB + launch + D2H 3 KB + synchronize",
-                                  "d kernel reads / writes page-locked host memory, spin", "e as d, synchronize"};
+                                  "d kernel reads / writes page-locked host memory, spin", "e as d, synchronize",
+                                  "f launch + polling hipStreamQuery", "g as c, polling hipStreamQuery", "h as c, hipEventSynchronize on a default event"};
     printf("{\"form\": \"%s\", \"median_us\": %.2f, \"p10_us\": %.2f, \"p90_us\": %.2f}\n", names[form], med, s[N / 10], s[N * 9 / 10]);
   }
   return 0;
